@@ -1,0 +1,87 @@
+// Device-side helpers shared by every kernel in csrc/ (gfx950 / CDNA4, wave64).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+namespace e2k {
+
+typedef uint16_t bf16_t;  // raw bfloat16 bits
+typedef short bf16x8 __attribute__((ext_vector_type(8)));
+typedef short bf16x4 __attribute__((ext_vector_type(4)));
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
+typedef unsigned u32x2 __attribute__((ext_vector_type(2)));
+
+constexpr int WAVE = 64;
+
+__device__ __forceinline__ float bf2f(bf16_t x) { return __uint_as_float(((unsigned)x) << 16); }
+// round-to-nearest-even, NaN kept quiet (same rule torch uses for float->bfloat16)
+__device__ __forceinline__ bf16_t f2bf(float f) {
+    unsigned u = __float_as_uint(f);
+    if ((u & 0x7fffffffu) > 0x7f800000u) return (bf16_t)((u >> 16) | 0x40);
+    u += 0x7fffu + ((u >> 16) & 1u);
+    return (bf16_t)(u >> 16);
+}
+__device__ __forceinline__ unsigned pack2bf(float lo, float hi) { return (unsigned)f2bf(lo) | ((unsigned)f2bf(hi) << 16); }
+__device__ __forceinline__ float bflo(unsigned u) { return __uint_as_float(u << 16); }
+__device__ __forceinline__ float bfhi(unsigned u) { return __uint_as_float(u & 0xffff0000u); }
+
+template <class T> __device__ __forceinline__ T ld(const void* p) { return *reinterpret_cast<const T*>(p); }
+template <class T> __device__ __forceinline__ void st(void* p, T v) { *reinterpret_cast<T*>(p) = v; }
+
+// 8 bf16 (16 B) <-> 8 floats
+__device__ __forceinline__ void unpack8(u32x4 v, float* f) {
+#pragma unroll
+    for (int i = 0; i < 4; ++i) { f[2 * i] = bflo(v[i]); f[2 * i + 1] = bfhi(v[i]); }
+}
+__device__ __forceinline__ u32x4 pack8(const float* f) {
+    u32x4 v;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) v[i] = pack2bf(f[2 * i], f[2 * i + 1]);
+    return v;
+}
+__device__ __forceinline__ void unpack4(u32x2 v, float* f) {
+    f[0] = bflo(v[0]); f[1] = bfhi(v[0]); f[2] = bflo(v[1]); f[3] = bfhi(v[1]);
+}
+__device__ __forceinline__ u32x2 pack4(const float* f) {
+    u32x2 v; v[0] = pack2bf(f[0], f[1]); v[1] = pack2bf(f[2], f[3]); return v;
+}
+
+__device__ __forceinline__ float wave_sum(float v) {
+#pragma unroll
+    for (int m = 32; m >= 1; m >>= 1) v += __shfl_xor(v, m);
+    return v;
+}
+__device__ __forceinline__ float wave_max(float v) {
+#pragma unroll
+    for (int m = 32; m >= 1; m >>= 1) v = fmaxf(v, __shfl_xor(v, m));
+    return v;
+}
+
+__device__ __forceinline__ float sigmoidf_(float x) { return 1.0f / (1.0f + __expf(-x)); }
+__device__ __forceinline__ float siluf_(float x) { return x * sigmoidf_(x); }
+// tanh via one exp; exact to fp32 rounding for |x| < ~40, saturates cleanly beyond
+__device__ __forceinline__ float tanhf_(float x) {
+    float e = __expf(-2.0f * fabsf(x));
+    float t = (1.0f - e) / (1.0f + e);
+    return x < 0.f ? -t : t;
+}
+
+// stateless counter hash -> 32 random bits (dropout masks; restated bit-exactly in oracle/dropout_hash.py)
+__device__ __forceinline__ unsigned fmix32(unsigned h) {
+    h ^= h >> 16; h *= 0x85ebca6bu; h ^= h >> 13; h *= 0xc2b2ae35u; h ^= h >> 16; return h;
+}
+__device__ __forceinline__ unsigned rand_u32(unsigned seed, unsigned stream, unsigned row, unsigned col) {
+    unsigned h = fmix32(seed ^ (stream * 0x9e3779b1u));
+    h = fmix32(h ^ (row * 0x85ebca77u + 0x165667b1u));
+    h = fmix32(h ^ (col * 0xc2b2ae3du + 0x27d4eb2fu));
+    return h;
+}
+
+}  // namespace e2k
+
+#define E2K_CHECK_LAUNCH()                                   \
+    do {                                                     \
+        hipError_t e__ = hipGetLastError();                  \
+        if (e__ != hipSuccess) return 1000 + (int)e__;       \
+    } while (0)

@@ -1,0 +1,285 @@
+// TEST INFRASTRUCTURE ONLY -- host-side logic checker for the HIP kernels in
+// e2-tts-pytorch_amd/csrc.  It is NOT a CPU fallback: nothing in the shipped
+// package includes, links or loads it.  tests/emu/build_emu.py compiles the very
+// same kernel sources (no #ifdefs in them) against this header instead of the
+// real <hip/hip_runtime.h>, producing tests/emu/libe2k_emu.so, so that index
+// math, reductions, MFMA fragment plumbing and barrier placement can be checked
+// on a machine with no GPU before GPU minutes are spent.
+//
+// Execution model: one OS thread runs one workgroup at a time; the workgroup's
+// threads are ucontext fibers scheduled round-robin.  __syncthreads() is a true
+// rendezvous over the block, wave-level exchanges (__shfl*, MFMA) a true
+// rendezvous over the 64-lane wave.  __shared__ maps to `static thread_local`
+// (one block per OS thread => block-shared).  "Device" pointers are host pointers.
+#pragma once
+#include <ucontext.h>
+#include <atomic>
+#include <cmath>
+#include <cstdint>
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <functional>
+#include <thread>
+#include <vector>
+
+#define __global__
+#define __device__
+#define __host__
+#define __forceinline__ inline __attribute__((always_inline))
+#define __shared__ static thread_local
+#define __launch_bounds__(...)
+
+struct dim3 {
+    unsigned x, y, z;
+    dim3(unsigned x_ = 1, unsigned y_ = 1, unsigned z_ = 1) : x(x_), y(y_), z(z_) {}
+};
+struct uint2 { unsigned x, y; };
+struct uint4 { unsigned x, y, z, w; };
+struct float2 { float x, y; };
+struct float4 { float x, y, z, w; };
+static inline uint2 make_uint2(unsigned a, unsigned b) { return uint2{a, b}; }
+static inline uint4 make_uint4(unsigned a, unsigned b, unsigned c, unsigned d) { return uint4{a, b, c, d}; }
+static inline float4 make_float4(float a, float b, float c, float d) { return float4{a, b, c, d}; }
+static inline float2 make_float2(float a, float b) { return float2{a, b}; }
+
+typedef void* hipStream_t;
+typedef int hipError_t;
+#define hipSuccess 0
+static inline hipError_t hipGetLastError() { return 0; }
+static inline const char* hipGetErrorString(hipError_t) { return "emu"; }
+static inline hipError_t hipMemsetAsync(void* p, int v, size_t n, hipStream_t) { memset(p, v, n); return 0; }
+
+namespace emu {
+
+constexpr int kWave = 64;
+constexpr size_t kStack = 256 * 1024;
+
+struct Wave {
+    alignas(16) unsigned char slot[2][kWave][64];
+    int arrived = 0;
+    unsigned gen = 0;
+    int nlanes = kWave;
+};
+
+struct Fiber {
+    ucontext_t ctx;
+    dim3 tid;
+    int lin = 0;
+    int par = 0;
+    bool done = false;
+    char* stack = nullptr;
+};
+
+struct Block {
+    dim3 bid, bdim, gdim;
+    int nthreads = 0;
+    int cur = 0;
+    std::vector<Fiber> fibers;
+    std::vector<Wave> waves;
+    ucontext_t sched;
+    int bar_arrived = 0;
+    unsigned bar_gen = 0;
+    const std::function<void()>* body = nullptr;
+};
+
+inline thread_local Block* g_blk = nullptr;
+
+inline Fiber& cur_fiber() { return g_blk->fibers[g_blk->cur]; }
+inline void yield() {
+    Fiber& f = cur_fiber();
+    swapcontext(&f.ctx, &g_blk->sched);
+}
+inline void block_rendezvous() {
+    Block* b = g_blk;
+    unsigned gen = b->bar_gen;
+    if (++b->bar_arrived == b->nthreads) {
+        b->bar_arrived = 0;
+        b->bar_gen++;
+    } else {
+        while (b->bar_gen == gen) yield();
+    }
+}
+inline Wave& cur_wave() { return g_blk->waves[cur_fiber().lin / kWave]; }
+inline int lane_id() { return cur_fiber().lin % kWave; }
+inline void wave_rendezvous(Wave& w) {
+    unsigned gen = w.gen;
+    if (++w.arrived == w.nlanes) {
+        w.arrived = 0;
+        w.gen++;
+    } else {
+        while (w.gen == gen) yield();
+    }
+}
+
+static void trampoline() {
+    Block* b = g_blk;
+    (*b->body)();
+    b->fibers[b->cur].done = true;
+    swapcontext(&b->fibers[b->cur].ctx, &b->sched);
+}
+
+inline void run_block(Block& blk, const std::function<void()>& body) {
+    g_blk = &blk;
+    blk.body = &body;
+    blk.bar_arrived = 0;
+    int n = blk.nthreads;
+    for (int i = 0; i < n; ++i) {
+        Fiber& f = blk.fibers[i];
+        f.done = false;
+        f.par = 0;
+        f.lin = i;
+        f.tid = dim3(i % blk.bdim.x, (i / blk.bdim.x) % blk.bdim.y, i / (blk.bdim.x * blk.bdim.y));
+        getcontext(&f.ctx);
+        f.ctx.uc_stack.ss_sp = f.stack;
+        f.ctx.uc_stack.ss_size = kStack;
+        f.ctx.uc_link = nullptr;
+        makecontext(&f.ctx, (void (*)())trampoline, 0);
+    }
+    int nw = (n + kWave - 1) / kWave;
+    for (int w = 0; w < nw; ++w) {
+        blk.waves[w].arrived = 0;
+        blk.waves[w].nlanes = std::min(kWave, n - w * kWave);
+    }
+    int remaining = n;
+    long spins = 0;
+    while (remaining > 0) {
+        for (int i = 0; i < n; ++i) {
+            Fiber& f = blk.fibers[i];
+            if (f.done) continue;
+            blk.cur = i;
+            swapcontext(&blk.sched, &f.ctx);
+            if (f.done) --remaining;
+        }
+        if (++spins > 200000000L) { fprintf(stderr, "emu: deadlock?\n"); abort(); }
+    }
+    g_blk = nullptr;
+}
+
+inline void launch(dim3 grid, dim3 block, const std::function<void()>& body) {
+    long nblocks = (long)grid.x * grid.y * grid.z;
+    int nthreads = block.x * block.y * block.z;
+    if (nblocks == 0 || nthreads == 0) return;
+    unsigned hw = std::thread::hardware_concurrency();
+    if (const char* e = getenv("E2K_EMU_THREADS")) hw = atoi(e);
+    if (hw < 1) hw = 1;
+    long nworkers = std::min<long>(hw, nblocks);
+    std::atomic<long> next{0};
+    auto worker = [&]() {
+        Block blk;
+        blk.bdim = block;
+        blk.gdim = grid;
+        blk.nthreads = nthreads;
+        blk.fibers.resize(nthreads);
+        blk.waves.resize((nthreads + kWave - 1) / kWave);
+        for (auto& f : blk.fibers) f.stack = (char*)malloc(kStack);
+        for (;;) {
+            long b = next.fetch_add(1);
+            if (b >= nblocks) break;
+            blk.bid = dim3(b % grid.x, (b / grid.x) % grid.y, b / ((long)grid.x * grid.y));
+            run_block(blk, body);
+        }
+        for (auto& f : blk.fibers) free(f.stack);
+    };
+    if (nworkers == 1) {
+        worker();
+    } else {
+        std::vector<std::thread> ts;
+        for (long i = 0; i < nworkers; ++i) ts.emplace_back(worker);
+        for (auto& t : ts) t.join();
+    }
+}
+
+template <class T>
+inline T wave_exchange(T v, int src_lane) {
+    static_assert(sizeof(T) <= 64, "exchange payload too large");
+    Wave& w = cur_wave();
+    Fiber& f = cur_fiber();
+    int p = f.par;
+    f.par ^= 1;
+    memcpy(w.slot[p][lane_id()], &v, sizeof(T));
+    wave_rendezvous(w);
+    T r;
+    int s = src_lane;
+    if (s < 0 || s >= w.nlanes) s = lane_id();
+    memcpy(&r, w.slot[p][s], sizeof(T));
+    return r;
+}
+
+}  // namespace emu
+
+#define threadIdx (emu::cur_fiber().tid)
+#define blockIdx (emu::g_blk->bid)
+#define blockDim (emu::g_blk->bdim)
+#define gridDim (emu::g_blk->gdim)
+#define warpSize 64
+
+template <class K, class... A>
+inline void hipLaunchKernelGGL(K k, dim3 g, dim3 b, size_t, hipStream_t, A... args) {
+    emu::launch(g, b, [=]() { k(args...); });
+}
+
+static inline void __syncthreads() { emu::block_rendezvous(); }
+static inline void __builtin_amdgcn_s_barrier() { emu::block_rendezvous(); }
+static inline void __builtin_amdgcn_s_setprio(int) {}
+static inline void __builtin_amdgcn_sched_barrier(int) {}
+#define __builtin_amdgcn_readfirstlane(x) (x)
+
+template <class T> static inline T __shfl_xor(T v, int mask, int = 64) { return emu::wave_exchange(v, emu::lane_id() ^ mask); }
+template <class T> static inline T __shfl(T v, int src, int = 64) { return emu::wave_exchange(v, src); }
+template <class T> static inline T __shfl_down(T v, int d, int = 64) { return emu::wave_exchange(v, emu::lane_id() + d); }
+
+static inline unsigned __float_as_uint(float f) { unsigned u; memcpy(&u, &f, 4); return u; }
+static inline float __uint_as_float(unsigned u) { float f; memcpy(&f, &u, 4); return f; }
+static inline float __expf(float x) { return expf(x); }
+static inline float __logf(float x) { return logf(x); }
+static inline float __fdividef(float a, float b) { return a / b; }
+static inline float __frcp_rn(float a) { return 1.0f / a; }
+static inline float rsqrtf(float a) { return 1.0f / sqrtf(a); }
+static inline float __sinf(float a) { return sinf(a); }
+static inline float __cosf(float a) { return cosf(a); }
+static inline void sincosf_(float a, float* s, float* c) { *s = sinf(a); *c = cosf(a); }
+
+static inline float atomicAdd(float* p, float v) {
+    unsigned* up = (unsigned*)p;
+    unsigned old = __atomic_load_n(up, __ATOMIC_RELAXED);
+    for (;;) {
+        float nf = __uint_as_float(old) + v;
+        unsigned nu = __float_as_uint(nf);
+        if (__atomic_compare_exchange_n(up, &old, nu, false, __ATOMIC_RELAXED, __ATOMIC_RELAXED)) return __uint_as_float(old);
+    }
+}
+static inline int atomicAdd(int* p, int v) { return __atomic_fetch_add(p, v, __ATOMIC_RELAXED); }
+static inline unsigned atomicAdd(unsigned* p, unsigned v) { return __atomic_fetch_add(p, v, __ATOMIC_RELAXED); }
+
+// ---- MFMA (gfx950) ----
+// v_mfma_f32_16x16x32_bf16: A 16x32 (lane l: row l&15, k-slots 8*(l>>4)+j), B 32x16 (lane l: col l&15, same
+// k-slots), C/D: col = l&15, row = 4*(l>>4)+reg  (cdna_hip_programming.md section 3).
+typedef short emu_bf16x8 __attribute__((ext_vector_type(8)));
+typedef float emu_f32x4 __attribute__((ext_vector_type(4)));
+static inline float emu_bf2f(short s) { return __uint_as_float(((unsigned)(unsigned short)s) << 16); }
+static inline emu_f32x4 __builtin_amdgcn_mfma_f32_16x16x32_bf16(emu_bf16x8 a, emu_bf16x8 b, emu_f32x4 c, int, int, int) {
+    struct AB { emu_bf16x8 a, b; };
+    emu::Wave& w = emu::cur_wave();
+    emu::Fiber& f = emu::cur_fiber();
+    int p = f.par;
+    f.par ^= 1;
+    int lane = emu::lane_id();
+    AB ab{a, b};
+    memcpy(w.slot[p][lane], &ab, sizeof(AB));
+    emu::wave_rendezvous(w);
+    int j = lane & 15, g = lane >> 4;
+    emu_f32x4 d = c;
+    for (int r = 0; r < 4; ++r) {
+        int i = 4 * g + r;
+        float acc = d[r];
+        for (int gg = 0; gg < 4; ++gg) {
+            AB ra, rb;
+            memcpy(&ra, w.slot[p][i + 16 * gg], sizeof(AB));
+            memcpy(&rb, w.slot[p][j + 16 * gg], sizeof(AB));
+            for (int e = 0; e < 8; ++e) acc = fmaf(emu_bf2f(ra.a[e]), emu_bf2f(rb.b[e]), acc);
+        }
+        d[r] = acc;
+    }
+    return d;
+}
