@@ -1,0 +1,372 @@
+// bf16 MFMA GEMMs for the transformer hot path (gfx950, v_mfma_f32_16x16x32_bf16, fp32 accumulate).
+//
+//   e2k_gemm_nt_bf16 : C[M,N]  = epilogue( [A1|A2][M,K1+K2] . B[N,K1+K2]^T )      forward + dgrad
+//   e2k_gemm_tn_bf16 : C[N,K] += A[M,N]^T . B[M,K]   (fp32 C, split over M)         wgrad
+//
+// Replaces the nn.Linear / F.linear calls of the reference hot loop: q/k/v/out projections
+// (x_transformers.Attention, called at e2_tts.py:875,911), GEGLU feed-forward (e2_tts.py:881,937),
+// skip projection on cat(x, skip) (e2_tts.py:895-896) and TextAudioCrossCondition on cat(audio, text)
+// (e2_tts.py:508-513).  The two concatenations are never materialised: the NT kernel walks K over two
+// source matrices ("dual-source A").
+//
+// Tile 128x128x64, 256 threads = 4 waves (2x2), each wave 64x64 = 4x4 MFMA tiles.  Operands are staged
+// global -> VGPR -> LDS (16 B per lane, XOR-swizzled 128-B rows => conflict-free ds_read_b128), the loads
+// of tile t+1 are issued before the MFMAs of tile t and written to the other LDS buffer after them
+// (one barrier per K step).  MFMA operands are swapped (srcA = weight fragment, srcB = activation fragment) so
+// that a lane's 4 accumulator registers are 4 consecutive output columns -> 8-byte bf16 stores.
+#include "e2k_device.h"
+#include <e2k_asm.h>
+#include "../../include/e2k.h"
+
+using namespace e2k;
+
+namespace {
+
+constexpr int BM = 128, BN = 128, BK = 64;
+
+__device__ __forceinline__ int xcd_remap(int orig, int nwg) {
+    // blocks are dispatched round-robin over the 8 XCDs; give each XCD a contiguous run of tiles (bijective)
+    int xcd = orig & 7, q = nwg >> 3, r = nwg & 7;
+    return (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + (orig >> 3);
+}
+
+__device__ __forceinline__ void tile_coords(int wgid, int tm, int tn, int& tile_m, int& tile_n) {
+    const int group = 8;
+    int width = group * tn;
+    int gid = wgid / width;
+    int first_m = gid * group;
+    int gsize = min(tm - first_m, group);
+    int in_g = wgid - gid * width;
+    tile_m = first_m + in_g % gsize;
+    tile_n = in_g / gsize;
+}
+
+struct NTArgs {
+    const bf16_t* A1; long lda1; int K1;
+    const bf16_t* A2; long lda2; int K2;
+    const bf16_t* B; long ldb;
+    void* C; long ldc; int accumulate;
+    int M, N;
+    const float* bias; const float* colscale; int rows_per_batch;
+    const uint8_t* rowmask; const bf16_t* resid; long ldr;
+};
+
+template <bool OUT_F32>
+__global__ __launch_bounds__(256) void gemm_nt_kernel(NTArgs p) {
+    __shared__ __attribute__((aligned(16))) unsigned char smem[2][2][BM * BK * 2];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int wm = wave >> 1, wn = wave & 1;
+    const int l15 = lane & 15, g = lane >> 4;
+    const int tm = (p.M + BM - 1) / BM, tn = (p.N + BN - 1) / BN;
+    int tile_m, tile_n;
+    tile_coords(xcd_remap(blockIdx.x, gridDim.x), tm, tn, tile_m, tile_n);
+    const int m0 = tile_m * BM, n0 = tile_n * BN;
+    const int K = p.K1 + p.K2;
+    const int nk = (K + BK - 1) / BK;
+
+    u32x4 ra[4], rb[4];
+    auto gload = [&](int kt) {
+        const int k0 = kt * BK;
+#pragma unroll
+        for (int c = 0; c < 4; ++c) {
+            int chunk = tid + c * 256;
+            int row = chunk >> 3, slot = chunk & 7;
+            int k = k0 + slot * 8;
+            int m = m0 + row, n = n0 + row;
+            u32x4 va = {0u, 0u, 0u, 0u}, vb = {0u, 0u, 0u, 0u};
+            if (k < K) {
+                if (m < p.M) {
+                    const bf16_t* src = (k < p.K1) ? p.A1 + (long)m * p.lda1 + k : p.A2 + (long)m * p.lda2 + (k - p.K1);
+                    va = ld<u32x4>(src);
+                }
+                if (n < p.N) vb = ld<u32x4>(p.B + (long)n * p.ldb + k);
+            }
+            ra[c] = va;
+            rb[c] = vb;
+        }
+    };
+    auto sstore = [&](int buf) {
+#pragma unroll
+        for (int c = 0; c < 4; ++c) {
+            int chunk = tid + c * 256;
+            int row = chunk >> 3, slot = chunk & 7;
+            int off = row * 128 + ((slot ^ (row & 7)) << 4);
+            st<u32x4>(&smem[buf][0][off], ra[c]);
+            st<u32x4>(&smem[buf][1][off], rb[c]);
+        }
+    };
+
+    f32x4 acc[4][4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+    gload(0);
+    sstore(0);
+    __syncthreads();
+    for (int kt = 0; kt < nk; ++kt) {
+        const int buf = kt & 1;
+        if (kt + 1 < nk) gload(kt + 1);
+        const unsigned char* As = smem[buf][0];
+        const unsigned char* Bs = smem[buf][1];
+#pragma unroll
+        for (int kk = 0; kk < 2; ++kk) {
+            bf16x8 af[4], bw[4];
+            const int slot = kk * 4 + g;
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                int row = wm * 64 + i * 16 + l15;
+                af[i] = ld<bf16x8>(As + row * 128 + ((slot ^ (row & 7)) << 4));
+            }
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                int row = wn * 64 + j * 16 + l15;
+                bw[j] = ld<bf16x8>(Bs + row * 128 + ((slot ^ (row & 7)) << 4));
+            }
+#pragma unroll
+            for (int i = 0; i < 4; ++i)
+#pragma unroll
+                for (int j = 0; j < 4; ++j)
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(bw[j], af[i], acc[i][j], 0, 0, 0);
+        }
+        if (kt + 1 < nk) sstore(buf ^ 1);
+        __syncthreads();
+    }
+
+    // epilogue: lane holds C[m][n..n+3], m = m0+wm*64+i*16+l15, n = n0+wn*64+j*16+4g
+    const bool vec_ok = (p.ldc & 3) == 0 && (p.resid == nullptr || (p.ldr & 3) == 0);
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        const int m = m0 + wm * 64 + i * 16 + l15;
+        if (m >= p.M) continue;
+        const float rm = p.rowmask ? (p.rowmask[m] ? 1.f : 0.f) : 1.f;
+        const float* cs = p.colscale ? p.colscale + (long)(m / p.rows_per_batch) * p.N : nullptr;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const int n = n0 + wn * 64 + j * 16 + 4 * g;
+            if (n >= p.N) continue;
+            float v[4];
+#pragma unroll
+            for (int r = 0; r < 4; ++r) v[r] = acc[i][j][r];
+            const bool full = (n + 3 < p.N) && vec_ok;
+            float rs[4] = {0.f, 0.f, 0.f, 0.f};
+            if (p.resid) {
+                if (full) {
+                    unpack4(ld<u32x2>(p.resid + (long)m * p.ldr + n), rs);
+                } else {
+                    for (int r = 0; r < 4; ++r)
+                        if (n + r < p.N) rs[r] = bf2f(p.resid[(long)m * p.ldr + n + r]);
+                }
+            }
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                if (n + r < p.N) {
+                    float x = v[r];
+                    if (p.bias) x += p.bias[n + r];
+                    if (cs) x *= cs[n + r];
+                    x = x * rm + rs[r];
+                    v[r] = x;
+                }
+            }
+            if (OUT_F32) {
+                float* c = (float*)p.C + (long)m * p.ldc + n;
+                if (full) {
+                    f32x4 o = {v[0], v[1], v[2], v[3]};
+                    if (p.accumulate) { f32x4 old = ld<f32x4>(c); o += old; }
+                    st<f32x4>(c, o);
+                } else {
+                    for (int r = 0; r < 4; ++r)
+                        if (n + r < p.N) c[r] = (p.accumulate ? c[r] : 0.f) + v[r];
+                }
+            } else {
+                bf16_t* c = (bf16_t*)p.C + (long)m * p.ldc + n;
+                if (full) {
+                    st<u32x2>(c, pack4(v));
+                } else {
+                    for (int r = 0; r < 4; ++r)
+                        if (n + r < p.N) c[r] = f2bf(v[r]);
+                }
+            }
+        }
+    }
+}
+
+// ---------------------------------------------------------------------------------------------- TN (wgrad)
+
+constexpr int TBM = 64;          // reduction (token) rows per step
+constexpr int TLD = 288;         // LDS row stride in bytes: 256 B of data + 32 B pad => tr-reads of 8 rows tile all 64 banks
+
+struct TNArgs {
+    const bf16_t* A; long lda;   // (M, N)  dY
+    const bf16_t* B; long ldb;   // (M, K)  X
+    float* C; long ldc;          // (N, K)
+    int M, N, K, splits, chunk;
+};
+
+template <bool USE_TR>
+__device__ __forceinline__ bf16x8 tn_frag(const unsigned char* T, int kk, int col0, int q, int g) {
+    bf16x8 f;
+    if (USE_TR) {
+        const unsigned char* p0 = T + (kk * 32 + 4 * g + (q >> 2)) * TLD + (col0 + (q & 3) * 4) * 2;
+        s16x4_ lo = lds_read_tr16_b64(p0);
+        s16x4_ hi = lds_read_tr16_b64(p0 + 16 * TLD);
+        f[0] = lo[0]; f[1] = lo[1]; f[2] = lo[2]; f[3] = lo[3];
+        f[4] = hi[0]; f[5] = hi[1]; f[6] = hi[2]; f[7] = hi[3];
+    } else {
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+            int row = kk * 32 + (j >> 2) * 16 + 4 * g + (j & 3);
+            f[j] = ld<short>(T + row * TLD + (col0 + q) * 2);
+        }
+    }
+    return f;
+}
+
+template <bool USE_TR>
+__global__ __launch_bounds__(256) void gemm_tn_kernel(TNArgs p) {
+    __shared__ __attribute__((aligned(16))) unsigned char smem[2][2][TBM * TLD];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int wn = wave >> 1, wk = wave & 1;
+    const int q = lane & 15, g = lane >> 4;
+    const int tn = (p.N + 127) / 128, tk = (p.K + 127) / 128;
+    int tile_n, tile_k;
+    tile_coords(xcd_remap(blockIdx.x, gridDim.x), tn, tk, tile_n, tile_k);
+    const int n0 = tile_n * 128, k0 = tile_k * 128;
+    const int mbeg = blockIdx.y * p.chunk;
+    const int mend = min(p.M, mbeg + p.chunk);
+    const int nsteps = (mend - mbeg + TBM - 1) / TBM;
+
+    u32x4 ra[4], rb[4];
+    auto gload = [&](int s) {
+        const int mb = mbeg + s * TBM;
+#pragma unroll
+        for (int c = 0; c < 4; ++c) {
+            int chunk = tid + c * 256;
+            int row = chunk >> 4, slot = chunk & 15;
+            int m = mb + row;
+            u32x4 va = {0u, 0u, 0u, 0u}, vb = {0u, 0u, 0u, 0u};
+            if (m < mend) {
+                int n = n0 + slot * 8, k = k0 + slot * 8;
+                if (n < p.N) va = ld<u32x4>(p.A + (long)m * p.lda + n);
+                if (k < p.K) vb = ld<u32x4>(p.B + (long)m * p.ldb + k);
+            }
+            ra[c] = va;
+            rb[c] = vb;
+        }
+    };
+    auto sstore = [&](int buf) {
+#pragma unroll
+        for (int c = 0; c < 4; ++c) {
+            int chunk = tid + c * 256;
+            int row = chunk >> 4, slot = chunk & 15;
+            st<u32x4>(&smem[buf][0][row * TLD + slot * 16], ra[c]);
+            st<u32x4>(&smem[buf][1][row * TLD + slot * 16], rb[c]);
+        }
+    };
+
+    f32x4 acc[4][4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+    if (nsteps > 0) {
+        gload(0);
+        sstore(0);
+    }
+    __syncthreads();
+    for (int s = 0; s < nsteps; ++s) {
+        const int buf = s & 1;
+        if (s + 1 < nsteps) gload(s + 1);
+        const unsigned char* At = smem[buf][0];
+        const unsigned char* Bt = smem[buf][1];
+#pragma unroll
+        for (int kk = 0; kk < 2; ++kk) {
+            bf16x8 fx[4], fy[4];
+#pragma unroll
+            for (int i = 0; i < 4; ++i) fx[i] = tn_frag<USE_TR>(Bt, kk, wk * 64 + i * 16, q, g);
+#pragma unroll
+            for (int j = 0; j < 4; ++j) fy[j] = tn_frag<USE_TR>(At, kk, wn * 64 + j * 16, q, g);
+#pragma unroll
+            for (int i = 0; i < 4; ++i)
+#pragma unroll
+                for (int j = 0; j < 4; ++j)
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fx[i], fy[j], acc[i][j], 0, 0, 0);
+        }
+        if (s + 1 < nsteps) sstore(buf ^ 1);
+        __syncthreads();
+    }
+    if (nsteps <= 0) return;
+    // acc[i][j]: C[n = n0+wn*64+j*16+q][k = k0+wk*64+i*16+4g+r]
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+        const int n = n0 + wn * 64 + j * 16 + q;
+        if (n >= p.N) continue;
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const int k = k0 + wk * 64 + i * 16 + 4 * g;
+            float* c = p.C + (long)n * p.ldc + k;
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                if (k + r < p.K) {
+                    if (p.splits > 1) atomicAdd(c + r, acc[i][j][r]);
+                    else c[r] += acc[i][j][r];
+                }
+            }
+        }
+    }
+}
+
+}  // namespace
+
+extern "C" int e2k_gemm_nt_bf16(const void* A1, int64_t lda1, int K1, const void* A2, int64_t lda2, int K2,
+                                const void* B, int64_t ldb, void* C, int64_t ldc, int out_f32, int accumulate,
+                                int M, int N, const float* bias, const float* colscale, int rows_per_batch,
+                                const uint8_t* rowmask, const void* resid, int64_t ldr, void* stream) {
+    if (M <= 0 || N <= 0) return 0;
+    if (K1 <= 0 || (K1 & 7) || (K2 & 7) || K2 < 0) return E2K_ERR_SHAPE;
+    if ((lda1 & 7) || (ldb & 7) || (K2 > 0 && ((lda2 & 7) || A2 == nullptr))) return E2K_ERR_ALIGN;
+    if (((uintptr_t)A1 | (uintptr_t)B | (uintptr_t)A2) & 15) return E2K_ERR_ALIGN;
+    if (colscale && rows_per_batch <= 0) return E2K_ERR_SHAPE;
+    if (accumulate && !out_f32) return E2K_ERR_SHAPE;
+    NTArgs p;
+    p.A1 = (const bf16_t*)A1; p.lda1 = lda1; p.K1 = K1;
+    p.A2 = (const bf16_t*)A2; p.lda2 = lda2; p.K2 = K2;
+    p.B = (const bf16_t*)B; p.ldb = ldb;
+    p.C = C; p.ldc = ldc; p.accumulate = accumulate;
+    p.M = M; p.N = N;
+    p.bias = bias; p.colscale = colscale; p.rows_per_batch = rows_per_batch;
+    p.rowmask = rowmask; p.resid = (const bf16_t*)resid; p.ldr = ldr;
+    const int tm = (M + BM - 1) / BM, tn = (N + BN - 1) / BN;
+    dim3 grid(tm * tn), block(256);
+    if (out_f32) hipLaunchKernelGGL(gemm_nt_kernel<true>, grid, block, 0, (hipStream_t)stream, p);
+    else hipLaunchKernelGGL(gemm_nt_kernel<false>, grid, block, 0, (hipStream_t)stream, p);
+    E2K_CHECK_LAUNCH();
+    return 0;
+}
+
+extern "C" int e2k_gemm_tn_bf16(const void* A, int64_t lda, const void* B, int64_t ldb, float* C, int64_t ldc,
+                                int M, int N, int K, int splits, int use_tr, void* stream) {
+    if (M <= 0 || N <= 0 || K <= 0) return 0;
+    if ((N & 7) || (K & 7) || (lda & 7) || (ldb & 7)) return E2K_ERR_ALIGN;
+    if (((uintptr_t)A | (uintptr_t)B) & 15) return E2K_ERR_ALIGN;
+    const int tn = (N + 127) / 128, tk = (K + 127) / 128;
+    if (splits <= 0) {
+        // enough (tile, split) pairs to fill 256 CUs about 4x over, at least 256 rows per split
+        int want = (1024 + tn * tk - 1) / (tn * tk);
+        int maxs = (M + 255) / 256;
+        splits = want < 1 ? 1 : (want > maxs ? maxs : want);
+    }
+    int chunk = (M + splits - 1) / splits;
+    chunk = (chunk + TBM - 1) / TBM * TBM;
+    splits = (M + chunk - 1) / chunk;
+    TNArgs p;
+    p.A = (const bf16_t*)A; p.lda = lda; p.B = (const bf16_t*)B; p.ldb = ldb;
+    p.C = C; p.ldc = ldc; p.M = M; p.N = N; p.K = K; p.splits = splits; p.chunk = chunk;
+    dim3 grid(tn * tk, splits), block(256);
+    if (use_tr) hipLaunchKernelGGL(gemm_tn_kernel<true>, grid, block, 0, (hipStream_t)stream, p);
+    else hipLaunchKernelGGL(gemm_tn_kernel<false>, grid, block, 0, (hipStream_t)stream, p);
+    E2K_CHECK_LAUNCH();
+    return 0;
+}

@@ -1,0 +1,29 @@
+// TEST INFRASTRUCTURE: host model of csrc/e2k_asm.h (see tests/emu/hip/hip_runtime.h).
+#pragma once
+#include <hip/hip_runtime.h>
+
+namespace e2k {
+
+typedef short s16x4_ __attribute__((ext_vector_type(4)));
+
+inline s16x4_ lds_read_tr16_b64(const void* lds_ptr) {
+    s16x4_ mine;
+    memcpy(&mine, lds_ptr, 8);
+    emu::Wave& w = emu::cur_wave();
+    emu::Fiber& f = emu::cur_fiber();
+    int p = f.par;
+    f.par ^= 1;
+    int lane = emu::lane_id();
+    memcpy(w.slot[p][lane], &mine, 8);
+    emu::wave_rendezvous(w);
+    int base = lane & ~15, q = lane & 15;
+    s16x4_ r;
+    for (int j = 0; j < 4; ++j) {
+        s16x4_ src;
+        memcpy(&src, w.slot[p][base + 4 * j + (q >> 2)], 8);
+        r[j] = src[q & 3];
+    }
+    return r;
+}
+
+}  // namespace e2k

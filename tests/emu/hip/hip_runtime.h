@@ -231,13 +231,17 @@ template <class T> static inline T __shfl_down(T v, int d, int = 64) { return em
 
 static inline unsigned __float_as_uint(float f) { unsigned u; memcpy(&u, &f, 4); return u; }
 static inline float __uint_as_float(unsigned u) { float f; memcpy(&f, &u, 4); return f; }
-static inline float __expf(float x) { return expf(x); }
-static inline float __logf(float x) { return logf(x); }
+#define __expf(x) expf(x)
+#define __logf(x) logf(x)
 static inline float __fdividef(float a, float b) { return a / b; }
 static inline float __frcp_rn(float a) { return 1.0f / a; }
 static inline float rsqrtf(float a) { return 1.0f / sqrtf(a); }
-static inline float __sinf(float a) { return sinf(a); }
-static inline float __cosf(float a) { return cosf(a); }
+#define __sinf(x) sinf(x)
+#define __cosf(x) cosf(x)
+static inline int min(int a, int b) { return a < b ? a : b; }
+static inline int max(int a, int b) { return a > b ? a : b; }
+static inline long min(long a, long b) { return a < b ? a : b; }
+static inline long max(long a, long b) { return a > b ? a : b; }
 static inline void sincosf_(float a, float* s, float* c) { *s = sinf(a); *c = cosf(a); }
 
 static inline float atomicAdd(float* p, float v) {
