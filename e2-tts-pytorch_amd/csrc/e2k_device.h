@@ -78,7 +78,44 @@ __device__ __forceinline__ unsigned rand_u32(unsigned seed, unsigned stream, uns
     return h;
 }
 
+// ---- one-wave-per-row access: lane owns VEC consecutive elements in each of NCH chunks of 64*VEC (D = 64*VEC*NCH)
+template <int VEC> __device__ __forceinline__ void load_vec(const bf16_t* p, float* f);
+template <> __device__ __forceinline__ void load_vec<8>(const bf16_t* p, float* f) { unpack8(ld<u32x4>(p), f); }
+template <> __device__ __forceinline__ void load_vec<4>(const bf16_t* p, float* f) { unpack4(ld<u32x2>(p), f); }
+template <> __device__ __forceinline__ void load_vec<2>(const bf16_t* p, float* f) { unsigned u = ld<unsigned>(p); f[0] = bflo(u); f[1] = bfhi(u); }
+template <int VEC> __device__ __forceinline__ void store_vec(bf16_t* p, const float* f);
+template <> __device__ __forceinline__ void store_vec<8>(bf16_t* p, const float* f) { st<u32x4>(p, pack8(f)); }
+template <> __device__ __forceinline__ void store_vec<4>(bf16_t* p, const float* f) { st<u32x2>(p, pack4(f)); }
+template <> __device__ __forceinline__ void store_vec<2>(bf16_t* p, const float* f) { st<unsigned>(p, pack2bf(f[0], f[1])); }
+
+template <int VEC, int NCH> __device__ __forceinline__ void load_row(const bf16_t* row, int lane, float* f) {
+#pragma unroll
+    for (int c = 0; c < NCH; ++c) load_vec<VEC>(row + c * 64 * VEC + lane * VEC, f + c * VEC);
+}
+template <int VEC, int NCH> __device__ __forceinline__ void store_row(bf16_t* row, int lane, const float* f) {
+#pragma unroll
+    for (int c = 0; c < NCH; ++c) store_vec<VEC>(row + c * 64 * VEC + lane * VEC, f + c * VEC);
+}
+template <int VEC, int NCH> __device__ __forceinline__ void load_row_f32(const float* row, int lane, float* f) {
+#pragma unroll
+    for (int c = 0; c < NCH; ++c)
+#pragma unroll
+        for (int v = 0; v < VEC; ++v) f[c * VEC + v] = row[c * 64 * VEC + lane * VEC + v];
+}
+
 }  // namespace e2k
+
+#define E2K_ROW_DISPATCH(D, FN, ...)                              \
+    switch (D) {                                                  \
+        case 128: rc = FN<2, 1>(__VA_ARGS__); break;              \
+        case 256: rc = FN<4, 1>(__VA_ARGS__); break;              \
+        case 512: rc = FN<8, 1>(__VA_ARGS__); break;              \
+        case 768: rc = FN<4, 3>(__VA_ARGS__); break;              \
+        case 1024: rc = FN<8, 2>(__VA_ARGS__); break;             \
+        case 1536: rc = FN<8, 3>(__VA_ARGS__); break;             \
+        case 2048: rc = FN<8, 4>(__VA_ARGS__); break;             \
+        default: rc = E2K_ERR_SHAPE;                              \
+    }
 
 #define E2K_CHECK_LAUNCH()                                   \
     do {                                                     \

@@ -1,0 +1,524 @@
+// HBM-bound row / element kernels of the transformer block (bf16 activations, fp32 statistics and parameters):
+//   RMSNorm / AdaptiveRMSNorm        x_transformers.RMSNorm, AdaptiveRMSNorm  (e2_tts.py:615,637,645,688,691,729)
+//   AdaLN-Zero gate backward         AdaLNZero                                (e2_tts.py:332-351)
+//   GEGLU                            x_transformers.FeedForward(glu=True)     (e2_tts.py:646,692)
+//   depthwise conv k=31 + SiLU       DepthwiseConv                            (e2_tts.py:295-328)
+//   column sums (bias gradients), fp32 -> bf16 parameter shadow casts.
+#include "e2k_device.h"
+#include "../../include/e2k.h"
+
+using namespace e2k;
+
+namespace {
+
+// ------------------------------------------------------------------------------------------------ RMSNorm
+
+struct NormArgs {
+    const bf16_t* x; const float* gamma; float gamma_off; int rows_per_batch;
+    bf16_t* y; float* rn; int M;
+    // backward
+    const bf16_t* dy; bf16_t* dx; float* dgamma;
+};
+
+template <int VEC, int NCH>
+__global__ __launch_bounds__(256) void rmsnorm_fwd_kernel(NormArgs p) {
+    constexpr int EPL = VEC * NCH, D = 64 * EPL;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const float sqrtD = sqrtf((float)D);
+    for (int row = blockIdx.x * 4 + wave; row < p.M; row += gridDim.x * 4) {
+        float x[EPL], g[EPL];
+        load_row<VEC, NCH>(p.x + (long)row * D, lane, x);
+        load_row_f32<VEC, NCH>(p.gamma + (long)(row / p.rows_per_batch) * D, lane, g);
+        float ss = 0.f;
+#pragma unroll
+        for (int e = 0; e < EPL; ++e) ss = fmaf(x[e], x[e], ss);
+        ss = wave_sum(ss);
+        const float rn = 1.f / fmaxf(sqrtf(ss), 1e-12f);
+        const float sc = rn * sqrtD;
+#pragma unroll
+        for (int e = 0; e < EPL; ++e) x[e] = x[e] * sc * (g[e] + p.gamma_off);
+        store_row<VEC, NCH>(p.y + (long)row * D, lane, x);
+        if (lane == 0) p.rn[row] = rn;
+    }
+}
+
+// grid (blocks_per_batch, nb): every block stays inside one batch row-group so d(gamma) reduces in registers
+template <int VEC, int NCH>
+__global__ __launch_bounds__(256) void rmsnorm_bwd_kernel(NormArgs p) {
+    constexpr int EPL = VEC * NCH, D = 64 * EPL;
+    __shared__ float red[4][D];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int b = blockIdx.y;
+    const int row0 = b * p.rows_per_batch;
+    const int nrows = min(p.rows_per_batch, p.M - row0);
+    const float sqrtD = sqrtf((float)D);
+    float g[EPL], dg[EPL];
+    load_row_f32<VEC, NCH>(p.gamma + (long)b * D, lane, g);
+#pragma unroll
+    for (int e = 0; e < EPL; ++e) { g[e] += p.gamma_off; dg[e] = 0.f; }
+    for (int i = blockIdx.x * 4 + wave; i < nrows; i += gridDim.x * 4) {
+        const long row = row0 + i;
+        float x[EPL], dy[EPL];
+        load_row<VEC, NCH>(p.x + row * D, lane, x);
+        load_row<VEC, NCH>(p.dy + row * D, lane, dy);
+        const float rn = p.rn[row];
+        float dot = 0.f;
+#pragma unroll
+        for (int e = 0; e < EPL; ++e) {
+            x[e] *= rn;                       // u
+            dg[e] = fmaf(dy[e] * sqrtD, x[e], dg[e]);
+            dy[e] *= g[e];                    // t
+            dot = fmaf(dy[e], x[e], dot);
+        }
+        dot = wave_sum(dot);
+        const float sc = rn * sqrtD;
+#pragma unroll
+        for (int e = 0; e < EPL; ++e) dy[e] = sc * (dy[e] - x[e] * dot);
+        store_row<VEC, NCH>(p.dx + row * D, lane, dy);
+    }
+#pragma unroll
+    for (int c = 0; c < NCH; ++c)
+#pragma unroll
+        for (int v = 0; v < VEC; ++v) red[wave][c * 64 * VEC + lane * VEC + v] = dg[c * VEC + v];
+    __syncthreads();
+    for (int d = threadIdx.x; d < D; d += 256)
+        atomicAdd(p.dgamma + (long)b * D + d, red[0][d] + red[1][d] + red[2][d] + red[3][d]);
+}
+
+template <int VEC, int NCH> int launch_norm_fwd(const NormArgs& a, hipStream_t st) {
+    int grid = (a.M + 3) / 4; if (grid > 2048) grid = 2048;
+    hipLaunchKernelGGL((rmsnorm_fwd_kernel<VEC, NCH>), dim3(grid), dim3(256), 0, st, a);
+    return 0;
+}
+template <int VEC, int NCH> int launch_norm_bwd(const NormArgs& a, hipStream_t st) {
+    const int nb = (a.M + a.rows_per_batch - 1) / a.rows_per_batch;
+    int per = (min(a.rows_per_batch, a.M) + 3) / 4;
+    int cap = (1024 + nb - 1) / nb;
+    if (per > cap) per = cap;
+    hipLaunchKernelGGL((rmsnorm_bwd_kernel<VEC, NCH>), dim3(per, nb), dim3(256), 0, st, a);
+    return 0;
+}
+
+// ------------------------------------------------------------------------------------------------ AdaLN-Zero gate backward
+//   forward (fused in the GEMM epilogue):  y = ao * g[b]            (g = sigmoid(to_gamma(c)), per batch row)
+//   backward: dao = dy * g[b] ;  gsum[b][d] += sum_rows dy * y      (so that dg = gsum / g, d(pre-sigmoid) = gsum * (1 - g))
+
+struct GateArgs { const bf16_t* dy; const bf16_t* y; const float* g; bf16_t* dao; float* gsum; int M, rows_per_batch; };
+
+template <int VEC, int NCH>
+__global__ __launch_bounds__(256) void gate_bwd_kernel(GateArgs p) {
+    constexpr int EPL = VEC * NCH, D = 64 * EPL;
+    __shared__ float red[4][D];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int b = blockIdx.y;
+    const int row0 = b * p.rows_per_batch;
+    const int nrows = min(p.rows_per_batch, p.M - row0);
+    float g[EPL], acc[EPL];
+    load_row_f32<VEC, NCH>(p.g + (long)b * D, lane, g);
+#pragma unroll
+    for (int e = 0; e < EPL; ++e) acc[e] = 0.f;
+    for (int i = blockIdx.x * 4 + wave; i < nrows; i += gridDim.x * 4) {
+        const long row = row0 + i;
+        float y[EPL], dy[EPL];
+        load_row<VEC, NCH>(p.y + row * D, lane, y);
+        load_row<VEC, NCH>(p.dy + row * D, lane, dy);
+#pragma unroll
+        for (int e = 0; e < EPL; ++e) { acc[e] = fmaf(dy[e], y[e], acc[e]); dy[e] *= g[e]; }
+        store_row<VEC, NCH>(p.dao + row * D, lane, dy);
+    }
+#pragma unroll
+    for (int c = 0; c < NCH; ++c)
+#pragma unroll
+        for (int v = 0; v < VEC; ++v) red[wave][c * 64 * VEC + lane * VEC + v] = acc[c * VEC + v];
+    __syncthreads();
+    for (int d = threadIdx.x; d < D; d += 256)
+        atomicAdd(p.gsum + (long)b * D + d, red[0][d] + red[1][d] + red[2][d] + red[3][d]);
+}
+template <int VEC, int NCH> int launch_gate_bwd(const GateArgs& a, hipStream_t st) {
+    const int nb = (a.M + a.rows_per_batch - 1) / a.rows_per_batch;
+    int per = (min(a.rows_per_batch, a.M) + 3) / 4;
+    int cap = (1024 + nb - 1) / nb;
+    if (per > cap) per = cap;
+    hipLaunchKernelGGL((gate_bwd_kernel<VEC, NCH>), dim3(per, nb), dim3(256), 0, st, a);
+    return 0;
+}
+
+// ------------------------------------------------------------------------------------------------ GEGLU
+
+__device__ __forceinline__ float gelu_erf(float x) { return 0.5f * x * (1.f + erff(x * 0.70710678118654752f)); }
+__device__ __forceinline__ float gelu_erf_grad(float x) {
+    return 0.5f * (1.f + erff(x * 0.70710678118654752f)) + x * 0.3989422804014327f * __expf(-0.5f * x * x);
+}
+__device__ __forceinline__ float keep_scale(unsigned seed, unsigned stream, unsigned row, unsigned col, unsigned thresh, float inv_keep) {
+    // one hash per pair of columns: low / high 16 bits
+    unsigned h = rand_u32(seed, stream, row, col >> 1);
+    unsigned r16 = (col & 1) ? (h >> 16) : (h & 0xffffu);
+    return r16 >= thresh ? inv_keep : 0.f;
+}
+
+struct GegluArgs {
+    const bf16_t* H; long ldh; bf16_t* out; const bf16_t* dout; bf16_t* dH; int M, F;
+    unsigned seed, stream, thresh; float inv_keep;     // dropout (thresh = 0: off)
+};
+
+template <bool BWD>
+__global__ __launch_bounds__(256) void geglu_kernel(GegluArgs p) {
+    const int fv = p.F / 8;
+    const long total = (long)p.M * fv;
+    for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < total; i += (long)gridDim.x * 256) {
+        const int m = (int)(i / fv), c = (int)(i % fv) * 8;
+        float u[8], gt[8];
+        unpack8(ld<u32x4>(p.H + (long)m * p.ldh + c), u);
+        unpack8(ld<u32x4>(p.H + (long)m * p.ldh + p.F + c), gt);
+        float ks[8];
+#pragma unroll
+        for (int e = 0; e < 8; ++e) ks[e] = p.thresh ? keep_scale(p.seed, p.stream, m, c + e, p.thresh, p.inv_keep) : 1.f;
+        if (!BWD) {
+            float o[8];
+#pragma unroll
+            for (int e = 0; e < 8; ++e) o[e] = u[e] * gelu_erf(gt[e]) * ks[e];
+            st<u32x4>(p.out + (long)m * p.F + c, pack8(o));
+        } else {
+            float d[8], du[8], dg[8];
+            unpack8(ld<u32x4>(p.dout + (long)m * p.F + c), d);
+#pragma unroll
+            for (int e = 0; e < 8; ++e) {
+                float dd = d[e] * ks[e];
+                du[e] = dd * gelu_erf(gt[e]);
+                dg[e] = dd * u[e] * gelu_erf_grad(gt[e]);
+            }
+            st<u32x4>(p.dH + (long)m * p.ldh + c, pack8(du));
+            st<u32x4>(p.dH + (long)m * p.ldh + p.F + c, pack8(dg));
+        }
+    }
+}
+
+// ------------------------------------------------------------------------------------------------ column sums
+
+__global__ __launch_bounds__(256) void colsum_kernel(const bf16_t* x, long ldx, float* out, int M, int N) {
+    const int col = (blockIdx.x * 256 + threadIdx.x) * 2;
+    if (col >= N) return;
+    float a0 = 0.f, a1 = 0.f;
+    for (int m = blockIdx.y; m < M; m += gridDim.y) {
+        unsigned v = ld<unsigned>(x + (long)m * ldx + col);
+        a0 += bflo(v);
+        a1 += bfhi(v);
+    }
+    atomicAdd(out + col, a0);
+    if (col + 1 < N) atomicAdd(out + col + 1, a1);
+}
+
+// ------------------------------------------------------------------------------------------------ casts
+
+__global__ __launch_bounds__(256) void cast_bf16_kernel(const float* src, bf16_t* dst, long n) {
+    const long nv = n / 8;
+    for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < nv; i += (long)gridDim.x * 256) {
+        f32x4 a = ld<f32x4>(src + i * 8), b = ld<f32x4>(src + i * 8 + 4);
+        float f[8] = {a[0], a[1], a[2], a[3], b[0], b[1], b[2], b[3]};
+        st<u32x4>(dst + i * 8, pack8(f));
+    }
+    if (blockIdx.x == 0) {
+        for (long i = nv * 8 + threadIdx.x; i < n; i += 256) dst[i] = f2bf(src[i]);
+    }
+}
+
+// src (R, C) fp32 row-major -> dst (C, R) bf16 row-major (ldd elements per dst row)
+__global__ __launch_bounds__(256) void cast_transpose_kernel(const float* src, bf16_t* dst, int R, int C, long ldd) {
+    __shared__ float tile[64][65];
+    const int r0 = blockIdx.y * 64, c0 = blockIdx.x * 64;
+    const int tx = threadIdx.x & 63, ty = threadIdx.x >> 6;
+    for (int i = ty; i < 64; i += 4) {
+        int r = r0 + i, c = c0 + tx;
+        tile[i][tx] = (r < R && c < C) ? src[(long)r * C + c] : 0.f;
+    }
+    __syncthreads();
+    for (int i = ty; i < 64; i += 4) {
+        int c = c0 + i, r = r0 + tx;
+        if (c < C && r < R) dst[(long)c * ldd + r] = f2bf(tile[tx][i]);
+    }
+}
+
+// ------------------------------------------------------------------------------------------------ depthwise conv + SiLU
+// channels-last: x (B, N, C); block = 64 frames x 64 channels of one batch row; thread = 2 channels x 8 frames.
+
+constexpr int CTN = 64, CTC = 64;
+
+struct ConvArgs {
+    const bf16_t* x; const uint8_t* mask; const float* w; const float* bias;
+    bf16_t* pre; bf16_t* y;
+    const bf16_t* dy; bf16_t* dx; float* dw; float* dbias;
+    int B, N, C;
+};
+
+template <int KS>
+__global__ __launch_bounds__(256) void dwconv_fwd_kernel(ConvArgs p) {
+    constexpr int PAD = KS / 2, ROWS = CTN + KS - 1;
+    __shared__ unsigned xt[ROWS][CTC / 2];
+    const int tid = threadIdx.x;
+    const int n0 = blockIdx.x * CTN, c0 = blockIdx.y * CTC, b = blockIdx.z;
+    for (int i = tid; i < ROWS * (CTC / 2); i += 256) {
+        int j = i / (CTC / 2), cp = i % (CTC / 2);
+        int n = n0 - PAD + j;
+        unsigned v = 0u;
+        if (n >= 0 && n < p.N && (p.mask == nullptr || p.mask[(long)b * p.N + n]))
+            v = ld<unsigned>(p.x + ((long)b * p.N + n) * p.C + c0 + cp * 2);
+        xt[j][cp] = v;
+    }
+    const int cp = tid & 31, fg = tid >> 5;
+    const int ch = c0 + cp * 2;
+    float w0[KS], w1[KS];
+#pragma unroll
+    for (int k = 0; k < KS; ++k) { w0[k] = p.w[(long)ch * KS + k]; w1[k] = p.w[(long)(ch + 1) * KS + k]; }
+    const float b0 = p.bias[ch], b1 = p.bias[ch + 1];
+    __syncthreads();
+    float a0[8], a1[8];
+#pragma unroll
+    for (int o = 0; o < 8; ++o) { a0[o] = b0; a1[o] = b1; }
+#pragma unroll
+    for (int i = 0; i < 8 + KS - 1; ++i) {
+        unsigned v = xt[fg * 8 + i][cp];
+        float x0 = bflo(v), x1 = bfhi(v);
+#pragma unroll
+        for (int o = 0; o < 8; ++o) {
+            const int k = i - o;
+            if (k >= 0 && k < KS) { a0[o] = fmaf(w0[k], x0, a0[o]); a1[o] = fmaf(w1[k], x1, a1[o]); }
+        }
+    }
+#pragma unroll
+    for (int o = 0; o < 8; ++o) {
+        const int n = n0 + fg * 8 + o;
+        if (n < p.N) {
+            const long off = ((long)b * p.N + n) * p.C + ch;
+            st<unsigned>(p.pre + off, pack2bf(a0[o], a1[o]));
+            const bool keep = p.mask == nullptr || p.mask[(long)b * p.N + n];
+            st<unsigned>(p.y + off, keep ? pack2bf(siluf_(a0[o]), siluf_(a1[o])) : 0u);
+        }
+    }
+}
+
+__device__ __forceinline__ float silu_grad(float x) { float s = sigmoidf_(x); return s * (1.f + x * (1.f - s)); }
+
+template <int KS>
+__global__ __launch_bounds__(256) void dwconv_bwd_kernel(ConvArgs p) {
+    constexpr int PAD = KS / 2, ROWS = CTN + KS - 1;
+    __shared__ float dpt[ROWS][CTC];       // d(pre-activation), frame n0 - PAD + j
+    __shared__ float xt[ROWS][CTC];        // masked input,      frame n0 - PAD + j
+    __shared__ float dwl[CTC][KS + 1];     // [..][KS] = dbias
+    const int tid = threadIdx.x;
+    const int n0 = blockIdx.x * CTN, c0 = blockIdx.y * CTC, b = blockIdx.z;
+    for (int i = tid; i < CTC * (KS + 1); i += 256) (&dwl[0][0])[i] = 0.f;
+    for (int i = tid; i < ROWS * (CTC / 2); i += 256) {
+        int j = i / (CTC / 2), cp = i % (CTC / 2);
+        int n = n0 - PAD + j;
+        float d0 = 0.f, d1 = 0.f, x0 = 0.f, x1 = 0.f;
+        if (n >= 0 && n < p.N && (p.mask == nullptr || p.mask[(long)b * p.N + n])) {
+            const long off = ((long)b * p.N + n) * p.C + c0 + cp * 2;
+            unsigned vd = ld<unsigned>(p.dy + off), vp = ld<unsigned>(p.pre + off), vx = ld<unsigned>(p.x + off);
+            d0 = bflo(vd) * silu_grad(bflo(vp));
+            d1 = bfhi(vd) * silu_grad(bfhi(vp));
+            x0 = bflo(vx);
+            x1 = bfhi(vx);
+        }
+        dpt[j][cp * 2] = d0; dpt[j][cp * 2 + 1] = d1;
+        xt[j][cp * 2] = x0;  xt[j][cp * 2 + 1] = x1;
+    }
+    const int cp = tid & 31, fg = tid >> 5;
+    const int ch = c0 + cp * 2;
+    float w0[KS], w1[KS];     // flipped
+#pragma unroll
+    for (int k = 0; k < KS; ++k) { w0[k] = p.w[(long)ch * KS + (KS - 1 - k)]; w1[k] = p.w[(long)(ch + 1) * KS + (KS - 1 - k)]; }
+    __syncthreads();
+    // dx[o] = sum_k' wflip[k'] dp_tile[o + k']
+    float a0[8], a1[8];
+#pragma unroll
+    for (int o = 0; o < 8; ++o) { a0[o] = 0.f; a1[o] = 0.f; }
+#pragma unroll
+    for (int i = 0; i < 8 + KS - 1; ++i) {
+        float d0 = dpt[fg * 8 + i][cp * 2], d1 = dpt[fg * 8 + i][cp * 2 + 1];
+#pragma unroll
+        for (int o = 0; o < 8; ++o) {
+            const int k = i - o;
+            if (k >= 0 && k < KS) { a0[o] = fmaf(w0[k], d0, a0[o]); a1[o] = fmaf(w1[k], d1, a1[o]); }
+        }
+    }
+#pragma unroll
+    for (int o = 0; o < 8; ++o) {
+        const int n = n0 + fg * 8 + o;
+        if (n < p.N) {
+            const bool keep = p.mask == nullptr || p.mask[(long)b * p.N + n];
+            st<unsigned>(p.dx + ((long)b * p.N + n) * p.C + ch, keep ? pack2bf(a0[o], a1[o]) : 0u);
+        }
+    }
+    // dw[k] += sum_o dp_tile[o + PAD] * x_tile[o + k]
+    float g0[KS], g1[KS], s0 = 0.f, s1 = 0.f;
+#pragma unroll
+    for (int k = 0; k < KS; ++k) { g0[k] = 0.f; g1[k] = 0.f; }
+    float dq0[8], dq1[8];
+#pragma unroll
+    for (int o = 0; o < 8; ++o) {
+        dq0[o] = dpt[fg * 8 + o + PAD][cp * 2];
+        dq1[o] = dpt[fg * 8 + o + PAD][cp * 2 + 1];
+        s0 += dq0[o];
+        s1 += dq1[o];
+    }
+#pragma unroll
+    for (int i = 0; i < 8 + KS - 1; ++i) {
+        float x0 = xt[fg * 8 + i][cp * 2], x1 = xt[fg * 8 + i][cp * 2 + 1];
+#pragma unroll
+        for (int o = 0; o < 8; ++o) {
+            const int k = i - o;
+            if (k >= 0 && k < KS) { g0[k] = fmaf(dq0[o], x0, g0[k]); g1[k] = fmaf(dq1[o], x1, g1[k]); }
+        }
+    }
+#pragma unroll
+    for (int k = 0; k < KS; ++k) { atomicAdd(&dwl[cp * 2][k], g0[k]); atomicAdd(&dwl[cp * 2 + 1][k], g1[k]); }
+    atomicAdd(&dwl[cp * 2][KS], s0);
+    atomicAdd(&dwl[cp * 2 + 1][KS], s1);
+    __syncthreads();
+    for (int i = tid; i < CTC * (KS + 1); i += 256) {
+        int c = i / (KS + 1), k = i % (KS + 1);
+        float v = dwl[c][k];
+        if (k < KS) atomicAdd(p.dw + (long)(c0 + c) * KS + k, v);
+        else atomicAdd(p.dbias + c0 + c, v);
+    }
+}
+
+template <int KS> int launch_conv(const ConvArgs& a, bool bwd, hipStream_t st) {
+    dim3 grid((a.N + CTN - 1) / CTN, a.C / CTC, a.B), block(256);
+    if (bwd) hipLaunchKernelGGL(dwconv_bwd_kernel<KS>, grid, block, 0, st, a);
+    else hipLaunchKernelGGL(dwconv_fwd_kernel<KS>, grid, block, 0, st, a);
+    return 0;
+}
+int dispatch_conv(const ConvArgs& a, int ks, bool bwd, hipStream_t st) {
+    switch (ks) {
+        case 31: return launch_conv<31>(a, bwd, st);
+        case 15: return launch_conv<15>(a, bwd, st);
+        case 7: return launch_conv<7>(a, bwd, st);
+        case 3: return launch_conv<3>(a, bwd, st);
+        default: return E2K_ERR_SHAPE;
+    }
+}
+
+}  // namespace
+
+extern "C" int e2k_rmsnorm_fwd(const void* x, const float* gamma, float gamma_off, int rows_per_batch, void* y,
+                               float* rn, int M, int D, void* stream) {
+    if (M <= 0) return 0;
+    if (!x || !gamma || !y || !rn || rows_per_batch <= 0) return E2K_ERR_ARG;
+    NormArgs a{};
+    a.x = (const bf16_t*)x; a.gamma = gamma; a.gamma_off = gamma_off; a.rows_per_batch = rows_per_batch;
+    a.y = (bf16_t*)y; a.rn = rn; a.M = M;
+    int rc = 0;
+    E2K_ROW_DISPATCH(D, launch_norm_fwd, a, (hipStream_t)stream);
+    if (rc) return rc;
+    E2K_CHECK_LAUNCH();
+    return 0;
+}
+
+extern "C" int e2k_rmsnorm_bwd(const void* dy, const void* x, const float* rn, const float* gamma, float gamma_off,
+                               int rows_per_batch, void* dx, float* dgamma, int M, int D, void* stream) {
+    if (M <= 0) return 0;
+    if (!dy || !x || !rn || !gamma || !dx || !dgamma || rows_per_batch <= 0) return E2K_ERR_ARG;
+    NormArgs a{};
+    a.x = (const bf16_t*)x; a.gamma = gamma; a.gamma_off = gamma_off; a.rows_per_batch = rows_per_batch;
+    a.rn = const_cast<float*>(rn); a.M = M; a.dy = (const bf16_t*)dy; a.dx = (bf16_t*)dx; a.dgamma = dgamma;
+    int rc = 0;
+    E2K_ROW_DISPATCH(D, launch_norm_bwd, a, (hipStream_t)stream);
+    if (rc) return rc;
+    E2K_CHECK_LAUNCH();
+    return 0;
+}
+
+extern "C" int e2k_gate_bwd(const void* dy, const void* y, const float* g, void* dao, float* gsum, int M, int D,
+                            int rows_per_batch, void* stream) {
+    if (M <= 0) return 0;
+    if (!dy || !y || !g || !dao || !gsum || rows_per_batch <= 0) return E2K_ERR_ARG;
+    GateArgs a{(const bf16_t*)dy, (const bf16_t*)y, g, (bf16_t*)dao, gsum, M, rows_per_batch};
+    int rc = 0;
+    E2K_ROW_DISPATCH(D, launch_gate_bwd, a, (hipStream_t)stream);
+    if (rc) return rc;
+    E2K_CHECK_LAUNCH();
+    return 0;
+}
+
+static int geglu_grid(long total) {
+    long g = (total + 255) / 256;
+    return (int)(g > 4096 ? 4096 : (g < 1 ? 1 : g));
+}
+
+extern "C" int e2k_geglu_fwd(const void* H, int64_t ldh, void* out, int M, int F, float p_drop, uint32_t seed,
+                             uint32_t stream_id, void* stream) {
+    if (M <= 0 || F <= 0) return 0;
+    if ((F & 7) || (ldh & 7)) return E2K_ERR_ALIGN;
+    GegluArgs a{};
+    a.H = (const bf16_t*)H; a.ldh = ldh; a.out = (bf16_t*)out; a.M = M; a.F = F;
+    a.seed = seed; a.stream = stream_id; a.thresh = (unsigned)(p_drop * 65536.f + 0.5f); a.inv_keep = 1.f / (1.f - p_drop);
+    hipLaunchKernelGGL(geglu_kernel<false>, dim3(geglu_grid((long)M * F / 8)), dim3(256), 0, (hipStream_t)stream, a);
+    E2K_CHECK_LAUNCH();
+    return 0;
+}
+
+extern "C" int e2k_geglu_bwd(const void* dout, const void* H, int64_t ldh, void* dH, int M, int F, float p_drop,
+                             uint32_t seed, uint32_t stream_id, void* stream) {
+    if (M <= 0 || F <= 0) return 0;
+    if ((F & 7) || (ldh & 7)) return E2K_ERR_ALIGN;
+    GegluArgs a{};
+    a.H = (const bf16_t*)H; a.ldh = ldh; a.dout = (const bf16_t*)dout; a.dH = (bf16_t*)dH; a.M = M; a.F = F;
+    a.seed = seed; a.stream = stream_id; a.thresh = (unsigned)(p_drop * 65536.f + 0.5f); a.inv_keep = 1.f / (1.f - p_drop);
+    hipLaunchKernelGGL(geglu_kernel<true>, dim3(geglu_grid((long)M * F / 8)), dim3(256), 0, (hipStream_t)stream, a);
+    E2K_CHECK_LAUNCH();
+    return 0;
+}
+
+extern "C" int e2k_colsum_bf16(const void* x, int64_t ldx, float* out, int M, int N, void* stream) {
+    if (M <= 0 || N <= 0) return 0;
+    if ((N & 1) || (ldx & 1)) return E2K_ERR_ALIGN;
+    int splits = (M + 63) / 64; if (splits > 128) splits = 128;
+    hipLaunchKernelGGL(colsum_kernel, dim3((N / 2 + 255) / 256, splits), dim3(256), 0, (hipStream_t)stream,
+                       (const bf16_t*)x, (long)ldx, out, M, N);
+    E2K_CHECK_LAUNCH();
+    return 0;
+}
+
+extern "C" int e2k_cast_bf16(const float* src, void* dst, int64_t n, void* stream) {
+    if (n <= 0) return 0;
+    if (((uintptr_t)src | (uintptr_t)dst) & 15) return E2K_ERR_ALIGN;
+    long g = (n / 8 + 255) / 256; if (g > 4096) g = 4096; if (g < 1) g = 1;
+    hipLaunchKernelGGL(cast_bf16_kernel, dim3((int)g), dim3(256), 0, (hipStream_t)stream, src, (bf16_t*)dst, (long)n);
+    E2K_CHECK_LAUNCH();
+    return 0;
+}
+
+extern "C" int e2k_cast_transpose_bf16(const float* src, void* dst, int R, int C, int64_t ldd, void* stream) {
+    if (R <= 0 || C <= 0) return 0;
+    hipLaunchKernelGGL(cast_transpose_kernel, dim3((C + 63) / 64, (R + 63) / 64), dim3(256), 0, (hipStream_t)stream,
+                       src, (bf16_t*)dst, R, C, (long)ldd);
+    E2K_CHECK_LAUNCH();
+    return 0;
+}
+
+extern "C" int e2k_dwconv_fwd(const void* x, const uint8_t* mask, const float* w, const float* bias, void* pre,
+                              void* y, int B, int N, int C, int ks, void* stream) {
+    if (B <= 0 || N <= 0) return 0;
+    if (C % CTC) return E2K_ERR_SHAPE;
+    ConvArgs a{};
+    a.x = (const bf16_t*)x; a.mask = mask; a.w = w; a.bias = bias; a.pre = (bf16_t*)pre; a.y = (bf16_t*)y;
+    a.B = B; a.N = N; a.C = C;
+    int rc = dispatch_conv(a, ks, false, (hipStream_t)stream);
+    if (rc) return rc;
+    E2K_CHECK_LAUNCH();
+    return 0;
+}
+
+extern "C" int e2k_dwconv_bwd(const void* dy, const void* pre, const void* x, const uint8_t* mask, const float* w,
+                              void* dx, float* dw, float* dbias, int B, int N, int C, int ks, void* stream) {
+    if (B <= 0 || N <= 0) return 0;
+    if (C % CTC) return E2K_ERR_SHAPE;
+    ConvArgs a{};
+    a.x = (const bf16_t*)x; a.mask = mask; a.w = w; a.pre = (bf16_t*)pre; a.dy = (const bf16_t*)dy;
+    a.dx = (bf16_t*)dx; a.dw = dw; a.dbias = dbias; a.B = B; a.N = N; a.C = C;
+    int rc = dispatch_conv(a, ks, true, (hipStream_t)stream);
+    if (rc) return rc;
+    E2K_CHECK_LAUNCH();
+    return 0;
+}

@@ -1,0 +1,430 @@
+// Hyper-connections (4 residual streams), fused depth + width connection, forward and backward.
+//
+// Replaces hyper_connections.HyperConnections as the reference uses it
+//     x, add_residual = hc(x) ... x = add_residual(branch_out)          (e2_tts.py:870-882, 900-939)
+// (arithmetic restated in SURVEY.md Appendix A.5 / oracle HyperConnections).
+//
+// Data layout: the reference keeps streams in the batch dim '(b s) n d'; here a token's 4 streams are
+// contiguous: X[token][s][d] (bf16), so one wave reads/writes one token as a single 4*D*2-byte burst.
+//
+// For HC instance i on stream tensor X_i:
+//   width :  r = X_i ;  z_s = r_s/|r_s| * sqrt(D) * (gamma+1)
+//            a[s][t] = tanh(z_s . Wa[:,t]) * sa + A[s][t]      (t = 0..4)
+//            b[s]    = tanh(z_s . wb) * sb + B[s]
+//            mix_t   = sum_s a[s][t] r_s ;  branch_in = mix_0 ;  M_i[s] = mix_{s+1}
+//   depth :  X_{i+1}[s] = M_i[s] + b[s] * y_i         (y_i = branch output)
+// The forward kernel fuses depth_{i-1} with width_i (X_i is never written: HBM traffic 5D in + 5D out per
+// token instead of 9D + 9D); the backward kernel fuses width_i-backward with depth_{i-1}-backward and
+// recomputes r from (M_{i-1}, y_{i-1}, b_{i-1}).  Per-token coefficients are saved in `coef` (52 floats).
+// HBM-bound: algorithmic bytes per token = 2*(5D+5D) forward, 2*(11D+5D) backward.
+#include "e2k_device.h"
+#include "../../include/e2k.h"
+
+using namespace e2k;
+
+namespace {
+
+constexpr int S = 4, NJ = 6, CW = 52;
+constexpr int CA = 0, CB = 20, CP = 24, CRN = 48;   // a[s*5+t], b[s], P[s*6+j] (pre-tanh dots), rn[s]
+
+struct HCParams {
+    const float* static_beta; const float* static_alpha; const float* dyn_alpha_fn; const float* dyn_alpha_scale;
+    const float* dyn_beta_fn; const float* dyn_beta_scale; const float* gamma;
+};
+
+// Wp[j][d] = (gamma[d]+1) * W[d][j]   (j < 5: dynamic_alpha_fn column, j = 5: dynamic_beta_fn)
+__device__ __forceinline__ void stage_wp(float* Wp, const HCParams& hp, int D, int tid) {
+    for (int d = tid; d < D; d += 256) {
+        float g = hp.gamma[d] + 1.f;
+#pragma unroll
+        for (int t = 0; t < 5; ++t) Wp[t * D + d] = g * hp.dyn_alpha_fn[d * 5 + t];
+        Wp[5 * D + d] = g * hp.dyn_beta_fn[d];
+    }
+}
+
+struct HCFwdArgs {
+    const bf16_t* Xin; const bf16_t* yprev; const float* coef_prev;
+    bf16_t* Mout; bf16_t* bin; float* coef;
+    HCParams hp;
+    int Mtok;
+};
+
+template <int VEC, int NCH, bool DEPTH, bool WIDTH>
+__global__ __launch_bounds__(256) void hc_fwd_kernel(HCFwdArgs p) {
+    constexpr int EPL = VEC * NCH, D = 64 * EPL;
+    __shared__ __attribute__((aligned(16))) float Wp[WIDTH ? NJ * D : 4];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    float sa = 0.f, sb = 0.f, A[20], B[4];
+    if (WIDTH) {
+        stage_wp(Wp, p.hp, D, tid);
+        sa = p.hp.dyn_alpha_scale[0];
+        sb = p.hp.dyn_beta_scale[0];
+#pragma unroll
+        for (int i = 0; i < 20; ++i) A[i] = p.hp.static_alpha[i];
+#pragma unroll
+        for (int i = 0; i < 4; ++i) B[i] = p.hp.static_beta[i];
+        __syncthreads();
+    }
+    const float sqrtD = sqrtf((float)D);
+    for (int tok = blockIdx.x * 4 + wave; tok < p.Mtok; tok += gridDim.x * 4) {
+        float r[S][EPL];
+#pragma unroll
+        for (int s = 0; s < S; ++s) load_row<VEC, NCH>(p.Xin + ((long)tok * S + s) * D, lane, r[s]);
+        if (DEPTH) {
+            float y[EPL];
+            load_row<VEC, NCH>(p.yprev + (long)tok * D, lane, y);
+#pragma unroll
+            for (int s = 0; s < S; ++s) {
+                const float bp = p.coef_prev[(long)tok * CW + CB + s];
+#pragma unroll
+                for (int e = 0; e < EPL; ++e) r[s][e] = fmaf(bp, y[e], r[s][e]);
+            }
+        }
+        if (!WIDTH) {
+#pragma unroll
+            for (int s = 0; s < S; ++s) store_row<VEC, NCH>(p.Mout + ((long)tok * S + s) * D, lane, r[s]);
+            continue;
+        }
+        float part[S][NJ + 1];
+#pragma unroll
+        for (int s = 0; s < S; ++s)
+#pragma unroll
+            for (int j = 0; j <= NJ; ++j) part[s][j] = 0.f;
+#pragma unroll
+        for (int j = 0; j < NJ; ++j) {
+            float w[EPL];
+            load_row_f32<VEC, NCH>(Wp + j * D, lane, w);
+#pragma unroll
+            for (int s = 0; s < S; ++s)
+#pragma unroll
+                for (int e = 0; e < EPL; ++e) part[s][j] = fmaf(r[s][e], w[e], part[s][j]);
+        }
+#pragma unroll
+        for (int s = 0; s < S; ++s)
+#pragma unroll
+            for (int e = 0; e < EPL; ++e) part[s][NJ] = fmaf(r[s][e], r[s][e], part[s][NJ]);
+#pragma unroll
+        for (int s = 0; s < S; ++s)
+#pragma unroll
+            for (int j = 0; j <= NJ; ++j) part[s][j] = wave_sum(part[s][j]);
+        float a[S][5], b[S], P[S][NJ], rn[S];
+#pragma unroll
+        for (int s = 0; s < S; ++s) {
+            rn[s] = 1.f / fmaxf(sqrtf(part[s][NJ]), 1e-12f);
+#pragma unroll
+            for (int j = 0; j < NJ; ++j) P[s][j] = part[s][j] * rn[s] * sqrtD;
+#pragma unroll
+            for (int t = 0; t < 5; ++t) a[s][t] = tanhf_(P[s][t]) * sa + A[s * 5 + t];
+            b[s] = tanhf_(P[s][5]) * sb + B[s];
+        }
+#pragma unroll
+        for (int t = 0; t < 5; ++t) {
+            float m[EPL];
+#pragma unroll
+            for (int e = 0; e < EPL; ++e) {
+                float v = a[0][t] * r[0][e];
+#pragma unroll
+                for (int s = 1; s < S; ++s) v = fmaf(a[s][t], r[s][e], v);
+                m[e] = v;
+            }
+            if (t == 0) store_row<VEC, NCH>(p.bin + (long)tok * D, lane, m);
+            else store_row<VEC, NCH>(p.Mout + ((long)tok * S + (t - 1)) * D, lane, m);
+        }
+        if (lane == 0) {
+            float* c = p.coef + (long)tok * CW;
+#pragma unroll
+            for (int s = 0; s < S; ++s) {
+#pragma unroll
+                for (int t = 0; t < 5; ++t) c[CA + s * 5 + t] = a[s][t];
+                c[CB + s] = b[s];
+#pragma unroll
+                for (int j = 0; j < NJ; ++j) c[CP + s * NJ + j] = P[s][j];
+                c[CRN + s] = rn[s];
+            }
+        }
+    }
+}
+
+struct HCBwdArgs {
+    const bf16_t* Xin; const bf16_t* yprev; const float* coef_prev;
+    const bf16_t* G; const bf16_t* dbin; const bf16_t* ycur; const float* coef;
+    bf16_t* dR; bf16_t* dyprev;
+    HCParams hp;
+    float* partial;      // [gridDim.x][NJ*D + 32]
+    int Mtok;
+};
+
+constexpr int NSC = 32;   // scalar partials: dA[20], dB[4], dsa, dsb, pad
+
+template <int VEC, int NCH, bool DEPTH, bool WIDTH>
+__global__ __launch_bounds__(256) void hc_bwd_kernel(HCBwdArgs p) {
+    constexpr int EPL = VEC * NCH, D = 64 * EPL;
+    __shared__ __attribute__((aligned(16))) float Wp[WIDTH ? NJ * D : 4];
+    __shared__ __attribute__((aligned(16))) float dWp[WIDTH ? NJ * D + NSC : 4];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    float sa = 0.f, sb = 0.f;
+    if (WIDTH) {
+        stage_wp(Wp, p.hp, D, tid);
+        for (int i = tid; i < NJ * D + NSC; i += 256) dWp[i] = 0.f;
+        sa = p.hp.dyn_alpha_scale[0];
+        sb = p.hp.dyn_beta_scale[0];
+        __syncthreads();
+    }
+    const float sqrtD = sqrtf((float)D);
+    float sc[26];
+#pragma unroll
+    for (int i = 0; i < 26; ++i) sc[i] = 0.f;
+
+    for (int tok = blockIdx.x * 4 + wave; tok < p.Mtok; tok += gridDim.x * 4) {
+        float bp[S];
+        if (DEPTH) {
+#pragma unroll
+            for (int s = 0; s < S; ++s) bp[s] = p.coef_prev[(long)tok * CW + CB + s];
+        }
+        if (!WIDTH) {
+            // only the depth connection of the previous instance: dy_prev = sum_s b_prev[s] * dX[s]
+            float dy[EPL];
+#pragma unroll
+            for (int e = 0; e < EPL; ++e) dy[e] = 0.f;
+#pragma unroll
+            for (int s = 0; s < S; ++s) {
+                float g[EPL];
+                load_row<VEC, NCH>(p.G + ((long)tok * S + s) * D, lane, g);
+#pragma unroll
+                for (int e = 0; e < EPL; ++e) dy[e] = fmaf(bp[s], g[e], dy[e]);
+            }
+            store_row<VEC, NCH>(p.dyprev + (long)tok * D, lane, dy);
+            continue;
+        }
+        float r[S][EPL], dm[5][EPL], yc[EPL];
+#pragma unroll
+        for (int s = 0; s < S; ++s) load_row<VEC, NCH>(p.Xin + ((long)tok * S + s) * D, lane, r[s]);
+        if (DEPTH) {
+            float y[EPL];
+            load_row<VEC, NCH>(p.yprev + (long)tok * D, lane, y);
+#pragma unroll
+            for (int s = 0; s < S; ++s)
+#pragma unroll
+                for (int e = 0; e < EPL; ++e) r[s][e] = fmaf(bp[s], y[e], r[s][e]);
+        }
+        load_row<VEC, NCH>(p.dbin + (long)tok * D, lane, dm[0]);
+#pragma unroll
+        for (int s = 0; s < S; ++s) load_row<VEC, NCH>(p.G + ((long)tok * S + s) * D, lane, dm[s + 1]);
+        load_row<VEC, NCH>(p.ycur + (long)tok * D, lane, yc);
+
+        // 24 dots: da[s][t] = dm_t . r_s ; db[s] = G_s . y_cur
+        float da[S][5], db[S];
+#pragma unroll
+        for (int s = 0; s < S; ++s) {
+#pragma unroll
+            for (int t = 0; t < 5; ++t) {
+                float v = 0.f;
+#pragma unroll
+                for (int e = 0; e < EPL; ++e) v = fmaf(dm[t][e], r[s][e], v);
+                da[s][t] = wave_sum(v);
+            }
+            float v = 0.f;
+#pragma unroll
+            for (int e = 0; e < EPL; ++e) v = fmaf(dm[s + 1][e], yc[e], v);
+            db[s] = wave_sum(v);
+        }
+        const float* cf = p.coef + (long)tok * CW;
+        float a[S][5], c[S][NJ], rn[S], uq[S];
+#pragma unroll
+        for (int s = 0; s < S; ++s) {
+            rn[s] = cf[CRN + s];
+            float acc_uq = 0.f;
+#pragma unroll
+            for (int t = 0; t < 5; ++t) {
+                a[s][t] = cf[CA + s * 5 + t];
+                float P = cf[CP + s * NJ + t];
+                float th = tanhf_(P);
+                c[s][t] = da[s][t] * sa * (1.f - th * th);
+                acc_uq = fmaf(c[s][t], P, acc_uq);
+                sc[s * 5 + t] += da[s][t];
+                sc[24] = fmaf(da[s][t], th, sc[24]);
+            }
+            float P = cf[CP + s * NJ + 5];
+            float th = tanhf_(P);
+            c[s][5] = db[s] * sb * (1.f - th * th);
+            acc_uq = fmaf(c[s][5], P, acc_uq);
+            sc[20 + s] += db[s];
+            sc[25] = fmaf(db[s], th, sc[25]);
+            uq[s] = acc_uq;
+        }
+        // q[s][e] = sqrtD * sum_j c[s][j] Wp[j][d] ; dWp[j][d] += sum_s c[s][j] rn[s] sqrtD r[s][d]
+        float q[S][EPL];
+#pragma unroll
+        for (int s = 0; s < S; ++s)
+#pragma unroll
+            for (int e = 0; e < EPL; ++e) q[s][e] = 0.f;
+#pragma unroll
+        for (int j = 0; j < NJ; ++j) {
+            float w[EPL];
+            load_row_f32<VEC, NCH>(Wp + j * D, lane, w);
+            float cs[S];
+#pragma unroll
+            for (int s = 0; s < S; ++s) cs[s] = c[s][j] * rn[s] * sqrtD;
+#pragma unroll
+            for (int e = 0; e < EPL; ++e) {
+                float g = 0.f;
+#pragma unroll
+                for (int s = 0; s < S; ++s) {
+                    q[s][e] = fmaf(c[s][j] * sqrtD, w[e], q[s][e]);
+                    g = fmaf(cs[s], r[s][e], g);
+                }
+                const int ch = e / VEC, v = e % VEC;
+                atomicAdd(&dWp[j * D + ch * 64 * VEC + lane * VEC + v], g);
+            }
+        }
+        float dyp[EPL];
+#pragma unroll
+        for (int e = 0; e < EPL; ++e) dyp[e] = 0.f;
+#pragma unroll
+        for (int s = 0; s < S; ++s) {
+            float dr[EPL];
+#pragma unroll
+            for (int e = 0; e < EPL; ++e) {
+                float v = a[s][0] * dm[0][e];
+#pragma unroll
+                for (int t = 1; t < 5; ++t) v = fmaf(a[s][t], dm[t][e], v);
+                float u = r[s][e] * rn[s];
+                v = fmaf(rn[s], q[s][e] - u * uq[s], v);
+                dr[e] = v;
+                if (DEPTH) dyp[e] = fmaf(bp[s], v, dyp[e]);
+            }
+            store_row<VEC, NCH>(p.dR + ((long)tok * S + s) * D, lane, dr);
+        }
+        if (DEPTH) store_row<VEC, NCH>(p.dyprev + (long)tok * D, lane, dyp);
+    }
+    if (WIDTH) {
+        if (lane == 0) {
+#pragma unroll
+            for (int i = 0; i < 26; ++i) atomicAdd(&dWp[NJ * D + i], sc[i]);
+        }
+        __syncthreads();
+        float* out = p.partial + (long)blockIdx.x * (NJ * D + NSC);
+        for (int i = tid; i < NJ * D + NSC; i += 256) out[i] = dWp[i];
+    }
+}
+
+// sum per-block partials and turn d(Wp) into parameter gradients (accumulated into the fp32 grad buffers)
+struct HCReduceArgs {
+    const float* partial; int nblocks; int D;
+    HCParams hp;
+    float *g_static_beta, *g_static_alpha, *g_dyn_alpha_fn, *g_dyn_alpha_scale, *g_dyn_beta_fn, *g_dyn_beta_scale, *g_gamma;
+};
+
+__global__ __launch_bounds__(256) void hc_reduce_kernel(HCReduceArgs p) {
+    const int D = p.D, stride = NJ * D + NSC;
+    const int i = blockIdx.x * 256 + threadIdx.x;
+    if (i < D) {
+        float acc[NJ];
+#pragma unroll
+        for (int j = 0; j < NJ; ++j) acc[j] = 0.f;
+        for (int b = 0; b < p.nblocks; ++b) {
+#pragma unroll
+            for (int j = 0; j < NJ; ++j) acc[j] += p.partial[(long)b * stride + j * D + i];
+        }
+        const float g = p.hp.gamma[i] + 1.f;
+        float dg = 0.f;
+#pragma unroll
+        for (int t = 0; t < 5; ++t) {
+            p.g_dyn_alpha_fn[i * 5 + t] += g * acc[t];
+            dg = fmaf(p.hp.dyn_alpha_fn[i * 5 + t], acc[t], dg);
+        }
+        p.g_dyn_beta_fn[i] += g * acc[5];
+        dg = fmaf(p.hp.dyn_beta_fn[i], acc[5], dg);
+        p.g_gamma[i] += dg;
+    } else if (i < D + 26) {
+        const int k = i - D;
+        float acc = 0.f;
+        for (int b = 0; b < p.nblocks; ++b) acc += p.partial[(long)b * stride + NJ * D + k];
+        if (k < 20) p.g_static_alpha[k] += acc;
+        else if (k < 24) p.g_static_beta[k - 20] += acc;
+        else if (k == 24) p.g_dyn_alpha_scale[0] += acc;
+        else p.g_dyn_beta_scale[0] += acc;
+    }
+}
+
+template <int VEC, int NCH>
+int launch_fwd(const HCFwdArgs& a, bool depth, bool width, int grid, hipStream_t st) {
+    dim3 g(grid), b(256);
+    if (depth && width) hipLaunchKernelGGL((hc_fwd_kernel<VEC, NCH, true, true>), g, b, 0, st, a);
+    else if (!depth && width) hipLaunchKernelGGL((hc_fwd_kernel<VEC, NCH, false, true>), g, b, 0, st, a);
+    else if (depth && !width) hipLaunchKernelGGL((hc_fwd_kernel<VEC, NCH, true, false>), g, b, 0, st, a);
+    else return E2K_ERR_ARG;
+    return 0;
+}
+template <int VEC, int NCH>
+int launch_bwd(const HCBwdArgs& a, bool depth, bool width, int grid, hipStream_t st) {
+    dim3 g(grid), b(256);
+    if (depth && width) hipLaunchKernelGGL((hc_bwd_kernel<VEC, NCH, true, true>), g, b, 0, st, a);
+    else if (!depth && width) hipLaunchKernelGGL((hc_bwd_kernel<VEC, NCH, false, true>), g, b, 0, st, a);
+    else if (depth && !width) hipLaunchKernelGGL((hc_bwd_kernel<VEC, NCH, true, false>), g, b, 0, st, a);
+    else return E2K_ERR_ARG;
+    return 0;
+}
+
+int grid_for(int Mtok, int max_blocks) {
+    int g = (Mtok + 3) / 4;
+    return g < max_blocks ? g : max_blocks;
+}
+
+}  // namespace
+
+extern "C" int e2k_query_hc_coef_width(void) { return CW; }
+extern "C" int e2k_query_hc_bwd_blocks(int Mtok) { return grid_for(Mtok, 512); }
+extern "C" int e2k_query_hc_partial_stride(int D) { return NJ * D + NSC; }
+
+extern "C" int e2k_hc_fwd(const void* Xin, const void* yprev, const float* coef_prev, void* Mout, void* bin,
+                          float* coef, const float* static_beta, const float* static_alpha,
+                          const float* dyn_alpha_fn, const float* dyn_alpha_scale, const float* dyn_beta_fn,
+                          const float* dyn_beta_scale, const float* gamma, int Mtok, int D, int has_depth,
+                          int has_width, void* stream) {
+    if (Mtok <= 0) return 0;
+    HCFwdArgs a;
+    a.Xin = (const bf16_t*)Xin; a.yprev = (const bf16_t*)yprev; a.coef_prev = coef_prev;
+    a.Mout = (bf16_t*)Mout; a.bin = (bf16_t*)bin; a.coef = coef;
+    a.hp = HCParams{static_beta, static_alpha, dyn_alpha_fn, dyn_alpha_scale, dyn_beta_fn, dyn_beta_scale, gamma};
+    a.Mtok = Mtok;
+    if (!Xin || !Mout || (has_depth && (!yprev || !coef_prev)) || (has_width && (!bin || !coef || !gamma))) return E2K_ERR_ARG;
+    int rc = 0;
+    E2K_ROW_DISPATCH(D, launch_fwd, a, has_depth != 0, has_width != 0, grid_for(Mtok, 2048), (hipStream_t)stream);
+    if (rc) return rc;
+    E2K_CHECK_LAUNCH();
+    return 0;
+}
+
+extern "C" int e2k_hc_bwd(const void* Xin, const void* yprev, const float* coef_prev, const void* G,
+                          const void* dbin, const void* ycur, const float* coef, void* dR, void* dyprev,
+                          const float* static_beta, const float* static_alpha, const float* dyn_alpha_fn,
+                          const float* dyn_alpha_scale, const float* dyn_beta_fn, const float* dyn_beta_scale,
+                          const float* gamma, float* g_static_beta, float* g_static_alpha, float* g_dyn_alpha_fn,
+                          float* g_dyn_alpha_scale, float* g_dyn_beta_fn, float* g_dyn_beta_scale, float* g_gamma,
+                          float* partial, int Mtok, int D, int has_depth, int has_width, void* stream) {
+    if (Mtok <= 0) return 0;
+    HCBwdArgs a;
+    a.Xin = (const bf16_t*)Xin; a.yprev = (const bf16_t*)yprev; a.coef_prev = coef_prev;
+    a.G = (const bf16_t*)G; a.dbin = (const bf16_t*)dbin; a.ycur = (const bf16_t*)ycur; a.coef = coef;
+    a.dR = (bf16_t*)dR; a.dyprev = (bf16_t*)dyprev;
+    a.hp = HCParams{static_beta, static_alpha, dyn_alpha_fn, dyn_alpha_scale, dyn_beta_fn, dyn_beta_scale, gamma};
+    a.partial = partial; a.Mtok = Mtok;
+    if (!G || (has_depth && (!yprev || !coef_prev || !dyprev))) return E2K_ERR_ARG;
+    if (has_width && (!Xin || !dbin || !ycur || !coef || !dR || !partial || !gamma || !g_gamma)) return E2K_ERR_ARG;
+    const int grid = grid_for(Mtok, 512);
+    int rc = 0;
+    E2K_ROW_DISPATCH(D, launch_bwd, a, has_depth != 0, has_width != 0, grid, (hipStream_t)stream);
+    if (rc) return rc;
+    E2K_CHECK_LAUNCH();
+    if (has_width) {
+        HCReduceArgs r;
+        r.partial = partial; r.nblocks = grid; r.D = D; r.hp = a.hp;
+        r.g_static_beta = g_static_beta; r.g_static_alpha = g_static_alpha; r.g_dyn_alpha_fn = g_dyn_alpha_fn;
+        r.g_dyn_alpha_scale = g_dyn_alpha_scale; r.g_dyn_beta_fn = g_dyn_beta_fn; r.g_dyn_beta_scale = g_dyn_beta_scale;
+        r.g_gamma = g_gamma;
+        hipLaunchKernelGGL(hc_reduce_kernel, dim3((D + 26 + 255) / 256), dim3(256), 0, (hipStream_t)stream, r);
+        E2K_CHECK_LAUNCH();
+    }
+    return 0;
+}

@@ -65,7 +65,10 @@ class _Lib:
             fn = getattr(self.cdll, name)        # AttributeError here == header/library mismatch: fail loudly
             fn.argtypes = types
             fn.restype = ctypes.c_int
-            setattr(self, name, self._wrap(name, fn))
+            if name.startswith('e2k_query_') or name == 'e2k_version':
+                setattr(self, name, fn)           # returns a value, not a status
+            else:
+                setattr(self, name, self._wrap(name, fn))
 
     @staticmethod
     def _wrap(name, fn):

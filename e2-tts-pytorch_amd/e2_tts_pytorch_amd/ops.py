@@ -81,3 +81,149 @@ def gemm_tn(a, b, out, *, splits=0, use_tr=True):
     _lib.get().e2k_gemm_tn_bf16(_p(a), lda, _p(b), ldb, _p(out), out.stride(0), M, N, K, int(splits),
                                 int(use_tr), _stream(a))
     return out
+
+
+# ------------------------------------------------------------------------------------------------ hyper-connections
+
+HC_PARAM_NAMES = ('static_beta', 'static_alpha', 'dynamic_alpha_fn', 'dynamic_alpha_scale', 'dynamic_beta_fn',
+                  'dynamic_beta_scale', 'norm.gamma')
+
+
+def hc_coef_width():
+    return _lib.get().e2k_query_hc_coef_width()
+
+
+def hc_fwd(xin, params, *, yprev=None, coef_prev=None, width=True):
+    """xin (Mtok,4,D) bf16.  Returns (Mout, bin, coef) if width else (X, None, None)."""
+    _chk(xin, yprev, coef_prev)
+    Mtok, S, D = xin.shape
+    assert S == 4 and xin.dtype == bf16 and xin.is_contiguous()
+    depth = yprev is not None
+    mout = torch.empty_like(xin)
+    binp = coef = None
+    if width:
+        binp = torch.empty((Mtok, D), dtype=bf16, device=xin.device)
+        coef = torch.empty((Mtok, hc_coef_width()), dtype=f32, device=xin.device)
+    ps = [_p(t) for t in params] if width else [None] * 7
+    _lib.get().e2k_hc_fwd(_p(xin), _p(yprev), _p(coef_prev), _p(mout), _p(binp), _p(coef), *ps, Mtok, D,
+                          int(depth), int(width), _stream(xin))
+    return mout, binp, coef
+
+
+def hc_bwd(G, *, xin=None, yprev=None, coef_prev=None, dbin=None, ycur=None, coef=None, params=None, grads=None):
+    """Backward of hc_fwd. width iff coef is given; depth iff yprev is given.
+    Returns (dR, dyprev); with width=False dR is G itself."""
+    _chk(G, xin, yprev, coef_prev, dbin, ycur, coef)
+    Mtok, S, D = G.shape
+    width, depth = coef is not None, yprev is not None
+    lib = _lib.get()
+    dR = torch.empty_like(G) if width else G
+    dyprev = torch.empty((Mtok, D), dtype=bf16, device=G.device) if depth else None
+    partial = None
+    if width:
+        partial = torch.empty((lib.e2k_query_hc_bwd_blocks(Mtok), lib.e2k_query_hc_partial_stride(D)), dtype=f32,
+                              device=G.device)
+    ps = [_p(t) for t in params] if width else [None] * 7
+    gs = [_p(t) for t in grads] if width else [None] * 7
+    lib.e2k_hc_bwd(_p(xin), _p(yprev), _p(coef_prev), _p(G), _p(dbin), _p(ycur), _p(coef),
+                   _p(dR) if width else None, _p(dyprev), *ps, *gs, _p(partial), Mtok, D, int(depth), int(width),
+                   _stream(G))
+    return dR, dyprev
+
+
+# ------------------------------------------------------------------------------------------------ norms / gates / GEGLU
+
+def rmsnorm_fwd(x, gamma, gamma_off, rows_per_batch):
+    """x (M,D) bf16; gamma fp32 (nb,D).  -> (y bf16, rn fp32 (M,))"""
+    _chk(x, gamma)
+    M, D = x.shape
+    assert x.dtype == bf16 and x.is_contiguous() and gamma.dtype == f32 and gamma.is_contiguous()
+    y = torch.empty_like(x)
+    rn = torch.empty((M,), dtype=f32, device=x.device)
+    _lib.get().e2k_rmsnorm_fwd(_p(x), _p(gamma), float(gamma_off), int(rows_per_batch), _p(y), _p(rn), M, D, _stream(x))
+    return y, rn
+
+
+def rmsnorm_bwd(dy, x, rn, gamma, gamma_off, rows_per_batch, dgamma):
+    _chk(dy, x, rn, gamma, dgamma)
+    M, D = x.shape
+    assert dy.dtype == bf16 and dy.is_contiguous() and dgamma.dtype == f32 and dgamma.is_contiguous()
+    dx = torch.empty_like(x)
+    _lib.get().e2k_rmsnorm_bwd(_p(dy), _p(x), _p(rn), _p(gamma), float(gamma_off), int(rows_per_batch), _p(dx),
+                               _p(dgamma), M, D, _stream(x))
+    return dx
+
+
+def gate_bwd(dy, y, g, gsum, rows_per_batch):
+    _chk(dy, y, g, gsum)
+    M, D = y.shape
+    assert dy.is_contiguous() and y.is_contiguous() and g.dtype == f32 and gsum.dtype == f32
+    dao = torch.empty_like(dy)
+    _lib.get().e2k_gate_bwd(_p(dy), _p(y), _p(g), _p(dao), _p(gsum), M, D, int(rows_per_batch), _stream(y))
+    return dao
+
+
+def geglu_fwd(H, p_drop=0., seed=0, stream_id=0):
+    _chk(H)
+    M, F2 = H.shape
+    assert H.dtype == bf16 and H.stride(1) == 1
+    out = torch.empty((M, F2 // 2), dtype=bf16, device=H.device)
+    _lib.get().e2k_geglu_fwd(_p(H), H.stride(0), _p(out), M, F2 // 2, float(p_drop), int(seed), int(stream_id), _stream(H))
+    return out
+
+
+def geglu_bwd(dout, H, p_drop=0., seed=0, stream_id=0):
+    _chk(dout, H)
+    M, F2 = H.shape
+    assert dout.is_contiguous() and dout.shape == (M, F2 // 2)
+    dH = torch.empty_like(H)
+    _lib.get().e2k_geglu_bwd(_p(dout), _p(H), H.stride(0), _p(dH), M, F2 // 2, float(p_drop), int(seed),
+                             int(stream_id), _stream(H))
+    return dH
+
+
+def colsum(x, out):
+    _chk(x, out)
+    M, N = x.shape
+    assert x.dtype == bf16 and x.stride(1) == 1 and out.dtype == f32 and out.numel() == N
+    _lib.get().e2k_colsum_bf16(_p(x), x.stride(0), _p(out), M, N, _stream(x))
+    return out
+
+
+def cast_bf16(src, dst):
+    _chk(src, dst)
+    assert src.dtype == f32 and dst.dtype == bf16 and src.numel() == dst.numel()
+    _lib.get().e2k_cast_bf16(_p(src), _p(dst), src.numel(), _stream(src))
+    return dst
+
+
+def cast_transpose_bf16(src, dst):
+    """src (R,C) fp32 contiguous -> dst (C,R) bf16 (row stride dst.stride(0))"""
+    _chk(src, dst)
+    R, C = src.shape
+    assert src.is_contiguous() and dst.shape == (C, R) and dst.stride(1) == 1
+    _lib.get().e2k_cast_transpose_bf16(_p(src), _p(dst), R, C, dst.stride(0), _stream(src))
+    return dst
+
+
+# ------------------------------------------------------------------------------------------------ depthwise conv
+
+def dwconv_fwd(x, mask, w, bias):
+    """x (B,N,C) bf16, mask (B,N) bool/u8 or None, w (C,1,ks)/(C,ks) fp32 -> (pre, y)"""
+    _chk(x, mask, w, bias)
+    B, N, C = x.shape
+    ks = w.shape[-1]
+    assert x.is_contiguous() and w.is_contiguous() and w.dtype == f32 and bias.dtype == f32
+    pre, y = torch.empty_like(x), torch.empty_like(x)
+    _lib.get().e2k_dwconv_fwd(_p(x), _p(mask), _p(w), _p(bias), _p(pre), _p(y), B, N, C, ks, _stream(x))
+    return pre, y
+
+
+def dwconv_bwd(dy, pre, x, mask, w, dw, dbias):
+    _chk(dy, pre, x, mask, w, dw, dbias)
+    B, N, C = x.shape
+    ks = w.shape[-1]
+    assert dy.is_contiguous() and dw.dtype == f32 and dbias.dtype == f32
+    dx = torch.empty_like(x)
+    _lib.get().e2k_dwconv_bwd(_p(dy), _p(pre), _p(x), _p(mask), _p(w), _p(dx), _p(dw), _p(dbias), B, N, C, ks, _stream(x))
+    return dx

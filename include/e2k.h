@@ -46,6 +46,70 @@ int e2k_gemm_nt_bf16(const void* A1, int64_t lda1, int K1, const void* A2, int64
 int e2k_gemm_tn_bf16(const void* A, int64_t lda, const void* B, int64_t ldb, float* C, int64_t ldc,
                      int M, int N, int K, int splits, int use_tr, void* stream);
 
+/* ---- hyper-connections (hyper_connections.HyperConnections; reference call sites e2_tts.py:870-882,900-939) ----
+ * Streams are stored token-major: X[token][4][D] bf16.  coef: per-token fp32 record (e2k_query_hc_coef_width()
+ * floats: a[4][5], b[4], pre-tanh dots[4][6], 1/|r_s|[4]).  D in {128,256,512,768,1024,1536,2048}.
+ *
+ * forward:  r = has_depth ? Xin + b_prev * yprev : Xin            (depth connection of the previous instance)
+ *           has_width ? (bin, Mout, coef) = width(r) : Mout = r   (width connection of this instance)   */
+int e2k_query_hc_coef_width(void);
+int e2k_query_hc_bwd_blocks(int Mtok);        /* rows of `partial` the backward needs */
+int e2k_query_hc_partial_stride(int D);       /* floats per row of `partial` */
+int e2k_hc_fwd(const void* Xin, const void* yprev, const float* coef_prev, void* Mout, void* bin,
+               float* coef, const float* static_beta, const float* static_alpha,
+               const float* dyn_alpha_fn, const float* dyn_alpha_scale, const float* dyn_beta_fn,
+               const float* dyn_beta_scale, const float* gamma, int Mtok, int D, int has_depth,
+               int has_width, void* stream);
+/* backward of the same fused pair.  G = grad wrt Mout (has_width) or wrt the materialised X (!has_width);
+ * dbin = grad wrt bin; ycur = this instance's branch output.  Writes dR = grad wrt r (== grad wrt Xin) and,
+ * if has_depth, dyprev = sum_s b_prev[s] * dR[s].  Parameter gradients are ACCUMULATED into g_* (fp32).
+ * partial: scratch [e2k_query_hc_bwd_blocks(Mtok)][e2k_query_hc_partial_stride(D)] fp32. */
+int e2k_hc_bwd(const void* Xin, const void* yprev, const float* coef_prev, const void* G,
+               const void* dbin, const void* ycur, const float* coef, void* dR, void* dyprev,
+               const float* static_beta, const float* static_alpha, const float* dyn_alpha_fn,
+               const float* dyn_alpha_scale, const float* dyn_beta_fn, const float* dyn_beta_scale,
+               const float* gamma, float* g_static_beta, float* g_static_alpha, float* g_dyn_alpha_fn,
+               float* g_dyn_alpha_scale, float* g_dyn_beta_fn, float* g_dyn_beta_scale, float* g_gamma,
+               float* partial, int Mtok, int D, int has_depth, int has_width, void* stream);
+
+/* ---- RMSNorm / AdaptiveRMSNorm (x_transformers; e2_tts.py:615,637,645,688,691,729,908,937) ----
+ * y[m] = x[m] / max(|x[m]|, 1e-12) * sqrt(D) * (gamma[m / rows_per_batch] + gamma_off);  rn[m] = 1 / max(|x[m]|, 1e-12)
+ * gamma fp32 (nb, D): nb = 1 (plain RMSNorm `g`, gamma_off = 0) or one row per batch element
+ * (AdaptiveRMSNorm: to_gamma(cond), gamma_off = 1). */
+int e2k_rmsnorm_fwd(const void* x, const float* gamma, float gamma_off, int rows_per_batch, void* y,
+                    float* rn, int M, int D, void* stream);
+/* dx and dgamma (ACCUMULATED, fp32 (nb, D)) */
+int e2k_rmsnorm_bwd(const void* dy, const void* x, const float* rn, const float* gamma, float gamma_off,
+                    int rows_per_batch, void* dx, float* dgamma, int M, int D, void* stream);
+
+/* AdaLN-Zero gate backward (AdaLNZero, e2_tts.py:346-351; the forward multiply is the colscale epilogue of
+ * e2k_gemm_nt_bf16):  dao = dy * g[b];  gsum[b][d] += sum_rows dy * y   (y = gated output, g = sigmoid gate) */
+int e2k_gate_bwd(const void* dy, const void* y, const float* g, void* dao, float* gsum, int M, int D,
+                 int rows_per_batch, void* stream);
+
+/* GEGLU (x_transformers.FeedForward(glu=True): `x, gate = proj(x).chunk(2); x * gelu(gate)` + Dropout, exact erf GELU).
+ * H (M, 2F) bf16 with row stride ldh; out (M, F).  p_drop = 0 disables dropout; the keep mask is the counter hash
+ * rand_u32(seed, stream_id, row, col/2) (e2k_device.h, restated in oracle/dropout_hash.py). */
+int e2k_geglu_fwd(const void* H, int64_t ldh, void* out, int M, int F, float p_drop, uint32_t seed,
+                  uint32_t stream_id, void* stream);
+int e2k_geglu_bwd(const void* dout, const void* H, int64_t ldh, void* dH, int M, int F, float p_drop,
+                  uint32_t seed, uint32_t stream_id, void* stream);
+
+/* out[n] += sum_m x[m][n]   (bias gradients; x bf16 (M,N), out fp32) */
+int e2k_colsum_bf16(const void* x, int64_t ldx, float* out, int M, int N, void* stream);
+
+/* fp32 master parameters -> bf16 compute shadows (flat, and (R,C) -> transposed (C,R) with row stride ldd) */
+int e2k_cast_bf16(const float* src, void* dst, int64_t n, void* stream);
+int e2k_cast_transpose_bf16(const float* src, void* dst, int R, int C, int64_t ldd, void* stream);
+
+/* DepthwiseConv (e2_tts.py:295-328): channels-last x (B,N,C) bf16, mask (B,N) u8 or NULL, w (C,ks) fp32, bias (C):
+ *   pre = conv1d(mask * x) + bias ;  y = mask * silu(pre).   ks in {3,7,15,31}, C multiple of 64. */
+int e2k_dwconv_fwd(const void* x, const uint8_t* mask, const float* w, const float* bias, void* pre,
+                   void* y, int B, int N, int C, int ks, void* stream);
+/* dx, and dw / dbias ACCUMULATED (fp32) */
+int e2k_dwconv_bwd(const void* dy, const void* pre, const void* x, const uint8_t* mask, const float* w,
+                   void* dx, float* dw, float* dbias, int B, int N, int C, int ks, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -1,0 +1,115 @@
+"""Host logic check of the row / element kernels against plain torch (fp32 autograd)."""
+import pytest
+import torch
+import torch.nn.functional as F
+
+bf16 = torch.bfloat16
+
+
+def rel(a, b):
+    return ((a.float() - b.float()).abs().max() / b.float().abs().max().clamp_min(1e-20)).item()
+
+
+@pytest.mark.parametrize('D,nb', [(128, 1), (256, 3), (1024, 2)])
+def test_rmsnorm(emu, D, nb):
+    from e2_tts_pytorch_amd import ops
+    torch.manual_seed(0)
+    rpb = 13
+    M = rpb * nb - (2 if nb > 1 else 0)
+    x = torch.randn(M, D).to(bf16)
+    gamma = torch.randn(nb, D) * 0.3
+    off = 1.0 if nb > 1 else 0.0
+    dy = torch.randn(M, D).to(bf16)
+    xr = x.float().requires_grad_(True)
+    gr = gamma.clone().requires_grad_(True)
+    idx = torch.arange(M) // rpb
+    yr = F.normalize(xr, dim=-1) * D ** 0.5 * (gr[idx] + off)
+    yr.backward(dy.float())
+    y, rn = ops.rmsnorm_fwd(x, gamma, off, rpb)
+    assert rel(y, yr) < 1e-2
+    dg = torch.zeros(nb, D)
+    dx = ops.rmsnorm_bwd(dy, x, rn, gamma, off, rpb, dg)
+    assert rel(dx, xr.grad) < 1e-2
+    assert rel(dg, gr.grad) < 1e-2
+
+
+def test_gate_bwd(emu):
+    from e2_tts_pytorch_amd import ops
+    torch.manual_seed(0)
+    D, rpb, nb = 256, 11, 3
+    M = rpb * nb
+    ao = torch.randn(M, D)
+    g = torch.rand(nb, D) * 0.5 + 0.1
+    idx = torch.arange(M) // rpb
+    y = (ao * g[idx]).to(bf16)
+    dy = torch.randn(M, D).to(bf16)
+    gsum = torch.zeros(nb, D)
+    dao = ops.gate_bwd(dy, y, g, gsum, rpb)
+    assert rel(dao, dy.float() * g[idx]) < 1e-2
+    ref = torch.zeros(nb, D).index_add_(0, idx, dy.float() * y.float())
+    assert rel(gsum, ref) < 1e-4
+
+
+def test_geglu(emu):
+    from e2_tts_pytorch_amd import ops
+    torch.manual_seed(0)
+    M, Fd = 19, 64
+    H = torch.randn(M, 2 * Fd).to(bf16)
+    da = torch.randn(M, Fd).to(bf16)
+    Hr = H.float().requires_grad_(True)
+    u, gt = Hr.chunk(2, dim=-1)
+    a = u * F.gelu(gt)
+    a.backward(da.float())
+    out = ops.geglu_fwd(H)
+    assert rel(out, a) < 1e-2
+    dH = ops.geglu_bwd(da, H)
+    assert rel(dH, Hr.grad) < 1e-2
+
+
+def test_colsum_cast(emu):
+    from e2_tts_pytorch_amd import ops
+    torch.manual_seed(0)
+    x = torch.randn(77, 130).to(bf16)
+    out = torch.ones(130)
+    ops.colsum(x, out)
+    assert rel(out, 1 + x.float().sum(0)) < 1e-5
+    src = torch.randn(1003)
+    dst = torch.empty(1003, dtype=bf16)
+    # 16-byte alignment of the test buffers is what torch gives us
+    ops.cast_bf16(src, dst)
+    assert torch.equal(dst, src.to(bf16))
+    w = torch.randn(70, 45)
+    wt = torch.empty(45, 70, dtype=bf16)
+    ops.cast_transpose_bf16(w, wt)
+    assert torch.equal(wt, w.t().to(bf16))
+
+
+@pytest.mark.parametrize('ks,use_mask', [(31, True), (7, False)])
+def test_dwconv(emu, ks, use_mask):
+    from e2_tts_pytorch_amd import ops
+    torch.manual_seed(0)
+    B, N, C = 2, 75, 128
+    x = torch.randn(B, N, C).to(bf16)
+    w = torch.randn(C, 1, ks) * 0.3
+    bias = torch.randn(C) * 0.1
+    mask = None
+    if use_mask:
+        lens = torch.tensor([75, 50])
+        mask = torch.arange(N)[None] < lens[:, None]
+    dy = torch.randn(B, N, C).to(bf16)
+    xr = x.float().requires_grad_(True)
+    wr = w.clone().requires_grad_(True)
+    br = bias.clone().requires_grad_(True)
+    xm = xr if mask is None else torch.where(mask[..., None], xr, torch.zeros_like(xr))
+    pre_r = F.conv1d(xm.transpose(1, 2), wr, br, padding=ks // 2, groups=C).transpose(1, 2)
+    yr = F.silu(pre_r)
+    if mask is not None:
+        yr = torch.where(mask[..., None], yr, torch.zeros_like(yr))
+    yr.backward(dy.float())
+    pre, y = ops.dwconv_fwd(x, mask, w, bias)
+    assert rel(y, yr) < 1e-2
+    dw, db = torch.zeros_like(w), torch.zeros_like(bias)
+    dx = ops.dwconv_bwd(dy, pre, x, mask, w, dw, db)
+    assert rel(dx, xr.grad) < 2e-2, rel(dx, xr.grad)
+    assert rel(dw, wr.grad) < 2e-2, rel(dw, wr.grad)
+    assert rel(db, br.grad) < 2e-2
