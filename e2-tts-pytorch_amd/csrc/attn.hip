@@ -1,0 +1,672 @@
+// Multi-head attention over mel frames (+32 register tokens): flash-style forward and backward on MFMA.
+//
+// Replaces x_transformers.Attention(..., gate_value_heads=True, softclamp_logits=True) with flash=False as the
+// reference calls it (e2_tts.py:641,689,875,911; arithmetic in SURVEY.md Appendix A.3 / oracle Attention):
+//   rotary(q,k) on interleaved pairs, v <- lerp(v_first, v, sigmoid(mix))   -> e2k_qkv_post_fwd / _bwd
+//   S = 50*tanh(q.k^T * dh^-1/2 / 50), key-padding mask, fp32 softmax, dropout on probabilities,
+//   O = P.V, O *= sigmoid(head gate)                                         -> e2k_attn_fwd
+//   backward (recompute P from the saved log-sum-exp)                         -> e2k_attn_bwd_prep / _dq / _dkv
+// The reference materialises S (B,h,N,N) in fp32 (571 MB per attention at B=8,h=16,N=1056) four times over;
+// here S only ever exists as MFMA accumulator tiles.
+//
+// dim_head is 64.  q/k/v live head-major (B,h,N,64) plus transposed copies (B,h,64,Npad) so that every MFMA
+// operand is a plain ds_read_b128 of 8 consecutive reduction elements.  One workgroup = 64 query rows (fwd, dq)
+// or 64 keys (dkv); a wave owns 16 of them and all scores of a row stay inside a 4-lane group (lanes l, l+16,
+// l+32, l+48) so the softmax needs two shuffles.  The 16x16 score tiles are computed transposed (S^T = K.Q^T) and
+// the key order inside a 64-key tile is permuted so that the accumulator registers of S^T are directly the
+// B-operand fragment of the second MFMA (O^T = V^T.P^T): no LDS round trip for P.
+#include "e2k_device.h"
+#include "../../include/e2k.h"
+
+using namespace e2k;
+
+namespace {
+
+constexpr int DH = 64;
+constexpr float LOG2E = 1.4426950408889634f;
+constexpr float CLAMP = 50.f;
+constexpr float NEG_BIG = -1e30f;
+
+// swizzled [64][64] bf16 tile: 128-B rows, 16-B slot index XOR (row & 7)
+__device__ __forceinline__ int tile_off(int row, int slot) { return row * 128 + ((slot ^ (row & 7)) << 4); }
+
+// index (within a 64-wide tile) of accumulator row i (0..15) of 16x16 tile t (0..3): makes the accumulator
+// registers of tiles (2k, 2k+1) the 8 consecutive reduction elements 32k + 8g .. 32k + 8g + 7 of lane group g.
+__device__ __forceinline__ int perm_row(int t, int i) { return 32 * (t >> 1) + 8 * (i >> 2) + 4 * (t & 1) + (i & 3); }
+
+struct TileRegs { u32x4 v[2]; };
+
+// global -> registers for a [64][64] bf16 tile whose rows are `stride` elements apart; rows >= nvalid read as 0
+__device__ __forceinline__ TileRegs tile_gload(const bf16_t* base, long stride, int nvalid, int tid) {
+    TileRegs r;
+#pragma unroll
+    for (int c = 0; c < 2; ++c) {
+        int chunk = tid + c * 256;
+        int row = chunk >> 3, slot = chunk & 7;
+        r.v[c] = (row < nvalid) ? ld<u32x4>(base + (long)row * stride + slot * 8) : u32x4{0u, 0u, 0u, 0u};
+    }
+    return r;
+}
+__device__ __forceinline__ void tile_sstore(unsigned char* lds, const TileRegs& r, int tid) {
+#pragma unroll
+    for (int c = 0; c < 2; ++c) {
+        int chunk = tid + c * 256;
+        int row = chunk >> 3, slot = chunk & 7;
+        st<u32x4>(lds + tile_off(row, slot), r.v[c]);
+    }
+}
+__device__ __forceinline__ bf16x8 tile_frag(const unsigned char* lds, int row, int slot) {
+    return ld<bf16x8>(lds + tile_off(row, slot));
+}
+
+__device__ __forceinline__ bf16x8 pack_frag(const float* lo4, const float* hi4) {
+    bf16x8 f;
+#pragma unroll
+    for (int r = 0; r < 4; ++r) { f[r] = (short)f2bf(lo4[r]); f[4 + r] = (short)f2bf(hi4[r]); }
+    return f;
+}
+
+__device__ __forceinline__ float drop_scale(unsigned seed, unsigned stream, int q, int key, unsigned thresh, float inv_keep) {
+    unsigned h = rand_u32(seed, stream, (unsigned)q, (unsigned)key >> 1);
+    unsigned r16 = (key & 1) ? (h >> 16) : (h & 0xffffu);
+    return r16 >= thresh ? inv_keep : 0.f;
+}
+
+// ------------------------------------------------------------------------------------------------ qkv post
+
+struct PostArgs {
+    const bf16_t* qkvg; long ldq;      // (B*N, ldq): [q | k | v | gate_pre(h) | mix_pre(h)]
+    const float* cosb; const float* sinb;   // (N, 32)
+    const bf16_t* vfirst;               // (B,h,N,64) or null (first layer)
+    bf16_t *Q, *K, *V, *QT, *KT, *VT;   // head-major and transposed
+    float* gate; float* mix;            // (B,h,N)
+    int B, H, N, Npad;
+    // backward
+    const bf16_t *dQ, *dK, *dV; const float* dgate_pre; float* dvfirst; bf16_t* dqkvg; int first_layer;
+};
+
+__global__ __launch_bounds__(256) void qkv_post_fwd_kernel(PostArgs p) {
+    __shared__ bf16_t tT[3][DH][64 + 8];
+    const int tid = threadIdx.x;
+    const int n0 = blockIdx.x * 64, h = blockIdx.y, b = blockIdx.z;
+    const int tok = tid >> 2, seg = tid & 3;
+    const int n = n0 + tok;
+    const int I = p.H * DH;
+    const long bh = (long)b * p.H + h;
+    float q[16], k[16], v[16];
+#pragma unroll
+    for (int e = 0; e < 16; ++e) { q[e] = 0.f; k[e] = 0.f; v[e] = 0.f; }
+    if (n < p.N) {
+        const bf16_t* row = p.qkvg + ((long)b * p.N + n) * p.ldq + h * DH + seg * 16;
+        unpack8(ld<u32x4>(row), q);             unpack8(ld<u32x4>(row + 8), q + 8);
+        unpack8(ld<u32x4>(row + I), k);         unpack8(ld<u32x4>(row + I + 8), k + 8);
+        unpack8(ld<u32x4>(row + 2 * I), v);     unpack8(ld<u32x4>(row + 2 * I + 8), v + 8);
+        const float* cs = p.cosb + (long)n * 32 + seg * 8;
+        const float* sn = p.sinb + (long)n * 32 + seg * 8;
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+            float c = cs[j], s = sn[j];
+            float q0 = q[2 * j], q1 = q[2 * j + 1], k0 = k[2 * j], k1 = k[2 * j + 1];
+            q[2 * j] = q0 * c - q1 * s;  q[2 * j + 1] = q1 * c + q0 * s;
+            k[2 * j] = k0 * c - k1 * s;  k[2 * j + 1] = k1 * c + k0 * s;
+        }
+        const bf16_t* gp = p.qkvg + ((long)b * p.N + n) * p.ldq + 3 * I;
+        if (p.vfirst) {
+            float mx = sigmoidf_(bf2f(gp[p.H + h]));
+            float vf[16];
+            const bf16_t* vr = p.vfirst + (bh * p.N + n) * DH + seg * 16;
+            unpack8(ld<u32x4>(vr), vf); unpack8(ld<u32x4>(vr + 8), vf + 8);
+#pragma unroll
+            for (int e = 0; e < 16; ++e) v[e] = vf[e] + mx * (v[e] - vf[e]);
+            if (seg == 0) p.mix[bh * p.N + n] = mx;
+        }
+        if (seg == 0) p.gate[bh * p.N + n] = sigmoidf_(bf2f(gp[h]));
+        const long o = (bh * p.N + n) * DH + seg * 16;
+        st<u32x4>(p.Q + o, pack8(q)); st<u32x4>(p.Q + o + 8, pack8(q + 8));
+        st<u32x4>(p.K + o, pack8(k)); st<u32x4>(p.K + o + 8, pack8(k + 8));
+        st<u32x4>(p.V + o, pack8(v)); st<u32x4>(p.V + o + 8, pack8(v + 8));
+    }
+#pragma unroll
+    for (int e = 0; e < 16; ++e) {
+        tT[0][seg * 16 + e][tok] = f2bf(q[e]);
+        tT[1][seg * 16 + e][tok] = f2bf(k[e]);
+        tT[2][seg * 16 + e][tok] = f2bf(v[e]);
+    }
+    __syncthreads();
+    // transposed copies: thread writes 16 consecutive tokens of one dh row
+    const int d = tid >> 2, ts = (tid & 3) * 16;
+    bf16_t* outs[3] = {p.QT, p.KT, p.VT};
+#pragma unroll
+    for (int w = 0; w < 3; ++w) {
+        bf16_t* dst = outs[w] + (bh * DH + d) * p.Npad + n0 + ts;
+        st<u32x4>(dst, ld<u32x4>(&tT[w][d][ts]));
+        st<u32x4>(dst + 8, ld<u32x4>(&tT[w][d][ts + 8]));
+    }
+}
+
+__global__ __launch_bounds__(256) void qkv_post_bwd_kernel(PostArgs p) {
+    const int tid = threadIdx.x;
+    const int n0 = blockIdx.x * 64, h = blockIdx.y, b = blockIdx.z;
+    const int tok = tid >> 2, seg = tid & 3;
+    const int n = min(n0 + tok, p.N - 1);          // clamp: out-of-range lanes redo the last token, stores predicated
+    const bool valid = n0 + tok < p.N;
+    const int I = p.H * DH;
+    const long bh = (long)b * p.H + h;
+    const long o = (bh * p.N + n) * DH + seg * 16;
+    float dq[16], dk[16], dv[16];
+    unpack8(ld<u32x4>(p.dQ + o), dq); unpack8(ld<u32x4>(p.dQ + o + 8), dq + 8);
+    unpack8(ld<u32x4>(p.dK + o), dk); unpack8(ld<u32x4>(p.dK + o + 8), dk + 8);
+    unpack8(ld<u32x4>(p.dV + o), dv); unpack8(ld<u32x4>(p.dV + o + 8), dv + 8);
+    const float* cs = p.cosb + (long)n * 32 + seg * 8;
+    const float* sn = p.sinb + (long)n * 32 + seg * 8;
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+        float c = cs[j], s = sn[j];
+        float a0 = dq[2 * j], a1 = dq[2 * j + 1], b0 = dk[2 * j], b1 = dk[2 * j + 1];
+        dq[2 * j] = a0 * c + a1 * s;  dq[2 * j + 1] = a1 * c - a0 * s;
+        dk[2 * j] = b0 * c + b1 * s;  dk[2 * j + 1] = b1 * c - b0 * s;
+    }
+    bf16_t* drow = p.dqkvg + ((long)b * p.N + n) * p.ldq;
+    if (p.vfirst) {
+        const float mx = p.mix[bh * p.N + n];
+        float v[16], vf[16];
+        const bf16_t* vrow = p.qkvg + ((long)b * p.N + n) * p.ldq + 2 * I + h * DH + seg * 16;
+        unpack8(ld<u32x4>(vrow), v); unpack8(ld<u32x4>(vrow + 8), v + 8);
+        const bf16_t* vr = p.vfirst + o;
+        unpack8(ld<u32x4>(vr), vf); unpack8(ld<u32x4>(vr + 8), vf + 8);
+        float* dvf = p.dvfirst + o;
+        float dmix = 0.f;
+#pragma unroll
+        for (int e = 0; e < 16; ++e) {
+            dmix = fmaf(dv[e], v[e] - vf[e], dmix);
+            if (valid) dvf[e] += dv[e] * (1.f - mx);
+            dv[e] *= mx;
+        }
+        dmix += __shfl_xor(dmix, 1);
+        dmix += __shfl_xor(dmix, 2);
+        dmix *= mx * (1.f - mx);
+        if (valid && seg == 0) drow[3 * I + p.H + h] = f2bf(dmix);
+    } else if (p.first_layer && p.dvfirst) {
+        const float* dvf = p.dvfirst + o;
+#pragma unroll
+        for (int e = 0; e < 16; ++e) dv[e] += dvf[e];
+    }
+    if (!valid) return;
+    if (seg == 0) drow[3 * I + h] = f2bf(p.dgate_pre[bh * p.N + n]);
+    bf16_t* dst = drow + h * DH + seg * 16;
+    st<u32x4>(dst, pack8(dq)); st<u32x4>(dst + 8, pack8(dq + 8));
+    st<u32x4>(dst + I, pack8(dk)); st<u32x4>(dst + I + 8, pack8(dk + 8));
+    st<u32x4>(dst + 2 * I, pack8(dv)); st<u32x4>(dst + 2 * I + 8, pack8(dv + 8));
+}
+
+// ------------------------------------------------------------------------------------------------ attention
+
+struct AttnArgs {
+    const bf16_t *Q, *K, *V, *QT, *KT, *VT;   // (B,h,N,64) / (B,h,64,Npad)
+    const uint8_t* kmask;                      // (B, Npad), 0 beyond N
+    const float* gate;                         // (B,h,N)
+    bf16_t* O; bf16_t* Og;                     // (B*N, h*64) token-major: un-gated / gated (+query-masked)
+    float* lse2;                               // (B,h,N)  log2-domain log-sum-exp
+    int B, H, N, Npad;
+    float scale; unsigned seed, stream_id, thresh; float inv_keep;
+    // backward
+    const bf16_t* dOg;                         // (B*N, h*64)
+    bf16_t* dO; bf16_t* dOT;                   // head-major / transposed
+    float* delta; float* dgate_pre;            // (B,h,N)
+    bf16_t *dQ, *dK, *dV;                      // (B,h,N,64)
+};
+
+// scores of one 64-key tile for this wave's 16 query rows, S^T layout: s[t][r] <-> key perm_row(t, 4g+r), q = l&15
+__device__ __forceinline__ void score_tile(const unsigned char* Kt, const bf16x8 (&qf)[2], int l15, int g, f32x4 (&s)[4]) {
+#pragma unroll
+    for (int t = 0; t < 4; ++t) {
+        s[t] = f32x4{0.f, 0.f, 0.f, 0.f};
+        const int row = perm_row(t, l15);
+#pragma unroll
+        for (int kk = 0; kk < 2; ++kk) {
+            bf16x8 kf = tile_frag(Kt, row, kk * 4 + g);
+            s[t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(kf, qf[kk], s[t], 0, 0, 0);
+        }
+    }
+}
+
+__device__ __forceinline__ float softclamp2(float raw, float scale) {
+    // 50*tanh(raw*scale/50), returned in the log2 domain
+    return CLAMP * LOG2E * tanhf_(raw * (scale / CLAMP));
+}
+
+__global__ __launch_bounds__(256) void attn_fwd_kernel(AttnArgs p) {
+    __shared__ __attribute__((aligned(16))) unsigned char Kt[64 * 128];
+    __shared__ __attribute__((aligned(16))) unsigned char Vt[64 * 128];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int l15 = lane & 15, g = lane >> 4;
+    const int q0 = blockIdx.x * 64, h = blockIdx.y, b = blockIdx.z;
+    const long bh = (long)b * p.H + h;
+    const int q = q0 + wave * 16 + l15;
+    const bool qin = q < p.N;
+    const unsigned dstream = p.stream_id * 8192u + (unsigned)bh;
+
+    bf16x8 qf[2];
+#pragma unroll
+    for (int kk = 0; kk < 2; ++kk)
+        qf[kk] = qin ? ld<bf16x8>(p.Q + (bh * p.N + q) * DH + kk * 32 + g * 8) : bf16x8{0, 0, 0, 0, 0, 0, 0, 0};
+
+    f32x4 o[4];
+#pragma unroll
+    for (int ct = 0; ct < 4; ++ct) o[ct] = f32x4{0.f, 0.f, 0.f, 0.f};
+    float m = NEG_BIG, lsum = 0.f;
+
+    const int ntiles = (p.N + 63) / 64;
+    const bf16_t* Kbase = p.K + bh * p.N * DH;
+    const bf16_t* VTbase = p.VT + bh * DH * p.Npad;
+    TileRegs rk = tile_gload(Kbase, DH, min(64, p.N), tid);
+    TileRegs rv = tile_gload(VTbase, p.Npad, 64, tid);
+    for (int kt = 0; kt < ntiles; ++kt) {
+        const int k0 = kt * 64;
+        tile_sstore(Kt, rk, tid);
+        tile_sstore(Vt, rv, tid);
+        __syncthreads();
+        if (kt + 1 < ntiles) {
+            rk = tile_gload(Kbase + (long)(k0 + 64) * DH, DH, min(64, p.N - k0 - 64), tid);
+            rv = tile_gload(VTbase + k0 + 64, p.Npad, 64, tid);
+        }
+        f32x4 s[4];
+        score_tile(Kt, qf, l15, g, s);
+        // mask bytes of keys k0 + 32*kk2 + 8g .. +8  (kk2 = t>>1, byte index = 4*(t&1)+r)
+        unsigned long long mk[2];
+#pragma unroll
+        for (int kk2 = 0; kk2 < 2; ++kk2) mk[kk2] = ld<unsigned long long>(p.kmask + (long)b * p.Npad + k0 + kk2 * 32 + g * 8);
+        float tmax = NEG_BIG;
+#pragma unroll
+        for (int t = 0; t < 4; ++t)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const bool keep = (mk[t >> 1] >> (8 * (4 * (t & 1) + r))) & 0xffull;
+                float v = keep ? softclamp2(s[t][r], p.scale) : NEG_BIG;
+                s[t][r] = v;
+                tmax = fmaxf(tmax, v);
+            }
+        tmax = fmaxf(tmax, __shfl_xor(tmax, 16));
+        tmax = fmaxf(tmax, __shfl_xor(tmax, 32));
+        const float mnew = fmaxf(m, tmax);
+        const float alpha = exp2f(m - mnew);
+        m = mnew;
+        float psum = 0.f;
+#pragma unroll
+        for (int t = 0; t < 4; ++t)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                float pv = (s[t][r] > 0.5f * NEG_BIG) ? exp2f(s[t][r] - mnew) : 0.f;
+                psum += pv;
+                if (p.thresh) pv *= drop_scale(p.seed, dstream, q, k0 + perm_row(t, 4 * g + r), p.thresh, p.inv_keep);
+                s[t][r] = pv;
+            }
+        psum += __shfl_xor(psum, 16);
+        psum += __shfl_xor(psum, 32);
+        lsum = lsum * alpha + psum;
+#pragma unroll
+        for (int ct = 0; ct < 4; ++ct) o[ct] *= alpha;
+#pragma unroll
+        for (int kk2 = 0; kk2 < 2; ++kk2) {
+            float lo[4] = {s[2 * kk2][0], s[2 * kk2][1], s[2 * kk2][2], s[2 * kk2][3]};
+            float hi[4] = {s[2 * kk2 + 1][0], s[2 * kk2 + 1][1], s[2 * kk2 + 1][2], s[2 * kk2 + 1][3]};
+            bf16x8 pf = pack_frag(lo, hi);
+#pragma unroll
+            for (int ct = 0; ct < 4; ++ct) {
+                bf16x8 vf = tile_frag(Vt, ct * 16 + l15, kk2 * 4 + g);
+                o[ct] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(vf, pf, o[ct], 0, 0, 0);
+            }
+        }
+        __syncthreads();
+    }
+    if (!qin) return;
+    const float inv = lsum > 0.f ? 1.f / lsum : 0.f;
+    const float gt = p.gate[bh * p.N + q];
+    const bool qkeep = p.kmask[(long)b * p.Npad + q] != 0;
+    if (g == 0) p.lse2[bh * p.N + q] = m + log2f(fmaxf(lsum, 1e-37f));
+    const long orow = ((long)b * p.N + q) * ((long)p.H * DH) + h * DH;
+#pragma unroll
+    for (int ct = 0; ct < 4; ++ct) {
+        float v[4], vg[4];
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            v[r] = qkeep ? o[ct][r] * inv : 0.f;
+            vg[r] = v[r] * gt;
+        }
+        st<u32x2>(p.O + orow + ct * 16 + 4 * g, pack4(v));
+        st<u32x2>(p.Og + orow + ct * 16 + 4 * g, pack4(vg));
+    }
+}
+
+// dO = dOg * gate (0 on masked query rows); delta = sum_dh dO*O; dgate_pre = sum_dh dOg*O * gate*(1-gate)
+__global__ __launch_bounds__(256) void attn_bwd_prep_kernel(AttnArgs p) {
+    __shared__ bf16_t tT[DH][64 + 8];
+    const int tid = threadIdx.x;
+    const int n0 = blockIdx.x * 64, h = blockIdx.y, b = blockIdx.z;
+    const int tok = tid >> 2, seg = tid & 3;
+    const int n = n0 + tok;
+    const long bh = (long)b * p.H + h;
+    float d[16], og[16], ov[16];
+#pragma unroll
+    for (int e = 0; e < 16; ++e) { d[e] = 0.f; og[e] = 0.f; ov[e] = 0.f; }
+    const bool valid = n < p.N;
+    float gt = 0.f;
+    bool qkeep = false;
+    if (valid) {
+        const long row = ((long)b * p.N + n) * ((long)p.H * DH) + h * DH + seg * 16;
+        unpack8(ld<u32x4>(p.dOg + row), og); unpack8(ld<u32x4>(p.dOg + row + 8), og + 8);
+        unpack8(ld<u32x4>(p.O + row), ov);   unpack8(ld<u32x4>(p.O + row + 8), ov + 8);
+        gt = p.gate[bh * p.N + n];
+        qkeep = p.kmask[(long)b * p.Npad + n] != 0;
+    }
+    float dot = 0.f;
+#pragma unroll
+    for (int e = 0; e < 16; ++e) dot = fmaf(og[e], ov[e], dot);
+    dot += __shfl_xor(dot, 1);
+    dot += __shfl_xor(dot, 2);
+    if (!qkeep) dot = 0.f;
+    if (valid) {
+#pragma unroll
+        for (int e = 0; e < 16; ++e) d[e] = qkeep ? og[e] * gt : 0.f;
+        if (seg == 0) {
+            p.delta[bh * p.N + n] = dot * gt;
+            p.dgate_pre[bh * p.N + n] = dot * gt * (1.f - gt);
+        }
+        const long o = (bh * p.N + n) * DH + seg * 16;
+        st<u32x4>(p.dO + o, pack8(d)); st<u32x4>(p.dO + o + 8, pack8(d + 8));
+    }
+#pragma unroll
+    for (int e = 0; e < 16; ++e) tT[seg * 16 + e][tok] = f2bf(d[e]);
+    __syncthreads();
+    const int dd = tid >> 2, ts = (tid & 3) * 16;
+    bf16_t* dst = p.dOT + (bh * DH + dd) * p.Npad + n0 + ts;
+    st<u32x4>(dst, ld<u32x4>(&tT[dd][ts]));
+    st<u32x4>(dst + 8, ld<u32x4>(&tT[dd][ts + 8]));
+}
+
+// dQ: same sweep as the forward; dS^T tiles feed dQ^T = K^T . dS^T
+__global__ __launch_bounds__(256) void attn_bwd_dq_kernel(AttnArgs p) {
+    __shared__ __attribute__((aligned(16))) unsigned char Kt[64 * 128];
+    __shared__ __attribute__((aligned(16))) unsigned char Vr[64 * 128];
+    __shared__ __attribute__((aligned(16))) unsigned char KTt[64 * 128];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int l15 = lane & 15, g = lane >> 4;
+    const int q0 = blockIdx.x * 64, h = blockIdx.y, b = blockIdx.z;
+    const long bh = (long)b * p.H + h;
+    const int q = q0 + wave * 16 + l15;
+    const bool qin = q < p.N;
+    const unsigned dstream = p.stream_id * 8192u + (unsigned)bh;
+
+    bf16x8 qf[2], dof[2];
+#pragma unroll
+    for (int kk = 0; kk < 2; ++kk) {
+        qf[kk] = qin ? ld<bf16x8>(p.Q + (bh * p.N + q) * DH + kk * 32 + g * 8) : bf16x8{0, 0, 0, 0, 0, 0, 0, 0};
+        dof[kk] = qin ? ld<bf16x8>(p.dO + (bh * p.N + q) * DH + kk * 32 + g * 8) : bf16x8{0, 0, 0, 0, 0, 0, 0, 0};
+    }
+    const float lse = qin ? p.lse2[bh * p.N + q] : 1e30f;
+    const float dl = qin ? p.delta[bh * p.N + q] : 0.f;
+
+    f32x4 dq[4];
+#pragma unroll
+    for (int ct = 0; ct < 4; ++ct) dq[ct] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+    const int ntiles = (p.N + 63) / 64;
+    const bf16_t* Kbase = p.K + bh * p.N * DH;
+    const bf16_t* Vbase = p.V + bh * p.N * DH;
+    const bf16_t* KTbase = p.KT + bh * DH * p.Npad;
+    TileRegs rk = tile_gload(Kbase, DH, min(64, p.N), tid);
+    TileRegs rv = tile_gload(Vbase, DH, min(64, p.N), tid);
+    TileRegs rt = tile_gload(KTbase, p.Npad, 64, tid);
+    for (int kt = 0; kt < ntiles; ++kt) {
+        const int k0 = kt * 64;
+        tile_sstore(Kt, rk, tid);
+        tile_sstore(Vr, rv, tid);
+        tile_sstore(KTt, rt, tid);
+        __syncthreads();
+        if (kt + 1 < ntiles) {
+            const int nv = min(64, p.N - k0 - 64);
+            rk = tile_gload(Kbase + (long)(k0 + 64) * DH, DH, nv, tid);
+            rv = tile_gload(Vbase + (long)(k0 + 64) * DH, DH, nv, tid);
+            rt = tile_gload(KTbase + k0 + 64, p.Npad, 64, tid);
+        }
+        f32x4 s[4], dp[4];
+        score_tile(Kt, qf, l15, g, s);
+        score_tile(Vr, dof, l15, g, dp);          // dP^T = V . dO^T  (same operand shapes)
+        unsigned long long mk[2];
+#pragma unroll
+        for (int kk2 = 0; kk2 < 2; ++kk2) mk[kk2] = ld<unsigned long long>(p.kmask + (long)b * p.Npad + k0 + kk2 * 32 + g * 8);
+#pragma unroll
+        for (int t = 0; t < 4; ++t)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const bool keep = (mk[t >> 1] >> (8 * (4 * (t & 1) + r))) & 0xffull;
+                float ds = 0.f;
+                if (keep) {
+                    const float th = tanhf_(s[t][r] * (p.scale / CLAMP));
+                    const float pv = exp2f(CLAMP * LOG2E * th - lse);
+                    float dpv = dp[t][r];
+                    if (p.thresh) dpv *= drop_scale(p.seed, dstream, q, k0 + perm_row(t, 4 * g + r), p.thresh, p.inv_keep);
+                    ds = pv * (dpv - dl) * (1.f - th * th) * p.scale;
+                }
+                s[t][r] = ds;
+            }
+#pragma unroll
+        for (int kk2 = 0; kk2 < 2; ++kk2) {
+            float lo[4] = {s[2 * kk2][0], s[2 * kk2][1], s[2 * kk2][2], s[2 * kk2][3]};
+            float hi[4] = {s[2 * kk2 + 1][0], s[2 * kk2 + 1][1], s[2 * kk2 + 1][2], s[2 * kk2 + 1][3]};
+            bf16x8 pf = pack_frag(lo, hi);
+#pragma unroll
+            for (int ct = 0; ct < 4; ++ct) {
+                bf16x8 kf = tile_frag(KTt, ct * 16 + l15, kk2 * 4 + g);
+                dq[ct] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(kf, pf, dq[ct], 0, 0, 0);
+            }
+        }
+        __syncthreads();
+    }
+    if (!qin) return;
+    const long orow = (bh * p.N + q) * DH;
+#pragma unroll
+    for (int ct = 0; ct < 4; ++ct) {
+        float v[4] = {dq[ct][0], dq[ct][1], dq[ct][2], dq[ct][3]};
+        st<u32x2>(p.dQ + orow + ct * 16 + 4 * g, pack4(v));
+    }
+}
+
+// dK, dV: one workgroup per 64 keys (a wave owns 16), sweep over query tiles.
+//   S = Q.K^T (rows = queries, permuted inside the tile), P^T-like accumulators feed dV^T = dO^T.P and dK^T = Q^T.dS
+__global__ __launch_bounds__(256) void attn_bwd_dkv_kernel(AttnArgs p) {
+    __shared__ __attribute__((aligned(16))) unsigned char Qt[64 * 128];
+    __shared__ __attribute__((aligned(16))) unsigned char dOt[64 * 128];
+    __shared__ __attribute__((aligned(16))) unsigned char QTt[64 * 128];
+    __shared__ __attribute__((aligned(16))) unsigned char dOTt[64 * 128];
+    __shared__ float lse_s[64], del_s[64];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int l15 = lane & 15, g = lane >> 4;
+    const int k0 = blockIdx.x * 64, h = blockIdx.y, b = blockIdx.z;
+    const long bh = (long)b * p.H + h;
+    const int key = k0 + wave * 16 + l15;
+    const bool kin = key < p.N;
+    const bool kkeep = kin && p.kmask[(long)b * p.Npad + key] != 0;
+    const unsigned dstream = p.stream_id * 8192u + (unsigned)bh;
+
+    bf16x8 kf[2], vf[2];
+#pragma unroll
+    for (int kk = 0; kk < 2; ++kk) {
+        kf[kk] = kin ? ld<bf16x8>(p.K + (bh * p.N + key) * DH + kk * 32 + g * 8) : bf16x8{0, 0, 0, 0, 0, 0, 0, 0};
+        vf[kk] = kin ? ld<bf16x8>(p.V + (bh * p.N + key) * DH + kk * 32 + g * 8) : bf16x8{0, 0, 0, 0, 0, 0, 0, 0};
+    }
+    f32x4 dk[4], dv[4];
+#pragma unroll
+    for (int ct = 0; ct < 4; ++ct) { dk[ct] = f32x4{0.f, 0.f, 0.f, 0.f}; dv[ct] = f32x4{0.f, 0.f, 0.f, 0.f}; }
+
+    const int ntiles = (p.N + 63) / 64;
+    const bf16_t* Qbase = p.Q + bh * p.N * DH;
+    const bf16_t* dObase = p.dO + bh * p.N * DH;
+    const bf16_t* QTbase = p.QT + bh * DH * p.Npad;
+    const bf16_t* dOTbase = p.dOT + bh * DH * p.Npad;
+    TileRegs r0 = tile_gload(Qbase, DH, min(64, p.N), tid);
+    TileRegs r1 = tile_gload(dObase, DH, min(64, p.N), tid);
+    TileRegs r2 = tile_gload(QTbase, p.Npad, 64, tid);
+    TileRegs r3 = tile_gload(dOTbase, p.Npad, 64, tid);
+    for (int qt = 0; qt < ntiles; ++qt) {
+        const int q0 = qt * 64;
+        tile_sstore(Qt, r0, tid);
+        tile_sstore(dOt, r1, tid);
+        tile_sstore(QTt, r2, tid);
+        tile_sstore(dOTt, r3, tid);
+        if (tid < 64) {
+            const int qq = q0 + tid;
+            lse_s[tid] = qq < p.N ? p.lse2[bh * p.N + qq] : 1e30f;
+            del_s[tid] = qq < p.N ? p.delta[bh * p.N + qq] : 0.f;
+        }
+        __syncthreads();
+        if (qt + 1 < ntiles) {
+            const int nv = min(64, p.N - q0 - 64);
+            r0 = tile_gload(Qbase + (long)(q0 + 64) * DH, DH, nv, tid);
+            r1 = tile_gload(dObase + (long)(q0 + 64) * DH, DH, nv, tid);
+            r2 = tile_gload(QTbase + q0 + 64, p.Npad, 64, tid);
+            r3 = tile_gload(dOTbase + q0 + 64, p.Npad, 64, tid);
+        }
+        // s[t][r] <-> query perm_row(t, 4g+r), key = l&15
+        f32x4 s[4], dp[4];
+#pragma unroll
+        for (int t = 0; t < 4; ++t) {
+            s[t] = f32x4{0.f, 0.f, 0.f, 0.f};
+            dp[t] = f32x4{0.f, 0.f, 0.f, 0.f};
+            const int row = perm_row(t, l15);
+#pragma unroll
+            for (int kk = 0; kk < 2; ++kk) {
+                bf16x8 qfr = tile_frag(Qt, row, kk * 4 + g);
+                bf16x8 dofr = tile_frag(dOt, row, kk * 4 + g);
+                s[t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(qfr, kf[kk], s[t], 0, 0, 0);
+                dp[t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(dofr, vf[kk], dp[t], 0, 0, 0);
+            }
+        }
+        float pd[4][4], dsv[4][4];
+#pragma unroll
+        for (int t = 0; t < 4; ++t)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const int qi = perm_row(t, 4 * g + r);
+                float pv = 0.f, ds = 0.f;
+                if (kkeep) {
+                    const float th = tanhf_(s[t][r] * (p.scale / CLAMP));
+                    const float pr = exp2f(CLAMP * LOG2E * th - lse_s[qi]);
+                    float ks = 1.f;
+                    if (p.thresh) ks = drop_scale(p.seed, dstream, q0 + qi, key, p.thresh, p.inv_keep);
+                    pv = pr * ks;
+                    ds = pr * (dp[t][r] * ks - del_s[qi]) * (1.f - th * th) * p.scale;
+                }
+                pd[t][r] = pv;
+                dsv[t][r] = ds;
+            }
+#pragma unroll
+        for (int kk2 = 0; kk2 < 2; ++kk2) {
+            bf16x8 pf = pack_frag(pd[2 * kk2], pd[2 * kk2 + 1]);
+            bf16x8 df = pack_frag(dsv[2 * kk2], dsv[2 * kk2 + 1]);
+#pragma unroll
+            for (int ct = 0; ct < 4; ++ct) {
+                bf16x8 dotf = tile_frag(dOTt, ct * 16 + l15, kk2 * 4 + g);
+                bf16x8 qtf = tile_frag(QTt, ct * 16 + l15, kk2 * 4 + g);
+                dv[ct] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(dotf, pf, dv[ct], 0, 0, 0);
+                dk[ct] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(qtf, df, dk[ct], 0, 0, 0);
+            }
+        }
+        __syncthreads();
+    }
+    if (!kin) return;
+    const long orow = (bh * p.N + key) * DH;
+#pragma unroll
+    for (int ct = 0; ct < 4; ++ct) {
+        float a[4] = {dk[ct][0], dk[ct][1], dk[ct][2], dk[ct][3]};
+        float c[4] = {dv[ct][0], dv[ct][1], dv[ct][2], dv[ct][3]};
+        st<u32x2>(p.dK + orow + ct * 16 + 4 * g, pack4(a));
+        st<u32x2>(p.dV + orow + ct * 16 + 4 * g, pack4(c));
+    }
+}
+
+}  // namespace
+
+extern "C" int e2k_qkv_post_fwd(const void* qkvg, int64_t ldq, const float* cosb, const float* sinb, const void* vfirst,
+                                void* Q, void* K, void* V, void* QT, void* KT, void* VT, float* gate, float* mix,
+                                int B, int H, int N, int Npad, void* stream) {
+    if (B <= 0 || N <= 0) return 0;
+    if ((ldq & 7) || (Npad & 63) || Npad < N) return E2K_ERR_ALIGN;
+    if (!qkvg || !cosb || !sinb || !Q || !K || !V || !QT || !KT || !VT || !gate || (vfirst && !mix)) return E2K_ERR_ARG;
+    PostArgs a{};
+    a.qkvg = (const bf16_t*)qkvg; a.ldq = ldq; a.cosb = cosb; a.sinb = sinb; a.vfirst = (const bf16_t*)vfirst;
+    a.Q = (bf16_t*)Q; a.K = (bf16_t*)K; a.V = (bf16_t*)V; a.QT = (bf16_t*)QT; a.KT = (bf16_t*)KT; a.VT = (bf16_t*)VT;
+    a.gate = gate; a.mix = mix; a.B = B; a.H = H; a.N = N; a.Npad = Npad;
+    hipLaunchKernelGGL(qkv_post_fwd_kernel, dim3(Npad / 64, H, B), dim3(256), 0, (hipStream_t)stream, a);
+    E2K_CHECK_LAUNCH();
+    return 0;
+}
+
+extern "C" int e2k_qkv_post_bwd(const void* dQ, const void* dK, const void* dV, const float* dgate_pre,
+                                const void* qkvg, int64_t ldq, const float* cosb, const float* sinb,
+                                const void* vfirst, const float* mix, float* dvfirst, int first_layer, void* dqkvg,
+                                int B, int H, int N, void* stream) {
+    if (B <= 0 || N <= 0) return 0;
+    if (ldq & 7) return E2K_ERR_ALIGN;
+    if (!dQ || !dK || !dV || !dgate_pre || !cosb || !sinb || !dqkvg || (vfirst && (!mix || !dvfirst || !qkvg))) return E2K_ERR_ARG;
+    PostArgs a{};
+    a.dQ = (const bf16_t*)dQ; a.dK = (const bf16_t*)dK; a.dV = (const bf16_t*)dV; a.dgate_pre = dgate_pre;
+    a.qkvg = (const bf16_t*)qkvg; a.ldq = ldq; a.cosb = cosb; a.sinb = sinb; a.vfirst = (const bf16_t*)vfirst;
+    a.mix = const_cast<float*>(mix); a.dvfirst = dvfirst; a.first_layer = first_layer; a.dqkvg = (bf16_t*)dqkvg;
+    a.B = B; a.H = H; a.N = N;
+    hipLaunchKernelGGL(qkv_post_bwd_kernel, dim3((N + 63) / 64, H, B), dim3(256), 0, (hipStream_t)stream, a);
+    E2K_CHECK_LAUNCH();
+    return 0;
+}
+
+static int fill_attn(AttnArgs& a, int B, int H, int N, int Npad, float p_drop, uint32_t seed, uint32_t stream_id) {
+    if ((Npad & 63) || Npad < N) return E2K_ERR_ALIGN;
+    if (B * H >= 8192) return E2K_ERR_SHAPE;
+    a.B = B; a.H = H; a.N = N; a.Npad = Npad;
+    a.scale = 0.125f;   // dim_head ** -0.5, dim_head = 64
+    a.seed = seed; a.stream_id = stream_id;
+    a.thresh = (unsigned)(p_drop * 65536.f + 0.5f);
+    a.inv_keep = 1.f / (1.f - p_drop);
+    return 0;
+}
+
+extern "C" int e2k_attn_fwd(const void* Q, const void* K, const void* VT, const uint8_t* kmask, const float* gate,
+                            void* O, void* Og, float* lse2, int B, int H, int N, int Npad, float p_drop,
+                            uint32_t seed, uint32_t stream_id, void* stream) {
+    if (B <= 0 || N <= 0) return 0;
+    if (!Q || !K || !VT || !kmask || !gate || !O || !Og || !lse2) return E2K_ERR_ARG;
+    AttnArgs a{};
+    int rc = fill_attn(a, B, H, N, Npad, p_drop, seed, stream_id);
+    if (rc) return rc;
+    a.Q = (const bf16_t*)Q; a.K = (const bf16_t*)K; a.VT = (const bf16_t*)VT; a.kmask = kmask; a.gate = gate;
+    a.O = (bf16_t*)O; a.Og = (bf16_t*)Og; a.lse2 = lse2;
+    hipLaunchKernelGGL(attn_fwd_kernel, dim3((N + 63) / 64, H, B), dim3(256), 0, (hipStream_t)stream, a);
+    E2K_CHECK_LAUNCH();
+    return 0;
+}
+
+extern "C" int e2k_attn_bwd(const void* dOg, const void* O, const float* gate, const float* lse2, const void* Q,
+                            const void* K, const void* V, const void* QT, const void* KT, const uint8_t* kmask,
+                            void* dO, void* dOT, float* delta, float* dgate_pre, void* dQ, void* dK, void* dV,
+                            int B, int H, int N, int Npad, float p_drop, uint32_t seed, uint32_t stream_id,
+                            void* stream) {
+    if (B <= 0 || N <= 0) return 0;
+    if (!dOg || !O || !gate || !lse2 || !Q || !K || !V || !QT || !KT || !kmask || !dO || !dOT || !delta || !dgate_pre ||
+        !dQ || !dK || !dV) return E2K_ERR_ARG;
+    AttnArgs a{};
+    int rc = fill_attn(a, B, H, N, Npad, p_drop, seed, stream_id);
+    if (rc) return rc;
+    a.dOg = (const bf16_t*)dOg; a.O = (bf16_t*)O; a.gate = gate; a.lse2 = const_cast<float*>(lse2);
+    a.Q = (const bf16_t*)Q; a.K = (const bf16_t*)K; a.V = (const bf16_t*)V; a.QT = (const bf16_t*)QT;
+    a.KT = (const bf16_t*)KT; a.kmask = kmask;
+    a.dO = (bf16_t*)dO; a.dOT = (bf16_t*)dOT; a.delta = delta; a.dgate_pre = dgate_pre;
+    a.dQ = (bf16_t*)dQ; a.dK = (bf16_t*)dK; a.dV = (bf16_t*)dV;
+    hipStream_t st = (hipStream_t)stream;
+    hipLaunchKernelGGL(attn_bwd_prep_kernel, dim3(Npad / 64, H, B), dim3(256), 0, st, a);
+    E2K_CHECK_LAUNCH();
+    hipLaunchKernelGGL(attn_bwd_dq_kernel, dim3((N + 63) / 64, H, B), dim3(256), 0, st, a);
+    E2K_CHECK_LAUNCH();
+    hipLaunchKernelGGL(attn_bwd_dkv_kernel, dim3((N + 63) / 64, H, B), dim3(256), 0, st, a);
+    E2K_CHECK_LAUNCH();
+    return 0;
+}

@@ -227,3 +227,78 @@ def dwconv_bwd(dy, pre, x, mask, w, dw, dbias):
     dx = torch.empty_like(x)
     _lib.get().e2k_dwconv_bwd(_p(dy), _p(pre), _p(x), _p(mask), _p(w), _p(dx), _p(dw), _p(dbias), B, N, C, ks, _stream(x))
     return dx
+
+
+# ------------------------------------------------------------------------------------------------ attention
+
+def rotary_table(n, device, dim_head=64, base=10000.):
+    """cos/sin (n, dim_head/2) fp32; x_transformers.RotaryEmbedding.forward_from_seq_len."""
+    inv_freq = 1. / (base ** (torch.arange(0, dim_head, 2, dtype=f32, device=device) / dim_head))
+    ang = torch.arange(n, dtype=f32, device=device)[:, None] * inv_freq[None, :]
+    return ang.cos().contiguous(), ang.sin().contiguous()
+
+
+class AttnState:
+    """buffers produced by qkv_post_fwd / attn_fwd and consumed by the backward"""
+    __slots__ = ('Q', 'K', 'V', 'QT', 'KT', 'VT', 'gate', 'mix', 'O', 'Og', 'lse2', 'B', 'H', 'N', 'Npad')
+
+
+def qkv_post_fwd(qkvg, B, H, N, cosb, sinb, vfirst=None):
+    _chk(qkvg, cosb, sinb, vfirst)
+    assert qkvg.dtype == bf16 and qkvg.stride(1) == 1 and qkvg.shape[0] == B * N
+    dev = qkvg.device
+    Npad = (N + 63) // 64 * 64
+    st = AttnState()
+    st.B, st.H, st.N, st.Npad = B, H, N, Npad
+    st.Q, st.K, st.V = (torch.empty((B, H, N, 64), dtype=bf16, device=dev) for _ in range(3))
+    st.QT, st.KT, st.VT = (torch.empty((B, H, 64, Npad), dtype=bf16, device=dev) for _ in range(3))
+    st.gate = torch.empty((B, H, N), dtype=f32, device=dev)
+    st.mix = torch.empty((B, H, N), dtype=f32, device=dev) if vfirst is not None else None
+    _lib.get().e2k_qkv_post_fwd(_p(qkvg), qkvg.stride(0), _p(cosb), _p(sinb), _p(vfirst), _p(st.Q), _p(st.K), _p(st.V),
+                                _p(st.QT), _p(st.KT), _p(st.VT), _p(st.gate), _p(st.mix), B, H, N, Npad, _stream(qkvg))
+    return st
+
+
+def attn_fwd(st, kmask_pad, p_drop=0., seed=0, stream_id=0):
+    """kmask_pad (B, Npad) uint8.  Fills st.O / st.Og / st.lse2, returns Og (B*N, H*64)."""
+    _chk(kmask_pad)
+    B, H, N, Npad = st.B, st.H, st.N, st.Npad
+    assert kmask_pad.shape == (B, Npad) and kmask_pad.dtype == torch.uint8 and kmask_pad.is_contiguous()
+    dev = st.Q.device
+    st.O = torch.empty((B * N, H * 64), dtype=bf16, device=dev)
+    st.Og = torch.empty((B * N, H * 64), dtype=bf16, device=dev)
+    st.lse2 = torch.empty((B, H, N), dtype=f32, device=dev)
+    _lib.get().e2k_attn_fwd(_p(st.Q), _p(st.K), _p(st.VT), _p(kmask_pad), _p(st.gate), _p(st.O), _p(st.Og), _p(st.lse2),
+                            B, H, N, Npad, float(p_drop), int(seed), int(stream_id), _stream(st.Q))
+    return st.Og
+
+
+def attn_bwd(st, dOg, kmask_pad, p_drop=0., seed=0, stream_id=0):
+    """-> dQ, dK, dV (B,H,N,64) bf16, dgate_pre (B,H,N) fp32"""
+    _chk(dOg, kmask_pad)
+    B, H, N, Npad = st.B, st.H, st.N, st.Npad
+    dev = st.Q.device
+    assert dOg.dtype == bf16 and dOg.is_contiguous() and dOg.shape == (B * N, H * 64)
+    dO = torch.empty((B, H, N, 64), dtype=bf16, device=dev)
+    dOT = torch.empty((B, H, 64, Npad), dtype=bf16, device=dev)
+    delta = torch.empty((B, H, N), dtype=f32, device=dev)
+    dgate = torch.empty((B, H, N), dtype=f32, device=dev)
+    dQ, dK, dV = (torch.empty((B, H, N, 64), dtype=bf16, device=dev) for _ in range(3))
+    _lib.get().e2k_attn_bwd(_p(dOg), _p(st.O), _p(st.gate), _p(st.lse2), _p(st.Q), _p(st.K), _p(st.V), _p(st.QT),
+                            _p(st.KT), _p(kmask_pad), _p(dO), _p(dOT), _p(delta), _p(dgate), _p(dQ), _p(dK), _p(dV),
+                            B, H, N, Npad, float(p_drop), int(seed), int(stream_id), _stream(dOg))
+    return dQ, dK, dV, dgate
+
+
+def qkv_post_bwd(st, dQ, dK, dV, dgate_pre, qkvg, cosb, sinb, vfirst=None, dvfirst=None, first_layer=False):
+    _chk(dQ, dK, dV, dgate_pre, qkvg, vfirst, dvfirst)
+    B, H, N = st.B, st.H, st.N
+    M, cols = qkvg.shape
+    ld = qkvg.stride(0)
+    if ld == cols:
+        dqkvg = torch.empty((M, cols), dtype=bf16, device=qkvg.device)
+    else:                                        # padded row stride: keep the pad columns zero
+        dqkvg = torch.zeros((M, ld), dtype=bf16, device=qkvg.device)[:, :cols]
+    _lib.get().e2k_qkv_post_bwd(_p(dQ), _p(dK), _p(dV), _p(dgate_pre), _p(qkvg), qkvg.stride(0), _p(cosb), _p(sinb),
+                                _p(vfirst), _p(st.mix), _p(dvfirst), int(first_layer), _p(dqkvg), B, H, N, _stream(dQ))
+    return dqkvg

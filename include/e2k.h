@@ -110,6 +110,34 @@ int e2k_dwconv_fwd(const void* x, const uint8_t* mask, const float* w, const flo
 int e2k_dwconv_bwd(const void* dy, const void* pre, const void* x, const uint8_t* mask, const float* w,
                    void* dx, float* dw, float* dbias, int B, int N, int C, int ks, void* stream);
 
+/* ---- attention (x_transformers.Attention, call sites e2_tts.py:875,911; dim_head = 64) ----
+ * qkvg (B*N, ldq) bf16 = fused projection output, columns [q (H*64) | k | v | head-gate logits (H) | value-residual
+ * mix logits (H)].  cosb/sinb: rotary table (N, 32) fp32 (theta_j = 10000^(-2j/64), interleaved pairs).
+ * vfirst: first layer's un-mixed values (B,H,N,64), NULL on the first layer (then V = v is what later layers use).
+ * Outputs head-major Q,K,V (B,H,N,64), transposed QT,KT,VT (B,H,64,Npad; Npad = N rounded up to 64, zero padded),
+ * gate = sigmoid(gate logits), mix = sigmoid(mix logits) (B,H,N) fp32. */
+int e2k_qkv_post_fwd(const void* qkvg, int64_t ldq, const float* cosb, const float* sinb, const void* vfirst,
+                     void* Q, void* K, void* V, void* QT, void* KT, void* VT, float* gate, float* mix,
+                     int B, int H, int N, int Npad, void* stream);
+/* dqkvg (B*N, ldq) from dQ,dK,dV (B,H,N,64): inverse rotary, value-residual mix backward (dvfirst (B,H,N,64) fp32
+ * is ACCUMULATED on later layers and consumed when first_layer = 1), gate / mix logit gradients. */
+int e2k_qkv_post_bwd(const void* dQ, const void* dK, const void* dV, const float* dgate_pre,
+                     const void* qkvg, int64_t ldq, const float* cosb, const float* sinb,
+                     const void* vfirst, const float* mix, float* dvfirst, int first_layer, void* dqkvg,
+                     int B, int H, int N, void* stream);
+/* O = softmax(mask(50*tanh(Q.K^T/8/50))) . V  (dropout on the probabilities if p_drop > 0), per (b,h).
+ * kmask (B, Npad) u8: 1 = attend; also used as the query-row mask of the output (reference: where(mask, out, 0)).
+ * O / Og: token-major (B*N, H*64) un-gated / gated by `gate`;  lse2 (B,H,N): log2-domain log-sum-exp. */
+int e2k_attn_fwd(const void* Q, const void* K, const void* VT, const uint8_t* kmask, const float* gate,
+                 void* O, void* Og, float* lse2, int B, int H, int N, int Npad, float p_drop,
+                 uint32_t seed, uint32_t stream_id, void* stream);
+/* backward: dOg (B*N, H*64) -> dQ, dK, dV (B,H,N,64), dgate_pre (B,H,N).  dO, dOT, delta are scratch outputs. */
+int e2k_attn_bwd(const void* dOg, const void* O, const float* gate, const float* lse2, const void* Q,
+                 const void* K, const void* V, const void* QT, const void* KT, const uint8_t* kmask,
+                 void* dO, void* dOT, float* delta, float* dgate_pre, void* dQ, void* dK, void* dV,
+                 int B, int H, int N, int Npad, float p_drop, uint32_t seed, uint32_t stream_id,
+                 void* stream);
+
 #ifdef __cplusplus
 }
 #endif

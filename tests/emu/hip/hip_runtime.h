@@ -80,6 +80,7 @@ struct Block {
     ucontext_t sched;
     int bar_arrived = 0;
     unsigned bar_gen = 0;
+    long progress = 0;      // bumped whenever a rendezvous completes or a fiber finishes (deadlock detection)
     const std::function<void()>* body = nullptr;
 };
 
@@ -96,6 +97,7 @@ inline void block_rendezvous() {
     if (++b->bar_arrived == b->nthreads) {
         b->bar_arrived = 0;
         b->bar_gen++;
+        b->progress++;
     } else {
         while (b->bar_gen == gen) yield();
     }
@@ -107,6 +109,7 @@ inline void wave_rendezvous(Wave& w) {
     if (++w.arrived == w.nlanes) {
         w.arrived = 0;
         w.gen++;
+        g_blk->progress++;
     } else {
         while (w.gen == gen) yield();
     }
@@ -142,16 +145,23 @@ inline void run_block(Block& blk, const std::function<void()>& body) {
         blk.waves[w].nlanes = std::min(kWave, n - w * kWave);
     }
     int remaining = n;
-    long spins = 0;
+    int idle_rounds = 0;
     while (remaining > 0) {
+        const long before = blk.progress;
         for (int i = 0; i < n; ++i) {
             Fiber& f = blk.fibers[i];
             if (f.done) continue;
             blk.cur = i;
             swapcontext(&blk.sched, &f.ctx);
-            if (f.done) --remaining;
+            if (f.done) { --remaining; blk.progress++; }
         }
-        if (++spins > 200000000L) { fprintf(stderr, "emu: deadlock?\n"); abort(); }
+        idle_rounds = (blk.progress == before) ? idle_rounds + 1 : 0;
+        if (idle_rounds > 2) {
+            fprintf(stderr, "emu: DEADLOCK in block (%u,%u,%u): %d threads stuck at a barrier / wave exchange that the "
+                            "others never reach (divergent __syncthreads/__shfl or early return)\n",
+                    blk.bid.x, blk.bid.y, blk.bid.z, remaining);
+            abort();
+        }
     }
     g_blk = nullptr;
 }

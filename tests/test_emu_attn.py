@@ -1,0 +1,87 @@
+"""Host logic check of the attention kernels (qkv_post, flash fwd, bwd) against the oracle Attention + autograd."""
+import pytest
+import torch
+
+from oracle.e2tts_oracle import Attention, RotaryEmbedding
+
+bf16 = torch.bfloat16
+
+
+def rel(a, b):
+    return ((a.float() - b.float()).abs().max() / b.float().abs().max().clamp_min(1e-20)).item()
+
+
+def hm(t, B, H, N):          # (B*N, H*64) token-major -> (B,H,N,64)
+    return t.view(B, N, H, 64).permute(0, 2, 1, 3)
+
+
+@pytest.mark.parametrize('N,has_vres,use_mask', [(70, False, False), (150, True, True)])
+def test_attention(emu, N, has_vres, use_mask):
+    from e2_tts_pytorch_amd import ops
+    torch.manual_seed(0)
+    B, H = 2, 4
+    D = I = H * 64
+    attn = Attention(dim=D, heads=H, dim_head=64, dropout=0., learned_value_residual_mix=has_vres)
+    with torch.no_grad():
+        attn.to_out.weight.copy_(torch.eye(D))
+        attn.to_v_head_gate.weight.normal_(0, 0.05)
+        attn.to_v_head_gate.bias.normal_(0, 1.0)
+        for lin in (attn.to_q, attn.to_k):
+            lin.weight.mul_(3.0)                      # sharper softmax
+        if has_vres:
+            attn.to_value_residual_mix[0].weight.normal_(0, 0.05)
+            attn.to_value_residual_mix[0].bias.normal_(0, 1.0)
+    x = torch.randn(B, N, D)
+    mask = None
+    if use_mask:
+        lens = torch.tensor([N, N - 37])
+        mask = torch.arange(N)[None] < lens[:, None]
+    rot = RotaryEmbedding(64).forward_from_seq_len(N)
+    vres = torch.randn(B, H, N, 64).to(bf16).float().requires_grad_(True) if has_vres else None
+
+    # fused projection, rounded to bf16 like the GEMM output; feed the SAME rounded values to the oracle
+    Ws = [attn.to_q.weight, attn.to_k.weight, attn.to_v.weight, attn.to_v_head_gate.weight]
+    bs = [torch.zeros(I), torch.zeros(I), torch.zeros(I), attn.to_v_head_gate.bias]
+    if has_vres:
+        Ws.append(attn.to_value_residual_mix[0].weight)
+        bs.append(attn.to_value_residual_mix[0].bias)
+    qkvg_c = (x.reshape(B * N, D) @ torch.cat(Ws).T + torch.cat(bs)).detach().to(bf16)
+    ld = (qkvg_c.shape[1] + 7) // 8 * 8
+    qkvg = torch.zeros(B * N, ld, dtype=bf16)[:, :qkvg_c.shape[1]]
+    qkvg.copy_(qkvg_c)
+    cols = qkvg.float().requires_grad_(True)
+    parts = list(cols.split([I, I, I, H] + ([H] if has_vres else []), dim=-1))
+
+    class Fixed(torch.nn.Module):                    # stands in for a Linear, returns the pre-rounded projection
+        def __init__(self, val):
+            super().__init__()
+            self.val = val
+
+        def forward(self, _x):
+            return self.val.view(B, N, -1)
+    attn.to_q, attn.to_k, attn.to_v, attn.to_v_head_gate = (Fixed(p) for p in parts[:4])
+    if has_vres:
+        attn.to_value_residual_mix = torch.nn.Sequential(Fixed(parts[4]), torch.nn.Sigmoid())
+    out, inter = attn(x, mask=mask, rotary_pos_emb=rot, value_residual=vres, return_intermediates=True)
+    R = torch.randn(B, N, D)
+    (out * R).sum().backward()
+
+    cosb, sinb = ops.rotary_table(N, 'cpu')
+    vfirst = vres.detach().to(bf16).contiguous() if has_vres else None
+    st = ops.qkv_post_fwd(qkvg, B, H, N, cosb, sinb, vfirst)
+    kmask = torch.zeros(B, st.Npad, dtype=torch.uint8)
+    kmask[:, :N] = 1 if mask is None else mask.to(torch.uint8)
+    Og = ops.attn_fwd(st, kmask)
+    assert rel(Og.view(B, N, D), out) < 2e-2, rel(Og.view(B, N, D), out)
+
+    dOg = R.reshape(B * N, D).to(bf16)
+    dQ, dK, dV, dgate = ops.attn_bwd(st, dOg, kmask)
+    dvfirst = torch.zeros(B, H, N, 64) if has_vres else None
+    dqkvg = ops.qkv_post_bwd(st, dQ, dK, dV, dgate, qkvg, cosb, sinb, vfirst, dvfirst)
+    ref = cols.grad
+    names = ['q', 'k', 'v', 'gate'] + (['mix'] if has_vres else [])
+    for name, got, want in zip(names, dqkvg.float().split([I, I, I, H] + ([H] if has_vres else []), dim=-1),
+                               ref.split([I, I, I, H] + ([H] if has_vres else []), dim=-1)):
+        assert rel(got, want) < 4e-2, (name, rel(got, want))
+    if has_vres:
+        assert rel(dvfirst, vres.grad) < 4e-2, rel(dvfirst, vres.grad)
