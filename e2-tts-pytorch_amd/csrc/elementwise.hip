@@ -14,7 +14,7 @@ namespace {
 // ------------------------------------------------------------------------------------------------ RMSNorm
 
 struct NormArgs {
-    const bf16_t* x; const float* gamma; float gamma_off; int rows_per_batch;
+    const bf16_t* x; const float* gamma; long ldg; float gamma_off; int rows_per_batch;
     bf16_t* y; float* rn; int M;
     // backward
     const bf16_t* dy; bf16_t* dx; float* dgamma;
@@ -28,7 +28,7 @@ __global__ __launch_bounds__(256) void rmsnorm_fwd_kernel(NormArgs p) {
     for (int row = blockIdx.x * 4 + wave; row < p.M; row += gridDim.x * 4) {
         float x[EPL], g[EPL];
         load_row<VEC, NCH>(p.x + (long)row * D, lane, x);
-        load_row_f32<VEC, NCH>(p.gamma + (long)(row / p.rows_per_batch) * D, lane, g);
+        load_row_f32<VEC, NCH>(p.gamma + (long)(row / p.rows_per_batch) * p.ldg, lane, g);
         float ss = 0.f;
 #pragma unroll
         for (int e = 0; e < EPL; ++e) ss = fmaf(x[e], x[e], ss);
@@ -53,7 +53,7 @@ __global__ __launch_bounds__(256) void rmsnorm_bwd_kernel(NormArgs p) {
     const int nrows = min(p.rows_per_batch, p.M - row0);
     const float sqrtD = sqrtf((float)D);
     float g[EPL], dg[EPL];
-    load_row_f32<VEC, NCH>(p.gamma + (long)b * D, lane, g);
+    load_row_f32<VEC, NCH>(p.gamma + (long)b * p.ldg, lane, g);
 #pragma unroll
     for (int e = 0; e < EPL; ++e) { g[e] += p.gamma_off; dg[e] = 0.f; }
     for (int i = blockIdx.x * 4 + wave; i < nrows; i += gridDim.x * 4) {
@@ -82,7 +82,7 @@ __global__ __launch_bounds__(256) void rmsnorm_bwd_kernel(NormArgs p) {
         for (int v = 0; v < VEC; ++v) red[wave][c * 64 * VEC + lane * VEC + v] = dg[c * VEC + v];
     __syncthreads();
     for (int d = threadIdx.x; d < D; d += 256)
-        atomicAdd(p.dgamma + (long)b * D + d, red[0][d] + red[1][d] + red[2][d] + red[3][d]);
+        atomicAdd(p.dgamma + (long)b * p.ldg + d, red[0][d] + red[1][d] + red[2][d] + red[3][d]);
 }
 
 template <int VEC, int NCH> int launch_norm_fwd(const NormArgs& a, hipStream_t st) {
@@ -103,7 +103,7 @@ template <int VEC, int NCH> int launch_norm_bwd(const NormArgs& a, hipStream_t s
 //   forward (fused in the GEMM epilogue):  y = ao * g[b]            (g = sigmoid(to_gamma(c)), per batch row)
 //   backward: dao = dy * g[b] ;  gsum[b][d] += sum_rows dy * y      (so that dg = gsum / g, d(pre-sigmoid) = gsum * (1 - g))
 
-struct GateArgs { const bf16_t* dy; const bf16_t* y; const float* g; bf16_t* dao; float* gsum; int M, rows_per_batch; };
+struct GateArgs { const bf16_t* dy; const bf16_t* y; const float* g; bf16_t* dao; float* gsum; long ldg; int M, rows_per_batch; };
 
 template <int VEC, int NCH>
 __global__ __launch_bounds__(256) void gate_bwd_kernel(GateArgs p) {
@@ -114,7 +114,7 @@ __global__ __launch_bounds__(256) void gate_bwd_kernel(GateArgs p) {
     const int row0 = b * p.rows_per_batch;
     const int nrows = min(p.rows_per_batch, p.M - row0);
     float g[EPL], acc[EPL];
-    load_row_f32<VEC, NCH>(p.g + (long)b * D, lane, g);
+    load_row_f32<VEC, NCH>(p.g + (long)b * p.ldg, lane, g);
 #pragma unroll
     for (int e = 0; e < EPL; ++e) acc[e] = 0.f;
     for (int i = blockIdx.x * 4 + wave; i < nrows; i += gridDim.x * 4) {
@@ -132,7 +132,7 @@ __global__ __launch_bounds__(256) void gate_bwd_kernel(GateArgs p) {
         for (int v = 0; v < VEC; ++v) red[wave][c * 64 * VEC + lane * VEC + v] = acc[c * VEC + v];
     __syncthreads();
     for (int d = threadIdx.x; d < D; d += 256)
-        atomicAdd(p.gsum + (long)b * D + d, red[0][d] + red[1][d] + red[2][d] + red[3][d]);
+        atomicAdd(p.gsum + (long)b * p.ldg + d, red[0][d] + red[1][d] + red[2][d] + red[3][d]);
 }
 template <int VEC, int NCH> int launch_gate_bwd(const GateArgs& a, hipStream_t st) {
     const int nb = (a.M + a.rows_per_batch - 1) / a.rows_per_batch;
@@ -401,12 +401,12 @@ int dispatch_conv(const ConvArgs& a, int ks, bool bwd, hipStream_t st) {
 
 }  // namespace
 
-extern "C" int e2k_rmsnorm_fwd(const void* x, const float* gamma, float gamma_off, int rows_per_batch, void* y,
-                               float* rn, int M, int D, void* stream) {
+extern "C" int e2k_rmsnorm_fwd(const void* x, const float* gamma, int64_t ldg, float gamma_off, int rows_per_batch,
+                               void* y, float* rn, int M, int D, void* stream) {
     if (M <= 0) return 0;
     if (!x || !gamma || !y || !rn || rows_per_batch <= 0) return E2K_ERR_ARG;
     NormArgs a{};
-    a.x = (const bf16_t*)x; a.gamma = gamma; a.gamma_off = gamma_off; a.rows_per_batch = rows_per_batch;
+    a.x = (const bf16_t*)x; a.gamma = gamma; a.ldg = ldg; a.gamma_off = gamma_off; a.rows_per_batch = rows_per_batch;
     a.y = (bf16_t*)y; a.rn = rn; a.M = M;
     int rc = 0;
     E2K_ROW_DISPATCH(D, launch_norm_fwd, a, (hipStream_t)stream);
@@ -415,12 +415,13 @@ extern "C" int e2k_rmsnorm_fwd(const void* x, const float* gamma, float gamma_of
     return 0;
 }
 
-extern "C" int e2k_rmsnorm_bwd(const void* dy, const void* x, const float* rn, const float* gamma, float gamma_off,
-                               int rows_per_batch, void* dx, float* dgamma, int M, int D, void* stream) {
+extern "C" int e2k_rmsnorm_bwd(const void* dy, const void* x, const float* rn, const float* gamma, int64_t ldg,
+                               float gamma_off, int rows_per_batch, void* dx, float* dgamma, int M, int D,
+                               void* stream) {
     if (M <= 0) return 0;
     if (!dy || !x || !rn || !gamma || !dx || !dgamma || rows_per_batch <= 0) return E2K_ERR_ARG;
     NormArgs a{};
-    a.x = (const bf16_t*)x; a.gamma = gamma; a.gamma_off = gamma_off; a.rows_per_batch = rows_per_batch;
+    a.x = (const bf16_t*)x; a.gamma = gamma; a.ldg = ldg; a.gamma_off = gamma_off; a.rows_per_batch = rows_per_batch;
     a.rn = const_cast<float*>(rn); a.M = M; a.dy = (const bf16_t*)dy; a.dx = (bf16_t*)dx; a.dgamma = dgamma;
     int rc = 0;
     E2K_ROW_DISPATCH(D, launch_norm_bwd, a, (hipStream_t)stream);
@@ -429,11 +430,11 @@ extern "C" int e2k_rmsnorm_bwd(const void* dy, const void* x, const float* rn, c
     return 0;
 }
 
-extern "C" int e2k_gate_bwd(const void* dy, const void* y, const float* g, void* dao, float* gsum, int M, int D,
-                            int rows_per_batch, void* stream) {
+extern "C" int e2k_gate_bwd(const void* dy, const void* y, const float* g, void* dao, float* gsum, int64_t ldg,
+                            int M, int D, int rows_per_batch, void* stream) {
     if (M <= 0) return 0;
     if (!dy || !y || !g || !dao || !gsum || rows_per_batch <= 0) return E2K_ERR_ARG;
-    GateArgs a{(const bf16_t*)dy, (const bf16_t*)y, g, (bf16_t*)dao, gsum, M, rows_per_batch};
+    GateArgs a{(const bf16_t*)dy, (const bf16_t*)y, g, (bf16_t*)dao, gsum, (long)ldg, M, rows_per_batch};
     int rc = 0;
     E2K_ROW_DISPATCH(D, launch_gate_bwd, a, (hipStream_t)stream);
     if (rc) return rc;

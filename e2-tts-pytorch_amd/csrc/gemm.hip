@@ -47,7 +47,7 @@ struct NTArgs {
     const bf16_t* B; long ldb;
     void* C; long ldc; int accumulate;
     int M, N;
-    const float* bias; const float* colscale; int rows_per_batch;
+    const float* bias; const float* colscale; long lds; int rows_per_batch;
     const uint8_t* rowmask; const bf16_t* resid; long ldr;
 };
 
@@ -141,7 +141,7 @@ __global__ __launch_bounds__(256) void gemm_nt_kernel(NTArgs p) {
         const int m = m0 + wm * 64 + i * 16 + l15;
         if (m >= p.M) continue;
         const float rm = p.rowmask ? (p.rowmask[m] ? 1.f : 0.f) : 1.f;
-        const float* cs = p.colscale ? p.colscale + (long)(m / p.rows_per_batch) * p.N : nullptr;
+        const float* cs = p.colscale ? p.colscale + (long)(m / p.rows_per_batch) * p.lds : nullptr;
 #pragma unroll
         for (int j = 0; j < 4; ++j) {
             const int n = n0 + wn * 64 + j * 16 + 4 * g;
@@ -322,8 +322,8 @@ __global__ __launch_bounds__(256) void gemm_tn_kernel(TNArgs p) {
 
 extern "C" int e2k_gemm_nt_bf16(const void* A1, int64_t lda1, int K1, const void* A2, int64_t lda2, int K2,
                                 const void* B, int64_t ldb, void* C, int64_t ldc, int out_f32, int accumulate,
-                                int M, int N, const float* bias, const float* colscale, int rows_per_batch,
-                                const uint8_t* rowmask, const void* resid, int64_t ldr, void* stream) {
+                                int M, int N, const float* bias, const float* colscale, int64_t lds,
+                                int rows_per_batch, const uint8_t* rowmask, const void* resid, int64_t ldr, void* stream) {
     if (M <= 0 || N <= 0) return 0;
     if (K1 <= 0 || (K1 & 7) || (K2 & 7) || K2 < 0) return E2K_ERR_SHAPE;
     if ((lda1 & 7) || (ldb & 7) || (K2 > 0 && ((lda2 & 7) || A2 == nullptr))) return E2K_ERR_ALIGN;
@@ -336,7 +336,7 @@ extern "C" int e2k_gemm_nt_bf16(const void* A1, int64_t lda1, int K1, const void
     p.B = (const bf16_t*)B; p.ldb = ldb;
     p.C = C; p.ldc = ldc; p.accumulate = accumulate;
     p.M = M; p.N = N;
-    p.bias = bias; p.colscale = colscale; p.rows_per_batch = rows_per_batch;
+    p.bias = bias; p.colscale = colscale; p.lds = lds; p.rows_per_batch = rows_per_batch;
     p.rowmask = rowmask; p.resid = (const bf16_t*)resid; p.ldr = ldr;
     const int tm = (M + BM - 1) / BM, tn = (N + BN - 1) / BN;
     dim3 grid(tm * tn), block(256);
@@ -349,7 +349,8 @@ extern "C" int e2k_gemm_nt_bf16(const void* A1, int64_t lda1, int K1, const void
 extern "C" int e2k_gemm_tn_bf16(const void* A, int64_t lda, const void* B, int64_t ldb, float* C, int64_t ldc,
                                 int M, int N, int K, int splits, int use_tr, void* stream) {
     if (M <= 0 || N <= 0 || K <= 0) return 0;
-    if ((N & 7) || (K & 7) || (lda & 7) || (ldb & 7)) return E2K_ERR_ALIGN;
+    // 16-B loads may run past N / K up to the next multiple of 8: that must still be inside the row
+    if ((lda & 7) || (ldb & 7) || ((N + 7) & ~7) > lda || ((K + 7) & ~7) > ldb) return E2K_ERR_ALIGN;
     if (((uintptr_t)A | (uintptr_t)B) & 15) return E2K_ERR_ALIGN;
     const int tn = (N + 127) / 128, tk = (K + 127) / 128;
     if (splits <= 0) {

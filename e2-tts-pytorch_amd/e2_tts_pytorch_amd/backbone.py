@@ -1,0 +1,896 @@
+"""Multistream (speech + text) U-Net transformer backbone on the e2k HIP kernels.
+
+Host-side mirror of `Transformer` (/root/reference/e2_tts_pytorch/e2_tts.py:518-952): same constructor keywords,
+same forward signature, same parameter / buffer names (state_dict compatible).  The
+arithmetic of the depth loop runs entirely in csrc/*.hip through the C ABI (ops.py); forward and backward are
+scheduled by hand here (one torch.autograd.Function around the whole backbone) so that
+  * hyper-connection depth/width pairs, AdaLN gates and concatenations are fused across op boundaries,
+  * all parameters live in ONE flat fp32 buffer (+ bf16 compute shadows), gradients in one flat fp32 buffer whose
+    per-layer slabs can be all-reduced while the backward of earlier layers is still running (ddp.py).
+There is no PyTorch fallback for the kernels: without libe2k.so (or on CPU tensors) every call raises.
+"""
+from __future__ import annotations
+
+import random as _pyrandom
+from types import SimpleNamespace as NS
+
+import torch
+from torch import nn
+from torch.nn import Module, ModuleList
+
+from . import ops
+from .ops import bf16, f32
+
+
+def exists(v):
+    return v is not None
+
+
+def default(v, d):
+    return v if exists(v) else d
+
+
+# ------------------------------------------------------------------------------------------------ parameter holders
+# Same attribute names / shapes / initialisation as the third-party modules the reference instantiates
+# (x_transformers, hyper_connections).  They only hold parameters: the math is in the kernels.
+
+class _Holder(Module):
+    def forward(self, *a, **k):
+        raise RuntimeError('parameter holder: the computation runs inside Transformer.forward on the HIP kernels')
+
+
+class RMSNorm(_Holder):                       # x_transformers.RMSNorm (e2_tts.py:615,688,691,729)
+    def __init__(self, dim):
+        super().__init__()
+        self.g = nn.Parameter(torch.ones(dim))
+
+
+class AdaptiveRMSNorm(_Holder):               # x_transformers.AdaptiveRMSNorm (e2_tts.py:615,637,645)
+    def __init__(self, dim):
+        super().__init__()
+        self.to_gamma = nn.Linear(dim, dim, bias=False)
+        nn.init.zeros_(self.to_gamma.weight)
+
+
+class AdaLNZero(_Holder):                     # e2_tts.py:332-351
+    def __init__(self, dim, init_bias_value=-2.):
+        super().__init__()
+        self.to_gamma = nn.Linear(dim, dim)
+        nn.init.zeros_(self.to_gamma.weight)
+        nn.init.constant_(self.to_gamma.bias, init_bias_value)
+
+
+class Identity(_Holder):                      # e2_tts.py:107
+    pass
+
+
+class Attention(_Holder):                     # x_transformers.Attention (e2_tts.py:641,689)
+    def __init__(self, dim, heads, dim_head, learned_value_residual_mix):
+        super().__init__()
+        inner = heads * dim_head
+        self.to_q = nn.Linear(dim, inner, bias=False)
+        self.to_k = nn.Linear(dim, inner, bias=False)
+        self.to_v = nn.Linear(dim, inner, bias=False)
+        self.to_out = nn.Linear(inner, dim, bias=False)
+        self.to_v_head_gate = nn.Linear(dim, heads)
+        nn.init.constant_(self.to_v_head_gate.weight, 0)
+        nn.init.constant_(self.to_v_head_gate.bias, 10)
+        self.to_value_residual_mix = None
+        if learned_value_residual_mix:
+            self.to_value_residual_mix = nn.Sequential(nn.Linear(dim, heads), nn.Sigmoid())
+
+
+class _GLU(_Holder):
+    def __init__(self, dim_in, dim_out):
+        super().__init__()
+        self.proj = nn.Linear(dim_in, dim_out * 2)
+
+
+class FeedForward(_Holder):                   # x_transformers.FeedForward(glu=True) (e2_tts.py:646,692)
+    def __init__(self, dim, mult, dropout):
+        super().__init__()
+        inner = int(dim * mult)
+        self.ff = nn.Sequential(_GLU(dim, inner), nn.Dropout(dropout), nn.Linear(inner, dim))
+
+
+class _HCNorm(_Holder):
+    def __init__(self, dim):
+        super().__init__()
+        self.gamma = nn.Parameter(torch.zeros(dim))
+
+
+class HyperConnections(_Holder):              # hyper_connections.HyperConnections (e2_tts.py:607,673-678,709-713)
+    def __init__(self, num_residual_streams, *, dim):
+        super().__init__()
+        s = num_residual_streams
+        self.norm = _HCNorm(dim)
+        init_idx = _pyrandom.randrange(s) % s
+        self.static_beta = nn.Parameter(torch.ones(s))
+        a0 = torch.zeros(s, 1)
+        a0[init_idx, 0] = 1.
+        self.static_alpha = nn.Parameter(torch.cat([a0, torch.eye(s)], dim=1))
+        self.dynamic_alpha_fn = nn.Parameter(torch.zeros(dim, s + 1))
+        self.dynamic_alpha_scale = nn.Parameter(torch.ones(()) * 1e-2)
+        self.dynamic_beta_fn = nn.Parameter(torch.zeros(dim))
+        self.dynamic_beta_scale = nn.Parameter(torch.ones(()) * 1e-2)
+
+    def param_list(self):
+        return [self.static_beta, self.static_alpha, self.dynamic_alpha_fn, self.dynamic_alpha_scale,
+                self.dynamic_beta_fn, self.dynamic_beta_scale, self.norm.gamma]
+
+
+class DepthwiseConv(_Holder):                 # e2_tts.py:295-328
+    def __init__(self, dim, *, kernel_size):
+        super().__init__()
+        assert kernel_size % 2 == 1
+        self.dw_conv1d = nn.Sequential(nn.Conv1d(dim, dim, kernel_size, groups=dim, padding=kernel_size // 2), nn.SiLU())
+
+
+class TextAudioCrossCondition(_Holder):       # e2_tts.py:486-513
+    def __init__(self, dim, dim_text, cond_audio_to_text=True):
+        super().__init__()
+        self.text_to_audio = nn.Linear(dim_text + dim, dim, bias=False)
+        nn.init.zeros_(self.text_to_audio.weight)
+        self.cond_audio_to_text = cond_audio_to_text
+        if cond_audio_to_text:
+            self.audio_to_text = nn.Linear(dim + dim_text, dim_text, bias=False)
+            nn.init.zeros_(self.audio_to_text.weight)
+
+
+class RandomFourierEmbed(Module):             # e2_tts.py:355-364 (tiny, stays in torch)
+    def __init__(self, dim):
+        super().__init__()
+        assert dim % 2 == 0
+        self.register_buffer('weights', torch.randn(dim // 2))
+
+    def forward(self, x):
+        freqs = x[:, None] * self.weights[None, :] * 2 * torch.pi
+        return torch.cat((x[:, None], freqs.sin(), freqs.cos()), dim=-1)
+
+
+class RotaryEmbedding(Module):                # x_transformers RotaryEmbedding: only the inv_freq buffer is kept
+    def __init__(self, dim, base=10000):
+        super().__init__()
+        self.register_buffer('inv_freq', 1. / (base ** (torch.arange(0, dim, 2).float() / dim)))
+
+
+# ------------------------------------------------------------------------------------------------ flat parameter layout
+
+class _Layout:
+    """element offsets into the flat fp32 parameter buffer (every slot 8-element aligned unless chained)"""
+
+    def __init__(self):
+        self.n = 0
+        self.slots = []            # (param, offset)
+
+    def align(self):
+        self.n = (self.n + 7) // 8 * 8
+
+    def add(self, p, chain=False):
+        if not chain:
+            self.align()
+        off = self.n
+        self.slots.append((p, off))
+        self.n += p.numel()
+        return off
+
+    def hole(self, numel, chain=False):
+        if not chain:
+            self.align()
+        off = self.n
+        self.n += numel
+        return off
+
+
+def _r8(n):
+    return (n + 7) // 8 * 8
+
+
+class _HCRec:
+    __slots__ = ('xin', 'yprev', 'coef_prev', 'coef', 'hc', 'prev', 'ycur', 'dy', 'dbin')
+
+
+class _Stream:
+    """a residual-stream tensor either materialised (X) or as pending depth connection (M + b*y)"""
+    __slots__ = ('X', 'M', 'y', 'coef', 'rec', 'key', 'D')
+
+    def __init__(self, X, key):
+        self.X, self.M, self.y, self.coef, self.rec, self.key = X, None, None, None, None, key
+        self.D = X.shape[-1]
+
+
+# ------------------------------------------------------------------------------------------------ the backbone
+
+class Transformer(Module):
+    def __init__(
+        self,
+        *,
+        dim,
+        dim_text=None,
+        depth=8,
+        heads=8,
+        dim_head=64,
+        ff_mult=4,
+        text_depth=None,
+        text_heads=None,
+        text_dim_head=None,
+        text_ff_mult=None,
+        has_freq_axis=False,
+        freq_heads=None,
+        freq_dim_head=None,
+        cond_on_time=True,
+        abs_pos_emb=True,
+        max_seq_len=8192,
+        kernel_size=31,
+        dropout=0.1,
+        num_registers=32,
+        scale_residual=False,
+        attn_laser=False,
+        attn_laser_softclamp_value=15.,
+        attn_fourier_embed_input=False,
+        attn_fourier_embed_input_frac=0.25,
+        num_residual_streams=4,
+        attn_kwargs: dict = dict(gate_value_heads=True, softclamp_logits=True),
+        ff_kwargs: dict = dict(),
+    ):
+        super().__init__()
+        assert depth % 2 == 0, 'depth needs to be even'
+        # default-off variants of the reference are not on the hot path
+        if has_freq_axis or attn_laser or attn_fourier_embed_input:
+            raise NotImplementedError('has_freq_axis / attn_laser / attn_fourier_embed_input are not built yet')
+        if num_residual_streams != 4:
+            raise NotImplementedError('the hyper-connection kernels are built for 4 residual streams')
+        if dict(attn_kwargs) != dict(gate_value_heads=True, softclamp_logits=True) or dict(ff_kwargs):
+            raise NotImplementedError('only the default attn_kwargs / ff_kwargs are built')
+        dim_text = default(dim_text, dim // 2)
+        text_heads = default(text_heads, heads)
+        text_dim_head = default(text_dim_head, dim_head)
+        text_ff_mult = default(text_ff_mult, ff_mult)
+        text_depth = default(text_depth, depth)
+        assert 1 <= text_depth <= depth, 'must have at least 1 layer of text conditioning, but less than total number of speech layers'
+        if dim_head != 64 or text_dim_head != 64:
+            raise NotImplementedError('the attention kernels are built for dim_head = 64')
+
+        self.max_seq_len = max_seq_len
+        self.abs_pos_emb = nn.Embedding(max_seq_len, dim) if abs_pos_emb else None
+        self.dim, self.dim_text = dim, dim_text
+        self.has_freq_axis = False
+        self.depth, self.text_depth = depth, text_depth
+        self.heads, self.text_heads = heads, text_heads
+        self.ff_inner, self.text_ff_inner = int(dim * ff_mult), int(dim_text * text_ff_mult)
+        self.kernel_size, self.dropout = kernel_size, dropout
+        self.num_registers = num_registers
+        self.registers = nn.Parameter(torch.zeros(num_registers, dim))
+        nn.init.normal_(self.registers, std=0.02)
+        self.text_registers = nn.Parameter(torch.zeros(num_registers, dim_text))
+        nn.init.normal_(self.text_registers, std=0.02)
+        self.rotary_emb = RotaryEmbedding(dim_head)
+        self.text_rotary_emb = RotaryEmbedding(text_dim_head)
+        self.cond_on_time = cond_on_time
+        norm_klass = (lambda: AdaptiveRMSNorm(dim)) if cond_on_time else (lambda: RMSNorm(dim))
+        post_klass = (lambda: AdaLNZero(dim)) if cond_on_time else Identity
+        self.time_cond_mlp = Identity()
+        if cond_on_time:
+            self.time_cond_mlp = nn.Sequential(RandomFourierEmbed(dim), nn.Linear(dim + 1, dim), nn.SiLU())
+
+        layers, hyper_conns = [], []
+        for ind in range(depth):
+            first, later_half, has_text = ind == 0, ind >= depth // 2, ind < text_depth
+            speech_modules = ModuleList([
+                nn.Linear(dim * 2, dim, bias=False) if later_half else None,
+                DepthwiseConv(dim, kernel_size=kernel_size),
+                norm_klass(),
+                Attention(dim, heads, dim_head, learned_value_residual_mix=not first),
+                nn.Identity(),
+                post_klass(),
+                norm_klass(),
+                FeedForward(dim, ff_mult, dropout),
+                post_klass(),
+                None, None, None])
+            speech_hc = ModuleList([HyperConnections(4, dim=dim) for _ in range(3)] + [None])
+            text_modules = text_hc = None
+            if has_text:
+                text_modules = ModuleList([
+                    DepthwiseConv(dim_text, kernel_size=kernel_size),
+                    RMSNorm(dim_text),
+                    Attention(dim_text, text_heads, text_dim_head, learned_value_residual_mix=not first),
+                    RMSNorm(dim_text),
+                    FeedForward(dim_text, text_ff_mult, dropout),
+                    TextAudioCrossCondition(dim=dim, dim_text=dim_text, cond_audio_to_text=ind != text_depth - 1)])
+                text_hc = ModuleList([HyperConnections(4, dim=dim_text) for _ in range(3)])
+            hyper_conns.append(ModuleList([speech_hc, text_hc]))
+            layers.append(ModuleList([speech_modules, text_modules]))
+        self.layers = ModuleList(layers)
+        self.hyper_conns = ModuleList(hyper_conns)
+        self.final_norm = RMSNorm(dim)
+
+        # flat storage is created lazily on the first forward on a device (and re-created if parameters were moved)
+        self._flat = None
+        self._build_layout()
+        self._grad_sync = None          # set by ddp.DataParallel: called with (grad_flat, start, end) per finished slab
+
+    # ------------------------------------------------------------------ layout
+
+    def _attn_rec(self, lay, attn, dim):
+        """fused [to_q; to_k; to_v; gate; mix] weight + bias row, to_out"""
+        H = attn.to_v_head_gate.out_features
+        I = attn.to_q.out_features
+        mixl = attn.to_value_residual_mix[0] if exists(attn.to_value_residual_mix) else None
+        cols = 3 * I + H + (H if exists(mixl) else 0)
+        r = NS(H=H, I=I, cols=cols, ldq=_r8(cols), has_mix=exists(mixl))
+        r.w = lay.add(attn.to_q.weight)
+        for p in (attn.to_k.weight, attn.to_v.weight, attn.to_v_head_gate.weight):
+            lay.add(p, chain=True)
+        if exists(mixl):
+            lay.add(mixl.weight, chain=True)
+        r.bias = lay.hole(3 * I)
+        lay.add(attn.to_v_head_gate.bias, chain=True)
+        if exists(mixl):
+            lay.add(mixl.bias, chain=True)
+        lay.hole(r.ldq - cols, chain=True)
+        r.out = lay.add(attn.to_out.weight)
+        r.dim = dim
+        return r
+
+    def _ff_rec(self, lay, ff, dim):
+        glu, lin = ff.ff[0], ff.ff[2]
+        r = NS(F=lin.in_features, dim=dim)
+        r.w1, r.b1 = lay.add(glu.proj.weight), lay.add(glu.proj.bias)
+        r.w2, r.b2 = lay.add(lin.weight), lay.add(lin.bias)
+        return r
+
+    def _conv_rec(self, lay, conv):
+        c = conv.dw_conv1d[0]
+        return NS(w=lay.add(c.weight), b=lay.add(c.bias), ks=c.kernel_size[0], C=c.out_channels)
+
+    def _hc_rec(self, lay, hc, dim):
+        return NS(offs=[lay.add(p) for p in hc.param_list()], shapes=[tuple(p.shape) for p in hc.param_list()], dim=dim)
+
+    def _build_layout(self):
+        lay = _Layout()
+        D, Dt, L = self.dim, self.dim_text, self.depth
+        g = NS()
+        g.abs_pos = lay.add(self.abs_pos_emb.weight) if exists(self.abs_pos_emb) else None
+        g.registers = lay.add(self.registers)
+        g.text_registers = lay.add(self.text_registers)
+        g.final_g = lay.add(self.final_norm.g)
+        # hoisted time conditioning: rows [layer][attn_norm gamma | attn AdaLN gate | ff_norm gamma | ff AdaLN gate]
+        if self.cond_on_time:
+            lay.align()
+            g.wcond = lay.n
+            for (sm, _tm) in self.layers:
+                for k, mod in enumerate((sm[2], sm[5], sm[6], sm[8])):
+                    lay.add(mod.to_gamma.weight, chain=True)
+            g.bcond = lay.hole(0)
+            for (sm, _tm) in self.layers:
+                lay.hole(D, chain=True)
+                lay.add(sm[5].to_gamma.bias, chain=True)
+                lay.hole(D, chain=True)
+                lay.add(sm[8].to_gamma.bias, chain=True)
+        lay.align()
+        g.end = lay.n
+        recs = []
+        for ind, ((sm, tm), (shc, thc)) in enumerate(zip(self.layers, self.hyper_conns)):
+            lay.align()
+            r = NS(start=lay.n, index=ind)
+            s = NS()
+            s.skip = lay.add(sm[0].weight) if exists(sm[0]) else None
+            s.conv = self._conv_rec(lay, sm[1])
+            s.attn = self._attn_rec(lay, sm[3], D)
+            s.ff = self._ff_rec(lay, sm[7], D)
+            if not self.cond_on_time:
+                s.attn_g, s.ff_g = lay.add(sm[2].g), lay.add(sm[6].g)
+            s.hc = [self._hc_rec(lay, h, D) for h in list(shc)[:3]]
+            r.s = s
+            r.t = None
+            if exists(tm):
+                t = NS()
+                t.conv = self._conv_rec(lay, tm[0])
+                t.attn_g = lay.add(tm[1].g)
+                t.attn = self._attn_rec(lay, tm[2], Dt)
+                t.ff_g = lay.add(tm[3].g)
+                t.ff = self._ff_rec(lay, tm[4], Dt)
+                t.cross = lay.add(tm[5].text_to_audio.weight)           # (D, D+Dt)  then  (Dt, D+Dt) chained
+                t.cross_rows = D
+                if tm[5].cond_audio_to_text:
+                    lay.add(tm[5].audio_to_text.weight, chain=True)
+                    t.cross_rows = D + Dt
+                t.hc = [self._hc_rec(lay, h, Dt) for h in list(thc)]
+                r.t = t
+            lay.align()
+            r.end = lay.n
+            recs.append(r)
+        lay.align()
+        self._layout, self._glob, self._recs = lay, g, recs
+        # transposed bf16 shadows (dgrad operands): (offset in flatT, src offset, R, C, ldd)
+        tl, tn = [], 0
+
+        def tr(off, R, C, ldd=None):
+            nonlocal tn
+            ldd = default(ldd, R)
+            rec = NS(dst=tn, src=off, R=R, C=C, ldd=ldd)
+            tl.append(rec)
+            tn += _r8(C * ldd)
+            return rec
+        for r in recs:
+            for st, d in ((r.s, D), (r.t, Dt)):
+                if st is None:
+                    continue
+                a, f = st.attn, st.ff
+                a.wT = tr(a.w, a.cols, d, a.ldq)         # (d, ldq)
+                a.outT = tr(a.out, d, a.I)                # (I, d)
+                f.w1T = tr(f.w1, 2 * f.F, d)              # (d, 2F)
+                f.w2T = tr(f.w2, d, f.F)                  # (F, d)
+            if exists(r.s.skip):
+                r.s.skipT = tr(r.s.skip, D, 2 * D)        # (2D, D)
+            if exists(r.t):
+                r.t.crossT = tr(r.t.cross, r.t.cross_rows, D + Dt)     # (D+Dt, rows)
+        self._tlist, self._tsize = tl, tn
+
+    # ------------------------------------------------------------------ flat storage
+
+    def _params_in_order(self):
+        return [p for p, _ in self._layout.slots]
+
+    def _is_packed(self):
+        if self._flat is None:
+            return False
+        base = self._flat.data_ptr()
+        slots = self._layout.slots
+        for p, off in (slots[0], slots[len(slots) // 2], slots[-1]):
+            if p.data_ptr() != base + off * 4:
+                return False
+        return True
+
+    @torch.no_grad()
+    def _pack(self, device):
+        lay = self._layout
+        flat = torch.zeros(lay.n, dtype=f32, device=device)
+        for p, off in lay.slots:
+            flat[off:off + p.numel()].copy_(p.detach().reshape(-1).to(device=device, dtype=f32))
+        for p, off in lay.slots:
+            p.data = flat[off:off + p.numel()].view(p.shape)
+        self._flat = flat
+        self._shadow = torch.zeros(lay.n, dtype=bf16, device=device)
+        self._shadowT = torch.zeros(max(self._tsize, 8), dtype=bf16, device=device)
+        self._shadow_key = None
+
+    def _sync(self, device):
+        if self._flat is None or self._flat.device != device or not self._is_packed():
+            for p, _ in self._layout.slots:
+                if p.device != device:
+                    raise RuntimeError(f'Transformer parameters live on {p.device} but the input is on {device}')
+            self._pack(device)
+        key = sum(p._version for p, _ in self._layout.slots)
+        if key != self._shadow_key:
+            ops.cast_bf16(self._flat, self._shadow)
+            for t in self._tlist:
+                src = self._flat[t.src:t.src + t.R * t.C].view(t.R, t.C)
+                dst = self._shadowT[t.dst:t.dst + t.C * t.ldd].view(t.C, t.ldd)[:, :t.R]
+                ops.cast_transpose_bf16(src, dst)
+            self._shadow_key = key
+
+    # views into the flat buffers -------------------------------------------------
+    def _w(self, off, R, C):                  # bf16 weight (R, C)
+        return self._shadow[off:off + R * C].view(R, C)
+
+    def _wT(self, t):                          # transposed bf16 weight (C, ldd)
+        return self._shadowT[t.dst:t.dst + t.C * t.ldd].view(t.C, t.ldd)
+
+    def _f(self, off, n):                      # fp32 parameter vector
+        return self._flat[off:off + n]
+
+    @staticmethod
+    def _g(gflat, off, *shape):                # fp32 gradient view
+        n = 1
+        for s in shape:
+            n *= s
+        return gflat[off:off + n].view(*shape)
+
+    # ------------------------------------------------------------------ public forward
+
+    def forward(self, x, times=None, mask=None, text_embed=None):
+        assert x.ndim == 3, 'has_freq_axis tensors (4 dims) are not supported'
+        assert not (exists(times) ^ self.cond_on_time), '`times` must be passed in if `cond_on_time` is set to `True` and vice versa'
+        B, T, _ = x.shape
+        if exists(self.abs_pos_emb):
+            assert T <= self.max_seq_len, f'{T} exceeds the set `max_seq_len` ({self.max_seq_len}) on Transformer'
+        cond = None
+        if exists(times):
+            if times.ndim == 0:
+                times = times[None].expand(B)
+            cond = self.time_cond_mlp(times.float())               # (B, D) fp32, tiny: stays in torch
+        self._sync(x.device)
+        need_grad = torch.is_grad_enabled() and (
+            x.requires_grad or (exists(cond) and cond.requires_grad) or (exists(text_embed) and text_embed.requires_grad)
+            or any(p.requires_grad for p, _ in self._layout.slots))
+        if need_grad:
+            return _BackboneFn.apply(self, x, cond, text_embed, mask, *self._params_in_order())
+        return self._run_forward(x, cond, text_embed, mask, False).out
+
+    # ------------------------------------------------------------------ forward schedule
+
+    def _run_forward(self, x_in, cond, text_embed, mask, want_tape):
+        dev = x_in.device
+        B, T, D = x_in.shape
+        Dt, R, L = self.dim_text, self.num_registers, self.depth
+        N = T + R
+        Mtok = B * N
+        run = NS(B=B, T=T, N=N, Mtok=Mtok, tape=[] if want_tape else None, dev=dev)
+        tape = run.tape
+        p_drop = self.dropout if self.training else 0.
+        run.p_drop = p_drop
+        run.seed = int(torch.randint(0, 2 ** 31 - 1, (1,)).item()) if p_drop > 0 else 0
+        g = self._glob
+
+        # masks
+        Npad = (N + 63) // 64 * 64
+        kmask = torch.zeros((B, Npad), dtype=torch.uint8, device=dev)
+        kmask[:, :R] = 1
+        if exists(mask):
+            kmask[:, R:N] = mask.to(torch.uint8)
+            run.mask_n = kmask[:, :N].contiguous()
+        else:
+            kmask[:, R:N] = 1
+            run.mask_n = None
+        run.kmask = kmask
+        run.rot = ops.rotary_table(N, dev)
+
+        # time conditioning, hoisted out of the layer loop: one GEMM for every layer's gamma / gate
+        if self.cond_on_time:
+            cb = cond.to(bf16).contiguous()
+            wc = self._w(g.wcond, 4 * L * D, D)
+            condall = ops.gemm_nt(cb, wc, bias=self._f(g.bcond, 4 * L * D), out_dtype=f32)       # (B, 4LD)
+            run.cb, run.condall = cb, condall
+            run.gates = torch.sigmoid(condall)
+            run.dcond = torch.zeros_like(condall) if want_tape else None
+
+        # pack: abs-pos + registers, expand to 4 identical streams (token-major)
+        xs = x_in.float()
+        if exists(self.abs_pos_emb):
+            xs = xs + self._f(g.abs_pos, self.max_seq_len * D).view(self.max_seq_len, D)[:T]
+        regs = self._f(g.registers, R * D).view(R, D)
+        X0 = torch.cat([regs[None].expand(B, -1, -1), xs], dim=1).to(bf16)
+        sx = _Stream(X0[:, :, None, :].expand(B, N, 4, D).contiguous().view(Mtok, 4, D), 'x')
+        st = None
+        if exists(text_embed):
+            tregs = self._f(g.text_registers, R * Dt).view(R, Dt)
+            T0 = torch.cat([tregs[None].expand(B, -1, -1), text_embed.float()], dim=1).to(bf16)
+            st = _Stream(T0[:, :, None, :].expand(B, N, 4, Dt).contiguous().view(Mtok, 4, Dt), 't')
+        run.has_text = exists(st)
+        run.vfirst = {'x': None, 't': None}
+        run.attn0 = {'x': None, 't': None}
+        skips = []
+
+        for r in self._recs:
+            ind = r.index
+            if exists(tape):
+                tape.append(('layer', r))
+            if exists(st) and exists(r.t):
+                self._branches(run, st, r.t, ind, text=True)
+                self._cross(run, sx, st, r.t)
+            if ind < L // 2:
+                self._materialize(run, sx)
+                skips.append(sx.X)
+                if exists(tape):
+                    tape.append(('skip_push',))
+            else:
+                self._skip(run, sx, skips.pop(), r.s)
+            self._branches(run, sx, r.s, ind, text=False)
+        assert len(skips) == 0
+        self._materialize(run, sx)
+        if exists(st):
+            self._materialize(run, st)      # (its value is unused; keeps the tape uniform)
+
+        # tail: drop registers, sum the 4 streams, final RMSNorm
+        Xf = sx.X.view(B, N, 4, D)[:, R:]
+        xsum = Xf.float().sum(dim=2).to(bf16).reshape(B * T, D)
+        gfin = self._f(g.final_g, D).view(1, D)
+        y, rn = ops.rmsnorm_fwd(xsum, gfin, 0., B * T)
+        run.tail = (xsum, rn)
+        run.out = y.view(B, T, D).float()
+        return run
+
+    # -- stream helpers --------------------------------------------------------
+    def _hc_params(self, hrec):
+        return [self._flat[o:o + _numel(s)].view(s) if len(s) else self._flat[o:o + 1].view(()) for o, s in zip(hrec.offs, hrec.shapes)]
+
+    def _hc_width(self, run, S, hrec):
+        rec = _HCRec()
+        rec.hc, rec.prev = hrec, S.rec
+        if exists(S.X):
+            rec.xin, rec.yprev, rec.coef_prev = S.X, None, None
+        else:
+            rec.xin, rec.yprev, rec.coef_prev = S.M, S.y, S.coef
+        Mout, binp, coef = ops.hc_fwd(rec.xin, self._hc_params(hrec), yprev=rec.yprev, coef_prev=rec.coef_prev)
+        rec.coef = coef
+        rec.ycur = rec.dy = rec.dbin = None
+        S.X, S.M, S.y, S.coef, S.rec = None, Mout, None, coef, rec
+        if exists(run.tape):
+            run.tape.append(('hc', rec, S.key))
+        return binp, rec
+
+    def _hc_depth(self, S, rec, y):
+        S.y = y
+        rec.ycur = y
+
+    def _materialize(self, run, S):
+        if exists(S.X):
+            return
+        X, _, _ = ops.hc_fwd(S.M, None, yprev=S.y, coef_prev=S.coef, width=False)
+        if exists(run.tape):
+            run.tape.append(('mat', S.rec, S.key))
+        S.X, S.M, S.y, S.coef, S.rec = X, None, None, None, None
+
+    # -- one stream's conv / attention / feed-forward branches ------------------
+    def _branches(self, run, S, lr, ind, text):
+        B, N, Mtok = run.B, run.N, run.Mtok
+        D = S.D
+        tape = run.tape
+        key = S.key
+        L = self.depth
+        # ---- conv
+        binp, rec = self._hc_width(run, S, lr.hc[0])
+        cw = self._f(lr.conv.w, D * lr.conv.ks).view(D, lr.conv.ks)
+        cb = self._f(lr.conv.b, D)
+        pre, y = ops.dwconv_fwd(binp.view(B, N, D), run.mask_n, cw, cb)
+        y = y.view(Mtok, D)
+        self._hc_depth(S, rec, y)
+        if exists(tape):
+            tape.append(('conv', rec, lr, binp, pre, key))
+        # ---- attention
+        binp, rec = self._hc_width(run, S, lr.hc[1])
+        a = lr.attn
+        if text or not self.cond_on_time:
+            gam, off, rpb, gate = self._f(lr.attn_g, D).view(1, D), 0., Mtok, None
+        else:
+            gam, off, rpb = run.condall[:, (ind * 4 + 0) * D:(ind * 4 + 1) * D], 1., N
+            gate = run.gates[:, (ind * 4 + 1) * D:(ind * 4 + 2) * D]
+        xn, rn = ops.rmsnorm_fwd(binp, gam, off, rpb)
+        qkvg = torch.empty((Mtok, a.ldq), dtype=bf16, device=run.dev)[:, :a.cols]
+        ops.gemm_nt(xn, self._w(a.w, a.cols, D), bias=self._f(a.bias, a.cols), out=qkvg)
+        first = run.vfirst[key] is None
+        ast = ops.qkv_post_fwd(qkvg, B, a.H, N, run.rot[0], run.rot[1], run.vfirst[key])
+        if first:
+            run.vfirst[key] = ast.V
+        sid = (ind * 2 + int(text)) * 4
+        Og = ops.attn_fwd(ast, run.kmask, run.p_drop, run.seed, sid)
+        y = ops.gemm_nt(Og, self._w(a.out, D, a.I), colscale=gate, rows_per_batch=N)
+        self._hc_depth(S, rec, y)
+        if exists(tape):
+            tape.append(('attn', rec, lr, ind, text, binp, xn, rn, qkvg, ast, first, y, key, sid))
+        # ---- feed-forward
+        binp, rec = self._hc_width(run, S, lr.hc[2])
+        f = lr.ff
+        if text or not self.cond_on_time:
+            gam, off, rpb, gate = self._f(lr.ff_g, D).view(1, D), 0., Mtok, None
+        else:
+            gam, off, rpb = run.condall[:, (ind * 4 + 2) * D:(ind * 4 + 3) * D], 1., N
+            gate = run.gates[:, (ind * 4 + 3) * D:(ind * 4 + 4) * D]
+        xn, rn = ops.rmsnorm_fwd(binp, gam, off, rpb)
+        Hh = ops.gemm_nt(xn, self._w(f.w1, 2 * f.F, D), bias=self._f(f.b1, 2 * f.F))
+        act = ops.geglu_fwd(Hh, run.p_drop, run.seed, sid + 1)
+        y = ops.gemm_nt(act, self._w(f.w2, D, f.F), bias=self._f(f.b2, D), colscale=gate, rows_per_batch=N)
+        self._hc_depth(S, rec, y)
+        if exists(tape):
+            tape.append(('ff', rec, lr, ind, text, binp, xn, rn, Hh, act, y, key, sid + 1))
+
+    # -- GEMMs on the 4x stream tensors -----------------------------------------
+    def _cross(self, run, sx, st, tr):
+        """TextAudioCrossCondition (e2_tts.py:503-513) without the concat: dual-source K"""
+        self._materialize(run, sx)
+        self._materialize(run, st)
+        D, Dt = self.dim, self.dim_text
+        X, Tt = sx.X.view(-1, D), st.X.view(-1, Dt)
+        W = self._w(tr.cross, tr.cross_rows, D + Dt)
+        Xn = ops.gemm_nt(X, W[:D], a2=Tt, resid=X)
+        Tn = ops.gemm_nt(X, W[D:], a2=Tt, resid=Tt) if tr.cross_rows > D else Tt
+        if exists(run.tape):
+            run.tape.append(('cross', tr, X, Tt))
+        sx.X, st.X = Xn.view(-1, 4, D), Tn.view(-1, 4, Dt)
+
+    def _skip(self, run, sx, skip, sr):
+        """x = skip_proj(cat(x, skip)) (e2_tts.py:893-896) without the concat"""
+        self._materialize(run, sx)
+        D = self.dim
+        X, Sk = sx.X.view(-1, D), skip.view(-1, D)
+        Xn = ops.gemm_nt(X, self._w(sr.skip, D, 2 * D), a2=Sk)
+        if exists(run.tape):
+            run.tape.append(('skip_pop', sr, X, Sk))
+        sx.X = Xn.view(-1, 4, D)
+
+    # ------------------------------------------------------------------ backward schedule
+
+    def _run_backward(self, run, dout):
+        B, T, N, Mtok = run.B, run.T, run.N, run.Mtok
+        D, Dt, R, L = self.dim, self.dim_text, self.num_registers, self.depth
+        dev = run.dev
+        lay, g = self._layout, self._glob
+        gflat = torch.zeros(lay.n, dtype=f32, device=dev)
+        G = lambda off, *shape: self._g(gflat, off, *shape)
+
+        # tail
+        xsum, rn = run.tail
+        gfin = self._f(g.final_g, D).view(1, D)
+        dxs = ops.rmsnorm_bwd(dout.reshape(B * T, D).to(bf16).contiguous(), xsum, rn, gfin, 0., B * T, G(g.final_g, 1, D))
+        dX = torch.zeros((B, N, 4, D), dtype=bf16, device=dev)
+        dX[:, R:] = dxs.view(B, T, 1, D)
+        grads = {'x': dX.view(Mtok, 4, D), 't': None}
+        if run.has_text:
+            grads['t'] = torch.zeros((Mtok, 4, Dt), dtype=bf16, device=dev)
+        dvfirst = {'x': torch.zeros((B, self.heads, N, 64), dtype=f32, device=dev),
+                   't': torch.zeros((B, self.text_heads, N, 64), dtype=f32, device=dev) if run.has_text else None}
+        skip_grads = []
+
+        for ent in reversed(run.tape):
+            kind = ent[0]
+            if kind == 'hc':
+                _, rec, key = ent
+                hg = [G(o, *s) if len(s) else G(o, 1).view(()) for o, s in zip(rec.hc.offs, rec.hc.shapes)]
+                dR, dyprev = ops.hc_bwd(grads[key], xin=rec.xin, yprev=rec.yprev, coef_prev=rec.coef_prev,
+                                        dbin=rec.dbin, ycur=rec.ycur, coef=rec.coef,
+                                        params=self._hc_params(rec.hc), grads=hg)
+                grads[key] = dR
+                if exists(rec.yprev):
+                    rec.prev.dy = dyprev
+            elif kind == 'mat':
+                _, rec, key = ent
+                _, dy = ops.hc_bwd(grads[key], yprev=rec.ycur, coef_prev=rec.coef)
+                rec.dy = dy
+            elif kind == 'conv':
+                _, rec, lr, binp, pre, key = ent
+                C, ks = lr.conv.C, lr.conv.ks
+                cw = self._f(lr.conv.w, C * ks).view(C, ks)
+                dbin = ops.dwconv_bwd(rec.dy.view(B, N, C), pre, binp.view(B, N, C), run.mask_n, cw,
+                                      G(lr.conv.w, C, ks), G(lr.conv.b, C))
+                rec.dbin = dbin.view(Mtok, C)
+            elif kind == 'attn':
+                self._attn_bwd(run, ent, G, dvfirst)
+            elif kind == 'ff':
+                self._ff_bwd(run, ent, G)
+            elif kind == 'cross':
+                _, tr, X, Tt = ent
+                gx, gt = grads['x'].view(-1, D), grads['t'].view(-1, Dt)
+                WT = self._wT(tr.crossT)                       # (D+Dt, rows)
+                gW = G(tr.cross, tr.cross_rows, D + Dt)
+                ops.gemm_tn(gx, X, gW[:D, :D])
+                ops.gemm_tn(gx, Tt, gW[:D, D:])
+                if tr.cross_rows > D:
+                    ops.gemm_tn(gt, X, gW[D:, :D])
+                    ops.gemm_tn(gt, Tt, gW[D:, D:])
+                    ngx = ops.gemm_nt(gx, WT[:D], a2=gt, resid=gx)
+                    ngt = ops.gemm_nt(gx, WT[D:], a2=gt, resid=gt)
+                else:
+                    ngx = ops.gemm_nt(gx, WT[:D], resid=gx)
+                    ngt = ops.gemm_nt(gx, WT[D:], resid=gt)
+                grads['x'], grads['t'] = ngx.view(Mtok, 4, D), ngt.view(Mtok, 4, Dt)
+            elif kind == 'skip_pop':
+                _, sr, X, Sk = ent
+                gx = grads['x'].view(-1, D)
+                gW = G(sr.skip, D, 2 * D)
+                ops.gemm_tn(gx, X, gW[:, :D])
+                ops.gemm_tn(gx, Sk, gW[:, D:])
+                WT = self._wT(sr.skipT)                        # (2D, D)
+                skip_grads.append((gx, WT[D:]))
+                grads['x'] = ops.gemm_nt(gx, WT[:D]).view(Mtok, 4, D)
+            elif kind == 'skip_push':
+                gsrc, WTs = skip_grads.pop()
+                gx = grads['x'].view(-1, D)
+                grads['x'] = ops.gemm_nt(gsrc, WTs, resid=gx).view(Mtok, 4, D)
+            elif kind == 'layer':
+                if exists(self._grad_sync):
+                    self._grad_sync(gflat, ent[1].start, ent[1].end)
+            else:
+                raise AssertionError(kind)
+
+        # pack backward (4 identical streams -> sum; registers; abs-pos)
+        dX0 = grads['x'].view(B, N, 4, D).float().sum(dim=2)
+        G(g.registers, R, D).add_(dX0[:, :R].sum(dim=0))
+        dxs = dX0[:, R:]
+        if exists(g.abs_pos):
+            G(g.abs_pos, self.max_seq_len, D)[:T].add_(dxs.sum(dim=0))
+        dtext = None
+        if run.has_text:
+            dT0 = grads['t'].view(B, N, 4, Dt).float().sum(dim=2)
+            G(g.text_registers, R, Dt).add_(dT0[:, :R].sum(dim=0))
+            dtext = dT0[:, R:]
+        dcond = None
+        if self.cond_on_time:
+            dc = run.dcond.view(B, L, 4, D)
+            gv = run.gates.view(B, L, 4, D)
+            dc[:, :, 1].mul_(1. - gv[:, :, 1])
+            dc[:, :, 3].mul_(1. - gv[:, :, 3])
+            dcb = run.dcond.to(bf16)
+            ops.gemm_tn(dcb, run.cb, G(g.wcond, 4 * L * D, D))                    # d W_cond
+            G(g.bcond, 4 * L * D).add_(run.dcond.sum(dim=0))
+            KB = _r8(B)
+            dct = torch.zeros((4 * L * D, KB), dtype=bf16, device=dev)
+            dct[:, :B] = dcb.t()
+            dcT = torch.zeros((D, KB), dtype=f32, device=dev)
+            ops.gemm_tn(self._w(g.wcond, 4 * L * D, D), dct, dcT)                 # (D, B) = W_cond^T . dcond^T
+            dcond = dcT[:, :B].t().contiguous()
+        if exists(self._grad_sync):
+            self._grad_sync(gflat, 0, g.end)
+            self._grad_sync(gflat, None, None)          # wait for every slab
+        pgrads = [gflat[off:off + p.numel()].view(p.shape) if p.requires_grad else None for p, off in lay.slots]
+        return dxs, dcond, dtext, pgrads
+
+    def _attn_bwd(self, run, ent, G, dvfirst):
+        _, rec, lr, ind, text, binp, xn, rn, qkvg, ast, first, y, key, sid = ent
+        B, N, Mtok = run.B, run.N, run.Mtok
+        a = lr.attn
+        D = a.dim
+        if text or not self.cond_on_time:
+            gam, off, rpb = self._f(lr.attn_g, D).view(1, D), 0., Mtok
+            dgam = G(lr.attn_g, 1, D)
+            dao = rec.dy
+        else:
+            gam, off, rpb = run.condall[:, (ind * 4 + 0) * D:(ind * 4 + 1) * D], 1., N
+            dgam = run.dcond[:, (ind * 4 + 0) * D:(ind * 4 + 1) * D]
+            gate = run.gates[:, (ind * 4 + 1) * D:(ind * 4 + 2) * D]
+            dao = ops.gate_bwd(rec.dy, y, gate, run.dcond[:, (ind * 4 + 1) * D:(ind * 4 + 2) * D], N)
+        ops.gemm_tn(dao, ast.Og, G(a.out, D, a.I))
+        dOg = ops.gemm_nt(dao, self._wT(a.outT))                                   # (Mtok, I)
+        dQ, dK, dV, dgate = ops.attn_bwd(ast, dOg, run.kmask, run.p_drop, run.seed, sid)
+        dqkvg = ops.qkv_post_bwd(ast, dQ, dK, dV, dgate, qkvg, run.rot[0], run.rot[1],
+                                 None if first else run.vfirst[key], dvfirst[key], first_layer=first)
+        ops.gemm_tn(dqkvg, xn, G(a.w, a.cols, D))
+        nb = a.cols - 3 * a.I                                                      # gate (+ mix) bias gradients
+        assert nb % 2 == 0, 'odd head counts are not supported'
+        ops.colsum(dqkvg[:, 3 * a.I:], G(a.bias + 3 * a.I, nb))
+        # dgrad over the padded row (pad columns of dqkvg / rows of W^T are zero)
+        dq_full = dqkvg if a.ldq == a.cols else torch.as_strided(dqkvg, (Mtok, a.ldq), (a.ldq, 1))
+        dxn = ops.gemm_nt(dq_full, self._wT(a.wT))
+        rec.dbin = ops.rmsnorm_bwd(dxn, binp, rn, gam, off, rpb, dgam)
+
+    def _ff_bwd(self, run, ent, G):
+        _, rec, lr, ind, text, binp, xn, rn, Hh, act, y, key, sid = ent
+        N, Mtok = run.N, run.Mtok
+        f = lr.ff
+        D = f.dim
+        if text or not self.cond_on_time:
+            gam, off, rpb = self._f(lr.ff_g, D).view(1, D), 0., Mtok
+            dgam = G(lr.ff_g, 1, D)
+            dao = rec.dy
+        else:
+            gam, off, rpb = run.condall[:, (ind * 4 + 2) * D:(ind * 4 + 3) * D], 1., N
+            dgam = run.dcond[:, (ind * 4 + 2) * D:(ind * 4 + 3) * D]
+            gate = run.gates[:, (ind * 4 + 3) * D:(ind * 4 + 4) * D]
+            dao = ops.gate_bwd(rec.dy, y, gate, run.dcond[:, (ind * 4 + 3) * D:(ind * 4 + 4) * D], N)
+        ops.colsum(dao, G(f.b2, D))
+        ops.gemm_tn(dao, act, G(f.w2, D, f.F))
+        dact = ops.gemm_nt(dao, self._wT(f.w2T))
+        dH = ops.geglu_bwd(dact, Hh, run.p_drop, run.seed, sid)
+        ops.colsum(dH, G(f.b1, 2 * f.F))
+        ops.gemm_tn(dH, xn, G(f.w1, 2 * f.F, D))
+        dxn = ops.gemm_nt(dH, self._wT(f.w1T))
+        rec.dbin = ops.rmsnorm_bwd(dxn, binp, rn, gam, off, rpb, dgam)
+
+
+def _numel(shape):
+    n = 1
+    for s in shape:
+        n *= s
+    return n
+
+
+class _BackboneFn(torch.autograd.Function):
+    """one autograd node around the hand-scheduled forward / backward of the whole backbone"""
+
+    @staticmethod
+    def forward(ctx, module, x_in, cond, text_embed, mask, *params):
+        run = module._run_forward(x_in.detach(), cond.detach() if exists(cond) else None,
+                                  text_embed.detach() if exists(text_embed) else None, mask, True)
+        ctx.run, ctx.module = run, module
+        ctx.has_cond, ctx.has_text = exists(cond), exists(text_embed)
+        ctx.x_dtype = x_in.dtype
+        ctx.t_dtype = text_embed.dtype if exists(text_embed) else None
+        return run.out
+
+    @staticmethod
+    def backward(ctx, dout):
+        run, module = ctx.run, ctx.module
+        ctx.run = None
+        dx, dcond, dtext, pgrads = module._run_backward(run, dout.contiguous())
+        return (None, dx.to(ctx.x_dtype), dcond if ctx.has_cond else None,
+                dtext.to(ctx.t_dtype) if ctx.has_text else None, None, *pgrads)

@@ -1,0 +1,438 @@
+"""E2TTS / DurationPredictor / MelSpec with the reference's constructor and call signatures
+(/root/reference/e2_tts_pytorch/e2_tts.py:248-290, 956-1113, 1115-1595) on top of the HIP backbone.
+
+What stays in torch here is bookkeeping around the hot loop (masks, noise draws, tokenisation, the 100-channel
+input / output projections, the scalar loss): device memory + a handful of small element-wise ops.
+"""
+from __future__ import annotations
+
+from collections import namedtuple
+from random import random
+
+import torch
+import torch.nn.functional as F
+from torch import nn
+from torch.nn import Module
+
+from . import ops
+from .backbone import Transformer, default, exists
+
+LossBreakdown = namedtuple('LossBreakdown', ['flow', 'velocity_consistency'])                       # e2_tts.py:71
+E2TTSReturn = namedtuple('E2TTS', ['loss', 'cond', 'pred_flow', 'pred_data', 'loss_breakdown'])     # e2_tts.py:73
+
+
+# ------------------------------------------------------------------------------------------------ host helpers
+
+def set_if_missing_key(d, key, value):
+    if key not in d:
+        d.update(**{key: value})
+
+
+def list_str_to_tensor(text, padding_value=-1):
+    """UTF-8 byte tokenizer (e2_tts.py:128-135; like upstream the pad value is always -1)"""
+    ts = [torch.tensor([*bytes(t, 'UTF-8')], dtype=torch.long) for t in text]
+    return nn.utils.rnn.pad_sequence(ts, padding_value=-1, batch_first=True)
+
+
+def lens_to_mask(t, length=None):                              # e2_tts.py:173-182
+    if not exists(length):
+        length = int(t.amax())
+    seq = torch.arange(length, device=t.device)
+    return seq[None, :] < t[:, None]
+
+
+def mask_from_start_end_indices(seq_len, start, end):          # e2_tts.py:184-191
+    max_seq_len = int(seq_len.max().item())
+    seq = torch.arange(max_seq_len, device=start.device).long()
+    return (seq[None, :] >= start[:, None]) & (seq[None, :] < end[:, None])
+
+
+def pad_to_length(t, length, value=None):                      # e2_tts.py:226-235
+    seq_len = t.shape[-1]
+    if length > seq_len:
+        t = F.pad(t, (0, length - seq_len), value=value)
+    return t[..., :length]
+
+
+def mask_from_frac_lengths(seq_len, frac_lengths, max_length=None, rand=None):       # e2_tts.py:193-210
+    lengths = (frac_lengths * seq_len).long()
+    max_start = seq_len - lengths
+    if rand is None:
+        rand = torch.rand_like(frac_lengths)
+    start = (max_start * rand).long().clamp(min=0)
+    end = start + lengths
+    out = mask_from_start_end_indices(seq_len, start, end)
+    if exists(max_length):
+        out = pad_to_length(out, max_length)
+    return out
+
+
+def maybe_masked_mean(t, mask=None):                           # e2_tts.py:212-224
+    if not exists(mask):
+        return t.mean(dim=1)
+    t = torch.where(mask[..., None], t, torch.zeros_like(t))
+    return t.sum(dim=1) / mask.float().sum(dim=1).clamp(min=1.)[:, None]
+
+
+def project(x, y):                                             # e2_tts.py:113-124 (fp64, per flattened sample)
+    shape, dtype = x.shape, x.dtype
+    xf, yf = x.reshape(shape[0], -1).double(), y.reshape(shape[0], -1).double()
+    unit = F.normalize(yf, dim=-1)
+    parallel = (xf * unit).sum(dim=-1, keepdim=True) * unit
+    orthogonal = xf - parallel
+    return parallel.reshape(shape).to(dtype), orthogonal.reshape(shape).to(dtype)
+
+
+# ------------------------------------------------------------------------------------------------ MelSpec
+
+def _melscale_fbanks_htk(n_freqs, f_min, f_max, n_mels, sample_rate):
+    """torchaudio.functional.melscale_fbanks(norm=None, mel_scale='htk'); built once on the host"""
+    import math
+    all_freqs = torch.linspace(0, sample_rate // 2, n_freqs)
+    m_min = 2595.0 * math.log10(1.0 + f_min / 700.0)
+    m_max = 2595.0 * math.log10(1.0 + f_max / 700.0)
+    m_pts = torch.linspace(m_min, m_max, n_mels + 2)
+    f_pts = 700.0 * (10 ** (m_pts / 2595.0) - 1.0)
+    f_diff = f_pts[1:] - f_pts[:-1]
+    slopes = f_pts.unsqueeze(0) - all_freqs.unsqueeze(1)
+    down = (-1.0 * slopes[:, :-2]) / f_diff[:-1]
+    up = slopes[:, 2:] / f_diff[1:]
+    return torch.max(torch.zeros(1), torch.min(down, up))
+
+
+class _Spectrogram(Module):
+    def __init__(self, win_length):
+        super().__init__()
+        self.register_buffer('window', torch.hann_window(win_length, periodic=True))
+
+
+class _MelScale(Module):
+    def __init__(self, n_mels, sample_rate, n_stft):
+        super().__init__()
+        self.register_buffer('fb', _melscale_fbanks_htk(n_stft, 0., float(sample_rate // 2), n_mels, sample_rate))
+
+
+class _MelSpectrogram(Module):      # buffer names of torchaudio.transforms.MelSpectrogram (state_dict keys, Appendix B)
+    def __init__(self, sample_rate, n_fft, win_length, n_mels):
+        super().__init__()
+        self.spectrogram = _Spectrogram(win_length)
+        self.mel_scale = _MelScale(n_mels, sample_rate, n_fft // 2 + 1)
+
+
+class MelSpec(Module):
+    """e2_tts.py:248-290: reflect-pad STFT magnitude -> htk mel filterbank -> log(clamp(1e-5)), on the HIP kernel."""
+
+    def __init__(self, filter_length=1024, hop_length=256, win_length=1024, n_mel_channels=100,
+                 sampling_rate=24_000, normalize=False, power=1, norm=None, center=True):
+        super().__init__()
+        if norm is not None or normalize or power != 1 or not center or win_length != filter_length:
+            raise NotImplementedError('only the reference defaults (power=1, center, norm=None) are built')
+        self.n_mel_channels = n_mel_channels
+        self.sampling_rate = sampling_rate
+        self.filter_length, self.hop_length = filter_length, hop_length
+        self.mel_stft = _MelSpectrogram(sampling_rate, filter_length, win_length, n_mel_channels)
+        self.register_buffer('dummy', torch.tensor(0), persistent=False)
+
+    def forward(self, inp):
+        if inp.ndim == 3:
+            inp = inp.squeeze(1)
+        assert inp.ndim == 2
+        if self.dummy.device != inp.device:
+            self.to(inp.device)
+        return ops.melspec(inp, self.mel_stft.spectrogram.window, self.mel_stft.mel_scale.fb,
+                           self.filter_length, self.hop_length)          # (b, n_mels, frames)
+
+
+# ------------------------------------------------------------------------------------------------ small modules
+
+class CharacterEmbed(Module):                                  # e2_tts.py:390-412
+    def __init__(self, dim, num_embeds=256):
+        super().__init__()
+        self.dim = dim
+        self.embed = nn.Embedding(num_embeds + 1, dim)
+
+    def forward(self, text, max_seq_len, **kwargs):
+        text = text + 1
+        text = text[:, :max_seq_len]
+        text = pad_to_length(text, max_seq_len, value=0)
+        return self.embed(text)
+
+
+class HLGaussLayer(Module):                                    # hl_gauss_pytorch.HLGaussLayer, regression mode (A.7)
+    def __init__(self, dim, hl_gauss_loss=None, use_regression=True, regress_activation=None):
+        super().__init__()
+        if not use_regression or hl_gauss_loss is not None:
+            raise NotImplementedError('only the regression mode of HLGaussLayer is built')
+        self.to_pred = nn.Linear(dim, 1, bias=False)
+        self.act = default(regress_activation, nn.Identity())
+
+    def forward(self, embed, target=None):
+        pred = self.act(self.to_pred(embed)).squeeze(-1)
+        if not exists(target):
+            return pred
+        return F.mse_loss(pred, target)
+
+
+def _resolve_tokenizer(tokenizer, text_num_embeds):
+    if callable(tokenizer):
+        assert exists(text_num_embeds), '`text_num_embeds` must be given if supplying your own tokenizer encode function'
+        return tokenizer, text_num_embeds
+    if tokenizer == 'char_utf8':
+        return list_str_to_tensor, 256
+    if tokenizer == 'phoneme_en':
+        raise NotImplementedError('phoneme_en needs g2p_en + nltk data (no network here); pass a callable tokenizer')
+    raise ValueError(f'unknown tokenizer string {tokenizer}')
+
+
+# ------------------------------------------------------------------------------------------------ DurationPredictor
+
+class DurationPredictor(Module):                               # e2_tts.py:956-1113
+    def __init__(self, transformer, num_channels=None, mel_spec_kwargs: dict = dict(), char_embed_kwargs: dict = dict(),
+                 text_num_embeds=None, num_freq_tokens=1, hl_gauss_loss=None, use_regression=True,
+                 tokenizer='char_utf8'):
+        super().__init__()
+        assert num_freq_tokens > 0
+        if num_freq_tokens != 1:
+            raise NotImplementedError('num_freq_tokens > 1 (has_freq_axis) is not built')
+        self.num_freq_tokens, self.has_freq_axis = 1, False
+        if isinstance(transformer, dict):
+            transformer = dict(transformer)
+            set_if_missing_key(transformer, 'has_freq_axis', False)
+            transformer = Transformer(**transformer, cond_on_time=False)
+        assert transformer.has_freq_axis == self.has_freq_axis
+        self.mel_spec = MelSpec(**mel_spec_kwargs)
+        self.num_channels = default(num_channels, self.mel_spec.n_mel_channels)
+        self.transformer = transformer
+        self.dim = transformer.dim
+        self.proj_in = nn.Linear(self.num_channels, self.dim)
+        self.tokenizer, text_num_embeds = _resolve_tokenizer(tokenizer, text_num_embeds)
+        self.embed_text = CharacterEmbed(transformer.dim_text, num_embeds=text_num_embeds, **char_embed_kwargs)
+        self.hl_gauss_layer = HLGaussLayer(self.dim, hl_gauss_loss=hl_gauss_loss, use_regression=use_regression,
+                                           regress_activation=nn.Softplus())
+
+    def forward(self, x, *, text=None, lens=None, return_loss=True, _rand_frac_index=None):
+        if x.ndim == 2:
+            x = self.mel_spec(x).transpose(1, 2)
+            assert x.shape[-1] == self.dim                      # reference quirk (e2_tts.py:1055)
+        x = self.proj_in(x)
+        batch, seq_len, device = x.shape[0], x.shape[-2], x.device
+        text_embed = None
+        if exists(text):
+            if isinstance(text, list):
+                text = list_str_to_tensor(text).to(device)
+                assert text.shape[0] == batch
+            text_embed = self.embed_text(text, seq_len)
+        if not exists(lens):
+            lens = torch.full((batch,), seq_len, device=device)
+        mask = lens_to_mask(lens, length=seq_len)
+        if return_loss:
+            rand_frac_index = _rand_frac_index if exists(_rand_frac_index) else x.new_zeros(batch).uniform_(0, 1)
+            rand_index = (rand_frac_index * lens).long()
+            seq = torch.arange(seq_len, device=device)
+            mask = mask & (seq[None, :] < rand_index[:, None])
+        embed = self.transformer(x, mask=mask, text_embed=text_embed)
+        pooled = maybe_masked_mean(embed, mask)
+        if not return_loss:
+            return self.hl_gauss_layer(pooled)
+        return self.hl_gauss_layer(pooled, lens.float())
+
+
+# ------------------------------------------------------------------------------------------------ E2TTS
+
+def _odeint_midpoint(fn, y0, t):
+    """torchdiffeq.odeint(method='midpoint') on the given grid; returns the final state only"""
+    y = y0
+    for t0, t1 in zip(t[:-1], t[1:]):
+        dt = t1 - t0
+        f0 = fn(t0, y)
+        y_mid = y + f0 * (dt * 0.5)
+        y = y + dt * fn(t0 + dt * 0.5, y_mid)
+    return y
+
+
+class E2TTS(Module):
+    def __init__(
+        self,
+        transformer=None,
+        duration_predictor=None,
+        odeint_kwargs: dict = dict(atol=1e-5, rtol=1e-5, method='midpoint'),
+        cond_drop_prob=0.25,
+        num_channels=None,
+        mel_spec_module=None,
+        num_freq_tokens=1,
+        char_embed_kwargs: dict = dict(),
+        mel_spec_kwargs: dict = dict(),
+        frac_lengths_mask=(0.7, 1.),
+        concat_cond=False,
+        interpolated_text=False,
+        text_num_embeds=None,
+        tokenizer='char_utf8',
+        use_vocos=True,
+        pretrained_vocos_path='charactr/vocos-mel-24khz',
+        sampling_rate=None,
+        velocity_consistency_weight=0.,
+    ):
+        super().__init__()
+        assert num_freq_tokens > 0
+        if num_freq_tokens != 1 or concat_cond or interpolated_text:
+            raise NotImplementedError('num_freq_tokens > 1 / concat_cond / interpolated_text are not built')
+        if odeint_kwargs.get('method', 'midpoint') != 'midpoint':
+            raise NotImplementedError('only the midpoint solver (the reference default) is built')
+        self.num_freq_tokens, self.has_freq_axis = 1, False
+        if isinstance(transformer, dict):
+            transformer = dict(transformer)
+            set_if_missing_key(transformer, 'has_freq_axis', False)
+            transformer = Transformer(**transformer, cond_on_time=True)
+        assert transformer.has_freq_axis == self.has_freq_axis
+        self.transformer = transformer
+        if isinstance(duration_predictor, dict):
+            duration_predictor = DurationPredictor(**duration_predictor)
+        dim, dim_text = transformer.dim, transformer.dim_text
+        self.dim, self.dim_text = dim, dim_text
+        self.frac_lengths_mask = frac_lengths_mask
+        self.duration_predictor = duration_predictor
+        self.odeint_kwargs = odeint_kwargs
+        self.mel_spec = default(mel_spec_module, MelSpec(**mel_spec_kwargs))
+        num_channels = default(num_channels, self.mel_spec.n_mel_channels)
+        self.num_channels = num_channels
+        self.sampling_rate = default(sampling_rate, getattr(self.mel_spec, 'sampling_rate', None))
+        self.concat_cond = False
+        self.proj_in = nn.Linear(num_channels, dim)
+        self.cond_proj_in = nn.Linear(num_channels, dim)
+        self.to_pred = nn.Linear(dim, num_channels)
+        self.tokenizer, text_num_embeds = _resolve_tokenizer(tokenizer, text_num_embeds)
+        self.cond_drop_prob = cond_drop_prob
+        self.embed_text = CharacterEmbed(dim_text, num_embeds=text_num_embeds, **char_embed_kwargs)
+        self.register_buffer('zero', torch.tensor(0.), persistent=False)
+        self.velocity_consistency_weight = velocity_consistency_weight
+        # the reference default downloads charactr/vocos-mel-24khz from the HF hub (e2_tts.py:1244); the vocoder is
+        # outside the hot path and there is no network here
+        self.vocos = None
+        if use_vocos:
+            try:
+                from vocos import Vocos
+                self.vocos = Vocos.from_pretrained(pretrained_vocos_path)
+            except Exception as e:      # noqa: BLE001
+                raise RuntimeError('use_vocos=True needs the `vocos` package and hub access; construct with '
+                                   'use_vocos=False and pass `vocoder=` to sample()') from e
+
+    @property
+    def device(self):
+        return next(self.parameters()).device
+
+    def transformer_with_pred_head(self, x, cond, times, mask=None, text=None, drop_text_cond=None,
+                                   return_drop_text_cond=False):
+        seq_len = x.shape[-2]
+        drop_text_cond = default(drop_text_cond, self.training and random() < self.cond_drop_prob)
+        x = self.proj_in(x) + self.cond_proj_in(cond)
+        text_embed = None
+        if exists(text) and not drop_text_cond:
+            text_embed = self.embed_text(text, seq_len, mask=mask)
+        embed = self.transformer(x, times=times, mask=mask, text_embed=text_embed)
+        pred = self.to_pred(embed)
+        if not return_drop_text_cond:
+            return pred
+        return pred, drop_text_cond
+
+    def cfg_transformer_with_pred_head(self, *args, cfg_strength: float = 1., cfg_null_model=None,
+                                       remove_parallel_component: bool = True, keep_parallel_frac: float = 0., **kwargs):
+        pred = self.transformer_with_pred_head(*args, drop_text_cond=False, **kwargs)
+        if cfg_strength < 1e-5:
+            return pred
+        null_drop_text_cond = not exists(cfg_null_model)
+        cfg_null_model = default(cfg_null_model, self)
+        null_pred = cfg_null_model.transformer_with_pred_head(*args, drop_text_cond=null_drop_text_cond, **kwargs)
+        cfg_update = pred - null_pred
+        if remove_parallel_component:
+            parallel, orthogonal = project(cfg_update, pred)
+            cfg_update = orthogonal + parallel * keep_parallel_frac
+        return pred + cfg_update * cfg_strength
+
+    @torch.no_grad()
+    def sample(self, cond, *, text=None, lens=None, duration=None, steps=32, cfg_strength=1., cfg_null_model=None,
+               max_duration=4096, vocoder=None, return_raw_output=None, save_to_filename=None, _y0=None):
+        self.eval()
+        if cond.ndim == 2:
+            cond = self.mel_spec(cond).transpose(1, 2)
+            assert cond.shape[-1] == self.num_channels
+        batch, cond_seq_len, device = cond.shape[0], cond.shape[1], cond.device
+        if not exists(lens):
+            lens = torch.full((batch,), cond_seq_len, device=device, dtype=torch.long)
+        if isinstance(text, list):
+            text = self.tokenizer(text).to(device)
+            assert text.shape[0] == batch
+        if exists(text):
+            text_lens = (text != -1).sum(dim=-1)
+            lens = torch.maximum(text_lens, lens)
+        cond_mask = lens_to_mask(lens)
+        if exists(duration):
+            if isinstance(duration, int):
+                duration = torch.full((batch,), duration, device=device, dtype=torch.long)
+        elif exists(self.duration_predictor):
+            duration = self.duration_predictor(cond, text=text, lens=lens, return_loss=False).long()
+        duration = torch.maximum(lens + 1, duration)
+        duration = duration.clamp(max=max_duration)
+        assert duration.shape[0] == batch
+        max_dur = int(duration.amax())
+        cond = F.pad(cond, (0, 0, 0, max_dur - cond_seq_len), value=0.)
+        cond_mask = F.pad(cond_mask, (0, max_dur - cond_mask.shape[-1]), value=False)
+        cond_mask = cond_mask[..., None]
+        mask = lens_to_mask(duration)
+        step_cond = torch.where(cond_mask, cond, torch.zeros_like(cond))
+
+        def fn(t, x):
+            return self.cfg_transformer_with_pred_head(x, step_cond, times=t, text=text, mask=mask,
+                                                       cfg_strength=cfg_strength, cfg_null_model=cfg_null_model)
+
+        y0 = _y0 if exists(_y0) else torch.randn_like(cond)
+        t = torch.linspace(0, 1, steps, device=self.device)
+        sampled = _odeint_midpoint(fn, y0, t)
+        out = torch.where(cond_mask, cond, sampled)
+        if exists(return_raw_output) and return_raw_output:
+            return out
+        if exists(vocoder):
+            assert not exists(self.vocos), '`use_vocos` should not be turned on if you are passing in a custom `vocoder` on sampling'
+            out = vocoder(out.transpose(1, 2))
+        elif exists(self.vocos):
+            raise NotImplementedError('vocos decode is outside the hot path (SURVEY.md section 2 row 3)')
+        if exists(save_to_filename):
+            raise NotImplementedError('audio file output needs torchaudio (not available); use the returned tensors')
+        return out
+
+    def forward(self, inp, *, text=None, times=None, lens=None, velocity_consistency_model=None,
+                velocity_consistency_delta=1e-5, _noise=None):
+        """`times` is accepted and ignored exactly like the reference (e2_tts.py:1473,1523).
+        _noise: optional dict(x0, times, frac_lengths, span_rand, drop_text_cond) -- explicit draws for parity tests."""
+        _noise = default(_noise, {})
+        if exists(velocity_consistency_model) and self.velocity_consistency_weight > 0.:
+            raise NotImplementedError('velocity-consistency loss is a default-off variant (SURVEY.md section 8f item 4)')
+        if inp.ndim == 2:
+            inp = self.mel_spec(inp).transpose(1, 2)
+            assert inp.shape[-1] == self.num_channels
+        batch, seq_len, dtype, device = inp.shape[0], inp.shape[1], inp.dtype, self.device
+        if isinstance(text, list):
+            text = self.tokenizer(text).to(device)
+            assert text.shape[0] == batch
+        if not exists(lens):
+            lens = torch.full((batch,), seq_len, device=device)
+        mask = lens_to_mask(lens, length=seq_len)
+        frac_lengths = _noise.get('frac_lengths')
+        if frac_lengths is None:
+            frac_lengths = torch.zeros((batch,), device=device).float().uniform_(*self.frac_lengths_mask)
+        rand_span_mask = mask_from_frac_lengths(lens, frac_lengths, max_length=seq_len, rand=_noise.get('span_rand'))
+        rand_span_mask = rand_span_mask & mask
+        x1 = inp
+        x0 = _noise['x0'] if 'x0' in _noise else torch.randn_like(x1)
+        times = _noise['times'] if 'times' in _noise else torch.rand((batch,), dtype=dtype, device=device)
+        t = times[:, None, None]
+        w = (1. - t) * x0 + t * x1
+        flow = x1 - x0
+        cond = torch.where(rand_span_mask[..., None], torch.zeros_like(x1), x1)
+        pred, _ = self.transformer_with_pred_head(w, cond, times=times, text=text, mask=mask,
+                                                  drop_text_cond=_noise.get('drop_text_cond'),
+                                                  return_drop_text_cond=True)
+        velocity_loss = self.zero
+        loss = F.mse_loss(pred, flow, reduction='none')
+        loss = loss[rand_span_mask].mean()
+        total_loss = loss + velocity_loss * self.velocity_consistency_weight
+        return E2TTSReturn(total_loss, cond, pred, x0 + pred, LossBreakdown(loss, velocity_loss))

@@ -56,7 +56,7 @@ def gemm_nt(a, b, *, a2=None, out=None, out_dtype=bf16, accumulate=False, bias=N
     if bias is not None:
         assert bias.dtype == f32 and bias.numel() == N and bias.is_contiguous()
     if colscale is not None:
-        assert colscale.dtype == f32 and colscale.is_contiguous() and colscale.shape[-1] == N and rows_per_batch > 0
+        assert colscale.dtype == f32 and colscale.dim() == 2 and colscale.stride(1) == 1 and colscale.shape[1] == N and rows_per_batch > 0
     if rowmask is not None:
         assert rowmask.dtype in (torch.uint8, torch.bool) and rowmask.numel() == M and rowmask.is_contiguous()
     ldr = 0
@@ -65,7 +65,7 @@ def gemm_nt(a, b, *, a2=None, out=None, out_dtype=bf16, accumulate=False, bias=N
         ldr = resid.stride(0)
     _lib.get().e2k_gemm_nt_bf16(_p(a), lda, K1, _p(a2), lda2, K2, _p(b), ldb, _p(out), out.stride(0),
                                 int(out.dtype == f32), int(accumulate), M, N, _p(bias), _p(colscale),
-                                int(rows_per_batch), _p(rowmask), _p(resid), ldr, _stream(a))
+                                0 if colscale is None else colscale.stride(0), int(rows_per_batch), _p(rowmask), _p(resid), ldr, _stream(a))
     return out
 
 
@@ -137,29 +137,30 @@ def rmsnorm_fwd(x, gamma, gamma_off, rows_per_batch):
     """x (M,D) bf16; gamma fp32 (nb,D).  -> (y bf16, rn fp32 (M,))"""
     _chk(x, gamma)
     M, D = x.shape
-    assert x.dtype == bf16 and x.is_contiguous() and gamma.dtype == f32 and gamma.is_contiguous()
+    assert x.dtype == bf16 and x.is_contiguous() and gamma.dtype == f32 and gamma.dim() == 2 and gamma.stride(1) == 1
     y = torch.empty_like(x)
     rn = torch.empty((M,), dtype=f32, device=x.device)
-    _lib.get().e2k_rmsnorm_fwd(_p(x), _p(gamma), float(gamma_off), int(rows_per_batch), _p(y), _p(rn), M, D, _stream(x))
+    _lib.get().e2k_rmsnorm_fwd(_p(x), _p(gamma), gamma.stride(0), float(gamma_off), int(rows_per_batch), _p(y), _p(rn),
+                               M, D, _stream(x))
     return y, rn
 
 
 def rmsnorm_bwd(dy, x, rn, gamma, gamma_off, rows_per_batch, dgamma):
     _chk(dy, x, rn, gamma, dgamma)
     M, D = x.shape
-    assert dy.dtype == bf16 and dy.is_contiguous() and dgamma.dtype == f32 and dgamma.is_contiguous()
+    assert dy.dtype == bf16 and dy.is_contiguous() and dgamma.dtype == f32 and dgamma.stride() == gamma.stride()
     dx = torch.empty_like(x)
-    _lib.get().e2k_rmsnorm_bwd(_p(dy), _p(x), _p(rn), _p(gamma), float(gamma_off), int(rows_per_batch), _p(dx),
-                               _p(dgamma), M, D, _stream(x))
+    _lib.get().e2k_rmsnorm_bwd(_p(dy), _p(x), _p(rn), _p(gamma), gamma.stride(0), float(gamma_off), int(rows_per_batch),
+                               _p(dx), _p(dgamma), M, D, _stream(x))
     return dx
 
 
 def gate_bwd(dy, y, g, gsum, rows_per_batch):
     _chk(dy, y, g, gsum)
     M, D = y.shape
-    assert dy.is_contiguous() and y.is_contiguous() and g.dtype == f32 and gsum.dtype == f32
+    assert dy.is_contiguous() and y.is_contiguous() and g.dtype == f32 and gsum.dtype == f32 and g.stride() == gsum.stride()
     dao = torch.empty_like(dy)
-    _lib.get().e2k_gate_bwd(_p(dy), _p(y), _p(g), _p(dao), _p(gsum), M, D, int(rows_per_batch), _stream(y))
+    _lib.get().e2k_gate_bwd(_p(dy), _p(y), _p(g), _p(dao), _p(gsum), g.stride(0), M, D, int(rows_per_batch), _stream(y))
     return dao
 
 

@@ -27,7 +27,7 @@ extern "C" {
 
 int e2k_version(void);
 
-/* C[M,N] = ((([A1|A2] . B^T) + bias[n]) * colscale[m / rows_per_batch][n]) * rowmask[m] + resid[m][n]
+/* C[M,N] = ((([A1|A2] . B^T) + bias[n]) * colscale[(m / rows_per_batch) * lds + n]) * rowmask[m] + resid[m][n]
  * A1 (M,K1), A2 (M,K2) optional second K-panel (K2 = 0: none), B (N,K1+K2), all bf16 row-major.
  * C bf16 (out_f32 = 0) or fp32 (out_f32 = 1; accumulate = 1 adds into C).  bias/colscale fp32, rowmask u8,
  * resid bf16 (any of them NULL = skipped).  K1, K2 multiples of 8.
@@ -37,8 +37,8 @@ int e2k_version(void);
  * (e2_tts.py:1267-1277,1296) and all of their dgrad GEMMs. */
 int e2k_gemm_nt_bf16(const void* A1, int64_t lda1, int K1, const void* A2, int64_t lda2, int K2,
                      const void* B, int64_t ldb, void* C, int64_t ldc, int out_f32, int accumulate,
-                     int M, int N, const float* bias, const float* colscale, int rows_per_batch,
-                     const uint8_t* rowmask, const void* resid, int64_t ldr, void* stream);
+                     int M, int N, const float* bias, const float* colscale, int64_t lds,
+                     int rows_per_batch, const uint8_t* rowmask, const void* resid, int64_t ldr, void* stream);
 
 /* C[N,K] += A[M,N]^T . B[M,K]  (weight gradients; C fp32, A = dY, B = X, bf16).  The token dimension M is
  * split over `splits` workgroups per tile (0 = choose), partial tiles are combined with fp32 atomics.
@@ -74,18 +74,19 @@ int e2k_hc_bwd(const void* Xin, const void* yprev, const float* coef_prev, const
 
 /* ---- RMSNorm / AdaptiveRMSNorm (x_transformers; e2_tts.py:615,637,645,688,691,729,908,937) ----
  * y[m] = x[m] / max(|x[m]|, 1e-12) * sqrt(D) * (gamma[m / rows_per_batch] + gamma_off);  rn[m] = 1 / max(|x[m]|, 1e-12)
- * gamma fp32 (nb, D): nb = 1 (plain RMSNorm `g`, gamma_off = 0) or one row per batch element
+ * gamma fp32 (nb rows, ldg floats apart; dgamma uses the same stride): nb = 1 (plain RMSNorm `g`, gamma_off = 0) or one row per batch element
  * (AdaptiveRMSNorm: to_gamma(cond), gamma_off = 1). */
-int e2k_rmsnorm_fwd(const void* x, const float* gamma, float gamma_off, int rows_per_batch, void* y,
-                    float* rn, int M, int D, void* stream);
+int e2k_rmsnorm_fwd(const void* x, const float* gamma, int64_t ldg, float gamma_off, int rows_per_batch,
+                    void* y, float* rn, int M, int D, void* stream);
 /* dx and dgamma (ACCUMULATED, fp32 (nb, D)) */
-int e2k_rmsnorm_bwd(const void* dy, const void* x, const float* rn, const float* gamma, float gamma_off,
-                    int rows_per_batch, void* dx, float* dgamma, int M, int D, void* stream);
+int e2k_rmsnorm_bwd(const void* dy, const void* x, const float* rn, const float* gamma, int64_t ldg,
+                    float gamma_off, int rows_per_batch, void* dx, float* dgamma, int M, int D,
+                    void* stream);
 
 /* AdaLN-Zero gate backward (AdaLNZero, e2_tts.py:346-351; the forward multiply is the colscale epilogue of
  * e2k_gemm_nt_bf16):  dao = dy * g[b];  gsum[b][d] += sum_rows dy * y   (y = gated output, g = sigmoid gate) */
-int e2k_gate_bwd(const void* dy, const void* y, const float* g, void* dao, float* gsum, int M, int D,
-                 int rows_per_batch, void* stream);
+int e2k_gate_bwd(const void* dy, const void* y, const float* g, void* dao, float* gsum, int64_t ldg,
+                 int M, int D, int rows_per_batch, void* stream);
 
 /* GEGLU (x_transformers.FeedForward(glu=True): `x, gate = proj(x).chunk(2); x * gelu(gate)` + Dropout, exact erf GELU).
  * H (M, 2F) bf16 with row stride ldh; out (M, F).  p_drop = 0 disables dropout; the keep mask is the counter hash

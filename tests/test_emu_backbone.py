@@ -1,0 +1,97 @@
+"""Host logic check of the whole hand-scheduled backbone (forward + backward) against the oracle Transformer."""
+import random
+
+import pytest
+import torch
+
+from oracle import e2tts_oracle as O
+
+bf16 = torch.bfloat16
+
+
+def rel(a, b):
+    return ((a.float() - b.float()).abs().max() / b.float().abs().max().clamp_min(1e-20)).item()
+
+
+def rel2(a, b):
+    """relative L2 error: bf16 rounding noise through the whole backbone sits at 1-3 %, a wrong term at >= 10 %"""
+    return ((a.float() - b.float()).norm() / b.float().norm().clamp_min(1e-20)).item()
+
+
+def randomize(model, seed=0):
+    """make every zero-initialised path (AdaLN, cross-condition, adaptive gamma, HC dynamics) active"""
+    g = torch.Generator().manual_seed(seed)
+    with torch.no_grad():
+        for name, p in model.named_parameters():
+            if name.endswith('to_gamma.weight') or 'text_to_audio' in name or 'audio_to_text' in name:
+                p.copy_(torch.randn(p.shape, generator=g) * (0.5 / p.shape[-1] ** 0.5))
+            elif name.endswith('to_gamma.bias'):
+                p.copy_(torch.randn(p.shape, generator=g) * 0.5 - 1.0)
+            elif 'dynamic_alpha_fn' in name or 'dynamic_beta_fn' in name:
+                p.copy_(torch.randn(p.shape, generator=g) * (p.shape[0] ** -0.5))
+            elif 'dynamic_alpha_scale' in name or 'dynamic_beta_scale' in name:
+                p.fill_(0.3)
+            elif 'norm.gamma' in name:
+                p.copy_(torch.randn(p.shape, generator=g) * 0.2)
+            elif 'to_v_head_gate.bias' in name or 'to_value_residual_mix.0.bias' in name:
+                p.copy_(torch.randn(p.shape, generator=g))
+            elif 'to_v_head_gate.weight' in name or 'to_value_residual_mix.0.weight' in name:
+                p.copy_(torch.randn(p.shape, generator=g) * 0.05)
+            elif name.endswith('.g'):
+                p.copy_(1 + torch.randn(p.shape, generator=g) * 0.2)
+
+
+@pytest.mark.parametrize('cond_on_time,with_text,with_mask', [(True, True, True), (False, False, False)])
+def test_backbone(emu, cond_on_time, with_text, with_mask):
+    from e2_tts_pytorch_amd import Transformer
+    random.seed(0)
+    torch.manual_seed(0)
+    kw = dict(dim=256, depth=4, heads=2, dropout=0., max_seq_len=64)
+    ref = O.Transformer(**kw, cond_on_time=cond_on_time)
+    randomize(ref)
+    mod = Transformer(**kw, cond_on_time=cond_on_time)
+    missing = mod.load_state_dict(ref.state_dict(), strict=True)
+    B, T = 2, 40
+    x = torch.randn(B, T, 256)
+    times = torch.rand(B) if cond_on_time else None
+    text = torch.randn(B, T, 128) if with_text else None
+    mask = None
+    if with_mask:
+        mask = torch.arange(T)[None] < torch.tensor([T, T - 9])[:, None]
+    R = torch.randn(B, T, 256)
+
+    xr = x.clone().requires_grad_(True)
+    tr = text.clone().requires_grad_(True) if with_text else None
+    out_r = ref(xr, times=times, mask=mask, text_embed=tr)
+    (out_r * R).sum().backward()
+
+    xk = x.clone().requires_grad_(True)
+    tk = text.clone().requires_grad_(True) if with_text else None
+    out_k = mod(xk, times=times, mask=mask, text_embed=tk)
+    assert rel(out_k, out_r) < 3e-2, rel(out_k, out_r)
+    (out_k * R).sum().backward()
+    assert rel2(out_k, out_r) < 2e-2, rel2(out_k, out_r)
+    assert rel2(xk.grad, xr.grad) < 5e-2, rel2(xk.grad, xr.grad)
+    if with_text:
+        assert rel2(tk.grad, tr.grad) < 5e-2, rel2(tk.grad, tr.grad)
+    refp = dict(ref.named_parameters())
+    bad, errs = [], []
+    for name, p in mod.named_parameters():
+        gr = refp[name].grad
+        if gr is None:
+            assert p.grad is None or float(p.grad.abs().max()) == 0., name
+            continue
+        assert p.grad is not None, name
+        err = rel2(p.grad, gr)
+        errs.append((err, name))
+        if p.numel() == 1:       # heavily cancelling sums over all tokens: absolute slack (unit-tested in test_emu_hc)
+            ok = abs(p.grad.item() - gr.item()) <= 0.25 * abs(gr.item()) + 2.0
+        else:
+            ok = err <= (0.35 if p.numel() <= 32 else 0.15)   # bf16 noise accumulated over the whole backward; a missing term shows as >= 0.3
+        if not ok:
+            bad.append((name, err, float(gr.norm())))
+    errs.sort(reverse=True)
+    print('worst parameter-gradient errors:', errs[:8])
+    import statistics
+    print('median err', statistics.median(e for e, _ in errs), 'n', len(errs), 'out', rel2(out_k, out_r), 'dx', rel2(xk.grad, xr.grad))
+    assert not bad, bad[:20]
