@@ -1,0 +1,189 @@
+"""bench.py -- one data-parallel training step (forward + backward [+ RCCL gradient all-reduce]) of the E2-TTS
+flow-matching transformer on synthetic data, BASELINE.json's metric on BASELINE.json's config.
+
+  python bench.py --gpus 1 --steps 10 --warmup 3
+  python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P \
+      bench.py --gpus N --steps K --warmup W
+
+Prints ONE JSON line on rank 0.  `roofline` is measured live: every launch of the dominant kernel
+(e2k_gemm_nt_bf16) inside the timed region is bracketed with HIP events on its own stream.
+`cpu_baseline` times the CPU oracle (kind "port": the reference itself cannot be imported)
+on a bounded sample of the same workload, rank 0 at N=1 only.
+"""
+from __future__ import annotations
+
+import argparse
+import json
+import os
+import random
+import sys
+import time
+from pathlib import Path
+
+ROOT = Path(__file__).resolve().parent
+for p in (ROOT / 'e2-tts-pytorch_amd', ROOT):
+    if str(p) not in sys.path:
+        sys.path.insert(0, str(p))
+
+import torch  # noqa: E402
+import torch.distributed as dist  # noqa: E402
+
+CONFIGS = {
+    # name: (dim, depth, heads, B per GPU, T)
+    'cfg2': (512, 8, 8, 8, 1024),
+    'cfg3': (1024, 24, 16, 8, 1024),
+}
+PEAK_BF16_TFLOPS = 2500.0      # MI355X dense bf16 MFMA (MI355X_MICROARCH.md)
+
+
+def step_flops(dim, depth, heads, B, T, text_on=True):
+    """algorithmic dense FLOPs of one fwd+bwd step"""
+    D, L, N = dim, depth, T + 32
+    I, Dt, m, s = heads * 64, dim // 2, 4, 4
+    f_tok = L * (8 * D * I + 4 * N * I + 6 * m * D * D) + 2 * s * L * D * D
+    if text_on:
+        f_tok += L * (8 * Dt * I + 4 * N * I + 6 * m * Dt * Dt) + s * (L * 2 * (D + Dt) * D + (L - 1) * 2 * (D + Dt) * Dt)
+    f_io = 2 * (2 * 100 * D) + 2 * D * 100
+    return 3 * B * (N * f_tok + T * f_io)
+
+
+def synthetic_text(B, seed):
+    rng = random.Random(seed)
+    alphabet = ''.join(chr(c) for c in range(32, 127))
+    return [''.join(rng.choice(alphabet) for _ in range(rng.randint(20, 200))) for _ in range(B)]
+
+
+def cpu_baseline(dim, depth, heads, T, seconds_hint=30):
+    """oracle (fp32, torch CPU) on a bounded sample: same model dims, B = 1, full T, one fwd+bwd"""
+    from oracle import e2tts_oracle as O
+    torch.set_num_threads(os.cpu_count())
+    random.seed(0)
+    torch.manual_seed(0)
+    model = O.E2TTS(transformer=dict(dim=dim, depth=depth, heads=heads), cond_drop_prob=0.)
+    mel = torch.randn(1, T, 100)
+    text = synthetic_text(1, 1)
+    t0 = time.perf_counter()
+    out = model(mel, text=text)
+    out.loss.backward()
+    dt = time.perf_counter() - t0
+    return {'value': T / dt, 'unit': 'mel-frames/s', 'cores': os.cpu_count(), 'kind': 'port',
+            'sample': f'CPU oracle (fp32 torch eager, {os.cpu_count()} threads), dim={dim} depth={depth} heads={heads}, '
+                      f'B=1, T={T}, one fwd+bwd incl. first-touch ({dt:.1f} s)'}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument('--gpus', type=int, default=1)
+    ap.add_argument('--steps', type=int, default=8)
+    ap.add_argument('--warmup', type=int, default=2)
+    ap.add_argument('--config', default='cfg3', choices=sorted(CONFIGS))
+    ap.add_argument('--dropout', type=float, default=0.1, help='reference training default (e2_tts.py:540)')
+    ap.add_argument('--drop-text', action='store_true', help='run with the text stream dropped (CFG null pass cost)')
+    ap.add_argument('--no-cpu-baseline', action='store_true')
+    ap.add_argument('--batch', type=int, default=None)
+    args = ap.parse_args()
+
+    from e2_tts_pytorch_amd import E2TTS, ops
+    from e2_tts_pytorch_amd.ddp import DataParallel
+
+    world = int(os.environ.get('WORLD_SIZE', '1'))
+    rank = int(os.environ.get('RANK', '0'))
+    local_rank = int(os.environ.get('LOCAL_RANK', '0'))
+    assert world == args.gpus, f'--gpus {args.gpus} but WORLD_SIZE={world}'
+    torch.cuda.set_device(local_rank)
+    dev = torch.device('cuda', local_rank)
+    if world > 1:
+        os.environ.setdefault('MASTER_ADDR', '127.0.0.1')
+        os.environ.setdefault('HSA_ENABLE_IPC_MODE_LEGACY', '0')
+        dist.init_process_group('nccl', device_id=dev)
+
+    dim, depth, heads, B, T = CONFIGS[args.config]
+    B = args.batch or B
+    random.seed(1234)                     # same python RNG on every rank: identical init + identical CFG coin flips
+    torch.manual_seed(1234)
+    model = E2TTS(transformer=dict(dim=dim, depth=depth, heads=heads, dropout=args.dropout), use_vocos=False,
+                  cond_drop_prob=0.).to(dev)
+    model.train()
+    net = DataParallel(model) if world > 1 else model
+    torch.manual_seed(1000 + rank)        # different synthetic data per rank (weak scaling: B per GPU fixed)
+    mel = torch.randn(B, T, 100, device=dev)
+    text = synthetic_text(B, 1000 + rank)
+    noise = {'drop_text_cond': True} if args.drop_text else None
+
+    def step():
+        out = net(mel, text=text, _noise=noise)
+        out.loss.backward()
+        model.zero_grad(set_to_none=True)
+        return out.loss
+
+    for _ in range(args.warmup):
+        step()
+    torch.cuda.synchronize()
+    if world > 1:
+        dist.barrier()
+    torch.cuda.synchronize()
+    prof = []
+    ops.set_gemm_profile(prof)
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        loss = step()
+    torch.cuda.synchronize()
+    if world > 1:
+        dist.barrier()
+    torch.cuda.synchronize()
+    dt = time.perf_counter() - t0
+    ops.set_gemm_profile(None)
+    loss_val = float(loss.item())
+
+    t = torch.tensor([dt], dtype=torch.float64, device=dev)
+    if world > 1:
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+    dt = float(t.item())
+    gemm_flops = sum(f for f, _, _ in prof)
+    gemm_ms = sum(e0.elapsed_time(e1) for _, e0, e1 in prof)
+    n_launch = len(prof)
+
+    if rank == 0:
+        ms = dt / args.steps * 1e3
+        frames = B * T * world
+        sf = step_flops(dim, depth, heads, B, T, text_on=not args.drop_text)
+        achieved = gemm_flops / (gemm_ms * 1e-3) / 1e12 if gemm_ms > 0 else 0.0
+        res = {
+            'metric': 'mel-frames/sec (fwd+bwd training step)',
+            'value': frames / (dt / args.steps),
+            'unit': 'mel-frames/s',
+            'n_gpus': world, 'steps': args.steps, 'warmup': args.warmup, 'ms_per_step': ms,
+            'higher_is_better': True, 'scaling': 'weak', 'vs_baseline': None, 'dtype': 'bf16', 'data': 'synthetic',
+            'config': {
+                'workload': f'{args.config}: E2TTS(dim={dim}, depth={depth}, heads={heads}) fwd+bwd, B={B}/GPU, T={T}, '
+                            f'n_mels=100, random-init weights, {"text stream dropped" if args.drop_text else "text stream on (cond_drop_prob=0)"}, '
+                            f'dropout={args.dropout}, bf16 MFMA compute / fp32 master weights+grads',
+                'global_batch': B * world, 'seq_len': T, 'parallelism': f'dp{world}',
+            },
+            'step_tflops_algorithmic': sf / 1e12,
+            'model_tflops_per_s_per_gpu': sf / (dt / args.steps) / 1e12,
+            'mfma_roofline_frac_whole_step': sf / (dt / args.steps) / 1e12 / PEAK_BF16_TFLOPS,
+            'loss': loss_val,
+            'roofline': {
+                'bound': 'mfma', 'kernel': 'e2k gemm_nt_kernel (bf16 MFMA 16x16x32, all forward + dgrad GEMMs)',
+                'achieved': achieved, 'peak': PEAK_BF16_TFLOPS, 'unit': 'TFLOP/s', 'frac': achieved / PEAK_BF16_TFLOPS,
+                'launches_per_step': n_launch / max(args.steps, 1),
+                'avg_launch_ms': gemm_ms / max(n_launch, 1),
+                'flops_per_launch_avg': gemm_flops / max(n_launch, 1),
+                'time_share_of_step': (gemm_ms / args.steps) / ms,
+                'traffic': None,
+            },
+        }
+        if world == 1 and not args.no_cpu_baseline:
+            try:
+                res['cpu_baseline'] = cpu_baseline(dim, depth, heads, T)
+            except Exception as e:      # noqa: BLE001
+                res['cpu_baseline'] = {'value': None, 'unit': 'mel-frames/s', 'cores': os.cpu_count(), 'kind': 'port',
+                                       'sample': f'failed: {e!r}'}
+        print(json.dumps(res), flush=True)
+    if world > 1:
+        dist.destroy_process_group()
+
+
+if __name__ == '__main__':
+    main()

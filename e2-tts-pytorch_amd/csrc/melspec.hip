@@ -1,0 +1,110 @@
+// Fused STFT-magnitude -> mel filterbank -> log for MelSpec (e2_tts.py:248-290; torchaudio MelSpectrogram semantics
+// restated in SURVEY.md Appendix A.8): reflect padding (center=True), periodic Hann window, 1024-point FFT, |.|,
+// (513 x n_mels) htk filterbank, log(clamp(min=1e-5)).  The reference runs this as torch.stft (cuFFT-class library
+// call) + abs + matmul + transpose + clamp + log, i.e. the (B, 513, frames) complex spectrum and magnitude make
+// four HBM round trips; here a workgroup keeps 4 frames in LDS from the raw samples to the log-mel row.
+// HBM-bound: algorithmic bytes = 4*nw (samples, read once; the 4x frame overlap is served from L2) + 4*n_mels*frames.
+#include "e2k_device.h"
+#include "../../include/e2k.h"
+
+using namespace e2k;
+
+namespace {
+
+constexpr int NFFT = 1024, LOGN = 10, NBIN = NFFT / 2 + 1, FR = 4;
+
+__device__ __forceinline__ int bitrev10(int x) {
+    int r = 0;
+#pragma unroll
+    for (int i = 0; i < LOGN; ++i) r |= ((x >> i) & 1) << (LOGN - 1 - i);
+    return r;
+}
+
+struct MelArgs {
+    const float* wave; long nw; const float* window; const float* fb; const float* twc; const float* tws;
+    float* out; int B, frames, hop, n_mels;
+};
+
+__global__ __launch_bounds__(256) void melspec_kernel(MelArgs p) {
+    __shared__ float re[FR][NFFT];
+    __shared__ float im[FR][NFFT];
+    __shared__ float tc[NFFT / 2], ts[NFFT / 2];
+    const int tid = threadIdx.x;
+    const int b = blockIdx.y;
+    const int f0 = blockIdx.x * FR;
+    const float* x = p.wave + (long)b * p.nw;
+    for (int i = tid; i < NFFT / 2; i += 256) { tc[i] = p.twc[i]; ts[i] = p.tws[i]; }
+    // load + reflect pad + window, stored bit-reversed
+    for (int fr = 0; fr < FR; ++fr) {
+        const int f = f0 + fr;
+        for (int i = tid; i < NFFT; i += 256) {
+            float v = 0.f;
+            if (f < p.frames) {
+                long j = (long)f * p.hop + i - NFFT / 2;
+                if (j < 0) j = -j;
+                if (j >= p.nw) j = 2 * (p.nw - 1) - j;
+                v = x[j] * p.window[i];
+            }
+            const int r = bitrev10(i);
+            re[fr][r] = v;
+            im[fr][r] = 0.f;
+        }
+    }
+    __syncthreads();
+    for (int s = 1; s <= LOGN; ++s) {
+        const int half = 1 << (s - 1);
+        const int tstep = NFFT >> s;
+        for (int j = tid; j < NFFT / 2; j += 256) {
+            const int grp = j >> (s - 1), pos = j & (half - 1);
+            const int i0 = (grp << s) + pos, i1 = i0 + half;
+            const float c = tc[pos * tstep], sn = ts[pos * tstep];      // W = c - i*sn
+#pragma unroll
+            for (int fr = 0; fr < FR; ++fr) {
+                const float xr = re[fr][i1], xi = im[fr][i1];
+                const float tr = xr * c + xi * sn;
+                const float ti = xi * c - xr * sn;
+                const float ur = re[fr][i0], ui = im[fr][i0];
+                re[fr][i0] = ur + tr; im[fr][i0] = ui + ti;
+                re[fr][i1] = ur - tr; im[fr][i1] = ui - ti;
+            }
+        }
+        __syncthreads();
+    }
+    // magnitude into re[fr][0..512]
+    for (int k = tid; k < NBIN; k += 256) {
+#pragma unroll
+        for (int fr = 0; fr < FR; ++fr) {
+            const float a = re[fr][k], c = im[fr][k];
+            re[fr][k] = sqrtf(a * a + c * c);
+        }
+    }
+    __syncthreads();
+    if (tid < p.n_mels) {
+        float acc[FR];
+#pragma unroll
+        for (int fr = 0; fr < FR; ++fr) acc[fr] = 0.f;
+        for (int k = 0; k < NBIN; ++k) {
+            const float w = p.fb[(long)k * p.n_mels + tid];
+#pragma unroll
+            for (int fr = 0; fr < FR; ++fr) acc[fr] = fmaf(re[fr][k], w, acc[fr]);
+        }
+#pragma unroll
+        for (int fr = 0; fr < FR; ++fr) {
+            const int f = f0 + fr;
+            if (f < p.frames) p.out[((long)b * p.n_mels + tid) * p.frames + f] = logf(fmaxf(acc[fr], 1e-5f));
+        }
+    }
+}
+
+}  // namespace
+
+extern "C" int e2k_melspec(const float* wave, int64_t nw, const float* window, const float* fb, const float* twc,
+                           const float* tws, float* out, int B, int n_fft, int hop, int n_mels, void* stream) {
+    if (B <= 0 || nw <= 0) return 0;
+    if (n_fft != NFFT || n_mels > 256 || n_mels <= 0 || hop <= 0 || nw <= NFFT / 2) return E2K_ERR_SHAPE;
+    if (!wave || !window || !fb || !twc || !tws || !out) return E2K_ERR_ARG;
+    MelArgs a{wave, (long)nw, window, fb, twc, tws, out, B, (int)(1 + nw / hop), hop, n_mels};
+    hipLaunchKernelGGL(melspec_kernel, dim3((a.frames + FR - 1) / FR, B), dim3(256), 0, (hipStream_t)stream, a);
+    E2K_CHECK_LAUNCH();
+    return 0;
+}

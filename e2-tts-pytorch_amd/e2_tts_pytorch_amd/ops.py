@@ -63,10 +63,27 @@ def gemm_nt(a, b, *, a2=None, out=None, out_dtype=bf16, accumulate=False, bias=N
     if resid is not None:
         assert resid.dtype == bf16 and resid.shape == (M, N) and resid.stride(1) == 1
         ldr = resid.stride(0)
+    prof = _gemm_profile
+    if prof is not None and a.is_cuda:
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
     _lib.get().e2k_gemm_nt_bf16(_p(a), lda, K1, _p(a2), lda2, K2, _p(b), ldb, _p(out), out.stride(0),
                                 int(out.dtype == f32), int(accumulate), M, N, _p(bias), _p(colscale),
                                 0 if colscale is None else colscale.stride(0), int(rows_per_batch), _p(rowmask), _p(resid), ldr, _stream(a))
+    if prof is not None and a.is_cuda:
+        e1.record()
+        prof.append((2.0 * M * N * (K1 + K2), e0, e1))
     return out
+
+
+_gemm_profile = None
+
+
+def set_gemm_profile(lst):
+    """bench.py: when a list is installed, every gemm_nt launch is bracketed by HIP events on its stream and
+    (flops, start, end) is appended -- used for the live roofline figure."""
+    global _gemm_profile
+    _gemm_profile = lst
 
 
 def gemm_tn(a, b, out, *, splits=0, use_tr=True):
@@ -303,3 +320,26 @@ def qkv_post_bwd(st, dQ, dK, dV, dgate_pre, qkvg, cosb, sinb, vfirst=None, dvfir
     _lib.get().e2k_qkv_post_bwd(_p(dQ), _p(dK), _p(dV), _p(dgate_pre), _p(qkvg), qkvg.stride(0), _p(cosb), _p(sinb),
                                 _p(vfirst), _p(st.mix), _p(dvfirst), int(first_layer), _p(dqkvg), B, H, N, _stream(dQ))
     return dqkvg
+
+
+# ------------------------------------------------------------------------------------------------ MelSpec
+
+_twiddles = {}
+
+
+def melspec(wave, window, fb, n_fft, hop):
+    """wave (B, nw) fp32 -> (B, n_mels, 1 + nw // hop) fp32 log-mel"""
+    _chk(wave, window, fb)
+    assert wave.dim() == 2
+    wave = wave.float().contiguous()
+    B, nw = wave.shape
+    key = (str(wave.device), n_fft)
+    if key not in _twiddles:
+        ang = 2 * torch.pi * torch.arange(n_fft // 2, dtype=torch.float64) / n_fft
+        _twiddles[key] = (ang.cos().float().to(wave.device), ang.sin().float().to(wave.device))
+    twc, tws = _twiddles[key]
+    n_mels = fb.shape[1]
+    out = torch.empty((B, n_mels, 1 + nw // hop), dtype=f32, device=wave.device)
+    _lib.get().e2k_melspec(_p(wave), nw, _p(window.float().contiguous()), _p(fb.float().contiguous()), _p(twc), _p(tws),
+                           _p(out), B, n_fft, hop, n_mels, _stream(wave))
+    return out

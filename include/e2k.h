@@ -139,6 +139,12 @@ int e2k_attn_bwd(const void* dOg, const void* O, const float* gate, const float*
                  int B, int H, int N, int Npad, float p_drop, uint32_t seed, uint32_t stream_id,
                  void* stream);
 
+/* ---- MelSpec (e2_tts.py:248-290 -> torchaudio MelSpectrogram(n_fft=1024, hop, power=1, center, htk, norm=None)) ----
+ * wave (B, nw) fp32 -> out (B, n_mels, 1 + nw/hop) fp32 = log(clamp(mel, 1e-5)).  window (n_fft) periodic Hann,
+ * fb (n_fft/2+1, n_mels) filterbank, twc/tws (n_fft/2): cos/sin(2*pi*k/n_fft).  n_fft must be 1024. */
+int e2k_melspec(const float* wave, int64_t nw, const float* window, const float* fb, const float* twc,
+                const float* tws, float* out, int B, int n_fft, int hop, int n_mels, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -12,7 +12,6 @@ for p in (ROOT / 'e2-tts-pytorch_amd', ROOT, ROOT / 'tests'):
 
 def pytest_configure(config):
     config.addinivalue_line('markers', 'gpu: needs a real MI355X (run with -m gpu on the GPU box)')
-    config.addinivalue_line('markers', 'slow: long-running CPU test')
 
 
 @pytest.fixture(scope='session')
@@ -28,3 +27,21 @@ def emu(emu_lib):
     _lib._install_for_tests(emu_lib, host_pointers=True)
     yield _lib.get()
     _lib._install_for_tests(None, host_pointers=False)
+
+
+@pytest.fixture(params=['emu', pytest.param('gpu', marks=pytest.mark.gpu)])
+def dev(request):
+    """'cpu' with the host logic-checker build of the kernels, or 'cuda' with the real libe2k.so (-m gpu).
+    The same test body checks the same kernels against the same oracle in both cases."""
+    from e2_tts_pytorch_amd import _lib
+    if request.param == 'emu':
+        lib = request.getfixturevalue('emu_lib')
+        _lib._install_for_tests(lib, host_pointers=True)
+        yield 'cpu'
+        _lib._install_for_tests(None, host_pointers=False)
+    else:
+        import torch
+        assert torch.cuda.is_available(), 'gpu tests need a HIP device'
+        _lib._install_for_tests(None, host_pointers=False)
+        _lib.get()                      # raises if libe2k.so is missing: no silent fallback
+        yield 'cuda'

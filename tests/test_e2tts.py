@@ -1,0 +1,123 @@
+"""End-to-end parity of the HIP path with the CPU oracle: E2TTS.forward (loss, pred_flow, gradients), E2TTS.sample,
+DurationPredictor, MelSpec.  North-star tolerance for the bf16 path: 1e-2 (relative, stated per quantity below)."""
+import random
+
+import pytest
+import torch
+
+from oracle import e2tts_oracle as O
+
+from test_backbone import randomize
+
+
+def rel2(a, b):
+    a, b = a.detach().cpu().float(), b.detach().cpu().float()
+    return ((a - b).norm() / b.norm().clamp_min(1e-20)).item()
+
+
+def relmax(a, b):
+    a, b = a.detach().cpu().float(), b.detach().cpu().float()
+    return ((a - b).abs().max() / b.abs().max().clamp_min(1e-20)).item()
+
+
+def test_melspec(dev):
+    from e2_tts_pytorch_amd import MelSpec
+    torch.manual_seed(0)
+    wave = torch.randn(2, 256 * 21 + 17)
+    ref = O.MelSpec()(wave)
+    got = MelSpec()(wave.to(dev))
+    assert got.shape == ref.shape == (2, 100, 22)
+    assert (got.cpu() - ref).abs().max().item() < 2e-3      # log-mel, fp32 FFT vs torch.stft
+
+
+def _pair(kw, seed=0, duration_predictor=None):
+    from e2_tts_pytorch_amd import E2TTS
+    random.seed(seed)
+    torch.manual_seed(seed)
+    ref = O.E2TTS(transformer=dict(**kw), cond_drop_prob=0., duration_predictor=duration_predictor)
+    randomize(ref)
+    model = E2TTS(transformer=dict(**kw), use_vocos=False, cond_drop_prob=0., duration_predictor=duration_predictor)
+    model.load_state_dict(ref.state_dict(), strict=True)
+    return ref, model
+
+
+def test_e2tts_forward_backward(dev):
+    kw = dict(dim=256, depth=2, heads=4, dropout=0.)
+    ref, model = _pair(kw)
+    model = model.to(dev)
+    B, T = 2, 72
+    mel = torch.randn(B, T, 100)
+    lens = torch.tensor([T, T - 11])
+    noise = dict(x0=torch.randn(B, T, 100), times=torch.rand(B), frac_lengths=torch.tensor([0.75, 0.9]),
+                 span_rand=torch.tensor([0.2, 0.7]), drop_text_cond=False)
+    text = ['Hello', 'Goodbye, world']
+    out_r = ref(mel, text=text, lens=lens, _noise=noise)
+    out_r.loss.backward()
+    dn = {k: (v.to(dev) if torch.is_tensor(v) else v) for k, v in noise.items()}
+    out = model(mel.to(dev), text=text, lens=lens.to(dev), _noise=dn)
+    out.loss.backward()
+    assert abs(out.loss.item() - out_r.loss.item()) / abs(out_r.loss.item()) < 1e-2          # loss: 1e-2 relative
+    assert relmax(out.pred_flow, out_r.pred_flow) < 3e-2                                      # max-abs / max-abs
+    assert rel2(out.pred_flow, out_r.pred_flow) < 1e-2                                        # rel-L2: 1e-2
+    assert torch.equal(out.cond.cpu(), out_r.cond)
+    for name in ('to_pred.weight', 'proj_in.weight', 'cond_proj_in.weight', 'embed_text.embed.weight',
+                 'transformer.time_cond_mlp.1.weight'):
+        gk = dict(model.named_parameters())[name].grad
+        gr = dict(ref.named_parameters())[name].grad
+        assert rel2(gk, gr) < 8e-2, (name, rel2(gk, gr))
+
+
+def test_e2tts_text_dropped(dev):
+    kw = dict(dim=256, depth=2, heads=4, dropout=0.)
+    ref, model = _pair(kw, seed=1)
+    model = model.to(dev)
+    B, T = 1, 40
+    mel = torch.randn(B, T, 100)
+    noise = dict(x0=torch.randn(B, T, 100), times=torch.rand(B), frac_lengths=torch.tensor([0.8]),
+                 span_rand=torch.tensor([0.5]), drop_text_cond=True)
+    out_r = ref(mel, text=['abc'], _noise=noise)
+    dn = {k: (v.to(dev) if torch.is_tensor(v) else v) for k, v in noise.items()}
+    out = model(mel.to(dev), text=['abc'], _noise=dn)
+    out.loss.backward()
+    assert abs(out.loss.item() - out_r.loss.item()) / abs(out_r.loss.item()) < 1e-2
+    # text parameters got exact zeros (DDP-friendly), not None
+    g = model.transformer.layers[0][1][4].ff[2].weight.grad
+    assert g is not None and float(g.abs().max()) == 0.
+
+
+def test_sample(dev):
+    kw = dict(dim=256, depth=2, heads=4, dropout=0.)
+    ref, model = _pair(kw, seed=2)
+    model = model.to(dev)
+    B, Tp, dur = 2, 5, 24
+    cond = torch.randn(B, Tp, 100)
+    y0 = torch.randn(B, dur, 100)
+    text = ['Hi there', 'Yo']
+    s_r = ref.sample(cond, text=text, duration=dur, steps=4, cfg_strength=1., _y0=y0)
+    s = model.sample(cond.to(dev), text=text, duration=dur, steps=4, cfg_strength=1., _y0=y0.to(dev))
+    assert s.shape == s_r.shape
+    assert rel2(s, s_r) < 2e-2, rel2(s, s_r)
+
+
+def test_duration_predictor(dev):
+    from e2_tts_pytorch_amd import DurationPredictor
+    random.seed(3)
+    torch.manual_seed(3)
+    kw = dict(dim=256, depth=2, heads=4, dropout=0.)
+    ref = O.DurationPredictor(transformer=dict(**kw))
+    randomize(ref)
+    model = DurationPredictor(transformer=dict(**kw))
+    model.load_state_dict(ref.state_dict(), strict=True)
+    model = model.to(dev)
+    B, T = 2, 48
+    mel = torch.randn(B, T, 100)
+    lens = torch.tensor([T, 30])
+    rfi = torch.tensor([0.6, 0.9])
+    loss_r = ref(mel, text=['ab', 'cde'], lens=lens, _rand_frac_index=rfi)
+    loss = model(mel.to(dev), text=['ab', 'cde'], lens=lens.to(dev), _rand_frac_index=rfi.to(dev))
+    loss.backward()
+    assert abs(loss.item() - loss_r.item()) / abs(loss_r.item()) < 2e-2
+    pred_r = ref(mel, text=['ab', 'cde'], lens=lens, return_loss=False)
+    with torch.no_grad():
+        pred = model(mel.to(dev), text=['ab', 'cde'], lens=lens.to(dev), return_loss=False)
+    assert rel2(pred, pred_r) < 2e-2

@@ -7,11 +7,12 @@ bf16 = torch.bfloat16
 
 
 def rel(a, b):
+    a, b = a.cpu(), b.cpu()
     return ((a.float() - b.float()).abs().max() / b.float().abs().max().clamp_min(1e-20)).item()
 
 
 @pytest.mark.parametrize('D,nb', [(128, 1), (256, 3), (1024, 2)])
-def test_rmsnorm(emu, D, nb):
+def test_rmsnorm(dev, D, nb):
     from e2_tts_pytorch_amd import ops
     torch.manual_seed(0)
     rpb = 13
@@ -25,15 +26,16 @@ def test_rmsnorm(emu, D, nb):
     idx = torch.arange(M) // rpb
     yr = F.normalize(xr, dim=-1) * D ** 0.5 * (gr[idx] + off)
     yr.backward(dy.float())
+    x, gamma, dy = x.to(dev), gamma.to(dev), dy.to(dev)
     y, rn = ops.rmsnorm_fwd(x, gamma, off, rpb)
     assert rel(y, yr) < 1e-2
-    dg = torch.zeros(nb, D)
+    dg = torch.zeros(nb, D, device=dev)
     dx = ops.rmsnorm_bwd(dy, x, rn, gamma, off, rpb, dg)
     assert rel(dx, xr.grad) < 1e-2
     assert rel(dg, gr.grad) < 1e-2
 
 
-def test_gate_bwd(emu):
+def test_gate_bwd(dev):
     from e2_tts_pytorch_amd import ops
     torch.manual_seed(0)
     D, rpb, nb = 256, 11, 3
@@ -43,14 +45,14 @@ def test_gate_bwd(emu):
     idx = torch.arange(M) // rpb
     y = (ao * g[idx]).to(bf16)
     dy = torch.randn(M, D).to(bf16)
-    gsum = torch.zeros(nb, D)
-    dao = ops.gate_bwd(dy, y, g, gsum, rpb)
+    gsum = torch.zeros(nb, D, device=dev)
+    dao = ops.gate_bwd(dy.to(dev), y.to(dev), g.to(dev), gsum, rpb)
     assert rel(dao, dy.float() * g[idx]) < 1e-2
     ref = torch.zeros(nb, D).index_add_(0, idx, dy.float() * y.float())
     assert rel(gsum, ref) < 1e-4
 
 
-def test_geglu(emu):
+def test_geglu(dev):
     from e2_tts_pytorch_amd import ops
     torch.manual_seed(0)
     M, Fd = 19, 64
@@ -60,32 +62,32 @@ def test_geglu(emu):
     u, gt = Hr.chunk(2, dim=-1)
     a = u * F.gelu(gt)
     a.backward(da.float())
-    out = ops.geglu_fwd(H)
+    out = ops.geglu_fwd(H.to(dev))
     assert rel(out, a) < 1e-2
-    dH = ops.geglu_bwd(da, H)
+    dH = ops.geglu_bwd(da.to(dev), H.to(dev))
     assert rel(dH, Hr.grad) < 1e-2
 
 
-def test_colsum_cast(emu):
+def test_colsum_cast(dev):
     from e2_tts_pytorch_amd import ops
     torch.manual_seed(0)
     x = torch.randn(77, 130).to(bf16)
-    out = torch.ones(130)
-    ops.colsum(x, out)
+    out = torch.ones(130, device=dev)
+    ops.colsum(x.to(dev), out)
     assert rel(out, 1 + x.float().sum(0)) < 1e-5
     src = torch.randn(1003)
-    dst = torch.empty(1003, dtype=bf16)
+    dst = torch.empty(1003, dtype=bf16, device=dev)
     # 16-byte alignment of the test buffers is what torch gives us
-    ops.cast_bf16(src, dst)
-    assert torch.equal(dst, src.to(bf16))
+    ops.cast_bf16(src.to(dev), dst)
+    assert torch.equal(dst.cpu(), src.to(bf16))
     w = torch.randn(70, 45)
-    wt = torch.empty(45, 70, dtype=bf16)
-    ops.cast_transpose_bf16(w, wt)
-    assert torch.equal(wt, w.t().to(bf16))
+    wt = torch.empty(45, 70, dtype=bf16, device=dev)
+    ops.cast_transpose_bf16(w.to(dev), wt)
+    assert torch.equal(wt.cpu(), w.t().to(bf16))
 
 
 @pytest.mark.parametrize('ks,use_mask', [(31, True), (7, False)])
-def test_dwconv(emu, ks, use_mask):
+def test_dwconv(dev, ks, use_mask):
     from e2_tts_pytorch_amd import ops
     torch.manual_seed(0)
     B, N, C = 2, 75, 128
@@ -106,10 +108,11 @@ def test_dwconv(emu, ks, use_mask):
     if mask is not None:
         yr = torch.where(mask[..., None], yr, torch.zeros_like(yr))
     yr.backward(dy.float())
-    pre, y = ops.dwconv_fwd(x, mask, w, bias)
+    xd, wd, bd, md = x.to(dev), w.to(dev), bias.to(dev), (None if mask is None else mask.to(dev))
+    pre, y = ops.dwconv_fwd(xd, md, wd, bd)
     assert rel(y, yr) < 1e-2
-    dw, db = torch.zeros_like(w), torch.zeros_like(bias)
-    dx = ops.dwconv_bwd(dy, pre, x, mask, w, dw, db)
+    dw, db = torch.zeros_like(wd), torch.zeros_like(bd)
+    dx = ops.dwconv_bwd(dy.to(dev), pre, xd, md, wd, dw, db)
     assert rel(dx, xr.grad) < 2e-2, rel(dx, xr.grad)
     assert rel(dw, wr.grad) < 2e-2, rel(dw, wr.grad)
     assert rel(db, br.grad) < 2e-2

@@ -1,0 +1,76 @@
+"""MFMA GEMM kernels against fp32 torch matmul on bf16-rounded operands (transpose-detecting: random asymmetric data)."""
+import pytest
+import torch
+
+bf16 = torch.bfloat16
+
+
+def rel(a, b):
+    a, b = a.cpu().float(), b.cpu().float()
+    return ((a - b).abs().max() / b.abs().max().clamp_min(1e-20)).item()
+
+
+@pytest.mark.parametrize('M,N,K1,K2,kw', [
+    (128, 128, 64, 0, {}),
+    (200, 136, 72, 0, dict(bias=1)),
+    (130, 260, 128, 64, dict(bias=1, cs=1, rm=1, rs=1)),
+    (64, 100, 64, 0, dict(f32=1, bias=1)),
+    (8, 1000, 256, 0, dict(f32=1, bias=1)),
+    (520, 392, 256, 128, dict(rs=1)),
+])
+def test_gemm_nt(dev, M, N, K1, K2, kw):
+    from e2_tts_pytorch_amd import ops
+    torch.manual_seed(0)
+    a = torch.randn(M, K1).to(bf16)
+    b = torch.randn(N, K1 + K2).to(bf16)
+    a2 = torch.randn(M, K2).to(bf16) if K2 else None
+    bias = torch.randn(N) if kw.get('bias') else None
+    nb = 3
+    rpb = (M + nb - 1) // nb
+    cs = torch.rand(nb, N) if kw.get('cs') else None
+    rm = (torch.rand(M) > 0.3) if kw.get('rm') else None
+    rs = torch.randn(M, N).to(bf16) if kw.get('rs') else None
+    to = lambda t: None if t is None else t.to(dev)
+    out = ops.gemm_nt(to(a), to(b), a2=to(a2), bias=to(bias), colscale=to(cs), rows_per_batch=rpb, rowmask=to(rm),
+                      resid=to(rs), out_dtype=torch.float32 if kw.get('f32') else bf16)
+    A = torch.cat([a, a2], 1).float() if K2 else a.float()
+    ref = A @ b.float().T
+    if bias is not None:
+        ref = ref + bias
+    if cs is not None:
+        ref = ref * cs[torch.arange(M) // rpb]
+    if rm is not None:
+        ref = ref * rm[:, None].float()
+    if rs is not None:
+        ref = ref + rs.float()
+    assert rel(out, ref) < (1e-5 if kw.get('f32') else 6e-3)
+    if kw.get('f32'):       # accumulate mode
+        out2 = ops.gemm_nt(to(a), to(b), bias=to(bias), out=out.clone(), accumulate=True)
+        assert rel(out2, 2 * ref) < 1e-5
+
+
+@pytest.mark.parametrize('use_tr', [False, True])
+@pytest.mark.parametrize('M,N,K,splits', [(128, 128, 128, 1), (300, 136, 72, 0), (1000, 392, 264, 3), (8, 256, 128, 1)])
+def test_gemm_tn(dev, M, N, K, splits, use_tr):
+    from e2_tts_pytorch_amd import ops
+    torch.manual_seed(0)
+    a = torch.randn(M, N).to(bf16)
+    b = torch.randn(M, K).to(bf16)
+    out = torch.ones(N, K, device=dev)
+    ops.gemm_tn(a.to(dev), b.to(dev), out, splits=splits, use_tr=use_tr)
+    ref = 1 + a.float().T @ b.float()
+    assert rel(out, ref) < 1e-5
+
+
+def test_gemm_tn_strided(dev):
+    """column-sliced operands / outputs as the backbone uses them (cross-condition and skip weight gradients)"""
+    from e2_tts_pytorch_amd import ops
+    torch.manual_seed(0)
+    M, N, K, ldc = 260, 128, 64, 200
+    a = torch.randn(M, N + 8).to(bf16)
+    b = torch.randn(M, K + 16).to(bf16)
+    C = torch.zeros(N, ldc, device=dev)
+    ops.gemm_tn(a.to(dev)[:, :N], b.to(dev)[:, 8:8 + K], C[:, 40:40 + K])
+    ref = a[:, :N].float().T @ b[:, 8:8 + K].float()
+    assert rel(C[:, 40:40 + K], ref) < 1e-5
+    assert float(C[:, :40].abs().max()) == 0 and float(C[:, 40 + K:].abs().max()) == 0

@@ -47,12 +47,13 @@ def _ok(got, want):
 
 
 @pytest.mark.parametrize('D', [128, 256, 1024])
-def test_hc_chain(emu, D):
+def test_hc_chain(dev, D):
     from e2_tts_pytorch_amd import ops
     Mtok = 37
     hc1, hc2 = _mk_hc(D, 1), _mk_hc(D, 2)
     torch.manual_seed(3)
     X = torch.randn(Mtok, 4, D).to(bf16)
+    to = lambda t: t.to(dev)
     Wl = torch.randn(Mtok, 4, D)
     f1 = lambda t: torch.tanh(t) * 1.5
     f2 = lambda t: torch.sin(t) + 0.1 * t
@@ -70,20 +71,21 @@ def test_hc_chain(emu, D):
     loss.backward()
 
     # ---- kernels: width1 ; depth1+width2 ; depth2 (materialise)
-    p1 = [t.detach() for t in _params(hc1)]
-    p2 = [t.detach() for t in _params(hc2)]
-    M1, bin1, c1 = ops.hc_fwd(X, p1)
+    p1 = [to(t.detach()) for t in _params(hc1)]
+    p2 = [to(t.detach()) for t in _params(hc2)]
+    Xd = to(X)
+    M1, bin1, c1 = ops.hc_fwd(Xd, p1)
     y1 = f1(bin1.float()).to(bf16)
     M2, bin2, c2 = ops.hc_fwd(M1, p2, yprev=y1, coef_prev=c1)
     y2 = f2(bin2.float()).to(bf16)
     X3, _, _ = ops.hc_fwd(M2, None, yprev=y2, coef_prev=c2, width=False)
-    assert rel(bin1, b1[0]) < 2e-2 and rel(bin2, b2[0]) < 2e-2
-    assert rel(X3, _from_ref_layout(x3)) < 2e-2
+    assert rel(bin1.cpu(), b1[0]) < 2e-2 and rel(bin2.cpu(), b2[0]) < 2e-2
+    assert rel(X3.cpu(), _from_ref_layout(x3)) < 2e-2
 
     # ---- backward
     g1 = [torch.zeros_like(t) for t in p1]
     g2 = [torch.zeros_like(t) for t in p2]
-    dX3 = Wl.to(bf16)
+    dX3 = to(Wl.to(bf16))
     _, dy2 = ops.hc_bwd(dX3, yprev=y2, coef_prev=c2)                       # depth2 only
     b2k = bin2.float().requires_grad_(True)
     f2(b2k).backward(dy2.float())
@@ -92,9 +94,9 @@ def test_hc_chain(emu, D):
     b1k = bin1.float().requires_grad_(True)
     f1(b1k).backward(dy1.float())
     dbin1 = b1k.grad.to(bf16)
-    dX, _ = ops.hc_bwd(dM1, xin=X, dbin=dbin1, ycur=y1, coef=c1, params=p1, grads=g1)
-    assert rel(dX, Xr.grad) < 3e-2, rel(dX, Xr.grad)
+    dX, _ = ops.hc_bwd(dM1, xin=Xd, dbin=dbin1, ycur=y1, coef=c1, params=p1, grads=g1)
+    assert rel(dX.cpu(), Xr.grad) < 3e-2, rel(dX.cpu(), Xr.grad)
     for name, gk, pr in zip(ops.HC_PARAM_NAMES, g2, _params(hc2)):
-        assert _ok(gk, pr.grad), (name, 2, gk, pr.grad)
+        assert _ok(gk.cpu(), pr.grad), (name, 2, gk, pr.grad)
     for name, gk, pr in zip(ops.HC_PARAM_NAMES, g1, _params(hc1)):
-        assert _ok(gk, pr.grad), (name, 1, gk, pr.grad)
+        assert _ok(gk.cpu(), pr.grad), (name, 1, gk, pr.grad)
