@@ -88,3 +88,49 @@ def test_attention(dev, N, has_vres, use_mask):
         assert rel(got, want) < 4e-2, (name, rel(got, want))
     if has_vres:
         assert rel(dvfirst, vres.grad) < 4e-2, rel(dvfirst, vres.grad)
+
+
+def test_attention_dropout(dev):
+    """attention-probability dropout: the oracle is fed the very mask the kernel's counter hash generates"""
+    from e2_tts_pytorch_amd import ops
+    from oracle.dropout_hash import attn_dropout_mask
+    torch.manual_seed(1)
+    B, H, N, p, seed, sid = 1, 8, 70, 0.25, 12345, 6
+    D = I = H * 64
+    attn = Attention(dim=D, heads=H, dim_head=64, dropout=p)
+    with torch.no_grad():
+        attn.to_out.weight.copy_(torch.eye(D))
+    x = torch.randn(B, N, D)
+    rot = RotaryEmbedding(64).forward_from_seq_len(N)
+    Ws = [attn.to_q.weight, attn.to_k.weight, attn.to_v.weight, attn.to_v_head_gate.weight]
+    bs = [torch.zeros(3 * I), attn.to_v_head_gate.bias]
+    qkvg = (x.reshape(B * N, D) @ torch.cat(Ws).T + torch.cat(bs)).detach().to(bf16)
+    cols = qkvg.float().requires_grad_(True)
+    parts = list(cols.split([I, I, I, H], dim=-1))
+
+    class Fixed(torch.nn.Module):
+        def __init__(self, val):
+            super().__init__()
+            self.val = val
+
+        def forward(self, _x):
+            return self.val.view(B, N, -1)
+    attn.to_q, attn.to_k, attn.to_v, attn.to_v_head_gate = (Fixed(q) for q in parts)
+    attn.dropout_mask = attn_dropout_mask(seed, sid, B, H, N, p)
+    frac = (attn.dropout_mask == 0).float().mean().item()
+    assert abs(frac - p) < 0.02, frac
+    out = attn(x, rotary_pos_emb=rot)
+    R = torch.randn(B, N, D)
+    (out * R).sum().backward()
+
+    cosb, sinb = ops.rotary_table(N, dev)
+    st = ops.qkv_post_fwd(qkvg.to(dev), B, H, N, cosb, sinb, None)
+    kmask = torch.zeros(B, st.Npad, dtype=torch.uint8)
+    kmask[:, :N] = 1
+    kmask = kmask.to(dev)
+    Og = ops.attn_fwd(st, kmask, p, seed, sid)
+    assert rel(Og.view(B, N, D), out) < 2e-2, rel(Og.view(B, N, D), out)
+    dQ, dK, dV, dgate = ops.attn_bwd(st, R.reshape(B * N, D).to(bf16).to(dev), kmask, p, seed, sid)
+    dqkvg = ops.qkv_post_bwd(st, dQ, dK, dV, dgate, qkvg.to(dev), cosb, sinb)
+    for name, got, want in zip('qkvg', dqkvg.float().cpu().split([I, I, I, H], dim=-1), cols.grad.split([I, I, I, H], dim=-1)):
+        assert rel(got, want) < 4e-2, (name, rel(got, want))

@@ -116,3 +116,23 @@ def test_dwconv(dev, ks, use_mask):
     assert rel(dx, xr.grad) < 2e-2, rel(dx, xr.grad)
     assert rel(dw, wr.grad) < 2e-2, rel(dw, wr.grad)
     assert rel(db, br.grad) < 2e-2
+
+
+def test_geglu_dropout(dev):
+    from e2_tts_pytorch_amd import ops
+    from oracle.dropout_hash import geglu_dropout_mask
+    torch.manual_seed(0)
+    M, Fd, p, seed, sid = 33, 64, 0.1, 777, 9
+    H = torch.randn(M, 2 * Fd).to(bf16)
+    da = torch.randn(M, Fd).to(bf16)
+    mask = geglu_dropout_mask(seed, sid, M, Fd, p)
+    assert 0.03 < (mask == 0).float().mean().item() < 0.2
+    Hr = H.float().requires_grad_(True)
+    u, gt = Hr.chunk(2, dim=-1)
+    a = u * F.gelu(gt) * mask
+    a.backward(da.float())
+    out = ops.geglu_fwd(H.to(dev), p, seed, sid)
+    assert torch.equal(out.cpu() == 0, (a == 0)) or rel(out, a) < 1e-2
+    assert rel(out, a) < 1e-2
+    dH = ops.geglu_bwd(da.to(dev), H.to(dev), p, seed, sid)
+    assert rel(dH, Hr.grad) < 1e-2
