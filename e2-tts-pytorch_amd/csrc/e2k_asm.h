@@ -15,4 +15,13 @@ __device__ __forceinline__ s16x4_ lds_read_tr16_b64(const void* lds_ptr) {
     return __builtin_amdgcn_ds_read_tr16_b64_v4i16((lp_t)(lds_ptr));
 }
 
+// global_load_lds_dwordx4: asynchronous 16-byte-per-lane copy HBM -> LDS that bypasses the VGPRs.  The LDS destination
+// is wave-uniform: lane l lands at lds_base + 16*l (the global source address is per lane).  Completion is tracked by
+// vmcnt; a following __syncthreads() drains it (cdna_hip_programming.md section 5).
+__device__ __forceinline__ void glds16(const void* gsrc, void* lds_base) {
+    typedef __attribute__((address_space(1))) void* gp_t;
+    typedef __attribute__((address_space(3))) void* lp_t;
+    __builtin_amdgcn_global_load_lds((gp_t)(gsrc), (lp_t)(lds_base), 16, 0, 0);
+}
+
 }  // namespace e2k

@@ -51,7 +51,7 @@ struct NTArgs {
     const uint8_t* rowmask; const bf16_t* resid; long ldr;
 };
 
-template <bool OUT_F32>
+template <bool OUT_F32, bool GLDS>
 __global__ __launch_bounds__(256) void gemm_nt_kernel(NTArgs p) {
     __shared__ __attribute__((aligned(16))) unsigned char smem[2][2][BM * BK * 2];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -96,18 +96,46 @@ __global__ __launch_bounds__(256) void gemm_nt_kernel(NTArgs p) {
         }
     };
 
+    // GLDS: HBM -> LDS directly (global_load_lds_dwordx4), no VGPR staging.  A wave instruction fills 8 consecutive
+    // 128-B LDS rows lane-linearly, so the XOR swizzle is applied to the per-lane SOURCE column instead
+    // (cdna_hip_programming.md 5.4 rule 21).  Needs K1, K2 multiples of 64; out-of-range rows are clamped (their
+    // results are never stored).
+    auto gissue = [&](int kt, int buf) {
+        const int k0 = kt * BK;
+        const bf16_t* Ab = p.A1;
+        long lda = p.lda1;
+        int ka = k0;
+        if (k0 >= p.K1) { Ab = p.A2; lda = p.lda2; ka = k0 - p.K1; }
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const int rb = wave * 4 + i;
+            const int row = rb * 8 + (lane >> 3);
+            const int c = (lane & 7) ^ (row & 7);
+            const int m = min(m0 + row, p.M - 1), n = min(n0 + row, p.N - 1);
+            glds16(Ab + (long)m * lda + ka + c * 8, &smem[buf][0][rb * 1024]);
+            glds16(p.B + (long)n * p.ldb + k0 + c * 8, &smem[buf][1][rb * 1024]);
+        }
+    };
+
     f32x4 acc[4][4];
 #pragma unroll
     for (int i = 0; i < 4; ++i)
 #pragma unroll
         for (int j = 0; j < 4; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
 
-    gload(0);
-    sstore(0);
+    if (GLDS) {
+        gissue(0, 0);
+    } else {
+        gload(0);
+        sstore(0);
+    }
     __syncthreads();
     for (int kt = 0; kt < nk; ++kt) {
         const int buf = kt & 1;
-        if (kt + 1 < nk) gload(kt + 1);
+        if (kt + 1 < nk) {
+            if (GLDS) gissue(kt + 1, buf ^ 1);
+            else gload(kt + 1);
+        }
         const unsigned char* As = smem[buf][0];
         const unsigned char* Bs = smem[buf][1];
 #pragma unroll
@@ -130,7 +158,7 @@ __global__ __launch_bounds__(256) void gemm_nt_kernel(NTArgs p) {
                 for (int j = 0; j < 4; ++j)
                     acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(bw[j], af[i], acc[i][j], 0, 0, 0);
         }
-        if (kt + 1 < nk) sstore(buf ^ 1);
+        if (!GLDS && kt + 1 < nk) sstore(buf ^ 1);
         __syncthreads();
     }
 
@@ -201,6 +229,7 @@ struct TNArgs {
     const bf16_t* A; long lda;   // (M, N)  dY
     const bf16_t* B; long ldb;   // (M, K)  X
     float* C; long ldc;          // (N, K)
+    float* ws;                   // [splits][N][K] partial tiles when splits > 1
     int M, N, K, splits, chunk;
 };
 
@@ -297,8 +326,13 @@ __global__ __launch_bounds__(256) void gemm_tn_kernel(TNArgs p) {
         if (s + 1 < nsteps) sstore(buf ^ 1);
         __syncthreads();
     }
-    if (nsteps <= 0) return;
     // acc[i][j]: C[n = n0+wn*64+j*16+q][k = k0+wk*64+i*16+4g+r]
+    // splits == 1: C += acc.  splits > 1: plain stores of the partial tile into ws[split] (combined by
+    // tn_reduce_kernel: fp32 atomics on C ran at ~60 G atomics/s and dominated small-output weight gradients).
+    const bool to_ws = p.splits > 1;
+    float* base = to_ws ? p.ws + (long)blockIdx.y * p.N * p.K : p.C;
+    const long ld = to_ws ? p.K : p.ldc;
+    const bool vec = to_ws && (p.K & 3) == 0;
 #pragma unroll
     for (int j = 0; j < 4; ++j) {
         const int n = n0 + wn * 64 + j * 16 + q;
@@ -306,16 +340,44 @@ __global__ __launch_bounds__(256) void gemm_tn_kernel(TNArgs p) {
 #pragma unroll
         for (int i = 0; i < 4; ++i) {
             const int k = k0 + wk * 64 + i * 16 + 4 * g;
-            float* c = p.C + (long)n * p.ldc + k;
+            float* c = base + (long)n * ld + k;
+            if (vec && k + 3 < p.K) {
+                st<f32x4>(c, acc[i][j]);
+            } else {
 #pragma unroll
-            for (int r = 0; r < 4; ++r) {
-                if (k + r < p.K) {
-                    if (p.splits > 1) atomicAdd(c + r, acc[i][j][r]);
-                    else c[r] += acc[i][j][r];
+                for (int r = 0; r < 4; ++r) {
+                    if (k + r < p.K) {
+                        if (to_ws) c[r] = acc[i][j][r];
+                        else c[r] += acc[i][j][r];
+                    }
                 }
             }
         }
     }
+}
+
+__global__ __launch_bounds__(256) void tn_reduce_kernel(const float* ws, float* C, long ldc, int N, int K, int splits) {
+    const long total = (long)N * K;
+    for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < total; i += (long)gridDim.x * 256) {
+        float s = 0.f;
+        for (int sp = 0; sp < splits; ++sp) s += ws[(long)sp * total + i];
+        const int n = (int)(i / K), k = (int)(i % K);
+        C[(long)n * ldc + k] += s;
+    }
+}
+
+int tn_splits(int M, int N, int K, int splits) {
+    const int tn = (N + 127) / 128, tk = (K + 127) / 128;
+    if (splits <= 0) {
+        // about two workgroups per CU, at least 8 reduction steps (512 token rows) per split
+        int want = (512 + tn * tk - 1) / (tn * tk);
+        int maxs = (M + 511) / 512;
+        splits = want < 1 ? 1 : (want > maxs ? maxs : want);
+        if (splits < 1) splits = 1;
+    }
+    int chunk = (M + splits - 1) / splits;
+    chunk = (chunk + TBM - 1) / TBM * TBM;
+    return (M + chunk - 1) / chunk;
 }
 
 }  // namespace
@@ -323,7 +385,8 @@ __global__ __launch_bounds__(256) void gemm_tn_kernel(TNArgs p) {
 extern "C" int e2k_gemm_nt_bf16(const void* A1, int64_t lda1, int K1, const void* A2, int64_t lda2, int K2,
                                 const void* B, int64_t ldb, void* C, int64_t ldc, int out_f32, int accumulate,
                                 int M, int N, const float* bias, const float* colscale, int64_t lds,
-                                int rows_per_batch, const uint8_t* rowmask, const void* resid, int64_t ldr, void* stream) {
+                                int rows_per_batch, const uint8_t* rowmask, const void* resid, int64_t ldr, int flags,
+                                void* stream) {
     if (M <= 0 || N <= 0) return 0;
     if (K1 <= 0 || (K1 & 7) || (K2 & 7) || K2 < 0) return E2K_ERR_SHAPE;
     if ((lda1 & 7) || (ldb & 7) || (K2 > 0 && ((lda2 & 7) || A2 == nullptr))) return E2K_ERR_ALIGN;
@@ -340,34 +403,50 @@ extern "C" int e2k_gemm_nt_bf16(const void* A1, int64_t lda1, int K1, const void
     p.rowmask = rowmask; p.resid = (const bf16_t*)resid; p.ldr = ldr;
     const int tm = (M + BM - 1) / BM, tn = (N + BN - 1) / BN;
     dim3 grid(tm * tn), block(256);
-    if (out_f32) hipLaunchKernelGGL(gemm_nt_kernel<true>, grid, block, 0, (hipStream_t)stream, p);
-    else hipLaunchKernelGGL(gemm_nt_kernel<false>, grid, block, 0, (hipStream_t)stream, p);
+    const bool glds = !(flags & E2K_GEMM_NO_GLDS) && (K1 % BK) == 0 && (K2 % BK) == 0;
+    hipStream_t st = (hipStream_t)stream;
+    if (out_f32) {
+        if (glds) hipLaunchKernelGGL((gemm_nt_kernel<true, true>), grid, block, 0, st, p);
+        else hipLaunchKernelGGL((gemm_nt_kernel<true, false>), grid, block, 0, st, p);
+    } else {
+        if (glds) hipLaunchKernelGGL((gemm_nt_kernel<false, true>), grid, block, 0, st, p);
+        else hipLaunchKernelGGL((gemm_nt_kernel<false, false>), grid, block, 0, st, p);
+    }
     E2K_CHECK_LAUNCH();
     return 0;
 }
 
+extern "C" int e2k_query_gemm_tn_splits(int M, int N, int K, int splits) {
+    if (M <= 0 || N <= 0 || K <= 0) return 1;
+    return tn_splits(M, N, K, splits);
+}
+
 extern "C" int e2k_gemm_tn_bf16(const void* A, int64_t lda, const void* B, int64_t ldb, float* C, int64_t ldc,
-                                int M, int N, int K, int splits, int use_tr, void* stream) {
+                                int M, int N, int K, int splits, int use_tr, float* ws, void* stream) {
     if (M <= 0 || N <= 0 || K <= 0) return 0;
     // 16-B loads may run past N / K up to the next multiple of 8: that must still be inside the row
     if ((lda & 7) || (ldb & 7) || ((N + 7) & ~7) > lda || ((K + 7) & ~7) > ldb) return E2K_ERR_ALIGN;
     if (((uintptr_t)A | (uintptr_t)B) & 15) return E2K_ERR_ALIGN;
     const int tn = (N + 127) / 128, tk = (K + 127) / 128;
-    if (splits <= 0) {
-        // enough (tile, split) pairs to fill 256 CUs about 4x over, at least 256 rows per split
-        int want = (1024 + tn * tk - 1) / (tn * tk);
-        int maxs = (M + 255) / 256;
-        splits = want < 1 ? 1 : (want > maxs ? maxs : want);
-    }
+    splits = tn_splits(M, N, K, splits);
     int chunk = (M + splits - 1) / splits;
     chunk = (chunk + TBM - 1) / TBM * TBM;
-    splits = (M + chunk - 1) / chunk;
+    if (splits > 1 && ws == nullptr) return E2K_ERR_ARG;
     TNArgs p;
+    p.ws = ws;
     p.A = (const bf16_t*)A; p.lda = lda; p.B = (const bf16_t*)B; p.ldb = ldb;
     p.C = C; p.ldc = ldc; p.M = M; p.N = N; p.K = K; p.splits = splits; p.chunk = chunk;
     dim3 grid(tn * tk, splits), block(256);
     if (use_tr) hipLaunchKernelGGL(gemm_tn_kernel<true>, grid, block, 0, (hipStream_t)stream, p);
     else hipLaunchKernelGGL(gemm_tn_kernel<false>, grid, block, 0, (hipStream_t)stream, p);
     E2K_CHECK_LAUNCH();
+    if (splits > 1) {
+        long total = (long)N * K;
+        long g = (total + 255) / 256;
+        if (g > 2048) g = 2048;
+        hipLaunchKernelGGL(tn_reduce_kernel, dim3((int)g), dim3(256), 0, (hipStream_t)stream, (const float*)ws, C,
+                           (long)ldc, N, K, splits);
+        E2K_CHECK_LAUNCH();
+    }
     return 0;
 }

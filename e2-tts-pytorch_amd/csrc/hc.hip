@@ -315,35 +315,61 @@ struct HCReduceArgs {
     float *g_static_beta, *g_static_alpha, *g_dyn_alpha_fn, *g_dyn_alpha_scale, *g_dyn_beta_fn, *g_dyn_beta_scale, *g_gamma;
 };
 
+// grid = D/32 + 1 workgroups.  Workgroup b < D/32: 32 columns d x 8 row-groups, each thread sums nblocks/8 partial
+// rows (coalesced over d), LDS tree over the row-groups.  Last workgroup: the 26 scalar gradients.
 __global__ __launch_bounds__(256) void hc_reduce_kernel(HCReduceArgs p) {
+    __shared__ float red[8][NJ][32];
     const int D = p.D, stride = NJ * D + NSC;
-    const int i = blockIdx.x * 256 + threadIdx.x;
-    if (i < D) {
+    const int tid = threadIdx.x;
+    if ((int)blockIdx.x < D / 32) {
+        const int dl = tid & 31, part = tid >> 5;
+        const int d = blockIdx.x * 32 + dl;
         float acc[NJ];
 #pragma unroll
         for (int j = 0; j < NJ; ++j) acc[j] = 0.f;
-        for (int b = 0; b < p.nblocks; ++b) {
+        for (int b = part; b < p.nblocks; b += 8) {
 #pragma unroll
-            for (int j = 0; j < NJ; ++j) acc[j] += p.partial[(long)b * stride + j * D + i];
+            for (int j = 0; j < NJ; ++j) acc[j] += p.partial[(long)b * stride + j * D + d];
         }
-        const float g = p.hp.gamma[i] + 1.f;
-        float dg = 0.f;
 #pragma unroll
-        for (int t = 0; t < 5; ++t) {
-            p.g_dyn_alpha_fn[i * 5 + t] += g * acc[t];
-            dg = fmaf(p.hp.dyn_alpha_fn[i * 5 + t], acc[t], dg);
+        for (int j = 0; j < NJ; ++j) red[part][j][dl] = acc[j];
+        __syncthreads();
+        if (part == 0) {
+#pragma unroll
+            for (int j = 0; j < NJ; ++j) {
+                float s = 0.f;
+#pragma unroll
+                for (int q = 0; q < 8; ++q) s += red[q][j][dl];
+                acc[j] = s;
+            }
+            const float g = p.hp.gamma[d] + 1.f;
+            float dg = 0.f;
+#pragma unroll
+            for (int t = 0; t < 5; ++t) {
+                p.g_dyn_alpha_fn[d * 5 + t] += g * acc[t];
+                dg = fmaf(p.hp.dyn_alpha_fn[d * 5 + t], acc[t], dg);
+            }
+            p.g_dyn_beta_fn[d] += g * acc[5];
+            dg = fmaf(p.hp.dyn_beta_fn[d], acc[5], dg);
+            p.g_gamma[d] += dg;
         }
-        p.g_dyn_beta_fn[i] += g * acc[5];
-        dg = fmaf(p.hp.dyn_beta_fn[i], acc[5], dg);
-        p.g_gamma[i] += dg;
-    } else if (i < D + 26) {
-        const int k = i - D;
+    } else {
+        // 26 scalars x 8 row-groups (208 threads)
+        const int k = tid & 31, part = tid >> 5;
         float acc = 0.f;
-        for (int b = 0; b < p.nblocks; ++b) acc += p.partial[(long)b * stride + NJ * D + k];
-        if (k < 20) p.g_static_alpha[k] += acc;
-        else if (k < 24) p.g_static_beta[k - 20] += acc;
-        else if (k == 24) p.g_dyn_alpha_scale[0] += acc;
-        else p.g_dyn_beta_scale[0] += acc;
+        if (k < 26)
+            for (int b = part; b < p.nblocks; b += 8) acc += p.partial[(long)b * stride + NJ * D + k];
+        red[part][0][k] = acc;
+        __syncthreads();
+        if (part == 0 && k < 26) {
+            float s = 0.f;
+#pragma unroll
+            for (int q = 0; q < 8; ++q) s += red[q][0][k];
+            if (k < 20) p.g_static_alpha[k] += s;
+            else if (k < 24) p.g_static_beta[k - 20] += s;
+            else if (k == 24) p.g_dyn_alpha_scale[0] += s;
+            else p.g_dyn_beta_scale[0] += s;
+        }
     }
 }
 
@@ -374,7 +400,7 @@ int grid_for(int Mtok, int max_blocks) {
 }  // namespace
 
 extern "C" int e2k_query_hc_coef_width(void) { return CW; }
-extern "C" int e2k_query_hc_bwd_blocks(int Mtok) { return grid_for(Mtok, 512); }
+extern "C" int e2k_query_hc_bwd_blocks(int Mtok) { return grid_for(Mtok, 256); }
 extern "C" int e2k_query_hc_partial_stride(int D) { return NJ * D + NSC; }
 
 extern "C" int e2k_hc_fwd(const void* Xin, const void* yprev, const float* coef_prev, void* Mout, void* bin,
@@ -412,7 +438,7 @@ extern "C" int e2k_hc_bwd(const void* Xin, const void* yprev, const float* coef_
     a.partial = partial; a.Mtok = Mtok;
     if (!G || (has_depth && (!yprev || !coef_prev || !dyprev))) return E2K_ERR_ARG;
     if (has_width && (!Xin || !dbin || !ycur || !coef || !dR || !partial || !gamma || !g_gamma)) return E2K_ERR_ARG;
-    const int grid = grid_for(Mtok, 512);
+    const int grid = grid_for(Mtok, 256);     // one workgroup per CU (the kernel runs at one wave per SIMD)
     int rc = 0;
     E2K_ROW_DISPATCH(D, launch_bwd, a, has_depth != 0, has_width != 0, grid, (hipStream_t)stream);
     if (rc) return rc;
@@ -423,7 +449,7 @@ extern "C" int e2k_hc_bwd(const void* Xin, const void* yprev, const float* coef_
         r.g_static_beta = g_static_beta; r.g_static_alpha = g_static_alpha; r.g_dyn_alpha_fn = g_dyn_alpha_fn;
         r.g_dyn_alpha_scale = g_dyn_alpha_scale; r.g_dyn_beta_fn = g_dyn_beta_fn; r.g_dyn_beta_scale = g_dyn_beta_scale;
         r.g_gamma = g_gamma;
-        hipLaunchKernelGGL(hc_reduce_kernel, dim3((D + 26 + 255) / 256), dim3(256), 0, (hipStream_t)stream, r);
+        hipLaunchKernelGGL(hc_reduce_kernel, dim3(D / 32 + 1), dim3(256), 0, (hipStream_t)stream, r);
         E2K_CHECK_LAUNCH();
     }
     return 0;

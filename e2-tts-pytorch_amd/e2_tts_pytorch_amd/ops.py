@@ -69,7 +69,8 @@ def gemm_nt(a, b, *, a2=None, out=None, out_dtype=bf16, accumulate=False, bias=N
         e0.record()
     _lib.get().e2k_gemm_nt_bf16(_p(a), lda, K1, _p(a2), lda2, K2, _p(b), ldb, _p(out), out.stride(0),
                                 int(out.dtype == f32), int(accumulate), M, N, _p(bias), _p(colscale),
-                                0 if colscale is None else colscale.stride(0), int(rows_per_batch), _p(rowmask), _p(resid), ldr, _stream(a))
+                                0 if colscale is None else colscale.stride(0), int(rows_per_batch), _p(rowmask), _p(resid), ldr,
+                                gemm_flags, _stream(a))
     if prof is not None and a.is_cuda:
         e1.record()
         prof.append((2.0 * M * N * (K1 + K2), e0, e1))
@@ -77,6 +78,7 @@ def gemm_nt(a, b, *, a2=None, out=None, out_dtype=bf16, accumulate=False, bias=N
 
 
 _gemm_profile = None
+gemm_flags = 0          # E2K_GEMM_* bits passed to every gemm_nt call (A/B benchmarking of kernel variants)
 
 
 def set_gemm_profile(lst):
@@ -95,8 +97,11 @@ def gemm_tn(a, b, out, *, splits=0, use_tr=True):
     assert M == M2
     N, K = a.shape[1], b.shape[1]
     assert out.shape == (N, K) and out.stride(1) == 1
-    _lib.get().e2k_gemm_tn_bf16(_p(a), lda, _p(b), ldb, _p(out), out.stride(0), M, N, K, int(splits),
-                                int(use_tr), _stream(a))
+    lib = _lib.get()
+    ns = lib.e2k_query_gemm_tn_splits(M, N, K, int(splits))
+    ws = torch.empty((ns * N * K,), dtype=f32, device=a.device) if ns > 1 else None
+    lib.e2k_gemm_tn_bf16(_p(a), lda, _p(b), ldb, _p(out), out.stride(0), M, N, K, int(splits), int(use_tr), _p(ws),
+                         _stream(a))
     return out
 
 

@@ -38,13 +38,18 @@ int e2k_version(void);
 int e2k_gemm_nt_bf16(const void* A1, int64_t lda1, int K1, const void* A2, int64_t lda2, int K2,
                      const void* B, int64_t ldb, void* C, int64_t ldc, int out_f32, int accumulate,
                      int M, int N, const float* bias, const float* colscale, int64_t lds,
-                     int rows_per_batch, const uint8_t* rowmask, const void* resid, int64_t ldr, void* stream);
+                     int rows_per_batch, const uint8_t* rowmask, const void* resid, int64_t ldr, int flags,
+                     void* stream);
+#define E2K_GEMM_NO_GLDS 1   /* flags: stage operands through VGPRs instead of global_load_lds (A/B benchmarking) */
 
 /* C[N,K] += A[M,N]^T . B[M,K]  (weight gradients; C fp32, A = dY, B = X, bf16).  The token dimension M is
  * split over `splits` workgroups per tile (0 = choose), partial tiles are combined with fp32 atomics.
  * use_tr = 1 reads MFMA fragments with ds_read_b64_tr_b16, 0 = plain 16-bit LDS gathers (same results). */
 int e2k_gemm_tn_bf16(const void* A, int64_t lda, const void* B, int64_t ldb, float* C, int64_t ldc,
-                     int M, int N, int K, int splits, int use_tr, void* stream);
+                     int M, int N, int K, int splits, int use_tr, float* ws, void* stream);
+/* number of token-dimension splits the call above will use for (M, N, K, splits); when it is > 1 the caller passes
+ * ws = scratch of splits*N*K floats (partial tiles are stored there and combined by a second small kernel). */
+int e2k_query_gemm_tn_splits(int M, int N, int K, int splits);
 
 /* ---- hyper-connections (hyper_connections.HyperConnections; reference call sites e2_tts.py:870-882,900-939) ----
  * Streams are stored token-major: X[token][4][D] bf16.  coef: per-token fp32 record (e2k_query_hc_coef_width()

@@ -26,4 +26,9 @@ inline s16x4_ lds_read_tr16_b64(const void* lds_ptr) {
     return r;
 }
 
+// host model of global_load_lds_dwordx4: lane l copies its 16 bytes to (wave-uniform) lds_base + 16*l
+inline void glds16(const void* gsrc, void* lds_base) {
+    memcpy((char*)lds_base + 16 * emu::lane_id(), gsrc, 16);
+}
+
 }  // namespace e2k

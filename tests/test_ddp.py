@@ -1,0 +1,76 @@
+"""Data-parallel path: 2 ranks over gloo on CPU (kernels = host logic-checker build).  The per-layer slab all-reduce
+inside the hand-scheduled backward must give every rank the mean of the per-rank gradients, i.e. the gradient of the
+mean loss over the global batch, for backbone and non-backbone parameters alike (also when one rank drops the text)."""
+import os
+import random
+import sys
+from pathlib import Path
+
+import pytest
+import torch
+import torch.distributed as dist
+import torch.multiprocessing as mp
+
+ROOT = Path(__file__).resolve().parent.parent
+
+
+def _worker(rank, world, port, emu_lib, q):
+    sys.path[:0] = [str(ROOT / 'e2-tts-pytorch_amd'), str(ROOT), str(ROOT / 'tests')]
+    os.environ.update(MASTER_ADDR='127.0.0.1', MASTER_PORT=str(port), E2K_EMU_THREADS='2')
+    torch.set_num_threads(2)
+    dist.init_process_group('gloo', rank=rank, world_size=world)
+    from e2_tts_pytorch_amd import E2TTS, _lib
+    from e2_tts_pytorch_amd.ddp import DataParallel
+    from test_backbone import randomize
+    _lib._install_for_tests(emu_lib, host_pointers=True)
+    random.seed(7 + rank)                 # different init per rank: the wrapper must broadcast rank 0's weights
+    torch.manual_seed(7 + rank)
+    model = E2TTS(transformer=dict(dim=256, depth=2, heads=4, dropout=0.), use_vocos=False, cond_drop_prob=0.)
+    randomize(model, seed=rank)
+    net = DataParallel(model)
+    torch.manual_seed(100)
+    B, T = 1, 24
+    mels = torch.randn(world, B, T, 100)
+    noises = [dict(x0=torch.randn(B, T, 100), times=torch.rand(B), frac_lengths=torch.tensor([0.8]),
+                   span_rand=torch.tensor([0.4]), drop_text_cond=(r == 1)) for r in range(world)]
+    out = net(mels[rank], text=['hello'], _noise=noises[rank])
+    out.loss.backward()
+    grads = {n: p.grad.clone() for n, p in model.named_parameters() if p.grad is not None}
+    if rank == 0:
+        # single-process reference with the broadcast weights: mean over both "ranks" of the per-sample gradients
+        ref = E2TTS(transformer=dict(dim=256, depth=2, heads=4, dropout=0.), use_vocos=False, cond_drop_prob=0.)
+        ref.load_state_dict(model.state_dict())
+        acc = {}
+        for r in range(world):
+            ref.zero_grad(set_to_none=True)
+            o = ref(mels[r], text=['hello'], _noise=noises[r])
+            o.loss.backward()
+            for n, p in ref.named_parameters():
+                if p.grad is not None:
+                    acc[n] = acc.get(n, 0) + p.grad / world
+        bad = []
+        for n, g in acc.items():
+            err = ((grads[n] - g).norm() / g.norm().clamp_min(1e-12)).item() if float(g.norm()) > 0 else float(grads[n].norm())
+            if err > 2e-2:
+                bad.append((n, err))
+        q.put(('ok', bad, net._sync.calls))
+    else:
+        q.put(('ok', [], net._sync.calls))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_two_rank_gradient_mean(emu_lib):
+    ctx = mp.get_context('spawn')
+    q = ctx.Queue()
+    port = 29500 + os.getpid() % 2000
+    procs = [ctx.Process(target=_worker, args=(r, 2, port, str(emu_lib), q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    res = [q.get(timeout=900) for _ in procs]
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    for status, bad, calls in res:
+        assert status == 'ok' and not bad, bad[:10]
+        assert calls >= 3          # one slab per layer + the global/conditioning slab

@@ -121,3 +121,25 @@ def test_duration_predictor(dev):
     with torch.no_grad():
         pred = model(mel.to(dev), text=['ab', 'cde'], lens=lens.to(dev), return_loss=False)
     assert rel2(pred, pred_r) < 2e-2
+
+
+def test_against_golden_fixture(dev):
+    """HIP path vs the committed oracle outputs (tests/golden/oracle_small.pt, made by tests/golden/make_golden.py)"""
+    from pathlib import Path
+    from e2_tts_pytorch_amd import E2TTS, MelSpec
+    fix = torch.load(Path(__file__).resolve().parent / 'golden' / 'oracle_small.pt', weights_only=False)
+    random.seed(fix['seeds'][0])
+    torch.manual_seed(fix['seeds'][0])
+    ref = O.E2TTS(transformer=dict(**fix['kw']), cond_drop_prob=0.)
+    randomize(ref, seed=fix['seeds'][1])
+    model = E2TTS(transformer=dict(**fix['kw']), use_vocos=False, cond_drop_prob=0.)
+    model.load_state_dict(ref.state_dict(), strict=True)
+    model = model.to(dev)
+    dn = {k: (v.to(dev) if torch.is_tensor(v) else v) for k, v in fix['noise'].items()}
+    out = model(fix['mel'].to(dev), text=fix['text'], lens=fix['lens'].to(dev), _noise=dn)
+    out.loss.backward()
+    assert abs(out.loss.item() - fix['loss'].item()) / abs(fix['loss'].item()) < 1e-2
+    assert rel2(out.pred_flow, fix['pred_flow']) < 1e-2
+    assert rel2(model.to_pred.weight.grad, fix['grad_to_pred']) < 5e-2
+    assert rel2(model.transformer.registers.grad, fix['grad_registers']) < 0.15
+    assert (MelSpec()(fix['wave'].to(dev)).cpu() - fix['logmel']).abs().max().item() < 2e-3

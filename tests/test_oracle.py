@@ -1,0 +1,156 @@
+"""Pins the CPU oracle (PARITY UNPINNED w.r.t. the reference, which cannot be imported here -- SURVEY.md 8c):
+independent implementations available in the container, analytic invariants of the reference initialisation,
+fp64 self-consistency, and the committed golden fixture."""
+import math
+import random
+from pathlib import Path
+
+import pytest
+import torch
+import torch.nn.functional as F
+
+from oracle import e2tts_oracle as O
+from oracle.dropout_hash import attn_dropout_mask, geglu_dropout_mask
+
+GOLD = Path(__file__).resolve().parent / 'golden' / 'oracle_small.pt'
+
+
+def test_fbank_against_hf():
+    from transformers.audio_utils import mel_filter_bank
+    fb = O.melscale_fbanks_htk(513, 0., 12000., 100, 24000)
+    hf = torch.from_numpy(mel_filter_bank(513, 100, 0., 12000., 24000, norm=None, mel_scale='htk')).float()
+    assert fb.shape == hf.shape == (513, 100)
+    assert (fb - hf).abs().max().item() < 2e-5
+
+
+def test_melspec_shape_and_manual_dft():
+    torch.manual_seed(0)
+    wave = torch.randn(1, 256 * 4)
+    mel = O.MelSpec()(wave)
+    assert mel.shape == (1, 100, 5)
+    # frame 2 by hand: reflect pad, periodic Hann, explicit DFT in fp64
+    x = F.pad(wave[:, None], (512, 512), mode='reflect')[0, 0].double()
+    fr = x[2 * 256:2 * 256 + 1024] * torch.hann_window(1024, periodic=True).double()
+    k = torch.arange(513).double()[:, None] * torch.arange(1024).double()[None, :]
+    spec = torch.complex(torch.cos(2 * math.pi * k / 1024), -torch.sin(2 * math.pi * k / 1024)) @ torch.complex(fr, torch.zeros_like(fr))
+    ref = (spec.abs().float() @ O.melscale_fbanks_htk(513, 0., 12000., 100, 24000)).clamp(min=1e-5).log()
+    assert (mel[0, :, 2] - ref).abs().max().item() < 1e-3
+
+
+def test_attention_against_sdpa():
+    """softclamp off, no gate: the restated attention must equal torch's own SDPA"""
+    torch.manual_seed(0)
+    attn = O.Attention(dim=128, heads=2, dim_head=64, gate_value_heads=False, softclamp_logits=False)
+    x = torch.randn(2, 17, 128)
+    mask = torch.arange(17)[None] < torch.tensor([17, 11])[:, None]
+    out = attn(x, mask=mask)
+    q, k, v = (lin(x).view(2, 17, 2, 64).transpose(1, 2) for lin in (attn.to_q, attn.to_k, attn.to_v))
+    ref = F.scaled_dot_product_attention(q, k, v, attn_mask=mask[:, None, None, :])
+    ref = attn.to_out(ref.transpose(1, 2).reshape(2, 17, 128)) * mask[..., None]
+    assert (out - ref).abs().max().item() < 1e-5
+
+
+def test_rotary_is_a_rotation_of_adjacent_pairs():
+    freqs, _ = O.RotaryEmbedding(64).forward_from_seq_len(9)
+    assert freqs.shape == (1, 9, 64) and torch.equal(freqs[..., 0::2], freqs[..., 1::2])
+    assert abs(freqs[0, 1, 2].item() - 10000 ** (-2 / 64)) < 1e-6
+    t = torch.randn(1, 2, 9, 64)
+    r = O.apply_rotary_pos_emb(t, freqs)
+    assert torch.allclose(r.norm(dim=-1), t.norm(dim=-1), atol=1e-4)
+    # relative-position property: <R_m q, R_n k> depends on m - n only
+    q, k = torch.randn(64), torch.randn(64)
+    rot = lambda v, n: O.apply_rotary_pos_emb(v.expand(1, 1, 9, 64).clone(), freqs)[0, 0, n]
+    assert abs((rot(q, 5) @ rot(k, 3)).item() - (rot(q, 7) @ rot(k, 5)).item()) < 1e-3
+
+
+def test_init_invariants():
+    """at initialisation the zero-init paths make exact statements possible"""
+    random.seed(0)
+    torch.manual_seed(0)
+    tr = O.Transformer(dim=128, depth=2, heads=2, dropout=0.)
+    tr.eval()
+    x = torch.randn(1, 10, 128)
+    t = torch.rand(1)
+    txt = torch.randn(1, 10, 64)
+    # cross-conditioning weights are zero at init: the speech output must not depend on the text stream
+    assert torch.allclose(tr(x, times=t, text_embed=txt), tr(x, times=t, text_embed=None), atol=1e-5)
+    # adaptive gamma weights are zero: AdaptiveRMSNorm == plain RMSNorm with g = 1
+    n = tr.layers[0][0][2]
+    assert torch.allclose(n(x, condition=torch.randn(1, 128)), F.normalize(x, dim=-1) * 128 ** 0.5, atol=1e-6)
+    # AdaLN-Zero gate is sigmoid(-2) for every channel at init
+    g = tr.layers[0][0][5]
+    assert torch.allclose(g(torch.ones(1, 3, 128), condition=torch.randn(1, 128)), torch.full((1, 3, 128), 0.11920292), atol=1e-6)
+    # hyper-connections at init: branch input = one of the 4 (identical) streams, beta = 1
+    hc = tr.hyper_conns[0][0][0]
+    xs = O.hc_expand(x, 4)
+    b, add = hc(xs)
+    assert torch.allclose(b, x, atol=1e-6)
+    assert torch.allclose(add(torch.zeros_like(x)), xs, atol=1e-6)
+    assert torch.allclose(O.hc_reduce(add(torch.ones_like(x)), 4), 4 * (x + 1), atol=1e-5)
+
+
+def test_fp64_consistency_and_grad():
+    random.seed(1)
+    torch.manual_seed(1)
+    m = O.E2TTS(transformer=dict(dim=128, depth=2, heads=2, dropout=0.), cond_drop_prob=0.)
+    mel = torch.randn(1, 12, 100)
+    noise = dict(x0=torch.randn(1, 12, 100), times=torch.rand(1), frac_lengths=torch.tensor([0.9]),
+                 span_rand=torch.tensor([0.1]), drop_text_cond=False)
+    l32 = m(mel, text=['ab'], _noise=noise).loss
+    m64 = m.double()
+    n64 = {k: (v.double() if torch.is_tensor(v) and v.is_floating_point() else v) for k, v in noise.items()}
+    l64 = m64(mel.double(), text=['ab'], _noise=n64).loss
+    assert abs(l32.item() - l64.item()) < 1e-4 * abs(l64.item())
+    # directional finite difference of the loss w.r.t. to_pred.weight in fp64
+    l64.backward()
+    w = m64.to_pred.weight
+    d = torch.randn_like(w)
+    eps = 1e-6
+    with torch.no_grad():
+        w.add_(eps * d)
+        lp = m64(mel.double(), text=['ab'], _noise=n64).loss
+        w.sub_(2 * eps * d)
+        lm = m64(mel.double(), text=['ab'], _noise=n64).loss
+        w.add_(eps * d)
+    fd = (lp - lm) / (2 * eps)
+    assert abs(fd.item() - (w.grad * d).sum().item()) < 1e-5 * max(1.0, abs(fd.item()))
+
+
+def test_midpoint_ode():
+    """dy/dt = y on [0,1] with the explicit midpoint rule: (1 + h + h^2/2)^n"""
+    t = torch.linspace(0, 1, 5)
+    traj = O.odeint_midpoint(lambda _t, y: y, torch.ones(1), t)
+    assert abs(traj[-1].item() - (1 + 0.25 + 0.25 ** 2 / 2) ** 4) < 1e-5
+
+
+def test_project_is_orthogonal():
+    x, y = torch.randn(3, 7, 5), torch.randn(3, 7, 5)
+    par, orth = O.project(x, y)
+    assert torch.allclose(par + orth, x, atol=1e-5)
+    assert (orth.flatten(1) * y.flatten(1)).sum(-1).abs().max().item() < 1e-4
+
+
+def test_dropout_hash_statistics():
+    m = attn_dropout_mask(1, 2, 1, 2, 64, 0.1)
+    assert all(v == 0.0 or abs(v - 1 / 0.9) < 1e-6 for v in m.unique().tolist())
+    assert abs((m == 0).float().mean().item() - 0.1) < 0.02
+    g = geglu_dropout_mask(3, 4, 50, 64, 0.1)
+    assert abs((g == 0).float().mean().item() - 0.1) < 0.03
+    assert not torch.equal(attn_dropout_mask(1, 2, 1, 1, 32, 0.5), attn_dropout_mask(2, 2, 1, 1, 32, 0.5))
+
+
+def test_golden_fixture():
+    fix = torch.load(GOLD, weights_only=False)
+    from test_backbone import randomize
+    random.seed(fix['seeds'][0])
+    torch.manual_seed(fix['seeds'][0])
+    model = O.E2TTS(transformer=dict(**fix['kw']), cond_drop_prob=0.)
+    randomize(model, seed=fix['seeds'][1])
+    wsum = sum(float(v.double().abs().sum()) for v in model.state_dict().values())
+    assert abs(wsum - fix['weight_abs_sum']) < 1e-6 * fix['weight_abs_sum'], 'seeded weights differ from the fixture run'
+    out = model(fix['mel'], text=fix['text'], lens=fix['lens'], _noise=fix['noise'])
+    out.loss.backward()
+    assert abs(out.loss.item() - fix['loss'].item()) < 1e-5
+    assert (out.pred_flow - fix['pred_flow']).abs().max().item() < 1e-4
+    assert (model.to_pred.weight.grad - fix['grad_to_pred']).abs().max().item() < 1e-4
+    assert (O.MelSpec()(fix['wave']) - fix['logmel']).abs().max().item() < 1e-4
