@@ -16,6 +16,7 @@
 // the key order inside a 64-key tile is permuted so that the accumulator registers of S^T are directly the
 // B-operand fragment of the second MFMA (O^T = V^T.P^T): no LDS round trip for P.
 #include "e2k_device.h"
+#include <e2k_asm.h>
 #include "../../include/e2k.h"
 
 using namespace e2k;
@@ -25,7 +26,8 @@ namespace {
 constexpr int DH = 64;
 constexpr float LOG2E = 1.4426950408889634f;
 constexpr float CLAMP = 50.f;
-constexpr float NEG_BIG = -1e30f;
+constexpr float NEG_BIG = -1e30f;     // initial running max
+constexpr float NEG_MASK = -2e30f;    // masked score (below NEG_BIG so that exp2(masked - max) is 0 even before any valid key)
 
 // swizzled [64][64] bf16 tile: 128-B rows, 16-B slot index XOR (row & 7)
 __device__ __forceinline__ int tile_off(int row, int slot) { return row * 128 + ((slot ^ (row & 7)) << 4); }
@@ -60,17 +62,19 @@ __device__ __forceinline__ bf16x8 tile_frag(const unsigned char* lds, int row, i
 }
 
 __device__ __forceinline__ bf16x8 pack_frag(const float* lo4, const float* hi4) {
-    bf16x8 f;
-#pragma unroll
-    for (int r = 0; r < 4; ++r) { f[r] = (short)f2bf(lo4[r]); f[4 + r] = (short)f2bf(hi4[r]); }
-    return f;
+    u32x4 v = {pack2bf(lo4[0], lo4[1]), pack2bf(lo4[2], lo4[3]), pack2bf(hi4[0], hi4[1]), pack2bf(hi4[2], hi4[3])};
+    return __builtin_bit_cast(bf16x8, v);
 }
 
-__device__ __forceinline__ float drop_scale(unsigned seed, unsigned stream, int q, int key, unsigned thresh, float inv_keep) {
-    unsigned h = rand_u32(seed, stream, (unsigned)q, (unsigned)key >> 1);
-    unsigned r16 = (key & 1) ? (h >> 16) : (h & 0xffffu);
-    return r16 >= thresh ? inv_keep : 0.f;
-}
+// dropout keep flags of the key pair (2j, 2j+1) for query row q: one hash, low / high 16 bits
+// (hrow = rand_base(seed, stream) + q * 0x85ebca77 is hoisted by the caller; oracle/dropout_hash.py restates this)
+__device__ __forceinline__ unsigned drop_hash(unsigned hrow, unsigned keypair) { return fmix32(hrow + keypair * 0xc2b2ae3du); }
+
+// soft-clamp: tanh(raw * scale / 50) via one v_exp_f32 and one v_rcp_f32: tanh(x) = 1 - 2 / (2^(2 x log2 e) + 1)
+__device__ __forceinline__ float clamp_tanh(float raw, float k2) { return 1.f - 2.f * fast_rcp(fast_exp2(raw * k2) + 1.f); }
+
+// the 8 mask bytes (each 0 / 1) of a lane's keys -> 8 bits
+__device__ __forceinline__ unsigned mask_bits(unsigned long long m) { return (unsigned)((m * 0x0102040810204080ull) >> 56); }
 
 // ------------------------------------------------------------------------------------------------ qkv post
 
@@ -230,10 +234,6 @@ __device__ __forceinline__ void score_tile(const unsigned char* Kt, const bf16x8
     }
 }
 
-__device__ __forceinline__ float softclamp2(float raw, float scale) {
-    // 50*tanh(raw*scale/50), returned in the log2 domain
-    return CLAMP * LOG2E * tanhf_(raw * (scale / CLAMP));
-}
 
 __global__ __launch_bounds__(256) void attn_fwd_kernel(AttnArgs p) {
     __shared__ __attribute__((aligned(16))) unsigned char Kt[64 * 128];
@@ -255,6 +255,8 @@ __global__ __launch_bounds__(256) void attn_fwd_kernel(AttnArgs p) {
 #pragma unroll
     for (int ct = 0; ct < 4; ++ct) o[ct] = f32x4{0.f, 0.f, 0.f, 0.f};
     float m = NEG_BIG, lsum = 0.f;
+    const float k2 = 2.f * LOG2E * p.scale / CLAMP, cl2 = CLAMP * LOG2E;
+    const unsigned hrow = rand_base(p.seed, dstream) + (unsigned)q * 0x85ebca77u;
 
     const int ntiles = (p.N + 63) / 64;
     const bf16_t* Kbase = p.K + bh * p.N * DH;
@@ -272,34 +274,38 @@ __global__ __launch_bounds__(256) void attn_fwd_kernel(AttnArgs p) {
         }
         f32x4 s[4];
         score_tile(Kt, qf, l15, g, s);
-        // mask bytes of keys k0 + 32*kk2 + 8g .. +8  (kk2 = t>>1, byte index = 4*(t&1)+r)
-        unsigned long long mk[2];
-#pragma unroll
-        for (int kk2 = 0; kk2 < 2; ++kk2) mk[kk2] = ld<unsigned long long>(p.kmask + (long)b * p.Npad + k0 + kk2 * 32 + g * 8);
-        float tmax = NEG_BIG;
+        // mask bits of keys k0 + 32*kk2 + 8g .. +8  (kk2 = t>>1, bit index = 8*kk2 + 4*(t&1) + r)
+        const unsigned km = mask_bits(ld<unsigned long long>(p.kmask + (long)b * p.Npad + k0 + g * 8)) |
+                            (mask_bits(ld<unsigned long long>(p.kmask + (long)b * p.Npad + k0 + 32 + g * 8)) << 8);
+        float tmax = NEG_MASK;
 #pragma unroll
         for (int t = 0; t < 4; ++t)
 #pragma unroll
             for (int r = 0; r < 4; ++r) {
-                const bool keep = (mk[t >> 1] >> (8 * (4 * (t & 1) + r))) & 0xffull;
-                float v = keep ? softclamp2(s[t][r], p.scale) : NEG_BIG;
+                const bool keep = (km >> (8 * (t >> 1) + 4 * (t & 1) + r)) & 1u;
+                float v = keep ? cl2 * clamp_tanh(s[t][r], k2) : NEG_MASK;
                 s[t][r] = v;
                 tmax = fmaxf(tmax, v);
             }
         tmax = fmaxf(tmax, __shfl_xor(tmax, 16));
         tmax = fmaxf(tmax, __shfl_xor(tmax, 32));
         const float mnew = fmaxf(m, tmax);
-        const float alpha = exp2f(m - mnew);
+        const float alpha = fast_exp2(m - mnew);
         m = mnew;
         float psum = 0.f;
 #pragma unroll
         for (int t = 0; t < 4; ++t)
 #pragma unroll
-            for (int r = 0; r < 4; ++r) {
-                float pv = (s[t][r] > 0.5f * NEG_BIG) ? exp2f(s[t][r] - mnew) : 0.f;
-                psum += pv;
-                if (p.thresh) pv *= drop_scale(p.seed, dstream, q, k0 + perm_row(t, 4 * g + r), p.thresh, p.inv_keep);
-                s[t][r] = pv;
+            for (int r = 0; r < 4; r += 2) {
+                float p0 = fast_exp2(s[t][r] - mnew), p1 = fast_exp2(s[t][r + 1] - mnew);
+                psum += p0 + p1;
+                if (p.thresh) {      // keys of r, r+1 are an (even, odd) pair; 1/(1-p) is applied once at the end
+                    const unsigned hh = drop_hash(hrow, (unsigned)(k0 + perm_row(t, 4 * g + r)) >> 1);
+                    p0 = (hh & 0xffffu) >= p.thresh ? p0 : 0.f;
+                    p1 = (hh >> 16) >= p.thresh ? p1 : 0.f;
+                }
+                s[t][r] = p0;
+                s[t][r + 1] = p1;
             }
         psum += __shfl_xor(psum, 16);
         psum += __shfl_xor(psum, 32);
@@ -320,7 +326,7 @@ __global__ __launch_bounds__(256) void attn_fwd_kernel(AttnArgs p) {
         __syncthreads();
     }
     if (!qin) return;
-    const float inv = lsum > 0.f ? 1.f / lsum : 0.f;
+    const float inv = lsum > 0.f ? (p.thresh ? p.inv_keep : 1.f) / lsum : 0.f;
     const float gt = p.gate[bh * p.N + q];
     const bool qkeep = p.kmask[(long)b * p.Npad + q] != 0;
     if (g == 0) p.lse2[bh * p.N + q] = m + log2f(fmaxf(lsum, 1e-37f));
@@ -405,6 +411,8 @@ __global__ __launch_bounds__(256) void attn_bwd_dq_kernel(AttnArgs p) {
     }
     const float lse = qin ? p.lse2[bh * p.N + q] : 1e30f;
     const float dl = qin ? p.delta[bh * p.N + q] : 0.f;
+    const float k2 = 2.f * LOG2E * p.scale / CLAMP, cl2 = CLAMP * LOG2E;
+    const unsigned hrow = rand_base(p.seed, dstream) + (unsigned)q * 0x85ebca77u;
 
     f32x4 dq[4];
 #pragma unroll
@@ -432,23 +440,26 @@ __global__ __launch_bounds__(256) void attn_bwd_dq_kernel(AttnArgs p) {
         f32x4 s[4], dp[4];
         score_tile(Kt, qf, l15, g, s);
         score_tile(Vr, dof, l15, g, dp);          // dP^T = V . dO^T  (same operand shapes)
-        unsigned long long mk[2];
-#pragma unroll
-        for (int kk2 = 0; kk2 < 2; ++kk2) mk[kk2] = ld<unsigned long long>(p.kmask + (long)b * p.Npad + k0 + kk2 * 32 + g * 8);
+        const unsigned km = mask_bits(ld<unsigned long long>(p.kmask + (long)b * p.Npad + k0 + g * 8)) |
+                            (mask_bits(ld<unsigned long long>(p.kmask + (long)b * p.Npad + k0 + 32 + g * 8)) << 8);
 #pragma unroll
         for (int t = 0; t < 4; ++t)
 #pragma unroll
-            for (int r = 0; r < 4; ++r) {
-                const bool keep = (mk[t >> 1] >> (8 * (4 * (t & 1) + r))) & 0xffull;
-                float ds = 0.f;
-                if (keep) {
-                    const float th = tanhf_(s[t][r] * (p.scale / CLAMP));
-                    const float pv = exp2f(CLAMP * LOG2E * th - lse);
-                    float dpv = dp[t][r];
-                    if (p.thresh) dpv *= drop_scale(p.seed, dstream, q, k0 + perm_row(t, 4 * g + r), p.thresh, p.inv_keep);
-                    ds = pv * (dpv - dl) * (1.f - th * th) * p.scale;
+            for (int r = 0; r < 4; r += 2) {
+                float ks0 = 1.f, ks1 = 1.f;
+                if (p.thresh) {
+                    const unsigned hh = drop_hash(hrow, (unsigned)(k0 + perm_row(t, 4 * g + r)) >> 1);
+                    ks0 = (hh & 0xffffu) >= p.thresh ? p.inv_keep : 0.f;
+                    ks1 = (hh >> 16) >= p.thresh ? p.inv_keep : 0.f;
                 }
-                s[t][r] = ds;
+#pragma unroll
+                for (int e = 0; e < 2; ++e) {
+                    const bool keep = (km >> (8 * (t >> 1) + 4 * (t & 1) + r + e)) & 1u;
+                    const float th = clamp_tanh(s[t][r + e], k2);
+                    const float pv = fast_exp2(cl2 * th - lse);
+                    const float ds = pv * (dp[t][r + e] * (e ? ks1 : ks0) - dl) * (1.f - th * th) * p.scale;
+                    s[t][r + e] = keep ? ds : 0.f;
+                }
             }
 #pragma unroll
         for (int kk2 = 0; kk2 < 2; ++kk2) {
@@ -498,6 +509,8 @@ __global__ __launch_bounds__(256) void attn_bwd_dkv_kernel(AttnArgs p) {
     f32x4 dk[4], dv[4];
 #pragma unroll
     for (int ct = 0; ct < 4; ++ct) { dk[ct] = f32x4{0.f, 0.f, 0.f, 0.f}; dv[ct] = f32x4{0.f, 0.f, 0.f, 0.f}; }
+    const float k2 = 2.f * LOG2E * p.scale / CLAMP, cl2 = CLAMP * LOG2E;
+    const unsigned hkey = rand_base(p.seed, dstream) + ((unsigned)key >> 1) * 0xc2b2ae3du;
 
     const int ntiles = (p.N + 63) / 64;
     const bf16_t* Qbase = p.Q + bh * p.N * DH;
@@ -550,10 +563,13 @@ __global__ __launch_bounds__(256) void attn_bwd_dkv_kernel(AttnArgs p) {
                 const int qi = perm_row(t, 4 * g + r);
                 float pv = 0.f, ds = 0.f;
                 if (kkeep) {
-                    const float th = tanhf_(s[t][r] * (p.scale / CLAMP));
-                    const float pr = exp2f(CLAMP * LOG2E * th - lse_s[qi]);
+                    const float th = clamp_tanh(s[t][r], k2);
+                    const float pr = fast_exp2(cl2 * th - lse_s[qi]);
                     float ks = 1.f;
-                    if (p.thresh) ks = drop_scale(p.seed, dstream, q0 + qi, key, p.thresh, p.inv_keep);
+                    if (p.thresh) {
+                        const unsigned hh = fmix32(hkey + (unsigned)(q0 + qi) * 0x85ebca77u);
+                        ks = ((key & 1) ? (hh >> 16) : (hh & 0xffffu)) >= p.thresh ? p.inv_keep : 0.f;
+                    }
                     pv = pr * ks;
                     ds = pr * (dp[t][r] * ks - del_s[qi]) * (1.f - th * th) * p.scale;
                 }

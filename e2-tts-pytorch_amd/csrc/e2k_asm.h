@@ -15,6 +15,40 @@ __device__ __forceinline__ s16x4_ lds_read_tr16_b64(const void* lds_ptr) {
     return __builtin_amdgcn_ds_read_tr16_b64_v4i16((lp_t)(lds_ptr));
 }
 
+// raw v_exp_f32 (2^x, no denormal fix-up: results below 2^-126 flush to 0) and v_rcp_f32 (1 ulp)
+__device__ __forceinline__ float fast_exp2(float x) { return __builtin_amdgcn_exp2f(x); }
+__device__ __forceinline__ float fast_rcp(float x) { return __builtin_amdgcn_rcpf(x); }
+
+// tell the compiler a value is wave-uniform (moves it to an SGPR; scalar loads / scalar operands downstream)
+__device__ __forceinline__ float uniform_f(float v) { return __builtin_bit_cast(float, __builtin_amdgcn_readfirstlane(__builtin_bit_cast(int, v))); }
+__device__ __forceinline__ int uniform_i(int v) { return __builtin_amdgcn_readfirstlane(v); }
+
+// wave64 sum on the VALU (DPP row operations, no LDS crossbar): quad swaps, half-row / row mirrors, then
+// row_bcast15 / row_bcast31 carry the row sums up to lane 63, which is broadcast through an SGPR.
+template <int CTRL, int ROW_MASK>
+__device__ __forceinline__ float dpp_add_(float v) {
+    int x = __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), CTRL, ROW_MASK, 0xf, false);
+    return v + __builtin_bit_cast(float, x);
+}
+__device__ __forceinline__ float wave_sum_fast(float v) {
+    v = dpp_add_<0xB1, 0xf>(v);      // quad_perm [1,0,3,2]
+    v = dpp_add_<0x4E, 0xf>(v);      // quad_perm [2,3,0,1]
+    v = dpp_add_<0x141, 0xf>(v);     // row_half_mirror
+    v = dpp_add_<0x140, 0xf>(v);     // row_mirror   -> every lane of a 16-lane row holds the row sum
+    v = dpp_add_<0x142, 0xa>(v);     // row_bcast15  -> rows 1, 3 += rows 0, 2
+    v = dpp_add_<0x143, 0xc>(v);     // row_bcast31  -> rows 2, 3 += row 1 (= rows 0+1)
+    return __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, v), 63));
+}
+
+// counted wait on outstanding vector-memory ops (LDS-DMA included) and a raw workgroup barrier that does NOT drain
+// them: lets global_load_lds prefetches stay in flight across barriers (cdna_hip_programming.md T3+T4)
+template <int N> __device__ __forceinline__ void wait_vmcnt() { asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory"); }
+__device__ __forceinline__ void barrier_keep_vm() {
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();
+    asm volatile("" ::: "memory");
+}
+
 // global_load_lds_dwordx4: asynchronous 16-byte-per-lane copy HBM -> LDS that bypasses the VGPRs.  The LDS destination
 // is wave-uniform: lane l lands at lds_base + 16*l (the global source address is per lane).  Completion is tracked by
 // vmcnt; a following __syncthreads() drains it (cdna_hip_programming.md section 5).

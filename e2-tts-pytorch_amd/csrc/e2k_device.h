@@ -16,13 +16,14 @@ constexpr int WAVE = 64;
 
 __device__ __forceinline__ float bf2f(bf16_t x) { return __uint_as_float(((unsigned)x) << 16); }
 // round-to-nearest-even, NaN kept quiet (same rule torch uses for float->bfloat16)
-__device__ __forceinline__ bf16_t f2bf(float f) {
-    unsigned u = __float_as_uint(f);
-    if ((u & 0x7fffffffu) > 0x7f800000u) return (bf16_t)((u >> 16) | 0x40);
-    u += 0x7fffu + ((u >> 16) & 1u);
-    return (bf16_t)(u >> 16);
+// (gfx950: one v_cvt_pk_bf16_f32 per pair)
+typedef float f32x2_ __attribute__((ext_vector_type(2)));
+typedef __bf16 bf16x2_ __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ unsigned pack2bf(float lo, float hi) {
+    f32x2_ v = {lo, hi};
+    return __builtin_bit_cast(unsigned, __builtin_convertvector(v, bf16x2_));
 }
-__device__ __forceinline__ unsigned pack2bf(float lo, float hi) { return (unsigned)f2bf(lo) | ((unsigned)f2bf(hi) << 16); }
+__device__ __forceinline__ bf16_t f2bf(float f) { return (bf16_t)(pack2bf(f, 0.f) & 0xffffu); }
 __device__ __forceinline__ float bflo(unsigned u) { return __uint_as_float(u << 16); }
 __device__ __forceinline__ float bfhi(unsigned u) { return __uint_as_float(u & 0xffff0000u); }
 
@@ -71,11 +72,13 @@ __device__ __forceinline__ float tanhf_(float x) {
 __device__ __forceinline__ unsigned fmix32(unsigned h) {
     h ^= h >> 16; h *= 0x85ebca6bu; h ^= h >> 13; h *= 0xc2b2ae35u; h ^= h >> 16; return h;
 }
+// per-(seed, stream) base (hoisted out of inner loops) and per-element hash: one multiply-add chain + one finaliser
+__device__ __forceinline__ unsigned rand_base(unsigned seed, unsigned stream) { return fmix32(seed ^ (stream * 0x9e3779b1u)); }
+__device__ __forceinline__ unsigned rand_at(unsigned base, unsigned row, unsigned col) {
+    return fmix32(base + row * 0x85ebca77u + col * 0xc2b2ae3du);
+}
 __device__ __forceinline__ unsigned rand_u32(unsigned seed, unsigned stream, unsigned row, unsigned col) {
-    unsigned h = fmix32(seed ^ (stream * 0x9e3779b1u));
-    h = fmix32(h ^ (row * 0x85ebca77u + 0x165667b1u));
-    h = fmix32(h ^ (col * 0xc2b2ae3du + 0x27d4eb2fu));
-    return h;
+    return rand_at(rand_base(seed, stream), row, col);
 }
 
 // ---- one-wave-per-row access: lane owns VEC consecutive elements in each of NCH chunks of 64*VEC (D = 64*VEC*NCH)

@@ -247,7 +247,7 @@ struct ConvArgs {
     const bf16_t* x; const uint8_t* mask; const float* w; const float* bias;
     bf16_t* pre; bf16_t* y;
     const bf16_t* dy; bf16_t* dx; float* dw; float* dbias;
-    int B, N, C;
+    int B, N, C, tiles_per_block;
 };
 
 template <int KS>
@@ -305,71 +305,80 @@ __global__ __launch_bounds__(256) void dwconv_bwd_kernel(ConvArgs p) {
     __shared__ float xt[ROWS][CTC];        // masked input,      frame n0 - PAD + j
     __shared__ float dwl[CTC][KS + 1];     // [..][KS] = dbias
     const int tid = threadIdx.x;
-    const int n0 = blockIdx.x * CTN, c0 = blockIdx.y * CTC, b = blockIdx.z;
-    for (int i = tid; i < CTC * (KS + 1); i += 256) (&dwl[0][0])[i] = 0.f;
-    for (int i = tid; i < ROWS * (CTC / 2); i += 256) {
-        int j = i / (CTC / 2), cp = i % (CTC / 2);
-        int n = n0 - PAD + j;
-        float d0 = 0.f, d1 = 0.f, x0 = 0.f, x1 = 0.f;
-        if (n >= 0 && n < p.N && (p.mask == nullptr || p.mask[(long)b * p.N + n])) {
-            const long off = ((long)b * p.N + n) * p.C + c0 + cp * 2;
-            unsigned vd = ld<unsigned>(p.dy + off), vp = ld<unsigned>(p.pre + off), vx = ld<unsigned>(p.x + off);
-            d0 = bflo(vd) * silu_grad(bflo(vp));
-            d1 = bfhi(vd) * silu_grad(bfhi(vp));
-            x0 = bflo(vx);
-            x1 = bfhi(vx);
-        }
-        dpt[j][cp * 2] = d0; dpt[j][cp * 2 + 1] = d1;
-        xt[j][cp * 2] = x0;  xt[j][cp * 2 + 1] = x1;
-    }
+    const int c0 = blockIdx.y * CTC, b = blockIdx.z;
     const int cp = tid & 31, fg = tid >> 5;
     const int ch = c0 + cp * 2;
+    for (int i = tid; i < CTC * (KS + 1); i += 256) (&dwl[0][0])[i] = 0.f;
     float w0[KS], w1[KS];     // flipped
 #pragma unroll
     for (int k = 0; k < KS; ++k) { w0[k] = p.w[(long)ch * KS + (KS - 1 - k)]; w1[k] = p.w[(long)(ch + 1) * KS + (KS - 1 - k)]; }
-    __syncthreads();
-    // dx[o] = sum_k' wflip[k'] dp_tile[o + k']
-    float a0[8], a1[8];
-#pragma unroll
-    for (int o = 0; o < 8; ++o) { a0[o] = 0.f; a1[o] = 0.f; }
-#pragma unroll
-    for (int i = 0; i < 8 + KS - 1; ++i) {
-        float d0 = dpt[fg * 8 + i][cp * 2], d1 = dpt[fg * 8 + i][cp * 2 + 1];
-#pragma unroll
-        for (int o = 0; o < 8; ++o) {
-            const int k = i - o;
-            if (k >= 0 && k < KS) { a0[o] = fmaf(w0[k], d0, a0[o]); a1[o] = fmaf(w1[k], d1, a1[o]); }
-        }
-    }
-#pragma unroll
-    for (int o = 0; o < 8; ++o) {
-        const int n = n0 + fg * 8 + o;
-        if (n < p.N) {
-            const bool keep = p.mask == nullptr || p.mask[(long)b * p.N + n];
-            st<unsigned>(p.dx + ((long)b * p.N + n) * p.C + ch, keep ? pack2bf(a0[o], a1[o]) : 0u);
-        }
-    }
-    // dw[k] += sum_o dp_tile[o + PAD] * x_tile[o + k]
+    // weight / bias gradient partials stay in registers over all frame tiles of this workgroup (p.tiles_per_block):
+    // one LDS + global atomic flush per workgroup instead of per tile
     float g0[KS], g1[KS], s0 = 0.f, s1 = 0.f;
 #pragma unroll
     for (int k = 0; k < KS; ++k) { g0[k] = 0.f; g1[k] = 0.f; }
-    float dq0[8], dq1[8];
+    const int ntiles = (p.N + CTN - 1) / CTN;
+    const int t_beg = blockIdx.x * p.tiles_per_block, t_end = min(ntiles, t_beg + p.tiles_per_block);
+    for (int tile = t_beg; tile < t_end; ++tile) {
+        const int n0 = tile * CTN;
+        __syncthreads();                  // previous tile fully consumed (also orders the dwl zero-fill)
+        for (int i = tid; i < ROWS * (CTC / 2); i += 256) {
+            int j = i / (CTC / 2), cq = i % (CTC / 2);
+            int n = n0 - PAD + j;
+            float d0 = 0.f, d1 = 0.f, x0 = 0.f, x1 = 0.f;
+            if (n >= 0 && n < p.N && (p.mask == nullptr || p.mask[(long)b * p.N + n])) {
+                const long off = ((long)b * p.N + n) * p.C + c0 + cq * 2;
+                unsigned vd = ld<unsigned>(p.dy + off), vp = ld<unsigned>(p.pre + off), vx = ld<unsigned>(p.x + off);
+                d0 = bflo(vd) * silu_grad(bflo(vp));
+                d1 = bfhi(vd) * silu_grad(bfhi(vp));
+                x0 = bflo(vx);
+                x1 = bfhi(vx);
+            }
+            dpt[j][cq * 2] = d0; dpt[j][cq * 2 + 1] = d1;
+            xt[j][cq * 2] = x0;  xt[j][cq * 2 + 1] = x1;
+        }
+        __syncthreads();
+        // dx[o] = sum_k' wflip[k'] dp_tile[o + k']
+        float a0[8], a1[8];
 #pragma unroll
-    for (int o = 0; o < 8; ++o) {
-        dq0[o] = dpt[fg * 8 + o + PAD][cp * 2];
-        dq1[o] = dpt[fg * 8 + o + PAD][cp * 2 + 1];
-        s0 += dq0[o];
-        s1 += dq1[o];
-    }
+        for (int o = 0; o < 8; ++o) { a0[o] = 0.f; a1[o] = 0.f; }
 #pragma unroll
-    for (int i = 0; i < 8 + KS - 1; ++i) {
-        float x0 = xt[fg * 8 + i][cp * 2], x1 = xt[fg * 8 + i][cp * 2 + 1];
+        for (int i = 0; i < 8 + KS - 1; ++i) {
+            float d0 = dpt[fg * 8 + i][cp * 2], d1 = dpt[fg * 8 + i][cp * 2 + 1];
+#pragma unroll
+            for (int o = 0; o < 8; ++o) {
+                const int k = i - o;
+                if (k >= 0 && k < KS) { a0[o] = fmaf(w0[k], d0, a0[o]); a1[o] = fmaf(w1[k], d1, a1[o]); }
+            }
+        }
 #pragma unroll
         for (int o = 0; o < 8; ++o) {
-            const int k = i - o;
-            if (k >= 0 && k < KS) { g0[k] = fmaf(dq0[o], x0, g0[k]); g1[k] = fmaf(dq1[o], x1, g1[k]); }
+            const int n = n0 + fg * 8 + o;
+            if (n < p.N) {
+                const bool keep = p.mask == nullptr || p.mask[(long)b * p.N + n];
+                st<unsigned>(p.dx + ((long)b * p.N + n) * p.C + ch, keep ? pack2bf(a0[o], a1[o]) : 0u);
+            }
+        }
+        // dw[k] += sum_o dp_tile[o + PAD] * x_tile[o + k]
+        float dq0[8], dq1[8];
+#pragma unroll
+        for (int o = 0; o < 8; ++o) {
+            dq0[o] = dpt[fg * 8 + o + PAD][cp * 2];
+            dq1[o] = dpt[fg * 8 + o + PAD][cp * 2 + 1];
+            s0 += dq0[o];
+            s1 += dq1[o];
+        }
+#pragma unroll
+        for (int i = 0; i < 8 + KS - 1; ++i) {
+            float x0 = xt[fg * 8 + i][cp * 2], x1 = xt[fg * 8 + i][cp * 2 + 1];
+#pragma unroll
+            for (int o = 0; o < 8; ++o) {
+                const int k = i - o;
+                if (k >= 0 && k < KS) { g0[k] = fmaf(dq0[o], x0, g0[k]); g1[k] = fmaf(dq1[o], x1, g1[k]); }
+            }
         }
     }
+    __syncthreads();
 #pragma unroll
     for (int k = 0; k < KS; ++k) { atomicAdd(&dwl[cp * 2][k], g0[k]); atomicAdd(&dwl[cp * 2 + 1][k], g1[k]); }
     atomicAdd(&dwl[cp * 2][KS], s0);
@@ -383,10 +392,21 @@ __global__ __launch_bounds__(256) void dwconv_bwd_kernel(ConvArgs p) {
     }
 }
 
-template <int KS> int launch_conv(const ConvArgs& a, bool bwd, hipStream_t st) {
-    dim3 grid((a.N + CTN - 1) / CTN, a.C / CTC, a.B), block(256);
-    if (bwd) hipLaunchKernelGGL(dwconv_bwd_kernel<KS>, grid, block, 0, st, a);
-    else hipLaunchKernelGGL(dwconv_fwd_kernel<KS>, grid, block, 0, st, a);
+template <int KS> int launch_conv(ConvArgs a, bool bwd, hipStream_t st) {
+    const int ntiles = (a.N + CTN - 1) / CTN;
+    dim3 grid(ntiles, a.C / CTC, a.B), block(256);
+    if (bwd) {
+        // about 512 workgroups: fewer, longer workgroups cut the atomic traffic on dw / dbias
+        const int cb = (a.C / CTC) * a.B;
+        int gx = (512 + cb - 1) / cb;
+        if (gx > ntiles) gx = ntiles;
+        if (gx < 1) gx = 1;
+        a.tiles_per_block = (ntiles + gx - 1) / gx;
+        grid.x = (ntiles + a.tiles_per_block - 1) / a.tiles_per_block;
+        hipLaunchKernelGGL(dwconv_bwd_kernel<KS>, grid, block, 0, st, a);
+    } else {
+        hipLaunchKernelGGL(dwconv_fwd_kernel<KS>, grid, block, 0, st, a);
+    }
     return 0;
 }
 int dispatch_conv(const ConvArgs& a, int ks, bool bwd, hipStream_t st) {

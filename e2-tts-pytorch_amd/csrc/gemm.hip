@@ -51,6 +51,66 @@ struct NTArgs {
     const uint8_t* rowmask; const bf16_t* resid; long ldr;
 };
 
+// epilogue shared by the NT kernels: lane holds C[m][n..n+3], m = m0+wm*64+i*16+l15, n = n0+wn*64+j*16+4g
+template <bool OUT_F32>
+__device__ __forceinline__ void nt_epilogue(const NTArgs& p, f32x4 (&acc)[4][4], int m0, int n0, int wm, int wn, int l15, int g) {
+    const bool vec_ok = (p.ldc & 3) == 0 && (p.resid == nullptr || (p.ldr & 3) == 0);
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        const int m = m0 + wm * 64 + i * 16 + l15;
+        if (m >= p.M) continue;
+        const float rm = p.rowmask ? (p.rowmask[m] ? 1.f : 0.f) : 1.f;
+        const float* cs = p.colscale ? p.colscale + (long)(m / p.rows_per_batch) * p.lds : nullptr;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const int n = n0 + wn * 64 + j * 16 + 4 * g;
+            if (n >= p.N) continue;
+            float v[4];
+#pragma unroll
+            for (int r = 0; r < 4; ++r) v[r] = acc[i][j][r];
+            const bool full = (n + 3 < p.N) && vec_ok;
+            float rs[4] = {0.f, 0.f, 0.f, 0.f};
+            if (p.resid) {
+                if (full) {
+                    unpack4(ld<u32x2>(p.resid + (long)m * p.ldr + n), rs);
+                } else {
+                    for (int r = 0; r < 4; ++r)
+                        if (n + r < p.N) rs[r] = bf2f(p.resid[(long)m * p.ldr + n + r]);
+                }
+            }
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                if (n + r < p.N) {
+                    float x = v[r];
+                    if (p.bias) x += p.bias[n + r];
+                    if (cs) x *= cs[n + r];
+                    x = x * rm + rs[r];
+                    v[r] = x;
+                }
+            }
+            if (OUT_F32) {
+                float* c = (float*)p.C + (long)m * p.ldc + n;
+                if (full) {
+                    f32x4 o = {v[0], v[1], v[2], v[3]};
+                    if (p.accumulate) { f32x4 old = ld<f32x4>(c); o += old; }
+                    st<f32x4>(c, o);
+                } else {
+                    for (int r = 0; r < 4; ++r)
+                        if (n + r < p.N) c[r] = (p.accumulate ? c[r] : 0.f) + v[r];
+                }
+            } else {
+                bf16_t* c = (bf16_t*)p.C + (long)m * p.ldc + n;
+                if (full) {
+                    st<u32x2>(c, pack4(v));
+                } else {
+                    for (int r = 0; r < 4; ++r)
+                        if (n + r < p.N) c[r] = f2bf(v[r]);
+                }
+            }
+        }
+    }
+}
+
 template <bool OUT_F32, bool GLDS>
 __global__ __launch_bounds__(256) void gemm_nt_kernel(NTArgs p) {
     __shared__ __attribute__((aligned(16))) unsigned char smem[2][2][BM * BK * 2];
@@ -162,62 +222,84 @@ __global__ __launch_bounds__(256) void gemm_nt_kernel(NTArgs p) {
         __syncthreads();
     }
 
-    // epilogue: lane holds C[m][n..n+3], m = m0+wm*64+i*16+l15, n = n0+wn*64+j*16+4g
-    const bool vec_ok = (p.ldc & 3) == 0 && (p.resid == nullptr || (p.ldr & 3) == 0);
+    nt_epilogue<OUT_F32>(p, acc, m0, n0, wm, wn, l15, g);
+}
+
+// Pipelined variant (default when K1, K2 are multiples of 32): BK = 32, four LDS stages of 16 KB, global_load_lds
+// prefetch THREE k-steps ahead, counted s_waitcnt vmcnt + raw s_barrier so the prefetches stay in flight across the
+// barrier (the 2-buffer kernel above drains them every step and is bound by L2/HBM latency, ~1500 cycles per
+// 512-cycle MFMA step).  64-B LDS rows: the 16-B slot s of row r is stored at s ^ P[(r >> 2) & 3], P = {0,2,3,1},
+// which makes every ds_read_b128 lane group hit 16 distinct slots of the 256-B bank row.
+constexpr int PBK = 32, PST = 4;
+__device__ __forceinline__ int pswz(int row) { return (0x78 >> (2 * ((row >> 2) & 3))) & 3; }
+
+template <bool OUT_F32>
+__global__ __launch_bounds__(256) void gemm_nt_pipe_kernel(NTArgs p) {
+    __shared__ __attribute__((aligned(16))) unsigned char smem[PST][2][BM * PBK * 2];
+    const int tid = threadIdx.x, lane = tid & 63, wave = uniform_i(tid >> 6);
+    const int wm = wave >> 1, wn = wave & 1;
+    const int l15 = lane & 15, g = lane >> 4;
+    const int tm = (p.M + BM - 1) / BM, tn = (p.N + BN - 1) / BN;
+    int tile_m, tile_n;
+    tile_coords(xcd_remap(blockIdx.x, gridDim.x), tm, tn, tile_m, tile_n);
+    const int m0 = tile_m * BM, n0 = tile_n * BN;
+    const int nk = (p.K1 + p.K2) / PBK;
+
+    auto gissue = [&](int kt) {
+        const int buf = kt & (PST - 1);
+        const int k0 = kt * PBK;
+        const bf16_t* Ab = p.A1;
+        long lda = p.lda1;
+        int ka = k0;
+        if (k0 >= p.K1) { Ab = p.A2; lda = p.lda2; ka = k0 - p.K1; }
 #pragma unroll
-    for (int i = 0; i < 4; ++i) {
-        const int m = m0 + wm * 64 + i * 16 + l15;
-        if (m >= p.M) continue;
-        const float rm = p.rowmask ? (p.rowmask[m] ? 1.f : 0.f) : 1.f;
-        const float* cs = p.colscale ? p.colscale + (long)(m / p.rows_per_batch) * p.lds : nullptr;
+        for (int i = 0; i < 2; ++i) {
+            const int rb = wave * 2 + i;                 // 1 KB of LDS = 16 rows of 64 B per wave instruction
+            const int row = rb * 16 + (lane >> 2);
+            const int c = (lane & 3) ^ pswz(row);
+            const int m = min(m0 + row, p.M - 1), n = min(n0 + row, p.N - 1);
+            glds16(Ab + (long)m * lda + ka + c * 8, &smem[buf][0][rb * 1024]);
+            glds16(p.B + (long)n * p.ldb + k0 + c * 8, &smem[buf][1][rb * 1024]);
+        }
+    };
+
+    f32x4 acc[4][4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+    gissue(0);
+    if (nk > 1) gissue(1);
+    if (nk > 2) gissue(2);
+    for (int kt = 0; kt < nk; ++kt) {
+        // tile kt must have landed; the (up to) two younger tiles may stay in flight: 4 loads per wave per tile
+        const int rem = nk - 1 - kt;
+        if (rem >= 2) wait_vmcnt<8>();
+        else if (rem == 1) wait_vmcnt<4>();
+        else wait_vmcnt<0>();
+        barrier_keep_vm();                               // everyone's part of tile kt is visible; stage (kt-1)&3 is free
+        if (kt + 3 < nk) gissue(kt + 3);
+        const unsigned char* As = smem[kt & (PST - 1)][0];
+        const unsigned char* Bs = smem[kt & (PST - 1)][1];
+        bf16x8 af[4], bw[4];
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const int row = wm * 64 + i * 16 + l15;
+            af[i] = ld<bf16x8>(As + row * 64 + ((g ^ pswz(row)) << 4));
+        }
 #pragma unroll
         for (int j = 0; j < 4; ++j) {
-            const int n = n0 + wn * 64 + j * 16 + 4 * g;
-            if (n >= p.N) continue;
-            float v[4];
-#pragma unroll
-            for (int r = 0; r < 4; ++r) v[r] = acc[i][j][r];
-            const bool full = (n + 3 < p.N) && vec_ok;
-            float rs[4] = {0.f, 0.f, 0.f, 0.f};
-            if (p.resid) {
-                if (full) {
-                    unpack4(ld<u32x2>(p.resid + (long)m * p.ldr + n), rs);
-                } else {
-                    for (int r = 0; r < 4; ++r)
-                        if (n + r < p.N) rs[r] = bf2f(p.resid[(long)m * p.ldr + n + r]);
-                }
-            }
-#pragma unroll
-            for (int r = 0; r < 4; ++r) {
-                if (n + r < p.N) {
-                    float x = v[r];
-                    if (p.bias) x += p.bias[n + r];
-                    if (cs) x *= cs[n + r];
-                    x = x * rm + rs[r];
-                    v[r] = x;
-                }
-            }
-            if (OUT_F32) {
-                float* c = (float*)p.C + (long)m * p.ldc + n;
-                if (full) {
-                    f32x4 o = {v[0], v[1], v[2], v[3]};
-                    if (p.accumulate) { f32x4 old = ld<f32x4>(c); o += old; }
-                    st<f32x4>(c, o);
-                } else {
-                    for (int r = 0; r < 4; ++r)
-                        if (n + r < p.N) c[r] = (p.accumulate ? c[r] : 0.f) + v[r];
-                }
-            } else {
-                bf16_t* c = (bf16_t*)p.C + (long)m * p.ldc + n;
-                if (full) {
-                    st<u32x2>(c, pack4(v));
-                } else {
-                    for (int r = 0; r < 4; ++r)
-                        if (n + r < p.N) c[r] = f2bf(v[r]);
-                }
-            }
+            const int row = wn * 64 + j * 16 + l15;
+            bw[j] = ld<bf16x8>(Bs + row * 64 + ((g ^ pswz(row)) << 4));
         }
+#pragma unroll
+        for (int i = 0; i < 4; ++i)
+#pragma unroll
+            for (int j = 0; j < 4; ++j)
+                acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(bw[j], af[i], acc[i][j], 0, 0, 0);
     }
+    nt_epilogue<OUT_F32>(p, acc, m0, n0, wm, wn, l15, g);
 }
 
 // ---------------------------------------------------------------------------------------------- TN (wgrad)
@@ -404,8 +486,12 @@ extern "C" int e2k_gemm_nt_bf16(const void* A1, int64_t lda1, int K1, const void
     const int tm = (M + BM - 1) / BM, tn = (N + BN - 1) / BN;
     dim3 grid(tm * tn), block(256);
     const bool glds = !(flags & E2K_GEMM_NO_GLDS) && (K1 % BK) == 0 && (K2 % BK) == 0;
+    const bool pipe = !(flags & (E2K_GEMM_NO_GLDS | E2K_GEMM_NO_PIPE)) && (K1 % PBK) == 0 && (K2 % PBK) == 0;
     hipStream_t st = (hipStream_t)stream;
-    if (out_f32) {
+    if (pipe) {
+        if (out_f32) hipLaunchKernelGGL(gemm_nt_pipe_kernel<true>, grid, block, 0, st, p);
+        else hipLaunchKernelGGL(gemm_nt_pipe_kernel<false>, grid, block, 0, st, p);
+    } else if (out_f32) {
         if (glds) hipLaunchKernelGGL((gemm_nt_kernel<true, true>), grid, block, 0, st, p);
         else hipLaunchKernelGGL((gemm_nt_kernel<true, false>), grid, block, 0, st, p);
     } else {

@@ -5,7 +5,7 @@
 // (arithmetic restated in SURVEY.md Appendix A.5 / oracle HyperConnections).
 //
 // Data layout: the reference keeps streams in the batch dim '(b s) n d'; here a token's 4 streams are
-// contiguous: X[token][s][d] (bf16), so one wave reads/writes one token as a single 4*D*2-byte burst.
+// contiguous: X[token][s][d] (bf16), one 4*D*2-byte burst per token.
 //
 // For HC instance i on stream tensor X_i:
 //   width :  r = X_i ;  z_s = r_s/|r_s| * sqrt(D) * (gamma+1)
@@ -17,7 +17,13 @@
 // token instead of 9D + 9D); the backward kernel fuses width_i-backward with depth_{i-1}-backward and
 // recomputes r from (M_{i-1}, y_{i-1}, b_{i-1}).  Per-token coefficients are saved in `coef` (52 floats).
 // HBM-bound: algorithmic bytes per token = 2*(5D+5D) forward, 2*(11D+5D) backward.
+//
+// Work split: NW waves share a token (each owns a contiguous D/NW slice, 8 elements per lane per row at D = 1024
+// and 512), so the per-lane state is small enough for 2-3 waves per SIMD; the 24-28 dot products of a token are
+// reduced with DPP row operations inside a wave and through a small LDS exchange across the NW waves.  The
+// backward accumulates d(Wp) in registers over all tokens of a wave and flushes it once.
 #include "e2k_device.h"
+#include <e2k_asm.h>
 #include "../../include/e2k.h"
 
 using namespace e2k;
@@ -26,6 +32,8 @@ namespace {
 
 constexpr int S = 4, NJ = 6, CW = 52;
 constexpr int CA = 0, CB = 20, CP = 24, CRN = 48;   // a[s*5+t], b[s], P[s*6+j] (pre-tanh dots), rn[s]
+constexpr int NSC = 32;                               // scalar partials: dA[20], dB[4], dsa, dsb, pad
+constexpr int NRED = 28;
 
 struct HCParams {
     const float* static_beta; const float* static_alpha; const float* dyn_alpha_fn; const float* dyn_alpha_scale;
@@ -42,6 +50,27 @@ __device__ __forceinline__ void stage_wp(float* Wp, const HCParams& hp, int D, i
     }
 }
 
+// sum `vals[0..N)` over the NW waves that share a token: wave-level DPP sums, then LDS exchange (one barrier)
+template <int N, int NW>
+__device__ __forceinline__ void token_sum(float* vals, float (*red)[4][NRED], int parity, int wave, int lane) {
+#pragma unroll
+    for (int i = 0; i < N; ++i) vals[i] = wave_sum_fast(vals[i]);
+    if (NW == 1) return;
+    if (lane == 0) {
+#pragma unroll
+        for (int i = 0; i < N; ++i) red[parity][wave][i] = vals[i];
+    }
+    __syncthreads();
+    const int w0 = (wave / NW) * NW;
+#pragma unroll
+    for (int i = 0; i < N; ++i) {
+        float s = red[parity][w0][i];
+#pragma unroll
+        for (int w = 1; w < NW; ++w) s += red[parity][w0 + w][i];
+        vals[i] = uniform_f(s);
+    }
+}
+
 struct HCFwdArgs {
     const bf16_t* Xin; const bf16_t* yprev; const float* coef_prev;
     bf16_t* Mout; bf16_t* bin; float* coef;
@@ -49,11 +78,13 @@ struct HCFwdArgs {
     int Mtok;
 };
 
-template <int VEC, int NCH, bool DEPTH, bool WIDTH>
+template <int VEC, int NCH, int NW, bool DEPTH, bool WIDTH>
 __global__ __launch_bounds__(256) void hc_fwd_kernel(HCFwdArgs p) {
-    constexpr int EPL = VEC * NCH, D = 64 * EPL;
+    constexpr int EPL = VEC * NCH, DS = 64 * EPL, D = DS * NW, TPB = 4 / NW;
     __shared__ __attribute__((aligned(16))) float Wp[WIDTH ? NJ * D : 4];
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    __shared__ float red[2][4][NRED];
+    const int tid = threadIdx.x, lane = tid & 63, wave = uniform_i(tid >> 6);
+    const int slot = wave / NW, doff = (wave % NW) * DS;
     float sa = 0.f, sb = 0.f, A[20], B[4];
     if (WIDTH) {
         stage_wp(Wp, p.hp, D, tid);
@@ -66,80 +97,84 @@ __global__ __launch_bounds__(256) void hc_fwd_kernel(HCFwdArgs p) {
         __syncthreads();
     }
     const float sqrtD = sqrtf((float)D);
-    for (int tok = blockIdx.x * 4 + wave; tok < p.Mtok; tok += gridDim.x * 4) {
+    const int per_iter = gridDim.x * TPB;
+    const int niter = (p.Mtok + per_iter - 1) / per_iter;
+    for (int it = 0; it < niter; ++it) {
+        const int tok_raw = (it * gridDim.x + blockIdx.x) * TPB + slot;
+        const bool valid = tok_raw < p.Mtok;
+        const long tok = valid ? tok_raw : p.Mtok - 1;
         float r[S][EPL];
 #pragma unroll
-        for (int s = 0; s < S; ++s) load_row<VEC, NCH>(p.Xin + ((long)tok * S + s) * D, lane, r[s]);
+        for (int s = 0; s < S; ++s) load_row<VEC, NCH>(p.Xin + (tok * S + s) * D + doff, lane, r[s]);
         if (DEPTH) {
             float y[EPL];
-            load_row<VEC, NCH>(p.yprev + (long)tok * D, lane, y);
+            load_row<VEC, NCH>(p.yprev + tok * D + doff, lane, y);
 #pragma unroll
             for (int s = 0; s < S; ++s) {
-                const float bp = p.coef_prev[(long)tok * CW + CB + s];
+                const float bp = p.coef_prev[tok * CW + CB + s];
 #pragma unroll
                 for (int e = 0; e < EPL; ++e) r[s][e] = fmaf(bp, y[e], r[s][e]);
             }
         }
         if (!WIDTH) {
+            if (valid) {
 #pragma unroll
-            for (int s = 0; s < S; ++s) store_row<VEC, NCH>(p.Mout + ((long)tok * S + s) * D, lane, r[s]);
+                for (int s = 0; s < S; ++s) store_row<VEC, NCH>(p.Mout + (tok * S + s) * D + doff, lane, r[s]);
+            }
             continue;
         }
-        float part[S][NJ + 1];
+        float part[NRED];       // [s*7 + j], j = 6: sum of squares
 #pragma unroll
-        for (int s = 0; s < S; ++s)
-#pragma unroll
-            for (int j = 0; j <= NJ; ++j) part[s][j] = 0.f;
+        for (int i = 0; i < NRED; ++i) part[i] = 0.f;
 #pragma unroll
         for (int j = 0; j < NJ; ++j) {
             float w[EPL];
-            load_row_f32<VEC, NCH>(Wp + j * D, lane, w);
+            load_row_f32<VEC, NCH>(Wp + j * D + doff, lane, w);
 #pragma unroll
             for (int s = 0; s < S; ++s)
 #pragma unroll
-                for (int e = 0; e < EPL; ++e) part[s][j] = fmaf(r[s][e], w[e], part[s][j]);
+                for (int e = 0; e < EPL; ++e) part[s * 7 + j] = fmaf(r[s][e], w[e], part[s * 7 + j]);
         }
 #pragma unroll
         for (int s = 0; s < S; ++s)
 #pragma unroll
-            for (int e = 0; e < EPL; ++e) part[s][NJ] = fmaf(r[s][e], r[s][e], part[s][NJ]);
-#pragma unroll
-        for (int s = 0; s < S; ++s)
-#pragma unroll
-            for (int j = 0; j <= NJ; ++j) part[s][j] = wave_sum(part[s][j]);
+            for (int e = 0; e < EPL; ++e) part[s * 7 + 6] = fmaf(r[s][e], r[s][e], part[s * 7 + 6]);
+        token_sum<NRED, NW>(part, red, it & 1, wave, lane);
         float a[S][5], b[S], P[S][NJ], rn[S];
 #pragma unroll
         for (int s = 0; s < S; ++s) {
-            rn[s] = 1.f / fmaxf(sqrtf(part[s][NJ]), 1e-12f);
+            rn[s] = 1.f / fmaxf(sqrtf(part[s * 7 + 6]), 1e-12f);
 #pragma unroll
-            for (int j = 0; j < NJ; ++j) P[s][j] = part[s][j] * rn[s] * sqrtD;
+            for (int j = 0; j < NJ; ++j) P[s][j] = part[s * 7 + j] * rn[s] * sqrtD;
 #pragma unroll
             for (int t = 0; t < 5; ++t) a[s][t] = tanhf_(P[s][t]) * sa + A[s * 5 + t];
             b[s] = tanhf_(P[s][5]) * sb + B[s];
         }
+        if (valid) {
 #pragma unroll
-        for (int t = 0; t < 5; ++t) {
-            float m[EPL];
+            for (int t = 0; t < 5; ++t) {
+                float m[EPL];
 #pragma unroll
-            for (int e = 0; e < EPL; ++e) {
-                float v = a[0][t] * r[0][e];
+                for (int e = 0; e < EPL; ++e) {
+                    float v = a[0][t] * r[0][e];
 #pragma unroll
-                for (int s = 1; s < S; ++s) v = fmaf(a[s][t], r[s][e], v);
-                m[e] = v;
+                    for (int s = 1; s < S; ++s) v = fmaf(a[s][t], r[s][e], v);
+                    m[e] = v;
+                }
+                if (t == 0) store_row<VEC, NCH>(p.bin + tok * D + doff, lane, m);
+                else store_row<VEC, NCH>(p.Mout + (tok * S + (t - 1)) * D + doff, lane, m);
             }
-            if (t == 0) store_row<VEC, NCH>(p.bin + (long)tok * D, lane, m);
-            else store_row<VEC, NCH>(p.Mout + ((long)tok * S + (t - 1)) * D, lane, m);
-        }
-        if (lane == 0) {
-            float* c = p.coef + (long)tok * CW;
+            if (lane == 0 && doff == 0) {
+                float* c = p.coef + tok * CW;
 #pragma unroll
-            for (int s = 0; s < S; ++s) {
+                for (int s = 0; s < S; ++s) {
 #pragma unroll
-                for (int t = 0; t < 5; ++t) c[CA + s * 5 + t] = a[s][t];
-                c[CB + s] = b[s];
+                    for (int t = 0; t < 5; ++t) c[CA + s * 5 + t] = a[s][t];
+                    c[CB + s] = b[s];
 #pragma unroll
-                for (int j = 0; j < NJ; ++j) c[CP + s * NJ + j] = P[s][j];
-                c[CRN + s] = rn[s];
+                    for (int j = 0; j < NJ; ++j) c[CP + s * NJ + j] = P[s][j];
+                    c[CRN + s] = rn[s];
+                }
             }
         }
     }
@@ -154,14 +189,14 @@ struct HCBwdArgs {
     int Mtok;
 };
 
-constexpr int NSC = 32;   // scalar partials: dA[20], dB[4], dsa, dsb, pad
-
-template <int VEC, int NCH, bool DEPTH, bool WIDTH>
+template <int VEC, int NCH, int NW, bool DEPTH, bool WIDTH>
 __global__ __launch_bounds__(256) void hc_bwd_kernel(HCBwdArgs p) {
-    constexpr int EPL = VEC * NCH, D = 64 * EPL;
+    constexpr int EPL = VEC * NCH, DS = 64 * EPL, D = DS * NW, TPB = 4 / NW;
     __shared__ __attribute__((aligned(16))) float Wp[WIDTH ? NJ * D : 4];
     __shared__ __attribute__((aligned(16))) float dWp[WIDTH ? NJ * D + NSC : 4];
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    __shared__ float red[2][4][NRED];
+    const int tid = threadIdx.x, lane = tid & 63, wave = uniform_i(tid >> 6);
+    const int slot = wave / NW, doff = (wave % NW) * DS;
     float sa = 0.f, sb = 0.f;
     if (WIDTH) {
         stage_wp(Wp, p.hp, D, tid);
@@ -171,15 +206,23 @@ __global__ __launch_bounds__(256) void hc_bwd_kernel(HCBwdArgs p) {
         __syncthreads();
     }
     const float sqrtD = sqrtf((float)D);
-    float sc[26];
+    float gw[WIDTH ? NJ : 1][EPL];   // d(Wp) accumulators of this lane's elements, over all tokens of this wave
 #pragma unroll
-    for (int i = 0; i < 26; ++i) sc[i] = 0.f;
+    for (int j = 0; j < (WIDTH ? NJ : 1); ++j)
+#pragma unroll
+        for (int e = 0; e < EPL; ++e) gw[j][e] = 0.f;
 
-    for (int tok = blockIdx.x * 4 + wave; tok < p.Mtok; tok += gridDim.x * 4) {
+    const int per_iter = gridDim.x * TPB;
+    const int niter = (p.Mtok + per_iter - 1) / per_iter;
+    for (int it = 0; it < niter; ++it) {
+        const int tok_raw = (it * gridDim.x + blockIdx.x) * TPB + slot;
+        const bool valid = tok_raw < p.Mtok;
+        const long tok = valid ? tok_raw : p.Mtok - 1;
+        const float vf = valid ? 1.f : 0.f;
         float bp[S];
         if (DEPTH) {
 #pragma unroll
-            for (int s = 0; s < S; ++s) bp[s] = p.coef_prev[(long)tok * CW + CB + s];
+            for (int s = 0; s < S; ++s) bp[s] = p.coef_prev[tok * CW + CB + s];
         }
         if (!WIDTH) {
             // only the depth connection of the previous instance: dy_prev = sum_s b_prev[s] * dX[s]
@@ -189,31 +232,31 @@ __global__ __launch_bounds__(256) void hc_bwd_kernel(HCBwdArgs p) {
 #pragma unroll
             for (int s = 0; s < S; ++s) {
                 float g[EPL];
-                load_row<VEC, NCH>(p.G + ((long)tok * S + s) * D, lane, g);
+                load_row<VEC, NCH>(p.G + (tok * S + s) * D + doff, lane, g);
 #pragma unroll
                 for (int e = 0; e < EPL; ++e) dy[e] = fmaf(bp[s], g[e], dy[e]);
             }
-            store_row<VEC, NCH>(p.dyprev + (long)tok * D, lane, dy);
+            if (valid) store_row<VEC, NCH>(p.dyprev + tok * D + doff, lane, dy);
             continue;
         }
         float r[S][EPL], dm[5][EPL], yc[EPL];
 #pragma unroll
-        for (int s = 0; s < S; ++s) load_row<VEC, NCH>(p.Xin + ((long)tok * S + s) * D, lane, r[s]);
+        for (int s = 0; s < S; ++s) load_row<VEC, NCH>(p.Xin + (tok * S + s) * D + doff, lane, r[s]);
         if (DEPTH) {
             float y[EPL];
-            load_row<VEC, NCH>(p.yprev + (long)tok * D, lane, y);
+            load_row<VEC, NCH>(p.yprev + tok * D + doff, lane, y);
 #pragma unroll
             for (int s = 0; s < S; ++s)
 #pragma unroll
                 for (int e = 0; e < EPL; ++e) r[s][e] = fmaf(bp[s], y[e], r[s][e]);
         }
-        load_row<VEC, NCH>(p.dbin + (long)tok * D, lane, dm[0]);
+        load_row<VEC, NCH>(p.dbin + tok * D + doff, lane, dm[0]);
 #pragma unroll
-        for (int s = 0; s < S; ++s) load_row<VEC, NCH>(p.G + ((long)tok * S + s) * D, lane, dm[s + 1]);
-        load_row<VEC, NCH>(p.ycur + (long)tok * D, lane, yc);
+        for (int s = 0; s < S; ++s) load_row<VEC, NCH>(p.G + (tok * S + s) * D + doff, lane, dm[s + 1]);
+        load_row<VEC, NCH>(p.ycur + tok * D + doff, lane, yc);
 
-        // 24 dots: da[s][t] = dm_t . r_s ; db[s] = G_s . y_cur
-        float da[S][5], db[S];
+        // 24 dots: da[s][t] = dm_t . r_s (index s*6 + t) ; db[s] = G_s . y_cur (index s*6 + 5)
+        float dots[24];
 #pragma unroll
         for (int s = 0; s < S; ++s) {
 #pragma unroll
@@ -221,15 +264,19 @@ __global__ __launch_bounds__(256) void hc_bwd_kernel(HCBwdArgs p) {
                 float v = 0.f;
 #pragma unroll
                 for (int e = 0; e < EPL; ++e) v = fmaf(dm[t][e], r[s][e], v);
-                da[s][t] = wave_sum(v);
+                dots[s * 6 + t] = v;
             }
             float v = 0.f;
 #pragma unroll
             for (int e = 0; e < EPL; ++e) v = fmaf(dm[s + 1][e], yc[e], v);
-            db[s] = wave_sum(v);
+            dots[s * 6 + 5] = v;
         }
-        const float* cf = p.coef + (long)tok * CW;
+        token_sum<24, NW>(dots, red, it & 1, wave, lane);
+
+        const float* cf = p.coef + tok * CW;
         float a[S][5], c[S][NJ], rn[S], uq[S];
+        const bool sc_lane = valid && doff == 0 && lane == 0;      // scalar partials: one lane per token
+        float dsa = 0.f, dsb = 0.f;
 #pragma unroll
         for (int s = 0; s < S; ++s) {
             rn[s] = cf[CRN + s];
@@ -237,44 +284,32 @@ __global__ __launch_bounds__(256) void hc_bwd_kernel(HCBwdArgs p) {
 #pragma unroll
             for (int t = 0; t < 5; ++t) {
                 a[s][t] = cf[CA + s * 5 + t];
-                float P = cf[CP + s * NJ + t];
-                float th = tanhf_(P);
-                c[s][t] = da[s][t] * sa * (1.f - th * th);
+                const float P = cf[CP + s * NJ + t];
+                const float th = tanhf_(P);
+                const float da = dots[s * 6 + t];
+                c[s][t] = da * sa * (1.f - th * th);
                 acc_uq = fmaf(c[s][t], P, acc_uq);
-                sc[s * 5 + t] += da[s][t];
-                sc[24] = fmaf(da[s][t], th, sc[24]);
+                if (sc_lane) atomicAdd(&dWp[NJ * D + s * 5 + t], da);
+                dsa = fmaf(da, th, dsa);
             }
-            float P = cf[CP + s * NJ + 5];
-            float th = tanhf_(P);
-            c[s][5] = db[s] * sb * (1.f - th * th);
+            const float P = cf[CP + s * NJ + 5];
+            const float th = tanhf_(P);
+            const float db = dots[s * 6 + 5];
+            c[s][5] = db * sb * (1.f - th * th);
             acc_uq = fmaf(c[s][5], P, acc_uq);
-            sc[20 + s] += db[s];
-            sc[25] = fmaf(db[s], th, sc[25]);
+            if (sc_lane) atomicAdd(&dWp[NJ * D + 20 + s], db);
+            dsb = fmaf(db, th, dsb);
             uq[s] = acc_uq;
         }
-        // q[s][e] = sqrtD * sum_j c[s][j] Wp[j][d] ; dWp[j][d] += sum_s c[s][j] rn[s] sqrtD r[s][d]
-        float q[S][EPL];
-#pragma unroll
-        for (int s = 0; s < S; ++s)
-#pragma unroll
-            for (int e = 0; e < EPL; ++e) q[s][e] = 0.f;
+        if (sc_lane) { atomicAdd(&dWp[NJ * D + 24], dsa); atomicAdd(&dWp[NJ * D + 25], dsb); }
+        // q[s][e] = sqrtD * sum_j c[s][j] Wp[j][d] ; gw[j][e] += sum_s c[s][j] rn[s] sqrtD r[s][e]
 #pragma unroll
         for (int j = 0; j < NJ; ++j) {
-            float w[EPL];
-            load_row_f32<VEC, NCH>(Wp + j * D, lane, w);
-            float cs[S];
 #pragma unroll
-            for (int s = 0; s < S; ++s) cs[s] = c[s][j] * rn[s] * sqrtD;
+            for (int s = 0; s < S; ++s) {
+                const float cs = c[s][j] * sqrtD * rn[s] * vf;
 #pragma unroll
-            for (int e = 0; e < EPL; ++e) {
-                float g = 0.f;
-#pragma unroll
-                for (int s = 0; s < S; ++s) {
-                    q[s][e] = fmaf(c[s][j] * sqrtD, w[e], q[s][e]);
-                    g = fmaf(cs[s], r[s][e], g);
-                }
-                const int ch = e / VEC, v = e % VEC;
-                atomicAdd(&dWp[j * D + ch * 64 * VEC + lane * VEC + v], g);
+                for (int e = 0; e < EPL; ++e) gw[j][e] = fmaf(cs, r[s][e], gw[j][e]);
             }
         }
         float dyp[EPL];
@@ -282,6 +317,18 @@ __global__ __launch_bounds__(256) void hc_bwd_kernel(HCBwdArgs p) {
         for (int e = 0; e < EPL; ++e) dyp[e] = 0.f;
 #pragma unroll
         for (int s = 0; s < S; ++s) {
+            // (Wp rows are re-read from LDS per stream: keeps the live register set small -> more waves per SIMD)
+            float qs[EPL];
+#pragma unroll
+            for (int e = 0; e < EPL; ++e) qs[e] = 0.f;
+#pragma unroll
+            for (int j = 0; j < NJ; ++j) {
+                float w[EPL];
+                load_row_f32<VEC, NCH>(Wp + j * D + doff, lane, w);
+                const float cq = c[s][j] * sqrtD;
+#pragma unroll
+                for (int e = 0; e < EPL; ++e) qs[e] = fmaf(cq, w[e], qs[e]);
+            }
             float dr[EPL];
 #pragma unroll
             for (int e = 0; e < EPL; ++e) {
@@ -289,19 +336,23 @@ __global__ __launch_bounds__(256) void hc_bwd_kernel(HCBwdArgs p) {
 #pragma unroll
                 for (int t = 1; t < 5; ++t) v = fmaf(a[s][t], dm[t][e], v);
                 float u = r[s][e] * rn[s];
-                v = fmaf(rn[s], q[s][e] - u * uq[s], v);
+                v = fmaf(rn[s], qs[e] - u * uq[s], v);
                 dr[e] = v;
                 if (DEPTH) dyp[e] = fmaf(bp[s], v, dyp[e]);
             }
-            store_row<VEC, NCH>(p.dR + ((long)tok * S + s) * D, lane, dr);
+            if (valid) store_row<VEC, NCH>(p.dR + (tok * S + s) * D + doff, lane, dr);
         }
-        if (DEPTH) store_row<VEC, NCH>(p.dyprev + (long)tok * D, lane, dyp);
+        if (DEPTH && valid) store_row<VEC, NCH>(p.dyprev + tok * D + doff, lane, dyp);
     }
     if (WIDTH) {
-        if (lane == 0) {
+        // flush the register accumulators (once per wave): LDS adds, then one row of `partial` per workgroup
 #pragma unroll
-            for (int i = 0; i < 26; ++i) atomicAdd(&dWp[NJ * D + i], sc[i]);
-        }
+        for (int j = 0; j < NJ; ++j)
+#pragma unroll
+            for (int ch = 0; ch < NCH; ++ch)
+#pragma unroll
+                for (int v = 0; v < VEC; ++v)
+                    atomicAdd(&dWp[j * D + doff + ch * 64 * VEC + lane * VEC + v], gw[j][ch * VEC + v]);
         __syncthreads();
         float* out = p.partial + (long)blockIdx.x * (NJ * D + NSC);
         for (int i = tid; i < NJ * D + NSC; i += 256) out[i] = dWp[i];
@@ -373,34 +424,66 @@ __global__ __launch_bounds__(256) void hc_reduce_kernel(HCReduceArgs p) {
     }
 }
 
-template <int VEC, int NCH>
+template <int VEC, int NCH, int NW>
 int launch_fwd(const HCFwdArgs& a, bool depth, bool width, int grid, hipStream_t st) {
     dim3 g(grid), b(256);
-    if (depth && width) hipLaunchKernelGGL((hc_fwd_kernel<VEC, NCH, true, true>), g, b, 0, st, a);
-    else if (!depth && width) hipLaunchKernelGGL((hc_fwd_kernel<VEC, NCH, false, true>), g, b, 0, st, a);
-    else if (depth && !width) hipLaunchKernelGGL((hc_fwd_kernel<VEC, NCH, true, false>), g, b, 0, st, a);
+    if (depth && width) hipLaunchKernelGGL((hc_fwd_kernel<VEC, NCH, NW, true, true>), g, b, 0, st, a);
+    else if (!depth && width) hipLaunchKernelGGL((hc_fwd_kernel<VEC, NCH, NW, false, true>), g, b, 0, st, a);
+    else if (depth && !width) hipLaunchKernelGGL((hc_fwd_kernel<VEC, NCH, NW, true, false>), g, b, 0, st, a);
     else return E2K_ERR_ARG;
     return 0;
 }
-template <int VEC, int NCH>
+template <int VEC, int NCH, int NW>
 int launch_bwd(const HCBwdArgs& a, bool depth, bool width, int grid, hipStream_t st) {
     dim3 g(grid), b(256);
-    if (depth && width) hipLaunchKernelGGL((hc_bwd_kernel<VEC, NCH, true, true>), g, b, 0, st, a);
-    else if (!depth && width) hipLaunchKernelGGL((hc_bwd_kernel<VEC, NCH, false, true>), g, b, 0, st, a);
-    else if (depth && !width) hipLaunchKernelGGL((hc_bwd_kernel<VEC, NCH, true, false>), g, b, 0, st, a);
+    if (depth && width) hipLaunchKernelGGL((hc_bwd_kernel<VEC, NCH, NW, true, true>), g, b, 0, st, a);
+    else if (!depth && width) hipLaunchKernelGGL((hc_bwd_kernel<VEC, NCH, NW, false, true>), g, b, 0, st, a);
+    else if (depth && !width) hipLaunchKernelGGL((hc_bwd_kernel<VEC, NCH, NW, true, false>), g, b, 0, st, a);
     else return E2K_ERR_ARG;
     return 0;
 }
 
-int grid_for(int Mtok, int max_blocks) {
-    int g = (Mtok + 3) / 4;
+// D -> (elements per lane per chunk, chunks, waves per token)
+#define HC_DISPATCH(D, FN, ...)                                       \
+    switch (D) {                                                      \
+        case 128: rc = FN<2, 1, 1>(__VA_ARGS__); break;               \
+        case 256: rc = FN<4, 1, 1>(__VA_ARGS__); break;               \
+        case 512: rc = FN<8, 1, 1>(__VA_ARGS__); break;               \
+        case 768: rc = FN<4, 3, 1>(__VA_ARGS__); break;               \
+        case 1024: rc = FN<8, 1, 2>(__VA_ARGS__); break;              \
+        case 1536: rc = FN<4, 3, 2>(__VA_ARGS__); break;              \
+        case 2048: rc = FN<8, 1, 4>(__VA_ARGS__); break;              \
+        default: rc = E2K_ERR_SHAPE;                                  \
+    }
+
+// the backward keeps more per-lane state (r, dm, d(Wp) accumulators): 4 elements per lane per row at D = 1024 / 512
+#define HC_DISPATCH_BWD(D, FN, ...)                                   \
+    switch (D) {                                                      \
+        case 128: rc = FN<2, 1, 1>(__VA_ARGS__); break;               \
+        case 256: rc = FN<4, 1, 1>(__VA_ARGS__); break;               \
+        case 512: rc = FN<4, 1, 2>(__VA_ARGS__); break;               \
+        case 768: rc = FN<4, 3, 1>(__VA_ARGS__); break;               \
+        case 1024: rc = FN<4, 1, 4>(__VA_ARGS__); break;              \
+        case 1536: rc = FN<4, 3, 2>(__VA_ARGS__); break;              \
+        case 2048: rc = FN<8, 1, 4>(__VA_ARGS__); break;              \
+        default: rc = E2K_ERR_SHAPE;                                  \
+    }
+
+int tokens_per_block(int D, bool bwd) {
+    if (bwd) return D == 1024 || D == 2048 ? 1 : (D == 512 || D == 1536 ? 2 : 4);
+    return D == 1024 || D == 1536 ? 2 : (D == 2048 ? 1 : 4);
+}
+
+int grid_for(int Mtok, int D, int max_blocks, bool bwd) {
+    const int tpb = tokens_per_block(D, bwd);
+    int g = (Mtok + tpb - 1) / tpb;
     return g < max_blocks ? g : max_blocks;
 }
 
 }  // namespace
 
 extern "C" int e2k_query_hc_coef_width(void) { return CW; }
-extern "C" int e2k_query_hc_bwd_blocks(int Mtok) { return grid_for(Mtok, 256); }
+extern "C" int e2k_query_hc_bwd_blocks(int Mtok, int D) { return grid_for(Mtok, D, 512, true); }
 extern "C" int e2k_query_hc_partial_stride(int D) { return NJ * D + NSC; }
 
 extern "C" int e2k_hc_fwd(const void* Xin, const void* yprev, const float* coef_prev, void* Mout, void* bin,
@@ -416,7 +499,7 @@ extern "C" int e2k_hc_fwd(const void* Xin, const void* yprev, const float* coef_
     a.Mtok = Mtok;
     if (!Xin || !Mout || (has_depth && (!yprev || !coef_prev)) || (has_width && (!bin || !coef || !gamma))) return E2K_ERR_ARG;
     int rc = 0;
-    E2K_ROW_DISPATCH(D, launch_fwd, a, has_depth != 0, has_width != 0, grid_for(Mtok, 2048), (hipStream_t)stream);
+    HC_DISPATCH(D, launch_fwd, a, has_depth != 0, has_width != 0, grid_for(Mtok, D, 1024, false), (hipStream_t)stream);
     if (rc) return rc;
     E2K_CHECK_LAUNCH();
     return 0;
@@ -438,9 +521,9 @@ extern "C" int e2k_hc_bwd(const void* Xin, const void* yprev, const float* coef_
     a.partial = partial; a.Mtok = Mtok;
     if (!G || (has_depth && (!yprev || !coef_prev || !dyprev))) return E2K_ERR_ARG;
     if (has_width && (!Xin || !dbin || !ycur || !coef || !dR || !partial || !gamma || !g_gamma)) return E2K_ERR_ARG;
-    const int grid = grid_for(Mtok, 256);     // one workgroup per CU (the kernel runs at one wave per SIMD)
+    const int grid = grid_for(Mtok, D, 512, true);
     int rc = 0;
-    E2K_ROW_DISPATCH(D, launch_bwd, a, has_depth != 0, has_width != 0, grid, (hipStream_t)stream);
+    HC_DISPATCH_BWD(D, launch_bwd, a, has_depth != 0, has_width != 0, grid, (hipStream_t)stream);
     if (rc) return rc;
     E2K_CHECK_LAUNCH();
     if (has_width) {

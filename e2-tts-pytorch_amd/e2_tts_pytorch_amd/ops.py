@@ -143,7 +143,7 @@ def hc_bwd(G, *, xin=None, yprev=None, coef_prev=None, dbin=None, ycur=None, coe
     dyprev = torch.empty((Mtok, D), dtype=bf16, device=G.device) if depth else None
     partial = None
     if width:
-        partial = torch.empty((lib.e2k_query_hc_bwd_blocks(Mtok), lib.e2k_query_hc_partial_stride(D)), dtype=f32,
+        partial = torch.empty((lib.e2k_query_hc_bwd_blocks(Mtok, D), lib.e2k_query_hc_partial_stride(D)), dtype=f32,
                               device=G.device)
     ps = [_p(t) for t in params] if width else [None] * 7
     gs = [_p(t) for t in grads] if width else [None] * 7

@@ -41,9 +41,10 @@ int e2k_gemm_nt_bf16(const void* A1, int64_t lda1, int K1, const void* A2, int64
                      int rows_per_batch, const uint8_t* rowmask, const void* resid, int64_t ldr, int flags,
                      void* stream);
 #define E2K_GEMM_NO_GLDS 1   /* flags: stage operands through VGPRs instead of global_load_lds (A/B benchmarking) */
+#define E2K_GEMM_NO_PIPE 2   /* flags: 2-buffer global_load_lds kernel instead of the 4-stage counted-vmcnt pipeline */
 
 /* C[N,K] += A[M,N]^T . B[M,K]  (weight gradients; C fp32, A = dY, B = X, bf16).  The token dimension M is
- * split over `splits` workgroups per tile (0 = choose), partial tiles are combined with fp32 atomics.
+ * split over `splits` workgroups per tile (0 = choose); partial tiles go to `ws` and are combined by a reduce kernel.
  * use_tr = 1 reads MFMA fragments with ds_read_b64_tr_b16, 0 = plain 16-bit LDS gathers (same results). */
 int e2k_gemm_tn_bf16(const void* A, int64_t lda, const void* B, int64_t ldb, float* C, int64_t ldc,
                      int M, int N, int K, int splits, int use_tr, float* ws, void* stream);
@@ -58,7 +59,7 @@ int e2k_query_gemm_tn_splits(int M, int N, int K, int splits);
  * forward:  r = has_depth ? Xin + b_prev * yprev : Xin            (depth connection of the previous instance)
  *           has_width ? (bin, Mout, coef) = width(r) : Mout = r   (width connection of this instance)   */
 int e2k_query_hc_coef_width(void);
-int e2k_query_hc_bwd_blocks(int Mtok);        /* rows of `partial` the backward needs */
+int e2k_query_hc_bwd_blocks(int Mtok, int D); /* rows of `partial` the backward needs */
 int e2k_query_hc_partial_stride(int D);       /* floats per row of `partial` */
 int e2k_hc_fwd(const void* Xin, const void* yprev, const float* coef_prev, void* Mout, void* bin,
                float* coef, const float* static_beta, const float* static_alpha,

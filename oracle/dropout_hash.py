@@ -1,5 +1,5 @@
 """TEST INFRASTRUCTURE (oracle side): bit-exact numpy restatement of the counter-hash dropout masks the HIP kernels
-generate (e2k_device.h: fmix32 / rand_u32; attn.hip: drop_scale; elementwise.hip: keep_scale).
+generate (e2k_device.h: fmix32 / rand_base / rand_at; attn.hip: drop_scale; elementwise.hip: keep_scale).
 
 The reference draws dropout masks from torch's Philox stream (nn.Dropout inside x_transformers, e2_tts.py:540,641,646);
 device RNG streams cannot be matched across implementations, so for parity runs the oracle is fed the masks the
@@ -24,9 +24,8 @@ def fmix32(h):
 def rand_u32(seed, stream, row, col):
     with np.errstate(over='ignore'):
         seed, stream = np.uint32(seed), np.uint32(stream)
-        h = fmix32(np.asarray(seed ^ np.uint32((int(stream) * 0x9e3779b1) & 0xffffffff), dtype=np.uint32))
-        h = fmix32(h ^ (row.astype(np.uint32) * _M(0x85ebca77) + _M(0x165667b1)))
-        h = fmix32(h ^ (col.astype(np.uint32) * _M(0xc2b2ae3d) + _M(0x27d4eb2f)))
+        base = fmix32(np.asarray(seed ^ np.uint32((int(stream) * 0x9e3779b1) & 0xffffffff), dtype=np.uint32))
+        h = fmix32(base + row.astype(np.uint32) * _M(0x85ebca77) + col.astype(np.uint32) * _M(0xc2b2ae3d))
     return h
 
 

@@ -26,6 +26,18 @@ inline s16x4_ lds_read_tr16_b64(const void* lds_ptr) {
     return r;
 }
 
+inline float uniform_f(float v) { return v; }
+inline int uniform_i(int v) { return v; }
+inline float wave_sum_fast(float v) {          // same result up to summation order
+    for (int m = 32; m >= 1; m >>= 1) v += __shfl_xor(v, m);
+    return v;
+}
+inline float fast_exp2(float x) { return exp2f(x); }
+inline float fast_rcp(float x) { return 1.0f / x; }
+
+template <int N> inline void wait_vmcnt() {}
+inline void barrier_keep_vm() { emu::block_rendezvous(); }
+
 // host model of global_load_lds_dwordx4: lane l copies its 16 bytes to (wave-uniform) lds_base + 16*l
 inline void glds16(const void* gsrc, void* lds_base) {
     memcpy((char*)lds_base + 16 * emu::lane_id(), gsrc, 16);
