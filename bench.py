@@ -131,6 +131,7 @@ def main():
     t0 = time.perf_counter()
     for _ in range(args.steps):
         loss = step()
+    t_enqueue = time.perf_counter() - t0          # host time to enqueue everything (no sync inside the loop)
     torch.cuda.synchronize()
     if world > 1:
         dist.barrier()
@@ -168,6 +169,7 @@ def main():
             'model_tflops_per_s_per_gpu': sf / (dt / args.steps) / 1e12,
             'mfma_roofline_frac_whole_step': sf / (dt / args.steps) / 1e12 / PEAK_BF16_TFLOPS,
             'loss': loss_val,
+            'host_enqueue_ms_per_step': t_enqueue / args.steps * 1e3,
             'roofline': {
                 'bound': 'mfma', 'kernel': 'e2k gemm_nt_kernel (bf16 MFMA 16x16x32, all forward + dgrad GEMMs)',
                 'achieved': achieved, 'peak': PEAK_BF16_TFLOPS, 'unit': 'TFLOP/s', 'frac': achieved / PEAK_BF16_TFLOPS,

@@ -225,7 +225,101 @@ __global__ __launch_bounds__(256) void gemm_nt_kernel(NTArgs p) {
     nt_epilogue<OUT_F32>(p, acc, m0, n0, wm, wn, l15, g);
 }
 
-// Pipelined variant (default when K1, K2 are multiples of 32): BK = 32, four LDS stages of 16 KB, global_load_lds
+// Default NT kernel: global_load_lds staging, two 32-KB LDS buffers, BK = 64, one barrier per K step.
+// All per-lane addressing is hoisted out of the K loop: the 8 source pointers (4 A rows + 4 B rows per lane, swizzled
+// source column) advance by one scalar add per step, the 16 fragment-read offsets are loop-invariant VGPRs and the
+// loop is unrolled by two so that the LDS buffer select is an immediate offset (the first version of this loop spent
+// ~50 VALU instructions per 32 MFMAs on address arithmetic: PMC showed 3.6 VALU per MFMA and MFMA busy at 25 %).
+template <bool OUT_F32>
+__global__ __launch_bounds__(256, 2) void gemm_nt_glds_kernel(NTArgs p) {
+    __shared__ __attribute__((aligned(16))) unsigned char smem[2][2][BM * BK * 2];
+    const int tid = threadIdx.x, lane = tid & 63, wave = uniform_i(tid >> 6);
+    const int wm = wave >> 1, wn = wave & 1;
+    const int l15 = lane & 15, g = lane >> 4;
+    const int tm = (p.M + BM - 1) / BM, tn = (p.N + BN - 1) / BN;
+    int tile_m, tile_n;
+    tile_coords(xcd_remap(blockIdx.x, gridDim.x), tm, tn, tile_m, tile_n);
+    const int m0 = tile_m * BM, n0 = tile_n * BN;
+    const int nk1 = p.K1 / BK, nk = (p.K1 + p.K2) / BK;
+
+    // per-lane 32-bit byte offsets of the 4 (A) + 4 (B) wave instructions of a K step at k = 0; the K advance goes
+    // into the scalar base, so a load is `global_load_lds_dwordx4 voff, s[base]` with no per-step vector arithmetic
+    unsigned va1[4], va2[4], vb[4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        const int row = (wave * 4 + i) * 8 + (lane >> 3);
+        const int c = (lane & 7) ^ (row & 7);
+        const int m = min(m0 + row, p.M - 1), n = min(n0 + row, p.N - 1);
+        va1[i] = (unsigned)(((long)m * p.lda1 + c * 8) * 2);
+        va2[i] = p.K2 ? (unsigned)(((long)m * p.lda2 + c * 8) * 2) : 0u;
+        vb[i] = (unsigned)(((long)n * p.ldb + c * 8) * 2);
+    }
+    // fragment read offsets (bytes inside one operand tile): [kk][i]
+    int offa[2][4], offb[2][4];
+#pragma unroll
+    for (int kk = 0; kk < 2; ++kk)
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const int ra = wm * 64 + i * 16 + l15, rb = wn * 64 + i * 16 + l15;
+            offa[kk][i] = ra * 128 + (((kk * 4 + g) ^ (ra & 7)) << 4);
+            offb[kk][i] = rb * 128 + (((kk * 4 + g) ^ (rb & 7)) << 4);
+        }
+
+    auto gissue = [&](int kt, int buf) {
+        const char* sb = (const char*)p.B + (long)kt * (BK * 2);
+        if (kt < nk1) {                       // wave-uniform branch; no register-array select (would go to scratch)
+            const char* sa = (const char*)p.A1 + (long)kt * (BK * 2);
+#pragma unroll
+            for (int i = 0; i < 4; ++i) glds16(sa + va1[i], &smem[buf][0][(wave * 4 + i) * 1024]);
+        } else {
+            const char* sa = (const char*)p.A2 + (long)(kt - nk1) * (BK * 2);
+#pragma unroll
+            for (int i = 0; i < 4; ++i) glds16(sa + va2[i], &smem[buf][0][(wave * 4 + i) * 1024]);
+        }
+#pragma unroll
+        for (int i = 0; i < 4; ++i) glds16(sb + vb[i], &smem[buf][1][(wave * 4 + i) * 1024]);
+    };
+
+    f32x4 acc[4][4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+    auto compute = [&](int buf) {
+        const unsigned char* As = smem[buf][0];
+        const unsigned char* Bs = smem[buf][1];
+#pragma unroll
+        for (int kk = 0; kk < 2; ++kk) {
+            bf16x8 af[4], bw[4];
+#pragma unroll
+            for (int i = 0; i < 4; ++i) af[i] = ld<bf16x8>(As + offa[kk][i]);
+#pragma unroll
+            for (int j = 0; j < 4; ++j) bw[j] = ld<bf16x8>(Bs + offb[kk][j]);
+#pragma unroll
+            for (int i = 0; i < 4; ++i)
+#pragma unroll
+                for (int j = 0; j < 4; ++j)
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(bw[j], af[i], acc[i][j], 0, 0, 0);
+        }
+    };
+
+    gissue(0, 0);
+    __syncthreads();
+    int kt = 0;
+    for (; kt + 1 < nk; kt += 2) {
+        gissue(kt + 1, 1);
+        compute(0);
+        __syncthreads();
+        if (kt + 2 < nk) gissue(kt + 2, 0);
+        compute(1);
+        __syncthreads();
+    }
+    if (kt < nk) compute(0);
+    nt_epilogue<OUT_F32>(p, acc, m0, n0, wm, wn, l15, g);
+}
+
+// Pipelined variant (flag E2K_GEMM_PIPE4; measured 5-10 % SLOWER than the 2-buffer kernel on MI355X, kept for A/B): BK = 32, four LDS stages of 16 KB, global_load_lds
 // prefetch THREE k-steps ahead, counted s_waitcnt vmcnt + raw s_barrier so the prefetches stay in flight across the
 // barrier (the 2-buffer kernel above drains them every step and is bound by L2/HBM latency, ~1500 cycles per
 // 512-cycle MFMA step).  64-B LDS rows: the 16-B slot s of row r is stored at s ^ P[(r >> 2) & 3], P = {0,2,3,1},
@@ -486,16 +580,16 @@ extern "C" int e2k_gemm_nt_bf16(const void* A1, int64_t lda1, int K1, const void
     const int tm = (M + BM - 1) / BM, tn = (N + BN - 1) / BN;
     dim3 grid(tm * tn), block(256);
     const bool glds = !(flags & E2K_GEMM_NO_GLDS) && (K1 % BK) == 0 && (K2 % BK) == 0;
-    const bool pipe = !(flags & (E2K_GEMM_NO_GLDS | E2K_GEMM_NO_PIPE)) && (K1 % PBK) == 0 && (K2 % PBK) == 0;
+    const bool pipe = (flags & E2K_GEMM_PIPE4) && (K1 % PBK) == 0 && (K2 % PBK) == 0;
     hipStream_t st = (hipStream_t)stream;
     if (pipe) {
         if (out_f32) hipLaunchKernelGGL(gemm_nt_pipe_kernel<true>, grid, block, 0, st, p);
         else hipLaunchKernelGGL(gemm_nt_pipe_kernel<false>, grid, block, 0, st, p);
     } else if (out_f32) {
-        if (glds) hipLaunchKernelGGL((gemm_nt_kernel<true, true>), grid, block, 0, st, p);
+        if (glds) hipLaunchKernelGGL(gemm_nt_glds_kernel<true>, grid, block, 0, st, p);
         else hipLaunchKernelGGL((gemm_nt_kernel<true, false>), grid, block, 0, st, p);
     } else {
-        if (glds) hipLaunchKernelGGL((gemm_nt_kernel<false, true>), grid, block, 0, st, p);
+        if (glds) hipLaunchKernelGGL(gemm_nt_glds_kernel<false>, grid, block, 0, st, p);
         else hipLaunchKernelGGL((gemm_nt_kernel<false, false>), grid, block, 0, st, p);
     }
     E2K_CHECK_LAUNCH();

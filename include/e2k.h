@@ -41,7 +41,7 @@ int e2k_gemm_nt_bf16(const void* A1, int64_t lda1, int K1, const void* A2, int64
                      int rows_per_batch, const uint8_t* rowmask, const void* resid, int64_t ldr, int flags,
                      void* stream);
 #define E2K_GEMM_NO_GLDS 1   /* flags: stage operands through VGPRs instead of global_load_lds (A/B benchmarking) */
-#define E2K_GEMM_NO_PIPE 2   /* flags: 2-buffer global_load_lds kernel instead of the 4-stage counted-vmcnt pipeline */
+#define E2K_GEMM_PIPE4 2     /* flags: 4-stage BK=32 counted-vmcnt pipeline instead of the 2-buffer BK=64 kernel (A/B) */
 
 /* C[N,K] += A[M,N]^T . B[M,K]  (weight gradients; C fp32, A = dY, B = X, bf16).  The token dimension M is
  * split over `splits` workgroups per tile (0 = choose); partial tiles go to `ws` and are combined by a reduce kernel.
