@@ -57,6 +57,18 @@ __device__ __forceinline__ void tile_sstore(unsigned char* lds, const TileRegs& 
         st<u32x4>(lds + tile_off(row, slot), r.v[c]);
     }
 }
+// same, but tile row R is stored at LDS row 16t + i with R = perm_row(t, i): the score MFMAs then read plain rows
+// 16t + (l & 15), for which the XOR swizzle is conflict-free (reading rows perm_row(t, l & 15) of a naturally
+// ordered tile was a 4-way bank conflict: 20 % of the LDS cycles of the backward kernels)
+__device__ __forceinline__ int perm_inv(int R) { return (R & 0x23) | ((R & 0x18) >> 1) | ((R & 0x04) << 2); }
+__device__ __forceinline__ void tile_sstore_perm(unsigned char* lds, const TileRegs& r, int tid) {
+#pragma unroll
+    for (int c = 0; c < 2; ++c) {
+        int chunk = tid + c * 256;
+        int row = perm_inv(chunk >> 3), slot = chunk & 7;
+        st<u32x4>(lds + tile_off(row, slot), r.v[c]);
+    }
+}
 __device__ __forceinline__ bf16x8 tile_frag(const unsigned char* lds, int row, int slot) {
     return ld<bf16x8>(lds + tile_off(row, slot));
 }
@@ -213,6 +225,7 @@ struct AttnArgs {
     float* lse2;                               // (B,h,N)  log2-domain log-sum-exp
     int B, H, N, Npad;
     float scale; unsigned seed, stream_id, thresh; float inv_keep;
+    const unsigned* seed_dev;                  // if set, the dropout seed is read from device memory (graph replay)
     // backward
     const bf16_t* dOg;                         // (B*N, h*64)
     bf16_t* dO; bf16_t* dOT;                   // head-major / transposed
@@ -225,7 +238,7 @@ __device__ __forceinline__ void score_tile(const unsigned char* Kt, const bf16x8
 #pragma unroll
     for (int t = 0; t < 4; ++t) {
         s[t] = f32x4{0.f, 0.f, 0.f, 0.f};
-        const int row = perm_row(t, l15);
+        const int row = 16 * t + l15;            // tile stored with tile_sstore_perm
 #pragma unroll
         for (int kk = 0; kk < 2; ++kk) {
             bf16x8 kf = tile_frag(Kt, row, kk * 4 + g);
@@ -256,7 +269,7 @@ __global__ __launch_bounds__(256) void attn_fwd_kernel(AttnArgs p) {
     for (int ct = 0; ct < 4; ++ct) o[ct] = f32x4{0.f, 0.f, 0.f, 0.f};
     float m = NEG_BIG, lsum = 0.f;
     const float k2 = 2.f * LOG2E * p.scale / CLAMP, cl2 = CLAMP * LOG2E;
-    const unsigned hrow = rand_base(p.seed, dstream) + (unsigned)q * 0x85ebca77u;
+    const unsigned hrow = rand_base(p.seed_dev ? *p.seed_dev : p.seed, dstream) + (unsigned)q * 0x85ebca77u;
 
     const int ntiles = (p.N + 63) / 64;
     const bf16_t* Kbase = p.K + bh * p.N * DH;
@@ -265,7 +278,7 @@ __global__ __launch_bounds__(256) void attn_fwd_kernel(AttnArgs p) {
     TileRegs rv = tile_gload(VTbase, p.Npad, 64, tid);
     for (int kt = 0; kt < ntiles; ++kt) {
         const int k0 = kt * 64;
-        tile_sstore(Kt, rk, tid);
+        tile_sstore_perm(Kt, rk, tid);
         tile_sstore(Vt, rv, tid);
         __syncthreads();
         if (kt + 1 < ntiles) {
@@ -412,7 +425,7 @@ __global__ __launch_bounds__(256) void attn_bwd_dq_kernel(AttnArgs p) {
     const float lse = qin ? p.lse2[bh * p.N + q] : 1e30f;
     const float dl = qin ? p.delta[bh * p.N + q] : 0.f;
     const float k2 = 2.f * LOG2E * p.scale / CLAMP, cl2 = CLAMP * LOG2E;
-    const unsigned hrow = rand_base(p.seed, dstream) + (unsigned)q * 0x85ebca77u;
+    const unsigned hrow = rand_base(p.seed_dev ? *p.seed_dev : p.seed, dstream) + (unsigned)q * 0x85ebca77u;
 
     f32x4 dq[4];
 #pragma unroll
@@ -427,8 +440,8 @@ __global__ __launch_bounds__(256) void attn_bwd_dq_kernel(AttnArgs p) {
     TileRegs rt = tile_gload(KTbase, p.Npad, 64, tid);
     for (int kt = 0; kt < ntiles; ++kt) {
         const int k0 = kt * 64;
-        tile_sstore(Kt, rk, tid);
-        tile_sstore(Vr, rv, tid);
+        tile_sstore_perm(Kt, rk, tid);
+        tile_sstore_perm(Vr, rv, tid);
         tile_sstore(KTt, rt, tid);
         __syncthreads();
         if (kt + 1 < ntiles) {
@@ -510,7 +523,7 @@ __global__ __launch_bounds__(256) void attn_bwd_dkv_kernel(AttnArgs p) {
 #pragma unroll
     for (int ct = 0; ct < 4; ++ct) { dk[ct] = f32x4{0.f, 0.f, 0.f, 0.f}; dv[ct] = f32x4{0.f, 0.f, 0.f, 0.f}; }
     const float k2 = 2.f * LOG2E * p.scale / CLAMP, cl2 = CLAMP * LOG2E;
-    const unsigned hkey = rand_base(p.seed, dstream) + ((unsigned)key >> 1) * 0xc2b2ae3du;
+    const unsigned hkey = rand_base(p.seed_dev ? *p.seed_dev : p.seed, dstream) + ((unsigned)key >> 1) * 0xc2b2ae3du;
 
     const int ntiles = (p.N + 63) / 64;
     const bf16_t* Qbase = p.Q + bh * p.N * DH;
@@ -523,8 +536,8 @@ __global__ __launch_bounds__(256) void attn_bwd_dkv_kernel(AttnArgs p) {
     TileRegs r3 = tile_gload(dOTbase, p.Npad, 64, tid);
     for (int qt = 0; qt < ntiles; ++qt) {
         const int q0 = qt * 64;
-        tile_sstore(Qt, r0, tid);
-        tile_sstore(dOt, r1, tid);
+        tile_sstore_perm(Qt, r0, tid);
+        tile_sstore_perm(dOt, r1, tid);
         tile_sstore(QTt, r2, tid);
         tile_sstore(dOTt, r3, tid);
         if (tid < 64) {
@@ -546,7 +559,7 @@ __global__ __launch_bounds__(256) void attn_bwd_dkv_kernel(AttnArgs p) {
         for (int t = 0; t < 4; ++t) {
             s[t] = f32x4{0.f, 0.f, 0.f, 0.f};
             dp[t] = f32x4{0.f, 0.f, 0.f, 0.f};
-            const int row = perm_row(t, l15);
+            const int row = 16 * t + l15;        // tiles stored with tile_sstore_perm
 #pragma unroll
             for (int kk = 0; kk < 2; ++kk) {
                 bf16x8 qfr = tile_frag(Qt, row, kk * 4 + g);
@@ -635,12 +648,13 @@ extern "C" int e2k_qkv_post_bwd(const void* dQ, const void* dK, const void* dV, 
     return 0;
 }
 
-static int fill_attn(AttnArgs& a, int B, int H, int N, int Npad, float p_drop, uint32_t seed, uint32_t stream_id) {
+static int fill_attn(AttnArgs& a, int B, int H, int N, int Npad, float p_drop, uint32_t seed, const uint32_t* seed_dev,
+                     uint32_t stream_id) {
     if ((Npad & 63) || Npad < N) return E2K_ERR_ALIGN;
     if (B * H >= 8192) return E2K_ERR_SHAPE;
     a.B = B; a.H = H; a.N = N; a.Npad = Npad;
     a.scale = 0.125f;   // dim_head ** -0.5, dim_head = 64
-    a.seed = seed; a.stream_id = stream_id;
+    a.seed = seed; a.seed_dev = seed_dev; a.stream_id = stream_id;
     a.thresh = (unsigned)(p_drop * 65536.f + 0.5f);
     a.inv_keep = 1.f / (1.f - p_drop);
     return 0;
@@ -648,11 +662,11 @@ static int fill_attn(AttnArgs& a, int B, int H, int N, int Npad, float p_drop, u
 
 extern "C" int e2k_attn_fwd(const void* Q, const void* K, const void* VT, const uint8_t* kmask, const float* gate,
                             void* O, void* Og, float* lse2, int B, int H, int N, int Npad, float p_drop,
-                            uint32_t seed, uint32_t stream_id, void* stream) {
+                            uint32_t seed, const uint32_t* seed_dev, uint32_t stream_id, void* stream) {
     if (B <= 0 || N <= 0) return 0;
     if (!Q || !K || !VT || !kmask || !gate || !O || !Og || !lse2) return E2K_ERR_ARG;
     AttnArgs a{};
-    int rc = fill_attn(a, B, H, N, Npad, p_drop, seed, stream_id);
+    int rc = fill_attn(a, B, H, N, Npad, p_drop, seed, seed_dev, stream_id);
     if (rc) return rc;
     a.Q = (const bf16_t*)Q; a.K = (const bf16_t*)K; a.VT = (const bf16_t*)VT; a.kmask = kmask; a.gate = gate;
     a.O = (bf16_t*)O; a.Og = (bf16_t*)Og; a.lse2 = lse2;
@@ -664,13 +678,13 @@ extern "C" int e2k_attn_fwd(const void* Q, const void* K, const void* VT, const 
 extern "C" int e2k_attn_bwd(const void* dOg, const void* O, const float* gate, const float* lse2, const void* Q,
                             const void* K, const void* V, const void* QT, const void* KT, const uint8_t* kmask,
                             void* dO, void* dOT, float* delta, float* dgate_pre, void* dQ, void* dK, void* dV,
-                            int B, int H, int N, int Npad, float p_drop, uint32_t seed, uint32_t stream_id,
-                            void* stream) {
+                            int B, int H, int N, int Npad, float p_drop, uint32_t seed, const uint32_t* seed_dev,
+                            uint32_t stream_id, void* stream) {
     if (B <= 0 || N <= 0) return 0;
     if (!dOg || !O || !gate || !lse2 || !Q || !K || !V || !QT || !KT || !kmask || !dO || !dOT || !delta || !dgate_pre ||
         !dQ || !dK || !dV) return E2K_ERR_ARG;
     AttnArgs a{};
-    int rc = fill_attn(a, B, H, N, Npad, p_drop, seed, stream_id);
+    int rc = fill_attn(a, B, H, N, Npad, p_drop, seed, seed_dev, stream_id);
     if (rc) return rc;
     a.dOg = (const bf16_t*)dOg; a.O = (bf16_t*)O; a.gate = gate; a.lse2 = const_cast<float*>(lse2);
     a.Q = (const bf16_t*)Q; a.K = (const bf16_t*)K; a.V = (const bf16_t*)V; a.QT = (const bf16_t*)QT;

@@ -159,12 +159,14 @@ __device__ __forceinline__ float keep_scale(unsigned seed, unsigned stream, unsi
 struct GegluArgs {
     const bf16_t* H; long ldh; bf16_t* out; const bf16_t* dout; bf16_t* dH; int M, F;
     unsigned seed, stream, thresh; float inv_keep;     // dropout (thresh = 0: off)
+    const unsigned* seed_dev;                          // if set, the seed is read from device memory (graph replay)
 };
 
 template <bool BWD>
 __global__ __launch_bounds__(256) void geglu_kernel(GegluArgs p) {
     const int fv = p.F / 8;
     const long total = (long)p.M * fv;
+    const unsigned seed = p.seed_dev ? *p.seed_dev : p.seed;
     for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < total; i += (long)gridDim.x * 256) {
         const int m = (int)(i / fv), c = (int)(i % fv) * 8;
         float u[8], gt[8];
@@ -172,7 +174,7 @@ __global__ __launch_bounds__(256) void geglu_kernel(GegluArgs p) {
         unpack8(ld<u32x4>(p.H + (long)m * p.ldh + p.F + c), gt);
         float ks[8];
 #pragma unroll
-        for (int e = 0; e < 8; ++e) ks[e] = p.thresh ? keep_scale(p.seed, p.stream, m, c + e, p.thresh, p.inv_keep) : 1.f;
+        for (int e = 0; e < 8; ++e) ks[e] = p.thresh ? keep_scale(seed, p.stream, m, c + e, p.thresh, p.inv_keep) : 1.f;
         if (!BWD) {
             float o[8];
 #pragma unroll
@@ -301,8 +303,8 @@ __device__ __forceinline__ float silu_grad(float x) { float s = sigmoidf_(x); re
 template <int KS>
 __global__ __launch_bounds__(256) void dwconv_bwd_kernel(ConvArgs p) {
     constexpr int PAD = KS / 2, ROWS = CTN + KS - 1;
-    __shared__ float dpt[ROWS][CTC];       // d(pre-activation), frame n0 - PAD + j
-    __shared__ float xt[ROWS][CTC];        // masked input,      frame n0 - PAD + j
+    __shared__ __attribute__((aligned(16))) float dpt[ROWS][CTC];       // d(pre-activation), frame n0 - PAD + j
+    __shared__ __attribute__((aligned(16))) float xt[ROWS][CTC];        // masked input,      frame n0 - PAD + j
     __shared__ float dwl[CTC][KS + 1];     // [..][KS] = dbias
     const int tid = threadIdx.x;
     const int c0 = blockIdx.y * CTC, b = blockIdx.z;
@@ -322,20 +324,25 @@ __global__ __launch_bounds__(256) void dwconv_bwd_kernel(ConvArgs p) {
     for (int tile = t_beg; tile < t_end; ++tile) {
         const int n0 = tile * CTN;
         __syncthreads();                  // previous tile fully consumed (also orders the dwl zero-fill)
-        for (int i = tid; i < ROWS * (CTC / 2); i += 256) {
-            int j = i / (CTC / 2), cq = i % (CTC / 2);
-            int n = n0 - PAD + j;
-            float d0 = 0.f, d1 = 0.f, x0 = 0.f, x1 = 0.f;
+        for (int i = tid; i < ROWS * (CTC / 8); i += 256) {          // 8 channels (16 B) per item
+            const int j = i / (CTC / 8), c8 = (i % (CTC / 8)) * 8;
+            const int n = n0 - PAD + j;
+            float d[8], x[8];
+#pragma unroll
+            for (int e = 0; e < 8; ++e) { d[e] = 0.f; x[e] = 0.f; }
             if (n >= 0 && n < p.N && (p.mask == nullptr || p.mask[(long)b * p.N + n])) {
-                const long off = ((long)b * p.N + n) * p.C + c0 + cq * 2;
-                unsigned vd = ld<unsigned>(p.dy + off), vp = ld<unsigned>(p.pre + off), vx = ld<unsigned>(p.x + off);
-                d0 = bflo(vd) * silu_grad(bflo(vp));
-                d1 = bfhi(vd) * silu_grad(bfhi(vp));
-                x0 = bflo(vx);
-                x1 = bfhi(vx);
+                const long off = ((long)b * p.N + n) * p.C + c0 + c8;
+                float pr[8];
+                unpack8(ld<u32x4>(p.dy + off), d);
+                unpack8(ld<u32x4>(p.pre + off), pr);
+                unpack8(ld<u32x4>(p.x + off), x);
+#pragma unroll
+                for (int e = 0; e < 8; ++e) d[e] *= silu_grad(pr[e]);
             }
-            dpt[j][cq * 2] = d0; dpt[j][cq * 2 + 1] = d1;
-            xt[j][cq * 2] = x0;  xt[j][cq * 2 + 1] = x1;
+            st<f32x4>(&dpt[j][c8], f32x4{d[0], d[1], d[2], d[3]});
+            st<f32x4>(&dpt[j][c8 + 4], f32x4{d[4], d[5], d[6], d[7]});
+            st<f32x4>(&xt[j][c8], f32x4{x[0], x[1], x[2], x[3]});
+            st<f32x4>(&xt[j][c8 + 4], f32x4{x[4], x[5], x[6], x[7]});
         }
         __syncthreads();
         // dx[o] = sum_k' wflip[k'] dp_tile[o + k']
@@ -344,7 +351,8 @@ __global__ __launch_bounds__(256) void dwconv_bwd_kernel(ConvArgs p) {
         for (int o = 0; o < 8; ++o) { a0[o] = 0.f; a1[o] = 0.f; }
 #pragma unroll
         for (int i = 0; i < 8 + KS - 1; ++i) {
-            float d0 = dpt[fg * 8 + i][cp * 2], d1 = dpt[fg * 8 + i][cp * 2 + 1];
+            const float2 dd = ld<float2>(&dpt[fg * 8 + i][cp * 2]);
+            const float d0 = dd.x, d1 = dd.y;
 #pragma unroll
             for (int o = 0; o < 8; ++o) {
                 const int k = i - o;
@@ -363,14 +371,16 @@ __global__ __launch_bounds__(256) void dwconv_bwd_kernel(ConvArgs p) {
         float dq0[8], dq1[8];
 #pragma unroll
         for (int o = 0; o < 8; ++o) {
-            dq0[o] = dpt[fg * 8 + o + PAD][cp * 2];
-            dq1[o] = dpt[fg * 8 + o + PAD][cp * 2 + 1];
+            const float2 dd = ld<float2>(&dpt[fg * 8 + o + PAD][cp * 2]);
+            dq0[o] = dd.x;
+            dq1[o] = dd.y;
             s0 += dq0[o];
             s1 += dq1[o];
         }
 #pragma unroll
         for (int i = 0; i < 8 + KS - 1; ++i) {
-            float x0 = xt[fg * 8 + i][cp * 2], x1 = xt[fg * 8 + i][cp * 2 + 1];
+            const float2 xx = ld<float2>(&xt[fg * 8 + i][cp * 2]);
+            const float x0 = xx.x, x1 = xx.y;
 #pragma unroll
             for (int o = 0; o < 8; ++o) {
                 const int k = i - o;
@@ -468,24 +478,24 @@ static int geglu_grid(long total) {
 }
 
 extern "C" int e2k_geglu_fwd(const void* H, int64_t ldh, void* out, int M, int F, float p_drop, uint32_t seed,
-                             uint32_t stream_id, void* stream) {
+                             const uint32_t* seed_dev, uint32_t stream_id, void* stream) {
     if (M <= 0 || F <= 0) return 0;
     if ((F & 7) || (ldh & 7)) return E2K_ERR_ALIGN;
     GegluArgs a{};
     a.H = (const bf16_t*)H; a.ldh = ldh; a.out = (bf16_t*)out; a.M = M; a.F = F;
-    a.seed = seed; a.stream = stream_id; a.thresh = (unsigned)(p_drop * 65536.f + 0.5f); a.inv_keep = 1.f / (1.f - p_drop);
+    a.seed = seed; a.seed_dev = seed_dev; a.stream = stream_id; a.thresh = (unsigned)(p_drop * 65536.f + 0.5f); a.inv_keep = 1.f / (1.f - p_drop);
     hipLaunchKernelGGL(geglu_kernel<false>, dim3(geglu_grid((long)M * F / 8)), dim3(256), 0, (hipStream_t)stream, a);
     E2K_CHECK_LAUNCH();
     return 0;
 }
 
 extern "C" int e2k_geglu_bwd(const void* dout, const void* H, int64_t ldh, void* dH, int M, int F, float p_drop,
-                             uint32_t seed, uint32_t stream_id, void* stream) {
+                             uint32_t seed, const uint32_t* seed_dev, uint32_t stream_id, void* stream) {
     if (M <= 0 || F <= 0) return 0;
     if ((F & 7) || (ldh & 7)) return E2K_ERR_ALIGN;
     GegluArgs a{};
     a.H = (const bf16_t*)H; a.ldh = ldh; a.dout = (const bf16_t*)dout; a.dH = (bf16_t*)dH; a.M = M; a.F = F;
-    a.seed = seed; a.stream = stream_id; a.thresh = (unsigned)(p_drop * 65536.f + 0.5f); a.inv_keep = 1.f / (1.f - p_drop);
+    a.seed = seed; a.seed_dev = seed_dev; a.stream = stream_id; a.thresh = (unsigned)(p_drop * 65536.f + 0.5f); a.inv_keep = 1.f / (1.f - p_drop);
     hipLaunchKernelGGL(geglu_kernel<true>, dim3(geglu_grid((long)M * F / 8)), dim3(256), 0, (hipStream_t)stream, a);
     E2K_CHECK_LAUNCH();
     return 0;

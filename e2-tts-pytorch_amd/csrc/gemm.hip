@@ -428,6 +428,37 @@ __device__ __forceinline__ bf16x8 tn_frag(const unsigned char* T, int kk, int co
     return f;
 }
 
+// acc[i][j]: C[n = n0+wn*64+j*16+q][k = k0+wk*64+i*16+4g+r]
+__device__ __forceinline__ void tn_store(const TNArgs& p, f32x4 (&acc)[4][4], int n0, int k0, int wn, int wk, int q, int g) {
+    // splits == 1: C += acc.  splits > 1: plain stores of the partial tile into ws[split] (combined by
+    // tn_reduce_kernel: fp32 atomics on C ran at ~60 G atomics/s and dominated small-output weight gradients).
+    const bool to_ws = p.splits > 1;
+    float* base = to_ws ? p.ws + (long)blockIdx.y * p.N * p.K : p.C;
+    const long ld = to_ws ? p.K : p.ldc;
+    const bool vec = to_ws && (p.K & 3) == 0;
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+        const int n = n0 + wn * 64 + j * 16 + q;
+        if (n >= p.N) continue;
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const int k = k0 + wk * 64 + i * 16 + 4 * g;
+            float* c = base + (long)n * ld + k;
+            if (vec && k + 3 < p.K) {
+                st<f32x4>(c, acc[i][j]);
+            } else {
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    if (k + r < p.K) {
+                        if (to_ws) c[r] = acc[i][j][r];
+                        else c[r] += acc[i][j][r];
+                    }
+                }
+            }
+        }
+    }
+}
+
 template <bool USE_TR>
 __global__ __launch_bounds__(256) void gemm_tn_kernel(TNArgs p) {
     __shared__ __attribute__((aligned(16))) unsigned char smem[2][2][TBM * TLD];
@@ -502,34 +533,94 @@ __global__ __launch_bounds__(256) void gemm_tn_kernel(TNArgs p) {
         if (s + 1 < nsteps) sstore(buf ^ 1);
         __syncthreads();
     }
-    // acc[i][j]: C[n = n0+wn*64+j*16+q][k = k0+wk*64+i*16+4g+r]
-    // splits == 1: C += acc.  splits > 1: plain stores of the partial tile into ws[split] (combined by
-    // tn_reduce_kernel: fp32 atomics on C ran at ~60 G atomics/s and dominated small-output weight gradients).
-    const bool to_ws = p.splits > 1;
-    float* base = to_ws ? p.ws + (long)blockIdx.y * p.N * p.K : p.C;
-    const long ld = to_ws ? p.K : p.ldc;
-    const bool vec = to_ws && (p.K & 3) == 0;
+    tn_store(p, acc, n0, k0, wn, wk, q, g);
+}
+
+// Fast TN path (token count a multiple of 64): global_load_lds staging into unpadded 256-B LDS rows whose 16-B chunks
+// are XOR-swizzled by 2*(row & 7) on the SOURCE side (conflict-free ds_read_b64_tr_b16: the 8 rows a half-wave reads
+// land on 8 distinct chunk pairs of the 256-B bank row), scalar base + hoisted 32-bit lane offsets, two LDS buffers.
+template <int DUMMY>
+__global__ __launch_bounds__(256, 2) void gemm_tn_glds_kernel(TNArgs p) {
+    __shared__ __attribute__((aligned(16))) unsigned char smem[2][2][TBM * 256];
+    const int tid = threadIdx.x, lane = tid & 63, wave = uniform_i(tid >> 6);
+    const int wn = wave >> 1, wk = wave & 1;
+    const int q = lane & 15, g = lane >> 4;
+    const int tn = (p.N + 127) / 128, tk = (p.K + 127) / 128;
+    int tile_n, tile_k;
+    tile_coords(xcd_remap(blockIdx.x, gridDim.x), tn, tk, tile_n, tile_k);
+    const int n0 = tile_n * 128, k0 = tile_k * 128;
+    const int mbeg = blockIdx.y * p.chunk;
+    const int mend = min(p.M, mbeg + p.chunk);
+    const int nsteps = (mend - mbeg) / TBM;
+
+    // source offsets (bytes) of this lane for the 4 + 4 wave instructions of a step, at step 0
+    unsigned va[4], vb[4];
 #pragma unroll
-    for (int j = 0; j < 4; ++j) {
-        const int n = n0 + wn * 64 + j * 16 + q;
-        if (n >= p.N) continue;
+    for (int i = 0; i < 4; ++i) {
+        const int row = (wave * 4 + i) * 4 + (lane >> 4);
+        const int c = (lane & 15) ^ (2 * (row & 7));
+        const int cn = min(n0 + c * 8, ((p.N + 7) & ~7) - 8), ck = min(k0 + c * 8, ((p.K + 7) & ~7) - 8);
+        va[i] = (unsigned)((((long)(mbeg + row)) * p.lda + cn) * 2);
+        vb[i] = (unsigned)((((long)(mbeg + row)) * p.ldb + ck) * 2);
+    }
+    // fragment read offsets: row (4g + q/4) of a 16-row slab, chunk ((col0/8) ^ 2*(row&7)) + (q&3)/2, byte (q&1)*8
+    const int r7 = (4 * g + (q >> 2)) & 7;
+    int offx[4], offy[4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        const int lanepart = (4 * g + (q >> 2)) * 256 + ((q & 3) >> 1) * 16 + (q & 1) * 8;
+        offx[i] = lanepart + (((wk * 8 + 2 * i) ^ (2 * r7)) << 4);
+        offy[i] = lanepart + (((wn * 8 + 2 * i) ^ (2 * r7)) << 4);
+    }
+    auto gissue = [&](int s, int buf) {
+        const char* sa = (const char*)p.A + (long)s * TBM * p.lda * 2;
+        const char* sb = (const char*)p.B + (long)s * TBM * p.ldb * 2;
 #pragma unroll
         for (int i = 0; i < 4; ++i) {
-            const int k = k0 + wk * 64 + i * 16 + 4 * g;
-            float* c = base + (long)n * ld + k;
-            if (vec && k + 3 < p.K) {
-                st<f32x4>(c, acc[i][j]);
-            } else {
-#pragma unroll
-                for (int r = 0; r < 4; ++r) {
-                    if (k + r < p.K) {
-                        if (to_ws) c[r] = acc[i][j][r];
-                        else c[r] += acc[i][j][r];
-                    }
-                }
-            }
+            glds16(sa + va[i], &smem[buf][0][(wave * 4 + i) * 1024]);
+            glds16(sb + vb[i], &smem[buf][1][(wave * 4 + i) * 1024]);
         }
+    };
+    f32x4 acc[4][4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+    auto compute = [&](int buf) {
+        const unsigned char* At = smem[buf][0];
+        const unsigned char* Bt = smem[buf][1];
+#pragma unroll
+        for (int kk = 0; kk < 2; ++kk) {
+            bf16x8 fx[4], fy[4];
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                s16x4_ lo = lds_read_tr16_b64(Bt + kk * 32 * 256 + offx[i]);
+                s16x4_ hi = lds_read_tr16_b64(Bt + (kk * 32 + 16) * 256 + offx[i]);
+                fx[i] = bf16x8{lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
+                s16x4_ lo2 = lds_read_tr16_b64(At + kk * 32 * 256 + offy[i]);
+                s16x4_ hi2 = lds_read_tr16_b64(At + (kk * 32 + 16) * 256 + offy[i]);
+                fy[i] = bf16x8{lo2[0], lo2[1], lo2[2], lo2[3], hi2[0], hi2[1], hi2[2], hi2[3]};
+            }
+#pragma unroll
+            for (int i = 0; i < 4; ++i)
+#pragma unroll
+                for (int j = 0; j < 4; ++j)
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fx[i], fy[j], acc[i][j], 0, 0, 0);
+        }
+    };
+    if (nsteps > 0) gissue(0, 0);
+    __syncthreads();
+    int s = 0;
+    for (; s + 1 < nsteps; s += 2) {
+        gissue(s + 1, 1);
+        compute(0);
+        __syncthreads();
+        if (s + 2 < nsteps) gissue(s + 2, 0);
+        compute(1);
+        __syncthreads();
     }
+    if (s < nsteps) compute(0);
+    tn_store(p, acc, n0, k0, wn, wk, q, g);
 }
 
 __global__ __launch_bounds__(256) void tn_reduce_kernel(const float* ws, float* C, long ldc, int N, int K, int splits) {
@@ -617,7 +708,8 @@ extern "C" int e2k_gemm_tn_bf16(const void* A, int64_t lda, const void* B, int64
     p.A = (const bf16_t*)A; p.lda = lda; p.B = (const bf16_t*)B; p.ldb = ldb;
     p.C = C; p.ldc = ldc; p.M = M; p.N = N; p.K = K; p.splits = splits; p.chunk = chunk;
     dim3 grid(tn * tk, splits), block(256);
-    if (use_tr) hipLaunchKernelGGL(gemm_tn_kernel<true>, grid, block, 0, (hipStream_t)stream, p);
+    if (use_tr && (M % TBM) == 0 && N >= 8 && K >= 8) hipLaunchKernelGGL(gemm_tn_glds_kernel<0>, grid, block, 0, (hipStream_t)stream, p);
+    else if (use_tr) hipLaunchKernelGGL(gemm_tn_kernel<true>, grid, block, 0, (hipStream_t)stream, p);
     else hipLaunchKernelGGL(gemm_tn_kernel<false>, grid, block, 0, (hipStream_t)stream, p);
     E2K_CHECK_LAUNCH();
     if (splits > 1) {

@@ -521,7 +521,7 @@ extern "C" int e2k_hc_bwd(const void* Xin, const void* yprev, const float* coef_
     a.partial = partial; a.Mtok = Mtok;
     if (!G || (has_depth && (!yprev || !coef_prev || !dyprev))) return E2K_ERR_ARG;
     if (has_width && (!Xin || !dbin || !ycur || !coef || !dR || !partial || !gamma || !g_gamma)) return E2K_ERR_ARG;
-    const int grid = grid_for(Mtok, D, 512, true);
+    const int grid = grid_for(Mtok, D, 512, true);      // two workgroups per CU (the kernel fits 2 waves per SIMD)
     int rc = 0;
     HC_DISPATCH_BWD(D, launch_bwd, a, has_depth != 0, has_width != 0, grid, (hipStream_t)stream);
     if (rc) return rc;

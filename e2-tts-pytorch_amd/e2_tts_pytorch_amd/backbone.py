@@ -308,6 +308,8 @@ class Transformer(Module):
         self._flat = None
         self._build_layout()
         self._grad_sync = None          # set by ddp.DataParallel: called with (grad_flat, start, end) per finished slab
+        self.use_graphs = False         # enable_graphs(): capture forward / per-layer backward into HIP graphs
+        self._graphs = {}
 
     # ------------------------------------------------------------------ layout
 
@@ -317,7 +319,9 @@ class Transformer(Module):
         I = attn.to_q.out_features
         mixl = attn.to_value_residual_mix[0] if exists(attn.to_value_residual_mix) else None
         cols = 3 * I + H + (H if exists(mixl) else 0)
-        r = NS(H=H, I=I, cols=cols, ldq=_r8(cols), has_mix=exists(mixl))
+        # row stride of the fused projection output / its gradient: a multiple of 64 so that the dgrad GEMM (K = ldq,
+        # zero padded) takes the global_load_lds path
+        r = NS(H=H, I=I, cols=cols, ldq=(cols + 63) // 64 * 64, has_mix=exists(mixl))
         r.w = lay.add(attn.to_q.weight)
         for p in (attn.to_k.weight, attn.to_v.weight, attn.to_v_head_gate.weight):
             lay.add(p, chain=True)
@@ -463,12 +467,16 @@ class Transformer(Module):
             self._pack(device)
         key = sum(p._version for p, _ in self._layout.slots)
         if key != self._shadow_key:
-            ops.cast_bf16(self._flat, self._shadow)
-            for t in self._tlist:
-                src = self._flat[t.src:t.src + t.R * t.C].view(t.R, t.C)
-                dst = self._shadowT[t.dst:t.dst + t.C * t.ldd].view(t.C, t.ldd)[:, :t.R]
-                ops.cast_transpose_bf16(src, dst)
+            self._recast()
             self._shadow_key = key
+
+    def _recast(self):
+        """fp32 master parameters -> bf16 shadows (+ transposed shadows for the dgrad GEMMs)"""
+        ops.cast_bf16(self._flat, self._shadow)
+        for t in self._tlist:
+            src = self._flat[t.src:t.src + t.R * t.C].view(t.R, t.C)
+            dst = self._shadowT[t.dst:t.dst + t.C * t.ldd].view(t.C, t.ldd)[:, :t.R]
+            ops.cast_transpose_bf16(src, dst)
 
     # views into the flat buffers -------------------------------------------------
     def _w(self, off, R, C):                  # bf16 weight (R, C)
@@ -500,17 +508,97 @@ class Transformer(Module):
             if times.ndim == 0:
                 times = times[None].expand(B)
             cond = self.time_cond_mlp(times.float())               # (B, D) fp32, tiny: stays in torch
-        self._sync(x.device)
         need_grad = torch.is_grad_enabled() and (
             x.requires_grad or (exists(cond) and cond.requires_grad) or (exists(text_embed) and text_embed.requires_grad)
             or any(p.requires_grad for p, _ in self._layout.slots))
+        if self.use_graphs and x.is_cuda:
+            st = self._graph_state(x, cond, text_embed, mask, need_grad)
+            if exists(st):
+                if need_grad:
+                    return _GraphFn.apply(self, st, x, cond, text_embed, mask, *self._params_in_order())
+                self._graph_inputs(st, x, cond, text_embed, mask)
+                st.fwd.replay()
+                return st.out.clone()
+        self._sync(x.device)
         if need_grad:
             return _BackboneFn.apply(self, x, cond, text_embed, mask, *self._params_in_order())
         return self._run_forward(x, cond, text_embed, mask, False).out
 
+    # ------------------------------------------------------------------ HIP graphs
+    # The eager schedule costs ~55 us of Python per kernel launch (~150 ms per cfg3 step, as much as the kernels take).
+    # With use_graphs the whole forward is captured once per (shape, text?, mask?, train?, grad?) into one HIP graph
+    # and the backward into one graph per layer (so ddp's per-layer gradient all-reduce still overlaps); later calls
+    # copy the inputs into static buffers and replay.  Dropout masks stay fresh: the kernels read the seed from a
+    # device word that is refilled before every replay.
+
+    def enable_graphs(self, on: bool = True):
+        self.use_graphs = on
+        if not on:
+            self._graphs = {}
+        return self
+
+    def _graph_state(self, x, cond, text_embed, mask, need_grad):
+        p_drop = self.dropout if self.training else 0.
+        key = (tuple(x.shape), x.dtype, exists(text_embed), exists(mask), need_grad, p_drop, x.device.index)
+        st = self._graphs.get(key)
+        if st is None:
+            self._graphs[key] = 'warm'              # first call with this signature runs eagerly (lazy inits, packing)
+            return None
+        if st == 'warm':
+            st = self._capture(x, cond, text_embed, mask, need_grad)
+            self._graphs[key] = st
+        return st
+
+    def _graph_inputs(self, st, x, cond, text_embed, mask):
+        st.x.copy_(x.detach())
+        if exists(cond):
+            st.cond.copy_(cond.detach())
+        if exists(text_embed):
+            st.text.copy_(text_embed.detach())
+        if exists(mask):
+            st.mask.copy_(mask)
+        if exists(st.seed):
+            st.seed.fill_(int(torch.randint(0, 2 ** 31 - 1, (1,)).item()))
+
+    def _capture(self, x, cond, text_embed, mask, need_grad):
+        dev = x.device
+        self._sync(dev)
+        st = NS(pool=torch.cuda.graph_pool_handle(), need_grad=need_grad)
+        st.x = torch.empty_like(x.detach())
+        st.cond = torch.empty_like(cond.detach()) if exists(cond) else None
+        st.text = torch.empty_like(text_embed.detach()) if exists(text_embed) else None
+        st.mask = torch.empty_like(mask) if exists(mask) else None
+        p_drop = self.dropout if self.training else 0.
+        st.seed = torch.zeros(1, dtype=torch.int32, device=dev) if p_drop > 0 else None
+        self._graph_inputs(st, x, cond, text_embed, mask)
+        torch.cuda.synchronize(dev)
+        st.fwd = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(st.fwd, pool=st.pool):
+            self._recast()
+            run = self._run_forward(st.x, st.cond, st.text, st.mask, need_grad, seed_dev=st.seed)
+        st.run, st.out = run, run.out
+        st.bwd = None
+        if need_grad:
+            st.dout = torch.zeros_like(run.out)
+            st.bwd = []
+            gen = self._backward_gen(run, st.dout)
+            done = False
+            while not done:
+                gr = torch.cuda.CUDAGraph()
+                slab = None
+                with torch.cuda.graph(gr, pool=st.pool):
+                    try:
+                        slab = next(gen)
+                    except StopIteration as e:
+                        st.dx, st.dcond, st.dtext, st.gflat = e.value
+                        done = True
+                st.bwd.append((gr, slab))
+        torch.cuda.synchronize(dev)
+        return st
+
     # ------------------------------------------------------------------ forward schedule
 
-    def _run_forward(self, x_in, cond, text_embed, mask, want_tape):
+    def _run_forward(self, x_in, cond, text_embed, mask, want_tape, seed_dev=None):
         dev = x_in.device
         B, T, D = x_in.shape
         Dt, R, L = self.dim_text, self.num_registers, self.depth
@@ -520,7 +608,8 @@ class Transformer(Module):
         tape = run.tape
         p_drop = self.dropout if self.training else 0.
         run.p_drop = p_drop
-        run.seed = int(torch.randint(0, 2 ** 31 - 1, (1,)).item()) if p_drop > 0 else 0
+        run.seed_dev = seed_dev             # graph mode: the kernels read the seed from this device word
+        run.seed = int(torch.randint(0, 2 ** 31 - 1, (1,)).item()) if (p_drop > 0 and seed_dev is None) else 0
         g = self._glob
 
         # masks
@@ -654,7 +743,7 @@ class Transformer(Module):
         if first:
             run.vfirst[key] = ast.V
         sid = (ind * 2 + int(text)) * 4
-        Og = ops.attn_fwd(ast, run.kmask, run.p_drop, run.seed, sid)
+        Og = ops.attn_fwd(ast, run.kmask, run.p_drop, run.seed, sid, run.seed_dev)
         y = ops.gemm_nt(Og, self._w(a.out, D, a.I), colscale=gate, rows_per_batch=N)
         self._hc_depth(S, rec, y)
         if exists(tape):
@@ -669,7 +758,7 @@ class Transformer(Module):
             gate = run.gates[:, (ind * 4 + 3) * D:(ind * 4 + 4) * D]
         xn, rn = ops.rmsnorm_fwd(binp, gam, off, rpb)
         Hh = ops.gemm_nt(xn, self._w(f.w1, 2 * f.F, D), bias=self._f(f.b1, 2 * f.F))
-        act = ops.geglu_fwd(Hh, run.p_drop, run.seed, sid + 1)
+        act = ops.geglu_fwd(Hh, run.p_drop, run.seed, sid + 1, run.seed_dev)
         y = ops.gemm_nt(act, self._w(f.w2, D, f.F), bias=self._f(f.b2, D), colscale=gate, rows_per_batch=N)
         self._hc_depth(S, rec, y)
         if exists(tape):
@@ -702,11 +791,30 @@ class Transformer(Module):
     # ------------------------------------------------------------------ backward schedule
 
     def _run_backward(self, run, dout):
+        """eager backward: drive the schedule, hand finished gradient slabs to the data-parallel hook"""
+        gen = self._backward_gen(run, dout)
+        while True:
+            try:
+                start, end = next(gen)
+            except StopIteration as e:
+                dxs, dcond, dtext, gflat = e.value
+                break
+            if exists(self._grad_sync):
+                self._grad_sync(run.gflat, start, end)
+        if exists(self._grad_sync):
+            self._grad_sync(gflat, None, None)          # wait for every slab
+        pgrads = [gflat[off:off + p.numel()].view(p.shape) if p.requires_grad else None for p, off in self._layout.slots]
+        return dxs, dcond, dtext, pgrads
+
+    def _backward_gen(self, run, dout):
+        """generator over the backward schedule: yields (start, end) of the flat-gradient slab that has just become
+        final (one per layer, then the global slab) and returns (dx, dcond, dtext, grad_flat)"""
         B, T, N, Mtok = run.B, run.T, run.N, run.Mtok
         D, Dt, R, L = self.dim, self.dim_text, self.num_registers, self.depth
         dev = run.dev
         lay, g = self._layout, self._glob
         gflat = torch.zeros(lay.n, dtype=f32, device=dev)
+        run.gflat = gflat
         G = lambda off, *shape: self._g(gflat, off, *shape)
 
         # tail
@@ -778,8 +886,7 @@ class Transformer(Module):
                 gx = grads['x'].view(-1, D)
                 grads['x'] = ops.gemm_nt(gsrc, WTs, resid=gx).view(Mtok, 4, D)
             elif kind == 'layer':
-                if exists(self._grad_sync):
-                    self._grad_sync(gflat, ent[1].start, ent[1].end)
+                yield ent[1].start, ent[1].end
             else:
                 raise AssertionError(kind)
 
@@ -809,11 +916,8 @@ class Transformer(Module):
             dcT = torch.zeros((D, KB), dtype=f32, device=dev)
             ops.gemm_tn(self._w(g.wcond, 4 * L * D, D), dct, dcT)                 # (D, B) = W_cond^T . dcond^T
             dcond = dcT[:, :B].t().contiguous()
-        if exists(self._grad_sync):
-            self._grad_sync(gflat, 0, g.end)
-            self._grad_sync(gflat, None, None)          # wait for every slab
-        pgrads = [gflat[off:off + p.numel()].view(p.shape) if p.requires_grad else None for p, off in lay.slots]
-        return dxs, dcond, dtext, pgrads
+        yield 0, g.end
+        return dxs, dcond, dtext, gflat
 
     def _attn_bwd(self, run, ent, G, dvfirst):
         _, rec, lr, ind, text, binp, xn, rn, qkvg, ast, first, y, key, sid = ent
@@ -831,7 +935,7 @@ class Transformer(Module):
             dao = ops.gate_bwd(rec.dy, y, gate, run.dcond[:, (ind * 4 + 1) * D:(ind * 4 + 2) * D], N)
         ops.gemm_tn(dao, ast.Og, G(a.out, D, a.I))
         dOg = ops.gemm_nt(dao, self._wT(a.outT))                                   # (Mtok, I)
-        dQ, dK, dV, dgate = ops.attn_bwd(ast, dOg, run.kmask, run.p_drop, run.seed, sid)
+        dQ, dK, dV, dgate = ops.attn_bwd(ast, dOg, run.kmask, run.p_drop, run.seed, sid, run.seed_dev)
         dqkvg = ops.qkv_post_bwd(ast, dQ, dK, dV, dgate, qkvg, run.rot[0], run.rot[1],
                                  None if first else run.vfirst[key], dvfirst[key], first_layer=first)
         ops.gemm_tn(dqkvg, xn, G(a.w, a.cols, D))
@@ -860,7 +964,7 @@ class Transformer(Module):
         ops.colsum(dao, G(f.b2, D))
         ops.gemm_tn(dao, act, G(f.w2, D, f.F))
         dact = ops.gemm_nt(dao, self._wT(f.w2T))
-        dH = ops.geglu_bwd(dact, Hh, run.p_drop, run.seed, sid)
+        dH = ops.geglu_bwd(dact, Hh, run.p_drop, run.seed, sid, run.seed_dev)
         ops.colsum(dH, G(f.b1, 2 * f.F))
         ops.gemm_tn(dH, xn, G(f.w1, 2 * f.F, D))
         dxn = ops.gemm_nt(dH, self._wT(f.w1T))
@@ -894,3 +998,33 @@ class _BackboneFn(torch.autograd.Function):
         dx, dcond, dtext, pgrads = module._run_backward(run, dout.contiguous())
         return (None, dx.to(ctx.x_dtype), dcond if ctx.has_cond else None,
                 dtext.to(ctx.t_dtype) if ctx.has_text else None, None, *pgrads)
+
+
+class _GraphFn(torch.autograd.Function):
+    """autograd node of the HIP-graph path: copies inputs into the static buffers and replays the captured graphs"""
+
+    @staticmethod
+    def forward(ctx, module, st, x_in, cond, text_embed, mask, *params):
+        module._graph_inputs(st, x_in, cond, text_embed, mask)
+        st.fwd.replay()
+        ctx.module, ctx.st = module, st
+        ctx.has_cond, ctx.has_text = exists(cond), exists(text_embed)
+        ctx.x_dtype = x_in.dtype
+        ctx.t_dtype = text_embed.dtype if exists(text_embed) else None
+        return st.out.clone()
+
+    @staticmethod
+    def backward(ctx, dout):
+        module, st = ctx.module, ctx.st
+        st.dout.copy_(dout)
+        sync = module._grad_sync
+        for gr, slab in st.bwd:
+            gr.replay()
+            if exists(sync) and exists(slab):
+                sync(st.gflat, slab[0], slab[1])
+        if exists(sync):
+            sync(st.gflat, None, None)
+        gflat = st.gflat.clone()          # the static buffer is rewritten by the next replay
+        pgrads = [gflat[off:off + p.numel()].view(p.shape) if p.requires_grad else None for p, off in module._layout.slots]
+        return (None, None, st.dx.to(ctx.x_dtype).clone(), st.dcond.clone() if ctx.has_cond else None,
+                st.dtext.to(ctx.t_dtype).clone() if ctx.has_text else None, None, *pgrads)

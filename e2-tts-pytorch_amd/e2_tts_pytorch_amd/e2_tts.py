@@ -61,10 +61,13 @@ def mask_from_frac_lengths(seq_len, frac_lengths, max_length=None, rand=None):  
         rand = torch.rand_like(frac_lengths)
     start = (max_start * rand).long().clamp(min=0)
     end = start + lengths
-    out = mask_from_start_end_indices(seq_len, start, end)
     if exists(max_length):
-        out = pad_to_length(out, max_length)
-    return out
+        # same mask as mask_from_start_end_indices + pad_to_length (end <= seq_len, so positions past max(seq_len) are
+        # False either way) without the reference's `.item()` device sync (e2_tts.py:189), which would stall the host
+        # once per training step
+        seq = torch.arange(max_length, device=start.device)
+        return (seq[None, :] >= start[:, None]) & (seq[None, :] < end[:, None])
+    return mask_from_start_end_indices(seq_len, start, end)
 
 
 def maybe_masked_mean(t, mask=None):                           # e2_tts.py:212-224
@@ -432,7 +435,10 @@ class E2TTS(Module):
                                                   drop_text_cond=_noise.get('drop_text_cond'),
                                                   return_drop_text_cond=True)
         velocity_loss = self.zero
-        loss = F.mse_loss(pred, flow, reduction='none')
-        loss = loss[rand_span_mask].mean()
+        # mean of the squared error over the masked span == loss[rand_span_mask].mean() (e2_tts.py:1580-1582), written
+        # as a masked sum so that no boolean-index gather (device sync for the element count) is needed
+        sq = F.mse_loss(pred, flow, reduction='none')
+        m = rand_span_mask[..., None].to(sq.dtype)
+        loss = (sq * m).sum() / (m.sum() * sq.shape[-1])
         total_loss = loss + velocity_loss * self.velocity_consistency_weight
         return E2TTSReturn(total_loss, cond, pred, x0 + pred, LossBreakdown(loss, velocity_loss))

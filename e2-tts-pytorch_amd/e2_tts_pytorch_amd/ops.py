@@ -186,21 +186,22 @@ def gate_bwd(dy, y, g, gsum, rows_per_batch):
     return dao
 
 
-def geglu_fwd(H, p_drop=0., seed=0, stream_id=0):
+def geglu_fwd(H, p_drop=0., seed=0, stream_id=0, seed_dev=None):
     _chk(H)
     M, F2 = H.shape
     assert H.dtype == bf16 and H.stride(1) == 1
     out = torch.empty((M, F2 // 2), dtype=bf16, device=H.device)
-    _lib.get().e2k_geglu_fwd(_p(H), H.stride(0), _p(out), M, F2 // 2, float(p_drop), int(seed), int(stream_id), _stream(H))
+    _lib.get().e2k_geglu_fwd(_p(H), H.stride(0), _p(out), M, F2 // 2, float(p_drop), int(seed), _p(seed_dev), int(stream_id),
+                             _stream(H))
     return out
 
 
-def geglu_bwd(dout, H, p_drop=0., seed=0, stream_id=0):
+def geglu_bwd(dout, H, p_drop=0., seed=0, stream_id=0, seed_dev=None):
     _chk(dout, H)
     M, F2 = H.shape
     assert dout.is_contiguous() and dout.shape == (M, F2 // 2)
     dH = torch.empty_like(H)
-    _lib.get().e2k_geglu_bwd(_p(dout), _p(H), H.stride(0), _p(dH), M, F2 // 2, float(p_drop), int(seed),
+    _lib.get().e2k_geglu_bwd(_p(dout), _p(H), H.stride(0), _p(dH), M, F2 // 2, float(p_drop), int(seed), _p(seed_dev),
                              int(stream_id), _stream(H))
     return dH
 
@@ -282,7 +283,7 @@ def qkv_post_fwd(qkvg, B, H, N, cosb, sinb, vfirst=None):
     return st
 
 
-def attn_fwd(st, kmask_pad, p_drop=0., seed=0, stream_id=0):
+def attn_fwd(st, kmask_pad, p_drop=0., seed=0, stream_id=0, seed_dev=None):
     """kmask_pad (B, Npad) uint8.  Fills st.O / st.Og / st.lse2, returns Og (B*N, H*64)."""
     _chk(kmask_pad)
     B, H, N, Npad = st.B, st.H, st.N, st.Npad
@@ -292,11 +293,11 @@ def attn_fwd(st, kmask_pad, p_drop=0., seed=0, stream_id=0):
     st.Og = torch.empty((B * N, H * 64), dtype=bf16, device=dev)
     st.lse2 = torch.empty((B, H, N), dtype=f32, device=dev)
     _lib.get().e2k_attn_fwd(_p(st.Q), _p(st.K), _p(st.VT), _p(kmask_pad), _p(st.gate), _p(st.O), _p(st.Og), _p(st.lse2),
-                            B, H, N, Npad, float(p_drop), int(seed), int(stream_id), _stream(st.Q))
+                            B, H, N, Npad, float(p_drop), int(seed), _p(seed_dev), int(stream_id), _stream(st.Q))
     return st.Og
 
 
-def attn_bwd(st, dOg, kmask_pad, p_drop=0., seed=0, stream_id=0):
+def attn_bwd(st, dOg, kmask_pad, p_drop=0., seed=0, stream_id=0, seed_dev=None):
     """-> dQ, dK, dV (B,H,N,64) bf16, dgate_pre (B,H,N) fp32"""
     _chk(dOg, kmask_pad)
     B, H, N, Npad = st.B, st.H, st.N, st.Npad
@@ -309,7 +310,7 @@ def attn_bwd(st, dOg, kmask_pad, p_drop=0., seed=0, stream_id=0):
     dQ, dK, dV = (torch.empty((B, H, N, 64), dtype=bf16, device=dev) for _ in range(3))
     _lib.get().e2k_attn_bwd(_p(dOg), _p(st.O), _p(st.gate), _p(st.lse2), _p(st.Q), _p(st.K), _p(st.V), _p(st.QT),
                             _p(st.KT), _p(kmask_pad), _p(dO), _p(dOT), _p(delta), _p(dgate), _p(dQ), _p(dK), _p(dV),
-                            B, H, N, Npad, float(p_drop), int(seed), int(stream_id), _stream(dOg))
+                            B, H, N, Npad, float(p_drop), int(seed), _p(seed_dev), int(stream_id), _stream(dOg))
     return dQ, dK, dV, dgate
 
 

@@ -96,11 +96,12 @@ int e2k_gate_bwd(const void* dy, const void* y, const float* g, void* dao, float
 
 /* GEGLU (x_transformers.FeedForward(glu=True): `x, gate = proj(x).chunk(2); x * gelu(gate)` + Dropout, exact erf GELU).
  * H (M, 2F) bf16 with row stride ldh; out (M, F).  p_drop = 0 disables dropout; the keep mask is the counter hash
- * rand_u32(seed, stream_id, row, col/2) (e2k_device.h, restated in oracle/dropout_hash.py). */
+ * rand_u32(seed, stream_id, row, col/2) (e2k_device.h, restated in oracle/dropout_hash.py).  seed_dev (device
+ * pointer, may be NULL) overrides `seed` when set: a captured HIP graph then draws a fresh mask on every replay. */
 int e2k_geglu_fwd(const void* H, int64_t ldh, void* out, int M, int F, float p_drop, uint32_t seed,
-                  uint32_t stream_id, void* stream);
+                  const uint32_t* seed_dev, uint32_t stream_id, void* stream);
 int e2k_geglu_bwd(const void* dout, const void* H, int64_t ldh, void* dH, int M, int F, float p_drop,
-                  uint32_t seed, uint32_t stream_id, void* stream);
+                  uint32_t seed, const uint32_t* seed_dev, uint32_t stream_id, void* stream);
 
 /* out[n] += sum_m x[m][n]   (bias gradients; x bf16 (M,N), out fp32) */
 int e2k_colsum_bf16(const void* x, int64_t ldx, float* out, int M, int N, void* stream);
@@ -137,13 +138,13 @@ int e2k_qkv_post_bwd(const void* dQ, const void* dK, const void* dV, const float
  * O / Og: token-major (B*N, H*64) un-gated / gated by `gate`;  lse2 (B,H,N): log2-domain log-sum-exp. */
 int e2k_attn_fwd(const void* Q, const void* K, const void* VT, const uint8_t* kmask, const float* gate,
                  void* O, void* Og, float* lse2, int B, int H, int N, int Npad, float p_drop,
-                 uint32_t seed, uint32_t stream_id, void* stream);
+                 uint32_t seed, const uint32_t* seed_dev, uint32_t stream_id, void* stream);
 /* backward: dOg (B*N, H*64) -> dQ, dK, dV (B,H,N,64), dgate_pre (B,H,N).  dO, dOT, delta are scratch outputs. */
 int e2k_attn_bwd(const void* dOg, const void* O, const float* gate, const float* lse2, const void* Q,
                  const void* K, const void* V, const void* QT, const void* KT, const uint8_t* kmask,
                  void* dO, void* dOT, float* delta, float* dgate_pre, void* dQ, void* dK, void* dV,
-                 int B, int H, int N, int Npad, float p_drop, uint32_t seed, uint32_t stream_id,
-                 void* stream);
+                 int B, int H, int N, int Npad, float p_drop, uint32_t seed, const uint32_t* seed_dev,
+                 uint32_t stream_id, void* stream);
 
 /* ---- MelSpec (e2_tts.py:248-290 -> torchaudio MelSpectrogram(n_fft=1024, hop, power=1, center, htk, norm=None)) ----
  * wave (B, nw) fp32 -> out (B, n_mels, 1 + nw/hop) fp32 = log(clamp(mel, 1e-5)).  window (n_fft) periodic Hann,

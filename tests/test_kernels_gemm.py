@@ -50,7 +50,8 @@ def test_gemm_nt(dev, M, N, K1, K2, kw):
 
 
 @pytest.mark.parametrize('use_tr', [False, True])
-@pytest.mark.parametrize('M,N,K,splits', [(128, 128, 128, 1), (300, 136, 72, 0), (1000, 392, 264, 3), (8, 256, 128, 1)])
+@pytest.mark.parametrize('M,N,K,splits', [(128, 128, 128, 1), (300, 136, 72, 0), (1000, 392, 264, 3), (8, 256, 128, 1),
+                                          (256, 136, 72, 0), (1024, 392, 264, 3), (192, 8, 520, 1)])
 def test_gemm_tn(dev, M, N, K, splits, use_tr):
     from e2_tts_pytorch_amd import ops
     torch.manual_seed(0)
@@ -66,7 +67,7 @@ def test_gemm_tn_strided(dev):
     """column-sliced operands / outputs as the backbone uses them (cross-condition and skip weight gradients)"""
     from e2_tts_pytorch_amd import ops
     torch.manual_seed(0)
-    M, N, K, ldc = 260, 128, 64, 200
+    M, N, K, ldc = 256, 128, 64, 200
     a = torch.randn(M, N + 8).to(bf16)
     b = torch.randn(M, K + 16).to(bf16)
     C = torch.zeros(N, ldc, device=dev)
