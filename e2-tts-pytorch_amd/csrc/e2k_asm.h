@@ -40,6 +40,57 @@ __device__ __forceinline__ float wave_sum_fast(float v) {
     return __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, v), 63));
 }
 
+// load through the constant address space: with a wave-uniform address this becomes s_load (scalar cache, lgkmcnt),
+// which neither occupies VGPRs nor forces a vmcnt(0) drain of vector loads that are still in flight.  Only for data
+// that no wave of the running kernel writes.
+__device__ __forceinline__ float sload(const float* p) {
+    typedef const __attribute__((address_space(4))) float* cp_t;
+    return *(cp_t)(p);
+}
+
+// same DPP reduction without the broadcast: the wave total is valid in lane 63 only
+__device__ __forceinline__ float wave_sum_last(float v) {
+    v = dpp_add_<0xB1, 0xf>(v);
+    v = dpp_add_<0x4E, 0xf>(v);
+    v = dpp_add_<0x141, 0xf>(v);
+    v = dpp_add_<0x140, 0xf>(v);
+    v = dpp_add_<0x142, 0xa>(v);
+    v = dpp_add_<0x143, 0xc>(v);
+    return v;
+}
+// four wave sums at once, totals valid in lane 63.  Written as v_add_f32 with the DPP modifier on the operand (the
+// builtin form above costs three instructions per step once the compiler packs the adds into v_pk_add_f32: old-value
+// init + v_mov_dpp + half a packed add).  The four chains are interleaved, which also covers the two wait states a DPP
+// read needs after a VALU write of its source; the leading s_nop covers the producer of `a`.
+#define E2K_DPP4_(ctrl)                                        \
+    "v_add_f32_dpp %0, %0, %0 " ctrl "\n"                       \
+    "v_add_f32_dpp %1, %1, %1 " ctrl "\n"                       \
+    "v_add_f32_dpp %2, %2, %2 " ctrl "\n"                       \
+    "v_add_f32_dpp %3, %3, %3 " ctrl "\n"
+__device__ __forceinline__ void wave_sum_last4(float& a, float& b, float& c, float& d) {
+    asm("s_nop 1\n"
+        E2K_DPP4_("quad_perm:[1,0,3,2] row_mask:0xf bank_mask:0xf")
+        E2K_DPP4_("quad_perm:[2,3,0,1] row_mask:0xf bank_mask:0xf")
+        E2K_DPP4_("row_half_mirror row_mask:0xf bank_mask:0xf")
+        E2K_DPP4_("row_mirror row_mask:0xf bank_mask:0xf")
+        E2K_DPP4_("row_bcast:15 row_mask:0xa bank_mask:0xf")
+        E2K_DPP4_("row_bcast:31 row_mask:0xc bank_mask:0xf")
+        : "+v"(a), "+v"(b), "+v"(c), "+v"(d));
+}
+#undef E2K_DPP4_
+// sum over each aligned group of 8 lanes (every lane of the group gets the group sum)
+__device__ __forceinline__ float group8_sum(float v) {
+    v = dpp_add_<0xB1, 0xf>(v);
+    v = dpp_add_<0x4E, 0xf>(v);
+    v = dpp_add_<0x141, 0xf>(v);
+    return v;
+}
+// value of lane L (wave-uniform index) as a wave-uniform scalar (v_readlane_b32 -> SGPR)
+__device__ __forceinline__ float lane_bcast(float v, int L) {
+    return __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, v), L));
+}
+__device__ __forceinline__ float fast_rsq(float x) { return __builtin_amdgcn_rsqf(x); }
+
 // counted wait on outstanding vector-memory ops (LDS-DMA included) and a raw workgroup barrier that does NOT drain
 // them: lets global_load_lds prefetches stay in flight across barriers (cdna_hip_programming.md T3+T4)
 template <int N> __device__ __forceinline__ void wait_vmcnt() { asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory"); }

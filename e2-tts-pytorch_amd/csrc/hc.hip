@@ -22,6 +22,7 @@
 // and 512), so the per-lane state is small enough for 2-3 waves per SIMD; the 24-28 dot products of a token are
 // reduced with DPP row operations inside a wave and through a small LDS exchange across the NW waves.  The
 // backward accumulates d(Wp) in registers over all tokens of a wave and flushes it once.
+#include <type_traits>
 #include "e2k_device.h"
 #include <e2k_asm.h>
 #include "../../include/e2k.h"
@@ -33,42 +34,105 @@ namespace {
 constexpr int S = 4, NJ = 6, CW = 52;
 constexpr int CA = 0, CB = 20, CP = 24, CRN = 48;   // a[s*5+t], b[s], P[s*6+j] (pre-tanh dots), rn[s]
 constexpr int NSC = 32;                               // scalar partials: dA[20], dB[4], dsa, dsb, pad
-constexpr int NRED = 28;
 
 struct HCParams {
     const float* static_beta; const float* static_alpha; const float* dyn_alpha_fn; const float* dyn_alpha_scale;
     const float* dyn_beta_fn; const float* dyn_beta_scale; const float* gamma;
 };
 
-// Wp[j][d] = (gamma[d]+1) * W[d][j]   (j < 5: dynamic_alpha_fn column, j = 5: dynamic_beta_fn)
+// Wp[j][d] = (gamma[d]+1) * W[d][j]   (j < 5: dynamic_alpha_fn column, j = 5: dynamic_beta_fn), fp32 in LDS.
+// A lane that owns 8 consecutive elements (VEC = 8) would read them as two 16-byte LDS accesses 32 bytes apart from
+// its neighbour's (bank conflicts); such rows are stored with the two halves of every 8-element group split into
+// separate 256-float planes, so that each 16-byte access of a wave is contiguous over the lanes.
+template <int VEC> __device__ __forceinline__ int wp_pos(int d) {
+    if (VEC != 8) return d;
+    return (d & ~511) | ((d & 4) << 6) | ((d & 504) >> 1) | (d & 3);
+}
+template <int VEC>
 __device__ __forceinline__ void stage_wp(float* Wp, const HCParams& hp, int D, int tid) {
     for (int d = tid; d < D; d += 256) {
         float g = hp.gamma[d] + 1.f;
+        const int q = wp_pos<VEC>(d);
 #pragma unroll
-        for (int t = 0; t < 5; ++t) Wp[t * D + d] = g * hp.dyn_alpha_fn[d * 5 + t];
-        Wp[5 * D + d] = g * hp.dyn_beta_fn[d];
+        for (int t = 0; t < 5; ++t) Wp[t * D + q] = g * hp.dyn_alpha_fn[d * 5 + t];
+        Wp[5 * D + q] = g * hp.dyn_beta_fn[d];
+    }
+}
+// the lane's elements of one Wp row (same element order as load_row<VEC, NCH>)
+template <int VEC, int NCH> __device__ __forceinline__ void load_wp(const float* row, int lane, float* f) {
+    if (VEC == 8) {
+#pragma unroll
+        for (int c = 0; c < NCH; ++c)
+#pragma unroll
+            for (int h = 0; h < 2; ++h) {
+                f32x4 v = *reinterpret_cast<const f32x4*>(row + c * 512 + h * 256 + lane * 4);
+                f[c * 8 + h * 4] = v[0]; f[c * 8 + h * 4 + 1] = v[1]; f[c * 8 + h * 4 + 2] = v[2]; f[c * 8 + h * 4 + 3] = v[3];
+            }
+    } else {
+        load_row_f32<VEC, NCH>(row, lane, f);
     }
 }
 
-// sum `vals[0..N)` over the NW waves that share a token: wave-level DPP sums, then LDS exchange (one barrier)
+// packed (raw bf16 pairs) row loads: the next token's rows are fetched into these while the current token is being
+// processed, half the registers of the unpacked floats
+template <int VEC, int NCH> __device__ __forceinline__ void load_raw(const bf16_t* row, int lane, unsigned* w) {
+#pragma unroll
+    for (int c = 0; c < NCH; ++c) {
+        const bf16_t* q = row + c * 64 * VEC + lane * VEC;
+        if (VEC == 8) { u32x4 v = ld<u32x4>(q); w[c * 4] = v[0]; w[c * 4 + 1] = v[1]; w[c * 4 + 2] = v[2]; w[c * 4 + 3] = v[3]; }
+        else if (VEC == 4) { u32x2 v = ld<u32x2>(q); w[c * 2] = v[0]; w[c * 2 + 1] = v[1]; }
+        else w[c] = ld<unsigned>(q);
+    }
+}
+template <int N> __device__ __forceinline__ void unpack_raw(const unsigned* w, float* f) {
+#pragma unroll
+    for (int i = 0; i < N / 2; ++i) { f[2 * i] = bflo(w[i]); f[2 * i + 1] = bfhi(w[i]); }
+}
+// dot product of two per-lane rows with packed fp32 FMAs (v_pk_fma_f32)
+typedef float f32x2_ __attribute__((ext_vector_type(2)));
+template <int N> __device__ __forceinline__ float dot_pk(const float* a, const float* b) {
+    f32x2_ acc = {0.f, 0.f};
+#pragma unroll
+    for (int i = 0; i < N; i += 2) {
+        f32x2_ x = {a[i], a[i + 1]}, y = {b[i], b[i + 1]};
+        acc = __builtin_elementwise_fma(x, y, acc);
+    }
+    return acc[0] + acc[1];
+}
+// tanh on the hardware exp2 / rcp units
+__device__ __forceinline__ float tanh_fast(float x) {
+    const float e = fast_exp2(-2.885390081777927f * fabsf(x));
+    const float t = (1.0f - e) * fast_rcp(1.0f + e);
+    return x < 0.f ? -t : t;
+}
+
+constexpr int NRED = 32;                             // LDS exchange row (28 forward / 24 backward values used)
+
+// Reduce N per-lane partials over the NW waves that share a token, leaving the totals spread over LANES instead of
+// broadcast: DPP sums bring each wave total to lane 63, lane 63 stores the N totals to LDS, and after one barrier
+// lane l (< 32) picks up the total with index `pick` (summed over the NW waves).  The per-token scalar math that
+// follows then runs once per lane-slot instead of N times on wave-uniform values.
 template <int N, int NW>
-__device__ __forceinline__ void token_sum(float* vals, float (*red)[4][NRED], int parity, int wave, int lane) {
+__device__ __forceinline__ void token_scatter(float* vals, float (*red)[4][NRED], int parity, int wave, int lane) {
+    static_assert(N % 4 == 0, "");
 #pragma unroll
-    for (int i = 0; i < N; ++i) vals[i] = wave_sum_fast(vals[i]);
-    if (NW == 1) return;
-    if (lane == 0) {
+    for (int i = 0; i < N; i += 4) wave_sum_last4(vals[i], vals[i + 1], vals[i + 2], vals[i + 3]);
+    if (lane == 63) {
 #pragma unroll
-        for (int i = 0; i < N; ++i) red[parity][wave][i] = vals[i];
+        for (int i = 0; i < N; i += 4) {
+            f32x4 v = {vals[i], vals[i + 1], vals[i + 2], vals[i + 3]};
+            *reinterpret_cast<f32x4*>(&red[parity][wave][i]) = v;
+        }
     }
     __syncthreads();
+}
+template <int NW>
+__device__ __forceinline__ float token_pick(float (*red)[4][NRED], int parity, int wave, int pick) {
     const int w0 = (wave / NW) * NW;
+    float s = red[parity][w0][pick];
 #pragma unroll
-    for (int i = 0; i < N; ++i) {
-        float s = red[parity][w0][i];
-#pragma unroll
-        for (int w = 1; w < NW; ++w) s += red[parity][w0 + w][i];
-        vals[i] = uniform_f(s);
-    }
+    for (int w = 1; w < NW; ++w) s += red[parity][w0 + w][pick];
+    return s;
 }
 
 struct HCFwdArgs {
@@ -82,73 +146,90 @@ template <int VEC, int NCH, int NW, bool DEPTH, bool WIDTH>
 __global__ __launch_bounds__(256) void hc_fwd_kernel(HCFwdArgs p) {
     constexpr int EPL = VEC * NCH, DS = 64 * EPL, D = DS * NW, TPB = 4 / NW;
     __shared__ __attribute__((aligned(16))) float Wp[WIDTH ? NJ * D : 4];
-    __shared__ float red[2][4][NRED];
+    __shared__ __attribute__((aligned(16))) float red[2][4][NRED];
     const int tid = threadIdx.x, lane = tid & 63, wave = uniform_i(tid >> 6);
     const int slot = wave / NW, doff = (wave % NW) * DS;
-    float sa = 0.f, sb = 0.f, A[20], B[4];
+    // lane slot (ls, lj) = (stream, column) of the per-token scalar math: lj < 5 alpha column, 5 beta, 6 sum of squares
+    const int ls = (lane >> 3) & 3, lj = lane & 7;
+    float scale_l = 0.f, stat_l = 0.f;
     if (WIDTH) {
-        stage_wp(Wp, p.hp, D, tid);
-        sa = p.hp.dyn_alpha_scale[0];
-        sb = p.hp.dyn_beta_scale[0];
-#pragma unroll
-        for (int i = 0; i < 20; ++i) A[i] = p.hp.static_alpha[i];
-#pragma unroll
-        for (int i = 0; i < 4; ++i) B[i] = p.hp.static_beta[i];
+        stage_wp<VEC>(Wp, p.hp, D, tid);
+        if (lane < 32 && lj < 5) { scale_l = p.hp.dyn_alpha_scale[0]; stat_l = p.hp.static_alpha[ls * 5 + lj]; }
+        if (lane < 32 && lj == 5) { scale_l = p.hp.dyn_beta_scale[0]; stat_l = p.hp.static_beta[ls]; }
         __syncthreads();
     }
     const float sqrtD = sqrtf((float)D);
     const int per_iter = gridDim.x * TPB;
     const int niter = (p.Mtok + per_iter - 1) / per_iter;
-    for (int it = 0; it < niter; ++it) {
+    unsigned rawX[S][EPL / 2], rawY[EPL / 2];
+    float bpn[S];
+    auto prefetch = [&](int it) {
+        const int tr = (it * gridDim.x + blockIdx.x) * TPB + slot;
+        const long tk = tr < p.Mtok ? tr : p.Mtok - 1;
+#pragma unroll
+        for (int s = 0; s < S; ++s) load_raw<VEC, NCH>(p.Xin + (tk * S + s) * D + doff, lane, rawX[s]);
+        if (DEPTH) {
+            load_raw<VEC, NCH>(p.yprev + tk * D + doff, lane, rawY);
+#pragma unroll
+            for (int s = 0; s < S; ++s) bpn[s] = p.coef_prev[tk * CW + CB + s];
+        }
+    };
+    prefetch(0);
+    // all-valid iterations run without any validity branch (lets the compiler count outstanding stores instead of
+    // draining them before it may touch the prefetched rows); at most one trailing iteration is checked
+    auto body = [&](int it, auto checked) {
+        constexpr bool CHECK = decltype(checked)::value;
         const int tok_raw = (it * gridDim.x + blockIdx.x) * TPB + slot;
-        const bool valid = tok_raw < p.Mtok;
+        const bool valid = !CHECK || tok_raw < p.Mtok;
         const long tok = valid ? tok_raw : p.Mtok - 1;
         float r[S][EPL];
 #pragma unroll
-        for (int s = 0; s < S; ++s) load_row<VEC, NCH>(p.Xin + (tok * S + s) * D + doff, lane, r[s]);
+        for (int s = 0; s < S; ++s) unpack_raw<EPL>(rawX[s], r[s]);
         if (DEPTH) {
             float y[EPL];
-            load_row<VEC, NCH>(p.yprev + tok * D + doff, lane, y);
+            unpack_raw<EPL>(rawY, y);
 #pragma unroll
             for (int s = 0; s < S; ++s) {
-                const float bp = p.coef_prev[tok * CW + CB + s];
 #pragma unroll
-                for (int e = 0; e < EPL; ++e) r[s][e] = fmaf(bp, y[e], r[s][e]);
+                for (int e = 0; e < EPL; ++e) r[s][e] = fmaf(bpn[s], y[e], r[s][e]);
             }
         }
+        if (!CHECK) prefetch(it + 1);       // (clamped to the last token past the end)
         if (!WIDTH) {
             if (valid) {
 #pragma unroll
                 for (int s = 0; s < S; ++s) store_row<VEC, NCH>(p.Mout + (tok * S + s) * D + doff, lane, r[s]);
             }
-            continue;
+            return;
         }
-        float part[NRED];       // [s*7 + j], j = 6: sum of squares
-#pragma unroll
-        for (int i = 0; i < NRED; ++i) part[i] = 0.f;
+        float part[28];       // [s*7 + j], j = 6: sum of squares
 #pragma unroll
         for (int j = 0; j < NJ; ++j) {
             float w[EPL];
-            load_row_f32<VEC, NCH>(Wp + j * D + doff, lane, w);
+            load_wp<VEC, NCH>(Wp + j * D + doff, lane, w);
 #pragma unroll
-            for (int s = 0; s < S; ++s)
-#pragma unroll
-                for (int e = 0; e < EPL; ++e) part[s * 7 + j] = fmaf(r[s][e], w[e], part[s * 7 + j]);
+            for (int s = 0; s < S; ++s) part[s * 7 + j] = dot_pk<EPL>(r[s], w);
         }
+#pragma unroll
+        for (int s = 0; s < S; ++s) part[s * 7 + 6] = dot_pk<EPL>(r[s], r[s]);
+        token_scatter<28, NW>(part, red, it & 1, wave, lane);
+        // lane-parallel coefficients: lane (ls, lj) owns a[ls][lj] (lj < 5) / b[ls] (lj == 5)
+        const float dotl = token_pick<NW>(red, it & 1, wave, ls * 7 + (lj < 7 ? lj : 6));
+        const float ssl = token_pick<NW>(red, it & 1, wave, ls * 7 + 6);
+        const float rnl = fast_rsq(fmaxf(ssl, 1e-24f));
+        const float Pl = dotl * rnl * sqrtD;
+        const float coefl = fmaf(tanh_fast(Pl), scale_l, stat_l);
+        float a[S][5];
 #pragma unroll
         for (int s = 0; s < S; ++s)
 #pragma unroll
-            for (int e = 0; e < EPL; ++e) part[s * 7 + 6] = fmaf(r[s][e], r[s][e], part[s * 7 + 6]);
-        token_sum<NRED, NW>(part, red, it & 1, wave, lane);
-        float a[S][5], b[S], P[S][NJ], rn[S];
-#pragma unroll
-        for (int s = 0; s < S; ++s) {
-            rn[s] = 1.f / fmaxf(sqrtf(part[s * 7 + 6]), 1e-12f);
-#pragma unroll
-            for (int j = 0; j < NJ; ++j) P[s][j] = part[s * 7 + j] * rn[s] * sqrtD;
-#pragma unroll
-            for (int t = 0; t < 5; ++t) a[s][t] = tanhf_(P[s][t]) * sa + A[s * 5 + t];
-            b[s] = tanhf_(P[s][5]) * sb + B[s];
+            for (int t = 0; t < 5; ++t) a[s][t] = lane_bcast(coefl, s * 8 + t);
+        if (valid && doff == 0 && lane < 32) {
+            float* c = p.coef + tok * CW;
+            if (lj < 5) c[CA + ls * 5 + lj] = coefl;
+            if (lj == 5) c[CB + ls] = coefl;
+            if (lj < 6) c[CP + ls * NJ + lj] = Pl;
+            if (lj == 6) c[CRN + ls] = rnl;
         }
         if (valid) {
 #pragma unroll
@@ -164,20 +245,11 @@ __global__ __launch_bounds__(256) void hc_fwd_kernel(HCFwdArgs p) {
                 if (t == 0) store_row<VEC, NCH>(p.bin + tok * D + doff, lane, m);
                 else store_row<VEC, NCH>(p.Mout + (tok * S + (t - 1)) * D + doff, lane, m);
             }
-            if (lane == 0 && doff == 0) {
-                float* c = p.coef + tok * CW;
-#pragma unroll
-                for (int s = 0; s < S; ++s) {
-#pragma unroll
-                    for (int t = 0; t < 5; ++t) c[CA + s * 5 + t] = a[s][t];
-                    c[CB + s] = b[s];
-#pragma unroll
-                    for (int j = 0; j < NJ; ++j) c[CP + s * NJ + j] = P[s][j];
-                    c[CRN + s] = rn[s];
-                }
-            }
         }
-    }
+    };
+    const int nfull = p.Mtok / per_iter;
+    for (int it = 0; it < nfull; ++it) body(it, std::false_type{});
+    if (nfull < niter) body(nfull, std::true_type{});
 }
 
 struct HCBwdArgs {
@@ -190,19 +262,22 @@ struct HCBwdArgs {
 };
 
 template <int VEC, int NCH, int NW, bool DEPTH, bool WIDTH>
-__global__ __launch_bounds__(256) void hc_bwd_kernel(HCBwdArgs p) {
+__global__ __launch_bounds__(256, 3) void hc_bwd_kernel(HCBwdArgs p) {
     constexpr int EPL = VEC * NCH, DS = 64 * EPL, D = DS * NW, TPB = 4 / NW;
     __shared__ __attribute__((aligned(16))) float Wp[WIDTH ? NJ * D : 4];
     __shared__ __attribute__((aligned(16))) float dWp[WIDTH ? NJ * D + NSC : 4];
-    __shared__ float red[2][4][NRED];
+    __shared__ __attribute__((aligned(16))) float red[2][4][NRED];
     const int tid = threadIdx.x, lane = tid & 63, wave = uniform_i(tid >> 6);
     const int slot = wave / NW, doff = (wave % NW) * DS;
-    float sa = 0.f, sb = 0.f;
+    // lane slot (ls, lj) of the per-token scalar math: pair (stream ls, column lj); lj < 5 alpha, 5 beta
+    const int ls = (lane >> 3) & 3, lj = lane & 7;
+    const bool lact = lane < 32 && lj < 6;
+    float scale_l = 0.f;
+    float accD = 0.f, accT = 0.f;        // per-lane sums over this wave's tokens: d(static), d(scale) contributions
     if (WIDTH) {
-        stage_wp(Wp, p.hp, D, tid);
+        stage_wp<VEC>(Wp, p.hp, D, tid);
         for (int i = tid; i < NJ * D + NSC; i += 256) dWp[i] = 0.f;
-        sa = p.hp.dyn_alpha_scale[0];
-        sb = p.hp.dyn_beta_scale[0];
+        if (lact) scale_l = lj < 5 ? p.hp.dyn_alpha_scale[0] : p.hp.dyn_beta_scale[0];
         __syncthreads();
     }
     const float sqrtD = sqrtf((float)D);
@@ -214,15 +289,40 @@ __global__ __launch_bounds__(256) void hc_bwd_kernel(HCBwdArgs p) {
 
     const int per_iter = gridDim.x * TPB;
     const int niter = (p.Mtok + per_iter - 1) / per_iter;
-    for (int it = 0; it < niter; ++it) {
+    // next-token rows, packed: G[4], and with WIDTH also Xin[4], yprev, dbin, ycur
+    unsigned rawG[S][EPL / 2], rawX[WIDTH ? S : 1][EPL / 2], rawY[EPL / 2], rawB[EPL / 2], rawC[EPL / 2];
+    float bpn[S], Pln = 0.f;
+    auto prefetch = [&](int it) {
+        const int tr = (it * gridDim.x + blockIdx.x) * TPB + slot;
+        const long tk = tr < p.Mtok ? tr : p.Mtok - 1;
+        if (WIDTH) {
+            if (lact) Pln = p.coef[tk * CW + CP + ls * NJ + lj];     // this lane's pre-tanh dot (used after the reduction)
+#pragma unroll
+            for (int s = 0; s < S; ++s) load_raw<VEC, NCH>(p.Xin + (tk * S + s) * D + doff, lane, rawX[s]);
+            if (DEPTH) load_raw<VEC, NCH>(p.yprev + tk * D + doff, lane, rawY);
+            load_raw<VEC, NCH>(p.dbin + tk * D + doff, lane, rawB);
+            load_raw<VEC, NCH>(p.ycur + tk * D + doff, lane, rawC);
+        }
+#pragma unroll
+        for (int s = 0; s < S; ++s) load_raw<VEC, NCH>(p.G + (tk * S + s) * D + doff, lane, rawG[s]);
+        if (DEPTH) {
+#pragma unroll
+            for (int s = 0; s < S; ++s) bpn[s] = p.coef_prev[tk * CW + CB + s];
+        }
+    };
+    prefetch(0);
+    // all-valid iterations run without any validity branch (lets the compiler count outstanding stores instead of
+    // draining them before it may touch the prefetched rows); at most one trailing iteration is checked
+    auto body = [&](int it, auto checked) {
+        constexpr bool CHECK = decltype(checked)::value;
         const int tok_raw = (it * gridDim.x + blockIdx.x) * TPB + slot;
-        const bool valid = tok_raw < p.Mtok;
+        const bool valid = !CHECK || tok_raw < p.Mtok;
         const long tok = valid ? tok_raw : p.Mtok - 1;
         const float vf = valid ? 1.f : 0.f;
         float bp[S];
         if (DEPTH) {
 #pragma unroll
-            for (int s = 0; s < S; ++s) bp[s] = p.coef_prev[tok * CW + CB + s];
+            for (int s = 0; s < S; ++s) bp[s] = bpn[s];
         }
         if (!WIDTH) {
             // only the depth connection of the previous instance: dy_prev = sum_s b_prev[s] * dX[s]
@@ -232,118 +332,109 @@ __global__ __launch_bounds__(256) void hc_bwd_kernel(HCBwdArgs p) {
 #pragma unroll
             for (int s = 0; s < S; ++s) {
                 float g[EPL];
-                load_row<VEC, NCH>(p.G + (tok * S + s) * D + doff, lane, g);
+                unpack_raw<EPL>(rawG[s], g);
 #pragma unroll
                 for (int e = 0; e < EPL; ++e) dy[e] = fmaf(bp[s], g[e], dy[e]);
             }
+            if (!CHECK) prefetch(it + 1);       // (clamped to the last token past the end)
             if (valid) store_row<VEC, NCH>(p.dyprev + tok * D + doff, lane, dy);
-            continue;
+            return;
         }
         float r[S][EPL], dm[5][EPL], yc[EPL];
 #pragma unroll
-        for (int s = 0; s < S; ++s) load_row<VEC, NCH>(p.Xin + (tok * S + s) * D + doff, lane, r[s]);
+        for (int s = 0; s < S; ++s) unpack_raw<EPL>(rawX[s], r[s]);
         if (DEPTH) {
             float y[EPL];
-            load_row<VEC, NCH>(p.yprev + tok * D + doff, lane, y);
+            unpack_raw<EPL>(rawY, y);
 #pragma unroll
             for (int s = 0; s < S; ++s)
 #pragma unroll
                 for (int e = 0; e < EPL; ++e) r[s][e] = fmaf(bp[s], y[e], r[s][e]);
         }
-        load_row<VEC, NCH>(p.dbin + tok * D + doff, lane, dm[0]);
+        unpack_raw<EPL>(rawB, dm[0]);
 #pragma unroll
-        for (int s = 0; s < S; ++s) load_row<VEC, NCH>(p.G + (tok * S + s) * D + doff, lane, dm[s + 1]);
-        load_row<VEC, NCH>(p.ycur + tok * D + doff, lane, yc);
-
-        // 24 dots: da[s][t] = dm_t . r_s (index s*6 + t) ; db[s] = G_s . y_cur (index s*6 + 5)
-        float dots[24];
-#pragma unroll
-        for (int s = 0; s < S; ++s) {
-#pragma unroll
-            for (int t = 0; t < 5; ++t) {
-                float v = 0.f;
-#pragma unroll
-                for (int e = 0; e < EPL; ++e) v = fmaf(dm[t][e], r[s][e], v);
-                dots[s * 6 + t] = v;
-            }
-            float v = 0.f;
-#pragma unroll
-            for (int e = 0; e < EPL; ++e) v = fmaf(dm[s + 1][e], yc[e], v);
-            dots[s * 6 + 5] = v;
-        }
-        token_sum<24, NW>(dots, red, it & 1, wave, lane);
+        for (int s = 0; s < S; ++s) unpack_raw<EPL>(rawG[s], dm[s + 1]);
+        unpack_raw<EPL>(rawC, yc);
+        const float Pl = Pln;
+        if (!CHECK) prefetch(it + 1);       // (clamped to the last token past the end)
 
         const float* cf = p.coef + tok * CW;
-        float a[S][5], c[S][NJ], rn[S], uq[S];
-        const bool sc_lane = valid && doff == 0 && lane == 0;      // scalar partials: one lane per token
-        float dsa = 0.f, dsb = 0.f;
+        // 24 dots: da[s][t] = dm_t . r_s (index s*6 + t) ; db[s] = G_s . y_cur (index s*6 + 5); reduced and handed
+        // to LDS four at a time so that few of them are live at once
+#pragma unroll
+        for (int g = 0; g < 6; ++g) {
+            float d4[4];
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                const int idx = g * 4 + q, s = idx / 6, t = idx % 6;
+                d4[q] = t < 5 ? dot_pk<EPL>(dm[t], r[s]) : dot_pk<EPL>(dm[s + 1], yc);
+            }
+            wave_sum_last4(d4[0], d4[1], d4[2], d4[3]);
+            if (lane == 63) {
+                f32x4 v = {d4[0], d4[1], d4[2], d4[3]};
+                *reinterpret_cast<f32x4*>(&red[it & 1][wave][g * 4]) = v;
+            }
+        }
+        __syncthreads();
+        // lane-parallel: lane (ls, lj) turns its dot into c = d(pre-tanh dot); group-of-8 sums give uq[ls]
+        const float dotl = lact ? token_pick<NW>(red, it & 1, wave, ls * 6 + (lj < 6 ? lj : 0)) * vf : 0.f;
+        const float th = tanh_fast(Pl);
+        const float cl = dotl * scale_l * (1.f - th * th);
+        accD += dotl;
+        accT = fmaf(dotl, th, accT);
+        const float uql = group8_sum(cl * Pl);
+        const float cql = cl * sqrtD;
+        float a[S][5], cq[S][NJ], rn[S], uq[S];
 #pragma unroll
         for (int s = 0; s < S; ++s) {
-            rn[s] = cf[CRN + s];
-            float acc_uq = 0.f;
+            rn[s] = sload(cf + CRN + s);
+            uq[s] = lane_bcast(uql, s * 8);
 #pragma unroll
-            for (int t = 0; t < 5; ++t) {
-                a[s][t] = cf[CA + s * 5 + t];
-                const float P = cf[CP + s * NJ + t];
-                const float th = tanhf_(P);
-                const float da = dots[s * 6 + t];
-                c[s][t] = da * sa * (1.f - th * th);
-                acc_uq = fmaf(c[s][t], P, acc_uq);
-                if (sc_lane) atomicAdd(&dWp[NJ * D + s * 5 + t], da);
-                dsa = fmaf(da, th, dsa);
-            }
-            const float P = cf[CP + s * NJ + 5];
-            const float th = tanhf_(P);
-            const float db = dots[s * 6 + 5];
-            c[s][5] = db * sb * (1.f - th * th);
-            acc_uq = fmaf(c[s][5], P, acc_uq);
-            if (sc_lane) atomicAdd(&dWp[NJ * D + 20 + s], db);
-            dsb = fmaf(db, th, dsb);
-            uq[s] = acc_uq;
+            for (int t = 0; t < 5; ++t) a[s][t] = sload(cf + CA + s * 5 + t);
+#pragma unroll
+            for (int j = 0; j < NJ; ++j) cq[s][j] = lane_bcast(cql, s * 8 + j);
         }
-        if (sc_lane) { atomicAdd(&dWp[NJ * D + 24], dsa); atomicAdd(&dWp[NJ * D + 25], dsb); }
-        // q[s][e] = sqrtD * sum_j c[s][j] Wp[j][d] ; gw[j][e] += sum_s c[s][j] rn[s] sqrtD r[s][e]
+        // u = r * rn (in place) ; q[s][e] = sum_j cq[s][j] Wp[j][d] ; gw[j][e] += sum_s cq[s][j] u[s][e]
+        // dr[s] = sum_t a[s][t] dm_t + rn[s] (q[s] - u[s] uq[s]).  Each Wp row is read from LDS once per token.
+        float qs[S][EPL];
+#pragma unroll
+        for (int s = 0; s < S; ++s)
+#pragma unroll
+            for (int e = 0; e < EPL; ++e) { r[s][e] *= rn[s]; qs[s][e] = 0.f; }
 #pragma unroll
         for (int j = 0; j < NJ; ++j) {
+            float w[EPL];
+            load_wp<VEC, NCH>(Wp + j * D + doff, lane, w);
 #pragma unroll
-            for (int s = 0; s < S; ++s) {
-                const float cs = c[s][j] * sqrtD * rn[s] * vf;
+            for (int s = 0; s < S; ++s)
 #pragma unroll
-                for (int e = 0; e < EPL; ++e) gw[j][e] = fmaf(cs, r[s][e], gw[j][e]);
-            }
+                for (int e = 0; e < EPL; ++e) {
+                    qs[s][e] = fmaf(cq[s][j], w[e], qs[s][e]);
+                    gw[j][e] = fmaf(cq[s][j], r[s][e], gw[j][e]);
+                }
         }
         float dyp[EPL];
 #pragma unroll
         for (int e = 0; e < EPL; ++e) dyp[e] = 0.f;
 #pragma unroll
         for (int s = 0; s < S; ++s) {
-            // (Wp rows are re-read from LDS per stream: keeps the live register set small -> more waves per SIMD)
-            float qs[EPL];
-#pragma unroll
-            for (int e = 0; e < EPL; ++e) qs[e] = 0.f;
-#pragma unroll
-            for (int j = 0; j < NJ; ++j) {
-                float w[EPL];
-                load_row_f32<VEC, NCH>(Wp + j * D + doff, lane, w);
-                const float cq = c[s][j] * sqrtD;
-#pragma unroll
-                for (int e = 0; e < EPL; ++e) qs[e] = fmaf(cq, w[e], qs[e]);
-            }
             float dr[EPL];
 #pragma unroll
             for (int e = 0; e < EPL; ++e) {
                 float v = a[s][0] * dm[0][e];
 #pragma unroll
                 for (int t = 1; t < 5; ++t) v = fmaf(a[s][t], dm[t][e], v);
-                float u = r[s][e] * rn[s];
-                v = fmaf(rn[s], qs[e] - u * uq[s], v);
+                v = fmaf(rn[s], qs[s][e] - r[s][e] * uq[s], v);
                 dr[e] = v;
                 if (DEPTH) dyp[e] = fmaf(bp[s], v, dyp[e]);
             }
             if (valid) store_row<VEC, NCH>(p.dR + (tok * S + s) * D + doff, lane, dr);
         }
         if (DEPTH && valid) store_row<VEC, NCH>(p.dyprev + tok * D + doff, lane, dyp);
-    }
+    };
+    const int nfull = p.Mtok / per_iter;
+    for (int it = 0; it < nfull; ++it) body(it, std::false_type{});
+    if (nfull < niter) body(nfull, std::true_type{});
     if (WIDTH) {
         // flush the register accumulators (once per wave): LDS adds, then one row of `partial` per workgroup
 #pragma unroll
@@ -353,6 +444,10 @@ __global__ __launch_bounds__(256) void hc_bwd_kernel(HCBwdArgs p) {
 #pragma unroll
                 for (int v = 0; v < VEC; ++v)
                     atomicAdd(&dWp[j * D + doff + ch * 64 * VEC + lane * VEC + v], gw[j][ch * VEC + v]);
+        if (doff == 0 && lact) {     // scalar gradients: d(static_alpha/beta) = sum of dots, d(scale) = sum of dot * tanh
+            atomicAdd(&dWp[NJ * D + (lj < 5 ? ls * 5 + lj : 20 + ls)], accD);
+            atomicAdd(&dWp[NJ * D + (lj < 5 ? 24 : 25)], accT);
+        }
         __syncthreads();
         float* out = p.partial + (long)blockIdx.x * (NJ * D + NSC);
         for (int i = tid; i < NJ * D + NSC; i += 256) out[i] = dWp[i];
@@ -366,19 +461,22 @@ struct HCReduceArgs {
     float *g_static_beta, *g_static_alpha, *g_dyn_alpha_fn, *g_dyn_alpha_scale, *g_dyn_beta_fn, *g_dyn_beta_scale, *g_gamma;
 };
 
-// grid = D/32 + 1 workgroups.  Workgroup b < D/32: 32 columns d x 8 row-groups, each thread sums nblocks/8 partial
-// rows (coalesced over d), LDS tree over the row-groups.  Last workgroup: the 26 scalar gradients.
+// grid = (D/32 + 1, RSPLIT).  Workgroup (x < D/32, y): 32 columns d x 8 row-groups over the partial rows
+// b = y*8 + part (mod 8*RSPLIT), coalesced over d, LDS tree over the row-groups, then one atomic add per gradient
+// element (RSPLIT adds per address).  x = D/32: the 26 scalar gradients.
+constexpr int RSPLIT = 8;
 __global__ __launch_bounds__(256) void hc_reduce_kernel(HCReduceArgs p) {
     __shared__ float red[8][NJ][32];
     const int D = p.D, stride = NJ * D + NSC;
     const int tid = threadIdx.x;
+    const int part = tid >> 5, row0 = blockIdx.y * 8 + part;
     if ((int)blockIdx.x < D / 32) {
-        const int dl = tid & 31, part = tid >> 5;
+        const int dl = tid & 31;
         const int d = blockIdx.x * 32 + dl;
         float acc[NJ];
 #pragma unroll
         for (int j = 0; j < NJ; ++j) acc[j] = 0.f;
-        for (int b = part; b < p.nblocks; b += 8) {
+        for (int b = row0; b < p.nblocks; b += 8 * RSPLIT) {
 #pragma unroll
             for (int j = 0; j < NJ; ++j) acc[j] += p.partial[(long)b * stride + j * D + d];
         }
@@ -397,29 +495,29 @@ __global__ __launch_bounds__(256) void hc_reduce_kernel(HCReduceArgs p) {
             float dg = 0.f;
 #pragma unroll
             for (int t = 0; t < 5; ++t) {
-                p.g_dyn_alpha_fn[d * 5 + t] += g * acc[t];
+                atomicAdd(&p.g_dyn_alpha_fn[d * 5 + t], g * acc[t]);
                 dg = fmaf(p.hp.dyn_alpha_fn[d * 5 + t], acc[t], dg);
             }
-            p.g_dyn_beta_fn[d] += g * acc[5];
+            atomicAdd(&p.g_dyn_beta_fn[d], g * acc[5]);
             dg = fmaf(p.hp.dyn_beta_fn[d], acc[5], dg);
-            p.g_gamma[d] += dg;
+            atomicAdd(&p.g_gamma[d], dg);
         }
     } else {
         // 26 scalars x 8 row-groups (208 threads)
-        const int k = tid & 31, part = tid >> 5;
+        const int k = tid & 31;
         float acc = 0.f;
         if (k < 26)
-            for (int b = part; b < p.nblocks; b += 8) acc += p.partial[(long)b * stride + NJ * D + k];
+            for (int b = row0; b < p.nblocks; b += 8 * RSPLIT) acc += p.partial[(long)b * stride + NJ * D + k];
         red[part][0][k] = acc;
         __syncthreads();
         if (part == 0 && k < 26) {
             float s = 0.f;
 #pragma unroll
             for (int q = 0; q < 8; ++q) s += red[q][0][k];
-            if (k < 20) p.g_static_alpha[k] += s;
-            else if (k < 24) p.g_static_beta[k - 20] += s;
-            else if (k == 24) p.g_dyn_alpha_scale[0] += s;
-            else p.g_dyn_beta_scale[0] += s;
+            if (k < 20) atomicAdd(&p.g_static_alpha[k], s);
+            else if (k < 24) atomicAdd(&p.g_static_beta[k - 20], s);
+            else if (k == 24) atomicAdd(&p.g_dyn_alpha_scale[0], s);
+            else atomicAdd(&p.g_dyn_beta_scale[0], s);
         }
     }
 }
@@ -448,7 +546,7 @@ int launch_bwd(const HCBwdArgs& a, bool depth, bool width, int grid, hipStream_t
     switch (D) {                                                      \
         case 128: rc = FN<2, 1, 1>(__VA_ARGS__); break;               \
         case 256: rc = FN<4, 1, 1>(__VA_ARGS__); break;               \
-        case 512: rc = FN<8, 1, 1>(__VA_ARGS__); break;               \
+        case 512: rc = FN<4, 1, 2>(__VA_ARGS__); break;               \
         case 768: rc = FN<4, 3, 1>(__VA_ARGS__); break;               \
         case 1024: rc = FN<8, 1, 2>(__VA_ARGS__); break;              \
         case 1536: rc = FN<4, 3, 2>(__VA_ARGS__); break;              \
@@ -471,7 +569,7 @@ int launch_bwd(const HCBwdArgs& a, bool depth, bool width, int grid, hipStream_t
 
 int tokens_per_block(int D, bool bwd) {
     if (bwd) return D == 1024 || D == 2048 ? 1 : (D == 512 || D == 1536 ? 2 : 4);
-    return D == 1024 || D == 1536 ? 2 : (D == 2048 ? 1 : 4);
+    return D == 512 || D == 1024 || D == 1536 ? 2 : (D == 2048 ? 1 : 4);
 }
 
 int grid_for(int Mtok, int D, int max_blocks, bool bwd) {
@@ -483,7 +581,7 @@ int grid_for(int Mtok, int D, int max_blocks, bool bwd) {
 }  // namespace
 
 extern "C" int e2k_query_hc_coef_width(void) { return CW; }
-extern "C" int e2k_query_hc_bwd_blocks(int Mtok, int D) { return grid_for(Mtok, D, 512, true); }
+extern "C" int e2k_query_hc_bwd_blocks(int Mtok, int D) { return grid_for(Mtok, D, 768, true); }
 extern "C" int e2k_query_hc_partial_stride(int D) { return NJ * D + NSC; }
 
 extern "C" int e2k_hc_fwd(const void* Xin, const void* yprev, const float* coef_prev, void* Mout, void* bin,
@@ -521,7 +619,7 @@ extern "C" int e2k_hc_bwd(const void* Xin, const void* yprev, const float* coef_
     a.partial = partial; a.Mtok = Mtok;
     if (!G || (has_depth && (!yprev || !coef_prev || !dyprev))) return E2K_ERR_ARG;
     if (has_width && (!Xin || !dbin || !ycur || !coef || !dR || !partial || !gamma || !g_gamma)) return E2K_ERR_ARG;
-    const int grid = grid_for(Mtok, D, 512, true);      // two workgroups per CU (the kernel fits 2 waves per SIMD)
+    const int grid = grid_for(Mtok, D, 768, true);      // three workgroups per CU (3 waves per SIMD, 50 KB LDS each)
     int rc = 0;
     HC_DISPATCH_BWD(D, launch_bwd, a, has_depth != 0, has_width != 0, grid, (hipStream_t)stream);
     if (rc) return rc;
@@ -532,7 +630,7 @@ extern "C" int e2k_hc_bwd(const void* Xin, const void* yprev, const float* coef_
         r.g_static_beta = g_static_beta; r.g_static_alpha = g_static_alpha; r.g_dyn_alpha_fn = g_dyn_alpha_fn;
         r.g_dyn_alpha_scale = g_dyn_alpha_scale; r.g_dyn_beta_fn = g_dyn_beta_fn; r.g_dyn_beta_scale = g_dyn_beta_scale;
         r.g_gamma = g_gamma;
-        hipLaunchKernelGGL(hc_reduce_kernel, dim3(D / 32 + 1), dim3(256), 0, (hipStream_t)stream, r);
+        hipLaunchKernelGGL(hc_reduce_kernel, dim3(D / 32 + 1, RSPLIT), dim3(256), 0, (hipStream_t)stream, r);
         E2K_CHECK_LAUNCH();
     }
     return 0;

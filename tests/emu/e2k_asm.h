@@ -32,6 +32,17 @@ inline float wave_sum_fast(float v) {          // same result up to summation or
     for (int m = 32; m >= 1; m >>= 1) v += __shfl_xor(v, m);
     return v;
 }
+inline float wave_sum_last(float v) { return wave_sum_fast(v); }     // (valid in every lane here; lane 63 is what is used)
+inline void wave_sum_last4(float& a, float& b, float& c, float& d) {
+    a = wave_sum_fast(a); b = wave_sum_fast(b); c = wave_sum_fast(c); d = wave_sum_fast(d);
+}
+inline float group8_sum(float v) {
+    for (int m = 1; m <= 4; m <<= 1) v += __shfl_xor(v, m);
+    return v;
+}
+inline float lane_bcast(float v, int L) { return __shfl(v, L); }
+inline float sload(const float* p) { return *p; }
+inline float fast_rsq(float x) { return 1.0f / sqrtf(x); }
 inline float fast_exp2(float x) { return exp2f(x); }
 inline float fast_rcp(float x) { return 1.0f / x; }
 

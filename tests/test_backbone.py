@@ -88,7 +88,7 @@ def test_backbone(dev, cond_on_time, with_text, with_mask):
         err = rel2(p.grad, gr)
         errs.append((err, name))
         if p.numel() == 1:       # heavily cancelling sums over all tokens: absolute slack (unit-tested in test_emu_hc)
-            ok = abs(p.grad.cpu().item() - gr.item()) <= 0.4 * abs(gr.item()) + 5.0
+            ok = abs(p.grad.cpu().item() - gr.item()) <= 0.4 * abs(gr.item()) + 10.0
         else:
             ok = err <= (0.6 if p.numel() <= 32 else 0.15)   # bf16 noise accumulated over the whole backward; a missing term shows as >= 0.3
         if not ok:

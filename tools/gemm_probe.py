@@ -28,4 +28,18 @@ elif which == 'attn':
     for _ in range(3):
         ops.attn_fwd(st, kmask, 0.1, 1, 3)
         ops.attn_bwd(st, dOg, kmask, 0.1, 1, 3)
+elif which == 'hc':
+    D = 1024
+    X = torch.randn(M, 4, D, device=dev).to(bf16)
+    params = [torch.ones(4, device=dev), torch.randn(4, 5, device=dev), torch.randn(D, 5, device=dev) * 0.03,
+              torch.tensor(0.01, device=dev), torch.randn(D, device=dev) * 0.03, torch.tensor(0.01, device=dev),
+              torch.zeros(D, device=dev)]
+    grads = [torch.zeros_like(p) for p in params]
+    M1, b1, c1 = ops.hc_fwd(X, params)
+    y1 = torch.randn(M, D, device=dev).to(bf16)
+    M2, b2, c2 = ops.hc_fwd(M1, params, yprev=y1, coef_prev=c1)
+    G = torch.randn(M, 4, D, device=dev).to(bf16); db = torch.randn(M, D, device=dev).to(bf16); y2 = torch.randn(M, D, device=dev).to(bf16)
+    for _ in range(4):
+        ops.hc_fwd(M1, params, yprev=y1, coef_prev=c1)
+        ops.hc_bwd(G, xin=M1, yprev=y1, coef_prev=c1, dbin=db, ycur=y2, coef=c2, params=params, grads=grads)
 torch.cuda.synchronize()
