@@ -51,10 +51,66 @@ struct NTArgs {
     const uint8_t* rowmask; const bf16_t* resid; long ldr;
 };
 
+// epilogue of an interior tile (all 128 x 128 outputs exist, rows 8-byte aligned): no per-element bounds checks, the
+// optional operands are selected once per tile (wave-uniform), bias kept in registers across the 4 row groups
+template <bool OUT_F32, bool HAS_CS, bool HAS_RES>
+__device__ __forceinline__ void nt_epilogue_full(const NTArgs& p, f32x4 (&acc)[4][4], int m0, int n0, int wm, int wn, int l15, int g) {
+    const int nb = n0 + wn * 64 + 4 * g;
+    f32x4 bias4[4];
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+        bias4[j] = f32x4{0.f, 0.f, 0.f, 0.f};
+        if (p.bias) {
+#pragma unroll
+            for (int r = 0; r < 4; ++r) bias4[j][r] = p.bias[nb + j * 16 + r];
+        }
+    }
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        const int m = m0 + wm * 64 + i * 16 + l15;
+        const float rm = p.rowmask ? (p.rowmask[m] ? 1.f : 0.f) : 1.f;
+        const float* cs = HAS_CS ? p.colscale + (long)(m / p.rows_per_batch) * p.lds : nullptr;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const int n = nb + j * 16;
+            f32x4 x = acc[i][j] + bias4[j];
+            if (HAS_CS) {
+#pragma unroll
+                for (int r = 0; r < 4; ++r) x[r] *= cs[n + r];
+            }
+            x *= rm;
+            if (HAS_RES) {
+                float rs[4];
+                unpack4(ld<u32x2>(p.resid + (long)m * p.ldr + n), rs);
+#pragma unroll
+                for (int r = 0; r < 4; ++r) x[r] += rs[r];
+            }
+            if (OUT_F32) {
+                float* c = (float*)p.C + (long)m * p.ldc + n;
+                if (p.accumulate) x += ld<f32x4>(c);
+                st<f32x4>(c, x);
+            } else {
+                float v[4] = {x[0], x[1], x[2], x[3]};
+                st<u32x2>((bf16_t*)p.C + (long)m * p.ldc + n, pack4(v));
+            }
+        }
+    }
+}
+
 // epilogue shared by the NT kernels: lane holds C[m][n..n+3], m = m0+wm*64+i*16+l15, n = n0+wn*64+j*16+4g
 template <bool OUT_F32>
 __device__ __forceinline__ void nt_epilogue(const NTArgs& p, f32x4 (&acc)[4][4], int m0, int n0, int wm, int wn, int l15, int g) {
     const bool vec_ok = (p.ldc & 3) == 0 && (p.resid == nullptr || (p.ldr & 3) == 0);
+    if (vec_ok && m0 + BM <= p.M && n0 + BN <= p.N) {       // wave-uniform
+        if (p.colscale) {
+            if (p.resid) nt_epilogue_full<OUT_F32, true, true>(p, acc, m0, n0, wm, wn, l15, g);
+            else nt_epilogue_full<OUT_F32, true, false>(p, acc, m0, n0, wm, wn, l15, g);
+        } else {
+            if (p.resid) nt_epilogue_full<OUT_F32, false, true>(p, acc, m0, n0, wm, wn, l15, g);
+            else nt_epilogue_full<OUT_F32, false, false>(p, acc, m0, n0, wm, wn, l15, g);
+        }
+        return;
+    }
 #pragma unroll
     for (int i = 0; i < 4; ++i) {
         const int m = m0 + wm * 64 + i * 16 + l15;

@@ -375,6 +375,24 @@ __global__ __launch_bounds__(256, 3) void hc_bwd_kernel(HCBwdArgs p) {
                 *reinterpret_cast<f32x4*>(&red[it & 1][wave][g * 4]) = v;
             }
         }
+        // independent of the reduction, done while the other waves arrive: pre[s] = sum_t a[s][t] dm_t
+        float a[S][5], rn[S], pre[S][EPL];
+#pragma unroll
+        for (int s = 0; s < S; ++s) {
+            rn[s] = sload(cf + CRN + s);
+#pragma unroll
+            for (int t = 0; t < 5; ++t) a[s][t] = sload(cf + CA + s * 5 + t);
+#pragma unroll
+            for (int e = 0; e < EPL; ++e) {
+                float v = a[s][0] * dm[0][e];
+#pragma unroll
+                for (int t = 1; t < 5; ++t) v = fmaf(a[s][t], dm[t][e], v);
+                pre[s][e] = v;
+            }
+        }
+        float w6[NJ][EPL];       // this lane's Wp elements (LDS reads in flight across the barrier)
+#pragma unroll
+        for (int j = 0; j < NJ; ++j) load_wp<VEC, NCH>(Wp + j * D + doff, lane, w6[j]);
         __syncthreads();
         // lane-parallel: lane (ls, lj) turns its dot into c = d(pre-tanh dot); group-of-8 sums give uq[ls]
         const float dotl = lact ? token_pick<NW>(red, it & 1, wave, ls * 6 + (lj < 6 ? lj : 0)) * vf : 0.f;
@@ -384,13 +402,10 @@ __global__ __launch_bounds__(256, 3) void hc_bwd_kernel(HCBwdArgs p) {
         accT = fmaf(dotl, th, accT);
         const float uql = group8_sum(cl * Pl);
         const float cql = cl * sqrtD;
-        float a[S][5], cq[S][NJ], rn[S], uq[S];
+        float cq[S][NJ], uq[S];
 #pragma unroll
         for (int s = 0; s < S; ++s) {
-            rn[s] = sload(cf + CRN + s);
             uq[s] = lane_bcast(uql, s * 8);
-#pragma unroll
-            for (int t = 0; t < 5; ++t) a[s][t] = sload(cf + CA + s * 5 + t);
 #pragma unroll
             for (int j = 0; j < NJ; ++j) cq[s][j] = lane_bcast(cql, s * 8 + j);
         }
@@ -403,13 +418,11 @@ __global__ __launch_bounds__(256, 3) void hc_bwd_kernel(HCBwdArgs p) {
             for (int e = 0; e < EPL; ++e) { r[s][e] *= rn[s]; qs[s][e] = 0.f; }
 #pragma unroll
         for (int j = 0; j < NJ; ++j) {
-            float w[EPL];
-            load_wp<VEC, NCH>(Wp + j * D + doff, lane, w);
 #pragma unroll
             for (int s = 0; s < S; ++s)
 #pragma unroll
                 for (int e = 0; e < EPL; ++e) {
-                    qs[s][e] = fmaf(cq[s][j], w[e], qs[s][e]);
+                    qs[s][e] = fmaf(cq[s][j], w6[j][e], qs[s][e]);
                     gw[j][e] = fmaf(cq[s][j], r[s][e], gw[j][e]);
                 }
         }
@@ -421,10 +434,7 @@ __global__ __launch_bounds__(256, 3) void hc_bwd_kernel(HCBwdArgs p) {
             float dr[EPL];
 #pragma unroll
             for (int e = 0; e < EPL; ++e) {
-                float v = a[s][0] * dm[0][e];
-#pragma unroll
-                for (int t = 1; t < 5; ++t) v = fmaf(a[s][t], dm[t][e], v);
-                v = fmaf(rn[s], qs[s][e] - r[s][e] * uq[s], v);
+                const float v = fmaf(rn[s], qs[s][e] - r[s][e] * uq[s], pre[s][e]);
                 dr[e] = v;
                 if (DEPTH) dyp[e] = fmaf(bp[s], v, dyp[e]);
             }
@@ -546,7 +556,7 @@ int launch_bwd(const HCBwdArgs& a, bool depth, bool width, int grid, hipStream_t
     switch (D) {                                                      \
         case 128: rc = FN<2, 1, 1>(__VA_ARGS__); break;               \
         case 256: rc = FN<4, 1, 1>(__VA_ARGS__); break;               \
-        case 512: rc = FN<4, 1, 2>(__VA_ARGS__); break;               \
+        case 512: rc = FN<8, 1, 1>(__VA_ARGS__); break;               \
         case 768: rc = FN<4, 3, 1>(__VA_ARGS__); break;               \
         case 1024: rc = FN<8, 1, 2>(__VA_ARGS__); break;              \
         case 1536: rc = FN<4, 3, 2>(__VA_ARGS__); break;              \
@@ -569,7 +579,7 @@ int launch_bwd(const HCBwdArgs& a, bool depth, bool width, int grid, hipStream_t
 
 int tokens_per_block(int D, bool bwd) {
     if (bwd) return D == 1024 || D == 2048 ? 1 : (D == 512 || D == 1536 ? 2 : 4);
-    return D == 512 || D == 1024 || D == 1536 ? 2 : (D == 2048 ? 1 : 4);
+    return D == 1024 || D == 1536 ? 2 : (D == 2048 ? 1 : 4);
 }
 
 int grid_for(int Mtok, int D, int max_blocks, bool bwd) {

@@ -16,6 +16,7 @@ def rel(a, b):
     (130, 260, 128, 64, dict(bias=1, cs=1, rm=1, rs=1)),
     (64, 100, 64, 0, dict(f32=1, bias=1)),
     (8, 1000, 256, 0, dict(f32=1, bias=1)),
+    (256, 384, 128, 0, dict(f32=1, bias=1)),
     (520, 392, 256, 128, dict(rs=1)),
 ])
 def test_gemm_nt(dev, M, N, K1, K2, kw):
