@@ -23,6 +23,7 @@ using namespace e2k;
 namespace {
 
 constexpr int BM = 128, BN = 128, BK = 64;
+constexpr int NT_SLOTS = 512;        // resident NT workgroups on the chip: 256 CUs x 2 (64 KB LDS each)
 
 __device__ __forceinline__ int xcd_remap(int orig, int nwg) {
     // blocks are dispatched round-robin over the 8 XCDs; give each XCD a contiguous run of tiles (bijective)
@@ -49,12 +50,16 @@ struct NTArgs {
     int M, N;
     const float* bias; const float* colscale; long lds; int rows_per_batch;
     const uint8_t* rowmask; const bf16_t* resid; long ldr;
+    int probe;          // E2K_GEMM_PROBE_* bits (bottleneck probes: results are wrong on purpose)
+    // remainder split: workgroups [0, full) own whole tiles; the last T - full tiles (a partial round of the 512
+    // resident workgroups) are cut into `split` K ranges each, fp32 partials go to `ws`, gemm_nt_fixup_kernel finishes
+    int full, split; float* ws;
 };
 
 // epilogue of an interior tile (all 128 x 128 outputs exist, rows 8-byte aligned): no per-element bounds checks, the
 // optional operands are selected once per tile (wave-uniform), bias kept in registers across the 4 row groups
-template <bool OUT_F32, bool HAS_CS, bool HAS_RES>
-__device__ __forceinline__ void nt_epilogue_full(const NTArgs& p, f32x4 (&acc)[4][4], int m0, int n0, int wm, int wn, int l15, int g) {
+template <bool OUT_F32, bool HAS_CS, bool HAS_RES, int NI>
+__device__ __forceinline__ void nt_epilogue_full(const NTArgs& p, f32x4 (&acc)[NI][4], int m0, int n0, int wm, int wn, int l15, int g) {
     const int nb = n0 + wn * 64 + 4 * g;
     f32x4 bias4[4];
 #pragma unroll
@@ -66,7 +71,7 @@ __device__ __forceinline__ void nt_epilogue_full(const NTArgs& p, f32x4 (&acc)[4
         }
     }
 #pragma unroll
-    for (int i = 0; i < 4; ++i) {
+    for (int i = 0; i < NI; ++i) {
         const int m = m0 + wm * 64 + i * 16 + l15;
         const float rm = p.rowmask ? (p.rowmask[m] ? 1.f : 0.f) : 1.f;
         const float* cs = HAS_CS ? p.colscale + (long)(m / p.rows_per_batch) * p.lds : nullptr;
@@ -97,22 +102,22 @@ __device__ __forceinline__ void nt_epilogue_full(const NTArgs& p, f32x4 (&acc)[4
     }
 }
 
-// epilogue shared by the NT kernels: lane holds C[m][n..n+3], m = m0+wm*64+i*16+l15, n = n0+wn*64+j*16+4g
-template <bool OUT_F32>
-__device__ __forceinline__ void nt_epilogue(const NTArgs& p, f32x4 (&acc)[4][4], int m0, int n0, int wm, int wn, int l15, int g) {
+// epilogue shared by the NT kernels: lane holds C[m][n..n+3], m = m0+wm*64+i*16+l15 (i < NI), n = n0+wn*64+j*16+4g
+template <bool OUT_F32, int NI>
+__device__ __forceinline__ void nt_epilogue(const NTArgs& p, f32x4 (&acc)[NI][4], int m0, int n0, int wm, int wn, int l15, int g) {
     const bool vec_ok = (p.ldc & 3) == 0 && (p.resid == nullptr || (p.ldr & 3) == 0);
     if (vec_ok && m0 + BM <= p.M && n0 + BN <= p.N) {       // wave-uniform
         if (p.colscale) {
-            if (p.resid) nt_epilogue_full<OUT_F32, true, true>(p, acc, m0, n0, wm, wn, l15, g);
-            else nt_epilogue_full<OUT_F32, true, false>(p, acc, m0, n0, wm, wn, l15, g);
+            if (p.resid) nt_epilogue_full<OUT_F32, true, true, NI>(p, acc, m0, n0, wm, wn, l15, g);
+            else nt_epilogue_full<OUT_F32, true, false, NI>(p, acc, m0, n0, wm, wn, l15, g);
         } else {
-            if (p.resid) nt_epilogue_full<OUT_F32, false, true>(p, acc, m0, n0, wm, wn, l15, g);
-            else nt_epilogue_full<OUT_F32, false, false>(p, acc, m0, n0, wm, wn, l15, g);
+            if (p.resid) nt_epilogue_full<OUT_F32, false, true, NI>(p, acc, m0, n0, wm, wn, l15, g);
+            else nt_epilogue_full<OUT_F32, false, false, NI>(p, acc, m0, n0, wm, wn, l15, g);
         }
         return;
     }
 #pragma unroll
-    for (int i = 0; i < 4; ++i) {
+    for (int i = 0; i < NI; ++i) {
         const int m = m0 + wm * 64 + i * 16 + l15;
         if (m >= p.M) continue;
         const float rm = p.rowmask ? (p.rowmask[m] ? 1.f : 0.f) : 1.f;
@@ -278,7 +283,7 @@ __global__ __launch_bounds__(256) void gemm_nt_kernel(NTArgs p) {
         __syncthreads();
     }
 
-    nt_epilogue<OUT_F32>(p, acc, m0, n0, wm, wn, l15, g);
+    nt_epilogue<OUT_F32, 4>(p, acc, m0, n0, wm, wn, l15, g);
 }
 
 // Default NT kernel: global_load_lds staging, two 32-KB LDS buffers, BK = 64, one barrier per K step.
@@ -294,9 +299,18 @@ __global__ __launch_bounds__(256, 2) void gemm_nt_glds_kernel(NTArgs p) {
     const int l15 = lane & 15, g = lane >> 4;
     const int tm = (p.M + BM - 1) / BM, tn = (p.N + BN - 1) / BN;
     int tile_m, tile_n;
-    tile_coords(xcd_remap(blockIdx.x, gridDim.x), tm, tn, tile_m, tile_n);
-    const int m0 = tile_m * BM, n0 = tile_n * BN;
     const int nk1 = p.K1 / BK, nk = (p.K1 + p.K2) / BK;
+    int kb = 0, ke = nk, part = -1;          // K-step range of this workgroup; part >= 0: partial result slot in ws
+    if ((int)blockIdx.x < p.full) {
+        tile_coords(xcd_remap(blockIdx.x, p.full), tm, tn, tile_m, tile_n);
+    } else {
+        part = blockIdx.x - p.full;
+        const int r = part / p.split, sidx = part - r * p.split;
+        tile_coords(p.full + r, tm, tn, tile_m, tile_n);
+        kb = (int)((long)nk * sidx / p.split);
+        ke = (int)((long)nk * (sidx + 1) / p.split);
+    }
+    const int m0 = tile_m * BM, n0 = tile_n * BN;
 
     // per-lane 32-bit byte offsets of the 4 (A) + 4 (B) wave instructions of a K step at k = 0; the K advance goes
     // into the scalar base, so a load is `global_load_lds_dwordx4 voff, s[base]` with no per-step vector arithmetic
@@ -360,19 +374,64 @@ __global__ __launch_bounds__(256, 2) void gemm_nt_glds_kernel(NTArgs p) {
         }
     };
 
-    gissue(0, 0);
+    gissue(kb, 0);
     __syncthreads();
-    int kt = 0;
-    for (; kt + 1 < nk; kt += 2) {
-        gissue(kt + 1, 1);
-        compute(0);
-        __syncthreads();
-        if (kt + 2 < nk) gissue(kt + 2, 0);
-        compute(1);
-        __syncthreads();
+    int kt = kb;
+    if (p.probe == 0) {
+        for (; kt + 1 < ke; kt += 2) {
+            gissue(kt + 1, 1);
+            compute(0);
+            __syncthreads();
+            if (kt + 2 < ke) gissue(kt + 2, 0);
+            compute(1);
+            __syncthreads();
+        }
+    } else {
+        // bottleneck probes: the same loop without its loads (LDS + MFMA side alone) or without its MFMAs (load side)
+        const bool loads = !(p.probe & E2K_GEMM_PROBE_NO_LOADS), math = !(p.probe & E2K_GEMM_PROBE_NO_MATH);
+        for (; kt + 1 < ke; kt += 2) {
+            if (loads) gissue(kt + 1, 1);
+            if (math) compute(0);
+            __syncthreads();
+            if (loads && kt + 2 < ke) gissue(kt + 2, 0);
+            if (math) compute(1);
+            __syncthreads();
+        }
     }
-    if (kt < nk) compute(0);
-    nt_epilogue<OUT_F32>(p, acc, m0, n0, wm, wn, l15, g);
+    if (kt < ke) compute(0);
+    if (part >= 0) {        // K-range partial of a remainder tile: raw accumulators, 64 floats per thread
+        float* w = p.ws + ((long)part * 16 * 256 + tid) * 4;       // [part][i*4+j][tid] x 4 floats: 1-KB runs per wave store
+#pragma unroll
+        for (int i = 0; i < 4; ++i)
+#pragma unroll
+            for (int j = 0; j < 4; ++j) st<f32x4>(w + (i * 4 + j) * 1024, acc[i][j]);
+        return;
+    }
+    nt_epilogue<OUT_F32, 4>(p, acc, m0, n0, wm, wn, l15, g);
+}
+
+// sums the K-range partials of a 16-row group (blockIdx.y = i) of one remainder tile (blockIdx.x), same thread <->
+// accumulator mapping as the GEMM kernel, and runs the shared epilogue on the totals
+template <bool OUT_F32>
+__global__ __launch_bounds__(256) void gemm_nt_fixup_kernel(NTArgs p) {
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int wm = wave >> 1, wn = wave & 1, l15 = lane & 15, g = lane >> 4;
+    const int tm = (p.M + BM - 1) / BM, tn = (p.N + BN - 1) / BN;
+    const int i = blockIdx.y;
+    int tile_m, tile_n;
+    tile_coords(p.full + blockIdx.x, tm, tn, tile_m, tile_n);
+    f32x4 acc[1][4];
+#pragma unroll
+    for (int j = 0; j < 4; ++j) acc[0][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+    const float* w = p.ws + (((long)blockIdx.x * p.split * 16 + i * 4) * 256 + tid) * 4;
+#pragma unroll 4
+    for (int sidx = 0; sidx < p.split; ++sidx) {
+#pragma unroll
+        for (int j = 0; j < 4; ++j) acc[0][j] += ld<f32x4>(w + ((long)sidx * 16 + j) * 1024);
+    }
+    // (rows m0 + wm*64 + i*16 + l15: pass the tile origin shifted by the row group; a shifted origin only ever makes
+    // the interior-tile test more conservative)
+    nt_epilogue<OUT_F32, 1>(p, acc, tile_m * BM + i * 16, tile_n * BN, wm, wn, l15, g);
 }
 
 // Pipelined variant (flag E2K_GEMM_PIPE4; measured 5-10 % SLOWER than the 2-buffer kernel on MI355X, kept for A/B): BK = 32, four LDS stages of 16 KB, global_load_lds
@@ -449,7 +508,7 @@ __global__ __launch_bounds__(256) void gemm_nt_pipe_kernel(NTArgs p) {
             for (int j = 0; j < 4; ++j)
                 acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(bw[j], af[i], acc[i][j], 0, 0, 0);
     }
-    nt_epilogue<OUT_F32>(p, acc, m0, n0, wm, wn, l15, g);
+    nt_epilogue<OUT_F32, 4>(p, acc, m0, n0, wm, wn, l15, g);
 }
 
 // ---------------------------------------------------------------------------------------------- TN (wgrad)
@@ -709,7 +768,7 @@ extern "C" int e2k_gemm_nt_bf16(const void* A1, int64_t lda1, int K1, const void
                                 const void* B, int64_t ldb, void* C, int64_t ldc, int out_f32, int accumulate,
                                 int M, int N, const float* bias, const float* colscale, int64_t lds,
                                 int rows_per_batch, const uint8_t* rowmask, const void* resid, int64_t ldr, int flags,
-                                void* stream) {
+                                float* ws, int64_t ws_bytes, void* stream) {
     if (M <= 0 || N <= 0) return 0;
     if (K1 <= 0 || (K1 & 7) || (K2 & 7) || K2 < 0) return E2K_ERR_SHAPE;
     if ((lda1 & 7) || (ldb & 7) || (K2 > 0 && ((lda2 & 7) || A2 == nullptr))) return E2K_ERR_ALIGN;
@@ -724,10 +783,29 @@ extern "C" int e2k_gemm_nt_bf16(const void* A1, int64_t lda1, int K1, const void
     p.M = M; p.N = N;
     p.bias = bias; p.colscale = colscale; p.lds = lds; p.rows_per_batch = rows_per_batch;
     p.rowmask = rowmask; p.resid = (const bf16_t*)resid; p.ldr = ldr;
-    const int tm = (M + BM - 1) / BM, tn = (N + BN - 1) / BN;
-    dim3 grid(tm * tn), block(256);
+    const int tm = (M + BM - 1) / BM, tn = (N + BN - 1) / BN, T = tm * tn;
+    p.probe = flags & (E2K_GEMM_PROBE_NO_LOADS | E2K_GEMM_PROBE_NO_MATH);
     const bool glds = !(flags & E2K_GEMM_NO_GLDS) && (K1 % BK) == 0 && (K2 % BK) == 0;
     const bool pipe = (flags & E2K_GEMM_PIPE4) && (K1 % PBK) == 0 && (K2 % PBK) == 0;
+    // Remainder split (default kernel only): 256 CUs x 2 resident workgroups = 512 tiles per round; a trailing partial
+    // round of `rem` tiles would run at rem/512 of the chip (8448 rows x 1024 columns = 528 tiles: the last 16 cost
+    // a whole round), so those tiles are cut into `split` K ranges that together fill the chip once more.
+    p.full = T; p.split = 1; p.ws = ws;
+    int rem = 0;
+    const int slots = (flags & E2K_GEMM_TEST_SLOTS8) ? 8 : NT_SLOTS;
+    if (glds && !pipe && ws && !(flags & E2K_GEMM_NO_SPLIT) && T > slots && (T % slots) != 0) {
+        rem = T % slots;
+        const int nk = (K1 + K2) / BK;
+        int split = 1;
+        while (split * 2 <= 16 && split * 2 * rem <= slots && split * 2 * 2 <= nk) split *= 2;
+        // worth it only when the partial round it removes (about half a round: ~0.5 us per K step, measured) costs more
+        // than writing + re-reading the fp32 partials (64 KB per workgroup at ~5 TB/s) and the fix-up launch (~4 us)
+        if (!(flags & E2K_GEMM_TEST_SLOTS8))
+            while (split > 1 && 0.5f * nk < 1.2f * (rem * split * 0.026f + 4.f)) split >>= 1;
+        if (split > 1 && (int64_t)rem * split * BM * BN * 4 <= ws_bytes) { p.full = T - rem; p.split = split; }
+        else rem = 0;
+    }
+    dim3 grid(p.full + rem * p.split), block(256);
     hipStream_t st = (hipStream_t)stream;
     if (pipe) {
         if (out_f32) hipLaunchKernelGGL(gemm_nt_pipe_kernel<true>, grid, block, 0, st, p);
@@ -740,8 +818,15 @@ extern "C" int e2k_gemm_nt_bf16(const void* A1, int64_t lda1, int K1, const void
         else hipLaunchKernelGGL((gemm_nt_kernel<false, false>), grid, block, 0, st, p);
     }
     E2K_CHECK_LAUNCH();
+    if (rem) {
+        if (out_f32) hipLaunchKernelGGL(gemm_nt_fixup_kernel<true>, dim3(rem, 4), block, 0, st, p);
+        else hipLaunchKernelGGL(gemm_nt_fixup_kernel<false>, dim3(rem, 4), block, 0, st, p);
+        E2K_CHECK_LAUNCH();
+    }
     return 0;
 }
+
+extern "C" int e2k_query_gemm_nt_ws_bytes(void) { return NT_SLOTS * BM * BN * 4; }
 
 extern "C" int e2k_query_gemm_tn_splits(int M, int N, int K, int splits) {
     if (M <= 0 || N <= 0 || K <= 0) return 1;

@@ -70,11 +70,23 @@ def gemm_nt(a, b, *, a2=None, out=None, out_dtype=bf16, accumulate=False, bias=N
     _lib.get().e2k_gemm_nt_bf16(_p(a), lda, K1, _p(a2), lda2, K2, _p(b), ldb, _p(out), out.stride(0),
                                 int(out.dtype == f32), int(accumulate), M, N, _p(bias), _p(colscale),
                                 0 if colscale is None else colscale.stride(0), int(rows_per_batch), _p(rowmask), _p(resid), ldr,
-                                gemm_flags, _stream(a))
+                                gemm_flags, *_nt_ws(a.device), _stream(a))
     if prof is not None and a.is_cuda:
         e1.record()
         prof.append((2.0 * M * N * (K1 + K2), e0, e1))
     return out
+
+
+_nt_ws_cache = {}
+
+
+def _nt_ws(device):
+    """per-device fp32 scratch of the NT GEMM remainder split (one compute stream per device uses it)"""
+    w = _nt_ws_cache.get(device)
+    if w is None:
+        w = torch.empty(_lib.get().e2k_query_gemm_nt_ws_bytes() // 4, dtype=f32, device=device)
+        _nt_ws_cache[device] = w
+    return _p(w), w.numel() * 4
 
 
 _gemm_profile = None

@@ -39,8 +39,16 @@ int e2k_gemm_nt_bf16(const void* A1, int64_t lda1, int K1, const void* A2, int64
                      const void* B, int64_t ldb, void* C, int64_t ldc, int out_f32, int accumulate,
                      int M, int N, const float* bias, const float* colscale, int64_t lds,
                      int rows_per_batch, const uint8_t* rowmask, const void* resid, int64_t ldr, int flags,
-                     void* stream);
+                     float* ws, int64_t ws_bytes, void* stream);
+/* ws: optional fp32 scratch (e2k_query_gemm_nt_ws_bytes() bytes cover every shape; NULL = never split).  When the tile
+ * count leaves a partial last round of the 512 resident workgroups, those tiles are split over K into partials in ws
+ * and finished by a second small kernel.  One ws per stream: launches on the same stream serialise on it. */
+int e2k_query_gemm_nt_ws_bytes(void);
 #define E2K_GEMM_NO_GLDS 1   /* flags: stage operands through VGPRs instead of global_load_lds (A/B benchmarking) */
+#define E2K_GEMM_PROBE_NO_LOADS 4 /* flags: bottleneck probe, K loop without its global loads (WRONG results) */
+#define E2K_GEMM_PROBE_NO_MATH 8  /* flags: bottleneck probe, K loop without its LDS reads + MFMAs (WRONG results) */
+#define E2K_GEMM_NO_SPLIT 16     /* flags: never split remainder tiles over K (A/B) */
+#define E2K_GEMM_TEST_SLOTS8 32  /* flags: pretend the chip holds 8 workgroups (lets small shapes exercise the remainder split in tests) */
 #define E2K_GEMM_PIPE4 2     /* flags: 4-stage BK=32 counted-vmcnt pipeline instead of the 2-buffer BK=64 kernel (A/B) */
 
 /* C[N,K] += A[M,N]^T . B[M,K]  (weight gradients; C fp32, A = dY, B = X, bf16).  The token dimension M is

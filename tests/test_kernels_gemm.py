@@ -50,6 +50,21 @@ def test_gemm_nt(dev, M, N, K1, K2, kw):
         assert rel(out2, 2 * ref) < 1e-5
 
 
+@pytest.mark.parametrize('M,N,K1,K2,kw', [
+    (1280, 128, 256, 0, dict(bias=1)),                       # 10 tiles on "8 slots": 2 remainder tiles x 2 K ranges
+    (700, 260, 128, 128, dict(bias=1, cs=1, rm=1, rs=1)),    # 18 tiles: 2 remainder tiles (ragged edge), dual-K
+    (1152, 128, 320, 0, dict(f32=1, bias=1)),                # 9 tiles: 1 remainder tile, 5 K steps -> uneven ranges
+])
+def test_gemm_nt_remainder_split(dev, M, N, K1, K2, kw):
+    from e2_tts_pytorch_amd import ops
+    old = ops.gemm_flags
+    ops.gemm_flags = 32          # E2K_GEMM_TEST_SLOTS8
+    try:
+        test_gemm_nt(dev, M, N, K1, K2, kw)
+    finally:
+        ops.gemm_flags = old
+
+
 @pytest.mark.parametrize('use_tr', [False, True])
 @pytest.mark.parametrize('M,N,K,splits', [(128, 128, 128, 1), (300, 136, 72, 0), (1000, 392, 264, 3), (8, 256, 128, 1),
                                           (256, 136, 72, 0), (1024, 392, 264, 3), (192, 8, 520, 1)])
