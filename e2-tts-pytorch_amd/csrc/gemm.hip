@@ -751,11 +751,20 @@ __global__ __launch_bounds__(256) void tn_reduce_kernel(const float* ws, float* 
 int tn_splits(int M, int N, int K, int splits) {
     const int tn = (N + 127) / 128, tk = (K + 127) / 128;
     if (splits <= 0) {
-        // about two workgroups per CU, at least 8 reduction steps (512 token rows) per split
-        int want = (512 + tn * tk - 1) / (tn * tk);
+        // 512 workgroups are resident (two per CU).  Pick the split count with the lowest estimated time: rounds of
+        // workgroups x reduction steps per split (~0.9 us per 64-row step) + the fp32 partial-tile round trip through
+        // the workspace (64 KB written and re-read per workgroup at ~5 TB/s); at least 512 token rows per split.
+        const int tiles = tn * tk;
         int maxs = (M + 511) / 512;
-        splits = want < 1 ? 1 : (want > maxs ? maxs : want);
-        if (splits < 1) splits = 1;
+        if (maxs > 64) maxs = 64;
+        float best = 1e30f;
+        splits = 1;
+        for (int sp = 1; sp <= maxs; ++sp) {
+            const int rounds = (tiles * sp + 511) / 512;
+            const float steps = (float)((M + sp - 1) / sp + TBM - 1) / TBM;
+            const float t = rounds * steps * 0.9f + (sp > 1 ? tiles * sp * 0.026f + 4.f : 0.f);
+            if (t < best * 0.97f) { best = t; splits = sp; }
+        }
     }
     int chunk = (M + splits - 1) / splits;
     chunk = (chunk + TBM - 1) / TBM * TBM;

@@ -59,10 +59,10 @@ if 'gemm' in which:
             ms = timeit(lambda: torch.matmul(a, b.t()))
             rec(f'  torch.matmul (hipBLASLt) {m}x{n}x{k1}', ms, flops=2.0 * m * n * k1)
 if 'tn' in which:
-    for (m, n, k) in [(M, 8192, 1024), (M, 1024, 4096), (M, 3104, 1024), (4 * M, 1024, 1024), (M, 4096, 512)]:
+    for (m, n, k) in [(M, 8192, 1024), (M, 1024, 4096), (M, 3104, 1024), (M, 1024, 1024), (4 * M, 1024, 1536), (4 * M, 512, 1536), (4 * M, 1024, 2048), (M, 3104, 512), (M, 4096, 512), (M, 512, 2048)]:
         a, b = rnd(m, n), rnd(m, k)
         out = torch.zeros(n, k, device=dev)
-        for tr in (1, 0):
+        for tr in (1,):
             ms = timeit(lambda: ops.gemm_tn(a, b, out, use_tr=tr))
             rec(f'gemm_tn use_tr={tr} M{m} N{n} K{k}', ms, flops=2.0 * m * n * k)
         ms = timeit(lambda: torch.matmul(a.t(), b))
