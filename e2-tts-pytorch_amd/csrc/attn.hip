@@ -192,11 +192,18 @@ __global__ __launch_bounds__(256) void qkv_post_bwd_kernel(PostArgs p) {
         unpack8(ld<u32x4>(vr), vf); unpack8(ld<u32x4>(vr + 8), vf + 8);
         float* dvf = p.dvfirst + o;
         float dmix = 0.f;
+        f32x4 acc4[4];                  // fp32 accumulator of d(v_first) over the layers: 16-byte read-modify-write
+#pragma unroll
+        for (int c = 0; c < 4; ++c) acc4[c] = ld<f32x4>(dvf + 4 * c);
 #pragma unroll
         for (int e = 0; e < 16; ++e) {
             dmix = fmaf(dv[e], v[e] - vf[e], dmix);
-            if (valid) dvf[e] += dv[e] * (1.f - mx);
+            acc4[e >> 2][e & 3] += dv[e] * (1.f - mx);
             dv[e] *= mx;
+        }
+        if (valid) {
+#pragma unroll
+            for (int c = 0; c < 4; ++c) st<f32x4>(dvf + 4 * c, acc4[c]);
         }
         dmix += __shfl_xor(dmix, 1);
         dmix += __shfl_xor(dmix, 2);
@@ -205,7 +212,11 @@ __global__ __launch_bounds__(256) void qkv_post_bwd_kernel(PostArgs p) {
     } else if (p.first_layer && p.dvfirst) {
         const float* dvf = p.dvfirst + o;
 #pragma unroll
-        for (int e = 0; e < 16; ++e) dv[e] += dvf[e];
+        for (int c = 0; c < 4; ++c) {
+            const f32x4 a4 = ld<f32x4>(dvf + 4 * c);
+#pragma unroll
+            for (int r = 0; r < 4; ++r) dv[4 * c + r] += a4[r];
+        }
     }
     if (!valid) return;
     if (seg == 0) drow[3 * I + h] = f2bf(p.dgate_pre[bh * p.N + n]);

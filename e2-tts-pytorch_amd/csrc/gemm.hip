@@ -522,6 +522,7 @@ struct TNArgs {
     float* C; long ldc;          // (N, K)
     float* ws;                   // [splits][N][K] partial tiles when splits > 1
     int M, N, K, splits, chunk;
+    float* colsum; int cs_from;  // optional: colsum[n] += sum_m A[m][n] for n >= cs_from (bias gradient of the same dY)
 };
 
 template <bool USE_TR>
@@ -701,6 +702,13 @@ __global__ __launch_bounds__(256, 2) void gemm_tn_glds_kernel(TNArgs p) {
     for (int i = 0; i < 4; ++i)
 #pragma unroll
         for (int j = 0; j < 4; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+    // Column sums of A (bias gradient) ride along in the k-tile-0 workgroups: one extra MFMA per 16 columns and K step
+    // with an all-ones first operand (every row of the result is the column sum); the two waves that share an n range
+    // (wk = 0 / 1) take two of its four 16-column groups each.
+    const bool do_cs = p.colsum != nullptr && tile_k == 0 && n0 + 128 > p.cs_from;     // wave-uniform
+    f32x4 cs[2] = {f32x4{0.f, 0.f, 0.f, 0.f}, f32x4{0.f, 0.f, 0.f, 0.f}};
+    const short one = 0x3F80;
+    const bf16x8 ones = bf16x8{one, one, one, one, one, one, one, one};
     auto compute = [&](int buf) {
         const unsigned char* At = smem[buf][0];
         const unsigned char* Bt = smem[buf][1];
@@ -721,6 +729,15 @@ __global__ __launch_bounds__(256, 2) void gemm_tn_glds_kernel(TNArgs p) {
 #pragma unroll
                 for (int j = 0; j < 4; ++j)
                     acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fx[i], fy[j], acc[i][j], 0, 0, 0);
+            if (do_cs) {
+                if (wk == 0) {
+                    cs[0] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ones, fy[0], cs[0], 0, 0, 0);
+                    cs[1] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ones, fy[1], cs[1], 0, 0, 0);
+                } else {
+                    cs[0] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ones, fy[2], cs[0], 0, 0, 0);
+                    cs[1] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ones, fy[3], cs[1], 0, 0, 0);
+                }
+            }
         }
     };
     if (nsteps > 0) gissue(0, 0);
@@ -736,6 +753,13 @@ __global__ __launch_bounds__(256, 2) void gemm_tn_glds_kernel(TNArgs p) {
     }
     if (s < nsteps) compute(0);
     tn_store(p, acc, n0, k0, wn, wk, q, g);
+    if (do_cs && g == 0) {
+#pragma unroll
+        for (int jj = 0; jj < 2; ++jj) {
+            const int n = n0 + wn * 64 + (2 * wk + jj) * 16 + q;
+            if (n < p.N && n >= p.cs_from) atomicAdd(p.colsum + n, cs[jj][0]);
+        }
+    }
 }
 
 __global__ __launch_bounds__(256) void tn_reduce_kernel(const float* ws, float* C, long ldc, int N, int K, int splits) {
@@ -842,8 +866,11 @@ extern "C" int e2k_query_gemm_tn_splits(int M, int N, int K, int splits) {
     return tn_splits(M, N, K, splits);
 }
 
+extern "C" int e2k_colsum_bf16(const void* x, int64_t ldx, float* out, int M, int N, void* stream);
+
 extern "C" int e2k_gemm_tn_bf16(const void* A, int64_t lda, const void* B, int64_t ldb, float* C, int64_t ldc,
-                                int M, int N, int K, int splits, int use_tr, float* ws, void* stream) {
+                                int M, int N, int K, int splits, int use_tr, float* ws, float* colsum, int cs_from,
+                                void* stream) {
     if (M <= 0 || N <= 0 || K <= 0) return 0;
     // 16-B loads may run past N / K up to the next multiple of 8: that must still be inside the row
     if ((lda & 7) || (ldb & 7) || ((N + 7) & ~7) > lda || ((K + 7) & ~7) > ldb) return E2K_ERR_ALIGN;
@@ -857,8 +884,15 @@ extern "C" int e2k_gemm_tn_bf16(const void* A, int64_t lda, const void* B, int64
     p.ws = ws;
     p.A = (const bf16_t*)A; p.lda = lda; p.B = (const bf16_t*)B; p.ldb = ldb;
     p.C = C; p.ldc = ldc; p.M = M; p.N = N; p.K = K; p.splits = splits; p.chunk = chunk;
+    const bool fast = use_tr && (M % TBM) == 0 && N >= 8 && K >= 8;
+    if (colsum && (cs_from < 0 || cs_from >= N || (cs_from & 1))) return E2K_ERR_ARG;
+    p.colsum = fast ? colsum : nullptr; p.cs_from = cs_from;
+    if (colsum && !fast) {          // the general kernels do not carry the column sums: separate pass over dY
+        int rc = e2k_colsum_bf16((const bf16_t*)A + cs_from, lda, colsum + cs_from, M, N - cs_from, stream);
+        if (rc) return rc;
+    }
     dim3 grid(tn * tk, splits), block(256);
-    if (use_tr && (M % TBM) == 0 && N >= 8 && K >= 8) hipLaunchKernelGGL(gemm_tn_glds_kernel<0>, grid, block, 0, (hipStream_t)stream, p);
+    if (fast) hipLaunchKernelGGL(gemm_tn_glds_kernel<0>, grid, block, 0, (hipStream_t)stream, p);
     else if (use_tr) hipLaunchKernelGGL(gemm_tn_kernel<true>, grid, block, 0, (hipStream_t)stream, p);
     else hipLaunchKernelGGL(gemm_tn_kernel<false>, grid, block, 0, (hipStream_t)stream, p);
     E2K_CHECK_LAUNCH();

@@ -938,10 +938,10 @@ class Transformer(Module):
         dQ, dK, dV, dgate = ops.attn_bwd(ast, dOg, run.kmask, run.p_drop, run.seed, sid, run.seed_dev)
         dqkvg = ops.qkv_post_bwd(ast, dQ, dK, dV, dgate, qkvg, run.rot[0], run.rot[1],
                                  None if first else run.vfirst[key], dvfirst[key], first_layer=first)
-        ops.gemm_tn(dqkvg, xn, G(a.w, a.cols, D))
         nb = a.cols - 3 * a.I                                                      # gate (+ mix) bias gradients
         assert nb % 2 == 0, 'odd head counts are not supported'
-        ops.colsum(dqkvg[:, 3 * a.I:], G(a.bias + 3 * a.I, nb))
+        # weight gradient; the gate (+ mix) bias gradients = column sums of the same dY ride along in the kernel
+        ops.gemm_tn(dqkvg, xn, G(a.w, a.cols, D), colsum=G(a.bias, a.cols), colsum_from=3 * a.I)
         # dgrad over the padded row (pad columns of dqkvg / rows of W^T are zero)
         dq_full = dqkvg if a.ldq == a.cols else torch.as_strided(dqkvg, (Mtok, a.ldq), (a.ldq, 1))
         dxn = ops.gemm_nt(dq_full, self._wT(a.wT))
@@ -961,12 +961,10 @@ class Transformer(Module):
             dgam = run.dcond[:, (ind * 4 + 2) * D:(ind * 4 + 3) * D]
             gate = run.gates[:, (ind * 4 + 3) * D:(ind * 4 + 4) * D]
             dao = ops.gate_bwd(rec.dy, y, gate, run.dcond[:, (ind * 4 + 3) * D:(ind * 4 + 4) * D], N)
-        ops.colsum(dao, G(f.b2, D))
-        ops.gemm_tn(dao, act, G(f.w2, D, f.F))
+        ops.gemm_tn(dao, act, G(f.w2, D, f.F), colsum=G(f.b2, D))                  # dW2 and db2 in one pass over dY
         dact = ops.gemm_nt(dao, self._wT(f.w2T))
         dH = ops.geglu_bwd(dact, Hh, run.p_drop, run.seed, sid, run.seed_dev)
-        ops.colsum(dH, G(f.b1, 2 * f.F))
-        ops.gemm_tn(dH, xn, G(f.w1, 2 * f.F, D))
+        ops.gemm_tn(dH, xn, G(f.w1, 2 * f.F, D), colsum=G(f.b1, 2 * f.F))           # dW1 and db1
         dxn = ops.gemm_nt(dH, self._wT(f.w1T))
         rec.dbin = ops.rmsnorm_bwd(dxn, binp, rn, gam, off, rpb, dgam)
 

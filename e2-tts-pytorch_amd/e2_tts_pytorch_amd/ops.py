@@ -100,8 +100,8 @@ def set_gemm_profile(lst):
     _gemm_profile = lst
 
 
-def gemm_tn(a, b, out, *, splits=0, use_tr=True):
-    """out[N,K] += a[M,N].T @ b[M,K]   (fp32 out, bf16 a/b)"""
+def gemm_tn(a, b, out, *, splits=0, use_tr=True, colsum=None, colsum_from=0):
+    """out[N,K] += a[M,N].T @ b[M,K]   (fp32 out, bf16 a/b); optionally colsum[n] += sum_m a[m][n] for n >= colsum_from"""
     _chk(a, b, out)
     assert a.dtype == bf16 and b.dtype == bf16 and out.dtype == f32
     M, lda = _rows(a)
@@ -112,8 +112,11 @@ def gemm_tn(a, b, out, *, splits=0, use_tr=True):
     lib = _lib.get()
     ns = lib.e2k_query_gemm_tn_splits(M, N, K, int(splits))
     ws = torch.empty((ns * N * K,), dtype=f32, device=a.device) if ns > 1 else None
+    if colsum is not None:
+        _chk(colsum)
+        assert colsum.dtype == f32 and colsum.numel() == N and colsum.is_contiguous()
     lib.e2k_gemm_tn_bf16(_p(a), lda, _p(b), ldb, _p(out), out.stride(0), M, N, K, int(splits), int(use_tr), _p(ws),
-                         _stream(a))
+                         _p(colsum), int(colsum_from), _stream(a))
     return out
 
 

@@ -53,9 +53,12 @@ int e2k_query_gemm_nt_ws_bytes(void);
 
 /* C[N,K] += A[M,N]^T . B[M,K]  (weight gradients; C fp32, A = dY, B = X, bf16).  The token dimension M is
  * split over `splits` workgroups per tile (0 = choose); partial tiles go to `ws` and are combined by a reduce kernel.
- * use_tr = 1 reads MFMA fragments with ds_read_b64_tr_b16, 0 = plain 16-bit LDS gathers (same results). */
+ * use_tr = 1 reads MFMA fragments with ds_read_b64_tr_b16, 0 = plain 16-bit LDS gathers (same results).
+ * colsum (optional, fp32 [N]): colsum[n] += sum_m A[m][n] for n >= cs_from (even) -- the bias gradient of the same
+ * Linear (e.g. FeedForward proj bias, e2_tts.py:937), computed in the same pass over dY by one extra MFMA per 16
+ * columns with an all-ones operand. */
 int e2k_gemm_tn_bf16(const void* A, int64_t lda, const void* B, int64_t ldb, float* C, int64_t ldc,
-                     int M, int N, int K, int splits, int use_tr, float* ws, void* stream);
+                     int M, int N, int K, int splits, int use_tr, float* ws, float* colsum, int cs_from, void* stream);
 /* number of token-dimension splits the call above will use for (M, N, K, splits); when it is > 1 the caller passes
  * ws = scratch of splits*N*K floats (partial tiles are stored there and combined by a second small kernel). */
 int e2k_query_gemm_tn_splits(int M, int N, int K, int splits);

@@ -91,3 +91,18 @@ def test_gemm_tn_strided(dev):
     ref = a[:, :N].float().T @ b[:, 8:8 + K].float()
     assert rel(C[:, 40:40 + K], ref) < 1e-5
     assert float(C[:, :40].abs().max()) == 0 and float(C[:, 40 + K:].abs().max()) == 0
+
+
+@pytest.mark.parametrize('M,N,K,cs_from', [(256, 264, 136, 0), (192, 392, 128, 130), (200, 136, 72, 8)])
+def test_gemm_tn_colsum(dev, M, N, K, cs_from):
+    """bias gradient riding along in the weight-gradient kernel (M % 64 == 0) / the separate pass of the general path"""
+    from e2_tts_pytorch_amd import ops
+    torch.manual_seed(1)
+    a = torch.randn(M, N).to(bf16)
+    b = torch.randn(M, K).to(bf16)
+    out = torch.zeros(N, K)
+    cs = torch.full((N,), 0.5)
+    ops.gemm_tn(a.to(dev), b.to(dev), out.to(dev), colsum=(csd := cs.to(dev)), colsum_from=cs_from)
+    want = torch.full((N,), 0.5)
+    want[cs_from:] += a.float().sum(0)[cs_from:]
+    assert torch.allclose(csd.cpu(), want, rtol=1e-4, atol=1e-3), (csd.cpu() - want).abs().max()
