@@ -434,82 +434,10 @@ __global__ __launch_bounds__(256) void gemm_nt_fixup_kernel(NTArgs p) {
     nt_epilogue<OUT_F32, 1>(p, acc, tile_m * BM + i * 16, tile_n * BN, wm, wn, l15, g);
 }
 
-// Pipelined variant (flag E2K_GEMM_PIPE4; measured 5-10 % SLOWER than the 2-buffer kernel on MI355X, kept for A/B): BK = 32, four LDS stages of 16 KB, global_load_lds
-// prefetch THREE k-steps ahead, counted s_waitcnt vmcnt + raw s_barrier so the prefetches stay in flight across the
-// barrier (the 2-buffer kernel above drains them every step and is bound by L2/HBM latency, ~1500 cycles per
-// 512-cycle MFMA step).  64-B LDS rows: the 16-B slot s of row r is stored at s ^ P[(r >> 2) & 3], P = {0,2,3,1},
-// which makes every ds_read_b128 lane group hit 16 distinct slots of the 256-B bank row.
-constexpr int PBK = 32, PST = 4;
-__device__ __forceinline__ int pswz(int row) { return (0x78 >> (2 * ((row >> 2) & 3))) & 3; }
-
-template <bool OUT_F32>
-__global__ __launch_bounds__(256) void gemm_nt_pipe_kernel(NTArgs p) {
-    __shared__ __attribute__((aligned(16))) unsigned char smem[PST][2][BM * PBK * 2];
-    const int tid = threadIdx.x, lane = tid & 63, wave = uniform_i(tid >> 6);
-    const int wm = wave >> 1, wn = wave & 1;
-    const int l15 = lane & 15, g = lane >> 4;
-    const int tm = (p.M + BM - 1) / BM, tn = (p.N + BN - 1) / BN;
-    int tile_m, tile_n;
-    tile_coords(xcd_remap(blockIdx.x, gridDim.x), tm, tn, tile_m, tile_n);
-    const int m0 = tile_m * BM, n0 = tile_n * BN;
-    const int nk = (p.K1 + p.K2) / PBK;
-
-    auto gissue = [&](int kt) {
-        const int buf = kt & (PST - 1);
-        const int k0 = kt * PBK;
-        const bf16_t* Ab = p.A1;
-        long lda = p.lda1;
-        int ka = k0;
-        if (k0 >= p.K1) { Ab = p.A2; lda = p.lda2; ka = k0 - p.K1; }
-#pragma unroll
-        for (int i = 0; i < 2; ++i) {
-            const int rb = wave * 2 + i;                 // 1 KB of LDS = 16 rows of 64 B per wave instruction
-            const int row = rb * 16 + (lane >> 2);
-            const int c = (lane & 3) ^ pswz(row);
-            const int m = min(m0 + row, p.M - 1), n = min(n0 + row, p.N - 1);
-            glds16(Ab + (long)m * lda + ka + c * 8, &smem[buf][0][rb * 1024]);
-            glds16(p.B + (long)n * p.ldb + k0 + c * 8, &smem[buf][1][rb * 1024]);
-        }
-    };
-
-    f32x4 acc[4][4];
-#pragma unroll
-    for (int i = 0; i < 4; ++i)
-#pragma unroll
-        for (int j = 0; j < 4; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
-
-    gissue(0);
-    if (nk > 1) gissue(1);
-    if (nk > 2) gissue(2);
-    for (int kt = 0; kt < nk; ++kt) {
-        // tile kt must have landed; the (up to) two younger tiles may stay in flight: 4 loads per wave per tile
-        const int rem = nk - 1 - kt;
-        if (rem >= 2) wait_vmcnt<8>();
-        else if (rem == 1) wait_vmcnt<4>();
-        else wait_vmcnt<0>();
-        barrier_keep_vm();                               // everyone's part of tile kt is visible; stage (kt-1)&3 is free
-        if (kt + 3 < nk) gissue(kt + 3);
-        const unsigned char* As = smem[kt & (PST - 1)][0];
-        const unsigned char* Bs = smem[kt & (PST - 1)][1];
-        bf16x8 af[4], bw[4];
-#pragma unroll
-        for (int i = 0; i < 4; ++i) {
-            const int row = wm * 64 + i * 16 + l15;
-            af[i] = ld<bf16x8>(As + row * 64 + ((g ^ pswz(row)) << 4));
-        }
-#pragma unroll
-        for (int j = 0; j < 4; ++j) {
-            const int row = wn * 64 + j * 16 + l15;
-            bw[j] = ld<bf16x8>(Bs + row * 64 + ((g ^ pswz(row)) << 4));
-        }
-#pragma unroll
-        for (int i = 0; i < 4; ++i)
-#pragma unroll
-            for (int j = 0; j < 4; ++j)
-                acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(bw[j], af[i], acc[i][j], 0, 0, 0);
-    }
-    nt_epilogue<OUT_F32, 4>(p, acc, m0, n0, wm, wn, l15, g);
-}
+// (A BK = 32 variant of this kernel -- three 16-KB LDS stages, loads two K steps ahead with counted s_waitcnt vmcnt,
+// three workgroups per CU -- was measured 40-90 % SLOWER on MI355X: with 64-byte LDS rows every global_load_lds
+// instruction fetches half cache lines, which doubles the request count on the load side that already takes as long
+// as the MFMA side.  Removed; see DESIGN.md.)
 
 // ---------------------------------------------------------------------------------------------- TN (wgrad)
 
@@ -819,16 +747,15 @@ extern "C" int e2k_gemm_nt_bf16(const void* A1, int64_t lda1, int K1, const void
     const int tm = (M + BM - 1) / BM, tn = (N + BN - 1) / BN, T = tm * tn;
     p.probe = flags & (E2K_GEMM_PROBE_NO_LOADS | E2K_GEMM_PROBE_NO_MATH);
     const bool glds = !(flags & E2K_GEMM_NO_GLDS) && (K1 % BK) == 0 && (K2 % BK) == 0;
-    const bool pipe = (flags & E2K_GEMM_PIPE4) && (K1 % PBK) == 0 && (K2 % PBK) == 0;
     // Remainder split (default kernel only): 256 CUs x 2 resident workgroups = 512 tiles per round; a trailing partial
     // round of `rem` tiles would run at rem/512 of the chip (8448 rows x 1024 columns = 528 tiles: the last 16 cost
     // a whole round), so those tiles are cut into `split` K ranges that together fill the chip once more.
     p.full = T; p.split = 1; p.ws = ws;
     int rem = 0;
     const int slots = (flags & E2K_GEMM_TEST_SLOTS8) ? 8 : NT_SLOTS;
-    if (glds && !pipe && ws && !(flags & E2K_GEMM_NO_SPLIT) && T > slots && (T % slots) != 0) {
+    if (glds && ws && !(flags & E2K_GEMM_NO_SPLIT) && T > slots && (T % slots) != 0) {
         rem = T % slots;
-        const int nk = (K1 + K2) / BK;
+        const int nk = (K1 + K2) / BK;          // (heuristics in units of 64-wide K steps for both kernels)
         int split = 1;
         while (split * 2 <= 16 && split * 2 * rem <= slots && split * 2 * 2 <= nk) split *= 2;
         // worth it only when the partial round it removes (about half a round: ~0.5 us per K step, measured) costs more
@@ -840,10 +767,7 @@ extern "C" int e2k_gemm_nt_bf16(const void* A1, int64_t lda1, int K1, const void
     }
     dim3 grid(p.full + rem * p.split), block(256);
     hipStream_t st = (hipStream_t)stream;
-    if (pipe) {
-        if (out_f32) hipLaunchKernelGGL(gemm_nt_pipe_kernel<true>, grid, block, 0, st, p);
-        else hipLaunchKernelGGL(gemm_nt_pipe_kernel<false>, grid, block, 0, st, p);
-    } else if (out_f32) {
+    if (out_f32) {
         if (glds) hipLaunchKernelGGL(gemm_nt_glds_kernel<true>, grid, block, 0, st, p);
         else hipLaunchKernelGGL((gemm_nt_kernel<true, false>), grid, block, 0, st, p);
     } else {

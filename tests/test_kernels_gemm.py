@@ -106,3 +106,4 @@ def test_gemm_tn_colsum(dev, M, N, K, cs_from):
     want = torch.full((N,), 0.5)
     want[cs_from:] += a.float().sum(0)[cs_from:]
     assert torch.allclose(csd.cpu(), want, rtol=1e-4, atol=1e-3), (csd.cpu() - want).abs().max()
+

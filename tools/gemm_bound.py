@@ -17,7 +17,7 @@ def timeit(fn, iters=20, warm=5):
     e.record(); torch.cuda.synchronize()
     return s.elapsed_time(e) / iters
 
-for (M, N, K) in [(8448, 8192, 1024), (8448, 1024, 4096), (8448, 1024, 1024), (33792, 1024, 2048), (33792, 512, 1536), (8448, 3104, 1024), (8448, 3104, 512), (8448, 1024, 8192), (8192, 1024, 4096)]:
+for (M, N, K) in [(8448, 8192, 1024), (8448, 1024, 4096), (8448, 1024, 1024), (33792, 1024, 2048), (33792, 512, 1536), (8448, 3104, 1024), (8448, 3104, 512), (8448, 1024, 8192), (8192, 1024, 4096), (8192, 8192, 1024), (8448, 4096, 512), (8448, 512, 2048)]:
     a = torch.randn(M, K, device=dev).to(bf16); b = torch.randn(N, K, device=dev).to(bf16)
     row = {}
     for name, fl in (('full', 0), ('nosplit', 16), ('no_loads', 4 | 16), ('no_math', 8 | 16), ('neither', 12 | 16)):
