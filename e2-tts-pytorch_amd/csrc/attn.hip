@@ -84,6 +84,8 @@ __device__ __forceinline__ unsigned drop_hash(unsigned hrow, unsigned keypair) {
 
 // soft-clamp: tanh(raw * scale / 50) via one v_exp_f32 and one v_rcp_f32: tanh(x) = 1 - 2 / (2^(2 x log2 e) + 1)
 __device__ __forceinline__ float clamp_tanh(float raw, float k2) { return 1.f - 2.f * fast_rcp(fast_exp2(raw * k2) + 1.f); }
+// cl2 * tanh(.) in one fma after the rcp
+__device__ __forceinline__ float clamp_tanh_scaled(float raw, float k2, float cl2) { return fmaf(-2.f * cl2, fast_rcp(fast_exp2(raw * k2) + 1.f), cl2); }
 
 // the 8 mask bytes (each 0 / 1) of a lane's keys -> 8 bits
 __device__ __forceinline__ unsigned mask_bits(unsigned long long m) { return (unsigned)((m * 0x0102040810204080ull) >> 56); }
@@ -259,6 +261,7 @@ __device__ __forceinline__ void score_tile(const unsigned char* Kt, const bf16x8
 }
 
 
+template <bool DROP>
 __global__ __launch_bounds__(256) void attn_fwd_kernel(AttnArgs p) {
     __shared__ __attribute__((aligned(16))) unsigned char Kt[64 * 128];
     __shared__ __attribute__((aligned(16))) unsigned char Vt[64 * 128];
@@ -301,20 +304,32 @@ __global__ __launch_bounds__(256) void attn_fwd_kernel(AttnArgs p) {
         // mask bits of keys k0 + 32*kk2 + 8g .. +8  (kk2 = t>>1, bit index = 8*kk2 + 4*(t&1) + r)
         const unsigned km = mask_bits(ld<unsigned long long>(p.kmask + (long)b * p.Npad + k0 + g * 8)) |
                             (mask_bits(ld<unsigned long long>(p.kmask + (long)b * p.Npad + k0 + 32 + g * 8)) << 8);
+        // soft-clamp all 16 scores as independent chains (no per-score control flow: the exp2 / rcp pipelines
+        // overlap), then mask; tiles without masked keys (all but the last one or two) skip the selects
+        const bool allk = wave_all(km == 0xffffu);
         float tmax = NEG_MASK;
 #pragma unroll
         for (int t = 0; t < 4; ++t)
 #pragma unroll
-            for (int r = 0; r < 4; ++r) {
-                const bool keep = (km >> (8 * (t >> 1) + 4 * (t & 1) + r)) & 1u;
-                float v = keep ? cl2 * clamp_tanh(s[t][r], k2) : NEG_MASK;
-                s[t][r] = v;
-                tmax = fmaxf(tmax, v);
-            }
+            for (int r = 0; r < 4; ++r) s[t][r] = clamp_tanh_scaled(s[t][r], k2, cl2);
+        if (!allk) {
+#pragma unroll
+            for (int t = 0; t < 4; ++t)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    const bool keep = (km >> (8 * (t >> 1) + 4 * (t & 1) + r)) & 1u;
+                    s[t][r] = keep ? s[t][r] : NEG_MASK;
+                }
+        }
+#pragma unroll
+        for (int t = 0; t < 4; ++t)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) tmax = fmaxf(tmax, s[t][r]);
         tmax = fmaxf(tmax, __shfl_xor(tmax, 16));
         tmax = fmaxf(tmax, __shfl_xor(tmax, 32));
         const float mnew = fmaxf(m, tmax);
-        const float alpha = fast_exp2(m - mnew);
+        const bool same_max = wave_all(mnew == m);          // running maxima settle after the first few tiles
+        const float alpha = same_max ? 1.f : fast_exp2(m - mnew);
         m = mnew;
         float psum = 0.f;
 #pragma unroll
@@ -323,7 +338,7 @@ __global__ __launch_bounds__(256) void attn_fwd_kernel(AttnArgs p) {
             for (int r = 0; r < 4; r += 2) {
                 float p0 = fast_exp2(s[t][r] - mnew), p1 = fast_exp2(s[t][r + 1] - mnew);
                 psum += p0 + p1;
-                if (p.thresh) {      // keys of r, r+1 are an (even, odd) pair; 1/(1-p) is applied once at the end
+                if (DROP) {          // keys of r, r+1 are an (even, odd) pair; 1/(1-p) is applied once at the end
                     const unsigned hh = drop_hash(hrow, (unsigned)(k0 + perm_row(t, 4 * g + r)) >> 1);
                     p0 = (hh & 0xffffu) >= p.thresh ? p0 : 0.f;
                     p1 = (hh >> 16) >= p.thresh ? p1 : 0.f;
@@ -334,8 +349,10 @@ __global__ __launch_bounds__(256) void attn_fwd_kernel(AttnArgs p) {
         psum += __shfl_xor(psum, 16);
         psum += __shfl_xor(psum, 32);
         lsum = lsum * alpha + psum;
+        if (!same_max) {
 #pragma unroll
-        for (int ct = 0; ct < 4; ++ct) o[ct] *= alpha;
+            for (int ct = 0; ct < 4; ++ct) o[ct] *= alpha;
+        }
 #pragma unroll
         for (int kk2 = 0; kk2 < 2; ++kk2) {
             float lo[4] = {s[2 * kk2][0], s[2 * kk2][1], s[2 * kk2][2], s[2 * kk2][3]};
@@ -350,7 +367,7 @@ __global__ __launch_bounds__(256) void attn_fwd_kernel(AttnArgs p) {
         __syncthreads();
     }
     if (!qin) return;
-    const float inv = lsum > 0.f ? (p.thresh ? p.inv_keep : 1.f) / lsum : 0.f;
+    const float inv = lsum > 0.f ? (DROP ? p.inv_keep : 1.f) / lsum : 0.f;
     const float gt = p.gate[bh * p.N + q];
     const bool qkeep = p.kmask[(long)b * p.Npad + q] != 0;
     if (g == 0) p.lse2[bh * p.N + q] = m + log2f(fmaxf(lsum, 1e-37f));
@@ -415,6 +432,7 @@ __global__ __launch_bounds__(256) void attn_bwd_prep_kernel(AttnArgs p) {
 }
 
 // dQ: same sweep as the forward; dS^T tiles feed dQ^T = K^T . dS^T
+template <bool DROP>
 __global__ __launch_bounds__(256) void attn_bwd_dq_kernel(AttnArgs p) {
     __shared__ __attribute__((aligned(16))) unsigned char Kt[64 * 128];
     __shared__ __attribute__((aligned(16))) unsigned char Vr[64 * 128];
@@ -466,25 +484,33 @@ __global__ __launch_bounds__(256) void attn_bwd_dq_kernel(AttnArgs p) {
         score_tile(Vr, dof, l15, g, dp);          // dP^T = V . dO^T  (same operand shapes)
         const unsigned km = mask_bits(ld<unsigned long long>(p.kmask + (long)b * p.Npad + k0 + g * 8)) |
                             (mask_bits(ld<unsigned long long>(p.kmask + (long)b * p.Npad + k0 + 32 + g * 8)) << 8);
+        const bool allk = wave_all(km == 0xffffu);
 #pragma unroll
         for (int t = 0; t < 4; ++t)
 #pragma unroll
             for (int r = 0; r < 4; r += 2) {
                 float ks0 = 1.f, ks1 = 1.f;
-                if (p.thresh) {
+                if (DROP) {
                     const unsigned hh = drop_hash(hrow, (unsigned)(k0 + perm_row(t, 4 * g + r)) >> 1);
                     ks0 = (hh & 0xffffu) >= p.thresh ? p.inv_keep : 0.f;
                     ks1 = (hh >> 16) >= p.thresh ? p.inv_keep : 0.f;
                 }
 #pragma unroll
                 for (int e = 0; e < 2; ++e) {
-                    const bool keep = (km >> (8 * (t >> 1) + 4 * (t & 1) + r + e)) & 1u;
                     const float th = clamp_tanh(s[t][r + e], k2);
                     const float pv = fast_exp2(cl2 * th - lse);
-                    const float ds = pv * (dp[t][r + e] * (e ? ks1 : ks0) - dl) * (1.f - th * th) * p.scale;
-                    s[t][r + e] = keep ? ds : 0.f;
+                    s[t][r + e] = pv * (dp[t][r + e] * (e ? ks1 : ks0) - dl) * (1.f - th * th) * p.scale;
                 }
             }
+        if (!allk) {        // masked keys contribute nothing (only the last tile or two of a sequence)
+#pragma unroll
+            for (int t = 0; t < 4; ++t)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    const bool keep = (km >> (8 * (t >> 1) + 4 * (t & 1) + r)) & 1u;
+                    s[t][r] = keep ? s[t][r] : 0.f;
+                }
+        }
 #pragma unroll
         for (int kk2 = 0; kk2 < 2; ++kk2) {
             float lo[4] = {s[2 * kk2][0], s[2 * kk2][1], s[2 * kk2][2], s[2 * kk2][3]};
@@ -509,6 +535,7 @@ __global__ __launch_bounds__(256) void attn_bwd_dq_kernel(AttnArgs p) {
 
 // dK, dV: one workgroup per 64 keys (a wave owns 16), sweep over query tiles.
 //   S = Q.K^T (rows = queries, permuted inside the tile), P^T-like accumulators feed dV^T = dO^T.P and dK^T = Q^T.dS
+template <bool DROP>
 __global__ __launch_bounds__(256) void attn_bwd_dkv_kernel(AttnArgs p) {
     __shared__ __attribute__((aligned(16))) unsigned char Qt[64 * 128];
     __shared__ __attribute__((aligned(16))) unsigned char dOt[64 * 128];
@@ -585,18 +612,16 @@ __global__ __launch_bounds__(256) void attn_bwd_dkv_kernel(AttnArgs p) {
 #pragma unroll
             for (int r = 0; r < 4; ++r) {
                 const int qi = perm_row(t, 4 * g + r);
-                float pv = 0.f, ds = 0.f;
-                if (kkeep) {
-                    const float th = clamp_tanh(s[t][r], k2);
-                    const float pr = fast_exp2(cl2 * th - lse_s[qi]);
-                    float ks = 1.f;
-                    if (p.thresh) {
-                        const unsigned hh = fmix32(hkey + (unsigned)(q0 + qi) * 0x85ebca77u);
-                        ks = ((key & 1) ? (hh >> 16) : (hh & 0xffffu)) >= p.thresh ? p.inv_keep : 0.f;
-                    }
-                    pv = pr * ks;
-                    ds = pr * (dp[t][r] * ks - del_s[qi]) * (1.f - th * th) * p.scale;
+                // (no key masking here: a lane's scores all belong to ITS key, whose dK / dV row is zeroed at the end)
+                const float th = clamp_tanh(s[t][r], k2);
+                const float pr = fast_exp2(cl2 * th - lse_s[qi]);
+                float ks = 1.f;
+                if (DROP) {
+                    const unsigned hh = fmix32(hkey + (unsigned)(q0 + qi) * 0x85ebca77u);
+                    ks = ((key & 1) ? (hh >> 16) : (hh & 0xffffu)) >= p.thresh ? p.inv_keep : 0.f;
                 }
+                const float pv = pr * ks;
+                const float ds = pr * (dp[t][r] * ks - del_s[qi]) * (1.f - th * th) * p.scale;
                 pd[t][r] = pv;
                 dsv[t][r] = ds;
             }
@@ -618,8 +643,9 @@ __global__ __launch_bounds__(256) void attn_bwd_dkv_kernel(AttnArgs p) {
     const long orow = (bh * p.N + key) * DH;
 #pragma unroll
     for (int ct = 0; ct < 4; ++ct) {
-        float a[4] = {dk[ct][0], dk[ct][1], dk[ct][2], dk[ct][3]};
-        float c[4] = {dv[ct][0], dv[ct][1], dv[ct][2], dv[ct][3]};
+        float a[4], c[4];
+#pragma unroll
+        for (int r = 0; r < 4; ++r) { a[r] = kkeep ? dk[ct][r] : 0.f; c[r] = kkeep ? dv[ct][r] : 0.f; }
         st<u32x2>(p.dK + orow + ct * 16 + 4 * g, pack4(a));
         st<u32x2>(p.dV + orow + ct * 16 + 4 * g, pack4(c));
     }
@@ -681,7 +707,8 @@ extern "C" int e2k_attn_fwd(const void* Q, const void* K, const void* VT, const 
     if (rc) return rc;
     a.Q = (const bf16_t*)Q; a.K = (const bf16_t*)K; a.VT = (const bf16_t*)VT; a.kmask = kmask; a.gate = gate;
     a.O = (bf16_t*)O; a.Og = (bf16_t*)Og; a.lse2 = lse2;
-    hipLaunchKernelGGL(attn_fwd_kernel, dim3((N + 63) / 64, H, B), dim3(256), 0, (hipStream_t)stream, a);
+    if (a.thresh) hipLaunchKernelGGL(attn_fwd_kernel<true>, dim3((N + 63) / 64, H, B), dim3(256), 0, (hipStream_t)stream, a);
+    else hipLaunchKernelGGL(attn_fwd_kernel<false>, dim3((N + 63) / 64, H, B), dim3(256), 0, (hipStream_t)stream, a);
     E2K_CHECK_LAUNCH();
     return 0;
 }
@@ -705,9 +732,11 @@ extern "C" int e2k_attn_bwd(const void* dOg, const void* O, const float* gate, c
     hipStream_t st = (hipStream_t)stream;
     hipLaunchKernelGGL(attn_bwd_prep_kernel, dim3(Npad / 64, H, B), dim3(256), 0, st, a);
     E2K_CHECK_LAUNCH();
-    hipLaunchKernelGGL(attn_bwd_dq_kernel, dim3((N + 63) / 64, H, B), dim3(256), 0, st, a);
+    if (a.thresh) hipLaunchKernelGGL(attn_bwd_dq_kernel<true>, dim3((N + 63) / 64, H, B), dim3(256), 0, st, a);
+    else hipLaunchKernelGGL(attn_bwd_dq_kernel<false>, dim3((N + 63) / 64, H, B), dim3(256), 0, st, a);
     E2K_CHECK_LAUNCH();
-    hipLaunchKernelGGL(attn_bwd_dkv_kernel, dim3((N + 63) / 64, H, B), dim3(256), 0, st, a);
+    if (a.thresh) hipLaunchKernelGGL(attn_bwd_dkv_kernel<true>, dim3((N + 63) / 64, H, B), dim3(256), 0, st, a);
+    else hipLaunchKernelGGL(attn_bwd_dkv_kernel<false>, dim3((N + 63) / 64, H, B), dim3(256), 0, st, a);
     E2K_CHECK_LAUNCH();
     return 0;
 }

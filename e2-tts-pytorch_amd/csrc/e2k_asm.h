@@ -91,6 +91,9 @@ __device__ __forceinline__ float lane_bcast(float v, int L) {
 }
 __device__ __forceinline__ float fast_rsq(float x) { return __builtin_amdgcn_rsqf(x); }
 
+// wave vote: true when the predicate holds in every lane (all 64 lanes active at the call sites)
+__device__ __forceinline__ bool wave_all(bool pred) { return __builtin_amdgcn_ballot_w64(pred) == ~0ull; }
+
 // counted wait on outstanding vector-memory ops (LDS-DMA included) and a raw workgroup barrier that does NOT drain
 // them: lets global_load_lds prefetches stay in flight across barriers (cdna_hip_programming.md T3+T4)
 template <int N> __device__ __forceinline__ void wait_vmcnt() { asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory"); }
