@@ -262,7 +262,7 @@ __device__ __forceinline__ void score_tile(const unsigned char* Kt, const bf16x8
 
 
 template <bool DROP>
-__global__ __launch_bounds__(256) void attn_fwd_kernel(AttnArgs p) {
+__global__ __launch_bounds__(256, 2) void attn_fwd_kernel(AttnArgs p) {
     __shared__ __attribute__((aligned(16))) unsigned char Kt[64 * 128];
     __shared__ __attribute__((aligned(16))) unsigned char Vt[64 * 128];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -433,7 +433,7 @@ __global__ __launch_bounds__(256) void attn_bwd_prep_kernel(AttnArgs p) {
 
 // dQ: same sweep as the forward; dS^T tiles feed dQ^T = K^T . dS^T
 template <bool DROP>
-__global__ __launch_bounds__(256) void attn_bwd_dq_kernel(AttnArgs p) {
+__global__ __launch_bounds__(256, 2) void attn_bwd_dq_kernel(AttnArgs p) {
     __shared__ __attribute__((aligned(16))) unsigned char Kt[64 * 128];
     __shared__ __attribute__((aligned(16))) unsigned char Vr[64 * 128];
     __shared__ __attribute__((aligned(16))) unsigned char KTt[64 * 128];
@@ -536,7 +536,7 @@ __global__ __launch_bounds__(256) void attn_bwd_dq_kernel(AttnArgs p) {
 // dK, dV: one workgroup per 64 keys (a wave owns 16), sweep over query tiles.
 //   S = Q.K^T (rows = queries, permuted inside the tile), P^T-like accumulators feed dV^T = dO^T.P and dK^T = Q^T.dS
 template <bool DROP>
-__global__ __launch_bounds__(256) void attn_bwd_dkv_kernel(AttnArgs p) {
+__global__ __launch_bounds__(256, 2) void attn_bwd_dkv_kernel(AttnArgs p) {
     __shared__ __attribute__((aligned(16))) unsigned char Qt[64 * 128];
     __shared__ __attribute__((aligned(16))) unsigned char dOt[64 * 128];
     __shared__ __attribute__((aligned(16))) unsigned char QTt[64 * 128];
