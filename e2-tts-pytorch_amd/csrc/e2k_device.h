@@ -99,6 +99,20 @@ template <int VEC, int NCH> __device__ __forceinline__ void store_row(bf16_t* ro
 #pragma unroll
     for (int c = 0; c < NCH; ++c) store_vec<VEC>(row + c * 64 * VEC + lane * VEC, f + c * VEC);
 }
+// packed (raw bf16 pairs) row loads for software prefetch: half the registers of the unpacked floats
+template <int VEC, int NCH> __device__ __forceinline__ void load_raw_row(const bf16_t* row, int lane, unsigned* w) {
+#pragma unroll
+    for (int c = 0; c < NCH; ++c) {
+        const bf16_t* q = row + c * 64 * VEC + lane * VEC;
+        if (VEC == 8) { u32x4 v = ld<u32x4>(q); w[c * 4] = v[0]; w[c * 4 + 1] = v[1]; w[c * 4 + 2] = v[2]; w[c * 4 + 3] = v[3]; }
+        else if (VEC == 4) { u32x2 v = ld<u32x2>(q); w[c * 2] = v[0]; w[c * 2 + 1] = v[1]; }
+        else w[c] = ld<unsigned>(q);
+    }
+}
+template <int N> __device__ __forceinline__ void unpack_raw_row(const unsigned* w, float* f) {
+#pragma unroll
+    for (int i = 0; i < N / 2; ++i) { f[2 * i] = bflo(w[i]); f[2 * i + 1] = bfhi(w[i]); }
+}
 template <int VEC, int NCH> __device__ __forceinline__ void load_row_f32(const float* row, int lane, float* f) {
 #pragma unroll
     for (int c = 0; c < NCH; ++c)

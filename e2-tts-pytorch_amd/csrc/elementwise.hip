@@ -5,6 +5,7 @@
 //   depthwise conv k=31 + SiLU       DepthwiseConv                            (e2_tts.py:295-328)
 //   column sums (bias gradients), fp32 -> bf16 parameter shadow casts.
 #include "e2k_device.h"
+#include <e2k_asm.h>
 #include "../../include/e2k.h"
 
 using namespace e2k;
@@ -56,12 +57,25 @@ __global__ __launch_bounds__(256) void rmsnorm_bwd_kernel(NormArgs p) {
     load_row_f32<VEC, NCH>(p.gamma + (long)b * p.ldg, lane, g);
 #pragma unroll
     for (int e = 0; e < EPL; ++e) { g[e] += p.gamma_off; dg[e] = 0.f; }
-    for (int i = blockIdx.x * 4 + wave; i < nrows; i += gridDim.x * 4) {
+    // the next row of this wave is fetched (packed bf16 pairs) while the current one is processed
+    unsigned rx[EPL / 2], rdy[EPL / 2];
+    float rnn = 0.f;
+    const int step = gridDim.x * 4;
+    int i = blockIdx.x * 4 + wave;
+    auto prefetch = [&](int ii) {
+        const long row = row0 + min(ii, nrows - 1);
+        load_raw_row<VEC, NCH>(p.x + row * D, lane, rx);
+        load_raw_row<VEC, NCH>(p.dy + row * D, lane, rdy);
+        rnn = p.rn[row];
+    };
+    if (i < nrows) prefetch(i);
+    for (; i < nrows; i += step) {
         const long row = row0 + i;
         float x[EPL], dy[EPL];
-        load_row<VEC, NCH>(p.x + row * D, lane, x);
-        load_row<VEC, NCH>(p.dy + row * D, lane, dy);
-        const float rn = p.rn[row];
+        unpack_raw_row<EPL>(rx, x);
+        unpack_raw_row<EPL>(rdy, dy);
+        const float rn = rnn;
+        prefetch(i + step);
         float dot = 0.f;
 #pragma unroll
         for (int e = 0; e < EPL; ++e) {
@@ -70,7 +84,7 @@ __global__ __launch_bounds__(256) void rmsnorm_bwd_kernel(NormArgs p) {
             dy[e] *= g[e];                    // t
             dot = fmaf(dy[e], x[e], dot);
         }
-        dot = wave_sum(dot);
+        dot = wave_sum_fast(dot);
         const float sc = rn * sqrtD;
 #pragma unroll
         for (int e = 0; e < EPL; ++e) dy[e] = sc * (dy[e] - x[e] * dot);
@@ -92,8 +106,10 @@ template <int VEC, int NCH> int launch_norm_fwd(const NormArgs& a, hipStream_t s
 }
 template <int VEC, int NCH> int launch_norm_bwd(const NormArgs& a, hipStream_t st) {
     const int nb = (a.M + a.rows_per_batch - 1) / a.rows_per_batch;
+    // ~512 workgroups in all: every workgroup ends with D atomic adds into d(gamma), and with one gamma row (plain
+    // RMSNorm) all of them hit the same D addresses
     int per = (min(a.rows_per_batch, a.M) + 3) / 4;
-    int cap = (1024 + nb - 1) / nb;
+    int cap = (512 + nb - 1) / nb;
     if (per > cap) per = cap;
     hipLaunchKernelGGL((rmsnorm_bwd_kernel<VEC, NCH>), dim3(per, nb), dim3(256), 0, st, a);
     return 0;
@@ -243,6 +259,7 @@ __global__ __launch_bounds__(256) void cast_transpose_kernel(const float* src, b
 // ------------------------------------------------------------------------------------------------ depthwise conv + SiLU
 // channels-last: x (B, N, C); block = 64 frames x 64 channels of one batch row; thread = 2 channels x 8 frames.
 
+typedef float f32x2_ __attribute__((ext_vector_type(2)));
 constexpr int CTN = 64, CTC = 64;
 
 struct ConvArgs {
@@ -255,37 +272,51 @@ struct ConvArgs {
 template <int KS>
 __global__ __launch_bounds__(256) void dwconv_fwd_kernel(ConvArgs p) {
     constexpr int PAD = KS / 2, ROWS = CTN + KS - 1;
-    __shared__ unsigned xt[ROWS][CTC / 2];
+    __shared__ __attribute__((aligned(16))) unsigned xt[ROWS][CTC / 2];
     const int tid = threadIdx.x;
     const int n0 = blockIdx.x * CTN, c0 = blockIdx.y * CTC, b = blockIdx.z;
-    for (int i = tid; i < ROWS * (CTC / 2); i += 256) {
-        int j = i / (CTC / 2), cp = i % (CTC / 2);
-        int n = n0 - PAD + j;
-        unsigned v = 0u;
-        if (n >= 0 && n < p.N && (p.mask == nullptr || p.mask[(long)b * p.N + n]))
-            v = ld<unsigned>(p.x + ((long)b * p.N + n) * p.C + c0 + cp * 2);
-        xt[j][cp] = v;
+    {   // tile load: 16 bytes (8 channels) per item, all loads of a thread issued before any is consumed
+        constexpr int ITEMS = ROWS * (CTC / 8), NIT = (ITEMS + 255) / 256;
+        u32x4 v[NIT];
+#pragma unroll
+        for (int it = 0; it < NIT; ++it) {
+            const int i = tid + it * 256;
+            const int j = i / (CTC / 8), c8 = (i % (CTC / 8)) * 8;
+            const int n = n0 - PAD + j;
+            const int nc = min(max(n, 0), p.N - 1);
+            const u32x4 raw = ld<u32x4>(p.x + ((long)b * p.N + nc) * p.C + c0 + c8);     // (c8 < CTC for any i)
+            const unsigned char mk = p.mask ? p.mask[(long)b * p.N + nc] : (unsigned char)1;
+            v[it] = (n >= 0 && n < p.N && mk != 0) ? raw : u32x4{0u, 0u, 0u, 0u};
+        }
+#pragma unroll
+        for (int it = 0; it < NIT; ++it) {
+            const int i = tid + it * 256;
+            if (i < ITEMS) st<u32x4>(&xt[i / (CTC / 8)][(i % (CTC / 8)) * 4], v[it]);
+        }
     }
     const int cp = tid & 31, fg = tid >> 5;
     const int ch = c0 + cp * 2;
-    float w0[KS], w1[KS];
+    f32x2_ w[KS];          // (channel ch, channel ch + 1) pairs: one v_pk_fma_f32 per tap and frame
 #pragma unroll
-    for (int k = 0; k < KS; ++k) { w0[k] = p.w[(long)ch * KS + k]; w1[k] = p.w[(long)(ch + 1) * KS + k]; }
-    const float b0 = p.bias[ch], b1 = p.bias[ch + 1];
+    for (int k = 0; k < KS; ++k) w[k] = f32x2_{p.w[(long)ch * KS + k], p.w[(long)(ch + 1) * KS + k]};
+    const f32x2_ bb = {p.bias[ch], p.bias[ch + 1]};
     __syncthreads();
-    float a0[8], a1[8];
+    f32x2_ a[8];
 #pragma unroll
-    for (int o = 0; o < 8; ++o) { a0[o] = b0; a1[o] = b1; }
+    for (int o = 0; o < 8; ++o) a[o] = bb;
 #pragma unroll
     for (int i = 0; i < 8 + KS - 1; ++i) {
-        unsigned v = xt[fg * 8 + i][cp];
-        float x0 = bflo(v), x1 = bfhi(v);
+        const unsigned v = xt[fg * 8 + i][cp];
+        const f32x2_ xx = {bflo(v), bfhi(v)};
 #pragma unroll
         for (int o = 0; o < 8; ++o) {
             const int k = i - o;
-            if (k >= 0 && k < KS) { a0[o] = fmaf(w0[k], x0, a0[o]); a1[o] = fmaf(w1[k], x1, a1[o]); }
+            if (k >= 0 && k < KS) a[o] = __builtin_elementwise_fma(w[k], xx, a[o]);
         }
     }
+    float a0[8], a1[8];
+#pragma unroll
+    for (int o = 0; o < 8; ++o) { a0[o] = a[o][0]; a1[o] = a[o][1]; }
 #pragma unroll
     for (int o = 0; o < 8; ++o) {
         const int n = n0 + fg * 8 + o;
@@ -301,7 +332,7 @@ __global__ __launch_bounds__(256) void dwconv_fwd_kernel(ConvArgs p) {
 __device__ __forceinline__ float silu_grad(float x) { float s = sigmoidf_(x); return s * (1.f + x * (1.f - s)); }
 
 template <int KS>
-__global__ __launch_bounds__(256) void dwconv_bwd_kernel(ConvArgs p) {
+__global__ __launch_bounds__(256, 2) void dwconv_bwd_kernel(ConvArgs p) {
     constexpr int PAD = KS / 2, ROWS = CTN + KS - 1;
     __shared__ __attribute__((aligned(16))) float dpt[ROWS][CTC];       // d(pre-activation), frame n0 - PAD + j
     __shared__ __attribute__((aligned(16))) float xt[ROWS][CTC];        // masked input,      frame n0 - PAD + j
@@ -311,52 +342,78 @@ __global__ __launch_bounds__(256) void dwconv_bwd_kernel(ConvArgs p) {
     const int cp = tid & 31, fg = tid >> 5;
     const int ch = c0 + cp * 2;
     for (int i = tid; i < CTC * (KS + 1); i += 256) (&dwl[0][0])[i] = 0.f;
-    float w0[KS], w1[KS];     // flipped
+    // channel pair (ch, ch+1) lives in the two halves of 64-bit register pairs: every FMA below is one v_pk_fma_f32
+    // whose operands are already adjacent (separate per-channel arrays cost a v_mov per operand to form the pairs)
+    f32x2_ w[KS];     // flipped
 #pragma unroll
-    for (int k = 0; k < KS; ++k) { w0[k] = p.w[(long)ch * KS + (KS - 1 - k)]; w1[k] = p.w[(long)(ch + 1) * KS + (KS - 1 - k)]; }
+    for (int k = 0; k < KS; ++k) w[k] = f32x2_{p.w[(long)ch * KS + (KS - 1 - k)], p.w[(long)(ch + 1) * KS + (KS - 1 - k)]};
     // weight / bias gradient partials stay in registers over all frame tiles of this workgroup (p.tiles_per_block):
     // one LDS + global atomic flush per workgroup instead of per tile
-    float g0[KS], g1[KS], s0 = 0.f, s1 = 0.f;
+    f32x2_ gw[KS], sb = {0.f, 0.f};
 #pragma unroll
-    for (int k = 0; k < KS; ++k) { g0[k] = 0.f; g1[k] = 0.f; }
+    for (int k = 0; k < KS; ++k) gw[k] = f32x2_{0.f, 0.f};
     const int ntiles = (p.N + CTN - 1) / CTN;
     const int t_beg = blockIdx.x * p.tiles_per_block, t_end = min(ntiles, t_beg + p.tiles_per_block);
     for (int tile = t_beg; tile < t_end; ++tile) {
         const int n0 = tile * CTN;
         __syncthreads();                  // previous tile fully consumed (also orders the dwl zero-fill)
-        for (int i = tid; i < ROWS * (CTC / 8); i += 256) {          // 8 channels (16 B) per item
-            const int j = i / (CTC / 8), c8 = (i % (CTC / 8)) * 8;
-            const int n = n0 - PAD + j;
-            float d[8], x[8];
+        // 8 channels (16 B) per item; the loads of two items (6 x 16 B) are in flight together (the weight / gradient
+        // registers of this kernel leave no room for more)
+        constexpr int ITEMS = ROWS * (CTC / 8), NIT = (ITEMS + 255) / 256;
 #pragma unroll
-            for (int e = 0; e < 8; ++e) { d[e] = 0.f; x[e] = 0.f; }
-            if (n >= 0 && n < p.N && (p.mask == nullptr || p.mask[(long)b * p.N + n])) {
-                const long off = ((long)b * p.N + n) * p.C + c0 + c8;
-                float pr[8];
-                unpack8(ld<u32x4>(p.dy + off), d);
-                unpack8(ld<u32x4>(p.pre + off), pr);
-                unpack8(ld<u32x4>(p.x + off), x);
+        for (int it0 = 0; it0 < NIT; it0 += 2) {
+            u32x4 rd[2], rp[2], rx[2];
+            bool live[2];
 #pragma unroll
-                for (int e = 0; e < 8; ++e) d[e] *= silu_grad(pr[e]);
+            for (int u = 0; u < 2; ++u) {
+                const int i = tid + (it0 + u) * 256;
+                const int j = i / (CTC / 8), c8 = (i % (CTC / 8)) * 8;
+                const int n = n0 - PAD + j;
+                // unconditional loads from a clamped row, mask byte fetched alongside (a load that depends on the mask
+                // byte costs a second memory latency per item)
+                const int nc = min(max(n, 0), p.N - 1), jc = min(j, ROWS - 1);
+                const long off = ((long)b * p.N + nc) * p.C + c0 + (i < ITEMS ? c8 : 0);
+                (void)jc;
+                rd[u] = ld<u32x4>(p.dy + off);
+                rp[u] = ld<u32x4>(p.pre + off);
+                rx[u] = ld<u32x4>(p.x + off);
+                const unsigned char mk = p.mask ? p.mask[(long)b * p.N + nc] : (unsigned char)1;
+                live[u] = it0 + u < NIT && i < ITEMS && n >= 0 && n < p.N && mk != 0;
             }
-            st<f32x4>(&dpt[j][c8], f32x4{d[0], d[1], d[2], d[3]});
-            st<f32x4>(&dpt[j][c8 + 4], f32x4{d[4], d[5], d[6], d[7]});
-            st<f32x4>(&xt[j][c8], f32x4{x[0], x[1], x[2], x[3]});
-            st<f32x4>(&xt[j][c8 + 4], f32x4{x[4], x[5], x[6], x[7]});
+#pragma unroll
+            for (int u = 0; u < 2; ++u) {
+                const int i = tid + (it0 + u) * 256;
+                if (it0 + u >= NIT || i >= ITEMS) continue;
+                const int j = i / (CTC / 8), c8 = (i % (CTC / 8)) * 8;
+                float d[8], x[8];
+#pragma unroll
+                for (int e = 0; e < 8; ++e) { d[e] = 0.f; x[e] = 0.f; }
+                if (live[u]) {
+                    float pr[8];
+                    unpack8(rd[u], d);
+                    unpack8(rp[u], pr);
+                    unpack8(rx[u], x);
+#pragma unroll
+                    for (int e = 0; e < 8; ++e) d[e] *= silu_grad(pr[e]);
+                }
+                st<f32x4>(&dpt[j][c8], f32x4{d[0], d[1], d[2], d[3]});
+                st<f32x4>(&dpt[j][c8 + 4], f32x4{d[4], d[5], d[6], d[7]});
+                st<f32x4>(&xt[j][c8], f32x4{x[0], x[1], x[2], x[3]});
+                st<f32x4>(&xt[j][c8 + 4], f32x4{x[4], x[5], x[6], x[7]});
+            }
         }
         __syncthreads();
         // dx[o] = sum_k' wflip[k'] dp_tile[o + k']
-        float a0[8], a1[8];
+        f32x2_ a[8];
 #pragma unroll
-        for (int o = 0; o < 8; ++o) { a0[o] = 0.f; a1[o] = 0.f; }
+        for (int o = 0; o < 8; ++o) a[o] = f32x2_{0.f, 0.f};
 #pragma unroll
         for (int i = 0; i < 8 + KS - 1; ++i) {
-            const float2 dd = ld<float2>(&dpt[fg * 8 + i][cp * 2]);
-            const float d0 = dd.x, d1 = dd.y;
+            const f32x2_ dd = ld<f32x2_>(&dpt[fg * 8 + i][cp * 2]);
 #pragma unroll
             for (int o = 0; o < 8; ++o) {
                 const int k = i - o;
-                if (k >= 0 && k < KS) { a0[o] = fmaf(w0[k], d0, a0[o]); a1[o] = fmaf(w1[k], d1, a1[o]); }
+                if (k >= 0 && k < KS) a[o] = __builtin_elementwise_fma(w[k], dd, a[o]);
             }
         }
 #pragma unroll
@@ -364,35 +421,31 @@ __global__ __launch_bounds__(256) void dwconv_bwd_kernel(ConvArgs p) {
             const int n = n0 + fg * 8 + o;
             if (n < p.N) {
                 const bool keep = p.mask == nullptr || p.mask[(long)b * p.N + n];
-                st<unsigned>(p.dx + ((long)b * p.N + n) * p.C + ch, keep ? pack2bf(a0[o], a1[o]) : 0u);
+                st<unsigned>(p.dx + ((long)b * p.N + n) * p.C + ch, keep ? pack2bf(a[o][0], a[o][1]) : 0u);
             }
         }
         // dw[k] += sum_o dp_tile[o + PAD] * x_tile[o + k]
-        float dq0[8], dq1[8];
+        f32x2_ dq[8];
 #pragma unroll
         for (int o = 0; o < 8; ++o) {
-            const float2 dd = ld<float2>(&dpt[fg * 8 + o + PAD][cp * 2]);
-            dq0[o] = dd.x;
-            dq1[o] = dd.y;
-            s0 += dq0[o];
-            s1 += dq1[o];
+            dq[o] = ld<f32x2_>(&dpt[fg * 8 + o + PAD][cp * 2]);
+            sb += dq[o];
         }
 #pragma unroll
         for (int i = 0; i < 8 + KS - 1; ++i) {
-            const float2 xx = ld<float2>(&xt[fg * 8 + i][cp * 2]);
-            const float x0 = xx.x, x1 = xx.y;
+            const f32x2_ xx = ld<f32x2_>(&xt[fg * 8 + i][cp * 2]);
 #pragma unroll
             for (int o = 0; o < 8; ++o) {
                 const int k = i - o;
-                if (k >= 0 && k < KS) { g0[k] = fmaf(dq0[o], x0, g0[k]); g1[k] = fmaf(dq1[o], x1, g1[k]); }
+                if (k >= 0 && k < KS) gw[k] = __builtin_elementwise_fma(dq[o], xx, gw[k]);
             }
         }
     }
     __syncthreads();
 #pragma unroll
-    for (int k = 0; k < KS; ++k) { atomicAdd(&dwl[cp * 2][k], g0[k]); atomicAdd(&dwl[cp * 2 + 1][k], g1[k]); }
-    atomicAdd(&dwl[cp * 2][KS], s0);
-    atomicAdd(&dwl[cp * 2 + 1][KS], s1);
+    for (int k = 0; k < KS; ++k) { atomicAdd(&dwl[cp * 2][k], gw[k][0]); atomicAdd(&dwl[cp * 2 + 1][k], gw[k][1]); }
+    atomicAdd(&dwl[cp * 2][KS], sb[0]);
+    atomicAdd(&dwl[cp * 2 + 1][KS], sb[1]);
     __syncthreads();
     for (int i = tid; i < CTC * (KS + 1); i += 256) {
         int c = i / (KS + 1), k = i % (KS + 1);
