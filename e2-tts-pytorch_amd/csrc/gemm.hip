@@ -59,8 +59,8 @@ struct NTArgs {
 // epilogue of an interior tile (all 128 x 128 outputs exist, rows 8-byte aligned): no per-element bounds checks, the
 // optional operands are selected once per tile (wave-uniform), bias kept in registers across the 4 row groups
 template <bool OUT_F32, bool HAS_CS, bool HAS_RES, int NI>
-__device__ __forceinline__ void nt_epilogue_full(const NTArgs& p, f32x4 (&acc)[NI][4], int m0, int n0, int wm, int wn, int l15, int g) {
-    const int nb = n0 + wn * 64 + 4 * g;
+__device__ __forceinline__ void nt_epilogue_full(const NTArgs& p, f32x4 (&acc)[NI][4], int mw, int nw, int l15, int g) {
+    const int nb = nw + 4 * g;
     f32x4 bias4[4];
 #pragma unroll
     for (int j = 0; j < 4; ++j) {
@@ -72,7 +72,7 @@ __device__ __forceinline__ void nt_epilogue_full(const NTArgs& p, f32x4 (&acc)[N
     }
 #pragma unroll
     for (int i = 0; i < NI; ++i) {
-        const int m = m0 + wm * 64 + i * 16 + l15;
+        const int m = mw + i * 16 + l15;
         const float rm = p.rowmask ? (p.rowmask[m] ? 1.f : 0.f) : 1.f;
         const float* cs = HAS_CS ? p.colscale + (long)(m / p.rows_per_batch) * p.lds : nullptr;
 #pragma unroll
@@ -102,29 +102,30 @@ __device__ __forceinline__ void nt_epilogue_full(const NTArgs& p, f32x4 (&acc)[N
     }
 }
 
-// epilogue shared by the NT kernels: lane holds C[m][n..n+3], m = m0+wm*64+i*16+l15 (i < NI), n = n0+wn*64+j*16+4g
+// epilogue shared by the NT kernels.  (mw, nw) = first row / column of this wave's (16 NI) x 64 sub-tile; lane holds
+// C[m][n..n+3], m = mw + i*16 + l15 (i < NI), n = nw + j*16 + 4g
 template <bool OUT_F32, int NI>
-__device__ __forceinline__ void nt_epilogue(const NTArgs& p, f32x4 (&acc)[NI][4], int m0, int n0, int wm, int wn, int l15, int g) {
+__device__ __forceinline__ void nt_epilogue(const NTArgs& p, f32x4 (&acc)[NI][4], int mw, int nw, int l15, int g) {
     const bool vec_ok = (p.ldc & 3) == 0 && (p.resid == nullptr || (p.ldr & 3) == 0);
-    if (vec_ok && m0 + BM <= p.M && n0 + BN <= p.N) {       // wave-uniform
+    if (vec_ok && mw + NI * 16 <= p.M && nw + 64 <= p.N) {       // wave-uniform: the whole sub-tile exists
         if (p.colscale) {
-            if (p.resid) nt_epilogue_full<OUT_F32, true, true, NI>(p, acc, m0, n0, wm, wn, l15, g);
-            else nt_epilogue_full<OUT_F32, true, false, NI>(p, acc, m0, n0, wm, wn, l15, g);
+            if (p.resid) nt_epilogue_full<OUT_F32, true, true, NI>(p, acc, mw, nw, l15, g);
+            else nt_epilogue_full<OUT_F32, true, false, NI>(p, acc, mw, nw, l15, g);
         } else {
-            if (p.resid) nt_epilogue_full<OUT_F32, false, true, NI>(p, acc, m0, n0, wm, wn, l15, g);
-            else nt_epilogue_full<OUT_F32, false, false, NI>(p, acc, m0, n0, wm, wn, l15, g);
+            if (p.resid) nt_epilogue_full<OUT_F32, false, true, NI>(p, acc, mw, nw, l15, g);
+            else nt_epilogue_full<OUT_F32, false, false, NI>(p, acc, mw, nw, l15, g);
         }
         return;
     }
 #pragma unroll
     for (int i = 0; i < NI; ++i) {
-        const int m = m0 + wm * 64 + i * 16 + l15;
+        const int m = mw + i * 16 + l15;
         if (m >= p.M) continue;
         const float rm = p.rowmask ? (p.rowmask[m] ? 1.f : 0.f) : 1.f;
         const float* cs = p.colscale ? p.colscale + (long)(m / p.rows_per_batch) * p.lds : nullptr;
 #pragma unroll
         for (int j = 0; j < 4; ++j) {
-            const int n = n0 + wn * 64 + j * 16 + 4 * g;
+            const int n = nw + j * 16 + 4 * g;
             if (n >= p.N) continue;
             float v[4];
 #pragma unroll
@@ -283,7 +284,7 @@ __global__ __launch_bounds__(256) void gemm_nt_kernel(NTArgs p) {
         __syncthreads();
     }
 
-    nt_epilogue<OUT_F32, 4>(p, acc, m0, n0, wm, wn, l15, g);
+    nt_epilogue<OUT_F32, 4>(p, acc, m0 + wm * 64, n0 + wn * 64, l15, g);
 }
 
 // Default NT kernel: global_load_lds staging, two 32-KB LDS buffers, BK = 64, one barrier per K step.
@@ -407,7 +408,7 @@ __global__ __launch_bounds__(256, 2) void gemm_nt_glds_kernel(NTArgs p) {
             for (int j = 0; j < 4; ++j) st<f32x4>(w + (i * 4 + j) * 1024, acc[i][j]);
         return;
     }
-    nt_epilogue<OUT_F32, 4>(p, acc, m0, n0, wm, wn, l15, g);
+    nt_epilogue<OUT_F32, 4>(p, acc, m0 + wm * 64, n0 + wn * 64, l15, g);
 }
 
 // sums the K-range partials of a 16-row group (blockIdx.y = i) of one remainder tile (blockIdx.x), same thread <->
@@ -429,9 +430,142 @@ __global__ __launch_bounds__(256) void gemm_nt_fixup_kernel(NTArgs p) {
 #pragma unroll
         for (int j = 0; j < 4; ++j) acc[0][j] += ld<f32x4>(w + ((long)sidx * 16 + j) * 1024);
     }
-    // (rows m0 + wm*64 + i*16 + l15: pass the tile origin shifted by the row group; a shifted origin only ever makes
-    // the interior-tile test more conservative)
-    nt_epilogue<OUT_F32, 1>(p, acc, tile_m * BM + i * 16, tile_n * BN, wm, wn, l15, g);
+    nt_epilogue<OUT_F32, 1>(p, acc, tile_m * BM + wm * 64 + i * 16, tile_n * BN + wn * 64, l15, g);
+}
+
+// Large-tile NT kernel: 256 x 128 x 64 tile, EIGHT waves of 64 x 64 (512 threads, two waves per SIMD), THREE 48-KB LDS
+// stages (144 of the CU's 160 KB: one workgroup per CU), global_load_lds prefetch two K steps ahead with a counted
+// s_waitcnt vmcnt and a raw s_barrier so that the prefetches stay in flight across the barrier.  Per flop it moves
+// 25 % fewer bytes through the texture path than the 128 x 128 kernel (whose load side takes as long as its MFMAs).
+// Same LDS row layout / swizzle, epilogue and remainder split as the kernel above.  OPT-IN (flag E2K_GEMM_BIG): on MI355X
+// it only matches the 128 x 128 kernel on its best shape (8192 x 1024 x 4096: 65.7 vs 65.3 us) and is 5-15 % slower on
+// the others -- one workgroup per CU means every barrier stalls the whole CU.  (A 4-wave version with 128 x 64 per
+// wave -- one wave per SIMD -- ran 20-25 % slower still: nothing covers a wave's LDS waits.)
+constexpr int GBM = 256, GST = 3, GSTAGE = (GBM + BN) * BK * 2, GTHREADS = 512;
+
+template <bool OUT_F32>
+__global__ __launch_bounds__(GTHREADS, 1) void gemm_nt_big_kernel(NTArgs p) {
+    __shared__ __attribute__((aligned(16))) unsigned char smem[GST][GSTAGE];
+    const int tid = threadIdx.x, lane = tid & 63, wave = uniform_i(tid >> 6);
+    const int wm = wave >> 1, wn = wave & 1;          // 4 x 2 waves of 64 x 64
+    const int l15 = lane & 15, g = lane >> 4;
+    const int tm = (p.M + GBM - 1) / GBM, tn = (p.N + BN - 1) / BN;
+    int tile_m, tile_n;
+    const int nk1 = p.K1 / BK, nk = (p.K1 + p.K2) / BK;
+    int kb = 0, ke = nk, part = -1;
+    if ((int)blockIdx.x < p.full) {
+        tile_coords(xcd_remap(blockIdx.x, p.full), tm, tn, tile_m, tile_n);
+    } else {
+        part = blockIdx.x - p.full;
+        const int r = part / p.split, sidx = part - r * p.split;
+        tile_coords(p.full + r, tm, tn, tile_m, tile_n);
+        kb = (int)((long)nk * sidx / p.split);
+        ke = (int)((long)nk * (sidx + 1) / p.split);
+    }
+    const int m0 = tile_m * GBM, n0 = tile_n * BN;
+
+    // A offsets: the second K panel (A2) is addressed as va1 + dv (never two arrays behind a select: the compiler turns
+    // that into a pointer select and parks both arrays in scratch)
+    unsigned va1[4], dv[4], vb[2];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        const int row = (wave * 4 + i) * 8 + (lane >> 3);
+        const int c = (lane & 7) ^ (row & 7);
+        const int m = min(m0 + row, p.M - 1);
+        va1[i] = (unsigned)(((long)m * p.lda1 + c * 8) * 2);
+        dv[i] = p.K2 ? (unsigned)(((long)m * p.lda2 + c * 8) * 2) - va1[i] : 0u;
+    }
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+        const int row = (wave * 2 + i) * 8 + (lane >> 3);
+        const int c = (lane & 7) ^ (row & 7);
+        const int n = min(n0 + row, p.N - 1);
+        vb[i] = (unsigned)(((long)n * p.ldb + c * 8) * 2);
+    }
+    int offa[2][4], offb[2][4];
+#pragma unroll
+    for (int kk = 0; kk < 2; ++kk)
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const int ra = wm * 64 + i * 16 + l15, rb = wn * 64 + i * 16 + l15;
+            offa[kk][i] = ra * 128 + (((kk * 4 + g) ^ (ra & 7)) << 4);
+            offb[kk][i] = GBM * 128 + rb * 128 + (((kk * 4 + g) ^ (rb & 7)) << 4);
+        }
+    unsigned char* const S0 = &smem[0][0];
+    auto gissue = [&](int kt, int stage_off) __attribute__((always_inline)) {
+        const char* sb = (const char*)p.B + (long)kt * (BK * 2);
+        const bool first = kt < nk1;                     // wave-uniform
+        const char* sa = first ? (const char*)p.A1 + (long)kt * (BK * 2) : (const char*)p.A2 + (long)(kt - nk1) * (BK * 2);
+        const unsigned sel = first ? 0u : ~0u;
+#pragma unroll
+        for (int i = 0; i < 4; ++i) glds16(sa + (va1[i] + (dv[i] & sel)), S0 + stage_off + (wave * 4 + i) * 1024);
+#pragma unroll
+        for (int i = 0; i < 2; ++i) glds16(sb + vb[i], S0 + stage_off + GBM * 128 + (wave * 2 + i) * 1024);
+    };
+
+    f32x4 acc[4][4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+    // ONE copy of the K step: the stage offset is a wave-uniform running value added to the fragment read offsets.
+    // Stage of step kt: (kt - kb) % 3; tile kt + 2 goes to the stage that step kt - 1 just released.
+    gissue(kb, 0);
+    if (kb + 1 < ke) gissue(kb + 1, GSTAGE);
+    int cur = 0, nxt = 2 * GSTAGE;
+    for (int kt = kb; kt < ke; ++kt) {
+        // tile kt must have landed; the younger tile kt + 1 (6 loads of this wave) may stay in flight
+        if (kt + 1 < ke) wait_vmcnt<6>();
+        else wait_vmcnt<0>();
+        barrier_keep_vm();
+        if (kt + 2 < ke) gissue(kt + 2, nxt);
+        const unsigned char* S = S0 + cur;
+#pragma unroll
+        for (int kk = 0; kk < 2; ++kk) {
+            bf16x8 af[4], bw[4];
+#pragma unroll
+            for (int i = 0; i < 4; ++i) af[i] = ld<bf16x8>(S + offa[kk][i]);
+#pragma unroll
+            for (int j = 0; j < 4; ++j) bw[j] = ld<bf16x8>(S + offb[kk][j]);
+#pragma unroll
+            for (int i = 0; i < 4; ++i)
+#pragma unroll
+                for (int j = 0; j < 4; ++j)
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(bw[j], af[i], acc[i][j], 0, 0, 0);
+        }
+        nxt = cur;
+        cur = cur == 2 * GSTAGE ? 0 : cur + GSTAGE;
+    }
+    if (part >= 0) {        // K-range partial of a remainder tile: [part][i*4+j][tid] x 4 floats
+        float* w = p.ws + ((long)part * 16 * GTHREADS + tid) * 4;
+#pragma unroll
+        for (int i = 0; i < 4; ++i)
+#pragma unroll
+            for (int j = 0; j < 4; ++j) st<f32x4>(w + (i * 4 + j) * (GTHREADS * 4), acc[i][j]);
+        return;
+    }
+    nt_epilogue<OUT_F32, 4>(p, acc, m0 + wm * 64, n0 + wn * 64, l15, g);
+}
+
+template <bool OUT_F32>
+__global__ __launch_bounds__(GTHREADS) void gemm_nt_big_fixup_kernel(NTArgs p) {
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int wm = wave >> 1, wn = wave & 1, l15 = lane & 15, g = lane >> 4;
+    const int tm = (p.M + GBM - 1) / GBM, tn = (p.N + BN - 1) / BN;
+    const int i = blockIdx.y;           // 16-row group of the wave's 64 rows
+    int tile_m, tile_n;
+    tile_coords(p.full + blockIdx.x, tm, tn, tile_m, tile_n);
+    f32x4 acc[1][4];
+#pragma unroll
+    for (int j = 0; j < 4; ++j) acc[0][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+    const float* w = p.ws + (((long)blockIdx.x * p.split * 16 + i * 4) * GTHREADS + tid) * 4;
+#pragma unroll 4
+    for (int sidx = 0; sidx < p.split; ++sidx) {
+#pragma unroll
+        for (int j = 0; j < 4; ++j) acc[0][j] += ld<f32x4>(w + ((long)sidx * 16 + j) * (GTHREADS * 4));
+    }
+    nt_epilogue<OUT_F32, 1>(p, acc, tile_m * GBM + wm * 64 + i * 16, tile_n * BN + wn * 64, l15, g);
 }
 
 // (A BK = 32 variant of this kernel -- three 16-KB LDS stages, loads two K steps ahead with counted s_waitcnt vmcnt,
@@ -744,30 +878,39 @@ extern "C" int e2k_gemm_nt_bf16(const void* A1, int64_t lda1, int K1, const void
     p.M = M; p.N = N;
     p.bias = bias; p.colscale = colscale; p.lds = lds; p.rows_per_batch = rows_per_batch;
     p.rowmask = rowmask; p.resid = (const bf16_t*)resid; p.ldr = ldr;
-    const int tm = (M + BM - 1) / BM, tn = (N + BN - 1) / BN, T = tm * tn;
+    const int tn = (N + BN - 1) / BN;
     p.probe = flags & (E2K_GEMM_PROBE_NO_LOADS | E2K_GEMM_PROBE_NO_MATH);
     const bool glds = !(flags & E2K_GEMM_NO_GLDS) && (K1 % BK) == 0 && (K2 % BK) == 0;
-    // Remainder split (default kernel only): 256 CUs x 2 resident workgroups = 512 tiles per round; a trailing partial
-    // round of `rem` tiles would run at rem/512 of the chip (8448 rows x 1024 columns = 528 tiles: the last 16 cost
-    // a whole round), so those tiles are cut into `split` K ranges that together fill the chip once more.
+    // 256-row tiles: opt-in (measured equal to the 128 x 128 kernel at best, 5-15 % slower on most cfg3 shapes)
+    const bool big = glds && !p.probe && (flags & E2K_GEMM_BIG);
+    const int bm = big ? GBM : BM;
+    const int tm = (M + bm - 1) / bm, T = tm * tn;
+    // Remainder split: `slots` workgroups are resident (256 CUs x 2 of the 128-row kernel, x 1 of the 256-row one); a
+    // trailing partial round of `rem` tiles would run at rem/slots of the chip (8448 rows x 1024 columns = 528 tiles
+    // of 128 x 128: the last 16 cost half a round), so those tiles are cut into `split` K ranges that together fill
+    // the chip once more.
     p.full = T; p.split = 1; p.ws = ws;
     int rem = 0;
-    const int slots = (flags & E2K_GEMM_TEST_SLOTS8) ? 8 : NT_SLOTS;
+    const int slots = (flags & E2K_GEMM_TEST_SLOTS8) ? 8 : (big ? 256 : NT_SLOTS);
     if (glds && ws && !(flags & E2K_GEMM_NO_SPLIT) && T > slots && (T % slots) != 0) {
         rem = T % slots;
-        const int nk = (K1 + K2) / BK;          // (heuristics in units of 64-wide K steps for both kernels)
+        const int nk = (K1 + K2) / BK;
         int split = 1;
         while (split * 2 <= 16 && split * 2 * rem <= slots && split * 2 * 2 <= nk) split *= 2;
         // worth it only when the partial round it removes (about half a round: ~0.5 us per K step, measured) costs more
-        // than writing + re-reading the fp32 partials (64 KB per workgroup at ~5 TB/s) and the fix-up launch (~4 us)
+        // than writing + re-reading the fp32 partials (64 KB per 128 x 128 tile at ~5 TB/s) and the fix-up launch (~4 us)
+        const float per_part = big ? 0.052f : 0.026f;
         if (!(flags & E2K_GEMM_TEST_SLOTS8))
-            while (split > 1 && 0.5f * nk < 1.2f * (rem * split * 0.026f + 4.f)) split >>= 1;
-        if (split > 1 && (int64_t)rem * split * BM * BN * 4 <= ws_bytes) { p.full = T - rem; p.split = split; }
+            while (split > 1 && 0.5f * nk < 1.2f * (rem * split * per_part + 4.f)) split >>= 1;
+        if (split > 1 && (int64_t)rem * split * bm * BN * 4 <= ws_bytes) { p.full = T - rem; p.split = split; }
         else rem = 0;
     }
     dim3 grid(p.full + rem * p.split), block(256);
     hipStream_t st = (hipStream_t)stream;
-    if (out_f32) {
+    if (big) {
+        if (out_f32) hipLaunchKernelGGL(gemm_nt_big_kernel<true>, grid, dim3(GTHREADS), 0, st, p);
+        else hipLaunchKernelGGL(gemm_nt_big_kernel<false>, grid, dim3(GTHREADS), 0, st, p);
+    } else if (out_f32) {
         if (glds) hipLaunchKernelGGL(gemm_nt_glds_kernel<true>, grid, block, 0, st, p);
         else hipLaunchKernelGGL((gemm_nt_kernel<true, false>), grid, block, 0, st, p);
     } else {
@@ -776,8 +919,13 @@ extern "C" int e2k_gemm_nt_bf16(const void* A1, int64_t lda1, int K1, const void
     }
     E2K_CHECK_LAUNCH();
     if (rem) {
-        if (out_f32) hipLaunchKernelGGL(gemm_nt_fixup_kernel<true>, dim3(rem, 4), block, 0, st, p);
-        else hipLaunchKernelGGL(gemm_nt_fixup_kernel<false>, dim3(rem, 4), block, 0, st, p);
+        if (big) {
+            if (out_f32) hipLaunchKernelGGL(gemm_nt_big_fixup_kernel<true>, dim3(rem, 4), dim3(GTHREADS), 0, st, p);
+            else hipLaunchKernelGGL(gemm_nt_big_fixup_kernel<false>, dim3(rem, 4), dim3(GTHREADS), 0, st, p);
+        } else {
+            if (out_f32) hipLaunchKernelGGL(gemm_nt_fixup_kernel<true>, dim3(rem, 4), block, 0, st, p);
+            else hipLaunchKernelGGL(gemm_nt_fixup_kernel<false>, dim3(rem, 4), block, 0, st, p);
+        }
         E2K_CHECK_LAUNCH();
     }
     return 0;

@@ -107,3 +107,22 @@ def test_gemm_tn_colsum(dev, M, N, K, cs_from):
     want[cs_from:] += a.float().sum(0)[cs_from:]
     assert torch.allclose(csd.cpu(), want, rtol=1e-4, atol=1e-3), (csd.cpu() - want).abs().max()
 
+
+
+@pytest.mark.parametrize('flags', [64, 64 | 32])
+@pytest.mark.parametrize('M,N,K1,K2,kw', [
+    (256, 128, 64, 0, {}),                                   # one tile, one K step
+    (300, 136, 128, 0, dict(bias=1)),                        # ragged edges, two steps
+    (520, 260, 192, 64, dict(bias=1, cs=1, rm=1, rs=1)),     # four steps (3 + 1), dual-K, every epilogue operand
+    (2304, 128, 448, 0, dict(f32=1, bias=1)),                # 9 tiles, seven steps; with flag 32: remainder split
+    (700, 260, 320, 0, dict(rs=1)),
+])
+def test_gemm_nt_big_tile(dev, M, N, K1, K2, kw, flags):
+    """256 x 128 tile, 3-stage NT kernel (opt-in flag E2K_GEMM_BIG), alone and with the remainder split"""
+    from e2_tts_pytorch_amd import ops
+    old = ops.gemm_flags
+    ops.gemm_flags = flags
+    try:
+        test_gemm_nt(dev, M, N, K1, K2, kw)
+    finally:
+        ops.gemm_flags = old
