@@ -87,6 +87,29 @@ __device__ __forceinline__ float clamp_tanh(float raw, float k2) { return 1.f - 
 // cl2 * tanh(.) in one fma after the rcp
 __device__ __forceinline__ float clamp_tanh_scaled(float raw, float k2, float cl2) { return fmaf(-2.f * cl2, fast_rcp(fast_exp2(raw * k2) + 1.f), cl2); }
 
+// Polynomial tanh for |x| <= 0.75 (max relative error 3.1e-5, minimax fit in x^2), two values per packed-fp32
+// instruction and no transcendental: soft-clamp arguments are raw * scale / 50, i.e. |raw * scale| <= 37.5 -- every
+// realistic attention logit.  Each 64-key tile takes this path only when a wave vote says all of its scores are in
+// range; otherwise the exp2 / rcp form above runs (same result to fp32 rounding).
+typedef float f32x2_ __attribute__((ext_vector_type(2)));
+constexpr float TANH_POLY_MAX = 0.75f;
+__device__ __forceinline__ f32x2_ tanh_poly2(f32x2_ x) {
+    const f32x2_ u = x * x;
+    f32x2_ pl = u * -0.0338411346f + 0.125959146f;
+    pl = pl * u + -0.332331483f;
+    pl = pl * u + 0.999968926f;
+    return x * pl;
+}
+// largest |score| of a lane's 16 scores
+__device__ __forceinline__ float abs_max16(const f32x4 (&s)[4]) {
+    float a = 0.f;
+#pragma unroll
+    for (int t = 0; t < 4; ++t)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) a = fmaxf(a, fabsf(s[t][r]));
+    return a;
+}
+
 // the 8 mask bytes (each 0 / 1) of a lane's keys -> 8 bits
 __device__ __forceinline__ unsigned mask_bits(unsigned long long m) { return (unsigned)((m * 0x0102040810204080ull) >> 56); }
 
@@ -308,10 +331,22 @@ __global__ __launch_bounds__(256, 2) void attn_fwd_kernel(AttnArgs p) {
         // overlap), then mask; tiles without masked keys (all but the last one or two) skip the selects
         const bool allk = wave_all(km == 0xffffu);
         float tmax = NEG_MASK;
+        const float kx = p.scale / CLAMP;
+        if (wave_all(abs_max16(s) * kx <= TANH_POLY_MAX)) {
 #pragma unroll
-        for (int t = 0; t < 4; ++t)
+            for (int t = 0; t < 4; ++t)
 #pragma unroll
-            for (int r = 0; r < 4; ++r) s[t][r] = clamp_tanh_scaled(s[t][r], k2, cl2);
+                for (int r = 0; r < 4; r += 2) {
+                    const f32x2_ th = tanh_poly2(f32x2_{s[t][r], s[t][r + 1]} * kx) * cl2;
+                    s[t][r] = th[0];
+                    s[t][r + 1] = th[1];
+                }
+        } else {
+#pragma unroll
+            for (int t = 0; t < 4; ++t)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) s[t][r] = clamp_tanh_scaled(s[t][r], k2, cl2);
+        }
         if (!allk) {
 #pragma unroll
             for (int t = 0; t < 4; ++t)
@@ -485,6 +520,8 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dq_kernel(AttnArgs p) {
         const unsigned km = mask_bits(ld<unsigned long long>(p.kmask + (long)b * p.Npad + k0 + g * 8)) |
                             (mask_bits(ld<unsigned long long>(p.kmask + (long)b * p.Npad + k0 + 32 + g * 8)) << 8);
         const bool allk = wave_all(km == 0xffffu);
+        const float kx = p.scale / CLAMP;
+        const bool small = wave_all(abs_max16(s) * kx <= TANH_POLY_MAX);
 #pragma unroll
         for (int t = 0; t < 4; ++t)
 #pragma unroll
@@ -495,9 +532,12 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dq_kernel(AttnArgs p) {
                     ks0 = (hh & 0xffffu) >= p.thresh ? p.inv_keep : 0.f;
                     ks1 = (hh >> 16) >= p.thresh ? p.inv_keep : 0.f;
                 }
+                f32x2_ th2;
+                if (small) th2 = tanh_poly2(f32x2_{s[t][r], s[t][r + 1]} * kx);
+                else th2 = f32x2_{clamp_tanh(s[t][r], k2), clamp_tanh(s[t][r + 1], k2)};
 #pragma unroll
                 for (int e = 0; e < 2; ++e) {
-                    const float th = clamp_tanh(s[t][r + e], k2);
+                    const float th = th2[e];
                     const float pv = fast_exp2(cl2 * th - lse);
                     s[t][r + e] = pv * (dp[t][r + e] * (e ? ks1 : ks0) - dl) * (1.f - th * th) * p.scale;
                 }
@@ -607,13 +647,29 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dkv_kernel(AttnArgs p) {
             }
         }
         float pd[4][4], dsv[4][4];
+        const float kx = p.scale / CLAMP;
+        if (wave_all(abs_max16(s) * kx <= TANH_POLY_MAX)) {      // soft-clamp tanh, see tanh_poly2
+#pragma unroll
+            for (int t = 0; t < 4; ++t)
+#pragma unroll
+                for (int r = 0; r < 4; r += 2) {
+                    const f32x2_ th = tanh_poly2(f32x2_{s[t][r], s[t][r + 1]} * kx);
+                    s[t][r] = th[0];
+                    s[t][r + 1] = th[1];
+                }
+        } else {
+#pragma unroll
+            for (int t = 0; t < 4; ++t)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) s[t][r] = clamp_tanh(s[t][r], k2);
+        }
 #pragma unroll
         for (int t = 0; t < 4; ++t)
 #pragma unroll
             for (int r = 0; r < 4; ++r) {
                 const int qi = perm_row(t, 4 * g + r);
                 // (no key masking here: a lane's scores all belong to ITS key, whose dK / dV row is zeroed at the end)
-                const float th = clamp_tanh(s[t][r], k2);
+                const float th = s[t][r];
                 const float pr = fast_exp2(cl2 * th - lse_s[qi]);
                 float ks = 1.f;
                 if (DROP) {

@@ -583,15 +583,19 @@ class Transformer(Module):
             st.bwd = []
             gen = self._backward_gen(run, st.dout)
             done = False
+            import warnings
             while not done:
                 gr = torch.cuda.CUDAGraph()
                 slab = None
-                with torch.cuda.graph(gr, pool=st.pool):
-                    try:
-                        slab = next(gen)
-                    except StopIteration as e:
-                        st.dx, st.dcond, st.dtext, st.gflat = e.value
-                        done = True
+                with warnings.catch_warnings():
+                    # the tail segment after the last gradient slab can be empty: that is fine
+                    warnings.filterwarnings('ignore', message='The CUDA Graph is empty')
+                    with torch.cuda.graph(gr, pool=st.pool):
+                        try:
+                            slab = next(gen)
+                        except StopIteration as e:
+                            st.dx, st.dcond, st.dtext, st.gflat = e.value
+                            done = True
                 st.bwd.append((gr, slab))
         torch.cuda.synchronize(dev)
         return st

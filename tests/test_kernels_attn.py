@@ -16,8 +16,9 @@ def hm(t, B, H, N):          # (B*N, H*64) token-major -> (B,H,N,64)
     return t.view(B, N, H, 64).permute(0, 2, 1, 3)
 
 
-@pytest.mark.parametrize('N,has_vres,use_mask', [(70, False, False), (150, True, True)])
-def test_attention(dev, N, has_vres, use_mask):
+# qk_gain 3: ordinary logits (polynomial soft-clamp path); 14: logits far into the tanh clamp (exp2 / rcp path)
+@pytest.mark.parametrize('N,has_vres,use_mask,qk_gain', [(70, False, False, 3.0), (150, True, True, 3.0), (100, False, True, 14.0)])
+def test_attention(dev, N, has_vres, use_mask, qk_gain):
     from e2_tts_pytorch_amd import ops
     torch.manual_seed(0)
     B, H = 2, 4
@@ -28,7 +29,7 @@ def test_attention(dev, N, has_vres, use_mask):
         attn.to_v_head_gate.weight.normal_(0, 0.05)
         attn.to_v_head_gate.bias.normal_(0, 1.0)
         for lin in (attn.to_q, attn.to_k):
-            lin.weight.mul_(3.0)                      # sharper softmax
+            lin.weight.mul_(qk_gain)                  # sharper softmax
         if has_vres:
             attn.to_value_residual_mix[0].weight.normal_(0, 0.05)
             attn.to_value_residual_mix[0].bias.normal_(0, 1.0)
