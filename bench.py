@@ -176,6 +176,18 @@ def main():
         frames = B * T * world
         sf = step_flops(dim, depth, heads, B, T, text_on=not args.drop_text)
         achieved = gemm_flops / (gemm_ms * 1e-3) / 1e12 if gemm_ms > 0 else 0.0
+        # HBM traffic of the dominant kernel per launch: PMC counters cannot be read from inside this process, so the
+        # number comes from the committed rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes over the same launch mix
+        # (profiles/r01_nt_traffic.json, produced by tools/nt_shapes.py + tools/nt_traffic_probe.py); cfg3 only
+        traffic, traffic_note = None, None
+        tf = ROOT / 'profiles' / 'r01_nt_traffic.json'
+        if args.config == 'cfg3' and B == CONFIGS['cfg3'][3] and not args.drop_text and tf.exists():
+            tj = json.load(open(tf))
+            traffic = tj['traffic_bytes_per_launch']
+            traffic_note = (f"bytes per launch from {tf.name}: fetch {tj['hbm_fetch_bytes_per_launch'] / 1e6:.1f} MB (FETCH_SIZE x2, gfx950) + "
+                            f"write {tj['hbm_write_bytes_per_launch'] / 1e6:.1f} MB; algorithmic {tj['algorithmic_bytes_per_launch'] / 1e6:.1f} MB "
+                            "(A + B + C + residual): operand panels are re-fetched from the memory side about once per round of "
+                            "resident workgroups (A + B + C of a round exceed the 4-MB L2 of an XCD)")
         res = {
             'metric': 'mel-frames/sec (fwd+bwd training step)',
             'value': frames / (dt / args.steps),
@@ -202,7 +214,7 @@ def main():
                 'flops_per_launch_avg': gemm_flops / max(n_launch, 1),
                 'time_share_of_step': (gemm_ms / nprof) / ms,
                 'measured': 'HIP events around every launch, 2 eager steps right after the timed region',
-                'traffic': None,
+                'traffic': traffic, 'traffic_note': traffic_note,
             },
         }
         if world == 1 and not args.no_cpu_baseline:

@@ -63,6 +63,9 @@ def gemm_nt(a, b, *, a2=None, out=None, out_dtype=bf16, accumulate=False, bias=N
     if resid is not None:
         assert resid.dtype == bf16 and resid.shape == (M, N) and resid.stride(1) == 1
         ldr = resid.stride(0)
+    if _gemm_shapes is not None:
+        key = (M, N, K1, K2, int(out.dtype == f32), int(resid is not None))
+        _gemm_shapes[key] = _gemm_shapes.get(key, 0) + 1
     prof = _gemm_profile
     if prof is not None and a.is_cuda:
         e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
@@ -90,6 +93,7 @@ def _nt_ws(device):
 
 
 _gemm_profile = None
+_gemm_shapes = None        # tools/nt_shapes.py: dict counting the (M, N, K1, K2, out_f32, has_resid) of every gemm_nt call
 gemm_flags = 0          # E2K_GEMM_* bits passed to every gemm_nt call (A/B benchmarking of kernel variants)
 
 
