@@ -414,7 +414,10 @@ class E2TTS(Module):
             assert inp.shape[-1] == self.num_channels
         batch, seq_len, dtype, device = inp.shape[0], inp.shape[1], inp.dtype, self.device
         if isinstance(text, list):
-            text = self.tokenizer(text).to(device)
+            text = self.tokenizer(text)
+            # pinned staging + non-blocking copy: a pageable H2D copy is a synchronising HIP call, i.e. the host would
+            # wait here for the previous step's kernels before it can enqueue this one
+            text = text.pin_memory().to(device, non_blocking=True) if device.type == 'cuda' else text.to(device)
             assert text.shape[0] == batch
         if not exists(lens):
             lens = torch.full((batch,), seq_len, device=device)
