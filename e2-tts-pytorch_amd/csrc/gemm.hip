@@ -717,7 +717,7 @@ __global__ __launch_bounds__(256) void gemm_tn_kernel(TNArgs p) {
 // Fast TN path (token count a multiple of 64): global_load_lds staging into unpadded 256-B LDS rows whose 16-B chunks
 // are XOR-swizzled by 2*(row & 7) on the SOURCE side (conflict-free ds_read_b64_tr_b16: the 8 rows a half-wave reads
 // land on 8 distinct chunk pairs of the 256-B bank row), scalar base + hoisted 32-bit lane offsets, two LDS buffers.
-template <int DUMMY>
+template <bool CS>       // CS: also accumulate the column sums of A (bias gradient) in the k-tile-0 workgroups
 __global__ __launch_bounds__(256, 2) void gemm_tn_glds_kernel(TNArgs p) {
     __shared__ __attribute__((aligned(16))) unsigned char smem[2][2][TBM * 256];
     const int tid = threadIdx.x, lane = tid & 63, wave = uniform_i(tid >> 6);
@@ -767,7 +767,7 @@ __global__ __launch_bounds__(256, 2) void gemm_tn_glds_kernel(TNArgs p) {
     // Column sums of A (bias gradient) ride along in the k-tile-0 workgroups: one extra MFMA per 16 columns and K step
     // with an all-ones first operand (every row of the result is the column sum); the two waves that share an n range
     // (wk = 0 / 1) take two of its four 16-column groups each.
-    const bool do_cs = p.colsum != nullptr && tile_k == 0 && n0 + 128 > p.cs_from;     // wave-uniform
+    const bool do_cs = CS && tile_k == 0 && n0 + 128 > p.cs_from;     // wave-uniform
     f32x4 cs[2] = {f32x4{0.f, 0.f, 0.f, 0.f}, f32x4{0.f, 0.f, 0.f, 0.f}};
     const short one = 0x3F80;
     const bf16x8 ones = bf16x8{one, one, one, one, one, one, one, one};
@@ -779,12 +779,13 @@ __global__ __launch_bounds__(256, 2) void gemm_tn_glds_kernel(TNArgs p) {
             bf16x8 fx[4], fy[4];
 #pragma unroll
             for (int i = 0; i < 4; ++i) {
+                // (concatenated with a shuffle: the two 64-bit results become one 128-bit register tuple without moves)
                 s16x4_ lo = lds_read_tr16_b64(Bt + kk * 32 * 256 + offx[i]);
                 s16x4_ hi = lds_read_tr16_b64(Bt + (kk * 32 + 16) * 256 + offx[i]);
-                fx[i] = bf16x8{lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
+                fx[i] = __builtin_shufflevector(lo, hi, 0, 1, 2, 3, 4, 5, 6, 7);
                 s16x4_ lo2 = lds_read_tr16_b64(At + kk * 32 * 256 + offy[i]);
                 s16x4_ hi2 = lds_read_tr16_b64(At + (kk * 32 + 16) * 256 + offy[i]);
-                fy[i] = bf16x8{lo2[0], lo2[1], lo2[2], lo2[3], hi2[0], hi2[1], hi2[2], hi2[3]};
+                fy[i] = __builtin_shufflevector(lo2, hi2, 0, 1, 2, 3, 4, 5, 6, 7);
             }
 #pragma unroll
             for (int i = 0; i < 4; ++i)
@@ -823,6 +824,11 @@ __global__ __launch_bounds__(256, 2) void gemm_tn_glds_kernel(TNArgs p) {
         }
     }
 }
+
+// (A pipelined variant of this kernel -- 32 token rows per step, four 16-KB LDS stages, loads three steps ahead with a
+// counted s_waitcnt vmcnt -- was measured 20-28 % SLOWER on every cfg3 shape: PMC shows the waves of the kernel above
+// parked at s_waitcnt / barriers 58 % of the time, but halving the MFMAs per barrier costs more than the deeper
+// prefetch recovers.  Removed; see DESIGN.md.)
 
 __global__ __launch_bounds__(256) void tn_reduce_kernel(const float* ws, float* C, long ldc, int N, int K, int splits) {
     const long total = (long)N * K;
@@ -964,7 +970,8 @@ extern "C" int e2k_gemm_tn_bf16(const void* A, int64_t lda, const void* B, int64
         if (rc) return rc;
     }
     dim3 grid(tn * tk, splits), block(256);
-    if (fast) hipLaunchKernelGGL(gemm_tn_glds_kernel<0>, grid, block, 0, (hipStream_t)stream, p);
+    if (fast && p.colsum) hipLaunchKernelGGL(gemm_tn_glds_kernel<true>, grid, block, 0, (hipStream_t)stream, p);
+    else if (fast) hipLaunchKernelGGL(gemm_tn_glds_kernel<false>, grid, block, 0, (hipStream_t)stream, p);
     else if (use_tr) hipLaunchKernelGGL(gemm_tn_kernel<true>, grid, block, 0, (hipStream_t)stream, p);
     else hipLaunchKernelGGL(gemm_tn_kernel<false>, grid, block, 0, (hipStream_t)stream, p);
     E2K_CHECK_LAUNCH();
