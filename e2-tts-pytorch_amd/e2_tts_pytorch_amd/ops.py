@@ -340,8 +340,10 @@ def qkv_post_bwd(st, dQ, dK, dV, dgate_pre, qkvg, cosb, sinb, vfirst=None, dvfir
     ld = qkvg.stride(0)
     if ld == cols:
         dqkvg = torch.empty((M, cols), dtype=bf16, device=qkvg.device)
-    else:                                        # padded row stride: keep the pad columns zero
-        dqkvg = torch.zeros((M, ld), dtype=bf16, device=qkvg.device)[:, :cols]
+    else:                                        # padded row stride: only the pad columns need zeroing (they are read
+        full = torch.empty((M, ld), dtype=bf16, device=qkvg.device)      # as K padding by the dgrad GEMM)
+        full[:, cols:].zero_()
+        dqkvg = full[:, :cols]
     _lib.get().e2k_qkv_post_bwd(_p(dQ), _p(dK), _p(dV), _p(dgate_pre), _p(qkvg), qkvg.stride(0), _p(cosb), _p(sinb),
                                 _p(vfirst), _p(st.mix), _p(dvfirst), int(first_layer), _p(dqkvg), B, H, N, _stream(dQ))
     return dqkvg
