@@ -132,6 +132,11 @@ def main():
         model.zero_grad(set_to_none=True)
         return out.loss
 
+    if not args.no_graphs:
+        # graph mode needs two set-up passes per input signature (eager warm-up, then capture) before steps replay;
+        # they are done here, outside the W warm-up steps, so that even --warmup 0 times replayed steps only
+        step()
+        step()
     for _ in range(args.warmup):
         step()
     torch.cuda.synchronize()
