@@ -1,0 +1,141 @@
+// Optimizer-side kernels over flat fp32 buffers: the reference trainer does
+//     accelerator.clip_grad_norm_(model.parameters(), max_grad_norm)      trainer.py:272-273
+//     optimizer.step()            (adam_atan2_pytorch.adopt.Adopt)        trainer.py:183,275
+//     ema_model.update()          (ema_pytorch.EMA)                       trainer.py:170,279
+// as ~10 multi-tensor passes over every parameter.  Here: one reduction pass over the gradients (sum of squares, fp64
+// accumulation) and ONE fused pass that applies the clip factor (computed on the device from that sum, no host sync),
+// the ADOPT update, decoupled weight decay, refreshes the bf16 compute shadow and
+// optionally folds the gradient back to zero -- 4 reads + 3-4 writes per element.  HBM bound.
+#include "e2k_device.h"
+#include "../../include/e2k.h"
+
+using namespace e2k;
+
+namespace {
+
+__global__ __launch_bounds__(256) void sumsq_kernel(const float* __restrict__ x, long n, double* out) {
+    __shared__ double red[4];
+    double acc = 0.0;
+    const long n4 = n >> 2;
+    for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < n4; i += (long)gridDim.x * 256) {
+        const f32x4 v = ld<f32x4>(x + 4 * i);
+#pragma unroll
+        for (int r = 0; r < 4; ++r) acc = fma((double)v[r], (double)v[r], acc);
+    }
+    if (blockIdx.x == 0 && threadIdx.x < (n & 3)) { const float v = x[4 * n4 + threadIdx.x]; acc += (double)v * v; }
+#pragma unroll
+    for (int m = 32; m >= 1; m >>= 1) acc += __shfl_xor(acc, m);
+    if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = acc;
+    __syncthreads();
+    if (threadIdx.x == 0) atomicAdd(out, red[0] + red[1] + red[2] + red[3]);
+}
+
+struct AdoptArgs {
+    float* p; const float* g; float* m; float* v; bf16_t* shadow;
+    long n;
+    float lr, beta1, beta2, eps, wd, max_norm, clamp;     // clamp = step^0.25 (ADOPT update clipping)
+    const double* gsumsq;                                  // device: sum of squares of ALL gradients (may be null)
+    int first;                                             // step 0: only v = g^2
+};
+
+// one element: returns the new parameter value
+__device__ __forceinline__ float adopt_one(const AdoptArgs& a, float p, float g, float& m, float& v) {
+    if (a.first) { v = g * g; return p; }
+    const float u = fminf(fmaxf(g / fmaxf(sqrtf(v), a.eps), -a.clamp), a.clamp);
+    m = m + (1.f - a.beta1) * (u - m);
+    p = p * (1.f - a.lr * a.wd) - a.lr * m;
+    v = v + (1.f - a.beta2) * (g * g - v);
+    return p;
+}
+
+__global__ __launch_bounds__(256) void adopt_kernel(AdoptArgs a) {
+    // clip factor of torch.nn.utils.clip_grad_norm_: min(1, max_norm / (total_norm + 1e-6))
+    float cs = 1.f;
+    if (a.gsumsq && a.max_norm > 0.f) cs = fminf(1.f, a.max_norm / ((float)sqrt(*a.gsumsq) + 1e-6f));
+    const long n4 = a.n >> 2, stride = (long)gridDim.x * 256;
+    auto one = [&](long i, f32x4 p, f32x4 g, f32x4 m, f32x4 v) {
+        float pv[4];
+#pragma unroll
+        for (int r = 0; r < 4; ++r) { float mm = m[r], vv = v[r]; pv[r] = adopt_one(a, p[r], g[r] * cs, mm, vv); m[r] = mm; v[r] = vv; }
+        st<f32x4>(a.p + 4 * i, f32x4{pv[0], pv[1], pv[2], pv[3]});
+        st<f32x4>(a.m + 4 * i, m);
+        st<f32x4>(a.v + 4 * i, v);
+        if (a.shadow) st<u32x2>(a.shadow + 4 * i, pack4(pv));
+    };
+    long i = (long)blockIdx.x * 256 + threadIdx.x;
+    for (; i + stride < n4; i += 2 * stride) {            // two elements groups (8 x 16-byte loads) per thread in flight
+        const long j = i + stride;
+        const f32x4 p0 = ld<f32x4>(a.p + 4 * i), g0 = ld<f32x4>(a.g + 4 * i), m0 = ld<f32x4>(a.m + 4 * i), v0 = ld<f32x4>(a.v + 4 * i);
+        const f32x4 p1 = ld<f32x4>(a.p + 4 * j), g1 = ld<f32x4>(a.g + 4 * j), m1 = ld<f32x4>(a.m + 4 * j), v1 = ld<f32x4>(a.v + 4 * j);
+        one(i, p0, g0, m0, v0);
+        one(j, p1, g1, m1, v1);
+    }
+    for (; i < n4; i += stride)
+        one(i, ld<f32x4>(a.p + 4 * i), ld<f32x4>(a.g + 4 * i), ld<f32x4>(a.m + 4 * i), ld<f32x4>(a.v + 4 * i));
+    if (blockIdx.x == 0 && threadIdx.x < (a.n & 3)) {
+        const long i = 4 * n4 + threadIdx.x;
+        float mm = a.m[i], vv = a.v[i];
+        const float pn = adopt_one(a, a.p[i], a.g[i] * cs, mm, vv);
+        a.p[i] = pn; a.m[i] = mm; a.v[i] = vv;
+        if (a.shadow) a.shadow[i] = f2bf(pn);
+    }
+}
+
+__global__ __launch_bounds__(256) void ema_kernel(float* ema, const float* p, long n, float one_minus_decay) {
+    const long n4 = n >> 2, stride = (long)gridDim.x * 256;
+    long i = (long)blockIdx.x * 256 + threadIdx.x;
+    for (; i + 3 * stride < n4; i += 4 * stride) {        // four independent 16-byte streams per thread in flight
+        f32x4 e[4], w[4];
+#pragma unroll
+        for (int u = 0; u < 4; ++u) { e[u] = ld<f32x4>(ema + 4 * (i + u * stride)); w[u] = ld<f32x4>(p + 4 * (i + u * stride)); }
+#pragma unroll
+        for (int u = 0; u < 4; ++u) st<f32x4>(ema + 4 * (i + u * stride), e[u] + (w[u] - e[u]) * one_minus_decay);
+    }
+    for (; i < n4; i += stride) {
+        f32x4 e = ld<f32x4>(ema + 4 * i);
+        const f32x4 w = ld<f32x4>(p + 4 * i);
+        st<f32x4>(ema + 4 * i, e + (w - e) * one_minus_decay);
+    }
+    if (blockIdx.x == 0 && threadIdx.x < (n & 3)) { const long j = 4 * n4 + threadIdx.x; ema[j] += (p[j] - ema[j]) * one_minus_decay; }
+}
+
+int grid_for(long n) {
+    long g = (n / 4 + 255) / 256;
+    return (int)(g < 1 ? 1 : (g > 4096 ? 4096 : g));
+}
+
+}  // namespace
+
+extern "C" int e2k_sumsq_f32(const float* x, int64_t n, double* out, void* stream) {
+    if (n <= 0) return 0;
+    if (!x || !out) return E2K_ERR_ARG;
+    if ((uintptr_t)x & 15) return E2K_ERR_ALIGN;
+    hipLaunchKernelGGL(sumsq_kernel, dim3(grid_for(n)), dim3(256), 0, (hipStream_t)stream, x, (long)n, out);
+    E2K_CHECK_LAUNCH();
+    return 0;
+}
+
+extern "C" int e2k_adopt_step(float* p, const float* g, float* m, float* v, void* shadow_bf16, int64_t n, float lr,
+                              float beta1, float beta2, float eps, float weight_decay, float max_grad_norm,
+                              const double* gsumsq, int step, void* stream) {
+    if (n <= 0) return 0;
+    if (!p || !g || !m || !v || step < 0) return E2K_ERR_ARG;
+    if (((uintptr_t)p | (uintptr_t)g | (uintptr_t)m | (uintptr_t)v) & 15 || ((uintptr_t)shadow_bf16 & 7)) return E2K_ERR_ALIGN;
+    AdoptArgs a;
+    a.p = p; a.g = g; a.m = m; a.v = v; a.shadow = (bf16_t*)shadow_bf16; a.n = n;
+    a.lr = lr; a.beta1 = beta1; a.beta2 = beta2; a.eps = eps; a.wd = weight_decay; a.max_norm = max_grad_norm;
+    a.clamp = sqrtf(sqrtf((float)step));
+    a.gsumsq = gsumsq; a.first = step == 0;
+    hipLaunchKernelGGL(adopt_kernel, dim3(grid_for(n)), dim3(256), 0, (hipStream_t)stream, a);
+    E2K_CHECK_LAUNCH();
+    return 0;
+}
+
+extern "C" int e2k_ema_update(float* ema, const float* p, int64_t n, float decay, void* stream) {
+    if (n <= 0) return 0;
+    if (!ema || !p) return E2K_ERR_ARG;
+    if (((uintptr_t)ema | (uintptr_t)p) & 15) return E2K_ERR_ALIGN;
+    hipLaunchKernelGGL(ema_kernel, dim3(grid_for(n)), dim3(256), 0, (hipStream_t)stream, ema, p, (long)n, 1.f - decay);
+    E2K_CHECK_LAUNCH();
+    return 0;
+}

@@ -370,3 +370,34 @@ def melspec(wave, window, fb, n_fft, hop):
     _lib.get().e2k_melspec(_p(wave), nw, _p(window.float().contiguous()), _p(fb.float().contiguous()), _p(twc), _p(tws),
                            _p(out), B, n_fft, hop, n_mels, _stream(wave))
     return out
+
+
+# ------------------------------------------------------------------------------------------------ optimizer side (K19)
+
+def sumsq(x, out):
+    """out[0] += sum(x^2)   (x fp32 contiguous, out fp64 scalar tensor)"""
+    _chk(x, out)
+    assert x.dtype == f32 and x.is_contiguous() and out.dtype == torch.float64 and out.numel() == 1
+    _lib.get().e2k_sumsq_f32(_p(x), x.numel(), _p(out), _stream(x))
+    return out
+
+
+def adopt_step(p, g, m, v, step, *, lr, beta1=0.9, beta2=0.99, eps=1e-6, weight_decay=0., max_grad_norm=0., gsumsq=None,
+               shadow=None):
+    """one fused ADOPT step on flat fp32 buffers (see e2k_adopt_step in include/e2k.h)"""
+    _chk(p, g, m, v, gsumsq, shadow)
+    n = p.numel()
+    for t in (p, g, m, v):
+        assert t.dtype == f32 and t.is_contiguous() and t.numel() == n
+    if shadow is not None:
+        assert shadow.dtype == bf16 and shadow.is_contiguous() and shadow.numel() == n
+    if gsumsq is not None:
+        assert gsumsq.dtype == torch.float64 and gsumsq.numel() == 1
+    _lib.get().e2k_adopt_step(_p(p), _p(g), _p(m), _p(v), _p(shadow), n, float(lr), float(beta1), float(beta2), float(eps),
+                              float(weight_decay), float(max_grad_norm), _p(gsumsq), int(step), _stream(p))
+
+
+def ema_update(ema, p, decay):
+    _chk(ema, p)
+    assert ema.dtype == f32 and p.dtype == f32 and ema.is_contiguous() and p.is_contiguous() and ema.numel() == p.numel()
+    _lib.get().e2k_ema_update(_p(ema), _p(p), p.numel(), float(decay), _stream(p))

@@ -1,0 +1,175 @@
+"""Fused optimizer side of the training step over flat fp32 buffers (kernel group K19):
+what /root/reference/e2_tts_pytorch/trainer.py:272-279 does with accelerate + adam_atan2_pytorch.Adopt + ema_pytorch.EMA
+as ~10 passes over every parameter, done in one reduction pass and one update pass per contiguous run of parameters.
+
+    opt = FusedAdopt(model, lr=1e-4, max_grad_norm=1.0)     # trainer.py:146,183
+    loss.backward(); opt.step(); opt.zero_grad()            # trainer.py:270-277
+    ema = FusedEMA(model); ema.update()                     # trainer.py:170,279
+
+Parameters whose storage AND gradient storage are adjacent (every backbone parameter: they are views of the Transformer's
+flat buffers) are merged into one run = one kernel launch.  No torch fallback: the update itself always runs in the HIP
+kernels (`ops.adopt_step` / `ops.ema_update`).
+"""
+from __future__ import annotations
+
+import copy
+
+import torch
+
+from . import ops
+from .backbone import Transformer
+
+
+def _runs(pairs):
+    """[(a, b)] fp32 tensor pairs -> [(a_flat, b_flat)]: tensors that are adjacent in memory in BOTH lists (up to the 7
+    alignment-padding elements the flat layout puts between slots; nothing ever writes those, they stay zero) are merged
+    into one flat view each = one kernel launch per run.  A run must start 16-byte aligned."""
+    order = sorted(range(len(pairs)), key=lambda i: pairs[i][0].data_ptr())
+    groups, cur = [], []
+    for i in order:
+        a, b = pairs[i]
+        if cur:
+            pa, pb = pairs[cur[-1]]
+            gap_a = a.data_ptr() - (pa.data_ptr() + pa.numel() * 4)
+            gap_b = b.data_ptr() - (pb.data_ptr() + pb.numel() * 4)
+            same = (a.untyped_storage().data_ptr() == pa.untyped_storage().data_ptr() and
+                    b.untyped_storage().data_ptr() == pb.untyped_storage().data_ptr())      # one allocation each
+            if not (same and gap_a == gap_b and 0 <= gap_a <= 28):
+                groups.append(cur)
+                cur = []
+        cur.append(i)
+    if cur:
+        groups.append(cur)
+    runs = []
+    for idx in groups:
+        a0, b0 = pairs[idx[0]]
+        al, bl = pairs[idx[-1]]
+        n = (al.data_ptr() + al.numel() * 4 - a0.data_ptr()) // 4
+        if (a0.data_ptr() | b0.data_ptr()) & 15 or len(idx) == 1:
+            runs.extend((pairs[i][0].view(-1), pairs[i][1].view(-1)) for i in idx)
+        else:
+            runs.append((torch.as_strided(a0, (n,), (1,)), torch.as_strided(b0, (n,), (1,))))
+    return runs
+
+
+def _grad_base(slots, n):
+    """the flat fp32 gradient buffer (n elements) that every slot's .grad is a view of at its layout offset, or None"""
+    q0, off0 = slots[0]
+    g0 = q0.grad
+    if g0 is None or g0.dtype != torch.float32:
+        return None
+    st = g0.untyped_storage()
+    start = g0.data_ptr() - off0 * 4 - st.data_ptr()            # byte offset of element 0 of the flat buffer
+    if start < 0 or start % 4 or start + n * 4 > st.nbytes():
+        return None
+    base_ptr = st.data_ptr() + start
+    for q, off in slots:
+        g = q.grad
+        if g is None or not g.is_contiguous() or g.data_ptr() != base_ptr + off * 4 or g.untyped_storage().data_ptr() != st.data_ptr():
+            return None
+    return torch.empty(0, dtype=torch.float32, device=g0.device).set_(st, start // 4, (n,), (1,))
+
+
+class FusedAdopt:
+    """ADOPT (adam_atan2_pytorch.adopt.Adopt defaults: betas (0.9, 0.99), eps 1e-6, decoupled weight decay) with the
+    global-norm gradient clip of `accelerator.clip_grad_norm_` folded in; state (m, v) lives in flat buffers per run."""
+
+    def __init__(self, model, lr=1e-4, betas=(0.9, 0.99), eps=1e-6, weight_decay=0., max_grad_norm=1.0):
+        self.model = model
+        self.params = [p for p in model.parameters() if p.requires_grad]
+        self.lr, self.betas, self.eps, self.weight_decay, self.max_grad_norm = lr, betas, eps, weight_decay, max_grad_norm
+        self.step_count = 0
+        self._state = {}           # (data_ptr of first param, n) -> (m, v)
+        self._backbones = [m for m in model.modules() if isinstance(m, Transformer)]
+
+    def zero_grad(self, set_to_none=True):
+        self.model.zero_grad(set_to_none=set_to_none)
+
+    @torch.no_grad()
+    def step(self):
+        pairs = [(p, p.grad) for p in self.params if p.grad is not None]
+        if not pairs:
+            return
+        for p, g in pairs:
+            assert p.dtype == torch.float32 and g.dtype == torch.float32 and p.is_contiguous() and g.is_contiguous()
+        dev = pairs[0][0].device
+        gs = torch.zeros(1, dtype=torch.float64, device=dev) if self.max_grad_norm > 0 else None
+        # a backbone whose gradients are the views of ONE flat buffer our backward produced is a single run over its
+        # whole flat parameter buffer (alignment pads and the zero "holes" of the layout included: nothing writes their
+        # gradients, so they stay exactly zero through the update)
+        runs, taken = [], set()
+        for tr in self._backbones:
+            slots = getattr(getattr(tr, '_layout', None), 'slots', None)
+            flat = getattr(tr, '_flat', None)
+            if not slots or flat is None or slots[0][0].grad is None:
+                continue
+            base = _grad_base(slots, flat.numel())
+            if base is not None and all(q.data_ptr() == flat.data_ptr() + off * 4 for q, off in slots):
+                runs.append((flat.view(-1), base))
+                taken.update(id(q) for q, _ in slots)
+        runs += _runs([(p, g) for p, g in pairs if id(p) not in taken])
+        if gs is not None:
+            for pf, gf in runs:
+                ops.sumsq(gf, gs)
+        b1, b2 = self.betas
+        for pf, gf in runs:
+            key = (pf.data_ptr(), pf.numel())
+            if key not in self._state:
+                self._state[key] = (torch.zeros_like(pf), torch.zeros_like(pf))
+            m, v = self._state[key]
+            ops.adopt_step(pf, gf, m, v, self.step_count, lr=self.lr, beta1=b1, beta2=b2, eps=self.eps,
+                           weight_decay=self.weight_decay, max_grad_norm=self.max_grad_norm, gsumsq=gs)
+        for p, _ in pairs:                                     # the kernels wrote behind autograd's back
+            torch.autograd.graph.increment_version(p)
+        self.step_count += 1
+
+
+class FusedEMA:
+    """ema_pytorch.EMA(model) defaults (beta 0.9999, update_after_step 100, update_every 10, inv_gamma 1, power 2/3):
+    `.ema_model` is a deep copy whose parameters follow the online model."""
+
+    def __init__(self, model, beta=0.9999, update_after_step=100, update_every=10, inv_gamma=1., power=2. / 3.):
+        self.online, self.ema_model = model, copy.deepcopy(model)
+        self.ema_model.requires_grad_(False)
+        self.beta, self.update_after_step, self.update_every = beta, update_after_step, update_every
+        self.inv_gamma, self.power = inv_gamma, power
+        self.step, self.initted = 0, False
+        for m in self.ema_model.modules():            # deepcopy clones every parameter separately: re-establish the
+            if isinstance(m, Transformer):            # flat storage of the copy, so that it is one run like the original
+                m._flat = None
+                m._sync(next(m.parameters()).device)
+
+    def current_decay(self):
+        epoch = max(self.step - self.update_after_step - 1, 0)
+        if epoch <= 0:
+            return 0.
+        return min(max(1. - (1. + epoch / self.inv_gamma) ** -self.power, 0.), self.beta)
+
+    @torch.no_grad()
+    def update(self):
+        step = self.step
+        self.step += 1
+        if step % self.update_every != 0:
+            return
+        if step <= self.update_after_step or not self.initted:
+            for e, p in zip(self.ema_model.parameters(), self.online.parameters()):
+                e.copy_(p)
+            self.initted = True
+            return
+        decay = self.current_decay()
+        pairs = [(e, p.detach()) for e, p in zip(self.ema_model.parameters(), self.online.parameters()) if e.numel()]
+        runs, taken = [], set()
+        for te, to in zip((m for m in self.ema_model.modules() if isinstance(m, Transformer)),
+                          (m for m in self.online.modules() if isinstance(m, Transformer))):
+            fe, fo = getattr(te, '_flat', None), getattr(to, '_flat', None)
+            se, so = getattr(getattr(te, '_layout', None), 'slots', None), getattr(getattr(to, '_layout', None), 'slots', None)
+            if fe is None or fo is None or not se or not so or fe.numel() != fo.numel():
+                continue
+            if all(q.data_ptr() == fe.data_ptr() + off * 4 for q, off in se) and all(q.data_ptr() == fo.data_ptr() + off * 4 for q, off in so):
+                runs.append((fe.view(-1), fo.view(-1)))          # whole flat buffers (holes / pads are zero in both)
+                taken.update(id(q) for q, _ in se)
+        runs += _runs([(e, p) for e, p in pairs if id(e) not in taken])
+        for ef, pf in runs:
+            ops.ema_update(ef, pf, decay)
+        for e, _ in pairs:
+            torch.autograd.graph.increment_version(e)

@@ -163,6 +163,20 @@ int e2k_attn_bwd(const void* dOg, const void* O, const float* gate, const float*
 int e2k_melspec(const float* wave, int64_t nw, const float* window, const float* fb, const float* twc,
                 const float* tws, float* out, int B, int n_fft, int hop, int n_mels, void* stream);
 
+/* ---- optimizer side over flat fp32 buffers (reference trainer.py:272-279) ----
+ * out[0] += sum x^2 (fp64 accumulation): the global gradient norm of accelerator.clip_grad_norm_ (trainer.py:272-273). */
+int e2k_sumsq_f32(const float* x, int64_t n, double* out, void* stream);
+/* One ADOPT step (adam_atan2_pytorch.adopt.Adopt, trainer.py:183,275) on n elements:
+ *   g' = g * min(1, max_grad_norm / (sqrt(*gsumsq) + 1e-6))      (gsumsq NULL or max_grad_norm <= 0: no clipping)
+ *   step 0: v = g'^2.   step >= 1: u = clamp(g' / max(sqrt(v), eps), +-step^0.25); m += (1-beta1)(u - m);
+ *   p = p (1 - lr weight_decay) - lr m;  v += (1-beta2)(g'^2 - v).
+ * shadow_bf16 (optional): the bf16 compute copy of p, refreshed in the same pass. */
+int e2k_adopt_step(float* p, const float* g, float* m, float* v, void* shadow_bf16, int64_t n, float lr,
+                   float beta1, float beta2, float eps, float weight_decay, float max_grad_norm,
+                   const double* gsumsq, int step, void* stream);
+/* ema += (1 - decay) (p - ema)   (ema_pytorch.EMA.update, trainer.py:170,279) */
+int e2k_ema_update(float* ema, const float* p, int64_t n, float decay, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -263,6 +263,7 @@ static inline float atomicAdd(float* p, float v) {
         if (__atomic_compare_exchange_n(up, &old, nu, false, __ATOMIC_RELAXED, __ATOMIC_RELAXED)) return __uint_as_float(old);
     }
 }
+static inline double atomicAdd(double* p, double v) { double old = *p; *p = old + v; return old; }     // (the model runs one fiber at a time)
 static inline int atomicAdd(int* p, int v) { return __atomic_fetch_add(p, v, __ATOMIC_RELAXED); }
 static inline unsigned atomicAdd(unsigned* p, unsigned v) { return __atomic_fetch_add(p, v, __ATOMIC_RELAXED); }
 
