@@ -91,6 +91,7 @@ def main():
     ap.add_argument('--no-cpu-baseline', action='store_true')
     ap.add_argument('--batch', type=int, default=None)
     ap.add_argument('--no-graphs', action='store_true', help='eager kernel launches instead of captured HIP graphs')
+    ap.add_argument('--copy-grads', action='store_true', help='graph mode: copy the gradients out of the static buffer every step')
     ap.add_argument('--force-ddp', action='store_true', help='wrap in ddp.DataParallel even with one rank (exercises the RCCL path)')
     args = ap.parse_args()
 
@@ -119,7 +120,9 @@ def main():
                   cond_drop_prob=0.).to(dev)
     model.train()
     if not args.no_graphs:
-        model.transformer.enable_graphs()
+        # gradients are consumed (here: dropped by zero_grad(set_to_none=True)) before the next backward, so the
+        # graph's static gradient buffer can be handed out without the extra copy
+        model.transformer.enable_graphs(alias_grads=not args.copy_grads)
     net = DataParallel(model) if (world > 1 or args.force_ddp) else model
     torch.manual_seed(1000 + rank)        # different synthetic data per rank (weak scaling: B per GPU fixed)
     mel = torch.randn(B, T, 100, device=dev)

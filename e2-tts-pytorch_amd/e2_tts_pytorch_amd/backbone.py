@@ -531,8 +531,13 @@ class Transformer(Module):
     # copy the inputs into static buffers and replay.  Dropout masks stay fresh: the kernels read the seed from a
     # device word that is refilled before every replay.
 
-    def enable_graphs(self, on: bool = True):
+    def enable_graphs(self, on: bool = True, alias_grads: bool = False):
+        """alias_grads: hand out the parameter gradients as views of the graph's static gradient buffer instead of a copy
+        (saves one read + write of every gradient per step: 5.8 GB at cfg3).  They are then only valid until the next
+        backward replay, and must not be accumulated across backward passes (use `zero_grad(set_to_none=True)` between
+        steps, as the reference trainer's optimizer.step() / zero_grad() sequence does, `trainer.py:275-277`)."""
         self.use_graphs = on
+        self._alias_grads = bool(alias_grads) and on
         if not on:
             self._graphs = {}
         return self
@@ -1026,7 +1031,8 @@ class _GraphFn(torch.autograd.Function):
                 sync(st.gflat, slab[0], slab[1])
         if exists(sync):
             sync(st.gflat, None, None)
-        gflat = st.gflat.clone()          # the static buffer is rewritten by the next replay
+        # the static buffer is rewritten by the next replay: copy it out unless the caller opted into aliasing
+        gflat = st.gflat if getattr(module, '_alias_grads', False) else st.gflat.clone()
         pgrads = [gflat[off:off + p.numel()].view(p.shape) if p.requires_grad else None for p, off in module._layout.slots]
         return (None, None, st.dx.to(ctx.x_dtype).clone(), st.dcond.clone() if ctx.has_cond else None,
                 st.dtext.to(ctx.t_dtype).clone() if ctx.has_text else None, None, *pgrads)

@@ -136,6 +136,15 @@ def test_graph_replay_matches_eager():
         assert rel2(o1, o0) < 1e-3 and rel2(dx1, dx0) < 1e-3 and rel2(dt1, dt0) < 1e-3
         for n in g0:
             assert rel2(g1[n], g0[n]) < 2e-3 or float(g0[n].norm()) < 1e-6, n
+    # gradients handed out as views of the static buffer (enable_graphs(alias_grads=True)): same values, no copy
+    mod.enable_graphs(False)
+    mod.enable_graphs(alias_grads=True)
+    got2 = [step(s) for s in (1, 2, 3)]
+    for (o0, dx0, dt0, g0), (o1, dx1, dt1, g1) in zip(ref, got2):
+        assert rel2(o1, o0) < 1e-3 and rel2(dx1, dx0) < 1e-3
+        for n in g0:
+            assert rel2(g1[n], g0[n]) < 2e-3 or float(g0[n].norm()) < 1e-6, n
+    mod.enable_graphs(False)
     # forward-only graph (sampling path)
     with torch.no_grad():
         x, t, txt, mask = inputs(4)
