@@ -522,7 +522,8 @@ class Transformer(Module):
         self._sync(x.device)
         if need_grad:
             return _BackboneFn.apply(self, x, cond, text_embed, mask, *self._params_in_order())
-        return self._run_forward(x, cond, text_embed, mask, False).out
+        with ops.pinned_stream(x.device):
+            return self._run_forward(x, cond, text_embed, mask, False).out
 
     # ------------------------------------------------------------------ HIP graphs
     # The eager schedule costs ~55 us of Python per kernel launch (~150 ms per cfg3 step, as much as the kernels take).
@@ -580,7 +581,8 @@ class Transformer(Module):
         st.fwd = torch.cuda.CUDAGraph()
         with torch.cuda.graph(st.fwd, pool=st.pool):
             self._recast()
-            run = self._run_forward(st.x, st.cond, st.text, st.mask, need_grad, seed_dev=st.seed)
+            with ops.pinned_stream(dev):
+                run = self._run_forward(st.x, st.cond, st.text, st.mask, need_grad, seed_dev=st.seed)
         st.run, st.out = run, run.out
         st.bwd = None
         if need_grad:
@@ -595,7 +597,7 @@ class Transformer(Module):
                 with warnings.catch_warnings():
                     # the tail segment after the last gradient slab can be empty: that is fine
                     warnings.filterwarnings('ignore', message='The CUDA Graph is empty')
-                    with torch.cuda.graph(gr, pool=st.pool):
+                    with torch.cuda.graph(gr, pool=st.pool), ops.pinned_stream(dev):
                         try:
                             slab = next(gen)
                         except StopIteration as e:
@@ -804,7 +806,8 @@ class Transformer(Module):
         gen = self._backward_gen(run, dout)
         while True:
             try:
-                start, end = next(gen)
+                with ops.pinned_stream(dout.device):        # (the hook below enqueues RCCL work on its own stream)
+                    start, end = next(gen)
             except StopIteration as e:
                 dxs, dcond, dtext, gflat = e.value
                 break
@@ -990,8 +993,9 @@ class _BackboneFn(torch.autograd.Function):
 
     @staticmethod
     def forward(ctx, module, x_in, cond, text_embed, mask, *params):
-        run = module._run_forward(x_in.detach(), cond.detach() if exists(cond) else None,
-                                  text_embed.detach() if exists(text_embed) else None, mask, True)
+        with ops.pinned_stream(x_in.device):
+            run = module._run_forward(x_in.detach(), cond.detach() if exists(cond) else None,
+                                      text_embed.detach() if exists(text_embed) else None, mask, True)
         ctx.run, ctx.module = run, module
         ctx.has_cond, ctx.has_text = exists(cond), exists(text_embed)
         ctx.x_dtype = x_in.dtype
