@@ -132,10 +132,13 @@ def main():
     text = synthetic_text(B, 1000 + rank)
     noise = {'drop_text_cond': True} if args.drop_text else None
 
+    params = list(model.parameters())
+
     def step():
         out = net(mel, text=text, _noise=noise)
         out.loss.backward()
-        model.zero_grad(set_to_none=True)
+        for p in params:                  # == optimizer.zero_grad(set_to_none=True) (trainer.py:277) without walking the
+            p.grad = None                 #    module tree every step (model.zero_grad costs ~10 ms of host time here)
         return out.loss
 
     if use_graphs:

@@ -308,6 +308,7 @@ class Transformer(Module):
         self._flat = None
         self._build_layout()
         self._grad_sync = None          # set by ddp.DataParallel: called with (grad_flat, start, end) per finished slab
+        self._vcache = {}
         self.use_graphs = False         # enable_graphs(): capture forward / per-layer backward into HIP graphs
         self._graphs = {}
 
@@ -455,6 +456,7 @@ class Transformer(Module):
         for p, off in lay.slots:
             p.data = flat[off:off + p.numel()].view(p.shape)
         self._flat = flat
+        self._vcache = {}
         self._shadow = torch.zeros(lay.n, dtype=bf16, device=device)
         self._shadowT = torch.zeros(max(self._tsize, 8), dtype=bf16, device=device)
         self._shadow_key = None
@@ -479,14 +481,28 @@ class Transformer(Module):
             ops.cast_transpose_bf16(src, dst)
 
     # views into the flat buffers -------------------------------------------------
+    # (views of the flat buffers are cached: the schedule asks for ~9000 of them per step and each torch view costs ~2 us
+    #  of host time; `_pack` drops the cache when the buffers are rebuilt)
     def _w(self, off, R, C):                  # bf16 weight (R, C)
-        return self._shadow[off:off + R * C].view(R, C)
+        key = ('w', off, R, C)
+        v = self._vcache.get(key)
+        if v is None:
+            v = self._vcache[key] = self._shadow[off:off + R * C].view(R, C)
+        return v
 
     def _wT(self, t):                          # transposed bf16 weight (C, ldd)
-        return self._shadowT[t.dst:t.dst + t.C * t.ldd].view(t.C, t.ldd)
+        key = ('t', t.dst, t.C, t.ldd)
+        v = self._vcache.get(key)
+        if v is None:
+            v = self._vcache[key] = self._shadowT[t.dst:t.dst + t.C * t.ldd].view(t.C, t.ldd)
+        return v
 
     def _f(self, off, n):                      # fp32 parameter vector
-        return self._flat[off:off + n]
+        key = ('f', off, n)
+        v = self._vcache.get(key)
+        if v is None:
+            v = self._vcache[key] = self._flat[off:off + n]
+        return v
 
     @staticmethod
     def _g(gflat, off, *shape):                # fp32 gradient view
@@ -693,7 +709,12 @@ class Transformer(Module):
 
     # -- stream helpers --------------------------------------------------------
     def _hc_params(self, hrec):
-        return [self._flat[o:o + _numel(s)].view(s) if len(s) else self._flat[o:o + 1].view(()) for o, s in zip(hrec.offs, hrec.shapes)]
+        key = ('hc', id(hrec))
+        v = self._vcache.get(key)
+        if v is None:
+            v = self._vcache[key] = [self._flat[o:o + _numel(s)].view(s) if len(s) else self._flat[o:o + 1].view(())
+                                     for o, s in zip(hrec.offs, hrec.shapes)]
+        return v
 
     def _hc_width(self, run, S, hrec):
         rec = _HCRec()
