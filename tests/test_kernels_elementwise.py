@@ -11,7 +11,7 @@ def rel(a, b):
     return ((a.float() - b.float()).abs().max() / b.float().abs().max().clamp_min(1e-20)).item()
 
 
-@pytest.mark.parametrize('D,nb', [(128, 1), (256, 3), (1024, 2)])
+@pytest.mark.parametrize('D,nb', [(128, 1), (256, 3), (512, 1), (768, 2), (1024, 2), (1536, 1), (2048, 2)])
 def test_rmsnorm(dev, D, nb):
     from e2_tts_pytorch_amd import ops
     torch.manual_seed(0)
@@ -35,10 +35,11 @@ def test_rmsnorm(dev, D, nb):
     assert rel(dg, gr.grad) < 1e-2
 
 
-def test_gate_bwd(dev):
+@pytest.mark.parametrize('D', [256, 512, 1024])
+def test_gate_bwd(dev, D):
     from e2_tts_pytorch_amd import ops
     torch.manual_seed(0)
-    D, rpb, nb = 256, 11, 3
+    rpb, nb = 11, 3
     M = rpb * nb
     ao = torch.randn(M, D)
     g = torch.rand(nb, D) * 0.5 + 0.1
@@ -86,17 +87,18 @@ def test_colsum_cast(dev):
     assert torch.equal(wt.cpu(), w.t().to(bf16))
 
 
-@pytest.mark.parametrize('ks,use_mask', [(31, True), (7, False)])
-def test_dwconv(dev, ks, use_mask):
+# (frames, kernel, mask): 75 frames = two tiles with a ragged tail; 200 frames = several tiles per workgroup in the backward
+@pytest.mark.parametrize('N,ks,use_mask', [(75, 31, True), (75, 7, False), (200, 31, True), (64, 15, False), (5, 3, False)])
+def test_dwconv(dev, N, ks, use_mask):
     from e2_tts_pytorch_amd import ops
     torch.manual_seed(0)
-    B, N, C = 2, 75, 128
+    B, C = 2, 128
     x = torch.randn(B, N, C).to(bf16)
     w = torch.randn(C, 1, ks) * 0.3
     bias = torch.randn(C) * 0.1
     mask = None
     if use_mask:
-        lens = torch.tensor([75, 50])
+        lens = torch.tensor([N, N - 25])
         mask = torch.arange(N)[None] < lens[:, None]
     dy = torch.randn(B, N, C).to(bf16)
     xr = x.float().requires_grad_(True)

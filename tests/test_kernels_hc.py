@@ -40,13 +40,15 @@ def rel(a, b):
     return ((a.float() - b.float()).abs().max() / b.float().abs().max().clamp_min(1e-20)).item()
 
 
-def _ok(got, want):
+def _ok(got, want, D=1024):
     if got.numel() == 1:        # heavily cancelling sums of bf16-rounded terms: absolute slack
         return abs(got.item() - want.item()) <= 0.15 * abs(want.item()) + 1.5
+    if got.numel() <= 32 and D > 1024:      # the 4 / 20 static gradients are sums over D * tokens bf16 products: noise ~ sqrt(D)
+        return rel(got, want) < 5e-2
     return rel(got, want) < 3e-2
 
 
-@pytest.mark.parametrize('D', [128, 256, 1024])
+@pytest.mark.parametrize('D', [128, 256, 512, 768, 1024, 1536, 2048])
 def test_hc_chain(dev, D):
     from e2_tts_pytorch_amd import ops
     Mtok = 37
@@ -97,6 +99,6 @@ def test_hc_chain(dev, D):
     dX, _ = ops.hc_bwd(dM1, xin=Xd, dbin=dbin1, ycur=y1, coef=c1, params=p1, grads=g1)
     assert rel(dX.cpu(), Xr.grad) < 3e-2, rel(dX.cpu(), Xr.grad)
     for name, gk, pr in zip(ops.HC_PARAM_NAMES, g2, _params(hc2)):
-        assert _ok(gk.cpu(), pr.grad), (name, 2, gk, pr.grad)
+        assert _ok(gk.cpu(), pr.grad, D), (name, 2, gk, pr.grad)
     for name, gk, pr in zip(ops.HC_PARAM_NAMES, g1, _params(hc1)):
-        assert _ok(gk.cpu(), pr.grad), (name, 1, gk, pr.grad)
+        assert _ok(gk.cpu(), pr.grad, D), (name, 1, gk, pr.grad)
