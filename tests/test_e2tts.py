@@ -67,6 +67,38 @@ def test_e2tts_forward_backward(dev):
         assert rel2(gk, gr) < 8e-2, (name, rel2(gk, gr))
 
 
+@pytest.mark.gpu
+def test_e2tts_cfg3_width():
+    """the widths the headline benchmark runs (dim 1024 / text dim 512 / 16 heads), two layers, ragged batch, against
+    the oracle: the D = 1024 / 512 kernel variants end to end on the hardware"""
+    from e2_tts_pytorch_amd import _lib
+    _lib._install_for_tests(None, host_pointers=False)
+    torch.set_num_threads(min(32, torch.get_num_threads()))
+    kw = dict(dim=1024, depth=2, heads=16, dropout=0.)
+    ref, model = _pair(kw)
+    model = model.cuda()
+    B, T = 2, 150
+    mel = torch.randn(B, T, 100)
+    lens = torch.tensor([T, T - 37])
+    noise = dict(x0=torch.randn(B, T, 100), times=torch.rand(B), frac_lengths=torch.tensor([0.75, 0.9]),
+                 span_rand=torch.tensor([0.2, 0.7]), drop_text_cond=False)
+    text = ['Hello', 'Goodbye, world']
+    out_r = ref(mel, text=text, lens=lens, _noise=noise)
+    out_r.loss.backward()
+    dn = {k: (v.cuda() if torch.is_tensor(v) else v) for k, v in noise.items()}
+    out = model(mel.cuda(), text=text, lens=lens.cuda(), _noise=dn)
+    out.loss.backward()
+    assert abs(out.loss.item() - out_r.loss.item()) / abs(out_r.loss.item()) < 1e-2
+    assert rel2(out.pred_flow, out_r.pred_flow) < 1e-2
+    refp = dict(ref.named_parameters())
+    for name in ('to_pred.weight', 'proj_in.weight', 'transformer.layers.0.0.3.to_out.weight', 'transformer.layers.1.0.3.to_q.weight',
+                 'transformer.layers.1.0.7.ff.0.proj.weight', 'transformer.layers.1.0.7.ff.2.bias', 'transformer.layers.1.1.2.to_v.weight',
+                 'transformer.layers.1.1.4.ff.0.proj.weight', 'transformer.layers.1.1.5.text_to_audio.weight',
+                 'transformer.layers.1.0.1.dw_conv1d.0.weight'):
+        gk, gr = dict(model.named_parameters())[name].grad, refp[name].grad
+        assert gk is not None and rel2(gk, gr) < 0.15, (name, rel2(gk, gr))
+
+
 def test_e2tts_text_dropped(dev):
     kw = dict(dim=256, depth=2, heads=4, dropout=0.)
     ref, model = _pair(kw, seed=1)
