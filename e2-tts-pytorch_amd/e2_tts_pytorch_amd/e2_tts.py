@@ -407,8 +407,7 @@ class E2TTS(Module):
         """`times` is accepted and ignored exactly like the reference (e2_tts.py:1473,1523).
         _noise: optional dict(x0, times, frac_lengths, span_rand, drop_text_cond) -- explicit draws for parity tests."""
         _noise = default(_noise, {})
-        if exists(velocity_consistency_model) and self.velocity_consistency_weight > 0.:
-            raise NotImplementedError('velocity-consistency loss is a default-off variant (SURVEY.md section 8f item 4)')
+        need_velocity_loss = exists(velocity_consistency_model) and self.velocity_consistency_weight > 0.     # e2_tts.py:1478
         if inp.ndim == 2:
             inp = self.mel_spec(inp).transpose(1, 2)
             assert inp.shape[-1] == self.num_channels
@@ -431,17 +430,28 @@ class E2TTS(Module):
         x0 = _noise['x0'] if 'x0' in _noise else torch.randn_like(x1)
         times = _noise['times'] if 'times' in _noise else torch.rand((batch,), dtype=dtype, device=device)
         t = times[:, None, None]
+        if need_velocity_loss:                      # e2_tts.py:1528-1529: keep t + delta inside [0, 1]
+            t = t * (1. - velocity_consistency_delta)
         w = (1. - t) * x0 + t * x1
         flow = x1 - x0
         cond = torch.where(rand_span_mask[..., None], torch.zeros_like(x1), x1)
-        pred, _ = self.transformer_with_pred_head(w, cond, times=times, text=text, mask=mask,
-                                                  drop_text_cond=_noise.get('drop_text_cond'),
-                                                  return_drop_text_cond=True)
+        pred, did_drop = self.transformer_with_pred_head(w, cond, times=times, text=text, mask=mask,
+                                                         drop_text_cond=_noise.get('drop_text_cond'),
+                                                         return_drop_text_cond=True)
+        m = rand_span_mask[..., None].to(pred.dtype)
         velocity_loss = self.zero
+        if need_velocity_loss:
+            # e2_tts.py:1558-1576: the EMA teacher (e.g. optim.FusedEMA(...).ema_model) predicts at t + delta with the
+            # same text-drop decision, no gradient; masked-span mean of the squared difference (sync-free form)
+            t_d = t + velocity_consistency_delta
+            w_d = (1. - t_d) * x0 + t_d * x1
+            with torch.no_grad():
+                ema_pred = velocity_consistency_model.transformer_with_pred_head(
+                    w_d, cond, times=times + velocity_consistency_delta, text=text, mask=mask, drop_text_cond=did_drop)
+            velocity_loss = (F.mse_loss(pred, ema_pred, reduction='none') * m).sum() / (m.sum() * pred.shape[-1])
         # mean of the squared error over the masked span == loss[rand_span_mask].mean() (e2_tts.py:1580-1582), written
         # as a masked sum so that no boolean-index gather (device sync for the element count) is needed
         sq = F.mse_loss(pred, flow, reduction='none')
-        m = rand_span_mask[..., None].to(sq.dtype)
         loss = (sq * m).sum() / (m.sum() * sq.shape[-1])
         total_loss = loss + velocity_loss * self.velocity_consistency_weight
         return E2TTSReturn(total_loss, cond, pred, x0 + pred, LossBreakdown(loss, velocity_loss))

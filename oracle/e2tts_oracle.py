@@ -809,7 +809,7 @@ class E2TTS(Module):
                 velocity_consistency_delta=1e-5, _noise=None):
         """_noise (test hook): dict with any of x0, times, frac_lengths, span_rand, drop_text_cond."""
         _noise = default(_noise, {})
-        assert not (exists(velocity_consistency_model) and self.velocity_consistency_weight > 0.), 'out of scope'
+        need_velocity_loss = exists(velocity_consistency_model) and self.velocity_consistency_weight > 0.      # e2_tts.py:1478
         if inp.ndim == 2:
             inp = self.mel_spec(inp).transpose(1, 2)
             assert inp.shape[-1] == self.num_channels
@@ -829,13 +829,23 @@ class E2TTS(Module):
         x0 = _noise['x0'] if 'x0' in _noise else torch.randn_like(x1)
         times = _noise['times'] if 'times' in _noise else torch.rand((batch,), dtype=dtype, device=device)
         t = times[:, None, None]
+        if need_velocity_loss:                      # e2_tts.py:1528-1529: keep t + delta inside [0, 1]
+            t = t * (1. - velocity_consistency_delta)
         w = (1. - t) * x0 + t * x1
         flow = x1 - x0
         cond = torch.where(rand_span_mask[..., None], torch.zeros_like(x1), x1)
-        pred, _ = self.transformer_with_pred_head(w, cond, times=times, text=text, mask=mask,
-                                                  drop_text_cond=_noise.get('drop_text_cond'),
-                                                  return_drop_text_cond=True)
+        pred, did_drop = self.transformer_with_pred_head(w, cond, times=times, text=text, mask=mask,
+                                                         drop_text_cond=_noise.get('drop_text_cond'),
+                                                         return_drop_text_cond=True)
         velocity_loss = self.zero
+        if need_velocity_loss:                      # e2_tts.py:1558-1576: EMA teacher at t + delta, same text-drop decision
+            t_d = t + velocity_consistency_delta
+            w_d = (1. - t_d) * x0 + t_d * x1
+            with torch.no_grad():
+                ema_pred = velocity_consistency_model.transformer_with_pred_head(
+                    w_d, cond, times=times + velocity_consistency_delta, text=text, mask=mask, drop_text_cond=did_drop)
+            velocity_loss = F.mse_loss(pred, ema_pred, reduction='none')
+            velocity_loss = velocity_loss[rand_span_mask].mean()
         loss = F.mse_loss(pred, flow, reduction='none')
         loss = loss[rand_span_mask].mean()
         total_loss = loss + velocity_loss * self.velocity_consistency_weight

@@ -30,13 +30,13 @@ def test_melspec(dev):
     assert (got.cpu() - ref).abs().max().item() < 2e-3      # log-mel, fp32 FFT vs torch.stft
 
 
-def _pair(kw, seed=0, duration_predictor=None):
+def _pair(kw, seed=0, duration_predictor=None, **extra):
     from e2_tts_pytorch_amd import E2TTS
     random.seed(seed)
     torch.manual_seed(seed)
-    ref = O.E2TTS(transformer=dict(**kw), cond_drop_prob=0., duration_predictor=duration_predictor)
+    ref = O.E2TTS(transformer=dict(**kw), cond_drop_prob=0., duration_predictor=duration_predictor, **extra)
     randomize(ref)
-    model = E2TTS(transformer=dict(**kw), use_vocos=False, cond_drop_prob=0., duration_predictor=duration_predictor)
+    model = E2TTS(transformer=dict(**kw), use_vocos=False, cond_drop_prob=0., duration_predictor=duration_predictor, **extra)
     model.load_state_dict(ref.state_dict(), strict=True)
     return ref, model
 
@@ -97,6 +97,41 @@ def test_e2tts_cfg3_width():
                  'transformer.layers.1.0.1.dw_conv1d.0.weight'):
         gk, gr = dict(model.named_parameters())[name].grad, refp[name].grad
         assert gk is not None and rel2(gk, gr) < 0.15, (name, rel2(gk, gr))
+
+
+def test_velocity_consistency_loss(dev):
+    """velocity-consistency term (e2_tts.py:1558-1576) with an EMA teacher: total loss, both breakdown terms and the
+    student's gradients against the oracle; the teacher receives no gradient"""
+    import copy
+    kw = dict(dim=256, depth=2, heads=4, dropout=0.)
+    ref, model = _pair(kw, velocity_consistency_weight=0.5)
+    tref = copy.deepcopy(ref)
+    with torch.no_grad():
+        for p in tref.parameters():
+            p.add_(torch.randn_like(p) * 0.02)               # a teacher that differs from the student
+    from e2_tts_pytorch_amd import E2TTS
+    teacher = E2TTS(transformer=dict(**kw), use_vocos=False, cond_drop_prob=0.)
+    teacher.load_state_dict(tref.state_dict(), strict=True)
+    model, teacher = model.to(dev), teacher.to(dev)
+    B, T = 2, 48
+    mel = torch.randn(B, T, 100)
+    lens = torch.tensor([T, T - 9])
+    noise = dict(x0=torch.randn(B, T, 100), times=torch.rand(B), frac_lengths=torch.tensor([0.8, 0.9]),
+                 span_rand=torch.tensor([0.1, 0.5]), drop_text_cond=False)
+    text = ['Hello', 'Goodbye']
+    out_r = ref(mel, text=text, lens=lens, velocity_consistency_model=tref, _noise=noise)
+    out_r.loss.backward()
+    dn = {k: (v.to(dev) if torch.is_tensor(v) else v) for k, v in noise.items()}
+    out = model(mel.to(dev), text=text, lens=lens.to(dev), velocity_consistency_model=teacher, _noise=dn)
+    out.loss.backward()
+    br, bk = out_r.loss_breakdown, out.loss_breakdown
+    assert br.velocity_consistency.item() > 0
+    assert abs(bk.flow.item() - br.flow.item()) / br.flow.item() < 1e-2
+    assert abs(bk.velocity_consistency.item() - br.velocity_consistency.item()) / br.velocity_consistency.item() < 3e-2
+    assert abs(out.loss.item() - out_r.loss.item()) / out_r.loss.item() < 1e-2
+    gk, gr = model.to_pred.weight.grad, ref.to_pred.weight.grad
+    assert rel2(gk, gr) < 8e-2
+    assert all(p.grad is None for p in teacher.parameters())
 
 
 def test_e2tts_text_dropped(dev):
