@@ -91,3 +91,30 @@ def test_fused_adopt_on_model(dev):
     assert 0. < d < 1.
     for e, p in zip(ema.ema_model.parameters(), model.parameters()):
         assert e.shape == p.shape and torch.isfinite(e).all()
+
+
+def test_training_loop_reduces_loss(dev):
+    """the pieces of the reference trainer's step (trainer.py:263-279) together: forward, backward, clip + ADOPT, EMA.
+    A fixed batch and fixed noise draws: the flow-matching loss must go down"""
+    from e2_tts_pytorch_amd import E2TTS
+    from e2_tts_pytorch_amd.optim import FusedAdopt, FusedEMA
+    import random
+    random.seed(0)
+    torch.manual_seed(0)
+    model = E2TTS(transformer=dict(dim=256, depth=2, heads=4, dropout=0.), use_vocos=False, cond_drop_prob=0.).to(dev)
+    B, T = 2, 24
+    mel = torch.randn(B, T, 100, device=dev)
+    noise = dict(x0=torch.randn(B, T, 100, device=dev), times=torch.tensor([0.3, 0.7], device=dev),
+                 frac_lengths=torch.tensor([0.8, 0.9], device=dev), span_rand=torch.tensor([0.1, 0.5], device=dev), drop_text_cond=False)
+    opt = FusedAdopt(model, lr=3e-3, max_grad_norm=1.0)
+    ema = FusedEMA(model, update_after_step=0, update_every=1)
+    losses = []
+    for _ in range(7):
+        out = model(mel, text=['hello', 'world'], _noise=noise)
+        out.loss.backward()
+        opt.step()
+        opt.zero_grad()
+        ema.update()
+        losses.append(out.loss.item())
+    assert all(l == l for l in losses), losses                 # finite
+    assert losses[-1] < 0.9 * losses[1], losses                # (step 0 of ADOPT only initialises v)
