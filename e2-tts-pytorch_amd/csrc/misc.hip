@@ -1,4 +1,4 @@
-// Small utility kernels: version, fp32 -> bf16 parameter shadow cast, column sums (bias gradients).
+// Library version (the ABI number bindings can check).
 #include "e2k_device.h"
 #include "../../include/e2k.h"
 

@@ -277,8 +277,8 @@ class E2TTS(Module):
     ):
         super().__init__()
         assert num_freq_tokens > 0
-        if num_freq_tokens != 1 or concat_cond or interpolated_text:
-            raise NotImplementedError('num_freq_tokens > 1 / concat_cond / interpolated_text are not built')
+        if num_freq_tokens != 1 or interpolated_text:
+            raise NotImplementedError('num_freq_tokens > 1 / interpolated_text are not built')
         if odeint_kwargs.get('method', 'midpoint') != 'midpoint':
             raise NotImplementedError('only the midpoint solver (the reference default) is built')
         self.num_freq_tokens, self.has_freq_axis = 1, False
@@ -299,9 +299,12 @@ class E2TTS(Module):
         num_channels = default(num_channels, self.mel_spec.n_mel_channels)
         self.num_channels = num_channels
         self.sampling_rate = default(sampling_rate, getattr(self.mel_spec, 'sampling_rate', None))
-        self.concat_cond = False
-        self.proj_in = nn.Linear(num_channels, dim)
-        self.cond_proj_in = nn.Linear(num_channels, dim)
+        self.concat_cond = concat_cond                    # e2_tts.py:1196-1204: one projection of cat(cond, x) instead of two summed
+        if concat_cond:
+            self.proj_in = nn.Linear(num_channels * 2, dim)
+        else:
+            self.proj_in = nn.Linear(num_channels, dim)
+            self.cond_proj_in = nn.Linear(num_channels, dim)
         self.to_pred = nn.Linear(dim, num_channels)
         self.tokenizer, text_num_embeds = _resolve_tokenizer(tokenizer, text_num_embeds)
         self.cond_drop_prob = cond_drop_prob
@@ -327,7 +330,10 @@ class E2TTS(Module):
                                    return_drop_text_cond=False):
         seq_len = x.shape[-2]
         drop_text_cond = default(drop_text_cond, self.training and random() < self.cond_drop_prob)
-        x = self.proj_in(x) + self.cond_proj_in(cond)
+        if self.concat_cond:                              # e2_tts.py:1263-1276
+            x = self.proj_in(torch.cat((cond, x), dim=-1))
+        else:
+            x = self.proj_in(x) + self.cond_proj_in(cond)
         text_embed = None
         if exists(text) and not drop_text_cond:
             text_embed = self.embed_text(text, seq_len, mask=mask)

@@ -699,7 +699,7 @@ class E2TTS(Module):
                  text_num_embeds=None, tokenizer='char_utf8', use_vocos=False, pretrained_vocos_path=None,
                  sampling_rate=None, velocity_consistency_weight=0.):
         super().__init__()
-        assert num_freq_tokens == 1 and not concat_cond and not interpolated_text and not use_vocos
+        assert num_freq_tokens == 1 and not interpolated_text and not use_vocos
         if isinstance(transformer, dict):
             transformer = Transformer(**transformer, cond_on_time=True)
         self.transformer = transformer
@@ -714,8 +714,12 @@ class E2TTS(Module):
         num_channels = default(num_channels, self.mel_spec.n_mel_channels)
         self.num_channels = num_channels
         self.sampling_rate = default(sampling_rate, getattr(self.mel_spec, 'sampling_rate', None))
-        self.proj_in = nn.Linear(num_channels, dim)
-        self.cond_proj_in = nn.Linear(num_channels, dim)
+        self.concat_cond = concat_cond                    # e2_tts.py:1196-1204
+        if concat_cond:
+            self.proj_in = nn.Linear(num_channels * 2, dim)
+        else:
+            self.proj_in = nn.Linear(num_channels, dim)
+            self.cond_proj_in = nn.Linear(num_channels, dim)
         self.to_pred = nn.Linear(dim, num_channels)
         if callable(tokenizer):
             assert exists(text_num_embeds)
@@ -738,7 +742,10 @@ class E2TTS(Module):
                                    return_drop_text_cond=False):
         seq_len = x.shape[-2]
         drop_text_cond = default(drop_text_cond, self.training and _pyrandom.random() < self.cond_drop_prob)
-        x = self.proj_in(x) + self.cond_proj_in(cond)
+        if self.concat_cond:                              # e2_tts.py:1263-1276
+            x = self.proj_in(torch.cat((cond, x), dim=-1))
+        else:
+            x = self.proj_in(x) + self.cond_proj_in(cond)
         text_embed = None
         if exists(text) and not drop_text_cond:
             text_embed = self.embed_text(text, seq_len, mask=mask)

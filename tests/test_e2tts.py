@@ -99,6 +99,26 @@ def test_e2tts_cfg3_width():
         assert gk is not None and rel2(gk, gr) < 0.15, (name, rel2(gk, gr))
 
 
+def test_concat_cond(dev):
+    """concat_cond=True (e2_tts.py:1196-1204,1263-1276): one Linear(2 * n_mels, dim) on cat(cond, x)"""
+    kw = dict(dim=256, depth=2, heads=4, dropout=0.)
+    ref, model = _pair(kw, concat_cond=True)
+    assert not hasattr(model, 'cond_proj_in') and model.proj_in.in_features == 200
+    model = model.to(dev)
+    B, T = 2, 40
+    mel = torch.randn(B, T, 100)
+    noise = dict(x0=torch.randn(B, T, 100), times=torch.rand(B), frac_lengths=torch.tensor([0.8, 0.9]),
+                 span_rand=torch.tensor([0.1, 0.5]), drop_text_cond=False)
+    out_r = ref(mel, text=['ab', 'cd'], _noise=noise)
+    out_r.loss.backward()
+    dn = {k: (v.to(dev) if torch.is_tensor(v) else v) for k, v in noise.items()}
+    out = model(mel.to(dev), text=['ab', 'cd'], _noise=dn)
+    out.loss.backward()
+    assert abs(out.loss.item() - out_r.loss.item()) / abs(out_r.loss.item()) < 1e-2
+    assert rel2(out.pred_flow, out_r.pred_flow) < 1e-2
+    assert rel2(model.proj_in.weight.grad, ref.proj_in.weight.grad) < 8e-2
+
+
 def test_velocity_consistency_loss(dev):
     """velocity-consistency term (e2_tts.py:1558-1576) with an EMA teacher: total loss, both breakdown terms and the
     student's gradients against the oracle; the teacher receives no gradient"""
