@@ -17,7 +17,8 @@ def hm(t, B, H, N):          # (B*N, H*64) token-major -> (B,H,N,64)
 
 
 # qk_gain 3: ordinary logits (polynomial soft-clamp path); 14: logits far into the tanh clamp (exp2 / rcp path)
-@pytest.mark.parametrize('N,has_vres,use_mask,qk_gain', [(70, False, False, 3.0), (150, True, True, 3.0), (100, False, True, 14.0)])
+@pytest.mark.parametrize('N,has_vres,use_mask,qk_gain', [(70, False, False, 3.0), (150, True, True, 3.0), (100, False, True, 14.0),
+                                                         (64, False, False, 3.0), (129, True, True, 3.0), (40, False, True, 3.0)])
 def test_attention(dev, N, has_vres, use_mask, qk_gain):
     from e2_tts_pytorch_amd import ops
     torch.manual_seed(0)

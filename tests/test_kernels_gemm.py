@@ -126,3 +126,59 @@ def test_gemm_nt_big_tile(dev, M, N, K1, K2, kw, flags):
         test_gemm_nt(dev, M, N, K1, K2, kw)
     finally:
         ops.gemm_flags = old
+
+
+def test_gemm_random_shapes(dev):
+    """seeded sweep over ragged shapes / operand combinations of both GEMMs (edge tiles, odd K panels, every epilogue
+    operand, the remainder split with the 8-slot test hook, column sums from an offset)"""
+    import random as pyrandom
+    from e2_tts_pytorch_amd import ops
+    rng = pyrandom.Random(1234)
+    to = lambda t: None if t is None else t.to(dev)
+    old = ops.gemm_flags
+    try:
+        for case in range(24):
+            M = rng.choice([1, 7, 64, 129, 200, 257, 520, 1100])
+            N = rng.choice([8, 24, 100, 128, 136, 260, 392])
+            K1 = 8 * rng.randint(1, 40)
+            K2 = rng.choice([0, 0, 8 * rng.randint(1, 24)])
+            torch.manual_seed(case)
+            a = torch.randn(M, K1).to(bf16)
+            a2 = torch.randn(M, K2).to(bf16) if K2 else None
+            b = torch.randn(N, K1 + K2).to(bf16)
+            bias = torch.randn(N) if rng.random() < 0.5 else None
+            rs = torch.randn(M, N).to(bf16) if rng.random() < 0.4 else None
+            rm = (torch.rand(M) > 0.3) if rng.random() < 0.3 else None
+            f32out = rng.random() < 0.3
+            ops.gemm_flags = rng.choice([0, 0, 32])
+            out = ops.gemm_nt(to(a), to(b), a2=to(a2), bias=to(bias), rowmask=to(rm), resid=to(rs),
+                              out_dtype=torch.float32 if f32out else bf16)
+            A = torch.cat([a, a2], 1).float() if K2 else a.float()
+            ref = A @ b.float().T
+            if bias is not None:
+                ref = ref + bias
+            if rm is not None:
+                ref = ref * rm[:, None].float()
+            if rs is not None:
+                ref = ref + rs.float()
+            assert rel(out, ref) < (1e-5 if f32out else 6e-3), ('nt', case, M, N, K1, K2, ops.gemm_flags)
+        ops.gemm_flags = 0
+        for case in range(16):
+            M = rng.choice([8, 64, 100, 192, 320, 1000])
+            N = 8 * rng.randint(1, 50)
+            K = 8 * rng.randint(1, 50)
+            torch.manual_seed(100 + case)
+            a = torch.randn(M, N).to(bf16)
+            b = torch.randn(M, K).to(bf16)
+            out = torch.ones(N, K, device=dev)
+            cs_from = 2 * rng.randint(0, N // 2 - 1) if rng.random() < 0.5 else None
+            cs = torch.zeros(N, device=dev) if cs_from is not None else None
+            ops.gemm_tn(a.to(dev), b.to(dev), out, splits=rng.choice([0, 1, 2, 3]), use_tr=rng.random() < 0.8,
+                        colsum=cs, colsum_from=cs_from or 0)
+            assert rel(out, 1 + a.float().T @ b.float()) < 1e-5, ('tn', case, M, N, K)
+            if cs is not None:
+                want = a.float().sum(0)
+                want[:cs_from] = 0
+                assert torch.allclose(cs.cpu(), want, rtol=1e-4, atol=1e-3), ('colsum', case, M, N, K, cs_from)
+    finally:
+        ops.gemm_flags = old
