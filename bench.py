@@ -240,7 +240,7 @@ def main():
             'host_enqueue_ms_per_step': t_enqueue / args.steps * 1e3,
             'hip_graphs': use_graphs, 'launch_mode': launch_mode_note,
             'roofline': {
-                'bound': 'mfma', 'kernel': 'e2k gemm_nt_kernel (bf16 MFMA 16x16x32, all forward + dgrad GEMMs)',
+                'bound': 'mfma', 'kernel': 'gemm_nt_glds_kernel + gemm_nt_fixup_kernel (bf16 MFMA 16x16x32; every forward and dgrad GEMM of the step)',
                 'achieved': achieved, 'peak': PEAK_BF16_TFLOPS, 'unit': 'TFLOP/s', 'frac': achieved / PEAK_BF16_TFLOPS,
                 'launches_per_step': n_launch / nprof,
                 'avg_launch_ms': gemm_ms / max(n_launch, 1),
