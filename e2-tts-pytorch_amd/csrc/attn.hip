@@ -262,6 +262,9 @@ struct AttnArgs {
     int B, H, N, Npad;
     float scale; unsigned seed, stream_id, thresh; float inv_keep;
     const unsigned* seed_dev;                  // if set, the dropout seed is read from device memory (graph replay)
+    // optional: keep decisions of the dropout as ballot words, written by the forward and read by the backward instead
+    // of re-hashing: [b*h][key tile][query tile][wave 0..3][slot 4t+r] uint64, bit (16 g + l15) = lane of the forward
+    unsigned long long* dropbits;
     // backward
     const bf16_t* dOg;                         // (B*N, h*64)
     bf16_t* dO; bf16_t* dOT;                   // head-major / transposed
@@ -284,7 +287,7 @@ __device__ __forceinline__ void score_tile(const unsigned char* Kt, const bf16x8
 }
 
 
-template <bool DROP>
+template <bool DROP, bool SHARE>      // SHARE: dropout keep masks are handed from the forward to the backward (p.dropbits)
 __global__ __launch_bounds__(256, 2) void attn_fwd_kernel(AttnArgs p) {
     __shared__ __attribute__((aligned(16))) unsigned char Kt[64 * 128];
     __shared__ __attribute__((aligned(16))) unsigned char Vt[64 * 128];
@@ -324,6 +327,8 @@ __global__ __launch_bounds__(256, 2) void attn_fwd_kernel(AttnArgs p) {
         }
         f32x4 s[4];
         score_tile(Kt, qf, l15, g, s);
+        unsigned long long* dropw = (DROP && SHARE)
+            ? p.dropbits + ((((long)bh * ntiles + kt) * gridDim.x + blockIdx.x) * 4 + wave) * 16 : nullptr;
         // mask bits of keys k0 + 32*kk2 + 8g .. +8  (kk2 = t>>1, bit index = 8*kk2 + 4*(t&1) + r)
         const unsigned km = mask_bits(ld<unsigned long long>(p.kmask + (long)b * p.Npad + k0 + g * 8)) |
                             (mask_bits(ld<unsigned long long>(p.kmask + (long)b * p.Npad + k0 + 32 + g * 8)) << 8);
@@ -375,8 +380,13 @@ __global__ __launch_bounds__(256, 2) void attn_fwd_kernel(AttnArgs p) {
                 psum += p0 + p1;
                 if (DROP) {          // keys of r, r+1 are an (even, odd) pair; 1/(1-p) is applied once at the end
                     const unsigned hh = drop_hash(hrow, (unsigned)(k0 + perm_row(t, 4 * g + r)) >> 1);
-                    p0 = (hh & 0xffffu) >= p.thresh ? p0 : 0.f;
-                    p1 = (hh >> 16) >= p.thresh ? p1 : 0.f;
+                    const bool keep0 = (hh & 0xffffu) >= p.thresh, keep1 = (hh >> 16) >= p.thresh;
+                    p0 = keep0 ? p0 : 0.f;
+                    p1 = keep1 ? p1 : 0.f;
+                    if (SHARE) {         // publish the compare masks for the backward kernels
+                        const unsigned long long m0 = wave_ballot(keep0), m1 = wave_ballot(keep1);
+                        if (lane == 0) { dropw[4 * t + r] = m0; dropw[4 * t + r + 1] = m1; }
+                    }
                 }
                 s[t][r] = p0;
                 s[t][r + 1] = p1;
@@ -467,7 +477,7 @@ __global__ __launch_bounds__(256) void attn_bwd_prep_kernel(AttnArgs p) {
 }
 
 // dQ: same sweep as the forward; dS^T tiles feed dQ^T = K^T . dS^T
-template <bool DROP>
+template <bool DROP, bool SHARE>      // SHARE: dropout keep masks are handed from the forward to the backward (p.dropbits)
 __global__ __launch_bounds__(256, 2) void attn_bwd_dq_kernel(AttnArgs p) {
     __shared__ __attribute__((aligned(16))) unsigned char Kt[64 * 128];
     __shared__ __attribute__((aligned(16))) unsigned char Vr[64 * 128];
@@ -522,15 +532,22 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dq_kernel(AttnArgs p) {
         const bool allk = wave_all(km == 0xffffu);
         const float kx = p.scale / CLAMP;
         const bool small = wave_all(abs_max16(s) * kx <= TANH_POLY_MAX);
+        const unsigned long long* dropw = (DROP && SHARE)
+            ? p.dropbits + ((((long)bh * ntiles + kt) * gridDim.x + blockIdx.x) * 4 + uniform_i(wave)) * 16 : nullptr;
 #pragma unroll
         for (int t = 0; t < 4; ++t)
 #pragma unroll
             for (int r = 0; r < 4; r += 2) {
                 float ks0 = 1.f, ks1 = 1.f;
                 if (DROP) {
-                    const unsigned hh = drop_hash(hrow, (unsigned)(k0 + perm_row(t, 4 * g + r)) >> 1);
-                    ks0 = (hh & 0xffffu) >= p.thresh ? p.inv_keep : 0.f;
-                    ks1 = (hh >> 16) >= p.thresh ? p.inv_keep : 0.f;
+                    if (SHARE) {         // the forward's compare masks: same lane <-> (query, key) layout as here
+                        ks0 = wave_inverse_ballot(sload64(dropw + 4 * t + r)) ? p.inv_keep : 0.f;
+                        ks1 = wave_inverse_ballot(sload64(dropw + 4 * t + r + 1)) ? p.inv_keep : 0.f;
+                    } else {
+                        const unsigned hh = drop_hash(hrow, (unsigned)(k0 + perm_row(t, 4 * g + r)) >> 1);
+                        ks0 = (hh & 0xffffu) >= p.thresh ? p.inv_keep : 0.f;
+                        ks1 = (hh >> 16) >= p.thresh ? p.inv_keep : 0.f;
+                    }
                 }
                 f32x2_ th2;
                 if (small) th2 = tanh_poly2(f32x2_{s[t][r], s[t][r + 1]} * kx);
@@ -575,7 +592,7 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dq_kernel(AttnArgs p) {
 
 // dK, dV: one workgroup per 64 keys (a wave owns 16), sweep over query tiles.
 //   S = Q.K^T (rows = queries, permuted inside the tile), P^T-like accumulators feed dV^T = dO^T.P and dK^T = Q^T.dS
-template <bool DROP>
+template <bool DROP, bool SHARE>      // SHARE: dropout keep masks are handed from the forward to the backward (p.dropbits)
 __global__ __launch_bounds__(256, 2) void attn_bwd_dkv_kernel(AttnArgs p) {
     __shared__ __attribute__((aligned(16))) unsigned char Qt[64 * 128];
     __shared__ __attribute__((aligned(16))) unsigned char dOt[64 * 128];
@@ -647,6 +664,20 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dkv_kernel(AttnArgs p) {
             }
         }
         float pd[4][4], dsv[4][4];
+        // Shared dropout masks: score (t, r) of this lane is (query qi = 32(t>>1) + 8g + 4(t&1) + r, key pos = 16 wave + l15).
+        // In the forward that pair sat in wave qi >> 4 = 2(t>>1) + (g>>1), lane 16 g' + (qi & 15), slot 4t' + r', with
+        // (t', g', r') the position of THIS key in the forward's key permutation: one 64-bit word per (t>>1) covers
+        // all eight (t&1, r) of it.
+        unsigned long long dword[2] = {0ull, 0ull};
+        int dbit0 = 0;
+        if (DROP && SHARE) {
+            const int pos = wave * 16 + l15;
+            const int tf = 2 * (pos >> 5) + ((pos >> 2) & 1), gf = (pos >> 3) & 3, rf = pos & 3;
+            dbit0 = 16 * gf + 8 * (g & 1);
+            const unsigned long long* base = p.dropbits + ((((long)bh * ntiles + blockIdx.x) * ntiles + qt) * 4 + (g >> 1)) * 16 + 4 * tf + rf;
+            dword[0] = base[0];
+            dword[1] = base[2 * 16];
+        }
         const float kx = p.scale / CLAMP;
         if (wave_all(abs_max16(s) * kx <= TANH_POLY_MAX)) {      // soft-clamp tanh, see tanh_poly2
 #pragma unroll
@@ -673,8 +704,12 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dkv_kernel(AttnArgs p) {
                 const float pr = fast_exp2(cl2 * th - lse_s[qi]);
                 float ks = 1.f;
                 if (DROP) {
-                    const unsigned hh = fmix32(hkey + (unsigned)(q0 + qi) * 0x85ebca77u);
-                    ks = ((key & 1) ? (hh >> 16) : (hh & 0xffffu)) >= p.thresh ? p.inv_keep : 0.f;
+                    if (SHARE) {         // bit of (query qi, this lane's key) in the forward's ballot words
+                        ks = ((dword[t >> 1] >> (dbit0 + 4 * (t & 1) + r)) & 1ull) ? p.inv_keep : 0.f;
+                    } else {
+                        const unsigned hh = fmix32(hkey + (unsigned)(q0 + qi) * 0x85ebca77u);
+                        ks = ((key & 1) ? (hh >> 16) : (hh & 0xffffu)) >= p.thresh ? p.inv_keep : 0.f;
+                    }
                 }
                 const float pv = pr * ks;
                 const float ds = pr * (dp[t][r] * ks - del_s[qi]) * (1.f - th * th) * p.scale;
@@ -753,8 +788,14 @@ static int fill_attn(AttnArgs& a, int B, int H, int N, int Npad, float p_drop, u
     return 0;
 }
 
+extern "C" int e2k_query_attn_dropbits_bytes(int B, int H, int N) {
+    const long nt = (N + 63) / 64;
+    const long bytes = (long)B * H * nt * nt * 4 * 16 * 8;
+    return bytes > 0x7fffffffL ? -1 : (int)bytes;
+}
+
 extern "C" int e2k_attn_fwd(const void* Q, const void* K, const void* VT, const uint8_t* kmask, const float* gate,
-                            void* O, void* Og, float* lse2, int B, int H, int N, int Npad, float p_drop,
+                            void* O, void* Og, float* lse2, void* dropbits, int B, int H, int N, int Npad, float p_drop,
                             uint32_t seed, const uint32_t* seed_dev, uint32_t stream_id, void* stream) {
     if (B <= 0 || N <= 0) return 0;
     if (!Q || !K || !VT || !kmask || !gate || !O || !Og || !lse2) return E2K_ERR_ARG;
@@ -763,16 +804,18 @@ extern "C" int e2k_attn_fwd(const void* Q, const void* K, const void* VT, const 
     if (rc) return rc;
     a.Q = (const bf16_t*)Q; a.K = (const bf16_t*)K; a.VT = (const bf16_t*)VT; a.kmask = kmask; a.gate = gate;
     a.O = (bf16_t*)O; a.Og = (bf16_t*)Og; a.lse2 = lse2;
-    if (a.thresh) hipLaunchKernelGGL(attn_fwd_kernel<true>, dim3((N + 63) / 64, H, B), dim3(256), 0, (hipStream_t)stream, a);
-    else hipLaunchKernelGGL(attn_fwd_kernel<false>, dim3((N + 63) / 64, H, B), dim3(256), 0, (hipStream_t)stream, a);
+    a.dropbits = (unsigned long long*)dropbits;
+    if (a.thresh && dropbits) hipLaunchKernelGGL((attn_fwd_kernel<true, true>), dim3((N + 63) / 64, H, B), dim3(256), 0, (hipStream_t)stream, a);
+    else if (a.thresh) hipLaunchKernelGGL((attn_fwd_kernel<true, false>), dim3((N + 63) / 64, H, B), dim3(256), 0, (hipStream_t)stream, a);
+    else hipLaunchKernelGGL((attn_fwd_kernel<false, false>), dim3((N + 63) / 64, H, B), dim3(256), 0, (hipStream_t)stream, a);
     E2K_CHECK_LAUNCH();
     return 0;
 }
 
 extern "C" int e2k_attn_bwd(const void* dOg, const void* O, const float* gate, const float* lse2, const void* Q,
                             const void* K, const void* V, const void* QT, const void* KT, const uint8_t* kmask,
-                            void* dO, void* dOT, float* delta, float* dgate_pre, void* dQ, void* dK, void* dV,
-                            int B, int H, int N, int Npad, float p_drop, uint32_t seed, const uint32_t* seed_dev,
+                            const void* dropbits, void* dO, void* dOT, float* delta, float* dgate_pre, void* dQ, void* dK,
+                            void* dV, int B, int H, int N, int Npad, float p_drop, uint32_t seed, const uint32_t* seed_dev,
                             uint32_t stream_id, void* stream) {
     if (B <= 0 || N <= 0) return 0;
     if (!dOg || !O || !gate || !lse2 || !Q || !K || !V || !QT || !KT || !kmask || !dO || !dOT || !delta || !dgate_pre ||
@@ -783,16 +826,19 @@ extern "C" int e2k_attn_bwd(const void* dOg, const void* O, const float* gate, c
     a.dOg = (const bf16_t*)dOg; a.O = (bf16_t*)O; a.gate = gate; a.lse2 = const_cast<float*>(lse2);
     a.Q = (const bf16_t*)Q; a.K = (const bf16_t*)K; a.V = (const bf16_t*)V; a.QT = (const bf16_t*)QT;
     a.KT = (const bf16_t*)KT; a.kmask = kmask;
+    a.dropbits = (unsigned long long*)dropbits;
     a.dO = (bf16_t*)dO; a.dOT = (bf16_t*)dOT; a.delta = delta; a.dgate_pre = dgate_pre;
     a.dQ = (bf16_t*)dQ; a.dK = (bf16_t*)dK; a.dV = (bf16_t*)dV;
     hipStream_t st = (hipStream_t)stream;
     hipLaunchKernelGGL(attn_bwd_prep_kernel, dim3(Npad / 64, H, B), dim3(256), 0, st, a);
     E2K_CHECK_LAUNCH();
-    if (a.thresh) hipLaunchKernelGGL(attn_bwd_dq_kernel<true>, dim3((N + 63) / 64, H, B), dim3(256), 0, st, a);
-    else hipLaunchKernelGGL(attn_bwd_dq_kernel<false>, dim3((N + 63) / 64, H, B), dim3(256), 0, st, a);
+    if (a.thresh && dropbits) hipLaunchKernelGGL((attn_bwd_dq_kernel<true, true>), dim3((N + 63) / 64, H, B), dim3(256), 0, st, a);
+    else if (a.thresh) hipLaunchKernelGGL((attn_bwd_dq_kernel<true, false>), dim3((N + 63) / 64, H, B), dim3(256), 0, st, a);
+    else hipLaunchKernelGGL((attn_bwd_dq_kernel<false, false>), dim3((N + 63) / 64, H, B), dim3(256), 0, st, a);
     E2K_CHECK_LAUNCH();
-    if (a.thresh) hipLaunchKernelGGL(attn_bwd_dkv_kernel<true>, dim3((N + 63) / 64, H, B), dim3(256), 0, st, a);
-    else hipLaunchKernelGGL(attn_bwd_dkv_kernel<false>, dim3((N + 63) / 64, H, B), dim3(256), 0, st, a);
+    if (a.thresh && dropbits) hipLaunchKernelGGL((attn_bwd_dkv_kernel<true, true>), dim3((N + 63) / 64, H, B), dim3(256), 0, st, a);
+    else if (a.thresh) hipLaunchKernelGGL((attn_bwd_dkv_kernel<true, false>), dim3((N + 63) / 64, H, B), dim3(256), 0, st, a);
+    else hipLaunchKernelGGL((attn_bwd_dkv_kernel<false, false>), dim3((N + 63) / 64, H, B), dim3(256), 0, st, a);
     E2K_CHECK_LAUNCH();
     return 0;
 }

@@ -94,6 +94,16 @@ __device__ __forceinline__ float fast_rsq(float x) { return __builtin_amdgcn_rsq
 // wave vote: true when the predicate holds in every lane (all 64 lanes active at the call sites)
 __device__ __forceinline__ bool wave_all(bool pred) { return __builtin_amdgcn_ballot_w64(pred) == ~0ull; }
 
+// lane predicate <-> 64-bit wave mask.  ballot is the SGPR pair a v_cmp writes anyway; inverse_ballot hands a mask to
+// v_cndmask as its select operand (no per-lane unpacking)
+__device__ __forceinline__ unsigned long long wave_ballot(bool pred) { return __builtin_amdgcn_ballot_w64(pred); }
+__device__ __forceinline__ bool wave_inverse_ballot(unsigned long long m) { return __builtin_amdgcn_inverse_ballot_w64(m); }
+// 64-bit load through the constant address space (s_load_dwordx2 when the address is wave-uniform), see sload()
+__device__ __forceinline__ unsigned long long sload64(const unsigned long long* p) {
+    typedef const __attribute__((address_space(4))) unsigned long long* cp_t;
+    return *(cp_t)(p);
+}
+
 // counted wait on outstanding vector-memory ops (LDS-DMA included) and a raw workgroup barrier that does NOT drain
 // them: lets global_load_lds prefetches stay in flight across barriers (cdna_hip_programming.md T3+T4)
 template <int N> __device__ __forceinline__ void wait_vmcnt() { asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory"); }

@@ -314,7 +314,7 @@ def rotary_table(n, device, dim_head=64, base=10000.):
 
 class AttnState:
     """buffers produced by qkv_post_fwd / attn_fwd and consumed by the backward"""
-    __slots__ = ('Q', 'K', 'V', 'QT', 'KT', 'VT', 'gate', 'mix', 'O', 'Og', 'lse2', 'B', 'H', 'N', 'Npad')
+    __slots__ = ('Q', 'K', 'V', 'QT', 'KT', 'VT', 'gate', 'mix', 'O', 'Og', 'lse2', 'B', 'H', 'N', 'Npad', 'dropbits')
 
 
 def qkv_post_fwd(qkvg, B, H, N, cosb, sinb, vfirst=None):
@@ -323,7 +323,7 @@ def qkv_post_fwd(qkvg, B, H, N, cosb, sinb, vfirst=None):
     dev = qkvg.device
     Npad = (N + 63) // 64 * 64
     st = AttnState()
-    st.B, st.H, st.N, st.Npad = B, H, N, Npad
+    st.B, st.H, st.N, st.Npad, st.dropbits = B, H, N, Npad, None
     st.Q, st.K, st.V = (torch.empty((B, H, N, 64), dtype=bf16, device=dev) for _ in range(3))
     st.QT, st.KT, st.VT = (torch.empty((B, H, 64, Npad), dtype=bf16, device=dev) for _ in range(3))
     st.gate = torch.empty((B, H, N), dtype=f32, device=dev)
@@ -331,6 +331,11 @@ def qkv_post_fwd(qkvg, B, H, N, cosb, sinb, vfirst=None):
     _lib.get().e2k_qkv_post_fwd(_p(qkvg), qkvg.stride(0), _p(cosb), _p(sinb), _p(vfirst), _p(st.Q), _p(st.K), _p(st.V),
                                 _p(st.QT), _p(st.KT), _p(st.VT), _p(st.gate), _p(st.mix), B, H, N, Npad, _stream(qkvg))
     return st
+
+
+# OPT-IN (unmeasured on hardware yet): the forward leaves its dropout keep decisions as wave ballot words (18 MB per cfg3
+# attention) and the two backward kernels read them back instead of re-hashing; bit-identical results either way
+attn_share_dropmask = False
 
 
 def attn_fwd(st, kmask_pad, p_drop=0., seed=0, stream_id=0, seed_dev=None):
@@ -342,8 +347,14 @@ def attn_fwd(st, kmask_pad, p_drop=0., seed=0, stream_id=0, seed_dev=None):
     st.O = torch.empty((B * N, H * 64), dtype=bf16, device=dev)
     st.Og = torch.empty((B * N, H * 64), dtype=bf16, device=dev)
     st.lse2 = torch.empty((B, H, N), dtype=f32, device=dev)
+    st.dropbits = None
+    if attn_share_dropmask and p_drop > 0:
+        nbytes = _lib.get().e2k_query_attn_dropbits_bytes(B, H, N)
+        if nbytes > 0:
+            st.dropbits = torch.empty(nbytes // 8, dtype=torch.int64, device=dev)
     _lib.get().e2k_attn_fwd(_p(st.Q), _p(st.K), _p(st.VT), _p(kmask_pad), _p(st.gate), _p(st.O), _p(st.Og), _p(st.lse2),
-                            B, H, N, Npad, float(p_drop), int(seed), _p(seed_dev), int(stream_id), _stream(st.Q))
+                            _p(st.dropbits), B, H, N, Npad, float(p_drop), int(seed), _p(seed_dev), int(stream_id),
+                            _stream(st.Q))
     return st.Og
 
 
@@ -359,8 +370,8 @@ def attn_bwd(st, dOg, kmask_pad, p_drop=0., seed=0, stream_id=0, seed_dev=None):
     dgate = torch.empty((B, H, N), dtype=f32, device=dev)
     dQ, dK, dV = (torch.empty((B, H, N, 64), dtype=bf16, device=dev) for _ in range(3))
     _lib.get().e2k_attn_bwd(_p(dOg), _p(st.O), _p(st.gate), _p(st.lse2), _p(st.Q), _p(st.K), _p(st.V), _p(st.QT),
-                            _p(st.KT), _p(kmask_pad), _p(dO), _p(dOT), _p(delta), _p(dgate), _p(dQ), _p(dK), _p(dV),
-                            B, H, N, Npad, float(p_drop), int(seed), _p(seed_dev), int(stream_id), _stream(dOg))
+                            _p(st.KT), _p(kmask_pad), _p(st.dropbits), _p(dO), _p(dOT), _p(delta), _p(dgate), _p(dQ), _p(dK),
+                            _p(dV), B, H, N, Npad, float(p_drop), int(seed), _p(seed_dev), int(stream_id), _stream(dOg))
     return dQ, dK, dV, dgate
 
 

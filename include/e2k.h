@@ -148,12 +148,16 @@ int e2k_qkv_post_bwd(const void* dQ, const void* dK, const void* dV, const float
  * kmask (B, Npad) u8: 1 = attend; also used as the query-row mask of the output (reference: where(mask, out, 0)).
  * O / Og: token-major (B*N, H*64) un-gated / gated by `gate`;  lse2 (B,H,N): log2-domain log-sum-exp. */
 int e2k_attn_fwd(const void* Q, const void* K, const void* VT, const uint8_t* kmask, const float* gate,
-                 void* O, void* Og, float* lse2, int B, int H, int N, int Npad, float p_drop,
+                 void* O, void* Og, float* lse2, void* dropbits, int B, int H, int N, int Npad, float p_drop,
                  uint32_t seed, const uint32_t* seed_dev, uint32_t stream_id, void* stream);
+/* dropbits (optional, both calls; NULL = every kernel re-derives the dropout mask from the counter hash): scratch of
+ * e2k_query_attn_dropbits_bytes(B, H, N) bytes in which the forward leaves its keep decisions as 64-bit wave ballot words
+ * and from which the backward kernels read them back.  Same mask either way (bit-identical results). */
+int e2k_query_attn_dropbits_bytes(int B, int H, int N);
 /* backward: dOg (B*N, H*64) -> dQ, dK, dV (B,H,N,64), dgate_pre (B,H,N).  dO, dOT, delta are scratch outputs. */
 int e2k_attn_bwd(const void* dOg, const void* O, const float* gate, const float* lse2, const void* Q,
                  const void* K, const void* V, const void* QT, const void* KT, const uint8_t* kmask,
-                 void* dO, void* dOT, float* delta, float* dgate_pre, void* dQ, void* dK, void* dV,
+                 const void* dropbits, void* dO, void* dOT, float* delta, float* dgate_pre, void* dQ, void* dK, void* dV,
                  int B, int H, int N, int Npad, float p_drop, uint32_t seed, const uint32_t* seed_dev,
                  uint32_t stream_id, void* stream);
 

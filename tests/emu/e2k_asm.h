@@ -48,6 +48,13 @@ inline bool wave_all(bool pred) {
     for (int m = 32; m >= 1; m >>= 1) v &= __shfl_xor(v, m);
     return v != 0;
 }
+inline unsigned long long wave_ballot(bool pred) {
+    unsigned long long v = pred ? (1ull << emu::lane_id()) : 0ull;
+    for (int m = 32; m >= 1; m >>= 1) v |= __shfl_xor(v, m);
+    return v;
+}
+inline bool wave_inverse_ballot(unsigned long long m) { return (m >> emu::lane_id()) & 1ull; }
+inline unsigned long long sload64(const unsigned long long* p) { return *p; }
 inline float fast_exp2(float x) { return exp2f(x); }
 inline float fast_rcp(float x) { return 1.0f / x; }
 

@@ -136,3 +136,32 @@ def test_attention_dropout(dev):
     dqkvg = ops.qkv_post_bwd(st, dQ, dK, dV, dgate, qkvg.to(dev), cosb, sinb)
     for name, got, want in zip('qkvg', dqkvg.float().cpu().split([I, I, I, H], dim=-1), cols.grad.split([I, I, I, H], dim=-1)):
         assert rel(got, want) < 4e-2, (name, rel(got, want))
+
+
+@pytest.mark.parametrize('N', [70, 150])
+def test_attention_shared_dropout_mask(dev, N):
+    """forward -> backward hand-over of the dropout keep decisions (ops.attn_share_dropmask): bit-identical to re-hashing"""
+    from e2_tts_pytorch_amd import ops
+    torch.manual_seed(0)
+    B, H = 2, 3
+    I = H * 64
+    qkvg = torch.zeros(B * N, (3 * I + H + 7) // 8 * 8, dtype=bf16)[:, :3 * I + H]
+    qkvg.copy_(torch.randn(B * N, 3 * I + H).to(bf16))
+    cosb, sinb = ops.rotary_table(N, dev)
+    kmask = torch.zeros(B, (N + 63) // 64 * 64, dtype=torch.uint8)
+    kmask[0, :N] = 1
+    kmask[1, :N - 9] = 1
+    dOg = torch.randn(B * N, I).to(bf16).to(dev)
+    res = []
+    for share in (False, True):
+        ops.attn_share_dropmask = share
+        try:
+            st = ops.qkv_post_fwd(qkvg.to(dev), B, H, N, cosb, sinb, None)
+            Og = ops.attn_fwd(st, kmask.to(dev), 0.25, 1234, 3).clone()
+            assert (st.dropbits is not None) == share
+            dQ, dK, dV, dg = ops.attn_bwd(st, dOg, kmask.to(dev), 0.25, 1234, 3)
+            res.append((Og, dQ.clone(), dK.clone(), dV.clone(), dg.clone()))
+        finally:
+            ops.attn_share_dropmask = False
+    for a, b in zip(*res):
+        assert torch.equal(a, b)
