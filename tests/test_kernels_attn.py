@@ -145,7 +145,7 @@ def test_attention_shared_dropout_mask(dev, N):
     torch.manual_seed(0)
     B, H = 2, 3
     I = H * 64
-    qkvg = torch.zeros(B * N, (3 * I + H + 7) // 8 * 8, dtype=bf16)[:, :3 * I + H]
+    qkvg = torch.zeros(B * N, (3 * I + H + 7) // 8 * 8, dtype=bf16, device=dev)[:, :3 * I + H]       # padded row stride
     qkvg.copy_(torch.randn(B * N, 3 * I + H).to(bf16))
     cosb, sinb = ops.rotary_table(N, dev)
     kmask = torch.zeros(B, (N + 63) // 64 * 64, dtype=torch.uint8)
@@ -156,7 +156,7 @@ def test_attention_shared_dropout_mask(dev, N):
     for share in (False, True):
         ops.attn_share_dropmask = share
         try:
-            st = ops.qkv_post_fwd(qkvg.to(dev), B, H, N, cosb, sinb, None)
+            st = ops.qkv_post_fwd(qkvg, B, H, N, cosb, sinb, None)
             Og = ops.attn_fwd(st, kmask.to(dev), 0.25, 1234, 3).clone()
             assert (st.dropbits is not None) == share
             dQ, dK, dV, dg = ops.attn_bwd(st, dOg, kmask.to(dev), 0.25, 1234, 3)
