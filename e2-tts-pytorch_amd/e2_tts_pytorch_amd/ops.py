@@ -333,9 +333,10 @@ def qkv_post_fwd(qkvg, B, H, N, cosb, sinb, vfirst=None):
     return st
 
 
-# OPT-IN (unmeasured on hardware yet): the forward leaves its dropout keep decisions as wave ballot words (18 MB per cfg3
-# attention) and the two backward kernels read them back instead of re-hashing; bit-identical results either way
-attn_share_dropmask = False
+# The forward leaves its dropout keep decisions as wave ballot words (18.9 MB per cfg3 attention) and the two backward
+# kernels read them back instead of re-hashing: bit-identical results (tools/attn_share_check.py on MI355X), forward
+# 0.132 -> 0.140 ms, backward 0.403 -> 0.358 ms per cfg3 attention.  False = every kernel re-derives the mask.
+attn_share_dropmask = True
 
 
 def attn_fwd(st, kmask_pad, p_drop=0., seed=0, stream_id=0, seed_dev=None):

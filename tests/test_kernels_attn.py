@@ -162,6 +162,6 @@ def test_attention_shared_dropout_mask(dev, N):
             dQ, dK, dV, dg = ops.attn_bwd(st, dOg, kmask.to(dev), 0.25, 1234, 3)
             res.append((Og, dQ.clone(), dK.clone(), dV.clone(), dg.clone()))
         finally:
-            ops.attn_share_dropmask = False
+            ops.attn_share_dropmask = True
     for a, b in zip(*res):
         assert torch.equal(a, b)

@@ -27,7 +27,7 @@ for N in (70, 150):
         if share:
             w = st.dropbits.view(B * H, -1)
             print('N', N, 'dropbits words', w.numel(), 'nonzero', int((w != 0).sum()))
-    ops.attn_share_dropmask = False
+    ops.attn_share_dropmask = True
     for k in res[0]:
         a, b = res[0][k].float(), res[1][k].float()
         print(' ', k, 'mismatches', int((a != b).sum()), 'of', a.numel(), 'max abs diff', float((a - b).abs().max()), 'max |ref|', float(a.abs().max()))

@@ -83,18 +83,18 @@ if 'attn' in which:
     kmask = torch.zeros(B, st.Npad, dtype=torch.uint8, device=dev)
     kmask[:, :N] = 1
     af = 4.0 * B * H * N * N * 64
+    ops.attn_share_dropmask = False
     for pd in (0.0, 0.1):
         ms = timeit(lambda: ops.attn_fwd(st, kmask, pd, 1, 3))
         rec(f'attn_fwd p_drop={pd}', ms, flops=af)
         dOg = rnd(M, I)
         ms = timeit(lambda: ops.attn_bwd(st, dOg, kmask, pd, 1, 3))
         rec(f'attn_bwd (prep+dq+dkv) p_drop={pd}', ms, flops=2.5 * af, note='tflops counts the algorithmic 5 matmuls; the kernels execute 7')
-    ops.attn_share_dropmask = True                 # opt-in: dropout keep masks handed from the forward to the backward
+    ops.attn_share_dropmask = True                 # default: dropout keep masks handed from the forward to the backward
     ms = timeit(lambda: ops.attn_fwd(st, kmask, 0.1, 1, 3))
     rec('attn_fwd p_drop=0.1, writes shared dropout masks', ms, flops=af)
     ms = timeit(lambda: ops.attn_bwd(st, dOg, kmask, 0.1, 1, 3))
     rec('attn_bwd p_drop=0.1, reads shared dropout masks', ms, flops=2.5 * af)
-    ops.attn_share_dropmask = False
     q, k, v = (rnd(B, H, N, 64) for _ in range(3))
     ms = timeit(lambda: torch.nn.functional.scaled_dot_product_attention(q, k, v))
     rec('  torch SDPA fwd (no softclamp/gate)', ms, flops=af)
