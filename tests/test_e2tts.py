@@ -99,6 +99,33 @@ def test_e2tts_cfg3_width():
         assert gk is not None and rel2(gk, gr) < 0.15, (name, rel2(gk, gr))
 
 
+def test_training_dropout_shared_masks(dev):
+    """a training step with dropout 0.1 (attention + GEGLU dropout active): handing the attention keep masks from the
+    forward to the backward (the default) gives exactly the loss and gradients of re-hashing them in every kernel"""
+    from e2_tts_pytorch_amd import E2TTS, ops
+    random.seed(0)
+    torch.manual_seed(0)
+    model = E2TTS(transformer=dict(dim=256, depth=2, heads=4, dropout=0.1), use_vocos=False, cond_drop_prob=0.).to(dev).train()
+    B, T = 2, 70
+    mel = torch.randn(B, T, 100, device=dev)
+    noise = dict(x0=torch.randn(B, T, 100, device=dev), times=torch.tensor([0.3, 0.7], device=dev),
+                 frac_lengths=torch.tensor([0.8, 0.9], device=dev), span_rand=torch.tensor([0.1, 0.5], device=dev), drop_text_cond=False)
+    res = []
+    try:
+        for share in (True, False):
+            ops.attn_share_dropmask = share
+            random.seed(1)
+            torch.manual_seed(1)                     # same dropout seed draw for both passes
+            model.zero_grad(set_to_none=True)
+            out = model(mel, text=['ab', 'cd'], lens=torch.tensor([T, T - 15], device=dev), _noise=noise)
+            out.loss.backward()
+            res.append((out.loss.item(), model.to_pred.weight.grad.clone(),
+                        dict(model.named_parameters())['transformer.layers.0.0.3.to_q.weight'].grad.clone()))
+    finally:
+        ops.attn_share_dropmask = True
+    assert res[0][0] == res[1][0] and torch.equal(res[0][1], res[1][1]) and torch.equal(res[0][2], res[1][2])
+
+
 def test_concat_cond(dev):
     """concat_cond=True (e2_tts.py:1196-1204,1263-1276): one Linear(2 * n_mels, dim) on cat(cond, x)"""
     kw = dict(dim=256, depth=2, heads=4, dropout=0.)
