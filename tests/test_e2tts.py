@@ -123,7 +123,10 @@ def test_training_dropout_shared_masks(dev):
                         dict(model.named_parameters())['transformer.layers.0.0.3.to_q.weight'].grad.clone()))
     finally:
         ops.attn_share_dropmask = True
-    assert res[0][0] == res[1][0] and torch.equal(res[0][1], res[1][1]) and torch.equal(res[0][2], res[1][2])
+    # (bit-identical in practice; the tolerance only allows for atomics-order noise should a future kernel add any on this path.
+    #  A single differing keep decision would move these by orders of magnitude more.)
+    assert abs(res[0][0] - res[1][0]) <= 1e-6 * abs(res[1][0])
+    assert torch.allclose(res[0][1], res[1][1], rtol=1e-5, atol=1e-7) and torch.allclose(res[0][2], res[1][2], rtol=1e-5, atol=1e-7)
 
 
 def test_concat_cond(dev):
