@@ -106,7 +106,7 @@ def test_training_dropout_shared_masks(dev):
     random.seed(0)
     torch.manual_seed(0)
     model = E2TTS(transformer=dict(dim=256, depth=2, heads=4, dropout=0.1), use_vocos=False, cond_drop_prob=0.).to(dev).train()
-    B, T = 2, 70
+    B, T = 2, 40                                     # 72 positions with the registers: two key tiles
     mel = torch.randn(B, T, 100, device=dev)
     noise = dict(x0=torch.randn(B, T, 100, device=dev), times=torch.tensor([0.3, 0.7], device=dev),
                  frac_lengths=torch.tensor([0.8, 0.9], device=dev), span_rand=torch.tensor([0.1, 0.5], device=dev), drop_text_cond=False)

@@ -63,7 +63,7 @@ def test_fused_adopt_on_model(dev):
     ema = FusedEMA(model, update_after_step=0, update_every=1)
     ref_params = [p.detach().cpu().clone().requires_grad_(True) for p in opt.params]
     ref = O.Adopt(ref_params, lr=1e-3)
-    for step in range(3):
+    for step in range(2):
         out = model(mel, text=['hello world', 'x'])
         out.loss.backward()
         pairs = [(p, p.grad) for p in opt.params if p.grad is not None]
@@ -87,7 +87,7 @@ def test_fused_adopt_on_model(dev):
     assert te._flat.data_ptr() != model.transformer._flat.data_ptr()
     assert all(q.data_ptr() == te._flat.data_ptr() + off * 4 for q, off in te._layout.slots)
     # EMA followed the online model (decay schedule from the oracle restatement)
-    d = O.ema_decay(2, update_after_step=0)
+    d = O.ema_decay(2, update_after_step=0)            # (schedule restatement sanity)
     assert 0. < d < 1.
     for e, p in zip(ema.ema_model.parameters(), model.parameters()):
         assert e.shape == p.shape and torch.isfinite(e).all()
@@ -102,14 +102,14 @@ def test_training_loop_reduces_loss(dev):
     random.seed(0)
     torch.manual_seed(0)
     model = E2TTS(transformer=dict(dim=256, depth=2, heads=4, dropout=0.), use_vocos=False, cond_drop_prob=0.).to(dev)
-    B, T = 2, 24
+    B, T = 2, 16
     mel = torch.randn(B, T, 100, device=dev)
     noise = dict(x0=torch.randn(B, T, 100, device=dev), times=torch.tensor([0.3, 0.7], device=dev),
                  frac_lengths=torch.tensor([0.8, 0.9], device=dev), span_rand=torch.tensor([0.1, 0.5], device=dev), drop_text_cond=False)
     opt = FusedAdopt(model, lr=3e-3, max_grad_norm=1.0)
     ema = FusedEMA(model, update_after_step=0, update_every=1)
     losses = []
-    for _ in range(7):
+    for _ in range(5):
         out = model(mel, text=['hello', 'world'], _noise=noise)
         out.loss.backward()
         opt.step()
