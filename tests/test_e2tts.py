@@ -129,6 +129,32 @@ def test_training_dropout_shared_masks(dev):
     assert torch.allclose(res[0][1], res[1][1], rtol=1e-5, atol=1e-7) and torch.allclose(res[0][2], res[1][2], rtol=1e-5, atol=1e-7)
 
 
+@pytest.mark.parametrize('case', ['no_text', 'empty_string', 'short_lens', 'one_key_tile', 'text_longer_than_audio'])
+def test_edge_inputs(dev, case):
+    """ragged / degenerate inputs behave like the oracle: no text, an empty string in the batch, a 2-frame sample next to
+    a 20-frame one, exactly one 64-position key tile, text longer than the audio (truncated)"""
+    kw = dict(dim=256, depth=2, heads=4, dropout=0.)
+    ref, model = _pair(kw)
+    model = model.to(dev)
+    cfg = dict(no_text=(1, 3, None, None), empty_string=(2, 10, ['', 'hello'], None), short_lens=(2, 20, ['ab', 'cd'], [20, 2]),
+               one_key_tile=(1, 32, ['x'], None), text_longer_than_audio=(1, 8, ['x' * 50], None))[case]
+    B, T, text, lens = cfg
+    mel = torch.randn(B, T, 100)
+    noise = dict(x0=torch.randn(B, T, 100), times=torch.rand(B), frac_lengths=torch.full((B,), 0.9),
+                 span_rand=torch.full((B,), 0.3), drop_text_cond=False)
+    kr = dict(text=text) if text is not None else {}
+    kk = dict(kr)
+    if lens is not None:
+        kr['lens'], kk['lens'] = torch.tensor(lens), torch.tensor(lens).to(dev)
+    out_r = ref(mel, _noise=noise, **kr)
+    dn = {k: (v.to(dev) if torch.is_tensor(v) else v) for k, v in noise.items()}
+    out = model(mel.to(dev), _noise=dn, **kk)
+    out.loss.backward()
+    assert torch.isfinite(out.pred_flow).all()
+    assert abs(out.loss.item() - out_r.loss.item()) / abs(out_r.loss.item()) < 1e-2
+    assert rel2(out.pred_flow, out_r.pred_flow) < 1.5e-2
+
+
 def test_concat_cond(dev):
     """concat_cond=True (e2_tts.py:1196-1204,1263-1276): one Linear(2 * n_mels, dim) on cat(cond, x)"""
     kw = dict(dim=256, depth=2, heads=4, dropout=0.)
