@@ -133,7 +133,7 @@ def test_training_dropout_shared_masks(dev):
 def test_edge_inputs(dev, case):
     """ragged / degenerate inputs behave like the oracle: no text, an empty string in the batch, a 2-frame sample next to
     a 20-frame one, exactly one 64-position key tile, text longer than the audio (truncated)"""
-    kw = dict(dim=256, depth=1, heads=4, dropout=0.)
+    kw = dict(dim=256, depth=2, heads=4, dropout=0.)
     ref, model = _pair(kw)
     model = model.to(dev)
     cfg = dict(no_text=(1, 3, None, None), empty_string=(2, 10, ['', 'hello'], None), short_lens=(2, 20, ['ab', 'cd'], [20, 2]),
