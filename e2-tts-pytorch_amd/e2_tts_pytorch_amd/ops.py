@@ -293,13 +293,18 @@ def dwconv_fwd(x, mask, w, bias):
     return pre, y
 
 
+# A/B switch (not measured on hardware yet): run the depthwise-conv backward as a dx kernel + a (dw, dbias) kernel
+dwconv_split_bwd = False
+
+
 def dwconv_bwd(dy, pre, x, mask, w, dw, dbias):
     _chk(dy, pre, x, mask, w, dw, dbias)
     B, N, C = x.shape
     ks = w.shape[-1]
     assert dy.is_contiguous() and dw.dtype == f32 and dbias.dtype == f32
     dx = torch.empty_like(x)
-    _lib.get().e2k_dwconv_bwd(_p(dy), _p(pre), _p(x), _p(mask), _p(w), _p(dx), _p(dw), _p(dbias), B, N, C, ks, _stream(x))
+    _lib.get().e2k_dwconv_bwd(_p(dy), _p(pre), _p(x), _p(mask), _p(w), _p(dx), _p(dw), _p(dbias), B, N, C, ks,
+                              int(dwconv_split_bwd), _stream(x))
     return dx
 
 

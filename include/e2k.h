@@ -125,9 +125,9 @@ int e2k_cast_transpose_bf16(const float* src, void* dst, int R, int C, int64_t l
  *   pre = conv1d(mask * x) + bias ;  y = mask * silu(pre).   ks in {3,7,15,31}, C multiple of 64. */
 int e2k_dwconv_fwd(const void* x, const uint8_t* mask, const float* w, const float* bias, void* pre,
                    void* y, int B, int N, int C, int ks, void* stream);
-/* dx, and dw / dbias ACCUMULATED (fp32) */
+/* dx, and dw / dbias ACCUMULATED (fp32).  split = 0: one fused kernel; 1: a dx kernel and a (dw, dbias) kernel (A/B) */
 int e2k_dwconv_bwd(const void* dy, const void* pre, const void* x, const uint8_t* mask, const float* w,
-                   void* dx, float* dw, float* dbias, int B, int N, int C, int ks, void* stream);
+                   void* dx, float* dw, float* dbias, int B, int N, int C, int ks, int split, void* stream);
 
 /* ---- attention (x_transformers.Attention, call sites e2_tts.py:875,911; dim_head = 64) ----
  * qkvg (B*N, ldq) bf16 = fused projection output, columns [q (H*64) | k | v | head-gate logits (H) | value-residual

@@ -89,7 +89,8 @@ def test_colsum_cast(dev):
 
 # (frames, kernel, mask): 75 frames = two tiles with a ragged tail; 200 frames = several tiles per workgroup in the backward
 @pytest.mark.parametrize('N,ks,use_mask', [(75, 31, True), (75, 7, False), (200, 31, True), (64, 15, False), (5, 3, False)])
-def test_dwconv(dev, N, ks, use_mask):
+@pytest.mark.parametrize('split', [False, True])
+def test_dwconv(dev, N, ks, use_mask, split):
     from e2_tts_pytorch_amd import ops
     torch.manual_seed(0)
     B, C = 2, 128
@@ -114,7 +115,11 @@ def test_dwconv(dev, N, ks, use_mask):
     pre, y = ops.dwconv_fwd(xd, md, wd, bd)
     assert rel(y, yr) < 1e-2
     dw, db = torch.zeros_like(wd), torch.zeros_like(bd)
-    dx = ops.dwconv_bwd(dy.to(dev), pre, xd, md, wd, dw, db)
+    ops.dwconv_split_bwd = split
+    try:
+        dx = ops.dwconv_bwd(dy.to(dev), pre, xd, md, wd, dw, db)
+    finally:
+        ops.dwconv_split_bwd = False
     assert rel(dx, xr.grad) < 2e-2, rel(dx, xr.grad)
     assert rel(dw, wr.grad) < 2e-2, rel(dw, wr.grad)
     assert rel(db, br.grad) < 2e-2
