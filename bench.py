@@ -93,6 +93,9 @@ def main():
     ap.add_argument('--graphs', action='store_true', help='replay captured HIP graphs instead of eager kernel launches (18 ms instead of '
                     '108 ms of host time per step, but 3-4 %% slower on the GPU: 128.3 vs 123.8 ms/step on MI355X)')
     ap.add_argument('--no-graphs', action='store_true', help='always eager launches (no host-bound probe / graph fallback)')
+    ap.add_argument('--persistent-grads', action='store_true',
+                    help='eager mode: Transformer.enable_persistent_grads() (one flat gradient buffer for the life of the module; '
+                         'saves ~20 %% of the host time of a step, tools/host_overhead.py; not yet measured on the GPU)')
     ap.add_argument('--copy-grads', action='store_true', help='graph mode: copy the gradients out of the static buffer every step')
     ap.add_argument('--force-ddp', action='store_true', help='wrap in ddp.DataParallel even with one rank (exercises the RCCL path)')
     args = ap.parse_args()
@@ -129,6 +132,10 @@ def main():
     noise = {'drop_text_cond': True} if args.drop_text else None
 
     params = list(model.parameters())
+    if args.persistent_grads:
+        model.transformer.enable_persistent_grads()
+        flat = {id(q) for q, _ in model.transformer._layout.slots}
+        params = [p for p in params if id(p) not in flat]          # (the backbone's gradients are overwritten in place)
 
     def step():
         out = net(mel, text=text, _noise=noise)
@@ -238,7 +245,7 @@ def main():
             'mfma_roofline_frac_whole_step': sf / (dt / args.steps) / 1e12 / PEAK_BF16_TFLOPS,
             'loss': loss_val,
             'host_enqueue_ms_per_step': t_enqueue / args.steps * 1e3,
-            'hip_graphs': use_graphs, 'launch_mode': launch_mode_note,
+            'hip_graphs': use_graphs, 'launch_mode': launch_mode_note, 'gemm_flags': ops.gemm_flags,
             'roofline': {
                 'bound': 'mfma', 'kernel': 'gemm_nt_glds_kernel + gemm_nt_fixup_kernel (bf16 MFMA 16x16x32; every forward and dgrad GEMM of the step)',
                 'achieved': achieved, 'peak': PEAK_BF16_TFLOPS, 'unit': 'TFLOP/s', 'frac': achieved / PEAK_BF16_TFLOPS,

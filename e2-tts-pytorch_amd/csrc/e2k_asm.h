@@ -113,6 +113,21 @@ __device__ __forceinline__ void barrier_keep_vm() {
     asm volatile("" ::: "memory");
 }
 
+// bare workgroup barrier: no counter is drained (ds_reads and global_load_lds issued before it stay in flight across it;
+// the consumer's own s_waitcnt decides what must have landed).  The sched_barriers pin the instruction groups on either
+// side: without them the scheduler is free to move MFMAs across, which is legal but undoes a hand-made phase schedule.
+__device__ __forceinline__ void barrier_raw() {
+    __builtin_amdgcn_sched_barrier(0);
+    asm volatile("" ::: "memory");
+    __builtin_amdgcn_s_barrier();
+    asm volatile("" ::: "memory");
+    __builtin_amdgcn_sched_barrier(0);
+}
+// issue priority of this wave (0..3): raised around an MFMA group so that it wins over the other wave of the SIMD,
+// which is in its load phase (cdna_hip_programming.md T5: only useful when the waves of a SIMD are in different phases)
+template <int P> __device__ __forceinline__ void set_prio() { __builtin_amdgcn_s_setprio(P); }
+__device__ __forceinline__ void sched_fence() { __builtin_amdgcn_sched_barrier(0); }
+
 // global_load_lds_dwordx4: asynchronous 16-byte-per-lane copy HBM -> LDS that bypasses the VGPRs.  The LDS destination
 // is wave-uniform: lane l lands at lds_base + 16*l (the global source address is per lane).  Completion is tracked by
 // vmcnt; a following __syncthreads() drains it (cdna_hip_programming.md section 5).

@@ -58,12 +58,12 @@ struct NTArgs {
 
 // epilogue of an interior tile (all 128 x 128 outputs exist, rows 8-byte aligned): no per-element bounds checks, the
 // optional operands are selected once per tile (wave-uniform), bias kept in registers across the 4 row groups
-template <bool OUT_F32, bool HAS_CS, bool HAS_RES, int NI>
-__device__ __forceinline__ void nt_epilogue_full(const NTArgs& p, f32x4 (&acc)[NI][4], int mw, int nw, int l15, int g) {
+template <bool OUT_F32, bool HAS_CS, bool HAS_RES, int NI, int NJ>
+__device__ __forceinline__ void nt_epilogue_full(const NTArgs& p, f32x4 (&acc)[NI][NJ], int mw, int nw, int l15, int g) {
     const int nb = nw + 4 * g;
-    f32x4 bias4[4];
+    f32x4 bias4[NJ];
 #pragma unroll
-    for (int j = 0; j < 4; ++j) {
+    for (int j = 0; j < NJ; ++j) {
         bias4[j] = f32x4{0.f, 0.f, 0.f, 0.f};
         if (p.bias) {
 #pragma unroll
@@ -76,7 +76,7 @@ __device__ __forceinline__ void nt_epilogue_full(const NTArgs& p, f32x4 (&acc)[N
         const float rm = p.rowmask ? (p.rowmask[m] ? 1.f : 0.f) : 1.f;
         const float* cs = HAS_CS ? p.colscale + (long)(m / p.rows_per_batch) * p.lds : nullptr;
 #pragma unroll
-        for (int j = 0; j < 4; ++j) {
+        for (int j = 0; j < NJ; ++j) {
             const int n = nb + j * 16;
             f32x4 x = acc[i][j] + bias4[j];
             if (HAS_CS) {
@@ -102,18 +102,18 @@ __device__ __forceinline__ void nt_epilogue_full(const NTArgs& p, f32x4 (&acc)[N
     }
 }
 
-// epilogue shared by the NT kernels.  (mw, nw) = first row / column of this wave's (16 NI) x 64 sub-tile; lane holds
-// C[m][n..n+3], m = mw + i*16 + l15 (i < NI), n = nw + j*16 + 4g
-template <bool OUT_F32, int NI>
-__device__ __forceinline__ void nt_epilogue(const NTArgs& p, f32x4 (&acc)[NI][4], int mw, int nw, int l15, int g) {
+// epilogue shared by the NT kernels.  (mw, nw) = first row / column of this wave's (16 NI) x (16 NJ) sub-tile; lane holds
+// C[m][n..n+3], m = mw + i*16 + l15 (i < NI), n = nw + j*16 + 4g (j < NJ)
+template <bool OUT_F32, int NI, int NJ = 4>
+__device__ __forceinline__ void nt_epilogue(const NTArgs& p, f32x4 (&acc)[NI][NJ], int mw, int nw, int l15, int g) {
     const bool vec_ok = (p.ldc & 3) == 0 && (p.resid == nullptr || (p.ldr & 3) == 0);
-    if (vec_ok && mw + NI * 16 <= p.M && nw + 64 <= p.N) {       // wave-uniform: the whole sub-tile exists
+    if (vec_ok && mw + NI * 16 <= p.M && nw + NJ * 16 <= p.N) {       // wave-uniform: the whole sub-tile exists
         if (p.colscale) {
-            if (p.resid) nt_epilogue_full<OUT_F32, true, true, NI>(p, acc, mw, nw, l15, g);
-            else nt_epilogue_full<OUT_F32, true, false, NI>(p, acc, mw, nw, l15, g);
+            if (p.resid) nt_epilogue_full<OUT_F32, true, true, NI, NJ>(p, acc, mw, nw, l15, g);
+            else nt_epilogue_full<OUT_F32, true, false, NI, NJ>(p, acc, mw, nw, l15, g);
         } else {
-            if (p.resid) nt_epilogue_full<OUT_F32, false, true, NI>(p, acc, mw, nw, l15, g);
-            else nt_epilogue_full<OUT_F32, false, false, NI>(p, acc, mw, nw, l15, g);
+            if (p.resid) nt_epilogue_full<OUT_F32, false, true, NI, NJ>(p, acc, mw, nw, l15, g);
+            else nt_epilogue_full<OUT_F32, false, false, NI, NJ>(p, acc, mw, nw, l15, g);
         }
         return;
     }
@@ -124,7 +124,7 @@ __device__ __forceinline__ void nt_epilogue(const NTArgs& p, f32x4 (&acc)[NI][4]
         const float rm = p.rowmask ? (p.rowmask[m] ? 1.f : 0.f) : 1.f;
         const float* cs = p.colscale ? p.colscale + (long)(m / p.rows_per_batch) * p.lds : nullptr;
 #pragma unroll
-        for (int j = 0; j < 4; ++j) {
+        for (int j = 0; j < NJ; ++j) {
             const int n = nw + j * 16 + 4 * g;
             if (n >= p.N) continue;
             float v[4];
@@ -568,6 +568,232 @@ __global__ __launch_bounds__(GTHREADS) void gemm_nt_big_fixup_kernel(NTArgs p) {
     nt_epilogue<OUT_F32, 1>(p, acc, tile_m * GBM + wm * 64 + i * 16, tile_n * BN + wn * 64, l15, g);
 }
 
+// 256 x 256 x 64 tile, EIGHT waves (512 threads, one workgroup per CU, two waves per SIMD), 128 KB of LDS, 8 phases per
+// pair of K tiles (cdna_hip_programming.md "256^2 8-phase template", rebuilt for this kernel's operand layout and
+// epilogue).  OPT-IN (flags E2K_GEMM_T256 / E2K_GEMM_T256_AUTO): written after round 1's GPU minutes were spent, so it is
+// parity-tested on the host model only -- its asynchronous-copy ordering has not run on hardware yet.
+//
+// Why: with 128 x 128 tiles a K step moves 32 KB through the texture path for 2.1 MFLOP, which takes the load side as
+// long as the MFMAs; a 256 x 256 tile moves 64 KB for 8.4 MFLOP, half the bytes per flop.
+//
+// LDS: two K-tile buffers of four 16-KB half tiles [A rows 0-127 | A rows 128-255 | B rows 0-127 | B rows 128-255], rows
+// of 128 B with the same source-side XOR swizzle as the other NT kernels.  Wave (wr, wc) = (wave >> 2, wave & 3) owns rows
+// wr*64..+63 of BOTH A halves and columns wc*32..+31 of BOTH B halves, i.e. four 64 x 32 quadrants (Alo|Ahi) x (Blo|Bhi),
+// so that every wave touches the same half tiles in the same phase:
+//
+//   phase 1: read Alo (8 x ds_read_b128) + Blo (4)   MFMA Alo x Blo        phase 3: read Ahi (8)   MFMA Ahi x Bhi
+//   phase 2: read Bhi (4)                            MFMA Alo x Bhi        phase 4: --             MFMA Ahi x Blo (kept)
+//
+// Each phase is [ds_reads, counted vmcnt, one half-tile prefetch (2 global_load_lds per lane)] barrier [16 MFMAs]
+// barrier.  Waves 4-7 run ONE BARRIER BEHIND waves 0-3 (they take an extra barrier first, waves 0-3 one at the end): a
+// SIMD holds wave w and wave w + 4, so while one of them issues its 16 MFMAs (256 cycles of the pipe, priority raised)
+// the other does its LDS reads and prefetch -- the barriers are the hand-over.
+//
+// Prefetch order (one half tile per phase, sequence element e = 4*tile + {0: Alo, 1: Blo, 2: Bhi, 3: Ahi}, element g + 6
+// is issued in phase g): phase 1 of tile t stages Bhi(t+1), phase 2 Ahi(t+1), phase 3 Alo(t+2), phase 4 Blo(t+2).
+//   * WAR: a half tile is restaged at least two phases after its last ds_read (Alo, Blo: read in phase 1, restaged in
+//     phases 3 / 4; Bhi: read in 2, restaged in phase 1 of the next tile; Ahi: read in 3, restaged in phase 2 of the next
+//     tile).  Two phases = at least one barrier between the trailing group's lgkmcnt wait and the leading group's issue.
+//   * RAW: the vmcnt before the issue of phase g leaves at most three half tiles (6 loads) in flight, i.e. elements
+//     <= g + 2 have landed for THIS wave; the barrier that follows publishes that, and the element is first read in
+//     phase g + 1 or later (phase 1 of tile t reads elements 4t, 4t+1; phase 2 reads 4t+2; phase 3 reads 4t+3).
+//   * In the last five phases nothing is left to issue, and the count is lowered step by step (4, 2, 0).
+constexpr int QBM = 256, QBN = 256, QHALF = 128 * BK * 2, QBUF = 4 * QHALF, QTHREADS = 512;
+
+template <bool OUT_F32>
+__global__ __launch_bounds__(QTHREADS, 1) void gemm_nt_256_kernel(NTArgs p) {
+    __shared__ __attribute__((aligned(16))) unsigned char smem[2 * QBUF];
+    const int tid = threadIdx.x, lane = tid & 63, wave = uniform_i(tid >> 6);
+    const int wr = wave >> 2, wc = wave & 3;
+    const int l15 = lane & 15, g = lane >> 4;
+    const int tm = (p.M + QBM - 1) / QBM, tn = (p.N + QBN - 1) / QBN;
+    int tile_m, tile_n;
+    const int nk1 = p.K1 / BK, nk = (p.K1 + p.K2) / BK;
+    int kb = 0, ke = nk, part = -1;
+    if ((int)blockIdx.x < p.full) {
+        tile_coords(xcd_remap(blockIdx.x, p.full), tm, tn, tile_m, tile_n);
+    } else {
+        part = blockIdx.x - p.full;
+        const int r = part / p.split, sidx = part - r * p.split;
+        tile_coords(p.full + r, tm, tn, tile_m, tile_n);
+        kb = (int)((long)nk * sidx / p.split);
+        ke = (int)((long)nk * (sidx + 1) / p.split);
+    }
+    const int m0 = tile_m * QBM, n0 = tile_n * QBN;
+    const int nt = ke - kb;                                  // K tiles of this workgroup (>= 1)
+
+    // staging: a half tile is 16 wave instructions of 8 rows; wave w issues rows (2w + u)*8 + (lane >> 3), u = 0, 1
+    unsigned va[2][2], dv[2][2], vb[2][2];
+#pragma unroll
+    for (int h = 0; h < 2; ++h)
+#pragma unroll
+        for (int u = 0; u < 2; ++u) {
+            const int row = (wave * 2 + u) * 8 + (lane >> 3);
+            const int c = (lane & 7) ^ (row & 7);
+            const int m = min(m0 + h * 128 + row, p.M - 1), n = min(n0 + h * 128 + row, p.N - 1);
+            va[h][u] = (unsigned)(((long)m * p.lda1 + c * 8) * 2);
+            dv[h][u] = p.K2 ? (unsigned)(((long)m * p.lda2 + c * 8) * 2) - va[h][u] : 0u;
+            vb[h][u] = (unsigned)(((long)n * p.ldb + c * 8) * 2);
+        }
+    // fragment read offsets inside a half tile
+    int offa[2][4], offb[2][2];
+#pragma unroll
+    for (int kk = 0; kk < 2; ++kk) {
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const int ra = wr * 64 + i * 16 + l15;
+            offa[kk][i] = ra * 128 + (((kk * 4 + g) ^ (ra & 7)) << 4);
+        }
+#pragma unroll
+        for (int j = 0; j < 2; ++j) {
+            const int rb = wc * 32 + j * 16 + l15;
+            offb[kk][j] = rb * 128 + (((kk * 4 + g) ^ (rb & 7)) << 4);
+        }
+    }
+    unsigned char* const S0 = &smem[0];
+    // half-tile slots of a buffer: 0 = Alo, 1 = Ahi, 2 = Blo, 3 = Bhi.  `tile` is relative to kb; tiles past the end of
+    // the K range are simply not staged (the waits below count what was really issued)
+    auto stage_a = [&](int tile, int h) __attribute__((always_inline)) {
+        if (tile >= nt) return;
+        const int kt = kb + tile;
+        const bool first = kt < nk1;                     // wave-uniform
+        const char* sa = first ? (const char*)p.A1 + (long)kt * (BK * 2) : (const char*)p.A2 + (long)(kt - nk1) * (BK * 2);
+        const unsigned sel = first ? 0u : ~0u;
+        unsigned char* dst = S0 + (tile & 1) * QBUF + h * QHALF + wave * 2048;
+#pragma unroll
+        for (int u = 0; u < 2; ++u) glds16(sa + (va[h][u] + (dv[h][u] & sel)), dst + u * 1024);
+    };
+    auto stage_b = [&](int tile, int h) __attribute__((always_inline)) {
+        if (tile >= nt) return;
+        const char* sb = (const char*)p.B + (long)(kb + tile) * (BK * 2);
+        unsigned char* dst = S0 + (tile & 1) * QBUF + (2 + h) * QHALF + wave * 2048;
+#pragma unroll
+        for (int u = 0; u < 2; ++u) glds16(sb + vb[h][u], dst + u * 1024);
+    };
+    // `left` = half tiles that may stay in flight (issued after the youngest one the next phase reads)
+    auto wait_landed = [&](int left) __attribute__((always_inline)) {
+        if (left >= 3) wait_vmcnt<6>();
+        else if (left == 2) wait_vmcnt<4>();
+        else if (left == 1) wait_vmcnt<2>();
+        else wait_vmcnt<0>();
+    };
+
+    f32x4 acc[2][2][4][2];                  // [A half][B half][m16][n16]
+#pragma unroll
+    for (int a = 0; a < 2; ++a)
+#pragma unroll
+        for (int b = 0; b < 2; ++b)
+#pragma unroll
+            for (int i = 0; i < 4; ++i)
+#pragma unroll
+                for (int j = 0; j < 2; ++j) acc[a][b][i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+    bf16x8 ar[2][4], blo[2][2], bhi[2][2];
+
+    auto read_a = [&](const unsigned char* S) __attribute__((always_inline)) {
+#pragma unroll
+        for (int kk = 0; kk < 2; ++kk)
+#pragma unroll
+            for (int i = 0; i < 4; ++i) ar[kk][i] = ld<bf16x8>(S + offa[kk][i]);
+    };
+    auto read_b = [&](bf16x8 (&b)[2][2], const unsigned char* S) __attribute__((always_inline)) {
+#pragma unroll
+        for (int kk = 0; kk < 2; ++kk)
+#pragma unroll
+            for (int j = 0; j < 2; ++j) b[kk][j] = ld<bf16x8>(S + offb[kk][j]);
+    };
+    auto mma = [&](f32x4 (&c)[4][2], const bf16x8 (&b)[2][2]) __attribute__((always_inline)) {
+        set_prio<1>();
+#pragma unroll
+        for (int kk = 0; kk < 2; ++kk)
+#pragma unroll
+            for (int i = 0; i < 4; ++i)
+#pragma unroll
+                for (int j = 0; j < 2; ++j)
+                    c[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(b[kk][j], ar[kk][i], c[i][j], 0, 0, 0);
+        set_prio<0>();
+    };
+
+    // prologue: sequence elements 0..5 = all of tile 0, then Alo, Blo of tile 1; elements 0, 1 must have landed
+    stage_a(0, 0); stage_b(0, 0); stage_b(0, 1); stage_a(0, 1); stage_a(1, 0); stage_b(1, 0);
+    if (nt >= 2) wait_vmcnt<8>();
+    else wait_vmcnt<4>();
+    barrier_raw();
+    if (wr == 1) barrier_raw();              // waves 4-7 trail by one barrier from here on
+
+    for (int t = 0; t < nt; ++t) {
+        const unsigned char* S = S0 + (t & 1) * QBUF;
+        const int left = 4 * (nt - t) - 3;   // phase g = 4t + k: 4 nt - g - 3
+        // phase 1
+        read_b(blo, S + 2 * QHALF);
+        sched_fence();
+        read_a(S);
+        wait_landed(left);
+        stage_b(t + 1, 1);
+        barrier_raw();
+        mma(acc[0][0], blo);
+        barrier_raw();
+        // phase 2
+        read_b(bhi, S + 3 * QHALF);
+        wait_landed(left - 1);
+        stage_a(t + 1, 1);
+        barrier_raw();
+        mma(acc[0][1], bhi);
+        barrier_raw();
+        // phase 3
+        read_a(S + QHALF);
+        wait_landed(left - 2);
+        stage_a(t + 2, 0);
+        barrier_raw();
+        mma(acc[1][1], bhi);
+        barrier_raw();
+        // phase 4
+        wait_landed(left - 3);
+        stage_b(t + 2, 0);
+        barrier_raw();
+        mma(acc[1][0], blo);
+        barrier_raw();
+    }
+    if (wr == 0) barrier_raw();              // pairs with the extra barrier waves 4-7 took at the start
+
+    if (part >= 0) {        // K-range partial of a remainder tile: [part][(a*2+b)*8 + i*2 + j][tid] x 4 floats
+        float* w = p.ws + ((long)part * 32 * QTHREADS + tid) * 4;
+#pragma unroll
+        for (int a = 0; a < 2; ++a)
+#pragma unroll
+            for (int b = 0; b < 2; ++b)
+#pragma unroll
+                for (int i = 0; i < 4; ++i)
+#pragma unroll
+                    for (int j = 0; j < 2; ++j) st<f32x4>(w + (((a * 2 + b) * 4 + i) * 2 + j) * (QTHREADS * 4), acc[a][b][i][j]);
+        return;
+    }
+#pragma unroll
+    for (int a = 0; a < 2; ++a)
+#pragma unroll
+        for (int b = 0; b < 2; ++b)
+            nt_epilogue<OUT_F32, 4, 2>(p, acc[a][b], m0 + a * 128 + wr * 64, n0 + b * 128 + wc * 32, l15, g);
+}
+
+// blockIdx.x = remainder tile, blockIdx.y = (A half * 2 + B half) * 4 + m16 group
+template <bool OUT_F32>
+__global__ __launch_bounds__(QTHREADS) void gemm_nt_256_fixup_kernel(NTArgs p) {
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int wr = wave >> 2, wc = wave & 3, l15 = lane & 15, g = lane >> 4;
+    const int tm = (p.M + QBM - 1) / QBM, tn = (p.N + QBN - 1) / QBN;
+    const int q = blockIdx.y >> 2, i = blockIdx.y & 3, a = q >> 1, b = q & 1;
+    int tile_m, tile_n;
+    tile_coords(p.full + blockIdx.x, tm, tn, tile_m, tile_n);
+    f32x4 acc[1][2];
+    acc[0][0] = acc[0][1] = f32x4{0.f, 0.f, 0.f, 0.f};
+    const float* w = p.ws + (((long)blockIdx.x * p.split * 32 + (q * 4 + i) * 2) * QTHREADS + tid) * 4;
+#pragma unroll 4
+    for (int sidx = 0; sidx < p.split; ++sidx) {
+#pragma unroll
+        for (int j = 0; j < 2; ++j) acc[0][j] += ld<f32x4>(w + ((long)sidx * 32 + j) * (QTHREADS * 4));
+    }
+    nt_epilogue<OUT_F32, 1, 2>(p, acc, tile_m * QBM + a * 128 + wr * 64 + i * 16, tile_n * QBN + b * 128 + wc * 32, l15, g);
+}
+
 // (A BK = 32 variant of this kernel -- three 16-KB LDS stages, loads two K steps ahead with counted s_waitcnt vmcnt,
 // three workgroups per CU -- was measured 40-90 % SLOWER on MI355X: with 64-byte LDS rows every global_load_lds
 // instruction fetches half cache lines, which doubles the request count on the load side that already takes as long
@@ -889,6 +1115,40 @@ extern "C" int e2k_gemm_nt_bf16(const void* A1, int64_t lda1, int K1, const void
     const bool glds = !(flags & E2K_GEMM_NO_GLDS) && (K1 % BK) == 0 && (K2 % BK) == 0;
     // 256-row tiles: opt-in (measured equal to the 128 x 128 kernel at best, 5-15 % slower on most cfg3 shapes)
     const bool big = glds && !p.probe && (flags & E2K_GEMM_BIG);
+    // 256 x 256 tiles (8-phase kernel): opt-in, not yet run on hardware.  T256 = every shape, T256_AUTO = only shapes
+    // whose 256 x 256 tiles fill at least 7/8 of a round of the 256 resident workgroups
+    const int t256 = ((M + QBM - 1) / QBM) * ((N + QBN - 1) / QBN);
+    const bool q256 = glds && !p.probe && !big &&
+                      ((flags & E2K_GEMM_T256) || ((flags & E2K_GEMM_T256_AUTO) && t256 >= 224 && (K1 + K2) >= 4 * BK));
+    if (q256) {
+        const int T = t256;
+        p.full = T; p.split = 1; p.ws = ws;
+        int rem = 0;
+        const int slots = (flags & E2K_GEMM_TEST_SLOTS8) ? 8 : 256;
+        if (ws && !(flags & E2K_GEMM_NO_SPLIT) && T > slots && (T % slots) != 0) {
+            rem = T % slots;
+            const int nk = (K1 + K2) / BK;
+            int split = 1;
+            while (split * 2 <= 16 && split * 2 * rem <= slots && split * 2 * 4 <= nk) split *= 2;   // >= 4 K tiles per part
+            // same trade as below: half a round saved (~1 us per K step of a 256 x 256 tile) against 256 KB of fp32
+            // partials per part written and re-read, plus the fix-up launch.  UNMEASURED constants (scaled from the 128 x 128 ones)
+            if (!(flags & E2K_GEMM_TEST_SLOTS8))
+                while (split > 1 && 1.0f * nk < 1.2f * (rem * split * 0.104f + 4.f)) split >>= 1;
+            if (split > 1 && (int64_t)rem * split * QBM * QBN * 4 <= ws_bytes) { p.full = T - rem; p.split = split; }
+            else rem = 0;
+        }
+        dim3 grid(p.full + rem * p.split);
+        hipStream_t st = (hipStream_t)stream;
+        if (out_f32) hipLaunchKernelGGL(gemm_nt_256_kernel<true>, grid, dim3(QTHREADS), 0, st, p);
+        else hipLaunchKernelGGL(gemm_nt_256_kernel<false>, grid, dim3(QTHREADS), 0, st, p);
+        E2K_CHECK_LAUNCH();
+        if (rem) {
+            if (out_f32) hipLaunchKernelGGL(gemm_nt_256_fixup_kernel<true>, dim3(rem, 16), dim3(QTHREADS), 0, st, p);
+            else hipLaunchKernelGGL(gemm_nt_256_fixup_kernel<false>, dim3(rem, 16), dim3(QTHREADS), 0, st, p);
+            E2K_CHECK_LAUNCH();
+        }
+        return 0;
+    }
     const int bm = big ? GBM : BM;
     const int tm = (M + bm - 1) / bm, T = tm * tn;
     // Remainder split: `slots` workgroups are resident (256 CUs x 2 of the 128-row kernel, x 1 of the 256-row one); a
@@ -937,7 +1197,8 @@ extern "C" int e2k_gemm_nt_bf16(const void* A1, int64_t lda1, int K1, const void
     return 0;
 }
 
-extern "C" int e2k_query_gemm_nt_ws_bytes(void) { return NT_SLOTS * BM * BN * 4; }
+// 512 partial slots of a 128 x 128 tile or 256 of a 256 x 256 tile (every remainder split fits: rem * split <= slots)
+extern "C" int e2k_query_gemm_nt_ws_bytes(void) { return 256 * QBM * QBN * 4; }
 
 extern "C" int e2k_query_gemm_tn_splits(int M, int N, int K, int splits) {
     if (M <= 0 || N <= 0 || K <= 0) return 1;

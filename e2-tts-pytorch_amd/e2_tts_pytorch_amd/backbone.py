@@ -311,6 +311,8 @@ class Transformer(Module):
         self._vcache = {}
         self.use_graphs = False         # enable_graphs(): capture forward / per-layer backward into HIP graphs
         self._graphs = {}
+        self._persist_grads = False     # enable_persistent_grads(): one flat gradient buffer for the life of the module
+        self._pg = None
 
     # ------------------------------------------------------------------ layout
 
@@ -509,7 +511,7 @@ class Transformer(Module):
         n = 1
         for s in shape:
             n *= s
-        return gflat[off:off + n].view(*shape)
+        return gflat[off:off + n].view(shape)
 
     # ------------------------------------------------------------------ public forward
 
@@ -824,7 +826,7 @@ class Transformer(Module):
 
     def _run_backward(self, run, dout):
         """eager backward: drive the schedule, hand finished gradient slabs to the data-parallel hook"""
-        gen = self._backward_gen(run, dout)
+        gen = self._backward_gen(run, dout, self._persist_grads)
         while True:
             try:
                 with ops.pinned_stream(dout.device):        # (the hook below enqueues RCCL work on its own stream)
@@ -836,19 +838,64 @@ class Transformer(Module):
                 self._grad_sync(run.gflat, start, end)
         if exists(self._grad_sync):
             self._grad_sync(gflat, None, None)          # wait for every slab
-        pgrads = [gflat[off:off + p.numel()].view(p.shape) if p.requires_grad else None for p, off in self._layout.slots]
+        if self._persist_grads:
+            self._attach_grads()
+            pgrads = self._no_pgrads
+        else:
+            pgrads = [gflat[off:off + p.numel()].view(p.shape) if p.requires_grad else None for p, off in self._layout.slots]
         return dxs, dcond, dtext, pgrads
 
-    def _backward_gen(self, run, dout):
+    # persistent gradients -------------------------------------------------------
+    # Handing ~600 gradient views to autograd costs host time that has nothing to do with the model: one view per
+    # parameter, one AccumulateGrad node each, and a `p.grad = None` per parameter in zero_grad -- about a quarter of the
+    # Python time of a step (tools/host_overhead.py).  In this mode the flat gradient buffer is allocated once, every
+    # parameter's `.grad` is a permanent view of it, and a backward pass zero-fills the buffer and writes into it.
+
+    def enable_persistent_grads(self, on: bool = True):
+        """Keep one flat fp32 gradient buffer for the life of the module (eager launches only; HIP-graph replay has
+        `enable_graphs(alias_grads=True)` for the same purpose).  Every backward pass OVERWRITES the gradients: there is
+        no accumulation over several backward passes, `zero_grad()` between steps is unnecessary (and with
+        `set_to_none=True` only costs a re-attach), and the module must not appear twice in one autograd graph.  Tensor
+        hooks registered on the parameters do not fire (the gradients do not travel through AccumulateGrad)."""
+        self._persist_grads = bool(on)
+        if not on:
+            self._pg = None
+        return self
+
+    def _pg_state(self, dev):
+        pg = self._pg
+        if pg is None or pg.buf.device != dev:
+            buf = torch.zeros(self._layout.n, dtype=f32, device=dev)
+            views = [buf[off:off + p.numel()].view(p.shape) for p, off in self._layout.slots]
+            pg = self._pg = NS(buf=buf, views=views, gcache={})
+            self._no_pgrads = [None] * len(views)
+        return pg
+
+    def _attach_grads(self):
+        for (p, _), v in zip(self._layout.slots, self._pg.views):
+            if p.requires_grad and p.grad is not v:
+                p.grad = v
+
+    def _backward_gen(self, run, dout, persist=False):
         """generator over the backward schedule: yields (start, end) of the flat-gradient slab that has just become
         final (one per layer, then the global slab) and returns (dx, dcond, dtext, grad_flat)"""
         B, T, N, Mtok = run.B, run.T, run.N, run.Mtok
         D, Dt, R, L = self.dim, self.dim_text, self.num_registers, self.depth
         dev = run.dev
         lay, g = self._layout, self._glob
-        gflat = torch.zeros(lay.n, dtype=f32, device=dev)
+        if persist:
+            pg = self._pg_state(dev)
+            gflat, gc, mk = pg.buf.zero_(), pg.gcache, self._g
+
+            def G(off, *shape):                       # the buffer outlives the step, so do its views
+                v = gc.get((off, shape))
+                if v is None:
+                    v = gc[(off, shape)] = mk(gflat, off, *shape)
+                return v
+        else:
+            gflat = torch.zeros(lay.n, dtype=f32, device=dev)
+            G = lambda off, *shape: self._g(gflat, off, *shape)
         run.gflat = gflat
-        G = lambda off, *shape: self._g(gflat, off, *shape)
 
         # tail
         xsum, rn = run.tail
@@ -867,7 +914,7 @@ class Transformer(Module):
             kind = ent[0]
             if kind == 'hc':
                 _, rec, key = ent
-                hg = [G(o, *s) if len(s) else G(o, 1).view(()) for o, s in zip(rec.hc.offs, rec.hc.shapes)]
+                hg = [G(o, *s) for o, s in zip(rec.hc.offs, rec.hc.shapes)]
                 dR, dyprev = ops.hc_bwd(grads[key], xin=rec.xin, yprev=rec.yprev, coef_prev=rec.coef_prev,
                                         dbin=rec.dbin, ycur=rec.ycur, coef=rec.coef,
                                         params=self._hc_params(rec.hc), grads=hg)

@@ -125,7 +125,10 @@ def _nt_ws(device):
 
 _gemm_profile = None
 _gemm_shapes = None        # tools/nt_shapes.py: dict counting the (M, N, K1, K2, out_f32, has_resid) of every gemm_nt call
-gemm_flags = 0          # E2K_GEMM_* bits passed to every gemm_nt call (A/B benchmarking of kernel variants)
+# E2K_GEMM_* bits passed to every gemm_nt call (A/B benchmarking of kernel variants: 64 = 256 x 128 tile, 128 = 256 x 256
+# 8-phase tile for every shape, 256 = the same where it fills the chip).  E2K_GEMM_FLAGS in the environment presets it.
+import os as _os
+gemm_flags = int(_os.environ.get('E2K_GEMM_FLAGS', '0'))
 
 
 def set_gemm_profile(lst):

@@ -83,7 +83,19 @@ class FusedAdopt:
         self._backbones = [m for m in model.modules() if isinstance(m, Transformer)]
 
     def zero_grad(self, set_to_none=True):
-        self.model.zero_grad(set_to_none=set_to_none)
+        """optimizer.zero_grad (trainer.py:277).  Backbones in persistent-gradient mode are skipped: their next backward
+        pass overwrites the flat gradient buffer anyway, and detaching ~600 views only to re-attach them costs host time"""
+        keep = set()
+        for tr in self._backbones:
+            if getattr(tr, '_persist_grads', False):
+                keep.update(id(q) for q, _ in tr._layout.slots)
+        for p in self.params:
+            if id(p) in keep or p.grad is None:
+                continue
+            if set_to_none:
+                p.grad = None
+            else:
+                p.grad.zero_()
 
     @torch.no_grad()
     def step(self):
@@ -103,7 +115,11 @@ class FusedAdopt:
             flat = getattr(tr, '_flat', None)
             if not slots or flat is None or slots[0][0].grad is None:
                 continue
-            base = _grad_base(slots, flat.numel())
+            pg = getattr(tr, '_pg', None)
+            if getattr(tr, '_persist_grads', False) and pg is not None and slots[0][0].grad is pg.views[0]:
+                base = pg.buf                       # persistent mode: the buffer is at hand, no need to re-derive it
+            else:
+                base = _grad_base(slots, flat.numel())
             if base is not None and all(q.data_ptr() == flat.data_ptr() + off * 4 for q, off in slots):
                 runs.append((flat.view(-1), base))
                 taken.update(id(q) for q, _ in slots)
@@ -137,6 +153,7 @@ class FusedEMA:
         for m in self.ema_model.modules():            # deepcopy clones every parameter separately: re-establish the
             if isinstance(m, Transformer):            # flat storage of the copy, so that it is one run like the original
                 m._flat = None
+                m.enable_persistent_grads(False)      # (the copy never sees a backward pass)
                 m._sync(next(m.parameters()).device)
 
     def current_decay(self):

@@ -48,6 +48,8 @@ int e2k_query_gemm_nt_ws_bytes(void);
 #define E2K_GEMM_PROBE_NO_LOADS 4 /* flags: bottleneck probe, K loop without its global loads (WRONG results) */
 #define E2K_GEMM_PROBE_NO_MATH 8  /* flags: bottleneck probe, K loop without its LDS reads + MFMAs (WRONG results) */
 #define E2K_GEMM_BIG 64          /* flags: use the 256 x 128 x 64, 8-wave, 3-stage kernel (A/B: not faster on MI355X, see gemm.hip) */
+#define E2K_GEMM_T256 128        /* flags: 256 x 256 x 64 tile, 8-wave 8-phase kernel for every shape (parity-tested on the host model, NOT yet run on hardware) */
+#define E2K_GEMM_T256_AUTO 256   /* flags: the same, only for shapes whose 256 x 256 tiles fill >= 7/8 of a round of 256 workgroups */
 #define E2K_GEMM_NO_SPLIT 16     /* flags: never split remainder tiles over K (A/B) */
 #define E2K_GEMM_TEST_SLOTS8 32  /* flags: pretend the chip holds 8 workgroups (lets small shapes exercise the remainder split in tests) */
 

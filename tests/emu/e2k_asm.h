@@ -58,12 +58,23 @@ inline unsigned long long sload64(const unsigned long long* p) { return *p; }
 inline float fast_exp2(float x) { return exp2f(x); }
 inline float fast_rcp(float x) { return 1.0f / x; }
 
-template <int N> inline void wait_vmcnt() {}
+template <int N> inline void wait_vmcnt() { emu::land_pending(N); }
 inline void barrier_keep_vm() { emu::block_rendezvous(); }
+inline void barrier_raw() { emu::block_rendezvous(); }
+template <int P> inline void set_prio() {}
+inline void sched_fence() {}
 
 // host model of global_load_lds_dwordx4: lane l copies its 16 bytes to (wave-uniform) lds_base + 16*l
 inline void glds16(const void* gsrc, void* lds_base) {
-    memcpy((char*)lds_base + 16 * emu::lane_id(), gsrc, 16);
+    void* dst = (char*)lds_base + 16 * emu::lane_id();
+    if (emu::g_glds_late) {
+        emu::PendingCopy c;
+        memcpy(c.data, gsrc, 16);
+        c.dst = dst;
+        emu::cur_fiber().pending.push_back(c);
+    } else {
+        memcpy(dst, gsrc, 16);
+    }
 }
 
 }  // namespace e2k

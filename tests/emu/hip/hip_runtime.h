@@ -62,7 +62,19 @@ struct Wave {
     int nlanes = kWave;
 };
 
+// global_load_lds (LDS-DMA) is asynchronous on the GPU: the bytes may land any time between the issue and the wave's
+// own `s_waitcnt vmcnt`.  The model can run both extremes: by default a copy lands AT ISSUE (earliest possible: exposes
+// write-after-read mistakes, i.e. restaging a buffer that is still being read); with E2K_EMU_GLDS_LATE=1 it lands only
+// when the issuing lane's counted wait (or a __syncthreads, which drains vmcnt on the GPU) forces it (latest possible:
+// exposes read-before-landed mistakes in counted-vmcnt pipelines).
+struct PendingCopy {
+    unsigned char data[16];
+    void* dst;
+};
+inline bool g_glds_late = false;
+
 struct Fiber {
+    std::vector<PendingCopy> pending;       // this lane's LDS-DMA copies that have not landed yet (late mode), oldest first
     ucontext_t ctx;
     dim3 tid;
     int lin = 0;
@@ -87,6 +99,14 @@ struct Block {
 inline thread_local Block* g_blk = nullptr;
 
 inline Fiber& cur_fiber() { return g_blk->fibers[g_blk->cur]; }
+// let all but the newest `keep` LDS-DMA copies of the calling lane land (s_waitcnt vmcnt(keep))
+inline void land_pending(int keep) {
+    Fiber& f = cur_fiber();
+    int n = (int)f.pending.size() - keep;
+    if (n <= 0) return;
+    for (int i = 0; i < n; ++i) memcpy(f.pending[i].dst, f.pending[i].data, 16);
+    f.pending.erase(f.pending.begin(), f.pending.begin() + n);
+}
 inline void yield() {
     Fiber& f = cur_fiber();
     swapcontext(&f.ctx, &g_blk->sched);
@@ -118,6 +138,7 @@ inline void wave_rendezvous(Wave& w) {
 static void trampoline() {
     Block* b = g_blk;
     (*b->body)();
+    land_pending(0);
     b->fibers[b->cur].done = true;
     swapcontext(&b->fibers[b->cur].ctx, &b->sched);
 }
@@ -130,6 +151,7 @@ inline void run_block(Block& blk, const std::function<void()>& body) {
     for (int i = 0; i < n; ++i) {
         Fiber& f = blk.fibers[i];
         f.done = false;
+        f.pending.clear();
         f.par = 0;
         f.lin = i;
         f.tid = dim3(i % blk.bdim.x, (i / blk.bdim.x) % blk.bdim.y, i / (blk.bdim.x * blk.bdim.y));
@@ -170,6 +192,7 @@ inline void launch(dim3 grid, dim3 block, const std::function<void()>& body) {
     long nblocks = (long)grid.x * grid.y * grid.z;
     int nthreads = block.x * block.y * block.z;
     if (nblocks == 0 || nthreads == 0) return;
+    g_glds_late = getenv("E2K_EMU_GLDS_LATE") && atoi(getenv("E2K_EMU_GLDS_LATE")) != 0;
     unsigned hw = std::thread::hardware_concurrency();
     if (const char* e = getenv("E2K_EMU_THREADS")) hw = atoi(e);
     if (hw < 1) hw = 1;
@@ -229,7 +252,10 @@ inline void hipLaunchKernelGGL(K k, dim3 g, dim3 b, size_t, hipStream_t, A... ar
     emu::launch(g, b, [=]() { k(args...); });
 }
 
-static inline void __syncthreads() { emu::block_rendezvous(); }
+static inline void __syncthreads() {
+    emu::land_pending(0);           // the compiler drains vmcnt before the barrier of a __syncthreads when LDS-DMA is in flight
+    emu::block_rendezvous();
+}
 static inline void __builtin_amdgcn_s_barrier() { emu::block_rendezvous(); }
 static inline void __builtin_amdgcn_s_setprio(int) {}
 static inline void __builtin_amdgcn_sched_barrier(int) {}

@@ -100,6 +100,60 @@ def test_backbone(dev, cond_on_time, with_text, with_mask):
     assert not bad, bad[:20]
 
 
+def test_persistent_grads(emu):
+    """enable_persistent_grads(): every .grad is a permanent view of one flat buffer that each backward overwrites; the
+    values are those of the default mode (fresh gradient tensors handed to autograd)"""
+    dev = 'cpu'                     # host logic only: the logic-checker build is enough ([gpu] variant: next round)
+    from e2_tts_pytorch_amd import Transformer
+    random.seed(0)
+    torch.manual_seed(0)
+    mod = Transformer(dim=256, depth=2, heads=2, dropout=0., max_seq_len=64)
+    randomize(mod)
+    mod = mod.to(dev)
+    B, T = 2, 24
+    R = torch.randn(B, T, 256).to(dev)
+
+    def step(seed, zero):
+        if zero:
+            mod.zero_grad(set_to_none=True)
+        else:                      # only the parameters outside the flat buffer (ordinary autograd accumulation)
+            for p in mod.time_cond_mlp.parameters():
+                p.grad = None
+        g = torch.Generator().manual_seed(seed)
+        x = torch.randn(B, T, 256, generator=g).to(dev).requires_grad_(True)
+        t = torch.rand(B, generator=g).to(dev)
+        txt = torch.randn(B, T, 128, generator=g).to(dev).requires_grad_(True)
+        out = mod(x, times=t, text_embed=txt)
+        (out * R).sum().backward()
+        return x.grad.clone(), txt.grad.clone(), {n: p.grad.clone() for n, p in mod.named_parameters() if p.grad is not None}
+
+    ref = [step(s, True) for s in (1, 2, 3)]
+    mod.zero_grad(set_to_none=True)
+    mod.enable_persistent_grads()
+    got = [step(1, False), step(2, False)]            # no zero_grad in between: the second pass must not accumulate
+    flat_ids = {id(q) for q, _ in mod._layout.slots}    # (time_cond_mlp sits outside the hand-scheduled part)
+    ids = {n: p.grad.data_ptr() for n, p in mod.named_parameters() if p.grad is not None and id(p) in flat_ids}
+    views = {n: p.grad for n, p in mod.named_parameters() if n in ids}
+    got.append(step(3, True))                          # zero_grad(set_to_none=True) detaches the views: re-attached
+    for n, p in mod.named_parameters():
+        if n in ids:
+            assert p.grad.data_ptr() == ids[n] and p.grad is views[n], n
+    for (dx0, dt0, g0), (dx1, dt1, g1) in zip(ref, got):
+        assert rel2(dx1, dx0) < 1e-5 and rel2(dt1, dt0) < 1e-5
+        assert g0.keys() == g1.keys()
+        for n in g0:                # (not bit-equal: several gradients are float atomics, whose order varies run to run)
+            assert rel2(g1[n], g0[n]) < 1e-4 or float(g0[n].norm()) < 1e-6, (n, rel2(g1[n], g0[n]))
+    buf = mod._pg.buf
+    lay = mod._layout
+    assert all(p.grad.data_ptr() == buf.data_ptr() + 4 * off for p, off in lay.slots if p.grad is not None)
+    # back to the default mode: fresh tensors again
+    mod.enable_persistent_grads(False)
+    again = step(1, True)
+    assert all(rel2(again[2][n], ref[0][2][n]) < 1e-4 or float(ref[0][2][n].norm()) < 1e-6 for n in ref[0][2])
+    n0 = next(iter(ids))
+    assert dict(mod.named_parameters())[n0].grad.data_ptr() != ids[n0]
+
+
 @pytest.mark.gpu
 def test_graph_replay_matches_eager():
     """HIP-graph path (one forward graph + per-layer backward graphs) reproduces the eager schedule"""

@@ -36,6 +36,23 @@ def _worker(rank, world, port, emu_lib, q):
     out = net(mels[rank], text=['hello'], _noise=noises[rank])
     out.loss.backward()
     grads = {n: p.grad.clone() for n, p in model.named_parameters() if p.grad is not None}
+    # persistent-gradient mode: the slabs are views of one long-lived buffer; two more steps (other inputs first, so
+    # that the second one has something to overwrite) must end with the same averaged gradients
+    tr = model.transformer
+    tr.enable_persistent_grads()
+    flat_ids = {id(q_) for q_, _ in tr._layout.slots}
+    bad_p = []
+    for which in ((rank + 1) % world, rank):
+        for p in model.parameters():
+            if id(p) not in flat_ids:
+                p.grad = None
+        net(mels[which], text=['hello'], _noise=noises[rank]).loss.backward()
+    for n, p in model.named_parameters():
+        if n in grads:
+            err = ((p.grad - grads[n]).norm() / grads[n].norm().clamp_min(1e-12)).item() if float(grads[n].norm()) > 0 else float(p.grad.norm())
+            if err > 1e-4:
+                bad_p.append((n + ' (persistent)', err))
+    assert tr._pg is not None and all(q_.grad is v for (q_, _), v in zip(tr._layout.slots, tr._pg.views) if q_.requires_grad)
     if rank == 0:
         # single-process reference with the broadcast weights: mean over both "ranks" of the per-sample gradients
         ref = E2TTS(transformer=dict(dim=256, depth=2, heads=4, dropout=0.), use_vocos=False, cond_drop_prob=0.)
@@ -53,9 +70,9 @@ def _worker(rank, world, port, emu_lib, q):
             err = ((grads[n] - g).norm() / g.norm().clamp_min(1e-12)).item() if float(g.norm()) > 0 else float(grads[n].norm())
             if err > 2e-2:
                 bad.append((n, err))
-        q.put(('ok', bad, net._sync.calls))
+        q.put(('ok', bad + bad_p, net._sync.calls))
     else:
-        q.put(('ok', [], net._sync.calls))
+        q.put(('ok', bad_p, net._sync.calls))
     dist.barrier()
     dist.destroy_process_group()
 

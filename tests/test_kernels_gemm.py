@@ -117,13 +117,42 @@ def test_gemm_tn_colsum(dev, M, N, K, cs_from):
     (2304, 128, 448, 0, dict(f32=1, bias=1)),                # 9 tiles, seven steps; with flag 32: remainder split
     (700, 260, 320, 0, dict(rs=1)),
 ])
-def test_gemm_nt_big_tile(dev, M, N, K1, K2, kw, flags):
-    """256 x 128 tile, 3-stage NT kernel (opt-in flag E2K_GEMM_BIG), alone and with the remainder split"""
+def test_gemm_nt_big_tile(dev, monkeypatch, M, N, K1, K2, kw, flags):
+    """256 x 128 tile, 3-stage NT kernel (opt-in flag E2K_GEMM_BIG), alone and with the remainder split.  On the host model
+    the LDS-DMA copies land as late as its counted vmcnt waits allow (E2K_EMU_GLDS_LATE; no effect on the GPU)"""
     from e2_tts_pytorch_amd import ops
+    monkeypatch.setenv('E2K_EMU_GLDS_LATE', '1')
     old = ops.gemm_flags
     ops.gemm_flags = flags
     try:
         test_gemm_nt(dev, M, N, K1, K2, kw)
+    finally:
+        ops.gemm_flags = old
+
+
+@pytest.mark.parametrize('flags', [128, 128 | 32])
+@pytest.mark.parametrize('M,N,K1,K2,kw', [
+    (256, 256, 64, 0, {}),                                   # one tile, ONE K tile (prologue and drain only)
+    (300, 300, 128, 0, dict(bias=1)),                        # ragged edges in both directions, two K tiles
+    (520, 260, 192, 64, dict(bias=1, cs=1, rm=1, rs=1)),     # dual-K (3 + 1 tiles), every epilogue operand
+    (2304, 256, 512, 0, dict(f32=1, bias=1)),                # 9 tiles, 8 K tiles; with flag 32: 1 remainder tile x 2 K ranges
+    (1280, 512, 256, 256, dict(bias=1, cs=1, rm=1, rs=1)),   # 10 tiles; with flag 32: 2 remainder tiles x 2 K ranges, dual-K
+    (700, 520, 320, 0, dict(rs=1)),                          # odd number of K tiles (5)
+])
+@pytest.mark.parametrize('late', [0, 1])
+def test_gemm_nt_256_tile(emu, monkeypatch, M, N, K1, K2, kw, flags, late):
+    """256 x 256 tile, 8-phase NT kernel (opt-in flag E2K_GEMM_T256), alone and with the remainder split.  Host model
+    only for now: the kernel was written after round 1's GPU time was spent; its first hardware run (and with it the
+    [gpu] variant of this test) belongs to the next round.  What this checks: tile / quadrant / fragment indexing, the
+    staging order against program-order overwrites, K-range tails, partials + fix-up, barrier pairing of the two wave
+    groups (the model aborts on a mismatched barrier).  late = 1: LDS-DMA copies land as late as the issuing lane's
+    counted `s_waitcnt vmcnt` allows instead of at issue (tests/emu/hip/hip_runtime.h) -- a wrong count reads stale data"""
+    from e2_tts_pytorch_amd import ops
+    monkeypatch.setenv('E2K_EMU_GLDS_LATE', str(late))
+    old = ops.gemm_flags
+    ops.gemm_flags = flags
+    try:
+        test_gemm_nt('cpu', M, N, K1, K2, kw)
     finally:
         ops.gemm_flags = old
 

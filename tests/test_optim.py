@@ -49,9 +49,11 @@ def test_ema_kernel(dev):
     assert torch.allclose(ek.cpu(), e.lerp(p, 0.01), rtol=1e-6, atol=1e-7)
 
 
-def test_fused_adopt_on_model(dev):
+@pytest.mark.parametrize('persist', [False, True])
+def test_fused_adopt_on_model(dev, persist):
     """FusedAdopt / FusedEMA on a small E2TTS: runs of adjacent parameters are merged, results match the oracle optimizer
-    fed with the same gradients (the backbone's parameters are views of one flat buffer)"""
+    fed with the same gradients (the backbone's parameters are views of one flat buffer).  persist: the same with
+    Transformer.enable_persistent_grads() -- the gradients stay attached across zero_grad and are overwritten in place"""
     from e2_tts_pytorch_amd import E2TTS
     from e2_tts_pytorch_amd.optim import FusedAdopt, FusedEMA, _runs
     import random
@@ -59,6 +61,8 @@ def test_fused_adopt_on_model(dev):
     torch.manual_seed(0)
     model = E2TTS(transformer=dict(dim=256, depth=2, heads=4, dropout=0.), use_vocos=False, cond_drop_prob=0.).to(dev)
     mel = torch.randn(2, 24, 100, device=dev)
+    if persist:
+        model.transformer.enable_persistent_grads()
     opt = FusedAdopt(model, lr=1e-3, max_grad_norm=1.0)
     ema = FusedEMA(model, update_after_step=0, update_every=1)
     ref_params = [p.detach().cpu().clone().requires_grad_(True) for p in opt.params]
@@ -83,6 +87,13 @@ def test_fused_adopt_on_model(dev):
         ema.update()
         for rp, p in zip(ref_params, opt.params):
             assert torch.allclose(p.detach().cpu(), rp.detach(), rtol=1e-4, atol=1e-6), step
+        tr = model.transformer
+        flat_ids = {id(q) for q, _ in tr._layout.slots}
+        if persist:                 # zero_grad left the backbone's views attached and dropped everything else
+            assert all(q.grad is v for (q, _), v in zip(tr._layout.slots, tr._pg.views) if q.requires_grad)
+            assert all(p.grad is None for p in opt.params if id(p) not in flat_ids)
+        else:
+            assert all(p.grad is None for p in opt.params)
     te = ema.ema_model.transformer                    # the copy has its own flat storage (one kernel launch per update)
     assert te._flat.data_ptr() != model.transformer._flat.data_ptr()
     assert all(q.data_ptr() == te._flat.data_ptr() + off * 4 for q, off in te._layout.slots)
