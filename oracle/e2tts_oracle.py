@@ -6,11 +6,15 @@ plus the arithmetic of the third-party packages the reference imports but does
 not vendor (x-transformers, hyper-connections, hl-gauss-pytorch, torchaudio,
 torchdiffeq, einx -- SURVEY.md Appendix A).
 
-PARITY UNPINNED: the reference ships no tests / golden vectors and cannot be
-imported in the build container (14 missing packages, no network), so this file
-is checked only against (i) independent implementations available here
-(torch.stft, transformers.audio_utils.mel_filter_bank, F.scaled_dot_product_attention),
-(ii) analytic invariants of the reference's initialisation and (iii) fp64
+PARITY: pinned to the reference's own source, unpinned for the third-party leaves.
+oracle/pin_against_reference.py executes /root/reference/e2_tts_pytorch/e2_tts.py itself (with stand-ins, built from
+the classes below, for the leaf modules of the packages that are not installed) and finds this file bit-identical to
+it for Transformer forward + gradients, E2TTS.forward (incl. the CFG coin and velocity consistency), E2TTS.sample,
+DurationPredictor, MelSpec and the helpers; tests/golden/reference_pinned.pt holds those reference outputs.  The
+leaves themselves (Attention, FeedForward, RMSNorm, AdaptiveRMSNorm, RotaryEmbedding, HyperConnections, HLGaussLayer,
+MelSpectrogram, midpoint odeint) restate the published algorithms and are checked only against (i) independent
+implementations available here (torch.stft, transformers.audio_utils.mel_filter_bank,
+F.scaled_dot_product_attention), (ii) analytic invariants of the reference's initialisation and (iii) fp64
 self-consistency / finite differences -- see tests/test_oracle.py.
 
 Only tests/, __graft_entry__.smoke() and bench.py's cpu_baseline leg may import

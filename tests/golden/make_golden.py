@@ -1,7 +1,7 @@
 """Generates tests/golden/oracle_small.pt: seeded inputs + explicit noise + the CPU oracle's outputs.
 
-PARITY UNPINNED: the reference itself cannot be imported in the build container, so these vectors
-pin the ORACLE (drift detector + a fixture the GPU box can check without /root/reference), not the reference.
+These vectors pin the ORACLE only (drift detector + a fixture the GPU box can check without /root/reference); the
+vectors that come from the reference's own source are tests/golden/reference_pinned.pt (oracle/pin_against_reference.py).
 Run:  python tests/golden/make_golden.py
 """
 import random

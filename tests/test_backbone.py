@@ -8,6 +8,10 @@ from oracle import e2tts_oracle as O
 
 bf16 = torch.bfloat16
 
+# device of the tests that run on the host model only (`emu` fixture); tools/gpu_variants_of_emu_tests.py points it at
+# the GPU for a one-off run against the real library
+EMU_ONLY_DEV = 'cpu'
+
 
 def rel(a, b):
     a, b = a.cpu(), b.cpu()
@@ -103,7 +107,7 @@ def test_backbone(dev, cond_on_time, with_text, with_mask):
 def test_persistent_grads(emu):
     """enable_persistent_grads(): every .grad is a permanent view of one flat buffer that each backward overwrites; the
     values are those of the default mode (fresh gradient tensors handed to autograd)"""
-    dev = 'cpu'                     # host logic only: the logic-checker build is enough ([gpu] variant: next round)
+    dev = EMU_ONLY_DEV                     # host logic only: the logic-checker build is enough ([gpu] variant: next round)
     from e2_tts_pytorch_amd import Transformer
     random.seed(0)
     torch.manual_seed(0)

@@ -1,6 +1,7 @@
-"""Pins the CPU oracle (PARITY UNPINNED w.r.t. the reference, which cannot be imported here -- SURVEY.md 8c):
-independent implementations available in the container, analytic invariants of the reference initialisation,
-fp64 self-consistency, and the committed golden fixture."""
+"""Pins the CPU oracle: (a) against the outputs of the reference's own source (tests/golden/reference_pinned.pt, written by
+oracle/pin_against_reference.py -- bottom of this file); (b) for the third-party leaf modules, which the reference
+imports from packages that are not installed: independent implementations available in the container, analytic
+invariants of the reference initialisation, fp64 self-consistency; (c) the older oracle-only drift fixture."""
 import math
 import random
 from pathlib import Path
@@ -154,3 +155,78 @@ def test_golden_fixture():
     assert (out.pred_flow - fix['pred_flow']).abs().max().item() < 1e-4
     assert (model.to_pred.weight.grad - fix['grad_to_pred']).abs().max().item() < 1e-4
     assert (O.MelSpec()(fix['wave']) - fix['logmel']).abs().max().item() < 1e-4
+
+
+# ---------------------------------------------------------------------------------------------- pinned to the reference
+# tests/golden/reference_pinned.pt holds outputs of /root/reference/e2_tts_pytorch/e2_tts.py ITSELF (executed by
+# oracle/pin_against_reference.py with stand-ins for the uninstalled third-party leaves); weights come from seeds.
+
+REF_GOLD = Path(__file__).resolve().parent / 'golden' / 'reference_pinned.pt'
+
+
+def _maxrel(a, b):
+    return ((a.double() - b.double()).abs().max() / b.double().abs().max().clamp_min(1e-30)).item()
+
+
+def test_reference_golden_transformer():
+    from oracle.golden_weights import fill_params
+    gold = torch.load(REF_GOLD, weights_only=False)
+    for name in ('transformer_full', 'transformer_bare'):
+        c = gold[name]
+        random.seed(0)
+        m = fill_params(O.Transformer(**c['kw'], cond_on_time=c['cond_on_time']), c['weight_seed'])
+        x = c['x'].clone().requires_grad_(True)
+        t = c['text'].clone().requires_grad_(True) if c['text'] is not None else None
+        out = m(x, times=c['times'], mask=c['mask'], text_embed=t)
+        (out * c['R']).sum().backward()
+        assert _maxrel(out, c['out']) < 1e-5 and _maxrel(x.grad, c['dx']) < 1e-5, name
+        for n, p in m.named_parameters():
+            if n in c['grad_abs_sums']:
+                want = c['grad_abs_sums'][n]
+                assert abs(float(p.grad.double().abs().sum()) - want) <= 1e-4 * want + 1e-9, (name, n)
+
+
+def test_reference_golden_e2tts():
+    from oracle.golden_weights import fill_params
+    gold = torch.load(REF_GOLD, weights_only=False)
+    for name in ('e2tts_text_on', 'e2tts_cfg_keep', 'e2tts_cfg_drop'):
+        c = gold[name]
+        random.seed(0)
+        m = fill_params(O.E2TTS(transformer=dict(**c['kw']), cond_drop_prob=c['cond_drop_prob']), c['weight_seed'])
+        out = m(c['mel'], text=c['text'], lens=c['lens'], _noise=c['noise'])
+        out.loss.backward()
+        assert abs(out.loss.item() - c['loss'].item()) <= 1e-5 * abs(c['loss'].item()), name
+        assert _maxrel(out.pred_flow, c['pred_flow']) < 1e-5 and torch.equal(out.cond, c['cond']), name
+        for n, p in m.named_parameters():
+            if n in c['grad_abs_sums']:
+                want = c['grad_abs_sums'][n]
+                assert abs(float(p.grad.double().abs().sum()) - want) <= 1e-4 * want + 1e-9, (name, n)
+    assert gold['e2tts_cfg_drop']['noise']['drop_text_cond'] and not gold['e2tts_cfg_keep']['noise']['drop_text_cond']
+    # velocity consistency with an EMA teacher
+    c = gold['velocity']
+    random.seed(0)
+    m = fill_params(O.E2TTS(transformer=dict(**c['kw']), cond_drop_prob=0.,
+                            velocity_consistency_weight=c['velocity_consistency_weight']), c['weight_seed'])
+    teacher = fill_params(O.E2TTS(transformer=dict(**c['kw']), cond_drop_prob=0.), c['teacher_weight_seed'])
+    out = m(c['mel'], text=c['text'], lens=c['lens'], velocity_consistency_model=teacher, _noise=c['noise'])
+    assert abs(out.loss.item() - c['loss'].item()) <= 1e-5 * abs(c['loss'].item())
+    assert abs(out.loss_breakdown.velocity_consistency.item() - c['velocity_loss'].item()) <= 1e-5 * abs(c['velocity_loss'].item())
+    assert c['velocity_loss'].item() > 0
+
+
+def test_reference_golden_sample_and_duration():
+    from oracle.golden_weights import fill_params
+    gold = torch.load(REF_GOLD, weights_only=False)
+    c = gold['sample']
+    random.seed(0)
+    m = fill_params(O.E2TTS(transformer=dict(**c['kw']), cond_drop_prob=0.2), c['weight_seed']).eval()
+    out = m.sample(c['cond'], text=c['text'], lens=c['lens'], duration=c['duration'], steps=c['steps'],
+                   cfg_strength=c['cfg_strength'], _y0=c['y0'])
+    assert _maxrel(out, c['out']) < 1e-5
+    c = gold['duration']
+    m = fill_params(O.DurationPredictor(transformer=dict(**c['kw'])), c['weight_seed'])
+    loss = m(c['mel'], text=c['text'], lens=c['lens'], _rand_frac_index=c['rand_frac_index'])
+    assert abs(loss.item() - c['loss'].item()) <= 1e-5 * abs(c['loss'].item())
+    m.eval()
+    with torch.no_grad():
+        assert _maxrel(m(c['mel'], text=c['text'], lens=c['lens'], return_loss=False), c['pred']) < 1e-5
