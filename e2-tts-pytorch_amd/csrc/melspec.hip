@@ -23,6 +23,7 @@ __device__ __forceinline__ int bitrev10(int x) {
 struct MelArgs {
     const float* wave; long nw; const float* window; const float* fb; const float* twc; const float* tws;
     float* out; int B, frames, hop, n_mels;
+    const int* lens; float pad_value;        // ragged batch: valid samples per row (nullptr = every row has nw), fill of the frames past a row's end
 };
 
 __global__ __launch_bounds__(256) void melspec_kernel(MelArgs p) {
@@ -33,16 +34,21 @@ __global__ __launch_bounds__(256) void melspec_kernel(MelArgs p) {
     const int b = blockIdx.y;
     const int f0 = blockIdx.x * FR;
     const float* x = p.wave + (long)b * p.nw;
+    // ragged batch: this row holds n valid samples; the reflection at its end and its frame count follow n, exactly as if
+    // the row had been transformed on its own (the reference's dataset does one clip at a time, trainer.py:101-131)
+    const long n = p.lens ? max(2L, min((long)p.lens[b], p.nw)) : p.nw;
+    const int nframes = p.lens ? (int)(1 + n / p.hop) : p.frames;
     for (int i = tid; i < NFFT / 2; i += 256) { tc[i] = p.twc[i]; ts[i] = p.tws[i]; }
     // load + reflect pad + window, stored bit-reversed
     for (int fr = 0; fr < FR; ++fr) {
         const int f = f0 + fr;
         for (int i = tid; i < NFFT; i += 256) {
             float v = 0.f;
-            if (f < p.frames) {
+            if (f < nframes) {
                 long j = (long)f * p.hop + i - NFFT / 2;
                 if (j < 0) j = -j;
-                if (j >= p.nw) j = 2 * (p.nw - 1) - j;
+                if (j >= n) j = 2 * (n - 1) - j;
+                j = max(0L, min(j, n - 1));          // (only rows shorter than n_fft / 2 + 1 get here: torch.stft rejects those)
                 v = x[j] * p.window[i];
             }
             const int r = bitrev10(i);
@@ -91,7 +97,7 @@ __global__ __launch_bounds__(256) void melspec_kernel(MelArgs p) {
 #pragma unroll
         for (int fr = 0; fr < FR; ++fr) {
             const int f = f0 + fr;
-            if (f < p.frames) p.out[((long)b * p.n_mels + tid) * p.frames + f] = logf(fmaxf(acc[fr], 1e-5f));
+            if (f < p.frames) p.out[((long)b * p.n_mels + tid) * p.frames + f] = f < nframes ? logf(fmaxf(acc[fr], 1e-5f)) : p.pad_value;
         }
     }
 }
@@ -103,7 +109,19 @@ extern "C" int e2k_melspec(const float* wave, int64_t nw, const float* window, c
     if (B <= 0 || nw <= 0) return 0;
     if (n_fft != NFFT || n_mels > 256 || n_mels <= 0 || hop <= 0 || nw <= NFFT / 2) return E2K_ERR_SHAPE;
     if (!wave || !window || !fb || !twc || !tws || !out) return E2K_ERR_ARG;
-    MelArgs a{wave, (long)nw, window, fb, twc, tws, out, B, (int)(1 + nw / hop), hop, n_mels};
+    MelArgs a{wave, (long)nw, window, fb, twc, tws, out, B, (int)(1 + nw / hop), hop, n_mels, nullptr, 0.f};
+    hipLaunchKernelGGL(melspec_kernel, dim3((a.frames + FR - 1) / FR, B), dim3(256), 0, (hipStream_t)stream, a);
+    E2K_CHECK_LAUNCH();
+    return 0;
+}
+
+extern "C" int e2k_melspec_ragged(const float* wave, int64_t nw, const int32_t* lens, const float* window, const float* fb,
+                                  const float* twc, const float* tws, float* out, float pad_value, int B, int n_fft, int hop,
+                                  int n_mels, void* stream) {
+    if (B <= 0 || nw <= 0) return 0;
+    if (n_fft != NFFT || n_mels > 256 || n_mels <= 0 || hop <= 0 || nw <= NFFT / 2) return E2K_ERR_SHAPE;
+    if (!wave || !lens || !window || !fb || !twc || !tws || !out) return E2K_ERR_ARG;
+    MelArgs a{wave, (long)nw, window, fb, twc, tws, out, B, (int)(1 + nw / hop), hop, n_mels, lens, pad_value};
     hipLaunchKernelGGL(melspec_kernel, dim3((a.frames + FR - 1) / FR, B), dim3(256), 0, (hipStream_t)stream, a);
     E2K_CHECK_LAUNCH();
     return 0;

@@ -136,14 +136,16 @@ class MelSpec(Module):
         self.mel_stft = _MelSpectrogram(sampling_rate, filter_length, win_length, n_mel_channels)
         self.register_buffer('dummy', torch.tensor(0), persistent=False)
 
-    def forward(self, inp):
+    def forward(self, inp, lens=None):
+        """lens (extension, see data.py): samples per row of a zero-padded ragged batch.  Every row then comes out as the
+        reference's one-clip-at-a-time transform followed by collate_fn's zero padding would give it (trainer.py:61-82)"""
         if inp.ndim == 3:
             inp = inp.squeeze(1)
         assert inp.ndim == 2
         if self.dummy.device != inp.device:
             self.to(inp.device)
         return ops.melspec(inp, self.mel_stft.spectrogram.window, self.mel_stft.mel_scale.fb,
-                           self.filter_length, self.hop_length)          # (b, n_mels, frames)
+                           self.filter_length, self.hop_length, lens=lens)          # (b, n_mels, frames)
 
 
 # ------------------------------------------------------------------------------------------------ small modules
@@ -159,6 +161,53 @@ class CharacterEmbed(Module):                                  # e2_tts.py:390-4
         text = text[:, :max_seq_len]
         text = pad_to_length(text, max_seq_len, value=0)
         return self.embed(text)
+
+
+class _AddLastDim(Module):                                      # stands where the reference has einops' Rearrange('... -> ... 1')
+    def forward(self, x):
+        return x[..., None]
+
+
+class InterpolatedCharacterEmbed(Module):
+    """e2_tts.py:414-484 (`interpolated_text=True`): each sample's character embeddings stretched linearly to its
+    audio length plus an MLP of the fractional character position.  The reference loops over the batch with one
+    `.item()` per sample; here the whole batch is one gather + lerp with no host synchronisation (front-end glue, not
+    a kernel: B x T x dim_text elements)."""
+
+    def __init__(self, dim, num_embeds=256):
+        super().__init__()
+        self.dim = dim
+        self.embed = nn.Embedding(num_embeds, dim)
+        self.abs_pos_mlp = nn.Sequential(_AddLastDim(), nn.Linear(1, dim), nn.SiLU(), nn.Linear(dim, dim))
+
+    def forward(self, text, max_seq_len, mask=None):
+        B, dev = text.shape[0], text.device
+        valid = text >= 0
+        nt = valid.sum(dim=-1)                                                      # characters per sample
+        # compact the valid tokens to the front (the tokenizer pads at the end, but a custom one may not)
+        order = torch.argsort((~valid).to(torch.int8), dim=-1, stable=True)
+        tok = text.gather(1, order).clamp(min=0)
+        n_audio = mask.sum(dim=-1) if exists(mask) else torch.full((B,), max_seq_len, device=dev)
+        i = torch.arange(max_seq_len, device=dev, dtype=torch.float32)[None, :]      # output position
+        ntf, naf = nt.to(torch.float32)[:, None], n_audio.to(torch.float32)[:, None]
+        # F.interpolate(mode='bilinear', align_corners=False) along the sequence: source coordinate of output i
+        src = ((i + 0.5) * (ntf / naf.clamp(min=1.)) - 0.5).clamp(min=0.)
+        i0 = src.floor()
+        w = src - i0
+        last = (nt - 1).clamp(min=0)[:, None]
+        i0 = torch.minimum(i0.long(), last)
+        i1 = torch.minimum(i0 + 1, last)
+        emb = self.embed(tok)                                                       # (B, nt_max, d)
+        e0 = emb.gather(1, i0[..., None].expand(-1, -1, self.dim))
+        e1 = emb.gather(1, i1[..., None].expand(-1, -1, self.dim))
+        out = e0 * (1. - w[..., None]) + e1 * w[..., None]
+        inside = (i < naf) & (ntf > 0)                                                 # positions this sample has audio for
+        # torch.linspace(0, nt, n_audio): step nt / (n_audio - 1); zero-padded beyond n_audio
+        pos = torch.where(inside, i * (ntf / (naf - 1.).clamp(min=1.)), torch.zeros_like(i))
+        out = torch.where(inside[..., None], out, torch.zeros_like(out)) + self.abs_pos_mlp(pos)
+        if exists(mask):
+            out = torch.where(mask[..., None], out, torch.zeros_like(out))
+        return out
 
 
 class HLGaussLayer(Module):                                    # hl_gauss_pytorch.HLGaussLayer, regression mode (A.7)
@@ -277,8 +326,8 @@ class E2TTS(Module):
     ):
         super().__init__()
         assert num_freq_tokens > 0
-        if num_freq_tokens != 1 or interpolated_text:
-            raise NotImplementedError('num_freq_tokens > 1 / interpolated_text are not built')
+        if num_freq_tokens != 1:
+            raise NotImplementedError('num_freq_tokens > 1 (has_freq_axis) is not built')
         if odeint_kwargs.get('method', 'midpoint') != 'midpoint':
             raise NotImplementedError('only the midpoint solver (the reference default) is built')
         self.num_freq_tokens, self.has_freq_axis = 1, False
@@ -308,7 +357,8 @@ class E2TTS(Module):
         self.to_pred = nn.Linear(dim, num_channels)
         self.tokenizer, text_num_embeds = _resolve_tokenizer(tokenizer, text_num_embeds)
         self.cond_drop_prob = cond_drop_prob
-        self.embed_text = CharacterEmbed(dim_text, num_embeds=text_num_embeds, **char_embed_kwargs)
+        embed_klass = InterpolatedCharacterEmbed if interpolated_text else CharacterEmbed      # e2_tts.py:1236-1238
+        self.embed_text = embed_klass(dim_text, num_embeds=text_num_embeds, **char_embed_kwargs)
         self.register_buffer('zero', torch.tensor(0.), persistent=False)
         self.velocity_consistency_weight = velocity_consistency_weight
         # the reference default downloads charactr/vocos-mel-24khz from the HF hub (e2_tts.py:1244); the vocoder is

@@ -405,9 +405,10 @@ def qkv_post_bwd(st, dQ, dK, dV, dgate_pre, qkvg, cosb, sinb, vfirst=None, dvfir
 _twiddles = {}
 
 
-def melspec(wave, window, fb, n_fft, hop):
-    """wave (B, nw) fp32 -> (B, n_mels, 1 + nw // hop) fp32 log-mel"""
-    _chk(wave, window, fb)
+def melspec(wave, window, fb, n_fft, hop, lens=None, pad_value=0.):
+    """wave (B, nw) fp32 -> (B, n_mels, 1 + nw // hop) fp32 log-mel.  lens (B,) int: ragged batch -- row b holds lens[b]
+    valid samples and is transformed as if it were alone; frames past 1 + lens[b] // hop are filled with pad_value"""
+    _chk(wave, window, fb, lens)
     assert wave.dim() == 2
     wave = wave.float().contiguous()
     B, nw = wave.shape
@@ -418,6 +419,12 @@ def melspec(wave, window, fb, n_fft, hop):
     twc, tws = _twiddles[key]
     n_mels = fb.shape[1]
     out = torch.empty((B, n_mels, 1 + nw // hop), dtype=f32, device=wave.device)
+    if lens is not None:
+        assert lens.shape == (B,)
+        lens32 = lens.to(device=wave.device, dtype=torch.int32).contiguous()
+        _lib.get().e2k_melspec_ragged(_p(wave), nw, _p(lens32), _p(window.float().contiguous()), _p(fb.float().contiguous()),
+                                      _p(twc), _p(tws), _p(out), float(pad_value), B, n_fft, hop, n_mels, _stream(wave))
+        return out
     _lib.get().e2k_melspec(_p(wave), nw, _p(window.float().contiguous()), _p(fb.float().contiguous()), _p(twc), _p(tws),
                            _p(out), B, n_fft, hop, n_mels, _stream(wave))
     return out

@@ -169,6 +169,15 @@ int e2k_attn_bwd(const void* dOg, const void* O, const float* gate, const float*
 int e2k_melspec(const float* wave, int64_t nw, const float* window, const float* fb, const float* twc,
                 const float* tws, float* out, int B, int n_fft, int hop, int n_mels, void* stream);
 
+/* Ragged batch (the dataset side): wave (B, nw) holds clips of different length, zero-padded; lens[b]
+ * = valid samples of row b (n_fft/2 < lens[b] <= nw).  Row b is transformed exactly as if it were alone (reflection
+ * about ITS end, 1 + lens[b]/hop frames); the remaining frames of the (B, n_mels, 1 + nw/hop) output get pad_value -- what
+ * the reference's per-clip MelSpec in HFDataset.__getitem__ followed by collate_fn's zero padding produces
+ * (trainer.py:61-82,101-131), in one launch on the device. */
+int e2k_melspec_ragged(const float* wave, int64_t nw, const int32_t* lens, const float* window, const float* fb,
+                       const float* twc, const float* tws, float* out, float pad_value, int B, int n_fft, int hop,
+                       int n_mels, void* stream);
+
 /* ---- optimizer side over flat fp32 buffers (reference trainer.py:272-279) ----
  * out[0] += sum x^2 (fp64 accumulation): the global gradient norm of accelerator.clip_grad_norm_ (trainer.py:272-273). */
 int e2k_sumsq_f32(const float* x, int64_t n, double* out, void* stream);

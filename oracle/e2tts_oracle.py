@@ -443,6 +443,41 @@ class CharacterEmbed(Module):                # e2_tts.py:390-412
         return self.embed(text)
 
 
+class _AddLastDim(Module):                   # einops Rearrange('... -> ... 1') (keeps the Sequential indices of the state_dict)
+    def forward(self, x):
+        return x[..., None]
+
+
+class InterpolatedCharacterEmbed(Module):    # e2_tts.py:414-484
+    """every sample's character embeddings are stretched (bilinear, i.e. linear along the sequence) to that sample's
+    audio length; an MLP of the fractional character position is added"""
+
+    def __init__(self, dim, num_embeds=256):
+        super().__init__()
+        self.dim = dim
+        self.embed = nn.Embedding(num_embeds, dim)
+        self.abs_pos_mlp = nn.Sequential(_AddLastDim(), nn.Linear(1, dim), nn.SiLU(), nn.Linear(dim, dim))
+
+    def forward(self, text, max_seq_len, mask=None):
+        embeds, positions = [], []
+        for b in range(text.shape[0]):
+            one = text[b][text[b] >= 0]
+            e = self.embed(one)                                                    # (nt, d)
+            nt = one.shape[0]
+            n_audio = int(mask[b].sum().item()) if exists(mask) else max_seq_len
+            e = F.interpolate(e.t()[None, :, :, None], (n_audio, 1), mode='bilinear')[0, :, :, 0].t()
+            embeds.append(e)
+            positions.append(torch.linspace(0, nt, n_audio, device=text.device))
+        embeds = nn.utils.rnn.pad_sequence(embeds, batch_first=True)
+        positions = nn.utils.rnn.pad_sequence(positions, batch_first=True)
+        embeds = F.pad(embeds, (0, 0, 0, max_seq_len - embeds.shape[-2]))
+        positions = pad_to_length(positions, max_seq_len)
+        embeds = embeds + self.abs_pos_mlp(positions)
+        if exists(mask):
+            embeds = torch.where(mask[..., None], embeds, torch.zeros_like(embeds))
+        return embeds
+
+
 class TextAudioCrossCondition(Module):       # e2_tts.py:486-513
     def __init__(self, dim, dim_text, cond_audio_to_text=True):
         super().__init__()
@@ -703,7 +738,7 @@ class E2TTS(Module):
                  text_num_embeds=None, tokenizer='char_utf8', use_vocos=False, pretrained_vocos_path=None,
                  sampling_rate=None, velocity_consistency_weight=0.):
         super().__init__()
-        assert num_freq_tokens == 1 and not interpolated_text and not use_vocos
+        assert num_freq_tokens == 1 and not use_vocos
         if isinstance(transformer, dict):
             transformer = Transformer(**transformer, cond_on_time=True)
         self.transformer = transformer
@@ -734,7 +769,8 @@ class E2TTS(Module):
         else:
             raise ValueError(f'unknown tokenizer string {tokenizer}')
         self.cond_drop_prob = cond_drop_prob
-        self.embed_text = CharacterEmbed(dim_text, num_embeds=text_num_embeds, **char_embed_kwargs)
+        embed_klass = InterpolatedCharacterEmbed if interpolated_text else CharacterEmbed      # e2_tts.py:1236-1238
+        self.embed_text = embed_klass(dim_text, num_embeds=text_num_embeds, **char_embed_kwargs)
         self.register_buffer('zero', torch.tensor(0.), persistent=False)
         self.velocity_consistency_weight = velocity_consistency_weight
 

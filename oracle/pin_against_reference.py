@@ -8,7 +8,8 @@ What is pinned, and what is not
 /root/reference/e2_tts_pytorch/e2_tts.py is executed as it lies there (nothing is copied): its `Transformer` (layer
 loop, registers, skip connections, text stream, TextAudioCrossCondition, DepthwiseConv, AdaLNZero, time conditioning),
 `E2TTS.forward` (span mask, flow-matching target, loss, classifier-free-guidance drop, velocity consistency),
-`E2TTS.sample`, `DurationPredictor.forward`, `MelSpec.forward`, `CharacterEmbed`, the tokenizer and the mask helpers.
+`E2TTS.sample`, `DurationPredictor.forward`, `MelSpec.forward`, `CharacterEmbed`, the tokenizer and the mask helpers; and
+trainer.py's data path (`HFDataset.__getitem__` + `collate_fn`).
 The file imports packages that are not installed here and cannot be fetched (x_transformers, hyper_connections,
 hl_gauss_pytorch, torchaudio, torchdiffeq, einx, jaxtyping, beartype, vocos).  Their LEAF modules are supplied to it as
 stand-ins built from this oracle's restatement of the published algorithms: `Attention`,
@@ -125,6 +126,24 @@ def load_reference():
     return mod
 
 
+def load_reference_trainer(R):
+    """trainer.py for its data path (HFDataset.__getitem__, collate_fn): its optimizer / EMA / logging imports are
+    not installed and are not exercised, so they get inert stand-ins"""
+    pkg = _module('e2_tts_pytorch')
+    pkg.e2_tts = R
+    sys.modules['e2_tts_pytorch.e2_tts'] = R
+    _module('torch.utils.tensorboard', SummaryWriter=None)
+    aa = _module('adam_atan2_pytorch')
+    aa.adopt = _module('adam_atan2_pytorch.adopt', Adopt=None)
+    _module('ema_pytorch', EMA=None)
+    _module('loguru', logger=types.SimpleNamespace(info=lambda *a, **k: None, warning=lambda *a, **k: None))
+    spec = importlib.util.spec_from_file_location('ref_trainer', REF.parent / 'trainer.py')
+    mod = importlib.util.module_from_spec(spec)
+    sys.modules['ref_trainer'] = mod
+    spec.loader.exec_module(mod)
+    return mod
+
+
 # ------------------------------------------------------------------------------------------------ cases
 
 def maxrel(a, b):
@@ -177,14 +196,16 @@ def case_transformer(R, results, golden):
 def case_e2tts(R, results, golden):
     kw = dict(dim=256, depth=2, heads=4, dim_head=64, dropout=0., max_seq_len=64)
     # python seeds 22 / 25: random() = 0.958 / 0.377, i.e. the classifier-free-guidance coin keeps / drops the text
-    for name, cdp, py_seed in (('text_on', 0.0, 21), ('cfg_keep', 0.5, 22), ('cfg_drop', 0.5, 25)):
+    for name, cdp, py_seed, extra in (('text_on', 0.0, 21, {}), ('cfg_keep', 0.5, 22, {}), ('cfg_drop', 0.5, 25, {}),
+                                      ('concat_cond', 0.0, 21, dict(concat_cond=True)),
+                                      ('interp_text', 0.0, 21, dict(interpolated_text=True))):
         random.seed(5)
         torch.manual_seed(5)
-        ref = R.E2TTS(transformer=dict(**kw), use_vocos=False, cond_drop_prob=cdp)
+        ref = R.E2TTS(transformer=dict(**kw), use_vocos=False, cond_drop_prob=cdp, **extra)
         randomize(ref, 2)
         random.seed(6)
         torch.manual_seed(6)
-        ora = O.E2TTS(transformer=dict(**kw), cond_drop_prob=cdp)
+        ora = O.E2TTS(transformer=dict(**kw), cond_drop_prob=cdp, **extra)
         ora.load_state_dict(ref.state_dict(), strict=True)
         B, T = 2, 32
         g = torch.Generator().manual_seed(30)
@@ -215,7 +236,7 @@ def case_e2tts(R, results, golden):
         go = {n: p.grad for n, p in ora.named_parameters() if p.grad is not None}
         assert gr.keys() == go.keys(), set(gr) ^ set(go)
         results[f'e2tts/{name}/param_grads'] = max(maxrel(go[n], gr[n]) for n in gr if float(gr[n].abs().max()) > 0)
-        golden[f'e2tts_{name}'] = dict(kw=kw, cond_drop_prob=cdp, weight_seed=2, mel=mel, lens=lens, text=text,
+        golden[f'e2tts_{name}'] = dict(kw=kw, cond_drop_prob=cdp, extra=extra, weight_seed=2, mel=mel, lens=lens, text=text,
                                        noise=noise, loss=out_r.loss.detach(), pred_flow=out_r.pred_flow.detach(),
                                        cond=out_r.cond.detach(),
                                        grad_abs_sums={n: float(v.double().abs().sum()) for n, v in gr.items()})
@@ -338,11 +359,31 @@ def case_helpers(R, results, golden):
     results['helpers'] = 0.0
 
 
+def case_data(R, results, golden):
+    """the dataset side: HFDataset.__getitem__ (one MelSpec per clip) + collate_fn (zero padding), trainer.py:61-131"""
+    import numpy as np
+    T = load_reference_trainer(R)
+    g = torch.Generator().manual_seed(35)
+    lens = [256 * 33 + 17, 7400, 256 * 30, 9000]                 # 0.3 s .. 20 s at 24 kHz is what the dataset keeps
+    rows = [dict(audio=dict(array=torch.randn(n, generator=g).numpy().astype(np.float32), sampling_rate=24_000),
+                 transcript='t' * (i + 1)) for i, n in enumerate(lens)]
+    ds = T.HFDataset(rows)
+    batch = T.collate_fn([ds[i] for i in range(len(rows))])
+    om = O.MelSpec()
+    specs = [om(torch.from_numpy(r['audio']['array'])[None])[0] for r in rows]
+    ml = torch.tensor([sp.shape[-1] for sp in specs])
+    want = torch.stack([torch.nn.functional.pad(sp, (0, int(ml.max()) - sp.shape[-1])) for sp in specs])
+    assert torch.equal(batch['mel_lengths'], ml) and batch['text'] == [r['transcript'] for r in rows]
+    results['data/collated_mel'] = maxrel(want, batch['mel'])
+    golden['data'] = dict(waves=[torch.from_numpy(r['audio']['array']) for r in rows], text=batch['text'],
+                          mel=batch['mel'], mel_lengths=batch['mel_lengths'], text_lengths=batch['text_lengths'])
+
+
 def main():
     assert REF.exists(), 'runs only where /root/reference is mounted'
     R = load_reference()
     results, golden = {}, {}
-    for case in (case_helpers, case_transformer, case_e2tts, case_velocity, case_sample, case_duration):
+    for case in (case_helpers, case_transformer, case_e2tts, case_velocity, case_sample, case_duration, case_data):
         case(R, results, golden)
     worst = max(results.values())
     for k, v in results.items():

@@ -189,10 +189,10 @@ def test_reference_golden_transformer():
 def test_reference_golden_e2tts():
     from oracle.golden_weights import fill_params
     gold = torch.load(REF_GOLD, weights_only=False)
-    for name in ('e2tts_text_on', 'e2tts_cfg_keep', 'e2tts_cfg_drop'):
+    for name in ('e2tts_text_on', 'e2tts_cfg_keep', 'e2tts_cfg_drop', 'e2tts_concat_cond', 'e2tts_interp_text'):
         c = gold[name]
         random.seed(0)
-        m = fill_params(O.E2TTS(transformer=dict(**c['kw']), cond_drop_prob=c['cond_drop_prob']), c['weight_seed'])
+        m = fill_params(O.E2TTS(transformer=dict(**c['kw']), cond_drop_prob=c['cond_drop_prob'], **c['extra']), c['weight_seed'])
         out = m(c['mel'], text=c['text'], lens=c['lens'], _noise=c['noise'])
         out.loss.backward()
         assert abs(out.loss.item() - c['loss'].item()) <= 1e-5 * abs(c['loss'].item()), name
