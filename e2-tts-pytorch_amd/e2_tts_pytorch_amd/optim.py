@@ -79,8 +79,71 @@ class FusedAdopt:
         self.params = [p for p in model.parameters() if p.requires_grad]
         self.lr, self.betas, self.eps, self.weight_decay, self.max_grad_norm = lr, betas, eps, weight_decay, max_grad_norm
         self.step_count = 0
-        self._state = {}           # (data_ptr of first param, n) -> (m, v)
+        self._state = {}           # data_ptr of a parameter STORAGE -> (m, v) flat fp32 buffers mirroring that storage
+        self._loaded = {}          # parameter index -> (m, v) from load_state_dict, not yet copied into a run
         self._backbones = [m for m in model.modules() if isinstance(m, Transformer)]
+
+    # checkpoint format (trainer.py:202-228 stores optimizer.state_dict()) ------------------------------------------
+    # torch.optim layout with adam_atan2_pytorch.adopt.Adopt's per-parameter keys ('steps', 'm', 'v'; SURVEY.md Appendix
+    # A.10), parameters numbered in model.parameters() order as `Adopt(model.parameters(), ...)` numbers them.
+
+    def _mv(self, t, create=True):
+        """(m, v) slices for the contiguous fp32 range `t` (a parameter or a run of adjacent parameters).  The moments
+        mirror the parameter STORAGE element for element (the backbone's flat buffer = one storage), so the same state is
+        found however the gradients happen to be grouped into runs on a given step"""
+        st = t.untyped_storage()
+        key = st.data_ptr()
+        if key not in self._state:
+            if not create:
+                return None
+            n = st.nbytes() // 4
+            self._state[key] = (torch.zeros(n, dtype=torch.float32, device=t.device), torch.zeros(n, dtype=torch.float32, device=t.device))
+        m, v = self._state[key]
+        o = (t.data_ptr() - key) // 4
+        return m[o:o + t.numel()], v[o:o + t.numel()]
+
+    def _views(self):
+        """{parameter index: (m, v) views shaped like the parameter} for every parameter that has state"""
+        out = {}
+        for i, p in enumerate(self.params):
+            mv = self._mv(p, create=False)
+            if mv is not None:
+                out[i] = (mv[0].view_as(p), mv[1].view_as(p))
+        return out
+
+    def state_dict(self):
+        state = {i: dict(steps=self.step_count, m=m.detach().clone(), v=v.detach().clone()) for i, (m, v) in sorted(self._views().items())}
+        for i, (m, v) in self._loaded.items():              # loaded but not yet stepped
+            state.setdefault(i, dict(steps=self.step_count, m=m.clone(), v=v.clone()))
+        group = dict(lr=self.lr, betas=tuple(self.betas), eps=self.eps, weight_decay=self.weight_decay, decoupled_wd=True,
+                     params=list(range(len(self.params))))
+        return dict(state=dict(sorted(state.items())), param_groups=[group])
+
+    def load_state_dict(self, sd):
+        g = sd['param_groups'][0]
+        assert len(g['params']) == len(self.params), 'parameter count differs from the checkpoint'
+        self.lr, self.betas, self.eps = g['lr'], tuple(g['betas']), g['eps']
+        self.weight_decay = g.get('weight_decay', 0.)
+        steps = [int(st['steps']) for st in sd['state'].values()]
+        self.step_count = max(steps) if steps else 0
+        self._loaded = {}
+        for i, st in sd['state'].items():
+            p = self.params[int(i)]
+            self._loaded[int(i)] = (st['m'].to(device=p.device, dtype=torch.float32).reshape(p.shape),
+                                    st['v'].to(device=p.device, dtype=torch.float32).reshape(p.shape))
+        self._install_loaded()
+
+    @torch.no_grad()
+    def _install_loaded(self):
+        """copy loaded per-parameter moments into the flat buffers of the runs that exist (runs are only known once
+        gradients have been seen, so this is called again from step() after new runs were created)"""
+        if not self._loaded:
+            return
+        for i, (m, v) in self._views().items():
+            if i in self._loaded:
+                lm, lv = self._loaded.pop(i)
+                m.copy_(lm)
+                v.copy_(lv)
 
     def zero_grad(self, set_to_none=True):
         """optimizer.zero_grad (trainer.py:277).  Backbones in persistent-gradient mode are skipped: their next backward
@@ -128,11 +191,11 @@ class FusedAdopt:
             for pf, gf in runs:
                 ops.sumsq(gf, gs)
         b1, b2 = self.betas
-        for pf, gf in runs:
-            key = (pf.data_ptr(), pf.numel())
-            if key not in self._state:
-                self._state[key] = (torch.zeros_like(pf), torch.zeros_like(pf))
-            m, v = self._state[key]
+        nstate = len(self._state)
+        mvs = [self._mv(pf) for pf, _ in runs]
+        if len(self._state) != nstate:
+            self._install_loaded()
+        for (pf, gf), (m, v) in zip(runs, mvs):
             ops.adopt_step(pf, gf, m, v, self.step_count, lr=self.lr, beta1=b1, beta2=b2, eps=self.eps,
                            weight_decay=self.weight_decay, max_grad_norm=self.max_grad_norm, gsumsq=gs)
         for p, _ in pairs:                                     # the kernels wrote behind autograd's back
@@ -155,6 +218,20 @@ class FusedEMA:
                 m._flat = None
                 m.enable_persistent_grads(False)      # (the copy never sees a backward pass)
                 m._sync(next(m.parameters()).device)
+
+    # checkpoint format: ema_pytorch.EMA is an nn.Module holding `ema_model` plus the buffers `initted` and `step`
+    # (include_online_model=False keeps the online model out of it, trainer.py:170-174)
+    def state_dict(self):
+        sd = {f'ema_model.{k}': v for k, v in self.ema_model.state_dict().items()}
+        sd['initted'] = torch.tensor(self.initted)
+        sd['step'] = torch.tensor(self.step)
+        return sd
+
+    def load_state_dict(self, sd):
+        inner = {k[len('ema_model.'):]: v for k, v in sd.items() if k.startswith('ema_model.')}
+        self.ema_model.load_state_dict(inner, strict=True)
+        self.initted = bool(sd['initted'])
+        self.step = int(sd['step'])
 
     def current_decay(self):
         epoch = max(self.step - self.update_after_step - 1, 0)
@@ -190,3 +267,23 @@ class FusedEMA:
             ops.ema_update(ef, pf, decay)
         for e, _ in pairs:
             torch.autograd.graph.increment_version(e)
+
+
+# ------------------------------------------------------------------------------------------------ checkpoints
+
+def save_checkpoint(path, model, optimizer, ema, scheduler=None, step=0):
+    """the reference trainer's single-file checkpoint (trainer.py:202-213): same keys, same nesting"""
+    torch.save(dict(model_state_dict=model.state_dict(), optimizer_state_dict=optimizer.state_dict(),
+                    ema_model_state_dict=ema.state_dict(),
+                    scheduler_state_dict=scheduler.state_dict() if scheduler is not None else None, step=step), path)
+
+
+def load_checkpoint(path, model, optimizer, ema, scheduler=None, map_location=None):
+    """trainer.py:215-228; returns the step to resume from"""
+    ck = torch.load(path, map_location=map_location, weights_only=False)
+    model.load_state_dict(ck['model_state_dict'])
+    optimizer.load_state_dict(ck['optimizer_state_dict'])
+    ema.load_state_dict(ck['ema_model_state_dict'])
+    if scheduler is not None and ck.get('scheduler_state_dict') is not None:
+        scheduler.load_state_dict(ck['scheduler_state_dict'])
+    return ck['step']

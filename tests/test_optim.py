@@ -129,3 +129,73 @@ def test_training_loop_reduces_loss(dev):
         losses.append(out.loss.item())
     assert all(l == l for l in losses), losses                 # finite
     assert losses[-1] < 0.9 * losses[1], losses                # (step 0 of ADOPT only initialises v)
+
+
+def test_checkpoint_round_trip_and_format(dev, tmp_path):
+    """the reference trainer's checkpoint (trainer.py:202-228): save after three steps, load into fresh objects, the
+    next step is the same; the optimizer entry is a torch.optim-style dict with per-parameter 'steps' / 'm' / 'v'
+    (adam_atan2_pytorch's keys) that the oracle optimizer can continue from"""
+    from e2_tts_pytorch_amd import E2TTS
+    from e2_tts_pytorch_amd.optim import FusedAdopt, FusedEMA, save_checkpoint, load_checkpoint
+    import random
+
+    def make():
+        random.seed(0)
+        torch.manual_seed(0)
+        model = E2TTS(transformer=dict(dim=256, depth=2, heads=4, dropout=0.), use_vocos=False, cond_drop_prob=0.).to(dev)
+        return model, FusedAdopt(model, lr=1e-3, max_grad_norm=1.0), FusedEMA(model, update_after_step=0, update_every=1)
+
+    def set_grads(model, seed):                # fixed gradients: the optimizer is then deterministic
+        g = torch.Generator().manual_seed(seed)
+        for p in model.parameters():
+            p.grad = (torch.randn(p.shape, generator=g) * 0.01).to(dev)
+
+    model, opt, ema = make()
+    mel = torch.randn(2, 24, 100, device=dev)
+    model(mel, text=['ab', 'c']).loss.backward()          # one real backward first, so the backbone's flat-gradient run exists
+    opt.step()
+    ema.update()
+    for s in (1, 2):
+        set_grads(model, s)
+        opt.step()
+        ema.update()
+    path = tmp_path / 'ck.pt'
+    save_checkpoint(path, model, opt, ema, step=3)
+    ck = torch.load(path, weights_only=False)
+    assert set(ck) == {'model_state_dict', 'optimizer_state_dict', 'ema_model_state_dict', 'scheduler_state_dict', 'step'}
+    osd = ck['optimizer_state_dict']
+    n = len(list(model.parameters()))
+    assert osd['param_groups'][0]['params'] == list(range(n)) and len(osd['state']) == n
+    assert all(set(st) == {'steps', 'm', 'v'} and st['steps'] == 3 for st in osd['state'].values())
+    assert all(st['m'].shape == p.shape for st, p in zip(osd['state'].values(), model.parameters()))
+    assert {'initted', 'step'} <= set(ck['ema_model_state_dict']) and all(
+        k.startswith('ema_model.') for k in ck['ema_model_state_dict'] if k not in ('initted', 'step'))
+    # (a) the oracle optimizer continues from the exported state exactly as the fused one does
+    ref_params = [p.detach().cpu().clone().requires_grad_(True) for p in model.parameters()]
+    ref = O.Adopt(ref_params, lr=1e-3)
+    ref.step_count = 3
+    for i, st in osd['state'].items():
+        ref.m[i].copy_(st['m'].cpu())
+        ref.v[i].copy_(st['v'].cpu())
+    set_grads(model, 7)
+    for rp, p in zip(ref_params, model.parameters()):
+        rp.grad = p.grad.detach().cpu().clone()
+    O.clip_grad_norm_([rp.grad for rp in ref_params], 1.0)
+    ref.step()
+    opt.step()
+    ema.update()
+    for rp, p in zip(ref_params, model.parameters()):
+        assert torch.allclose(p.detach().cpu(), rp.detach(), rtol=1e-4, atol=1e-6)
+    # (b) fresh objects + load_checkpoint take the same step
+    model2, opt2, ema2 = make()
+    assert load_checkpoint(path, model2, opt2, ema2, map_location=dev) == 3
+    assert ema2.step == 3 and ema2.initted and opt2.step_count == 3
+    set_grads(model2, 7)
+    opt2.step()
+    ema2.update()
+    for a, b in zip(model.parameters(), model2.parameters()):
+        assert torch.allclose(a.detach().cpu(), b.detach().cpu(), rtol=1e-6, atol=1e-8)
+    for a, b in zip(ema.ema_model.parameters(), ema2.ema_model.parameters()):
+        assert torch.allclose(a.detach().cpu(), b.detach().cpu(), rtol=1e-6, atol=1e-8)
+    sd2 = opt2.state_dict()
+    assert all(torch.allclose(sd2['state'][i]['v'].cpu(), opt.state_dict()['state'][i]['v'].cpu(), rtol=1e-6, atol=1e-12) for i in range(n))
