@@ -157,6 +157,45 @@ def test_gemm_nt_256_tile(emu, monkeypatch, M, N, K1, K2, kw, flags, late):
         ops.gemm_flags = old
 
 
+@pytest.mark.parametrize('late', [0, 1])
+def test_gemm_nt_256_random_shapes(emu, monkeypatch, late):
+    """seeded sweep of the 256 x 256 kernel over ragged M / N, 1..9 K tiles, dual-K splits at every tile boundary, every
+    epilogue operand, with and without the remainder split (8-slot test hook); both LDS-DMA landing extremes"""
+    import random as pyrandom
+    from e2_tts_pytorch_amd import ops
+    monkeypatch.setenv('E2K_EMU_GLDS_LATE', str(late))
+    rng = pyrandom.Random(4321 + late)
+    old = ops.gemm_flags
+    try:
+        for case in range(10):
+            M = rng.choice([1, 100, 256, 257, 511, 700, 1100, 2304])
+            N = rng.choice([8, 100, 256, 264, 500, 520])
+            nk = rng.randint(1, 9)
+            nk2 = rng.choice([0, 0, rng.randint(1, 4)])
+            K1, K2 = 64 * nk, 64 * nk2
+            torch.manual_seed(case)
+            a = torch.randn(M, K1).to(bf16)
+            a2 = torch.randn(M, K2).to(bf16) if K2 else None
+            b = torch.randn(N, K1 + K2).to(bf16)
+            bias = torch.randn(N) if rng.random() < 0.5 else None
+            rs = torch.randn(M, N).to(bf16) if rng.random() < 0.4 else None
+            rm = (torch.rand(M) > 0.3) if rng.random() < 0.3 else None
+            f32out = rng.random() < 0.3
+            ops.gemm_flags = 128 | rng.choice([0, 32])
+            out = ops.gemm_nt(a, b, a2=a2, bias=bias, rowmask=rm, resid=rs, out_dtype=torch.float32 if f32out else bf16)
+            A = torch.cat([a, a2], 1).float() if K2 else a.float()
+            ref = A @ b.float().T
+            if bias is not None:
+                ref = ref + bias
+            if rm is not None:
+                ref = ref * rm[:, None].float()
+            if rs is not None:
+                ref = ref + rs.float()
+            assert rel(out, ref) < (1e-5 if f32out else 6e-3), (case, M, N, K1, K2, ops.gemm_flags)
+    finally:
+        ops.gemm_flags = old
+
+
 def test_gemm_random_shapes(dev):
     """seeded sweep over ragged shapes / operand combinations of both GEMMs (edge tiles, odd K panels, every epilogue
     operand, the remainder split with the 8-slot test hook, column sums from an offset)"""
