@@ -309,6 +309,32 @@ def case_sample(R, results, golden):
                             steps=4, cfg_strength=1.5, y0=y0, out=out_r)
 
 
+def case_sample_front_end(R, results, golden):
+    """the branches of sample() around the solver: raw-wave prompt (MelSpec inside), duration from the duration
+    predictor, clamping to max_duration, autoguidance with a second model as the CFG null branch (e2_tts.py:1351-1465)"""
+    kw = dict(dim=256, depth=2, heads=4, dim_head=64, dropout=0., max_seq_len=64)
+    models = []
+    for cls in (R.E2TTS, O.E2TTS):
+        extra = dict(use_vocos=False) if cls is R.E2TTS else {}
+        random.seed(12)
+        torch.manual_seed(12)
+        m = randomize(cls(transformer=dict(**kw), duration_predictor=dict(transformer=dict(**kw)), cond_drop_prob=0.2, **extra), 7).eval()
+        null = randomize(cls(transformer=dict(**kw), cond_drop_prob=0.2, **extra), 8).eval()
+        models.append((m, null))
+    (ref, ref_null), (ora, ora_null) = models
+    g = torch.Generator().manual_seed(36)
+    wave = torch.randn(2, 256 * 10, generator=g)             # 11 prompt frames
+    kwargs = dict(text=['front', 'end of sample'], lens=torch.tensor([11, 8]), steps=3, cfg_strength=2., max_duration=40)
+    torch.manual_seed(66)
+    out_r = ref.sample(wave, cfg_null_model=ref_null, **kwargs)
+    torch.manual_seed(66)
+    out_o = ora.sample(wave, cfg_null_model=ora_null, **kwargs)
+    assert out_r.shape == out_o.shape and out_r.shape[1] > 12, out_r.shape
+    results['sample_front_end/out'] = maxrel(out_o, out_r)
+    golden['sample_front_end'] = dict(kw=kw, weight_seed=7, null_weight_seed=8, wave=wave, text=kwargs['text'], lens=kwargs['lens'],
+                                      steps=3, cfg_strength=2., max_duration=40, torch_seed=66, out=out_r)
+
+
 def case_duration(R, results, golden):
     kw = dict(dim=256, depth=2, heads=4, dim_head=64, dropout=0., max_seq_len=64)
     random.seed(8)
@@ -383,7 +409,7 @@ def main():
     assert REF.exists(), 'runs only where /root/reference is mounted'
     R = load_reference()
     results, golden = {}, {}
-    for case in (case_helpers, case_transformer, case_e2tts, case_velocity, case_sample, case_duration, case_data):
+    for case in (case_helpers, case_transformer, case_e2tts, case_velocity, case_sample, case_sample_front_end, case_duration, case_data):
         case(R, results, golden)
     worst = max(results.values())
     for k, v in results.items():

@@ -376,3 +376,21 @@ def test_reference_golden_data_path(dev):
     assert torch.equal(batch['text_lengths'], c['text_lengths'])
     assert batch['mel'].shape == c['mel'].shape
     assert (batch['mel'].cpu() - c['mel']).abs().max().item() < 2e-3           # log-mel, fp32 FFT vs torch.stft
+
+
+def test_reference_golden_sample_front_end(emu):
+    """sample() front end on the HIP path vs the reference's output: raw-wave prompt (MelSpec kernel inside), duration from
+    the duration predictor, max_duration clamp, autoguidance null model.  Host model only: the initial noise is drawn
+    inside sample() from the CPU generator (a GPU run draws different noise), and the predicted durations are truncated
+    to integers, so the comparison needs the reference's own draw"""
+    from e2_tts_pytorch_amd import E2TTS
+    from oracle.golden_weights import fill_params
+    c = _ref_gold()['sample_front_end']
+    random.seed(0)
+    m = fill_params(E2TTS(transformer=dict(**c['kw']), duration_predictor=dict(transformer=dict(**c['kw'])), use_vocos=False,
+                          cond_drop_prob=0.2), c['weight_seed']).eval()
+    null = fill_params(E2TTS(transformer=dict(**c['kw']), use_vocos=False, cond_drop_prob=0.2), c['null_weight_seed']).eval()
+    torch.manual_seed(c['torch_seed'])
+    out = m.sample(c['wave'], text=c['text'], lens=c['lens'], steps=c['steps'], cfg_strength=c['cfg_strength'],
+                   max_duration=c['max_duration'], cfg_null_model=null)
+    assert out.shape == c['out'].shape and rel2(out, c['out']) < 2e-2, rel2(out, c['out'])

@@ -223,6 +223,16 @@ def test_reference_golden_sample_and_duration():
     out = m.sample(c['cond'], text=c['text'], lens=c['lens'], duration=c['duration'], steps=c['steps'],
                    cfg_strength=c['cfg_strength'], _y0=c['y0'])
     assert _maxrel(out, c['out']) < 1e-5
+    # sample() front end: raw-wave prompt, duration from the duration predictor, max_duration clamp, autoguidance null model
+    c = gold['sample_front_end']
+    random.seed(0)
+    m = fill_params(O.E2TTS(transformer=dict(**c['kw']), duration_predictor=dict(transformer=dict(**c['kw'])), cond_drop_prob=0.2),
+                    c['weight_seed']).eval()
+    null = fill_params(O.E2TTS(transformer=dict(**c['kw']), cond_drop_prob=0.2), c['null_weight_seed']).eval()
+    torch.manual_seed(c['torch_seed'])
+    out = m.sample(c['wave'], text=c['text'], lens=c['lens'], steps=c['steps'], cfg_strength=c['cfg_strength'],
+                   max_duration=c['max_duration'], cfg_null_model=null)
+    assert out.shape == c['out'].shape and _maxrel(out, c['out']) < 1e-5
     c = gold['duration']
     m = fill_params(O.DurationPredictor(transformer=dict(**c['kw'])), c['weight_seed'])
     loss = m(c['mel'], text=c['text'], lens=c['lens'], _rand_frac_index=c['rand_frac_index'])
