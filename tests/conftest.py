@@ -12,6 +12,15 @@ for p in (ROOT / 'e2-tts-pytorch_amd', ROOT, ROOT / 'tests'):
 
 def pytest_configure(config):
     config.addinivalue_line('markers', 'gpu: needs a real MI355X (run with -m gpu on the GPU box)')
+    config.addinivalue_line('markers', 'late: run after everything else (tests whose [gpu] variant has not been on hardware yet, '
+                                       'so that with -x a surprise there cannot hide the established kernel parity results)')
+
+
+def pytest_collection_modifyitems(config, items):
+    late = [it for it in items if it.get_closest_marker('late')]
+    if late:
+        rest = [it for it in items if not it.get_closest_marker('late')]
+        items[:] = rest + late
 
 
 @pytest.fixture(scope='session')

@@ -34,6 +34,7 @@ def test_melspec(dev):
     assert (got.cpu() - ref).abs().max().item() < 2e-3      # log-mel, fp32 FFT vs torch.stft
 
 
+@pytest.mark.late
 def test_melspec_ragged_batch(dev):
     """one launch over a zero-padded ragged batch == the reference's data path: MelSpec of every clip on its own
     (HFDataset.__getitem__, trainer.py:101-131) followed by collate_fn's zero padding (trainer.py:61-82)"""
@@ -324,6 +325,7 @@ def _ref_gold():
     return torch.load(Path(__file__).resolve().parent / 'golden' / 'reference_pinned.pt', weights_only=False)
 
 
+@pytest.mark.late
 @pytest.mark.parametrize('case', ['e2tts_text_on', 'e2tts_cfg_drop', 'e2tts_concat_cond', 'e2tts_interp_text'])
 def test_reference_golden_forward(dev, case):
     from e2_tts_pytorch_amd import E2TTS
@@ -348,6 +350,7 @@ def test_reference_golden_forward(dev, case):
         assert abs(got - c['grad_abs_sums'][n]) < 5e-2 * c['grad_abs_sums'][n], (n, got, c['grad_abs_sums'][n])
 
 
+@pytest.mark.late
 def test_reference_golden_sample_duration(dev):
     from e2_tts_pytorch_amd import E2TTS, DurationPredictor
     from oracle.golden_weights import fill_params
@@ -364,6 +367,7 @@ def test_reference_golden_sample_duration(dev):
     assert abs(loss.item() - c['loss'].item()) / abs(c['loss'].item()) < 2e-2
 
 
+@pytest.mark.late
 def test_reference_golden_data_path(dev):
     """ragged MelSpec kernel + collate_wave_fn / mel_batch vs what the reference's HFDataset.__getitem__ + collate_fn
     produced for the same clips (trainer.py:61-131, executed by oracle/pin_against_reference.py)"""

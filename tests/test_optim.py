@@ -49,6 +49,7 @@ def test_ema_kernel(dev):
     assert torch.allclose(ek.cpu(), e.lerp(p, 0.01), rtol=1e-6, atol=1e-7)
 
 
+@pytest.mark.late
 @pytest.mark.parametrize('persist', [False, True])
 def test_fused_adopt_on_model(dev, persist):
     """FusedAdopt / FusedEMA on a small E2TTS: runs of adjacent parameters are merged, results match the oracle optimizer
@@ -131,6 +132,7 @@ def test_training_loop_reduces_loss(dev):
     assert losses[-1] < 0.9 * losses[1], losses                # (step 0 of ADOPT only initialises v)
 
 
+@pytest.mark.late
 def test_checkpoint_round_trip_and_format(dev, tmp_path):
     """the reference trainer's checkpoint (trainer.py:202-228): save after three steps, load into fresh objects, the
     next step is the same; the optimizer entry is a torch.optim-style dict with per-parameter 'steps' / 'm' / 'v'
