@@ -289,7 +289,18 @@ static inline float atomicAdd(float* p, float v) {
         if (__atomic_compare_exchange_n(up, &old, nu, false, __ATOMIC_RELAXED, __ATOMIC_RELAXED)) return __uint_as_float(old);
     }
 }
-static inline double atomicAdd(double* p, double v) { double old = *p; *p = old + v; return old; }     // (the model runs one fiber at a time)
+static inline double atomicAdd(double* p, double v) {       // (blocks run on several OS threads: a real CAS loop)
+    unsigned long long* up = (unsigned long long*)p;
+    unsigned long long old = __atomic_load_n(up, __ATOMIC_RELAXED);
+    for (;;) {
+        double od;
+        memcpy(&od, &old, 8);
+        double nd = od + v;
+        unsigned long long nu;
+        memcpy(&nu, &nd, 8);
+        if (__atomic_compare_exchange_n(up, &old, nu, false, __ATOMIC_RELAXED, __ATOMIC_RELAXED)) return od;
+    }
+}
 static inline int atomicAdd(int* p, int v) { return __atomic_fetch_add(p, v, __ATOMIC_RELAXED); }
 static inline unsigned atomicAdd(unsigned* p, unsigned v) { return __atomic_fetch_add(p, v, __ATOMIC_RELAXED); }
 
