@@ -77,7 +77,8 @@ def cpu_baseline(dim, depth, heads, T, sample_depth=12, threads=None):
     return {'value': T / dt * sd / depth, 'unit': 'mel-frames/s', 'cores': threads, 'kind': 'port',
             'sample': f'CPU oracle (fp32 torch eager, {threads} threads): dim={dim} heads={heads} T={T} B=1, '
                       f'{sd} of {depth} layers, one fwd+bwd = {dt:.1f} s measured; value = T/dt scaled by {sd}/{depth} '
-                      f'to the full-depth step'}
+                      f'to the full-depth step.  The port reproduces the reference source bit for bit where that can be '
+                      f'executed (oracle/pin_against_reference.py); /root/reference itself cannot travel to the GPU box'}
 
 
 def main():
