@@ -154,8 +154,13 @@ from oracle.golden_weights import fill_params as randomize  # noqa: E402  (same 
 
 
 def case_transformer(R, results, golden):
-    kw = dict(dim=256, depth=4, heads=2, dim_head=64, dropout=0., max_seq_len=64)
-    for name, cond_on_time, with_text, with_mask in (('full', True, True, True), ('bare', False, False, False)):
+    kw0 = dict(dim=256, depth=4, heads=2, dim_head=64, dropout=0., max_seq_len=64)
+    # non-default constructor branches: text stream only in the first 2 of 4 layers, 128-wide text stream with its own
+    # head count, 15-tap convolution, 8 registers, no absolute position embedding
+    kw1 = dict(dim=256, depth=4, heads=4, dim_head=64, dropout=0., max_seq_len=64, text_depth=2, dim_text=128, text_heads=2,
+               kernel_size=15, num_registers=8, abs_pos_emb=False, ff_mult=2, text_ff_mult=4)
+    for name, cond_on_time, with_text, with_mask, kw in (('full', True, True, True, kw0), ('bare', False, False, False, kw0),
+                                                         ('variant', True, True, True, kw1)):
         random.seed(3)
         torch.manual_seed(3)
         ref = R.Transformer(**kw, cond_on_time=cond_on_time)

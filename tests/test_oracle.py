@@ -171,7 +171,7 @@ def _maxrel(a, b):
 def test_reference_golden_transformer():
     from oracle.golden_weights import fill_params
     gold = torch.load(REF_GOLD, weights_only=False)
-    for name in ('transformer_full', 'transformer_bare'):
+    for name in ('transformer_full', 'transformer_bare', 'transformer_variant'):
         c = gold[name]
         random.seed(0)
         m = fill_params(O.Transformer(**c['kw'], cond_on_time=c['cond_on_time']), c['weight_seed'])

@@ -1,0 +1,245 @@
+"""Checks every kernel IN SITU: runs a backbone forward + backward on the host model (tests/emu) or a GPU and compares each
+kernel call's outputs with an fp32 torch reference computed from that call's ACTUAL inputs (hooks on `ops.*`).
+
+Why: a whole-backbone comparison against the oracle mixes two things, kernel correctness and the conditioning of the
+model.  With every parameter drawn at random (the reference-golden `transformer_variant` case) the backbone's early-layer
+weight gradients differ from the fp32 oracle's by 20-30 % although the forward output agrees to 0.5 %.  This tool shows
+that each kernel reproduces its fp32 reference to 0.2-0.4 % on the inputs it really gets, i.e. the difference is
+rounding noise amplified by an ill-conditioned backward pass, not a missing term; `--emulate` shows the same effect in
+the fp32 oracle when its intermediate tensors are rounded to bf16.
+
+    python tools/insitu_check.py [--lam 1.0] [--gpu] [--emulate]
+      --lam: weights = (1 - lam) * reference-like (tests/test_backbone.randomize) + lam * all-random (golden_weights)
+"""
+import argparse
+import os
+import random
+import sys
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+for p in ('e2-tts-pytorch_amd', '', 'tests'):
+    sys.path.insert(0, os.path.join(ROOT, p))
+
+import torch  # noqa: E402
+import torch.nn.functional as F  # noqa: E402
+
+from e2_tts_pytorch_amd import Transformer, _lib, ops  # noqa: E402
+from oracle import e2tts_oracle as O  # noqa: E402
+from oracle.golden_weights import fill_params  # noqa: E402
+
+
+def rel(a, b):
+    return ((a.float().cpu() - b.float().cpu()).norm() / b.float().cpu().norm().clamp_min(1e-30)).item()
+
+
+def build_models(lam):
+    from test_backbone import randomize
+    c = torch.load(os.path.join(ROOT, 'tests', 'golden', 'reference_pinned.pt'), weights_only=False)['transformer_variant']
+    kw = dict(c['kw'])
+    random.seed(0)
+    torch.manual_seed(0)
+    tame_m = O.Transformer(**kw, cond_on_time=True)
+    randomize(tame_m)
+    wild_m = fill_params(O.Transformer(**kw, cond_on_time=True), 1)
+    tame, wild = dict(tame_m.named_parameters()), dict(wild_m.named_parameters())
+    ref = O.Transformer(**kw, cond_on_time=True)
+    with torch.no_grad():
+        for n, p in ref.named_parameters():
+            p.copy_(tame[n] * (1 - lam) + wild[n] * lam)
+        for n, b in ref.named_buffers():
+            if n.endswith('.weights'):
+                b.copy_(dict(wild_m.named_buffers())[n])
+    mod = Transformer(**kw, cond_on_time=True)
+    mod.load_state_dict(ref.state_dict(), strict=True)
+    return c, kw, ref, mod
+
+
+class RoundBoth(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, x):
+        return x.bfloat16().float()
+
+    @staticmethod
+    def backward(ctx, g):
+        return g.bfloat16().float()
+
+
+def emulate(c, ref):
+    """fp32 oracle with bf16 rounding (values and gradients) after Linear / norm / GLU / conv / gate / softmax / HC"""
+    import torch.nn as nn
+    mods = [O.RMSNorm, O.AdaptiveRMSNorm, O._GLU, O.DepthwiseConv, O.AdaLNZero, O._HCNorm]
+    saved = {m: m.forward for m in mods}
+    hc0, lin0, sm0 = O.HyperConnections.forward, nn.Linear.forward, torch.Tensor.softmax
+
+    def hc(self, residuals):
+        b, add = hc0(self, RoundBoth.apply(residuals))
+        return RoundBoth.apply(b), (lambda y: RoundBoth.apply(add(y)))
+
+    def run():
+        x = c['x'].clone().requires_grad_(True)
+        t = c['text'].clone().requires_grad_(True)
+        for p in ref.parameters():
+            p.grad = None
+        out = ref(x, times=c['times'], mask=c['mask'], text_embed=t)
+        (out * c['R']).sum().backward()
+        return out.detach(), x.grad, {n: p.grad.clone() for n, p in ref.named_parameters() if p.grad is not None}
+
+    o0, d0, g0 = run()
+    try:
+        O.HyperConnections.forward = hc
+        nn.Linear.forward = lambda self, x: RoundBoth.apply(lin0(self, RoundBoth.apply(x)))
+        torch.Tensor.softmax = lambda self, *a, **k: RoundBoth.apply(sm0(self, *a, **k))
+        for m in mods:
+            m.forward = (lambda f: lambda self, *a, **k: RoundBoth.apply(f(self, *a, **k)))(saved[m])
+        o1, d1, g1 = run()
+    finally:
+        O.HyperConnections.forward, nn.Linear.forward, torch.Tensor.softmax = hc0, lin0, sm0
+        for m in mods:
+            m.forward = saved[m]
+    print('fp32 oracle with bf16-rounded intermediates vs plain fp32 oracle: out %.4f  dx %.3f' % (rel(o1, o0), rel(d1, d0)))
+    for n in g0:
+        if g0[n].ndim >= 2 and ('to_q' in n or 'ff.2.weight' in n or n.endswith('.0.0.weight')):
+            print('   %-40s rel %.3f  sum|g| ratio %.3f' % (n, rel(g1[n], g0[n]), float(g1[n].abs().sum() / g0[n].abs().sum())))
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument('--lam', type=float, default=1.0)
+    ap.add_argument('--gpu', action='store_true')
+    ap.add_argument('--emulate', action='store_true')
+    a = ap.parse_args()
+    c, kw, ref, mod = build_models(a.lam)
+    if a.emulate:
+        emulate(c, ref)
+        return
+    if a.gpu:
+        dev = 'cuda'
+        _lib._install_for_tests(None, host_pointers=False)
+    else:
+        from emu.build_emu import build
+        dev = 'cpu'
+        _lib._install_for_tests(build(), host_pointers=True)
+    mod = mod.to(dev)
+    worst = {}
+
+    def note(k, e, extra=''):
+        if e > worst.get(k, (-1, ''))[0]:
+            worst[k] = (e, extra)
+
+    o_nt, o_tn, o_ge, o_gb, o_rb, o_hb, o_ab = ops.gemm_nt, ops.gemm_tn, ops.geglu_fwd, ops.geglu_bwd, ops.rmsnorm_bwd, ops.hc_bwd, ops.attn_bwd
+
+    def nt(x, b, *, a2=None, out=None, out_dtype=torch.bfloat16, accumulate=False, bias=None, colscale=None, rows_per_batch=0,
+           rowmask=None, resid=None):
+        r = o_nt(x, b, a2=a2, out=out, out_dtype=out_dtype, accumulate=accumulate, bias=bias, colscale=colscale,
+                 rows_per_batch=rows_per_batch, rowmask=rowmask, resid=resid)
+        if not accumulate:
+            A = torch.cat([x.float(), a2.float()], 1) if a2 is not None else x.float()
+            w = A @ b.float().T
+            if bias is not None:
+                w = w + bias
+            if colscale is not None:
+                w = w * colscale[torch.arange(w.shape[0], device=w.device) // rows_per_batch]
+            if rowmask is not None:
+                w = w * rowmask[:, None].float()
+            if resid is not None:
+                w = w + resid.float()
+            note('gemm_nt', rel(r, w), str((tuple(x.shape), tuple(b.shape))))
+        return r
+
+    def tn(x, b, out, splits=0, use_tr=True, colsum=None, colsum_from=0):
+        before = out.clone()
+        r = o_tn(x, b, out, splits=splits, use_tr=use_tr, colsum=colsum, colsum_from=colsum_from)
+        note('gemm_tn', rel(out - before, x.float().T @ b.float()), str((tuple(x.shape), tuple(b.shape))))
+        return r
+
+    def ge(H, *aa, **k):
+        r = o_ge(H, *aa, **k)
+        x, g = H.float().chunk(2, -1)
+        note('geglu_fwd', rel(r, x * F.gelu(g)))
+        return r
+
+    def gb(dout, H, *aa, **k):
+        r = o_gb(dout, H, *aa, **k)
+        with torch.enable_grad():
+            Hf = H.float().requires_grad_(True)
+            x, g = Hf.chunk(2, -1)
+            (x * F.gelu(g)).backward(dout.float())
+        note('geglu_bwd', rel(r, Hf.grad))
+        return r
+
+    def rb(dy, x, rn, gamma, gamma_off, rows_per_batch, dgamma):
+        before = dgamma.clone()
+        dx = o_rb(dy, x, rn, gamma, gamma_off, rows_per_batch, dgamma)
+        M, D = x.shape
+        with torch.enable_grad():
+            xf = x.float().requires_grad_(True)
+            gm = gamma.detach().float().clone().requires_grad_(True)
+            y = F.normalize(xf, dim=-1) * D ** 0.5 * (gm[torch.arange(M, device=x.device) // rows_per_batch] + gamma_off)
+            y.backward(dy.float())
+        note('rmsnorm_bwd dx', rel(dx, xf.grad))
+        note('rmsnorm_bwd dgamma', rel(dgamma - before, gm.grad))
+        return dx
+
+    names = ['static_beta', 'static_alpha', 'dynamic_alpha_fn', 'dynamic_alpha_scale', 'dynamic_beta_fn', 'dynamic_beta_scale', 'norm.gamma']
+
+    def hb(G, *, xin=None, yprev=None, coef_prev=None, dbin=None, ycur=None, coef=None, params=None, grads=None):
+        before = [g.clone() for g in grads] if grads is not None else None
+        dR, dyp = o_hb(G, xin=xin, yprev=yprev, coef_prev=coef_prev, dbin=dbin, ycur=ycur, coef=coef, params=params, grads=grads)
+        if coef is None:
+            return dR, dyp
+        D = G.shape[-1]
+        with torch.enable_grad():
+            Xin = xin.float().clone().requires_grad_(True)
+            X, yp = Xin, None
+            if yprev is not None:
+                yp = yprev.float().clone().requires_grad_(True)
+                X = Xin + yp[:, None, :] * coef_prev[:, 20:24, None]
+            hc = O.HyperConnections(4, dim=D).to(G.device)
+            hc.load_state_dict({n: p.detach().clone().reshape(dict(hc.named_parameters())[n].shape) for n, p in zip(names, params)})
+            b_in, add = hc(X.permute(1, 0, 2))
+            out = add(ycur.float()[None]).permute(1, 0, 2)
+            ((out * G.float()).sum() + (b_in[0] * dbin.float()).sum()).backward()
+        note('hc_bwd dR', rel(dR, Xin.grad))
+        if yp is not None:
+            note('hc_bwd dyprev', rel(dyp, yp.grad))
+        hp = dict(hc.named_parameters())
+        for n, g, b0 in zip(names, grads, before):
+            if g.numel() > 1:
+                note('hc_bwd d' + n, rel(g - b0, hp[n].grad.reshape(g.shape)))
+        return dR, dyp
+
+    def ab(st, dOg, kmask_pad, *aa, **k):
+        dQ, dK, dV, dg = o_ab(st, dOg, kmask_pad, *aa, **k)
+        B, H, N = st.B, st.H, st.N
+        with torch.enable_grad():
+            Q, K, V = (t.float().requires_grad_(True) for t in (st.Q, st.K, st.V))
+            km = kmask_pad[:, :N].bool()
+            S = torch.tanh(torch.einsum('bhid,bhjd->bhij', Q, K) * 0.125 / 50.) * 50.
+            S = S.masked_fill(~km[:, None, None, :], -torch.finfo(torch.float32).max)
+            Oo = torch.einsum('bhij,bhjd->bhid', S.softmax(-1), V) * st.gate[..., None] * km[:, None, :, None]
+            Og = Oo.permute(0, 2, 1, 3).reshape(B * N, H * 64)
+            Og.backward(dOg.float())
+        note('attn_fwd Og', rel(st.Og, Og))
+        note('attn_bwd dQ', rel(dQ, Q.grad))
+        note('attn_bwd dK', rel(dK, K.grad))
+        note('attn_bwd dV', rel(dV, V.grad))
+        return dQ, dK, dV, dg
+
+    ops.gemm_nt, ops.gemm_tn, ops.geglu_fwd, ops.geglu_bwd, ops.rmsnorm_bwd, ops.hc_bwd, ops.attn_bwd = nt, tn, ge, gb, rb, hb, ab
+    to = lambda t: t.to(dev)
+    x = to(c['x']).clone().requires_grad_(True)
+    t = to(c['text']).clone().requires_grad_(True)
+    out = mod(x, times=to(c['times']), mask=to(c['mask']), text_embed=t)
+    (out * to(c['R'])).sum().backward()
+    xr = c['x'].clone().requires_grad_(True)
+    tr = c['text'].clone().requires_grad_(True)
+    outr = ref(xr, times=c['times'], mask=c['mask'], text_embed=tr)
+    (outr * c['R']).sum().backward()
+    print('whole backbone vs fp32 oracle (lam = %.2f): out %.4f  dx %.3f  dtext %.3f' % (a.lam, rel(out, outr), rel(x.grad, xr.grad), rel(t.grad, tr.grad)))
+    print('every kernel call vs an fp32 torch reference on ITS OWN inputs (worst call, relative L2):')
+    for k, v in worst.items():
+        print('   %-22s %.4f  %s' % (k, v[0], v[1]))
+
+
+if __name__ == '__main__':
+    main()
