@@ -2,6 +2,7 @@
 # "cheap and safe first".   gpurun --timeout 1500 -- 'bash tools/gpu/round2_first.sh'
 #   1. pytest -m gpu (includes the new reference-golden tests and FusedAdopt with persistent gradients)
 #   2. emu-only tests run against the real library (persistent gradients, edge inputs, shared dropout masks)
+#   2b. every kernel call of a backbone step vs an fp32 reference on its own inputs (tools/insitu_check.py)
 #   3. 256 x 256 NT kernel: small shapes under a timeout, then race screen + A/B on the cfg3 shapes
 #   4. bench A/B: default | --persistent-grads | E2K_GEMM_FLAGS=256 | both
 #   5. micro-benchmarks of the element-wise kernels (depthwise-conv split backward vs fused)
@@ -9,6 +10,7 @@ export PYTHONUNBUFFERED=1
 mkdir -p gpurun_out
 (timeout 500 python -m pytest tests -m gpu -q -p no:cacheprovider) > gpurun_out/r2_pytest.log 2>&1; echo "pytest rc=$?"; tail -n 3 gpurun_out/r2_pytest.log
 (timeout 300 python tools/gpu_variants_of_emu_tests.py) > gpurun_out/r2_emu_only.log 2>&1; echo "emu-only tests on the GPU rc=$?"; tail -n 5 gpurun_out/r2_emu_only.log
+(timeout 200 python tools/insitu_check.py --gpu --lam 0) > gpurun_out/r2_insitu.log 2>&1; (timeout 200 python tools/insitu_check.py --gpu --lam 1) >> gpurun_out/r2_insitu.log 2>&1; echo "in-situ kernel check rc=$?"; grep -E 'whole|attn_bwd dQ|hc_bwd dR' gpurun_out/r2_insitu.log
 (timeout 120 python tools/gemm_t256_check.py --quick) > gpurun_out/r2_t256_quick.log 2>&1; rc=$?; echo "t256 quick rc=$rc"; tail -n 2 gpurun_out/r2_t256_quick.log
 if [ $rc -eq 0 ]; then
   (timeout 300 python tools/gemm_t256_check.py) > gpurun_out/r2_t256_full.log 2>&1; echo "t256 full rc=$?"; tail -n 13 gpurun_out/r2_t256_full.log | cut -c1-260
