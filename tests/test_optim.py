@@ -121,7 +121,7 @@ def test_training_loop_reduces_loss(dev):
     opt = FusedAdopt(model, lr=3e-3, max_grad_norm=1.0)
     ema = FusedEMA(model, update_after_step=0, update_every=1)
     losses = []
-    for _ in range(5):
+    for _ in range(4):
         out = model(mel, text=['hello', 'world'], _noise=noise)
         out.loss.backward()
         opt.step()
