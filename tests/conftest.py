@@ -12,19 +12,11 @@ for p in (ROOT / 'e2-tts-pytorch_amd', ROOT, ROOT / 'tests'):
 
 def pytest_configure(config):
     config.addinivalue_line('markers', 'gpu: needs a real MI355X (run with -m gpu on the GPU box)')
-    config.addinivalue_line('markers', 'cpu_redundant: [emu] variant skipped by default (same ground covered by the reference-golden tests)')
     config.addinivalue_line('markers', 'late: run after everything else (tests whose [gpu] variant has not been on hardware yet, '
                                        'so that with -x a surprise there cannot hide the established kernel parity results)')
 
 
 def pytest_collection_modifyitems(config, items):
-    # [emu] variants whose ground is covered twice on the CPU (the reference-golden tests hold the same HIP code paths to the
-    # reference's own outputs): skipped on the host model to keep the CPU suite short, still run on the GPU.  E2K_RUN_ALL=1
-    # runs them anyway.
-    if not os.environ.get('E2K_RUN_ALL'):
-        for it in items:
-            if it.get_closest_marker('cpu_redundant') and '[emu' in it.nodeid:
-                it.add_marker(pytest.mark.skip(reason='covered by the reference-golden tests on the host model (E2K_RUN_ALL=1 to run)'))
     late = [it for it in items if it.get_closest_marker('late')]
     if late:
         rest = [it for it in items if not it.get_closest_marker('late')]

@@ -7,12 +7,11 @@
 // on a machine with no GPU before GPU minutes are spent.
 //
 // Execution model: one OS thread runs one workgroup at a time; the workgroup's
-// threads are ucontext fibers scheduled round-robin.  __syncthreads() is a true
+// threads are fibers (a minimal x86-64 stack switch) scheduled round-robin.  __syncthreads() is a true
 // rendezvous over the block, wave-level exchanges (__shfl*, MFMA) a true
 // rendezvous over the 64-lane wave.  __shared__ maps to `static thread_local`
 // (one block per OS thread => block-shared).  "Device" pointers are host pointers.
 #pragma once
-#include <ucontext.h>
 #include <atomic>
 #include <cmath>
 #include <cstdint>
@@ -73,9 +72,22 @@ struct PendingCopy {
 };
 inline bool g_glds_late = false;
 
+// Fiber switch: callee-saved registers + stack pointer (x86-64 SysV).  glibc's swapcontext also saves / restores the
+// signal mask with a system call on every switch, which dominated the model's run time (every MFMA and every barrier is
+// a rendezvous of 64 / 256 / 512 fibers).
+struct Ctx { void* sp = nullptr; };
+__attribute__((naked, noinline)) static void emu_switch(Ctx* /*from: rdi*/, Ctx* /*to: rsi*/) {
+    __asm__ volatile(
+        "pushq %rbp\n\tpushq %rbx\n\tpushq %r12\n\tpushq %r13\n\tpushq %r14\n\tpushq %r15\n\t"
+        "movq %rsp, (%rdi)\n\t"
+        "movq (%rsi), %rsp\n\t"
+        "popq %r15\n\tpopq %r14\n\tpopq %r13\n\tpopq %r12\n\tpopq %rbx\n\tpopq %rbp\n\t"
+        "ret\n\t");
+}
+
 struct Fiber {
     std::vector<PendingCopy> pending;       // this lane's LDS-DMA copies that have not landed yet (late mode), oldest first
-    ucontext_t ctx;
+    Ctx ctx;
     dim3 tid;
     int lin = 0;
     int par = 0;
@@ -89,7 +101,7 @@ struct Block {
     int cur = 0;
     std::vector<Fiber> fibers;
     std::vector<Wave> waves;
-    ucontext_t sched;
+    Ctx sched;
     int bar_arrived = 0;
     unsigned bar_gen = 0;
     long progress = 0;      // bumped whenever a rendezvous completes or a fiber finishes (deadlock detection)
@@ -109,7 +121,7 @@ inline void land_pending(int keep) {
 }
 inline void yield() {
     Fiber& f = cur_fiber();
-    swapcontext(&f.ctx, &g_blk->sched);
+    emu_switch(&f.ctx, &g_blk->sched);
 }
 inline void block_rendezvous() {
     Block* b = g_blk;
@@ -140,7 +152,7 @@ static void trampoline() {
     (*b->body)();
     land_pending(0);
     b->fibers[b->cur].done = true;
-    swapcontext(&b->fibers[b->cur].ctx, &b->sched);
+    emu_switch(&b->fibers[b->cur].ctx, &b->sched);
 }
 
 inline void run_block(Block& blk, const std::function<void()>& body) {
@@ -155,11 +167,14 @@ inline void run_block(Block& blk, const std::function<void()>& body) {
         f.par = 0;
         f.lin = i;
         f.tid = dim3(i % blk.bdim.x, (i / blk.bdim.x) % blk.bdim.y, i / (blk.bdim.x * blk.bdim.y));
-        getcontext(&f.ctx);
-        f.ctx.uc_stack.ss_sp = f.stack;
-        f.ctx.uc_stack.ss_size = kStack;
-        f.ctx.uc_link = nullptr;
-        makecontext(&f.ctx, (void (*)())trampoline, 0);
+        // first switch "returns" into trampoline(): [6 callee-saved slots][&trampoline][fake return address], with the
+        // stack pointer at function entry = 8 mod 16 as after a call
+        uintptr_t top = ((uintptr_t)f.stack + kStack) & ~(uintptr_t)15;
+        uint64_t* sp = (uint64_t*)top;
+        *(--sp) = 0;
+        *(--sp) = (uint64_t)(uintptr_t)&trampoline;
+        for (int r = 0; r < 6; ++r) *(--sp) = 0;
+        f.ctx.sp = sp;
     }
     int nw = (n + kWave - 1) / kWave;
     for (int w = 0; w < nw; ++w) {
@@ -174,7 +189,7 @@ inline void run_block(Block& blk, const std::function<void()>& body) {
             Fiber& f = blk.fibers[i];
             if (f.done) continue;
             blk.cur = i;
-            swapcontext(&blk.sched, &f.ctx);
+            emu_switch(&blk.sched, &f.ctx);
             if (f.done) { --remaining; blk.progress++; }
         }
         idle_rounds = (blk.progress == before) ? idle_rounds + 1 : 0;

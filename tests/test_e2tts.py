@@ -183,7 +183,6 @@ def test_edge_inputs(emu, case):
     assert rel2(out.pred_flow, out_r.pred_flow) < 1.5e-2
 
 
-@pytest.mark.cpu_redundant
 def test_concat_cond(dev):
     """concat_cond=True (e2_tts.py:1196-1204,1263-1276): one Linear(2 * n_mels, dim) on cat(cond, x)"""
     kw = dict(dim=256, depth=2, heads=4, dropout=0.)
@@ -257,7 +256,6 @@ def test_e2tts_text_dropped(dev):
     assert g is not None and float(g.abs().max()) == 0.
 
 
-@pytest.mark.cpu_redundant
 def test_sample(dev):
     kw = dict(dim=256, depth=2, heads=4, dropout=0.)
     ref, model = _pair(kw, seed=2)
@@ -296,7 +294,6 @@ def test_duration_predictor(dev):
     assert rel2(pred, pred_r) < 2e-2
 
 
-@pytest.mark.cpu_redundant
 def test_against_golden_fixture(dev):
     """HIP path vs the committed oracle outputs (tests/golden/oracle_small.pt, made by tests/golden/make_golden.py)"""
     from pathlib import Path
