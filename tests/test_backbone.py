@@ -104,6 +104,16 @@ def test_backbone(dev, cond_on_time, with_text, with_mask):
     assert not bad, bad[:20]
 
 
+@pytest.mark.parametrize('late', [0, 1])
+def test_backbone_with_256_tile_gemm(emu, monkeypatch, late):
+    """the whole backbone with EVERY forward / dgrad GEMM on the opt-in 256 x 256 8-phase kernel (E2K_GEMM_T256), under both
+    LDS-DMA landing extremes of the host model -- the kernel has not run on hardware yet"""
+    from e2_tts_pytorch_amd import ops
+    monkeypatch.setenv('E2K_EMU_GLDS_LATE', str(late))
+    monkeypatch.setattr(ops, 'gemm_flags', 128)
+    test_backbone(EMU_ONLY_DEV, True, True, True)
+
+
 def test_persistent_grads(emu):
     """enable_persistent_grads(): every .grad is a permanent view of one flat buffer that each backward overwrites; the
     values are those of the default mode (fresh gradient tensors handed to autograd)"""
