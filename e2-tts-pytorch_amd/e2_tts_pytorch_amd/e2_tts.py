@@ -302,6 +302,30 @@ def _odeint_midpoint(fn, y0, t):
     return y
 
 
+def _odeint_euler(fn, y0, t):
+    """torchdiffeq.odeint(method='euler'): fixed grid, y += dt f(t0, y)"""
+    y = y0
+    for t0, t1 in zip(t[:-1], t[1:]):
+        y = y + (t1 - t0) * fn(t0, y)
+    return y
+
+
+def _odeint_rk4(fn, y0, t):
+    """torchdiffeq.odeint(method='rk4'): its fixed-grid fourth-order step is the 3/8 rule (`rk4_alt_step_func`)"""
+    y = y0
+    for t0, t1 in zip(t[:-1], t[1:]):
+        dt = t1 - t0
+        k1 = fn(t0, y)
+        k2 = fn(t0 + dt / 3, y + dt * k1 / 3)
+        k3 = fn(t0 + dt * 2 / 3, y + dt * (k2 - k1 / 3))
+        k4 = fn(t1, y + dt * (k1 - k2 + k3))
+        y = y + dt * (k1 + 3 * (k2 + k3) + k4) / 8
+    return y
+
+
+_SOLVERS = {'midpoint': _odeint_midpoint, 'euler': _odeint_euler, 'rk4': _odeint_rk4}
+
+
 class E2TTS(Module):
     def __init__(
         self,
@@ -328,8 +352,9 @@ class E2TTS(Module):
         assert num_freq_tokens > 0
         if num_freq_tokens != 1:
             raise NotImplementedError('num_freq_tokens > 1 (has_freq_axis) is not built')
-        if odeint_kwargs.get('method', 'midpoint') != 'midpoint':
-            raise NotImplementedError('only the midpoint solver (the reference default) is built')
+        if odeint_kwargs.get('method', 'midpoint') not in _SOLVERS:
+            raise NotImplementedError(f'fixed-grid solvers {sorted(_SOLVERS)} are built (the reference default is midpoint); '
+                                      'adaptive torchdiffeq methods are not')
         self.num_freq_tokens, self.has_freq_axis = 1, False
         if isinstance(transformer, dict):
             transformer = dict(transformer)
@@ -445,7 +470,7 @@ class E2TTS(Module):
 
         y0 = _y0 if exists(_y0) else torch.randn_like(cond)
         t = torch.linspace(0, 1, steps, device=self.device)
-        sampled = _odeint_midpoint(fn, y0, t)
+        sampled = _SOLVERS[self.odeint_kwargs.get('method', 'midpoint')](fn, y0, t)
         out = torch.where(cond_mask, cond, sampled)
         if exists(return_raw_output) and return_raw_output:
             return out

@@ -728,6 +728,28 @@ def odeint_midpoint(fn, y0, t):
     return torch.stack(ys)
 
 
+def odeint_fixed(fn, y0, t, method='midpoint'):
+    """the other fixed-grid torchdiffeq solvers (restated, unpinned): 'euler', and 'rk4' = the 3/8-rule step
+    torchdiffeq uses on a fixed grid (rk4_alt_step_func)"""
+    if method == 'midpoint':
+        return odeint_midpoint(fn, y0, t)
+    ys, y = [y0], y0
+    for t0, t1 in zip(t[:-1], t[1:]):
+        dt = t1 - t0
+        if method == 'euler':
+            y = y + dt * fn(t0, y)
+        elif method == 'rk4':
+            k1 = fn(t0, y)
+            k2 = fn(t0 + dt / 3, y + dt * k1 / 3)
+            k3 = fn(t0 + dt * 2 / 3, y + dt * (k2 - k1 / 3))
+            k4 = fn(t1, y + dt * (k1 - k2 + k3))
+            y = y + dt * (k1 + 3 * (k2 + k3) + k4) / 8
+        else:
+            raise ValueError(method)
+        ys.append(y)
+    return torch.stack(ys)
+
+
 # ---------------------------------------------------------------- E2TTS (e2_tts.py:1115-1595)
 
 class E2TTS(Module):
@@ -848,7 +870,7 @@ class E2TTS(Module):
 
         y0 = _y0 if exists(_y0) else torch.randn_like(cond)
         t = torch.linspace(0, 1, steps, device=device)
-        trajectory = odeint_midpoint(fn, y0, t)
+        trajectory = odeint_fixed(fn, y0, t, self.odeint_kwargs.get('method', 'midpoint'))
         out = torch.where(cond_mask, cond, trajectory[-1])
         return out
 

@@ -270,6 +270,20 @@ def test_sample(dev):
     assert rel2(s, s_r) < 2e-2, rel2(s, s_r)
 
 
+@pytest.mark.late
+@pytest.mark.parametrize('method', ['euler', 'rk4'])
+def test_sample_other_fixed_grid_solvers(dev, method):
+    """odeint_kwargs method 'euler' / 'rk4' (torchdiffeq's fixed-grid solvers) against the oracle restatement"""
+    kw = dict(dim=256, depth=2, heads=4, dropout=0.)
+    ref, model = _pair(kw, seed=4, odeint_kwargs=dict(method=method))
+    model = model.to(dev)
+    cond = torch.randn(1, 5, 100)
+    y0 = torch.randn(1, 20, 100)
+    s_r = ref.sample(cond, text=['solver'], duration=20, steps=3, cfg_strength=0.5, _y0=y0)
+    s = model.sample(cond.to(dev), text=['solver'], duration=20, steps=3, cfg_strength=0.5, _y0=y0.to(dev))
+    assert rel2(s, s_r) < 2e-2, rel2(s, s_r)
+
+
 def test_duration_predictor(dev):
     from e2_tts_pytorch_amd import DurationPredictor
     random.seed(3)

@@ -124,6 +124,21 @@ def test_midpoint_ode():
     assert abs(traj[-1].item() - (1 + 0.25 + 0.25 ** 2 / 2) ** 4) < 1e-5
 
 
+def test_fixed_grid_solvers_order():
+    """euler / midpoint / rk4 (3/8 rule) on y' = -y: errors shrink with the expected orders (1, 2, 4)"""
+    fn = lambda t, y: -y
+    y0 = torch.ones(1, dtype=torch.float64)
+    exact = math.exp(-1.0)
+    errs = {}
+    for m in ('euler', 'midpoint', 'rk4'):
+        e = []
+        for n in (9, 17):
+            t = torch.linspace(0, 1, n, dtype=torch.float64)
+            e.append(abs(O.odeint_fixed(fn, y0, t, m)[-1].item() - exact))
+        errs[m] = e[0] / e[1]
+    assert 1.8 < errs['euler'] < 2.2 and 3.6 < errs['midpoint'] < 4.4 and 14 < errs['rk4'] < 18, errs
+
+
 def test_project_is_orthogonal():
     x, y = torch.randn(3, 7, 5), torch.randn(3, 7, 5)
     par, orth = O.project(x, y)
