@@ -989,7 +989,9 @@ class Transformer(Module):
             dc[:, :, 3].mul_(1. - gv[:, :, 3])
             dcb = run.dcond.to(bf16)
             ops.gemm_tn(dcb, run.cb, G(g.wcond, 4 * L * D, D))                    # d W_cond
-            G(g.bcond, 4 * L * D).add_(run.dcond.sum(dim=0))
+            # only slots 1 and 3 of a layer's row are parameters (the AdaLN-Zero biases); slots 0 and 2 are layout holes
+            # (AdaptiveRMSNorm.to_gamma has no bias) and must keep a zero gradient, or the flat optimizer would train them
+            G(g.bcond, 4 * L * D).view(L, 4, D)[:, 1::2].add_(run.dcond.sum(dim=0).view(L, 4, D)[:, 1::2])
             KB = _r8(B)
             dct = torch.zeros((4 * L * D, KB), dtype=bf16, device=dev)
             dct[:, :B] = dcb.t()

@@ -144,8 +144,38 @@ class MelSpec(Module):
         assert inp.ndim == 2
         if self.dummy.device != inp.device:
             self.to(inp.device)
+        if inp.device.type == 'cpu' and not ops.host_ok():
+            # CPU tensors (the trainer builds MelSpec inside HFDataset / E2Trainer on the host, trainer.py:96,122,188):
+            # the same HIP kernel, with the wave staged to the current HIP device and the log-mel copied back.  Not a CPU
+            # implementation -- without a HIP device this raises like every other op of the package.
+            if not torch.cuda.is_available():
+                raise ops.E2KError('MelSpec on a CPU tensor stages through the HIP device, and none is visible')
+            dev = torch.device('cuda', torch.cuda.current_device())
+            win, fb = self._staged_consts(dev)
+            src = inp.float()
+            src = src.pin_memory() if not src.is_pinned() else src
+            out = ops.melspec(src.to(dev, non_blocking=True), win, fb, self.filter_length, self.hop_length,
+                              lens=None if lens is None else lens.to(dev))
+            return out.to('cpu')
         return ops.melspec(inp, self.mel_stft.spectrogram.window, self.mel_stft.mel_scale.fb,
                            self.filter_length, self.hop_length, lens=lens)          # (b, n_mels, frames)
+
+    def _staged_consts(self, dev):
+        c = self.__dict__.get('_staged')
+        if c is None or c[0] != dev:
+            c = (dev, self.mel_stft.spectrogram.window.to(dev), self.mel_stft.mel_scale.fb.to(dev))
+            self.__dict__['_staged'] = c
+        return c[1], c[2]
+
+    def __deepcopy__(self, memo):       # (the staged device copies are a cache, not state: EMA deep-copies the model)
+        import copy
+        cls = self.__class__
+        new = cls.__new__(cls)
+        memo[id(self)] = new
+        for k, v in self.__dict__.items():
+            if k != '_staged':
+                new.__dict__[k] = copy.deepcopy(v, memo)
+        return new
 
 
 # ------------------------------------------------------------------------------------------------ small modules

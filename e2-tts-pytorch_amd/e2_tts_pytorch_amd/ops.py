@@ -10,6 +10,12 @@ from . import _lib
 
 bf16 = torch.bfloat16
 f32 = torch.float32
+E2KError = _lib.E2KError
+
+
+def host_ok():
+    """True only under the test-side host model of the kernels (tests/emu); the product library takes device pointers"""
+    return _lib.host_pointers_ok()
 
 
 def _chk(*ts):

@@ -8,10 +8,6 @@ from oracle import e2tts_oracle as O
 
 bf16 = torch.bfloat16
 
-# device of the tests that run on the host model only (`emu` fixture); tools/gpu_variants_of_emu_tests.py points it at
-# the GPU for a one-off run against the real library
-EMU_ONLY_DEV = 'cpu'
-
 
 def rel(a, b):
     a, b = a.cpu(), b.cpu()
@@ -105,19 +101,20 @@ def test_backbone(dev, cond_on_time, with_text, with_mask):
 
 
 @pytest.mark.parametrize('late', [0, 1])
-def test_backbone_with_256_tile_gemm(emu, monkeypatch, late):
-    """the whole backbone with EVERY forward / dgrad GEMM on the opt-in 256 x 256 8-phase kernel (E2K_GEMM_T256), under both
-    LDS-DMA landing extremes of the host model -- the kernel has not run on hardware yet"""
+def test_backbone_with_256_tile_gemm(dev, monkeypatch, late):
+    """the whole backbone with EVERY forward / dgrad GEMM forced onto the 256 x 256 8-phase kernel (E2K_GEMM_T256); on the
+    host model under both LDS-DMA landing extremes (`late` has no meaning on the GPU: one run there)"""
     from e2_tts_pytorch_amd import ops
+    if dev == 'cuda' and late:
+        pytest.skip('LDS-DMA landing extremes exist on the host model only')
     monkeypatch.setenv('E2K_EMU_GLDS_LATE', str(late))
     monkeypatch.setattr(ops, 'gemm_flags', 128)
-    test_backbone(EMU_ONLY_DEV, True, True, True)
+    test_backbone(dev, True, True, True)
 
 
-def test_persistent_grads(emu):
+def test_persistent_grads(dev):
     """enable_persistent_grads(): every .grad is a permanent view of one flat buffer that each backward overwrites; the
     values are those of the default mode (fresh gradient tensors handed to autograd)"""
-    dev = EMU_ONLY_DEV                     # host logic only: the logic-checker build is enough ([gpu] variant: next round)
     from e2_tts_pytorch_amd import Transformer
     random.seed(0)
     torch.manual_seed(0)

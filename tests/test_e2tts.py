@@ -9,10 +9,6 @@ from oracle import e2tts_oracle as O
 
 from test_backbone import randomize
 
-# device of the tests that run on the host model only (`emu` fixture); tools/gpu_variants_of_emu_tests.py points it at
-# the GPU for a one-off run against the real library
-EMU_ONLY_DEV = 'cpu'
-
 
 def rel2(a, b):
     a, b = a.detach().cpu().float(), b.detach().cpu().float()
@@ -32,6 +28,35 @@ def test_melspec(dev):
     got = MelSpec()(wave.to(dev))
     assert got.shape == ref.shape == (2, 100, 22)
     assert (got.cpu() - ref).abs().max().item() < 2e-3      # log-mel, fp32 FFT vs torch.stft
+
+
+@pytest.mark.gpu
+def test_melspec_cpu_tensor_stages_through_the_device():
+    """MelSpec is constructed and called on CPU tensors by the reference's HFDataset / E2Trainer (trainer.py:96,122,188):
+    a CPU wave goes through the same HIP kernel (staged to the device, log-mel copied back) and comes back on the CPU"""
+    import copy
+    from e2_tts_pytorch_amd import MelSpec, _lib
+    _lib._install_for_tests(None, host_pointers=False)
+    torch.manual_seed(0)
+    wave = torch.randn(3, 256 * 40 + 5)
+    m = MelSpec()
+    got = m(wave)
+    assert got.device.type == 'cpu' and m.dummy.device.type == 'cpu'
+    ref = O.MelSpec()(wave)
+    assert got.shape == ref.shape and (got - ref).abs().max().item() < 2e-3
+    assert torch.equal(got, m(wave.cuda()).cpu())                       # the very kernel the device path runs
+    m2 = copy.deepcopy(m)                                               # EMA deep-copies the model (trainer.py:170)
+    assert torch.equal(m2(wave[:, None, :]), got)                       # (b, 1, nw) form of the trainer's data path
+
+
+def test_melspec_cpu_tensor_without_a_device_raises():
+    """no HIP device, no host model: the CPU-tensor path must fail loudly, never compute on the CPU"""
+    from e2_tts_pytorch_amd import MelSpec, _lib
+    if torch.cuda.is_available():
+        pytest.skip('a HIP device is visible')
+    _lib._install_for_tests(None, host_pointers=False)
+    with pytest.raises(_lib.E2KError):
+        MelSpec()(torch.randn(1, 4096))
 
 
 @pytest.mark.late
@@ -125,8 +150,7 @@ def test_e2tts_cfg3_width():
         assert gk is not None and rel2(gk, gr) < 0.15, (name, rel2(gk, gr))
 
 
-def test_training_dropout_shared_masks(emu):
-    dev = EMU_ONLY_DEV      # host logic checker only for now (the kernel-level hand-over test above runs on the GPU as well)
+def test_training_dropout_shared_masks(dev):
     """a training step with dropout 0.1 (attention + GEGLU dropout active): handing the attention keep masks from the
     forward to the backward (the default) gives exactly the loss and gradients of re-hashing them in every kernel"""
     from e2_tts_pytorch_amd import E2TTS, ops
@@ -157,8 +181,7 @@ def test_training_dropout_shared_masks(emu):
 
 
 @pytest.mark.parametrize('case', ['no_text', 'empty_string', 'short_lens', 'one_key_tile', 'text_longer_than_audio'])
-def test_edge_inputs(emu, case):
-    dev = EMU_ONLY_DEV      # host logic checker only for now: written after this round's GPU minutes were spent (enable [gpu] next round)
+def test_edge_inputs(dev, case):
     """ragged / degenerate inputs behave like the oracle: no text, an empty string in the batch, a 2-frame sample next to
     a 20-frame one, exactly one 64-position key tile, text longer than the audio (truncated)"""
     kw = dict(dim=256, depth=2, heads=4, dropout=0.)
@@ -396,19 +419,21 @@ def test_reference_golden_data_path(dev):
     assert (batch['mel'].cpu() - c['mel']).abs().max().item() < 2e-3           # log-mel, fp32 FFT vs torch.stft
 
 
-def test_reference_golden_sample_front_end(emu):
+def test_reference_golden_sample_front_end(dev):
     """sample() front end on the HIP path vs the reference's output: raw-wave prompt (MelSpec kernel inside), duration from
-    the duration predictor, max_duration clamp, autoguidance null model.  Host model only: the initial noise is drawn
-    inside sample() from the CPU generator (a GPU run draws different noise), and the predicted durations are truncated
-    to integers, so the comparison needs the reference's own draw"""
+    the duration predictor, max_duration clamp, autoguidance null model.  The reference drew its initial noise inside
+    sample() from the CPU generator (first draw after the seed, shape of the padded prompt = shape of the output); the
+    same draw is handed in through `_y0` so that the GPU run integrates from the reference's own starting point.  The
+    predicted durations are truncated to integers: the output shape check holds them to the reference's"""
     from e2_tts_pytorch_amd import E2TTS
     from oracle.golden_weights import fill_params
     c = _ref_gold()['sample_front_end']
     random.seed(0)
     m = fill_params(E2TTS(transformer=dict(**c['kw']), duration_predictor=dict(transformer=dict(**c['kw'])), use_vocos=False,
-                          cond_drop_prob=0.2), c['weight_seed']).eval()
-    null = fill_params(E2TTS(transformer=dict(**c['kw']), use_vocos=False, cond_drop_prob=0.2), c['null_weight_seed']).eval()
+                          cond_drop_prob=0.2), c['weight_seed']).to(dev).eval()
+    null = fill_params(E2TTS(transformer=dict(**c['kw']), use_vocos=False, cond_drop_prob=0.2), c['null_weight_seed']).to(dev).eval()
     torch.manual_seed(c['torch_seed'])
-    out = m.sample(c['wave'], text=c['text'], lens=c['lens'], steps=c['steps'], cfg_strength=c['cfg_strength'],
-                   max_duration=c['max_duration'], cfg_null_model=null)
+    y0 = torch.randn(c['out'].shape)
+    out = m.sample(c['wave'].to(dev), text=c['text'], lens=c['lens'].to(dev), steps=c['steps'], cfg_strength=c['cfg_strength'],
+                   max_duration=c['max_duration'], cfg_null_model=null, _y0=y0.to(dev))
     assert out.shape == c['out'].shape and rel2(out, c['out']) < 2e-2, rel2(out, c['out'])

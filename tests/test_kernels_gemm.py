@@ -140,29 +140,32 @@ def test_gemm_nt_big_tile(dev, monkeypatch, M, N, K1, K2, kw, flags):
     (700, 520, 320, 0, dict(rs=1)),                          # odd number of K tiles (5)
 ])
 @pytest.mark.parametrize('late', [0, 1])
-def test_gemm_nt_256_tile(emu, monkeypatch, M, N, K1, K2, kw, flags, late):
-    """256 x 256 tile, 8-phase NT kernel (opt-in flag E2K_GEMM_T256), alone and with the remainder split.  Host model
-    only for now: the kernel was written after round 1's GPU time was spent; its first hardware run (and with it the
-    [gpu] variant of this test) belongs to the next round.  What this checks: tile / quadrant / fragment indexing, the
+def test_gemm_nt_256_tile(dev, monkeypatch, M, N, K1, K2, kw, flags, late):
+    """256 x 256 tile, 8-phase NT kernel (flag E2K_GEMM_T256), alone and with the remainder split, on the host model and on
+    the GPU.  What the host model checks: tile / quadrant / fragment indexing, the
     staging order against program-order overwrites, K-range tails, partials + fix-up, barrier pairing of the two wave
     groups (the model aborts on a mismatched barrier).  late = 1: LDS-DMA copies land as late as the issuing lane's
     counted `s_waitcnt vmcnt` allows instead of at issue (tests/emu/hip/hip_runtime.h) -- a wrong count reads stale data"""
     from e2_tts_pytorch_amd import ops
+    if dev == 'cuda' and late:
+        pytest.skip('LDS-DMA landing extremes exist on the host model only')
     monkeypatch.setenv('E2K_EMU_GLDS_LATE', str(late))
     old = ops.gemm_flags
     ops.gemm_flags = flags
     try:
-        test_gemm_nt('cpu', M, N, K1, K2, kw)
+        test_gemm_nt(dev, M, N, K1, K2, kw)
     finally:
         ops.gemm_flags = old
 
 
 @pytest.mark.parametrize('late', [0, 1])
-def test_gemm_nt_256_random_shapes(emu, monkeypatch, late):
+def test_gemm_nt_256_random_shapes(dev, monkeypatch, late):
     """seeded sweep of the 256 x 256 kernel over ragged M / N, 1..9 K tiles, dual-K splits at every tile boundary, every
     epilogue operand, with and without the remainder split (8-slot test hook); both LDS-DMA landing extremes"""
     import random as pyrandom
     from e2_tts_pytorch_amd import ops
+    if dev == 'cuda' and late:
+        pytest.skip('LDS-DMA landing extremes exist on the host model only')
     monkeypatch.setenv('E2K_EMU_GLDS_LATE', str(late))
     rng = pyrandom.Random(4321 + late)
     old = ops.gemm_flags
@@ -182,7 +185,9 @@ def test_gemm_nt_256_random_shapes(emu, monkeypatch, late):
             rm = (torch.rand(M) > 0.3) if rng.random() < 0.3 else None
             f32out = rng.random() < 0.3
             ops.gemm_flags = 128 | rng.choice([0, 32])
-            out = ops.gemm_nt(a, b, a2=a2, bias=bias, rowmask=rm, resid=rs, out_dtype=torch.float32 if f32out else bf16)
+            d = lambda t: None if t is None else t.to(dev)
+            out = ops.gemm_nt(d(a), d(b), a2=d(a2), bias=d(bias), rowmask=d(rm), resid=d(rs),
+                              out_dtype=torch.float32 if f32out else bf16).cpu()
             A = torch.cat([a, a2], 1).float() if K2 else a.float()
             ref = A @ b.float().T
             if bias is not None:

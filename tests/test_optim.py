@@ -105,6 +105,37 @@ def test_fused_adopt_on_model(dev, persist):
         assert e.shape == p.shape and torch.isfinite(e).all()
 
 
+def test_layout_holes_stay_zero(dev):
+    """the flat parameter buffer has layout holes (the bias slots of the bias-free AdaptiveRMSNorm.to_gamma rows of the
+    hoisted time-conditioning block, alignment gaps, the padded tail of the fused qkv bias row).  The flat optimizer
+    treats the whole buffer as one run, so every hole must keep a zero gradient and a zero value -- otherwise it becomes
+    a trained parameter that the forward reads but state_dict() does not carry."""
+    from e2_tts_pytorch_amd import E2TTS
+    from e2_tts_pytorch_amd.optim import FusedAdopt
+    import random
+    random.seed(0)
+    torch.manual_seed(0)
+    model = E2TTS(transformer=dict(dim=256, depth=2, heads=4, dropout=0.), use_vocos=False, cond_drop_prob=0.).to(dev)
+    with torch.no_grad():           # zero-init gates would hide the time-conditioning gradients
+        for n, p in model.named_parameters():
+            if 'to_gamma' in n:
+                p.add_(torch.randn_like(p) * 0.05)
+    tr = model.transformer
+    tr.enable_persistent_grads()
+    opt = FusedAdopt(model, lr=1e-2, max_grad_norm=1.0)
+    mel = torch.randn(2, 24, 100, device=dev)
+    for _ in range(3):
+        model(mel, text=['hello', 'x']).loss.backward()
+        opt.step()
+        opt.zero_grad()
+    hole = torch.ones(tr._flat.numel(), dtype=torch.bool)
+    for p, off in tr._layout.slots:
+        hole[off:off + p.numel()] = False
+    assert int(hole.sum()) > 0
+    assert float(tr._pg.buf.cpu()[hole].abs().max()) == 0., 'a layout hole received a gradient'
+    assert float(tr._flat.cpu()[hole].abs().max()) == 0., 'a layout hole was trained'
+
+
 def test_training_loop_reduces_loss(dev):
     """the pieces of the reference trainer's step (trainer.py:263-279) together: forward, backward, clip + ADOPT, EMA.
     A fixed batch and fixed noise draws: the flow-matching loss must go down"""
