@@ -47,6 +47,22 @@ def step_flops(dim, depth, heads, B, T, text_on=True):
     return 3 * B * (N * f_tok + T * f_io)
 
 
+def _groups(rows, nprof):
+    """per-step HIP-event milliseconds, launches and achieved TFLOP/s of every e2k call name in a profiled plan replay"""
+    g = {}
+    for r in rows:
+        e = g.setdefault(r['name'], [0.0, 0, 0.0])
+        e[0] += r['ms']
+        e[1] += 1
+        e[2] += r['flops']
+    out = {}
+    for k, (ms, n, fl) in sorted(g.items(), key=lambda kv: -kv[1][0]):
+        out[k] = {'ms': round(ms / nprof, 3), 'launches': n // nprof}
+        if fl > 0:
+            out[k]['tflops'] = round(fl / (ms * 1e-3) / 1e12, 1)
+    return out
+
+
 def synthetic_text(B, seed):
     rng = random.Random(seed)
     alphabet = ''.join(chr(c) for c in range(32, 127))
@@ -91,13 +107,11 @@ def main():
     ap.add_argument('--drop-text', action='store_true', help='run with the text stream dropped (CFG null pass cost)')
     ap.add_argument('--no-cpu-baseline', action='store_true')
     ap.add_argument('--batch', type=int, default=None)
-    ap.add_argument('--graphs', action='store_true', help='replay captured HIP graphs instead of eager kernel launches (18 ms instead of '
-                    '108 ms of host time per step, but 3-4 %% slower on the GPU: 128.3 vs 123.8 ms/step on MI355X)')
-    ap.add_argument('--no-graphs', action='store_true', help='always eager launches (no host-bound probe / graph fallback)')
-    ap.add_argument('--persistent-grads', action='store_true',
-                    help='eager mode: Transformer.enable_persistent_grads() (one flat gradient buffer for the life of the module; '
-                         'saves ~20 %% of the host time of a step, tools/host_overhead.py; not yet measured on the GPU)')
-    ap.add_argument('--copy-grads', action='store_true', help='graph mode: copy the gradients out of the static buffer every step')
+    ap.add_argument('--eager', action='store_true', help='drive every kernel launch from Python instead of replaying the recorded '
+                    'launch plan from C++ (A/B: ~35 us of host time per launch, the step becomes host bound)')
+    ap.add_argument('--autograd-grads', action='store_true',
+                    help='hand the backbone gradients to autograd every step (default here: Transformer.enable_persistent_grads(), one '
+                         'flat gradient buffer that each backward overwrites -- what an optimizer over the flat buffer consumes)')
     ap.add_argument('--force-ddp', action='store_true', help='wrap in ddp.DataParallel even with one rank (exercises the RCCL path)')
     args = ap.parse_args()
 
@@ -125,17 +139,18 @@ def main():
     model = E2TTS(transformer=dict(dim=dim, depth=depth, heads=heads, dropout=args.dropout), use_vocos=False,
                   cond_drop_prob=0.).to(dev)
     model.train()
-    use_graphs = args.graphs and not args.no_graphs
     net = DataParallel(model) if (world > 1 or args.force_ddp) else model
     torch.manual_seed(1000 + rank)        # different synthetic data per rank (weak scaling: B per GPU fixed)
     mel = torch.randn(B, T, 100, device=dev)
     text = synthetic_text(B, 1000 + rank)
     noise = {'drop_text_cond': True} if args.drop_text else None
 
+    tr = model.transformer
+    tr.enable_plans(not args.eager)
     params = list(model.parameters())
-    if args.persistent_grads:
-        model.transformer.enable_persistent_grads()
-        flat = {id(q) for q, _ in model.transformer._layout.slots}
+    if not args.autograd_grads:
+        tr.enable_persistent_grads()
+        flat = {id(q) for q, _ in tr._layout.slots}
         params = [p for p in params if id(p) not in flat]          # (the backbone's gradients are overwritten in place)
 
     def step():
@@ -145,34 +160,12 @@ def main():
             p.grad = None                 #    module tree every step (model.zero_grad costs ~10 ms of host time here)
         return out.loss
 
-    launch_mode_note = 'eager launches (default)'
-    if not args.graphs and not args.no_graphs:
-        # Safety net for a slow or busy host: eager launches are 3-4 % faster on the GPU, but only while the host can
-        # enqueue a step faster than the GPU runs it (106 vs 123 ms on the MI355X boxes this was tuned on).  Two untimed
-        # probe steps measure both; if the host is within 5 % of the step time, fall back to HIP-graph replay.
-        step()
-        torch.cuda.synchronize()
-        t0 = time.perf_counter()
-        step()
-        t_host = time.perf_counter() - t0
-        torch.cuda.synchronize()
-        t_all = time.perf_counter() - t0
-        flag = torch.tensor([1.0 if t_host > 0.95 * t_all else 0.0], device=dev)
-        if world > 1:
-            dist.all_reduce(flag, op=dist.ReduceOp.MAX)          # every rank takes the same path
-        if flag.item() > 0:
-            use_graphs = True
-            launch_mode_note = f'HIP-graph replay (host-bound probe: {t_host * 1e3:.0f} of {t_all * 1e3:.0f} ms enqueuing)'
-    if use_graphs:
-        # gradients are consumed (here: dropped by zero_grad(set_to_none=True)) before the next backward, so the
-        # graph's static gradient buffer can be handed out without the extra copy.  Graph mode needs two set-up passes
-        # per input signature (eager warm-up, then capture) before steps replay; they are done here, outside the W
-        # warm-up steps, so that even --warmup 0 times replayed steps only
-        model.transformer.enable_graphs(alias_grads=not args.copy_grads)
-        if args.graphs:
-            launch_mode_note = 'HIP-graph replay (--graphs)'
-        step()
-        step()
+    launch_mode_note = 'eager launches from Python (--eager)' if args.eager else \
+        'recorded launch plan re-issued from C++ (e2k_plan_run; eager stream launches, no HIP graph)'
+    # a signature is recorded the second time it is seen (forward) and at its first backward; do that outside the W
+    # warm-up steps so that even --warmup 0 times replayed steps only
+    step()
+    step()
     for _ in range(args.warmup):
         step()
     torch.cuda.synchronize()
@@ -190,28 +183,30 @@ def main():
     dt = time.perf_counter() - t0
     loss_val = float(loss.item())
 
-    # roofline leg: the dominant kernel's launches cannot be bracketed by events inside a captured graph, so the same
-    # step is replayed with eager launches (identical kernels, shapes and data) and every e2k_gemm_nt launch is timed
-    # with HIP events on its stream; the committed rocprofv3 summary (profiles/) must agree with this average.
-    prof = []
-    model.transformer.enable_graphs(False)
-    step()
-    torch.cuda.synchronize()
-    ops.set_gemm_profile(prof)
-    nprof = 2
-    for _ in range(nprof):
-        step()
-    torch.cuda.synchronize()
-    ops.set_gemm_profile(None)
+    # roofline leg: HIP events on the launch stream around every recorded launch of the step (e2k_plan_profile replays
+    # the very plan the timed region ran, one event after each call); the committed rocprofv3 summary (profiles/) must
+    # agree with these averages.  With --eager the NT launches are bracketed by torch events instead.
+    prof_rows, nprof = [], 2
+    if not args.eager:
+        for _ in range(nprof):
+            prof_rows += tr.plan_profile()
+        gemm = [r for r in prof_rows if r['name'] == 'gemm_nt_bf16']
+        gemm_flops, gemm_ms, n_launch = sum(r['flops'] for r in gemm), sum(r['ms'] for r in gemm), len(gemm)
+    else:
+        prof = []
+        ops.set_gemm_profile(prof)
+        for _ in range(nprof):
+            step()
+        torch.cuda.synchronize()
+        ops.set_gemm_profile(None)
+        gemm_flops = sum(f for f, _, _ in prof)
+        gemm_ms = sum(e0.elapsed_time(e1) for _, e0, e1 in prof)
+        n_launch = len(prof)
 
     t = torch.tensor([dt], dtype=torch.float64, device=dev)
     if world > 1:
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
     dt = float(t.item())
-    gemm_flops = sum(f for f, _, _ in prof)
-    gemm_ms = sum(e0.elapsed_time(e1) for _, e0, e1 in prof)
-    n_launch = len(prof)
-
     if rank == 0:
         ms = dt / args.steps * 1e3
         frames = B * T * world
@@ -246,7 +241,9 @@ def main():
             'mfma_roofline_frac_whole_step': sf / (dt / args.steps) / 1e12 / PEAK_BF16_TFLOPS,
             'loss': loss_val,
             'host_enqueue_ms_per_step': t_enqueue / args.steps * 1e3,
-            'hip_graphs': use_graphs, 'launch_mode': launch_mode_note, 'gemm_flags': ops.gemm_flags,
+            'launch_mode': launch_mode_note, 'gemm_flags': ops.gemm_flags,
+            'launches_per_step': (len(prof_rows) // nprof) if prof_rows else None,
+            'kernel_groups_ms_per_step': _groups(prof_rows, nprof) if prof_rows else None,
             'roofline': {
                 'bound': 'mfma', 'kernel': 'gemm_nt_glds_kernel + gemm_nt_fixup_kernel (bf16 MFMA 16x16x32; every forward and dgrad GEMM of the step)',
                 'achieved': achieved, 'peak': PEAK_BF16_TFLOPS, 'unit': 'TFLOP/s', 'frac': achieved / PEAK_BF16_TFLOPS,
@@ -254,7 +251,8 @@ def main():
                 'avg_launch_ms': gemm_ms / max(n_launch, 1),
                 'flops_per_launch_avg': gemm_flops / max(n_launch, 1),
                 'time_share_of_step': (gemm_ms / nprof) / ms,
-                'measured': 'HIP events around every launch, 2 eager steps right after the timed region',
+                'measured': 'HIP events on the launch stream around every recorded launch (e2k_plan_profile), 2 replays of the '
+                            'timed plan right after the timed region',
                 'traffic': traffic, 'traffic_note': traffic_note,
             },
         }

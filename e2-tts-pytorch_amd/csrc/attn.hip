@@ -16,6 +16,7 @@
 // the key order inside a 64-key tile is permuted so that the accumulator registers of S^T are directly the
 // B-operand fragment of the second MFMA (O^T = V^T.P^T): no LDS round trip for P.
 #include "e2k_device.h"
+#include "plan.h"
 #include <e2k_asm.h>
 #include "../../include/e2k.h"
 
@@ -744,7 +745,7 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dkv_kernel(AttnArgs p) {
 
 }  // namespace
 
-extern "C" int e2k_qkv_post_fwd(const void* qkvg, int64_t ldq, const float* cosb, const float* sinb, const void* vfirst,
+static int qkv_post_fwd_impl(const void* qkvg, int64_t ldq, const float* cosb, const float* sinb, const void* vfirst,
                                 void* Q, void* K, void* V, void* QT, void* KT, void* VT, float* gate, float* mix,
                                 int B, int H, int N, int Npad, void* stream) {
     if (B <= 0 || N <= 0) return 0;
@@ -759,7 +760,7 @@ extern "C" int e2k_qkv_post_fwd(const void* qkvg, int64_t ldq, const float* cosb
     return 0;
 }
 
-extern "C" int e2k_qkv_post_bwd(const void* dQ, const void* dK, const void* dV, const float* dgate_pre,
+static int qkv_post_bwd_impl(const void* dQ, const void* dK, const void* dV, const float* dgate_pre,
                                 const void* qkvg, int64_t ldq, const float* cosb, const float* sinb,
                                 const void* vfirst, const float* mix, float* dvfirst, int first_layer, void* dqkvg,
                                 int B, int H, int N, void* stream) {
@@ -794,7 +795,7 @@ extern "C" int e2k_query_attn_dropbits_bytes(int B, int H, int N) {
     return bytes > 0x7fffffffL ? -1 : (int)bytes;
 }
 
-extern "C" int e2k_attn_fwd(const void* Q, const void* K, const void* VT, const uint8_t* kmask, const float* gate,
+static int attn_fwd_impl(const void* Q, const void* K, const void* VT, const uint8_t* kmask, const float* gate,
                             void* O, void* Og, float* lse2, void* dropbits, int B, int H, int N, int Npad, float p_drop,
                             uint32_t seed, const uint32_t* seed_dev, uint32_t stream_id, void* stream) {
     if (B <= 0 || N <= 0) return 0;
@@ -812,7 +813,7 @@ extern "C" int e2k_attn_fwd(const void* Q, const void* K, const void* VT, const 
     return 0;
 }
 
-extern "C" int e2k_attn_bwd(const void* dOg, const void* O, const float* gate, const float* lse2, const void* Q,
+static int attn_bwd_impl(const void* dOg, const void* O, const float* gate, const float* lse2, const void* Q,
                             const void* K, const void* V, const void* QT, const void* KT, const uint8_t* kmask,
                             const void* dropbits, void* dO, void* dOT, float* delta, float* dgate_pre, void* dQ, void* dK,
                             void* dV, int B, int H, int N, int Npad, float p_drop, uint32_t seed, const uint32_t* seed_dev,
@@ -841,4 +842,33 @@ extern "C" int e2k_attn_bwd(const void* dOg, const void* O, const float* gate, c
     else hipLaunchKernelGGL((attn_bwd_dkv_kernel<false, false>), dim3((N + 63) / 64, H, B), dim3(256), 0, st, a);
     E2K_CHECK_LAUNCH();
     return 0;
+}
+
+// ---- C ABI: every compute entry point goes through e2k::dispatch (plan.h) so that a launch plan can record it
+
+extern "C" int e2k_qkv_post_fwd(const void* qkvg, int64_t ldq, const float* cosb, const float* sinb, const void* vfirst,
+                                void* Q, void* K, void* V, void* QT, void* KT, void* VT, float* gate, float* mix,
+                                int B, int H, int N, int Npad, void* stream) {
+    return e2k::dispatch("qkv_post_fwd", qkv_post_fwd_impl, qkvg, ldq, cosb, sinb, vfirst, Q, K, V, QT, KT, VT, gate, mix, B, H, N, Npad, stream);
+}
+
+extern "C" int e2k_qkv_post_bwd(const void* dQ, const void* dK, const void* dV, const float* dgate_pre,
+                                const void* qkvg, int64_t ldq, const float* cosb, const float* sinb,
+                                const void* vfirst, const float* mix, float* dvfirst, int first_layer, void* dqkvg,
+                                int B, int H, int N, void* stream) {
+    return e2k::dispatch("qkv_post_bwd", qkv_post_bwd_impl, dQ, dK, dV, dgate_pre, qkvg, ldq, cosb, sinb, vfirst, mix, dvfirst, first_layer, dqkvg, B, H, N, stream);
+}
+
+extern "C" int e2k_attn_fwd(const void* Q, const void* K, const void* VT, const uint8_t* kmask, const float* gate,
+                            void* O, void* Og, float* lse2, void* dropbits, int B, int H, int N, int Npad, float p_drop,
+                            uint32_t seed, const uint32_t* seed_dev, uint32_t stream_id, void* stream) {
+    return e2k::dispatch("attn_fwd", attn_fwd_impl, Q, K, VT, kmask, gate, O, Og, lse2, dropbits, B, H, N, Npad, p_drop, seed, seed_dev, stream_id, stream);
+}
+
+extern "C" int e2k_attn_bwd(const void* dOg, const void* O, const float* gate, const float* lse2, const void* Q,
+                            const void* K, const void* V, const void* QT, const void* KT, const uint8_t* kmask,
+                            const void* dropbits, void* dO, void* dOT, float* delta, float* dgate_pre, void* dQ, void* dK,
+                            void* dV, int B, int H, int N, int Npad, float p_drop, uint32_t seed, const uint32_t* seed_dev,
+                            uint32_t stream_id, void* stream) {
+    return e2k::dispatch("attn_bwd", attn_bwd_impl, dOg, O, gate, lse2, Q, K, V, QT, KT, kmask, dropbits, dO, dOT, delta, dgate_pre, dQ, dK, dV, B, H, N, Npad, p_drop, seed, seed_dev, stream_id, stream);
 }

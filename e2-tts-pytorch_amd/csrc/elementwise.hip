@@ -5,6 +5,7 @@
 //   depthwise conv k=31 + SiLU       DepthwiseConv                            (e2_tts.py:295-328)
 //   column sums (bias gradients), fp32 -> bf16 parameter shadow casts.
 #include "e2k_device.h"
+#include "plan.h"
 #include <e2k_asm.h>
 #include "../../include/e2k.h"
 
@@ -670,7 +671,7 @@ int dispatch_conv(const ConvArgs& a, int ks, bool bwd, hipStream_t st) {
 
 }  // namespace
 
-extern "C" int e2k_rmsnorm_fwd(const void* x, const float* gamma, int64_t ldg, float gamma_off, int rows_per_batch,
+static int rmsnorm_fwd_impl(const void* x, const float* gamma, int64_t ldg, float gamma_off, int rows_per_batch,
                                void* y, float* rn, int M, int D, void* stream) {
     if (M <= 0) return 0;
     if (!x || !gamma || !y || !rn || rows_per_batch <= 0) return E2K_ERR_ARG;
@@ -684,7 +685,7 @@ extern "C" int e2k_rmsnorm_fwd(const void* x, const float* gamma, int64_t ldg, f
     return 0;
 }
 
-extern "C" int e2k_rmsnorm_bwd(const void* dy, const void* x, const float* rn, const float* gamma, int64_t ldg,
+static int rmsnorm_bwd_impl(const void* dy, const void* x, const float* rn, const float* gamma, int64_t ldg,
                                float gamma_off, int rows_per_batch, void* dx, float* dgamma, int M, int D,
                                void* stream) {
     if (M <= 0) return 0;
@@ -699,7 +700,7 @@ extern "C" int e2k_rmsnorm_bwd(const void* dy, const void* x, const float* rn, c
     return 0;
 }
 
-extern "C" int e2k_gate_bwd(const void* dy, const void* y, const float* g, void* dao, float* gsum, int64_t ldg,
+static int gate_bwd_impl(const void* dy, const void* y, const float* g, void* dao, float* gsum, int64_t ldg,
                             int M, int D, int rows_per_batch, void* stream) {
     if (M <= 0) return 0;
     if (!dy || !y || !g || !dao || !gsum || rows_per_batch <= 0) return E2K_ERR_ARG;
@@ -716,7 +717,7 @@ static int geglu_grid(long total) {
     return (int)(g > 4096 ? 4096 : (g < 1 ? 1 : g));
 }
 
-extern "C" int e2k_geglu_fwd(const void* H, int64_t ldh, void* out, int M, int F, float p_drop, uint32_t seed,
+static int geglu_fwd_impl(const void* H, int64_t ldh, void* out, int M, int F, float p_drop, uint32_t seed,
                              const uint32_t* seed_dev, uint32_t stream_id, void* stream) {
     if (M <= 0 || F <= 0) return 0;
     if ((F & 7) || (ldh & 7)) return E2K_ERR_ALIGN;
@@ -728,7 +729,7 @@ extern "C" int e2k_geglu_fwd(const void* H, int64_t ldh, void* out, int M, int F
     return 0;
 }
 
-extern "C" int e2k_geglu_bwd(const void* dout, const void* H, int64_t ldh, void* dH, int M, int F, float p_drop,
+static int geglu_bwd_impl(const void* dout, const void* H, int64_t ldh, void* dH, int M, int F, float p_drop,
                              uint32_t seed, const uint32_t* seed_dev, uint32_t stream_id, void* stream) {
     if (M <= 0 || F <= 0) return 0;
     if ((F & 7) || (ldh & 7)) return E2K_ERR_ALIGN;
@@ -740,7 +741,7 @@ extern "C" int e2k_geglu_bwd(const void* dout, const void* H, int64_t ldh, void*
     return 0;
 }
 
-extern "C" int e2k_colsum_bf16(const void* x, int64_t ldx, float* out, int M, int N, void* stream) {
+static int colsum_bf16_impl(const void* x, int64_t ldx, float* out, int M, int N, void* stream) {
     if (M <= 0 || N <= 0) return 0;
     if ((N & 1) || (ldx & 1)) return E2K_ERR_ALIGN;
     int splits = (M + 63) / 64; if (splits > 128) splits = 128;
@@ -750,7 +751,7 @@ extern "C" int e2k_colsum_bf16(const void* x, int64_t ldx, float* out, int M, in
     return 0;
 }
 
-extern "C" int e2k_cast_bf16(const float* src, void* dst, int64_t n, void* stream) {
+static int cast_bf16_impl(const float* src, void* dst, int64_t n, void* stream) {
     if (n <= 0) return 0;
     if (((uintptr_t)src | (uintptr_t)dst) & 15) return E2K_ERR_ALIGN;
     long g = (n / 8 + 255) / 256; if (g > 4096) g = 4096; if (g < 1) g = 1;
@@ -759,7 +760,7 @@ extern "C" int e2k_cast_bf16(const float* src, void* dst, int64_t n, void* strea
     return 0;
 }
 
-extern "C" int e2k_cast_transpose_bf16(const float* src, void* dst, int R, int C, int64_t ldd, void* stream) {
+static int cast_transpose_bf16_impl(const float* src, void* dst, int R, int C, int64_t ldd, void* stream) {
     if (R <= 0 || C <= 0) return 0;
     hipLaunchKernelGGL(cast_transpose_kernel, dim3((C + 63) / 64, (R + 63) / 64), dim3(256), 0, (hipStream_t)stream,
                        src, (bf16_t*)dst, R, C, (long)ldd);
@@ -767,7 +768,7 @@ extern "C" int e2k_cast_transpose_bf16(const float* src, void* dst, int R, int C
     return 0;
 }
 
-extern "C" int e2k_dwconv_fwd(const void* x, const uint8_t* mask, const float* w, const float* bias, void* pre,
+static int dwconv_fwd_impl(const void* x, const uint8_t* mask, const float* w, const float* bias, void* pre,
                               void* y, int B, int N, int C, int ks, void* stream) {
     if (B <= 0 || N <= 0) return 0;
     if (C % CTC) return E2K_ERR_SHAPE;
@@ -780,7 +781,7 @@ extern "C" int e2k_dwconv_fwd(const void* x, const uint8_t* mask, const float* w
     return 0;
 }
 
-extern "C" int e2k_dwconv_bwd(const void* dy, const void* pre, const void* x, const uint8_t* mask, const float* w,
+static int dwconv_bwd_impl(const void* dy, const void* pre, const void* x, const uint8_t* mask, const float* w,
                               void* dx, float* dw, float* dbias, int B, int N, int C, int ks, int split, void* stream) {
     if (B <= 0 || N <= 0) return 0;
     if (C % CTC) return E2K_ERR_SHAPE;
@@ -791,4 +792,54 @@ extern "C" int e2k_dwconv_bwd(const void* dy, const void* pre, const void* x, co
     if (rc) return rc;
     E2K_CHECK_LAUNCH();
     return 0;
+}
+
+// ---- C ABI: every compute entry point goes through e2k::dispatch (plan.h) so that a launch plan can record it
+
+extern "C" int e2k_rmsnorm_fwd(const void* x, const float* gamma, int64_t ldg, float gamma_off, int rows_per_batch,
+                               void* y, float* rn, int M, int D, void* stream) {
+    return e2k::dispatch("rmsnorm_fwd", rmsnorm_fwd_impl, x, gamma, ldg, gamma_off, rows_per_batch, y, rn, M, D, stream);
+}
+
+extern "C" int e2k_rmsnorm_bwd(const void* dy, const void* x, const float* rn, const float* gamma, int64_t ldg,
+                               float gamma_off, int rows_per_batch, void* dx, float* dgamma, int M, int D,
+                               void* stream) {
+    return e2k::dispatch("rmsnorm_bwd", rmsnorm_bwd_impl, dy, x, rn, gamma, ldg, gamma_off, rows_per_batch, dx, dgamma, M, D, stream);
+}
+
+extern "C" int e2k_gate_bwd(const void* dy, const void* y, const float* g, void* dao, float* gsum, int64_t ldg,
+                            int M, int D, int rows_per_batch, void* stream) {
+    return e2k::dispatch("gate_bwd", gate_bwd_impl, dy, y, g, dao, gsum, ldg, M, D, rows_per_batch, stream);
+}
+
+extern "C" int e2k_geglu_fwd(const void* H, int64_t ldh, void* out, int M, int F, float p_drop, uint32_t seed,
+                             const uint32_t* seed_dev, uint32_t stream_id, void* stream) {
+    return e2k::dispatch("geglu_fwd", geglu_fwd_impl, H, ldh, out, M, F, p_drop, seed, seed_dev, stream_id, stream);
+}
+
+extern "C" int e2k_geglu_bwd(const void* dout, const void* H, int64_t ldh, void* dH, int M, int F, float p_drop,
+                             uint32_t seed, const uint32_t* seed_dev, uint32_t stream_id, void* stream) {
+    return e2k::dispatch("geglu_bwd", geglu_bwd_impl, dout, H, ldh, dH, M, F, p_drop, seed, seed_dev, stream_id, stream);
+}
+
+extern "C" int e2k_colsum_bf16(const void* x, int64_t ldx, float* out, int M, int N, void* stream) {
+    return e2k::dispatch("colsum_bf16", colsum_bf16_impl, x, ldx, out, M, N, stream);
+}
+
+extern "C" int e2k_cast_bf16(const float* src, void* dst, int64_t n, void* stream) {
+    return e2k::dispatch("cast_bf16", cast_bf16_impl, src, dst, n, stream);
+}
+
+extern "C" int e2k_cast_transpose_bf16(const float* src, void* dst, int R, int C, int64_t ldd, void* stream) {
+    return e2k::dispatch("cast_transpose_bf16", cast_transpose_bf16_impl, src, dst, R, C, ldd, stream);
+}
+
+extern "C" int e2k_dwconv_fwd(const void* x, const uint8_t* mask, const float* w, const float* bias, void* pre,
+                              void* y, int B, int N, int C, int ks, void* stream) {
+    return e2k::dispatch("dwconv_fwd", dwconv_fwd_impl, x, mask, w, bias, pre, y, B, N, C, ks, stream);
+}
+
+extern "C" int e2k_dwconv_bwd(const void* dy, const void* pre, const void* x, const uint8_t* mask, const float* w,
+                              void* dx, float* dw, float* dbias, int B, int N, int C, int ks, int split, void* stream) {
+    return e2k::dispatch("dwconv_bwd", dwconv_bwd_impl, dy, pre, x, mask, w, dx, dw, dbias, B, N, C, ks, split, stream);
 }

@@ -15,6 +15,7 @@
 // (one barrier per K step).  MFMA operands are swapped (srcA = weight fragment, srcB = activation fragment) so
 // that a lane's 4 accumulator registers are 4 consecutive output columns -> 8-byte bf16 stores.
 #include "e2k_device.h"
+#include "plan.h"
 #include <e2k_asm.h>
 #include "../../include/e2k.h"
 
@@ -1091,7 +1092,7 @@ int tn_splits(int M, int N, int K, int splits) {
 
 }  // namespace
 
-extern "C" int e2k_gemm_nt_bf16(const void* A1, int64_t lda1, int K1, const void* A2, int64_t lda2, int K2,
+static int gemm_nt_bf16_impl(const void* A1, int64_t lda1, int K1, const void* A2, int64_t lda2, int K2,
                                 const void* B, int64_t ldb, void* C, int64_t ldc, int out_f32, int accumulate,
                                 int M, int N, const float* bias, const float* colscale, int64_t lds,
                                 int rows_per_batch, const uint8_t* rowmask, const void* resid, int64_t ldr, int flags,
@@ -1207,7 +1208,7 @@ extern "C" int e2k_query_gemm_tn_splits(int M, int N, int K, int splits) {
 
 extern "C" int e2k_colsum_bf16(const void* x, int64_t ldx, float* out, int M, int N, void* stream);
 
-extern "C" int e2k_gemm_tn_bf16(const void* A, int64_t lda, const void* B, int64_t ldb, float* C, int64_t ldc,
+static int gemm_tn_bf16_impl(const void* A, int64_t lda, const void* B, int64_t ldb, float* C, int64_t ldc,
                                 int M, int N, int K, int splits, int use_tr, float* ws, float* colsum, int cs_from,
                                 void* stream) {
     if (M <= 0 || N <= 0 || K <= 0) return 0;
@@ -1245,4 +1246,20 @@ extern "C" int e2k_gemm_tn_bf16(const void* A, int64_t lda, const void* B, int64
         E2K_CHECK_LAUNCH();
     }
     return 0;
+}
+
+// ---- C ABI: every compute entry point goes through e2k::dispatch (plan.h) so that a launch plan can record it
+
+extern "C" int e2k_gemm_nt_bf16(const void* A1, int64_t lda1, int K1, const void* A2, int64_t lda2, int K2,
+                                const void* B, int64_t ldb, void* C, int64_t ldc, int out_f32, int accumulate,
+                                int M, int N, const float* bias, const float* colscale, int64_t lds,
+                                int rows_per_batch, const uint8_t* rowmask, const void* resid, int64_t ldr, int flags,
+                                float* ws, int64_t ws_bytes, void* stream) {
+    return e2k::dispatch("gemm_nt_bf16", gemm_nt_bf16_impl, A1, lda1, K1, A2, lda2, K2, B, ldb, C, ldc, out_f32, accumulate, M, N, bias, colscale, lds, rows_per_batch, rowmask, resid, ldr, flags, ws, ws_bytes, stream);
+}
+
+extern "C" int e2k_gemm_tn_bf16(const void* A, int64_t lda, const void* B, int64_t ldb, float* C, int64_t ldc,
+                                int M, int N, int K, int splits, int use_tr, float* ws, float* colsum, int cs_from,
+                                void* stream) {
+    return e2k::dispatch("gemm_tn_bf16", gemm_tn_bf16_impl, A, lda, B, ldb, C, ldc, M, N, K, splits, use_tr, ws, colsum, cs_from, stream);
 }

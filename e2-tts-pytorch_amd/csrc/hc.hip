@@ -24,6 +24,7 @@
 // backward accumulates d(Wp) in registers over all tokens of a wave and flushes it once.
 #include <type_traits>
 #include "e2k_device.h"
+#include "plan.h"
 #include <e2k_asm.h>
 #include "../../include/e2k.h"
 
@@ -594,7 +595,7 @@ extern "C" int e2k_query_hc_coef_width(void) { return CW; }
 extern "C" int e2k_query_hc_bwd_blocks(int Mtok, int D) { return grid_for(Mtok, D, 768, true); }
 extern "C" int e2k_query_hc_partial_stride(int D) { return NJ * D + NSC; }
 
-extern "C" int e2k_hc_fwd(const void* Xin, const void* yprev, const float* coef_prev, void* Mout, void* bin,
+static int hc_fwd_impl(const void* Xin, const void* yprev, const float* coef_prev, void* Mout, void* bin,
                           float* coef, const float* static_beta, const float* static_alpha,
                           const float* dyn_alpha_fn, const float* dyn_alpha_scale, const float* dyn_beta_fn,
                           const float* dyn_beta_scale, const float* gamma, int Mtok, int D, int has_depth,
@@ -613,7 +614,7 @@ extern "C" int e2k_hc_fwd(const void* Xin, const void* yprev, const float* coef_
     return 0;
 }
 
-extern "C" int e2k_hc_bwd(const void* Xin, const void* yprev, const float* coef_prev, const void* G,
+static int hc_bwd_impl(const void* Xin, const void* yprev, const float* coef_prev, const void* G,
                           const void* dbin, const void* ycur, const float* coef, void* dR, void* dyprev,
                           const float* static_beta, const float* static_alpha, const float* dyn_alpha_fn,
                           const float* dyn_alpha_scale, const float* dyn_beta_fn, const float* dyn_beta_scale,
@@ -644,4 +645,24 @@ extern "C" int e2k_hc_bwd(const void* Xin, const void* yprev, const float* coef_
         E2K_CHECK_LAUNCH();
     }
     return 0;
+}
+
+// ---- C ABI: every compute entry point goes through e2k::dispatch (plan.h) so that a launch plan can record it
+
+extern "C" int e2k_hc_fwd(const void* Xin, const void* yprev, const float* coef_prev, void* Mout, void* bin,
+                          float* coef, const float* static_beta, const float* static_alpha,
+                          const float* dyn_alpha_fn, const float* dyn_alpha_scale, const float* dyn_beta_fn,
+                          const float* dyn_beta_scale, const float* gamma, int Mtok, int D, int has_depth,
+                          int has_width, void* stream) {
+    return e2k::dispatch("hc_fwd", hc_fwd_impl, Xin, yprev, coef_prev, Mout, bin, coef, static_beta, static_alpha, dyn_alpha_fn, dyn_alpha_scale, dyn_beta_fn, dyn_beta_scale, gamma, Mtok, D, has_depth, has_width, stream);
+}
+
+extern "C" int e2k_hc_bwd(const void* Xin, const void* yprev, const float* coef_prev, const void* G,
+                          const void* dbin, const void* ycur, const float* coef, void* dR, void* dyprev,
+                          const float* static_beta, const float* static_alpha, const float* dyn_alpha_fn,
+                          const float* dyn_alpha_scale, const float* dyn_beta_fn, const float* dyn_beta_scale,
+                          const float* gamma, float* g_static_beta, float* g_static_alpha, float* g_dyn_alpha_fn,
+                          float* g_dyn_alpha_scale, float* g_dyn_beta_fn, float* g_dyn_beta_scale, float* g_gamma,
+                          float* partial, int Mtok, int D, int has_depth, int has_width, void* stream) {
+    return e2k::dispatch("hc_bwd", hc_bwd_impl, Xin, yprev, coef_prev, G, dbin, ycur, coef, dR, dyprev, static_beta, static_alpha, dyn_alpha_fn, dyn_alpha_scale, dyn_beta_fn, dyn_beta_scale, gamma, g_static_beta, g_static_alpha, g_dyn_alpha_fn, g_dyn_alpha_scale, g_dyn_beta_fn, g_dyn_beta_scale, g_gamma, partial, Mtok, D, has_depth, has_width, stream);
 }

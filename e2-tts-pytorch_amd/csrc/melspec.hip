@@ -5,6 +5,7 @@
 // four HBM round trips; here a workgroup keeps 4 frames in LDS from the raw samples to the log-mel row.
 // HBM-bound: algorithmic bytes = 4*nw (samples, read once; the 4x frame overlap is served from L2) + 4*n_mels*frames.
 #include "e2k_device.h"
+#include "plan.h"
 #include "../../include/e2k.h"
 
 using namespace e2k;
@@ -104,7 +105,7 @@ __global__ __launch_bounds__(256) void melspec_kernel(MelArgs p) {
 
 }  // namespace
 
-extern "C" int e2k_melspec(const float* wave, int64_t nw, const float* window, const float* fb, const float* twc,
+static int melspec_impl(const float* wave, int64_t nw, const float* window, const float* fb, const float* twc,
                            const float* tws, float* out, int B, int n_fft, int hop, int n_mels, void* stream) {
     if (B <= 0 || nw <= 0) return 0;
     if (n_fft != NFFT || n_mels > 256 || n_mels <= 0 || hop <= 0 || nw <= NFFT / 2) return E2K_ERR_SHAPE;
@@ -115,7 +116,7 @@ extern "C" int e2k_melspec(const float* wave, int64_t nw, const float* window, c
     return 0;
 }
 
-extern "C" int e2k_melspec_ragged(const float* wave, int64_t nw, const int32_t* lens, const float* window, const float* fb,
+static int melspec_ragged_impl(const float* wave, int64_t nw, const int32_t* lens, const float* window, const float* fb,
                                   const float* twc, const float* tws, float* out, float pad_value, int B, int n_fft, int hop,
                                   int n_mels, void* stream) {
     if (B <= 0 || nw <= 0) return 0;
@@ -125,4 +126,17 @@ extern "C" int e2k_melspec_ragged(const float* wave, int64_t nw, const int32_t* 
     hipLaunchKernelGGL(melspec_kernel, dim3((a.frames + FR - 1) / FR, B), dim3(256), 0, (hipStream_t)stream, a);
     E2K_CHECK_LAUNCH();
     return 0;
+}
+
+// ---- C ABI: every compute entry point goes through e2k::dispatch (plan.h) so that a launch plan can record it
+
+extern "C" int e2k_melspec(const float* wave, int64_t nw, const float* window, const float* fb, const float* twc,
+                           const float* tws, float* out, int B, int n_fft, int hop, int n_mels, void* stream) {
+    return e2k::dispatch("melspec", melspec_impl, wave, nw, window, fb, twc, tws, out, B, n_fft, hop, n_mels, stream);
+}
+
+extern "C" int e2k_melspec_ragged(const float* wave, int64_t nw, const int32_t* lens, const float* window, const float* fb,
+                                  const float* twc, const float* tws, float* out, float pad_value, int B, int n_fft, int hop,
+                                  int n_mels, void* stream) {
+    return e2k::dispatch("melspec_ragged", melspec_ragged_impl, wave, nw, lens, window, fb, twc, tws, out, pad_value, B, n_fft, hop, n_mels, stream);
 }

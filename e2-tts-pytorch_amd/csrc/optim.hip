@@ -7,6 +7,7 @@
 // the ADOPT update, decoupled weight decay, refreshes the bf16 compute shadow and
 // optionally folds the gradient back to zero -- 4 reads + 3-4 writes per element.  HBM bound.
 #include "e2k_device.h"
+#include "plan.h"
 #include "../../include/e2k.h"
 
 using namespace e2k;
@@ -106,7 +107,7 @@ int grid_for(long n) {
 
 }  // namespace
 
-extern "C" int e2k_sumsq_f32(const float* x, int64_t n, double* out, void* stream) {
+static int sumsq_f32_impl(const float* x, int64_t n, double* out, void* stream) {
     if (n <= 0) return 0;
     if (!x || !out) return E2K_ERR_ARG;
     if ((uintptr_t)x & 15) return E2K_ERR_ALIGN;
@@ -115,7 +116,7 @@ extern "C" int e2k_sumsq_f32(const float* x, int64_t n, double* out, void* strea
     return 0;
 }
 
-extern "C" int e2k_adopt_step(float* p, const float* g, float* m, float* v, void* shadow_bf16, int64_t n, float lr,
+static int adopt_step_impl(float* p, const float* g, float* m, float* v, void* shadow_bf16, int64_t n, float lr,
                               float beta1, float beta2, float eps, float weight_decay, float max_grad_norm,
                               const double* gsumsq, int step, void* stream) {
     if (n <= 0) return 0;
@@ -131,11 +132,27 @@ extern "C" int e2k_adopt_step(float* p, const float* g, float* m, float* v, void
     return 0;
 }
 
-extern "C" int e2k_ema_update(float* ema, const float* p, int64_t n, float decay, void* stream) {
+static int ema_update_impl(float* ema, const float* p, int64_t n, float decay, void* stream) {
     if (n <= 0) return 0;
     if (!ema || !p) return E2K_ERR_ARG;
     if (((uintptr_t)ema | (uintptr_t)p) & 15) return E2K_ERR_ALIGN;
     hipLaunchKernelGGL(ema_kernel, dim3(grid_for(n)), dim3(256), 0, (hipStream_t)stream, ema, p, (long)n, 1.f - decay);
     E2K_CHECK_LAUNCH();
     return 0;
+}
+
+// ---- C ABI: every compute entry point goes through e2k::dispatch (plan.h) so that a launch plan can record it
+
+extern "C" int e2k_sumsq_f32(const float* x, int64_t n, double* out, void* stream) {
+    return e2k::dispatch("sumsq_f32", sumsq_f32_impl, x, n, out, stream);
+}
+
+extern "C" int e2k_adopt_step(float* p, const float* g, float* m, float* v, void* shadow_bf16, int64_t n, float lr,
+                              float beta1, float beta2, float eps, float weight_decay, float max_grad_norm,
+                              const double* gsumsq, int step, void* stream) {
+    return e2k::dispatch("adopt_step", adopt_step_impl, p, g, m, v, shadow_bf16, n, lr, beta1, beta2, eps, weight_decay, max_grad_norm, gsumsq, step, stream);
+}
+
+extern "C" int e2k_ema_update(float* ema, const float* p, int64_t n, float decay, void* stream) {
+    return e2k::dispatch("ema_update", ema_update_impl, ema, p, n, decay, stream);
 }

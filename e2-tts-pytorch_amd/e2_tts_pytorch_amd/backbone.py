@@ -11,6 +11,7 @@ There is no PyTorch fallback for the kernels: without libe2k.so (or on CPU tenso
 """
 from __future__ import annotations
 
+import contextlib
 import random as _pyrandom
 from types import SimpleNamespace as NS
 
@@ -137,7 +138,7 @@ class TextAudioCrossCondition(_Holder):       # e2_tts.py:486-513
             nn.init.zeros_(self.audio_to_text.weight)
 
 
-class RandomFourierEmbed(Module):             # e2_tts.py:355-364 (tiny, stays in torch)
+class RandomFourierEmbed(Module):             # e2_tts.py:355-364 (parameter holder of the time-conditioning kernel; forward kept for tools)
     def __init__(self, dim):
         super().__init__()
         assert dim % 2 == 0
@@ -305,14 +306,42 @@ class Transformer(Module):
         self.final_norm = RMSNorm(dim)
 
         # flat storage is created lazily on the first forward on a device (and re-created if parameters were moved)
-        self._flat = None
         self._build_layout()
         self._grad_sync = None          # set by ddp.DataParallel: called with (grad_flat, start, end) per finished slab
+        self._reset_runtime()
+
+    # runtime state (device buffers, caches, recorded plans): never part of the module's identity -- a deep copy (the
+    # trainer's EMA, trainer.py:170) starts without it and rebuilds its own on first use
+    _RUNTIME = ('_flat', '_shadow', '_shadowT', '_shadow_key', '_vcache', '_rot_cache', '_plans', '_pool', '_pg', '_no_pgrads')
+
+    def _reset_runtime(self):
+        self._flat = None
         self._vcache = {}
-        self.use_graphs = False         # enable_graphs(): capture forward / per-layer backward into HIP graphs
-        self._graphs = {}
-        self._persist_grads = False     # enable_persistent_grads(): one flat gradient buffer for the life of the module
+        self._rot_cache = {}
+        self._plans_on = getattr(self, '_plans_on', True)       # enable_plans(): record-and-replay of the launch schedule
+        self._max_plans = getattr(self, '_max_plans', 4)
+        self._plans = {}
+        self._plan_tick = 0
+        self._plan_py_seed = False
+        self._pool = None
+        self._persist_grads = getattr(self, '_persist_grads', False)   # enable_persistent_grads()
         self._pg = None
+
+    def __deepcopy__(self, memo):
+        import copy
+        saved = {k: self.__dict__.pop(k) for k in self._RUNTIME if k in self.__dict__}
+        hook, self._grad_sync = self._grad_sync, None
+        try:
+            new = self.__class__.__new__(self.__class__)
+            memo[id(self)] = new
+            for k, v in self.__dict__.items():
+                new.__dict__[k] = copy.deepcopy(v, memo)
+        finally:
+            self.__dict__.update(saved)
+            self._grad_sync = hook
+        new._reset_runtime()
+        new._build_layout()              # slots must point at the copy's parameters
+        return new
 
     # ------------------------------------------------------------------ layout
 
@@ -459,6 +488,8 @@ class Transformer(Module):
             p.data = flat[off:off + p.numel()].view(p.shape)
         self._flat = flat
         self._vcache = {}
+        self._drop_plans()              # recorded launches point into the old buffers
+        self._pg = None
         self._shadow = torch.zeros(lay.n, dtype=bf16, device=device)
         self._shadowT = torch.zeros(max(self._tsize, 8), dtype=bf16, device=device)
         self._shadow_key = None
@@ -525,55 +556,122 @@ class Transformer(Module):
         if exists(times):
             if times.ndim == 0:
                 times = times[None].expand(B)
-            cond = self.time_cond_mlp(times.float())               # (B, D) fp32, tiny: stays in torch
+            cond = self._time_cond(times)                          # (B, D) fp32: RandomFourierEmbed + Linear + SiLU kernel
         need_grad = torch.is_grad_enabled() and (
             x.requires_grad or (exists(cond) and cond.requires_grad) or (exists(text_embed) and text_embed.requires_grad)
             or any(p.requires_grad for p, _ in self._layout.slots))
-        if self.use_graphs and x.is_cuda:
-            st = self._graph_state(x, cond, text_embed, mask, need_grad)
-            if exists(st):
-                if need_grad:
-                    return _GraphFn.apply(self, st, x, cond, text_embed, mask, *self._params_in_order())
-                self._graph_inputs(st, x, cond, text_embed, mask)
-                st.fwd.replay()
-                return st.out.clone()
-        self._sync(x.device)
+        dev = x.device
+        rot = self._rot_table(T + self.num_registers, dev)
+        if self._plans_on and (x.is_cuda or ops.host_ok()):
+            out = self._plan_forward(x, cond, text_embed, mask, need_grad, rot)
+            if exists(out):
+                return out
+        self._sync(dev)
         if need_grad:
-            return _BackboneFn.apply(self, x, cond, text_embed, mask, *self._params_in_order())
-        with ops.pinned_stream(x.device):
-            return self._run_forward(x, cond, text_embed, mask, False).out
+            return _BackboneFn.apply(self, x, cond, text_embed, mask, rot, *self._params_in_order())
+        with ops.pinned_stream(dev):
+            return self._run_forward(x, cond, text_embed, mask, False, rot=rot).out
 
-    # ------------------------------------------------------------------ HIP graphs
-    # The eager schedule costs ~55 us of Python per kernel launch (~150 ms per cfg3 step, as much as the kernels take).
-    # With use_graphs the whole forward is captured once per (shape, text?, mask?, train?, grad?) into one HIP graph
-    # and the backward into one graph per layer (so ddp's per-layer gradient all-reduce still overlaps); later calls
-    # copy the inputs into static buffers and replay.  Dropout masks stay fresh: the kernels read the seed from a
-    # device word that is refilled before every replay.
+    def _time_cond(self, times):
+        mlp = self.time_cond_mlp
+        return _TimeCondFn.apply(times.float().contiguous(), mlp[0].weights, mlp[1].weight, mlp[1].bias)
 
-    def enable_graphs(self, on: bool = True, alias_grads: bool = False):
-        """alias_grads: hand out the parameter gradients as views of the graph's static gradient buffer instead of a copy
-        (saves one read + write of every gradient per step: 5.8 GB at cfg3).  They are then only valid until the next
-        backward replay, and must not be accumulated across backward passes (use `zero_grad(set_to_none=True)` between
-        steps, as the reference trainer's optimizer.step() / zero_grad() sequence does, `trainer.py:275-277`)."""
-        self.use_graphs = on
-        self._alias_grads = bool(alias_grads) and on
+    def _rot_table(self, N, dev):
+        key = (N, str(dev))
+        v = self._rot_cache.get(key)
+        if v is None:
+            if len(self._rot_cache) > 16:
+                self._rot_cache.clear()
+            v = self._rot_cache[key] = ops.rotary_table(N, dev)
+        return v
+
+    # ------------------------------------------------------------------ launch plans
+    # The eager schedule costs ~35 us of Python / ctypes per kernel launch -- as long as the kernels of a dim-1024 step take.
+    # A plan is the recorded launch sequence of one input signature (csrc/plan.h): the second time a signature is seen its
+    # forward is run with the C ABI in recording mode, inside a private memory pool so that every buffer it touched stays
+    # reserved; from then on a forward is `copy the inputs into the plan's static buffers + e2k_plan_run`, a backward one
+    # e2k_plan_run per layer segment (the data-parallel hook fires between segments exactly as in the eager schedule).
+    # Launches are issued eagerly from C++ (no HIP graph), dropout masks stay fresh through a device-side seed word.
+
+    def enable_plans(self, on: bool = True, max_plans: int = 4):
+        """Record-and-replay of the launch schedule (default: on).  A plan keeps the activations of its signature resident
+        (~50 GB for a dim-1024 / depth-24 training step at B = 8); at most `max_plans` signatures are kept (least recently
+        used first out), everything else runs through the eager schedule.  Gradients of a recorded training step live in
+        one flat buffer that every backward pass OVERWRITES (see enable_persistent_grads)."""
+        self._plans_on = bool(on)
+        self._max_plans = int(max_plans)
         if not on:
-            self._graphs = {}
+            self._drop_plans()
         return self
 
-    def _graph_state(self, x, cond, text_embed, mask, need_grad):
+    def _drop_plans(self):
+        lib = None
+        for st in self._plans.values():
+            if isinstance(st, NS):
+                lib = lib or ops.lib()
+                for h in (st.fwd, st.bwd):
+                    if h:
+                        lib.e2k_plan_free(h)
+        self._plans = {}
+
+    def _pool_ctx(self, dev):
+        if dev.type != 'cuda':
+            return contextlib.nullcontext()
+        if self._pool is None:
+            self._pool = torch.cuda.MemPool()
+        return torch.cuda.use_mem_pool(self._pool, device=dev)
+
+    def _plan_forward(self, x, cond, text_embed, mask, need_grad, rot):
         p_drop = self.dropout if self.training else 0.
-        key = (tuple(x.shape), x.dtype, exists(text_embed), exists(mask), need_grad, p_drop, x.device.index)
-        st = self._graphs.get(key)
-        if st is None:
-            self._graphs[key] = 'warm'              # first call with this signature runs eagerly (lazy inits, packing)
+        key = (tuple(x.shape), exists(text_embed), exists(mask), need_grad, p_drop, str(x.device))
+        st = self._plans.get(key)
+        if st is None:                              # first sighting: eager (one-off shapes never pay for a recording)
+            if len(self._plans) > 64:
+                self._plans = {k: v for k, v in self._plans.items() if isinstance(v, NS)}
+            self._plans[key] = 'seen'
             return None
-        if st == 'warm':
-            st = self._capture(x, cond, text_embed, mask, need_grad)
-            self._graphs[key] = st
+        if st == 'seen':
+            self._sync(x.device)
+            live = [k for k, v in self._plans.items() if isinstance(v, NS)]
+            if len(live) >= self._max_plans:
+                old = min(live, key=lambda k: self._plans[k].used)
+                if self._plans[old].outstanding:
+                    return None
+                ost = self._plans.pop(old)
+                for h in (ost.fwd, ost.bwd):
+                    if h:
+                        ops.lib().e2k_plan_free(h)
+            st = self._plan_new(key, x, cond, text_embed, mask, need_grad, p_drop)
+            self._plans[key] = st
+        elif st.outstanding or not self._is_packed():
+            # a second forward of the same signature before the backward of the first would overwrite its saved
+            # activations; a re-packed parameter buffer (`.to()`) invalidates recorded pointers
+            if not self._is_packed():
+                self._drop_plans()
+            return None
+        self._plan_tick += 1
+        st.used = self._plan_tick
+        if need_grad:
+            return _PlanFn.apply(self, st, rot, x, cond, text_embed, mask, *self._params_in_order())
+        if exists(st.fwd):
+            self._sync(x.device)                    # eval: parameters rarely change; refresh the bf16 shadows if they did
+        self._plan_inputs(st, x, cond, text_embed, mask)
+        self._plan_run_forward(st, rot)
+        return st.out.detach()
+
+    def _plan_new(self, key, x, cond, text_embed, mask, need_grad, p_drop):
+        dev = x.device
+        st = NS(key=key, need_grad=need_grad, fwd=None, bwd=None, segs=None, outstanding=False, used=0, keep=[], meta_f=[], meta_b=[])
+        with self._pool_ctx(dev):
+            st.x = torch.empty(x.shape, dtype=f32, device=dev)
+            st.cond = torch.empty(cond.shape, dtype=f32, device=dev) if exists(cond) else None
+            st.text = torch.empty(text_embed.shape, dtype=f32, device=dev) if exists(text_embed) else None
+            st.mask = torch.empty(mask.shape, dtype=torch.bool, device=dev) if exists(mask) else None
+            st.seed = torch.zeros(1, dtype=torch.int32, device=dev) if p_drop > 0 else None
+            st.dout = torch.empty(x.shape, dtype=f32, device=dev) if need_grad else None
         return st
 
-    def _graph_inputs(self, st, x, cond, text_embed, mask):
+    def _plan_inputs(self, st, x, cond, text_embed, mask):
         st.x.copy_(x.detach())
         if exists(cond):
             st.cond.copy_(cond.detach())
@@ -582,52 +680,87 @@ class Transformer(Module):
         if exists(mask):
             st.mask.copy_(mask)
         if exists(st.seed):
-            st.seed.fill_(int(torch.randint(0, 2 ** 31 - 1, (1,)).item()))
+            st.seed.fill_(_pyrandom.getrandbits(31) if self._plan_py_seed else int(torch.randint(0, 2 ** 31 - 1, (1,)).item()))
 
-    def _capture(self, x, cond, text_embed, mask, need_grad):
-        dev = x.device
-        self._sync(dev)
-        st = NS(pool=torch.cuda.graph_pool_handle(), need_grad=need_grad)
-        st.x = torch.empty_like(x.detach())
-        st.cond = torch.empty_like(cond.detach()) if exists(cond) else None
-        st.text = torch.empty_like(text_embed.detach()) if exists(text_embed) else None
-        st.mask = torch.empty_like(mask) if exists(mask) else None
-        p_drop = self.dropout if self.training else 0.
-        st.seed = torch.zeros(1, dtype=torch.int32, device=dev) if p_drop > 0 else None
-        self._graph_inputs(st, x, cond, text_embed, mask)
-        torch.cuda.synchronize(dev)
-        st.fwd = torch.cuda.CUDAGraph()
-        with torch.cuda.graph(st.fwd, pool=st.pool):
-            self._recast()
-            with ops.pinned_stream(dev):
-                run = self._run_forward(st.x, st.cond, st.text, st.mask, need_grad, seed_dev=st.seed)
+    def _plan_run_forward(self, st, rot):
+        dev = st.x.device
+        lib = ops.lib()
+        if exists(st.fwd):
+            lib.e2k_plan_run(st.fwd, 0, -1, ops.raw_stream(dev))
+            return
+        # first run of this plan: execute the schedule with the C ABI recording, inside the pool
+        with self._pool_ctx(dev), _RecordGuard(st.keep if dev.type != 'cuda' else None):
+            ops.begin_recording(st.meta_f)
+            try:
+                if st.need_grad:
+                    self._recast()                  # training: the parameters change every step
+                with ops.pinned_stream(dev):
+                    run = self._run_forward(st.x, st.cond, st.text, st.mask, st.need_grad, seed_dev=st.seed, rot=rot)
+                st.fwd = ops.end_recording()
+            except BaseException:
+                ops.abort_recording()
+                raise
         st.run, st.out = run, run.out
-        st.bwd = None
-        if need_grad:
-            st.dout = torch.zeros_like(run.out)
-            st.bwd = []
-            gen = self._backward_gen(run, st.dout)
-            done = False
-            import warnings
-            while not done:
-                gr = torch.cuda.CUDAGraph()
-                slab = None
-                with warnings.catch_warnings():
-                    # the tail segment after the last gradient slab can be empty: that is fine
-                    warnings.filterwarnings('ignore', message='The CUDA Graph is empty')
-                    with torch.cuda.graph(gr, pool=st.pool), ops.pinned_stream(dev):
+
+    def _plan_run_backward(self, st):
+        dev = st.x.device
+        lib = ops.lib()
+        sync = self._grad_sync
+        if exists(st.bwd):
+            stream = ops.raw_stream(dev)
+            for first, count, slab in st.segs:
+                lib.e2k_plan_run(st.bwd, first, count, stream)
+                if exists(sync) and exists(slab):
+                    sync(st.gflat, slab[0], slab[1])
+        else:
+            self._pg_state(dev)
+            ops.begin_recording(st.meta_b)
+            try:
+                gen = self._backward_gen(st.run, st.dout, True)
+                segs, first = [], 0
+                while True:
+                    slab = None
+                    with self._pool_ctx(dev), _RecordGuard(st.keep if dev.type != 'cuda' else None), ops.pinned_stream(dev):
                         try:
                             slab = next(gen)
                         except StopIteration as e:
                             st.dx, st.dcond, st.dtext, st.gflat = e.value
-                            done = True
-                st.bwd.append((gr, slab))
-        torch.cuda.synchronize(dev)
-        return st
+                    n = ops.recorded()
+                    if n > first:
+                        segs.append((first, n - first, slab))
+                        first = n
+                    if slab is None:
+                        break
+                    if exists(sync):
+                        sync(st.run.gflat, slab[0], slab[1])
+                st.bwd, st.segs = ops.end_recording(), segs
+            except BaseException:
+                ops.abort_recording()
+                raise
+        if exists(sync):
+            sync(st.gflat, None, None)
+        if self._persist_grads:
+            self._attach_grads()
+            return self._no_pgrads
+        # default: hand the gradients to autograd (AccumulateGrad, DDP hooks, accumulation over several backward passes
+        # all behave as usual).  The plan's gradient buffer is rewritten by the next replay, hence the copy (one read +
+        # write of the gradients, ~1 ms at dim 1024 / depth 24); enable_persistent_grads() removes it.
+        gflat = st.gflat.clone()
+        return [gflat[off:off + p.numel()].view(p.shape) if p.requires_grad else None for p, off in self._layout.slots]
+
+    def plan_profile(self):
+        """HIP-event time of every recorded launch of the most recently used plan: list of dict(name, ms, flops, phase)"""
+        live = [v for v in self._plans.values() if isinstance(v, NS) and exists(v.fwd)]
+        assert live, 'no recorded plan'
+        st = max(live, key=lambda v: v.used)
+        return ops.profile_plan(st.fwd, st.meta_f, 'fwd', st.x.device) + (
+            ops.profile_plan(st.bwd, st.meta_b, 'bwd', st.x.device) if exists(st.bwd) else [])
 
     # ------------------------------------------------------------------ forward schedule
 
-    def _run_forward(self, x_in, cond, text_embed, mask, want_tape, seed_dev=None):
+    def _run_forward(self, x_in, cond, text_embed, mask, want_tape, seed_dev=None, rot=None):
+        """the whole forward as a sequence of e2k calls (nothing else touches the device in here: a launch plan replays
+        exactly the recorded calls, so a tensor-library op in between would silently be skipped on replay)"""
         dev = x_in.device
         B, T, D = x_in.shape
         Dt, R, L = self.dim_text, self.num_registers, self.depth
@@ -637,44 +770,34 @@ class Transformer(Module):
         tape = run.tape
         p_drop = self.dropout if self.training else 0.
         run.p_drop = p_drop
-        run.seed_dev = seed_dev             # graph mode: the kernels read the seed from this device word
+        run.seed_dev = seed_dev             # plan mode: the kernels read the seed from this device word
         run.seed = int(torch.randint(0, 2 ** 31 - 1, (1,)).item()) if (p_drop > 0 and seed_dev is None) else 0
         g = self._glob
 
-        # masks
-        Npad = (N + 63) // 64 * 64
-        kmask = torch.zeros((B, Npad), dtype=torch.uint8, device=dev)
-        kmask[:, :R] = 1
+        # masks: registers are always attended (e2_tts.py:771), the pad up to a multiple of 64 never
         if exists(mask):
-            kmask[:, R:N] = mask.to(torch.uint8)
-            run.mask_n = kmask[:, :N].contiguous()
-        else:
-            kmask[:, R:N] = 1
-            run.mask_n = None
-        run.kmask = kmask
-        run.rot = ops.rotary_table(N, dev)
+            mask = mask if mask.is_contiguous() else mask.contiguous()
+        run.kmask, run.mask_n = ops.build_masks(mask, B, T, R, dev, want_mask_n=exists(mask))
+        run.rot = rot if exists(rot) else ops.rotary_table(N, dev)
 
         # time conditioning, hoisted out of the layer loop: one GEMM for every layer's gamma / gate
         if self.cond_on_time:
-            cb = cond.to(bf16).contiguous()
+            cond = cond if (cond.dtype == f32 and cond.is_contiguous()) else cond.float().contiguous()
+            cb = ops.cast_bf16(cond, torch.empty(cond.shape, dtype=bf16, device=dev))
             wc = self._w(g.wcond, 4 * L * D, D)
             condall = ops.gemm_nt(cb, wc, bias=self._f(g.bcond, 4 * L * D), out_dtype=f32)       # (B, 4LD)
             run.cb, run.condall = cb, condall
-            run.gates = torch.sigmoid(condall)
-            run.dcond = torch.zeros_like(condall) if want_tape else None
+            run.gates = ops.sigmoid(condall)
+            run.dcond = ops.zeros(condall.shape, f32, dev) if want_tape else None
 
         # pack: abs-pos + registers, expand to 4 identical streams (token-major)
-        xs = x_in.float()
-        if exists(self.abs_pos_emb):
-            xs = xs + self._f(g.abs_pos, self.max_seq_len * D).view(self.max_seq_len, D)[:T]
-        regs = self._f(g.registers, R * D).view(R, D)
-        X0 = torch.cat([regs[None].expand(B, -1, -1), xs], dim=1).to(bf16)
-        sx = _Stream(X0[:, :, None, :].expand(B, N, 4, D).contiguous().view(Mtok, 4, D), 'x')
+        xs = x_in if (x_in.dtype == f32 and x_in.is_contiguous()) else x_in.float().contiguous()
+        apos = self._f(g.abs_pos, self.max_seq_len * D).view(self.max_seq_len, D) if exists(self.abs_pos_emb) else None
+        sx = _Stream(ops.stream_pack_fwd(xs, apos, self._f(g.registers, R * D).view(R, D)), 'x')
         st = None
         if exists(text_embed):
-            tregs = self._f(g.text_registers, R * Dt).view(R, Dt)
-            T0 = torch.cat([tregs[None].expand(B, -1, -1), text_embed.float()], dim=1).to(bf16)
-            st = _Stream(T0[:, :, None, :].expand(B, N, 4, Dt).contiguous().view(Mtok, 4, Dt), 't')
+            te = text_embed if (text_embed.dtype == f32 and text_embed.is_contiguous()) else text_embed.float().contiguous()
+            st = _Stream(ops.stream_pack_fwd(te, None, self._f(g.text_registers, R * Dt).view(R, Dt)), 't')
         run.has_text = exists(st)
         run.vfirst = {'x': None, 't': None}
         run.attn0 = {'x': None, 't': None}
@@ -701,12 +824,11 @@ class Transformer(Module):
             self._materialize(run, st)      # (its value is unused; keeps the tape uniform)
 
         # tail: drop registers, sum the 4 streams, final RMSNorm
-        Xf = sx.X.view(B, N, 4, D)[:, R:]
-        xsum = Xf.float().sum(dim=2).to(bf16).reshape(B * T, D)
+        xsum = ops.stream_unpack_fwd(sx.X, B, T, R)
         gfin = self._f(g.final_g, D).view(1, D)
         y, rn = ops.rmsnorm_fwd(xsum, gfin, 0., B * T)
         run.tail = (xsum, rn)
-        run.out = y.view(B, T, D).float()
+        run.out = ops.cast_f32(y).view(B, T, D)
         return run
 
     # -- stream helpers --------------------------------------------------------
@@ -853,7 +975,7 @@ class Transformer(Module):
 
     def enable_persistent_grads(self, on: bool = True):
         """Keep one flat fp32 gradient buffer for the life of the module (eager launches only; HIP-graph replay has
-        `enable_graphs(alias_grads=True)` for the same purpose).  Every backward pass OVERWRITES the gradients: there is
+        recorded plans use the same buffer).  Every backward pass OVERWRITES the gradients: there is
         no accumulation over several backward passes, `zero_grad()` between steps is unnecessary (and with
         `set_to_none=True` only costs a re-attach), and the module must not appear twice in one autograd graph.  Tensor
         hooks registered on the parameters do not fire (the gradients do not travel through AccumulateGrad)."""
@@ -885,7 +1007,7 @@ class Transformer(Module):
         lay, g = self._layout, self._glob
         if persist:
             pg = self._pg_state(dev)
-            gflat, gc, mk = pg.buf.zero_(), pg.gcache, self._g
+            gflat, gc, mk = ops.fill_(pg.buf), pg.gcache, self._g
 
             def G(off, *shape):                       # the buffer outlives the step, so do its views
                 v = gc.get((off, shape))
@@ -893,21 +1015,21 @@ class Transformer(Module):
                     v = gc[(off, shape)] = mk(gflat, off, *shape)
                 return v
         else:
-            gflat = torch.zeros(lay.n, dtype=f32, device=dev)
+            gflat = ops.zeros((lay.n,), f32, dev)
             G = lambda off, *shape: self._g(gflat, off, *shape)
         run.gflat = gflat
 
         # tail
         xsum, rn = run.tail
         gfin = self._f(g.final_g, D).view(1, D)
-        dxs = ops.rmsnorm_bwd(dout.reshape(B * T, D).to(bf16).contiguous(), xsum, rn, gfin, 0., B * T, G(g.final_g, 1, D))
-        dX = torch.zeros((B, N, 4, D), dtype=bf16, device=dev)
-        dX[:, R:] = dxs.view(B, T, 1, D)
-        grads = {'x': dX.view(Mtok, 4, D), 't': None}
+        do = dout if (dout.dtype == f32 and dout.is_contiguous()) else dout.float().contiguous()
+        dob = ops.cast_bf16(do.view(-1), torch.empty((B * T, D), dtype=bf16, device=dev))
+        dxs = ops.rmsnorm_bwd(dob, xsum, rn, gfin, 0., B * T, G(g.final_g, 1, D))
+        grads = {'x': ops.stream_unpack_bwd(dxs, B, T, R), 't': None}
         if run.has_text:
-            grads['t'] = torch.zeros((Mtok, 4, Dt), dtype=bf16, device=dev)
-        dvfirst = {'x': torch.zeros((B, self.heads, N, 64), dtype=f32, device=dev),
-                   't': torch.zeros((B, self.text_heads, N, 64), dtype=f32, device=dev) if run.has_text else None}
+            grads['t'] = ops.zeros((Mtok, 4, Dt), bf16, dev)
+        dvfirst = {'x': ops.zeros((B, self.heads, N, 64), f32, dev),
+                   't': ops.zeros((B, self.text_heads, N, 64), f32, dev) if run.has_text else None}
         skip_grads = []
 
         for ent in reversed(run.tape):
@@ -971,33 +1093,21 @@ class Transformer(Module):
                 raise AssertionError(kind)
 
         # pack backward (4 identical streams -> sum; registers; abs-pos)
-        dX0 = grads['x'].view(B, N, 4, D).float().sum(dim=2)
-        G(g.registers, R, D).add_(dX0[:, :R].sum(dim=0))
-        dxs = dX0[:, R:]
-        if exists(g.abs_pos):
-            G(g.abs_pos, self.max_seq_len, D)[:T].add_(dxs.sum(dim=0))
+        dabs = G(g.abs_pos, self.max_seq_len, D) if exists(g.abs_pos) else None
+        dxs = ops.stream_pack_bwd(grads['x'], B, T, R, G(g.registers, R, D), dabs)
         dtext = None
         if run.has_text:
-            dT0 = grads['t'].view(B, N, 4, Dt).float().sum(dim=2)
-            G(g.text_registers, R, Dt).add_(dT0[:, :R].sum(dim=0))
-            dtext = dT0[:, R:]
+            dtext = ops.stream_pack_bwd(grads['t'], B, T, R, G(g.text_registers, R, Dt), None)
         dcond = None
         if self.cond_on_time:
-            dc = run.dcond.view(B, L, 4, D)
-            gv = run.gates.view(B, L, 4, D)
-            dc[:, :, 1].mul_(1. - gv[:, :, 1])
-            dc[:, :, 3].mul_(1. - gv[:, :, 3])
-            dcb = run.dcond.to(bf16)
+            # gate slots x (1 - gate), bf16 copies (plain and transposed) for the two GEMMs below; only the AdaLN-Zero
+            # biases (slots 1, 3 of a layer's row) receive a bias gradient -- slots 0, 2 are layout holes that must
+            # keep a zero gradient (AdaptiveRMSNorm.to_gamma has no bias), or the flat optimizer would train them
+            dcb, dct = ops.cond_bwd_prep(run.dcond, run.gates, G(g.bcond, 4 * L * D), B, L, D)
             ops.gemm_tn(dcb, run.cb, G(g.wcond, 4 * L * D, D))                    # d W_cond
-            # only slots 1 and 3 of a layer's row are parameters (the AdaLN-Zero biases); slots 0 and 2 are layout holes
-            # (AdaptiveRMSNorm.to_gamma has no bias) and must keep a zero gradient, or the flat optimizer would train them
-            G(g.bcond, 4 * L * D).view(L, 4, D)[:, 1::2].add_(run.dcond.sum(dim=0).view(L, 4, D)[:, 1::2])
-            KB = _r8(B)
-            dct = torch.zeros((4 * L * D, KB), dtype=bf16, device=dev)
-            dct[:, :B] = dcb.t()
-            dcT = torch.zeros((D, KB), dtype=f32, device=dev)
+            dcT = ops.zeros((D, dct.shape[1]), f32, dev)
             ops.gemm_tn(self._w(g.wcond, 4 * L * D, D), dct, dcT)                 # (D, B) = W_cond^T . dcond^T
-            dcond = dcT[:, :B].t().contiguous()
+            dcond = ops.transpose_f32(dcT, B)
         yield 0, g.end
         return dxs, dcond, dtext, gflat
 
@@ -1062,10 +1172,10 @@ class _BackboneFn(torch.autograd.Function):
     """one autograd node around the hand-scheduled forward / backward of the whole backbone"""
 
     @staticmethod
-    def forward(ctx, module, x_in, cond, text_embed, mask, *params):
+    def forward(ctx, module, x_in, cond, text_embed, mask, rot, *params):
         with ops.pinned_stream(x_in.device):
             run = module._run_forward(x_in.detach(), cond.detach() if exists(cond) else None,
-                                      text_embed.detach() if exists(text_embed) else None, mask, True)
+                                      text_embed.detach() if exists(text_embed) else None, mask, True, rot=rot)
         ctx.run, ctx.module = run, module
         ctx.has_cond, ctx.has_text = exists(cond), exists(text_embed)
         ctx.x_dtype = x_in.dtype
@@ -1078,35 +1188,79 @@ class _BackboneFn(torch.autograd.Function):
         ctx.run = None
         dx, dcond, dtext, pgrads = module._run_backward(run, dout.contiguous())
         return (None, dx.to(ctx.x_dtype), dcond if ctx.has_cond else None,
-                dtext.to(ctx.t_dtype) if ctx.has_text else None, None, *pgrads)
+                dtext.to(ctx.t_dtype) if ctx.has_text else None, None, None, *pgrads)
 
 
-class _GraphFn(torch.autograd.Function):
-    """autograd node of the HIP-graph path: copies inputs into the static buffers and replays the captured graphs"""
+class _PlanFn(torch.autograd.Function):
+    """autograd node of a recorded plan: copy the inputs into the plan's static buffers, replay (or, the first time,
+    record) the launch sequence"""
 
     @staticmethod
-    def forward(ctx, module, st, x_in, cond, text_embed, mask, *params):
-        module._graph_inputs(st, x_in, cond, text_embed, mask)
-        st.fwd.replay()
+    def forward(ctx, module, st, rot, x_in, cond, text_embed, mask, *params):
+        module._plan_inputs(st, x_in, cond, text_embed, mask)
+        module._plan_run_forward(st, rot)
+        st.outstanding = True
         ctx.module, ctx.st = module, st
         ctx.has_cond, ctx.has_text = exists(cond), exists(text_embed)
         ctx.x_dtype = x_in.dtype
         ctx.t_dtype = text_embed.dtype if exists(text_embed) else None
-        return st.out.clone()
+        return st.out.detach()
 
     @staticmethod
     def backward(ctx, dout):
         module, st = ctx.module, ctx.st
         st.dout.copy_(dout)
-        sync = module._grad_sync
-        for gr, slab in st.bwd:
-            gr.replay()
-            if exists(sync) and exists(slab):
-                sync(st.gflat, slab[0], slab[1])
-        if exists(sync):
-            sync(st.gflat, None, None)
-        # the static buffer is rewritten by the next replay: copy it out unless the caller opted into aliasing
-        gflat = st.gflat if getattr(module, '_alias_grads', False) else st.gflat.clone()
-        pgrads = [gflat[off:off + p.numel()].view(p.shape) if p.requires_grad else None for p, off in module._layout.slots]
-        return (None, None, st.dx.to(ctx.x_dtype).clone(), st.dcond.clone() if ctx.has_cond else None,
-                st.dtext.to(ctx.t_dtype).clone() if ctx.has_text else None, None, *pgrads)
+        try:
+            pgrads = module._plan_run_backward(st)
+        finally:
+            st.outstanding = False
+        return (None, None, None, st.dx.detach().to(ctx.x_dtype), st.dcond.detach() if ctx.has_cond else None,
+                st.dtext.detach().to(ctx.t_dtype) if ctx.has_text else None, None, *pgrads)
+
+
+class _TimeCondFn(torch.autograd.Function):
+    """RandomFourierEmbed + Linear(D + 1, D) + SiLU (e2_tts.py:355-364,621-625,782) on the time-conditioning kernel"""
+
+    @staticmethod
+    def forward(ctx, times, fw, W, bias):
+        out, four, pre = ops.time_cond_fwd(times, fw.detach().float().contiguous(), W.detach().contiguous(), bias.detach().contiguous())
+        ctx.save_for_backward(four, pre)
+        ctx.wshape = W.shape
+        return out
+
+    @staticmethod
+    def backward(ctx, dout):
+        four, pre = ctx.saved_tensors
+        dW = ops.zeros(ctx.wshape, f32, pre.device)
+        db = ops.zeros((ctx.wshape[0],), f32, pre.device)
+        ops.time_cond_bwd(dout.float().contiguous(), four, pre, dW, db)
+        return None, None, dW, db
+
+
+_VIEW_OPS = {'view', '_unsafe_view', 'as_strided', 'slice', 'select', 'expand', 't', 'transpose', 'permute', 'unsqueeze', 'squeeze',
+             'detach', 'alias', '_reshape_alias', 'reshape', 'split', 'split_with_sizes', 'unbind', 'narrow', 'lift_fresh', 'unfold',
+             'view_as_real', 'view_as_complex', 'diagonal', 'chunk', 'unsafe_split', 'unsafe_chunk', 'flatten', 'unflatten'}
+_ALLOC_OPS = {'empty', 'empty_like', 'empty_strided', 'new_empty', 'new_empty_strided'}
+
+
+class _RecordGuard(torch.utils._python_dispatch.TorchDispatchMode):
+    """active while a launch plan is being recorded: a plan replays the e2k calls only, so any tensor-library op that
+    does device work in between would silently be missing from the replay -- raise instead.  Views and uninitialised
+    allocations are fine.  On the host model of the kernels (tests) there is no private memory pool: `keep` then holds
+    every buffer allocated during the recording so that no recorded pointer is ever handed out again."""
+
+    def __init__(self, keep=None):
+        super().__init__()
+        self.keep = keep
+
+    def __torch_dispatch__(self, func, types, args=(), kwargs=None):
+        name = func._schema.name.split('::')[-1]
+        if name in _VIEW_OPS:
+            return func(*args, **(kwargs or {}))
+        if name in _ALLOC_OPS:
+            out = func(*args, **(kwargs or {}))
+            if self.keep is not None:
+                self.keep.append(out)
+            return out
+        raise RuntimeError(f'aten::{name} inside a recorded launch plan: only e2k calls, views and empty() allocations may run '
+                           f'between e2k_plan_begin and e2k_plan_end')

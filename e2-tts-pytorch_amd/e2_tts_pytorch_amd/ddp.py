@@ -63,22 +63,28 @@ class DataParallel(nn.Module):
         self._sync = _GradSync(process_group)
         for bb in self._backbones:
             bb._grad_sync = self._hook
+        self._outside_queued = False
         if broadcast_from is not None:
             with torch.no_grad():
                 for t in list(module.parameters()) + list(module.buffers()):
                     dist.broadcast(t.data, src=broadcast_from, group=process_group)
+            for bb in self._backbones:          # the broadcast wrote behind the version counters: refresh the bf16 shadows
+                bb._shadow_key = None
 
     @staticmethod
     def _in_flat(bb, p):
         return any(p is q for q, _ in bb._layout.slots)
 
     def _hook(self, gflat, start, end):
-        if start is None and self._outside:
+        if start is None and self._outside and not self._outside_queued:
             # the rest of the autograd pass (input projections, embeddings) finishes after the backbone: reduce then
+            # (once per backward pass, however many backbones the wrapped module holds)
+            self._outside_queued = True
             torch.autograd.Variable._execution_engine.queue_callback(self._reduce_outside)
         self._sync(gflat, start, end)
 
     def _reduce_outside(self):
+        self._outside_queued = False
         # every rank contributes every parameter (zeros where it produced no gradient, e.g. the text embedding on a
         # step whose classifier-free-guidance coin flip dropped the text): the collective has the same size everywhere
         ps = [p for p in self._outside if p.requires_grad]

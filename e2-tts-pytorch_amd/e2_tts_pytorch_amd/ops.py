@@ -65,6 +65,74 @@ class pinned_stream:
         return False
 
 
+def lib():
+    return _lib.get()
+
+
+def raw_stream(device):
+    """hipStream_t of torch's current stream on `device` (None on the host model)"""
+    device = torch.device(device)
+    if device.type != 'cuda':
+        return None
+    ps = _pinned_stream
+    idx = device.index if device.index is not None else torch.cuda.current_device()
+    if ps is not None and ps[0] == idx:
+        return ps[1]
+    return torch.cuda.current_stream(device).cuda_stream
+
+
+# ---- launch-plan recording (csrc/plan.h): while one is active the GEMM / attention wrappers note their algorithmic
+# FLOPs next to the index of the recorded call, so that a profiled replay can be priced against the roofline
+_rec_meta = None
+
+
+def begin_recording(meta=None):
+    global _rec_meta
+    _lib.get().e2k_plan_begin()
+    _rec_meta = meta
+
+
+def recorded():
+    return _lib.get().e2k_query_plan_recorded()
+
+
+def end_recording():
+    global _rec_meta
+    _rec_meta = None
+    h = _lib.get().e2k_query_plan_end()
+    if h <= 0:
+        raise _lib.E2KError(f'e2k_query_plan_end failed with code {h}')
+    return h
+
+
+def abort_recording():
+    global _rec_meta
+    _rec_meta = None
+    _lib.get().e2k_plan_abort()
+
+
+def _note(flops):
+    m = _rec_meta
+    if m is not None:
+        m.append((_lib.get().e2k_query_plan_recorded(), float(flops)))
+
+
+def profile_plan(handle, meta, phase, device):
+    """replay `handle` once with a HIP event after every call -> [dict(name, ms, flops, phase)] (synchronises)"""
+    import ctypes
+    L = _lib.get()
+    n = L.e2k_query_plan_size(handle)
+    ms = (ctypes.c_float * max(n, 1))()
+    L.e2k_plan_profile(handle, 0, n, ctypes.addressof(ms), raw_stream(device))
+    buf = ctypes.create_string_buffer(64)
+    flops = dict(meta or ())
+    out = []
+    for i in range(n):
+        L.e2k_plan_op_name(handle, i, ctypes.addressof(buf), 64)
+        out.append(dict(name=buf.value.decode(), ms=float(ms[i]), flops=flops.get(i, 0.0), phase=phase, index=i))
+    return out
+
+
 def _rows(t):
     """(rows, row_stride) of a 2-D view whose last dim is contiguous."""
     assert t.dim() == 2 and t.stride(1) == 1, (t.shape, t.stride())
@@ -107,6 +175,7 @@ def gemm_nt(a, b, *, a2=None, out=None, out_dtype=bf16, accumulate=False, bias=N
     if prof is not None and a.is_cuda:
         e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
         e0.record()
+    _note(2.0 * M * N * (K1 + K2))
     _lib.get().e2k_gemm_nt_bf16(_p(a), lda, K1, _p(a2), lda2, K2, _p(b), ldb, _p(out), out.stride(0),
                                 int(out.dtype == f32), int(accumulate), M, N, _p(bias), _p(colscale),
                                 0 if colscale is None else colscale.stride(0), int(rows_per_batch), _p(rowmask), _p(resid), ldr,
@@ -159,6 +228,7 @@ def gemm_tn(a, b, out, *, splits=0, use_tr=True, colsum=None, colsum_from=0):
     if colsum is not None:
         _chk(colsum)
         assert colsum.dtype == f32 and colsum.numel() == N and colsum.is_contiguous()
+    _note(2.0 * M * N * K)
     lib.e2k_gemm_tn_bf16(_p(a), lda, _p(b), ldb, _p(out), out.stride(0), M, N, K, int(splits), int(use_tr), _p(ws),
                          _p(colsum), int(colsum_from), _stream(a))
     return out
@@ -367,6 +437,7 @@ def attn_fwd(st, kmask_pad, p_drop=0., seed=0, stream_id=0, seed_dev=None):
         nbytes = _lib.get().e2k_query_attn_dropbits_bytes(B, H, N)
         if nbytes > 0:
             st.dropbits = torch.empty(nbytes // 8, dtype=torch.int64, device=dev)
+    _note(4.0 * B * H * N * N * 64)
     _lib.get().e2k_attn_fwd(_p(st.Q), _p(st.K), _p(st.VT), _p(kmask_pad), _p(st.gate), _p(st.O), _p(st.Og), _p(st.lse2),
                             _p(st.dropbits), B, H, N, Npad, float(p_drop), int(seed), _p(seed_dev), int(stream_id),
                             _stream(st.Q))
@@ -384,6 +455,7 @@ def attn_bwd(st, dOg, kmask_pad, p_drop=0., seed=0, stream_id=0, seed_dev=None):
     delta = torch.empty((B, H, N), dtype=f32, device=dev)
     dgate = torch.empty((B, H, N), dtype=f32, device=dev)
     dQ, dK, dV = (torch.empty((B, H, N, 64), dtype=bf16, device=dev) for _ in range(3))
+    _note(10.0 * B * H * N * N * 64)
     _lib.get().e2k_attn_bwd(_p(dOg), _p(st.O), _p(st.gate), _p(st.lse2), _p(st.Q), _p(st.K), _p(st.V), _p(st.QT),
                             _p(st.KT), _p(kmask_pad), _p(st.dropbits), _p(dO), _p(dOT), _p(delta), _p(dgate), _p(dQ), _p(dK),
                             _p(dV), B, H, N, Npad, float(p_drop), int(seed), _p(seed_dev), int(stream_id), _stream(dOg))
@@ -399,11 +471,148 @@ def qkv_post_bwd(st, dQ, dK, dV, dgate_pre, qkvg, cosb, sinb, vfirst=None, dvfir
         dqkvg = torch.empty((M, cols), dtype=bf16, device=qkvg.device)
     else:                                        # padded row stride: only the pad columns need zeroing (they are read
         full = torch.empty((M, ld), dtype=bf16, device=qkvg.device)      # as K padding by the dgrad GEMM)
-        full[:, cols:].zero_()
+        fill_cols_(full, cols)
         dqkvg = full[:, :cols]
     _lib.get().e2k_qkv_post_bwd(_p(dQ), _p(dK), _p(dV), _p(dgate_pre), _p(qkvg), qkvg.stride(0), _p(cosb), _p(sinb),
                                 _p(vfirst), _p(st.mix), _p(dvfirst), int(first_layer), _p(dqkvg), B, H, N, _stream(dQ))
     return dqkvg
+
+
+# ------------------------------------------------------------------------------------------------ glue (csrc/glue.hip)
+
+def fill_(t, value=0):
+    """byte fill of a contiguous tensor (hipMemsetAsync as a recordable e2k call); value is a BYTE"""
+    _chk(t)
+    assert t.is_contiguous()
+    _lib.get().e2k_fill_bytes(_p(t), int(value), t.numel() * t.element_size(), _stream(t))
+    return t
+
+
+def fill_cols_(t, c0, value=0):
+    """byte fill of columns [c0:] of every row of a 2-D tensor with contiguous rows"""
+    _chk(t)
+    assert t.dim() == 2 and t.stride(1) == 1
+    es = t.element_size()
+    _lib.get().e2k_fill_bytes_2d(t.data_ptr() + c0 * es, t.stride(0) * es, int(value), (t.shape[1] - c0) * es, t.shape[0], _stream(t))
+    return t
+
+
+def zeros(shape, dtype, device):
+    return fill_(torch.empty(shape, dtype=dtype, device=device))
+
+
+def cast_f32(src, dst=None):
+    _chk(src, dst)
+    assert src.dtype == bf16 and src.is_contiguous()
+    if dst is None:
+        dst = torch.empty(src.shape, dtype=f32, device=src.device)
+    assert dst.dtype == f32 and dst.is_contiguous() and dst.numel() == src.numel()
+    _lib.get().e2k_cast_f32(_p(src), _p(dst), src.numel(), _stream(src))
+    return dst
+
+
+def sigmoid(src):
+    _chk(src)
+    assert src.dtype == f32 and src.is_contiguous()
+    dst = torch.empty_like(src)
+    _lib.get().e2k_sigmoid_f32(_p(src), _p(dst), src.numel(), _stream(src))
+    return dst
+
+
+def build_masks(mask, B, T, R, device, want_mask_n):
+    """-> kmask (B, Npad) u8, mask_n (B, N) u8 or None"""
+    _chk(mask)
+    N = T + R
+    Npad = (N + 63) // 64 * 64
+    if mask is not None:
+        assert mask.shape == (B, T) and mask.is_contiguous() and mask.dtype in (torch.bool, torch.uint8)
+    kmask = torch.empty((B, Npad), dtype=torch.uint8, device=device)
+    mask_n = torch.empty((B, N), dtype=torch.uint8, device=device) if want_mask_n else None
+    _lib.get().e2k_build_masks(_p(mask), _p(kmask), _p(mask_n), B, T, R, Npad, _stream(kmask))
+    return kmask, mask_n
+
+
+def stream_pack_fwd(x, abs_pos, regs):
+    """x (B,T,D) fp32, abs_pos (>=T, D) fp32 or None, regs (R,D) fp32 -> X (B*(T+R), 4, D) bf16"""
+    _chk(x, abs_pos, regs)
+    B, T, D = x.shape
+    R = regs.shape[0]
+    assert x.dtype == f32 and x.is_contiguous() and regs.dtype == f32 and regs.is_contiguous()
+    if abs_pos is not None:
+        assert abs_pos.dtype == f32 and abs_pos.is_contiguous() and abs_pos.shape[0] >= T and abs_pos.shape[1] == D
+    X = torch.empty((B * (T + R), 4, D), dtype=bf16, device=x.device)
+    _lib.get().e2k_stream_pack_fwd(_p(x), _p(abs_pos), _p(regs), _p(X), B, T, R, D, _stream(x))
+    return X
+
+
+def stream_pack_bwd(dX, B, T, R, dregs, dabs):
+    """dX (B*(T+R), 4, D) bf16 -> dx (B,T,D) fp32; dregs (R,D) / dabs (T.., D) fp32 accumulated"""
+    _chk(dX, dregs, dabs)
+    D = dX.shape[-1]
+    assert dX.dtype == bf16 and dX.is_contiguous() and dregs.is_contiguous() and (dabs is None or dabs.is_contiguous())
+    dx = torch.empty((B, T, D), dtype=f32, device=dX.device)
+    _lib.get().e2k_stream_pack_bwd(_p(dX), _p(dx), _p(dregs), _p(dabs), B, T, R, D, _stream(dX))
+    return dx
+
+
+def stream_unpack_fwd(X, B, T, R):
+    _chk(X)
+    D = X.shape[-1]
+    assert X.dtype == bf16 and X.is_contiguous()
+    xsum = torch.empty((B * T, D), dtype=bf16, device=X.device)
+    _lib.get().e2k_stream_unpack_fwd(_p(X), _p(xsum), B, T, R, D, _stream(X))
+    return xsum
+
+
+def stream_unpack_bwd(dxs, B, T, R):
+    _chk(dxs)
+    D = dxs.shape[-1]
+    assert dxs.dtype == bf16 and dxs.is_contiguous()
+    dX = torch.empty((B * (T + R), 4, D), dtype=bf16, device=dxs.device)
+    _lib.get().e2k_stream_unpack_bwd(_p(dxs), _p(dX), B, T, R, D, _stream(dxs))
+    return dX
+
+
+def time_cond_fwd(times, fw, W, bias):
+    """-> (out (B,D), four (B,D+1), pre (B,D)) fp32"""
+    _chk(times, fw, W, bias)
+    B, D = times.shape[0], W.shape[0]
+    for t in (times, fw, W, bias):
+        assert t.dtype == f32 and t.is_contiguous()
+    assert W.shape == (D, D + 1) and fw.numel() == D // 2
+    four = torch.empty((B, D + 1), dtype=f32, device=W.device)
+    pre = torch.empty((B, D), dtype=f32, device=W.device)
+    out = torch.empty((B, D), dtype=f32, device=W.device)
+    _lib.get().e2k_time_cond_fwd(_p(times), _p(fw), _p(W), _p(bias), _p(four), _p(pre), _p(out), B, D, _stream(W))
+    return out, four, pre
+
+
+def time_cond_bwd(dout, four, pre, dW, dbias):
+    _chk(dout, four, pre, dW, dbias)
+    B, D = pre.shape
+    assert dout.dtype == f32 and dout.is_contiguous() and dW.is_contiguous() and dbias.is_contiguous()
+    _lib.get().e2k_time_cond_bwd(_p(dout), _p(four), _p(pre), _p(dW), _p(dbias), B, D, _stream(pre))
+
+
+def cond_bwd_prep(dcond, gates, gbias, B, L, D):
+    """-> dcb (B, 4LD) bf16, dct (4LD, KB) bf16 (KB = B rounded up to 8, zero padded); dcond's gate slots scaled in place"""
+    _chk(dcond, gates, gbias)
+    KB = (B + 7) // 8 * 8
+    assert dcond.is_contiguous() and gates.is_contiguous() and gbias.is_contiguous()
+    dcb = torch.empty((B, 4 * L * D), dtype=bf16, device=dcond.device)
+    dct = torch.empty((4 * L * D, KB), dtype=bf16, device=dcond.device)
+    _lib.get().e2k_cond_bwd_prep(_p(dcond), _p(gates), _p(dcb), _p(dct), _p(gbias), B, L, D, KB, _stream(dcond))
+    return dcb, dct
+
+
+def transpose_f32(src, C):
+    """src (R, ld) fp32 -> (C, R) fp32 of its first C columns"""
+    _chk(src)
+    R = src.shape[0]
+    assert src.dtype == f32 and src.stride(1) == 1
+    out = torch.empty((C, R), dtype=f32, device=src.device)
+    _lib.get().e2k_transpose_f32(_p(src), src.stride(0), _p(out), R, C, _stream(src))
+    return out
 
 
 # ------------------------------------------------------------------------------------------------ MelSpec

@@ -192,6 +192,67 @@ int e2k_adopt_step(float* p, const float* g, float* m, float* v, void* shadow_bf
 /* ema += (1 - decay) (p - ema)   (ema_pytorch.EMA.update, trainer.py:170,279) */
 int e2k_ema_update(float* ema, const float* p, int64_t n, float decay, void* stream);
 
+
+/* ---- launch plans: the native scheduler of the backbone (csrc/plan.h) ----
+ * The reference's hot loop is Python calling one ATen op at a time (e2_tts.py:825-939); replayed naively through this ABI
+ * a dim-1024 / depth-24 step is ~3000 calls whose Python / ctypes cost equals the kernels' own time.  A plan records the
+ * calls once and re-issues them from C++.
+ *   e2k_plan_begin()            start recording on the calling thread: every compute entry point called from now on is
+ *                               executed AND appended (its arguments by value: the buffers must stay where they are)
+ *   e2k_query_plan_recorded()   number of calls recorded so far (-1: not recording) -- segment boundaries
+ *   e2k_query_plan_end()        stop recording, returns the plan handle (> 0) or a negative error
+ *   e2k_plan_abort()            drop a recording in progress
+ *   e2k_plan_run(plan, first, count, stream)   re-issue calls [first, first + count) (count < 0: to the end) on `stream`
+ *   e2k_plan_profile(...)       the same with a HIP event after every call; ms_host[i] (HOST pointer, count floats)
+ *                               receives the time between the events around call first + i; synchronises the stream
+ *   e2k_plan_op_name(...)       name of recorded call `index` into the HOST buffer buf_host (e.g. "gemm_nt_bf16")
+ *   e2k_plan_free(plan)
+ * The registry of plans is the one piece of process-global state in the library (mutex protected); the recording state
+ * is per thread.  Device-side values that change between replays are read through pointers (seed_dev, adopt's gsumsq). */
+int e2k_plan_begin(void);
+int e2k_query_plan_recorded(void);
+int e2k_query_plan_end(void);
+int e2k_plan_abort(void);
+int e2k_plan_free(int plan);
+int e2k_query_plan_size(int plan);
+int e2k_plan_run(int plan, int first, int count, void* stream);
+int e2k_plan_profile(int plan, int first, int count, float* ms_host, void* stream);
+int e2k_plan_op_name(int plan, int index, char* buf_host, int nbuf);
+
+/* ---- stream pack / unpack, masks, time conditioning: the glue around the depth loop (csrc/glue.hip) ----
+ * byte fill (hipMemsetAsync as a recordable call) and a strided form: `rows` rows of `width` bytes, `pitch` bytes apart */
+int e2k_fill_bytes(void* dst, int value, int64_t nbytes, void* stream);
+int e2k_fill_bytes_2d(void* dst, int64_t pitch, int value, int64_t width, int64_t rows, void* stream);
+int e2k_cast_f32(const void* src_bf16, float* dst, int64_t n, void* stream);
+int e2k_sigmoid_f32(const float* src, float* dst, int64_t n, void* stream);
+/* key / row masks of a batch (e2_tts.py:771: registers are always attended): mask (B,T) u8 / bool or NULL (= all ones)
+ * -> kmask (B,Npad): [1 x R | mask | 0 x (Npad - N)],  mask_n (B,N) (optional): the first N columns, contiguous */
+int e2k_build_masks(const uint8_t* mask, uint8_t* kmask, uint8_t* mask_n, int B, int T, int R, int Npad, void* stream);
+/* residual-stream pack (e2_tts.py:760-768,818: abs-pos added, registers prepended, expanded to 4 hyper-connection
+ * streams):  X[b][n][s][:] = bf16( n < R ? regs[n] : x[b][n-R] + abs_pos[n-R] ),  x fp32 (B,T,D), abs_pos (>=T, D) or NULL */
+int e2k_stream_pack_fwd(const float* x, const float* abs_pos, const float* regs, void* X, int B, int T, int R, int D,
+                        void* stream);
+/* backward: dx[b][t] = sum_s dX[b][R+t][s];  dregs[n] += sum_b sum_s dX[b][n][s];  dabs[t] += sum_b dx[b][t] (optional) */
+int e2k_stream_pack_bwd(const void* dX, float* dx, float* dregs, float* dabs, int B, int T, int R, int D, void* stream);
+/* reduce (e2_tts.py:947: sum of the streams) without the registers (e2_tts.py:949): xsum[b*T+t] = bf16(sum_s X[b][R+t][s]) */
+int e2k_stream_unpack_fwd(const void* X, void* xsum, int B, int T, int R, int D, void* stream);
+/* backward: dX[b][n][s] = n < R ? 0 : dxs[b*T + n - R]   (all four streams) */
+int e2k_stream_unpack_bwd(const void* dxs, void* dX, int B, int T, int R, int D, void* stream);
+/* time conditioning (e2_tts.py:355-364,621-625,782): out[b][j] = silu(pre), pre = W[j][:] . [t_b, sin(2 pi t_b w), cos(2 pi t_b w)] + bias[j]
+ * times (B) fp32, fw (D/2) the fixed random Fourier weights, W (D, D+1) fp32, bias (D); `four` (B, D+1) and `pre` (B, D)
+ * are kept for the backward.  bwd: dW += dpre^T four, dbias += sum_b dpre, dpre = dout * silu'(pre). */
+int e2k_time_cond_fwd(const float* times, const float* fw, const float* W, const float* bias, float* four, float* pre,
+                      float* out, int B, int D, void* stream);
+int e2k_time_cond_bwd(const float* dout, const float* four, const float* pre, float* dW, float* dbias, int B, int D,
+                      void* stream);
+/* backward of the hoisted time-conditioning block (rows [layer][4][D] of dcond, gates = sigmoid(condall)):
+ * gate slots (1, 3) of dcond are multiplied by (1 - gate) in place, dcb = bf16(dcond), dct (4LD, KB) = bf16(dcond)^T zero
+ * padded to KB columns, gbias[l][1|3][:] += sum_b dcond (the AdaLN-Zero biases; slots 0, 2 have no bias) */
+int e2k_cond_bwd_prep(float* dcond, const float* gates, void* dcb, void* dct, float* gbias, int B, int L, int D, int KB,
+                      void* stream);
+/* out (C, R) = in (R, ld >= C)^T, fp32, first C columns */
+int e2k_transpose_f32(const float* in, int64_t ld, float* out, int R, int C, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -48,6 +48,17 @@ typedef int hipError_t;
 static inline hipError_t hipGetLastError() { return 0; }
 static inline const char* hipGetErrorString(hipError_t) { return "emu"; }
 static inline hipError_t hipMemsetAsync(void* p, int v, size_t n, hipStream_t) { memset(p, v, n); return 0; }
+// events: the host model runs every launch synchronously; elapsed times are host wall-clock (plan profiling logic only)
+#include <chrono>
+typedef std::chrono::steady_clock::time_point* hipEvent_t;
+static inline hipError_t hipEventCreate(hipEvent_t* e) { *e = new std::chrono::steady_clock::time_point(); return 0; }
+static inline hipError_t hipEventDestroy(hipEvent_t e) { delete e; return 0; }
+static inline hipError_t hipEventRecord(hipEvent_t e, hipStream_t) { *e = std::chrono::steady_clock::now(); return 0; }
+static inline hipError_t hipEventElapsedTime(float* ms, hipEvent_t a, hipEvent_t b) {
+    *ms = std::chrono::duration<float, std::milli>(*b - *a).count();
+    return 0;
+}
+static inline hipError_t hipStreamSynchronize(hipStream_t) { return 0; }
 
 namespace emu {
 

@@ -185,40 +185,56 @@ def test_reference_golden_backbone(dev, case):
     # alone moves it by 6 % in the fp32 model.  0.15 still separates rounding from a missing term (>= 0.3)
     assert rel2(x.grad, c['dx']) < 0.15, rel2(x.grad, c['dx'])
     # parameter gradients: the fixture carries sum |g| per parameter; compare for the large matrices (for small / heavily
-    # cancelling ones the sum of magnitudes is dominated by rounding noise; element-wise parity is test_backbone's job)
-    # (not for `variant`: with these all-random weights the backward pass is ill-conditioned and its early-layer weight
-    #  gradients differ from the fp32 oracle's by 20-30 % although every kernel reproduces an fp32 reference on its own
-    #  inputs to < 1 % -- tools/insitu_check.py)
+    # cancelling ones the sum of magnitudes is dominated by rounding noise; element-wise parity is test_backbone's job).
+    # `variant` draws EVERY parameter at random, which makes the early layers' weight gradients ill-conditioned in the
+    # MODEL: rounding the fp32 oracle's own activations to bf16 (tests/bf16_emulation.py) already moves their sum of
+    # magnitudes by up to ~17 % (tools/probes/which_rounding.py: it is the FORWARD roundings that do it -- stream storage
+    # 5 %, branch inputs / outputs 4 %, together 17 % -- rounding the stream gradients alone moves them by 0.4 %).  The
+    # tolerance of each parameter is therefore 0.15 plus twice the deviation of that emulation for the same parameter.
+    slack = {}
+    if case == 'transformer_variant':
+        from bf16_emulation import bf16_intermediates
+        random.seed(0)
+        ref = fill_params(O.Transformer(**c['kw'], cond_on_time=c['cond_on_time']), c['weight_seed'])
+        xr = c['x'].clone().requires_grad_(True)
+        tr_ = c['text'].clone().requires_grad_(True) if c['text'] is not None else None
+        with bf16_intermediates():
+            (ref(xr, times=c['times'], mask=c['mask'], text_embed=tr_) * c['R']).sum().backward()
+        for n, p in ref.named_parameters():
+            want = c['grad_abs_sums'].get(n)
+            if want and p.grad is not None:
+                slack[n] = 2. * abs(float(p.grad.double().abs().sum()) / want - 1.)
     bad = []
-    for n, p in (mod.named_parameters() if case != 'transformer_variant' else ()):
+    for n, p in mod.named_parameters():
         want = c['grad_abs_sums'].get(n)
         if want is None or p.grad is None or p.numel() < 16384 or want == 0.:
             continue
         got = float(p.grad.double().abs().sum())
-        if abs(got - want) > 0.15 * want:
-            bad.append((n, got, want))
+        if abs(got - want) > (0.15 + slack.get(n, 0.)) * want:
+            bad.append((n, got / want, slack.get(n, 0.)))
     assert not bad, bad[:10]
 
 
-@pytest.mark.gpu
-def test_graph_replay_matches_eager():
-    """HIP-graph path (one forward graph + per-layer backward graphs) reproduces the eager schedule"""
-    from e2_tts_pytorch_amd import Transformer, _lib
-    _lib._install_for_tests(None, host_pointers=False)
+def test_plan_replay_matches_eager(dev):
+    """launch plans (csrc/plan.h): the recorded launch sequence of a signature, re-issued from C++, reproduces the eager
+    schedule bit for bit -- forward, input gradients and every parameter gradient; gradients delivered through autograd
+    (default, accumulating) and through the persistent flat buffer; a forward-only plan (the sampling path); a second
+    forward before the backward falls back to the eager schedule instead of overwriting the saved activations"""
+    from e2_tts_pytorch_amd import Transformer
     random.seed(0)
     torch.manual_seed(0)
     mod = Transformer(dim=256, depth=4, heads=2, dropout=0., max_seq_len=64)
     randomize(mod)
-    mod = mod.cuda()
+    mod = mod.to(dev)
     B, T = 2, 40
-    R = torch.randn(B, T, 256, device='cuda')
+    R = torch.randn(B, T, 256).to(dev)
 
     def inputs(seed):
         g = torch.Generator().manual_seed(seed)
-        x = torch.randn(B, T, 256, generator=g).cuda().requires_grad_(True)
-        t = torch.rand(B, generator=g).cuda()
-        txt = torch.randn(B, T, 128, generator=g).cuda().requires_grad_(True)
-        mask = (torch.arange(T)[None] < torch.tensor([T, T - 5 - seed])[:, None]).cuda()
+        x = torch.randn(B, T, 256, generator=g).to(dev).requires_grad_(True)
+        t = torch.rand(B, generator=g).to(dev)
+        txt = torch.randn(B, T, 128, generator=g).to(dev).requires_grad_(True)
+        mask = (torch.arange(T)[None] < torch.tensor([T, T - 5 - seed])[:, None]).to(dev)
         return x, t, txt, mask
 
     def step(seed):
@@ -228,27 +244,63 @@ def test_graph_replay_matches_eager():
         (out * R).sum().backward()
         return out.detach().clone(), x.grad.clone(), txt.grad.clone(), {n: p.grad.clone() for n, p in mod.named_parameters()}
 
+    def live_plans():
+        return [v for v in mod._plans.values() if not isinstance(v, str)]
+
+    mod.enable_plans(False)
     ref = [step(s) for s in (1, 2, 3)]
-    mod.enable_graphs()
-    got = [step(s) for s in (1, 2, 3)]          # warm (eager), capture + replay, replay
-    assert any(not isinstance(v, str) for v in mod._graphs.values()), 'nothing was captured'
+    mod.enable_plans(True)
+    got = [step(s) for s in (1, 2, 3)]          # first sighting (eager), recording pass, replay
+    assert len(live_plans()) == 1 and live_plans()[0].bwd, 'nothing was recorded'
     for (o0, dx0, dt0, g0), (o1, dx1, dt1, g1) in zip(ref, got):
-        assert rel2(o1, o0) < 1e-3 and rel2(dx1, dx0) < 1e-3 and rel2(dt1, dt0) < 1e-3
-        for n in g0:
+        assert torch.equal(o1, o0) and torch.equal(dx1, dx0) and torch.equal(dt1, dt0)
+        for n in g0:        # (fp32 atomics in the gradient reductions: order-of-arrival noise, amplified where a bf16 rounding follows)
             assert rel2(g1[n], g0[n]) < 2e-3 or float(g0[n].norm()) < 1e-6, n
-    # gradients handed out as views of the static buffer (enable_graphs(alias_grads=True)): same values, no copy
-    mod.enable_graphs(False)
-    mod.enable_graphs(alias_grads=True)
+    # accumulation over two backward passes without zero_grad: autograd adds, as with any module
+    x, t, txt, mask = inputs(3)
+    (mod(x, times=t, mask=mask, text_embed=txt) * R).sum().backward()
+    n0 = 'layers.1.0.3.to_q.weight'
+    assert rel2(dict(mod.named_parameters())[n0].grad, 2 * got[2][3][n0]) < 2e-3
+    # persistent flat gradient buffer: same values, no copy, nothing handed to autograd
+    mod.enable_persistent_grads()
     got2 = [step(s) for s in (1, 2, 3)]
     for (o0, dx0, dt0, g0), (o1, dx1, dt1, g1) in zip(ref, got2):
-        assert rel2(o1, o0) < 1e-3 and rel2(dx1, dx0) < 1e-3
+        assert torch.equal(o1, o0) and torch.equal(dx1, dx0)
         for n in g0:
             assert rel2(g1[n], g0[n]) < 2e-3 or float(g0[n].norm()) < 1e-6, n
-    mod.enable_graphs(False)
-    # forward-only graph (sampling path)
+    mod.enable_persistent_grads(False)
+    # two forwards of one signature before a backward: the second must not touch the first one's saved activations
+    mod.zero_grad(set_to_none=True)
+    xa, ta, txa, ma = inputs(1)
+    xb, tb, txb, mb = inputs(2)
+    la = (mod(xa, times=ta, mask=ma, text_embed=txa) * R).sum()
+    lb = (mod(xb, times=tb, mask=mb, text_embed=txb) * R).sum()
+    (la + lb).backward()
+    assert torch.equal(xa.grad, ref[0][1]) and torch.equal(xb.grad, ref[1][1])
+    # forward-only plan (sampling path)
     with torch.no_grad():
         x, t, txt, mask = inputs(4)
-        eager = mod.enable_graphs(False)(x, times=t, mask=mask, text_embed=txt)
-        mod.enable_graphs()
-        outs = [mod(x, times=t, mask=mask, text_embed=txt) for _ in range(3)]
-    assert rel2(outs[1], eager) < 1e-3 and rel2(outs[2], eager) < 1e-3
+        eager = mod.enable_plans(False)(x, times=t, mask=mask, text_embed=txt).clone()
+        mod.enable_plans(True)
+        outs = [mod(x, times=t, mask=mask, text_embed=txt).clone() for _ in range(3)]
+    assert torch.equal(outs[1], eager) and torch.equal(outs[2], eager)
+    assert len(live_plans()) == 1 and not live_plans()[0].need_grad       # (enable_plans(False) dropped the training plan)
+    # a deep copy (the trainer's EMA) starts without runtime state and works on its own
+    import copy
+    twin = copy.deepcopy(mod)
+    assert twin._plans == {} and twin._flat is None
+    with torch.no_grad():
+        assert torch.equal(twin(x, times=t, mask=mask, text_embed=txt), eager)
+
+
+def test_plan_recording_rejects_tensor_library_ops(dev):
+    """a plan replays e2k calls only: a torch op doing device work inside the recorded region must raise, not vanish"""
+    from e2_tts_pytorch_amd import ops
+    from e2_tts_pytorch_amd.backbone import _RecordGuard
+    a = torch.ones(16).to(dev)
+    with _RecordGuard():
+        b = a.view(4, 4)[1:]                    # views are fine
+        c = torch.empty(8, device=dev)          # so are uninitialised allocations
+        with pytest.raises(RuntimeError, match='inside a recorded launch plan'):
+            a + 1
+    assert b.shape == (3, 4) and c.numel() == 8

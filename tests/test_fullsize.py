@@ -1,0 +1,137 @@
+"""Parity at the sizes BASELINE.json names (GPU only: the CPU oracle needs seconds to a minute per case, the host model
+of the kernels would need hours).  North-star tolerances for the bf16 path: loss 1e-2 relative, pred_flow rel-L2 1e-2,
+sampled mel rel-L2 1e-2.  Weight gradients are reported per layer (JSON under gpurun_out/) and bounded.
+
+  cfg1   README example exactly: E2TTS(dim=512, depth=8) (8 heads), mel = randn(2, 1024, 100), text = ['Hello', 'Goodbye'],
+         one forward + backward (/root/reference/README.md:30-64) -- with the reference's own initialisation and with
+         every zero-initialised path switched on (`randomize`)
+  cfg3   the headline benchmark's dimensions: dim 1024, depth 24, 16 heads, T = 1024 (N = 1056 positions: 17 key tiles,
+         66 row tiles and the remainder-split GEMM path the benchmark takes), B = 1
+  cfg5   sample() shaped like BASELINE.json's inference config: prompt of 5 frames, 1024 target frames, 32 midpoint steps
+         with classifier-free guidance (62 function evaluations x (cond + null)); small width (the ODE glue, masking,
+         CFG projection and the T = 1024 attention are what this exercises)
+"""
+import json
+import os
+import random
+from pathlib import Path
+
+import pytest
+import torch
+
+from oracle import e2tts_oracle as O
+
+from test_backbone import randomize
+
+pytestmark = [pytest.mark.gpu, pytest.mark.late]
+ROOT = Path(__file__).resolve().parent.parent
+
+
+def rel2(a, b):
+    a, b = a.detach().cpu().float(), b.detach().cpu().float()
+    return ((a - b).norm() / b.norm().clamp_min(1e-20)).item()
+
+
+def _report(name, rec):
+    out = ROOT / 'gpurun_out'
+    if out.is_dir():
+        json.dump(rec, open(out / f'r02_parity_{name}.json', 'w'), indent=1)
+
+
+def _pair(kw, init, seed=0):
+    from e2_tts_pytorch_amd import E2TTS, _lib
+    _lib._install_for_tests(None, host_pointers=False)
+    random.seed(seed)
+    torch.manual_seed(seed)
+    ref = O.E2TTS(transformer=dict(**kw), cond_drop_prob=0.)
+    if init == 'randomized':
+        randomize(ref)
+    model = E2TTS(transformer=dict(**kw), use_vocos=False, cond_drop_prob=0.)
+    model.load_state_dict(ref.state_dict(), strict=True)
+    return ref, model.cuda()
+
+
+def _train_step_parity(name, kw, B, T, text, init):
+    torch.set_num_threads(min(32, os.cpu_count() or 1))
+    ref, model = _pair(kw, init)
+    mel = torch.randn(B, T, 100)
+    noise = dict(x0=torch.randn(B, T, 100), times=torch.rand(B), frac_lengths=torch.full((B,), 0.85),
+                 span_rand=torch.rand(B), drop_text_cond=False)
+    out_r = ref(mel, text=text, _noise=noise)
+    out_r.loss.backward()
+    # how far the fp32 oracle itself moves when its activations are STORED in bf16 (tests/bf16_emulation.py): with every
+    # zero-initialised path switched on (`randomized`) the residual streams carry large cross-condition / gate terms and
+    # bf16 stream storage alone costs 2.4 % of pred_flow at depth 8 (tools/probes/flow_rounding.py) -- more than the
+    # north-star tolerance.  The north-star 1e-2 is asserted for the reference's own initialisation (the configuration
+    # BASELINE.json names); the stress case is held to 1.3 x this emulation.
+    e_emul = None
+    if init == 'randomized':
+        from bf16_emulation import bf16_intermediates
+        with torch.no_grad(), bf16_intermediates():
+            e_emul = rel2(ref(mel, text=text, _noise=noise).pred_flow, out_r.pred_flow)
+    dn = {k: (v.cuda() if torch.is_tensor(v) else v) for k, v in noise.items()}
+    out = model(mel.cuda(), text=text, _noise=dn)
+    out.loss.backward()
+    torch.cuda.synchronize()
+    e_loss = abs(out.loss.item() - out_r.loss.item()) / abs(out_r.loss.item())
+    e_flow = rel2(out.pred_flow, out_r.pred_flow)
+    refp = dict(ref.named_parameters())
+    per_layer, worst = {}, []
+    for n, p in model.named_parameters():
+        gr = refp[n].grad
+        if gr is None or p.grad is None or float(gr.norm()) == 0.:
+            continue
+        e = rel2(p.grad, gr)
+        key = '.'.join(n.split('.')[:3]) if n.startswith('transformer.layers.') else ('transformer.other' if n.startswith('transformer.') else 'head')
+        if p.numel() >= 4096:                    # (tiny, heavily cancelling parameters are test_backbone's subject)
+            per_layer.setdefault(key, []).append(e)
+            worst.append((e, n))
+    worst.sort(reverse=True)
+    layer_rms = {k: (sum(x * x for x in v) / len(v)) ** 0.5 for k, v in per_layer.items()}
+    rec = dict(case=name, init=init, kw=kw, B=B, T=T, loss=out.loss.item(), loss_ref=out_r.loss.item(), loss_rel=e_loss,
+               pred_flow_rel_l2=e_flow, pred_flow_rel_l2_of_bf16_emulated_oracle=e_emul, weight_grad_rel_l2_by_layer=layer_rms, worst=[(round(e, 4), n) for e, n in worst[:10]])
+    _report(f'{name}_{init}', rec)
+    print(json.dumps({k: rec[k] for k in ('case', 'init', 'loss_rel', 'pred_flow_rel_l2')}), 'worst grads:', rec['worst'][:4])
+    assert e_loss < 1e-2, e_loss
+    assert e_flow < (1e-2 if e_emul is None else max(1e-2, 1.3 * e_emul)), (e_flow, e_emul)
+    return rec
+
+
+@pytest.mark.parametrize('init', ['reference_init', 'randomized'])
+def test_cfg1_readme_exact(init):
+    rec = _train_step_parity('cfg1', dict(dim=512, depth=8, dropout=0.), 2, 1024, ['Hello', 'Goodbye'], init)
+    # weight gradients, rel-L2 against the fp32 oracle, per layer (rms over its matrices) and the worst single matrix:
+    # reference initialisation 2 % / 5 % (measured 0.9 % / 1.2 %), stress weights 10 % / 20 % (measured 7.6 % / 14.7 %)
+    lim = (0.02, 0.05) if init == 'reference_init' else (0.10, 0.20)
+    assert max(rec['weight_grad_rel_l2_by_layer'].values()) < lim[0], rec['weight_grad_rel_l2_by_layer']
+    assert rec['worst'][0][0] < lim[1], rec['worst'][:5]
+
+
+@pytest.mark.parametrize('init', ['reference_init', 'randomized'])
+def test_cfg3_dims_depth24(init):
+    rec = _train_step_parity('cfg3', dict(dim=1024, depth=24, heads=16, dropout=0.), 1, 1024, ['The quick brown fox jumps over the lazy dog.'],
+                             init)
+    lim = (0.03, 0.08) if init == 'reference_init' else (0.15, 0.30)
+    assert max(rec['weight_grad_rel_l2_by_layer'].values()) < lim[0], rec['weight_grad_rel_l2_by_layer']
+    assert rec['worst'][0][0] < lim[1], rec['worst'][:5]
+
+
+@pytest.mark.parametrize('init', ['reference_init', 'randomized'])
+def test_cfg5_shape_sample_32_steps(init):
+    torch.set_num_threads(min(32, os.cpu_count() or 1))
+    kw = dict(dim=256, depth=2, heads=4, dropout=0.)
+    ref, model = _pair(kw, init, seed=2)
+    B, Tp, dur, steps = 2, 5, 1024, 32
+    cond = torch.randn(B, Tp, 100)
+    y0 = torch.randn(B, dur, 100)
+    text = ['Hi there', 'A somewhat longer line of text to speak']
+    s_r = ref.sample(cond, text=text, duration=dur, steps=steps, cfg_strength=1., _y0=y0)
+    s = model.sample(cond.cuda(), text=text, duration=dur, steps=steps, cfg_strength=1., _y0=y0.cuda())
+    e = rel2(s, s_r)
+    _report(f'cfg5_sample_{init}', dict(case='cfg5-shaped sample()', init=init, kw=kw, B=B, prompt=Tp, duration=dur, steps=steps,
+                                        sampled_mel_rel_l2=e))
+    print('sampled mel rel-L2', init, e)
+    assert s.shape == s_r.shape == (B, dur, 100)
+    # 31 midpoint steps x 2 evaluations integrate the per-evaluation error; north star 1e-2 for the reference's own
+    # initialisation, 3e-2 for the stress weights (bf16 residual-stream storage, see _train_step_parity)
+    assert e < (1e-2 if init == 'reference_init' else 3e-2), e

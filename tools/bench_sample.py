@@ -20,11 +20,11 @@ dev = 'cuda'
 random.seed(0)
 torch.manual_seed(0)
 model = E2TTS(transformer=dict(dim=1024, depth=24, heads=16), use_vocos=False).to(dev)
-if '--graphs' in sys.argv:
-    model.transformer.enable_graphs()      # forward-only graphs (one per input signature: cond pass / null pass)
+if '--eager' in sys.argv:
+    model.transformer.enable_plans(False)  # default: forward-only launch plans (one per input signature: cond pass / null pass)
 cond = torch.randn(B, 5, 100, device=dev)
 text = synthetic_text(B, 3)
-model.sample(cond, text=text, duration=1024, steps=3)          # warm-up (packs weights, builds shadows, captures graphs)
+model.sample(cond, text=text, duration=1024, steps=3)          # warm-up (packs weights, builds shadows, records the launch plans)
 torch.cuda.synchronize()
 t0 = time.perf_counter()
 out = model.sample(cond, text=text, duration=1024, steps=steps, cfg_strength=1.)
@@ -32,5 +32,5 @@ torch.cuda.synchronize()
 dt = time.perf_counter() - t0
 fwd_flops = 6336e12 * (B / 32) * ((steps - 1) / 31)
 print(json.dumps({'metric': 'sampled mel-frames/sec (E2TTS.sample, 32 midpoint steps, CFG)', 'value': B * 1024 / dt,
-                  'unit': 'mel-frames/s', 'seconds': dt, 'B': B, 'steps': steps, 'finite': bool(torch.isfinite(out).all()), 'hip_graphs': '--graphs' in sys.argv,
+                  'unit': 'mel-frames/s', 'seconds': dt, 'B': B, 'steps': steps, 'finite': bool(torch.isfinite(out).all()), 'launch_plans': '--eager' not in sys.argv,
                   'model_tflops_per_s': fwd_flops / dt / 1e12, 'shape': list(out.shape)}))

@@ -1,4 +1,4 @@
-"""list host<->device synchronisation points of a graph-mode training step (torch.cuda.set_sync_debug_mode)"""
+"""list host<->device synchronisation points of a plan-mode training step (torch.cuda.set_sync_debug_mode)"""
 import random, sys, time, warnings
 from pathlib import Path
 ROOT = Path(__file__).resolve().parent.parent
@@ -9,7 +9,6 @@ from e2_tts_pytorch_amd import E2TTS
 dim, depth, heads, B, T = bench.CONFIGS['cfg3']
 random.seed(1234); torch.manual_seed(1234)
 model = E2TTS(transformer=dict(dim=dim, depth=depth, heads=heads, dropout=0.1), use_vocos=False, cond_drop_prob=0.).cuda().train()
-model.transformer.enable_graphs()
 mel = torch.randn(B, T, 100, device='cuda'); text = bench.synthetic_text(B, 1000)
 def step():
     out = model(mel, text=text); out.loss.backward(); model.zero_grad(set_to_none=True); return out.loss
