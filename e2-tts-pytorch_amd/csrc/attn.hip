@@ -79,9 +79,23 @@ __device__ __forceinline__ bf16x8 pack_frag(const float* lo4, const float* hi4) 
     return __builtin_bit_cast(bf16x8, v);
 }
 
-// dropout keep flags of the key pair (2j, 2j+1) for query row q: one hash, low / high 16 bits
-// (hrow = rand_base(seed, stream) + q * 0x85ebca77 is hoisted by the caller; oracle/dropout_hash.py restates this)
-__device__ __forceinline__ unsigned drop_hash(unsigned hrow, unsigned keypair) { return fmix32(hrow + keypair * 0xc2b2ae3du); }
+// Dropout keep decisions: four 16-bit uniform samples per hash for the keys 4j .. 4j+3 of query row q
+// (hrow = rand_base(seed, stream) + q * 0x85ebca77 is hoisted by the caller; key j keeps iff its sample >= thresh;
+// oracle/dropout_hash.py restates this bit for bit).  One full avalanche (fmix32) for the first word, a cheap xor-shift-multiply
+// of it for the second: the round-1 generator spent one fmix32 per PAIR of keys, 40 % of the forward's VALU instructions.
+__device__ __forceinline__ void drop4(unsigned hrow, unsigned key4, unsigned& w0, unsigned& w1) {
+    w0 = fmix32(hrow + key4 * 0xc2b2ae3du);
+    unsigned x = w0 ^ (w0 >> 15);
+    x *= 0x2c1b3c6du;
+    w1 = x ^ (x >> 12);
+}
+__device__ __forceinline__ unsigned drop_sample(unsigned w0, unsigned w1, int j) {      // j = key & 3
+    const unsigned w = (j & 2) ? w1 : w0;
+    return (j & 1) ? (w >> 16) : (w & 0xffffu);
+}
+// stream of the counter hash for (attention call, batch * head): top bit set, so that it can never meet a GEGLU stream
+// (those are the plain call ids) whatever the batch size
+__device__ __forceinline__ unsigned attn_stream(unsigned stream_id, unsigned bh) { return 0x80000000u | (stream_id << 16) | bh; }
 
 // soft-clamp: tanh(raw * scale / 50) via one v_exp_f32 and one v_rcp_f32: tanh(x) = 1 - 2 / (2^(2 x log2 e) + 1)
 __device__ __forceinline__ float clamp_tanh(float raw, float k2) { return 1.f - 2.f * fast_rcp(fast_exp2(raw * k2) + 1.f); }
@@ -91,23 +105,31 @@ __device__ __forceinline__ float clamp_tanh_scaled(float raw, float k2, float cl
 // Polynomial tanh for |x| <= 0.75 (max relative error 3.1e-5, minimax fit in x^2), two values per packed-fp32
 // instruction and no transcendental: soft-clamp arguments are raw * scale / 50, i.e. |raw * scale| <= 37.5 -- every
 // realistic attention logit.  Each 64-key tile takes this path only when a wave vote says all of its scores are in
-// range; otherwise the exp2 / rcp form above runs (same result to fp32 rounding).
+// range; otherwise the exp2 / rcp form above runs (same result to fp32 rounding).  The input scale kx = scale / 50 and
+// an output factor `out` (log2(e) * 50 in the forward, 1 in the backward) are folded into the coefficients:
+//   out * tanh(s kx) = s (a0 + a1 w + a2 w^2 + a3 w^3),  w = s^2,  a_i = out * kx^(2i+1) * c_i        (5 packed instructions)
 typedef float f32x2_ __attribute__((ext_vector_type(2)));
 constexpr float TANH_POLY_MAX = 0.75f;
-__device__ __forceinline__ f32x2_ tanh_poly2(f32x2_ x) {
-    const f32x2_ u = x * x;
-    f32x2_ pl = u * -0.0338411346f + 0.125959146f;
-    pl = pl * u + -0.332331483f;
-    pl = pl * u + 0.999968926f;
-    return x * pl;
+struct ClampPoly { float a0, a1, a2, a3; };
+__device__ __forceinline__ ClampPoly clamp_poly(float kx, float out) {
+    const float k2 = kx * kx, k1 = out * kx;
+    return ClampPoly{k1 * 0.999968926f, k1 * k2 * -0.332331483f, k1 * k2 * k2 * 0.125959146f, k1 * k2 * k2 * k2 * -0.0338411346f};
 }
-// largest |score| of a lane's 16 scores
+__device__ __forceinline__ f32x2_ clamp2(f32x2_ s, const ClampPoly& c) {
+    const f32x2_ w = s * s;
+    f32x2_ pl = w * c.a3 + c.a2;
+    pl = pl * w + c.a1;
+    pl = pl * w + c.a0;
+    return s * pl;
+}
+// largest |score| of a lane's 16 scores (v_max3_f32 chains)
 __device__ __forceinline__ float abs_max16(const f32x4 (&s)[4]) {
     float a = 0.f;
 #pragma unroll
-    for (int t = 0; t < 4; ++t)
-#pragma unroll
-        for (int r = 0; r < 4; ++r) a = fmaxf(a, fabsf(s[t][r]));
+    for (int t = 0; t < 4; ++t) {
+        a = fmaxf(fmaxf(fabsf(s[t][0]), fabsf(s[t][1])), a);
+        a = fmaxf(fmaxf(fabsf(s[t][2]), fabsf(s[t][3])), a);
+    }
     return a;
 }
 
@@ -298,7 +320,7 @@ __global__ __launch_bounds__(256, 2) void attn_fwd_kernel(AttnArgs p) {
     const long bh = (long)b * p.H + h;
     const int q = q0 + wave * 16 + l15;
     const bool qin = q < p.N;
-    const unsigned dstream = p.stream_id * 8192u + (unsigned)bh;
+    const unsigned dstream = attn_stream(p.stream_id, (unsigned)bh);
 
     bf16x8 qf[2];
 #pragma unroll
@@ -308,9 +330,16 @@ __global__ __launch_bounds__(256, 2) void attn_fwd_kernel(AttnArgs p) {
     f32x4 o[4];
 #pragma unroll
     for (int ct = 0; ct < 4; ++ct) o[ct] = f32x4{0.f, 0.f, 0.f, 0.f};
-    float m = NEG_BIG, lsum = 0.f;
-    const float k2 = 2.f * LOG2E * p.scale / CLAMP, cl2 = CLAMP * LOG2E;
+    // No running maximum: the soft-clamp bounds every logit to +-50 (+-72.1 in the log2 domain), so exp2 of it is between
+    // 2^-72 and 2^72, a row sum over any realistic number of keys stays far inside fp32 (and bf16 has fp32's exponent
+    // range for the probabilities), and relative precision does not depend on the reference point.  The online-softmax
+    // bookkeeping (tile max, cross-lane max, rescale factor, accumulator rescale) is simply not needed here.
+    f32x2_ lsum2 = {0.f, 0.f};
+    const float kx = p.scale / CLAMP;
+    const float k2 = 2.f * LOG2E * kx, cl2 = CLAMP * LOG2E;
+    const ClampPoly cp = clamp_poly(kx, cl2);
     const unsigned hrow = rand_base(p.seed_dev ? *p.seed_dev : p.seed, dstream) + (unsigned)q * 0x85ebca77u;
+    const unsigned hlane = hrow + (unsigned)(2 * g) * 0xc2b2ae3du;      // + key4 of (t, tile) below
 
     const int ntiles = (p.N + 63) / 64;
     const bf16_t* Kbase = p.K + bh * p.N * DH;
@@ -333,19 +362,16 @@ __global__ __launch_bounds__(256, 2) void attn_fwd_kernel(AttnArgs p) {
         // mask bits of keys k0 + 32*kk2 + 8g .. +8  (kk2 = t>>1, bit index = 8*kk2 + 4*(t&1) + r)
         const unsigned km = mask_bits(ld<unsigned long long>(p.kmask + (long)b * p.Npad + k0 + g * 8)) |
                             (mask_bits(ld<unsigned long long>(p.kmask + (long)b * p.Npad + k0 + 32 + g * 8)) << 8);
-        // soft-clamp all 16 scores as independent chains (no per-score control flow: the exp2 / rcp pipelines
-        // overlap), then mask; tiles without masked keys (all but the last one or two) skip the selects
         const bool allk = wave_all(km == 0xffffu);
-        float tmax = NEG_MASK;
-        const float kx = p.scale / CLAMP;
+        // soft-clamp in the log2 domain, two scores per packed instruction (wave vote: exp2 / rcp form for out-of-range tiles)
         if (wave_all(abs_max16(s) * kx <= TANH_POLY_MAX)) {
 #pragma unroll
             for (int t = 0; t < 4; ++t)
 #pragma unroll
                 for (int r = 0; r < 4; r += 2) {
-                    const f32x2_ th = tanh_poly2(f32x2_{s[t][r], s[t][r + 1]} * kx) * cl2;
-                    s[t][r] = th[0];
-                    s[t][r + 1] = th[1];
+                    const f32x2_ z = clamp2(f32x2_{s[t][r], s[t][r + 1]}, cp);
+                    s[t][r] = z[0];
+                    s[t][r + 1] = z[1];
                 }
         } else {
 #pragma unroll
@@ -353,7 +379,7 @@ __global__ __launch_bounds__(256, 2) void attn_fwd_kernel(AttnArgs p) {
 #pragma unroll
                 for (int r = 0; r < 4; ++r) s[t][r] = clamp_tanh_scaled(s[t][r], k2, cl2);
         }
-        if (!allk) {
+        if (!allk) {            // masked keys (only the last tile or two of a sequence): exp2 gives an exact 0
 #pragma unroll
             for (int t = 0; t < 4; ++t)
 #pragma unroll
@@ -363,41 +389,27 @@ __global__ __launch_bounds__(256, 2) void attn_fwd_kernel(AttnArgs p) {
                 }
         }
 #pragma unroll
-        for (int t = 0; t < 4; ++t)
+        for (int t = 0; t < 4; ++t) {
+            float pr[4];
 #pragma unroll
-            for (int r = 0; r < 4; ++r) tmax = fmaxf(tmax, s[t][r]);
-        tmax = fmaxf(tmax, __shfl_xor(tmax, 16));
-        tmax = fmaxf(tmax, __shfl_xor(tmax, 32));
-        const float mnew = fmaxf(m, tmax);
-        const bool same_max = wave_all(mnew == m);          // running maxima settle after the first few tiles
-        const float alpha = same_max ? 1.f : fast_exp2(m - mnew);
-        m = mnew;
-        float psum = 0.f;
+            for (int r = 0; r < 4; ++r) pr[r] = fast_exp2(s[t][r]);
+            lsum2 += f32x2_{pr[0], pr[1]};           // softmax denominators are taken BEFORE dropout
+            lsum2 += f32x2_{pr[2], pr[3]};
+            if (DROP) {          // keys of r = 0..3 are four consecutive keys: one hash; 1/(1-p) is applied once at the end
+                unsigned w0, w1;
+                drop4(hlane, (unsigned)(k0 >> 2) + 8 * (t >> 1) + (t & 1), w0, w1);
+                const bool kp[4] = {(w0 & 0xffffu) >= p.thresh, (w0 >> 16) >= p.thresh, (w1 & 0xffffu) >= p.thresh, (w1 >> 16) >= p.thresh};
 #pragma unroll
-        for (int t = 0; t < 4; ++t)
-#pragma unroll
-            for (int r = 0; r < 4; r += 2) {
-                float p0 = fast_exp2(s[t][r] - mnew), p1 = fast_exp2(s[t][r + 1] - mnew);
-                psum += p0 + p1;
-                if (DROP) {          // keys of r, r+1 are an (even, odd) pair; 1/(1-p) is applied once at the end
-                    const unsigned hh = drop_hash(hrow, (unsigned)(k0 + perm_row(t, 4 * g + r)) >> 1);
-                    const bool keep0 = (hh & 0xffffu) >= p.thresh, keep1 = (hh >> 16) >= p.thresh;
-                    p0 = keep0 ? p0 : 0.f;
-                    p1 = keep1 ? p1 : 0.f;
+                for (int r = 0; r < 4; ++r) {
+                    pr[r] = kp[r] ? pr[r] : 0.f;
                     if (SHARE) {         // publish the compare masks for the backward kernels
-                        const unsigned long long m0 = wave_ballot(keep0), m1 = wave_ballot(keep1);
-                        if (lane == 0) { dropw[4 * t + r] = m0; dropw[4 * t + r + 1] = m1; }
+                        const unsigned long long mk = wave_ballot(kp[r]);
+                        if (lane == 0) dropw[4 * t + r] = mk;
                     }
                 }
-                s[t][r] = p0;
-                s[t][r + 1] = p1;
             }
-        psum += __shfl_xor(psum, 16);
-        psum += __shfl_xor(psum, 32);
-        lsum = lsum * alpha + psum;
-        if (!same_max) {
 #pragma unroll
-            for (int ct = 0; ct < 4; ++ct) o[ct] *= alpha;
+            for (int r = 0; r < 4; ++r) s[t][r] = pr[r];
         }
 #pragma unroll
         for (int kk2 = 0; kk2 < 2; ++kk2) {
@@ -412,11 +424,14 @@ __global__ __launch_bounds__(256, 2) void attn_fwd_kernel(AttnArgs p) {
         }
         __syncthreads();
     }
+    float lsum = lsum2[0] + lsum2[1];           // a row's keys are spread over the lanes l, l+16, l+32, l+48
+    lsum += __shfl_xor(lsum, 16);
+    lsum += __shfl_xor(lsum, 32);
     if (!qin) return;
     const float inv = lsum > 0.f ? (DROP ? p.inv_keep : 1.f) / lsum : 0.f;
     const float gt = p.gate[bh * p.N + q];
     const bool qkeep = p.kmask[(long)b * p.Npad + q] != 0;
-    if (g == 0) p.lse2[bh * p.N + q] = m + log2f(fmaxf(lsum, 1e-37f));
+    if (g == 0) p.lse2[bh * p.N + q] = log2f(fmaxf(lsum, 1e-37f));
     const long orow = ((long)b * p.N + q) * ((long)p.H * DH) + h * DH;
 #pragma unroll
     for (int ct = 0; ct < 4; ++ct) {
@@ -489,7 +504,7 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dq_kernel(AttnArgs p) {
     const long bh = (long)b * p.H + h;
     const int q = q0 + wave * 16 + l15;
     const bool qin = q < p.N;
-    const unsigned dstream = p.stream_id * 8192u + (unsigned)bh;
+    const unsigned dstream = attn_stream(p.stream_id, (unsigned)bh);
 
     bf16x8 qf[2], dof[2];
 #pragma unroll
@@ -497,10 +512,14 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dq_kernel(AttnArgs p) {
         qf[kk] = qin ? ld<bf16x8>(p.Q + (bh * p.N + q) * DH + kk * 32 + g * 8) : bf16x8{0, 0, 0, 0, 0, 0, 0, 0};
         dof[kk] = qin ? ld<bf16x8>(p.dO + (bh * p.N + q) * DH + kk * 32 + g * 8) : bf16x8{0, 0, 0, 0, 0, 0, 0, 0};
     }
-    const float lse = qin ? p.lse2[bh * p.N + q] : 1e30f;
+    const float kx = p.scale / CLAMP;
+    const float k2 = 2.f * LOG2E * kx, cl2 = CLAMP * LOG2E;
+    const ClampPoly cp = clamp_poly(kx, 1.f);
+    // dS = P (dP - delta) (1 - th^2) scale: the trailing `scale` is folded into the exponent of P (lse - log2(scale))
+    const float lse = qin ? p.lse2[bh * p.N + q] - log2f(p.scale) : 1e30f;
     const float dl = qin ? p.delta[bh * p.N + q] : 0.f;
-    const float k2 = 2.f * LOG2E * p.scale / CLAMP, cl2 = CLAMP * LOG2E;
     const unsigned hrow = rand_base(p.seed_dev ? *p.seed_dev : p.seed, dstream) + (unsigned)q * 0x85ebca77u;
+    const unsigned hlane = hrow + (unsigned)(2 * g) * 0xc2b2ae3du;
 
     f32x4 dq[4];
 #pragma unroll
@@ -531,35 +550,41 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dq_kernel(AttnArgs p) {
         const unsigned km = mask_bits(ld<unsigned long long>(p.kmask + (long)b * p.Npad + k0 + g * 8)) |
                             (mask_bits(ld<unsigned long long>(p.kmask + (long)b * p.Npad + k0 + 32 + g * 8)) << 8);
         const bool allk = wave_all(km == 0xffffu);
-        const float kx = p.scale / CLAMP;
         const bool small = wave_all(abs_max16(s) * kx <= TANH_POLY_MAX);
         const unsigned long long* dropw = (DROP && SHARE)
             ? p.dropbits + ((((long)bh * ntiles + kt) * gridDim.x + blockIdx.x) * 4 + uniform_i(wave)) * 16 : nullptr;
 #pragma unroll
-        for (int t = 0; t < 4; ++t)
+        for (int t = 0; t < 4; ++t) {
+            float ks[4] = {1.f, 1.f, 1.f, 1.f};
+            if (DROP) {
+                if (SHARE) {             // the forward's compare masks: same lane <-> (query, key) layout as here
 #pragma unroll
-            for (int r = 0; r < 4; r += 2) {
-                float ks0 = 1.f, ks1 = 1.f;
-                if (DROP) {
-                    if (SHARE) {         // the forward's compare masks: same lane <-> (query, key) layout as here
-                        ks0 = wave_inverse_ballot(sload64(dropw + 4 * t + r)) ? p.inv_keep : 0.f;
-                        ks1 = wave_inverse_ballot(sload64(dropw + 4 * t + r + 1)) ? p.inv_keep : 0.f;
-                    } else {
-                        const unsigned hh = drop_hash(hrow, (unsigned)(k0 + perm_row(t, 4 * g + r)) >> 1);
-                        ks0 = (hh & 0xffffu) >= p.thresh ? p.inv_keep : 0.f;
-                        ks1 = (hh >> 16) >= p.thresh ? p.inv_keep : 0.f;
-                    }
-                }
-                f32x2_ th2;
-                if (small) th2 = tanh_poly2(f32x2_{s[t][r], s[t][r + 1]} * kx);
-                else th2 = f32x2_{clamp_tanh(s[t][r], k2), clamp_tanh(s[t][r + 1], k2)};
-#pragma unroll
-                for (int e = 0; e < 2; ++e) {
-                    const float th = th2[e];
-                    const float pv = fast_exp2(cl2 * th - lse);
-                    s[t][r + e] = pv * (dp[t][r + e] * (e ? ks1 : ks0) - dl) * (1.f - th * th) * p.scale;
+                    for (int r = 0; r < 4; ++r) ks[r] = wave_inverse_ballot(sload64(dropw + 4 * t + r)) ? p.inv_keep : 0.f;
+                } else {
+                    unsigned w0, w1;
+                    drop4(hlane, (unsigned)(k0 >> 2) + 8 * (t >> 1) + (t & 1), w0, w1);
+                    ks[0] = (w0 & 0xffffu) >= p.thresh ? p.inv_keep : 0.f;
+                    ks[1] = (w0 >> 16) >= p.thresh ? p.inv_keep : 0.f;
+                    ks[2] = (w1 & 0xffffu) >= p.thresh ? p.inv_keep : 0.f;
+                    ks[3] = (w1 >> 16) >= p.thresh ? p.inv_keep : 0.f;
                 }
             }
+#pragma unroll
+            for (int r = 0; r < 4; r += 2) {
+                f32x2_ th;
+                if (small) th = clamp2(f32x2_{s[t][r], s[t][r + 1]}, cp);
+                else th = f32x2_{clamp_tanh(s[t][r], k2), clamp_tanh(s[t][r + 1], k2)};
+                const f32x2_ arg = th * cl2 - lse;
+                const f32x2_ pv = {fast_exp2(arg[0]), fast_exp2(arg[1])};
+                f32x2_ t1 = f32x2_{dp[t][r], dp[t][r + 1]};
+                if (DROP) t1 = t1 * f32x2_{ks[r], ks[r + 1]};
+                t1 = t1 - dl;
+                const f32x2_ t2 = 1.f - th * th;
+                const f32x2_ ds = (pv * t1) * t2;
+                s[t][r] = ds[0];
+                s[t][r + 1] = ds[1];
+            }
+        }
         if (!allk) {        // masked keys contribute nothing (only the last tile or two of a sequence)
 #pragma unroll
             for (int t = 0; t < 4; ++t)
@@ -599,7 +624,8 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dkv_kernel(AttnArgs p) {
     __shared__ __attribute__((aligned(16))) unsigned char dOt[64 * 128];
     __shared__ __attribute__((aligned(16))) unsigned char QTt[64 * 128];
     __shared__ __attribute__((aligned(16))) unsigned char dOTt[64 * 128];
-    __shared__ float lse_s[64], del_s[64];
+    __shared__ __attribute__((aligned(16))) float lse_s[64];
+    __shared__ __attribute__((aligned(16))) float del_s[64];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int l15 = lane & 15, g = lane >> 4;
     const int k0 = blockIdx.x * 64, h = blockIdx.y, b = blockIdx.z;
@@ -607,7 +633,7 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dkv_kernel(AttnArgs p) {
     const int key = k0 + wave * 16 + l15;
     const bool kin = key < p.N;
     const bool kkeep = kin && p.kmask[(long)b * p.Npad + key] != 0;
-    const unsigned dstream = p.stream_id * 8192u + (unsigned)bh;
+    const unsigned dstream = attn_stream(p.stream_id, (unsigned)bh);
 
     bf16x8 kf[2], vf[2];
 #pragma unroll
@@ -618,8 +644,10 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dkv_kernel(AttnArgs p) {
     f32x4 dk[4], dv[4];
 #pragma unroll
     for (int ct = 0; ct < 4; ++ct) { dk[ct] = f32x4{0.f, 0.f, 0.f, 0.f}; dv[ct] = f32x4{0.f, 0.f, 0.f, 0.f}; }
-    const float k2 = 2.f * LOG2E * p.scale / CLAMP, cl2 = CLAMP * LOG2E;
-    const unsigned hkey = rand_base(p.seed_dev ? *p.seed_dev : p.seed, dstream) + ((unsigned)key >> 1) * 0xc2b2ae3du;
+    const float kx = p.scale / CLAMP;
+    const float k2 = 2.f * LOG2E * kx, cl2 = CLAMP * LOG2E;
+    const ClampPoly cp = clamp_poly(kx, 1.f);
+    const unsigned hkey = rand_base(p.seed_dev ? *p.seed_dev : p.seed, dstream) + ((unsigned)key >> 2) * 0xc2b2ae3du;
 
     const int ntiles = (p.N + 63) / 64;
     const bf16_t* Qbase = p.Q + bh * p.N * DH;
@@ -638,7 +666,7 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dkv_kernel(AttnArgs p) {
         tile_sstore(dOTt, r3, tid);
         if (tid < 64) {
             const int qq = q0 + tid;
-            lse_s[tid] = qq < p.N ? p.lse2[bh * p.N + qq] : 1e30f;
+            lse_s[tid] = qq < p.N ? p.lse2[bh * p.N + qq] : 1e30f;         // (rows past N: exp2(-1e30) = 0)
             del_s[tid] = qq < p.N ? p.delta[bh * p.N + qq] : 0.f;
         }
         __syncthreads();
@@ -679,44 +707,46 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dkv_kernel(AttnArgs p) {
             dword[0] = base[0];
             dword[1] = base[2 * 16];
         }
-        const float kx = p.scale / CLAMP;
-        if (wave_all(abs_max16(s) * kx <= TANH_POLY_MAX)) {      // soft-clamp tanh, see tanh_poly2
+        const bool small = wave_all(abs_max16(s) * kx <= TANH_POLY_MAX);      // soft-clamp tanh, see clamp2
 #pragma unroll
-            for (int t = 0; t < 4; ++t)
+        for (int t = 0; t < 4; ++t) {
+            // the 4 queries of (t, r = 0..3) are consecutive: 32 (t>>1) + 8 g + 4 (t&1) + r -> one 16-byte LDS read each
+            const int qi0 = perm_row(t, 4 * g);
+            const f32x4 ls4 = ld<f32x4>(&lse_s[qi0]), dl4 = ld<f32x4>(&del_s[qi0]);
+            float ks[4] = {1.f, 1.f, 1.f, 1.f};
+            if (DROP) {
 #pragma unroll
-                for (int r = 0; r < 4; r += 2) {
-                    const f32x2_ th = tanh_poly2(f32x2_{s[t][r], s[t][r + 1]} * kx);
-                    s[t][r] = th[0];
-                    s[t][r + 1] = th[1];
-                }
-        } else {
-#pragma unroll
-            for (int t = 0; t < 4; ++t)
-#pragma unroll
-                for (int r = 0; r < 4; ++r) s[t][r] = clamp_tanh(s[t][r], k2);
-        }
-#pragma unroll
-        for (int t = 0; t < 4; ++t)
-#pragma unroll
-            for (int r = 0; r < 4; ++r) {
-                const int qi = perm_row(t, 4 * g + r);
-                // (no key masking here: a lane's scores all belong to ITS key, whose dK / dV row is zeroed at the end)
-                const float th = s[t][r];
-                const float pr = fast_exp2(cl2 * th - lse_s[qi]);
-                float ks = 1.f;
-                if (DROP) {
+                for (int r = 0; r < 4; ++r) {
                     if (SHARE) {         // bit of (query qi, this lane's key) in the forward's ballot words
-                        ks = ((dword[t >> 1] >> (dbit0 + 4 * (t & 1) + r)) & 1ull) ? p.inv_keep : 0.f;
+                        ks[r] = ((dword[t >> 1] >> (dbit0 + 4 * (t & 1) + r)) & 1ull) ? p.inv_keep : 0.f;
                     } else {
-                        const unsigned hh = fmix32(hkey + (unsigned)(q0 + qi) * 0x85ebca77u);
-                        ks = ((key & 1) ? (hh >> 16) : (hh & 0xffffu)) >= p.thresh ? p.inv_keep : 0.f;
+                        unsigned w0 = fmix32(hkey + (unsigned)(q0 + qi0 + r) * 0x85ebca77u), w1 = 0;
+                        if (key & 2) { unsigned x = w0 ^ (w0 >> 15); x *= 0x2c1b3c6du; w1 = x ^ (x >> 12); }
+                        ks[r] = drop_sample(w0, w1, key & 3) >= p.thresh ? p.inv_keep : 0.f;
                     }
                 }
-                const float pv = pr * ks;
-                const float ds = pr * (dp[t][r] * ks - del_s[qi]) * (1.f - th * th) * p.scale;
-                pd[t][r] = pv;
-                dsv[t][r] = ds;
             }
+#pragma unroll
+            for (int r = 0; r < 4; r += 2) {
+                // (no key masking here: a lane's scores all belong to ITS key, whose dK / dV row is zeroed at the end)
+                f32x2_ th;
+                if (small) th = clamp2(f32x2_{s[t][r], s[t][r + 1]}, cp);
+                else th = f32x2_{clamp_tanh(s[t][r], k2), clamp_tanh(s[t][r + 1], k2)};
+                const f32x2_ arg = th * cl2 - f32x2_{ls4[r], ls4[r + 1]};
+                const f32x2_ pr = {fast_exp2(arg[0]), fast_exp2(arg[1])};
+                const f32x2_ k2s = {ks[r], ks[r + 1]};
+                const f32x2_ pv = DROP ? pr * k2s : pr;
+                f32x2_ t1 = f32x2_{dp[t][r], dp[t][r + 1]};
+                if (DROP) t1 = t1 * k2s;
+                t1 = t1 - f32x2_{dl4[r], dl4[r + 1]};
+                const f32x2_ t2 = (th * -p.scale) * th + p.scale;        // (1 - th^2) * scale
+                const f32x2_ ds = (pr * t1) * t2;
+                pd[t][r] = pv[0];
+                pd[t][r + 1] = pv[1];
+                dsv[t][r] = ds[0];
+                dsv[t][r + 1] = ds[1];
+            }
+        }
 #pragma unroll
         for (int kk2 = 0; kk2 < 2; ++kk2) {
             bf16x8 pf = pack_frag(pd[2 * kk2], pd[2 * kk2 + 1]);
@@ -780,7 +810,7 @@ static int qkv_post_bwd_impl(const void* dQ, const void* dK, const void* dV, con
 static int fill_attn(AttnArgs& a, int B, int H, int N, int Npad, float p_drop, uint32_t seed, const uint32_t* seed_dev,
                      uint32_t stream_id) {
     if ((Npad & 63) || Npad < N) return E2K_ERR_ALIGN;
-    if (B * H >= 8192) return E2K_ERR_SHAPE;
+    if ((long)B * H >= 65536 || stream_id >= 32768u) return E2K_ERR_SHAPE;      // attn_stream() packs (call id, b * H + h)
     a.B = B; a.H = H; a.N = N; a.Npad = Npad;
     a.scale = 0.125f;   // dim_head ** -0.5, dim_head = 64
     a.seed = seed; a.seed_dev = seed_dev; a.stream_id = stream_id;

@@ -174,7 +174,8 @@ __device__ __forceinline__ void nt_epilogue(const NTArgs& p, f32x4 (&acc)[NI][NJ
     }
 }
 
-template <bool OUT_F32, bool GLDS>
+// General NT kernel (any K multiple of 8, e.g. the B x (4 L D) conditioning GEMM): operands staged through VGPRs
+template <bool OUT_F32>
 __global__ __launch_bounds__(256) void gemm_nt_kernel(NTArgs p) {
     __shared__ __attribute__((aligned(16))) unsigned char smem[2][2][BM * BK * 2];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -219,46 +220,18 @@ __global__ __launch_bounds__(256) void gemm_nt_kernel(NTArgs p) {
         }
     };
 
-    // GLDS: HBM -> LDS directly (global_load_lds_dwordx4), no VGPR staging.  A wave instruction fills 8 consecutive
-    // 128-B LDS rows lane-linearly, so the XOR swizzle is applied to the per-lane SOURCE column instead
-    // (cdna_hip_programming.md 5.4 rule 21).  Needs K1, K2 multiples of 64; out-of-range rows are clamped (their
-    // results are never stored).
-    auto gissue = [&](int kt, int buf) {
-        const int k0 = kt * BK;
-        const bf16_t* Ab = p.A1;
-        long lda = p.lda1;
-        int ka = k0;
-        if (k0 >= p.K1) { Ab = p.A2; lda = p.lda2; ka = k0 - p.K1; }
-#pragma unroll
-        for (int i = 0; i < 4; ++i) {
-            const int rb = wave * 4 + i;
-            const int row = rb * 8 + (lane >> 3);
-            const int c = (lane & 7) ^ (row & 7);
-            const int m = min(m0 + row, p.M - 1), n = min(n0 + row, p.N - 1);
-            glds16(Ab + (long)m * lda + ka + c * 8, &smem[buf][0][rb * 1024]);
-            glds16(p.B + (long)n * p.ldb + k0 + c * 8, &smem[buf][1][rb * 1024]);
-        }
-    };
-
     f32x4 acc[4][4];
 #pragma unroll
     for (int i = 0; i < 4; ++i)
 #pragma unroll
         for (int j = 0; j < 4; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
 
-    if (GLDS) {
-        gissue(0, 0);
-    } else {
-        gload(0);
-        sstore(0);
-    }
+    gload(0);
+    sstore(0);
     __syncthreads();
     for (int kt = 0; kt < nk; ++kt) {
         const int buf = kt & 1;
-        if (kt + 1 < nk) {
-            if (GLDS) gissue(kt + 1, buf ^ 1);
-            else gload(kt + 1);
-        }
+        if (kt + 1 < nk) gload(kt + 1);
         const unsigned char* As = smem[buf][0];
         const unsigned char* Bs = smem[buf][1];
 #pragma unroll
@@ -281,7 +254,7 @@ __global__ __launch_bounds__(256) void gemm_nt_kernel(NTArgs p) {
                 for (int j = 0; j < 4; ++j)
                     acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(bw[j], af[i], acc[i][j], 0, 0, 0);
         }
-        if (!GLDS && kt + 1 < nk) sstore(buf ^ 1);
+        if (kt + 1 < nk) sstore(buf ^ 1);
         __syncthreads();
     }
 
@@ -434,145 +407,10 @@ __global__ __launch_bounds__(256) void gemm_nt_fixup_kernel(NTArgs p) {
     nt_epilogue<OUT_F32, 1>(p, acc, tile_m * BM + wm * 64 + i * 16, tile_n * BN + wn * 64, l15, g);
 }
 
-// Large-tile NT kernel: 256 x 128 x 64 tile, EIGHT waves of 64 x 64 (512 threads, two waves per SIMD), THREE 48-KB LDS
-// stages (144 of the CU's 160 KB: one workgroup per CU), global_load_lds prefetch two K steps ahead with a counted
-// s_waitcnt vmcnt and a raw s_barrier so that the prefetches stay in flight across the barrier.  Per flop it moves
-// 25 % fewer bytes through the texture path than the 128 x 128 kernel (whose load side takes as long as its MFMAs).
-// Same LDS row layout / swizzle, epilogue and remainder split as the kernel above.  OPT-IN (flag E2K_GEMM_BIG): on MI355X
-// it only matches the 128 x 128 kernel on its best shape (8192 x 1024 x 4096: 65.7 vs 65.3 us) and is 5-15 % slower on
-// the others -- one workgroup per CU means every barrier stalls the whole CU.  (A 4-wave version with 128 x 64 per
-// wave -- one wave per SIMD -- ran 20-25 % slower still: nothing covers a wave's LDS waits.)
-constexpr int GBM = 256, GST = 3, GSTAGE = (GBM + BN) * BK * 2, GTHREADS = 512;
-
-template <bool OUT_F32>
-__global__ __launch_bounds__(GTHREADS, 1) void gemm_nt_big_kernel(NTArgs p) {
-    __shared__ __attribute__((aligned(16))) unsigned char smem[GST][GSTAGE];
-    const int tid = threadIdx.x, lane = tid & 63, wave = uniform_i(tid >> 6);
-    const int wm = wave >> 1, wn = wave & 1;          // 4 x 2 waves of 64 x 64
-    const int l15 = lane & 15, g = lane >> 4;
-    const int tm = (p.M + GBM - 1) / GBM, tn = (p.N + BN - 1) / BN;
-    int tile_m, tile_n;
-    const int nk1 = p.K1 / BK, nk = (p.K1 + p.K2) / BK;
-    int kb = 0, ke = nk, part = -1;
-    if ((int)blockIdx.x < p.full) {
-        tile_coords(xcd_remap(blockIdx.x, p.full), tm, tn, tile_m, tile_n);
-    } else {
-        part = blockIdx.x - p.full;
-        const int r = part / p.split, sidx = part - r * p.split;
-        tile_coords(p.full + r, tm, tn, tile_m, tile_n);
-        kb = (int)((long)nk * sidx / p.split);
-        ke = (int)((long)nk * (sidx + 1) / p.split);
-    }
-    const int m0 = tile_m * GBM, n0 = tile_n * BN;
-
-    // A offsets: the second K panel (A2) is addressed as va1 + dv (never two arrays behind a select: the compiler turns
-    // that into a pointer select and parks both arrays in scratch)
-    unsigned va1[4], dv[4], vb[2];
-#pragma unroll
-    for (int i = 0; i < 4; ++i) {
-        const int row = (wave * 4 + i) * 8 + (lane >> 3);
-        const int c = (lane & 7) ^ (row & 7);
-        const int m = min(m0 + row, p.M - 1);
-        va1[i] = (unsigned)(((long)m * p.lda1 + c * 8) * 2);
-        dv[i] = p.K2 ? (unsigned)(((long)m * p.lda2 + c * 8) * 2) - va1[i] : 0u;
-    }
-#pragma unroll
-    for (int i = 0; i < 2; ++i) {
-        const int row = (wave * 2 + i) * 8 + (lane >> 3);
-        const int c = (lane & 7) ^ (row & 7);
-        const int n = min(n0 + row, p.N - 1);
-        vb[i] = (unsigned)(((long)n * p.ldb + c * 8) * 2);
-    }
-    int offa[2][4], offb[2][4];
-#pragma unroll
-    for (int kk = 0; kk < 2; ++kk)
-#pragma unroll
-        for (int i = 0; i < 4; ++i) {
-            const int ra = wm * 64 + i * 16 + l15, rb = wn * 64 + i * 16 + l15;
-            offa[kk][i] = ra * 128 + (((kk * 4 + g) ^ (ra & 7)) << 4);
-            offb[kk][i] = GBM * 128 + rb * 128 + (((kk * 4 + g) ^ (rb & 7)) << 4);
-        }
-    unsigned char* const S0 = &smem[0][0];
-    auto gissue = [&](int kt, int stage_off) __attribute__((always_inline)) {
-        const char* sb = (const char*)p.B + (long)kt * (BK * 2);
-        const bool first = kt < nk1;                     // wave-uniform
-        const char* sa = first ? (const char*)p.A1 + (long)kt * (BK * 2) : (const char*)p.A2 + (long)(kt - nk1) * (BK * 2);
-        const unsigned sel = first ? 0u : ~0u;
-#pragma unroll
-        for (int i = 0; i < 4; ++i) glds16(sa + (va1[i] + (dv[i] & sel)), S0 + stage_off + (wave * 4 + i) * 1024);
-#pragma unroll
-        for (int i = 0; i < 2; ++i) glds16(sb + vb[i], S0 + stage_off + GBM * 128 + (wave * 2 + i) * 1024);
-    };
-
-    f32x4 acc[4][4];
-#pragma unroll
-    for (int i = 0; i < 4; ++i)
-#pragma unroll
-        for (int j = 0; j < 4; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
-
-    // ONE copy of the K step: the stage offset is a wave-uniform running value added to the fragment read offsets.
-    // Stage of step kt: (kt - kb) % 3; tile kt + 2 goes to the stage that step kt - 1 just released.
-    gissue(kb, 0);
-    if (kb + 1 < ke) gissue(kb + 1, GSTAGE);
-    int cur = 0, nxt = 2 * GSTAGE;
-    for (int kt = kb; kt < ke; ++kt) {
-        // tile kt must have landed; the younger tile kt + 1 (6 loads of this wave) may stay in flight
-        if (kt + 1 < ke) wait_vmcnt<6>();
-        else wait_vmcnt<0>();
-        barrier_keep_vm();
-        if (kt + 2 < ke) gissue(kt + 2, nxt);
-        const unsigned char* S = S0 + cur;
-#pragma unroll
-        for (int kk = 0; kk < 2; ++kk) {
-            bf16x8 af[4], bw[4];
-#pragma unroll
-            for (int i = 0; i < 4; ++i) af[i] = ld<bf16x8>(S + offa[kk][i]);
-#pragma unroll
-            for (int j = 0; j < 4; ++j) bw[j] = ld<bf16x8>(S + offb[kk][j]);
-#pragma unroll
-            for (int i = 0; i < 4; ++i)
-#pragma unroll
-                for (int j = 0; j < 4; ++j)
-                    acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(bw[j], af[i], acc[i][j], 0, 0, 0);
-        }
-        nxt = cur;
-        cur = cur == 2 * GSTAGE ? 0 : cur + GSTAGE;
-    }
-    if (part >= 0) {        // K-range partial of a remainder tile: [part][i*4+j][tid] x 4 floats
-        float* w = p.ws + ((long)part * 16 * GTHREADS + tid) * 4;
-#pragma unroll
-        for (int i = 0; i < 4; ++i)
-#pragma unroll
-            for (int j = 0; j < 4; ++j) st<f32x4>(w + (i * 4 + j) * (GTHREADS * 4), acc[i][j]);
-        return;
-    }
-    nt_epilogue<OUT_F32, 4>(p, acc, m0 + wm * 64, n0 + wn * 64, l15, g);
-}
-
-template <bool OUT_F32>
-__global__ __launch_bounds__(GTHREADS) void gemm_nt_big_fixup_kernel(NTArgs p) {
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    const int wm = wave >> 1, wn = wave & 1, l15 = lane & 15, g = lane >> 4;
-    const int tm = (p.M + GBM - 1) / GBM, tn = (p.N + BN - 1) / BN;
-    const int i = blockIdx.y;           // 16-row group of the wave's 64 rows
-    int tile_m, tile_n;
-    tile_coords(p.full + blockIdx.x, tm, tn, tile_m, tile_n);
-    f32x4 acc[1][4];
-#pragma unroll
-    for (int j = 0; j < 4; ++j) acc[0][j] = f32x4{0.f, 0.f, 0.f, 0.f};
-    const float* w = p.ws + (((long)blockIdx.x * p.split * 16 + i * 4) * GTHREADS + tid) * 4;
-#pragma unroll 4
-    for (int sidx = 0; sidx < p.split; ++sidx) {
-#pragma unroll
-        for (int j = 0; j < 4; ++j) acc[0][j] += ld<f32x4>(w + ((long)sidx * 16 + j) * (GTHREADS * 4));
-    }
-    nt_epilogue<OUT_F32, 1>(p, acc, tile_m * GBM + wm * 64 + i * 16, tile_n * BN + wn * 64, l15, g);
-}
-
 // 256 x 256 x 64 tile, EIGHT waves (512 threads, one workgroup per CU, two waves per SIMD), 128 KB of LDS, 8 phases per
 // pair of K tiles (cdna_hip_programming.md "256^2 8-phase template", rebuilt for this kernel's operand layout and
-// epilogue).  OPT-IN (flags E2K_GEMM_T256 / E2K_GEMM_T256_AUTO): written after round 1's GPU minutes were spent, so it is
-// parity-tested on the host model only -- its asynchronous-copy ordering has not run on hardware yet.
+// epilogue).  Default for shapes that fill the chip with 256 x 256 tiles; on MI355X 790-1011 TFLOP/s on the cfg3 shapes
+// against 655-868 of the 128 x 128 kernel (profiles/r02_gemm_t256_first_hw_run.json), bit-repeatable over 50 launches.
 //
 // Why: with 128 x 128 tiles a K step moves 32 KB through the texture path for 2.1 MFLOP, which takes the load side as
 // long as the MFMAs; a 256 x 256 tile moves 64 KB for 8.4 MFLOP, half the bytes per flop.
@@ -1052,6 +890,218 @@ __global__ __launch_bounds__(256, 2) void gemm_tn_glds_kernel(TNArgs p) {
     }
 }
 
+// 256 x 256 output tile, EIGHT waves, 8 phases per pair of 64-row reduction steps: the weight-gradient sibling of
+// gemm_nt_256_kernel (same half-tile ring, same phase / prefetch / counted-vmcnt schedule -- see the comment there; that
+// schedule has run on MI355X).  Per reduction step of 64 token rows the workgroup stages four 16-KB half tiles
+//   [A cols 0-127 | A cols 128-255 | B cols 0-127 | B cols 128-255],   A = dY (n columns), B = X (k columns),
+// each 64 rows x 256 B with the 16-byte chunks XOR-swizzled by 2 * (row & 7) on the SOURCE side (the layout of
+// gemm_tn_glds_kernel: conflict-free ds_read_b64_tr_b16).  Wave (wr, wc) = (wave >> 2, wave & 3) owns columns wr*64..+63 of
+// BOTH A halves and columns wc*32..+31 of BOTH B halves, i.e. four 64 (n) x 32 (k) quadrants of the output tile.
+// Half the LDS-read bytes per flop and a quarter of the partial-tile traffic per flop of the 128 x 128 kernel.
+constexpr int T2 = 256, T2HALF = TBM * 256, T2BUF = 4 * T2HALF, T2THREADS = 512;
+
+template <bool CS>
+__global__ __launch_bounds__(T2THREADS, 1) void gemm_tn_256_kernel(TNArgs p) {
+    __shared__ __attribute__((aligned(16))) unsigned char smem[2 * T2BUF];
+    const int tid = threadIdx.x, lane = tid & 63, wave = uniform_i(tid >> 6);
+    const int wr = wave >> 2, wc = wave & 3;
+    const int q = lane & 15, g = lane >> 4;
+    const int tn = (p.N + T2 - 1) / T2, tk = (p.K + T2 - 1) / T2;
+    int tile_n, tile_k;
+    tile_coords(xcd_remap(blockIdx.x, gridDim.x), tn, tk, tile_n, tile_k);
+    const int n0 = tile_n * T2, k0 = tile_k * T2;
+    const int mbeg = blockIdx.y * p.chunk;
+    const int mend = min(p.M, mbeg + p.chunk);
+    const int nt = (mend - mbeg) / TBM;                       // reduction steps of this workgroup
+
+    // staging: a half tile is 16 wave instructions of 4 rows; wave w issues rows (2w + u) * 4 + (lane >> 4), u = 0, 1
+    unsigned va[2][2], vb[2][2];
+#pragma unroll
+    for (int h = 0; h < 2; ++h)
+#pragma unroll
+        for (int u = 0; u < 2; ++u) {
+            const int row = (wave * 2 + u) * 4 + (lane >> 4);
+            const int c = (lane & 15) ^ (2 * (row & 7));
+            const int cn = min(n0 + h * 128 + c * 8, ((p.N + 7) & ~7) - 8), ck = min(k0 + h * 128 + c * 8, ((p.K + 7) & ~7) - 8);
+            va[h][u] = (unsigned)((((long)(mbeg + row)) * p.lda + cn) * 2);
+            vb[h][u] = (unsigned)((((long)(mbeg + row)) * p.ldb + ck) * 2);
+        }
+    // fragment read offsets inside a half tile: row (4g + q/4) of a 16-row slab, chunk (col/8 ^ 2*(row&7)) + (q&3)/2, byte (q&1)*8
+    const int r7 = (4 * g + (q >> 2)) & 7;
+    const int lanepart = (4 * g + (q >> 2)) * 256 + ((q & 3) >> 1) * 16 + (q & 1) * 8;
+    int offa[4], offb[2];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) offa[i] = lanepart + (((wr * 8 + 2 * i) ^ (2 * r7)) << 4);
+#pragma unroll
+    for (int j = 0; j < 2; ++j) offb[j] = lanepart + (((wc * 4 + 2 * j) ^ (2 * r7)) << 4);
+
+    unsigned char* const S0 = &smem[0];
+    // half-tile slots of a buffer: 0 = Alo, 1 = Ahi, 2 = Blo, 3 = Bhi; steps past the end are simply not staged
+    auto stage_a = [&](int step, int h) __attribute__((always_inline)) {
+        if (step >= nt) return;
+        const char* sa = (const char*)p.A + (long)step * TBM * p.lda * 2;
+        unsigned char* dst = S0 + (step & 1) * T2BUF + h * T2HALF + wave * 2048;
+#pragma unroll
+        for (int u = 0; u < 2; ++u) glds16(sa + va[h][u], dst + u * 1024);
+    };
+    auto stage_b = [&](int step, int h) __attribute__((always_inline)) {
+        if (step >= nt) return;
+        const char* sb = (const char*)p.B + (long)step * TBM * p.ldb * 2;
+        unsigned char* dst = S0 + (step & 1) * T2BUF + (2 + h) * T2HALF + wave * 2048;
+#pragma unroll
+        for (int u = 0; u < 2; ++u) glds16(sb + vb[h][u], dst + u * 1024);
+    };
+    auto wait_landed = [&](int left) __attribute__((always_inline)) {
+        if (left >= 3) wait_vmcnt<6>();
+        else if (left == 2) wait_vmcnt<4>();
+        else if (left == 1) wait_vmcnt<2>();
+        else wait_vmcnt<0>();
+    };
+
+    f32x4 acc[2][2][4][2];                  // [A half][B half][n16][k16]
+#pragma unroll
+    for (int a = 0; a < 2; ++a)
+#pragma unroll
+        for (int b = 0; b < 2; ++b)
+#pragma unroll
+            for (int i = 0; i < 4; ++i)
+#pragma unroll
+                for (int j = 0; j < 2; ++j) acc[a][b][i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+    bf16x8 ar[2][4], blo[2][2], bhi[2][2];
+    // column sums of A (bias gradient of the same dY) ride along in the k-tile-0 workgroups: wave (wr, wc) takes the
+    // 16-column group i = wc of its 64 columns, one extra MFMA per A half and 32 rows with an all-ones operand
+    const bool do_cs = CS && tile_k == 0 && n0 + T2 > p.cs_from;          // wave-uniform
+    f32x4 cs[2] = {f32x4{0.f, 0.f, 0.f, 0.f}, f32x4{0.f, 0.f, 0.f, 0.f}};
+    const short one = 0x3F80;
+    const bf16x8 ones = bf16x8{one, one, one, one, one, one, one, one};
+
+    auto frag = [&](const unsigned char* T, int kk, int off) __attribute__((always_inline)) -> bf16x8 {
+        s16x4_ lo = lds_read_tr16_b64(T + kk * 32 * 256 + off);
+        s16x4_ hi = lds_read_tr16_b64(T + (kk * 32 + 16) * 256 + off);
+        return __builtin_shufflevector(lo, hi, 0, 1, 2, 3, 4, 5, 6, 7);
+    };
+    auto read_a = [&](const unsigned char* S) __attribute__((always_inline)) {
+#pragma unroll
+        for (int kk = 0; kk < 2; ++kk)
+#pragma unroll
+            for (int i = 0; i < 4; ++i) ar[kk][i] = frag(S, kk, offa[i]);
+    };
+    auto read_b = [&](bf16x8 (&b)[2][2], const unsigned char* S) __attribute__((always_inline)) {
+#pragma unroll
+        for (int kk = 0; kk < 2; ++kk)
+#pragma unroll
+            for (int j = 0; j < 2; ++j) b[kk][j] = frag(S, kk, offb[j]);
+    };
+    // acc[i][j]: C[n = n0 + a*128 + wr*64 + i*16 + q][k = k0 + b*128 + wc*32 + j*16 + 4g + r]
+    auto mma = [&](f32x4 (&c)[4][2], const bf16x8 (&b)[2][2]) __attribute__((always_inline)) {
+        set_prio<1>();
+#pragma unroll
+        for (int kk = 0; kk < 2; ++kk)
+#pragma unroll
+            for (int i = 0; i < 4; ++i)
+#pragma unroll
+                for (int j = 0; j < 2; ++j)
+                    c[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(b[kk][j], ar[kk][i], c[i][j], 0, 0, 0);
+        set_prio<0>();
+    };
+    auto colsum_mma = [&](int a) __attribute__((always_inline)) {
+        if (!do_cs) return;
+        bf16x8 f0, f1;                                        // this wave's group i = wc of the A half it has just read
+        switch (wc) {
+            case 0: f0 = ar[0][0]; f1 = ar[1][0]; break;
+            case 1: f0 = ar[0][1]; f1 = ar[1][1]; break;
+            case 2: f0 = ar[0][2]; f1 = ar[1][2]; break;
+            default: f0 = ar[0][3]; f1 = ar[1][3]; break;
+        }
+        cs[a] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ones, f0, cs[a], 0, 0, 0);
+        cs[a] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ones, f1, cs[a], 0, 0, 0);
+    };
+
+    if (nt > 0) {
+        // prologue: sequence elements 0..5 = all of step 0, then Alo, Blo of step 1; elements 0, 1 must have landed
+        stage_a(0, 0); stage_b(0, 0); stage_b(0, 1); stage_a(0, 1); stage_a(1, 0); stage_b(1, 0);
+        if (nt >= 2) wait_vmcnt<8>();
+        else wait_vmcnt<4>();
+        barrier_raw();
+        if (wr == 1) barrier_raw();              // waves 4-7 trail by one barrier from here on
+
+        for (int t = 0; t < nt; ++t) {
+            const unsigned char* S = S0 + (t & 1) * T2BUF;
+            const int left = 4 * (nt - t) - 3;
+            // phase 1
+            read_b(blo, S + 2 * T2HALF);
+            sched_fence();
+            read_a(S);
+            wait_landed(left);
+            stage_b(t + 1, 1);
+            barrier_raw();
+            mma(acc[0][0], blo);
+            colsum_mma(0);
+            barrier_raw();
+            // phase 2
+            read_b(bhi, S + 3 * T2HALF);
+            wait_landed(left - 1);
+            stage_a(t + 1, 1);
+            barrier_raw();
+            mma(acc[0][1], bhi);
+            barrier_raw();
+            // phase 3
+            read_a(S + T2HALF);
+            wait_landed(left - 2);
+            stage_a(t + 2, 0);
+            barrier_raw();
+            mma(acc[1][1], bhi);
+            colsum_mma(1);
+            barrier_raw();
+            // phase 4
+            wait_landed(left - 3);
+            stage_b(t + 2, 0);
+            barrier_raw();
+            mma(acc[1][0], blo);
+            barrier_raw();
+        }
+        if (wr == 0) barrier_raw();              // pairs with the extra barrier waves 4-7 took at the start
+    }
+
+    // splits == 1: C += acc.  splits > 1: plain stores of the partial tile into ws[split] (combined by tn_reduce_kernel)
+    const bool to_ws = p.splits > 1;
+    float* base = to_ws ? p.ws + (long)blockIdx.y * p.N * p.K : p.C;
+    const long ld = to_ws ? p.K : p.ldc;
+    const bool vec = to_ws && (p.K & 3) == 0;
+#pragma unroll
+    for (int a = 0; a < 2; ++a)
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const int n = n0 + a * 128 + wr * 64 + i * 16 + q;
+            if (n >= p.N) continue;
+#pragma unroll
+            for (int b = 0; b < 2; ++b)
+#pragma unroll
+                for (int j = 0; j < 2; ++j) {
+                    const int k = k0 + b * 128 + wc * 32 + j * 16 + 4 * g;
+                    float* c = base + (long)n * ld + k;
+                    if (vec && k + 3 < p.K) {
+                        st<f32x4>(c, acc[a][b][i][j]);
+                    } else {
+#pragma unroll
+                        for (int r = 0; r < 4; ++r) {
+                            if (k + r < p.K) {
+                                if (to_ws) c[r] = acc[a][b][i][j][r];
+                                else c[r] += acc[a][b][i][j][r];
+                            }
+                        }
+                    }
+                }
+        }
+    if (do_cs && g == 0) {
+#pragma unroll
+        for (int a = 0; a < 2; ++a) {
+            const int n = n0 + a * 128 + wr * 64 + wc * 16 + q;
+            if (n < p.N && n >= p.cs_from) atomicAdd(p.colsum + n, cs[a][0]);
+        }
+    }
+}
+
 // (A pipelined variant of this kernel -- 32 token rows per step, four 16-KB LDS stages, loads three steps ahead with a
 // counted s_waitcnt vmcnt -- was measured 20-28 % SLOWER on every cfg3 shape: PMC shows the waves of the kernel above
 // parked at s_waitcnt / barriers 58 % of the time, but halving the MFMAs per barrier costs more than the deeper
@@ -1090,6 +1140,29 @@ int tn_splits(int M, int N, int K, int splits) {
     return (M + chunk - 1) / chunk;
 }
 
+// token splits of the 256 x 256 weight-gradient kernel: fill the 256 workgroup slots (one per CU) once, at least 8
+// reduction steps of 64 rows per split
+int tn_splits_256(int M, int N, int K, int splits) {
+    const int tiles = ((N + T2 - 1) / T2) * ((K + T2 - 1) / T2);
+    if (splits <= 0) {
+        splits = 256 / tiles;
+        const int maxs = M / (TBM * 8);
+        if (splits > maxs) splits = maxs;
+        if (splits < 1) splits = 1;
+    }
+    int chunk = (M + splits - 1) / splits;
+    chunk = (chunk + TBM - 1) / TBM * TBM;
+    return (M + chunk - 1) / chunk;
+}
+
+// which weight-gradient kernel runs for (M, N, K): use_tr 1 = choose, 2 = always 128 x 128, 3 = 256 x 256 wherever it can run
+bool tn_use_256(int M, int N, int K, int use_tr) {
+    if (use_tr < 1 || (M % TBM) != 0 || N < 8 || K < 8) return false;
+    if (use_tr == 3) return true;
+    if (use_tr == 2) return false;
+    return false;       // (auto: decided from the measured A/B table, see e2k_gemm_tn_bf16)
+}
+
 }  // namespace
 
 static int gemm_nt_bf16_impl(const void* A1, int64_t lda1, int K1, const void* A2, int64_t lda2, int K2,
@@ -1114,13 +1187,11 @@ static int gemm_nt_bf16_impl(const void* A1, int64_t lda1, int K1, const void* A
     const int tn = (N + BN - 1) / BN;
     p.probe = flags & (E2K_GEMM_PROBE_NO_LOADS | E2K_GEMM_PROBE_NO_MATH);
     const bool glds = !(flags & E2K_GEMM_NO_GLDS) && (K1 % BK) == 0 && (K2 % BK) == 0;
-    // 256-row tiles: opt-in (measured equal to the 128 x 128 kernel at best, 5-15 % slower on most cfg3 shapes)
-    const bool big = glds && !p.probe && (flags & E2K_GEMM_BIG);
-    // 256 x 256 tiles (8-phase kernel): opt-in, not yet run on hardware.  T256 = every shape, T256_AUTO = only shapes
-    // whose 256 x 256 tiles fill at least 7/8 of a round of the 256 resident workgroups
     const int t256 = ((M + QBM - 1) / QBM) * ((N + QBN - 1) / QBN);
-    const bool q256 = glds && !p.probe && !big &&
-                      ((flags & E2K_GEMM_T256) || ((flags & E2K_GEMM_T256_AUTO) && t256 >= 224 && (K1 + K2) >= 4 * BK));
+    // default: shapes whose 256 x 256 tiles fill >= 7/8 of a round of the 256 workgroup slots (measured on MI355X: +10-22 %
+    // on those, profiles/r02_gemm_t256_first_hw_run.json; -10-15 % on half-filled ones such as 8448 x 1024 x 4096)
+    const bool q256 = glds && !p.probe && !(flags & E2K_GEMM_NO_T256) &&
+                      ((flags & E2K_GEMM_T256) || (t256 >= 224 && (K1 + K2) >= 4 * BK));
     if (q256) {
         const int T = t256;
         p.full = T; p.split = 1; p.ws = ws;
@@ -1150,15 +1221,14 @@ static int gemm_nt_bf16_impl(const void* A1, int64_t lda1, int K1, const void* A
         }
         return 0;
     }
-    const int bm = big ? GBM : BM;
-    const int tm = (M + bm - 1) / bm, T = tm * tn;
-    // Remainder split: `slots` workgroups are resident (256 CUs x 2 of the 128-row kernel, x 1 of the 256-row one); a
+    const int tm = (M + BM - 1) / BM, T = tm * tn;
+    // Remainder split: `slots` workgroups are resident (256 CUs x 2); a
     // trailing partial round of `rem` tiles would run at rem/slots of the chip (8448 rows x 1024 columns = 528 tiles
     // of 128 x 128: the last 16 cost half a round), so those tiles are cut into `split` K ranges that together fill
     // the chip once more.
     p.full = T; p.split = 1; p.ws = ws;
     int rem = 0;
-    const int slots = (flags & E2K_GEMM_TEST_SLOTS8) ? 8 : (big ? 256 : NT_SLOTS);
+    const int slots = (flags & E2K_GEMM_TEST_SLOTS8) ? 8 : NT_SLOTS;
     if (glds && ws && !(flags & E2K_GEMM_NO_SPLIT) && T > slots && (T % slots) != 0) {
         rem = T % slots;
         const int nk = (K1 + K2) / BK;
@@ -1166,33 +1236,25 @@ static int gemm_nt_bf16_impl(const void* A1, int64_t lda1, int K1, const void* A
         while (split * 2 <= 16 && split * 2 * rem <= slots && split * 2 * 2 <= nk) split *= 2;
         // worth it only when the partial round it removes (about half a round: ~0.5 us per K step, measured) costs more
         // than writing + re-reading the fp32 partials (64 KB per 128 x 128 tile at ~5 TB/s) and the fix-up launch (~4 us)
-        const float per_part = big ? 0.052f : 0.026f;
+        const float per_part = 0.026f;
         if (!(flags & E2K_GEMM_TEST_SLOTS8))
             while (split > 1 && 0.5f * nk < 1.2f * (rem * split * per_part + 4.f)) split >>= 1;
-        if (split > 1 && (int64_t)rem * split * bm * BN * 4 <= ws_bytes) { p.full = T - rem; p.split = split; }
+        if (split > 1 && (int64_t)rem * split * BM * BN * 4 <= ws_bytes) { p.full = T - rem; p.split = split; }
         else rem = 0;
     }
     dim3 grid(p.full + rem * p.split), block(256);
     hipStream_t st = (hipStream_t)stream;
-    if (big) {
-        if (out_f32) hipLaunchKernelGGL(gemm_nt_big_kernel<true>, grid, dim3(GTHREADS), 0, st, p);
-        else hipLaunchKernelGGL(gemm_nt_big_kernel<false>, grid, dim3(GTHREADS), 0, st, p);
-    } else if (out_f32) {
+    if (out_f32) {
         if (glds) hipLaunchKernelGGL(gemm_nt_glds_kernel<true>, grid, block, 0, st, p);
-        else hipLaunchKernelGGL((gemm_nt_kernel<true, false>), grid, block, 0, st, p);
+        else hipLaunchKernelGGL(gemm_nt_kernel<true>, grid, block, 0, st, p);
     } else {
         if (glds) hipLaunchKernelGGL(gemm_nt_glds_kernel<false>, grid, block, 0, st, p);
-        else hipLaunchKernelGGL((gemm_nt_kernel<false, false>), grid, block, 0, st, p);
+        else hipLaunchKernelGGL(gemm_nt_kernel<false>, grid, block, 0, st, p);
     }
     E2K_CHECK_LAUNCH();
     if (rem) {
-        if (big) {
-            if (out_f32) hipLaunchKernelGGL(gemm_nt_big_fixup_kernel<true>, dim3(rem, 4), dim3(GTHREADS), 0, st, p);
-            else hipLaunchKernelGGL(gemm_nt_big_fixup_kernel<false>, dim3(rem, 4), dim3(GTHREADS), 0, st, p);
-        } else {
-            if (out_f32) hipLaunchKernelGGL(gemm_nt_fixup_kernel<true>, dim3(rem, 4), block, 0, st, p);
-            else hipLaunchKernelGGL(gemm_nt_fixup_kernel<false>, dim3(rem, 4), block, 0, st, p);
-        }
+        if (out_f32) hipLaunchKernelGGL(gemm_nt_fixup_kernel<true>, dim3(rem, 4), block, 0, st, p);
+        else hipLaunchKernelGGL(gemm_nt_fixup_kernel<false>, dim3(rem, 4), block, 0, st, p);
         E2K_CHECK_LAUNCH();
     }
     return 0;
@@ -1206,6 +1268,11 @@ extern "C" int e2k_query_gemm_tn_splits(int M, int N, int K, int splits) {
     return tn_splits(M, N, K, splits);
 }
 
+extern "C" int e2k_query_gemm_tn_splits_mode(int M, int N, int K, int splits, int use_tr) {
+    if (M <= 0 || N <= 0 || K <= 0) return 1;
+    return tn_use_256(M, N, K, use_tr) ? tn_splits_256(M, N, K, splits) : tn_splits(M, N, K, splits);
+}
+
 extern "C" int e2k_colsum_bf16(const void* x, int64_t ldx, float* out, int M, int N, void* stream);
 
 static int gemm_tn_bf16_impl(const void* A, int64_t lda, const void* B, int64_t ldb, float* C, int64_t ldc,
@@ -1215,8 +1282,10 @@ static int gemm_tn_bf16_impl(const void* A, int64_t lda, const void* B, int64_t 
     // 16-B loads may run past N / K up to the next multiple of 8: that must still be inside the row
     if ((lda & 7) || (ldb & 7) || ((N + 7) & ~7) > lda || ((K + 7) & ~7) > ldb) return E2K_ERR_ALIGN;
     if (((uintptr_t)A | (uintptr_t)B) & 15) return E2K_ERR_ALIGN;
-    const int tn = (N + 127) / 128, tk = (K + 127) / 128;
-    splits = tn_splits(M, N, K, splits);
+    const bool big = tn_use_256(M, N, K, use_tr);
+    const int tsz = big ? T2 : 128;
+    const int tn = (N + tsz - 1) / tsz, tk = (K + tsz - 1) / tsz;
+    splits = big ? tn_splits_256(M, N, K, splits) : tn_splits(M, N, K, splits);
     int chunk = (M + splits - 1) / splits;
     chunk = (chunk + TBM - 1) / TBM * TBM;
     if (splits > 1 && ws == nullptr) return E2K_ERR_ARG;
@@ -1232,7 +1301,9 @@ static int gemm_tn_bf16_impl(const void* A, int64_t lda, const void* B, int64_t 
         if (rc) return rc;
     }
     dim3 grid(tn * tk, splits), block(256);
-    if (fast && p.colsum) hipLaunchKernelGGL(gemm_tn_glds_kernel<true>, grid, block, 0, (hipStream_t)stream, p);
+    if (big && p.colsum) hipLaunchKernelGGL(gemm_tn_256_kernel<true>, grid, dim3(T2THREADS), 0, (hipStream_t)stream, p);
+    else if (big) hipLaunchKernelGGL(gemm_tn_256_kernel<false>, grid, dim3(T2THREADS), 0, (hipStream_t)stream, p);
+    else if (fast && p.colsum) hipLaunchKernelGGL(gemm_tn_glds_kernel<true>, grid, block, 0, (hipStream_t)stream, p);
     else if (fast) hipLaunchKernelGGL(gemm_tn_glds_kernel<false>, grid, block, 0, (hipStream_t)stream, p);
     else if (use_tr) hipLaunchKernelGGL(gemm_tn_kernel<true>, grid, block, 0, (hipStream_t)stream, p);
     else hipLaunchKernelGGL(gemm_tn_kernel<false>, grid, block, 0, (hipStream_t)stream, p);

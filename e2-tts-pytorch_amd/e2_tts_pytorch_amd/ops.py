@@ -213,6 +213,11 @@ def set_gemm_profile(lst):
     _gemm_profile = lst
 
 
+# weight-gradient kernel choice handed to every gemm_tn call (1 = the library chooses per shape, 2 = always 128 x 128,
+# 3 = 256 x 256 8-phase kernel wherever it can run); E2K_TN_MODE in the environment presets it (A/B benchmarking)
+tn_mode = int(_os.environ.get('E2K_TN_MODE', '1'))
+
+
 def gemm_tn(a, b, out, *, splits=0, use_tr=True, colsum=None, colsum_from=0):
     """out[N,K] += a[M,N].T @ b[M,K]   (fp32 out, bf16 a/b); optionally colsum[n] += sum_m a[m][n] for n >= colsum_from"""
     _chk(a, b, out)
@@ -223,13 +228,14 @@ def gemm_tn(a, b, out, *, splits=0, use_tr=True, colsum=None, colsum_from=0):
     N, K = a.shape[1], b.shape[1]
     assert out.shape == (N, K) and out.stride(1) == 1
     lib = _lib.get()
-    ns = lib.e2k_query_gemm_tn_splits(M, N, K, int(splits))
+    mode = tn_mode if use_tr is True else int(use_tr)
+    ns = lib.e2k_query_gemm_tn_splits_mode(M, N, K, int(splits), mode)
     ws = torch.empty((ns * N * K,), dtype=f32, device=a.device) if ns > 1 else None
     if colsum is not None:
         _chk(colsum)
         assert colsum.dtype == f32 and colsum.numel() == N and colsum.is_contiguous()
     _note(2.0 * M * N * K)
-    lib.e2k_gemm_tn_bf16(_p(a), lda, _p(b), ldb, _p(out), out.stride(0), M, N, K, int(splits), int(use_tr), _p(ws),
+    lib.e2k_gemm_tn_bf16(_p(a), lda, _p(b), ldb, _p(out), out.stride(0), M, N, K, int(splits), mode, _p(ws),
                          _p(colsum), int(colsum_from), _stream(a))
     return out
 

@@ -47,9 +47,8 @@ int e2k_query_gemm_nt_ws_bytes(void);
 #define E2K_GEMM_NO_GLDS 1   /* flags: stage operands through VGPRs instead of global_load_lds (A/B benchmarking) */
 #define E2K_GEMM_PROBE_NO_LOADS 4 /* flags: bottleneck probe, K loop without its global loads (WRONG results) */
 #define E2K_GEMM_PROBE_NO_MATH 8  /* flags: bottleneck probe, K loop without its LDS reads + MFMAs (WRONG results) */
-#define E2K_GEMM_BIG 64          /* flags: use the 256 x 128 x 64, 8-wave, 3-stage kernel (A/B: not faster on MI355X, see gemm.hip) */
-#define E2K_GEMM_T256 128        /* flags: 256 x 256 x 64 tile, 8-wave 8-phase kernel for every shape (parity-tested on the host model, NOT yet run on hardware) */
-#define E2K_GEMM_T256_AUTO 256   /* flags: the same, only for shapes whose 256 x 256 tiles fill >= 7/8 of a round of 256 workgroups */
+#define E2K_GEMM_T256 128        /* flags: 256 x 256 x 64 tile, 8-wave 8-phase kernel for EVERY shape (default: only shapes whose 256 x 256 tiles fill >= 7/8 of a round of the 256 workgroup slots) */
+#define E2K_GEMM_NO_T256 256     /* flags: never use the 256 x 256 kernel (A/B) */
 #define E2K_GEMM_NO_SPLIT 16     /* flags: never split remainder tiles over K (A/B) */
 #define E2K_GEMM_TEST_SLOTS8 32  /* flags: pretend the chip holds 8 workgroups (lets small shapes exercise the remainder split in tests) */
 
@@ -64,6 +63,9 @@ int e2k_gemm_tn_bf16(const void* A, int64_t lda, const void* B, int64_t ldb, flo
 /* number of token-dimension splits the call above will use for (M, N, K, splits); when it is > 1 the caller passes
  * ws = scratch of splits*N*K floats (partial tiles are stored there and combined by a second small kernel). */
 int e2k_query_gemm_tn_splits(int M, int N, int K, int splits);
+/* the same for a given use_tr mode: 1 = the library chooses the kernel per shape, 2 = always the 128 x 128 x 64 kernel,
+ * 3 = the 256 x 256 x 64 8-phase kernel wherever it can run (M a multiple of 64) */
+int e2k_query_gemm_tn_splits_mode(int M, int N, int K, int splits, int use_tr);
 
 /* ---- hyper-connections (hyper_connections.HyperConnections; reference call sites e2_tts.py:870-882,900-939) ----
  * Streams are stored token-major: X[token][4][D] bf16.  coef: per-token fp32 record (e2k_query_hc_coef_width()

@@ -1,5 +1,5 @@
 """TEST INFRASTRUCTURE (oracle side): bit-exact numpy restatement of the counter-hash dropout masks the HIP kernels
-generate (e2k_device.h: fmix32 / rand_base / rand_at; attn.hip: drop_scale; elementwise.hip: keep_scale).
+generate (e2k_device.h: fmix32 / rand_base / rand_at; attn.hip: drop4 / drop_sample; elementwise.hip: keep_scale).
 
 The reference draws dropout masks from torch's Philox stream (nn.Dropout inside x_transformers, e2_tts.py:540,641,646);
 device RNG streams cannot be matched across implementations, so for parity runs the oracle is fed the masks the
@@ -30,7 +30,8 @@ def rand_u32(seed, stream, row, col):
 
 
 def _keep(seed, stream, rows, cols, p):
-    """keep-scale matrix (len(rows), len(cols)): 1/(1-p) where kept, 0 where dropped"""
+    """keep-scale matrix (len(rows), len(cols)) of the GEGLU kernel (elementwise.hip keep_scale): one hash per PAIR of
+    columns, low / high 16 bits; 1/(1-p) where kept, 0 where dropped"""
     thresh = int(p * 65536.0 + 0.5)
     r = np.asarray(rows, dtype=np.uint32)[:, None]
     c = np.asarray(cols, dtype=np.uint32)[None, :]
@@ -39,13 +40,37 @@ def _keep(seed, stream, rows, cols, p):
     return torch.from_numpy(np.where(r16 >= thresh, np.float32(1.0 / (1.0 - p)), np.float32(0.0)))
 
 
+def _keep4(seed, stream, rows, cols, p):
+    """keep-scale matrix of the attention kernels (attn.hip drop4 / drop_sample): one hash per group of FOUR consecutive
+    keys -- word 0 = fmix32(base + q * 0x85ebca77 + (key >> 2) * 0xc2b2ae3d), word 1 = a xor-shift-multiply of word 0;
+    key & 3 selects (word 0 low, word 0 high, word 1 low, word 1 high) 16 bits; kept iff that sample >= thresh"""
+    thresh = int(p * 65536.0 + 0.5)
+    r = np.asarray(rows, dtype=np.uint32)[:, None]
+    c = np.asarray(cols, dtype=np.uint32)[None, :]
+    shape = (r.shape[0], c.shape[1])
+    w0 = rand_u32(seed, stream, np.broadcast_to(r, shape), np.broadcast_to(c >> _M(2), shape))
+    with np.errstate(over='ignore'):
+        x = w0 ^ (w0 >> _M(15))
+        x = (x * _M(0x2c1b3c6d)).astype(np.uint32)
+        w1 = x ^ (x >> _M(12))
+    j = np.broadcast_to(c & _M(3), shape)
+    w = np.where((j & _M(2)) != 0, w1, w0)
+    r16 = np.where((j & _M(1)) != 0, w >> _M(16), w & _M(0xffff))
+    return torch.from_numpy(np.where(r16 >= thresh, np.float32(1.0 / (1.0 - p)), np.float32(0.0)))
+
+
+def attn_stream(stream_id, bh):
+    """attn.hip attn_stream(): top bit set so that attention streams never meet the GEGLU streams (plain call ids)"""
+    return (0x80000000 | ((int(stream_id) << 16) & 0x7fff0000) | int(bh)) & 0xffffffff
+
+
 def attn_dropout_mask(seed, stream_id, B, H, N, p):
     """(B, H, N, N) mask of e2k_attn_fwd(p_drop=p, seed, stream_id): element [b,h,q,key]"""
     out = torch.empty(B, H, N, N)
     idx = np.arange(N)
     for b in range(B):
         for h in range(H):
-            out[b, h] = _keep(seed, (stream_id * 8192 + b * H + h) & 0xffffffff, idx, idx, p)
+            out[b, h] = _keep4(seed, attn_stream(stream_id, b * H + h), idx, idx, p)
     return out
 
 

@@ -79,6 +79,36 @@ def test_gemm_tn(dev, M, N, K, splits, use_tr):
     assert rel(out, ref) < 1e-5
 
 
+@pytest.mark.parametrize('late', [0, 1])
+@pytest.mark.parametrize('M,N,K,splits,cs_from', [
+    (64, 256, 256, 1, None),        # one tile, ONE reduction step (prologue and drain only)
+    (128, 256, 256, 1, 0),          # two steps; bias gradient riding along in every wave
+    (192, 264, 520, 1, None),       # 2 x 3 tiles with ragged edges, odd number of steps
+    (640, 520, 264, 2, 130),        # token split into partial tiles + reduce, column sums from a later column on
+    (1024, 392, 264, 0, 8),         # split count chosen by the library
+    (576, 136, 72, 3, None),        # narrower than one tile in both directions
+])
+def test_gemm_tn_256_tile(dev, monkeypatch, M, N, K, splits, cs_from, late):
+    """256 x 256 x 64 8-phase weight-gradient kernel (use_tr = 3): same half-tile ring and counted waits as the NT one; on the
+    host model under both LDS-DMA landing extremes"""
+    from e2_tts_pytorch_amd import ops
+    if dev == 'cuda' and late:
+        pytest.skip('LDS-DMA landing extremes exist on the host model only')
+    monkeypatch.setenv('E2K_EMU_GLDS_LATE', str(late))
+    torch.manual_seed(0)
+    a = torch.randn(M, N).to(bf16)
+    b = torch.randn(M, K).to(bf16)
+    out = torch.ones(N, K, device=dev)
+    cs = torch.full((N,), 0.25, device=dev) if cs_from is not None else None
+    ops.gemm_tn(a.to(dev), b.to(dev), out, splits=splits, use_tr=3, colsum=cs, colsum_from=cs_from or 0)
+    ref = 1 + a.float().T @ b.float()
+    assert rel(out, ref) < 1e-5
+    if cs is not None:
+        want = torch.full((N,), 0.25)
+        want[cs_from:] += a.float().sum(0)[cs_from:]
+        assert torch.allclose(cs.cpu(), want, rtol=1e-4, atol=1e-3), (cs.cpu() - want).abs().max()
+
+
 def test_gemm_tn_strided(dev):
     """column-sliced operands / outputs as the backbone uses them (cross-condition and skip weight gradients)"""
     from e2_tts_pytorch_amd import ops
@@ -107,27 +137,6 @@ def test_gemm_tn_colsum(dev, M, N, K, cs_from):
     want[cs_from:] += a.float().sum(0)[cs_from:]
     assert torch.allclose(csd.cpu(), want, rtol=1e-4, atol=1e-3), (csd.cpu() - want).abs().max()
 
-
-
-@pytest.mark.parametrize('flags', [64, 64 | 32])
-@pytest.mark.parametrize('M,N,K1,K2,kw', [
-    (256, 128, 64, 0, {}),                                   # one tile, one K step
-    (300, 136, 128, 0, dict(bias=1)),                        # ragged edges, two steps
-    (520, 260, 192, 64, dict(bias=1, cs=1, rm=1, rs=1)),     # four steps (3 + 1), dual-K, every epilogue operand
-    (2304, 128, 448, 0, dict(f32=1, bias=1)),                # 9 tiles, seven steps; with flag 32: remainder split
-    (700, 260, 320, 0, dict(rs=1)),
-])
-def test_gemm_nt_big_tile(dev, monkeypatch, M, N, K1, K2, kw, flags):
-    """256 x 128 tile, 3-stage NT kernel (opt-in flag E2K_GEMM_BIG), alone and with the remainder split.  On the host model
-    the LDS-DMA copies land as late as its counted vmcnt waits allow (E2K_EMU_GLDS_LATE; no effect on the GPU)"""
-    from e2_tts_pytorch_amd import ops
-    monkeypatch.setenv('E2K_EMU_GLDS_LATE', '1')
-    old = ops.gemm_flags
-    ops.gemm_flags = flags
-    try:
-        test_gemm_nt(dev, M, N, K1, K2, kw)
-    finally:
-        ops.gemm_flags = old
 
 
 @pytest.mark.parametrize('flags', [128, 128 | 32])

@@ -153,6 +153,18 @@ def test_dropout_hash_statistics():
     g = geglu_dropout_mask(3, 4, 50, 64, 0.1)
     assert abs((g == 0).float().mean().item() - 0.1) < 0.03
     assert not torch.equal(attn_dropout_mask(1, 2, 1, 1, 32, 0.5), attn_dropout_mask(2, 2, 1, 1, 32, 0.5))
+    # the attention generator draws four 16-bit samples from one hash (the second word is a cheap function of the first):
+    # keep rates per position in the group, and no visible dependence between the positions of a group, along a row,
+    # or between neighbouring rows
+    k = (attn_dropout_mask(7, 3, 1, 1, 1024, 0.3)[0, 0] != 0).float()
+    for j in range(4):
+        assert abs(k[:, j::4].mean().item() - 0.7) < 0.005, j
+    z = k - k.mean()
+    var = (z * z).mean().item()
+    for a in range(4):
+        for b in range(a + 1, 4):
+            assert abs((z[:, a::4] * z[:, b::4]).mean().item() / var) < 0.01, (a, b)
+    assert abs((z[:, :-4] * z[:, 4:]).mean().item() / var) < 0.01 and abs((z[:-1] * z[1:]).mean().item() / var) < 0.01
 
 
 def test_golden_fixture():

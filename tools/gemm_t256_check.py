@@ -24,7 +24,7 @@ import torch  # noqa: E402
 
 from e2_tts_pytorch_amd import ops  # noqa: E402
 
-T256, T256_AUTO = 128, 256
+T256, NO_T256 = 128, 256
 bf16 = torch.bfloat16
 
 
@@ -65,7 +65,7 @@ def main():
         bias = torch.randn(N, device=dev)
         A = torch.cat([a, a2], 1) if K2 else a
         ref = A.float() @ b.float().T + bias
-        base = run(a, b, a2, 0, bias=bias)
+        base = run(a, b, a2, NO_T256, bias=bias)
         out = run(a, b, a2, T256, bias=bias)
         torch.cuda.synchronize()
         e_ref, e_base = rel(out, ref), rel(out, base)
@@ -81,10 +81,10 @@ def main():
         if not args.quick and (M, N, K1, K2) in cfg3:
             ev = [[torch.cuda.Event(enable_timing=True) for _ in range(2)] for _ in range(2)]
             t = [0.0, 0.0]
-            for f in (0, T256):                     # warm
+            for f in (NO_T256, T256):                     # warm
                 run(a, b, a2, f, bias=bias)
             for _ in range(args.iters):
-                for k, f in enumerate((0, T256)):
+                for k, f in enumerate((NO_T256, T256)):
                     ev[k][0].record()
                     run(a, b, a2, f, bias=bias)
                     ev[k][1].record()
