@@ -63,6 +63,37 @@ def _groups(rows, nprof):
     return out
 
 
+def host_launch_floor(depth, dev, dropout):
+    """host time per training step when the GPU is NOT the bottleneck: the same depth (= the same number of recorded
+    launches per step) at a tiny width / batch / length, so that the kernels are negligible.  `host_enqueue_ms_per_step`
+    of the real workload cannot show this: once the HIP queue is full the enqueuing thread blocks until the GPU frees a
+    slot, so on a GPU-bound step it simply tracks the GPU time."""
+    from e2_tts_pytorch_amd import E2TTS
+    m = E2TTS(transformer=dict(dim=256, depth=depth, heads=4, dropout=dropout), use_vocos=False, cond_drop_prob=0.).to(dev).train()
+    tr = m.transformer
+    tr.enable_persistent_grads()
+    flat = {id(q) for q, _ in tr._layout.slots}
+    rest = [p for p in m.parameters() if id(p) not in flat]
+    mel, text = torch.randn(1, 96, 100, device=dev), ['launch floor']
+
+    def step():
+        m(mel, text=text).loss.backward()
+        for p in rest:
+            p.grad = None
+    for _ in range(4):
+        step()
+    torch.cuda.synchronize()
+    n = 8
+    t0 = time.perf_counter()
+    for _ in range(n):
+        step()
+    t_host = time.perf_counter() - t0
+    torch.cuda.synchronize()
+    t_all = time.perf_counter() - t0
+    return {'host_ms_per_step': t_host / n * 1e3, 'wall_ms_per_step': t_all / n * 1e3,
+            'probe': f'E2TTS(dim=256, depth={depth}, heads=4), B=1, T=96: same launches per step, negligible kernel time'}
+
+
 def synthetic_text(B, seed):
     rng = random.Random(seed)
     alphabet = ''.join(chr(c) for c in range(32, 127))
@@ -256,6 +287,11 @@ def main():
                 'traffic': traffic, 'traffic_note': traffic_note,
             },
         }
+        if not args.eager:
+            try:
+                res['host_launch_floor'] = host_launch_floor(depth, dev, args.dropout)
+            except Exception as e:      # noqa: BLE001
+                res['host_launch_floor'] = {'error': repr(e)}
         if world == 1 and not args.no_cpu_baseline:
             try:
                 res['cpu_baseline'] = cpu_baseline(dim, depth, heads, T)

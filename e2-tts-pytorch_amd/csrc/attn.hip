@@ -37,23 +37,26 @@ __device__ __forceinline__ int tile_off(int row, int slot) { return row * 128 + 
 // registers of tiles (2k, 2k+1) the 8 consecutive reduction elements 32k + 8g .. 32k + 8g + 7 of lane group g.
 __device__ __forceinline__ int perm_row(int t, int i) { return 32 * (t >> 1) + 8 * (i >> 2) + 4 * (t & 1) + (i & 3); }
 
-struct TileRegs { u32x4 v[2]; };
+// a [64][64] bf16 tile is 512 chunks of 16 bytes: NC = 2 per thread in a 256-thread workgroup, 1 in a 512-thread one
+template <int NC> struct TileRegsT { u32x4 v[NC]; };
 
 // global -> registers for a [64][64] bf16 tile whose rows are `stride` elements apart; rows >= nvalid read as 0
-__device__ __forceinline__ TileRegs tile_gload(const bf16_t* base, long stride, int nvalid, int tid) {
-    TileRegs r;
+template <int NC>
+__device__ __forceinline__ TileRegsT<NC> tile_gload(const bf16_t* base, long stride, int nvalid, int tid) {
+    TileRegsT<NC> r;
 #pragma unroll
-    for (int c = 0; c < 2; ++c) {
-        int chunk = tid + c * 256;
+    for (int c = 0; c < NC; ++c) {
+        int chunk = tid + c * (512 / NC);
         int row = chunk >> 3, slot = chunk & 7;
         r.v[c] = (row < nvalid) ? ld<u32x4>(base + (long)row * stride + slot * 8) : u32x4{0u, 0u, 0u, 0u};
     }
     return r;
 }
-__device__ __forceinline__ void tile_sstore(unsigned char* lds, const TileRegs& r, int tid) {
+template <int NC>
+__device__ __forceinline__ void tile_sstore(unsigned char* lds, const TileRegsT<NC>& r, int tid) {
 #pragma unroll
-    for (int c = 0; c < 2; ++c) {
-        int chunk = tid + c * 256;
+    for (int c = 0; c < NC; ++c) {
+        int chunk = tid + c * (512 / NC);
         int row = chunk >> 3, slot = chunk & 7;
         st<u32x4>(lds + tile_off(row, slot), r.v[c]);
     }
@@ -62,10 +65,11 @@ __device__ __forceinline__ void tile_sstore(unsigned char* lds, const TileRegs& 
 // 16t + (l & 15), for which the XOR swizzle is conflict-free (reading rows perm_row(t, l & 15) of a naturally
 // ordered tile was a 4-way bank conflict: 20 % of the LDS cycles of the backward kernels)
 __device__ __forceinline__ int perm_inv(int R) { return (R & 0x23) | ((R & 0x18) >> 1) | ((R & 0x04) << 2); }
-__device__ __forceinline__ void tile_sstore_perm(unsigned char* lds, const TileRegs& r, int tid) {
+template <int NC>
+__device__ __forceinline__ void tile_sstore_perm(unsigned char* lds, const TileRegsT<NC>& r, int tid) {
 #pragma unroll
-    for (int c = 0; c < 2; ++c) {
-        int chunk = tid + c * 256;
+    for (int c = 0; c < NC; ++c) {
+        int chunk = tid + c * (512 / NC);
         int row = perm_inv(chunk >> 3), slot = chunk & 7;
         st<u32x4>(lds + tile_off(row, slot), r.v[c]);
     }
@@ -284,7 +288,8 @@ struct AttnArgs {
     float* lse2;                               // (B,h,N)  log2-domain log-sum-exp
     int B, H, N, Npad;
     float scale; unsigned seed, stream_id, thresh; float inv_keep;
-    const unsigned* seed_dev;                  // if set, the dropout seed is read from device memory (graph replay)
+    const unsigned* seed_dev;                  // if set, the dropout seed is read from device memory (plan replay)
+    int probe;                                 // E2K_ATTN_PROBE_* bits (bottleneck probes of the forward: results are wrong on purpose)
     // optional: keep decisions of the dropout as ballot words, written by the forward and read by the backward instead
     // of re-hashing: [b*h][key tile][query tile][wave 0..3][slot 4t+r] uint64, bit (16 g + l15) = lane of the forward
     unsigned long long* dropbits;
@@ -310,13 +315,22 @@ __device__ __forceinline__ void score_tile(const unsigned char* Kt, const bf16x8
 }
 
 
-template <bool DROP, bool SHARE>      // SHARE: dropout keep masks are handed from the forward to the backward (p.dropbits)
-__global__ __launch_bounds__(256, 2) void attn_fwd_kernel(AttnArgs p) {
+// NW = waves per workgroup (4: 64 query rows, the default; 8: 128, flag E2K_ATTN_WG128).  Every workgroup sweeps ALL key /
+// value tiles of its (batch, head).  tools/probes/attn_ablate.py (MI355X, cfg3 shape): the skeleton alone -- global tile
+// loads, LDS staging, two barriers per tile, no MFMA / softmax -- takes 62 of the kernel's 99 us, and halving the re-read
+// traffic with 128-row workgroups changes nothing (profiles/r02_attn_ablate.json): the floor is the LATENCY of the
+// one-tile-deep register prefetch (load -> LDS write -> barrier per 64-key tile), not bandwidth.  A deeper LDS-DMA ring
+// is the structural fix.
+// PROBE: the bottleneck probes (E2K_ATTN_PROBE_*) are compiled into a separate instantiation: the product kernel carries none of their branches
+template <bool DROP, bool SHARE, int NW, bool PROBE = false>      // SHARE: dropout keep masks are handed from the forward to the backward (p.dropbits)
+__global__ __launch_bounds__(NW * 64, NW == 8 ? 4 : 2) void attn_fwd_kernel(AttnArgs p) {
     __shared__ __attribute__((aligned(16))) unsigned char Kt[64 * 128];
     __shared__ __attribute__((aligned(16))) unsigned char Vt[64 * 128];
+    constexpr int NC = 8 / NW;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int l15 = lane & 15, g = lane >> 4;
-    const int q0 = blockIdx.x * 64, h = blockIdx.y, b = blockIdx.z;
+    const int q0 = blockIdx.x * (NW * 16), h = blockIdx.y, b = blockIdx.z;
+    const int qt64 = blockIdx.x * (NW / 4) + (wave >> 2);            // 64-row query tile of this wave (dropbits layout)
     const long bh = (long)b * p.H + h;
     const int q = q0 + wave * 16 + l15;
     const bool qin = q < p.N;
@@ -344,27 +358,35 @@ __global__ __launch_bounds__(256, 2) void attn_fwd_kernel(AttnArgs p) {
     const int ntiles = (p.N + 63) / 64;
     const bf16_t* Kbase = p.K + bh * p.N * DH;
     const bf16_t* VTbase = p.VT + bh * DH * p.Npad;
-    TileRegs rk = tile_gload(Kbase, DH, min(64, p.N), tid);
-    TileRegs rv = tile_gload(VTbase, p.Npad, 64, tid);
+    TileRegsT<NC> rk = tile_gload<NC>(Kbase, DH, min(64, p.N), tid);
+    TileRegsT<NC> rv = tile_gload<NC>(VTbase, p.Npad, 64, tid);
     for (int kt = 0; kt < ntiles; ++kt) {
         const int k0 = kt * 64;
         tile_sstore_perm(Kt, rk, tid);
         tile_sstore(Vt, rv, tid);
-        __syncthreads();
-        if (kt + 1 < ntiles) {
-            rk = tile_gload(Kbase + (long)(k0 + 64) * DH, DH, min(64, p.N - k0 - 64), tid);
-            rv = tile_gload(VTbase + k0 + 64, p.Npad, 64, tid);
+        if (!(PROBE && (p.probe & E2K_ATTN_PROBE_NO_BARRIER))) __syncthreads();
+        if (kt + 1 < ntiles && !(PROBE && (p.probe & E2K_ATTN_PROBE_NO_LOADS))) {
+            rk = tile_gload<NC>(Kbase + (long)(k0 + 64) * DH, DH, min(64, p.N - k0 - 64), tid);
+            rv = tile_gload<NC>(VTbase + k0 + 64, p.Npad, 64, tid);
         }
         f32x4 s[4];
-        score_tile(Kt, qf, l15, g, s);
-        unsigned long long* dropw = (DROP && SHARE)
-            ? p.dropbits + ((((long)bh * ntiles + kt) * gridDim.x + blockIdx.x) * 4 + wave) * 16 : nullptr;
+        if (!(PROBE && (p.probe & E2K_ATTN_PROBE_NO_QK))) score_tile(Kt, qf, l15, g, s);
+        else {
+#pragma unroll
+            for (int t = 0; t < 4; ++t) s[t] = f32x4{0.5f, 0.25f, -0.5f, 0.125f} * (float)(kt + 1);
+        }
+        unsigned long long* dropw = (DROP && SHARE && qt64 < ntiles)
+            ? p.dropbits + ((((long)bh * ntiles + kt) * ntiles + qt64) * 4 + (wave & 3)) * 16 : nullptr;
         // mask bits of keys k0 + 32*kk2 + 8g .. +8  (kk2 = t>>1, bit index = 8*kk2 + 4*(t&1) + r)
-        const unsigned km = mask_bits(ld<unsigned long long>(p.kmask + (long)b * p.Npad + k0 + g * 8)) |
-                            (mask_bits(ld<unsigned long long>(p.kmask + (long)b * p.Npad + k0 + 32 + g * 8)) << 8);
+        unsigned km = 0xffffu;
+        if (!(PROBE && (p.probe & E2K_ATTN_PROBE_NO_KMASK)))
+            km = mask_bits(ld<unsigned long long>(p.kmask + (long)b * p.Npad + k0 + g * 8)) |
+                 (mask_bits(ld<unsigned long long>(p.kmask + (long)b * p.Npad + k0 + 32 + g * 8)) << 8);
         const bool allk = wave_all(km == 0xffffu);
         // soft-clamp in the log2 domain, two scores per packed instruction (wave vote: exp2 / rcp form for out-of-range tiles)
-        if (wave_all(abs_max16(s) * kx <= TANH_POLY_MAX)) {
+        if (PROBE && (p.probe & E2K_ATTN_PROBE_NO_SOFTMAX)) {
+            // (probe: scores go straight into the second MFMA)
+        } else if (wave_all(abs_max16(s) * kx <= TANH_POLY_MAX)) {
 #pragma unroll
             for (int t = 0; t < 4; ++t)
 #pragma unroll
@@ -390,6 +412,7 @@ __global__ __launch_bounds__(256, 2) void attn_fwd_kernel(AttnArgs p) {
         }
 #pragma unroll
         for (int t = 0; t < 4; ++t) {
+            if (PROBE && (p.probe & E2K_ATTN_PROBE_NO_SOFTMAX)) break;
             float pr[4];
 #pragma unroll
             for (int r = 0; r < 4; ++r) pr[r] = fast_exp2(s[t][r]);
@@ -404,7 +427,7 @@ __global__ __launch_bounds__(256, 2) void attn_fwd_kernel(AttnArgs p) {
                     pr[r] = kp[r] ? pr[r] : 0.f;
                     if (SHARE) {         // publish the compare masks for the backward kernels
                         const unsigned long long mk = wave_ballot(kp[r]);
-                        if (lane == 0) dropw[4 * t + r] = mk;
+                        if (lane == 0 && dropw) dropw[4 * t + r] = mk;
                     }
                 }
             }
@@ -416,13 +439,17 @@ __global__ __launch_bounds__(256, 2) void attn_fwd_kernel(AttnArgs p) {
             float lo[4] = {s[2 * kk2][0], s[2 * kk2][1], s[2 * kk2][2], s[2 * kk2][3]};
             float hi[4] = {s[2 * kk2 + 1][0], s[2 * kk2 + 1][1], s[2 * kk2 + 1][2], s[2 * kk2 + 1][3]};
             bf16x8 pf = pack_frag(lo, hi);
+            if (PROBE && (p.probe & E2K_ATTN_PROBE_NO_PV)) {           // keep the probabilities alive without the second MFMA
+                o[0][0] += __builtin_bit_cast(f32x4, pf)[kk2];
+                continue;
+            }
 #pragma unroll
             for (int ct = 0; ct < 4; ++ct) {
                 bf16x8 vf = tile_frag(Vt, ct * 16 + l15, kk2 * 4 + g);
                 o[ct] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(vf, pf, o[ct], 0, 0, 0);
             }
         }
-        __syncthreads();
+        if (!(PROBE && (p.probe & E2K_ATTN_PROBE_NO_BARRIER))) __syncthreads();
     }
     float lsum = lsum2[0] + lsum2[1];           // a row's keys are spread over the lanes l, l+16, l+32, l+48
     lsum += __shfl_xor(lsum, 16);
@@ -493,14 +520,16 @@ __global__ __launch_bounds__(256) void attn_bwd_prep_kernel(AttnArgs p) {
 }
 
 // dQ: same sweep as the forward; dS^T tiles feed dQ^T = K^T . dS^T
-template <bool DROP, bool SHARE>      // SHARE: dropout keep masks are handed from the forward to the backward (p.dropbits)
-__global__ __launch_bounds__(256, 2) void attn_bwd_dq_kernel(AttnArgs p) {
+template <bool DROP, bool SHARE, int NW>      // SHARE: dropout keep masks are handed from the forward to the backward (p.dropbits)
+__global__ __launch_bounds__(NW * 64, 2) void attn_bwd_dq_kernel(AttnArgs p) {
     __shared__ __attribute__((aligned(16))) unsigned char Kt[64 * 128];
     __shared__ __attribute__((aligned(16))) unsigned char Vr[64 * 128];
     __shared__ __attribute__((aligned(16))) unsigned char KTt[64 * 128];
+    constexpr int NC = 8 / NW;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int l15 = lane & 15, g = lane >> 4;
-    const int q0 = blockIdx.x * 64, h = blockIdx.y, b = blockIdx.z;
+    const int q0 = blockIdx.x * (NW * 16), h = blockIdx.y, b = blockIdx.z;
+    const int qt64 = blockIdx.x * (NW / 4) + (wave >> 2);
     const long bh = (long)b * p.H + h;
     const int q = q0 + wave * 16 + l15;
     const bool qin = q < p.N;
@@ -529,9 +558,9 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dq_kernel(AttnArgs p) {
     const bf16_t* Kbase = p.K + bh * p.N * DH;
     const bf16_t* Vbase = p.V + bh * p.N * DH;
     const bf16_t* KTbase = p.KT + bh * DH * p.Npad;
-    TileRegs rk = tile_gload(Kbase, DH, min(64, p.N), tid);
-    TileRegs rv = tile_gload(Vbase, DH, min(64, p.N), tid);
-    TileRegs rt = tile_gload(KTbase, p.Npad, 64, tid);
+    TileRegsT<NC> rk = tile_gload<NC>(Kbase, DH, min(64, p.N), tid);
+    TileRegsT<NC> rv = tile_gload<NC>(Vbase, DH, min(64, p.N), tid);
+    TileRegsT<NC> rt = tile_gload<NC>(KTbase, p.Npad, 64, tid);
     for (int kt = 0; kt < ntiles; ++kt) {
         const int k0 = kt * 64;
         tile_sstore_perm(Kt, rk, tid);
@@ -540,9 +569,9 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dq_kernel(AttnArgs p) {
         __syncthreads();
         if (kt + 1 < ntiles) {
             const int nv = min(64, p.N - k0 - 64);
-            rk = tile_gload(Kbase + (long)(k0 + 64) * DH, DH, nv, tid);
-            rv = tile_gload(Vbase + (long)(k0 + 64) * DH, DH, nv, tid);
-            rt = tile_gload(KTbase + k0 + 64, p.Npad, 64, tid);
+            rk = tile_gload<NC>(Kbase + (long)(k0 + 64) * DH, DH, nv, tid);
+            rv = tile_gload<NC>(Vbase + (long)(k0 + 64) * DH, DH, nv, tid);
+            rt = tile_gload<NC>(KTbase + k0 + 64, p.Npad, 64, tid);
         }
         f32x4 s[4], dp[4];
         score_tile(Kt, qf, l15, g, s);
@@ -551,8 +580,9 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dq_kernel(AttnArgs p) {
                             (mask_bits(ld<unsigned long long>(p.kmask + (long)b * p.Npad + k0 + 32 + g * 8)) << 8);
         const bool allk = wave_all(km == 0xffffu);
         const bool small = wave_all(abs_max16(s) * kx <= TANH_POLY_MAX);
+        // (waves of a query tile past the end of the sequence read tile 0's words: their rows are never stored)
         const unsigned long long* dropw = (DROP && SHARE)
-            ? p.dropbits + ((((long)bh * ntiles + kt) * gridDim.x + blockIdx.x) * 4 + uniform_i(wave)) * 16 : nullptr;
+            ? p.dropbits + ((((long)bh * ntiles + kt) * ntiles + uniform_i(qt64 < ntiles ? qt64 : 0)) * 4 + uniform_i(wave & 3)) * 16 : nullptr;
 #pragma unroll
         for (int t = 0; t < 4; ++t) {
             float ks[4] = {1.f, 1.f, 1.f, 1.f};
@@ -616,19 +646,21 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dq_kernel(AttnArgs p) {
     }
 }
 
-// dK, dV: one workgroup per 64 keys (a wave owns 16), sweep over query tiles.
+// dK, dV: one workgroup per 16 NW keys (a wave owns 16), sweep over query tiles.
 //   S = Q.K^T (rows = queries, permuted inside the tile), P^T-like accumulators feed dV^T = dO^T.P and dK^T = Q^T.dS
-template <bool DROP, bool SHARE>      // SHARE: dropout keep masks are handed from the forward to the backward (p.dropbits)
-__global__ __launch_bounds__(256, 2) void attn_bwd_dkv_kernel(AttnArgs p) {
+template <bool DROP, bool SHARE, int NW>      // SHARE: dropout keep masks are handed from the forward to the backward (p.dropbits)
+__global__ __launch_bounds__(NW * 64, 2) void attn_bwd_dkv_kernel(AttnArgs p) {
     __shared__ __attribute__((aligned(16))) unsigned char Qt[64 * 128];
     __shared__ __attribute__((aligned(16))) unsigned char dOt[64 * 128];
     __shared__ __attribute__((aligned(16))) unsigned char QTt[64 * 128];
     __shared__ __attribute__((aligned(16))) unsigned char dOTt[64 * 128];
     __shared__ __attribute__((aligned(16))) float lse_s[64];
     __shared__ __attribute__((aligned(16))) float del_s[64];
+    constexpr int NC = 8 / NW;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int l15 = lane & 15, g = lane >> 4;
-    const int k0 = blockIdx.x * 64, h = blockIdx.y, b = blockIdx.z;
+    const int k0 = blockIdx.x * (NW * 16), h = blockIdx.y, b = blockIdx.z;
+    const int kt64 = blockIdx.x * (NW / 4) + (wave >> 2);            // 64-key tile of this wave (dropbits layout)
     const long bh = (long)b * p.H + h;
     const int key = k0 + wave * 16 + l15;
     const bool kin = key < p.N;
@@ -654,10 +686,10 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dkv_kernel(AttnArgs p) {
     const bf16_t* dObase = p.dO + bh * p.N * DH;
     const bf16_t* QTbase = p.QT + bh * DH * p.Npad;
     const bf16_t* dOTbase = p.dOT + bh * DH * p.Npad;
-    TileRegs r0 = tile_gload(Qbase, DH, min(64, p.N), tid);
-    TileRegs r1 = tile_gload(dObase, DH, min(64, p.N), tid);
-    TileRegs r2 = tile_gload(QTbase, p.Npad, 64, tid);
-    TileRegs r3 = tile_gload(dOTbase, p.Npad, 64, tid);
+    TileRegsT<NC> r0 = tile_gload<NC>(Qbase, DH, min(64, p.N), tid);
+    TileRegsT<NC> r1 = tile_gload<NC>(dObase, DH, min(64, p.N), tid);
+    TileRegsT<NC> r2 = tile_gload<NC>(QTbase, p.Npad, 64, tid);
+    TileRegsT<NC> r3 = tile_gload<NC>(dOTbase, p.Npad, 64, tid);
     for (int qt = 0; qt < ntiles; ++qt) {
         const int q0 = qt * 64;
         tile_sstore_perm(Qt, r0, tid);
@@ -672,10 +704,10 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dkv_kernel(AttnArgs p) {
         __syncthreads();
         if (qt + 1 < ntiles) {
             const int nv = min(64, p.N - q0 - 64);
-            r0 = tile_gload(Qbase + (long)(q0 + 64) * DH, DH, nv, tid);
-            r1 = tile_gload(dObase + (long)(q0 + 64) * DH, DH, nv, tid);
-            r2 = tile_gload(QTbase + q0 + 64, p.Npad, 64, tid);
-            r3 = tile_gload(dOTbase + q0 + 64, p.Npad, 64, tid);
+            r0 = tile_gload<NC>(Qbase + (long)(q0 + 64) * DH, DH, nv, tid);
+            r1 = tile_gload<NC>(dObase + (long)(q0 + 64) * DH, DH, nv, tid);
+            r2 = tile_gload<NC>(QTbase + q0 + 64, p.Npad, 64, tid);
+            r3 = tile_gload<NC>(dOTbase + q0 + 64, p.Npad, 64, tid);
         }
         // s[t][r] <-> query perm_row(t, 4g+r), key = l&15
         f32x4 s[4], dp[4];
@@ -700,10 +732,10 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dkv_kernel(AttnArgs p) {
         unsigned long long dword[2] = {0ull, 0ull};
         int dbit0 = 0;
         if (DROP && SHARE) {
-            const int pos = wave * 16 + l15;
+            const int pos = (wave & 3) * 16 + l15;
             const int tf = 2 * (pos >> 5) + ((pos >> 2) & 1), gf = (pos >> 3) & 3, rf = pos & 3;
             dbit0 = 16 * gf + 8 * (g & 1);
-            const unsigned long long* base = p.dropbits + ((((long)bh * ntiles + blockIdx.x) * ntiles + qt) * 4 + (g >> 1)) * 16 + 4 * tf + rf;
+            const unsigned long long* base = p.dropbits + ((((long)bh * ntiles + (kt64 < ntiles ? kt64 : 0)) * ntiles + qt) * 4 + (g >> 1)) * 16 + 4 * tf + rf;
             dword[0] = base[0];
             dword[1] = base[2 * 16];
         }
@@ -827,7 +859,7 @@ extern "C" int e2k_query_attn_dropbits_bytes(int B, int H, int N) {
 
 static int attn_fwd_impl(const void* Q, const void* K, const void* VT, const uint8_t* kmask, const float* gate,
                             void* O, void* Og, float* lse2, void* dropbits, int B, int H, int N, int Npad, float p_drop,
-                            uint32_t seed, const uint32_t* seed_dev, uint32_t stream_id, void* stream) {
+                            uint32_t seed, const uint32_t* seed_dev, uint32_t stream_id, int flags, void* stream) {
     if (B <= 0 || N <= 0) return 0;
     if (!Q || !K || !VT || !kmask || !gate || !O || !Og || !lse2) return E2K_ERR_ARG;
     AttnArgs a{};
@@ -836,9 +868,24 @@ static int attn_fwd_impl(const void* Q, const void* K, const void* VT, const uin
     a.Q = (const bf16_t*)Q; a.K = (const bf16_t*)K; a.VT = (const bf16_t*)VT; a.kmask = kmask; a.gate = gate;
     a.O = (bf16_t*)O; a.Og = (bf16_t*)Og; a.lse2 = lse2;
     a.dropbits = (unsigned long long*)dropbits;
-    if (a.thresh && dropbits) hipLaunchKernelGGL((attn_fwd_kernel<true, true>), dim3((N + 63) / 64, H, B), dim3(256), 0, (hipStream_t)stream, a);
-    else if (a.thresh) hipLaunchKernelGGL((attn_fwd_kernel<true, false>), dim3((N + 63) / 64, H, B), dim3(256), 0, (hipStream_t)stream, a);
-    else hipLaunchKernelGGL((attn_fwd_kernel<false, false>), dim3((N + 63) / 64, H, B), dim3(256), 0, (hipStream_t)stream, a);
+    a.probe = flags & 63;
+    hipStream_t st = (hipStream_t)stream;
+    if (a.probe) {              // bottleneck probes (wrong results on purpose): separate instantiations
+        const dim3 grid((N + 63) / 64, H, B), block(256);
+        if (a.thresh && dropbits) hipLaunchKernelGGL((attn_fwd_kernel<true, true, 4, true>), grid, block, 0, st, a);
+        else if (a.thresh) hipLaunchKernelGGL((attn_fwd_kernel<true, false, 4, true>), grid, block, 0, st, a);
+        else hipLaunchKernelGGL((attn_fwd_kernel<false, false, 4, true>), grid, block, 0, st, a);
+    } else if (!(flags & E2K_ATTN_WG128)) {
+        const dim3 grid((N + 63) / 64, H, B), block(256);
+        if (a.thresh && dropbits) hipLaunchKernelGGL((attn_fwd_kernel<true, true, 4>), grid, block, 0, st, a);
+        else if (a.thresh) hipLaunchKernelGGL((attn_fwd_kernel<true, false, 4>), grid, block, 0, st, a);
+        else hipLaunchKernelGGL((attn_fwd_kernel<false, false, 4>), grid, block, 0, st, a);
+    } else {
+        const dim3 grid((N + 127) / 128, H, B), block(512);
+        if (a.thresh && dropbits) hipLaunchKernelGGL((attn_fwd_kernel<true, true, 8>), grid, block, 0, st, a);
+        else if (a.thresh) hipLaunchKernelGGL((attn_fwd_kernel<true, false, 8>), grid, block, 0, st, a);
+        else hipLaunchKernelGGL((attn_fwd_kernel<false, false, 8>), grid, block, 0, st, a);
+    }
     E2K_CHECK_LAUNCH();
     return 0;
 }
@@ -847,7 +894,7 @@ static int attn_bwd_impl(const void* dOg, const void* O, const float* gate, cons
                             const void* K, const void* V, const void* QT, const void* KT, const uint8_t* kmask,
                             const void* dropbits, void* dO, void* dOT, float* delta, float* dgate_pre, void* dQ, void* dK,
                             void* dV, int B, int H, int N, int Npad, float p_drop, uint32_t seed, const uint32_t* seed_dev,
-                            uint32_t stream_id, void* stream) {
+                            uint32_t stream_id, int flags, void* stream) {
     if (B <= 0 || N <= 0) return 0;
     if (!dOg || !O || !gate || !lse2 || !Q || !K || !V || !QT || !KT || !kmask || !dO || !dOT || !delta || !dgate_pre ||
         !dQ || !dK || !dV) return E2K_ERR_ARG;
@@ -863,13 +910,25 @@ static int attn_bwd_impl(const void* dOg, const void* O, const float* gate, cons
     hipStream_t st = (hipStream_t)stream;
     hipLaunchKernelGGL(attn_bwd_prep_kernel, dim3(Npad / 64, H, B), dim3(256), 0, st, a);
     E2K_CHECK_LAUNCH();
-    if (a.thresh && dropbits) hipLaunchKernelGGL((attn_bwd_dq_kernel<true, true>), dim3((N + 63) / 64, H, B), dim3(256), 0, st, a);
-    else if (a.thresh) hipLaunchKernelGGL((attn_bwd_dq_kernel<true, false>), dim3((N + 63) / 64, H, B), dim3(256), 0, st, a);
-    else hipLaunchKernelGGL((attn_bwd_dq_kernel<false, false>), dim3((N + 63) / 64, H, B), dim3(256), 0, st, a);
-    E2K_CHECK_LAUNCH();
-    if (a.thresh && dropbits) hipLaunchKernelGGL((attn_bwd_dkv_kernel<true, true>), dim3((N + 63) / 64, H, B), dim3(256), 0, st, a);
-    else if (a.thresh) hipLaunchKernelGGL((attn_bwd_dkv_kernel<true, false>), dim3((N + 63) / 64, H, B), dim3(256), 0, st, a);
-    else hipLaunchKernelGGL((attn_bwd_dkv_kernel<false, false>), dim3((N + 63) / 64, H, B), dim3(256), 0, st, a);
+    if (!(flags & E2K_ATTN_WG128)) {
+        const dim3 grid((N + 63) / 64, H, B), block(256);
+        if (a.thresh && dropbits) hipLaunchKernelGGL((attn_bwd_dq_kernel<true, true, 4>), grid, block, 0, st, a);
+        else if (a.thresh) hipLaunchKernelGGL((attn_bwd_dq_kernel<true, false, 4>), grid, block, 0, st, a);
+        else hipLaunchKernelGGL((attn_bwd_dq_kernel<false, false, 4>), grid, block, 0, st, a);
+        E2K_CHECK_LAUNCH();
+        if (a.thresh && dropbits) hipLaunchKernelGGL((attn_bwd_dkv_kernel<true, true, 4>), grid, block, 0, st, a);
+        else if (a.thresh) hipLaunchKernelGGL((attn_bwd_dkv_kernel<true, false, 4>), grid, block, 0, st, a);
+        else hipLaunchKernelGGL((attn_bwd_dkv_kernel<false, false, 4>), grid, block, 0, st, a);
+    } else {
+        const dim3 grid((N + 127) / 128, H, B), block(512);
+        if (a.thresh && dropbits) hipLaunchKernelGGL((attn_bwd_dq_kernel<true, true, 8>), grid, block, 0, st, a);
+        else if (a.thresh) hipLaunchKernelGGL((attn_bwd_dq_kernel<true, false, 8>), grid, block, 0, st, a);
+        else hipLaunchKernelGGL((attn_bwd_dq_kernel<false, false, 8>), grid, block, 0, st, a);
+        E2K_CHECK_LAUNCH();
+        if (a.thresh && dropbits) hipLaunchKernelGGL((attn_bwd_dkv_kernel<true, true, 8>), grid, block, 0, st, a);
+        else if (a.thresh) hipLaunchKernelGGL((attn_bwd_dkv_kernel<true, false, 8>), grid, block, 0, st, a);
+        else hipLaunchKernelGGL((attn_bwd_dkv_kernel<false, false, 8>), grid, block, 0, st, a);
+    }
     E2K_CHECK_LAUNCH();
     return 0;
 }
@@ -891,14 +950,14 @@ extern "C" int e2k_qkv_post_bwd(const void* dQ, const void* dK, const void* dV, 
 
 extern "C" int e2k_attn_fwd(const void* Q, const void* K, const void* VT, const uint8_t* kmask, const float* gate,
                             void* O, void* Og, float* lse2, void* dropbits, int B, int H, int N, int Npad, float p_drop,
-                            uint32_t seed, const uint32_t* seed_dev, uint32_t stream_id, void* stream) {
-    return e2k::dispatch("attn_fwd", attn_fwd_impl, Q, K, VT, kmask, gate, O, Og, lse2, dropbits, B, H, N, Npad, p_drop, seed, seed_dev, stream_id, stream);
+                            uint32_t seed, const uint32_t* seed_dev, uint32_t stream_id, int flags, void* stream) {
+    return e2k::dispatch("attn_fwd", attn_fwd_impl, Q, K, VT, kmask, gate, O, Og, lse2, dropbits, B, H, N, Npad, p_drop, seed, seed_dev, stream_id, flags, stream);
 }
 
 extern "C" int e2k_attn_bwd(const void* dOg, const void* O, const float* gate, const float* lse2, const void* Q,
                             const void* K, const void* V, const void* QT, const void* KT, const uint8_t* kmask,
                             const void* dropbits, void* dO, void* dOT, float* delta, float* dgate_pre, void* dQ, void* dK,
                             void* dV, int B, int H, int N, int Npad, float p_drop, uint32_t seed, const uint32_t* seed_dev,
-                            uint32_t stream_id, void* stream) {
-    return e2k::dispatch("attn_bwd", attn_bwd_impl, dOg, O, gate, lse2, Q, K, V, QT, KT, kmask, dropbits, dO, dOT, delta, dgate_pre, dQ, dK, dV, B, H, N, Npad, p_drop, seed, seed_dev, stream_id, stream);
+                            uint32_t stream_id, int flags, void* stream) {
+    return e2k::dispatch("attn_bwd", attn_bwd_impl, dOg, O, gate, lse2, Q, K, V, QT, KT, kmask, dropbits, dO, dOT, delta, dgate_pre, dQ, dK, dV, B, H, N, Npad, p_drop, seed, seed_dev, stream_id, flags, stream);
 }

@@ -257,6 +257,64 @@ __global__ __launch_bounds__(256) void cast_transpose_kernel(const float* src, b
     }
 }
 
+// All transposed bf16 shadows of a module in ONE launch (the per-matrix kernel above: 228 launches, 4.3 ms per dim-1024 /
+// depth-24 step -- 2-byte stores and a tail of tiny grids).  desc[i] = {src offset, dst offset, R, C, ldd, first block}
+// (int64, element offsets into the flat fp32 parameter buffer / the flat transposed-shadow buffer); a block finds its
+// matrix by binary search over `first block`, transposes one 64 x 64 tile through LDS and writes 32 contiguous bytes
+// per thread.
+__global__ __launch_bounds__(256) void cast_transpose_batch_kernel(const float* flat, bf16_t* flatT, const long* desc, int n) {
+    __shared__ float tile[64][65];
+    int lo = 0, hi = n - 1;
+    const long blk = blockIdx.x;
+    while (lo < hi) {
+        const int mid = (lo + hi + 1) >> 1;
+        if (desc[mid * 6 + 5] <= blk) lo = mid;
+        else hi = mid - 1;
+    }
+    const long* d = desc + lo * 6;
+    const float* src = flat + d[0];
+    bf16_t* dst = flatT + d[1];
+    const int R = (int)d[2], C = (int)d[3];
+    const long ldd = d[4];
+    const int local = (int)(blk - d[5]), tiles_c = (C + 63) / 64;
+    const int r0 = (local / tiles_c) * 64, c0 = (local % tiles_c) * 64;
+    const int tid = threadIdx.x;
+    {
+        const int tx = tid & 15, ty = tid >> 4;
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            const int r = r0 + ty + 16 * k, c = c0 + 4 * tx;
+            f32x4 v = {0.f, 0.f, 0.f, 0.f};
+            if (r < R) {
+                const float* q = src + (long)r * C + c;
+                if (c + 3 < C && ((C & 3) == 0) && (((uintptr_t)q & 15) == 0)) v = ld<f32x4>(q);
+                else {
+#pragma unroll
+                    for (int e = 0; e < 4; ++e)
+                        if (c + e < C) v[e] = q[e];
+                }
+            }
+#pragma unroll
+            for (int e = 0; e < 4; ++e) tile[ty + 16 * k][4 * tx + e] = v[e];
+        }
+    }
+    __syncthreads();
+    const int c = c0 + (tid >> 2), rb = (tid & 3) * 16;
+    if (c >= C) return;
+    bf16_t* o = dst + (long)c * ldd + r0 + rb;
+    float f[16];
+#pragma unroll
+    for (int j = 0; j < 16; ++j) f[j] = tile[rb + j][tid >> 2];
+    if (r0 + rb + 15 < R && (((uintptr_t)o & 15) == 0)) {
+        st<u32x4>(o, pack8(f));
+        st<u32x4>(o + 8, pack8(f + 8));
+    } else {
+#pragma unroll
+        for (int j = 0; j < 16; ++j)
+            if (r0 + rb + j < R) o[j] = f2bf(f[j]);
+    }
+}
+
 // ------------------------------------------------------------------------------------------------ depthwise conv + SiLU
 // channels-last: x (B, N, C); block = 64 frames x 64 channels of one batch row; thread = 2 channels x 8 frames.
 
@@ -768,6 +826,15 @@ static int cast_transpose_bf16_impl(const float* src, void* dst, int R, int C, i
     return 0;
 }
 
+static int cast_transpose_batch_impl(const float* flat, void* flatT, const int64_t* desc, int n, int total_blocks, void* stream) {
+    if (n <= 0 || total_blocks <= 0) return 0;
+    if (!flat || !flatT || !desc) return E2K_ERR_ARG;
+    hipLaunchKernelGGL(cast_transpose_batch_kernel, dim3(total_blocks), dim3(256), 0, (hipStream_t)stream, flat, (bf16_t*)flatT,
+                       (const long*)desc, n);
+    E2K_CHECK_LAUNCH();
+    return 0;
+}
+
 static int dwconv_fwd_impl(const void* x, const uint8_t* mask, const float* w, const float* bias, void* pre,
                               void* y, int B, int N, int C, int ks, void* stream) {
     if (B <= 0 || N <= 0) return 0;
@@ -832,6 +899,10 @@ extern "C" int e2k_cast_bf16(const float* src, void* dst, int64_t n, void* strea
 
 extern "C" int e2k_cast_transpose_bf16(const float* src, void* dst, int R, int C, int64_t ldd, void* stream) {
     return e2k::dispatch("cast_transpose_bf16", cast_transpose_bf16_impl, src, dst, R, C, ldd, stream);
+}
+
+extern "C" int e2k_cast_transpose_batch(const float* flat, void* flatT, const int64_t* desc, int n, int total_blocks, void* stream) {
+    return e2k::dispatch("cast_transpose_batch", cast_transpose_batch_impl, flat, flatT, desc, n, total_blocks, stream);
 }
 
 extern "C" int e2k_dwconv_fwd(const void* x, const uint8_t* mask, const float* w, const float* bias, void* pre,

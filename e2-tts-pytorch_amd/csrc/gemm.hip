@@ -1160,7 +1160,10 @@ bool tn_use_256(int M, int N, int K, int use_tr) {
     if (use_tr < 1 || (M % TBM) != 0 || N < 8 || K < 8) return false;
     if (use_tr == 3) return true;
     if (use_tr == 2) return false;
-    return false;       // (auto: decided from the measured A/B table, see e2k_gemm_tn_bf16)
+    // measured on MI355X (profiles/r02_tn_ab.json, cfg3 shapes): the 256 x 256 kernel wins where both output dimensions
+    // reach 1024 and the product is large -- 8448 x 8192 x 1024: 932 vs 780 TFLOP/s, 33792 x 1024 x 1024: 825 vs 732,
+    // 8448 x 3104 x 1024: 652 vs 620, 8448 x 1024 x 4096: 807 vs 801 -- and loses on narrow (512) or small outputs
+    return N >= 1024 && K >= 1024 && (double)M * N * K >= 2e10;
 }
 
 }  // namespace

@@ -247,7 +247,81 @@ __global__ __launch_bounds__(256) void transpose_f32_kernel(const float* in, lon
     }
 }
 
+// fp32 (R, C) -> bf16 (R, ldd) with the columns C..Cpad-1 of every row zeroed (K padding of the 100-channel input /
+// output projections: the GEMM kernels want K in multiples of 8)
+__global__ __launch_bounds__(256) void cast_pad_kernel(const float* src, long lds_, bf16_t* dst, long ldd, int R, int C, int Cpad) {
+    const long total = (long)R * Cpad;
+    for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < total; i += (long)gridDim.x * 256) {
+        const int r = (int)(i / Cpad), c = (int)(i - (long)r * Cpad);
+        dst[(long)r * ldd + c] = c < C ? f2bf(src[(long)r * lds_ + c]) : (bf16_t)0;
+    }
+}
+
+// masked mean squared error over the masked span (e2_tts.py:1580-1582: F.mse_loss(pred, flow)[mask].mean()):
+// acc[0] += sum_m mask[m] * sum_c (pred - flow)^2,  acc[1] += sum_m mask[m]      (fp32 atomics, one per block)
+__global__ __launch_bounds__(256) void masked_mse_fwd_kernel(const float* pred, const float* flow, const uint8_t* mask, float* acc,
+                                                              int M, int C) {
+    __shared__ float red[2][4];
+    float s = 0.f, cnt = 0.f;
+    const long total = (long)M * C;
+    for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < total; i += (long)gridDim.x * 256) {
+        const int m = (int)(i / C);
+        if (mask[m]) {
+            const float d = pred[i] - flow[i];
+            s = fmaf(d, d, s);
+            if (i - (long)m * C == 0) cnt += 1.f;
+        }
+    }
+    s = wave_sum(s);
+    cnt = wave_sum(cnt);
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    if (lane == 0) { red[0][wave] = s; red[1][wave] = cnt; }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        atomicAdd(acc, red[0][0] + red[0][1] + red[0][2] + red[0][3]);
+        atomicAdd(acc + 1, red[1][0] + red[1][1] + red[1][2] + red[1][3]);
+    }
+}
+// loss = acc[0] / (acc[1] * C);   dpred = dloss * 2 (pred - flow) mask / (acc[1] * C)
+__global__ __launch_bounds__(256) void masked_mse_bwd_kernel(const float* pred, const float* flow, const uint8_t* mask, const float* acc,
+                                                              const float* dloss, float* dpred, int M, int C) {
+    const float k = 2.f * dloss[0] / (acc[1] * (float)C);
+    const long total = (long)M * C;
+    for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < total; i += (long)gridDim.x * 256) {
+        const int m = (int)(i / C);
+        dpred[i] = mask[m] ? k * (pred[i] - flow[i]) : 0.f;
+    }
+}
+
 }  // namespace
+
+static int cast_pad_bf16_impl(const float* src, int64_t lds_, void* dst, int64_t ldd, int R, int C, int Cpad, void* stream) {
+    if (R <= 0 || Cpad <= 0) return 0;
+    if (C > Cpad || ldd < Cpad || lds_ < C) return E2K_ERR_SHAPE;
+    hipLaunchKernelGGL(cast_pad_kernel, dim3(grid_1d((long)R * Cpad)), dim3(256), 0, (hipStream_t)stream, src, (long)lds_, (bf16_t*)dst,
+                       (long)ldd, R, C, Cpad);
+    E2K_CHECK_LAUNCH();
+    return 0;
+}
+
+static int masked_mse_fwd_impl(const float* pred, const float* flow, const uint8_t* mask, float* acc, int M, int C, void* stream) {
+    if (M <= 0 || C <= 0) return E2K_ERR_SHAPE;
+    hipError_t e = hipMemsetAsync(acc, 0, 2 * sizeof(float), (hipStream_t)stream);
+    if (e != hipSuccess) return 1000 + (int)e;
+    hipLaunchKernelGGL(masked_mse_fwd_kernel, dim3(grid_1d((long)M * C, 256, 1024)), dim3(256), 0, (hipStream_t)stream, pred, flow, mask,
+                       acc, M, C);
+    E2K_CHECK_LAUNCH();
+    return 0;
+}
+
+static int masked_mse_bwd_impl(const float* pred, const float* flow, const uint8_t* mask, const float* acc, const float* dloss,
+                               float* dpred, int M, int C, void* stream) {
+    if (M <= 0 || C <= 0) return E2K_ERR_SHAPE;
+    hipLaunchKernelGGL(masked_mse_bwd_kernel, dim3(grid_1d((long)M * C)), dim3(256), 0, (hipStream_t)stream, pred, flow, mask, acc,
+                       dloss, dpred, M, C);
+    E2K_CHECK_LAUNCH();
+    return 0;
+}
 
 static int fill_bytes_impl(void* dst, int value, int64_t nbytes, void* stream) {
     if (nbytes <= 0) return 0;
@@ -405,4 +479,14 @@ extern "C" int e2k_cond_bwd_prep(float* dcond, const float* gates, void* dcb, vo
 }
 extern "C" int e2k_transpose_f32(const float* in, int64_t ld, float* out, int R, int C, void* stream) {
     return e2k::dispatch("transpose_f32", transpose_f32_impl, in, ld, out, R, C, stream);
+}
+extern "C" int e2k_cast_pad_bf16(const float* src, int64_t lds_, void* dst, int64_t ldd, int R, int C, int Cpad, void* stream) {
+    return e2k::dispatch("cast_pad_bf16", cast_pad_bf16_impl, src, lds_, dst, ldd, R, C, Cpad, stream);
+}
+extern "C" int e2k_masked_mse_fwd(const float* pred, const float* flow, const uint8_t* mask, float* acc, int M, int C, void* stream) {
+    return e2k::dispatch("masked_mse_fwd", masked_mse_fwd_impl, pred, flow, mask, acc, M, C, stream);
+}
+extern "C" int e2k_masked_mse_bwd(const float* pred, const float* flow, const uint8_t* mask, const float* acc, const float* dloss,
+                                  float* dpred, int M, int C, void* stream) {
+    return e2k::dispatch("masked_mse_bwd", masked_mse_bwd_impl, pred, flow, mask, acc, dloss, dpred, M, C, stream);
 }

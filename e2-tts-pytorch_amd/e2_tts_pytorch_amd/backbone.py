@@ -312,7 +312,7 @@ class Transformer(Module):
 
     # runtime state (device buffers, caches, recorded plans): never part of the module's identity -- a deep copy (the
     # trainer's EMA, trainer.py:170) starts without it and rebuilds its own on first use
-    _RUNTIME = ('_flat', '_shadow', '_shadowT', '_shadow_key', '_vcache', '_rot_cache', '_plans', '_pool', '_pg', '_no_pgrads')
+    _RUNTIME = ('_flat', '_shadow', '_shadowT', '_shadow_key', '_tdesc', '_vcache', '_rot_cache', '_plans', '_pool', '_pg', '_no_pgrads')
 
     def _reset_runtime(self):
         self._flat = None
@@ -493,6 +493,12 @@ class Transformer(Module):
         self._shadow = torch.zeros(lay.n, dtype=bf16, device=device)
         self._shadowT = torch.zeros(max(self._tsize, 8), dtype=bf16, device=device)
         self._shadow_key = None
+        rows, blk = [], 0
+        for t in self._tlist:
+            rows.append([t.src, t.dst, t.R, t.C, t.ldd, blk])
+            blk += ((t.R + 63) // 64) * ((t.C + 63) // 64)
+        self._tdesc = torch.tensor(rows, dtype=torch.int64, device=device).reshape(-1, 6) if rows else None
+        self._tblocks = blk
 
     def _sync(self, device):
         if self._flat is None or self._flat.device != device or not self._is_packed():
@@ -508,10 +514,8 @@ class Transformer(Module):
     def _recast(self):
         """fp32 master parameters -> bf16 shadows (+ transposed shadows for the dgrad GEMMs)"""
         ops.cast_bf16(self._flat, self._shadow)
-        for t in self._tlist:
-            src = self._flat[t.src:t.src + t.R * t.C].view(t.R, t.C)
-            dst = self._shadowT[t.dst:t.dst + t.C * t.ldd].view(t.C, t.ldd)[:, :t.R]
-            ops.cast_transpose_bf16(src, dst)
+        if self._tdesc is not None:
+            ops.cast_transpose_batch(self._flat, self._shadowT, self._tdesc, self._tblocks)
 
     # views into the flat buffers -------------------------------------------------
     # (views of the flat buffers are cached: the schedule asks for ~9000 of them per step and each torch view costs ~2 us

@@ -9,6 +9,18 @@ finished a layer, its slab is all-reduced on a side HIP stream while the backwar
 the compute stream busy -- few, large collectives, which is what point-to-point xGMI links want.
 Parameters outside the backbone (100-channel projections, text embedding, time MLP; < 1 M) are reduced in one
 small flat all-reduce when the autograd pass ends.
+
+Two ways in:
+  * `DataParallel(model)`: the wrapper used by bench.py -- call it like the model, then `loss.backward()`;
+  * `enable_overlap_under_ddp(model)` + the stock `torch.nn.parallel.DistributedDataParallel` (what
+    `accelerator.prepare(model)` builds, trainer.py:155-162,190): the backbone's parameters are taken out of the stock
+    reducer (`_ddp_params_and_buffers_to_ignore`) and exchanged by the slab hook with overlap; everything else stays with
+    stock DDP.  Without the shim stock DDP still works (the gradients travel through autograd), but all of its buckets
+    become ready at once when the backbone's single autograd node finishes, i.e. nothing overlaps.
+
+`grad_dtype=torch.bfloat16` halves the bytes on the links (2.9 GB -> 1.45 GB per dim-1024 / depth-24 step): a slab is
+pre-divided by the world size in fp32, rounded to bf16, summed by RCCL in bf16 and added back into the fp32 buffer.
+`bucket_layers=k` merges k consecutive layer slabs into one collective.
 """
 from __future__ import annotations
 
@@ -20,60 +32,97 @@ from .backbone import Transformer
 
 
 class _GradSync:
-    def __init__(self, group=None):
+    def __init__(self, group=None, grad_dtype=torch.float32, bucket_layers=1):
+        assert grad_dtype in (torch.float32, torch.bfloat16)
         self.group = group
         self.world = dist.get_world_size(group)
+        self.grad_dtype = grad_dtype
+        self.bucket_layers = max(1, int(bucket_layers))
         self.side = None
         self.calls = 0
+        self.bytes = 0
+        self._pending = None          # (start, end, layers) of the slabs merged so far
 
-    def __call__(self, gflat, start, end):
-        if start is None:                                   # wait for every slab launched so far
-            if self.side is not None:
-                torch.cuda.current_stream(gflat.device).wait_stream(self.side)
-            return
-        if end <= start:
-            return
+    def _reduce(self, gflat, start, end):
         slab = gflat[start:end]
         self.calls += 1
+        self.bytes += slab.numel() * (2 if self.grad_dtype == torch.bfloat16 else 4)
+
+        def run():
+            if self.grad_dtype == torch.bfloat16:
+                buf = (slab * (1.0 / self.world)).to(torch.bfloat16)
+                dist.all_reduce(buf, op=dist.ReduceOp.SUM, group=self.group)
+                slab.copy_(buf)
+            else:
+                slab.mul_(1.0 / self.world)
+                dist.all_reduce(slab, op=dist.ReduceOp.SUM, group=self.group)
+
         if gflat.is_cuda:
             if self.side is None:
                 self.side = torch.cuda.Stream(device=gflat.device)
             self.side.wait_stream(torch.cuda.current_stream(gflat.device))     # the slab is complete on the compute stream
             with torch.cuda.stream(self.side):
-                slab.mul_(1.0 / self.world)
-                dist.all_reduce(slab, op=dist.ReduceOp.SUM, group=self.group)
+                run()
             slab.record_stream(self.side)
         else:
-            slab.mul_(1.0 / self.world)
-            dist.all_reduce(slab, op=dist.ReduceOp.SUM, group=self.group)
+            run()
+
+    def __call__(self, gflat, start, end):
+        if start is None:                                   # flush, then wait for every slab launched so far
+            if self._pending is not None:
+                s, e, _ = self._pending
+                self._pending = None
+                self._reduce(gflat, s, e)
+            if self.side is not None:
+                torch.cuda.current_stream(gflat.device).wait_stream(self.side)
+            return
+        if end <= start:
+            return
+        # the backward finishes layers from the last to the first: consecutive slabs are adjacent in the flat buffer
+        if self._pending is not None and self._pending[0] == end:
+            s, e, k = start, self._pending[1], self._pending[2] + 1
+        else:
+            if self._pending is not None:
+                self._reduce(gflat, self._pending[0], self._pending[1])
+            s, e, k = start, end, 1
+        if k >= self.bucket_layers:
+            self._pending = None
+            self._reduce(gflat, s, e)
+        else:
+            self._pending = (s, e, k)
+
+
+def _flat_params(bb):
+    return [p for p, _ in bb._layout.slots]
+
+
+@torch.no_grad()
+def _broadcast(tensors, src, group):
+    for t in tensors:
+        dist.broadcast(t.data, src=src, group=group)
 
 
 class DataParallel(nn.Module):
     """wraps an E2TTS / DurationPredictor / Transformer; call it like the wrapped module, then loss.backward()."""
 
-    def __init__(self, module: nn.Module, process_group=None, broadcast_from: int | None = 0):
+    def __init__(self, module: nn.Module, process_group=None, broadcast_from: int | None = 0,
+                 grad_dtype: torch.dtype = torch.float32, bucket_layers: int = 1):
         super().__init__()
         assert dist.is_initialized(), 'torch.distributed must be initialised (backend "nccl" is RCCL on ROCm)'
         self.module = module
         self.group = process_group
         self.world = dist.get_world_size(process_group)
         self._backbones = [m for m in module.modules() if isinstance(m, Transformer)]
-        inside = {id(p) for bb in self._backbones for p in bb.parameters() if self._in_flat(bb, p)}
+        inside = {id(p) for bb in self._backbones for p in _flat_params(bb)}
         self._outside = [p for p in module.parameters() if id(p) not in inside]
-        self._sync = _GradSync(process_group)
+        self._sync = _GradSync(process_group, grad_dtype, bucket_layers)
+        self._outside_queued = False
         for bb in self._backbones:
             bb._grad_sync = self._hook
-        self._outside_queued = False
         if broadcast_from is not None:
-            with torch.no_grad():
-                for t in list(module.parameters()) + list(module.buffers()):
-                    dist.broadcast(t.data, src=broadcast_from, group=process_group)
+            _broadcast(list(module.parameters()) + list(module.buffers()), broadcast_from, process_group)
             for bb in self._backbones:          # the broadcast wrote behind the version counters: refresh the bf16 shadows
                 bb._shadow_key = None
-
-    @staticmethod
-    def _in_flat(bb, p):
-        return any(p is q for q, _ in bb._layout.slots)
 
     def _hook(self, gflat, start, end):
         if start is None and self._outside and not self._outside_queued:
@@ -111,3 +160,26 @@ class DataParallel(nn.Module):
             return super().__getattr__(name)
         except AttributeError:
             return getattr(self.module, name)
+
+
+def enable_overlap_under_ddp(module: nn.Module, process_group=None, broadcast_from: int | None = 0,
+                             grad_dtype: torch.dtype = torch.float32, bucket_layers: int = 1):
+    """Call BEFORE wrapping `module` in the stock DistributedDataParallel (`accelerator.prepare(model)` in the reference
+    trainer): every backbone's parameters are marked to be ignored by the stock reducer and exchanged by the per-layer
+    slab hook instead (overlapped with the backbone's backward on a side stream); the remaining parameters keep going
+    through stock DDP's buckets.  Returns the hook object (`.calls`, `.bytes` for inspection)."""
+    assert dist.is_initialized()
+    backbones = [(name, m) for name, m in module.named_modules() if isinstance(m, Transformer)]
+    sync = _GradSync(process_group, grad_dtype, bucket_layers)
+    ignore = list(getattr(module, '_ddp_params_and_buffers_to_ignore', []))
+    names = {id(p): n for n, p in module.named_parameters()}
+    for _, bb in backbones:
+        bb._grad_sync = sync
+        for p in _flat_params(bb):
+            ignore.append(names[id(p)])
+    module._ddp_params_and_buffers_to_ignore = ignore
+    if broadcast_from is not None:               # stock DDP only broadcasts what it manages
+        _broadcast([p for _, bb in backbones for p in _flat_params(bb)], broadcast_from, process_group)
+        for _, bb in backbones:
+            bb._shadow_key = None
+    return sync

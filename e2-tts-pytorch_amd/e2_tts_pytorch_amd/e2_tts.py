@@ -1,8 +1,9 @@
 """E2TTS / DurationPredictor / MelSpec with the reference's constructor and call signatures
 (/root/reference/e2_tts_pytorch/e2_tts.py:248-290, 956-1113, 1115-1595) on top of the HIP backbone.
 
-What stays in torch here is bookkeeping around the hot loop (masks, noise draws, tokenisation, the 100-channel
-input / output projections, the scalar loss): device memory + a handful of small element-wise ops.
+The 100-channel input / output projections and the masked flow-matching loss run on the HIP GEMM / reduction kernels
+(_InProjFn, _OutProjFn, _MaskedMSEFn); what stays in torch is bookkeeping around them (masks, noise draws, the
+interpolation w = (1 - t) x0 + t x1, tokenisation + embedding gather): a handful of small element-wise ops.
 """
 from __future__ import annotations
 
@@ -84,6 +85,100 @@ def project(x, y):                                             # e2_tts.py:113-1
     parallel = (xf * unit).sum(dim=-1, keepdim=True) * unit
     orthogonal = xf - parallel
     return parallel.reshape(shape).to(dtype), orthogonal.reshape(shape).to(dtype)
+
+
+# ------------------------------------------------------------------------------------------------ head / tail on the HIP GEMMs
+
+def _r8(n):
+    return (n + 7) // 8 * 8
+
+
+def _f32c(t):
+    return t if (t.dtype == torch.float32 and t.is_contiguous()) else t.float().contiguous()
+
+
+class _InProjFn(torch.autograd.Function):
+    """a1 @ w1.T + a2 @ w2.T + bias as ONE dual-K-panel NT GEMM: `proj_in(x) + cond_proj_in(cond)`
+    (e2_tts.py:1274-1277) or, for concat_cond, `proj_in(cat(cond, x))` (:1263-1272) with the weight's two column blocks.
+    The 100-channel panels are padded to K = 104 in the bf16 operand copies (cast_pad kernel); weight and bias gradients
+    come from the weight-gradient GEMM (bias gradient riding along as its column sums)."""
+
+    @staticmethod
+    def forward(ctx, a1, a2, w1, w2, bias):
+        B, T, C = a1.shape
+        M, Cp, D = B * T, _r8(C), w1.shape[0]
+        a1b = ops.cast_pad_bf16(_f32c(a1.detach()).view(M, C), Cp)
+        a2b = ops.cast_pad_bf16(_f32c(a2.detach()).view(M, C), Cp)
+        wb = torch.empty((D, 2 * Cp), dtype=torch.bfloat16, device=a1.device)
+        ops.cast_pad_bf16(w1.detach(), Cp, out=wb, col0=0)
+        ops.cast_pad_bf16(w2.detach(), Cp, out=wb, col0=Cp)
+        out = ops.gemm_nt(a1b, wb, a2=a2b, bias=_f32c(bias.detach()), out_dtype=torch.float32)
+        ctx.save_for_backward(a1b, a2b)
+        ctx.dims = (B, T, C, D)
+        return out.view(B, T, D)
+
+    @staticmethod
+    def backward(ctx, dout):
+        a1b, a2b = ctx.saved_tensors
+        B, T, C, D = ctx.dims
+        M, dev = B * T, dout.device
+        dob = ops.cast_bf16(_f32c(dout).view(-1), torch.empty((M, D), dtype=torch.bfloat16, device=dev))
+        dw1, dw2, db = ops.zeros((D, C), torch.float32, dev), ops.zeros((D, C), torch.float32, dev), ops.zeros((D,), torch.float32, dev)
+        ops.gemm_tn(dob, a1b[:, :C], dw1, colsum=db)
+        ops.gemm_tn(dob, a2b[:, :C], dw2)
+        return None, None, dw1, dw2, db
+
+
+class _OutProjFn(torch.autograd.Function):
+    """to_pred (e2_tts.py:1296): (B, T, D) -> (B, T, C) on the NT GEMM; backward dgrad over the K = 104 padded gradient"""
+
+    @staticmethod
+    def forward(ctx, e, w, bias):
+        B, T, D = e.shape
+        M, C, dev = B * T, w.shape[0], e.device
+        eb = ops.cast_bf16(_f32c(e.detach()).view(-1), torch.empty((M, D), dtype=torch.bfloat16, device=dev))
+        wf = _f32c(w.detach())
+        wb = ops.cast_bf16(wf.view(-1), torch.empty((C, D), dtype=torch.bfloat16, device=dev))
+        out = ops.gemm_nt(eb, wb, bias=_f32c(bias.detach()), out_dtype=torch.float32)
+        ctx.save_for_backward(eb, wf)
+        ctx.dims = (B, T, D, C)
+        return out.view(B, T, C)
+
+    @staticmethod
+    def backward(ctx, dout):
+        eb, wf = ctx.saved_tensors
+        B, T, D, C = ctx.dims
+        M, Cp, dev = B * T, _r8(C), dout.device
+        dpb = ops.cast_pad_bf16(_f32c(dout).view(M, C), Cp)
+        wT = ops.zeros((D, Cp), torch.bfloat16, dev)
+        ops.cast_transpose_bf16(wf, wT[:, :C])
+        de = ops.gemm_nt(dpb, wT, out_dtype=torch.float32)
+        dw, db = ops.zeros((C, D), torch.float32, dev), ops.zeros((C,), torch.float32, dev)
+        ops.gemm_tn(dpb[:, :C], eb, dw, colsum=db)
+        return de.view(B, T, D), dw, db
+
+
+class _MaskedMSEFn(torch.autograd.Function):
+    """mean of (pred - flow)^2 over the masked span (e2_tts.py:1578-1582) in one reduction kernel, no boolean-index gather"""
+
+    @staticmethod
+    def forward(ctx, pred, flow, mask):
+        B, T, C = pred.shape
+        p2, f2 = _f32c(pred.detach()).view(B * T, C), _f32c(flow.detach()).view(B * T, C)
+        m8 = mask.contiguous().view(torch.uint8).view(-1)
+        acc = ops.masked_mse_fwd(p2, f2, m8)
+        ctx.save_for_backward(p2, f2, m8, acc)
+        ctx.shape = pred.shape
+        return acc[0] / (acc[1] * C)
+
+    @staticmethod
+    def backward(ctx, dloss):
+        p2, f2, m8, acc = ctx.saved_tensors
+        return ops.masked_mse_bwd(p2, f2, m8, acc, _f32c(dloss).view(1)).view(ctx.shape), None, None
+
+
+def _on_kernels(t):
+    return t.is_cuda or ops.host_ok()
 
 
 # ------------------------------------------------------------------------------------------------ MelSpec
@@ -435,15 +530,19 @@ class E2TTS(Module):
                                    return_drop_text_cond=False):
         seq_len = x.shape[-2]
         drop_text_cond = default(drop_text_cond, self.training and random() < self.cond_drop_prob)
-        if self.concat_cond:                              # e2_tts.py:1263-1276
-            x = self.proj_in(torch.cat((cond, x), dim=-1))
-        else:
-            x = self.proj_in(x) + self.cond_proj_in(cond)
+        C = self.num_channels
+        if not _on_kernels(x):
+            raise ops.E2KError('e2_tts_pytorch_amd kernels need tensors on a HIP device (no CPU path)')
+        if self.concat_cond:                              # e2_tts.py:1263-1276: proj_in(cat(cond, x)), never concatenated
+            w = self.proj_in.weight
+            x = _InProjFn.apply(cond, x, w[:, :C], w[:, C:], self.proj_in.bias)
+        else:                                             # e2_tts.py:1274-1277: proj_in(x) + cond_proj_in(cond), one GEMM
+            x = _InProjFn.apply(x, cond, self.proj_in.weight, self.cond_proj_in.weight, self.proj_in.bias + self.cond_proj_in.bias)
         text_embed = None
         if exists(text) and not drop_text_cond:
             text_embed = self.embed_text(text, seq_len, mask=mask)
         embed = self.transformer(x, times=times, mask=mask, text_embed=text_embed)
-        pred = self.to_pred(embed)
+        pred = _OutProjFn.apply(embed, self.to_pred.weight, self.to_pred.bias)
         if not return_drop_text_cond:
             return pred
         return pred, drop_text_cond
@@ -562,7 +661,6 @@ class E2TTS(Module):
             velocity_loss = (F.mse_loss(pred, ema_pred, reduction='none') * m).sum() / (m.sum() * pred.shape[-1])
         # mean of the squared error over the masked span == loss[rand_span_mask].mean() (e2_tts.py:1580-1582), written
         # as a masked sum so that no boolean-index gather (device sync for the element count) is needed
-        sq = F.mse_loss(pred, flow, reduction='none')
-        loss = (sq * m).sum() / (m.sum() * sq.shape[-1])
+        loss = _MaskedMSEFn.apply(pred, flow, rand_span_mask)
         total_loss = loss + velocity_loss * self.velocity_consistency_weight
         return E2TTSReturn(total_loss, cond, pred, x0 + pred, LossBreakdown(loss, velocity_loss))

@@ -365,6 +365,13 @@ def cast_transpose_bf16(src, dst):
     return dst
 
 
+def cast_transpose_batch(flat, flatT, desc, total_blocks):
+    """all transposed bf16 shadows in one launch; desc: int64 (n, 6) device tensor, see e2k_cast_transpose_batch"""
+    _chk(flat, flatT, desc)
+    assert flat.dtype == f32 and flatT.dtype == bf16 and desc.dtype == torch.int64 and desc.is_contiguous() and desc.shape[1] == 6
+    _lib.get().e2k_cast_transpose_batch(_p(flat), _p(flatT), _p(desc), desc.shape[0], int(total_blocks), _stream(flat))
+
+
 # ------------------------------------------------------------------------------------------------ depthwise conv
 
 def dwconv_fwd(x, mask, w, bias):
@@ -427,6 +434,7 @@ def qkv_post_fwd(qkvg, B, H, N, cosb, sinb, vfirst=None):
 # kernels read them back instead of re-hashing: bit-identical results (tools/attn_share_check.py on MI355X), forward
 # 0.132 -> 0.140 ms, backward 0.403 -> 0.358 ms per cfg3 attention.  False = every kernel re-derives the mask.
 attn_share_dropmask = True
+attn_probe = int(_os.environ.get('E2K_ATTN_FLAGS', '0'))      # E2K_ATTN_* bits: 64 = 64-row workgroups (A/B); probes 1..32 give wrong results on purpose
 
 
 def attn_fwd(st, kmask_pad, p_drop=0., seed=0, stream_id=0, seed_dev=None):
@@ -446,7 +454,7 @@ def attn_fwd(st, kmask_pad, p_drop=0., seed=0, stream_id=0, seed_dev=None):
     _note(4.0 * B * H * N * N * 64)
     _lib.get().e2k_attn_fwd(_p(st.Q), _p(st.K), _p(st.VT), _p(kmask_pad), _p(st.gate), _p(st.O), _p(st.Og), _p(st.lse2),
                             _p(st.dropbits), B, H, N, Npad, float(p_drop), int(seed), _p(seed_dev), int(stream_id),
-                            _stream(st.Q))
+                            attn_probe, _stream(st.Q))
     return st.Og
 
 
@@ -464,7 +472,8 @@ def attn_bwd(st, dOg, kmask_pad, p_drop=0., seed=0, stream_id=0, seed_dev=None):
     _note(10.0 * B * H * N * N * 64)
     _lib.get().e2k_attn_bwd(_p(dOg), _p(st.O), _p(st.gate), _p(st.lse2), _p(st.Q), _p(st.K), _p(st.V), _p(st.QT),
                             _p(st.KT), _p(kmask_pad), _p(st.dropbits), _p(dO), _p(dOT), _p(delta), _p(dgate), _p(dQ), _p(dK),
-                            _p(dV), B, H, N, Npad, float(p_drop), int(seed), _p(seed_dev), int(stream_id), _stream(dOg))
+                            _p(dV), B, H, N, Npad, float(p_drop), int(seed), _p(seed_dev), int(stream_id), attn_probe & 64,
+                            _stream(dOg))
     return dQ, dK, dV, dgate
 
 
@@ -609,6 +618,37 @@ def cond_bwd_prep(dcond, gates, gbias, B, L, D):
     dct = torch.empty((4 * L * D, KB), dtype=bf16, device=dcond.device)
     _lib.get().e2k_cond_bwd_prep(_p(dcond), _p(gates), _p(dcb), _p(dct), _p(gbias), B, L, D, KB, _stream(dcond))
     return dcb, dct
+
+
+def cast_pad_bf16(src, cpad, out=None, col0=0):
+    """src (R, C) fp32 (rows contiguous) -> bf16 (R, cpad) zero padded; with `out` (R, ld) the result goes to its columns
+    col0 .. col0 + cpad"""
+    _chk(src, out)
+    R, C = src.shape
+    assert src.dtype == f32 and src.stride(1) == 1 and cpad >= C
+    if out is None:
+        out = torch.empty((R, cpad), dtype=bf16, device=src.device)
+    assert out.dtype == bf16 and out.stride(1) == 1 and out.shape[0] == R and col0 + cpad <= out.shape[1]
+    _lib.get().e2k_cast_pad_bf16(_p(src), src.stride(0), out.data_ptr() + 2 * col0, out.stride(0), R, C, cpad, _stream(src))
+    return out
+
+
+def masked_mse_fwd(pred, flow, mask):
+    """-> acc (2,) fp32 = [sum of squared errors over the masked rows, number of masked rows]"""
+    _chk(pred, flow, mask)
+    M, C = pred.shape
+    assert pred.dtype == f32 and flow.dtype == f32 and pred.is_contiguous() and flow.is_contiguous() and mask.numel() == M and mask.is_contiguous()
+    acc = torch.empty(2, dtype=f32, device=pred.device)
+    _lib.get().e2k_masked_mse_fwd(_p(pred), _p(flow), _p(mask), _p(acc), M, C, _stream(pred))
+    return acc
+
+
+def masked_mse_bwd(pred, flow, mask, acc, dloss):
+    _chk(pred, flow, mask, acc, dloss)
+    M, C = pred.shape
+    dpred = torch.empty_like(pred)
+    _lib.get().e2k_masked_mse_bwd(_p(pred), _p(flow), _p(mask), _p(acc), _p(dloss), _p(dpred), M, C, _stream(pred))
+    return dpred
 
 
 def transpose_f32(src, C):

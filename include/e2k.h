@@ -124,6 +124,9 @@ int e2k_colsum_bf16(const void* x, int64_t ldx, float* out, int M, int N, void* 
 /* fp32 master parameters -> bf16 compute shadows (flat, and (R,C) -> transposed (C,R) with row stride ldd) */
 int e2k_cast_bf16(const float* src, void* dst, int64_t n, void* stream);
 int e2k_cast_transpose_bf16(const float* src, void* dst, int R, int C, int64_t ldd, void* stream);
+/* every transposed shadow of a module in one launch: desc (DEVICE, n x 6 int64) = {src element offset into `flat`, dst
+ * element offset into `flatT`, R, C, ldd, index of the matrix's first 64 x 64 tile}, total_blocks = sum of the tiles */
+int e2k_cast_transpose_batch(const float* flat, void* flatT, const int64_t* desc, int n, int total_blocks, void* stream);
 
 /* DepthwiseConv (e2_tts.py:295-328): channels-last x (B,N,C) bf16, mask (B,N) u8 or NULL, w (C,ks) fp32, bias (C):
  *   pre = conv1d(mask * x) + bias ;  y = mask * silu(pre).   ks in {3,7,15,31}, C multiple of 64. */
@@ -153,7 +156,15 @@ int e2k_qkv_post_bwd(const void* dQ, const void* dK, const void* dV, const float
  * O / Og: token-major (B*N, H*64) un-gated / gated by `gate`;  lse2 (B,H,N): log2-domain log-sum-exp. */
 int e2k_attn_fwd(const void* Q, const void* K, const void* VT, const uint8_t* kmask, const float* gate,
                  void* O, void* Og, float* lse2, void* dropbits, int B, int H, int N, int Npad, float p_drop,
-                 uint32_t seed, const uint32_t* seed_dev, uint32_t stream_id, void* stream);
+                 uint32_t seed, const uint32_t* seed_dev, uint32_t stream_id, int flags, void* stream);
+/* flags: 0, or bottleneck probes of the forward kernel (tools/probes/attn_ablate.py; the RESULTS ARE WRONG on purpose) */
+#define E2K_ATTN_PROBE_NO_KMASK 1    /* no key-mask load per tile */
+#define E2K_ATTN_PROBE_NO_QK 2       /* no K LDS reads + score MFMAs */
+#define E2K_ATTN_PROBE_NO_SOFTMAX 4  /* no soft-clamp / exp2 / dropout */
+#define E2K_ATTN_PROBE_NO_PV 8       /* no V LDS reads + second MFMAs */
+#define E2K_ATTN_PROBE_NO_LOADS 16   /* no global K / V tile loads after the first */
+#define E2K_ATTN_PROBE_NO_BARRIER 32 /* no workgroup barriers */
+#define E2K_ATTN_WG128 64            /* (both calls) 128 query rows / keys per workgroup instead of 64 (A/B; same results, not faster on MI355X) */
 /* dropbits (optional, both calls; NULL = every kernel re-derives the dropout mask from the counter hash): scratch of
  * e2k_query_attn_dropbits_bytes(B, H, N) bytes in which the forward leaves its keep decisions as 64-bit wave ballot words
  * and from which the backward kernels read them back.  Same mask either way (bit-identical results). */
@@ -163,7 +174,7 @@ int e2k_attn_bwd(const void* dOg, const void* O, const float* gate, const float*
                  const void* K, const void* V, const void* QT, const void* KT, const uint8_t* kmask,
                  const void* dropbits, void* dO, void* dOT, float* delta, float* dgate_pre, void* dQ, void* dK, void* dV,
                  int B, int H, int N, int Npad, float p_drop, uint32_t seed, const uint32_t* seed_dev,
-                 uint32_t stream_id, void* stream);
+                 uint32_t stream_id, int flags, void* stream);
 
 /* ---- MelSpec (e2_tts.py:248-290 -> torchaudio MelSpectrogram(n_fft=1024, hop, power=1, center, htk, norm=None)) ----
  * wave (B, nw) fp32 -> out (B, n_mels, 1 + nw/hop) fp32 = log(clamp(mel, 1e-5)).  window (n_fft) periodic Hann,
@@ -252,6 +263,15 @@ int e2k_time_cond_bwd(const float* dout, const float* four, const float* pre, fl
  * padded to KB columns, gbias[l][1|3][:] += sum_b dcond (the AdaLN-Zero biases; slots 0, 2 have no bias) */
 int e2k_cond_bwd_prep(float* dcond, const float* gates, void* dcb, void* dct, float* gbias, int B, int L, int D, int KB,
                       void* stream);
+/* fp32 (R, C), rows lds floats apart -> bf16 (R, ldd) with columns C .. Cpad-1 zeroed: operands of the 100-channel input /
+ * output projections (e2_tts.py:1267-1277,1296: proj_in, cond_proj_in, to_pred), whose K is padded to a multiple of 8 */
+int e2k_cast_pad_bf16(const float* src, int64_t lds, void* dst, int64_t ldd, int R, int C, int Cpad, void* stream);
+/* flow-matching loss (e2_tts.py:1578-1582: F.mse_loss(pred, flow, reduction = 'none')[rand_span_mask].mean()) without the
+ * boolean-index gather: acc[0] = sum over masked rows of sum_c (pred - flow)^2, acc[1] = number of masked rows (acc is
+ * zeroed by the call); loss = acc[0] / (acc[1] * C).  bwd: dpred = dloss[0] * 2 (pred - flow) mask / (acc[1] * C) */
+int e2k_masked_mse_fwd(const float* pred, const float* flow, const uint8_t* mask, float* acc, int M, int C, void* stream);
+int e2k_masked_mse_bwd(const float* pred, const float* flow, const uint8_t* mask, const float* acc, const float* dloss,
+                       float* dpred, int M, int C, void* stream);
 /* out (C, R) = in (R, ld >= C)^T, fp32, first C columns */
 int e2k_transpose_f32(const float* in, int64_t ld, float* out, int R, int C, void* stream);
 

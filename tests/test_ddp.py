@@ -53,6 +53,26 @@ def _worker(rank, world, port, emu_lib, q):
             if err > 1e-4:
                 bad_p.append((n + ' (persistent)', err))
     assert tr._pg is not None and all(q_.grad is v for (q_, _), v in zip(tr._layout.slots, tr._pg.views) if q_.requires_grad)
+    tr.enable_persistent_grads(False)
+    # the stock torch DistributedDataParallel (what accelerator.prepare builds, trainer.py:155-162,190) with the overlap
+    # shim: the backbone leaves the stock reducer, its slabs go through the hook -- here in bf16, two layers per collective
+    from torch.nn.parallel import DistributedDataParallel as DDP
+    from e2_tts_pytorch_amd.ddp import enable_overlap_under_ddp
+    for bb in (tr,):
+        bb._grad_sync = None
+    model.zero_grad(set_to_none=True)
+    hook = enable_overlap_under_ddp(model, grad_dtype=torch.bfloat16, bucket_layers=2)
+    stock = DDP(model, find_unused_parameters=True)
+    stock(mels[rank], text=['hello'], _noise=noises[rank]).loss.backward()
+    bad_s = []
+    for n, p in model.named_parameters():
+        if n in grads:
+            g = grads[n]
+            err = ((p.grad - g).norm() / g.norm().clamp_min(1e-12)).item() if float(g.norm()) > 0 else float(p.grad.norm())
+            if err > 1e-2:                        # bf16 rounding of the summed slabs
+                bad_s.append((n + ' (stock DDP + shim, bf16 slabs)', err))
+    assert hook.calls >= 2 and any(n.startswith('transformer.') for n in model._ddp_params_and_buffers_to_ignore)
+    bad_p += bad_s
     if rank == 0:
         # single-process reference with the broadcast weights: mean over both "ranks" of the per-sample gradients
         ref = E2TTS(transformer=dict(dim=256, depth=2, heads=4, dropout=0.), use_vocos=False, cond_drop_prob=0.)

@@ -384,7 +384,11 @@ def test_reference_golden_forward(dev, case):
         if n not in c['grad_abs_sums']:           # (concat_cond has no cond_proj_in)
             continue
         got = float(dict(model.named_parameters())[n].grad.double().abs().sum())
-        assert abs(got - c['grad_abs_sums'][n]) < 5e-2 * c['grad_abs_sums'][n], (n, got, c['grad_abs_sums'][n])
+        # to_pred sees the backbone's forward only; the input projections hang off the backbone's INPUT gradient, which with
+        # the fixture's all-random weights is ill-conditioned in the model itself (rounding weights and input to bf16 alone
+        # moves it by 6 % in the fp32 oracle, tests/test_backbone.py::test_reference_golden_backbone)
+        tol = 5e-2 if n == 'to_pred.weight' else 1e-1
+        assert abs(got - c['grad_abs_sums'][n]) < tol * c['grad_abs_sums'][n], (n, got, c['grad_abs_sums'][n])
 
 
 @pytest.mark.late

@@ -87,6 +87,31 @@ def test_colsum_cast(dev):
     assert torch.equal(wt.cpu(), w.t().to(bf16))
 
 
+def test_cast_transpose_batch(dev):
+    """every transposed bf16 shadow of a module in one launch: ragged shapes, padded destination rows, matrices at
+    8-element-aligned offsets of one flat buffer (the backbone's layout), untouched gaps"""
+    from e2_tts_pytorch_amd import ops
+    torch.manual_seed(0)
+    shapes = [(70, 45, 72), (128, 64, 128), (8, 200, 8), (3104, 256, 3136), (64, 1, 64), (130, 136, 136)]     # (R, C, ldd)
+    flat, rows, soff, doff, blk = [], [], 0, 0, 0
+    for R, C, ldd in shapes:
+        flat.append(torch.randn(R * C))
+        flat.append(torch.zeros((-R * C) % 8))
+        rows.append([soff, doff, R, C, ldd, blk])
+        soff += R * C + (-R * C) % 8
+        doff += (C * ldd + 7) // 8 * 8
+        blk += ((R + 63) // 64) * ((C + 63) // 64)
+    flat = torch.cat(flat)
+    flatT = torch.full((doff,), -7.0, dtype=bf16, device=dev)
+    ops.cast_transpose_batch(flat.to(dev), flatT, torch.tensor(rows, dtype=torch.int64, device=dev), blk)
+    got = flatT.cpu()
+    for (R, C, ldd), (so, do, *_rest) in zip(shapes, rows):
+        w = flat[so:so + R * C].view(R, C)
+        t = got[do:do + C * ldd].view(C, ldd)
+        assert torch.equal(t[:, :R], w.t().to(bf16)), (R, C)
+        assert bool((t[:, R:] == -7.0).all())                 # pad columns of the destination rows are left alone
+
+
 # (frames, kernel, mask): 75 frames = two tiles with a ragged tail; 200 frames = several tiles per workgroup in the backward
 @pytest.mark.parametrize('N,ks,use_mask', [(75, 31, True), (75, 7, False), (200, 31, True), (64, 15, False), (5, 3, False)])
 @pytest.mark.parametrize('split', [False, True])

@@ -31,6 +31,9 @@ out = model.sample(cond, text=text, duration=1024, steps=steps, cfg_strength=1.)
 torch.cuda.synchronize()
 dt = time.perf_counter() - t0
 fwd_flops = 6336e12 * (B / 32) * ((steps - 1) / 31)
-print(json.dumps({'metric': 'sampled mel-frames/sec (E2TTS.sample, 32 midpoint steps, CFG)', 'value': B * 1024 / dt,
-                  'unit': 'mel-frames/s', 'seconds': dt, 'B': B, 'steps': steps, 'finite': bool(torch.isfinite(out).all()), 'launch_plans': '--eager' not in sys.argv,
-                  'model_tflops_per_s': fwd_flops / dt / 1e12, 'shape': list(out.shape)}))
+res = {'metric': 'sampled mel-frames/sec (E2TTS.sample, 32 midpoint steps, CFG)', 'value': B * 1024 / dt,
+       'unit': 'mel-frames/s', 'seconds': dt, 'B': B, 'steps': steps, 'finite': bool(torch.isfinite(out).all()),
+       'launch_plans': '--eager' not in sys.argv, 'model_tflops_per_s': fwd_flops / dt / 1e12, 'shape': list(out.shape)}
+print(json.dumps(res))
+(ROOT / 'gpurun_out').mkdir(exist_ok=True)
+json.dump(res, open(ROOT / 'gpurun_out' / ('r02_sample_cfg5%s.json' % ('_eager' if '--eager' in sys.argv else '')), 'w'), indent=1)
