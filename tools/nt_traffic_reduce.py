@@ -1,4 +1,4 @@
-"""gpurun_out/nt_traffic_{FETCH,WRITE}_SIZE.csv (tools/gpu/traffic.sh) -> profiles/r01_nt_traffic.json
+"""gpurun_out/nt_traffic_{FETCH,WRITE}_SIZE.csv (tools/gpu/traffic.sh) -> profiles/r02_nt_traffic.json
 
 One main-kernel dispatch (+ its fix-up dispatch, if any) per entry of tools/nt_shapes_cfg3.json, in file order; the
 per-launch numbers are weighted by the call count of each shape in a cfg3 training step."""
@@ -11,7 +11,7 @@ shapes = json.load(open(ROOT / 'tools' / 'nt_shapes_cfg3.json'))
 def per_shape(fn):
     d = []
     for r in csv.DictReader(open(fn)):
-        if re.search(r'gemm_nt_glds_kernel|gemm_nt_fixup_kernel|gemm_nt_kernel', r['Kernel_Name']):
+        if re.search(r'gemm_nt_glds_kernel|gemm_nt_fixup_kernel|gemm_nt_kernel|gemm_nt_256_kernel|gemm_nt_256_fixup_kernel', r['Kernel_Name']):
             d.append((int(r['Dispatch_Id']), 'fixup' in r['Kernel_Name'], float(r['Counter_Value'])))
     d.sort()
     g = []
@@ -34,12 +34,12 @@ for s, f, w in zip(shapes, gf, gw):
     fb, wb = f * 1024 * 2, w * 1024        # KB -> bytes; gfx950 FETCH_SIZE tallies 128-B requests at 64 B (x2)
     rows.append(dict(s, fetch_bytes=fb, write_bytes=wb, algorithmic_bytes=a))
     fetch += fb * s['count']; write += wb * s['count']; alg += a * s['count']
-res = dict(kernel='gemm_nt_glds_kernel (+fixup)', launches_per_step=n, hbm_fetch_bytes_per_launch=fetch / n,
+res = dict(kernel='gemm_nt_256_kernel / gemm_nt_glds_kernel (+fix-ups): the NT launch mix of a cfg3 step', launches_per_step=n, hbm_fetch_bytes_per_launch=fetch / n,
            hbm_write_bytes_per_launch=write / n, traffic_bytes_per_launch=(fetch + write) / n,
            algorithmic_bytes_per_launch=alg / n,
            method='rocprofv3 --pmc FETCH_SIZE and --pmc WRITE_SIZE (separate passes) over tools/nt_traffic_probe.py: one launch '
                   'per distinct NT shape of a cfg3 step (tools/nt_shapes_cfg3.json), weighted by its call count; FETCH_SIZE (KB) '
                   'doubled (gfx950 counts 128-B requests as 64 B, MI355X_MICROARCH.md HBM section); WRITE_SIZE (KB) uncalibrated',
            shapes=rows)
-json.dump(res, open(ROOT / 'profiles' / 'r01_nt_traffic.json', 'w'), indent=1)
+json.dump(res, open(ROOT / 'profiles' / 'r02_nt_traffic.json', 'w'), indent=1)
 print({k: v for k, v in res.items() if k not in ('shapes', 'method')})
