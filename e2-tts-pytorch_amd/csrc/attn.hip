@@ -473,6 +473,194 @@ __global__ __launch_bounds__(NW * 64, NW == 8 ? 4 : 2) void attn_fwd_kernel(Attn
     }
 }
 
+// ---- forward with an LDS-DMA ring ---------------------------------------------------------------------------------
+// Same arithmetic and the same LDS tile images as attn_fwd_kernel (NW = 4), different data movement.  K / V tiles go
+// HBM -> LDS directly (global_load_lds, no staging VGPRs, no LDS write pass) into a ring of 16-KB stages with a counted
+// s_waitcnt and ONE raw barrier per tile; the key mask of the whole row sits in LDS (no global load inside the tile loop),
+// and the dropout ballots of a tile leave through LDS as one 128-byte store instead of 16 scalar-lane stores.
+// Measured on MI355X (cfg3 shape, dropout 0.1 with mask publication): register-staged kernel 144.7 us; ring of 3 stages
+// (3 workgroups per CU) 141.9; ring of 4 (2 per CU) 140.9; ring of TWO stages = 112 VGPRs and 37 KB of LDS = FOUR workgroups
+// per CU: 115.4 us (no dropout: 93.1 -> 79.6).  The kernel is bound by dependency stalls (MFMA -> soft-max VALU -> MFMA
+// chains, 16 MFMAs between barriers), so the fourth wave per SIMD is what pays, not the deeper prefetch: RING = 2 is
+// the default.
+//   iteration t:  wait until tile t has landed (tile t+1 may stay in flight) | barrier | issue tile t+2 into the stage
+//                 tile t-1 was read from (every wave has passed the barrier, i.e. finished tile t-1) | compute tile t
+// The LDS images are those of tile_sstore_perm (K: row perm_inv(R), 16-byte slots XOR-swizzled by row & 7) and tile_sstore
+// (V^T), produced by permuting the per-lane SOURCE address (the LDS destination of an LDS-DMA is lane-linear).
+constexpr int RSTAGE = 16384, RKM = 4096;
+
+template <bool DROP, bool SHARE, int RING>       // RING stages: tiles are issued RING - 1 ahead
+__global__ __launch_bounds__(256, 2) void attn_fwd_ring_kernel(AttnArgs p) {
+    __shared__ __attribute__((aligned(16))) unsigned char smem[RING * RSTAGE + RKM + 4 * 256];
+    unsigned char* const kms = smem + RING * RSTAGE;                 // key mask of this batch row (Npad bytes)
+    unsigned long long* const bal = (unsigned long long*)(smem + RING * RSTAGE + RKM);     // [wave][2][16] ballot words
+    const int tid = threadIdx.x, lane = tid & 63, wave = uniform_i(tid >> 6);
+    const int l15 = lane & 15, g = lane >> 4;
+    const int q0 = blockIdx.x * 64, h = blockIdx.y, b = blockIdx.z;
+    const long bh = (long)b * p.H + h;
+    const int q = q0 + wave * 16 + l15;
+    const bool qin = q < p.N;
+    const unsigned dstream = attn_stream(p.stream_id, (unsigned)bh);
+    const int ntiles = (p.N + 63) / 64;
+
+    for (int i = tid * 16; i < p.Npad; i += 256 * 16) st<u32x4>(kms + i, ld<u32x4>(p.kmask + (long)b * p.Npad + i));
+
+    bf16x8 qf[2];
+#pragma unroll
+    for (int kk = 0; kk < 2; ++kk)
+        qf[kk] = qin ? ld<bf16x8>(p.Q + (bh * p.N + q) * DH + kk * 32 + g * 8) : bf16x8{0, 0, 0, 0, 0, 0, 0, 0};
+
+    // staging: a [64][64] bf16 tile = 8 wave instructions of 8 LDS rows; wave w issues instructions 2w, 2w + 1 of K and of V^T
+    const bf16_t* Kbase = p.K + bh * p.N * DH;
+    const bf16_t* VTbase = p.VT + bh * DH * p.Npad;
+    int krow[2];                  // source row of K (inside a tile) for this lane's LDS position
+    unsigned kcol[2], voff[2];    // byte offsets: K column chunk; V^T row + column chunk
+#pragma unroll
+    for (int u = 0; u < 2; ++u) {
+        const int r = (wave * 2 + u) * 8 + (lane >> 3), sp = lane & 7;      // LDS row, 16-byte slot position
+        krow[u] = (r & 0x23) | ((r & 0x10) >> 2) | ((r & 0x0c) << 1);       // tile row stored at LDS row r (perm_inv^-1)
+        kcol[u] = (unsigned)((sp ^ (r & 7)) * 16);
+        voff[u] = (unsigned)(((long)r * p.Npad + (sp ^ (r & 7)) * 8) * 2);
+    }
+    auto issue = [&](int t, int stage) __attribute__((always_inline)) {
+        const int k0 = t * 64;
+        unsigned char* S = smem + stage * RSTAGE;
+#pragma unroll
+        for (int u = 0; u < 2; ++u) {
+            const int row = min(k0 + krow[u], p.N - 1);                     // keys past the end: any valid row (masked below)
+            glds16((const char*)Kbase + (long)row * (DH * 2) + kcol[u], S + (wave * 2 + u) * 1024);
+            glds16((const char*)VTbase + (long)k0 * 2 + voff[u], S + 8192 + (wave * 2 + u) * 1024);
+        }
+    };
+
+    f32x4 o[4];
+#pragma unroll
+    for (int ct = 0; ct < 4; ++ct) o[ct] = f32x4{0.f, 0.f, 0.f, 0.f};
+    f32x2_ lsum2 = {0.f, 0.f};
+    const float kx = p.scale / CLAMP;
+    const float k2 = 2.f * LOG2E * kx, cl2 = CLAMP * LOG2E;
+    const ClampPoly cp = clamp_poly(kx, cl2);
+    const unsigned hrow = rand_base(p.seed_dev ? *p.seed_dev : p.seed, dstream) + (unsigned)q * 0x85ebca77u;
+    const unsigned hlane = hrow + (unsigned)(2 * g) * 0xc2b2ae3du;
+    unsigned long long* const wbal = bal + wave * 32;
+
+    // every ordinary global load of the prologue must have been waited for BEFORE the first LDS-DMA is issued: the
+    // compiler counts vmcnt in order, so a Q fragment first used inside the loop would make it drain the whole prefetch
+    // queue there (s_waitcnt vmcnt(0) in every iteration)
+    asm volatile("" ::"v"(qf[0]), "v"(qf[1]), "v"(hrow));
+#pragma unroll
+    for (int d = 0; d < RING - 1; ++d)
+        if (d < ntiles) issue(d, d);
+    int stage = 0;
+    for (int kt = 0; kt < ntiles; ++kt) {
+        const int k0 = kt * 64;
+        // tile kt must have landed for this wave; the younger tiles kt + 1 .. kt + RING - 2 (4 loads each) may stay in flight
+        const int fly = min(RING - 2, ntiles - 1 - kt);
+        if (fly >= 2) wait_vmcnt<8>();
+        else if (fly == 1) wait_vmcnt<4>();
+        else wait_vmcnt<0>();
+        barrier_raw();                                  // ... and for every wave; everyone has finished tile kt - 1
+        if (kt + RING - 1 < ntiles) issue(kt + RING - 1, stage == 0 ? RING - 1 : stage - 1);
+        const unsigned char* Kt = smem + stage * RSTAGE;
+        const unsigned char* Vt = Kt + 8192;
+        f32x4 s[4];
+        score_tile(Kt, qf, l15, g, s);
+        const unsigned km = mask_bits(ld<unsigned long long>(kms + k0 + g * 8)) |
+                            (mask_bits(ld<unsigned long long>(kms + k0 + 32 + g * 8)) << 8);
+        const bool allk = wave_all(km == 0xffffu);
+        if (wave_all(abs_max16(s) * kx <= TANH_POLY_MAX)) {
+#pragma unroll
+            for (int t = 0; t < 4; ++t)
+#pragma unroll
+                for (int r = 0; r < 4; r += 2) {
+                    const f32x2_ z = clamp2(f32x2_{s[t][r], s[t][r + 1]}, cp);
+                    s[t][r] = z[0];
+                    s[t][r + 1] = z[1];
+                }
+        } else {
+#pragma unroll
+            for (int t = 0; t < 4; ++t)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) s[t][r] = clamp_tanh_scaled(s[t][r], k2, cl2);
+        }
+        if (!allk) {
+#pragma unroll
+            for (int t = 0; t < 4; ++t)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    const bool keep = (km >> (8 * (t >> 1) + 4 * (t & 1) + r)) & 1u;
+                    s[t][r] = keep ? s[t][r] : NEG_MASK;
+                }
+        }
+        unsigned long long mk[16];
+#pragma unroll
+        for (int t = 0; t < 4; ++t) {
+            float pr[4];
+#pragma unroll
+            for (int r = 0; r < 4; ++r) pr[r] = fast_exp2(s[t][r]);
+            lsum2 += f32x2_{pr[0], pr[1]};           // softmax denominators are taken BEFORE dropout
+            lsum2 += f32x2_{pr[2], pr[3]};
+            if (DROP) {
+                unsigned w0, w1;
+                drop4(hlane, (unsigned)(k0 >> 2) + 8 * (t >> 1) + (t & 1), w0, w1);
+                const bool kp[4] = {(w0 & 0xffffu) >= p.thresh, (w0 >> 16) >= p.thresh, (w1 & 0xffffu) >= p.thresh, (w1 >> 16) >= p.thresh};
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    pr[r] = kp[r] ? pr[r] : 0.f;
+                    if (SHARE) mk[4 * t + r] = wave_ballot(kp[r]);
+                }
+            }
+#pragma unroll
+            for (int r = 0; r < 4; ++r) s[t][r] = pr[r];
+        }
+        if (DROP && SHARE) {
+            // the 16 compare masks of this tile: lane 0 parks them in LDS, lanes 0-15 write them out as one 128-byte store
+            unsigned long long* wb = wbal + (kt & 1) * 16;
+            if (lane == 0) {
+#pragma unroll
+                for (int i = 0; i < 16; ++i) wb[i] = mk[i];
+            }
+            wave_sync();
+            if (lane < 16) {
+                unsigned long long* dropw = p.dropbits + ((((long)bh * ntiles + kt) * ntiles + blockIdx.x) * 4 + wave) * 16;
+                dropw[lane] = wb[lane];
+            }
+        }
+#pragma unroll
+        for (int kk2 = 0; kk2 < 2; ++kk2) {
+            float lo[4] = {s[2 * kk2][0], s[2 * kk2][1], s[2 * kk2][2], s[2 * kk2][3]};
+            float hi[4] = {s[2 * kk2 + 1][0], s[2 * kk2 + 1][1], s[2 * kk2 + 1][2], s[2 * kk2 + 1][3]};
+            bf16x8 pf = pack_frag(lo, hi);
+#pragma unroll
+            for (int ct = 0; ct < 4; ++ct) {
+                bf16x8 vf = tile_frag(Vt, ct * 16 + l15, kk2 * 4 + g);
+                o[ct] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(vf, pf, o[ct], 0, 0, 0);
+            }
+        }
+        stage = stage == RING - 1 ? 0 : stage + 1;
+    }
+    float lsum = lsum2[0] + lsum2[1];           // a row's keys are spread over the lanes l, l+16, l+32, l+48
+    lsum += __shfl_xor(lsum, 16);
+    lsum += __shfl_xor(lsum, 32);
+    if (!qin) return;
+    const float inv = lsum > 0.f ? (DROP ? p.inv_keep : 1.f) / lsum : 0.f;
+    const float gt = p.gate[bh * p.N + q];
+    const bool qkeep = p.kmask[(long)b * p.Npad + q] != 0;
+    if (g == 0) p.lse2[bh * p.N + q] = log2f(fmaxf(lsum, 1e-37f));
+    const long orow = ((long)b * p.N + q) * ((long)p.H * DH) + h * DH;
+#pragma unroll
+    for (int ct = 0; ct < 4; ++ct) {
+        float v[4], vg[4];
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            v[r] = qkeep ? o[ct][r] * inv : 0.f;
+            vg[r] = v[r] * gt;
+        }
+        st<u32x2>(p.O + orow + ct * 16 + 4 * g, pack4(v));
+        st<u32x2>(p.Og + orow + ct * 16 + 4 * g, pack4(vg));
+    }
+}
+
 // dO = dOg * gate (0 on masked query rows); delta = sum_dh dO*O; dgate_pre = sum_dh dOg*O * gate*(1-gate)
 __global__ __launch_bounds__(256) void attn_bwd_prep_kernel(AttnArgs p) {
     __shared__ bf16_t tT[DH][64 + 8];
@@ -868,13 +1056,28 @@ static int attn_fwd_impl(const void* Q, const void* K, const void* VT, const uin
     a.Q = (const bf16_t*)Q; a.K = (const bf16_t*)K; a.VT = (const bf16_t*)VT; a.kmask = kmask; a.gate = gate;
     a.O = (bf16_t*)O; a.Og = (bf16_t*)Og; a.lse2 = lse2;
     a.dropbits = (unsigned long long*)dropbits;
-    a.probe = flags & 63;
+    a.probe = flags & 63;      // (bits 6.. select kernel variants, see e2k.h)
     hipStream_t st = (hipStream_t)stream;
     if (a.probe) {              // bottleneck probes (wrong results on purpose): separate instantiations
         const dim3 grid((N + 63) / 64, H, B), block(256);
         if (a.thresh && dropbits) hipLaunchKernelGGL((attn_fwd_kernel<true, true, 4, true>), grid, block, 0, st, a);
         else if (a.thresh) hipLaunchKernelGGL((attn_fwd_kernel<true, false, 4, true>), grid, block, 0, st, a);
         else hipLaunchKernelGGL((attn_fwd_kernel<false, false, 4, true>), grid, block, 0, st, a);
+    } else if (!(flags & (E2K_ATTN_WG128 | E2K_ATTN_NO_RING)) && Npad <= RKM) {
+        const dim3 grid((N + 63) / 64, H, B), block(256);
+        if (!(flags & (E2K_ATTN_RING3 | E2K_ATTN_RING4))) {
+            if (a.thresh && dropbits) hipLaunchKernelGGL((attn_fwd_ring_kernel<true, true, 2>), grid, block, 0, st, a);
+            else if (a.thresh) hipLaunchKernelGGL((attn_fwd_ring_kernel<true, false, 2>), grid, block, 0, st, a);
+            else hipLaunchKernelGGL((attn_fwd_ring_kernel<false, false, 2>), grid, block, 0, st, a);
+        } else if (flags & E2K_ATTN_RING4) {
+            if (a.thresh && dropbits) hipLaunchKernelGGL((attn_fwd_ring_kernel<true, true, 4>), grid, block, 0, st, a);
+            else if (a.thresh) hipLaunchKernelGGL((attn_fwd_ring_kernel<true, false, 4>), grid, block, 0, st, a);
+            else hipLaunchKernelGGL((attn_fwd_ring_kernel<false, false, 4>), grid, block, 0, st, a);
+        } else {
+            if (a.thresh && dropbits) hipLaunchKernelGGL((attn_fwd_ring_kernel<true, true, 3>), grid, block, 0, st, a);
+            else if (a.thresh) hipLaunchKernelGGL((attn_fwd_ring_kernel<true, false, 3>), grid, block, 0, st, a);
+            else hipLaunchKernelGGL((attn_fwd_ring_kernel<false, false, 3>), grid, block, 0, st, a);
+        }
     } else if (!(flags & E2K_ATTN_WG128)) {
         const dim3 grid((N + 63) / 64, H, B), block(256);
         if (a.thresh && dropbits) hipLaunchKernelGGL((attn_fwd_kernel<true, true, 4>), grid, block, 0, st, a);

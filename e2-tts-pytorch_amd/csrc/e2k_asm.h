@@ -125,6 +125,9 @@ __device__ __forceinline__ void barrier_raw() {
 }
 // issue priority of this wave (0..3): raised around an MFMA group so that it wins over the other wave of the SIMD,
 // which is in its load phase (cdna_hip_programming.md T5: only useful when the waves of a SIMD are in different phases)
+// lanes of a wave exchanging data through LDS: the hardware runs them in lockstep (the compiler's lgkmcnt wait orders the
+// read after the write); this only keeps the compiler from moving the accesses across.  The host model rendezvouses here.
+__device__ __forceinline__ void wave_sync() { __builtin_amdgcn_wave_barrier(); }
 template <int P> __device__ __forceinline__ void set_prio() { __builtin_amdgcn_s_setprio(P); }
 __device__ __forceinline__ void sched_fence() { __builtin_amdgcn_sched_barrier(0); }
 

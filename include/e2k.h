@@ -164,6 +164,9 @@ int e2k_attn_fwd(const void* Q, const void* K, const void* VT, const uint8_t* km
 #define E2K_ATTN_PROBE_NO_PV 8       /* no V LDS reads + second MFMAs */
 #define E2K_ATTN_PROBE_NO_LOADS 16   /* no global K / V tile loads after the first */
 #define E2K_ATTN_PROBE_NO_BARRIER 32 /* no workgroup barriers */
+#define E2K_ATTN_RING3 256           /* (forward) three / four LDS-DMA ring stages instead of two (A/B: lower occupancy, slower) */
+#define E2K_ATTN_RING4 512
+#define E2K_ATTN_NO_RING 128         /* (forward) register-staged K / V tiles instead of the LDS-DMA ring (A/B; same results) */
 #define E2K_ATTN_WG128 64            /* (both calls) 128 query rows / keys per workgroup instead of 64 (A/B; same results, not faster on MI355X) */
 /* dropbits (optional, both calls; NULL = every kernel re-derives the dropout mask from the counter hash): scratch of
  * e2k_query_attn_dropbits_bytes(B, H, N) bytes in which the forward leaves its keep decisions as 64-bit wave ballot words

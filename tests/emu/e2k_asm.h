@@ -61,6 +61,7 @@ inline float fast_rcp(float x) { return 1.0f / x; }
 template <int N> inline void wait_vmcnt() { emu::land_pending(N); }
 inline void barrier_keep_vm() { emu::block_rendezvous(); }
 inline void barrier_raw() { emu::block_rendezvous(); }
+inline void wave_sync() { (void)__shfl_xor(0, 1); }       // fibers of a wave run one after the other: a true rendezvous
 template <int P> inline void set_prio() {}
 inline void sched_fence() {}
 
