@@ -147,6 +147,8 @@ def main():
     ap.add_argument('--grad-dtype', default='bf16', choices=['fp32', 'bf16'],
                     help='element type of the gradient slabs on the xGMI links (bf16 halves the bytes: 1.45 instead of 2.9 GB per step)')
     ap.add_argument('--bucket-layers', type=int, default=1, help='layer slabs merged per all-reduce')
+    ap.add_argument('--dump-ops', default=None, help='write the per-shape launch table of the profiled plan replays (name, flops, count, '
+                    'average ms, TFLOP/s) to this JSON file')
     args = ap.parse_args()
 
     from e2_tts_pytorch_amd import E2TTS, ops
@@ -237,6 +239,19 @@ def main():
         gemm_flops = sum(f for f, _, _ in prof)
         gemm_ms = sum(e0.elapsed_time(e1) for _, e0, e1 in prof)
         n_launch = len(prof)
+
+    if args.dump_ops and prof_rows and rank == 0:
+        by = {}
+        for r in prof_rows:
+            k = (r['name'], int(r['flops']))
+            e = by.setdefault(k, [0, 0.0])
+            e[0] += 1
+            e[1] += r['ms']
+        table = [dict(name=k[0], flops=k[1], launches_per_step=c // nprof, avg_ms=round(m / c, 5), ms_per_step=round(m / nprof, 4),
+                      tflops=(round(k[1] / (m / c) / 1e9, 1) if k[1] else None)) for k, (c, m) in by.items()]
+        table.sort(key=lambda e: -e['ms_per_step'])
+        Path(args.dump_ops).parent.mkdir(parents=True, exist_ok=True)
+        json.dump(table, open(args.dump_ops, 'w'), indent=1)
 
     t = torch.tensor([dt], dtype=torch.float64, device=dev)
     if world > 1:

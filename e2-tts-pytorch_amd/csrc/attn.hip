@@ -834,6 +834,174 @@ __global__ __launch_bounds__(NW * 64, 2) void attn_bwd_dq_kernel(AttnArgs p) {
     }
 }
 
+// dQ with LDS-DMA staging and transposing LDS reads (default; the kernel above stays as the E2K_ATTN_NO_RING fallback):
+//   * K and V tiles go global -> LDS by global_load_lds into a 2-stage ring (no staging registers), the key mask of the
+//     batch row sits in LDS: the loop holds NO ordinary global load.  In the kernel above the key-mask load follows the
+//     next tile's prefetch loads in program order, and vmcnt is counted in order: its s_waitcnt vmcnt(1) / vmcnt(0) before
+//     the element-wise phase waits for the WHOLE prefetch, i.e. the HBM / L2 latency of a tile is exposed in every
+//     iteration (that, not the arithmetic, was the "dependency stall" of the round-2 ablation)
+//   * K^T for dQ^T = K^T . dS^T is read from the row-major K tile with ds_read_b64_tr_b16: the transposed copy KT in HBM
+//     is not read
+//   * one half of the key tile (32 keys) at a time from the score MFMAs to the dQ MFMAs
+// Keys past the end of the sequence are read from row N - 1 and masked through the key mask (0 past N).
+template <bool DROP, bool SHARE>
+__global__ __launch_bounds__(256, 3) void attn_bwd_dq_ring_kernel(AttnArgs p) {
+    __shared__ __attribute__((aligned(16))) unsigned char smem[2 * RSTAGE + RKM];
+    unsigned char* const kms = smem + 2 * RSTAGE;
+    const int tid = threadIdx.x, lane = tid & 63, wave = uniform_i(tid >> 6);
+    const int l15 = lane & 15, g = lane >> 4;
+    const int q0 = blockIdx.x * 64, h = blockIdx.y, b = blockIdx.z;
+    const long bh = (long)b * p.H + h;
+    const int q = q0 + wave * 16 + l15;
+    const bool qin = q < p.N;
+    const unsigned dstream = attn_stream(p.stream_id, (unsigned)bh);
+    const int ntiles = (p.N + 63) / 64;
+
+    for (int i = tid * 16; i < p.Npad; i += 256 * 16) st<u32x4>(kms + i, ld<u32x4>(p.kmask + (long)b * p.Npad + i));
+
+    bf16x8 qf[2], dof[2];
+#pragma unroll
+    for (int kk = 0; kk < 2; ++kk) {
+        qf[kk] = qin ? ld<bf16x8>(p.Q + (bh * p.N + q) * DH + kk * 32 + g * 8) : bf16x8{0, 0, 0, 0, 0, 0, 0, 0};
+        dof[kk] = qin ? ld<bf16x8>(p.dO + (bh * p.N + q) * DH + kk * 32 + g * 8) : bf16x8{0, 0, 0, 0, 0, 0, 0, 0};
+    }
+    const float kx = p.scale / CLAMP;
+    const float k2 = 2.f * LOG2E * kx, cl2 = CLAMP * LOG2E;
+    const ClampPoly cp = clamp_poly(kx, 1.f);
+    // dS = P (dP - delta) (1 - th^2) scale: the trailing `scale` is folded into the exponent of P (lse - log2(scale))
+    const float lse = qin ? p.lse2[bh * p.N + q] - log2f(p.scale) : 1e30f;
+    const float dl = qin ? p.delta[bh * p.N + q] : 0.f;
+    const unsigned hrow = rand_base(p.seed_dev ? *p.seed_dev : p.seed, dstream) + (unsigned)q * 0x85ebca77u;
+    const unsigned hlane = hrow + (unsigned)(2 * g) * 0xc2b2ae3du;
+
+    f32x4 dq[4];
+#pragma unroll
+    for (int ct = 0; ct < 4; ++ct) dq[ct] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+    // staging (as in attn_fwd_ring_kernel): wave w issues the wave instructions 2w, 2w + 1 (8 LDS rows each) of K and of V,
+    // both as tile_sstore_perm images
+    const bf16_t* Kbase = p.K + bh * p.N * DH;
+    const bf16_t* Vbase = p.V + bh * p.N * DH;
+    int srow[2];
+    unsigned scol[2];
+#pragma unroll
+    for (int u = 0; u < 2; ++u) {
+        const int r = (wave * 2 + u) * 8 + (lane >> 3), sp = lane & 7;
+        srow[u] = (r & 0x23) | ((r & 0x10) >> 2) | ((r & 0x0c) << 1);
+        scol[u] = (unsigned)((sp ^ (r & 7)) * 16);
+    }
+    auto issue = [&](int t, int stage) __attribute__((always_inline)) {
+        const int k0 = t * 64;
+        unsigned char* S = smem + stage * RSTAGE;
+#pragma unroll
+        for (int u = 0; u < 2; ++u) {
+            const long row = min(k0 + srow[u], p.N - 1);
+            glds16((const char*)Kbase + row * (DH * 2) + scol[u], S + (wave * 2 + u) * 1024);
+            glds16((const char*)Vbase + row * (DH * 2) + scol[u], S + 8192 + (wave * 2 + u) * 1024);
+        }
+    };
+    // transposing reads of K^T (see attn_bwd_dkv_ring_kernel): lane (i = l15, g) addresses key 8g + (i >> 2) (+ 4, + 32 kk2)
+    const int rho = (l15 >> 2) | ((g & 1) << 2);
+    const int troff = ((l15 >> 2) | (g << 2)) * 128 + (l15 & 1) * 8;
+    const int tslot = ((l15 & 3) >> 1) ^ (rho & 1);
+    int trc[4];
+#pragma unroll
+    for (int ct = 0; ct < 4; ++ct) trc[ct] = troff + ((((2 * ct) ^ (rho & 6)) | tslot) << 4);
+
+    __syncthreads();                 // key mask row is in LDS; every ordinary load above has been waited for
+    asm volatile("" ::"v"(qf[0]), "v"(qf[1]), "v"(dof[0]), "v"(dof[1]), "v"(lse), "v"(dl), "v"(hrow));
+    issue(0, 0);
+    for (int kt = 0; kt < ntiles; ++kt) {
+        const int k0 = kt * 64;
+        wait_vmcnt<0>();
+        barrier_raw();
+        if (kt + 1 < ntiles) issue(kt + 1, (kt + 1) & 1);
+        const unsigned char* Kt = smem + (kt & 1) * RSTAGE;
+        const unsigned char* Vr = Kt + 8192;
+        const unsigned km = mask_bits(ld<unsigned long long>(kms + k0 + g * 8)) |
+                            (mask_bits(ld<unsigned long long>(kms + k0 + 32 + g * 8)) << 8);
+        const bool allk = wave_all(km == 0xffffu);
+        const unsigned long long* dropw = (DROP && SHARE)
+            ? p.dropbits + ((((long)bh * ntiles + kt) * ntiles + blockIdx.x) * 4 + wave) * 16 : nullptr;
+#pragma unroll
+        for (int kk2 = 0; kk2 < 2; ++kk2) {
+            s16x4_ klo[4], khi[4];
+#pragma unroll
+            for (int ct = 0; ct < 4; ++ct) {
+                lds_tr_issue(klo[ct], Kt + trc[ct], kk2 * (32 * 128));
+                lds_tr_issue(khi[ct], Kt + trc[ct], kk2 * (32 * 128) + 16 * 128);
+            }
+            float dsv[2][4];
+#pragma unroll
+            for (int tt = 0; tt < 2; ++tt) {
+                const int t = 2 * kk2 + tt;
+                // s[r] <-> key perm_row(t, 4g+r), q = l&15
+                f32x4 st_ = {0.f, 0.f, 0.f, 0.f}, dpt = {0.f, 0.f, 0.f, 0.f};
+                const int row = 16 * t + l15;
+#pragma unroll
+                for (int kk = 0; kk < 2; ++kk) {
+                    bf16x8 kfr = tile_frag(Kt, row, kk * 4 + g);
+                    bf16x8 vfr = tile_frag(Vr, row, kk * 4 + g);
+                    st_ = __builtin_amdgcn_mfma_f32_16x16x32_bf16(kfr, qf[kk], st_, 0, 0, 0);
+                    dpt = __builtin_amdgcn_mfma_f32_16x16x32_bf16(vfr, dof[kk], dpt, 0, 0, 0);      // dP^T = V . dO^T
+                }
+                const float am = fmaxf(fmaxf(fabsf(st_[0]), fabsf(st_[1])), fmaxf(fabsf(st_[2]), fabsf(st_[3])));
+                const bool small = wave_all(am * kx <= TANH_POLY_MAX);
+                float ks[4] = {1.f, 1.f, 1.f, 1.f};
+                if (DROP) {
+                    if (SHARE) {             // the forward's compare masks: same lane <-> (query, key) layout as here
+#pragma unroll
+                        for (int r = 0; r < 4; ++r) ks[r] = wave_inverse_ballot(sload64(dropw + 4 * t + r)) ? p.inv_keep : 0.f;
+                    } else {
+                        unsigned w0, w1;
+                        drop4(hlane, (unsigned)(k0 >> 2) + 8 * (t >> 1) + (t & 1), w0, w1);
+                        ks[0] = (w0 & 0xffffu) >= p.thresh ? p.inv_keep : 0.f;
+                        ks[1] = (w0 >> 16) >= p.thresh ? p.inv_keep : 0.f;
+                        ks[2] = (w1 & 0xffffu) >= p.thresh ? p.inv_keep : 0.f;
+                        ks[3] = (w1 >> 16) >= p.thresh ? p.inv_keep : 0.f;
+                    }
+                }
+#pragma unroll
+                for (int r = 0; r < 4; r += 2) {
+                    f32x2_ th;
+                    if (small) th = clamp2(f32x2_{st_[r], st_[r + 1]}, cp);
+                    else th = f32x2_{clamp_tanh(st_[r], k2), clamp_tanh(st_[r + 1], k2)};
+                    const f32x2_ arg = th * cl2 - lse;
+                    const f32x2_ pv = {fast_exp2(arg[0]), fast_exp2(arg[1])};
+                    f32x2_ t1 = f32x2_{dpt[r], dpt[r + 1]};
+                    if (DROP) t1 = t1 * f32x2_{ks[r], ks[r + 1]};
+                    t1 = t1 - dl;
+                    const f32x2_ t2 = 1.f - th * th;
+                    const f32x2_ ds = (pv * t1) * t2;
+                    dsv[tt][r] = ds[0];
+                    dsv[tt][r + 1] = ds[1];
+                }
+                if (!allk) {        // masked keys contribute nothing (only the last tile or two of a sequence)
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) {
+                        const bool keep = (km >> (8 * kk2 + 4 * tt + r)) & 1u;
+                        dsv[tt][r] = keep ? dsv[tt][r] : 0.f;
+                    }
+                }
+            }
+            bf16x8 pf = pack_frag(dsv[0], dsv[1]);
+            lds_tr_wait(klo[0], khi[0], klo[1], khi[1], klo[2], khi[2], klo[3], khi[3]);
+#pragma unroll
+            for (int ct = 0; ct < 4; ++ct) {
+                bf16x8 ktf = __builtin_shufflevector(klo[ct], khi[ct], 0, 1, 2, 3, 4, 5, 6, 7);
+                dq[ct] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ktf, pf, dq[ct], 0, 0, 0);
+            }
+        }
+    }
+    if (!qin) return;
+    const long orow = (bh * p.N + q) * DH;
+#pragma unroll
+    for (int ct = 0; ct < 4; ++ct) {
+        float v[4] = {dq[ct][0], dq[ct][1], dq[ct][2], dq[ct][3]};
+        st<u32x2>(p.dQ + orow + ct * 16 + 4 * g, pack4(v));
+    }
+}
+
 // dK, dV: one workgroup per 16 NW keys (a wave owns 16), sweep over query tiles.
 //   S = Q.K^T (rows = queries, permuted inside the tile), P^T-like accumulators feed dV^T = dO^T.P and dK^T = Q^T.dS
 template <bool DROP, bool SHARE, int NW>      // SHARE: dropout keep masks are handed from the forward to the backward (p.dropbits)
@@ -897,22 +1065,6 @@ __global__ __launch_bounds__(NW * 64, 2) void attn_bwd_dkv_kernel(AttnArgs p) {
             r2 = tile_gload<NC>(QTbase + q0 + 64, p.Npad, 64, tid);
             r3 = tile_gload<NC>(dOTbase + q0 + 64, p.Npad, 64, tid);
         }
-        // s[t][r] <-> query perm_row(t, 4g+r), key = l&15
-        f32x4 s[4], dp[4];
-#pragma unroll
-        for (int t = 0; t < 4; ++t) {
-            s[t] = f32x4{0.f, 0.f, 0.f, 0.f};
-            dp[t] = f32x4{0.f, 0.f, 0.f, 0.f};
-            const int row = 16 * t + l15;        // tiles stored with tile_sstore_perm
-#pragma unroll
-            for (int kk = 0; kk < 2; ++kk) {
-                bf16x8 qfr = tile_frag(Qt, row, kk * 4 + g);
-                bf16x8 dofr = tile_frag(dOt, row, kk * 4 + g);
-                s[t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(qfr, kf[kk], s[t], 0, 0, 0);
-                dp[t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(dofr, vf[kk], dp[t], 0, 0, 0);
-            }
-        }
-        float pd[4][4], dsv[4][4];
         // Shared dropout masks: score (t, r) of this lane is (query qi = 32(t>>1) + 8g + 4(t&1) + r, key pos = 16 wave + l15).
         // In the forward that pair sat in wave qi >> 4 = 2(t>>1) + (g>>1), lane 16 g' + (qi & 15), slot 4t' + r', with
         // (t', g', r') the position of THIS key in the forward's key permutation: one 64-bit word per (t>>1) covers
@@ -927,50 +1079,66 @@ __global__ __launch_bounds__(NW * 64, 2) void attn_bwd_dkv_kernel(AttnArgs p) {
             dword[0] = base[0];
             dword[1] = base[2 * 16];
         }
-        const bool small = wave_all(abs_max16(s) * kx <= TANH_POLY_MAX);      // soft-clamp tanh, see clamp2
-#pragma unroll
-        for (int t = 0; t < 4; ++t) {
-            // the 4 queries of (t, r = 0..3) are consecutive: 32 (t>>1) + 8 g + 4 (t&1) + r -> one 16-byte LDS read each
-            const int qi0 = perm_row(t, 4 * g);
-            const f32x4 ls4 = ld<f32x4>(&lse_s[qi0]), dl4 = ld<f32x4>(&del_s[qi0]);
-            float ks[4] = {1.f, 1.f, 1.f, 1.f};
-            if (DROP) {
-#pragma unroll
-                for (int r = 0; r < 4; ++r) {
-                    if (SHARE) {         // bit of (query qi, this lane's key) in the forward's ballot words
-                        ks[r] = ((dword[t >> 1] >> (dbit0 + 4 * (t & 1) + r)) & 1ull) ? p.inv_keep : 0.f;
-                    } else {
-                        unsigned w0 = fmix32(hkey + (unsigned)(q0 + qi0 + r) * 0x85ebca77u), w1 = 0;
-                        if (key & 2) { unsigned x = w0 ^ (w0 >> 15); x *= 0x2c1b3c6du; w1 = x ^ (x >> 12); }
-                        ks[r] = drop_sample(w0, w1, key & 3) >= p.thresh ? p.inv_keep : 0.f;
-                    }
-                }
-            }
-#pragma unroll
-            for (int r = 0; r < 4; r += 2) {
-                // (no key masking here: a lane's scores all belong to ITS key, whose dK / dV row is zeroed at the end)
-                f32x2_ th;
-                if (small) th = clamp2(f32x2_{s[t][r], s[t][r + 1]}, cp);
-                else th = f32x2_{clamp_tanh(s[t][r], k2), clamp_tanh(s[t][r + 1], k2)};
-                const f32x2_ arg = th * cl2 - f32x2_{ls4[r], ls4[r + 1]};
-                const f32x2_ pr = {fast_exp2(arg[0]), fast_exp2(arg[1])};
-                const f32x2_ k2s = {ks[r], ks[r + 1]};
-                const f32x2_ pv = DROP ? pr * k2s : pr;
-                f32x2_ t1 = f32x2_{dp[t][r], dp[t][r + 1]};
-                if (DROP) t1 = t1 * k2s;
-                t1 = t1 - f32x2_{dl4[r], dl4[r + 1]};
-                const f32x2_ t2 = (th * -p.scale) * th + p.scale;        // (1 - th^2) * scale
-                const f32x2_ ds = (pr * t1) * t2;
-                pd[t][r] = pv[0];
-                pd[t][r + 1] = pv[1];
-                dsv[t][r] = ds[0];
-                dsv[t][r + 1] = ds[1];
-            }
-        }
+        // One half of the query tile (32 queries = score tiles 2 kk2, 2 kk2 + 1) at a time, from the score MFMAs to the
+        // dV / dK MFMAs: only 8 score + 8 dP accumulators and one pair of packed operands are live at once (all four
+        // score tiles first = 64 more live registers = one wave per SIMD less)
 #pragma unroll
         for (int kk2 = 0; kk2 < 2; ++kk2) {
-            bf16x8 pf = pack_frag(pd[2 * kk2], pd[2 * kk2 + 1]);
-            bf16x8 df = pack_frag(dsv[2 * kk2], dsv[2 * kk2 + 1]);
+            float pd[2][4], dsv[2][4];
+#pragma unroll
+            for (int tt = 0; tt < 2; ++tt) {
+                const int t = 2 * kk2 + tt;
+                // s[r] <-> query perm_row(t, 4g+r), key = l&15
+                f32x4 st_ = {0.f, 0.f, 0.f, 0.f}, dpt = {0.f, 0.f, 0.f, 0.f};
+                const int row = 16 * t + l15;        // tiles stored with tile_sstore_perm
+#pragma unroll
+                for (int kk = 0; kk < 2; ++kk) {
+                    bf16x8 qfr = tile_frag(Qt, row, kk * 4 + g);
+                    bf16x8 dofr = tile_frag(dOt, row, kk * 4 + g);
+                    st_ = __builtin_amdgcn_mfma_f32_16x16x32_bf16(qfr, kf[kk], st_, 0, 0, 0);
+                    dpt = __builtin_amdgcn_mfma_f32_16x16x32_bf16(dofr, vf[kk], dpt, 0, 0, 0);
+                }
+                const float am = fmaxf(fmaxf(fabsf(st_[0]), fabsf(st_[1])), fmaxf(fabsf(st_[2]), fabsf(st_[3])));
+                const bool small = wave_all(am * kx <= TANH_POLY_MAX);      // soft-clamp tanh, see clamp2
+                // the 4 queries of (t, r = 0..3) are consecutive: 32 (t>>1) + 8 g + 4 (t&1) + r -> one 16-byte LDS read each
+                const int qi0 = perm_row(t, 4 * g);
+                const f32x4 ls4 = ld<f32x4>(&lse_s[qi0]), dl4 = ld<f32x4>(&del_s[qi0]);
+                float ks[4] = {1.f, 1.f, 1.f, 1.f};
+                if (DROP) {
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) {
+                        if (SHARE) {         // bit of (query qi, this lane's key) in the forward's ballot words
+                            ks[r] = ((dword[kk2] >> (dbit0 + 4 * tt + r)) & 1ull) ? p.inv_keep : 0.f;
+                        } else {
+                            unsigned w0 = fmix32(hkey + (unsigned)(q0 + qi0 + r) * 0x85ebca77u), w1 = 0;
+                            if (key & 2) { unsigned x = w0 ^ (w0 >> 15); x *= 0x2c1b3c6du; w1 = x ^ (x >> 12); }
+                            ks[r] = drop_sample(w0, w1, key & 3) >= p.thresh ? p.inv_keep : 0.f;
+                        }
+                    }
+                }
+#pragma unroll
+                for (int r = 0; r < 4; r += 2) {
+                    // (no key masking here: a lane's scores all belong to ITS key, whose dK / dV row is zeroed at the end)
+                    f32x2_ th;
+                    if (small) th = clamp2(f32x2_{st_[r], st_[r + 1]}, cp);
+                    else th = f32x2_{clamp_tanh(st_[r], k2), clamp_tanh(st_[r + 1], k2)};
+                    const f32x2_ arg = th * cl2 - f32x2_{ls4[r], ls4[r + 1]};
+                    const f32x2_ pr = {fast_exp2(arg[0]), fast_exp2(arg[1])};
+                    const f32x2_ k2s = {ks[r], ks[r + 1]};
+                    const f32x2_ pv = DROP ? pr * k2s : pr;
+                    f32x2_ t1 = f32x2_{dpt[r], dpt[r + 1]};
+                    if (DROP) t1 = t1 * k2s;
+                    t1 = t1 - f32x2_{dl4[r], dl4[r + 1]};
+                    const f32x2_ t2 = (th * -p.scale) * th + p.scale;        // (1 - th^2) * scale
+                    const f32x2_ ds = (pr * t1) * t2;
+                    pd[tt][r] = pv[0];
+                    pd[tt][r + 1] = pv[1];
+                    dsv[tt][r] = ds[0];
+                    dsv[tt][r + 1] = ds[1];
+                }
+            }
+            bf16x8 pf = pack_frag(pd[0], pd[1]);
+            bf16x8 df = pack_frag(dsv[0], dsv[1]);
 #pragma unroll
             for (int ct = 0; ct < 4; ++ct) {
                 bf16x8 dotf = tile_frag(dOTt, ct * 16 + l15, kk2 * 4 + g);
@@ -980,6 +1148,207 @@ __global__ __launch_bounds__(NW * 64, 2) void attn_bwd_dkv_kernel(AttnArgs p) {
             }
         }
         __syncthreads();
+    }
+    if (!kin) return;
+    const long orow = (bh * p.N + key) * DH;
+#pragma unroll
+    for (int ct = 0; ct < 4; ++ct) {
+        float a[4], c[4];
+#pragma unroll
+        for (int r = 0; r < 4; ++r) { a[r] = kkeep ? dk[ct][r] : 0.f; c[r] = kkeep ? dv[ct][r] : 0.f; }
+        st<u32x2>(p.dK + orow + ct * 16 + 4 * g, pack4(a));
+        st<u32x2>(p.dV + orow + ct * 16 + 4 * g, pack4(c));
+    }
+}
+
+
+// dK, dV with LDS-DMA staging and transposing LDS reads (default): the same arithmetic as attn_bwd_dkv_kernel<.., 4>, but
+//   * the Q and dO tiles (and the 64 lse / delta values that go with them) go global -> LDS by global_load_lds into a
+//     2-stage ring: no staging registers (the register-staged kernel holds four 64x64 tiles = 32 VGPRs across the compute
+//     phase), which is what brings the kernel under 168 VGPRs = three waves per SIMD instead of two
+//   * the A operands of the dV^T = dO^T.P and dK^T = Q^T.dS MFMAs (dO^T, Q^T: dh rows, 8 consecutive queries per lane)
+//     are read from the SAME row-major tiles with ds_read_b64_tr_b16: the transposed copies QT / dOT in HBM are not read
+//     (half the LDS footprint and half the tile traffic)
+// Rows past the end of the sequence are read from row N - 1 and switched off through lse = 1e30 (p = exp2(-1e30) = 0).
+constexpr int DSTAGE = 2 * 8192 + 512;
+
+template <bool DROP, bool SHARE>
+__global__ __launch_bounds__(256, 3) void attn_bwd_dkv_ring_kernel(AttnArgs p) {
+    __shared__ __attribute__((aligned(16))) unsigned char smem[2 * DSTAGE];
+    const int tid = threadIdx.x, lane = tid & 63, wave = uniform_i(tid >> 6);
+    const int l15 = lane & 15, g = lane >> 4;
+    const int k0 = blockIdx.x * 64, h = blockIdx.y, b = blockIdx.z;
+    const int kt64 = blockIdx.x;
+    const long bh = (long)b * p.H + h;
+    const int key = k0 + wave * 16 + l15;
+    const bool kin = key < p.N;
+    const int kkeep = kin && p.kmask[(long)b * p.Npad + key] != 0;
+    const unsigned dstream = attn_stream(p.stream_id, (unsigned)bh);
+
+    bf16x8 kf[2], vf[2];
+#pragma unroll
+    for (int kk = 0; kk < 2; ++kk) {
+        kf[kk] = kin ? ld<bf16x8>(p.K + (bh * p.N + key) * DH + kk * 32 + g * 8) : bf16x8{0, 0, 0, 0, 0, 0, 0, 0};
+        vf[kk] = kin ? ld<bf16x8>(p.V + (bh * p.N + key) * DH + kk * 32 + g * 8) : bf16x8{0, 0, 0, 0, 0, 0, 0, 0};
+    }
+    f32x4 dk[4], dv[4];
+#pragma unroll
+    for (int ct = 0; ct < 4; ++ct) { dk[ct] = f32x4{0.f, 0.f, 0.f, 0.f}; dv[ct] = f32x4{0.f, 0.f, 0.f, 0.f}; }
+    const float kx = p.scale / CLAMP;
+    const float k2 = 2.f * LOG2E * kx, cl2 = CLAMP * LOG2E;
+    const ClampPoly cp = clamp_poly(kx, 1.f);
+    const unsigned hkey = rand_base(p.seed_dev ? *p.seed_dev : p.seed, dstream) + ((unsigned)key >> 2) * 0xc2b2ae3du;
+
+    const int ntiles = (p.N + 63) / 64;
+    const bf16_t* Qbase = p.Q + bh * p.N * DH;
+    const bf16_t* dObase = p.dO + bh * p.N * DH;
+    const float* lsebase = p.lse2 + bh * p.N;
+    const float* delbase = p.delta + bh * p.N;
+
+    // staging: a [64][64] bf16 tile = 8 wave instructions of 8 LDS rows; wave w issues instructions 2w, 2w + 1 of Q and dO
+    // (LDS image of tile_sstore_perm: tile row R at LDS row perm_inv(R), 16-byte slots XOR-swizzled by row & 7), wave 0
+    // the 64 lse values, wave 1 the 64 delta values
+    int srow[2];
+    unsigned scol[2];
+#pragma unroll
+    for (int u = 0; u < 2; ++u) {
+        const int r = (wave * 2 + u) * 8 + (lane >> 3), sp = lane & 7;
+        srow[u] = (r & 0x23) | ((r & 0x10) >> 2) | ((r & 0x0c) << 1);
+        scol[u] = (unsigned)((sp ^ (r & 7)) * 16);
+    }
+    auto issue = [&](int t, int stage) __attribute__((always_inline)) {
+        const int q0 = t * 64;
+        unsigned char* S = smem + stage * DSTAGE;
+#pragma unroll
+        for (int u = 0; u < 2; ++u) {
+            const long row = min(q0 + srow[u], p.N - 1);
+            glds16((const char*)Qbase + row * (DH * 2) + scol[u], S + (wave * 2 + u) * 1024);
+            glds16((const char*)dObase + row * (DH * 2) + scol[u], S + 8192 + (wave * 2 + u) * 1024);
+        }
+        if (wave < 2) glds4((wave == 0 ? lsebase : delbase) + min(q0 + lane, p.N - 1), S + 16384 + wave * 256);
+    };
+    // transposing reads: lane (i = l15, g) addresses query 8g + (i >> 2) (+ 4, + 32 kk2) = LDS row (i >> 2) | g << 2
+    // (| 16, | 32 kk2), columns 16 ct + 4 (i & 3) ..; it receives column 16 ct + i of queries 8g .. 8g + 3 (+ 4)
+    const int rho = (l15 >> 2) | ((g & 1) << 2);                  // LDS row & 7
+    const int troff = ((l15 >> 2) | (g << 2)) * 128 + (l15 & 1) * 8;
+    const int tslot = ((l15 & 3) >> 1) ^ (rho & 1);
+    int trc[4];                   // per 16-column group ct: byte offset of this lane's 8 bytes inside the tile
+#pragma unroll
+    for (int ct = 0; ct < 4; ++ct) trc[ct] = troff + ((((2 * ct) ^ (rho & 6)) | tslot) << 4);
+    // (lds_tr_issue, not the builtin: see e2k_asm.h -- the builtin would drain the LDS-DMA queue in every iteration)
+    auto tr_issue4 = [&](s16x4_ (&lo)[4], s16x4_ (&hi)[4], const unsigned char* T, int kk2) __attribute__((always_inline)) {
+#pragma unroll
+        for (int ct = 0; ct < 4; ++ct) {
+            lds_tr_issue(lo[ct], T + trc[ct], kk2 * (32 * 128));
+            lds_tr_issue(hi[ct], T + trc[ct], kk2 * (32 * 128) + 16 * 128);
+        }
+    };
+    // Shared dropout masks: score (t, r) of this lane is (query qi = 32(t>>1) + 8g + 4(t&1) + r, key pos = 16 wave + l15).
+    // In the forward that pair sat in wave qi >> 4 = 2(t>>1) + (g>>1), lane 16 g' + (qi & 15), slot 4t' + r', with
+    // (t', g', r') the position of THIS key in the forward's key permutation: one 64-bit word per (t>>1) covers
+    // all eight (t&1, r) of it.  The words of tile qt + 1 are fetched while tile qt is computed.
+    const int pos = wave * 16 + l15;
+    const int dbit0 = 16 * ((pos >> 3) & 3) + 8 * (g & 1);
+    const unsigned long long* dbase = nullptr;
+    unsigned long long dnext[2] = {0ull, 0ull};
+    if (DROP && SHARE) {
+        const int tf = 2 * (pos >> 5) + ((pos >> 2) & 1), rf = pos & 3;
+        dbase = p.dropbits + ((((long)bh * ntiles + kt64) * ntiles) * 4 + (g >> 1)) * 16 + 4 * tf + rf;
+        dnext[0] = dbase[0];
+        dnext[1] = dbase[2 * 16];
+    }
+    // every ordinary global load of the prologue is waited for BEFORE the first LDS-DMA (see attn_fwd_ring_kernel)
+    asm volatile("" ::"v"(kf[0]), "v"(kf[1]), "v"(vf[0]), "v"(vf[1]), "v"(hkey), "v"(kkeep));
+    issue(0, 0);
+    for (int qt = 0; qt < ntiles; ++qt) {
+        const int q0 = qt * 64;
+        wait_vmcnt<0>();                 // tile qt has landed for this wave ...
+        barrier_raw();                   // ... and for every wave; everyone has finished tile qt - 1
+        const unsigned long long dword[2] = {dnext[0], dnext[1]};
+        if (qt + 1 < ntiles) {
+            if (DROP && SHARE) {
+                dnext[0] = dbase[(long)(qt + 1) * 64];
+                dnext[1] = dbase[(long)(qt + 1) * 64 + 2 * 16];
+            }
+            issue(qt + 1, (qt + 1) & 1);
+        }
+        const unsigned char* Qt = smem + (qt & 1) * DSTAGE;
+        const unsigned char* dOt = Qt + 8192;
+        const float* lse_s = (const float*)(Qt + 16384);
+        const float* del_s = lse_s + 64;
+        const bool tail = q0 + 64 > p.N;
+#pragma unroll
+        for (int kk2 = 0; kk2 < 2; ++kk2) {
+            float pd[2][4], dsv[2][4];
+#pragma unroll
+            for (int tt = 0; tt < 2; ++tt) {
+                const int t = 2 * kk2 + tt;
+                f32x4 st_ = {0.f, 0.f, 0.f, 0.f}, dpt = {0.f, 0.f, 0.f, 0.f};
+                const int row = 16 * t + l15;
+#pragma unroll
+                for (int kk = 0; kk < 2; ++kk) {
+                    bf16x8 qfr = tile_frag(Qt, row, kk * 4 + g);
+                    bf16x8 dofr = tile_frag(dOt, row, kk * 4 + g);
+                    st_ = __builtin_amdgcn_mfma_f32_16x16x32_bf16(qfr, kf[kk], st_, 0, 0, 0);
+                    dpt = __builtin_amdgcn_mfma_f32_16x16x32_bf16(dofr, vf[kk], dpt, 0, 0, 0);
+                }
+                const float am = fmaxf(fmaxf(fabsf(st_[0]), fabsf(st_[1])), fmaxf(fabsf(st_[2]), fabsf(st_[3])));
+                const bool small = wave_all(am * kx <= TANH_POLY_MAX);
+                const int qi0 = perm_row(t, 4 * g);
+                f32x4 ls4 = ld<f32x4>(&lse_s[qi0]);
+                const f32x4 dl4 = ld<f32x4>(&del_s[qi0]);
+                if (tail) {
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) ls4[r] = q0 + qi0 + r < p.N ? ls4[r] : 1e30f;
+                }
+                float ks[4] = {1.f, 1.f, 1.f, 1.f};
+                if (DROP) {
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) {
+                        if (SHARE) {
+                            ks[r] = ((dword[kk2] >> (dbit0 + 4 * tt + r)) & 1ull) ? p.inv_keep : 0.f;
+                        } else {
+                            unsigned w0 = fmix32(hkey + (unsigned)(q0 + qi0 + r) * 0x85ebca77u), w1 = 0;
+                            if (key & 2) { unsigned x = w0 ^ (w0 >> 15); x *= 0x2c1b3c6du; w1 = x ^ (x >> 12); }
+                            ks[r] = drop_sample(w0, w1, key & 3) >= p.thresh ? p.inv_keep : 0.f;
+                        }
+                    }
+                }
+#pragma unroll
+                for (int r = 0; r < 4; r += 2) {
+                    f32x2_ th;
+                    if (small) th = clamp2(f32x2_{st_[r], st_[r + 1]}, cp);
+                    else th = f32x2_{clamp_tanh(st_[r], k2), clamp_tanh(st_[r + 1], k2)};
+                    const f32x2_ arg = th * cl2 - f32x2_{ls4[r], ls4[r + 1]};
+                    const f32x2_ pr = {fast_exp2(arg[0]), fast_exp2(arg[1])};
+                    const f32x2_ k2s = {ks[r], ks[r + 1]};
+                    const f32x2_ pv = DROP ? pr * k2s : pr;
+                    f32x2_ t1 = f32x2_{dpt[r], dpt[r + 1]};
+                    if (DROP) t1 = t1 * k2s;
+                    t1 = t1 - f32x2_{dl4[r], dl4[r + 1]};
+                    const f32x2_ t2 = (th * -p.scale) * th + p.scale;
+                    const f32x2_ ds = (pr * t1) * t2;
+                    pd[tt][r] = pv[0];
+                    pd[tt][r + 1] = pv[1];
+                    dsv[tt][r] = ds[0];
+                    dsv[tt][r + 1] = ds[1];
+                }
+            }
+            bf16x8 pf = pack_frag(pd[0], pd[1]);
+            bf16x8 df = pack_frag(dsv[0], dsv[1]);
+            s16x4_ dlo[4], dhi[4], qlo[4], qhi[4];
+            tr_issue4(dlo, dhi, dOt, kk2);
+            tr_issue4(qlo, qhi, Qt, kk2);
+            lds_tr_wait(dlo[0], dhi[0], dlo[1], dhi[1], dlo[2], dhi[2], dlo[3], dhi[3],
+                        qlo[0], qhi[0], qlo[1], qhi[1], qlo[2], qhi[2], qlo[3], qhi[3]);
+#pragma unroll
+            for (int ct = 0; ct < 4; ++ct) {
+                bf16x8 dotf = __builtin_shufflevector(dlo[ct], dhi[ct], 0, 1, 2, 3, 4, 5, 6, 7);
+                bf16x8 qtf = __builtin_shufflevector(qlo[ct], qhi[ct], 0, 1, 2, 3, 4, 5, 6, 7);
+                dv[ct] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(dotf, pf, dv[ct], 0, 0, 0);
+                dk[ct] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(qtf, df, dk[ct], 0, 0, 0);
+            }
+        }
     }
     if (!kin) return;
     const long orow = (bh * p.N + key) * DH;
@@ -1115,11 +1484,19 @@ static int attn_bwd_impl(const void* dOg, const void* O, const float* gate, cons
     E2K_CHECK_LAUNCH();
     if (!(flags & E2K_ATTN_WG128)) {
         const dim3 grid((N + 63) / 64, H, B), block(256);
-        if (a.thresh && dropbits) hipLaunchKernelGGL((attn_bwd_dq_kernel<true, true, 4>), grid, block, 0, st, a);
+        if (!(flags & E2K_ATTN_NO_RING) && Npad <= RKM) {
+            if (a.thresh && dropbits) hipLaunchKernelGGL((attn_bwd_dq_ring_kernel<true, true>), grid, block, 0, st, a);
+            else if (a.thresh) hipLaunchKernelGGL((attn_bwd_dq_ring_kernel<true, false>), grid, block, 0, st, a);
+            else hipLaunchKernelGGL((attn_bwd_dq_ring_kernel<false, false>), grid, block, 0, st, a);
+        } else if (a.thresh && dropbits) hipLaunchKernelGGL((attn_bwd_dq_kernel<true, true, 4>), grid, block, 0, st, a);
         else if (a.thresh) hipLaunchKernelGGL((attn_bwd_dq_kernel<true, false, 4>), grid, block, 0, st, a);
         else hipLaunchKernelGGL((attn_bwd_dq_kernel<false, false, 4>), grid, block, 0, st, a);
         E2K_CHECK_LAUNCH();
-        if (a.thresh && dropbits) hipLaunchKernelGGL((attn_bwd_dkv_kernel<true, true, 4>), grid, block, 0, st, a);
+        if (!(flags & E2K_ATTN_NO_RING)) {
+            if (a.thresh && dropbits) hipLaunchKernelGGL((attn_bwd_dkv_ring_kernel<true, true>), grid, block, 0, st, a);
+            else if (a.thresh) hipLaunchKernelGGL((attn_bwd_dkv_ring_kernel<true, false>), grid, block, 0, st, a);
+            else hipLaunchKernelGGL((attn_bwd_dkv_ring_kernel<false, false>), grid, block, 0, st, a);
+        } else if (a.thresh && dropbits) hipLaunchKernelGGL((attn_bwd_dkv_kernel<true, true, 4>), grid, block, 0, st, a);
         else if (a.thresh) hipLaunchKernelGGL((attn_bwd_dkv_kernel<true, false, 4>), grid, block, 0, st, a);
         else hipLaunchKernelGGL((attn_bwd_dkv_kernel<false, false, 4>), grid, block, 0, st, a);
     } else {

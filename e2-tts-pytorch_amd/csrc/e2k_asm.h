@@ -15,6 +15,25 @@ __device__ __forceinline__ s16x4_ lds_read_tr16_b64(const void* lds_ptr) {
     return __builtin_amdgcn_ds_read_tr16_b64_v4i16((lp_t)(lds_ptr));
 }
 
+// The same instruction through inline assembly, for kernels that prefetch with global_load_lds.  The builtin above carries
+// no information about WHICH LDS bytes it reads, so the compiler orders it after every LDS-DMA in flight: it puts an
+// s_waitcnt vmcnt(0) in front of each group of transposing reads, which drains the prefetch queue once per phase (seen in
+// the ISA of the round-2 gemm_tn_256_kernel: five vmcnt(0) per loop iteration next to the hand-counted waits).  This form
+// is opaque to the compiler: the caller orders it against the DMA exactly like the ordinary ds_reads (counted wait_vmcnt +
+// barrier), and calls lds_tr_wait(regs...) before the first use of the results (s_waitcnt lgkmcnt(0); the empty
+// assembly statements tie the result registers to the wait so that no consumer is scheduled above it).
+// imm_off: byte offset that is a compile-time constant after unrolling (DS offset field, < 65536).
+__device__ __forceinline__ void lds_tr_issue(s16x4_& dst, const void* lds_ptr, int imm_off) {
+    typedef const __attribute__((address_space(3))) void* lp_t;
+    const unsigned a = (unsigned)(unsigned long long)(lp_t)(lds_ptr);
+    asm volatile("ds_read_b64_tr_b16 %0, %1 offset:%2" : "=v"(dst) : "v"(a), "n"(imm_off) : "memory");
+}
+template <class T> __device__ __forceinline__ void lds_tie(T& r) { asm volatile("" : "+v"(r)); }
+template <class... T> __device__ __forceinline__ void lds_tr_wait(T&... r) {
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    (lds_tie(r), ...);
+}
+
 // raw v_exp_f32 (2^x, no denormal fix-up: results below 2^-126 flush to 0) and v_rcp_f32 (1 ulp)
 __device__ __forceinline__ float fast_exp2(float x) { return __builtin_amdgcn_exp2f(x); }
 __device__ __forceinline__ float fast_rcp(float x) { return __builtin_amdgcn_rcpf(x); }
@@ -138,6 +157,12 @@ __device__ __forceinline__ void glds16(const void* gsrc, void* lds_base) {
     typedef __attribute__((address_space(1))) void* gp_t;
     typedef __attribute__((address_space(3))) void* lp_t;
     __builtin_amdgcn_global_load_lds((gp_t)(gsrc), (lp_t)(lds_base), 16, 0, 0);
+}
+// global_load_lds_dword: 4 bytes per lane, lane l lands at lds_base + 4*l
+__device__ __forceinline__ void glds4(const void* gsrc, void* lds_base) {
+    typedef __attribute__((address_space(1))) void* gp_t;
+    typedef __attribute__((address_space(3))) void* lp_t;
+    __builtin_amdgcn_global_load_lds((gp_t)(gsrc), (lp_t)(lds_base), 4, 0, 0);
 }
 
 }  // namespace e2k

@@ -842,15 +842,22 @@ __global__ __launch_bounds__(256, 2) void gemm_tn_glds_kernel(TNArgs p) {
 #pragma unroll
         for (int kk = 0; kk < 2; ++kk) {
             bf16x8 fx[4], fy[4];
+            s16x4_ xl[4], xh[4], yl[4], yh[4];
+            // (lds_tr_issue, not the builtin: the builtin makes the compiler drain the LDS-DMA prefetch of the next step
+            // in front of every group of reads, see e2k_asm.h)
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                lds_tr_issue(xl[i], Bt + offx[i], kk * 32 * 256);
+                lds_tr_issue(xh[i], Bt + offx[i], (kk * 32 + 16) * 256);
+                lds_tr_issue(yl[i], At + offy[i], kk * 32 * 256);
+                lds_tr_issue(yh[i], At + offy[i], (kk * 32 + 16) * 256);
+            }
+            lds_tr_wait(xl[0], xh[0], xl[1], xh[1], xl[2], xh[2], xl[3], xh[3], yl[0], yh[0], yl[1], yh[1], yl[2], yh[2], yl[3], yh[3]);
 #pragma unroll
             for (int i = 0; i < 4; ++i) {
                 // (concatenated with a shuffle: the two 64-bit results become one 128-bit register tuple without moves)
-                s16x4_ lo = lds_read_tr16_b64(Bt + kk * 32 * 256 + offx[i]);
-                s16x4_ hi = lds_read_tr16_b64(Bt + (kk * 32 + 16) * 256 + offx[i]);
-                fx[i] = __builtin_shufflevector(lo, hi, 0, 1, 2, 3, 4, 5, 6, 7);
-                s16x4_ lo2 = lds_read_tr16_b64(At + kk * 32 * 256 + offy[i]);
-                s16x4_ hi2 = lds_read_tr16_b64(At + (kk * 32 + 16) * 256 + offy[i]);
-                fy[i] = __builtin_shufflevector(lo2, hi2, 0, 1, 2, 3, 4, 5, 6, 7);
+                fx[i] = __builtin_shufflevector(xl[i], xh[i], 0, 1, 2, 3, 4, 5, 6, 7);
+                fy[i] = __builtin_shufflevector(yl[i], yh[i], 0, 1, 2, 3, 4, 5, 6, 7);
             }
 #pragma unroll
             for (int i = 0; i < 4; ++i)
@@ -967,7 +974,8 @@ __global__ __launch_bounds__(T2THREADS, 1) void gemm_tn_256_kernel(TNArgs p) {
             for (int i = 0; i < 4; ++i)
 #pragma unroll
                 for (int j = 0; j < 2; ++j) acc[a][b][i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
-    bf16x8 ar[2][4], blo[2][2], bhi[2][2];
+    // fragments as pairs of 64-bit halves (rows 0-15 / 16-31 of a 32-row reduction slice), joined at the MFMA
+    s16x4_ ar[2][4][2], blo[2][2][2], bhi[2][2][2];
     // column sums of A (bias gradient of the same dY) ride along in the k-tile-0 workgroups: wave (wr, wc) takes the
     // 16-column group i = wc of its 64 columns, one extra MFMA per A half and 32 rows with an all-ones operand
     const bool do_cs = CS && tile_k == 0 && n0 + T2 > p.cs_from;          // wave-uniform
@@ -975,25 +983,40 @@ __global__ __launch_bounds__(T2THREADS, 1) void gemm_tn_256_kernel(TNArgs p) {
     const short one = 0x3F80;
     const bf16x8 ones = bf16x8{one, one, one, one, one, one, one, one};
 
-    auto frag = [&](const unsigned char* T, int kk, int off) __attribute__((always_inline)) -> bf16x8 {
-        s16x4_ lo = lds_read_tr16_b64(T + kk * 32 * 256 + off);
-        s16x4_ hi = lds_read_tr16_b64(T + (kk * 32 + 16) * 256 + off);
-        return __builtin_shufflevector(lo, hi, 0, 1, 2, 3, 4, 5, 6, 7);
-    };
+    // Transposing reads go through lds_tr_issue (inline assembly), not the builtin: the compiler cannot tell which LDS
+    // bytes the builtin reads and put an s_waitcnt vmcnt(0) in front of every read group -- five drains of the LDS-DMA
+    // prefetch queue per iteration, next to the counted waits of the schedule (e2k_asm.h).  The reads of a phase are
+    // issued before its barrier and waited for (lgkmcnt(0)) right before its MFMAs.
     auto read_a = [&](const unsigned char* S) __attribute__((always_inline)) {
 #pragma unroll
         for (int kk = 0; kk < 2; ++kk)
 #pragma unroll
-            for (int i = 0; i < 4; ++i) ar[kk][i] = frag(S, kk, offa[i]);
+            for (int i = 0; i < 4; ++i) {
+                lds_tr_issue(ar[kk][i][0], S + offa[i], kk * 32 * 256);
+                lds_tr_issue(ar[kk][i][1], S + offa[i], (kk * 32 + 16) * 256);
+            }
     };
-    auto read_b = [&](bf16x8 (&b)[2][2], const unsigned char* S) __attribute__((always_inline)) {
+    auto read_b = [&](s16x4_ (&b)[2][2][2], const unsigned char* S) __attribute__((always_inline)) {
 #pragma unroll
         for (int kk = 0; kk < 2; ++kk)
 #pragma unroll
-            for (int j = 0; j < 2; ++j) b[kk][j] = frag(S, kk, offb[j]);
+            for (int j = 0; j < 2; ++j) {
+                lds_tr_issue(b[kk][j][0], S + offb[j], kk * 32 * 256);
+                lds_tr_issue(b[kk][j][1], S + offb[j], (kk * 32 + 16) * 256);
+            }
+    };
+    auto landed_a = [&]() __attribute__((always_inline)) {
+        lds_tr_wait(ar[0][0][0], ar[0][0][1], ar[0][1][0], ar[0][1][1], ar[0][2][0], ar[0][2][1], ar[0][3][0], ar[0][3][1],
+                    ar[1][0][0], ar[1][0][1], ar[1][1][0], ar[1][1][1], ar[1][2][0], ar[1][2][1], ar[1][3][0], ar[1][3][1]);
+    };
+    auto landed_b = [&](s16x4_ (&b)[2][2][2]) __attribute__((always_inline)) {
+        lds_tr_wait(b[0][0][0], b[0][0][1], b[0][1][0], b[0][1][1], b[1][0][0], b[1][0][1], b[1][1][0], b[1][1][1]);
+    };
+    auto join = [](const s16x4_ (&h)[2]) __attribute__((always_inline)) -> bf16x8 {
+        return __builtin_shufflevector(h[0], h[1], 0, 1, 2, 3, 4, 5, 6, 7);
     };
     // acc[i][j]: C[n = n0 + a*128 + wr*64 + i*16 + q][k = k0 + b*128 + wc*32 + j*16 + 4g + r]
-    auto mma = [&](f32x4 (&c)[4][2], const bf16x8 (&b)[2][2]) __attribute__((always_inline)) {
+    auto mma = [&](f32x4 (&c)[4][2], const s16x4_ (&b)[2][2][2]) __attribute__((always_inline)) {
         set_prio<1>();
 #pragma unroll
         for (int kk = 0; kk < 2; ++kk)
@@ -1001,17 +1024,17 @@ __global__ __launch_bounds__(T2THREADS, 1) void gemm_tn_256_kernel(TNArgs p) {
             for (int i = 0; i < 4; ++i)
 #pragma unroll
                 for (int j = 0; j < 2; ++j)
-                    c[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(b[kk][j], ar[kk][i], c[i][j], 0, 0, 0);
+                    c[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(join(b[kk][j]), join(ar[kk][i]), c[i][j], 0, 0, 0);
         set_prio<0>();
     };
     auto colsum_mma = [&](int a) __attribute__((always_inline)) {
         if (!do_cs) return;
         bf16x8 f0, f1;                                        // this wave's group i = wc of the A half it has just read
         switch (wc) {
-            case 0: f0 = ar[0][0]; f1 = ar[1][0]; break;
-            case 1: f0 = ar[0][1]; f1 = ar[1][1]; break;
-            case 2: f0 = ar[0][2]; f1 = ar[1][2]; break;
-            default: f0 = ar[0][3]; f1 = ar[1][3]; break;
+            case 0: f0 = join(ar[0][0]); f1 = join(ar[1][0]); break;
+            case 1: f0 = join(ar[0][1]); f1 = join(ar[1][1]); break;
+            case 2: f0 = join(ar[0][2]); f1 = join(ar[1][2]); break;
+            default: f0 = join(ar[0][3]); f1 = join(ar[1][3]); break;
         }
         cs[a] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ones, f0, cs[a], 0, 0, 0);
         cs[a] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ones, f1, cs[a], 0, 0, 0);
@@ -1035,6 +1058,8 @@ __global__ __launch_bounds__(T2THREADS, 1) void gemm_tn_256_kernel(TNArgs p) {
             wait_landed(left);
             stage_b(t + 1, 1);
             barrier_raw();
+            landed_b(blo);
+            landed_a();
             mma(acc[0][0], blo);
             colsum_mma(0);
             barrier_raw();
@@ -1043,6 +1068,7 @@ __global__ __launch_bounds__(T2THREADS, 1) void gemm_tn_256_kernel(TNArgs p) {
             wait_landed(left - 1);
             stage_a(t + 1, 1);
             barrier_raw();
+            landed_b(bhi);
             mma(acc[0][1], bhi);
             barrier_raw();
             // phase 3
@@ -1050,6 +1076,7 @@ __global__ __launch_bounds__(T2THREADS, 1) void gemm_tn_256_kernel(TNArgs p) {
             wait_landed(left - 2);
             stage_a(t + 2, 0);
             barrier_raw();
+            landed_a();
             mma(acc[1][1], bhi);
             colsum_mma(1);
             barrier_raw();
@@ -1160,10 +1187,12 @@ bool tn_use_256(int M, int N, int K, int use_tr) {
     if (use_tr < 1 || (M % TBM) != 0 || N < 8 || K < 8) return false;
     if (use_tr == 3) return true;
     if (use_tr == 2) return false;
-    // measured on MI355X (profiles/r02_tn_ab.json, cfg3 shapes): the 256 x 256 kernel wins where both output dimensions
-    // reach 1024 and the product is large -- 8448 x 8192 x 1024: 932 vs 780 TFLOP/s, 33792 x 1024 x 1024: 825 vs 732,
-    // 8448 x 3104 x 1024: 652 vs 620, 8448 x 1024 x 4096: 807 vs 801 -- and loses on narrow (512) or small outputs
-    return N >= 1024 && K >= 1024 && (double)M * N * K >= 2e10;
+    // measured on MI355X (profiles/r02_tn_ab.json, cfg3 shapes, 256 x 256 vs 128 x 128 in TFLOP/s): the large tile wins on
+    // very wide outputs (8448 x 8192 x 1024: 965 vs 912) and on long token counts, where it halves the number of partial
+    // tiles (33792 x 1024 x 1024: 853 vs 659; 33792 x 1024 x 512: 554 vs 537); it loses in between (8448 x 1024 x 4096:
+    // 825 vs 858, 8448 x 3104 x 1024: 700 vs 754) and on narrow outputs (33792 x 512 x 512: 373 vs 383)
+    const long nk = (long)N * K;
+    return N >= 512 && K >= 512 && (nk >= 6l << 20 || (M >= 16384 && nk >= 512l << 10));
 }
 
 }  // namespace

@@ -608,6 +608,12 @@ class Transformer(Module):
             self._drop_plans()
         return self
 
+    def _side_stream(self, dev):
+        ss = self.__dict__.get('_side')
+        if ss is None:
+            ss = self.__dict__['_side'] = torch.cuda.Stream(device=dev)
+        return ss
+
     def _drop_plans(self):
         lib = None
         for st in self._plans.values():
@@ -807,13 +813,30 @@ class Transformer(Module):
         run.attn0 = {'x': None, 't': None}
         skips = []
 
+        dual = _DUAL_STREAM and dev.type == 'cuda' and exists(st) and not self._plans_on
+        if dual:
+            side = self._side_stream(dev)
+            ev_main, ev_side = torch.cuda.Event(), torch.cuda.Event()
+            ev_main.record(torch.cuda.current_stream(dev))
         for r in self._recs:
             ind = r.index
             if exists(tape):
                 tape.append(('layer', r))
             if exists(st) and exists(r.t):
-                self._branches(run, st, r.t, ind, text=True)
-                self._cross(run, sx, st, r.t)
+                if dual:
+                    # EXPERIMENT (E2K_DUAL_STREAM, eager mode): the text branches of layer i only need the text stream as
+                    # the cross projection of layer i - 1 left it: they run on a side stream next to the audio branches
+                    # of layer i - 1
+                    side.wait_event(ev_main)
+                    with torch.cuda.stream(side), ops.pinned_stream(dev):
+                        self._branches(run, st, r.t, ind, text=True)
+                    ev_side.record(side)
+                    torch.cuda.current_stream(dev).wait_event(ev_side)
+                    self._cross(run, sx, st, r.t)
+                    ev_main.record(torch.cuda.current_stream(dev))
+                else:
+                    self._branches(run, st, r.t, ind, text=True)
+                    self._cross(run, sx, st, r.t)
             if ind < L // 2:
                 self._materialize(run, sx)
                 skips.append(sx.X)
@@ -1036,7 +1059,7 @@ class Transformer(Module):
                    't': ops.zeros((B, self.text_heads, N, 64), f32, dev) if run.has_text else None}
         skip_grads = []
 
-        for ent in reversed(run.tape):
+        def entry(ent):
             kind = ent[0]
             if kind == 'hc':
                 _, rec, key = ent
@@ -1091,11 +1114,38 @@ class Transformer(Module):
                 gsrc, WTs = skip_grads.pop()
                 gx = grads['x'].view(-1, D)
                 grads['x'] = ops.gemm_nt(gsrc, WTs, resid=gx).view(Mtok, 4, D)
-            elif kind == 'layer':
-                yield ent[1].start, ent[1].end
             else:
                 raise AssertionError(kind)
 
+        dual = _DUAL_STREAM and dev.type == 'cuda' and run.has_text and not self._plans_on
+        if dual:
+            side = self._side_stream(dev)
+            ev_main, ev_side = torch.cuda.Event(), torch.cuda.Event()
+            ev_main.record(torch.cuda.current_stream(dev))
+            ev_side.record(side)
+        for ent in reversed(run.tape):
+            kind = ent[0]
+            if dual:
+                is_text = (kind in ('hc', 'mat') and ent[2] == 't') or (kind == 'conv' and ent[5] == 't') or \
+                          (kind in ('attn', 'ff') and ent[4])
+                if is_text:
+                    side.wait_event(ev_main)
+                    with torch.cuda.stream(side), ops.pinned_stream(dev):
+                        entry(ent)
+                    ev_side.record(side)
+                    continue
+                if kind == 'cross':
+                    torch.cuda.current_stream(dev).wait_event(ev_side)
+                    entry(ent)
+                    ev_main.record(torch.cuda.current_stream(dev))
+                    continue
+            if kind == 'layer':
+                yield ent[1].start, ent[1].end
+            else:
+                entry(ent)
+
+        if dual:
+            torch.cuda.current_stream(dev).wait_event(ev_side)
         # pack backward (4 identical streams -> sum; registers; abs-pos)
         dabs = G(g.abs_pos, self.max_seq_len, D) if exists(g.abs_pos) else None
         dxs = ops.stream_pack_bwd(grads['x'], B, T, R, G(g.registers, R, D), dabs)
@@ -1240,6 +1290,9 @@ class _TimeCondFn(torch.autograd.Function):
         ops.time_cond_bwd(dout.float().contiguous(), four, pre, dW, db)
         return None, None, dW, db
 
+
+import os as _os
+_DUAL_STREAM = bool(int(_os.environ.get('E2K_DUAL_STREAM', '0')))      # experiment, see _run_forward
 
 _VIEW_OPS = {'view', '_unsafe_view', 'as_strided', 'slice', 'select', 'expand', 't', 'transpose', 'permute', 'unsqueeze', 'squeeze',
              'detach', 'alias', '_reshape_alias', 'reshape', 'split', 'split_with_sizes', 'unbind', 'narrow', 'lift_fresh', 'unfold',

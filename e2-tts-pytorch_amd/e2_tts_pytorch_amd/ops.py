@@ -472,7 +472,7 @@ def attn_bwd(st, dOg, kmask_pad, p_drop=0., seed=0, stream_id=0, seed_dev=None):
     _note(10.0 * B * H * N * N * 64)
     _lib.get().e2k_attn_bwd(_p(dOg), _p(st.O), _p(st.gate), _p(st.lse2), _p(st.Q), _p(st.K), _p(st.V), _p(st.QT),
                             _p(st.KT), _p(kmask_pad), _p(st.dropbits), _p(dO), _p(dOT), _p(delta), _p(dgate), _p(dQ), _p(dK),
-                            _p(dV), B, H, N, Npad, float(p_drop), int(seed), _p(seed_dev), int(stream_id), attn_probe & 64,
+                            _p(dV), B, H, N, Npad, float(p_drop), int(seed), _p(seed_dev), int(stream_id), attn_probe & (64 | 128),
                             _stream(dOg))
     return dQ, dK, dV, dgate
 

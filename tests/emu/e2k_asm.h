@@ -26,6 +26,10 @@ inline s16x4_ lds_read_tr16_b64(const void* lds_ptr) {
     return r;
 }
 
+// asynchronous form (device: inline assembly + lds_tr_wait): the model reads at issue
+inline void lds_tr_issue(s16x4_& dst, const void* lds_ptr, int imm_off) { dst = lds_read_tr16_b64((const char*)lds_ptr + imm_off); }
+template <class... T> inline void lds_tr_wait(T&...) {}
+
 inline float uniform_f(float v) { return v; }
 inline int uniform_i(int v) { return v; }
 inline float wave_sum_fast(float v) {          // same result up to summation order
@@ -72,9 +76,23 @@ inline void glds16(const void* gsrc, void* lds_base) {
         emu::PendingCopy c;
         memcpy(c.data, gsrc, 16);
         c.dst = dst;
+        c.size = 16;
         emu::cur_fiber().pending.push_back(c);
     } else {
         memcpy(dst, gsrc, 16);
+    }
+}
+// global_load_lds_dword: lane l copies 4 bytes to lds_base + 4*l
+inline void glds4(const void* gsrc, void* lds_base) {
+    void* dst = (char*)lds_base + 4 * emu::lane_id();
+    if (emu::g_glds_late) {
+        emu::PendingCopy c;
+        memcpy(c.data, gsrc, 4);
+        c.dst = dst;
+        c.size = 4;
+        emu::cur_fiber().pending.push_back(c);
+    } else {
+        memcpy(dst, gsrc, 4);
     }
 }
 

@@ -80,6 +80,7 @@ struct Wave {
 struct PendingCopy {
     unsigned char data[16];
     void* dst;
+    int size = 16;
 };
 inline bool g_glds_late = false;
 
@@ -127,7 +128,7 @@ inline void land_pending(int keep) {
     Fiber& f = cur_fiber();
     int n = (int)f.pending.size() - keep;
     if (n <= 0) return;
-    for (int i = 0; i < n; ++i) memcpy(f.pending[i].dst, f.pending[i].data, 16);
+    for (int i = 0; i < n; ++i) memcpy(f.pending[i].dst, f.pending[i].data, f.pending[i].size);
     f.pending.erase(f.pending.begin(), f.pending.begin() + n);
 }
 inline void yield() {

@@ -7,6 +7,15 @@ from oracle.e2tts_oracle import Attention, RotaryEmbedding
 bf16 = torch.bfloat16
 
 
+@pytest.fixture(params=[0, 1], ids=['dma_early', 'dma_late'], autouse=True)
+def dma_landing(request, dev, monkeypatch):
+    """the forward and the dK/dV kernels stage their tiles with LDS-DMA into a 2-stage ring: on the host model run both
+    landing extremes (at issue / only at the counted wait), see tests/emu/hip/hip_runtime.h"""
+    if dev == 'cuda' and request.param:
+        pytest.skip('LDS-DMA landing extremes exist on the host model only')
+    monkeypatch.setenv('E2K_EMU_GLDS_LATE', str(request.param))
+
+
 def rel(a, b):
     a, b = a.cpu(), b.cpu()
     return ((a.float() - b.float()).abs().max() / b.float().abs().max().clamp_min(1e-20)).item()
