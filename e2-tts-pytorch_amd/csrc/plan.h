@@ -19,18 +19,33 @@
 
 namespace e2k {
 
+// Launch lanes.  The backbone's schedule is not a chain: the text branches of layer i + 1 only need what the cross
+// projection of layer i left behind, and no weight gradient is read before the optimizer (or the gradient all-reduce)
+// runs.  A recorded call therefore carries a LANE -- lane 0 is the caller's stream, lanes 1.. are side streams handed to
+// e2k_plan_run_lanes -- and the recording holds explicit ordering points between lanes: "record event e on lane a",
+// "lane b waits for event e" (hipEventRecord / hipStreamWaitEvent at replay).  Replayed on one stream (e2k_plan_run,
+// e2k_plan_profile) the lanes collapse into program order and the ordering points are skipped.
+constexpr int PLAN_MAX_LANES = 4;
+enum PlanOpKind { PLAN_CALL = 0, PLAN_EVENT_RECORD = 1, PLAN_EVENT_WAIT = 2 };
+
 struct PlanOp {
     const char* name;
     std::function<int(void*)> run;      // argument: the stream to enqueue on
+    int lane = 0;
+    int kind = PLAN_CALL;
+    int ev = -1;                        // PLAN_EVENT_*: index into Plan::events
 };
 
 struct Plan {
     std::vector<PlanOp> ops;
+    std::vector<void*> events;          // hipEvent_t, created at the first multi-lane replay
+    ~Plan();
 };
 
 struct PlanTls {
     Plan* recording = nullptr;
     int depth = 0;                      // entry points that call other entry points record only the outermost call
+    int lane = 0;                       // lane of the calls recorded from now on (e2k_plan_lane)
 };
 PlanTls& plan_tls();
 
@@ -42,10 +57,14 @@ int dispatch(const char* name, int (*impl)(A...), typename same_<A>::type... a) 
     PlanTls& t = plan_tls();
     if (t.recording && t.depth == 0) {
         std::tuple<A...> args(a...);
-        t.recording->ops.push_back(PlanOp{name, [impl, args](void* stream) mutable -> int {
-                                               std::get<sizeof...(A) - 1>(args) = stream;
-                                               return std::apply(impl, args);
-                                           }});
+        PlanOp op;
+        op.name = name;
+        op.run = [impl, args](void* stream) mutable -> int {
+            std::get<sizeof...(A) - 1>(args) = stream;
+            return std::apply(impl, args);
+        };
+        op.lane = t.lane;
+        t.recording->ops.push_back(std::move(op));
     }
     ++t.depth;
     const int rc = impl(a...);

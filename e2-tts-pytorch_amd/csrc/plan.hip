@@ -14,6 +14,11 @@ PlanTls& plan_tls() {
     return t;
 }
 
+Plan::~Plan() {
+    for (void* e : events)
+        if (e) hipEventDestroy((hipEvent_t)e);
+}
+
 namespace {
 std::mutex g_mu;
 std::vector<std::unique_ptr<Plan>> g_plans;        // handle = index + 1; freed slots stay as nullptr
@@ -33,8 +38,33 @@ extern "C" int e2k_plan_begin(void) {
     if (t.recording) return E2K_ERR_ARG;
     t.recording = new Plan();
     t.depth = 0;
+    t.lane = 0;
     return 0;
 }
+
+extern "C" int e2k_plan_lane(int lane) {
+    if (lane < 0 || lane >= PLAN_MAX_LANES) return E2K_ERR_ARG;
+    plan_tls().lane = lane;
+    return 0;
+}
+
+static int plan_event_op(int lane, int ev, int kind) {
+    if (lane < 0 || lane >= PLAN_MAX_LANES || ev < 0 || ev >= 65536) return E2K_ERR_ARG;
+    PlanTls& t = plan_tls();
+    if (!t.recording) return 0;                     // outside a recording the caller orders its streams itself
+    if (kind == PLAN_EVENT_WAIT && ev >= (int)t.recording->events.size()) return E2K_ERR_ARG;     // wait before any record
+    if (ev >= (int)t.recording->events.size()) t.recording->events.resize(ev + 1, nullptr);
+    PlanOp op;
+    op.name = kind == PLAN_EVENT_RECORD ? "lane_event_record" : "lane_event_wait";
+    op.lane = lane;
+    op.kind = kind;
+    op.ev = ev;
+    t.recording->ops.push_back(std::move(op));
+    return 0;
+}
+
+extern "C" int e2k_plan_event_record(int lane, int ev) { return plan_event_op(lane, ev, PLAN_EVENT_RECORD); }
+extern "C" int e2k_plan_event_wait(int lane, int ev) { return plan_event_op(lane, ev, PLAN_EVENT_WAIT); }
 
 extern "C" int e2k_query_plan_recorded(void) {
     PlanTls& t = plan_tls();
@@ -73,9 +103,9 @@ extern "C" int e2k_query_plan_size(int plan) {
     return p ? (int)p->ops.size() : -1;
 }
 
-extern "C" int e2k_plan_run(int plan, int first, int count, void* stream) {
+extern "C" int e2k_plan_run_lanes(int plan, int first, int count, void** streams_host, int nstreams) {
     Plan* p = lookup(plan);
-    if (!p) return E2K_ERR_ARG;
+    if (!p || !streams_host || nstreams < 1 || nstreams > PLAN_MAX_LANES) return E2K_ERR_ARG;
     const int n = (int)p->ops.size();
     if (first < 0 || first > n) return E2K_ERR_ARG;
     const int last = count < 0 ? n : first + count;
@@ -83,10 +113,29 @@ extern "C" int e2k_plan_run(int plan, int first, int count, void* stream) {
     PlanTls& t = plan_tls();
     if (t.recording) return E2K_ERR_ARG;            // a replay inside a recording would record the replayed calls again
     for (int i = first; i < last; ++i) {
-        const int rc = p->ops[i].run(stream);
-        if (rc) return rc;
+        PlanOp& op = p->ops[i];
+        const int lane = op.lane < nstreams ? op.lane : 0;      // lanes the caller has no stream for run on lane 0
+        if (op.kind == PLAN_CALL) {
+            const int rc = op.run(streams_host[lane]);
+            if (rc) return rc;
+            continue;
+        }
+        if (nstreams == 1) continue;                // one stream: program order is the order
+        void*& ev = p->events[op.ev];
+        if (!ev) {
+            hipEvent_t e;
+            if (hipEventCreateWithFlags(&e, hipEventDisableTiming) != hipSuccess) return 1000;
+            ev = (void*)e;
+        }
+        const hipError_t rc = op.kind == PLAN_EVENT_RECORD ? hipEventRecord((hipEvent_t)ev, (hipStream_t)streams_host[lane])
+                                                           : hipStreamWaitEvent((hipStream_t)streams_host[lane], (hipEvent_t)ev, 0);
+        if (rc != hipSuccess) return 1000 + (int)rc;
     }
     return 0;
+}
+
+extern "C" int e2k_plan_run(int plan, int first, int count, void* stream) {
+    return e2k_plan_run_lanes(plan, first, count, &stream, 1);
 }
 
 extern "C" int e2k_plan_profile(int plan, int first, int count, float* ms_host, void* stream) {
@@ -104,8 +153,8 @@ extern "C" int e2k_plan_profile(int plan, int first, int count, float* ms_host, 
         if (hipEventCreate(&e) != hipSuccess) return 1000;
     int rc = 0;
     hipEventRecord(ev[0], st);
-    for (int i = 0; i < m && !rc; ++i) {
-        rc = p->ops[first + i].run(stream);
+    for (int i = 0; i < m && !rc; ++i) {          // one stream: the lane ordering points are skipped (0 ms)
+        if (p->ops[first + i].kind == PLAN_CALL) rc = p->ops[first + i].run(stream);
         hipEventRecord(ev[i + 1], st);
     }
     hipStreamSynchronize(st);

@@ -13,6 +13,7 @@ from __future__ import annotations
 
 import contextlib
 import random as _pyrandom
+import os as _os
 from types import SimpleNamespace as NS
 
 import torch
@@ -312,7 +313,7 @@ class Transformer(Module):
 
     # runtime state (device buffers, caches, recorded plans): never part of the module's identity -- a deep copy (the
     # trainer's EMA, trainer.py:170) starts without it and rebuilds its own on first use
-    _RUNTIME = ('_flat', '_shadow', '_shadowT', '_shadow_key', '_tdesc', '_vcache', '_rot_cache', '_plans', '_pool', '_pg', '_no_pgrads')
+    _RUNTIME = ('_flat', '_shadow', '_shadowT', '_shadow_key', '_tdesc', '_vcache', '_rot_cache', '_plans', '_pool', '_pg', '_no_pgrads', '_lane_ss')
 
     def _reset_runtime(self):
         self._flat = None
@@ -320,6 +321,10 @@ class Transformer(Module):
         self._rot_cache = {}
         self._plans_on = getattr(self, '_plans_on', True)       # enable_plans(): record-and-replay of the launch schedule
         self._max_plans = getattr(self, '_max_plans', 4)
+        self._lane_mask = int(_os.environ.get('E2K_LANES', '0')) or 3   # bit 0: TEXT lane, bit 1: WGRAD lane (A/B, fault isolation)
+        self._lanes_on = getattr(self, '_lanes_on', _os.environ.get('E2K_LANES', '0') != '0')      # enable_lanes(); OFF by default
+        self._lanes_bwd = getattr(self, '_lanes_bwd', _os.environ.get('E2K_LANES_BWD', '0') != '0')
+        self.__dict__.pop('_lane_ss', None)
         self._plans = {}
         self._plan_tick = 0
         self._plan_py_seed = False
@@ -608,11 +613,38 @@ class Transformer(Module):
             self._drop_plans()
         return self
 
-    def _side_stream(self, dev):
-        ss = self.__dict__.get('_side')
-        if ss is None:
-            ss = self.__dict__['_side'] = torch.cuda.Stream(device=dev)
-        return ss
+    def enable_lanes(self, on: bool = True, backward: bool | None = None):
+        """Launch lanes (EXPERIMENTAL, off by default; E2K_LANES=3 / E2K_LANES_BWD=1 in the environment): the text
+        stream's branches run on a side stream next to the audio stream's chain and, with `backward=True`, the
+        weight-gradient GEMMs of the backward pass on a third one (ops.Lanes; csrc/plan.h for recorded plans).  Measured
+        on MI355X at cfg3: 114 -> 98 ms per step with both, nothing with the forward alone.  Not a default because
+        hc_bwd_kernel does not reproduce its own results next to a concurrent LDS-DMA GEMM (see _backward_gen and
+        DESIGN.md section 5.1).  Plans recorded under another setting are dropped."""
+        bw = self._lanes_bwd if backward is None else bool(backward)
+        if bool(on) != self._lanes_on or bw != self._lanes_bwd:
+            self._drop_plans()
+        self._lanes_on, self._lanes_bwd = bool(on), bw
+        return self
+
+    def _sync_lanes(self, streams):
+        """tell the data-parallel hook which side streams a finished gradient slab must also be final on"""
+        sync = self._grad_sync
+        tgt = getattr(sync, '__self__', sync)           # (the hook may be a bound method of the _GradSync object)
+        if exists(tgt) and hasattr(tgt, 'lanes'):
+            tgt.lanes = [ss for ss in streams if exists(ss)]
+
+    def _lane_streams(self, dev):
+        """side streams of the TEXT and WGRAD lanes ([] = single lane); on the host model of the kernels there are no
+        streams, only the lane bookkeeping of a recording"""
+        if not self._lanes_on:
+            return []
+        dev = torch.device(dev)
+        if dev.type != 'cuda':
+            return [None, None]
+        ss = self.__dict__.get('_lane_ss')
+        if ss is None or ss[0] != dev:
+            ss = self.__dict__['_lane_ss'] = (dev, [torch.cuda.Stream(device=dev), torch.cuda.Stream(device=dev)])
+        return ss[1]
 
     def _drop_plans(self):
         lib = None
@@ -696,7 +728,7 @@ class Transformer(Module):
         dev = st.x.device
         lib = ops.lib()
         if exists(st.fwd):
-            lib.e2k_plan_run(st.fwd, 0, -1, ops.raw_stream(dev))
+            ops.run_plan(st.fwd, 0, -1, dev, st.lane_ss)
             return
         # first run of this plan: execute the schedule with the C ABI recording, inside the pool
         with self._pool_ctx(dev), _RecordGuard(st.keep if dev.type != 'cuda' else None):
@@ -711,15 +743,16 @@ class Transformer(Module):
                 ops.abort_recording()
                 raise
         st.run, st.out = run, run.out
+        st.lane_ss = self._lane_streams(dev) if run.lanes.on else []
 
     def _plan_run_backward(self, st):
         dev = st.x.device
         lib = ops.lib()
         sync = self._grad_sync
+        self._sync_lanes(st.lane_ss)
         if exists(st.bwd):
-            stream = ops.raw_stream(dev)
             for first, count, slab in st.segs:
-                lib.e2k_plan_run(st.bwd, first, count, stream)
+                ops.run_plan(st.bwd, first, count, dev, st.lane_ss)
                 if exists(sync) and exists(slab):
                     sync(st.gflat, slab[0], slab[1])
         else:
@@ -773,7 +806,7 @@ class Transformer(Module):
         exactly the recorded calls, so a tensor-library op in between would silently be skipped on replay)"""
         dev = x_in.device
         B, T, D = x_in.shape
-        Dt, R, L = self.dim_text, self.num_registers, self.depth
+        Dt, R, depth = self.dim_text, self.num_registers, self.depth
         N = T + R
         Mtok = B * N
         run = NS(B=B, T=T, N=N, Mtok=Mtok, tape=[] if want_tape else None, dev=dev)
@@ -794,8 +827,8 @@ class Transformer(Module):
         if self.cond_on_time:
             cond = cond if (cond.dtype == f32 and cond.is_contiguous()) else cond.float().contiguous()
             cb = ops.cast_bf16(cond, torch.empty(cond.shape, dtype=bf16, device=dev))
-            wc = self._w(g.wcond, 4 * L * D, D)
-            condall = ops.gemm_nt(cb, wc, bias=self._f(g.bcond, 4 * L * D), out_dtype=f32)       # (B, 4LD)
+            wc = self._w(g.wcond, 4 * depth * D, D)
+            condall = ops.gemm_nt(cb, wc, bias=self._f(g.bcond, 4 * depth * D), out_dtype=f32)       # (B, 4LD)
             run.cb, run.condall = cb, condall
             run.gates = ops.sigmoid(condall)
             run.dcond = ops.zeros(condall.shape, f32, dev) if want_tape else None
@@ -813,31 +846,28 @@ class Transformer(Module):
         run.attn0 = {'x': None, 't': None}
         skips = []
 
-        dual = _DUAL_STREAM and dev.type == 'cuda' and exists(st) and not self._plans_on
-        if dual:
-            side = self._side_stream(dev)
-            ev_main, ev_side = torch.cuda.Event(), torch.cuda.Event()
-            ev_main.record(torch.cuda.current_stream(dev))
+        # launch lanes (ops.Lanes): the text branches of layer i only need the text stream as the cross projection of layer
+        # i - 1 left it, so they run on the TEXT lane next to the audio branches of layer i - 1
+        L = run.lanes = ops.Lanes(dev, self._lane_streams(dev) if exists(st) else [], self._lane_mask)
+        ev_cross = L.record(ops.MAIN)
+        # what MAIN hands to the TEXT lane (the packed text stream, then each cross projection's output) is allocated on
+        # MAIN: it must stay referenced until MAIN has waited for the TEXT lane again, or the next MAIN allocation could
+        # land on it while the TEXT lane still reads it
+        xhold = [st.X] if exists(st) else []
         for r in self._recs:
             ind = r.index
             if exists(tape):
                 tape.append(('layer', r))
             if exists(st) and exists(r.t):
-                if dual:
-                    # EXPERIMENT (E2K_DUAL_STREAM, eager mode): the text branches of layer i only need the text stream as
-                    # the cross projection of layer i - 1 left it: they run on a side stream next to the audio branches
-                    # of layer i - 1
-                    side.wait_event(ev_main)
-                    with torch.cuda.stream(side), ops.pinned_stream(dev):
-                        self._branches(run, st, r.t, ind, text=True)
-                    ev_side.record(side)
-                    torch.cuda.current_stream(dev).wait_event(ev_side)
-                    self._cross(run, sx, st, r.t)
-                    ev_main.record(torch.cuda.current_stream(dev))
-                else:
+                L.wait(ops.TEXT, ev_cross)
+                with L.lane(ops.TEXT):
                     self._branches(run, st, r.t, ind, text=True)
-                    self._cross(run, sx, st, r.t)
-            if ind < L // 2:
+                L.fence(ops.TEXT, ops.MAIN)
+                xhold.clear()
+                self._cross(run, sx, st, r.t)
+                xhold.append(st.X)
+                ev_cross = L.record(ops.MAIN)
+            if ind < depth // 2:
                 self._materialize(run, sx)
                 skips.append(sx.X)
                 if exists(tape):
@@ -976,6 +1006,7 @@ class Transformer(Module):
     def _run_backward(self, run, dout):
         """eager backward: drive the schedule, hand finished gradient slabs to the data-parallel hook"""
         gen = self._backward_gen(run, dout, self._persist_grads)
+        self._sync_lanes(self._lane_streams(dout.device) if run.lanes.on else [])
         while True:
             try:
                 with ops.pinned_stream(dout.device):        # (the hook below enqueues RCCL work on its own stream)
@@ -1059,6 +1090,22 @@ class Transformer(Module):
                    't': ops.zeros((B, self.text_heads, N, 64), f32, dev) if run.has_text else None}
         skip_grads = []
 
+        # (backward lanes are OFF by default: hc_bwd_kernel returns slightly different results -- a few tokens, last bits of
+        # bf16 -- whenever a weight-gradient GEMM runs next to it on another stream, with disjoint data and unchanged inputs;
+        # tools/probes/hc_concurrent.py reproduces it, the cause is not understood yet.  The forward
+        # pass has no such kernel: its results with lanes are bit-identical to the single-stream schedule.)
+        Ln = run.blanes = ops.Lanes(dev, self._lane_streams(dev) if (run.lanes.on and self._lanes_bwd) else [], self._lane_mask)
+        hold = [[], []]           # operands of the weight-gradient GEMMs of [this layer, the layer before]
+
+        def wgrad(a, b, out, **kw):
+            """out += a^T b for a parameter gradient: nothing on the chain reads it, so it goes to the WGRAD lane"""
+            if not Ln.has(ops.WGRAD):
+                return ops.gemm_tn(a, b, out, **kw)
+            Ln.fence(Ln.cur, ops.WGRAD)
+            with Ln.lane(ops.WGRAD):
+                ops.gemm_tn(a, b, out, hold=hold[0], **kw)
+        run.wgrad = wgrad
+
         def entry(ent):
             kind = ent[0]
             if kind == 'hc':
@@ -1090,11 +1137,11 @@ class Transformer(Module):
                 gx, gt = grads['x'].view(-1, D), grads['t'].view(-1, Dt)
                 WT = self._wT(tr.crossT)                       # (D+Dt, rows)
                 gW = G(tr.cross, tr.cross_rows, D + Dt)
-                ops.gemm_tn(gx, X, gW[:D, :D])
-                ops.gemm_tn(gx, Tt, gW[:D, D:])
+                wgrad(gx, X, gW[:D, :D])
+                wgrad(gx, Tt, gW[:D, D:])
                 if tr.cross_rows > D:
-                    ops.gemm_tn(gt, X, gW[D:, :D])
-                    ops.gemm_tn(gt, Tt, gW[D:, D:])
+                    wgrad(gt, X, gW[D:, :D])
+                    wgrad(gt, Tt, gW[D:, D:])
                     ngx = ops.gemm_nt(gx, WT[:D], a2=gt, resid=gx)
                     ngt = ops.gemm_nt(gx, WT[D:], a2=gt, resid=gt)
                 else:
@@ -1105,8 +1152,8 @@ class Transformer(Module):
                 _, sr, X, Sk = ent
                 gx = grads['x'].view(-1, D)
                 gW = G(sr.skip, D, 2 * D)
-                ops.gemm_tn(gx, X, gW[:, :D])
-                ops.gemm_tn(gx, Sk, gW[:, D:])
+                wgrad(gx, X, gW[:, :D])
+                wgrad(gx, Sk, gW[:, D:])
                 WT = self._wT(sr.skipT)                        # (2D, D)
                 skip_grads.append((gx, WT[D:]))
                 grads['x'] = ops.gemm_nt(gx, WT[:D]).view(Mtok, 4, D)
@@ -1117,35 +1164,43 @@ class Transformer(Module):
             else:
                 raise AssertionError(kind)
 
-        dual = _DUAL_STREAM and dev.type == 'cuda' and run.has_text and not self._plans_on
-        if dual:
-            side = self._side_stream(dev)
-            ev_main, ev_side = torch.cuda.Event(), torch.cuda.Event()
-            ev_main.record(torch.cuda.current_stream(dev))
-            ev_side.record(side)
+        # Launch lanes (ops.Lanes).  TEXT: the text branches' backward of layer i only needs the cross projection's backward
+        # of layer i and runs next to the audio branches' backward of layer i - 1.  WGRAD: the weight-gradient GEMMs (see
+        # wgrad() above) trail the chain; main waits for the weight gradients of layer i + 1 at the end of layer i, which
+        # is also when their operands are released.
+        ev_main, need_main, text_dirty = Ln.record(ops.MAIN), True, False
+        ev_w = -1
+        thold = [grads['t']]      # MAIN-allocated gradients handed to the TEXT lane: referenced until MAIN waits for it again
         for ent in reversed(run.tape):
             kind = ent[0]
-            if dual:
-                is_text = (kind in ('hc', 'mat') and ent[2] == 't') or (kind == 'conv' and ent[5] == 't') or \
-                          (kind in ('attn', 'ff') and ent[4])
-                if is_text:
-                    side.wait_event(ev_main)
-                    with torch.cuda.stream(side), ops.pinned_stream(dev):
-                        entry(ent)
-                    ev_side.record(side)
-                    continue
-                if kind == 'cross':
-                    torch.cuda.current_stream(dev).wait_event(ev_side)
-                    entry(ent)
-                    ev_main.record(torch.cuda.current_stream(dev))
-                    continue
             if kind == 'layer':
+                if Ln.has(ops.WGRAD):
+                    Ln.wait(ops.MAIN, ev_w)
+                    hold[1].clear()
+                    hold.reverse()
+                    ev_w = Ln.record(ops.WGRAD)
                 yield ent[1].start, ent[1].end
+            elif Ln.has(ops.TEXT) and ((kind in ('hc', 'mat') and ent[2] == 't') or (kind == 'conv' and ent[5] == 't') or
+                                       (kind in ('attn', 'ff') and ent[4])):
+                if need_main:
+                    Ln.wait(ops.TEXT, ev_main)
+                    need_main = False
+                with Ln.lane(ops.TEXT):
+                    entry(ent)
+                text_dirty = True
+            elif kind == 'cross':
+                if text_dirty:
+                    Ln.fence(ops.TEXT, ops.MAIN)
+                    text_dirty = False
+                    thold.clear()
+                entry(ent)
+                thold.append(grads['t'])
+                ev_main, need_main = Ln.record(ops.MAIN), True
             else:
                 entry(ent)
+        Ln.join()                 # (the remaining weight gradients included: their operands die with this frame)
+        thold.clear()
 
-        if dual:
-            torch.cuda.current_stream(dev).wait_event(ev_side)
         # pack backward (4 identical streams -> sum; registers; abs-pos)
         dabs = G(g.abs_pos, self.max_seq_len, D) if exists(g.abs_pos) else None
         dxs = ops.stream_pack_bwd(grads['x'], B, T, R, G(g.registers, R, D), dabs)
@@ -1179,7 +1234,7 @@ class Transformer(Module):
             dgam = run.dcond[:, (ind * 4 + 0) * D:(ind * 4 + 1) * D]
             gate = run.gates[:, (ind * 4 + 1) * D:(ind * 4 + 2) * D]
             dao = ops.gate_bwd(rec.dy, y, gate, run.dcond[:, (ind * 4 + 1) * D:(ind * 4 + 2) * D], N)
-        ops.gemm_tn(dao, ast.Og, G(a.out, D, a.I))
+        run.wgrad(dao, ast.Og, G(a.out, D, a.I))
         dOg = ops.gemm_nt(dao, self._wT(a.outT))                                   # (Mtok, I)
         dQ, dK, dV, dgate = ops.attn_bwd(ast, dOg, run.kmask, run.p_drop, run.seed, sid, run.seed_dev)
         dqkvg = ops.qkv_post_bwd(ast, dQ, dK, dV, dgate, qkvg, run.rot[0], run.rot[1],
@@ -1187,7 +1242,7 @@ class Transformer(Module):
         nb = a.cols - 3 * a.I                                                      # gate (+ mix) bias gradients
         assert nb % 2 == 0, 'odd head counts are not supported'
         # weight gradient; the gate (+ mix) bias gradients = column sums of the same dY ride along in the kernel
-        ops.gemm_tn(dqkvg, xn, G(a.w, a.cols, D), colsum=G(a.bias, a.cols), colsum_from=3 * a.I)
+        run.wgrad(dqkvg, xn, G(a.w, a.cols, D), colsum=G(a.bias, a.cols), colsum_from=3 * a.I)
         # dgrad over the padded row (pad columns of dqkvg / rows of W^T are zero)
         dq_full = dqkvg if a.ldq == a.cols else torch.as_strided(dqkvg, (Mtok, a.ldq), (a.ldq, 1))
         dxn = ops.gemm_nt(dq_full, self._wT(a.wT))
@@ -1207,10 +1262,10 @@ class Transformer(Module):
             dgam = run.dcond[:, (ind * 4 + 2) * D:(ind * 4 + 3) * D]
             gate = run.gates[:, (ind * 4 + 3) * D:(ind * 4 + 4) * D]
             dao = ops.gate_bwd(rec.dy, y, gate, run.dcond[:, (ind * 4 + 3) * D:(ind * 4 + 4) * D], N)
-        ops.gemm_tn(dao, act, G(f.w2, D, f.F), colsum=G(f.b2, D))                  # dW2 and db2 in one pass over dY
+        run.wgrad(dao, act, G(f.w2, D, f.F), colsum=G(f.b2, D))                  # dW2 and db2 in one pass over dY
         dact = ops.gemm_nt(dao, self._wT(f.w2T))
         dH = ops.geglu_bwd(dact, Hh, run.p_drop, run.seed, sid, run.seed_dev)
-        ops.gemm_tn(dH, xn, G(f.w1, 2 * f.F, D), colsum=G(f.b1, 2 * f.F))           # dW1 and db1
+        run.wgrad(dH, xn, G(f.w1, 2 * f.F, D), colsum=G(f.b1, 2 * f.F))           # dW1 and db1
         dxn = ops.gemm_nt(dH, self._wT(f.w1T))
         rec.dbin = ops.rmsnorm_bwd(dxn, binp, rn, gam, off, rpb, dgam)
 
@@ -1290,9 +1345,6 @@ class _TimeCondFn(torch.autograd.Function):
         ops.time_cond_bwd(dout.float().contiguous(), four, pre, dW, db)
         return None, None, dW, db
 
-
-import os as _os
-_DUAL_STREAM = bool(int(_os.environ.get('E2K_DUAL_STREAM', '0')))      # experiment, see _run_forward
 
 _VIEW_OPS = {'view', '_unsafe_view', 'as_strided', 'slice', 'select', 'expand', 't', 'transpose', 'permute', 'unsqueeze', 'squeeze',
              'detach', 'alias', '_reshape_alias', 'reshape', 'split', 'split_with_sizes', 'unbind', 'narrow', 'lift_fresh', 'unfold',

@@ -39,6 +39,7 @@ class _GradSync:
         self.grad_dtype = grad_dtype
         self.bucket_layers = max(1, int(bucket_layers))
         self.side = None
+        self.lanes = []               # side streams of the backbone's launch lanes (set by the backbone): a slab is final on all of them
         self.calls = 0
         self.bytes = 0
         self._pending = None          # (start, end, layers) of the slabs merged so far
@@ -61,6 +62,8 @@ class _GradSync:
             if self.side is None:
                 self.side = torch.cuda.Stream(device=gflat.device)
             self.side.wait_stream(torch.cuda.current_stream(gflat.device))     # the slab is complete on the compute stream
+            for ls in self.lanes:                                               # ... and on the text / weight-gradient lanes
+                self.side.wait_stream(ls)
             with torch.cuda.stream(self.side):
                 run()
             slab.record_stream(self.side)

@@ -4,6 +4,8 @@ PyTorch is plumbing here (device memory + stream); all arithmetic happens in csr
 """
 from __future__ import annotations
 
+import contextlib
+
 import torch
 
 from . import _lib
@@ -176,10 +178,11 @@ def gemm_nt(a, b, *, a2=None, out=None, out_dtype=bf16, accumulate=False, bias=N
         e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
         e0.record()
     _note(2.0 * M * N * (K1 + K2))
+    stream = _stream(a)
     _lib.get().e2k_gemm_nt_bf16(_p(a), lda, K1, _p(a2), lda2, K2, _p(b), ldb, _p(out), out.stride(0),
                                 int(out.dtype == f32), int(accumulate), M, N, _p(bias), _p(colscale),
                                 0 if colscale is None else colscale.stride(0), int(rows_per_batch), _p(rowmask), _p(resid), ldr,
-                                gemm_flags, *_nt_ws(a.device), _stream(a))
+                                gemm_flags, *_nt_ws(a.device, stream), stream)
     if prof is not None and a.is_cuda:
         e1.record()
         prof.append((2.0 * M * N * (K1 + K2), e0, e1))
@@ -189,12 +192,14 @@ def gemm_nt(a, b, *, a2=None, out=None, out_dtype=bf16, accumulate=False, bias=N
 _nt_ws_cache = {}
 
 
-def _nt_ws(device):
-    """per-device fp32 scratch of the NT GEMM remainder split (one compute stream per device uses it)"""
-    w = _nt_ws_cache.get(device)
+def _nt_ws(device, stream):
+    """fp32 scratch of the NT GEMM remainder split: one per (device, stream) -- launches of one stream use it one after
+    the other, launches of different streams (launch lanes) may overlap"""
+    key = (device, stream)
+    w = _nt_ws_cache.get(key)
     if w is None:
         w = torch.empty(_lib.get().e2k_query_gemm_nt_ws_bytes() // 4, dtype=f32, device=device)
-        _nt_ws_cache[device] = w
+        _nt_ws_cache[key] = w
     return _p(w), w.numel() * 4
 
 
@@ -202,6 +207,98 @@ _gemm_profile = None
 _gemm_shapes = None        # tools/nt_shapes.py: dict counting the (M, N, K1, K2, out_f32, has_resid) of every gemm_nt call
 # E2K_GEMM_* bits passed to every gemm_nt call (A/B benchmarking of kernel variants: 64 = 256 x 128 tile, 128 = 256 x 256
 # 8-phase tile for every shape, 256 = the same where it fills the chip).  E2K_GEMM_FLAGS in the environment presets it.
+# ---- launch lanes (csrc/plan.h) --------------------------------------------------------------------------------------
+MAIN, TEXT, WGRAD = 0, 1, 2
+
+
+class Lanes:
+    """The backbone's schedule on up to three launch lanes: MAIN (the caller's stream), TEXT (the text stream's branches of
+    layer i + 1 run next to the audio branches of layer i: both only need the cross projection of layer i) and WGRAD (no
+    weight gradient is read before the optimizer / the gradient all-reduce).  The same calls drive the eager schedule
+    (torch streams + events, executed now) and a launch-plan recording (e2k_plan_lane / e2k_plan_event_*: what the replay
+    will do); on the host model of the kernels only the recording half exists.  Event ids are local to one Lanes object =
+    one recording."""
+
+    def __init__(self, device, side_streams, mask=3):
+        self.dev = torch.device(device)
+        self.mask = mask              # bit k - 1: lane k in use (A/B and fault isolation)
+        self.on = len(side_streams) > 0 and mask != 0
+        self.cuda = self.on and self.dev.type == 'cuda'
+        self.cur = MAIN
+        self.n = 1 + len(side_streams)
+        self.streams = ([torch.cuda.current_stream(self.dev)] + list(side_streams)) if self.cuda else None
+        self._ev = []
+
+    def has(self, k):
+        return self.on and k < self.n and (k == 0 or bool(self.mask >> (k - 1) & 1))
+
+    @contextlib.contextmanager
+    def lane(self, k):
+        """launch what the block launches on lane k (allocations made inside belong to that lane's stream)"""
+        if not self.has(k) or k == self.cur:
+            yield
+            return
+        prev, self.cur = self.cur, k
+        L = _lib.get()
+        L.e2k_plan_lane(k)
+        try:
+            if self.cuda:
+                with torch.cuda.stream(self.streams[k]), pinned_stream(self.dev):
+                    yield
+            else:
+                yield
+        finally:
+            self.cur = prev
+            L.e2k_plan_lane(prev)
+
+    def record(self, k=None):
+        """ordering point: everything launched on lane k so far; returns the event id"""
+        if not self.on:
+            return -1
+        k = self.cur if k is None else k
+        e = len(self._ev)
+        if self.cuda:
+            ev = torch.cuda.Event()
+            ev.record(self.streams[k])
+            self._ev.append(ev)
+        else:
+            self._ev.append(None)
+        _lib.get().e2k_plan_event_record(k, e)
+        return e
+
+    def wait(self, k, e):
+        """lane k does not start anything new before event e has happened"""
+        if not self.on or e < 0:
+            return
+        if self.cuda:
+            self.streams[k].wait_event(self._ev[e])
+        _lib.get().e2k_plan_event_wait(k, e)
+
+    def fence(self, frm, to):
+        if self.has(frm) and self.has(to) and frm != to:
+            self.wait(to, self.record(frm))
+
+    def join(self):
+        """MAIN waits for every side lane (end of a pass)"""
+        for k in range(1, self.n):
+            self.fence(k, MAIN)
+
+
+def run_plan(handle, first, count, device, side_streams=()):
+    """replay calls [first, first + count) of a plan: lane 0 on the current stream, lanes 1.. on `side_streams`"""
+    import ctypes
+    L = _lib.get()
+    dev = torch.device(device)
+    if not side_streams:
+        return L.e2k_plan_run(handle, first, count, raw_stream(dev))
+    n = 1 + len(side_streams)
+    arr = (ctypes.c_void_p * n)()
+    arr[0] = raw_stream(dev)
+    for i, ss in enumerate(side_streams):
+        arr[1 + i] = ss.cuda_stream if dev.type == 'cuda' else None
+    return L.e2k_plan_run_lanes(handle, first, count, ctypes.addressof(arr), n)
+
+
 import os as _os
 gemm_flags = int(_os.environ.get('E2K_GEMM_FLAGS', '0'))
 
@@ -218,7 +315,7 @@ def set_gemm_profile(lst):
 tn_mode = int(_os.environ.get('E2K_TN_MODE', '1'))
 
 
-def gemm_tn(a, b, out, *, splits=0, use_tr=True, colsum=None, colsum_from=0):
+def gemm_tn(a, b, out, *, splits=0, use_tr=True, colsum=None, colsum_from=0, hold=None):
     """out[N,K] += a[M,N].T @ b[M,K]   (fp32 out, bf16 a/b); optionally colsum[n] += sum_m a[m][n] for n >= colsum_from"""
     _chk(a, b, out)
     assert a.dtype == bf16 and b.dtype == bf16 and out.dtype == f32
@@ -237,6 +334,8 @@ def gemm_tn(a, b, out, *, splits=0, use_tr=True, colsum=None, colsum_from=0):
     _note(2.0 * M * N * K)
     lib.e2k_gemm_tn_bf16(_p(a), lda, _p(b), ldb, _p(out), out.stride(0), M, N, K, int(splits), mode, _p(ws),
                          _p(colsum), int(colsum_from), _stream(a))
+    if hold is not None:              # launched on a side lane: the caller keeps the operands alive until that lane has been waited for
+        hold.append((a, b, ws))
     return out
 
 

@@ -232,6 +232,15 @@ int e2k_plan_abort(void);
 int e2k_plan_free(int plan);
 int e2k_query_plan_size(int plan);
 int e2k_plan_run(int plan, int first, int count, void* stream);
+/* Launch lanes (csrc/plan.h): a recorded call belongs to the lane that was current when it was recorded (0 = the caller's
+ * stream; the text stream's branches and the weight-gradient GEMMs of the backbone go to lanes 1 and 2), and the
+ * recording holds explicit ordering points between lanes.  While nothing is being recorded the three calls below are
+ * no-ops (the caller orders its own streams); e2k_plan_run_lanes replays with streams_host[lane] (HOST array of
+ * nstreams <= 4 hipStream_t; calls of lanes >= nstreams run on streams_host[0]; nstreams = 1 is e2k_plan_run). */
+int e2k_plan_lane(int lane);
+int e2k_plan_event_record(int lane, int ev);
+int e2k_plan_event_wait(int lane, int ev);
+int e2k_plan_run_lanes(int plan, int first, int count, void** streams_host, int nstreams);
 int e2k_plan_profile(int plan, int first, int count, float* ms_host, void* stream);
 int e2k_plan_op_name(int plan, int index, char* buf_host, int nbuf);
 

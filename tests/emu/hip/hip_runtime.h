@@ -59,6 +59,13 @@ static inline hipError_t hipEventElapsedTime(float* ms, hipEvent_t a, hipEvent_t
     return 0;
 }
 static inline hipError_t hipStreamSynchronize(hipStream_t) { return 0; }
+#define hipEventDisableTiming 2u
+static inline hipError_t hipEventCreateWithFlags(hipEvent_t* e, unsigned) { return hipEventCreate(e); }
+// launch lanes (csrc/plan.h): everything runs synchronously here, so a wait has nothing to wait for -- but waiting for an
+// event that was never recorded (a no-op on the GPU, i.e. a missing ordering) is reported as an error
+static inline hipError_t hipStreamWaitEvent(hipStream_t, hipEvent_t e, unsigned) {
+    return *e == std::chrono::steady_clock::time_point() ? 900 : 0;
+}
 
 namespace emu {
 
