@@ -325,8 +325,10 @@ struct ConvArgs {
     const bf16_t* x; const uint8_t* mask; const float* w; const float* bias;
     bf16_t* pre; bf16_t* y;
     const bf16_t* dy; bf16_t* dx; float* dw; float* dbias;
+    float* ws;          // backward: per-workgroup (dw, dbias) partials [b][channel tile][x][64][ks + 1], or NULL (atomics)
     int B, N, C, tiles_per_block;
     int split;          // backward: 1 = separate dx and (dw, dbias) kernels
+    int tune;           // backward tuning / ablation bits (e2k_dwconv_bwd `split` argument >> 1): 1 = no gradient flush, 2 = no arithmetic; >> 7: workgroups per (channel tile, batch)
 };
 
 template <int KS>
@@ -394,14 +396,14 @@ __device__ __forceinline__ float silu_grad(float x) { float s = sigmoidf_(x); re
 template <int KS>
 __global__ __launch_bounds__(256, 2) void dwconv_bwd_kernel(ConvArgs p) {
     constexpr int PAD = KS / 2, ROWS = CTN + KS - 1;
-    __shared__ __attribute__((aligned(16))) float dpt[ROWS][CTC];       // d(pre-activation), frame n0 - PAD + j
-    __shared__ __attribute__((aligned(16))) float xt[ROWS][CTC];        // masked input,      frame n0 - PAD + j
-    __shared__ float dwl[CTC][KS + 1];     // [..][KS] = dbias
+    __shared__ __attribute__((aligned(16))) float smem[2][ROWS][CTC];
+    float (*dpt)[CTC] = smem[0];        // d(pre-activation), frame n0 - PAD + j
+    float (*xt)[CTC] = smem[1];         // masked input,      frame n0 - PAD + j
+    static_assert(4 * (KS + 1) * CTC <= 2 * ROWS * CTC, "the gradient staging reuses the tile buffers");
     const int tid = threadIdx.x;
     const int c0 = blockIdx.y * CTC, b = blockIdx.z;
     const int cp = tid & 31, fg = tid >> 5;
     const int ch = c0 + cp * 2;
-    for (int i = tid; i < CTC * (KS + 1); i += 256) (&dwl[0][0])[i] = 0.f;
     // channel pair (ch, ch+1) lives in the two halves of 64-bit register pairs: every FMA below is one v_pk_fma_f32
     // whose operands are already adjacent (separate per-channel arrays cost a v_mov per operand to form the pairs)
     f32x2_ w[KS];     // flipped
@@ -463,6 +465,7 @@ __global__ __launch_bounds__(256, 2) void dwconv_bwd_kernel(ConvArgs p) {
             }
         }
         __syncthreads();
+        if (p.tune & 2) continue;
         // dx[o] = sum_k' wflip[k'] dp_tile[o + k']
         f32x2_ a[8];
 #pragma unroll
@@ -502,15 +505,27 @@ __global__ __launch_bounds__(256, 2) void dwconv_bwd_kernel(ConvArgs p) {
         }
     }
     __syncthreads();
+    if (p.tune & 1) return;
+    // (dw, dbias) of the workgroup: the two frame groups of a wave (lanes l, l + 32: same channel pair) are added with a
+    // shuffle, the four waves through plain LDS stores into the (now free) tile buffers.  LDS float atomics here
+    // (8 adds per address) cost 42 of the kernel's 84 us at the cfg3 audio shape (tools/probes/conv_ablate.py).
+    float (*stage)[KS + 1][CTC] = reinterpret_cast<float (*)[KS + 1][CTC]>(&smem[0][0][0]);
+    const int wv = tid >> 6, lane = tid & 63;
 #pragma unroll
-    for (int k = 0; k < KS; ++k) { atomicAdd(&dwl[cp * 2][k], gw[k][0]); atomicAdd(&dwl[cp * 2 + 1][k], gw[k][1]); }
-    atomicAdd(&dwl[cp * 2][KS], sb[0]);
-    atomicAdd(&dwl[cp * 2 + 1][KS], sb[1]);
+    for (int k = 0; k <= KS; ++k) {
+        const f32x2_ g = k < KS ? gw[k < KS ? k : 0] : sb;
+        const float s0 = g[0] + __shfl_xor(g[0], 32), s1 = g[1] + __shfl_xor(g[1], 32);
+        if (lane < 32) st<f32x2_>(&stage[wv][k][cp * 2], f32x2_{s0, s1});
+    }
     __syncthreads();
+    // 512 workgroups x 2080 fp32 atomics on 32-fold shared addresses were more than half of this kernel's time (45 of 84 us
+    // at the cfg3 audio shape, tools/probes/conv_ablate.py): the partials go to a workspace, conv_reduce_kernel adds them up
+    float* wsb = p.ws ? p.ws + (((long)blockIdx.z * gridDim.y + blockIdx.y) * gridDim.x + blockIdx.x) * (CTC * (KS + 1)) : nullptr;
     for (int i = tid; i < CTC * (KS + 1); i += 256) {
-        int c = i / (KS + 1), k = i % (KS + 1);
-        float v = dwl[c][k];
-        if (k < KS) atomicAdd(p.dw + (long)(c0 + c) * KS + k, v);
+        int k = i / CTC, c = i % CTC;
+        float v = (stage[0][k][c] + stage[1][k][c]) + (stage[2][k][c] + stage[3][k][c]);
+        if (wsb) wsb[i] = v;
+        else if (k < KS) atomicAdd(p.dw + (long)(c0 + c) * KS + k, v);
         else atomicAdd(p.dbias + c0 + c, v);
     }
 }
@@ -593,7 +608,7 @@ __global__ __launch_bounds__(256) void dwconv_bwd_dw_kernel(ConvArgs p) {
     constexpr int PAD = KS / 2, ROWS = CTN + KS - 1;
     __shared__ __attribute__((aligned(16))) float dpc[CTN][CTC];        // d(pre-activation) of the tile's own frames
     __shared__ __attribute__((aligned(16))) float xt[ROWS][CTC];        // masked input, frame n0 - PAD + j
-    __shared__ float dwl[CTC][KS + 1];     // [..][KS] = dbias
+    __shared__ float dwl[KS + 1][CTC];     // [tap][channel] (a wave's 32 channel pairs spread over the banks; [channel][tap] put them all on one), [KS][..] = dbias
     const int tid = threadIdx.x;
     const int c0 = blockIdx.y * CTC, b = blockIdx.z;
     const int cp = tid & 31, fg = tid >> 5;
@@ -682,35 +697,59 @@ __global__ __launch_bounds__(256) void dwconv_bwd_dw_kernel(ConvArgs p) {
     }
     __syncthreads();
 #pragma unroll
-    for (int k = 0; k < KS; ++k) { atomicAdd(&dwl[cp * 2][k], gw[k][0]); atomicAdd(&dwl[cp * 2 + 1][k], gw[k][1]); }
-    atomicAdd(&dwl[cp * 2][KS], sb[0]);
-    atomicAdd(&dwl[cp * 2 + 1][KS], sb[1]);
+    for (int k = 0; k < KS; ++k) { atomicAdd(&dwl[k][cp * 2], gw[k][0]); atomicAdd(&dwl[k][cp * 2 + 1], gw[k][1]); }
+    atomicAdd(&dwl[KS][cp * 2], sb[0]);
+    atomicAdd(&dwl[KS][cp * 2 + 1], sb[1]);
     __syncthreads();
     for (int i = tid; i < CTC * (KS + 1); i += 256) {
-        int c = i / (KS + 1), k = i % (KS + 1);
-        float v = dwl[c][k];
+        int k = i / CTC, c = i % CTC;
+        float v = dwl[k][c];
         if (k < KS) atomicAdd(p.dw + (long)(c0 + c) * KS + k, v);
         else atomicAdd(p.dbias + c0 + c, v);
     }
+}
+
+// dw[c][k] += sum over (batch, x) of the workgroup partials; grid (C / 64, ceil(64 (ks + 1) / 256))
+__global__ __launch_bounds__(256) void conv_reduce_kernel(const float* ws, float* dw, float* dbias, int B, int nct, int gx, int KS) {
+    const int E = CTC * (KS + 1);
+    const int ct = blockIdx.x, i = blockIdx.y * 256 + threadIdx.x;
+    if (i >= E) return;
+    float s = 0.f;
+    for (int b = 0; b < B; ++b)
+        for (int x = 0; x < gx; ++x) s += ws[(((long)b * nct + ct) * gx + x) * E + i];
+    const int k = i / CTC, c = i % CTC;
+    if (k < KS) dw[(long)(ct * CTC + c) * KS + k] += s;
+    else dbias[ct * CTC + c] += s;
+}
+
+int conv_bwd_gx(int B, int N, int C, int tune) {
+    // about 512 workgroups: fewer, longer workgroups cut the traffic of the (dw, dbias) partials
+    const int ntiles = (N + CTN - 1) / CTN, cb = (C / CTC) * B;
+    int gx = (512 + cb - 1) / cb;
+    if (tune >> 7) gx = tune >> 7;
+    if (gx > ntiles) gx = ntiles;
+    if (gx < 1) gx = 1;
+    const int tpb = (ntiles + gx - 1) / gx;
+    return (ntiles + tpb - 1) / tpb;          // workgroups along x actually launched
 }
 
 template <int KS> int launch_conv(ConvArgs a, bool bwd, hipStream_t st) {
     const int ntiles = (a.N + CTN - 1) / CTN;
     dim3 grid(ntiles, a.C / CTC, a.B), block(256);
     if (bwd) {
-        // about 512 workgroups: fewer, longer workgroups cut the atomic traffic on dw / dbias
-        const int cb = (a.C / CTC) * a.B;
-        int gx = (512 + cb - 1) / cb;
-        if (gx > ntiles) gx = ntiles;
-        if (gx < 1) gx = 1;
-        a.tiles_per_block = (ntiles + gx - 1) / gx;
+        const int gxl = conv_bwd_gx(a.B, a.N, a.C, a.tune);
+        a.tiles_per_block = (ntiles + gxl - 1) / gxl;
         if (a.split) {
+            a.ws = nullptr;
             hipLaunchKernelGGL(dwconv_bwd_dx_kernel<KS>, grid, block, 0, st, a);
             grid.x = (ntiles + a.tiles_per_block - 1) / a.tiles_per_block;
             hipLaunchKernelGGL(dwconv_bwd_dw_kernel<KS>, grid, block, 0, st, a);
         } else {
             grid.x = (ntiles + a.tiles_per_block - 1) / a.tiles_per_block;
             hipLaunchKernelGGL(dwconv_bwd_kernel<KS>, grid, block, 0, st, a);
+            if (a.ws && !(a.tune & 1))
+                hipLaunchKernelGGL(conv_reduce_kernel, dim3(a.C / CTC, (CTC * (KS + 1) + 255) / 256), dim3(256), 0, st,
+                                   (const float*)a.ws, a.dw, a.dbias, a.B, a.C / CTC, (int)grid.x, KS);
         }
     } else {
         hipLaunchKernelGGL(dwconv_fwd_kernel<KS>, grid, block, 0, st, a);
@@ -849,12 +888,12 @@ static int dwconv_fwd_impl(const void* x, const uint8_t* mask, const float* w, c
 }
 
 static int dwconv_bwd_impl(const void* dy, const void* pre, const void* x, const uint8_t* mask, const float* w,
-                              void* dx, float* dw, float* dbias, int B, int N, int C, int ks, int split, void* stream) {
+                              void* dx, float* dw, float* dbias, float* ws, int B, int N, int C, int ks, int split, void* stream) {
     if (B <= 0 || N <= 0) return 0;
     if (C % CTC) return E2K_ERR_SHAPE;
     ConvArgs a{};
     a.x = (const bf16_t*)x; a.mask = mask; a.w = w; a.pre = (bf16_t*)pre; a.dy = (const bf16_t*)dy;
-    a.dx = (bf16_t*)dx; a.dw = dw; a.dbias = dbias; a.B = B; a.N = N; a.C = C; a.split = split != 0;
+    a.dx = (bf16_t*)dx; a.dw = dw; a.dbias = dbias; a.ws = ws; a.B = B; a.N = N; a.C = C; a.split = (split & 1) != 0; a.tune = split >> 1;
     int rc = dispatch_conv(a, ks, true, (hipStream_t)stream);
     if (rc) return rc;
     E2K_CHECK_LAUNCH();
@@ -910,7 +949,12 @@ extern "C" int e2k_dwconv_fwd(const void* x, const uint8_t* mask, const float* w
     return e2k::dispatch("dwconv_fwd", dwconv_fwd_impl, x, mask, w, bias, pre, y, B, N, C, ks, stream);
 }
 
+extern "C" int e2k_query_dwconv_bwd_ws_floats(int B, int N, int C, int ks) {
+    if (B <= 0 || N <= 0 || C <= 0 || (C % CTC)) return 0;
+    return conv_bwd_gx(B, N, C, 0) * B * (C / CTC) * CTC * (ks + 1);
+}
+
 extern "C" int e2k_dwconv_bwd(const void* dy, const void* pre, const void* x, const uint8_t* mask, const float* w,
-                              void* dx, float* dw, float* dbias, int B, int N, int C, int ks, int split, void* stream) {
-    return e2k::dispatch("dwconv_bwd", dwconv_bwd_impl, dy, pre, x, mask, w, dx, dw, dbias, B, N, C, ks, split, stream);
+                              void* dx, float* dw, float* dbias, float* ws, int B, int N, int C, int ks, int split, void* stream) {
+    return e2k::dispatch("dwconv_bwd", dwconv_bwd_impl, dy, pre, x, mask, w, dx, dw, dbias, ws, B, N, C, ks, split, stream);
 }

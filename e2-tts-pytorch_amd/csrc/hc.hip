@@ -266,7 +266,7 @@ template <int VEC, int NCH, int NW, bool DEPTH, bool WIDTH>
 __global__ __launch_bounds__(256, 3) void hc_bwd_kernel(HCBwdArgs p) {
     constexpr int EPL = VEC * NCH, DS = 64 * EPL, D = DS * NW, TPB = 4 / NW;
     __shared__ __attribute__((aligned(16))) float Wp[WIDTH ? NJ * D : 4];
-    __shared__ __attribute__((aligned(16))) float dWp[WIDTH ? NJ * D + NSC : 4];
+    __shared__ __attribute__((aligned(16))) float dWp[WIDTH ? TPB * (NJ * D + NSC) : 4];      // one d(Wp) + scalars copy per token slot
     __shared__ __attribute__((aligned(16))) float red[2][4][NRED];
     const int tid = threadIdx.x, lane = tid & 63, wave = uniform_i(tid >> 6);
     const int slot = wave / NW, doff = (wave % NW) * DS;
@@ -277,7 +277,6 @@ __global__ __launch_bounds__(256, 3) void hc_bwd_kernel(HCBwdArgs p) {
     float accD = 0.f, accT = 0.f;        // per-lane sums over this wave's tokens: d(static), d(scale) contributions
     if (WIDTH) {
         stage_wp<VEC>(Wp, p.hp, D, tid);
-        for (int i = tid; i < NJ * D + NSC; i += 256) dWp[i] = 0.f;
         if (lact) scale_l = lj < 5 ? p.hp.dyn_alpha_scale[0] : p.hp.dyn_beta_scale[0];
         __syncthreads();
     }
@@ -447,21 +446,38 @@ __global__ __launch_bounds__(256, 3) void hc_bwd_kernel(HCBwdArgs p) {
     for (int it = 0; it < nfull; ++it) body(it, std::false_type{});
     if (nfull < niter) body(nfull, std::true_type{});
     if (WIDTH) {
-        // flush the register accumulators (once per wave): LDS adds, then one row of `partial` per workgroup
+        // flush the register accumulators (once per wave): plain LDS stores into the wave's token slot (every element of a
+        // slot has exactly one owner; LDS float atomics cost ~0.6 us per instruction and workgroup round on this part, see
+        // dwconv_bwd_kernel), the slots are added on the way out: one row of `partial` per workgroup
 #pragma unroll
         for (int j = 0; j < NJ; ++j)
 #pragma unroll
             for (int ch = 0; ch < NCH; ++ch)
 #pragma unroll
                 for (int v = 0; v < VEC; ++v)
-                    atomicAdd(&dWp[j * D + doff + ch * 64 * VEC + lane * VEC + v], gw[j][ch * VEC + v]);
-        if (doff == 0 && lact) {     // scalar gradients: d(static_alpha/beta) = sum of dots, d(scale) = sum of dot * tanh
-            atomicAdd(&dWp[NJ * D + (lj < 5 ? ls * 5 + lj : 20 + ls)], accD);
-            atomicAdd(&dWp[NJ * D + (lj < 5 ? 24 : 25)], accT);
+                    dWp[(slot * NJ + j) * D + doff + ch * 64 * VEC + lane * VEC + v] = gw[j][ch * VEC + v];
+        if (doff == 0) {             // scalar gradients: d(static_alpha/beta) = sum of dots, d(scale) = sum of dot * tanh
+            float* sc = dWp + TPB * NJ * D + slot * NSC;
+            const float ta = wave_sum_fast(lact && lj < 5 ? accT : 0.f), tb = wave_sum_fast(lact && lj == 5 ? accT : 0.f);
+            if (lact) sc[lj < 5 ? ls * 5 + lj : 20 + ls] = accD;        // (one lane per entry)
+            if (lane == 0) { sc[24] = ta; sc[25] = tb; }
+            if (lane >= 26 && lane < NSC) sc[lane] = 0.f;
         }
         __syncthreads();
         float* out = p.partial + (long)blockIdx.x * (NJ * D + NSC);
-        for (int i = tid; i < NJ * D + NSC; i += 256) out[i] = dWp[i];
+        for (int i = tid; i < NJ * D + NSC; i += 256) {
+            float v;
+            if (i < NJ * D) {
+                v = dWp[i];
+#pragma unroll
+                for (int t = 1; t < TPB; ++t) v += dWp[t * NJ * D + i];
+            } else {
+                v = dWp[TPB * NJ * D + (i - NJ * D)];
+#pragma unroll
+                for (int t = 1; t < TPB; ++t) v += dWp[TPB * NJ * D + t * NSC + (i - NJ * D)];
+            }
+            out[i] = v;
+        }
     }
 }
 

@@ -321,9 +321,9 @@ class Transformer(Module):
         self._rot_cache = {}
         self._plans_on = getattr(self, '_plans_on', True)       # enable_plans(): record-and-replay of the launch schedule
         self._max_plans = getattr(self, '_max_plans', 4)
-        self._lane_mask = int(_os.environ.get('E2K_LANES', '0')) or 3   # bit 0: TEXT lane, bit 1: WGRAD lane (A/B, fault isolation)
-        self._lanes_on = getattr(self, '_lanes_on', _os.environ.get('E2K_LANES', '0') != '0')      # enable_lanes(); OFF by default
-        self._lanes_bwd = getattr(self, '_lanes_bwd', _os.environ.get('E2K_LANES_BWD', '0') != '0')
+        self._lane_mask = int(_os.environ.get('E2K_LANES', '3')) or 3   # bit 0: TEXT lane, bit 1: WGRAD lane (A/B, fault isolation)
+        self._lanes_on = getattr(self, '_lanes_on', _os.environ.get('E2K_LANES', '3') != '0')      # enable_lanes(); E2K_LANES=0 turns them off
+        self._lanes_bwd = getattr(self, '_lanes_bwd', _os.environ.get('E2K_LANES_BWD', '1') != '0')
         self.__dict__.pop('_lane_ss', None)
         self._plans = {}
         self._plan_tick = 0
@@ -614,12 +614,12 @@ class Transformer(Module):
         return self
 
     def enable_lanes(self, on: bool = True, backward: bool | None = None):
-        """Launch lanes (EXPERIMENTAL, off by default; E2K_LANES=3 / E2K_LANES_BWD=1 in the environment): the text
-        stream's branches run on a side stream next to the audio stream's chain and, with `backward=True`, the
+        """Launch lanes (default: on; E2K_LANES=0 in the environment turns them off, E2K_LANES_BWD=0 only those of the
+        backward pass): the text stream's branches run on a side stream next to the audio stream's chain and the
         weight-gradient GEMMs of the backward pass on a third one (ops.Lanes; csrc/plan.h for recorded plans).  Measured
-        on MI355X at cfg3: 114 -> 98 ms per step with both, nothing with the forward alone.  Not a default because
-        hc_bwd_kernel does not reproduce its own results next to a concurrent LDS-DMA GEMM (see _backward_gen and
-        DESIGN.md section 5.1).  Plans recorded under another setting are dropped."""
+        on MI355X at cfg3: 114 -> 98 ms per step.  Results are those of the single-stream schedule (bit for bit for
+        outputs and input gradients: tests/test_backbone.py::test_launch_lanes_match_single_stream).  Plans recorded
+        under another setting are dropped."""
         bw = self._lanes_bwd if backward is None else bool(backward)
         if bool(on) != self._lanes_on or bw != self._lanes_bwd:
             self._drop_plans()
@@ -1090,10 +1090,8 @@ class Transformer(Module):
                    't': ops.zeros((B, self.text_heads, N, 64), f32, dev) if run.has_text else None}
         skip_grads = []
 
-        # (backward lanes are OFF by default: hc_bwd_kernel returns slightly different results -- a few tokens, last bits of
-        # bf16 -- whenever a weight-gradient GEMM runs next to it on another stream, with disjoint data and unchanged inputs;
-        # tools/probes/hc_concurrent.py reproduces it, the cause is not understood yet.  The forward
-        # pass has no such kernel: its results with lanes are bit-identical to the single-stream schedule.)
+        # (history: with LDS float atomics in its gradient flush hc_bwd_kernel did not reproduce its own results next to an
+        # LDS-DMA GEMM on another stream -- tools/probes/hc_concurrent.py; no kernel uses them now)
         Ln = run.blanes = ops.Lanes(dev, self._lane_streams(dev) if (run.lanes.on and self._lanes_bwd) else [], self._lane_mask)
         hold = [[], []]           # operands of the weight-gradient GEMMs of [this layer, the layer before]
 

@@ -494,8 +494,10 @@ def dwconv_bwd(dy, pre, x, mask, w, dw, dbias):
     ks = w.shape[-1]
     assert dy.is_contiguous() and dw.dtype == f32 and dbias.dtype == f32
     dx = torch.empty_like(x)
-    _lib.get().e2k_dwconv_bwd(_p(dy), _p(pre), _p(x), _p(mask), _p(w), _p(dx), _p(dw), _p(dbias), B, N, C, ks,
-                              int(dwconv_split_bwd), _stream(x))
+    L = _lib.get()
+    ws = None if dwconv_split_bwd else torch.empty((L.e2k_query_dwconv_bwd_ws_floats(B, N, C, ks),), dtype=f32, device=x.device)
+    L.e2k_dwconv_bwd(_p(dy), _p(pre), _p(x), _p(mask), _p(w), _p(dx), _p(dw), _p(dbias), _p(ws), B, N, C, ks,
+                     int(dwconv_split_bwd), _stream(x))
     return dx
 
 
