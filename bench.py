@@ -224,9 +224,14 @@ def main():
     # the very plan the timed region ran, one event after each call); the committed rocprofv3 summary (profiles/) must
     # agree with these averages.  With --eager the NT launches are bracketed by torch events instead.
     prof_rows, nprof = [], 2
+    lane_ops = 0
     if not args.eager:
         for _ in range(nprof):
             prof_rows += tr.plan_profile()
+        # (the profiled replay runs on ONE stream: the lane ordering points are skipped there and drop out of the tables;
+        # the per-call times are those of each kernel running alone, their sum exceeds the step time when lanes overlap)
+        lane_ops = sum(r['name'].startswith('lane_event') for r in prof_rows) // nprof
+        prof_rows = [r for r in prof_rows if not r['name'].startswith('lane_event')]
         gemm = [r for r in prof_rows if r['name'] == 'gemm_nt_bf16']
         gemm_flops, gemm_ms, n_launch = sum(r['flops'] for r in gemm), sum(r['ms'] for r in gemm), len(gemm)
     else:
@@ -293,6 +298,8 @@ def main():
             'host_enqueue_ms_per_step': t_enqueue / args.steps * 1e3,
             'launch_mode': launch_mode_note, 'gemm_flags': ops.gemm_flags,
             'launches_per_step': (len(prof_rows) // nprof) if prof_rows else None,
+            'launch_lanes': {'on': bool(getattr(tr, '_lanes_on', False)), 'backward': bool(getattr(tr, '_lanes_bwd', False)), 'ordering_points_per_step': lane_ops,
+                             'note': 'text branches / weight-gradient GEMMs on side streams (ops.Lanes, csrc/plan.h); E2K_LANES=0 for the single-stream schedule'},
             'kernel_groups_ms_per_step': _groups(prof_rows, nprof) if prof_rows else None,
             'roofline': {
                 'bound': 'mfma', 'kernel': 'e2k_gemm_nt_bf16: gemm_nt_256_kernel (256x256x64, 8-phase) / gemm_nt_glds_kernel (128x128x64) + fix-ups (bf16 MFMA 16x16x32; every forward and dgrad GEMM of the step)',
