@@ -196,16 +196,18 @@ __global__ __launch_bounds__(256) void qkv_post_fwd_kernel(PostArgs p) {
     }
 #pragma unroll
     for (int e = 0; e < 16; ++e) {
-        tT[0][seg * 16 + e][tok] = f2bf(q[e]);
-        tT[1][seg * 16 + e][tok] = f2bf(k[e]);
+        if (p.QT) tT[0][seg * 16 + e][tok] = f2bf(q[e]);
+        if (p.KT) tT[1][seg * 16 + e][tok] = f2bf(k[e]);
         tT[2][seg * 16 + e][tok] = f2bf(v[e]);
     }
     __syncthreads();
-    // transposed copies: thread writes 16 consecutive tokens of one dh row
+    // transposed copies: thread writes 16 consecutive tokens of one dh row (Q^T, K^T only for the register-staged backward
+    // kernels: the ring kernels read them out of the row-major tiles with transposing LDS reads)
     const int d = tid >> 2, ts = (tid & 3) * 16;
     bf16_t* outs[3] = {p.QT, p.KT, p.VT};
 #pragma unroll
     for (int w = 0; w < 3; ++w) {
+        if (!outs[w]) continue;
         bf16_t* dst = outs[w] + (bh * DH + d) * p.Npad + n0 + ts;
         st<u32x4>(dst, ld<u32x4>(&tT[w][d][ts]));
         st<u32x4>(dst + 8, ld<u32x4>(&tT[w][d][ts + 8]));
@@ -698,6 +700,7 @@ __global__ __launch_bounds__(256) void attn_bwd_prep_kernel(AttnArgs p) {
         const long o = (bh * p.N + n) * DH + seg * 16;
         st<u32x4>(p.dO + o, pack8(d)); st<u32x4>(p.dO + o + 8, pack8(d + 8));
     }
+    if (!p.dOT) return;            // (wave-uniform; only the register-staged dK,dV kernel reads dO^T)
 #pragma unroll
     for (int e = 0; e < 16; ++e) tT[seg * 16 + e][tok] = f2bf(d[e]);
     __syncthreads();
@@ -1369,7 +1372,7 @@ static int qkv_post_fwd_impl(const void* qkvg, int64_t ldq, const float* cosb, c
                                 int B, int H, int N, int Npad, void* stream) {
     if (B <= 0 || N <= 0) return 0;
     if ((ldq & 7) || (Npad & 63) || Npad < N) return E2K_ERR_ALIGN;
-    if (!qkvg || !cosb || !sinb || !Q || !K || !V || !QT || !KT || !VT || !gate || (vfirst && !mix)) return E2K_ERR_ARG;
+    if (!qkvg || !cosb || !sinb || !Q || !K || !V || !VT || !gate || (vfirst && !mix)) return E2K_ERR_ARG;     // (QT, KT: optional)
     PostArgs a{};
     a.qkvg = (const bf16_t*)qkvg; a.ldq = ldq; a.cosb = cosb; a.sinb = sinb; a.vfirst = (const bf16_t*)vfirst;
     a.Q = (bf16_t*)Q; a.K = (bf16_t*)K; a.V = (bf16_t*)V; a.QT = (bf16_t*)QT; a.KT = (bf16_t*)KT; a.VT = (bf16_t*)VT;
@@ -1406,6 +1409,11 @@ static int fill_attn(AttnArgs& a, int B, int H, int N, int Npad, float p_drop, u
     a.thresh = (unsigned)(p_drop * 65536.f + 0.5f);
     a.inv_keep = 1.f / (1.f - p_drop);
     return 0;
+}
+
+extern "C" int e2k_query_attn_bwd_transposes(int Npad, int flags) {
+    const bool staged = (flags & (E2K_ATTN_WG128 | E2K_ATTN_NO_RING)) != 0;
+    return ((staged || Npad > RKM) ? 1 : 0) | (staged ? 2 : 0);
 }
 
 extern "C" int e2k_query_attn_dropbits_bytes(int B, int H, int N) {
@@ -1468,8 +1476,10 @@ static int attn_bwd_impl(const void* dOg, const void* O, const float* gate, cons
                             void* dV, int B, int H, int N, int Npad, float p_drop, uint32_t seed, const uint32_t* seed_dev,
                             uint32_t stream_id, int flags, void* stream) {
     if (B <= 0 || N <= 0) return 0;
-    if (!dOg || !O || !gate || !lse2 || !Q || !K || !V || !QT || !KT || !kmask || !dO || !dOT || !delta || !dgate_pre ||
-        !dQ || !dK || !dV) return E2K_ERR_ARG;
+    if (!dOg || !O || !gate || !lse2 || !Q || !K || !V || !kmask || !dO || !delta || !dgate_pre || !dQ || !dK || !dV) return E2K_ERR_ARG;
+    const int need = e2k_query_attn_bwd_transposes(Npad, flags);      // 1: KT (register-staged dQ), 2: QT and dOT (register-staged dK,dV)
+    if (((need & 1) && !KT) || ((need & 2) && (!QT || !dOT))) return E2K_ERR_ARG;
+    if (!(need & 2)) dOT = nullptr;
     AttnArgs a{};
     int rc = fill_attn(a, B, H, N, Npad, p_drop, seed, seed_dev, stream_id);
     if (rc) return rc;

@@ -523,7 +523,10 @@ def qkv_post_fwd(qkvg, B, H, N, cosb, sinb, vfirst=None):
     st = AttnState()
     st.B, st.H, st.N, st.Npad, st.dropbits = B, H, N, Npad, None
     st.Q, st.K, st.V = (torch.empty((B, H, N, 64), dtype=bf16, device=dev) for _ in range(3))
-    st.QT, st.KT, st.VT = (torch.empty((B, H, 64, Npad), dtype=bf16, device=dev) for _ in range(3))
+    need = _lib.get().e2k_query_attn_bwd_transposes(Npad, attn_probe & (64 | 128))
+    st.VT = torch.empty((B, H, 64, Npad), dtype=bf16, device=dev)
+    st.KT = torch.empty((B, H, 64, Npad), dtype=bf16, device=dev) if need & 1 else None
+    st.QT = torch.empty((B, H, 64, Npad), dtype=bf16, device=dev) if need & 2 else None
     st.gate = torch.empty((B, H, N), dtype=f32, device=dev)
     st.mix = torch.empty((B, H, N), dtype=f32, device=dev) if vfirst is not None else None
     _lib.get().e2k_qkv_post_fwd(_p(qkvg), qkvg.stride(0), _p(cosb), _p(sinb), _p(vfirst), _p(st.Q), _p(st.K), _p(st.V),
@@ -566,7 +569,7 @@ def attn_bwd(st, dOg, kmask_pad, p_drop=0., seed=0, stream_id=0, seed_dev=None):
     dev = st.Q.device
     assert dOg.dtype == bf16 and dOg.is_contiguous() and dOg.shape == (B * N, H * 64)
     dO = torch.empty((B, H, N, 64), dtype=bf16, device=dev)
-    dOT = torch.empty((B, H, 64, Npad), dtype=bf16, device=dev)
+    dOT = torch.empty((B, H, 64, Npad), dtype=bf16, device=dev) if st.QT is not None else None
     delta = torch.empty((B, H, N), dtype=f32, device=dev)
     dgate = torch.empty((B, H, N), dtype=f32, device=dev)
     dQ, dK, dV = (torch.empty((B, H, N, 64), dtype=bf16, device=dev) for _ in range(3))

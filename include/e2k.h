@@ -176,6 +176,12 @@ int e2k_attn_fwd(const void* Q, const void* K, const void* VT, const uint8_t* km
  * e2k_query_attn_dropbits_bytes(B, H, N) bytes in which the forward leaves its keep decisions as 64-bit wave ballot words
  * and from which the backward kernels read them back.  Same mask either way (bit-identical results). */
 int e2k_query_attn_dropbits_bytes(int B, int H, int N);
+/* Which transposed copies the backward needs: bit 0 = KT (the register-staged dQ kernel: flags E2K_ATTN_NO_RING /
+ * E2K_ATTN_WG128, or Npad > 4096), bit 1 = QT and dOT (the register-staged dK,dV kernel: those flags).  The default
+ * (LDS-DMA ring) kernels read K^T / Q^T / dO^T out of the row-major tiles with ds_read_b64_tr_b16: e2k_qkv_post_fwd
+ * then takes QT = KT = NULL and e2k_attn_bwd dOT = NULL (17 MB less written per transposed copy at the cfg3 shape). */
+int e2k_query_attn_bwd_transposes(int Npad, int flags);
+
 /* backward: dOg (B*N, H*64) -> dQ, dK, dV (B,H,N,64), dgate_pre (B,H,N).  dO, dOT, delta are scratch outputs. */
 int e2k_attn_bwd(const void* dOg, const void* O, const float* gate, const float* lse2, const void* Q,
                  const void* K, const void* V, const void* QT, const void* KT, const uint8_t* kmask,
