@@ -327,7 +327,6 @@ struct ConvArgs {
     const bf16_t* dy; bf16_t* dx; float* dw; float* dbias;
     float* ws;          // backward: per-workgroup (dw, dbias) partials [b][channel tile][x][64][ks + 1], or NULL (atomics)
     int B, N, C, tiles_per_block;
-    int split;          // backward: 1 = separate dx and (dw, dbias) kernels
     int tune;           // backward tuning / ablation bits (e2k_dwconv_bwd `split` argument >> 1): 1 = no gradient flush, 2 = no arithmetic; >> 7: workgroups per (channel tile, batch)
 };
 
@@ -530,185 +529,6 @@ __global__ __launch_bounds__(256, 2) void dwconv_bwd_kernel(ConvArgs p) {
     }
 }
 
-// Split form of the backward (opt-in, e2k_dwconv_bwd(..., split = 1)): the fused kernel above keeps 62 weight and 62 gradient
-// registers per lane alive at once (234 VGPRs, two workgroups per CU) and runs its phases back to back; here dx and
-// (dw, dbias) are two kernels of ~half the register state each, at the price of reading dy / pre twice.
-
-template <int KS>
-__global__ __launch_bounds__(256) void dwconv_bwd_dx_kernel(ConvArgs p) {
-    constexpr int PAD = KS / 2, ROWS = CTN + KS - 1;
-    __shared__ __attribute__((aligned(16))) float dpt[ROWS][CTC];       // d(pre-activation), frame n0 - PAD + j
-    const int tid = threadIdx.x;
-    const int n0 = blockIdx.x * CTN, c0 = blockIdx.y * CTC, b = blockIdx.z;
-    {
-        constexpr int ITEMS = ROWS * (CTC / 8), NIT = (ITEMS + 255) / 256;
-        u32x4 rd[NIT], rp[NIT];
-        bool live[NIT];
-#pragma unroll
-        for (int it = 0; it < NIT; ++it) {
-            const int i = tid + it * 256;
-            const int j = i / (CTC / 8), c8 = (i % (CTC / 8)) * 8;
-            const int n = n0 - PAD + j;
-            const int nc = min(max(n, 0), p.N - 1);
-            const long off = ((long)b * p.N + nc) * p.C + c0 + c8;
-            rd[it] = ld<u32x4>(p.dy + off);
-            rp[it] = ld<u32x4>(p.pre + off);
-            const unsigned char mk = p.mask ? p.mask[(long)b * p.N + nc] : (unsigned char)1;
-            live[it] = i < ITEMS && n >= 0 && n < p.N && mk != 0;
-        }
-#pragma unroll
-        for (int it = 0; it < NIT; ++it) {
-            const int i = tid + it * 256;
-            if (i >= ITEMS) continue;
-            const int j = i / (CTC / 8), c8 = (i % (CTC / 8)) * 8;
-            float d[8];
-#pragma unroll
-            for (int e = 0; e < 8; ++e) d[e] = 0.f;
-            if (live[it]) {
-                float pr[8];
-                unpack8(rd[it], d);
-                unpack8(rp[it], pr);
-#pragma unroll
-                for (int e = 0; e < 8; ++e) d[e] *= silu_grad(pr[e]);
-            }
-            st<f32x4>(&dpt[j][c8], f32x4{d[0], d[1], d[2], d[3]});
-            st<f32x4>(&dpt[j][c8 + 4], f32x4{d[4], d[5], d[6], d[7]});
-        }
-    }
-    const int cp = tid & 31, fg = tid >> 5;
-    const int ch = c0 + cp * 2;
-    f32x2_ w[KS];     // flipped
-#pragma unroll
-    for (int k = 0; k < KS; ++k) w[k] = f32x2_{p.w[(long)ch * KS + (KS - 1 - k)], p.w[(long)(ch + 1) * KS + (KS - 1 - k)]};
-    __syncthreads();
-    f32x2_ a[8];
-#pragma unroll
-    for (int o = 0; o < 8; ++o) a[o] = f32x2_{0.f, 0.f};
-#pragma unroll
-    for (int i = 0; i < 8 + KS - 1; ++i) {
-        const f32x2_ dd = ld<f32x2_>(&dpt[fg * 8 + i][cp * 2]);
-#pragma unroll
-        for (int o = 0; o < 8; ++o) {
-            const int k = i - o;
-            if (k >= 0 && k < KS) a[o] = __builtin_elementwise_fma(w[k], dd, a[o]);
-        }
-    }
-#pragma unroll
-    for (int o = 0; o < 8; ++o) {
-        const int n = n0 + fg * 8 + o;
-        if (n < p.N) {
-            const bool keep = p.mask == nullptr || p.mask[(long)b * p.N + n];
-            st<unsigned>(p.dx + ((long)b * p.N + n) * p.C + ch, keep ? pack2bf(a[o][0], a[o][1]) : 0u);
-        }
-    }
-}
-
-template <int KS>
-__global__ __launch_bounds__(256) void dwconv_bwd_dw_kernel(ConvArgs p) {
-    constexpr int PAD = KS / 2, ROWS = CTN + KS - 1;
-    __shared__ __attribute__((aligned(16))) float dpc[CTN][CTC];        // d(pre-activation) of the tile's own frames
-    __shared__ __attribute__((aligned(16))) float xt[ROWS][CTC];        // masked input, frame n0 - PAD + j
-    __shared__ float dwl[KS + 1][CTC];     // [tap][channel] (a wave's 32 channel pairs spread over the banks; [channel][tap] put them all on one), [KS][..] = dbias
-    const int tid = threadIdx.x;
-    const int c0 = blockIdx.y * CTC, b = blockIdx.z;
-    const int cp = tid & 31, fg = tid >> 5;
-    for (int i = tid; i < CTC * (KS + 1); i += 256) (&dwl[0][0])[i] = 0.f;
-    f32x2_ gw[KS], sb = {0.f, 0.f};
-#pragma unroll
-    for (int k = 0; k < KS; ++k) gw[k] = f32x2_{0.f, 0.f};
-    const int ntiles = (p.N + CTN - 1) / CTN;
-    const int t_beg = blockIdx.x * p.tiles_per_block, t_end = min(ntiles, t_beg + p.tiles_per_block);
-    for (int tile = t_beg; tile < t_end; ++tile) {
-        const int n0 = tile * CTN;
-        __syncthreads();                  // previous tile fully consumed (also orders the dwl zero-fill)
-        {
-            constexpr int IX = ROWS * (CTC / 8), NX = (IX + 255) / 256, ID = CTN * (CTC / 8), ND = ID / 256;
-            u32x4 rx[NX], rd[ND], rp[ND];
-            bool lx[NX], ldv[ND];
-#pragma unroll
-            for (int it = 0; it < NX; ++it) {
-                const int i = tid + it * 256;
-                const int j = i / (CTC / 8), c8 = (i % (CTC / 8)) * 8;
-                const int n = n0 - PAD + j;
-                const int nc = min(max(n, 0), p.N - 1);
-                rx[it] = ld<u32x4>(p.x + ((long)b * p.N + nc) * p.C + c0 + c8);
-                const unsigned char mk = p.mask ? p.mask[(long)b * p.N + nc] : (unsigned char)1;
-                lx[it] = i < IX && n >= 0 && n < p.N && mk != 0;
-            }
-#pragma unroll
-            for (int it = 0; it < ND; ++it) {
-                const int i = tid + it * 256;
-                const int j = i / (CTC / 8), c8 = (i % (CTC / 8)) * 8;
-                const int n = n0 + j;
-                const int nc = min(n, p.N - 1);
-                const long off = ((long)b * p.N + nc) * p.C + c0 + c8;
-                rd[it] = ld<u32x4>(p.dy + off);
-                rp[it] = ld<u32x4>(p.pre + off);
-                const unsigned char mk = p.mask ? p.mask[(long)b * p.N + nc] : (unsigned char)1;
-                ldv[it] = n < p.N && mk != 0;
-            }
-#pragma unroll
-            for (int it = 0; it < NX; ++it) {
-                const int i = tid + it * 256;
-                if (i >= IX) continue;
-                const int j = i / (CTC / 8), c8 = (i % (CTC / 8)) * 8;
-                float x[8];
-#pragma unroll
-                for (int e = 0; e < 8; ++e) x[e] = 0.f;
-                if (lx[it]) unpack8(rx[it], x);
-                st<f32x4>(&xt[j][c8], f32x4{x[0], x[1], x[2], x[3]});
-                st<f32x4>(&xt[j][c8 + 4], f32x4{x[4], x[5], x[6], x[7]});
-            }
-#pragma unroll
-            for (int it = 0; it < ND; ++it) {
-                const int i = tid + it * 256;
-                const int j = i / (CTC / 8), c8 = (i % (CTC / 8)) * 8;
-                float d[8];
-#pragma unroll
-                for (int e = 0; e < 8; ++e) d[e] = 0.f;
-                if (ldv[it]) {
-                    float pr[8];
-                    unpack8(rd[it], d);
-                    unpack8(rp[it], pr);
-#pragma unroll
-                    for (int e = 0; e < 8; ++e) d[e] *= silu_grad(pr[e]);
-                }
-                st<f32x4>(&dpc[j][c8], f32x4{d[0], d[1], d[2], d[3]});
-                st<f32x4>(&dpc[j][c8 + 4], f32x4{d[4], d[5], d[6], d[7]});
-            }
-        }
-        __syncthreads();
-        // dw[k] += sum_o dp[o] * x_tile[o + k]
-        f32x2_ dq[8];
-#pragma unroll
-        for (int o = 0; o < 8; ++o) {
-            dq[o] = ld<f32x2_>(&dpc[fg * 8 + o][cp * 2]);
-            sb += dq[o];
-        }
-#pragma unroll
-        for (int i = 0; i < 8 + KS - 1; ++i) {
-            const f32x2_ xx = ld<f32x2_>(&xt[fg * 8 + i][cp * 2]);
-#pragma unroll
-            for (int o = 0; o < 8; ++o) {
-                const int k = i - o;
-                if (k >= 0 && k < KS) gw[k] = __builtin_elementwise_fma(dq[o], xx, gw[k]);
-            }
-        }
-    }
-    __syncthreads();
-#pragma unroll
-    for (int k = 0; k < KS; ++k) { atomicAdd(&dwl[k][cp * 2], gw[k][0]); atomicAdd(&dwl[k][cp * 2 + 1], gw[k][1]); }
-    atomicAdd(&dwl[KS][cp * 2], sb[0]);
-    atomicAdd(&dwl[KS][cp * 2 + 1], sb[1]);
-    __syncthreads();
-    for (int i = tid; i < CTC * (KS + 1); i += 256) {
-        int k = i / CTC, c = i % CTC;
-        float v = dwl[k][c];
-        if (k < KS) atomicAdd(p.dw + (long)(c0 + c) * KS + k, v);
-        else atomicAdd(p.dbias + c0 + c, v);
-    }
-}
-
 // dw[c][k] += sum over (batch, x) of the workgroup partials; grid (C / 64, ceil(64 (ks + 1) / 256))
 __global__ __launch_bounds__(256) void conv_reduce_kernel(const float* ws, float* dw, float* dbias, int B, int nct, int gx, int KS) {
     const int E = CTC * (KS + 1);
@@ -739,12 +559,7 @@ template <int KS> int launch_conv(ConvArgs a, bool bwd, hipStream_t st) {
     if (bwd) {
         const int gxl = conv_bwd_gx(a.B, a.N, a.C, a.tune);
         a.tiles_per_block = (ntiles + gxl - 1) / gxl;
-        if (a.split) {
-            a.ws = nullptr;
-            hipLaunchKernelGGL(dwconv_bwd_dx_kernel<KS>, grid, block, 0, st, a);
-            grid.x = (ntiles + a.tiles_per_block - 1) / a.tiles_per_block;
-            hipLaunchKernelGGL(dwconv_bwd_dw_kernel<KS>, grid, block, 0, st, a);
-        } else {
+        {
             grid.x = (ntiles + a.tiles_per_block - 1) / a.tiles_per_block;
             hipLaunchKernelGGL(dwconv_bwd_kernel<KS>, grid, block, 0, st, a);
             if (a.ws && !(a.tune & 1))
@@ -891,9 +706,10 @@ static int dwconv_bwd_impl(const void* dy, const void* pre, const void* x, const
                               void* dx, float* dw, float* dbias, float* ws, int B, int N, int C, int ks, int split, void* stream) {
     if (B <= 0 || N <= 0) return 0;
     if (C % CTC) return E2K_ERR_SHAPE;
+    if (split & 1) return E2K_ERR_ARG;          // (the two-kernel form of round 1 is gone: it was slower and used LDS float atomics)
     ConvArgs a{};
     a.x = (const bf16_t*)x; a.mask = mask; a.w = w; a.pre = (bf16_t*)pre; a.dy = (const bf16_t*)dy;
-    a.dx = (bf16_t*)dx; a.dw = dw; a.dbias = dbias; a.ws = ws; a.B = B; a.N = N; a.C = C; a.split = (split & 1) != 0; a.tune = split >> 1;
+    a.dx = (bf16_t*)dx; a.dw = dw; a.dbias = dbias; a.ws = ws; a.B = B; a.N = N; a.C = C; a.tune = split >> 1;
     int rc = dispatch_conv(a, ks, true, (hipStream_t)stream);
     if (rc) return rc;
     E2K_CHECK_LAUNCH();

@@ -484,8 +484,9 @@ def dwconv_fwd(x, mask, w, bias):
     return pre, y
 
 
-# A/B switch (not measured on hardware yet): run the depthwise-conv backward as a dx kernel + a (dw, dbias) kernel
-dwconv_split_bwd = False
+# False: the (dw, dbias) partials of the depthwise-conv backward go through global fp32 atomics instead of a workspace +
+# reduce pass (A/B; the C ABI accepts ws = NULL)
+dwconv_bwd_workspace = True
 
 
 def dwconv_bwd(dy, pre, x, mask, w, dw, dbias):
@@ -495,9 +496,9 @@ def dwconv_bwd(dy, pre, x, mask, w, dw, dbias):
     assert dy.is_contiguous() and dw.dtype == f32 and dbias.dtype == f32
     dx = torch.empty_like(x)
     L = _lib.get()
-    ws = None if dwconv_split_bwd else torch.empty((L.e2k_query_dwconv_bwd_ws_floats(B, N, C, ks),), dtype=f32, device=x.device)
+    ws = torch.empty((L.e2k_query_dwconv_bwd_ws_floats(B, N, C, ks),), dtype=f32, device=x.device) if dwconv_bwd_workspace else None
     L.e2k_dwconv_bwd(_p(dy), _p(pre), _p(x), _p(mask), _p(w), _p(dx), _p(dw), _p(dbias), _p(ws), B, N, C, ks,
-                     int(dwconv_split_bwd), _stream(x))
+                     0, _stream(x))
     return dx
 
 

@@ -133,9 +133,9 @@ int e2k_cast_transpose_batch(const float* flat, void* flatT, const int64_t* desc
 int e2k_dwconv_fwd(const void* x, const uint8_t* mask, const float* w, const float* bias, void* pre,
                    void* y, int B, int N, int C, int ks, void* stream);
 /* dx, and dw / dbias ACCUMULATED (fp32).  ws: scratch of e2k_query_dwconv_bwd_ws_floats(B, N, C, ks) floats for the
- * per-workgroup (dw, dbias) partials (NULL: global fp32 atomics instead, ~2x slower at the cfg3 shapes).
- * split bit 0: 0 = one fused kernel, 1 = a dx kernel and a (dw, dbias) kernel (A/B, atomics); bits 1..: tuning /
- * ablation (2 = no gradient flush, 4 = loads and staging only, WRONG results; >> 8: workgroups per channel tile and batch) */
+ * per-workgroup (dw, dbias) partials (NULL: global fp32 atomics instead, ~1.3x slower at the cfg3 shapes).
+ * split: bit 0 must be 0 (round 1's two-kernel form is gone); bits 1..: tuning / ablation (2 = no gradient flush,
+ * 4 = loads and staging only -- WRONG results; >> 8: workgroups per channel tile and batch) */
 int e2k_query_dwconv_bwd_ws_floats(int B, int N, int C, int ks);
 int e2k_dwconv_bwd(const void* dy, const void* pre, const void* x, const uint8_t* mask, const float* w,
                    void* dx, float* dw, float* dbias, float* ws, int B, int N, int C, int ks, int split, void* stream);

@@ -140,11 +140,11 @@ def test_dwconv(dev, N, ks, use_mask, split):
     pre, y = ops.dwconv_fwd(xd, md, wd, bd)
     assert rel(y, yr) < 1e-2
     dw, db = torch.zeros_like(wd), torch.zeros_like(bd)
-    ops.dwconv_split_bwd = split
+    ops.dwconv_bwd_workspace = not split          # (True: workspace + reduce pass, the default; False: global atomics)
     try:
         dx = ops.dwconv_bwd(dy.to(dev), pre, xd, md, wd, dw, db)
     finally:
-        ops.dwconv_split_bwd = False
+        ops.dwconv_bwd_workspace = True
     assert rel(dx, xr.grad) < 2e-2, rel(dx, xr.grad)
     assert rel(dw, wr.grad) < 2e-2, rel(dw, wr.grad)
     assert rel(db, br.grad) < 2e-2

@@ -143,10 +143,10 @@ if 'ew' in which:
     dw, dbi = torch.zeros_like(w), torch.zeros_like(bias)
     ms = timeit(lambda: ops.dwconv_bwd(xc, pre, xc, None, w, dw, dbi))
     rec('dwconv_bwd', ms, bytes_=M * D * 8)
-    ops.dwconv_split_bwd = True
+    ops.dwconv_bwd_workspace = False
     ms = timeit(lambda: ops.dwconv_bwd(xc, pre, xc, None, w, dw, dbi))
-    rec('dwconv_bwd split (dx kernel + dw kernel)', ms, bytes_=M * D * 8)
-    ops.dwconv_split_bwd = False
+    rec('dwconv_bwd with global atomics instead of the workspace pass', ms, bytes_=M * D * 8)
+    ops.dwconv_bwd_workspace = True
     out = torch.zeros(8192, device=dev)
     ms = timeit(lambda: ops.colsum(Hh, out))
     rec('colsum M x 8192', ms, bytes_=M * 8192 * 2)
