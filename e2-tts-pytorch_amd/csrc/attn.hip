@@ -317,12 +317,11 @@ __device__ __forceinline__ void score_tile(const unsigned char* Kt, const bf16x8
 }
 
 
-// NW = waves per workgroup (4: 64 query rows, the default; 8: 128, flag E2K_ATTN_WG128).  Every workgroup sweeps ALL key /
-// value tiles of its (batch, head).  tools/probes/attn_ablate.py (MI355X, cfg3 shape): the skeleton alone -- global tile
-// loads, LDS staging, two barriers per tile, no MFMA / softmax -- takes 62 of the kernel's 99 us, and halving the re-read
-// traffic with 128-row workgroups changes nothing (profiles/r02_attn_ablate.json): the floor is the LATENCY of the
-// one-tile-deep register prefetch (load -> LDS write -> barrier per 64-key tile), not bandwidth.  A deeper LDS-DMA ring
-// is the structural fix.
+// Register-staged forward: the fallback for sequences whose key mask does not fit the ring kernel's LDS (Npad > 4096) and
+// the E2K_ATTN_NO_RING A/B.  NW = waves per workgroup (4 = 64 query rows; a 128-row variant changed nothing on MI355X,
+// profiles/r02_attn_ablate.json, and is not instantiated).  Every workgroup sweeps ALL key / value tiles of its (batch,
+// head).  Its loop holds an ordinary global load (the key mask) behind the next tile's prefetch: see attn_bwd_dq_ring_kernel
+// for what that costs.
 // PROBE: the bottleneck probes (E2K_ATTN_PROBE_*) are compiled into a separate instantiation: the product kernel carries none of their branches
 template <bool DROP, bool SHARE, int NW, bool PROBE = false>      // SHARE: dropout keep masks are handed from the forward to the backward (p.dropbits)
 __global__ __launch_bounds__(NW * 64, NW == 8 ? 4 : 2) void attn_fwd_kernel(AttnArgs p) {
@@ -1412,7 +1411,7 @@ static int fill_attn(AttnArgs& a, int B, int H, int N, int Npad, float p_drop, u
 }
 
 extern "C" int e2k_query_attn_bwd_transposes(int Npad, int flags) {
-    const bool staged = (flags & (E2K_ATTN_WG128 | E2K_ATTN_NO_RING)) != 0;
+    const bool staged = (flags & E2K_ATTN_NO_RING) != 0;
     return ((staged || Npad > RKM) ? 1 : 0) | (staged ? 2 : 0);
 }
 
@@ -1440,31 +1439,16 @@ static int attn_fwd_impl(const void* Q, const void* K, const void* VT, const uin
         if (a.thresh && dropbits) hipLaunchKernelGGL((attn_fwd_kernel<true, true, 4, true>), grid, block, 0, st, a);
         else if (a.thresh) hipLaunchKernelGGL((attn_fwd_kernel<true, false, 4, true>), grid, block, 0, st, a);
         else hipLaunchKernelGGL((attn_fwd_kernel<false, false, 4, true>), grid, block, 0, st, a);
-    } else if (!(flags & (E2K_ATTN_WG128 | E2K_ATTN_NO_RING)) && Npad <= RKM) {
+    } else if (!(flags & E2K_ATTN_NO_RING) && Npad <= RKM) {
         const dim3 grid((N + 63) / 64, H, B), block(256);
-        if (!(flags & (E2K_ATTN_RING3 | E2K_ATTN_RING4))) {
-            if (a.thresh && dropbits) hipLaunchKernelGGL((attn_fwd_ring_kernel<true, true, 2>), grid, block, 0, st, a);
-            else if (a.thresh) hipLaunchKernelGGL((attn_fwd_ring_kernel<true, false, 2>), grid, block, 0, st, a);
-            else hipLaunchKernelGGL((attn_fwd_ring_kernel<false, false, 2>), grid, block, 0, st, a);
-        } else if (flags & E2K_ATTN_RING4) {
-            if (a.thresh && dropbits) hipLaunchKernelGGL((attn_fwd_ring_kernel<true, true, 4>), grid, block, 0, st, a);
-            else if (a.thresh) hipLaunchKernelGGL((attn_fwd_ring_kernel<true, false, 4>), grid, block, 0, st, a);
-            else hipLaunchKernelGGL((attn_fwd_ring_kernel<false, false, 4>), grid, block, 0, st, a);
-        } else {
-            if (a.thresh && dropbits) hipLaunchKernelGGL((attn_fwd_ring_kernel<true, true, 3>), grid, block, 0, st, a);
-            else if (a.thresh) hipLaunchKernelGGL((attn_fwd_ring_kernel<true, false, 3>), grid, block, 0, st, a);
-            else hipLaunchKernelGGL((attn_fwd_ring_kernel<false, false, 3>), grid, block, 0, st, a);
-        }
-    } else if (!(flags & E2K_ATTN_WG128)) {
+        if (a.thresh && dropbits) hipLaunchKernelGGL((attn_fwd_ring_kernel<true, true, 2>), grid, block, 0, st, a);
+        else if (a.thresh) hipLaunchKernelGGL((attn_fwd_ring_kernel<true, false, 2>), grid, block, 0, st, a);
+        else hipLaunchKernelGGL((attn_fwd_ring_kernel<false, false, 2>), grid, block, 0, st, a);
+    } else {
         const dim3 grid((N + 63) / 64, H, B), block(256);
         if (a.thresh && dropbits) hipLaunchKernelGGL((attn_fwd_kernel<true, true, 4>), grid, block, 0, st, a);
         else if (a.thresh) hipLaunchKernelGGL((attn_fwd_kernel<true, false, 4>), grid, block, 0, st, a);
         else hipLaunchKernelGGL((attn_fwd_kernel<false, false, 4>), grid, block, 0, st, a);
-    } else {
-        const dim3 grid((N + 127) / 128, H, B), block(512);
-        if (a.thresh && dropbits) hipLaunchKernelGGL((attn_fwd_kernel<true, true, 8>), grid, block, 0, st, a);
-        else if (a.thresh) hipLaunchKernelGGL((attn_fwd_kernel<true, false, 8>), grid, block, 0, st, a);
-        else hipLaunchKernelGGL((attn_fwd_kernel<false, false, 8>), grid, block, 0, st, a);
     }
     E2K_CHECK_LAUNCH();
     return 0;
@@ -1492,7 +1476,7 @@ static int attn_bwd_impl(const void* dOg, const void* O, const float* gate, cons
     hipStream_t st = (hipStream_t)stream;
     hipLaunchKernelGGL(attn_bwd_prep_kernel, dim3(Npad / 64, H, B), dim3(256), 0, st, a);
     E2K_CHECK_LAUNCH();
-    if (!(flags & E2K_ATTN_WG128)) {
+    {
         const dim3 grid((N + 63) / 64, H, B), block(256);
         if (!(flags & E2K_ATTN_NO_RING) && Npad <= RKM) {
             if (a.thresh && dropbits) hipLaunchKernelGGL((attn_bwd_dq_ring_kernel<true, true>), grid, block, 0, st, a);
@@ -1509,15 +1493,6 @@ static int attn_bwd_impl(const void* dOg, const void* O, const float* gate, cons
         } else if (a.thresh && dropbits) hipLaunchKernelGGL((attn_bwd_dkv_kernel<true, true, 4>), grid, block, 0, st, a);
         else if (a.thresh) hipLaunchKernelGGL((attn_bwd_dkv_kernel<true, false, 4>), grid, block, 0, st, a);
         else hipLaunchKernelGGL((attn_bwd_dkv_kernel<false, false, 4>), grid, block, 0, st, a);
-    } else {
-        const dim3 grid((N + 127) / 128, H, B), block(512);
-        if (a.thresh && dropbits) hipLaunchKernelGGL((attn_bwd_dq_kernel<true, true, 8>), grid, block, 0, st, a);
-        else if (a.thresh) hipLaunchKernelGGL((attn_bwd_dq_kernel<true, false, 8>), grid, block, 0, st, a);
-        else hipLaunchKernelGGL((attn_bwd_dq_kernel<false, false, 8>), grid, block, 0, st, a);
-        E2K_CHECK_LAUNCH();
-        if (a.thresh && dropbits) hipLaunchKernelGGL((attn_bwd_dkv_kernel<true, true, 8>), grid, block, 0, st, a);
-        else if (a.thresh) hipLaunchKernelGGL((attn_bwd_dkv_kernel<true, false, 8>), grid, block, 0, st, a);
-        else hipLaunchKernelGGL((attn_bwd_dkv_kernel<false, false, 8>), grid, block, 0, st, a);
     }
     E2K_CHECK_LAUNCH();
     return 0;

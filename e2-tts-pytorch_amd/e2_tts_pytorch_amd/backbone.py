@@ -1101,7 +1101,7 @@ class Transformer(Module):
                 return ops.gemm_tn(a, b, out, **kw)
             Ln.fence(Ln.cur, ops.WGRAD)
             with Ln.lane(ops.WGRAD):
-                ops.gemm_tn(a, b, out, hold=hold[0], **kw)
+                ops.gemm_tn(a, b, out, hold=hold[0], splits=_WGRAD_LANE_SPLITS, **kw)
         run.wgrad = wgrad
 
         def entry(ent):
@@ -1343,6 +1343,10 @@ class _TimeCondFn(torch.autograd.Function):
         ops.time_cond_bwd(dout.float().contiguous(), four, pre, dW, db)
         return None, None, dW, db
 
+
+# token-dimension splits of the weight-gradient GEMMs on the WGRAD lane (0 = the library's cost model, which assumes the
+# GEMM has the chip to itself; on the lane it runs next to the main chain)
+_WGRAD_LANE_SPLITS = int(_os.environ.get('E2K_WGRAD_SPLITS', '0'))
 
 _VIEW_OPS = {'view', '_unsafe_view', 'as_strided', 'slice', 'select', 'expand', 't', 'transpose', 'permute', 'unsqueeze', 'squeeze',
              'detach', 'alias', '_reshape_alias', 'reshape', 'split', 'split_with_sizes', 'unbind', 'narrow', 'lift_fresh', 'unfold',

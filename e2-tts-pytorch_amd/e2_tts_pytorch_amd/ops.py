@@ -524,7 +524,7 @@ def qkv_post_fwd(qkvg, B, H, N, cosb, sinb, vfirst=None):
     st = AttnState()
     st.B, st.H, st.N, st.Npad, st.dropbits = B, H, N, Npad, None
     st.Q, st.K, st.V = (torch.empty((B, H, N, 64), dtype=bf16, device=dev) for _ in range(3))
-    need = _lib.get().e2k_query_attn_bwd_transposes(Npad, attn_probe & (64 | 128))
+    need = _lib.get().e2k_query_attn_bwd_transposes(Npad, attn_probe & 128)
     st.VT = torch.empty((B, H, 64, Npad), dtype=bf16, device=dev)
     st.KT = torch.empty((B, H, 64, Npad), dtype=bf16, device=dev) if need & 1 else None
     st.QT = torch.empty((B, H, 64, Npad), dtype=bf16, device=dev) if need & 2 else None
@@ -539,7 +539,7 @@ def qkv_post_fwd(qkvg, B, H, N, cosb, sinb, vfirst=None):
 # kernels read them back instead of re-hashing: bit-identical results (tools/attn_share_check.py on MI355X), forward
 # 0.132 -> 0.140 ms, backward 0.403 -> 0.358 ms per cfg3 attention.  False = every kernel re-derives the mask.
 attn_share_dropmask = True
-attn_probe = int(_os.environ.get('E2K_ATTN_FLAGS', '0'))      # E2K_ATTN_* bits: 64 = 64-row workgroups (A/B); probes 1..32 give wrong results on purpose
+attn_probe = int(_os.environ.get('E2K_ATTN_FLAGS', '0'))      # E2K_ATTN_* bits: 128 = the register-staged kernels instead of the LDS-DMA rings (A/B); probes 1..32 give wrong results on purpose
 
 
 def attn_fwd(st, kmask_pad, p_drop=0., seed=0, stream_id=0, seed_dev=None):
@@ -577,7 +577,7 @@ def attn_bwd(st, dOg, kmask_pad, p_drop=0., seed=0, stream_id=0, seed_dev=None):
     _note(10.0 * B * H * N * N * 64)
     _lib.get().e2k_attn_bwd(_p(dOg), _p(st.O), _p(st.gate), _p(st.lse2), _p(st.Q), _p(st.K), _p(st.V), _p(st.QT),
                             _p(st.KT), _p(kmask_pad), _p(st.dropbits), _p(dO), _p(dOT), _p(delta), _p(dgate), _p(dQ), _p(dK),
-                            _p(dV), B, H, N, Npad, float(p_drop), int(seed), _p(seed_dev), int(stream_id), attn_probe & (64 | 128),
+                            _p(dV), B, H, N, Npad, float(p_drop), int(seed), _p(seed_dev), int(stream_id), attn_probe & 128,
                             _stream(dOg))
     return dQ, dK, dV, dgate
 

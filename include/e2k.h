@@ -168,16 +168,13 @@ int e2k_attn_fwd(const void* Q, const void* K, const void* VT, const uint8_t* km
 #define E2K_ATTN_PROBE_NO_PV 8       /* no V LDS reads + second MFMAs */
 #define E2K_ATTN_PROBE_NO_LOADS 16   /* no global K / V tile loads after the first */
 #define E2K_ATTN_PROBE_NO_BARRIER 32 /* no workgroup barriers */
-#define E2K_ATTN_RING3 256           /* (forward) three / four LDS-DMA ring stages instead of two (A/B: lower occupancy, slower) */
-#define E2K_ATTN_RING4 512
-#define E2K_ATTN_NO_RING 128         /* (forward) register-staged K / V tiles instead of the LDS-DMA ring (A/B; same results) */
-#define E2K_ATTN_WG128 64            /* (both calls) 128 query rows / keys per workgroup instead of 64 (A/B; same results, not faster on MI355X) */
+#define E2K_ATTN_NO_RING 128         /* (both calls) the register-staged kernels instead of the LDS-DMA ring kernels (A/B; same results) */
 /* dropbits (optional, both calls; NULL = every kernel re-derives the dropout mask from the counter hash): scratch of
  * e2k_query_attn_dropbits_bytes(B, H, N) bytes in which the forward leaves its keep decisions as 64-bit wave ballot words
  * and from which the backward kernels read them back.  Same mask either way (bit-identical results). */
 int e2k_query_attn_dropbits_bytes(int B, int H, int N);
-/* Which transposed copies the backward needs: bit 0 = KT (the register-staged dQ kernel: flags E2K_ATTN_NO_RING /
- * E2K_ATTN_WG128, or Npad > 4096), bit 1 = QT and dOT (the register-staged dK,dV kernel: those flags).  The default
+/* Which transposed copies the backward needs: bit 0 = KT (the register-staged dQ kernel: flag E2K_ATTN_NO_RING, or
+ * Npad > 4096), bit 1 = QT and dOT (the register-staged dK,dV kernel: that flag).  The default
  * (LDS-DMA ring) kernels read K^T / Q^T / dO^T out of the row-major tiles with ds_read_b64_tr_b16: e2k_qkv_post_fwd
  * then takes QT = KT = NULL and e2k_attn_bwd dOT = NULL (17 MB less written per transposed copy at the cfg3 shape). */
 int e2k_query_attn_bwd_transposes(int Npad, int flags);
