@@ -137,6 +137,8 @@ def main():
     ap.add_argument('--dropout', type=float, default=0.1, help='reference training default (e2_tts.py:540)')
     ap.add_argument('--drop-text', action='store_true', help='run with the text stream dropped (CFG null pass cost)')
     ap.add_argument('--no-cpu-baseline', action='store_true')
+    ap.add_argument('--no-launch-floor', action='store_true', help='skip the host_launch_floor probe (a tiny model with the same launch '
+                    'count per step: its kernels would dilute a rocprofv3 per-kernel summary of this command)')
     ap.add_argument('--batch', type=int, default=None)
     ap.add_argument('--eager', action='store_true', help='drive every kernel launch from Python instead of replaying the recorded '
                     'launch plan from C++ (A/B: ~35 us of host time per launch, the step becomes host bound)')
@@ -309,11 +311,13 @@ def main():
                 'flops_per_launch_avg': gemm_flops / max(n_launch, 1),
                 'time_share_of_step': (gemm_ms / nprof) / ms,
                 'measured': 'HIP events on the launch stream around every recorded launch (e2k_plan_profile), 2 replays of the '
-                            'timed plan right after the timed region',
+                            'timed plan right after the timed region, every call ALONE on one stream; the rocprofv3 summary that '
+                            'agrees with avg_launch_ms is the single-stream one (E2K_LANES=0, profiles/r02_bench_cfg3_kernel_stats_e_single_stream.csv): '
+                            'with the launch lanes the kernels of different lanes overlap and stretch (…_d_lanes.csv)',
                 'traffic': traffic, 'traffic_note': traffic_note,
             },
         }
-        if not args.eager:
+        if not args.eager and not args.no_launch_floor:
             try:
                 res['host_launch_floor'] = host_launch_floor(depth, dev, args.dropout)
             except Exception as e:      # noqa: BLE001

@@ -9,6 +9,6 @@ run plan python bench.py --steps 8 --warmup 2
 run plan_t256 env E2K_GEMM_FLAGS=256 python bench.py --steps 8 --warmup 2 --no-cpu-baseline
 run eager python bench.py --steps 6 --warmup 2 --no-cpu-baseline --eager
 cd /tmp && export TMPDIR=/tmp
-(timeout 500 rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/prof_$tag -- python $GRAFT_REPO_ROOT/bench.py --steps 3 --warmup 1 --no-cpu-baseline) > $GRAFT_REPO_ROOT/gpurun_out/prof_$tag.log 2>&1; echo "prof rc=$?"
+(timeout 500 rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/prof_$tag -- python $GRAFT_REPO_ROOT/bench.py --steps 3 --warmup 1 --no-cpu-baseline --no-launch-floor) > $GRAFT_REPO_ROOT/gpurun_out/prof_$tag.log 2>&1; echo "prof rc=$?"
 find /tmp/prof_$tag -name "*kernel_stats.csv" -exec cp {} $GRAFT_REPO_ROOT/gpurun_out/prof_${tag}_kernel_stats.csv \;
 head -n 14 $GRAFT_REPO_ROOT/gpurun_out/prof_${tag}_kernel_stats.csv | cut -c1-150
