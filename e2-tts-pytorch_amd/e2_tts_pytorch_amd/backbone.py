@@ -629,9 +629,11 @@ class Transformer(Module):
     def _sync_lanes(self, streams):
         """tell the data-parallel hook which side streams a finished gradient slab must also be final on"""
         sync = self._grad_sync
-        tgt = getattr(sync, '__self__', sync)           # (the hook may be a bound method of the _GradSync object)
-        if exists(tgt) and hasattr(tgt, 'lanes'):
-            tgt.lanes = [ss for ss in streams if exists(ss)]
+        if not exists(sync):
+            return
+        tgt = getattr(sync, '__self__', sync)           # (ddp.DataParallel installs a bound method, the stock-DDP shim the _GradSync itself)
+        assert hasattr(type(tgt), 'lanes') or hasattr(tgt, 'lanes'), 'the gradient hook must accept the launch lanes (see ddp._GradSync.lanes)'
+        tgt.lanes = [ss for ss in streams if exists(ss)]
 
     def _lane_streams(self, dev):
         """side streams of the TEXT and WGRAD lanes ([] = single lane); on the host model of the kernels there are no

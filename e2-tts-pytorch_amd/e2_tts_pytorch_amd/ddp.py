@@ -127,6 +127,15 @@ class DataParallel(nn.Module):
             for bb in self._backbones:          # the broadcast wrote behind the version counters: refresh the bf16 shadows
                 bb._shadow_key = None
 
+    @property
+    def lanes(self):
+        """side streams of the backbone's launch lanes: a slab is final only when they have caught up (set by the backbone)"""
+        return self._sync.lanes
+
+    @lanes.setter
+    def lanes(self, streams):
+        self._sync.lanes = list(streams)
+
     def _hook(self, gflat, start, end):
         if start is None and self._outside and not self._outside_queued:
             # the rest of the autograd pass (input projections, embeddings) finishes after the backbone: reduce then

@@ -34,7 +34,9 @@ def _worker(rank, world, port, emu_lib, q):
     noises = [dict(x0=torch.randn(B, T, 100), times=torch.rand(B), frac_lengths=torch.tensor([0.8]),
                    span_rand=torch.tensor([0.4]), drop_text_cond=(r == 1)) for r in range(world)]
     out = net(mels[rank], text=['hello'], _noise=noises[rank])
+    net._sync.lanes = None                # (must be set by the backbone through DataParallel.lanes before the first slab goes out)
     out.loss.backward()
+    assert net._sync.lanes == []          # no streams on the host model, but the hand-over has happened
     grads = {n: p.grad.clone() for n, p in model.named_parameters() if p.grad is not None}
     # persistent-gradient mode: the slabs are views of one long-lived buffer; two more steps (other inputs first, so
     # that the second one has something to overwrite) must end with the same averaged gradients
