@@ -66,3 +66,50 @@ def test_results_do_not_depend_on_a_concurrent_gemm():
             if n:
                 bad[vn, cn] = n
     assert not bad, bad
+
+
+@pytest.mark.gpu
+def test_data_parallel_hook_waits_for_the_launch_lanes():
+    """ddp.DataParallel on one rank (RCCL, world size 1): the slab all-reduce runs on its own stream and must not start
+    before the TEXT and WGRAD lanes have finished the layer -- same gradients as the unwrapped module, replayed plans"""
+    import copy
+    import os
+    import random
+    import torch.distributed as dist
+    from e2_tts_pytorch_amd import Transformer, _lib
+    from e2_tts_pytorch_amd.ddp import DataParallel
+    from test_backbone import randomize, rel2
+    _lib._install_for_tests(None, host_pointers=False)
+    dev = 'cuda'
+    random.seed(0)
+    torch.manual_seed(0)
+    dim, depth, B, T = 512, 4, 4, 200
+    plain = Transformer(dim=dim, depth=depth, heads=dim // 64, dropout=0., max_seq_len=T)
+    randomize(plain)
+    plain = plain.to(dev)
+    wrapped_mod = copy.deepcopy(plain)
+    R = torch.randn(B, T, dim, device=dev)
+    created = not dist.is_initialized()
+    if created:
+        dist.init_process_group('nccl', init_method=f'tcp://127.0.0.1:{29600 + os.getpid() % 300}', rank=0, world_size=1)
+    try:
+        net = DataParallel(wrapped_mod, grad_dtype=torch.float32)
+
+        def step(m, seed):
+            m.zero_grad(set_to_none=True)
+            g = torch.Generator().manual_seed(seed)
+            x = torch.randn(B, T, dim, generator=g).to(dev)
+            t = torch.rand(B, generator=g).to(dev)
+            txt = torch.randn(B, T, dim // 2, generator=g).to(dev)
+            (m(x, times=t, text_embed=txt) * R).sum().backward()
+            torch.cuda.synchronize()
+            return {n: p.grad.clone() for n, p in (m.module if isinstance(m, DataParallel) else m).named_parameters()}
+
+        for seed in (1, 2, 3, 4):              # first sighting, recording, two replays
+            g0, g1 = step(plain, seed), step(net, seed)
+            assert net._sync.lanes and net._sync.calls > 0
+            bad = [(n, rel2(g1[n], g0[n])) for n in g0 if float(g0[n].norm()) > 1e-6 and rel2(g1[n], g0[n]) > 2e-3]
+            assert not bad, (seed, bad[:5])
+    finally:
+        if created:
+            dist.destroy_process_group()
