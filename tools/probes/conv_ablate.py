@@ -1,4 +1,6 @@
-"""depthwise-conv backward at the cfg3 audio shape: workgroups per (channel tile, batch) sweep and ablations (no flush / loads + staging only)"""
+"""depthwise-conv backward at the cfg3 audio shape: workgroups per (channel tile, batch) sweep and ablations (no flush / loads + staging only).
+profiles/r02_conv_ablate.json keeps the run that found the LDS float atomics (then in the flush) to be half the kernel: 92 us with them,
+50 with plain LDS stores in their place, 38 without any flush."""
 import json, sys
 from pathlib import Path
 ROOT = Path(__file__).resolve().parent.parent.parent
@@ -25,8 +27,8 @@ def timeit(flag, iters=20):
     e1.record(); torch.cuda.synchronize()
     return e0.elapsed_time(e1) / iters * 1e3
 rows = []
-for gx in (0, 17):
-    for tune, tag in ((0, 'full, workspace'), (-1, 'full, atomics'), (1, 'no flush'), (4, 'plain LDS stores instead of LDS atomics, workspace')):
+for gx in (0, 2, 4, 9, 17):
+    for tune, tag in ((0, 'full, workspace'), (-1, 'full, global atomics'), (1, 'no flush'), (3, 'loads + staging only, no flush')):
         use_ws = tune != -1
         tune = max(tune, 0)
         flag = ((tune | (gx << 7)) << 1)
