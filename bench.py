@@ -300,6 +300,9 @@ def main():
             'host_enqueue_ms_per_step': t_enqueue / args.steps * 1e3,
             'launch_mode': launch_mode_note, 'gemm_flags': ops.gemm_flags,
             'launches_per_step': (len(prof_rows) // nprof) if prof_rows else None,
+            'lane_ms_per_step': ({('main', 'text', 'wgrad', 'lane3')[k]: {ph: round(sum(r['ms'] for r in prof_rows if r.get('lane', 0) == k and r['phase'] == ph) / nprof, 2)
+                                                                          for ph in ('fwd', 'bwd')} for k in sorted({r.get('lane', 0) for r in prof_rows})}
+                                 if prof_rows else None),          # work of each lane, every call timed alone: the step cannot be shorter than the longest chain
             'launch_lanes': {'on': bool(getattr(tr, '_lanes_on', False)), 'backward': bool(getattr(tr, '_lanes_bwd', False)), 'ordering_points_per_step': lane_ops,
                              'note': 'text branches / weight-gradient GEMMs on side streams (ops.Lanes, csrc/plan.h); E2K_LANES=0 for the single-stream schedule'},
             'kernel_groups_ms_per_step': _groups(prof_rows, nprof) if prof_rows else None,

@@ -168,6 +168,12 @@ extern "C" int e2k_plan_profile(int plan, int first, int count, float* ms_host, 
     return rc;
 }
 
+extern "C" int e2k_query_plan_op_lane(int plan, int index) {
+    Plan* p = lookup(plan);
+    if (!p || index < 0 || index >= (int)p->ops.size()) return -1;
+    return p->ops[index].lane;
+}
+
 extern "C" int e2k_plan_op_name(int plan, int index, char* buf_host, int nbuf) {
     Plan* p = lookup(plan);
     if (!p || index < 0 || index >= (int)p->ops.size() || !buf_host || nbuf <= 0) return E2K_ERR_ARG;

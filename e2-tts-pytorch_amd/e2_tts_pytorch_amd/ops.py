@@ -131,7 +131,7 @@ def profile_plan(handle, meta, phase, device):
     out = []
     for i in range(n):
         L.e2k_plan_op_name(handle, i, ctypes.addressof(buf), 64)
-        out.append(dict(name=buf.value.decode(), ms=float(ms[i]), flops=flops.get(i, 0.0), phase=phase, index=i))
+        out.append(dict(name=buf.value.decode(), ms=float(ms[i]), flops=flops.get(i, 0.0), phase=phase, index=i, lane=L.e2k_query_plan_op_lane(handle, i)))
     return out
 
 

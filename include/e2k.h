@@ -250,6 +250,7 @@ int e2k_plan_event_wait(int lane, int ev);
 int e2k_plan_run_lanes(int plan, int first, int count, void** streams_host, int nstreams);
 int e2k_plan_profile(int plan, int first, int count, float* ms_host, void* stream);
 int e2k_plan_op_name(int plan, int index, char* buf_host, int nbuf);
+int e2k_query_plan_op_lane(int plan, int index);      /* launch lane of recorded call `index` (-1: no such call) */
 
 /* ---- stream pack / unpack, masks, time conditioning: the glue around the depth loop (csrc/glue.hip) ----
  * byte fill (hipMemsetAsync as a recordable call) and a strided form: `rows` rows of `width` bytes, `pitch` bytes apart */

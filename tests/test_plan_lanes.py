@@ -61,6 +61,7 @@ def test_record_and_replay_with_lanes(emu):
     ns = names(L, h)
     assert ns == ['gemm_nt_bf16', 'lane_event_record', 'lane_event_wait', 'gemm_nt_bf16', 'fill_bytes',
                   'lane_event_record', 'lane_event_wait', 'lane_event_record', 'lane_event_wait'], ns
+    assert [L.e2k_query_plan_op_lane(h, i) for i in range(len(ns))] == [0, 0, 1, 1, 2, 1, 0, 2, 0] and L.e2k_query_plan_op_lane(h, 99) == -1
     ref_y, ref_z = y.clone(), z.clone()
     arr3 = (ctypes.c_void_p * 3)()
     arr1 = (ctypes.c_void_p * 1)()
