@@ -63,6 +63,18 @@ def _groups(rows, nprof):
     return out
 
 
+def _lane_ms(rows, nprof):
+    """per-step milliseconds of the calls of each launch lane (profiled replay: every call alone on one stream), fwd / bwd"""
+    try:
+        if not rows:
+            return None
+        names = ('main', 'text', 'wgrad', 'lane3')
+        return {names[k]: {ph: round(sum(r['ms'] for r in rows if r.get('lane', 0) == k and r['phase'] == ph) / nprof, 2) for ph in ('fwd', 'bwd')}
+                for k in sorted({r.get('lane', 0) for r in rows})}
+    except Exception as e:      # noqa: BLE001  (a diagnostic must not cost the bench line)
+        return {'error': repr(e)}
+
+
 def host_launch_floor(depth, dev, dropout):
     """host time per training step when the GPU is NOT the bottleneck: the same depth (= the same number of recorded
     launches per step) at a tiny width / batch / length, so that the kernels are negligible.  `host_enqueue_ms_per_step`
@@ -300,9 +312,7 @@ def main():
             'host_enqueue_ms_per_step': t_enqueue / args.steps * 1e3,
             'launch_mode': launch_mode_note, 'gemm_flags': ops.gemm_flags,
             'launches_per_step': (len(prof_rows) // nprof) if prof_rows else None,
-            'lane_ms_per_step': ({('main', 'text', 'wgrad', 'lane3')[k]: {ph: round(sum(r['ms'] for r in prof_rows if r.get('lane', 0) == k and r['phase'] == ph) / nprof, 2)
-                                                                          for ph in ('fwd', 'bwd')} for k in sorted({r.get('lane', 0) for r in prof_rows})}
-                                 if prof_rows else None),          # work of each lane, every call timed alone: the step cannot be shorter than the longest chain
+            'lane_ms_per_step': _lane_ms(prof_rows, nprof),          # work of each lane, every call timed alone: the step cannot be shorter than the longest chain
             'launch_lanes': {'on': bool(getattr(tr, '_lanes_on', False)), 'backward': bool(getattr(tr, '_lanes_bwd', False)), 'ordering_points_per_step': lane_ops,
                              'note': 'text branches / weight-gradient GEMMs on side streams (ops.Lanes, csrc/plan.h); E2K_LANES=0 for the single-stream schedule'},
             'kernel_groups_ms_per_step': _groups(prof_rows, nprof) if prof_rows else None,
