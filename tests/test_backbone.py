@@ -266,6 +266,10 @@ def test_launch_lanes_match_single_stream(dev):
     if True:
         names = ops_names(st[0].bwd)
         assert names.count('lane_event_wait') >= 2 * depth and names.count('lane_event_record') >= 2 * depth
+    step(seeds[0])                                      # (make the training plan the most recently used one)
+    rows = mod.plan_profile()                           # (what bench.py prices the roofline with: every call alone on one stream)
+    assert {r['lane'] for r in rows} == {0, 1, 2} and all(r['ms'] >= 0 for r in rows) and {r['phase'] for r in rows} == {'fwd', 'bwd'}
+    assert sum(r['name'] == 'gemm_tn_bf16' and r['lane'] == 2 for r in rows) > 0 and not any(r['name'] == 'gemm_tn_bf16' and r['phase'] == 'fwd' for r in rows)
     ref_t, ref_i = res[False, False]
     for key in ((True, False), (True, True), (False, True)):
         got_t, got_i = res[key]
