@@ -227,7 +227,7 @@ def test_launch_lanes_match_single_stream(dev):
     random.seed(0)
     torch.manual_seed(0)
     big = dev == 'cuda'
-    dim, depth, B, T = (512, 6, 4, 200) if big else (256, 2, 2, 24)
+    dim, depth, B, T = (512, 6, 4, 200) if big else (256, 2, 1, 16)
     mod = Transformer(dim=dim, depth=depth, heads=dim // 64, dropout=0., max_seq_len=T)
     randomize(mod)
     mod = mod.to(dev)
@@ -257,6 +257,8 @@ def test_launch_lanes_match_single_stream(dev):
     for lanes in (False, True):
         mod.enable_lanes(lanes, backward=lanes)
         for plans in (False, True):
+            if not big and plans and not lanes:
+                continue                    # (host model: test_plan_replay_matches_eager covers plans without lanes)
             mod.enable_plans(plans)
             res[lanes, plans] = [step(s) for s in seeds], [infer(s) for s in seeds]
     st = [v for v in mod._plans.values() if not isinstance(v, str) and v.bwd]
@@ -272,6 +274,8 @@ def test_launch_lanes_match_single_stream(dev):
     assert sum(r['name'] == 'gemm_tn_bf16' and r['lane'] == 2 for r in rows) > 0 and not any(r['name'] == 'gemm_tn_bf16' and r['phase'] == 'fwd' for r in rows)
     ref_t, ref_i = res[False, False]
     for key in ((True, False), (True, True), (False, True)):
+        if key not in res:
+            continue
         got_t, got_i = res[key]
         for (o0, dx0, dt0, g0), (o1, dx1, dt1, g1) in zip(ref_t, got_t):
             assert torch.equal(o1, o0) and torch.equal(dx1, dx0) and torch.equal(dt1, dt0), key
@@ -301,10 +305,11 @@ def test_plan_replay_matches_eager(dev):
     from e2_tts_pytorch_amd import Transformer
     random.seed(0)
     torch.manual_seed(0)
-    mod = Transformer(dim=256, depth=4, heads=2, dropout=0., max_seq_len=64)
+    depth, T = (4, 40) if dev == 'cuda' else (2, 24)          # (the host model is ~1000x slower than the GPU: same schedule, fewer layers / frames)
+    mod = Transformer(dim=256, depth=depth, heads=2, dropout=0., max_seq_len=64)
     randomize(mod)
     mod = mod.to(dev)
-    B, T = 2, 40
+    B = 2
     R = torch.randn(B, T, 256).to(dev)
 
     def inputs(seed):
