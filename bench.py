@@ -330,7 +330,7 @@ def main():
                 'traffic': traffic, 'traffic_note': traffic_note,
             },
         }
-        if not args.eager and not args.no_launch_floor:
+        if world == 1 and not args.eager and not args.no_launch_floor:      # (rank 0 alone would keep the other ranks waiting)
             try:
                 res['host_launch_floor'] = host_launch_floor(depth, dev, args.dropout)
             except Exception as e:      # noqa: BLE001
@@ -343,6 +343,7 @@ def main():
                                        'sample': f'failed: {e!r}'}
         print(json.dumps(res), flush=True)
     if world > 1 or args.force_ddp:
+        dist.barrier()                    # nobody tears the communicator down while rank 0 is still reporting
         dist.destroy_process_group()
 
 
