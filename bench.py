@@ -246,7 +246,7 @@ def main():
         # the per-call times are those of each kernel running alone, their sum exceeds the step time when lanes overlap)
         lane_ops = sum(r['name'].startswith('lane_event') for r in prof_rows) // nprof
         prof_rows = [r for r in prof_rows if not r['name'].startswith('lane_event')]
-        gemm = [r for r in prof_rows if r['name'] == 'gemm_nt_bf16']
+        gemm = [r for r in prof_rows if r['name'] in ('gemm_nt_bf16', 'gemm_nt_geglu_bf16')]     # (the second only with E2K_FUSE_GEGLU=1)
         gemm_flops, gemm_ms, n_launch = sum(r['flops'] for r in gemm), sum(r['ms'] for r in gemm), len(gemm)
     else:
         prof = []
@@ -310,7 +310,7 @@ def main():
             'mfma_roofline_frac_whole_step': sf / (dt / args.steps) / 1e12 / PEAK_BF16_TFLOPS,
             'loss': loss_val,
             'host_enqueue_ms_per_step': t_enqueue / args.steps * 1e3,
-            'launch_mode': launch_mode_note, 'gemm_flags': ops.gemm_flags,
+            'launch_mode': launch_mode_note, 'gemm_flags': ops.gemm_flags, 'fuse_geglu': bool(ops.fuse_geglu),
             'launches_per_step': (len(prof_rows) // nprof) if prof_rows else None,
             'lane_ms_per_step': _lane_ms(prof_rows, nprof),          # work of each lane, every call timed alone: the step cannot be shorter than the longest chain
             'launch_lanes': {'on': bool(getattr(tr, '_lanes_on', False)), 'backward': bool(getattr(tr, '_lanes_bwd', False)), 'ordering_points_per_step': lane_ops,

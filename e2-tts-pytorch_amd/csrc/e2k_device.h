@@ -81,6 +81,19 @@ __device__ __forceinline__ unsigned rand_u32(unsigned seed, unsigned stream, uns
     return rand_at(rand_base(seed, stream), row, col);
 }
 
+// exact (erf) GELU and the GEGLU dropout keep factor: used by geglu_kernel (elementwise.hip) and by the GEGLU epilogue of
+// the 256 x 256 NT GEMM (gemm.hip) -- one definition, so that the two produce the same bits
+__device__ __forceinline__ float gelu_erf(float x) { return 0.5f * x * (1.f + erff(x * 0.70710678118654752f)); }
+__device__ __forceinline__ float gelu_erf_grad(float x) {
+    return 0.5f * (1.f + erff(x * 0.70710678118654752f)) + x * 0.3989422804014327f * __expf(-0.5f * x * x);
+}
+__device__ __forceinline__ float keep_scale(unsigned seed, unsigned stream, unsigned row, unsigned col, unsigned thresh, float inv_keep) {
+    // one hash per pair of columns: low / high 16 bits
+    unsigned h = rand_u32(seed, stream, row, col >> 1);
+    unsigned r16 = (col & 1) ? (h >> 16) : (h & 0xffffu);
+    return r16 >= thresh ? inv_keep : 0.f;
+}
+
 // ---- one-wave-per-row access: lane owns VEC consecutive elements in each of NCH chunks of 64*VEC (D = 64*VEC*NCH)
 template <int VEC> __device__ __forceinline__ void load_vec(const bf16_t* p, float* f);
 template <> __device__ __forceinline__ void load_vec<8>(const bf16_t* p, float* f) { unpack8(ld<u32x4>(p), f); }

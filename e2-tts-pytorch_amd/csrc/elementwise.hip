@@ -162,16 +162,7 @@ template <int VEC, int NCH> int launch_gate_bwd(const GateArgs& a, hipStream_t s
 
 // ------------------------------------------------------------------------------------------------ GEGLU
 
-__device__ __forceinline__ float gelu_erf(float x) { return 0.5f * x * (1.f + erff(x * 0.70710678118654752f)); }
-__device__ __forceinline__ float gelu_erf_grad(float x) {
-    return 0.5f * (1.f + erff(x * 0.70710678118654752f)) + x * 0.3989422804014327f * __expf(-0.5f * x * x);
-}
-__device__ __forceinline__ float keep_scale(unsigned seed, unsigned stream, unsigned row, unsigned col, unsigned thresh, float inv_keep) {
-    // one hash per pair of columns: low / high 16 bits
-    unsigned h = rand_u32(seed, stream, row, col >> 1);
-    unsigned r16 = (col & 1) ? (h >> 16) : (h & 0xffffu);
-    return r16 >= thresh ? inv_keep : 0.f;
-}
+// (gelu_erf, gelu_erf_grad, keep_scale: e2k_device.h -- shared with the GEGLU epilogue of the NT GEMM)
 
 struct GegluArgs {
     const bf16_t* H; long ldh; bf16_t* out; const bf16_t* dout; bf16_t* dH; int M, F;

@@ -55,6 +55,8 @@ struct NTArgs {
     // remainder split: workgroups [0, full) own whole tiles; the last T - full tiles (a partial round of the 512
     // resident workgroups) are cut into `split` K ranges each, fp32 partials go to `ws`, gemm_nt_fixup_kernel finishes
     int full, split; float* ws;
+    // GEGLU epilogue (gemm_nt_256_kernel<false, true> only): N = 2F, C = pre-activation H (may be NULL), glu_out (M, F)
+    bf16_t* glu_out; long ldg; unsigned seed, stream_id, thresh; float inv_keep; const unsigned* seed_dev;
 };
 
 // epilogue of an interior tile (all 128 x 128 outputs exist, rows 8-byte aligned): no per-element bounds checks, the
@@ -407,6 +409,52 @@ __global__ __launch_bounds__(256) void gemm_nt_fixup_kernel(NTArgs p) {
     nt_epilogue<OUT_F32, 1>(p, acc, tile_m * BM + wm * 64 + i * 16, tile_n * BN + wn * 64, l15, g);
 }
 
+// GEGLU epilogue of the 256 x 256 kernel (FeedForward(glu=True), e2_tts.py:646,692: `x, gate = proj(x).chunk(2);
+// x * gelu(gate)` + Dropout).  The kernel stages W1 rows [n0, n0+128) as its "B low" half and rows [F + n0, F + n0+128)
+// as its "B high" half, so a lane's accumulators au / ag hold the value and the gate of the SAME (row, 4 columns).
+// The pre-activation is rounded to bf16 first (and stored for the backward when C is set), the product is formed from
+// the rounded values: the output is exactly e2k_geglu_fwd of the stored H.
+template <int NI>
+__device__ __forceinline__ void nt_epilogue_glu(const NTArgs& p, f32x4 (&au)[NI][2], f32x4 (&ag)[NI][2], int mw, int nw, int l15, int g) {
+    const int F = p.N >> 1;
+    const unsigned seed = p.seed_dev ? *p.seed_dev : p.seed;
+    const int nb = nw + 4 * g;
+    f32x4 bu[2], bg[2];
+#pragma unroll
+    for (int j = 0; j < 2; ++j) {
+        bu[j] = bg[j] = f32x4{0.f, 0.f, 0.f, 0.f};
+        if (p.bias) {
+#pragma unroll
+            for (int r = 0; r < 4; ++r) { bu[j][r] = p.bias[nb + j * 16 + r]; bg[j][r] = p.bias[F + nb + j * 16 + r]; }
+        }
+    }
+#pragma unroll
+    for (int i = 0; i < NI; ++i) {
+        const int m = mw + i * 16 + l15;
+        if (m >= p.M) continue;
+#pragma unroll
+        for (int j = 0; j < 2; ++j) {
+            const int n = nb + j * 16;
+            const f32x4 xu = au[i][j] + bu[j], xg = ag[i][j] + bg[j];
+            float u[4] = {xu[0], xu[1], xu[2], xu[3]}, gt[4] = {xg[0], xg[1], xg[2], xg[3]};
+            const u32x2 hu = pack4(u), hg = pack4(gt);
+            if (p.C) {
+                st<u32x2>((bf16_t*)p.C + (long)m * p.ldc + n, hu);
+                st<u32x2>((bf16_t*)p.C + (long)m * p.ldc + F + n, hg);
+            }
+            unpack4(hu, u);
+            unpack4(hg, gt);
+            float o[4];
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const float ks = p.thresh ? keep_scale(seed, p.stream_id, m, n + r, p.thresh, p.inv_keep) : 1.f;
+                o[r] = u[r] * gelu_erf(gt[r]) * ks;
+            }
+            st<u32x2>(p.glu_out + (long)m * p.ldg + n, pack4(o));
+        }
+    }
+}
+
 // 256 x 256 x 64 tile, EIGHT waves (512 threads, one workgroup per CU, two waves per SIMD), 128 KB of LDS, 8 phases per
 // pair of K tiles (cdna_hip_programming.md "256^2 8-phase template", rebuilt for this kernel's operand layout and
 // epilogue).  Default for shapes that fill the chip with 256 x 256 tiles; on MI355X 790-1011 TFLOP/s on the cfg3 shapes
@@ -439,13 +487,13 @@ __global__ __launch_bounds__(256) void gemm_nt_fixup_kernel(NTArgs p) {
 //   * In the last five phases nothing is left to issue, and the count is lowered step by step (4, 2, 0).
 constexpr int QBM = 256, QBN = 256, QHALF = 128 * BK * 2, QBUF = 4 * QHALF, QTHREADS = 512;
 
-template <bool OUT_F32>
+template <bool OUT_F32, bool GLU = false>
 __global__ __launch_bounds__(QTHREADS, 1) void gemm_nt_256_kernel(NTArgs p) {
     __shared__ __attribute__((aligned(16))) unsigned char smem[2 * QBUF];
     const int tid = threadIdx.x, lane = tid & 63, wave = uniform_i(tid >> 6);
     const int wr = wave >> 2, wc = wave & 3;
     const int l15 = lane & 15, g = lane >> 4;
-    const int tm = (p.M + QBM - 1) / QBM, tn = (p.N + QBN - 1) / QBN;
+    const int tm = (p.M + QBM - 1) / QBM, tn = (p.N + QBN - 1) / QBN;      // GLU: N = 2F, F % 128 == 0: tn = F / 128 tiles of 128 value + 128 gate columns
     int tile_m, tile_n;
     const int nk1 = p.K1 / BK, nk = (p.K1 + p.K2) / BK;
     int kb = 0, ke = nk, part = -1;
@@ -458,7 +506,8 @@ __global__ __launch_bounds__(QTHREADS, 1) void gemm_nt_256_kernel(NTArgs p) {
         kb = (int)((long)nk * sidx / p.split);
         ke = (int)((long)nk * (sidx + 1) / p.split);
     }
-    const int m0 = tile_m * QBM, n0 = tile_n * QBN;
+    const int m0 = tile_m * QBM, n0 = GLU ? tile_n * 128 : tile_n * QBN;
+    const int nhalf = GLU ? (p.N >> 1) : 128;                // B rows between the "low" and the "high" half tile
     const int nt = ke - kb;                                  // K tiles of this workgroup (>= 1)
 
     // staging: a half tile is 16 wave instructions of 8 rows; wave w issues rows (2w + u)*8 + (lane >> 3), u = 0, 1
@@ -469,7 +518,7 @@ __global__ __launch_bounds__(QTHREADS, 1) void gemm_nt_256_kernel(NTArgs p) {
         for (int u = 0; u < 2; ++u) {
             const int row = (wave * 2 + u) * 8 + (lane >> 3);
             const int c = (lane & 7) ^ (row & 7);
-            const int m = min(m0 + h * 128 + row, p.M - 1), n = min(n0 + h * 128 + row, p.N - 1);
+            const int m = min(m0 + h * 128 + row, p.M - 1), n = min(n0 + h * nhalf + row, p.N - 1);
             va[h][u] = (unsigned)(((long)m * p.lda1 + c * 8) * 2);
             dv[h][u] = p.K2 ? (unsigned)(((long)m * p.lda2 + c * 8) * 2) - va[h][u] : 0u;
             vb[h][u] = (unsigned)(((long)n * p.ldb + c * 8) * 2);
@@ -606,6 +655,11 @@ __global__ __launch_bounds__(QTHREADS, 1) void gemm_nt_256_kernel(NTArgs p) {
                     for (int j = 0; j < 2; ++j) st<f32x4>(w + (((a * 2 + b) * 4 + i) * 2 + j) * (QTHREADS * 4), acc[a][b][i][j]);
         return;
     }
+    if (GLU) {
+#pragma unroll
+        for (int a = 0; a < 2; ++a) nt_epilogue_glu<4>(p, acc[a][0], acc[a][1], m0 + a * 128 + wr * 64, n0 + wc * 32, l15, g);
+        return;
+    }
 #pragma unroll
     for (int a = 0; a < 2; ++a)
 #pragma unroll
@@ -631,6 +685,28 @@ __global__ __launch_bounds__(QTHREADS) void gemm_nt_256_fixup_kernel(NTArgs p) {
         for (int j = 0; j < 2; ++j) acc[0][j] += ld<f32x4>(w + ((long)sidx * 32 + j) * (QTHREADS * 4));
     }
     nt_epilogue<OUT_F32, 1, 2>(p, acc, tile_m * QBM + a * 128 + wr * 64 + i * 16, tile_n * QBN + b * 128 + wc * 32, l15, g);
+}
+
+// GEGLU fix-up: blockIdx.y = A half * 4 + m16 group; both B halves (value | gate) are summed by the same lane
+__global__ __launch_bounds__(QTHREADS) void gemm_nt_256_fixup_glu_kernel(NTArgs p) {
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int wr = wave >> 2, wc = wave & 3, l15 = lane & 15, g = lane >> 4;
+    const int tm = (p.M + QBM - 1) / QBM, tn = (p.N + QBN - 1) / QBN;
+    const int a = blockIdx.y >> 2, i = blockIdx.y & 3;
+    int tile_m, tile_n;
+    tile_coords(p.full + blockIdx.x, tm, tn, tile_m, tile_n);
+    f32x4 acc[2][1][2];
+#pragma unroll
+    for (int b = 0; b < 2; ++b) {
+        acc[b][0][0] = acc[b][0][1] = f32x4{0.f, 0.f, 0.f, 0.f};
+        const float* w = p.ws + (((long)blockIdx.x * p.split * 32 + ((a * 2 + b) * 4 + i) * 2) * QTHREADS + tid) * 4;
+#pragma unroll 4
+        for (int sidx = 0; sidx < p.split; ++sidx) {
+#pragma unroll
+            for (int j = 0; j < 2; ++j) acc[b][0][j] += ld<f32x4>(w + ((long)sidx * 32 + j) * (QTHREADS * 4));
+        }
+    }
+    nt_epilogue_glu<1>(p, acc[0], acc[1], tile_m * QBM + a * 128 + wr * 64 + i * 16, tile_n * 128 + wc * 32, l15, g);
 }
 
 // (A BK = 32 variant of this kernel -- three 16-KB LDS stages, loads two K steps ahead with counted s_waitcnt vmcnt,
@@ -1292,6 +1368,53 @@ static int gemm_nt_bf16_impl(const void* A1, int64_t lda1, int K1, const void* A
     return 0;
 }
 
+// FeedForward GEMM1 with the GEGLU (+ dropout) as its epilogue: always the 256 x 256 kernel (its two B half tiles are the
+// value and the gate columns of the same outputs); shapes it cannot take are refused, the caller then runs
+// e2k_gemm_nt_bf16 + e2k_geglu_fwd (e2k_query_gemm_nt_geglu says which)
+static bool nt_geglu_ok(int M, int F, int K) { return M > 0 && F >= 128 && (F % 128) == 0 && K >= BK && (K % BK) == 0; }
+
+static int gemm_nt_geglu_bf16_impl(const void* A, int64_t lda, int K, const void* W1, int64_t ldb, const float* bias,
+                                      void* H, int64_t ldh, void* out, int64_t ldo, int M, int F, float p_drop, uint32_t seed,
+                                      const uint32_t* seed_dev, uint32_t stream_id, int flags, float* ws, int64_t ws_bytes,
+                                      void* stream) {
+    if (M <= 0 || F <= 0) return 0;
+    if (!nt_geglu_ok(M, F, K)) return E2K_ERR_SHAPE;
+    if ((lda & 7) || (ldb & 7) || (ldo & 3) || (H && (ldh & 3))) return E2K_ERR_ALIGN;
+    if (((uintptr_t)A | (uintptr_t)W1) & 15) return E2K_ERR_ALIGN;
+    if (out == nullptr || !(p_drop >= 0.f && p_drop < 1.f)) return E2K_ERR_ARG;
+    NTArgs p{};
+    p.A1 = (const bf16_t*)A; p.lda1 = lda; p.K1 = K;
+    p.B = (const bf16_t*)W1; p.ldb = ldb;
+    p.C = H; p.ldc = ldh; p.M = M; p.N = 2 * F; p.bias = bias;
+    p.glu_out = (bf16_t*)out; p.ldg = ldo;
+    p.seed = seed; p.seed_dev = seed_dev; p.stream_id = stream_id;
+    p.thresh = (unsigned)(p_drop * 65536.f + 0.5f); p.inv_keep = 1.f / (1.f - p_drop);
+    const int T = ((M + QBM - 1) / QBM) * (F / 128);
+    p.full = T; p.split = 1; p.ws = ws;
+    int rem = 0;
+    const int slots = (flags & E2K_GEMM_TEST_SLOTS8) ? 8 : 256;
+    if (ws && !(flags & E2K_GEMM_NO_SPLIT) && T > slots && (T % slots) != 0) {      // same remainder split as the plain kernel
+        rem = T % slots;
+        const int nk = K / BK;
+        int split = 1;
+        while (split * 2 <= 16 && split * 2 * rem <= slots && split * 2 * 4 <= nk) split *= 2;
+        if (!(flags & E2K_GEMM_TEST_SLOTS8))
+            while (split > 1 && 1.0f * nk < 1.2f * (rem * split * 0.104f + 4.f)) split >>= 1;
+        if (split > 1 && (int64_t)rem * split * QBM * QBN * 4 <= ws_bytes) { p.full = T - rem; p.split = split; }
+        else rem = 0;
+    }
+    hipStream_t st = (hipStream_t)stream;
+    hipLaunchKernelGGL((gemm_nt_256_kernel<false, true>), dim3(p.full + rem * p.split), dim3(QTHREADS), 0, st, p);
+    E2K_CHECK_LAUNCH();
+    if (rem) {
+        hipLaunchKernelGGL(gemm_nt_256_fixup_glu_kernel, dim3(rem, 8), dim3(QTHREADS), 0, st, p);
+        E2K_CHECK_LAUNCH();
+    }
+    return 0;
+}
+
+extern "C" int e2k_query_gemm_nt_geglu(int M, int F, int K) { return nt_geglu_ok(M, F, K) ? 1 : 0; }
+
 // 512 partial slots of a 128 x 128 tile or 256 of a 256 x 256 tile (every remainder split fits: rem * split <= slots)
 extern "C" int e2k_query_gemm_nt_ws_bytes(void) { return 256 * QBM * QBN * 4; }
 
@@ -1359,6 +1482,13 @@ extern "C" int e2k_gemm_nt_bf16(const void* A1, int64_t lda1, int K1, const void
                                 int rows_per_batch, const uint8_t* rowmask, const void* resid, int64_t ldr, int flags,
                                 float* ws, int64_t ws_bytes, void* stream) {
     return e2k::dispatch("gemm_nt_bf16", gemm_nt_bf16_impl, A1, lda1, K1, A2, lda2, K2, B, ldb, C, ldc, out_f32, accumulate, M, N, bias, colscale, lds, rows_per_batch, rowmask, resid, ldr, flags, ws, ws_bytes, stream);
+}
+
+extern "C" int e2k_gemm_nt_geglu_bf16(const void* A, int64_t lda, int K, const void* W1, int64_t ldb, const float* bias,
+                                      void* H, int64_t ldh, void* out, int64_t ldo, int M, int F, float p_drop, uint32_t seed,
+                                      const uint32_t* seed_dev, uint32_t stream_id, int flags, float* ws, int64_t ws_bytes,
+                                      void* stream) {
+    return e2k::dispatch("gemm_nt_geglu_bf16", gemm_nt_geglu_bf16_impl, A, lda, K, W1, ldb, bias, H, ldh, out, ldo, M, F, p_drop, seed, seed_dev, stream_id, flags, ws, ws_bytes, stream);
 }
 
 extern "C" int e2k_gemm_tn_bf16(const void* A, int64_t lda, const void* B, int64_t ldb, float* C, int64_t ldc,

@@ -972,8 +972,12 @@ class Transformer(Module):
             gam, off, rpb = run.condall[:, (ind * 4 + 2) * D:(ind * 4 + 3) * D], 1., N
             gate = run.gates[:, (ind * 4 + 3) * D:(ind * 4 + 4) * D]
         xn, rn = ops.rmsnorm_fwd(binp, gam, off, rpb)
-        Hh = ops.gemm_nt(xn, self._w(f.w1, 2 * f.F, D), bias=self._f(f.b1, 2 * f.F))
-        act = ops.geglu_fwd(Hh, run.p_drop, run.seed, sid + 1, run.seed_dev)
+        if ops.fuse_geglu and ops.can_fuse_geglu(xn.shape[0], f.F, D):
+            Hh, act = ops.gemm_nt_geglu(xn, self._w(f.w1, 2 * f.F, D), self._f(f.b1, 2 * f.F), run.p_drop, run.seed, sid + 1,
+                                        run.seed_dev, want_h=exists(tape))
+        else:
+            Hh = ops.gemm_nt(xn, self._w(f.w1, 2 * f.F, D), bias=self._f(f.b1, 2 * f.F))
+            act = ops.geglu_fwd(Hh, run.p_drop, run.seed, sid + 1, run.seed_dev)
         y = ops.gemm_nt(act, self._w(f.w2, D, f.F), bias=self._f(f.b2, D), colscale=gate, rows_per_batch=N)
         self._hc_depth(S, rec, y)
         if exists(tape):

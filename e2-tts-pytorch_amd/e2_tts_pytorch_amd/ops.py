@@ -430,6 +430,34 @@ def geglu_fwd(H, p_drop=0., seed=0, stream_id=0, seed_dev=None):
     return out
 
 
+fuse_geglu = bool(int(_os.environ.get('E2K_FUSE_GEGLU', '0')))     # GEGLU as the epilogue of FeedForward's first GEMM (off: not yet timed on hardware)
+
+
+def can_fuse_geglu(M, F, K):
+    return bool(_lib.get().e2k_query_gemm_nt_geglu(int(M), int(F), int(K)))
+
+
+def gemm_nt_geglu(a, w1, bias=None, p_drop=0., seed=0, stream_id=0, seed_dev=None, want_h=True):
+    """(H, act): H (M, 2F) = a @ w1.T + bias (None if not want_h), act (M, F) = H[:, :F] * gelu(H[:, F:]) * keep --
+    one launch; act is exactly geglu_fwd of the returned H.  Shapes: can_fuse_geglu(M, F, K)."""
+    _chk(a, w1, bias, seed_dev)
+    assert a.dtype == bf16 and w1.dtype == bf16
+    M, lda = _rows(a)
+    N, ldb = _rows(w1)
+    K, F = a.shape[1], N // 2
+    assert w1.shape[1] == K and N == 2 * F
+    if bias is not None:
+        assert bias.dtype == f32 and bias.numel() == N and bias.is_contiguous()
+    H = torch.empty((M, N), dtype=bf16, device=a.device) if want_h else None
+    act = torch.empty((M, F), dtype=bf16, device=a.device)
+    _note(2.0 * M * N * K)
+    stream = _stream(a)
+    _lib.get().e2k_gemm_nt_geglu_bf16(_p(a), lda, K, _p(w1), ldb, _p(bias), _p(H), 0 if H is None else H.stride(0), _p(act), act.stride(0),
+                                      M, F, float(p_drop), int(seed), _p(seed_dev), int(stream_id), gemm_flags,
+                                      *_nt_ws(a.device, stream), stream)
+    return H, act
+
+
 def geglu_bwd(dout, H, p_drop=0., seed=0, stream_id=0, seed_dev=None):
     _chk(dout, H)
     M, F2 = H.shape

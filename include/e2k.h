@@ -118,6 +118,20 @@ int e2k_geglu_fwd(const void* H, int64_t ldh, void* out, int M, int F, float p_d
 int e2k_geglu_bwd(const void* dout, const void* H, int64_t ldh, void* dH, int M, int F, float p_drop,
                   uint32_t seed, const uint32_t* seed_dev, uint32_t stream_id, void* stream);
 
+/* FeedForward's first Linear with the GEGLU (+ Dropout) as the GEMM's epilogue (x_transformers.FeedForward(glu=True),
+ * e2_tts.py:646,692):  h = A (M,K) . W1 (2F,K)^T + bias;  out (M,F) = h[:, :F] * gelu(h[:, F:]) * keep.
+ * One launch instead of e2k_gemm_nt_bf16 + e2k_geglu_fwd: h is rounded to bf16 before the product, so out is exactly
+ * e2k_geglu_fwd of the stored H (and H is bit-identical to e2k_gemm_nt_bf16's wherever both sum K in one pass);
+ * h is stored to H (M, 2F; what e2k_geglu_bwd reads) unless H is NULL (inference).  The 256 x 256 kernel stages the
+ * value rows and the gate rows of W1 as its two B half tiles, which needs F % 128 == 0 and K % 64 == 0:
+ * e2k_query_gemm_nt_geglu returns 1 for shapes it takes, other shapes are refused with E2K_ERR_SHAPE.
+ * flags / ws / ws_bytes as e2k_gemm_nt_bf16 (remainder split); dropout arguments as e2k_geglu_fwd. */
+int e2k_gemm_nt_geglu_bf16(const void* A, int64_t lda, int K, const void* W1, int64_t ldb, const float* bias,
+                           void* H, int64_t ldh, void* out, int64_t ldo, int M, int F, float p_drop, uint32_t seed,
+                           const uint32_t* seed_dev, uint32_t stream_id, int flags, float* ws, int64_t ws_bytes,
+                           void* stream);
+int e2k_query_gemm_nt_geglu(int M, int F, int K);
+
 /* out[n] += sum_m x[m][n]   (bias gradients; x bf16 (M,N), out fp32) */
 int e2k_colsum_bf16(const void* x, int64_t ldx, float* out, int M, int N, void* stream);
 

@@ -285,6 +285,64 @@ def test_launch_lanes_match_single_stream(dev):
             assert torch.equal(a, b), key
 
 
+def test_geglu_epilogue_in_the_backbone(dev):
+    """ops.fuse_geglu (E2K_FUSE_GEGLU=1): FeedForward's GEGLU + dropout as the epilogue of its first GEMM
+    (e2k_gemm_nt_geglu_bf16) instead of a separate pass over H -- training step (H kept for the backward)
+    and inference (H never written), eager and through a recorded plan, with dropout on: the keep mask is a function of
+    (seed, stream id, row, column) only, so the fused and the separate schedules draw the same one."""
+    from e2_tts_pytorch_amd import Transformer, ops
+    random.seed(0)
+    torch.manual_seed(0)
+    big = dev == 'cuda'
+    dim, depth, B, T = (512, 4, 4, 200) if big else (256, 2, 1, 24)
+    mod = Transformer(dim=dim, depth=depth, heads=dim // 64, dropout=0.1, max_seq_len=T)
+    randomize(mod)
+    mod = mod.to(dev)
+    mod.train()
+    R = torch.randn(B, T, dim).to(dev)
+    g = torch.Generator().manual_seed(5)
+    x0, t0, txt0 = torch.randn(B, T, dim, generator=g), torch.rand(B, generator=g), torch.randn(B, T, dim // 2, generator=g)
+
+    def step(train):
+        mod.zero_grad(set_to_none=True)
+        x, txt = x0.clone().to(dev).requires_grad_(train), txt0.clone().to(dev).requires_grad_(train)
+        torch.manual_seed(77)                                # the dropout seed of the step is drawn from torch's generator
+        if not train:
+            mod.eval()
+            with torch.no_grad():
+                out = mod(x, times=t0.to(dev), text_embed=txt)
+            mod.train()
+            return [out.clone()]
+        out = mod(x, times=t0.to(dev), text_embed=txt)
+        (out * R).sum().backward()
+        return [out.detach().clone(), x.grad.clone(), txt.grad.clone()] + [p.grad.clone() for p in mod.parameters()]
+
+    res, names = {}, {}
+    old = ops.fuse_geglu
+    try:
+        for fused in (False, True):
+            ops.fuse_geglu = fused
+            mod._plans.clear()
+            for plans in (False, True):
+                mod.enable_plans(plans)
+                reps = 3 if plans else 1                    # (a signature is recorded the second time it is seen)
+                for _ in range(reps):
+                    res[fused, plans] = step(True), step(False)
+            st = [v for v in mod._plans.values() if not isinstance(v, str) and v.bwd]
+            names[fused] = ops_names(st[0].fwd)
+    finally:
+        ops.fuse_geglu = old
+    assert names[True].count('gemm_nt_geglu_bf16') == 2 * depth and 'geglu_fwd' not in names[True]
+    assert names[False].count('geglu_fwd') == 2 * depth and 'gemm_nt_geglu_bf16' not in names[False]
+    ref = res[False, False]
+    for key in ((True, False), (True, True), (False, True)):
+        for a_list, b_list in zip(ref, res[key]):
+            for a, b in zip(a_list, b_list):
+                assert rel2(b, a) < 2e-3 or float(a.norm()) < 1e-6, (key, rel2(b, a))
+    for a, b in zip(res[True, False][0][:3] + res[True, False][1], res[True, True][0][:3] + res[True, True][1]):
+        assert torch.equal(a, b)                             # plan replay of the fused schedule == its eager run
+
+
 def ops_names(handle):
     import ctypes
     from e2_tts_pytorch_amd import ops
