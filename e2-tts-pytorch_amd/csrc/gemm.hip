@@ -409,11 +409,29 @@ __global__ __launch_bounds__(256) void gemm_nt_fixup_kernel(NTArgs p) {
     nt_epilogue<OUT_F32, 1>(p, acc, tile_m * BM + wm * 64 + i * 16, tile_n * BN + wn * 64, l15, g);
 }
 
+// x * Phi(x) (erf GELU) for the GEGLU epilogue below.  The kernel runs one workgroup per CU, so its epilogue is not hidden
+// behind anything: the library erff (two branches, a full-range expf; ~40 VALU instructions per value) would cost more
+// there than the separate GEGLU pass it replaces.  Abramowitz & Stegun 7.1.26 instead (|error| <= 1.5e-7 in erf, one
+// v_rcp_f32 + one v_exp_f32 + 5 fma):  erfc(z) = t (a1 + t (a2 + t (a3 + t (a4 + t a5)))) exp(-z^2),  t = 1 / (1 + p z),
+// z = |x| / sqrt 2.  With the halved coefficients y = erfc(z) / 2:  Phi(x) = y for x < 0 (no 1 + erf cancellation) and
+// 1 - y otherwise.
+__device__ __forceinline__ float gelu_erf_fast(float x) {
+    const float ax = fabsf(x);
+    const float t = fast_rcp(fmaf(0.3275911f * 0.70710678118654752f, ax, 1.f));
+    float y = fmaf(t, 0.5f * 1.061405429f, 0.5f * -1.453152027f);
+    y = fmaf(t, y, 0.5f * 1.421413741f);
+    y = fmaf(t, y, 0.5f * -0.284496736f);
+    y = fmaf(t, y, 0.5f * 0.254829592f);
+    y = y * t * fast_exp2(x * x * (-0.5f * 1.4426950408889634f));
+    return x * (x < 0.f ? y : 1.f - y);
+}
+
 // GEGLU epilogue of the 256 x 256 kernel (FeedForward(glu=True), e2_tts.py:646,692: `x, gate = proj(x).chunk(2);
 // x * gelu(gate)` + Dropout).  The kernel stages W1 rows [n0, n0+128) as its "B low" half and rows [F + n0, F + n0+128)
 // as its "B high" half, so a lane's accumulators au / ag hold the value and the gate of the SAME (row, 4 columns).
 // The pre-activation is rounded to bf16 first (and stored for the backward when C is set), the product is formed from
-// the rounded values: the output is exactly e2k_geglu_fwd of the stored H.
+// the rounded values: the output is e2k_geglu_fwd of the stored H up to the 1.5e-7 of gelu_erf_fast (below bf16 rounding
+// except for the odd last-place flip).
 template <int NI>
 __device__ __forceinline__ void nt_epilogue_glu(const NTArgs& p, f32x4 (&au)[NI][2], f32x4 (&ag)[NI][2], int mw, int nw, int l15, int g) {
     const int F = p.N >> 1;
@@ -448,7 +466,7 @@ __device__ __forceinline__ void nt_epilogue_glu(const NTArgs& p, f32x4 (&au)[NI]
 #pragma unroll
             for (int r = 0; r < 4; ++r) {
                 const float ks = p.thresh ? keep_scale(seed, p.stream_id, m, n + r, p.thresh, p.inv_keep) : 1.f;
-                o[r] = u[r] * gelu_erf(gt[r]) * ks;
+                o[r] = u[r] * gelu_erf_fast(gt[r]) * ks;
             }
             st<u32x2>(p.glu_out + (long)m * p.ldg + n, pack4(o));
         }

@@ -439,7 +439,7 @@ def can_fuse_geglu(M, F, K):
 
 def gemm_nt_geglu(a, w1, bias=None, p_drop=0., seed=0, stream_id=0, seed_dev=None, want_h=True):
     """(H, act): H (M, 2F) = a @ w1.T + bias (None if not want_h), act (M, F) = H[:, :F] * gelu(H[:, F:]) * keep --
-    one launch; act is exactly geglu_fwd of the returned H.  Shapes: can_fuse_geglu(M, F, K)."""
+    one launch; act is geglu_fwd of the returned H (erf to 1.5e-7).  Shapes: can_fuse_geglu(M, F, K)."""
     _chk(a, w1, bias, seed_dev)
     assert a.dtype == bf16 and w1.dtype == bf16
     M, lda = _rows(a)

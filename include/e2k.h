@@ -120,8 +120,9 @@ int e2k_geglu_bwd(const void* dout, const void* H, int64_t ldh, void* dH, int M,
 
 /* FeedForward's first Linear with the GEGLU (+ Dropout) as the GEMM's epilogue (x_transformers.FeedForward(glu=True),
  * e2_tts.py:646,692):  h = A (M,K) . W1 (2F,K)^T + bias;  out (M,F) = h[:, :F] * gelu(h[:, F:]) * keep.
- * One launch instead of e2k_gemm_nt_bf16 + e2k_geglu_fwd: h is rounded to bf16 before the product, so out is exactly
- * e2k_geglu_fwd of the stored H (and H is bit-identical to e2k_gemm_nt_bf16's wherever both sum K in one pass);
+ * One launch instead of e2k_gemm_nt_bf16 + e2k_geglu_fwd: h is rounded to bf16 before the product, so out is
+ * e2k_geglu_fwd of the stored H up to the erf approximation of the epilogue (|error| <= 1.5e-7, below bf16 rounding), and H
+ * is bit-identical to e2k_gemm_nt_bf16's wherever both sum K in one pass;
  * h is stored to H (M, 2F; what e2k_geglu_bwd reads) unless H is NULL (inference).  The 256 x 256 kernel stages the
  * value rows and the gate rows of W1 as its two B half tiles, which needs F % 128 == 0 and K % 64 == 0:
  * e2k_query_gemm_nt_geglu returns 1 for shapes it takes, other shapes are refused with E2K_ERR_SHAPE.

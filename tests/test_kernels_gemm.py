@@ -300,10 +300,9 @@ def test_gemm_nt_geglu_epilogue(dev, monkeypatch, M, F, K, p, flags, bias, want_
     finally:
         ops.gemm_flags = old
     # the activation is formed from the bf16-rounded H, exactly as the separate kernel reads it
-    # (bit for bit on the kernel model; on hardware the two kernels are separate compilations of the same expression --
-    #  until that has been seen to give the same bits there, allow the odd last-place difference)
-    same = (lambda x, y: torch.equal(x.cpu(), y.cpu())) if dev == 'cpu' else \
-        (lambda x, y: (x.cpu() != y.cpu()).float().mean().item() < 1e-4 and rel(x, y) < 1e-2)
+    # the epilogue's erf is a 1.5e-7 approximation (csrc/gemm.hip: gelu_erf_fast): below bf16 rounding but for the odd last place,
+    # and it differs (towards the exact value) for gates below about -3.7, where the separate kernel's fp32 `1 + erf` cancels
+    same = lambda x, y: (x.cpu() != y.cpu()).float().mean().item() < 1e-2 and rel(x, y) < 8e-3
     if want_h:
         assert same(act, ops.geglu_fwd(H, p, seed, sid))
     else:
@@ -314,10 +313,35 @@ def test_gemm_nt_geglu_epilogue(dev, monkeypatch, M, F, K, p, flags, bias, want_
     if not (flags & 32):
         assert same(act, act2) and (H is None or torch.equal(H.cpu(), H2.cpu()))
     else:
-        assert (act.cpu() != act2.cpu()).float().mean().item() < 1e-3 and rel(act, act2) < 1e-2
-        assert H is None or rel(H, H2) < 1e-2
+        assert same(act, act2) and (H is None or ((H.cpu() != H2.cpu()).float().mean().item() < 1e-3 and rel(H, H2) < 1e-2))
     h = a.float() @ w1.float().T + (b1 if bias else 0.)
     ref = h[:, :F] * Fn.gelu(h[:, F:]) * (geglu_dropout_mask(seed, sid, M, F, p) if p else 1.)
     assert rel(act, ref) < 1e-2
     with pytest.raises(Exception):
         ops.gemm_nt_geglu(d(a), d(torch.zeros(2 * (F + 8), K).to(bf16)), None)
+
+
+def test_gelu_erf_fast_accuracy(dev):
+    """the GEGLU epilogue's x * Phi(x) (Abramowitz & Stegun 7.1.26 with one rcp + one exp2; csrc/gemm.hip) against
+    float64 erf over the range of bf16 gates: within one bf16 last place of the exact value from -5 up, and no
+    `1 + erf` cancellation on the negative side (the tail keeps a relative accuracy of a few percent down to -12).  The gates go in through the
+    bias (A = W1 = 0; value bias 1, gate bias g), one launch per row of 128 gates."""
+    import math
+    from e2_tts_pytorch_amd import ops
+    M, F, K = 16, 128, 64
+    gates = torch.cat([torch.linspace(-12., 12., 3072), torch.randn(1024) * 3.]).to(bf16).float().view(-1, F)
+    a, w1 = torch.zeros(M, K).to(bf16).to(dev), torch.zeros(2 * F, K).to(bf16).to(dev)
+    worst_tail = 0.
+    for gb in gates:
+        _, act = ops.gemm_nt_geglu(a, w1, torch.cat([torch.ones(F), gb]).to(dev), want_h=False)
+        x = gb.double()
+        ref = x * 0.5 * torch.erfc(-x / math.sqrt(2.))
+        got = act[0].cpu().double()
+        body = x >= -5.
+        assert ((got - ref).abs() <= ref.abs() * 2. ** -7 + 1e-38)[body].all(), ((got - ref).abs() / ref.abs().clamp_min(1e-38))[body].max()
+        tail = ~body & (ref.abs() > 1e-36)
+        if tail.any():
+            worst_tail = max(worst_tail, ((got - ref) / ref).abs()[tail].max().item())
+    # beyond -5 (|value| < 1.5e-6 |x|) the formula's relative error grows slowly (3 % at -12, where the value is 1e-32);
+    # the separate kernel's fp32 `1 + erf` is exactly 0 from about -5.5 on
+    assert 0. < worst_tail < 0.05, worst_tail
