@@ -81,7 +81,7 @@ class _Lib:
 
 
 _lib = None
-_host_pointers_ok = False      # only the test-side logic checker sets this (tests/emu)
+_host_pointers_ok = False      # only the test-side logic checker sets this (tests/emu/install.py)
 
 
 def get() -> _Lib:
@@ -92,13 +92,6 @@ def get() -> _Lib:
                            '(hipcc --offload-arch=gfx950); there is no CPU / PyTorch fallback')
         _lib = _Lib(_LIB_PATH)
     return _lib
-
-
-def _install_for_tests(path, host_pointers: bool):
-    """tests only: swap in another build of the same ABI (the host logic-checker build)."""
-    global _lib, _host_pointers_ok
-    _lib = _Lib(path) if path is not None else None
-    _host_pointers_ok = host_pointers
 
 
 def host_pointers_ok() -> bool:

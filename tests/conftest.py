@@ -4,6 +4,12 @@ from pathlib import Path
 
 import pytest
 
+
+def install_lib(path, host_pointers):
+    from emu.install import install
+    install(path, host_pointers)
+
+
 ROOT = Path(__file__).resolve().parent.parent
 for p in (ROOT / 'e2-tts-pytorch_amd', ROOT, ROOT / 'tests'):
     if str(p) not in sys.path:
@@ -33,9 +39,9 @@ def emu_lib():
 @pytest.fixture()
 def emu(emu_lib):
     from e2_tts_pytorch_amd import _lib
-    _lib._install_for_tests(emu_lib, host_pointers=True)
+    install_lib(emu_lib, host_pointers=True)
     yield _lib.get()
-    _lib._install_for_tests(None, host_pointers=False)
+    install_lib(None, host_pointers=False)
 
 
 @pytest.fixture(params=['emu', pytest.param('gpu', marks=pytest.mark.gpu)])
@@ -45,12 +51,12 @@ def dev(request):
     from e2_tts_pytorch_amd import _lib
     if request.param == 'emu':
         lib = request.getfixturevalue('emu_lib')
-        _lib._install_for_tests(lib, host_pointers=True)
+        install_lib(lib, host_pointers=True)
         yield 'cpu'
-        _lib._install_for_tests(None, host_pointers=False)
+        install_lib(None, host_pointers=False)
     else:
         import torch
         assert torch.cuda.is_available(), 'gpu tests need a HIP device'
-        _lib._install_for_tests(None, host_pointers=False)
+        install_lib(None, host_pointers=False)
         _lib.get()                      # raises if libe2k.so is missing: no silent fallback
         yield 'cuda'

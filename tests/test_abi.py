@@ -4,6 +4,12 @@ from pathlib import Path
 
 import pytest
 
+
+def install_lib(path, host_pointers):
+    from emu.install import install
+    install(path, host_pointers)
+
+
 ROOT = Path(__file__).resolve().parent.parent
 
 
@@ -29,7 +35,7 @@ def test_no_cpu_fallback():
     """product ops refuse CPU tensors (the host logic-checker is only reachable through the test fixtures)"""
     import torch
     from e2_tts_pytorch_amd import _lib, ops
-    _lib._install_for_tests(None, host_pointers=False)
+    install_lib(None, host_pointers=False)
     with pytest.raises(_lib.E2KError):
         ops.gemm_nt(torch.zeros(8, 8, dtype=torch.bfloat16), torch.zeros(8, 8, dtype=torch.bfloat16))
 

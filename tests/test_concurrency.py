@@ -6,13 +6,19 @@ runs one kernel at a time."""
 import pytest
 import torch
 
+
+def install_lib(path, host_pointers):
+    from emu.install import install
+    install(path, host_pointers)
+
+
 bf16 = torch.bfloat16
 
 
 @pytest.mark.gpu
 def test_results_do_not_depend_on_a_concurrent_gemm():
     from e2_tts_pytorch_amd import ops, _lib
-    _lib._install_for_tests(None, host_pointers=False)
+    install_lib(None, host_pointers=False)
     dev = 'cuda'
     torch.manual_seed(0)
     M, D = 960, 512
@@ -79,7 +85,7 @@ def test_data_parallel_hook_waits_for_the_launch_lanes():
     from e2_tts_pytorch_amd import Transformer, _lib
     from e2_tts_pytorch_amd.ddp import DataParallel
     from test_backbone import randomize, rel2
-    _lib._install_for_tests(None, host_pointers=False)
+    install_lib(None, host_pointers=False)
     dev = 'cuda'
     random.seed(0)
     torch.manual_seed(0)

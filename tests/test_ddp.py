@@ -11,6 +11,12 @@ import torch
 import torch.distributed as dist
 import torch.multiprocessing as mp
 
+
+def install_lib(path, host_pointers):
+    from emu.install import install
+    install(path, host_pointers)
+
+
 ROOT = Path(__file__).resolve().parent.parent
 
 
@@ -22,7 +28,7 @@ def _worker(rank, world, port, emu_lib, q):
     from e2_tts_pytorch_amd import E2TTS, _lib
     from e2_tts_pytorch_amd.ddp import DataParallel
     from test_backbone import randomize
-    _lib._install_for_tests(emu_lib, host_pointers=True)
+    install_lib(emu_lib, host_pointers=True)
     random.seed(7 + rank)                 # different init per rank: the wrapper must broadcast rank 0's weights
     torch.manual_seed(7 + rank)
     model = E2TTS(transformer=dict(dim=256, depth=2, heads=4, dropout=0.), use_vocos=False, cond_drop_prob=0.)

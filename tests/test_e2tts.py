@@ -10,6 +10,11 @@ from oracle import e2tts_oracle as O
 from test_backbone import randomize
 
 
+def install_lib(path, host_pointers):
+    from emu.install import install
+    install(path, host_pointers)
+
+
 def rel2(a, b):
     a, b = a.detach().cpu().float(), b.detach().cpu().float()
     return ((a - b).norm() / b.norm().clamp_min(1e-20)).item()
@@ -36,7 +41,7 @@ def test_melspec_cpu_tensor_stages_through_the_device():
     a CPU wave goes through the same HIP kernel (staged to the device, log-mel copied back) and comes back on the CPU"""
     import copy
     from e2_tts_pytorch_amd import MelSpec, _lib
-    _lib._install_for_tests(None, host_pointers=False)
+    install_lib(None, host_pointers=False)
     torch.manual_seed(0)
     wave = torch.randn(3, 256 * 40 + 5)
     m = MelSpec()
@@ -54,7 +59,7 @@ def test_melspec_cpu_tensor_without_a_device_raises():
     from e2_tts_pytorch_amd import MelSpec, _lib
     if torch.cuda.is_available():
         pytest.skip('a HIP device is visible')
-    _lib._install_for_tests(None, host_pointers=False)
+    install_lib(None, host_pointers=False)
     with pytest.raises(_lib.E2KError):
         MelSpec()(torch.randn(1, 4096))
 
@@ -123,7 +128,7 @@ def test_e2tts_cfg3_width():
     """the widths the headline benchmark runs (dim 1024 / text dim 512 / 16 heads), two layers, ragged batch, against
     the oracle: the D = 1024 / 512 kernel variants end to end on the hardware"""
     from e2_tts_pytorch_amd import _lib
-    _lib._install_for_tests(None, host_pointers=False)
+    install_lib(None, host_pointers=False)
     torch.set_num_threads(min(32, torch.get_num_threads()))
     kw = dict(dim=1024, depth=2, heads=16, dropout=0.)
     ref, model = _pair(kw)

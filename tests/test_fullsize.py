@@ -23,6 +23,12 @@ from oracle import e2tts_oracle as O
 
 from test_backbone import randomize
 
+
+def install_lib(path, host_pointers):
+    from emu.install import install
+    install(path, host_pointers)
+
+
 pytestmark = [pytest.mark.gpu, pytest.mark.late]
 ROOT = Path(__file__).resolve().parent.parent
 
@@ -40,7 +46,7 @@ def _report(name, rec):
 
 def _pair(kw, init, seed=0):
     from e2_tts_pytorch_amd import E2TTS, _lib
-    _lib._install_for_tests(None, host_pointers=False)
+    install_lib(None, host_pointers=False)
     random.seed(seed)
     torch.manual_seed(seed)
     ref = O.E2TTS(transformer=dict(**kw), cond_drop_prob=0.)

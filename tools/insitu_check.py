@@ -28,6 +28,12 @@ from oracle import e2tts_oracle as O  # noqa: E402
 from oracle.golden_weights import fill_params  # noqa: E402
 
 
+def install_lib(path, host_pointers):
+    sys.path.insert(0, os.path.join(ROOT, 'tests'))
+    from emu.install import install
+    install(path, host_pointers)
+
+
 def rel(a, b):
     return ((a.float().cpu() - b.float().cpu()).norm() / b.float().cpu().norm().clamp_min(1e-30)).item()
 
@@ -114,11 +120,11 @@ def main():
         return
     if a.gpu:
         dev = 'cuda'
-        _lib._install_for_tests(None, host_pointers=False)
+        install_lib(None, host_pointers=False)
     else:
         from emu.build_emu import build
         dev = 'cpu'
-        _lib._install_for_tests(build(), host_pointers=True)
+        install_lib(build(), host_pointers=True)
     mod = mod.to(dev)
     worst = {}
 

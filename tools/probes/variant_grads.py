@@ -7,7 +7,14 @@ import torch
 from e2_tts_pytorch_amd import Transformer, _lib
 from oracle.golden_weights import fill_params
 from emu.build_emu import build
-_lib._install_for_tests(build(), host_pointers=True)
+
+
+def install_lib(path, host_pointers):
+    from emu.install import install
+    install(path, host_pointers)
+
+
+install_lib(build(), host_pointers=True)
 case = sys.argv[1] if len(sys.argv) > 1 else 'transformer_variant'
 c = torch.load(ROOT / 'tests' / 'golden' / 'reference_pinned.pt', weights_only=False)[case]
 random.seed(0)
