@@ -345,3 +345,27 @@ def test_gelu_erf_fast_accuracy(dev):
     # beyond -5 (|value| < 1.5e-6 |x|) the formula's relative error grows slowly (3 % at -12, where the value is 1e-32);
     # the separate kernel's fp32 `1 + erf` is exactly 0 from about -5.5 on
     assert 0. < worst_tail < 0.05, worst_tail
+
+
+@pytest.mark.parametrize('M', [1, 17, 257])
+def test_gemm_nt_geglu_edge_shapes(dev, M):
+    """GEGLU-epilogue GEMM on ragged row counts (1 row, a partial 16-row group, one row past a tile) with operands that
+    are column slices of wider buffers (row strides larger than K), against the two separate launches"""
+    from e2_tts_pytorch_amd import ops
+    torch.manual_seed(M)
+    F, K = 128, 128
+    abuf = (torch.randn(M, K + 64) * 0.5).to(bf16).to(dev)
+    wbuf = (torch.randn(2 * F, K + 192) * 0.1).to(bf16).to(dev)
+    a, w1 = abuf[:, 64:], wbuf[:, 128:128 + K]              # 16-byte aligned starts, strides K + 64 / K + 192
+    b1 = torch.randn(2 * F).to(dev)
+    H, act = ops.gemm_nt_geglu(a, w1, b1, 0.2, 99, 3)
+    old = ops.gemm_flags
+    ops.gemm_flags = 128
+    try:
+        H2 = ops.gemm_nt(a, w1, bias=b1)
+    finally:
+        ops.gemm_flags = old
+    act2 = ops.geglu_fwd(H2, 0.2, 99, 3)
+    assert torch.equal(H.cpu(), H2.cpu())
+    assert (act.cpu() != act2.cpu()).float().mean().item() < 2e-2 and rel(act, act2) < 8e-3
+    assert H.shape == (M, 2 * F) and act.shape == (M, F)
