@@ -284,12 +284,22 @@ def test_launch_lanes_match_single_stream(dev):
         for a, b in zip(ref_i, got_i):
             assert torch.equal(a, b), key
 
+def _first_hardware_run_pending(dev):
+    """the E2K_FUSE_GEGLU path (off by default) was written after the GPU minutes of round 2 were spent: its hardware
+    variants run when asked for (E2K_TEST_UNTIMED=1, set by tools/gpu/round3_first.sh), so that a never-executed kernel
+    cannot take the -x run of the default path down with it"""
+    import os
+    if dev == 'cuda' and os.environ.get('E2K_TEST_UNTIMED', '0') != '1':
+        pytest.skip('E2K_FUSE_GEGLU path: first hardware run pending (E2K_TEST_UNTIMED=1 runs it)')
+
+
 
 def test_geglu_epilogue_in_the_backbone(dev):
     """ops.fuse_geglu (E2K_FUSE_GEGLU=1): FeedForward's GEGLU + dropout as the epilogue of its first GEMM
     (e2k_gemm_nt_geglu_bf16) instead of a separate pass over H -- training step (H kept for the backward)
     and inference (H never written), eager and through a recorded plan, with dropout on: the keep mask is a function of
     (seed, stream id, row, column) only, so the fused and the separate schedules draw the same one."""
+    _first_hardware_run_pending(dev)
     from e2_tts_pytorch_amd import Transformer, ops
     random.seed(0)
     torch.manual_seed(0)

@@ -265,6 +265,15 @@ def test_gemm_random_shapes(dev):
     finally:
         ops.gemm_flags = old
 
+def _first_hardware_run_pending(dev):
+    """the E2K_FUSE_GEGLU path (off by default) was written after the GPU minutes of round 2 were spent: its hardware
+    variants run when asked for (E2K_TEST_UNTIMED=1, set by tools/gpu/round3_first.sh), so that a never-executed kernel
+    cannot take the -x run of the default path down with it"""
+    import os
+    if dev == 'cuda' and os.environ.get('E2K_TEST_UNTIMED', '0') != '1':
+        pytest.skip('E2K_FUSE_GEGLU path: first hardware run pending (E2K_TEST_UNTIMED=1 runs it)')
+
+
 
 @pytest.mark.parametrize('M,F,K,p,flags,bias,want_h', [
     (256, 128, 256, 0.0, 0, 1, 1),          # one tile: value rows | gate rows as the two B half tiles
@@ -277,6 +286,7 @@ def test_gemm_nt_geglu_epilogue(dev, monkeypatch, M, F, K, p, flags, bias, want_
     """FeedForward GEMM1 with the GEGLU (+ dropout) as its epilogue (e2_tts.py:646,692) against the two
     launches it replaces (the epilogue rounds H to bf16 before the product, as the separate kernel reads it) and against
     the fp32 formula with the oracle's dropout mask"""
+    _first_hardware_run_pending(dev)
     import torch.nn.functional as Fn
     from e2_tts_pytorch_amd import ops
     from oracle.dropout_hash import geglu_dropout_mask
@@ -326,6 +336,7 @@ def test_gelu_erf_fast_accuracy(dev):
     float64 erf over the range of bf16 gates: within one bf16 last place of the exact value from -5 up, and no
     `1 + erf` cancellation on the negative side (the tail keeps a relative accuracy of a few percent down to -12).  The gates go in through the
     bias (A = W1 = 0; value bias 1, gate bias g), one launch per row of 128 gates."""
+    _first_hardware_run_pending(dev)
     import math
     from e2_tts_pytorch_amd import ops
     M, F, K = 16, 128, 64
@@ -351,6 +362,7 @@ def test_gelu_erf_fast_accuracy(dev):
 def test_gemm_nt_geglu_edge_shapes(dev, M):
     """GEGLU-epilogue GEMM on ragged row counts (1 row, a partial 16-row group, one row past a tile) with operands that
     are column slices of wider buffers (row strides larger than K), against the two separate launches"""
+    _first_hardware_run_pending(dev)
     from e2_tts_pytorch_amd import ops
     torch.manual_seed(M)
     F, K = 128, 128
