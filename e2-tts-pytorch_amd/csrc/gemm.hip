@@ -744,7 +744,47 @@ struct TNArgs {
     float* ws;                   // [splits][N][K] partial tiles when splits > 1
     int M, N, K, splits, chunk;
     float* colsum; int cs_from;  // optional: colsum[n] += sum_m A[m][n] for n >= cs_from (bias gradient of the same dY)
+    int* counters;               // optional (splits > 1): one arrival counter per output tile, zero on entry and on exit:
+                                 // the LAST workgroup of a tile to arrive sums the partial tiles into C (no tn_reduce_kernel)
 };
+
+// In-kernel finish of a token-split weight gradient (TNArgs::counters).  Every workgroup has stored its partial tile to
+// ws[split]; the one whose arrival makes the count complete reads ALL partials of the tile back in split order and adds
+// the sum to C -- the arithmetic of tn_reduce_kernel (s = 0; s += ws[0..splits); C += s), so the result is the same
+// bits whichever workgroup comes last.  Release / acquire at agent scope around the counter: the partials of the other
+// workgroups were written through other XCDs' L2s.
+template <int TILE, int THREADS>
+__device__ __forceinline__ void tn_finish_last(const TNArgs& p, int tile, int n0, int k0, int tid) {
+    __shared__ int last_arrival;
+    __threadfence();                                   // release: this thread's partial-tile stores
+    __syncthreads();
+    if (tid == 0) last_arrival = (atomicAdd(p.counters + tile, 1) == p.splits - 1) ? 1 : 0;
+    __syncthreads();
+    if (!last_arrival) return;
+    __threadfence();                                   // acquire: the other workgroups' partial tiles
+    const long total = (long)p.N * p.K;
+    if ((p.K & 3) == 0 && (p.ldc & 3) == 0) {
+        constexpr int C4 = TILE / 4;
+        for (int idx = tid; idx < TILE * C4; idx += THREADS) {
+            const int n = n0 + idx / C4, k = k0 + (idx % C4) * 4;
+            if (n >= p.N || k >= p.K) continue;
+            f32x4 sum = {0.f, 0.f, 0.f, 0.f};
+            const float* w = p.ws + (long)n * p.K + k;
+            for (int sp = 0; sp < p.splits; ++sp) sum += ld<f32x4>(w + sp * total);
+            float* c = p.C + (long)n * p.ldc + k;
+            st<f32x4>(c, ld<f32x4>(c) + sum);
+        }
+    } else {
+        for (int idx = tid; idx < TILE * TILE; idx += THREADS) {
+            const int n = n0 + idx / TILE, k = k0 + idx % TILE;
+            if (n >= p.N || k >= p.K) continue;
+            float sum = 0.f;
+            for (int sp = 0; sp < p.splits; ++sp) sum += p.ws[sp * total + (long)n * p.K + k];
+            p.C[(long)n * p.ldc + k] += sum;
+        }
+    }
+    if (tid == 0) p.counters[tile] = 0;               // (nobody else touches this counter any more: ready for the next launch)
+}
 
 template <bool USE_TR>
 __device__ __forceinline__ bf16x8 tn_frag(const unsigned char* T, int kk, int col0, int q, int g) {
@@ -871,6 +911,7 @@ __global__ __launch_bounds__(256) void gemm_tn_kernel(TNArgs p) {
         __syncthreads();
     }
     tn_store(p, acc, n0, k0, wn, wk, q, g);
+    if (p.counters && p.splits > 1) tn_finish_last<128, 256>(p, tile_n * tk + tile_k, n0, k0, threadIdx.x);
 }
 
 // Fast TN path (token count a multiple of 64): global_load_lds staging into unpadded 256-B LDS rows whose 16-B chunks
@@ -989,6 +1030,7 @@ __global__ __launch_bounds__(256, 2) void gemm_tn_glds_kernel(TNArgs p) {
             if (n < p.N && n >= p.cs_from) atomicAdd(p.colsum + n, cs[jj][0]);
         }
     }
+    if (p.counters && p.splits > 1) tn_finish_last<128, 256>(p, tile_n * tk + tile_k, n0, k0, threadIdx.x);
 }
 
 // 256 x 256 output tile, EIGHT waves, 8 phases per pair of 64-row reduction steps: the weight-gradient sibling of
@@ -1221,6 +1263,7 @@ __global__ __launch_bounds__(T2THREADS, 1) void gemm_tn_256_kernel(TNArgs p) {
             if (n < p.N && n >= p.cs_from) atomicAdd(p.colsum + n, cs[a][0]);
         }
     }
+    if (p.counters && p.splits > 1) tn_finish_last<T2, T2THREADS>(p, tile_n * tk + tile_k, n0, k0, tid);
 }
 
 // (A pipelined variant of this kernel -- 32 token rows per step, four 16-KB LDS stages, loads three steps ahead with a
@@ -1448,9 +1491,11 @@ extern "C" int e2k_query_gemm_tn_splits_mode(int M, int N, int K, int splits, in
 
 extern "C" int e2k_colsum_bf16(const void* x, int64_t ldx, float* out, int M, int N, void* stream);
 
+constexpr int TN_COUNTERS = 4096;      // arrival counters of the in-kernel finish: one per output tile
+
 static int gemm_tn_bf16_impl(const void* A, int64_t lda, const void* B, int64_t ldb, float* C, int64_t ldc,
                                 int M, int N, int K, int splits, int use_tr, float* ws, float* colsum, int cs_from,
-                                void* stream) {
+                                int* counters, void* stream) {
     if (M <= 0 || N <= 0 || K <= 0) return 0;
     // 16-B loads may run past N / K up to the next multiple of 8: that must still be inside the row
     if ((lda & 7) || (ldb & 7) || ((N + 7) & ~7) > lda || ((K + 7) & ~7) > ldb) return E2K_ERR_ALIGN;
@@ -1462,8 +1507,9 @@ static int gemm_tn_bf16_impl(const void* A, int64_t lda, const void* B, int64_t 
     int chunk = (M + splits - 1) / splits;
     chunk = (chunk + TBM - 1) / TBM * TBM;
     if (splits > 1 && ws == nullptr) return E2K_ERR_ARG;
+    if (counters && tn * tk > TN_COUNTERS) return E2K_ERR_SHAPE;
     TNArgs p;
-    p.ws = ws;
+    p.ws = ws; p.counters = counters;
     p.A = (const bf16_t*)A; p.lda = lda; p.B = (const bf16_t*)B; p.ldb = ldb;
     p.C = C; p.ldc = ldc; p.M = M; p.N = N; p.K = K; p.splits = splits; p.chunk = chunk;
     const bool fast = use_tr && (M % TBM) == 0 && N >= 8 && K >= 8;
@@ -1481,7 +1527,7 @@ static int gemm_tn_bf16_impl(const void* A, int64_t lda, const void* B, int64_t 
     else if (use_tr) hipLaunchKernelGGL(gemm_tn_kernel<true>, grid, block, 0, (hipStream_t)stream, p);
     else hipLaunchKernelGGL(gemm_tn_kernel<false>, grid, block, 0, (hipStream_t)stream, p);
     E2K_CHECK_LAUNCH();
-    if (splits > 1) {
+    if (splits > 1 && !counters) {
         long total = (long)N * K;
         long g = (total + 255) / 256;
         if (g > 2048) g = 2048;
@@ -1512,5 +1558,14 @@ extern "C" int e2k_gemm_nt_geglu_bf16(const void* A, int64_t lda, int K, const v
 extern "C" int e2k_gemm_tn_bf16(const void* A, int64_t lda, const void* B, int64_t ldb, float* C, int64_t ldc,
                                 int M, int N, int K, int splits, int use_tr, float* ws, float* colsum, int cs_from,
                                 void* stream) {
-    return e2k::dispatch("gemm_tn_bf16", gemm_tn_bf16_impl, A, lda, B, ldb, C, ldc, M, N, K, splits, use_tr, ws, colsum, cs_from, stream);
+    return e2k::dispatch("gemm_tn_bf16", gemm_tn_bf16_impl, A, lda, B, ldb, C, ldc, M, N, K, splits, use_tr, ws, colsum, cs_from, (int*)nullptr, stream);
 }
+
+extern "C" int e2k_gemm_tn_self_reduce_bf16(const void* A, int64_t lda, const void* B, int64_t ldb, float* C, int64_t ldc,
+                                            int M, int N, int K, int splits, int use_tr, float* ws, float* colsum, int cs_from,
+                                            int32_t* counters, void* stream) {
+    if (counters == nullptr) return E2K_ERR_ARG;
+    return e2k::dispatch("gemm_tn_self_reduce_bf16", gemm_tn_bf16_impl, A, lda, B, ldb, C, ldc, M, N, K, splits, use_tr, ws, colsum, cs_from, (int*)counters, stream);
+}
+
+extern "C" int e2k_query_gemm_tn_counters(void) { return TN_COUNTERS; }

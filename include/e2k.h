@@ -60,6 +60,14 @@ int e2k_query_gemm_nt_ws_bytes(void);
  * columns with an all-ones operand. */
 int e2k_gemm_tn_bf16(const void* A, int64_t lda, const void* B, int64_t ldb, float* C, int64_t ldc,
                      int M, int N, int K, int splits, int use_tr, float* ws, float* colsum, int cs_from, void* stream);
+/* The same weight gradient with the split finished INSIDE the kernel instead of by a second launch: `counters` points to
+ * e2k_query_gemm_tn_counters() int32 arrival counters (one per output tile) that are ZERO on entry and are left zero;
+ * the last workgroup of a tile to arrive adds the partial tiles to C in split order (the reduce kernel's arithmetic:
+ * same bits).  Launches that share `counters` must not overlap (one buffer per stream).  Not yet timed on hardware. */
+int e2k_gemm_tn_self_reduce_bf16(const void* A, int64_t lda, const void* B, int64_t ldb, float* C, int64_t ldc,
+                                 int M, int N, int K, int splits, int use_tr, float* ws, float* colsum, int cs_from,
+                                 int32_t* counters, void* stream);
+int e2k_query_gemm_tn_counters(void);
 /* number of token-dimension splits the call above will use for (M, N, K, splits); when it is > 1 the caller passes
  * ws = scratch of splits*N*K floats (partial tiles are stored there and combined by a second small kernel). */
 int e2k_query_gemm_tn_splits(int M, int N, int K, int splits);

@@ -336,6 +336,7 @@ static inline double atomicAdd(double* p, double v) {       // (blocks run on se
     }
 }
 static inline int atomicAdd(int* p, int v) { return __atomic_fetch_add(p, v, __ATOMIC_RELAXED); }
+static inline void __threadfence() { __atomic_thread_fence(__ATOMIC_SEQ_CST); }      // (blocks run on several OS threads)
 static inline unsigned atomicAdd(unsigned* p, unsigned v) { return __atomic_fetch_add(p, v, __ATOMIC_RELAXED); }
 
 // ---- MFMA (gfx950) ----

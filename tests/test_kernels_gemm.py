@@ -381,3 +381,45 @@ def test_gemm_nt_geglu_edge_shapes(dev, M):
     assert torch.equal(H.cpu(), H2.cpu())
     assert (act.cpu() != act2.cpu()).float().mean().item() < 2e-2 and rel(act, act2) < 8e-3
     assert H.shape == (M, 2 * F) and act.shape == (M, F)
+
+
+@pytest.mark.parametrize('M,N,K,splits,mode,cs,pad', [
+    (512, 128, 128, 4, 1, 0, 0),         # one tile, four splits (128 x 128 kernel)
+    (1024, 296, 200, 4, 1, 1, 0),        # ragged tiles (3 x 2) with the bias-gradient column sums
+    (1024, 512, 512, 4, 3, 0, 0),        # 256 x 256 kernel, 4 tiles x 4 splits
+    (768, 264, 136, 3, 2, 1, 1),         # C is a column slice with an odd row stride: scalar finish
+    (200, 128, 136, 2, 1, 0, 0),         # M not a multiple of 64: the general kernel
+])
+def test_gemm_tn_self_reduce(dev, M, N, K, splits, mode, cs, pad):
+    """token-split weight gradient finished inside the GEMM (e2k_gemm_tn_self_reduce_bf16: the last workgroup of a tile to
+    arrive sums the partial tiles in split order) against the two-launch form (GEMM + tn_reduce_kernel): the same bits,
+    accumulated onto a non-zero C, and the arrival counters are back at zero (three launches in a row reuse them)"""
+    from e2_tts_pytorch_amd import ops
+    _first_hardware_run_pending(dev)
+    torch.manual_seed(M + N)
+    a = torch.randn(M, N).to(bf16).to(dev)
+    b = torch.randn(M, K).to(bf16).to(dev)
+    c0 = torch.randn(N, K)
+    old = ops.tn_self_reduce
+    res = {}
+    try:
+        for fused in (False, True):
+            ops.tn_self_reduce = fused
+            buf = torch.zeros(N, K + pad).to(dev)
+            out = buf[:, :K]
+            out.copy_(c0)
+            col = torch.ones(N).to(dev) if cs else None
+            for _ in range(3):
+                ops.gemm_tn(a, b, out, splits=splits, use_tr=mode, colsum=col, colsum_from=0)
+            assert pad == 0 or float(buf[:, K:].abs().sum()) == 0.
+            res[fused] = out.cpu().clone(), None if col is None else col.cpu()
+    finally:
+        ops.tn_self_reduce = old
+    assert ops.lib().e2k_query_gemm_tn_splits_mode(M, N, K, splits, mode) > 1
+    assert torch.equal(res[True][0], res[False][0])
+    if cs:
+        assert rel(res[True][1], res[False][1]) < 1e-5             # (fp32 atomics: order)
+    cnt = ops._tn_counter_cache[next(k for k in ops._tn_counter_cache if k[0] == a.device)]
+    assert int(cnt.abs().sum()) == 0
+    ref = c0 + 3 * (a.float().cpu().T @ b.float().cpu())
+    assert rel(res[True][0], ref) < 2e-3
