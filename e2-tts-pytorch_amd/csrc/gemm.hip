@@ -57,7 +57,23 @@ struct NTArgs {
     int full, split; float* ws;
     // GEGLU epilogue (gemm_nt_256_kernel<false, true> only): N = 2F, C = pre-activation H (may be NULL), glu_out (M, F)
     bf16_t* glu_out; long ldg; unsigned seed, stream_id, thresh; float inv_keep; const unsigned* seed_dev;
+    // in-kernel fix-up (E2K_GEMM_SELF_FIXUP): one arrival counter per remainder tile, zero on entry and on exit; the LAST
+    // K-range part of a tile to arrive sums the parts in order and runs the epilogue (no fix-up launch)
+    int* counters;
 };
+
+// arrival of one K-range part of remainder tile r: true for the part that completes the tile.  Release / acquire at agent
+// scope around the counter: the other parts were written through other XCDs' L2s.
+__device__ __forceinline__ bool nt_part_arrived(const NTArgs& p, int r, int tid) {
+    __shared__ int last_part;
+    __threadfence();
+    __syncthreads();
+    if (tid == 0) last_part = (atomicAdd(p.counters + r, 1) == p.split - 1) ? 1 : 0;
+    __syncthreads();
+    if (!last_part) return false;
+    __threadfence();
+    return true;
+}
 
 // epilogue of an interior tile (all 128 x 128 outputs exist, rows 8-byte aligned): no per-element bounds checks, the
 // optional operands are selected once per tile (wave-uniform), bias kept in registers across the 4 row groups
@@ -268,7 +284,7 @@ __global__ __launch_bounds__(256) void gemm_nt_kernel(NTArgs p) {
 // source column) advance by one scalar add per step, the 16 fragment-read offsets are loop-invariant VGPRs and the
 // loop is unrolled by two so that the LDS buffer select is an immediate offset (the first version of this loop spent
 // ~50 VALU instructions per 32 MFMAs on address arithmetic: PMC showed 3.6 VALU per MFMA and MFMA busy at 25 %).
-template <bool OUT_F32>
+template <bool OUT_F32, bool SELF = false>
 __global__ __launch_bounds__(256, 2) void gemm_nt_glds_kernel(NTArgs p) {
     __shared__ __attribute__((aligned(16))) unsigned char smem[2][2][BM * BK * 2];
     const int tid = threadIdx.x, lane = tid & 63, wave = uniform_i(tid >> 6);
@@ -382,7 +398,22 @@ __global__ __launch_bounds__(256, 2) void gemm_nt_glds_kernel(NTArgs p) {
         for (int i = 0; i < 4; ++i)
 #pragma unroll
             for (int j = 0; j < 4; ++j) st<f32x4>(w + (i * 4 + j) * 1024, acc[i][j]);
-        return;
+        if (!SELF) return;                                    // (gemm_nt_fixup_kernel finishes the tile)
+        const int r = part / p.split;
+        if (!nt_part_arrived(p, r, tid)) return;
+        // last part of this tile: total = parts in K order, exactly as gemm_nt_fixup_kernel adds them
+        const float* w0 = p.ws + ((long)r * p.split * 16 * 256 + tid) * 4;
+#pragma unroll
+        for (int i = 0; i < 4; ++i)
+#pragma unroll
+            for (int j = 0; j < 4; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+        for (int sidx = 0; sidx < p.split; ++sidx) {
+#pragma unroll
+            for (int i = 0; i < 4; ++i)
+#pragma unroll
+                for (int j = 0; j < 4; ++j) acc[i][j] += ld<f32x4>(w0 + ((long)sidx * 16 + i * 4 + j) * 1024);
+        }
+        if (tid == 0) p.counters[r] = 0;
     }
     nt_epilogue<OUT_F32, 4>(p, acc, m0 + wm * 64, n0 + wn * 64, l15, g);
 }
@@ -505,7 +536,7 @@ __device__ __forceinline__ void nt_epilogue_glu(const NTArgs& p, f32x4 (&au)[NI]
 //   * In the last five phases nothing is left to issue, and the count is lowered step by step (4, 2, 0).
 constexpr int QBM = 256, QBN = 256, QHALF = 128 * BK * 2, QBUF = 4 * QHALF, QTHREADS = 512;
 
-template <bool OUT_F32, bool GLU = false>
+template <bool OUT_F32, bool GLU = false, bool SELF = false>          // SELF: remainder tiles finish in the kernel (NTArgs::counters)
 __global__ __launch_bounds__(QTHREADS, 1) void gemm_nt_256_kernel(NTArgs p) {
     __shared__ __attribute__((aligned(16))) unsigned char smem[2 * QBUF];
     const int tid = threadIdx.x, lane = tid & 63, wave = uniform_i(tid >> 6);
@@ -671,7 +702,29 @@ __global__ __launch_bounds__(QTHREADS, 1) void gemm_nt_256_kernel(NTArgs p) {
                 for (int i = 0; i < 4; ++i)
 #pragma unroll
                     for (int j = 0; j < 2; ++j) st<f32x4>(w + (((a * 2 + b) * 4 + i) * 2 + j) * (QTHREADS * 4), acc[a][b][i][j]);
-        return;
+        if (!SELF) return;                                    // (the fix-up kernels finish the tile)
+        const int r = part / p.split;
+        if (!nt_part_arrived(p, r, tid)) return;
+        // last part of this tile: total = parts in K order (the fix-up kernels' arithmetic), one quadrant at a time
+        const float* w0 = p.ws + ((long)r * p.split * 32 * QTHREADS + tid) * 4;
+#pragma unroll
+        for (int a = 0; a < 2; ++a)
+#pragma unroll
+            for (int b = 0; b < 2; ++b) {
+#pragma unroll
+                for (int i = 0; i < 4; ++i)
+#pragma unroll
+                    for (int j = 0; j < 2; ++j) acc[a][b][i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+                for (int sidx = 0; sidx < p.split; ++sidx) {
+#pragma unroll
+                    for (int i = 0; i < 4; ++i)
+#pragma unroll
+                        for (int j = 0; j < 2; ++j)
+                            acc[a][b][i][j] += ld<f32x4>(w0 + ((long)sidx * 32 + ((a * 2 + b) * 4 + i) * 2 + j) * (QTHREADS * 4));
+                }
+                sched_fence();
+            }
+        if (tid == 0) p.counters[r] = 0;
     }
     if (GLU) {
 #pragma unroll
@@ -1354,6 +1407,10 @@ static int gemm_nt_bf16_impl(const void* A1, int64_t lda1, int K1, const void* A
     p.bias = bias; p.colscale = colscale; p.lds = lds; p.rows_per_batch = rows_per_batch;
     p.rowmask = rowmask; p.resid = (const bf16_t*)resid; p.ldr = ldr;
     const int tn = (N + BN - 1) / BN;
+    // E2K_GEMM_SELF_FIXUP: the last 4 KB of ws are zeroed arrival counters (left zero), remainder tiles finish in the kernel
+    int* counters = nullptr;
+    if ((flags & E2K_GEMM_SELF_FIXUP) && ws && ws_bytes >= 8192) { ws_bytes -= 4096; counters = (int*)((char*)ws + ws_bytes); }
+    p.counters = nullptr;
     p.probe = flags & (E2K_GEMM_PROBE_NO_LOADS | E2K_GEMM_PROBE_NO_MATH);
     const bool glds = !(flags & E2K_GEMM_NO_GLDS) && (K1 % BK) == 0 && (K2 % BK) == 0;
     const int t256 = ((M + QBM - 1) / QBM) * ((N + QBN - 1) / QBN);
@@ -1378,12 +1435,15 @@ static int gemm_nt_bf16_impl(const void* A1, int64_t lda1, int K1, const void* A
             if (split > 1 && (int64_t)rem * split * QBM * QBN * 4 <= ws_bytes) { p.full = T - rem; p.split = split; }
             else rem = 0;
         }
+        if (rem && rem <= 1024) p.counters = counters;
         dim3 grid(p.full + rem * p.split);
         hipStream_t st = (hipStream_t)stream;
-        if (out_f32) hipLaunchKernelGGL(gemm_nt_256_kernel<true>, grid, dim3(QTHREADS), 0, st, p);
+        if (p.counters && out_f32) hipLaunchKernelGGL((gemm_nt_256_kernel<true, false, true>), grid, dim3(QTHREADS), 0, st, p);
+        else if (p.counters) hipLaunchKernelGGL((gemm_nt_256_kernel<false, false, true>), grid, dim3(QTHREADS), 0, st, p);
+        else if (out_f32) hipLaunchKernelGGL(gemm_nt_256_kernel<true>, grid, dim3(QTHREADS), 0, st, p);
         else hipLaunchKernelGGL(gemm_nt_256_kernel<false>, grid, dim3(QTHREADS), 0, st, p);
         E2K_CHECK_LAUNCH();
-        if (rem) {
+        if (rem && !p.counters) {
             if (out_f32) hipLaunchKernelGGL(gemm_nt_256_fixup_kernel<true>, dim3(rem, 16), dim3(QTHREADS), 0, st, p);
             else hipLaunchKernelGGL(gemm_nt_256_fixup_kernel<false>, dim3(rem, 16), dim3(QTHREADS), 0, st, p);
             E2K_CHECK_LAUNCH();
@@ -1411,9 +1471,13 @@ static int gemm_nt_bf16_impl(const void* A1, int64_t lda1, int K1, const void* A
         if (split > 1 && (int64_t)rem * split * BM * BN * 4 <= ws_bytes) { p.full = T - rem; p.split = split; }
         else rem = 0;
     }
+    if (rem && rem <= 1024) p.counters = counters;
     dim3 grid(p.full + rem * p.split), block(256);
     hipStream_t st = (hipStream_t)stream;
-    if (out_f32) {
+    if (p.counters) {             // (only with glds: the remainder split above requires it)
+        if (out_f32) hipLaunchKernelGGL((gemm_nt_glds_kernel<true, true>), grid, block, 0, st, p);
+        else hipLaunchKernelGGL((gemm_nt_glds_kernel<false, true>), grid, block, 0, st, p);
+    } else if (out_f32) {
         if (glds) hipLaunchKernelGGL(gemm_nt_glds_kernel<true>, grid, block, 0, st, p);
         else hipLaunchKernelGGL(gemm_nt_kernel<true>, grid, block, 0, st, p);
     } else {
@@ -1421,7 +1485,7 @@ static int gemm_nt_bf16_impl(const void* A1, int64_t lda1, int K1, const void* A
         else hipLaunchKernelGGL(gemm_nt_kernel<false>, grid, block, 0, st, p);
     }
     E2K_CHECK_LAUNCH();
-    if (rem) {
+    if (rem && !p.counters) {
         if (out_f32) hipLaunchKernelGGL(gemm_nt_fixup_kernel<true>, dim3(rem, 4), block, 0, st, p);
         else hipLaunchKernelGGL(gemm_nt_fixup_kernel<false>, dim3(rem, 4), block, 0, st, p);
         E2K_CHECK_LAUNCH();
@@ -1451,6 +1515,8 @@ static int gemm_nt_geglu_bf16_impl(const void* A, int64_t lda, int K, const void
     p.seed = seed; p.seed_dev = seed_dev; p.stream_id = stream_id;
     p.thresh = (unsigned)(p_drop * 65536.f + 0.5f); p.inv_keep = 1.f / (1.f - p_drop);
     const int T = ((M + QBM - 1) / QBM) * (F / 128);
+    int* counters = nullptr;
+    if ((flags & E2K_GEMM_SELF_FIXUP) && ws && ws_bytes >= 8192) { ws_bytes -= 4096; counters = (int*)((char*)ws + ws_bytes); }
     p.full = T; p.split = 1; p.ws = ws;
     int rem = 0;
     const int slots = (flags & E2K_GEMM_TEST_SLOTS8) ? 8 : 256;
@@ -1465,9 +1531,11 @@ static int gemm_nt_geglu_bf16_impl(const void* A, int64_t lda, int K, const void
         else rem = 0;
     }
     hipStream_t st = (hipStream_t)stream;
-    hipLaunchKernelGGL((gemm_nt_256_kernel<false, true>), dim3(p.full + rem * p.split), dim3(QTHREADS), 0, st, p);
+    if (rem && rem <= 1024) p.counters = counters;
+    if (p.counters) hipLaunchKernelGGL((gemm_nt_256_kernel<false, true, true>), dim3(p.full + rem * p.split), dim3(QTHREADS), 0, st, p);
+    else hipLaunchKernelGGL((gemm_nt_256_kernel<false, true>), dim3(p.full + rem * p.split), dim3(QTHREADS), 0, st, p);
     E2K_CHECK_LAUNCH();
-    if (rem) {
+    if (rem && !p.counters) {
         hipLaunchKernelGGL(gemm_nt_256_fixup_glu_kernel, dim3(rem, 8), dim3(QTHREADS), 0, st, p);
         E2K_CHECK_LAUNCH();
     }

@@ -194,11 +194,13 @@ _nt_ws_cache = {}
 
 def _nt_ws(device, stream):
     """fp32 scratch of the NT GEMM remainder split: one per (device, stream) -- launches of one stream use it one after
-    the other, launches of different streams (launch lanes) may overlap"""
+    the other, launches of different streams (launch lanes) may overlap.  Its last 4 KB are the arrival counters of the
+    in-kernel fix-up (E2K_GEMM_SELF_FIXUP = 512 in gemm_flags): zeroed once here, left zero by every launch."""
     key = (device, stream)
     w = _nt_ws_cache.get(key)
     if w is None:
-        w = torch.empty(_lib.get().e2k_query_gemm_nt_ws_bytes() // 4, dtype=f32, device=device)
+        w = torch.empty(_lib.get().e2k_query_gemm_nt_ws_bytes() // 4 + 1024, dtype=f32, device=device)
+        fill_(w[-1024:])
         _nt_ws_cache[key] = w
     return _p(w), w.numel() * 4
 

@@ -51,6 +51,7 @@ int e2k_query_gemm_nt_ws_bytes(void);
 #define E2K_GEMM_NO_T256 256     /* flags: never use the 256 x 256 kernel (A/B) */
 #define E2K_GEMM_NO_SPLIT 16     /* flags: never split remainder tiles over K (A/B) */
 #define E2K_GEMM_TEST_SLOTS8 32  /* flags: pretend the chip holds 8 workgroups (lets small shapes exercise the remainder split in tests) */
+#define E2K_GEMM_SELF_FIXUP 512  /* flags: the last 4096 bytes of ws are int32 arrival counters, ZERO on entry (left zero): the last K-range part of a remainder tile to arrive sums the parts and runs the epilogue inside the GEMM kernel -- no fix-up launch, same bits.  One ws per stream.  Not yet timed on hardware */
 
 /* C[N,K] += A[M,N]^T . B[M,K]  (weight gradients; C fp32, A = dY, B = X, bf16).  The token dimension M is
  * split over `splits` workgroups per tile (0 = choose); partial tiles go to `ws` and are combined by a reduce kernel.

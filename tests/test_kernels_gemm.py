@@ -423,3 +423,69 @@ def test_gemm_tn_self_reduce(dev, M, N, K, splits, mode, cs, pad):
     assert int(cnt.abs().sum()) == 0
     ref = c0 + 3 * (a.float().cpu().T @ b.float().cpu())
     assert rel(res[True][0], ref) < 2e-3
+
+
+@pytest.mark.parametrize('M,N,K1,K2,kw,base', [
+    (1100, 260, 256, 0, dict(bias=1), 32),                          # 128 x 128 kernel: 27 tiles on 8 slots, 3 remainder tiles
+    (1100, 392, 256, 128, dict(bias=1, cs=1, rm=1, rs=1), 32),      # ... dual-K, every epilogue operand
+    (520, 392, 512, 0, dict(f32=1, bias=1), 32),                    # ... fp32 output
+    (2304, 256, 512, 0, dict(f32=1, bias=1), 32 | 128),             # 256 x 256 kernel: 1 remainder tile x 2 K ranges
+    (1280, 512, 256, 256, dict(bias=1, cs=1, rm=1, rs=1), 32 | 128),  # ... 2 remainder tiles, dual-K, every epilogue operand
+])
+@pytest.mark.parametrize('late', [0, 1])
+def test_gemm_nt_self_fixup(dev, monkeypatch, M, N, K1, K2, kw, base, late):
+    """remainder tiles finished inside the GEMM kernel (E2K_GEMM_SELF_FIXUP: the last K-range part of a tile to arrive sums
+    the parts in K order and runs the epilogue) against the fix-up launch: the same bits, three launches in a row on the
+    same counters, counters back at zero"""
+    from e2_tts_pytorch_amd import ops
+    _first_hardware_run_pending(dev)
+    if dev == 'cuda' and late:
+        pytest.skip('LDS-DMA landing extremes exist on the host model only')
+    monkeypatch.setenv('E2K_EMU_GLDS_LATE', str(late))
+    torch.manual_seed(M + N)
+    d = lambda t: None if t is None else t.to(dev)
+    a = d(torch.randn(M, K1).to(bf16))
+    a2 = d(torch.randn(M, K2).to(bf16)) if K2 else None
+    b = d(torch.randn(N, K1 + K2).to(bf16))
+    bias = d(torch.randn(N)) if kw.get('bias') else None
+    nb = 3
+    rpb = (M + nb - 1) // nb
+    cs = d(torch.rand(nb, N)) if kw.get('cs') else None
+    rm = d(torch.rand(M) > 0.3) if kw.get('rm') else None
+    rs = d(torch.randn(M, N).to(bf16)) if kw.get('rs') else None
+    old = ops.gemm_flags
+    res = {}
+    try:
+        for flags in (base, base | 512):
+            ops.gemm_flags = flags
+            for _ in range(3):
+                out = ops.gemm_nt(a, b, a2=a2, bias=bias, colscale=cs, rows_per_batch=rpb, rowmask=rm, resid=rs,
+                                  out_dtype=torch.float32 if kw.get('f32') else bf16)
+            res[flags] = out.cpu()
+    finally:
+        ops.gemm_flags = old
+    assert torch.equal(res[base], res[base | 512])
+    ws = next(v for k, v in ops._nt_ws_cache.items() if k[0] == a.device)
+    assert int(ws[-1024:].view(torch.int32).abs().sum()) == 0
+
+
+def test_gemm_nt_geglu_self_fixup(dev):
+    """the GEGLU-epilogue GEMM with its remainder tiles finished in the kernel: same bits as with the GEGLU fix-up launch"""
+    from e2_tts_pytorch_amd import ops
+    _first_hardware_run_pending(dev)
+    torch.manual_seed(3)
+    M, F, K = 2304, 256, 512                 # 18 tiles on the 8-slot hook: 2 remainder tiles x 2 K ranges
+    a = (torch.randn(M, K) * 0.5).to(bf16).to(dev)
+    w1 = (torch.randn(2 * F, K) * 0.1).to(bf16).to(dev)
+    b1 = torch.randn(2 * F).to(dev)
+    old = ops.gemm_flags
+    res = {}
+    try:
+        for flags in (32, 32 | 512):
+            ops.gemm_flags = flags
+            for _ in range(2):
+                H, act = ops.gemm_nt_geglu(a, w1, b1, 0.1, 5, 2)
+            res[flags] = H.cpu(), act.cpu()
+    finally:
+        ops.gemm_flags = old
+    assert torch.equal(res[32][0], res[32 | 512][0]) and torch.equal(res[32][1], res[32 | 512][1])
