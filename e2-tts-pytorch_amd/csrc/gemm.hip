@@ -889,7 +889,7 @@ __device__ __forceinline__ void tn_store(const TNArgs& p, f32x4 (&acc)[4][4], in
     }
 }
 
-template <bool USE_TR>
+template <bool USE_TR, bool SELF = false>          // SELF: the token split is finished in the kernel (TNArgs::counters)
 __global__ __launch_bounds__(256) void gemm_tn_kernel(TNArgs p) {
     __shared__ __attribute__((aligned(16))) unsigned char smem[2][2][TBM * TLD];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -964,13 +964,13 @@ __global__ __launch_bounds__(256) void gemm_tn_kernel(TNArgs p) {
         __syncthreads();
     }
     tn_store(p, acc, n0, k0, wn, wk, q, g);
-    if (p.counters && p.splits > 1) tn_finish_last<128, 256>(p, tile_n * tk + tile_k, n0, k0, threadIdx.x);
+    if (SELF && p.splits > 1) tn_finish_last<128, 256>(p, tile_n * tk + tile_k, n0, k0, threadIdx.x);
 }
 
 // Fast TN path (token count a multiple of 64): global_load_lds staging into unpadded 256-B LDS rows whose 16-B chunks
 // are XOR-swizzled by 2*(row & 7) on the SOURCE side (conflict-free ds_read_b64_tr_b16: the 8 rows a half-wave reads
 // land on 8 distinct chunk pairs of the 256-B bank row), scalar base + hoisted 32-bit lane offsets, two LDS buffers.
-template <bool CS>       // CS: also accumulate the column sums of A (bias gradient) in the k-tile-0 workgroups
+template <bool CS, bool SELF = false>       // CS: also accumulate the column sums of A (bias gradient) in the k-tile-0 workgroups
 __global__ __launch_bounds__(256, 2) void gemm_tn_glds_kernel(TNArgs p) {
     __shared__ __attribute__((aligned(16))) unsigned char smem[2][2][TBM * 256];
     const int tid = threadIdx.x, lane = tid & 63, wave = uniform_i(tid >> 6);
@@ -1083,7 +1083,7 @@ __global__ __launch_bounds__(256, 2) void gemm_tn_glds_kernel(TNArgs p) {
             if (n < p.N && n >= p.cs_from) atomicAdd(p.colsum + n, cs[jj][0]);
         }
     }
-    if (p.counters && p.splits > 1) tn_finish_last<128, 256>(p, tile_n * tk + tile_k, n0, k0, threadIdx.x);
+    if (SELF && p.splits > 1) tn_finish_last<128, 256>(p, tile_n * tk + tile_k, n0, k0, threadIdx.x);
 }
 
 // 256 x 256 output tile, EIGHT waves, 8 phases per pair of 64-row reduction steps: the weight-gradient sibling of
@@ -1096,7 +1096,7 @@ __global__ __launch_bounds__(256, 2) void gemm_tn_glds_kernel(TNArgs p) {
 // Half the LDS-read bytes per flop and a quarter of the partial-tile traffic per flop of the 128 x 128 kernel.
 constexpr int T2 = 256, T2HALF = TBM * 256, T2BUF = 4 * T2HALF, T2THREADS = 512;
 
-template <bool CS>
+template <bool CS, bool SELF = false>
 __global__ __launch_bounds__(T2THREADS, 1) void gemm_tn_256_kernel(TNArgs p) {
     __shared__ __attribute__((aligned(16))) unsigned char smem[2 * T2BUF];
     const int tid = threadIdx.x, lane = tid & 63, wave = uniform_i(tid >> 6);
@@ -1316,7 +1316,7 @@ __global__ __launch_bounds__(T2THREADS, 1) void gemm_tn_256_kernel(TNArgs p) {
             if (n < p.N && n >= p.cs_from) atomicAdd(p.colsum + n, cs[a][0]);
         }
     }
-    if (p.counters && p.splits > 1) tn_finish_last<T2, T2THREADS>(p, tile_n * tk + tile_k, n0, k0, tid);
+    if (SELF && p.splits > 1) tn_finish_last<T2, T2THREADS>(p, tile_n * tk + tile_k, n0, k0, tid);
 }
 
 // (A pipelined variant of this kernel -- 32 token rows per step, four 16-KB LDS stages, loads three steps ahead with a
@@ -1588,7 +1588,15 @@ static int gemm_tn_bf16_impl(const void* A, int64_t lda, const void* B, int64_t 
         if (rc) return rc;
     }
     dim3 grid(tn * tk, splits), block(256);
-    if (big && p.colsum) hipLaunchKernelGGL(gemm_tn_256_kernel<true>, grid, dim3(T2THREADS), 0, (hipStream_t)stream, p);
+    const bool self = counters && splits > 1;
+    if (!self) p.counters = nullptr;
+    if (self && big && p.colsum) hipLaunchKernelGGL((gemm_tn_256_kernel<true, true>), grid, dim3(T2THREADS), 0, (hipStream_t)stream, p);
+    else if (self && big) hipLaunchKernelGGL((gemm_tn_256_kernel<false, true>), grid, dim3(T2THREADS), 0, (hipStream_t)stream, p);
+    else if (self && fast && p.colsum) hipLaunchKernelGGL((gemm_tn_glds_kernel<true, true>), grid, block, 0, (hipStream_t)stream, p);
+    else if (self && fast) hipLaunchKernelGGL((gemm_tn_glds_kernel<false, true>), grid, block, 0, (hipStream_t)stream, p);
+    else if (self && use_tr) hipLaunchKernelGGL((gemm_tn_kernel<true, true>), grid, block, 0, (hipStream_t)stream, p);
+    else if (self) hipLaunchKernelGGL((gemm_tn_kernel<false, true>), grid, block, 0, (hipStream_t)stream, p);
+    else if (big && p.colsum) hipLaunchKernelGGL(gemm_tn_256_kernel<true>, grid, dim3(T2THREADS), 0, (hipStream_t)stream, p);
     else if (big) hipLaunchKernelGGL(gemm_tn_256_kernel<false>, grid, dim3(T2THREADS), 0, (hipStream_t)stream, p);
     else if (fast && p.colsum) hipLaunchKernelGGL(gemm_tn_glds_kernel<true>, grid, block, 0, (hipStream_t)stream, p);
     else if (fast) hipLaunchKernelGGL(gemm_tn_glds_kernel<false>, grid, block, 0, (hipStream_t)stream, p);
