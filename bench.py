@@ -310,7 +310,7 @@ def main():
             'mfma_roofline_frac_whole_step': sf / (dt / args.steps) / 1e12 / PEAK_BF16_TFLOPS,
             'loss': loss_val,
             'host_enqueue_ms_per_step': t_enqueue / args.steps * 1e3,
-            'launch_mode': launch_mode_note, 'gemm_flags': ops.gemm_flags, 'fuse_geglu': bool(ops.fuse_geglu), 'tn_self_reduce': bool(ops.tn_self_reduce),
+            'launch_mode': launch_mode_note, 'gemm_flags': ops.gemm_flags, 'fuse_geglu': bool(ops.fuse_geglu),
             'launches_per_step': (len(prof_rows) // nprof) if prof_rows else None,
             'lane_ms_per_step': _lane_ms(prof_rows, nprof),          # work of each lane, every call timed alone: the step cannot be shorter than the longest chain
             'launch_lanes': {'on': bool(getattr(tr, '_lanes_on', False)), 'backward': bool(getattr(tr, '_lanes_bwd', False)), 'ordering_points_per_step': lane_ops,

@@ -57,23 +57,7 @@ struct NTArgs {
     int full, split; float* ws;
     // GEGLU epilogue (gemm_nt_256_kernel<false, true> only): N = 2F, C = pre-activation H (may be NULL), glu_out (M, F)
     bf16_t* glu_out; long ldg; unsigned seed, stream_id, thresh; float inv_keep; const unsigned* seed_dev;
-    // in-kernel fix-up (E2K_GEMM_SELF_FIXUP): one arrival counter per remainder tile, zero on entry and on exit; the LAST
-    // K-range part of a tile to arrive sums the parts in order and runs the epilogue (no fix-up launch)
-    int* counters;
 };
-
-// arrival of one K-range part of remainder tile r: true for the part that completes the tile.  Release / acquire at agent
-// scope around the counter: the other parts were written through other XCDs' L2s.
-__device__ __forceinline__ bool nt_part_arrived(const NTArgs& p, int r, int tid) {
-    __shared__ int last_part;
-    __threadfence();
-    __syncthreads();
-    if (tid == 0) last_part = (atomicAdd(p.counters + r, 1) == p.split - 1) ? 1 : 0;
-    __syncthreads();
-    if (!last_part) return false;
-    __threadfence();
-    return true;
-}
 
 // epilogue of an interior tile (all 128 x 128 outputs exist, rows 8-byte aligned): no per-element bounds checks, the
 // optional operands are selected once per tile (wave-uniform), bias kept in registers across the 4 row groups
@@ -284,7 +268,7 @@ __global__ __launch_bounds__(256) void gemm_nt_kernel(NTArgs p) {
 // source column) advance by one scalar add per step, the 16 fragment-read offsets are loop-invariant VGPRs and the
 // loop is unrolled by two so that the LDS buffer select is an immediate offset (the first version of this loop spent
 // ~50 VALU instructions per 32 MFMAs on address arithmetic: PMC showed 3.6 VALU per MFMA and MFMA busy at 25 %).
-template <bool OUT_F32, bool SELF = false>
+template <bool OUT_F32>
 __global__ __launch_bounds__(256, 2) void gemm_nt_glds_kernel(NTArgs p) {
     __shared__ __attribute__((aligned(16))) unsigned char smem[2][2][BM * BK * 2];
     const int tid = threadIdx.x, lane = tid & 63, wave = uniform_i(tid >> 6);
@@ -398,22 +382,7 @@ __global__ __launch_bounds__(256, 2) void gemm_nt_glds_kernel(NTArgs p) {
         for (int i = 0; i < 4; ++i)
 #pragma unroll
             for (int j = 0; j < 4; ++j) st<f32x4>(w + (i * 4 + j) * 1024, acc[i][j]);
-        if (!SELF) return;                                    // (gemm_nt_fixup_kernel finishes the tile)
-        const int r = part / p.split;
-        if (!nt_part_arrived(p, r, tid)) return;
-        // last part of this tile: total = parts in K order, exactly as gemm_nt_fixup_kernel adds them
-        const float* w0 = p.ws + ((long)r * p.split * 16 * 256 + tid) * 4;
-#pragma unroll
-        for (int i = 0; i < 4; ++i)
-#pragma unroll
-            for (int j = 0; j < 4; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
-        for (int sidx = 0; sidx < p.split; ++sidx) {
-#pragma unroll
-            for (int i = 0; i < 4; ++i)
-#pragma unroll
-                for (int j = 0; j < 4; ++j) acc[i][j] += ld<f32x4>(w0 + ((long)sidx * 16 + i * 4 + j) * 1024);
-        }
-        if (tid == 0) p.counters[r] = 0;
+        return;                                               // (gemm_nt_fixup_kernel finishes the tile)
     }
     nt_epilogue<OUT_F32, 4>(p, acc, m0 + wm * 64, n0 + wn * 64, l15, g);
 }
@@ -536,7 +505,7 @@ __device__ __forceinline__ void nt_epilogue_glu(const NTArgs& p, f32x4 (&au)[NI]
 //   * In the last five phases nothing is left to issue, and the count is lowered step by step (4, 2, 0).
 constexpr int QBM = 256, QBN = 256, QHALF = 128 * BK * 2, QBUF = 4 * QHALF, QTHREADS = 512;
 
-template <bool OUT_F32, bool GLU = false, bool SELF = false>          // SELF: remainder tiles finish in the kernel (NTArgs::counters)
+template <bool OUT_F32, bool GLU = false>
 __global__ __launch_bounds__(QTHREADS, 1) void gemm_nt_256_kernel(NTArgs p) {
     __shared__ __attribute__((aligned(16))) unsigned char smem[2 * QBUF];
     const int tid = threadIdx.x, lane = tid & 63, wave = uniform_i(tid >> 6);
@@ -702,29 +671,7 @@ __global__ __launch_bounds__(QTHREADS, 1) void gemm_nt_256_kernel(NTArgs p) {
                 for (int i = 0; i < 4; ++i)
 #pragma unroll
                     for (int j = 0; j < 2; ++j) st<f32x4>(w + (((a * 2 + b) * 4 + i) * 2 + j) * (QTHREADS * 4), acc[a][b][i][j]);
-        if (!SELF) return;                                    // (the fix-up kernels finish the tile)
-        const int r = part / p.split;
-        if (!nt_part_arrived(p, r, tid)) return;
-        // last part of this tile: total = parts in K order (the fix-up kernels' arithmetic), one quadrant at a time
-        const float* w0 = p.ws + ((long)r * p.split * 32 * QTHREADS + tid) * 4;
-#pragma unroll
-        for (int a = 0; a < 2; ++a)
-#pragma unroll
-            for (int b = 0; b < 2; ++b) {
-#pragma unroll
-                for (int i = 0; i < 4; ++i)
-#pragma unroll
-                    for (int j = 0; j < 2; ++j) acc[a][b][i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
-                for (int sidx = 0; sidx < p.split; ++sidx) {
-#pragma unroll
-                    for (int i = 0; i < 4; ++i)
-#pragma unroll
-                        for (int j = 0; j < 2; ++j)
-                            acc[a][b][i][j] += ld<f32x4>(w0 + ((long)sidx * 32 + ((a * 2 + b) * 4 + i) * 2 + j) * (QTHREADS * 4));
-                }
-                sched_fence();
-            }
-        if (tid == 0) p.counters[r] = 0;
+        return;                                               // (the fix-up kernels finish the tile)
     }
     if (GLU) {
 #pragma unroll
@@ -797,47 +744,7 @@ struct TNArgs {
     float* ws;                   // [splits][N][K] partial tiles when splits > 1
     int M, N, K, splits, chunk;
     float* colsum; int cs_from;  // optional: colsum[n] += sum_m A[m][n] for n >= cs_from (bias gradient of the same dY)
-    int* counters;               // optional (splits > 1): one arrival counter per output tile, zero on entry and on exit:
-                                 // the LAST workgroup of a tile to arrive sums the partial tiles into C (no tn_reduce_kernel)
 };
-
-// In-kernel finish of a token-split weight gradient (TNArgs::counters).  Every workgroup has stored its partial tile to
-// ws[split]; the one whose arrival makes the count complete reads ALL partials of the tile back in split order and adds
-// the sum to C -- the arithmetic of tn_reduce_kernel (s = 0; s += ws[0..splits); C += s), so the result is the same
-// bits whichever workgroup comes last.  Release / acquire at agent scope around the counter: the partials of the other
-// workgroups were written through other XCDs' L2s.
-template <int TILE, int THREADS>
-__device__ __forceinline__ void tn_finish_last(const TNArgs& p, int tile, int n0, int k0, int tid) {
-    __shared__ int last_arrival;
-    __threadfence();                                   // release: this thread's partial-tile stores
-    __syncthreads();
-    if (tid == 0) last_arrival = (atomicAdd(p.counters + tile, 1) == p.splits - 1) ? 1 : 0;
-    __syncthreads();
-    if (!last_arrival) return;
-    __threadfence();                                   // acquire: the other workgroups' partial tiles
-    const long total = (long)p.N * p.K;
-    if ((p.K & 3) == 0 && (p.ldc & 3) == 0) {
-        constexpr int C4 = TILE / 4;
-        for (int idx = tid; idx < TILE * C4; idx += THREADS) {
-            const int n = n0 + idx / C4, k = k0 + (idx % C4) * 4;
-            if (n >= p.N || k >= p.K) continue;
-            f32x4 sum = {0.f, 0.f, 0.f, 0.f};
-            const float* w = p.ws + (long)n * p.K + k;
-            for (int sp = 0; sp < p.splits; ++sp) sum += ld<f32x4>(w + sp * total);
-            float* c = p.C + (long)n * p.ldc + k;
-            st<f32x4>(c, ld<f32x4>(c) + sum);
-        }
-    } else {
-        for (int idx = tid; idx < TILE * TILE; idx += THREADS) {
-            const int n = n0 + idx / TILE, k = k0 + idx % TILE;
-            if (n >= p.N || k >= p.K) continue;
-            float sum = 0.f;
-            for (int sp = 0; sp < p.splits; ++sp) sum += p.ws[sp * total + (long)n * p.K + k];
-            p.C[(long)n * p.ldc + k] += sum;
-        }
-    }
-    if (tid == 0) p.counters[tile] = 0;               // (nobody else touches this counter any more: ready for the next launch)
-}
 
 template <bool USE_TR>
 __device__ __forceinline__ bf16x8 tn_frag(const unsigned char* T, int kk, int col0, int q, int g) {
@@ -889,7 +796,7 @@ __device__ __forceinline__ void tn_store(const TNArgs& p, f32x4 (&acc)[4][4], in
     }
 }
 
-template <bool USE_TR, bool SELF = false>          // SELF: the token split is finished in the kernel (TNArgs::counters)
+template <bool USE_TR>
 __global__ __launch_bounds__(256) void gemm_tn_kernel(TNArgs p) {
     __shared__ __attribute__((aligned(16))) unsigned char smem[2][2][TBM * TLD];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -964,13 +871,12 @@ __global__ __launch_bounds__(256) void gemm_tn_kernel(TNArgs p) {
         __syncthreads();
     }
     tn_store(p, acc, n0, k0, wn, wk, q, g);
-    if (SELF && p.splits > 1) tn_finish_last<128, 256>(p, tile_n * tk + tile_k, n0, k0, threadIdx.x);
 }
 
 // Fast TN path (token count a multiple of 64): global_load_lds staging into unpadded 256-B LDS rows whose 16-B chunks
 // are XOR-swizzled by 2*(row & 7) on the SOURCE side (conflict-free ds_read_b64_tr_b16: the 8 rows a half-wave reads
 // land on 8 distinct chunk pairs of the 256-B bank row), scalar base + hoisted 32-bit lane offsets, two LDS buffers.
-template <bool CS, bool SELF = false>       // CS: also accumulate the column sums of A (bias gradient) in the k-tile-0 workgroups
+template <bool CS>       // CS: also accumulate the column sums of A (bias gradient) in the k-tile-0 workgroups
 __global__ __launch_bounds__(256, 2) void gemm_tn_glds_kernel(TNArgs p) {
     __shared__ __attribute__((aligned(16))) unsigned char smem[2][2][TBM * 256];
     const int tid = threadIdx.x, lane = tid & 63, wave = uniform_i(tid >> 6);
@@ -1083,7 +989,6 @@ __global__ __launch_bounds__(256, 2) void gemm_tn_glds_kernel(TNArgs p) {
             if (n < p.N && n >= p.cs_from) atomicAdd(p.colsum + n, cs[jj][0]);
         }
     }
-    if (SELF && p.splits > 1) tn_finish_last<128, 256>(p, tile_n * tk + tile_k, n0, k0, threadIdx.x);
 }
 
 // 256 x 256 output tile, EIGHT waves, 8 phases per pair of 64-row reduction steps: the weight-gradient sibling of
@@ -1096,7 +1001,7 @@ __global__ __launch_bounds__(256, 2) void gemm_tn_glds_kernel(TNArgs p) {
 // Half the LDS-read bytes per flop and a quarter of the partial-tile traffic per flop of the 128 x 128 kernel.
 constexpr int T2 = 256, T2HALF = TBM * 256, T2BUF = 4 * T2HALF, T2THREADS = 512;
 
-template <bool CS, bool SELF = false>
+template <bool CS>
 __global__ __launch_bounds__(T2THREADS, 1) void gemm_tn_256_kernel(TNArgs p) {
     __shared__ __attribute__((aligned(16))) unsigned char smem[2 * T2BUF];
     const int tid = threadIdx.x, lane = tid & 63, wave = uniform_i(tid >> 6);
@@ -1316,7 +1221,6 @@ __global__ __launch_bounds__(T2THREADS, 1) void gemm_tn_256_kernel(TNArgs p) {
             if (n < p.N && n >= p.cs_from) atomicAdd(p.colsum + n, cs[a][0]);
         }
     }
-    if (SELF && p.splits > 1) tn_finish_last<T2, T2THREADS>(p, tile_n * tk + tile_k, n0, k0, tid);
 }
 
 // (A pipelined variant of this kernel -- 32 token rows per step, four 16-KB LDS stages, loads three steps ahead with a
@@ -1407,10 +1311,6 @@ static int gemm_nt_bf16_impl(const void* A1, int64_t lda1, int K1, const void* A
     p.bias = bias; p.colscale = colscale; p.lds = lds; p.rows_per_batch = rows_per_batch;
     p.rowmask = rowmask; p.resid = (const bf16_t*)resid; p.ldr = ldr;
     const int tn = (N + BN - 1) / BN;
-    // E2K_GEMM_SELF_FIXUP: the last 4 KB of ws are zeroed arrival counters (left zero), remainder tiles finish in the kernel
-    int* counters = nullptr;
-    if ((flags & E2K_GEMM_SELF_FIXUP) && ws && ws_bytes >= 8192) { ws_bytes -= 4096; counters = (int*)((char*)ws + ws_bytes); }
-    p.counters = nullptr;
     p.probe = flags & (E2K_GEMM_PROBE_NO_LOADS | E2K_GEMM_PROBE_NO_MATH);
     const bool glds = !(flags & E2K_GEMM_NO_GLDS) && (K1 % BK) == 0 && (K2 % BK) == 0;
     const int t256 = ((M + QBM - 1) / QBM) * ((N + QBN - 1) / QBN);
@@ -1435,15 +1335,12 @@ static int gemm_nt_bf16_impl(const void* A1, int64_t lda1, int K1, const void* A
             if (split > 1 && (int64_t)rem * split * QBM * QBN * 4 <= ws_bytes) { p.full = T - rem; p.split = split; }
             else rem = 0;
         }
-        if (rem && rem <= 1024) p.counters = counters;
         dim3 grid(p.full + rem * p.split);
         hipStream_t st = (hipStream_t)stream;
-        if (p.counters && out_f32) hipLaunchKernelGGL((gemm_nt_256_kernel<true, false, true>), grid, dim3(QTHREADS), 0, st, p);
-        else if (p.counters) hipLaunchKernelGGL((gemm_nt_256_kernel<false, false, true>), grid, dim3(QTHREADS), 0, st, p);
-        else if (out_f32) hipLaunchKernelGGL(gemm_nt_256_kernel<true>, grid, dim3(QTHREADS), 0, st, p);
+        if (out_f32) hipLaunchKernelGGL(gemm_nt_256_kernel<true>, grid, dim3(QTHREADS), 0, st, p);
         else hipLaunchKernelGGL(gemm_nt_256_kernel<false>, grid, dim3(QTHREADS), 0, st, p);
         E2K_CHECK_LAUNCH();
-        if (rem && !p.counters) {
+        if (rem) {
             if (out_f32) hipLaunchKernelGGL(gemm_nt_256_fixup_kernel<true>, dim3(rem, 16), dim3(QTHREADS), 0, st, p);
             else hipLaunchKernelGGL(gemm_nt_256_fixup_kernel<false>, dim3(rem, 16), dim3(QTHREADS), 0, st, p);
             E2K_CHECK_LAUNCH();
@@ -1471,13 +1368,9 @@ static int gemm_nt_bf16_impl(const void* A1, int64_t lda1, int K1, const void* A
         if (split > 1 && (int64_t)rem * split * BM * BN * 4 <= ws_bytes) { p.full = T - rem; p.split = split; }
         else rem = 0;
     }
-    if (rem && rem <= 1024) p.counters = counters;
     dim3 grid(p.full + rem * p.split), block(256);
     hipStream_t st = (hipStream_t)stream;
-    if (p.counters) {             // (only with glds: the remainder split above requires it)
-        if (out_f32) hipLaunchKernelGGL((gemm_nt_glds_kernel<true, true>), grid, block, 0, st, p);
-        else hipLaunchKernelGGL((gemm_nt_glds_kernel<false, true>), grid, block, 0, st, p);
-    } else if (out_f32) {
+    if (out_f32) {
         if (glds) hipLaunchKernelGGL(gemm_nt_glds_kernel<true>, grid, block, 0, st, p);
         else hipLaunchKernelGGL(gemm_nt_kernel<true>, grid, block, 0, st, p);
     } else {
@@ -1485,7 +1378,7 @@ static int gemm_nt_bf16_impl(const void* A1, int64_t lda1, int K1, const void* A
         else hipLaunchKernelGGL(gemm_nt_kernel<false>, grid, block, 0, st, p);
     }
     E2K_CHECK_LAUNCH();
-    if (rem && !p.counters) {
+    if (rem) {
         if (out_f32) hipLaunchKernelGGL(gemm_nt_fixup_kernel<true>, dim3(rem, 4), block, 0, st, p);
         else hipLaunchKernelGGL(gemm_nt_fixup_kernel<false>, dim3(rem, 4), block, 0, st, p);
         E2K_CHECK_LAUNCH();
@@ -1515,8 +1408,6 @@ static int gemm_nt_geglu_bf16_impl(const void* A, int64_t lda, int K, const void
     p.seed = seed; p.seed_dev = seed_dev; p.stream_id = stream_id;
     p.thresh = (unsigned)(p_drop * 65536.f + 0.5f); p.inv_keep = 1.f / (1.f - p_drop);
     const int T = ((M + QBM - 1) / QBM) * (F / 128);
-    int* counters = nullptr;
-    if ((flags & E2K_GEMM_SELF_FIXUP) && ws && ws_bytes >= 8192) { ws_bytes -= 4096; counters = (int*)((char*)ws + ws_bytes); }
     p.full = T; p.split = 1; p.ws = ws;
     int rem = 0;
     const int slots = (flags & E2K_GEMM_TEST_SLOTS8) ? 8 : 256;
@@ -1531,11 +1422,9 @@ static int gemm_nt_geglu_bf16_impl(const void* A, int64_t lda, int K, const void
         else rem = 0;
     }
     hipStream_t st = (hipStream_t)stream;
-    if (rem && rem <= 1024) p.counters = counters;
-    if (p.counters) hipLaunchKernelGGL((gemm_nt_256_kernel<false, true, true>), dim3(p.full + rem * p.split), dim3(QTHREADS), 0, st, p);
-    else hipLaunchKernelGGL((gemm_nt_256_kernel<false, true>), dim3(p.full + rem * p.split), dim3(QTHREADS), 0, st, p);
+    hipLaunchKernelGGL((gemm_nt_256_kernel<false, true>), dim3(p.full + rem * p.split), dim3(QTHREADS), 0, st, p);
     E2K_CHECK_LAUNCH();
-    if (rem && !p.counters) {
+    if (rem) {
         hipLaunchKernelGGL(gemm_nt_256_fixup_glu_kernel, dim3(rem, 8), dim3(QTHREADS), 0, st, p);
         E2K_CHECK_LAUNCH();
     }
@@ -1547,9 +1436,13 @@ extern "C" int e2k_query_gemm_nt_geglu(int M, int F, int K) { return nt_geglu_ok
 // 512 partial slots of a 128 x 128 tile or 256 of a 256 x 256 tile (every remainder split fits: rem * split <= slots)
 extern "C" int e2k_query_gemm_nt_ws_bytes(void) { return 256 * QBM * QBN * 4; }
 
+// upper bound over both weight-gradient kernels (use_tr = 1 lets the library choose between them): a caller that sizes
+// ws = splits * N * K floats from this number is safe whichever kernel e2k_gemm_tn_bf16 selects
 extern "C" int e2k_query_gemm_tn_splits(int M, int N, int K, int splits) {
     if (M <= 0 || N <= 0 || K <= 0) return 1;
-    return tn_splits(M, N, K, splits);
+    const int a = tn_splits(M, N, K, splits);
+    const int b = tn_use_256(M, N, K, 3) ? tn_splits_256(M, N, K, splits) : 1;
+    return a > b ? a : b;
 }
 
 extern "C" int e2k_query_gemm_tn_splits_mode(int M, int N, int K, int splits, int use_tr) {
@@ -1559,11 +1452,9 @@ extern "C" int e2k_query_gemm_tn_splits_mode(int M, int N, int K, int splits, in
 
 extern "C" int e2k_colsum_bf16(const void* x, int64_t ldx, float* out, int M, int N, void* stream);
 
-constexpr int TN_COUNTERS = 4096;      // arrival counters of the in-kernel finish: one per output tile
-
 static int gemm_tn_bf16_impl(const void* A, int64_t lda, const void* B, int64_t ldb, float* C, int64_t ldc,
                                 int M, int N, int K, int splits, int use_tr, float* ws, float* colsum, int cs_from,
-                                int* counters, void* stream) {
+                                void* stream) {
     if (M <= 0 || N <= 0 || K <= 0) return 0;
     // 16-B loads may run past N / K up to the next multiple of 8: that must still be inside the row
     if ((lda & 7) || (ldb & 7) || ((N + 7) & ~7) > lda || ((K + 7) & ~7) > ldb) return E2K_ERR_ALIGN;
@@ -1575,9 +1466,8 @@ static int gemm_tn_bf16_impl(const void* A, int64_t lda, const void* B, int64_t 
     int chunk = (M + splits - 1) / splits;
     chunk = (chunk + TBM - 1) / TBM * TBM;
     if (splits > 1 && ws == nullptr) return E2K_ERR_ARG;
-    if (counters && tn * tk > TN_COUNTERS) return E2K_ERR_SHAPE;
     TNArgs p;
-    p.ws = ws; p.counters = counters;
+    p.ws = ws;
     p.A = (const bf16_t*)A; p.lda = lda; p.B = (const bf16_t*)B; p.ldb = ldb;
     p.C = C; p.ldc = ldc; p.M = M; p.N = N; p.K = K; p.splits = splits; p.chunk = chunk;
     const bool fast = use_tr && (M % TBM) == 0 && N >= 8 && K >= 8;
@@ -1588,22 +1478,14 @@ static int gemm_tn_bf16_impl(const void* A, int64_t lda, const void* B, int64_t 
         if (rc) return rc;
     }
     dim3 grid(tn * tk, splits), block(256);
-    const bool self = counters && splits > 1;
-    if (!self) p.counters = nullptr;
-    if (self && big && p.colsum) hipLaunchKernelGGL((gemm_tn_256_kernel<true, true>), grid, dim3(T2THREADS), 0, (hipStream_t)stream, p);
-    else if (self && big) hipLaunchKernelGGL((gemm_tn_256_kernel<false, true>), grid, dim3(T2THREADS), 0, (hipStream_t)stream, p);
-    else if (self && fast && p.colsum) hipLaunchKernelGGL((gemm_tn_glds_kernel<true, true>), grid, block, 0, (hipStream_t)stream, p);
-    else if (self && fast) hipLaunchKernelGGL((gemm_tn_glds_kernel<false, true>), grid, block, 0, (hipStream_t)stream, p);
-    else if (self && use_tr) hipLaunchKernelGGL((gemm_tn_kernel<true, true>), grid, block, 0, (hipStream_t)stream, p);
-    else if (self) hipLaunchKernelGGL((gemm_tn_kernel<false, true>), grid, block, 0, (hipStream_t)stream, p);
-    else if (big && p.colsum) hipLaunchKernelGGL(gemm_tn_256_kernel<true>, grid, dim3(T2THREADS), 0, (hipStream_t)stream, p);
+    if (big && p.colsum) hipLaunchKernelGGL(gemm_tn_256_kernel<true>, grid, dim3(T2THREADS), 0, (hipStream_t)stream, p);
     else if (big) hipLaunchKernelGGL(gemm_tn_256_kernel<false>, grid, dim3(T2THREADS), 0, (hipStream_t)stream, p);
     else if (fast && p.colsum) hipLaunchKernelGGL(gemm_tn_glds_kernel<true>, grid, block, 0, (hipStream_t)stream, p);
     else if (fast) hipLaunchKernelGGL(gemm_tn_glds_kernel<false>, grid, block, 0, (hipStream_t)stream, p);
     else if (use_tr) hipLaunchKernelGGL(gemm_tn_kernel<true>, grid, block, 0, (hipStream_t)stream, p);
     else hipLaunchKernelGGL(gemm_tn_kernel<false>, grid, block, 0, (hipStream_t)stream, p);
     E2K_CHECK_LAUNCH();
-    if (splits > 1 && !counters) {
+    if (splits > 1) {
         long total = (long)N * K;
         long g = (total + 255) / 256;
         if (g > 2048) g = 2048;
@@ -1634,14 +1516,5 @@ extern "C" int e2k_gemm_nt_geglu_bf16(const void* A, int64_t lda, int K, const v
 extern "C" int e2k_gemm_tn_bf16(const void* A, int64_t lda, const void* B, int64_t ldb, float* C, int64_t ldc,
                                 int M, int N, int K, int splits, int use_tr, float* ws, float* colsum, int cs_from,
                                 void* stream) {
-    return e2k::dispatch("gemm_tn_bf16", gemm_tn_bf16_impl, A, lda, B, ldb, C, ldc, M, N, K, splits, use_tr, ws, colsum, cs_from, (int*)nullptr, stream);
+    return e2k::dispatch("gemm_tn_bf16", gemm_tn_bf16_impl, A, lda, B, ldb, C, ldc, M, N, K, splits, use_tr, ws, colsum, cs_from, stream);
 }
-
-extern "C" int e2k_gemm_tn_self_reduce_bf16(const void* A, int64_t lda, const void* B, int64_t ldb, float* C, int64_t ldc,
-                                            int M, int N, int K, int splits, int use_tr, float* ws, float* colsum, int cs_from,
-                                            int32_t* counters, void* stream) {
-    if (counters == nullptr) return E2K_ERR_ARG;
-    return e2k::dispatch("gemm_tn_self_reduce_bf16", gemm_tn_bf16_impl, A, lda, B, ldb, C, ldc, M, N, K, splits, use_tr, ws, colsum, cs_from, (int*)counters, stream);
-}
-
-extern "C" int e2k_query_gemm_tn_counters(void) { return TN_COUNTERS; }

@@ -313,7 +313,7 @@ class Transformer(Module):
 
     # runtime state (device buffers, caches, recorded plans): never part of the module's identity -- a deep copy (the
     # trainer's EMA, trainer.py:170) starts without it and rebuilds its own on first use
-    _RUNTIME = ('_flat', '_shadow', '_shadowT', '_shadow_key', '_tdesc', '_vcache', '_rot_cache', '_plans', '_pool', '_pg', '_no_pgrads', '_lane_ss')
+    _RUNTIME = ('_flat', '_shadow', '_shadowT', '_shadow_key', '_tdesc', '_vcache', '_rot_cache', '_plans', '_pg', '_no_pgrads', '_lane_ss')
 
     def _reset_runtime(self):
         self._flat = None
@@ -328,7 +328,6 @@ class Transformer(Module):
         self._plans = {}
         self._plan_tick = 0
         self._plan_py_seed = False
-        self._pool = None
         self._persist_grads = getattr(self, '_persist_grads', False)   # enable_persistent_grads()
         self._pg = None
 
@@ -658,12 +657,15 @@ class Transformer(Module):
                         lib.e2k_plan_free(h)
         self._plans = {}
 
-    def _pool_ctx(self, dev):
+    def _pool_ctx(self, dev, st):
+        # one private pool PER PLAN: a block freed while plan A is being recorded may only be handed out again inside plan
+        # A's own recording (the replay repeats that order).  With a pool shared by all plans of the module such a block
+        # could become a saved activation of plan B, and replaying A between B's forward and backward would overwrite it.
         if dev.type != 'cuda':
             return contextlib.nullcontext()
-        if self._pool is None:
-            self._pool = torch.cuda.MemPool()
-        return torch.cuda.use_mem_pool(self._pool, device=dev)
+        if st.pool is None:
+            st.pool = torch.cuda.MemPool()
+        return torch.cuda.use_mem_pool(st.pool, device=dev)
 
     def _plan_forward(self, x, cond, text_embed, mask, need_grad, rot):
         p_drop = self.dropout if self.training else 0.
@@ -701,12 +703,12 @@ class Transformer(Module):
             self._sync(x.device)                    # eval: parameters rarely change; refresh the bf16 shadows if they did
         self._plan_inputs(st, x, cond, text_embed, mask)
         self._plan_run_forward(st, rot)
-        return st.out.detach()
+        return st.out.clone()              # (a fresh tensor, as the reference returns: the next replay overwrites st.out)
 
     def _plan_new(self, key, x, cond, text_embed, mask, need_grad, p_drop):
         dev = x.device
-        st = NS(key=key, need_grad=need_grad, fwd=None, bwd=None, segs=None, outstanding=False, used=0, keep=[], meta_f=[], meta_b=[])
-        with self._pool_ctx(dev):
+        st = NS(key=key, need_grad=need_grad, fwd=None, bwd=None, segs=None, outstanding=False, used=0, keep=[], meta_f=[], meta_b=[], pool=None)
+        with self._pool_ctx(dev, st):
             st.x = torch.empty(x.shape, dtype=f32, device=dev)
             st.cond = torch.empty(cond.shape, dtype=f32, device=dev) if exists(cond) else None
             st.text = torch.empty(text_embed.shape, dtype=f32, device=dev) if exists(text_embed) else None
@@ -733,7 +735,7 @@ class Transformer(Module):
             ops.run_plan(st.fwd, 0, -1, dev, st.lane_ss)
             return
         # first run of this plan: execute the schedule with the C ABI recording, inside the pool
-        with self._pool_ctx(dev), _RecordGuard(st.keep if dev.type != 'cuda' else None):
+        with self._pool_ctx(dev, st), _RecordGuard(st.keep if dev.type != 'cuda' else None):
             ops.begin_recording(st.meta_f)
             try:
                 if st.need_grad:
@@ -765,7 +767,7 @@ class Transformer(Module):
                 segs, first = [], 0
                 while True:
                     slab = None
-                    with self._pool_ctx(dev), _RecordGuard(st.keep if dev.type != 'cuda' else None), ops.pinned_stream(dev):
+                    with self._pool_ctx(dev, st), _RecordGuard(st.keep if dev.type != 'cuda' else None), ops.pinned_stream(dev):
                         try:
                             slab = next(gen)
                         except StopIteration as e:
@@ -972,9 +974,12 @@ class Transformer(Module):
             gam, off, rpb = run.condall[:, (ind * 4 + 2) * D:(ind * 4 + 3) * D], 1., N
             gate = run.gates[:, (ind * 4 + 3) * D:(ind * 4 + 4) * D]
         xn, rn = ops.rmsnorm_fwd(binp, gam, off, rpb)
-        if ops.fuse_geglu and ops.can_fuse_geglu(xn.shape[0], f.F, D):
+        if ops.fuse_geglu and not exists(tape) and ops.can_fuse_geglu(xn.shape[0], f.F, D):
+            # no-grad forward (sample()): GEGLU as the epilogue of the first GEMM, the pre-activation H is never written
+            # (MI355X, 8448 x 8192 x 1024: 154 us against 225 for GEMM + geglu_fwd, profiles/r03_geglu_fused.json).  With H
+            # stored for a backward pass the fusion measured step-neutral (95.4 vs 95.2 ms), so training keeps two launches.
             Hh, act = ops.gemm_nt_geglu(xn, self._w(f.w1, 2 * f.F, D), self._f(f.b1, 2 * f.F), run.p_drop, run.seed, sid + 1,
-                                        run.seed_dev, want_h=exists(tape))
+                                        run.seed_dev, want_h=False)
         else:
             Hh = ops.gemm_nt(xn, self._w(f.w1, 2 * f.F, D), bias=self._f(f.b1, 2 * f.F))
             act = ops.geglu_fwd(Hh, run.p_drop, run.seed, sid + 1, run.seed_dev)
@@ -1317,7 +1322,7 @@ class _PlanFn(torch.autograd.Function):
         ctx.has_cond, ctx.has_text = exists(cond), exists(text_embed)
         ctx.x_dtype = x_in.dtype
         ctx.t_dtype = text_embed.dtype if exists(text_embed) else None
-        return st.out.detach()
+        return st.out.clone()              # (not a view of the plan's static output: the next replay overwrites that)
 
     @staticmethod
     def backward(ctx, dout):

@@ -113,20 +113,28 @@ class _InProjFn(torch.autograd.Function):
         ops.cast_pad_bf16(w1.detach(), Cp, out=wb, col0=0)
         ops.cast_pad_bf16(w2.detach(), Cp, out=wb, col0=Cp)
         out = ops.gemm_nt(a1b, wb, a2=a2b, bias=_f32c(bias.detach()), out_dtype=torch.float32)
-        ctx.save_for_backward(a1b, a2b)
+        ctx.save_for_backward(a1b, a2b, w1, w2)
         ctx.dims = (B, T, C, D)
+        ctx.in_dtypes = (a1.dtype, a2.dtype)
         return out.view(B, T, D)
 
     @staticmethod
     def backward(ctx, dout):
-        a1b, a2b = ctx.saved_tensors
+        a1b, a2b, w1, w2 = ctx.saved_tensors
         B, T, C, D = ctx.dims
         M, dev = B * T, dout.device
         dob = ops.cast_bf16(_f32c(dout).view(-1), torch.empty((M, D), dtype=torch.bfloat16, device=dev))
         dw1, dw2, db = ops.zeros((D, C), torch.float32, dev), ops.zeros((D, C), torch.float32, dev), ops.zeros((D,), torch.float32, dev)
         ops.gemm_tn(dob, a1b[:, :C], dw1, colsum=db)
         ops.gemm_tn(dob, a2b[:, :C], dw2)
-        return None, None, dw1, dw2, db
+        # input gradients (nn.Linear propagates them: a trainable module in front of cond, input-gradient objectives);
+        # the training step itself never asks for them
+        das = [None, None]
+        for i, w in enumerate((w1, w2)):
+            if ctx.needs_input_grad[i]:
+                wT = ops.cast_transpose_bf16(_f32c(w.detach()), torch.empty((C, D), dtype=torch.bfloat16, device=dev))
+                das[i] = ops.gemm_nt(dob, wT, out_dtype=torch.float32).view(B, T, C).to(ctx.in_dtypes[i])
+        return das[0], das[1], dw1, dw2, db
 
 
 class _OutProjFn(torch.autograd.Function):
@@ -174,7 +182,8 @@ class _MaskedMSEFn(torch.autograd.Function):
     @staticmethod
     def backward(ctx, dloss):
         p2, f2, m8, acc = ctx.saved_tensors
-        return ops.masked_mse_bwd(p2, f2, m8, acc, _f32c(dloss).view(1)).view(ctx.shape), None, None
+        dpred = ops.masked_mse_bwd(p2, f2, m8, acc, _f32c(dloss).view(1)).view(ctx.shape)
+        return dpred, (-dpred if ctx.needs_input_grad[1] else None), None          # d/d(flow) = -d/d(pred)
 
 
 def _on_kernels(t):

@@ -194,13 +194,11 @@ _nt_ws_cache = {}
 
 def _nt_ws(device, stream):
     """fp32 scratch of the NT GEMM remainder split: one per (device, stream) -- launches of one stream use it one after
-    the other, launches of different streams (launch lanes) may overlap.  Its last 4 KB are the arrival counters of the
-    in-kernel fix-up (E2K_GEMM_SELF_FIXUP = 512 in gemm_flags): zeroed once here, left zero by every launch."""
+    the other, launches of different streams (launch lanes) may overlap."""
     key = (device, stream)
     w = _nt_ws_cache.get(key)
     if w is None:
-        w = torch.empty(_lib.get().e2k_query_gemm_nt_ws_bytes() // 4 + 1024, dtype=f32, device=device)
-        fill_(w[-1024:])
+        w = torch.empty(_lib.get().e2k_query_gemm_nt_ws_bytes() // 4, dtype=f32, device=device)
         _nt_ws_cache[key] = w
     return _p(w), w.numel() * 4
 
@@ -317,21 +315,6 @@ def set_gemm_profile(lst):
 tn_mode = int(_os.environ.get('E2K_TN_MODE', '1'))
 
 
-tn_self_reduce = bool(int(_os.environ.get('E2K_TN_SELF_REDUCE', '0')))     # finish token-split weight gradients inside the GEMM (off: not yet timed on hardware)
-_tn_counter_cache = {}
-
-
-def _tn_counters(device, stream):
-    """arrival counters of e2k_gemm_tn_self_reduce_bf16: zero when created, left zero by every launch; one buffer per
-    (device, stream) -- launches of one stream run one after the other, launches of different lanes may overlap"""
-    key = (device, stream)
-    c = _tn_counter_cache.get(key)
-    if c is None:
-        c = zeros((_lib.get().e2k_query_gemm_tn_counters(),), torch.int32, device)     # (an e2k call on this stream: recordable, ordered before the GEMM)
-        _tn_counter_cache[key] = c
-    return c
-
-
 def gemm_tn(a, b, out, *, splits=0, use_tr=True, colsum=None, colsum_from=0, hold=None):
     """out[N,K] += a[M,N].T @ b[M,K]   (fp32 out, bf16 a/b); optionally colsum[n] += sum_m a[m][n] for n >= colsum_from"""
     _chk(a, b, out)
@@ -350,12 +333,8 @@ def gemm_tn(a, b, out, *, splits=0, use_tr=True, colsum=None, colsum_from=0, hol
         assert colsum.dtype == f32 and colsum.numel() == N and colsum.is_contiguous()
     _note(2.0 * M * N * K)
     stream = _stream(a)
-    if tn_self_reduce and ns > 1:
-        lib.e2k_gemm_tn_self_reduce_bf16(_p(a), lda, _p(b), ldb, _p(out), out.stride(0), M, N, K, int(splits), mode, _p(ws),
-                                         _p(colsum), int(colsum_from), _p(_tn_counters(a.device, stream)), stream)
-    else:
-        lib.e2k_gemm_tn_bf16(_p(a), lda, _p(b), ldb, _p(out), out.stride(0), M, N, K, int(splits), mode, _p(ws),
-                             _p(colsum), int(colsum_from), stream)
+    lib.e2k_gemm_tn_bf16(_p(a), lda, _p(b), ldb, _p(out), out.stride(0), M, N, K, int(splits), mode, _p(ws),
+                         _p(colsum), int(colsum_from), stream)
     if hold is not None:              # launched on a side lane: the caller keeps the operands alive until that lane has been waited for
         hold.append((a, b, ws))
     return out
@@ -452,7 +431,8 @@ def geglu_fwd(H, p_drop=0., seed=0, stream_id=0, seed_dev=None):
     return out
 
 
-fuse_geglu = bool(int(_os.environ.get('E2K_FUSE_GEGLU', '0')))     # GEGLU as the epilogue of FeedForward's first GEMM (off: not yet timed on hardware)
+# GEGLU as the epilogue of FeedForward's first GEMM in no-grad forwards (E2K_FUSE_GEGLU=0: always two launches)
+fuse_geglu = bool(int(_os.environ.get('E2K_FUSE_GEGLU', '1')))
 
 
 def can_fuse_geglu(M, F, K):

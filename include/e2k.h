@@ -51,26 +51,21 @@ int e2k_query_gemm_nt_ws_bytes(void);
 #define E2K_GEMM_NO_T256 256     /* flags: never use the 256 x 256 kernel (A/B) */
 #define E2K_GEMM_NO_SPLIT 16     /* flags: never split remainder tiles over K (A/B) */
 #define E2K_GEMM_TEST_SLOTS8 32  /* flags: pretend the chip holds 8 workgroups (lets small shapes exercise the remainder split in tests) */
-#define E2K_GEMM_SELF_FIXUP 512  /* flags: the last 4096 bytes of ws are int32 arrival counters, ZERO on entry (left zero): the last K-range part of a remainder tile to arrive sums the parts and runs the epilogue inside the GEMM kernel -- no fix-up launch, same bits.  One ws per stream.  Not yet timed on hardware */
 
 /* C[N,K] += A[M,N]^T . B[M,K]  (weight gradients; C fp32, A = dY, B = X, bf16).  The token dimension M is
  * split over `splits` workgroups per tile (0 = choose); partial tiles go to `ws` and are combined by a reduce kernel.
- * use_tr = 1 reads MFMA fragments with ds_read_b64_tr_b16, 0 = plain 16-bit LDS gathers (same results).
+ * use_tr: 0 = the general kernel with plain 16-bit LDS gathers; 1 = the library chooses per shape between the 128 x 128
+ * and the 256 x 256 kernel (both read fragments with ds_read_b64_tr_b16); 2 = always 128 x 128; 3 = 256 x 256 wherever
+ * it can run (M a multiple of 64).  Same results up to summation order.
  * colsum (optional, fp32 [N]): colsum[n] += sum_m A[m][n] for n >= cs_from (even) -- the bias gradient of the same
  * Linear (e.g. FeedForward proj bias, e2_tts.py:937), computed in the same pass over dY by one extra MFMA per 16
  * columns with an all-ones operand. */
 int e2k_gemm_tn_bf16(const void* A, int64_t lda, const void* B, int64_t ldb, float* C, int64_t ldc,
                      int M, int N, int K, int splits, int use_tr, float* ws, float* colsum, int cs_from, void* stream);
-/* The same weight gradient with the split finished INSIDE the kernel instead of by a second launch: `counters` points to
- * e2k_query_gemm_tn_counters() int32 arrival counters (one per output tile) that are ZERO on entry and are left zero;
- * the last workgroup of a tile to arrive adds the partial tiles to C in split order (the reduce kernel's arithmetic:
- * same bits).  Launches that share `counters` must not overlap (one buffer per stream).  Not yet timed on hardware. */
-int e2k_gemm_tn_self_reduce_bf16(const void* A, int64_t lda, const void* B, int64_t ldb, float* C, int64_t ldc,
-                                 int M, int N, int K, int splits, int use_tr, float* ws, float* colsum, int cs_from,
-                                 int32_t* counters, void* stream);
-int e2k_query_gemm_tn_counters(void);
-/* number of token-dimension splits the call above will use for (M, N, K, splits); when it is > 1 the caller passes
- * ws = scratch of splits*N*K floats (partial tiles are stored there and combined by a second small kernel). */
+/* upper bound on the token-dimension splits the call above uses for (M, N, K, splits), whichever kernel it selects
+ * (use_tr = 1 means "the library chooses per shape", not "transposing reads"); when it is > 1 the caller passes
+ * ws = scratch of at least that many * N * K floats (partial tiles are stored there and combined afterwards).  The exact
+ * count for a given use_tr mode: e2k_query_gemm_tn_splits_mode. */
 int e2k_query_gemm_tn_splits(int M, int N, int K, int splits);
 /* the same for a given use_tr mode: 1 = the library chooses the kernel per shape, 2 = always the 128 x 128 x 64 kernel,
  * 3 = the 256 x 256 x 64 8-phase kernel wherever it can run (M a multiple of 64) */

@@ -284,22 +284,12 @@ def test_launch_lanes_match_single_stream(dev):
         for a, b in zip(ref_i, got_i):
             assert torch.equal(a, b), key
 
-def _first_hardware_run_pending(dev):
-    """the E2K_FUSE_GEGLU path (off by default) was written after the GPU minutes of round 2 were spent: its hardware
-    variants run when asked for (E2K_TEST_UNTIMED=1, set by tools/gpu/round3_first.sh), so that a never-executed kernel
-    cannot take the -x run of the default path down with it"""
-    import os
-    if dev == 'cuda' and os.environ.get('E2K_TEST_UNTIMED', '0') != '1':
-        pytest.skip('E2K_FUSE_GEGLU path: first hardware run pending (E2K_TEST_UNTIMED=1 runs it)')
-
-
-
 def test_geglu_epilogue_in_the_backbone(dev):
-    """ops.fuse_geglu (E2K_FUSE_GEGLU=1): FeedForward's GEGLU + dropout as the epilogue of its first GEMM
-    (e2k_gemm_nt_geglu_bf16) instead of a separate pass over H -- training step (H kept for the backward)
-    and inference (H never written), eager and through a recorded plan, with dropout on: the keep mask is a function of
-    (seed, stream id, row, column) only, so the fused and the separate schedules draw the same one."""
-    _first_hardware_run_pending(dev)
+    """ops.fuse_geglu (default on): in no-grad forwards FeedForward's GEGLU + dropout is the epilogue of its first GEMM
+    (e2k_gemm_nt_geglu_bf16, SURVEY K11; the pre-activation H is never written) instead of a separate pass over H;
+    training steps keep GEMM + e2k_geglu_fwd (H is needed by the backward, and the fusion measured step-neutral there:
+    profiles/r03_first_call_switch_ab.jsonl).  Eager and through a recorded plan, module in train() mode so that dropout
+    is on: the keep mask is a function of (seed, stream id, row, column) only, so both schedules draw the same one."""
     from e2_tts_pytorch_amd import Transformer, ops
     random.seed(0)
     torch.manual_seed(0)
@@ -309,51 +299,45 @@ def test_geglu_epilogue_in_the_backbone(dev):
     randomize(mod)
     mod = mod.to(dev)
     mod.train()
-    R = torch.randn(B, T, dim).to(dev)
     g = torch.Generator().manual_seed(5)
     x0, t0, txt0 = torch.randn(B, T, dim, generator=g), torch.rand(B, generator=g), torch.randn(B, T, dim // 2, generator=g)
 
-    def step(train):
-        mod.zero_grad(set_to_none=True)
-        x, txt = x0.clone().to(dev).requires_grad_(train), txt0.clone().to(dev).requires_grad_(train)
+    def infer():
         torch.manual_seed(77)                                # the dropout seed of the step is drawn from torch's generator
-        if not train:
-            mod.eval()
-            with torch.no_grad():
-                out = mod(x, times=t0.to(dev), text_embed=txt)
-            mod.train()
-            return [out.clone()]
-        out = mod(x, times=t0.to(dev), text_embed=txt)
-        (out * R).sum().backward()
-        return [out.detach().clone(), x.grad.clone(), txt.grad.clone()] + [p.grad.clone() for p in mod.parameters()]
+        with torch.no_grad():
+            return mod(x0.to(dev), times=t0.to(dev), text_embed=txt0.to(dev)).clone()
+
+    def train_names():
+        x = x0.clone().to(dev).requires_grad_(True)
+        for _ in range(3):
+            mod.zero_grad(set_to_none=True)
+            mod(x, times=t0.to(dev), text_embed=txt0.to(dev)).sum().backward()
+        st = [v for v in mod._plans.values() if not isinstance(v, str) and v.bwd]
+        return ops_names(st[0].fwd)
 
     res, names = {}, {}
     old = ops.fuse_geglu
     try:
         for fused in (False, True):
             ops.fuse_geglu = fused
-            mod._plans.clear()
+            mod._drop_plans()
             for plans in (False, True):
                 mod.enable_plans(plans)
-                reps = 3 if plans else 1                    # (a signature is recorded the second time it is seen)
-                for _ in range(reps):
-                    res[fused, plans] = step(True), step(False)
-            st = [v for v in mod._plans.values() if not isinstance(v, str) and v.bwd]
+                for _ in range(3 if plans else 1):          # (a signature is recorded the second time it is seen)
+                    res[fused, plans] = infer()
+            st = [v for v in mod._plans.values() if not isinstance(v, str) and not v.need_grad]
             names[fused] = ops_names(st[0].fwd)
+            if fused:
+                tn = train_names()
+                assert tn.count('geglu_fwd') == 2 * depth and 'gemm_nt_geglu_bf16' not in tn
     finally:
         ops.fuse_geglu = old
     assert names[True].count('gemm_nt_geglu_bf16') == 2 * depth and 'geglu_fwd' not in names[True]
     assert names[False].count('geglu_fwd') == 2 * depth and 'gemm_nt_geglu_bf16' not in names[False]
     ref = res[False, False]
-    for key in ((True, False), (True, True), (False, True)):
-        for a_list, b_list in zip(ref, res[key]):
-            for a, b in zip(a_list, b_list):
-                # (the epilogue's erf differs from the library's in the last place of a few activations: bf16 noise level)
-                # (scalars and small vectors are cancelling sums over few tokens: last-place noise in the activations moves the
-                #  hyper-connection scale gradients by up to ~10 % here -- the oracle comparisons allow them 15 % for the same reason)
-                assert rel2(b, a) < (5e-2 if a.numel() >= 1024 else 0.3) or float(a.norm()) < 1e-6, (key, tuple(a.shape), rel2(b, a))
-    for a, b in zip(res[True, False][0][:3] + res[True, False][1], res[True, True][0][:3] + res[True, True][1]):
-        assert torch.equal(a, b)                             # plan replay of the fused schedule == its eager run
+    # (the epilogue's erf differs from the library's in the last place of a few activations: bf16 noise level)
+    assert rel2(res[True, False], ref) < 2e-2 and rel2(res[False, True], ref) < 1e-6
+    assert torch.equal(res[True, True], res[True, False])   # plan replay of the fused schedule == its eager run
 
 
 def ops_names(handle):

@@ -265,16 +265,6 @@ def test_gemm_random_shapes(dev):
     finally:
         ops.gemm_flags = old
 
-def _first_hardware_run_pending(dev):
-    """the E2K_FUSE_GEGLU path (off by default) was written after the GPU minutes of round 2 were spent: its hardware
-    variants run when asked for (E2K_TEST_UNTIMED=1, set by tools/gpu/round3_first.sh), so that a never-executed kernel
-    cannot take the -x run of the default path down with it"""
-    import os
-    if dev == 'cuda' and os.environ.get('E2K_TEST_UNTIMED', '0') != '1':
-        pytest.skip('E2K_FUSE_GEGLU path: first hardware run pending (E2K_TEST_UNTIMED=1 runs it)')
-
-
-
 @pytest.mark.parametrize('M,F,K,p,flags,bias,want_h', [
     (256, 128, 256, 0.0, 0, 1, 1),          # one tile: value rows | gate rows as the two B half tiles
     (300, 256, 320, 0.1, 0, 1, 1),          # ragged rows, two column tiles, odd number of K tiles, dropout
@@ -286,7 +276,6 @@ def test_gemm_nt_geglu_epilogue(dev, monkeypatch, M, F, K, p, flags, bias, want_
     """FeedForward GEMM1 with the GEGLU (+ dropout) as its epilogue (e2_tts.py:646,692) against the two
     launches it replaces (the epilogue rounds H to bf16 before the product, as the separate kernel reads it) and against
     the fp32 formula with the oracle's dropout mask"""
-    _first_hardware_run_pending(dev)
     import torch.nn.functional as Fn
     from e2_tts_pytorch_amd import ops
     from oracle.dropout_hash import geglu_dropout_mask
@@ -336,7 +325,6 @@ def test_gelu_erf_fast_accuracy(dev):
     float64 erf over the range of bf16 gates: within one bf16 last place of the exact value from -5 up, and no
     `1 + erf` cancellation on the negative side (the tail keeps a relative accuracy of a few percent down to -12).  The gates go in through the
     bias (A = W1 = 0; value bias 1, gate bias g), one launch per row of 128 gates."""
-    _first_hardware_run_pending(dev)
     import math
     from e2_tts_pytorch_amd import ops
     M, F, K = 16, 128, 64
@@ -362,7 +350,6 @@ def test_gelu_erf_fast_accuracy(dev):
 def test_gemm_nt_geglu_edge_shapes(dev, M):
     """GEGLU-epilogue GEMM on ragged row counts (1 row, a partial 16-row group, one row past a tile) with operands that
     are column slices of wider buffers (row strides larger than K), against the two separate launches"""
-    _first_hardware_run_pending(dev)
     from e2_tts_pytorch_amd import ops
     torch.manual_seed(M)
     F, K = 128, 128
@@ -381,111 +368,3 @@ def test_gemm_nt_geglu_edge_shapes(dev, M):
     assert torch.equal(H.cpu(), H2.cpu())
     assert (act.cpu() != act2.cpu()).float().mean().item() < 2e-2 and rel(act, act2) < 8e-3
     assert H.shape == (M, 2 * F) and act.shape == (M, F)
-
-
-@pytest.mark.parametrize('M,N,K,splits,mode,cs,pad', [
-    (512, 128, 128, 4, 1, 0, 0),         # one tile, four splits (128 x 128 kernel)
-    (1024, 296, 200, 4, 1, 1, 0),        # ragged tiles (3 x 2) with the bias-gradient column sums
-    (1024, 512, 512, 4, 3, 0, 0),        # 256 x 256 kernel, 4 tiles x 4 splits
-    (768, 264, 136, 3, 2, 1, 1),         # C is a column slice with an odd row stride: scalar finish
-    (200, 128, 136, 2, 1, 0, 0),         # M not a multiple of 64: the general kernel
-])
-def test_gemm_tn_self_reduce(dev, M, N, K, splits, mode, cs, pad):
-    """token-split weight gradient finished inside the GEMM (e2k_gemm_tn_self_reduce_bf16: the last workgroup of a tile to
-    arrive sums the partial tiles in split order) against the two-launch form (GEMM + tn_reduce_kernel): the same bits,
-    accumulated onto a non-zero C, and the arrival counters are back at zero (three launches in a row reuse them)"""
-    from e2_tts_pytorch_amd import ops
-    _first_hardware_run_pending(dev)
-    torch.manual_seed(M + N)
-    a = torch.randn(M, N).to(bf16).to(dev)
-    b = torch.randn(M, K).to(bf16).to(dev)
-    c0 = torch.randn(N, K)
-    old = ops.tn_self_reduce
-    res = {}
-    try:
-        for fused in (False, True):
-            ops.tn_self_reduce = fused
-            buf = torch.zeros(N, K + pad).to(dev)
-            out = buf[:, :K]
-            out.copy_(c0)
-            col = torch.ones(N).to(dev) if cs else None
-            for _ in range(3):
-                ops.gemm_tn(a, b, out, splits=splits, use_tr=mode, colsum=col, colsum_from=0)
-            assert pad == 0 or float(buf[:, K:].abs().sum()) == 0.
-            res[fused] = out.cpu().clone(), None if col is None else col.cpu()
-    finally:
-        ops.tn_self_reduce = old
-    assert ops.lib().e2k_query_gemm_tn_splits_mode(M, N, K, splits, mode) > 1
-    assert torch.equal(res[True][0], res[False][0])
-    if cs:
-        assert rel(res[True][1], res[False][1]) < 1e-5             # (fp32 atomics: order)
-    cnt = ops._tn_counter_cache[next(k for k in ops._tn_counter_cache if k[0] == a.device)]
-    assert int(cnt.abs().sum()) == 0
-    ref = c0 + 3 * (a.float().cpu().T @ b.float().cpu())
-    assert rel(res[True][0], ref) < 2e-3
-
-
-@pytest.mark.parametrize('M,N,K1,K2,kw,base', [
-    (1100, 260, 256, 0, dict(bias=1), 32),                          # 128 x 128 kernel: 27 tiles on 8 slots, 3 remainder tiles
-    (1100, 392, 256, 128, dict(bias=1, cs=1, rm=1, rs=1), 32),      # ... dual-K, every epilogue operand
-    (520, 392, 512, 0, dict(f32=1, bias=1), 32),                    # ... fp32 output
-    (2304, 256, 512, 0, dict(f32=1, bias=1), 32 | 128),             # 256 x 256 kernel: 1 remainder tile x 2 K ranges
-    (1280, 512, 256, 256, dict(bias=1, cs=1, rm=1, rs=1), 32 | 128),  # ... 2 remainder tiles, dual-K, every epilogue operand
-])
-@pytest.mark.parametrize('late', [0, 1])
-def test_gemm_nt_self_fixup(dev, monkeypatch, M, N, K1, K2, kw, base, late):
-    """remainder tiles finished inside the GEMM kernel (E2K_GEMM_SELF_FIXUP: the last K-range part of a tile to arrive sums
-    the parts in K order and runs the epilogue) against the fix-up launch: the same bits, three launches in a row on the
-    same counters, counters back at zero"""
-    from e2_tts_pytorch_amd import ops
-    _first_hardware_run_pending(dev)
-    if dev == 'cuda' and late:
-        pytest.skip('LDS-DMA landing extremes exist on the host model only')
-    monkeypatch.setenv('E2K_EMU_GLDS_LATE', str(late))
-    torch.manual_seed(M + N)
-    d = lambda t: None if t is None else t.to(dev)
-    a = d(torch.randn(M, K1).to(bf16))
-    a2 = d(torch.randn(M, K2).to(bf16)) if K2 else None
-    b = d(torch.randn(N, K1 + K2).to(bf16))
-    bias = d(torch.randn(N)) if kw.get('bias') else None
-    nb = 3
-    rpb = (M + nb - 1) // nb
-    cs = d(torch.rand(nb, N)) if kw.get('cs') else None
-    rm = d(torch.rand(M) > 0.3) if kw.get('rm') else None
-    rs = d(torch.randn(M, N).to(bf16)) if kw.get('rs') else None
-    old = ops.gemm_flags
-    res = {}
-    try:
-        for flags in (base, base | 512):
-            ops.gemm_flags = flags
-            for _ in range(3):
-                out = ops.gemm_nt(a, b, a2=a2, bias=bias, colscale=cs, rows_per_batch=rpb, rowmask=rm, resid=rs,
-                                  out_dtype=torch.float32 if kw.get('f32') else bf16)
-            res[flags] = out.cpu()
-    finally:
-        ops.gemm_flags = old
-    assert torch.equal(res[base], res[base | 512])
-    ws = next(v for k, v in ops._nt_ws_cache.items() if k[0] == a.device)
-    assert int(ws[-1024:].view(torch.int32).abs().sum()) == 0
-
-
-def test_gemm_nt_geglu_self_fixup(dev):
-    """the GEGLU-epilogue GEMM with its remainder tiles finished in the kernel: same bits as with the GEGLU fix-up launch"""
-    from e2_tts_pytorch_amd import ops
-    _first_hardware_run_pending(dev)
-    torch.manual_seed(3)
-    M, F, K = 2304, 256, 512                 # 18 tiles on the 8-slot hook: 2 remainder tiles x 2 K ranges
-    a = (torch.randn(M, K) * 0.5).to(bf16).to(dev)
-    w1 = (torch.randn(2 * F, K) * 0.1).to(bf16).to(dev)
-    b1 = torch.randn(2 * F).to(dev)
-    old = ops.gemm_flags
-    res = {}
-    try:
-        for flags in (32, 32 | 512):
-            ops.gemm_flags = flags
-            for _ in range(2):
-                H, act = ops.gemm_nt_geglu(a, w1, b1, 0.1, 5, 2)
-            res[flags] = H.cpu(), act.cpu()
-    finally:
-        ops.gemm_flags = old
-    assert torch.equal(res[32][0], res[32 | 512][0]) and torch.equal(res[32][1], res[32 | 512][1])

@@ -83,44 +83,3 @@ def test_record_and_replay_with_lanes(emu):
     L.e2k_plan_run_lanes(h, 2, -1, ctypes.addressof(arr3), 3)
     assert torch.equal(z, ref_z)
     L.e2k_plan_free(h)
-
-
-def test_self_reducing_weight_gradient_in_a_plan(emu):
-    """e2k_gemm_tn_self_reduce_bf16 inside a recorded plan: the arrival counters are created (zero-filled by a recorded
-    e2k call) the first time a stream needs them, every launch leaves them at zero, so replays of the plan and later
-    eager launches on the same stream keep giving the two-launch result"""
-    from e2_tts_pytorch_amd import ops
-    L = emu
-    torch.manual_seed(1)
-    a = torch.randn(512, 128).to(bf16)
-    b = torch.randn(512, 136).to(bf16)
-    out = torch.zeros(128, 136)
-    ref = torch.zeros(128, 136)
-    ops.gemm_tn(a, b, ref, splits=4)                        # the two-launch form
-    old, old_cache = ops.tn_self_reduce, dict(ops._tn_counter_cache)
-    ops.tn_self_reduce = True
-    ops._tn_counter_cache.clear()
-    keep = []
-    try:
-        ops.begin_recording()
-        try:
-            ops.gemm_tn(a, b, out, splits=4, hold=keep)     # (hold: the partial-tile workspace must outlive the replays)
-            h = ops.end_recording()
-        except BaseException:
-            ops.abort_recording()
-            raise
-        ns = names(L, h)
-        assert ns == ['fill_bytes', 'gemm_tn_self_reduce_bf16'], ns
-        assert torch.equal(out, ref)
-        for k in range(2, 4):
-            L.e2k_plan_run(h, 0, -1, None)
-            assert torch.equal(out, ref * k)
-        out.zero_()
-        ops.gemm_tn(a, b, out, splits=4)                    # eager again, same counters
-        assert torch.equal(out, ref)
-        cnt = next(iter(ops._tn_counter_cache.values()))
-        assert int(cnt.abs().sum()) == 0
-    finally:
-        ops.tn_self_reduce = old
-        ops._tn_counter_cache.clear()
-        ops._tn_counter_cache.update(old_cache)
