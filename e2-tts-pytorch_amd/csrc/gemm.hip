@@ -55,6 +55,7 @@ struct NTArgs {
     // remainder split: workgroups [0, full) own whole tiles; the last T - full tiles (a partial round of the 512
     // resident workgroups) are cut into `split` K ranges each, fp32 partials go to `ws`, gemm_nt_fixup_kernel finishes
     int full, split; float* ws;
+    int rem;            // remainder tiles (persistent kernel: parts = rem * split)
     // GEGLU epilogue (gemm_nt_256_kernel<false, true> only): N = 2F, C = pre-activation H (may be NULL), glu_out (M, F)
     bf16_t* glu_out; long ldg; unsigned seed, stream_id, thresh; float inv_keep; const unsigned* seed_dev;
 };
@@ -683,6 +684,240 @@ __global__ __launch_bounds__(QTHREADS, 1) void gemm_nt_256_kernel(NTArgs p) {
 #pragma unroll
         for (int b = 0; b < 2; ++b)
             nt_epilogue<OUT_F32, 4, 2>(p, acc[a][b], m0 + a * 128 + wr * 64, n0 + b * 128 + wc * 32, l15, g);
+}
+
+// PERSISTENT form of the kernel above (E2K_GEMM_PERSIST; one workgroup per CU for the whole launch).  Workgroup b walks a
+// list of UNITS -- its share of the whole 256 x 256 tiles, then at most one K-range part of a remainder tile -- and the
+// half-tile ring simply keeps running across unit boundaries: while the last K tiles of a unit are being multiplied the
+// staging cursor has already moved on to the first K tiles of the next unit, so a unit starts with its operands in LDS.
+// What the one-tile-per-workgroup kernel pays per tile and this one pays once per launch: the dispatch of a workgroup,
+// its address set-up, the latency of the first six half tiles (about 2 us of the 17-40 us of a tile at K = 1024-2048).
+//
+//   * units of workgroup b = (xcd, slot) = (b & 7, b >> 3), G8 = gridDim.x / 8 workgroups per XCD, R = whole tiles per
+//     workgroup:  tile(i) = xcd * R * G8 + i * G8 + slot  (i < R): at any time the workgroups of an XCD work on G8
+//     consecutive tiles of the grouped order (8 tile rows x all tile columns), which is what keeps their A / B panels in
+//     that XCD's L2;  then part q = b of the rem * split remainder parts (q < rem * split), finished by the fix-up launch.
+//   * staging state (source offsets, K cursor) and compute state (accumulators, epilogue coordinates) are separate: the
+//     staging side switches to the next unit in phase 3 of the second-to-last K tile (where Alo(t + 2) is issued).
+//   * vmcnt: `issued` half tiles so far, global phase g: at most issued - g - 3 may stay in flight (3 in steady state).
+//     The epilogue issues stores, which share the counter with the loads and may retire in any order relative to them:
+//     a counted wait then still guarantees "all but the newest N LOADS have landed" (loads retire in order among
+//     themselves, the stores only make it wait longer).  To keep those stores off the critical path the kernel waits
+//     for every issued half tile BEFORE the epilogue (exact: only loads are outstanding there) and skips the waits of the
+//     four phases after it, whose guarantees (elements up to E0 + 5) that wait has already given at the same place in the
+//     barrier sequence; the next counted wait (phase 4 after the epilogue) sees stores that are ~1.3 us old.
+//   * the two wave groups stay one barrier apart for the whole launch (the epilogue contains no barrier).
+template <bool OUT_F32>
+__global__ __launch_bounds__(QTHREADS, 1) void gemm_nt_256p_kernel(NTArgs p) {
+    __shared__ __attribute__((aligned(16))) unsigned char smem[2 * QBUF];
+    const int tid = threadIdx.x, lane = tid & 63, wave = uniform_i(tid >> 6);
+    const int wr = wave >> 2, wc = wave & 3;
+    const int l15 = lane & 15, g = lane >> 4;
+    const int tm = (p.M + QBM - 1) / QBM, tn = (p.N + QBN - 1) / QBN;
+    const int nk1 = p.K1 / BK, nk = (p.K1 + p.K2) / BK;
+    const int G = gridDim.x, G8 = G >> 3, R = p.full / G;
+    const int b = blockIdx.x, xcd = b & 7, slot = b >> 3;
+    const int nextra = p.rem * p.split;      // remainder tiles, whole (split == 1) or cut into `split` K ranges each
+    const int nunits = R + (b < nextra ? 1 : 0);
+
+    // unit u of this workgroup -> tile origin, K-tile range, partial slot (-1: whole tile)
+    auto unit = [&](int u, int& m0, int& n0, int& kb, int& ke, int& part) __attribute__((always_inline)) {
+        int tile, tile_m, tile_n;
+        if (u < R) {
+            tile = xcd * R * G8 + u * G8 + slot;
+            kb = 0; ke = nk; part = -1;
+        } else {
+            const int r = b / p.split, sidx = b - r * p.split;
+            tile = p.full + r;
+            kb = (int)((long)nk * sidx / p.split);
+            ke = (int)((long)nk * (sidx + 1) / p.split);
+            part = p.split > 1 ? b : -1;
+        }
+        tile_coords(tile, tm, tn, tile_m, tile_n);
+        m0 = tile_m * QBM; n0 = tile_n * QBN;
+    };
+
+    // ---- staging side
+    unsigned va[2][2], dv[2][2], vb[2][2];
+    int su = 0, skt = 0, ske = 0;            // staging unit, its current K tile (absolute), its end
+    bool svalid = nunits > 0;
+    auto stage_unit = [&](int u) __attribute__((always_inline)) {
+        int m0, n0, kb, ke, part;
+        unit(u, m0, n0, kb, ke, part);
+        skt = kb; ske = ke;
+#pragma unroll
+        for (int h = 0; h < 2; ++h)
+#pragma unroll
+            for (int uu = 0; uu < 2; ++uu) {
+                const int row = (wave * 2 + uu) * 8 + (lane >> 3);
+                const int c = (lane & 7) ^ (row & 7);
+                const int m = min(m0 + h * 128 + row, p.M - 1), n = min(n0 + h * 128 + row, p.N - 1);
+                va[h][uu] = (unsigned)(((long)m * p.lda1 + c * 8) * 2);
+                dv[h][uu] = p.K2 ? (unsigned)(((long)m * p.lda2 + c * 8) * 2) - va[h][uu] : 0u;
+                vb[h][uu] = (unsigned)(((long)n * p.ldb + c * 8) * 2);
+            }
+    };
+    auto advance = [&]() __attribute__((always_inline)) {          // staging cursor to the next K tile (maybe of the next unit)
+        if (!svalid) return;
+        if (++skt == ske) {
+            if (++su < nunits) stage_unit(su);
+            else svalid = false;
+        }
+    };
+    unsigned char* const S0 = &smem[0];
+    int issued = 0;
+    auto stage_a = [&](int par, int h) __attribute__((always_inline)) {
+        if (!svalid) return;
+        const bool first = skt < nk1;                    // wave-uniform
+        const char* sa = first ? (const char*)p.A1 + (long)skt * (BK * 2) : (const char*)p.A2 + (long)(skt - nk1) * (BK * 2);
+        const unsigned sel = first ? 0u : ~0u;
+        unsigned char* dst = S0 + par * QBUF + h * QHALF + wave * 2048;
+#pragma unroll
+        for (int uu = 0; uu < 2; ++uu) glds16(sa + (va[h][uu] + (dv[h][uu] & sel)), dst + uu * 1024);
+        ++issued;
+    };
+    auto stage_b = [&](int par, int h) __attribute__((always_inline)) {
+        if (!svalid) return;
+        const char* sb = (const char*)p.B + (long)skt * (BK * 2);
+        unsigned char* dst = S0 + par * QBUF + (2 + h) * QHALF + wave * 2048;
+#pragma unroll
+        for (int uu = 0; uu < 2; ++uu) glds16(sb + vb[h][uu], dst + uu * 1024);
+        ++issued;
+    };
+    auto wait_landed = [&](int left) __attribute__((always_inline)) {
+        if (left >= 3) wait_vmcnt<6>();
+        else if (left == 2) wait_vmcnt<4>();
+        else if (left == 1) wait_vmcnt<2>();
+        else wait_vmcnt<0>();
+    };
+
+    // ---- compute side
+    int offa[2][4], offb[2][2];
+#pragma unroll
+    for (int kk = 0; kk < 2; ++kk) {
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const int ra = wr * 64 + i * 16 + l15;
+            offa[kk][i] = ra * 128 + (((kk * 4 + g) ^ (ra & 7)) << 4);
+        }
+#pragma unroll
+        for (int j = 0; j < 2; ++j) {
+            const int rb = wc * 32 + j * 16 + l15;
+            offb[kk][j] = rb * 128 + (((kk * 4 + g) ^ (rb & 7)) << 4);
+        }
+    }
+    f32x4 acc[2][2][4][2];
+    bf16x8 ar[2][4], blo[2][2], bhi[2][2];
+    auto read_a = [&](const unsigned char* S) __attribute__((always_inline)) {
+#pragma unroll
+        for (int kk = 0; kk < 2; ++kk)
+#pragma unroll
+            for (int i = 0; i < 4; ++i) ar[kk][i] = ld<bf16x8>(S + offa[kk][i]);
+    };
+    auto read_b = [&](bf16x8 (&bq)[2][2], const unsigned char* S) __attribute__((always_inline)) {
+#pragma unroll
+        for (int kk = 0; kk < 2; ++kk)
+#pragma unroll
+            for (int j = 0; j < 2; ++j) bq[kk][j] = ld<bf16x8>(S + offb[kk][j]);
+    };
+    auto mma = [&](f32x4 (&c)[4][2], const bf16x8 (&bq)[2][2]) __attribute__((always_inline)) {
+        set_prio<1>();
+#pragma unroll
+        for (int kk = 0; kk < 2; ++kk)
+#pragma unroll
+            for (int i = 0; i < 4; ++i)
+#pragma unroll
+                for (int j = 0; j < 2; ++j)
+                    c[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(bq[kk][j], ar[kk][i], c[i][j], 0, 0, 0);
+        set_prio<0>();
+    };
+
+    if (nunits == 0) return;
+    // prologue (once per launch): all of the first K tile, then Alo, Blo of the second; elements 0, 1 must have landed
+    stage_unit(0);
+    stage_a(0, 0); stage_b(0, 0); stage_b(0, 1); stage_a(0, 1);
+    advance();
+    stage_a(1, 0); stage_b(1, 0);
+    if (issued >= 6) wait_vmcnt<8>();
+    else wait_vmcnt<4>();
+    barrier_raw();
+    if (wr == 1) barrier_raw();              // waves 4-7 trail by one barrier from here on
+
+    int gph = 0, cpar = 0, skip = 0;         // global phase count, LDS buffer of the K tile being multiplied, waits to skip
+    for (int cu = 0; cu < nunits; ++cu) {
+        int m0, n0, kb, ke, part;
+        unit(cu, m0, n0, kb, ke, part);
+#pragma unroll
+        for (int a = 0; a < 2; ++a)
+#pragma unroll
+            for (int bq = 0; bq < 2; ++bq)
+#pragma unroll
+                for (int i = 0; i < 4; ++i)
+#pragma unroll
+                    for (int j = 0; j < 2; ++j) acc[a][bq][i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+        for (int t = kb; t < ke; ++t) {
+            const unsigned char* S = S0 + cpar * QBUF;
+            // phase 1
+            read_b(blo, S + 2 * QHALF);
+            sched_fence();
+            read_a(S);
+            if (skip > 0) --skip; else wait_landed(issued - gph - 3);
+            ++gph;
+            stage_b(cpar ^ 1, 1);
+            barrier_raw();
+            mma(acc[0][0], blo);
+            barrier_raw();
+            // phase 2
+            read_b(bhi, S + 3 * QHALF);
+            if (skip > 0) --skip; else wait_landed(issued - gph - 3);
+            ++gph;
+            stage_a(cpar ^ 1, 1);
+            barrier_raw();
+            mma(acc[0][1], bhi);
+            barrier_raw();
+            // phase 3
+            read_a(S + QHALF);
+            if (skip > 0) --skip; else wait_landed(issued - gph - 3);
+            ++gph;
+            advance();
+            stage_a(cpar, 0);
+            barrier_raw();
+            mma(acc[1][1], bhi);
+            barrier_raw();
+            // phase 4
+            if (skip > 0) --skip; else wait_landed(issued - gph - 3);
+            ++gph;
+            stage_b(cpar, 0);
+            barrier_raw();
+            mma(acc[1][0], blo);
+            barrier_raw();
+            cpar ^= 1;
+        }
+        // every half tile issued so far has landed once this returns (only loads are outstanding here: exact); the four
+        // phases after the epilogue need no wait of their own
+        wait_vmcnt<0>();
+        skip = 4;
+        if (part >= 0) {        // K-range partial of a remainder tile: [part][(a*2+b)*8 + i*2 + j][tid] x 4 floats
+            float* w = p.ws + ((long)part * 32 * QTHREADS + tid) * 4;
+#pragma unroll
+            for (int a = 0; a < 2; ++a)
+#pragma unroll
+                for (int bq = 0; bq < 2; ++bq)
+#pragma unroll
+                    for (int i = 0; i < 4; ++i)
+#pragma unroll
+                        for (int j = 0; j < 2; ++j) st<f32x4>(w + (((a * 2 + bq) * 4 + i) * 2 + j) * (QTHREADS * 4), acc[a][bq][i][j]);
+        } else {
+#pragma unroll
+            for (int a = 0; a < 2; ++a)
+#pragma unroll
+                for (int bq = 0; bq < 2; ++bq) {
+                    nt_epilogue<OUT_F32, 4, 2>(p, acc[a][bq], m0 + a * 128 + wr * 64, n0 + bq * 128 + wc * 32, l15, g);
+                    sched_fence();
+                }
+        }
+    }
+    if (wr == 0) barrier_raw();              // pairs with the extra barrier waves 4-7 took at the start
 }
 
 // blockIdx.x = remainder tile, blockIdx.y = (A half * 2 + B half) * 4 + m16 group
@@ -1337,7 +1572,14 @@ static int gemm_nt_bf16_impl(const void* A1, int64_t lda1, int K1, const void* A
         }
         dim3 grid(p.full + rem * p.split);
         hipStream_t st = (hipStream_t)stream;
-        if (out_f32) hipLaunchKernelGGL(gemm_nt_256_kernel<true>, grid, dim3(QTHREADS), 0, st, p);
+        p.rem = rem;
+        if ((flags & E2K_GEMM_PERSIST) && T >= slots) {
+            // persistent form: `slots` workgroups, each walks its share of the whole tiles and then at most one remainder
+            // unit (a K-range part when the remainder is split, a whole remainder tile otherwise)
+            if (!rem) { p.full = T - T % slots; p.split = 1; p.rem = T % slots; }
+            if (out_f32) hipLaunchKernelGGL(gemm_nt_256p_kernel<true>, dim3(slots), dim3(QTHREADS), 0, st, p);
+            else hipLaunchKernelGGL(gemm_nt_256p_kernel<false>, dim3(slots), dim3(QTHREADS), 0, st, p);
+        } else if (out_f32) hipLaunchKernelGGL(gemm_nt_256_kernel<true>, grid, dim3(QTHREADS), 0, st, p);
         else hipLaunchKernelGGL(gemm_nt_256_kernel<false>, grid, dim3(QTHREADS), 0, st, p);
         E2K_CHECK_LAUNCH();
         if (rem) {

@@ -105,6 +105,32 @@ int grid_for(long n) {
     return (int)(g < 1 ? 1 : (g > 4096 ? 4096 : g));
 }
 
+// ---- gradient slab <-> bf16 wire format of the data-parallel exchange (ddp.py; replaces the implicit DDP reducer of
+// trainer.py:155-162,190-192): wire = bf16(g * scale) in ONE pass into a preallocated buffer, and g = float(wire) back --
+// 6 B per element each way instead of the three tensor-library passes (scale, round, copy: 20 B and a 58-MB allocation
+// per slab) that cost 11.5 ms per cfg3 step on the side stream (profiles/r02_force_ddp_ab.jsonl)
+__global__ __launch_bounds__(256) void grad_pack_kernel(const float* __restrict__ g, bf16_t* __restrict__ wire, long n, float scale) {
+    const long nv = n >> 3, stride = (long)gridDim.x * 256;
+    for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < nv; i += stride) {
+        const f32x4 a = ld<f32x4>(g + i * 8) * scale, b = ld<f32x4>(g + i * 8 + 4) * scale;
+        float f[8] = {a[0], a[1], a[2], a[3], b[0], b[1], b[2], b[3]};
+        st<u32x4>(wire + i * 8, pack8(f));
+    }
+    if (blockIdx.x == 0)
+        for (long i = nv * 8 + threadIdx.x; i < n; i += 256) wire[i] = f2bf(g[i] * scale);
+}
+__global__ __launch_bounds__(256) void grad_unpack_kernel(const bf16_t* __restrict__ wire, float* __restrict__ g, long n) {
+    const long nv = n >> 3, stride = (long)gridDim.x * 256;
+    for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < nv; i += stride) {
+        float f[8];
+        unpack8(ld<u32x4>(wire + i * 8), f);
+        st<f32x4>(g + i * 8, f32x4{f[0], f[1], f[2], f[3]});
+        st<f32x4>(g + i * 8 + 4, f32x4{f[4], f[5], f[6], f[7]});
+    }
+    if (blockIdx.x == 0)
+        for (long i = nv * 8 + threadIdx.x; i < n; i += 256) g[i] = bf2f(wire[i]);
+}
+
 }  // namespace
 
 static int sumsq_f32_impl(const float* x, int64_t n, double* out, void* stream) {
@@ -141,6 +167,26 @@ static int ema_update_impl(float* ema, const float* p, int64_t n, float decay, v
     return 0;
 }
 
+static int grad_pack_impl(const float* g, void* wire, int64_t n, float scale, void* stream) {
+    if (n <= 0) return 0;
+    if (!g || !wire) return E2K_ERR_ARG;
+    if (((uintptr_t)g | (uintptr_t)wire) & 15) return E2K_ERR_ALIGN;
+    // a modest grid: the exchange runs on a side stream NEXT to the backward pass and should not take the chip from it
+    long gr = (n / 8 + 255) / 256; if (gr > 512) gr = 512; if (gr < 1) gr = 1;
+    hipLaunchKernelGGL(grad_pack_kernel, dim3((int)gr), dim3(256), 0, (hipStream_t)stream, g, (bf16_t*)wire, (long)n, scale);
+    E2K_CHECK_LAUNCH();
+    return 0;
+}
+static int grad_unpack_impl(const void* wire, float* g, int64_t n, void* stream) {
+    if (n <= 0) return 0;
+    if (!g || !wire) return E2K_ERR_ARG;
+    if (((uintptr_t)g | (uintptr_t)wire) & 15) return E2K_ERR_ALIGN;
+    long gr = (n / 8 + 255) / 256; if (gr > 512) gr = 512; if (gr < 1) gr = 1;
+    hipLaunchKernelGGL(grad_unpack_kernel, dim3((int)gr), dim3(256), 0, (hipStream_t)stream, (const bf16_t*)wire, g, (long)n);
+    E2K_CHECK_LAUNCH();
+    return 0;
+}
+
 // ---- C ABI: every compute entry point goes through e2k::dispatch (plan.h) so that a launch plan can record it
 
 extern "C" int e2k_sumsq_f32(const float* x, int64_t n, double* out, void* stream) {
@@ -155,4 +201,12 @@ extern "C" int e2k_adopt_step(float* p, const float* g, float* m, float* v, void
 
 extern "C" int e2k_ema_update(float* ema, const float* p, int64_t n, float decay, void* stream) {
     return e2k::dispatch("ema_update", ema_update_impl, ema, p, n, decay, stream);
+}
+
+extern "C" int e2k_grad_pack_bf16(const float* g, void* wire, int64_t n, float scale, void* stream) {
+    return e2k::dispatch("grad_pack_bf16", grad_pack_impl, g, wire, n, scale, stream);
+}
+
+extern "C" int e2k_grad_unpack_bf16(const void* wire, float* g, int64_t n, void* stream) {
+    return e2k::dispatch("grad_unpack_bf16", grad_unpack_impl, wire, g, n, stream);
 }

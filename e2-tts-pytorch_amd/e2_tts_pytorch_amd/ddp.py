@@ -43,6 +43,9 @@ class _GradSync:
         self.calls = 0
         self.bytes = 0
         self._pending = None          # (start, end, layers) of the slabs merged so far
+        self._wire = None             # bf16 wire buffer, grown to the largest slab seen (slabs are serialised on the side stream)
+        be = dist.get_backend(group)
+        self._avg = dist.ReduceOp.AVG if be == 'nccl' else None      # RCCL averages on the links; gloo (CPU tests) only sums
 
     def _reduce(self, gflat, start, end):
         slab = gflat[start:end]
@@ -51,9 +54,22 @@ class _GradSync:
 
         def run():
             if self.grad_dtype == torch.bfloat16:
-                buf = (slab * (1.0 / self.world)).to(torch.bfloat16)
-                dist.all_reduce(buf, op=dist.ReduceOp.SUM, group=self.group)
-                slab.copy_(buf)
+                from . import ops
+                if slab.is_cuda or ops.host_ok():
+                    # one HIP pass each way through a preallocated wire buffer (no tensor-library temporaries on the side
+                    # stream): pre-divided in fp32, rounded to bf16, summed by RCCL in bf16, widened back into the slab
+                    if self._wire is None or self._wire.numel() < slab.numel() or self._wire.device != slab.device:
+                        self._wire = torch.empty(slab.numel(), dtype=torch.bfloat16, device=slab.device)
+                    buf = self._wire[:slab.numel()]
+                    ops.grad_pack_bf16(slab, buf, 1.0 / self.world)
+                    dist.all_reduce(buf, op=dist.ReduceOp.SUM, group=self.group)
+                    ops.grad_unpack_bf16(buf, slab)
+                else:
+                    buf = (slab * (1.0 / self.world)).to(torch.bfloat16)
+                    dist.all_reduce(buf, op=dist.ReduceOp.SUM, group=self.group)
+                    slab.copy_(buf)
+            elif self._avg is not None:
+                dist.all_reduce(slab, op=self._avg, group=self.group)          # in place, no scaling pass
             else:
                 slab.mul_(1.0 / self.world)
                 dist.all_reduce(slab, op=dist.ReduceOp.SUM, group=self.group)

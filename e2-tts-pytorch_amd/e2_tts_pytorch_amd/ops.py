@@ -855,3 +855,16 @@ def ema_update(ema, p, decay):
     _chk(ema, p)
     assert ema.dtype == f32 and p.dtype == f32 and ema.is_contiguous() and p.is_contiguous() and ema.numel() == p.numel()
     _lib.get().e2k_ema_update(_p(ema), _p(p), p.numel(), float(decay), _stream(p))
+
+
+def grad_pack_bf16(g, wire, scale):
+    """wire[i] = bf16(g[i] * scale): gradient slab -> wire format of the data-parallel exchange (one pass)"""
+    _chk(g, wire)
+    assert g.dtype == f32 and wire.dtype == bf16 and g.is_contiguous() and wire.is_contiguous() and wire.numel() >= g.numel()
+    _lib.get().e2k_grad_pack_bf16(_p(g), _p(wire), g.numel(), float(scale), _stream(g))
+
+
+def grad_unpack_bf16(wire, g):
+    _chk(g, wire)
+    assert g.dtype == f32 and wire.dtype == bf16 and g.is_contiguous() and wire.is_contiguous() and wire.numel() >= g.numel()
+    _lib.get().e2k_grad_unpack_bf16(_p(wire), _p(g), g.numel(), _stream(g))

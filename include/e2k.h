@@ -49,6 +49,7 @@ int e2k_query_gemm_nt_ws_bytes(void);
 #define E2K_GEMM_PROBE_NO_MATH 8  /* flags: bottleneck probe, K loop without its LDS reads + MFMAs (WRONG results) */
 #define E2K_GEMM_T256 128        /* flags: 256 x 256 x 64 tile, 8-wave 8-phase kernel for EVERY shape (default: only shapes whose 256 x 256 tiles fill >= 7/8 of a round of the 256 workgroup slots) */
 #define E2K_GEMM_NO_T256 256     /* flags: never use the 256 x 256 kernel (A/B) */
+#define E2K_GEMM_PERSIST 64      /* flags: persistent form of the 256 x 256 kernel (one workgroup per CU walks several tiles, the K-tile prefetch ring keeps running across tile boundaries) for shapes with at least one whole round of tiles */
 #define E2K_GEMM_NO_SPLIT 16     /* flags: never split remainder tiles over K (A/B) */
 #define E2K_GEMM_TEST_SLOTS8 32  /* flags: pretend the chip holds 8 workgroups (lets small shapes exercise the remainder split in tests) */
 
@@ -233,6 +234,11 @@ int e2k_adopt_step(float* p, const float* g, float* m, float* v, void* shadow_bf
                    const double* gsumsq, int step, void* stream);
 /* ema += (1 - decay) (p - ema)   (ema_pytorch.EMA.update, trainer.py:170,279) */
 int e2k_ema_update(float* ema, const float* p, int64_t n, float decay, void* stream);
+/* Data-parallel gradient exchange in bf16 (replaces the implicit DDP reducer of trainer.py:155-162,190-192,270 for the
+ * backbone's flat gradient slabs): wire[i] = bf16(g[i] * scale) into a preallocated buffer, and g[i] = float(wire[i]) after
+ * the all-reduce.  One pass each, 16-byte aligned pointers. */
+int e2k_grad_pack_bf16(const float* g, void* wire_bf16, int64_t n, float scale, void* stream);
+int e2k_grad_unpack_bf16(const void* wire_bf16, float* g, int64_t n, void* stream);
 
 
 /* ---- launch plans: the native scheduler of the backbone (csrc/plan.h) ----

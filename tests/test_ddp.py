@@ -44,13 +44,13 @@ def _worker(rank, world, port, emu_lib, q):
     out.loss.backward()
     assert net._sync.lanes == []          # no streams on the host model, but the hand-over has happened
     grads = {n: p.grad.clone() for n, p in model.named_parameters() if p.grad is not None}
-    # persistent-gradient mode: the slabs are views of one long-lived buffer; two more steps (other inputs first, so
-    # that the second one has something to overwrite) must end with the same averaged gradients
+    # persistent-gradient mode: the slabs are views of one long-lived buffer; three more steps (other inputs first, so
+    # that the last one has something to overwrite) must end with the same averaged gradients
     tr = model.transformer
     tr.enable_persistent_grads()
     flat_ids = {id(q_) for q_, _ in tr._layout.slots}
     bad_p = []
-    for which in ((rank + 1) % world, rank):
+    for which in ((rank + 1) % world, (rank + 1) % world, rank):      # first sighting (eager), recording, replay
         for p in model.parameters():
             if id(p) not in flat_ids:
                 p.grad = None
@@ -61,6 +61,12 @@ def _worker(rank, world, port, emu_lib, q):
             if err > 1e-4:
                 bad_p.append((n + ' (persistent)', err))
     assert tr._pg is not None and all(q_.grad is v for (q_, _), v in zip(tr._layout.slots, tr._pg.views) if q_.requires_grad)
+    # the last two steps were a plan RECORDING (second sighting of the signature) and a plan REPLAY, both with the launch
+    # lanes on (rank 0; rank 1 drops the text, whose schedule is single-lane) and the slab hook firing between the recorded
+    # backward segments: the combination the 8-GPU run uses
+    plans = [v for v in tr._plans.values() if not isinstance(v, str)]
+    assert len(plans) == 1 and plans[0].bwd and plans[0].segs and len(plans[0].lane_ss) == (2 if rank == 0 else 0) and tr._plan_tick >= 2, (len(plans), tr._plan_tick, bool(plans[0].bwd), plans[0].segs and len(plans[0].segs), plans[0].lane_ss)
+    assert sum(1 for _f, _c, slab in plans[0].segs if slab is not None) >= 2          # hook points inside the replayed backward
     tr.enable_persistent_grads(False)
     # the stock torch DistributedDataParallel (what accelerator.prepare builds, trainer.py:155-162,190) with the overlap
     # shim: the backbone leaves the stock reducer, its slabs go through the hook -- here in bf16, two layers per collective
@@ -112,7 +118,19 @@ def test_two_rank_gradient_mean(emu_lib):
     procs = [ctx.Process(target=_worker, args=(r, 2, port, str(emu_lib), q)) for r in range(2)]
     for p in procs:
         p.start()
-    res = [q.get(timeout=900) for _ in procs]
+    import queue as _queue
+    res, waited = [], 0
+    while len(res) < len(procs) and waited < 900:
+        try:
+            res.append(q.get(timeout=5))
+        except _queue.Empty:
+            waited += 5
+            dead = [p.exitcode for p in procs if p.exitcode not in (None, 0)]
+            if dead:                                        # a rank died (assertion in the worker): do not wait for the other one
+                for p in procs:
+                    p.kill()
+                raise AssertionError(f'a rank exited with {dead} (see its traceback above)')
+    assert len(res) == len(procs), 'timed out'
     for p in procs:
         p.join(timeout=60)
         assert p.exitcode == 0

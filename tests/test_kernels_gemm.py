@@ -167,6 +167,34 @@ def test_gemm_nt_256_tile(dev, monkeypatch, M, N, K1, K2, kw, flags, late):
         ops.gemm_flags = old
 
 
+@pytest.mark.parametrize('M,N,K1,K2,kw,extra', [
+    (2048, 256, 64, 0, {}, 0),                                    # 8 tiles on the 8-slot hook: one unit each, ONE K tile per unit
+    (2048, 512, 128, 0, dict(bias=1), 0),                         # 16 tiles: two units per workgroup, two K tiles each
+    (2304, 256, 512, 0, dict(f32=1, bias=1), 0),                  # 9 tiles: one whole + 1 remainder tile x 2 K ranges
+    (2304, 768, 320, 0, dict(rs=1), 0),                           # 27 tiles, 5 K tiles (the LDS buffer parity flips between units), 3 whole remainder tiles
+    (1280, 512, 256, 256, dict(bias=1, cs=1, rm=1, rs=1), 0),     # 10 tiles, dual-K, every epilogue operand, 2 remainder tiles x 2 K ranges
+    (2304, 700, 576, 64, dict(bias=1, rs=1), 0),                  # ragged N, 27 tiles, 10 K tiles dual-K: 3 remainder tiles x 2 K ranges
+    (2300, 520, 192, 0, dict(bias=1), 16),                        # ragged M and N, remainder never split (whole remainder tiles)
+    (4352, 512, 192, 0, dict(rm=1), 0),                           # 34 tiles: four whole + 2 remainder
+])
+@pytest.mark.parametrize('late', [0, 1])
+def test_gemm_nt_256_persistent(dev, monkeypatch, M, N, K1, K2, kw, extra, late):
+    """persistent form of the 256 x 256 kernel (E2K_GEMM_PERSIST: a workgroup walks several tiles, the half-tile ring keeps
+    running across tile boundaries) on the 8-slot test hook: unit bookkeeping (whole tiles per XCD range, remainder parts or
+    whole remainder tiles), the staging cursor crossing into the next unit, buffer parity with odd K-tile counts, the
+    waits around the in-loop epilogue; late = 1: LDS-DMA copies land as late as the counted waits allow"""
+    from e2_tts_pytorch_amd import ops
+    if dev == 'cuda' and late:
+        pytest.skip('LDS-DMA landing extremes exist on the host model only')
+    monkeypatch.setenv('E2K_EMU_GLDS_LATE', str(late))
+    old = ops.gemm_flags
+    ops.gemm_flags = 128 | 32 | 64 | extra
+    try:
+        test_gemm_nt(dev, M, N, K1, K2, kw)
+    finally:
+        ops.gemm_flags = old
+
+
 @pytest.mark.parametrize('late', [0, 1])
 def test_gemm_nt_256_random_shapes(dev, monkeypatch, late):
     """seeded sweep of the 256 x 256 kernel over ragged M / N, 1..9 K tiles, dual-K splits at every tile boundary, every
