@@ -161,6 +161,7 @@ def main():
     ap.add_argument('--grad-dtype', default='bf16', choices=['fp32', 'bf16'],
                     help='element type of the gradient slabs on the xGMI links (bf16 halves the bytes: 1.45 instead of 2.9 GB per step)')
     ap.add_argument('--bucket-layers', type=int, default=1, help='layer slabs merged per all-reduce')
+    ap.add_argument('--ddp-defer', action='store_true', help='one gradient all-reduce after the backward pass instead of per-layer slabs overlapped with it (A/B)')
     ap.add_argument('--dump-ops', default=None, help='write the per-shape launch table of the profiled plan replays (name, flops, count, '
                     'average ms, TFLOP/s) to this JSON file')
     args = ap.parse_args()
@@ -190,7 +191,7 @@ def main():
                   cond_drop_prob=0.).to(dev)
     model.train()
     net = DataParallel(model, grad_dtype=torch.bfloat16 if args.grad_dtype == 'bf16' else torch.float32,
-                       bucket_layers=args.bucket_layers) if (world > 1 or args.force_ddp) else model
+                       bucket_layers=args.bucket_layers, defer=args.ddp_defer) if (world > 1 or args.force_ddp) else model
     torch.manual_seed(1000 + rank)        # different synthetic data per rank (weak scaling: B per GPU fixed)
     mel = torch.randn(B, T, 100, device=dev)
     text = synthetic_text(B, 1000 + rank)
@@ -303,7 +304,7 @@ def main():
                             f'n_mels=100, random-init weights, {"text stream dropped" if args.drop_text else "text stream on (cond_drop_prob=0)"}, '
                             f'dropout={args.dropout}, bf16 MFMA compute / fp32 master weights+grads',
                 'global_batch': B * world, 'seq_len': T, 'parallelism': f'dp{world}',
-                'grad_exchange': (f'{args.grad_dtype} slabs, {args.bucket_layers} layer(s) per all-reduce, side stream' if (world > 1 or args.force_ddp) else None),
+                'grad_exchange': ((f'{args.grad_dtype}, ONE all-reduce after the backward pass' if args.ddp_defer else f'{args.grad_dtype} slabs, {args.bucket_layers} layer(s) per all-reduce, side stream') if (world > 1 or args.force_ddp) else None),
             },
             'step_tflops_algorithmic': sf / 1e12,
             'model_tflops_per_s_per_gpu': sf / (dt / args.steps) / 1e12,

@@ -833,6 +833,12 @@ __global__ __launch_bounds__(QTHREADS, 1) void gemm_nt_256p_kernel(NTArgs p) {
     };
 
     if (nunits == 0) return;
+    if (p.probe & E2K_GEMM_PROBE_STAGGER) {
+        // bottleneck probe: workgroup b starts (b & 3) quarters of a tile time late (~0.4 us per K tile and quarter), so
+        // that the C-tile store bursts of different workgroups no longer coincide.  Costs up to 3/4 of a tile time once per
+        // launch; on a shape with many rounds the time PER TILE shows what de-synchronised epilogues would buy
+        spin_wall_ticks((long long)(b & 3) * nk * 40);            // 100 MHz clock: 40 ticks = 0.4 us
+    }
     // prologue (once per launch): all of the first K tile, then Alo, Blo of the second; elements 0, 1 must have landed
     stage_unit(0);
     stage_a(0, 0); stage_b(0, 0); stage_b(0, 1); stage_a(0, 1);
@@ -907,6 +913,16 @@ __global__ __launch_bounds__(QTHREADS, 1) void gemm_nt_256p_kernel(NTArgs p) {
                     for (int i = 0; i < 4; ++i)
 #pragma unroll
                         for (int j = 0; j < 2; ++j) st<f32x4>(w + (((a * 2 + bq) * 4 + i) * 2 + j) * (QTHREADS * 4), acc[a][bq][i][j]);
+        } else if (p.probe & E2K_GEMM_PROBE_NO_STORE) {
+            // bottleneck probe (WRONG results): the K loops without the C-tile stores; the accumulators are kept alive
+#pragma unroll
+            for (int a = 0; a < 2; ++a)
+#pragma unroll
+                for (int bq = 0; bq < 2; ++bq)
+#pragma unroll
+                    for (int i = 0; i < 4; ++i)
+#pragma unroll
+                        for (int j = 0; j < 2; ++j) asm volatile("" :: "v"(acc[a][bq][i][j]));
         } else {
 #pragma unroll
             for (int a = 0; a < 2; ++a)
@@ -1547,6 +1563,7 @@ static int gemm_nt_bf16_impl(const void* A1, int64_t lda1, int K1, const void* A
     p.rowmask = rowmask; p.resid = (const bf16_t*)resid; p.ldr = ldr;
     const int tn = (N + BN - 1) / BN;
     p.probe = flags & (E2K_GEMM_PROBE_NO_LOADS | E2K_GEMM_PROBE_NO_MATH);
+    const int pprobe = flags & (E2K_GEMM_PROBE_NO_STORE | E2K_GEMM_PROBE_STAGGER);        // probes of the persistent kernel only
     const bool glds = !(flags & E2K_GEMM_NO_GLDS) && (K1 % BK) == 0 && (K2 % BK) == 0;
     const int t256 = ((M + QBM - 1) / QBM) * ((N + QBN - 1) / QBN);
     // default: shapes whose 256 x 256 tiles fill >= 7/8 of a round of the 256 workgroup slots (measured on MI355X: +10-22 %
@@ -1574,6 +1591,7 @@ static int gemm_nt_bf16_impl(const void* A1, int64_t lda1, int K1, const void* A
         hipStream_t st = (hipStream_t)stream;
         p.rem = rem;
         if ((flags & E2K_GEMM_PERSIST) && T >= slots) {
+            p.probe = pprobe;
             // persistent form: `slots` workgroups, each walks its share of the whole tiles and then at most one remainder
             // unit (a K-range part when the remainder is split, a whole remainder tile otherwise)
             if (!rem) { p.full = T - T % slots; p.split = 1; p.rem = T % slots; }

@@ -37,12 +37,17 @@ struct AdoptArgs {
     float lr, beta1, beta2, eps, wd, max_norm, clamp;     // clamp = step^0.25 (ADOPT update clipping)
     const double* gsumsq;                                  // device: sum of squares of ALL gradients (may be null)
     int first;                                             // step 0: only v = g^2
+    // second parameter group (Adopt keeps `steps` PER PARAMETER and skips parameters whose .grad is None -- the text
+    // stream's on the steps whose classifier-free-guidance coin drops the text, trainer.py:183,275 / e2_tts.py:1261):
+    // elements inside one of the `nranges` sorted [start, end) element ranges use (first_b, clamp_b), or are left
+    // untouched when active_b == 0.  Range bounds are multiples of 4 elements.
+    const int* ranges; int nranges; int first_b; float clamp_b; int active_b;
 };
 
 // one element: returns the new parameter value
-__device__ __forceinline__ float adopt_one(const AdoptArgs& a, float p, float g, float& m, float& v) {
-    if (a.first) { v = g * g; return p; }
-    const float u = fminf(fmaxf(g / fmaxf(sqrtf(v), a.eps), -a.clamp), a.clamp);
+__device__ __forceinline__ float adopt_one(const AdoptArgs& a, bool first, float clamp, float p, float g, float& m, float& v) {
+    if (first) { v = g * g; return p; }
+    const float u = fminf(fmaxf(g / fmaxf(sqrtf(v), a.eps), -clamp), clamp);
     m = m + (1.f - a.beta1) * (u - m);
     p = p * (1.f - a.lr * a.wd) - a.lr * m;
     v = v + (1.f - a.beta2) * (g * g - v);
@@ -54,10 +59,25 @@ __global__ __launch_bounds__(256) void adopt_kernel(AdoptArgs a) {
     float cs = 1.f;
     if (a.gsumsq && a.max_norm > 0.f) cs = fminf(1.f, a.max_norm / ((float)sqrt(*a.gsumsq) + 1e-6f));
     const long n4 = a.n >> 2, stride = (long)gridDim.x * 256;
+    // the ranges of the second group, staged once per workgroup (at most 128 ranges)
+    __shared__ int rng[256];
+    const int nr = a.nranges;
+    for (int k = threadIdx.x; k < 2 * nr; k += 256) rng[k] = a.ranges[k];
+    if (nr) __syncthreads();
+    auto in_b = [&](long e) {            // is element e inside one of the sorted ranges?  (binary search for the last start <= e)
+        int lo = 0, hi = nr;
+        while (lo < hi) { const int mid = (lo + hi) >> 1; if ((long)rng[2 * mid] <= e) lo = mid + 1; else hi = mid; }
+        return lo > 0 && e < (long)rng[2 * lo - 1];
+    };
     auto one = [&](long i, f32x4 p, f32x4 g, f32x4 m, f32x4 v) {
         float pv[4];
+        bool first = a.first; float clamp = a.clamp;
+        if (nr && in_b(4 * i)) {
+            if (!a.active_b) return;                       // no gradient this step: parameter, moments and step count stay
+            first = a.first_b; clamp = a.clamp_b;
+        }
 #pragma unroll
-        for (int r = 0; r < 4; ++r) { float mm = m[r], vv = v[r]; pv[r] = adopt_one(a, p[r], g[r] * cs, mm, vv); m[r] = mm; v[r] = vv; }
+        for (int r = 0; r < 4; ++r) { float mm = m[r], vv = v[r]; pv[r] = adopt_one(a, first, clamp, p[r], g[r] * cs, mm, vv); m[r] = mm; v[r] = vv; }
         st<f32x4>(a.p + 4 * i, f32x4{pv[0], pv[1], pv[2], pv[3]});
         st<f32x4>(a.m + 4 * i, m);
         st<f32x4>(a.v + 4 * i, v);
@@ -76,7 +96,7 @@ __global__ __launch_bounds__(256) void adopt_kernel(AdoptArgs a) {
     if (blockIdx.x == 0 && threadIdx.x < (a.n & 3)) {
         const long i = 4 * n4 + threadIdx.x;
         float mm = a.m[i], vv = a.v[i];
-        const float pn = adopt_one(a, a.p[i], a.g[i] * cs, mm, vv);
+        const float pn = adopt_one(a, a.first, a.clamp, a.p[i], a.g[i] * cs, mm, vv);        // (the tail is never inside a range)
         a.p[i] = pn; a.m[i] = mm; a.v[i] = vv;
         if (a.shadow) a.shadow[i] = f2bf(pn);
     }
@@ -144,15 +164,17 @@ static int sumsq_f32_impl(const float* x, int64_t n, double* out, void* stream) 
 
 static int adopt_step_impl(float* p, const float* g, float* m, float* v, void* shadow_bf16, int64_t n, float lr,
                               float beta1, float beta2, float eps, float weight_decay, float max_grad_norm,
-                              const double* gsumsq, int step, void* stream) {
+                              const double* gsumsq, int step, int step_b, int active_b, const int32_t* ranges, int nranges,
+                              void* stream) {
     if (n <= 0) return 0;
-    if (!p || !g || !m || !v || step < 0) return E2K_ERR_ARG;
+    if (!p || !g || !m || !v || step < 0 || step_b < 0 || nranges < 0 || nranges > 128 || (nranges && !ranges)) return E2K_ERR_ARG;
     if (((uintptr_t)p | (uintptr_t)g | (uintptr_t)m | (uintptr_t)v) & 15 || ((uintptr_t)shadow_bf16 & 7)) return E2K_ERR_ALIGN;
     AdoptArgs a;
     a.p = p; a.g = g; a.m = m; a.v = v; a.shadow = (bf16_t*)shadow_bf16; a.n = n;
     a.lr = lr; a.beta1 = beta1; a.beta2 = beta2; a.eps = eps; a.wd = weight_decay; a.max_norm = max_grad_norm;
     a.clamp = sqrtf(sqrtf((float)step));
     a.gsumsq = gsumsq; a.first = step == 0;
+    a.ranges = ranges; a.nranges = nranges; a.first_b = step_b == 0; a.clamp_b = sqrtf(sqrtf((float)step_b)); a.active_b = active_b;
     hipLaunchKernelGGL(adopt_kernel, dim3(grid_for(n)), dim3(256), 0, (hipStream_t)stream, a);
     E2K_CHECK_LAUNCH();
     return 0;
@@ -196,7 +218,14 @@ extern "C" int e2k_sumsq_f32(const float* x, int64_t n, double* out, void* strea
 extern "C" int e2k_adopt_step(float* p, const float* g, float* m, float* v, void* shadow_bf16, int64_t n, float lr,
                               float beta1, float beta2, float eps, float weight_decay, float max_grad_norm,
                               const double* gsumsq, int step, void* stream) {
-    return e2k::dispatch("adopt_step", adopt_step_impl, p, g, m, v, shadow_bf16, n, lr, beta1, beta2, eps, weight_decay, max_grad_norm, gsumsq, step, stream);
+    return e2k::dispatch("adopt_step", adopt_step_impl, p, g, m, v, shadow_bf16, n, lr, beta1, beta2, eps, weight_decay, max_grad_norm, gsumsq, step, 0, 1, (const int32_t*)nullptr, 0, stream);
+}
+
+extern "C" int e2k_adopt_step_groups(float* p, const float* g, float* m, float* v, void* shadow_bf16, int64_t n, float lr,
+                                     float beta1, float beta2, float eps, float weight_decay, float max_grad_norm,
+                                     const double* gsumsq, int step, int step_b, int active_b, const int32_t* ranges, int nranges,
+                                     void* stream) {
+    return e2k::dispatch("adopt_step_groups", adopt_step_impl, p, g, m, v, shadow_bf16, n, lr, beta1, beta2, eps, weight_decay, max_grad_norm, gsumsq, step, step_b, active_b, ranges, nranges, stream);
 }
 
 extern "C" int e2k_ema_update(float* ema, const float* p, int64_t n, float decay, void* stream) {

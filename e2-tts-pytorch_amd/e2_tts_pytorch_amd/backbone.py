@@ -467,6 +467,27 @@ class Transformer(Module):
                 r.t.crossT = tr(r.t.cross, r.t.cross_rows, D + Dt)     # (D+Dt, rows)
         self._tlist, self._tsize = tl, tn
 
+    def text_param_ranges(self):
+        """[(start, end)] element ranges of the flat parameter buffer that belong to the TEXT stream (text registers, every
+        layer's text branches, hyper-connections and cross-condition): the parameters that receive no gradient on a step
+        whose classifier-free-guidance coin drops the text (e2_tts.py:1261-1262), which the reference optimizer then
+        skips (`p.grad is None`, trainer.py:275).  Sorted, bounds multiples of 8."""
+        lay, out = self._layout, []
+        off_of = {id(p): off for p, off in lay.slots}
+        a = off_of[id(self.text_registers)]
+        out.append((a, (a + self.text_registers.numel() + 7) // 8 * 8))
+        for r in self._recs:
+            if r.t is not None:
+                out.append((r.t.conv.w, r.end))
+        out.sort()
+        merged = []
+        for s_, e_ in out:
+            if merged and s_ <= merged[-1][1]:
+                merged[-1] = (merged[-1][0], max(merged[-1][1], e_))
+            else:
+                merged.append((s_, e_))
+        return merged
+
     # ------------------------------------------------------------------ flat storage
 
     def _params_in_order(self):
@@ -753,6 +774,7 @@ class Transformer(Module):
         dev = st.x.device
         lib = ops.lib()
         sync = self._grad_sync
+        self._text_grad_live = getattr(self, '_text_grad_live', False) or st.key[1]      # (key[1]: the signature has a text stream)
         self._sync_lanes(st.lane_ss)
         if exists(st.bwd):
             for first, count, slab in st.segs:
@@ -1017,6 +1039,7 @@ class Transformer(Module):
     def _run_backward(self, run, dout):
         """eager backward: drive the schedule, hand finished gradient slabs to the data-parallel hook"""
         gen = self._backward_gen(run, dout, self._persist_grads)
+        self._text_grad_live = getattr(self, '_text_grad_live', False) or run.has_text
         self._sync_lanes(self._lane_streams(dout.device) if run.lanes.on else [])
         while True:
             try:

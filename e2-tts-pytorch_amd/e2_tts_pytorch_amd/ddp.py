@@ -32,8 +32,9 @@ from .backbone import Transformer
 
 
 class _GradSync:
-    def __init__(self, group=None, grad_dtype=torch.float32, bucket_layers=1):
+    def __init__(self, group=None, grad_dtype=torch.float32, bucket_layers=1, defer=False):
         assert grad_dtype in (torch.float32, torch.bfloat16)
+        self.defer = bool(defer)      # one collective over everything when the backward pass has finished (no overlap, no CU sharing)
         self.group = group
         self.world = dist.get_world_size(group)
         self.grad_dtype = grad_dtype
@@ -97,6 +98,10 @@ class _GradSync:
             return
         if end <= start:
             return
+        if self.defer:                                      # just remember the covered range; reduced at the flush
+            p0 = self._pending
+            self._pending = (start, end, 1) if p0 is None else (min(p0[0], start), max(p0[1], end), p0[2] + 1)
+            return
         # the backward finishes layers from the last to the first: consecutive slabs are adjacent in the flat buffer
         if self._pending is not None and self._pending[0] == end:
             s, e, k = start, self._pending[1], self._pending[2] + 1
@@ -125,7 +130,7 @@ class DataParallel(nn.Module):
     """wraps an E2TTS / DurationPredictor / Transformer; call it like the wrapped module, then loss.backward()."""
 
     def __init__(self, module: nn.Module, process_group=None, broadcast_from: int | None = 0,
-                 grad_dtype: torch.dtype = torch.float32, bucket_layers: int = 1):
+                 grad_dtype: torch.dtype = torch.float32, bucket_layers: int = 1, defer: bool = False):
         super().__init__()
         assert dist.is_initialized(), 'torch.distributed must be initialised (backend "nccl" is RCCL on ROCm)'
         self.module = module
@@ -134,7 +139,7 @@ class DataParallel(nn.Module):
         self._backbones = [m for m in module.modules() if isinstance(m, Transformer)]
         inside = {id(p) for bb in self._backbones for p in _flat_params(bb)}
         self._outside = [p for p in module.parameters() if id(p) not in inside]
-        self._sync = _GradSync(process_group, grad_dtype, bucket_layers)
+        self._sync = _GradSync(process_group, grad_dtype, bucket_layers, defer)
         self._outside_queued = False
         for bb in self._backbones:
             bb._grad_sync = self._hook

@@ -20,10 +20,11 @@ from . import ops
 from .backbone import Transformer
 
 
-def _runs(pairs):
+def _runs(pairs, keys=None):
     """[(a, b)] fp32 tensor pairs -> [(a_flat, b_flat)]: tensors that are adjacent in memory in BOTH lists (up to the 7
     alignment-padding elements the flat layout puts between slots; nothing ever writes those, they stay zero) are merged
-    into one flat view each = one kernel launch per run.  A run must start 16-byte aligned."""
+    into one flat view each = one kernel launch per run.  A run must start 16-byte aligned.  keys (optional, one per
+    pair): only pairs with equal keys are merged (per-parameter step counts); returns [(a_flat, b_flat, key)] then."""
     order = sorted(range(len(pairs)), key=lambda i: pairs[i][0].data_ptr())
     groups, cur = [], []
     for i in order:
@@ -34,7 +35,7 @@ def _runs(pairs):
             gap_b = b.data_ptr() - (pb.data_ptr() + pb.numel() * 4)
             same = (a.untyped_storage().data_ptr() == pa.untyped_storage().data_ptr() and
                     b.untyped_storage().data_ptr() == pb.untyped_storage().data_ptr())      # one allocation each
-            if not (same and gap_a == gap_b and 0 <= gap_a <= 28):
+            if not (same and gap_a == gap_b and 0 <= gap_a <= 28) or (keys is not None and keys[i] != keys[cur[-1]]):
                 groups.append(cur)
                 cur = []
         cur.append(i)
@@ -46,9 +47,9 @@ def _runs(pairs):
         al, bl = pairs[idx[-1]]
         n = (al.data_ptr() + al.numel() * 4 - a0.data_ptr()) // 4
         if (a0.data_ptr() | b0.data_ptr()) & 15 or len(idx) == 1:
-            runs.extend((pairs[i][0].view(-1), pairs[i][1].view(-1)) for i in idx)
+            runs.extend((pairs[i][0].view(-1), pairs[i][1].view(-1)) + ((keys[i],) if keys is not None else ()) for i in idx)
         else:
-            runs.append((torch.as_strided(a0, (n,), (1,)), torch.as_strided(b0, (n,), (1,))))
+            runs.append((torch.as_strided(a0, (n,), (1,)), torch.as_strided(b0, (n,), (1,))) + ((keys[idx[0]],) if keys is not None else ()))
     return runs
 
 
@@ -72,16 +73,38 @@ def _grad_base(slots, n):
 
 class FusedAdopt:
     """ADOPT (adam_atan2_pytorch.adopt.Adopt defaults: betas (0.9, 0.99), eps 1e-6, decoupled weight decay) with the
-    global-norm gradient clip of `accelerator.clip_grad_norm_` folded in; state (m, v) lives in flat buffers per run."""
+    global-norm gradient clip of `accelerator.clip_grad_norm_` folded in; state (m, v) lives in flat buffers per run.
+
+    `steps` is kept PER PARAMETER and a parameter without a gradient is skipped, as Adopt does (trainer.py:183,275): on a
+    step whose classifier-free-guidance coin dropped the text (25 % of the reference's training steps, e2_tts.py:1261) the
+    text embedding has `.grad is None`, and the backbone's text-stream parameters -- whose slots of the flat gradient
+    buffer then hold zeros rather than None -- are treated the same way (`Transformer._text_grad_live`): parameter,
+    moments and step count stay as they are.  The backbone remains ONE launch: its text-stream slots are a second
+    parameter group inside the flat buffer (e2k_adopt_step_groups)."""
 
     def __init__(self, model, lr=1e-4, betas=(0.9, 0.99), eps=1e-6, weight_decay=0., max_grad_norm=1.0):
         self.model = model
         self.params = [p for p in model.parameters() if p.requires_grad]
         self.lr, self.betas, self.eps, self.weight_decay, self.max_grad_norm = lr, betas, eps, weight_decay, max_grad_norm
-        self.step_count = 0
+        self.steps = [0] * len(self.params)            # per parameter, as Adopt's state['steps']
         self._state = {}           # data_ptr of a parameter STORAGE -> (m, v) flat fp32 buffers mirroring that storage
         self._loaded = {}          # parameter index -> (m, v) from load_state_dict, not yet copied into a run
         self._backbones = [m for m in model.modules() if isinstance(m, Transformer)]
+        self._index = {id(p): i for i, p in enumerate(self.params)}
+        self._ranges = {}          # id(backbone) -> (device int32 (nr, 2) text ranges, set of text parameter ids)
+
+    @property
+    def step_count(self):
+        """optimizer steps taken (= the largest per-parameter count)"""
+        return max(self.steps) if self.steps else 0
+
+    def _text_group(self, tr, dev):
+        ent = self._ranges.get(id(tr))
+        if ent is None or ent[0].device != dev:
+            rs = tr.text_param_ranges()
+            ids = {id(q) for q, off in tr._layout.slots if any(a <= off < b for a, b in rs)}
+            ent = self._ranges[id(tr)] = (torch.tensor(rs, dtype=torch.int32, device=dev).reshape(-1, 2), ids)
+        return ent
 
     # checkpoint format (trainer.py:202-228 stores optimizer.state_dict()) ------------------------------------------
     # torch.optim layout with adam_atan2_pytorch.adopt.Adopt's per-parameter keys ('steps', 'm', 'v'; SURVEY.md Appendix
@@ -112,9 +135,9 @@ class FusedAdopt:
         return out
 
     def state_dict(self):
-        state = {i: dict(steps=self.step_count, m=m.detach().clone(), v=v.detach().clone()) for i, (m, v) in sorted(self._views().items())}
+        state = {i: dict(steps=self.steps[i], m=m.detach().clone(), v=v.detach().clone()) for i, (m, v) in sorted(self._views().items())}
         for i, (m, v) in self._loaded.items():              # loaded but not yet stepped
-            state.setdefault(i, dict(steps=self.step_count, m=m.clone(), v=v.clone()))
+            state.setdefault(i, dict(steps=self.steps[i], m=m.clone(), v=v.clone()))
         group = dict(lr=self.lr, betas=tuple(self.betas), eps=self.eps, weight_decay=self.weight_decay, decoupled_wd=True,
                      params=list(range(len(self.params))))
         return dict(state=dict(sorted(state.items())), param_groups=[group])
@@ -124,11 +147,11 @@ class FusedAdopt:
         assert len(g['params']) == len(self.params), 'parameter count differs from the checkpoint'
         self.lr, self.betas, self.eps = g['lr'], tuple(g['betas']), g['eps']
         self.weight_decay = g.get('weight_decay', 0.)
-        steps = [int(st['steps']) for st in sd['state'].values()]
-        self.step_count = max(steps) if steps else 0
+        self.steps = [0] * len(self.params)
         self._loaded = {}
         for i, st in sd['state'].items():
             p = self.params[int(i)]
+            self.steps[int(i)] = int(st['steps'])
             self._loaded[int(i)] = (st['m'].to(device=p.device, dtype=torch.float32).reshape(p.shape),
                                     st['v'].to(device=p.device, dtype=torch.float32).reshape(p.shape))
         self._install_loaded()
@@ -172,7 +195,7 @@ class FusedAdopt:
         # a backbone whose gradients are the views of ONE flat buffer our backward produced is a single run over its
         # whole flat parameter buffer (alignment pads and the zero "holes" of the layout included: nothing writes their
         # gradients, so they stay exactly zero through the update)
-        runs, taken = [], set()
+        runs, taken, stepped = [], set(), []
         for tr in self._backbones:
             slots = getattr(getattr(tr, '_layout', None), 'slots', None)
             flat = getattr(tr, '_flat', None)
@@ -184,23 +207,35 @@ class FusedAdopt:
             else:
                 base = _grad_base(slots, flat.numel())
             if base is not None and all(q.data_ptr() == flat.data_ptr() + off * 4 for q, off in slots):
-                runs.append((flat.view(-1), base))
+                ranges, text_ids = self._text_group(tr, flat.device)
+                live = bool(getattr(tr, '_text_grad_live', True))
+                main = [self._index[id(q)] for q, _ in slots if id(q) not in text_ids and id(q) in self._index]
+                text = [self._index[id(q)] for q, _ in slots if id(q) in text_ids and id(q) in self._index]
+                # (all parameters of a group have stepped together since construction / load, so one count per group)
+                runs.append((flat.view(-1), base, dict(step=self.steps[main[0]] if main else 0, ranges=ranges,
+                                                       step_b=self.steps[text[0]] if text else 0, active_b=live)))
+                stepped += main + (text if live else [])
                 taken.update(id(q) for q, _ in slots)
-        runs += _runs([(p, g) for p, g in pairs if id(p) not in taken])
+                tr._text_grad_live = False
+        rest = [(p, g) for p, g in pairs if id(p) not in taken]
+        for pf, gf, k in _runs(rest, [self.steps[self._index[id(p)]] for p, _ in rest]):
+            runs.append((pf, gf, dict(step=k)))
+        stepped += [self._index[id(p)] for p, _ in rest]
         if gs is not None:
-            for pf, gf in runs:
+            for pf, gf, _ in runs:
                 ops.sumsq(gf, gs)
         b1, b2 = self.betas
         nstate = len(self._state)
-        mvs = [self._mv(pf) for pf, _ in runs]
+        mvs = [self._mv(pf) for pf, _, _ in runs]
         if len(self._state) != nstate:
             self._install_loaded()
-        for (pf, gf), (m, v) in zip(runs, mvs):
-            ops.adopt_step(pf, gf, m, v, self.step_count, lr=self.lr, beta1=b1, beta2=b2, eps=self.eps,
-                           weight_decay=self.weight_decay, max_grad_norm=self.max_grad_norm, gsumsq=gs)
+        for (pf, gf, kw), (m, v) in zip(runs, mvs):
+            ops.adopt_step(pf, gf, m, v, kw.pop('step'), lr=self.lr, beta1=b1, beta2=b2, eps=self.eps,
+                           weight_decay=self.weight_decay, max_grad_norm=self.max_grad_norm, gsumsq=gs, **kw)
         for p, _ in pairs:                                     # the kernels wrote behind autograd's back
             torch.autograd.graph.increment_version(p)
-        self.step_count += 1
+        for i in stepped:
+            self.steps[i] += 1
 
 
 class FusedEMA:

@@ -46,6 +46,8 @@ int e2k_gemm_nt_bf16(const void* A1, int64_t lda1, int K1, const void* A2, int64
 int e2k_query_gemm_nt_ws_bytes(void);
 #define E2K_GEMM_NO_GLDS 1   /* flags: stage operands through VGPRs instead of global_load_lds (A/B benchmarking) */
 #define E2K_GEMM_PROBE_NO_LOADS 4 /* flags: bottleneck probe, K loop without its global loads (WRONG results) */
+#define E2K_GEMM_PROBE_NO_STORE 2 /* flags: bottleneck probe of the persistent kernel, K loops without the C-tile stores (WRONG results) */
+#define E2K_GEMM_PROBE_STAGGER 512 /* flags: bottleneck probe of the persistent kernel, workgroups start up to 3/4 of a tile time apart (results unchanged) */
 #define E2K_GEMM_PROBE_NO_MATH 8  /* flags: bottleneck probe, K loop without its LDS reads + MFMAs (WRONG results) */
 #define E2K_GEMM_T256 128        /* flags: 256 x 256 x 64 tile, 8-wave 8-phase kernel for EVERY shape (default: only shapes whose 256 x 256 tiles fill >= 7/8 of a round of the 256 workgroup slots) */
 #define E2K_GEMM_NO_T256 256     /* flags: never use the 256 x 256 kernel (A/B) */
@@ -232,6 +234,15 @@ int e2k_sumsq_f32(const float* x, int64_t n, double* out, void* stream);
 int e2k_adopt_step(float* p, const float* g, float* m, float* v, void* shadow_bf16, int64_t n, float lr,
                    float beta1, float beta2, float eps, float weight_decay, float max_grad_norm,
                    const double* gsumsq, int step, void* stream);
+/* The same step with TWO parameter groups in one flat buffer: Adopt keeps `steps` per parameter and skips parameters whose
+ * .grad is None (trainer.py:183,275) -- the text stream's parameters on steps whose classifier-free-guidance coin drops
+ * the text (e2_tts.py:1261).  Elements inside one of the `nranges` (<= 128) sorted [start, end) element ranges
+ * (int32 pairs on the device, bounds multiples of 4) belong to group b: they use step_b, or are left untouched
+ * (parameter, moments, shadow) when active_b == 0; all other elements use `step`. */
+int e2k_adopt_step_groups(float* p, const float* g, float* m, float* v, void* shadow_bf16, int64_t n, float lr,
+                          float beta1, float beta2, float eps, float weight_decay, float max_grad_norm,
+                          const double* gsumsq, int step, int step_b, int active_b, const int32_t* ranges, int nranges,
+                          void* stream);
 /* ema += (1 - decay) (p - ema)   (ema_pytorch.EMA.update, trainer.py:170,279) */
 int e2k_ema_update(float* ema, const float* p, int64_t n, float decay, void* stream);
 /* Data-parallel gradient exchange in bf16 (replaces the implicit DDP reducer of trainer.py:155-162,190-192,270 for the

@@ -20,23 +20,27 @@ def clip_grad_norm_(grads, max_norm):
 class Adopt:
     """adam_atan2_pytorch.adopt.Adopt(params, lr, betas=(0.9, 0.99), eps=1e-6, weight_decay=0, decoupled_wd=True)
     (trainer.py:183,275): step 0 only sets v = g^2; afterwards
-    u = clamp(g / max(sqrt(v), eps), +-step^0.25), m.lerp_(u, 1 - beta1), p -= lr * m, v.lerp_(g^2, 1 - beta2)."""
+    u = clamp(g / max(sqrt(v), eps), +-step^0.25), m.lerp_(u, 1 - beta1), p -= lr * m, v.lerp_(g^2, 1 - beta2).
+    `steps` is per-parameter state and a parameter whose .grad is None is skipped (its count does not advance), as in
+    the torch.optim-style loop of that package -- which matters here: the text stream has no gradient on the 25 % of the
+    training steps whose classifier-free-guidance coin drops the text (e2_tts.py:1261-1262)."""
 
     def __init__(self, params, lr=1e-4, betas=(0.9, 0.99), eps=1e-6, weight_decay=0.):
         self.params = list(params)
         self.lr, self.betas, self.eps, self.wd = lr, betas, eps, weight_decay
-        self.step_count = 0
+        self.steps = [0] * len(self.params)
         self.m = [torch.zeros_like(p) for p in self.params]
         self.v = [torch.zeros_like(p) for p in self.params]
 
     @torch.no_grad()
     def step(self):
         b1, b2 = self.betas
-        t = self.step_count
-        for p, m, v in zip(self.params, self.m, self.v):
+        for i, (p, m, v) in enumerate(zip(self.params, self.m, self.v)):
             g = p.grad
             if g is None:
                 continue
+            t = self.steps[i]
+            self.steps[i] += 1
             if t == 0:
                 v.copy_(g * g)
                 continue
@@ -46,7 +50,10 @@ class Adopt:
             m.lerp_(u, 1. - b1)
             p.add_(m, alpha=-self.lr)
             v.lerp_(g * g, 1. - b2)
-        self.step_count += 1
+
+    @property
+    def step_count(self):
+        return max(self.steps) if self.steps else 0
 
 
 def ema_decay(step, beta=0.9999, update_after_step=100, inv_gamma=1., power=2. / 3., min_value=0.):

@@ -105,6 +105,73 @@ def test_fused_adopt_on_model(dev, persist):
         assert e.shape == p.shape and torch.isfinite(e).all()
 
 
+def _text_stream_names(model):
+    """parameters that only the text stream touches, by the reference's names"""
+    out = set()
+    for n, _ in model.named_parameters():
+        parts = n.split('.')
+        if n == 'transformer.text_registers' or n.startswith('embed_text.'):
+            out.add(n)
+        elif n.startswith('transformer.layers.') and parts[3] == '1':
+            out.add(n)
+        elif n.startswith('transformer.hyper_conns.') and parts[3] == '1':
+            out.add(n)
+    return out
+
+
+@pytest.mark.late
+@pytest.mark.parametrize('persist', [False, True])
+def test_adopt_steps_are_per_parameter_and_text_is_skipped(dev, persist):
+    """Adopt keeps `steps` per parameter and skips parameters without a gradient (trainer.py:183,275).  On a step whose
+    classifier-free-guidance coin drops the text (e2_tts.py:1261) the text embedding has .grad None and the backbone's
+    text-stream slots of the flat gradient buffer hold zeros: FusedAdopt must leave those parameters, their moments and
+    their step counts alone (an update with g = 0 would keep moving them along the old momentum and decay v), while the
+    backbone stays one launch.  Sequence: text, dropped, text, dropped, text -- compared with the oracle optimizer fed
+    None for the text-stream parameters on the dropped steps."""
+    from e2_tts_pytorch_amd import E2TTS
+    from e2_tts_pytorch_amd.optim import FusedAdopt
+    import random
+    random.seed(0)
+    torch.manual_seed(0)
+    model = E2TTS(transformer=dict(dim=256, depth=2, heads=4, dropout=0.), use_vocos=False, cond_drop_prob=0.).to(dev)
+    if persist:
+        model.transformer.enable_persistent_grads()
+    opt = FusedAdopt(model, lr=1e-3, max_grad_norm=1.0)
+    names = [n for n, p in model.named_parameters() if p.requires_grad]
+    text_names = _text_stream_names(model)
+    tr = model.transformer
+    tids = opt._text_group(tr, tr.registers.device)[1] if tr._flat is not None else None
+    ref_params = [p.detach().cpu().clone().requires_grad_(True) for p in opt.params]
+    ref = O.Adopt(ref_params, lr=1e-3)
+    B, T = 2, 24
+    g = torch.Generator().manual_seed(3)
+    launches = []
+    for step, drop in enumerate([False, True, False, True, False]):
+        mel = torch.randn(B, T, 100, generator=g).to(dev)
+        noise = dict(x0=torch.randn(B, T, 100, generator=g).to(dev), times=torch.rand(B, generator=g).to(dev),
+                     frac_lengths=torch.tensor([0.8, 0.9]).to(dev), span_rand=torch.tensor([0.1, 0.5]).to(dev), drop_text_cond=drop)
+        model(mel, text=['hello', 'x'], _noise=noise).loss.backward()
+        for n, rp, p in zip(names, ref_params, opt.params):
+            rp.grad = None if (p.grad is None or (drop and n in text_names)) else p.grad.detach().cpu().clone()
+            if drop and n in text_names and p.grad is not None:
+                assert float(p.grad.abs().max()) == 0., n           # the flat buffer holds zeros there, not None
+        O.clip_grad_norm_([rp.grad for rp in ref_params if rp.grad is not None], 1.0)
+        ref.step()
+        opt.step()
+        opt.zero_grad()
+        for n, rp, p in zip(names, ref_params, opt.params):
+            assert torch.allclose(p.detach().cpu(), rp.detach(), rtol=1e-4, atol=1e-6), (step, n)
+        assert opt.steps == ref.steps, step
+    # the product's notion of "text stream" (ranges of the flat layout) is the reference's, by name
+    tids = opt._text_group(tr, tr._flat.device)[1]
+    by_id = {id(p): n for n, p in model.named_parameters()}
+    assert {by_id[i] for i in tids} == {n for n in text_names if n.startswith('transformer.')}
+    i_text, i_main = names.index('transformer.text_registers'), names.index('transformer.registers')
+    assert opt.steps[i_text] == 3 and opt.steps[i_main] == 5 and opt.steps[names.index('embed_text.embed.weight')] == 3
+    sd = opt.state_dict()
+    assert sd['state'][i_text]['steps'] == 3 and sd['state'][i_main]['steps'] == 5
+
+
 def test_layout_holes_stay_zero(dev):
     """the flat parameter buffer has layout holes (the bias slots of the bias-free AdaptiveRMSNorm.to_gamma rows of the
     hoisted time-conditioning block, alignment gaps, the padded tail of the fused qkv bias row).  The flat optimizer
@@ -206,7 +273,7 @@ def test_checkpoint_round_trip_and_format(dev, tmp_path):
     # (a) the oracle optimizer continues from the exported state exactly as the fused one does
     ref_params = [p.detach().cpu().clone().requires_grad_(True) for p in model.parameters()]
     ref = O.Adopt(ref_params, lr=1e-3)
-    ref.step_count = 3
+    ref.steps = [3] * len(ref_params)
     for i, st in osd['state'].items():
         ref.m[i].copy_(st['m'].cpu())
         ref.v[i].copy_(st['v'].cpu())
