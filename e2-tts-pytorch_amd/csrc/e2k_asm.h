@@ -165,10 +165,4 @@ __device__ __forceinline__ void glds4(const void* gsrc, void* lds_base) {
     __builtin_amdgcn_global_load_lds((gp_t)(gsrc), (lp_t)(lds_base), 4, 0, 0);
 }
 
-// busy-wait for `ticks` of the constant 100-MHz wall clock (bottleneck probes only)
-__device__ __forceinline__ void spin_wall_ticks(long long ticks) {
-    const long long t0 = wall_clock64();
-    while (wall_clock64() - t0 < ticks) __builtin_amdgcn_s_sleep(32);
-}
-
 }  // namespace e2k

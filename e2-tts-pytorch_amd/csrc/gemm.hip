@@ -55,7 +55,7 @@ struct NTArgs {
     // remainder split: workgroups [0, full) own whole tiles; the last T - full tiles (a partial round of the 512
     // resident workgroups) are cut into `split` K ranges each, fp32 partials go to `ws`, gemm_nt_fixup_kernel finishes
     int full, split; float* ws;
-    int rem;            // remainder tiles (persistent kernel: parts = rem * split)
+    int staged;         // 256 x 256 kernel: C tile written through LDS in whole 512-byte row segments (nt_epilogue_staged)
     // GEGLU epilogue (gemm_nt_256_kernel<false, true> only): N = 2F, C = pre-activation H (may be NULL), glu_out (M, F)
     bf16_t* glu_out; long ldg; unsigned seed, stream_id, thresh; float inv_keep; const unsigned* seed_dev;
 };
@@ -177,6 +177,93 @@ __device__ __forceinline__ void nt_epilogue(const NTArgs& p, f32x4 (&acc)[NI][NJ
     }
 }
 
+// Epilogue of the 256 x 256 kernel through LDS.  The direct epilogue above stores what a lane holds -- 4 consecutive
+// columns of one row, i.e. 16 rows x 32 bytes per wave instruction: sixteen partial cache lines.  Measured on MI355X
+// (profiles/r03_nt_store_burst.json): a round of 256 tiles at K = 1024 takes 35.4 us with those stores and 25.6 us
+// without, whether or not the workgroups' epilogues coincide -- 10 us for 128 KB per CU is the per-CU cost of partial-line
+// stores, not an HBM burst.  Here half a tile (128 rows x 256 columns, fp32, rows padded by 16 B so that the 16 rows of a
+// ds_write_b128 group tile all 64 banks) goes to LDS -- the K-tile ring is free by then -- and is read back row-wise:
+// 32 consecutive lanes own 128 consecutive columns, so every global access (C, residual, bias, per-batch gate) covers
+// whole 128-byte lines.  Same arithmetic, in the same order, as nt_epilogue: ((acc + bias) * gate) * rowmask + residual.
+constexpr int QSTAGE_ROW = 256 * 4 + 16, QSTAGE_BYTES = 128 * QSTAGE_ROW;
+constexpr int GSTAGE_ROW = 128 * 4 + 16, GSTAGE_BYTES = 128 * GSTAGE_ROW;       // 128 x 128 kernel: the whole tile at once
+
+// read-back half of the staged epilogue: ROWS x COLS fp32 staged at S (row stride COLS * 4 + 16 bytes), C rows m_base + r,
+// columns n0 + ...; lane (tid & 31) owns columns h * 128 + 4 (tid & 31) .. + 3 of row pass * (THREADS / 32) + (tid >> 5)
+template <bool OUT_F32, int ROWS, int COLS, int THREADS>
+__device__ __forceinline__ void nt_stage_readback(const NTArgs& p, const unsigned char* S, int m_base, int n0, int tid) {
+    constexpr int HN = COLS / 128, RPP = THREADS / 32, ROWB = COLS * 4 + 16;
+    const int c = tid & 31, rsub = tid >> 5;
+    f32x4 bias4[HN];
+    bool colok[HN];
+#pragma unroll
+    for (int h = 0; h < HN; ++h) {
+        const int n = n0 + h * 128 + 4 * c;
+        colok[h] = n < p.N;                              // (N is a multiple of 4 on this path: a chunk is in or out as a whole)
+        bias4[h] = (p.bias && colok[h]) ? ld<f32x4>(p.bias + n) : f32x4{0.f, 0.f, 0.f, 0.f};
+    }
+#pragma unroll 2
+    for (int pass = 0; pass < ROWS / RPP; ++pass) {
+        const int r = pass * RPP + rsub, m = m_base + r;
+        if (m >= p.M) continue;
+        const float rm = p.rowmask ? (p.rowmask[m] ? 1.f : 0.f) : 1.f;
+        const float* cs = p.colscale ? p.colscale + (long)(m / p.rows_per_batch) * p.lds : nullptr;
+#pragma unroll
+        for (int h = 0; h < HN; ++h) {
+            if (!colok[h]) continue;
+            const int n = n0 + h * 128 + 4 * c;
+            f32x4 x = ld<f32x4>(S + r * ROWB + (h * 128 + 4 * c) * 4) + bias4[h];
+            if (cs) x *= ld<f32x4>(cs + n);
+            x *= rm;
+            if (p.resid) {
+                float rs[4];
+                unpack4(ld<u32x2>(p.resid + (long)m * p.ldr + n), rs);
+#pragma unroll
+                for (int q = 0; q < 4; ++q) x[q] += rs[q];
+            }
+            if (OUT_F32) {
+                float* cp = (float*)p.C + (long)m * p.ldc + n;
+                if (p.accumulate) x += ld<f32x4>(cp);
+                st<f32x4>(cp, x);
+            } else {
+                float v[4] = {x[0], x[1], x[2], x[3]};
+                st<u32x2>((bf16_t*)p.C + (long)m * p.ldc + n, pack4(v));
+            }
+        }
+    }
+}
+
+template <bool OUT_F32>
+__device__ __forceinline__ void nt_epilogue_staged(const NTArgs& p, f32x4 (&acc)[2][2][4][2], unsigned char* S, int m0, int n0,
+                                                   int tid, int wr, int wc, int l15, int g) {
+#pragma unroll
+    for (int a = 0; a < 2; ++a) {
+#pragma unroll
+        for (int b = 0; b < 2; ++b)
+#pragma unroll
+            for (int i = 0; i < 4; ++i)
+#pragma unroll
+                for (int j = 0; j < 2; ++j)
+                    st<f32x4>(S + (wr * 64 + i * 16 + l15) * QSTAGE_ROW + (b * 128 + wc * 32 + j * 16 + 4 * g) * 4, acc[a][b][i][j]);
+        __syncthreads();
+        nt_stage_readback<OUT_F32, 128, 256, 512>(p, S, m0 + a * 128, n0, tid);
+        if (a == 0) __syncthreads();                     // the second half overwrites the staging rows
+    }
+}
+
+// the same for the 128 x 128 kernel (4 waves of 64 x 64, acc[i][j]: row wm*64 + i*16 + l15, columns wn*64 + j*16 + 4g ..)
+template <bool OUT_F32>
+__device__ __forceinline__ void nt_epilogue_staged_128(const NTArgs& p, f32x4 (&acc)[4][4], unsigned char* S, int m0, int n0,
+                                                       int tid, int wm, int wn, int l15, int g) {
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int j = 0; j < 4; ++j)
+            st<f32x4>(S + (wm * 64 + i * 16 + l15) * GSTAGE_ROW + (wn * 64 + j * 16 + 4 * g) * 4, acc[i][j]);
+    __syncthreads();
+    nt_stage_readback<OUT_F32, 128, 128, 256>(p, S, m0, n0, tid);
+}
+
 // General NT kernel (any K multiple of 8, e.g. the B x (4 L D) conditioning GEMM): operands staged through VGPRs
 template <bool OUT_F32>
 __global__ __launch_bounds__(256) void gemm_nt_kernel(NTArgs p) {
@@ -271,7 +358,9 @@ __global__ __launch_bounds__(256) void gemm_nt_kernel(NTArgs p) {
 // ~50 VALU instructions per 32 MFMAs on address arithmetic: PMC showed 3.6 VALU per MFMA and MFMA busy at 25 %).
 template <bool OUT_F32>
 __global__ __launch_bounds__(256, 2) void gemm_nt_glds_kernel(NTArgs p) {
-    __shared__ __attribute__((aligned(16))) unsigned char smem[2][2][BM * BK * 2];
+    // two K-tile buffers (64 KB); the staged epilogue needs 66 KB (two workgroups per CU still fit the 160 KB)
+    __shared__ __attribute__((aligned(16))) unsigned char smem_raw[GSTAGE_BYTES > 4 * BM * BK * 2 ? GSTAGE_BYTES : 4 * BM * BK * 2];
+    unsigned char (*smem)[2][BM * BK * 2] = reinterpret_cast<unsigned char (*)[2][BM * BK * 2]>(smem_raw);
     const int tid = threadIdx.x, lane = tid & 63, wave = uniform_i(tid >> 6);
     const int wm = wave >> 1, wn = wave & 1;
     const int l15 = lane & 15, g = lane >> 4;
@@ -384,6 +473,11 @@ __global__ __launch_bounds__(256, 2) void gemm_nt_glds_kernel(NTArgs p) {
 #pragma unroll
             for (int j = 0; j < 4; ++j) st<f32x4>(w + (i * 4 + j) * 1024, acc[i][j]);
         return;                                               // (gemm_nt_fixup_kernel finishes the tile)
+    }
+    if (p.staged) {                          // (the loop's last __syncthreads / compute has drained every DMA and fragment read)
+        __syncthreads();
+        nt_epilogue_staged_128<OUT_F32>(p, acc, smem_raw, m0, n0, tid, wm, wn, l15, g);
+        return;
     }
     nt_epilogue<OUT_F32, 4>(p, acc, m0 + wm * 64, n0 + wn * 64, l15, g);
 }
@@ -508,7 +602,7 @@ constexpr int QBM = 256, QBN = 256, QHALF = 128 * BK * 2, QBUF = 4 * QHALF, QTHR
 
 template <bool OUT_F32, bool GLU = false>
 __global__ __launch_bounds__(QTHREADS, 1) void gemm_nt_256_kernel(NTArgs p) {
-    __shared__ __attribute__((aligned(16))) unsigned char smem[2 * QBUF];
+    __shared__ __attribute__((aligned(16))) unsigned char smem[(2 * QBUF > QSTAGE_BYTES) ? 2 * QBUF : QSTAGE_BYTES];
     const int tid = threadIdx.x, lane = tid & 63, wave = uniform_i(tid >> 6);
     const int wr = wave >> 2, wc = wave & 3;
     const int l15 = lane & 15, g = lane >> 4;
@@ -679,261 +773,16 @@ __global__ __launch_bounds__(QTHREADS, 1) void gemm_nt_256_kernel(NTArgs p) {
         for (int a = 0; a < 2; ++a) nt_epilogue_glu<4>(p, acc[a][0], acc[a][1], m0 + a * 128 + wr * 64, n0 + wc * 32, l15, g);
         return;
     }
+    if (p.staged) {                          // (every DMA has landed and every fragment read has been waited for: the ring is free)
+        __syncthreads();
+        nt_epilogue_staged<OUT_F32>(p, acc, smem, m0, n0, tid, wr, wc, l15, g);
+        return;
+    }
 #pragma unroll
     for (int a = 0; a < 2; ++a)
 #pragma unroll
         for (int b = 0; b < 2; ++b)
             nt_epilogue<OUT_F32, 4, 2>(p, acc[a][b], m0 + a * 128 + wr * 64, n0 + b * 128 + wc * 32, l15, g);
-}
-
-// PERSISTENT form of the kernel above (E2K_GEMM_PERSIST; one workgroup per CU for the whole launch).  Workgroup b walks a
-// list of UNITS -- its share of the whole 256 x 256 tiles, then at most one K-range part of a remainder tile -- and the
-// half-tile ring simply keeps running across unit boundaries: while the last K tiles of a unit are being multiplied the
-// staging cursor has already moved on to the first K tiles of the next unit, so a unit starts with its operands in LDS.
-// What the one-tile-per-workgroup kernel pays per tile and this one pays once per launch: the dispatch of a workgroup,
-// its address set-up, the latency of the first six half tiles (about 2 us of the 17-40 us of a tile at K = 1024-2048).
-//
-//   * units of workgroup b = (xcd, slot) = (b & 7, b >> 3), G8 = gridDim.x / 8 workgroups per XCD, R = whole tiles per
-//     workgroup:  tile(i) = xcd * R * G8 + i * G8 + slot  (i < R): at any time the workgroups of an XCD work on G8
-//     consecutive tiles of the grouped order (8 tile rows x all tile columns), which is what keeps their A / B panels in
-//     that XCD's L2;  then part q = b of the rem * split remainder parts (q < rem * split), finished by the fix-up launch.
-//   * staging state (source offsets, K cursor) and compute state (accumulators, epilogue coordinates) are separate: the
-//     staging side switches to the next unit in phase 3 of the second-to-last K tile (where Alo(t + 2) is issued).
-//   * vmcnt: `issued` half tiles so far, global phase g: at most issued - g - 3 may stay in flight (3 in steady state).
-//     The epilogue issues stores, which share the counter with the loads and may retire in any order relative to them:
-//     a counted wait then still guarantees "all but the newest N LOADS have landed" (loads retire in order among
-//     themselves, the stores only make it wait longer).  To keep those stores off the critical path the kernel waits
-//     for every issued half tile BEFORE the epilogue (exact: only loads are outstanding there) and skips the waits of the
-//     four phases after it, whose guarantees (elements up to E0 + 5) that wait has already given at the same place in the
-//     barrier sequence; the next counted wait (phase 4 after the epilogue) sees stores that are ~1.3 us old.
-//   * the two wave groups stay one barrier apart for the whole launch (the epilogue contains no barrier).
-template <bool OUT_F32>
-__global__ __launch_bounds__(QTHREADS, 1) void gemm_nt_256p_kernel(NTArgs p) {
-    __shared__ __attribute__((aligned(16))) unsigned char smem[2 * QBUF];
-    const int tid = threadIdx.x, lane = tid & 63, wave = uniform_i(tid >> 6);
-    const int wr = wave >> 2, wc = wave & 3;
-    const int l15 = lane & 15, g = lane >> 4;
-    const int tm = (p.M + QBM - 1) / QBM, tn = (p.N + QBN - 1) / QBN;
-    const int nk1 = p.K1 / BK, nk = (p.K1 + p.K2) / BK;
-    const int G = gridDim.x, G8 = G >> 3, R = p.full / G;
-    const int b = blockIdx.x, xcd = b & 7, slot = b >> 3;
-    const int nextra = p.rem * p.split;      // remainder tiles, whole (split == 1) or cut into `split` K ranges each
-    const int nunits = R + (b < nextra ? 1 : 0);
-
-    // unit u of this workgroup -> tile origin, K-tile range, partial slot (-1: whole tile)
-    auto unit = [&](int u, int& m0, int& n0, int& kb, int& ke, int& part) __attribute__((always_inline)) {
-        int tile, tile_m, tile_n;
-        if (u < R) {
-            tile = xcd * R * G8 + u * G8 + slot;
-            kb = 0; ke = nk; part = -1;
-        } else {
-            const int r = b / p.split, sidx = b - r * p.split;
-            tile = p.full + r;
-            kb = (int)((long)nk * sidx / p.split);
-            ke = (int)((long)nk * (sidx + 1) / p.split);
-            part = p.split > 1 ? b : -1;
-        }
-        tile_coords(tile, tm, tn, tile_m, tile_n);
-        m0 = tile_m * QBM; n0 = tile_n * QBN;
-    };
-
-    // ---- staging side
-    unsigned va[2][2], dv[2][2], vb[2][2];
-    int su = 0, skt = 0, ske = 0;            // staging unit, its current K tile (absolute), its end
-    bool svalid = nunits > 0;
-    auto stage_unit = [&](int u) __attribute__((always_inline)) {
-        int m0, n0, kb, ke, part;
-        unit(u, m0, n0, kb, ke, part);
-        skt = kb; ske = ke;
-#pragma unroll
-        for (int h = 0; h < 2; ++h)
-#pragma unroll
-            for (int uu = 0; uu < 2; ++uu) {
-                const int row = (wave * 2 + uu) * 8 + (lane >> 3);
-                const int c = (lane & 7) ^ (row & 7);
-                const int m = min(m0 + h * 128 + row, p.M - 1), n = min(n0 + h * 128 + row, p.N - 1);
-                va[h][uu] = (unsigned)(((long)m * p.lda1 + c * 8) * 2);
-                dv[h][uu] = p.K2 ? (unsigned)(((long)m * p.lda2 + c * 8) * 2) - va[h][uu] : 0u;
-                vb[h][uu] = (unsigned)(((long)n * p.ldb + c * 8) * 2);
-            }
-    };
-    auto advance = [&]() __attribute__((always_inline)) {          // staging cursor to the next K tile (maybe of the next unit)
-        if (!svalid) return;
-        if (++skt == ske) {
-            if (++su < nunits) stage_unit(su);
-            else svalid = false;
-        }
-    };
-    unsigned char* const S0 = &smem[0];
-    int issued = 0;
-    auto stage_a = [&](int par, int h) __attribute__((always_inline)) {
-        if (!svalid) return;
-        const bool first = skt < nk1;                    // wave-uniform
-        const char* sa = first ? (const char*)p.A1 + (long)skt * (BK * 2) : (const char*)p.A2 + (long)(skt - nk1) * (BK * 2);
-        const unsigned sel = first ? 0u : ~0u;
-        unsigned char* dst = S0 + par * QBUF + h * QHALF + wave * 2048;
-#pragma unroll
-        for (int uu = 0; uu < 2; ++uu) glds16(sa + (va[h][uu] + (dv[h][uu] & sel)), dst + uu * 1024);
-        ++issued;
-    };
-    auto stage_b = [&](int par, int h) __attribute__((always_inline)) {
-        if (!svalid) return;
-        const char* sb = (const char*)p.B + (long)skt * (BK * 2);
-        unsigned char* dst = S0 + par * QBUF + (2 + h) * QHALF + wave * 2048;
-#pragma unroll
-        for (int uu = 0; uu < 2; ++uu) glds16(sb + vb[h][uu], dst + uu * 1024);
-        ++issued;
-    };
-    auto wait_landed = [&](int left) __attribute__((always_inline)) {
-        if (left >= 3) wait_vmcnt<6>();
-        else if (left == 2) wait_vmcnt<4>();
-        else if (left == 1) wait_vmcnt<2>();
-        else wait_vmcnt<0>();
-    };
-
-    // ---- compute side
-    int offa[2][4], offb[2][2];
-#pragma unroll
-    for (int kk = 0; kk < 2; ++kk) {
-#pragma unroll
-        for (int i = 0; i < 4; ++i) {
-            const int ra = wr * 64 + i * 16 + l15;
-            offa[kk][i] = ra * 128 + (((kk * 4 + g) ^ (ra & 7)) << 4);
-        }
-#pragma unroll
-        for (int j = 0; j < 2; ++j) {
-            const int rb = wc * 32 + j * 16 + l15;
-            offb[kk][j] = rb * 128 + (((kk * 4 + g) ^ (rb & 7)) << 4);
-        }
-    }
-    f32x4 acc[2][2][4][2];
-    bf16x8 ar[2][4], blo[2][2], bhi[2][2];
-    auto read_a = [&](const unsigned char* S) __attribute__((always_inline)) {
-#pragma unroll
-        for (int kk = 0; kk < 2; ++kk)
-#pragma unroll
-            for (int i = 0; i < 4; ++i) ar[kk][i] = ld<bf16x8>(S + offa[kk][i]);
-    };
-    auto read_b = [&](bf16x8 (&bq)[2][2], const unsigned char* S) __attribute__((always_inline)) {
-#pragma unroll
-        for (int kk = 0; kk < 2; ++kk)
-#pragma unroll
-            for (int j = 0; j < 2; ++j) bq[kk][j] = ld<bf16x8>(S + offb[kk][j]);
-    };
-    auto mma = [&](f32x4 (&c)[4][2], const bf16x8 (&bq)[2][2]) __attribute__((always_inline)) {
-        set_prio<1>();
-#pragma unroll
-        for (int kk = 0; kk < 2; ++kk)
-#pragma unroll
-            for (int i = 0; i < 4; ++i)
-#pragma unroll
-                for (int j = 0; j < 2; ++j)
-                    c[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(bq[kk][j], ar[kk][i], c[i][j], 0, 0, 0);
-        set_prio<0>();
-    };
-
-    if (nunits == 0) return;
-    if (p.probe & E2K_GEMM_PROBE_STAGGER) {
-        // bottleneck probe: workgroup b starts (b & 3) quarters of a tile time late (~0.4 us per K tile and quarter), so
-        // that the C-tile store bursts of different workgroups no longer coincide.  Costs up to 3/4 of a tile time once per
-        // launch; on a shape with many rounds the time PER TILE shows what de-synchronised epilogues would buy
-        spin_wall_ticks((long long)(b & 3) * nk * 40);            // 100 MHz clock: 40 ticks = 0.4 us
-    }
-    // prologue (once per launch): all of the first K tile, then Alo, Blo of the second; elements 0, 1 must have landed
-    stage_unit(0);
-    stage_a(0, 0); stage_b(0, 0); stage_b(0, 1); stage_a(0, 1);
-    advance();
-    stage_a(1, 0); stage_b(1, 0);
-    if (issued >= 6) wait_vmcnt<8>();
-    else wait_vmcnt<4>();
-    barrier_raw();
-    if (wr == 1) barrier_raw();              // waves 4-7 trail by one barrier from here on
-
-    int gph = 0, cpar = 0, skip = 0;         // global phase count, LDS buffer of the K tile being multiplied, waits to skip
-    for (int cu = 0; cu < nunits; ++cu) {
-        int m0, n0, kb, ke, part;
-        unit(cu, m0, n0, kb, ke, part);
-#pragma unroll
-        for (int a = 0; a < 2; ++a)
-#pragma unroll
-            for (int bq = 0; bq < 2; ++bq)
-#pragma unroll
-                for (int i = 0; i < 4; ++i)
-#pragma unroll
-                    for (int j = 0; j < 2; ++j) acc[a][bq][i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
-        for (int t = kb; t < ke; ++t) {
-            const unsigned char* S = S0 + cpar * QBUF;
-            // phase 1
-            read_b(blo, S + 2 * QHALF);
-            sched_fence();
-            read_a(S);
-            if (skip > 0) --skip; else wait_landed(issued - gph - 3);
-            ++gph;
-            stage_b(cpar ^ 1, 1);
-            barrier_raw();
-            mma(acc[0][0], blo);
-            barrier_raw();
-            // phase 2
-            read_b(bhi, S + 3 * QHALF);
-            if (skip > 0) --skip; else wait_landed(issued - gph - 3);
-            ++gph;
-            stage_a(cpar ^ 1, 1);
-            barrier_raw();
-            mma(acc[0][1], bhi);
-            barrier_raw();
-            // phase 3
-            read_a(S + QHALF);
-            if (skip > 0) --skip; else wait_landed(issued - gph - 3);
-            ++gph;
-            advance();
-            stage_a(cpar, 0);
-            barrier_raw();
-            mma(acc[1][1], bhi);
-            barrier_raw();
-            // phase 4
-            if (skip > 0) --skip; else wait_landed(issued - gph - 3);
-            ++gph;
-            stage_b(cpar, 0);
-            barrier_raw();
-            mma(acc[1][0], blo);
-            barrier_raw();
-            cpar ^= 1;
-        }
-        // every half tile issued so far has landed once this returns (only loads are outstanding here: exact); the four
-        // phases after the epilogue need no wait of their own
-        wait_vmcnt<0>();
-        skip = 4;
-        if (part >= 0) {        // K-range partial of a remainder tile: [part][(a*2+b)*8 + i*2 + j][tid] x 4 floats
-            float* w = p.ws + ((long)part * 32 * QTHREADS + tid) * 4;
-#pragma unroll
-            for (int a = 0; a < 2; ++a)
-#pragma unroll
-                for (int bq = 0; bq < 2; ++bq)
-#pragma unroll
-                    for (int i = 0; i < 4; ++i)
-#pragma unroll
-                        for (int j = 0; j < 2; ++j) st<f32x4>(w + (((a * 2 + bq) * 4 + i) * 2 + j) * (QTHREADS * 4), acc[a][bq][i][j]);
-        } else if (p.probe & E2K_GEMM_PROBE_NO_STORE) {
-            // bottleneck probe (WRONG results): the K loops without the C-tile stores; the accumulators are kept alive
-#pragma unroll
-            for (int a = 0; a < 2; ++a)
-#pragma unroll
-                for (int bq = 0; bq < 2; ++bq)
-#pragma unroll
-                    for (int i = 0; i < 4; ++i)
-#pragma unroll
-                        for (int j = 0; j < 2; ++j) asm volatile("" :: "v"(acc[a][bq][i][j]));
-        } else {
-#pragma unroll
-            for (int a = 0; a < 2; ++a)
-#pragma unroll
-                for (int bq = 0; bq < 2; ++bq) {
-                    nt_epilogue<OUT_F32, 4, 2>(p, acc[a][bq], m0 + a * 128 + wr * 64, n0 + bq * 128 + wc * 32, l15, g);
-                    sched_fence();
-                }
-        }
-    }
-    if (wr == 0) barrier_raw();              // pairs with the extra barrier waves 4-7 took at the start
 }
 
 // blockIdx.x = remainder tile, blockIdx.y = (A half * 2 + B half) * 4 + m16 group
@@ -1017,13 +866,20 @@ __device__ __forceinline__ bf16x8 tn_frag(const unsigned char* T, int kk, int co
 }
 
 // acc[i][j]: C[n = n0+wn*64+j*16+q][k = k0+wk*64+i*16+4g+r]
-__device__ __forceinline__ void tn_store(const TNArgs& p, f32x4 (&acc)[4][4], int n0, int k0, int wn, int wk, int q, int g) {
-    // splits == 1: C += acc.  splits > 1: plain stores of the partial tile into ws[split] (combined by
-    // tn_reduce_kernel: fp32 atomics on C ran at ~60 G atomics/s and dominated small-output weight gradients).
-    const bool to_ws = p.splits > 1;
-    float* base = to_ws ? p.ws + (long)blockIdx.y * p.N * p.K : p.C;
-    const long ld = to_ws ? p.K : p.ldc;
-    const bool vec = to_ws && (p.K & 3) == 0;
+// splits == 1: C += acc.  splits > 1: the partial tile goes to the workspace in FRAGMENT order,
+//     ws[((split * tiles + tile) * 16 + i*4 + j) * 256 + tid]   (f32x4 units),
+// i.e. every wave store is one contiguous 1-KB run (the row-major [split][N][K] layout of rounds 1-2 made it 16 rows x
+// 64 bytes: partial cache lines, the store pattern that costs the NT kernel 10 us per 128 KB, profiles/r03_nt_store_burst.json);
+// tn_reduce_frag_kernel maps fragments back to (n, k).  (fp32 atomics on C instead of a workspace ran at ~60 G atomics/s.)
+__device__ __forceinline__ void tn_store(const TNArgs& p, f32x4 (&acc)[4][4], int tile, int tiles, int n0, int k0, int wn, int wk, int q, int g) {
+    if (p.splits > 1) {
+        f32x4* w = (f32x4*)p.ws + ((long)blockIdx.y * tiles + tile) * (16 * 256) + threadIdx.x;
+#pragma unroll
+        for (int i = 0; i < 4; ++i)
+#pragma unroll
+            for (int j = 0; j < 4; ++j) w[(i * 4 + j) * 256] = acc[i][j];
+        return;
+    }
 #pragma unroll
     for (int j = 0; j < 4; ++j) {
         const int n = n0 + wn * 64 + j * 16 + q;
@@ -1031,18 +887,10 @@ __device__ __forceinline__ void tn_store(const TNArgs& p, f32x4 (&acc)[4][4], in
 #pragma unroll
         for (int i = 0; i < 4; ++i) {
             const int k = k0 + wk * 64 + i * 16 + 4 * g;
-            float* c = base + (long)n * ld + k;
-            if (vec && k + 3 < p.K) {
-                st<f32x4>(c, acc[i][j]);
-            } else {
+            float* c = p.C + (long)n * p.ldc + k;
 #pragma unroll
-                for (int r = 0; r < 4; ++r) {
-                    if (k + r < p.K) {
-                        if (to_ws) c[r] = acc[i][j][r];
-                        else c[r] += acc[i][j][r];
-                    }
-                }
-            }
+            for (int r = 0; r < 4; ++r)
+                if (k + r < p.K) c[r] += acc[i][j][r];
         }
     }
 }
@@ -1121,7 +969,7 @@ __global__ __launch_bounds__(256) void gemm_tn_kernel(TNArgs p) {
         if (s + 1 < nsteps) sstore(buf ^ 1);
         __syncthreads();
     }
-    tn_store(p, acc, n0, k0, wn, wk, q, g);
+    tn_store(p, acc, tile_n * tk + tile_k, tn * tk, n0, k0, wn, wk, q, g);
 }
 
 // Fast TN path (token count a multiple of 64): global_load_lds staging into unpadded 256-B LDS rows whose 16-B chunks
@@ -1232,7 +1080,7 @@ __global__ __launch_bounds__(256, 2) void gemm_tn_glds_kernel(TNArgs p) {
         __syncthreads();
     }
     if (s < nsteps) compute(0);
-    tn_store(p, acc, n0, k0, wn, wk, q, g);
+    tn_store(p, acc, tile_n * tk + tile_k, tn * tk, n0, k0, wn, wk, q, g);
     if (do_cs && g == 0) {
 #pragma unroll
         for (int jj = 0; jj < 2; ++jj) {
@@ -1435,36 +1283,37 @@ __global__ __launch_bounds__(T2THREADS, 1) void gemm_tn_256_kernel(TNArgs p) {
         if (wr == 0) barrier_raw();              // pairs with the extra barrier waves 4-7 took at the start
     }
 
-    // splits == 1: C += acc.  splits > 1: plain stores of the partial tile into ws[split] (combined by tn_reduce_kernel)
-    const bool to_ws = p.splits > 1;
-    float* base = to_ws ? p.ws + (long)blockIdx.y * p.N * p.K : p.C;
-    const long ld = to_ws ? p.K : p.ldc;
-    const bool vec = to_ws && (p.K & 3) == 0;
+    // splits == 1: C += acc.  splits > 1: the partial tile in fragment order (see tn_store),
+    //     ws[((split * tiles + tile) * 32 + ((a*2 + b)*4 + i)*2 + j) * 512 + tid]   (f32x4 units)
+    if (p.splits > 1) {
+        f32x4* w = (f32x4*)p.ws + ((long)blockIdx.y * (tn * tk) + tile_n * tk + tile_k) * (32 * T2THREADS) + tid;
 #pragma unroll
-    for (int a = 0; a < 2; ++a)
-#pragma unroll
-        for (int i = 0; i < 4; ++i) {
-            const int n = n0 + a * 128 + wr * 64 + i * 16 + q;
-            if (n >= p.N) continue;
+        for (int a = 0; a < 2; ++a)
 #pragma unroll
             for (int b = 0; b < 2; ++b)
 #pragma unroll
-                for (int j = 0; j < 2; ++j) {
-                    const int k = k0 + b * 128 + wc * 32 + j * 16 + 4 * g;
-                    float* c = base + (long)n * ld + k;
-                    if (vec && k + 3 < p.K) {
-                        st<f32x4>(c, acc[a][b][i][j]);
-                    } else {
+                for (int i = 0; i < 4; ++i)
 #pragma unroll
-                        for (int r = 0; r < 4; ++r) {
-                            if (k + r < p.K) {
-                                if (to_ws) c[r] = acc[a][b][i][j][r];
-                                else c[r] += acc[a][b][i][j][r];
-                            }
-                        }
+                    for (int j = 0; j < 2; ++j) w[(((a * 2 + b) * 4 + i) * 2 + j) * T2THREADS] = acc[a][b][i][j];
+    } else {
+#pragma unroll
+        for (int a = 0; a < 2; ++a)
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                const int n = n0 + a * 128 + wr * 64 + i * 16 + q;
+                if (n >= p.N) continue;
+#pragma unroll
+                for (int b = 0; b < 2; ++b)
+#pragma unroll
+                    for (int j = 0; j < 2; ++j) {
+                        const int k = k0 + b * 128 + wc * 32 + j * 16 + 4 * g;
+                        float* c = p.C + (long)n * p.ldc + k;
+#pragma unroll
+                        for (int r = 0; r < 4; ++r)
+                            if (k + r < p.K) c[r] += acc[a][b][i][j][r];
                     }
-                }
-        }
+            }
+    }
     if (do_cs && g == 0) {
 #pragma unroll
         for (int a = 0; a < 2; ++a) {
@@ -1479,13 +1328,37 @@ __global__ __launch_bounds__(T2THREADS, 1) void gemm_tn_256_kernel(TNArgs p) {
 // parked at s_waitcnt / barriers 58 % of the time, but halving the MFMAs per barrier costs more than the deeper
 // prefetch recovers.  Removed; see DESIGN.md.)
 
-__global__ __launch_bounds__(256) void tn_reduce_kernel(const float* ws, float* C, long ldc, int N, int K, int splits) {
-    const long total = (long)N * K;
-    for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < total; i += (long)gridDim.x * 256) {
-        float s = 0.f;
-        for (int sp = 0; sp < splits; ++sp) s += ws[(long)sp * total + i];
-        const int n = (int)(i / K), k = (int)(i % K);
-        C[(long)n * ldc + k] += s;
+// sums the fragment-order partial tiles over the splits and adds the total to C.  One workgroup per (tile, fragment group):
+// the thread <-> (n, k) mapping of a fragment is the GEMM kernel's, so its 16-byte loads are contiguous over the lanes
+template <bool BIG>
+__global__ __launch_bounds__(BIG ? 512 : 256) void tn_reduce_frag_kernel(const f32x4* ws, float* C, long ldc, int N, int K, int splits, int tk) {
+    constexpr int NF = BIG ? 32 : 16, T = BIG ? 512 : 256, TS = BIG ? 256 : 128;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, q = lane & 15, g = lane >> 4;
+    const int tile = blockIdx.x, tiles = gridDim.x, f = blockIdx.y;
+    const int n0 = (tile / tk) * TS, k0 = (tile % tk) * TS;
+    int n, k;
+    if (BIG) {
+        const int wr = wave >> 2, wc = wave & 3, a = f >> 4, b = (f >> 3) & 1, i = (f >> 1) & 3, j = f & 1;
+        n = n0 + a * 128 + wr * 64 + i * 16 + q;
+        k = k0 + b * 128 + wc * 32 + j * 16 + 4 * g;
+    } else {
+        const int wn = wave >> 1, wk = wave & 1, i = f >> 2, j = f & 3;
+        n = n0 + wn * 64 + j * 16 + q;
+        k = k0 + wk * 64 + i * 16 + 4 * g;
+    }
+    if (n >= N || k >= K) return;
+    f32x4 s = {0.f, 0.f, 0.f, 0.f};
+    const f32x4* w = ws + ((long)tile * NF + f) * T + tid;
+    const long stride = (long)tiles * NF * T;
+#pragma unroll 4
+    for (int sp = 0; sp < splits; ++sp) s += w[sp * stride];
+    float* c = C + (long)n * ldc + k;
+    if (k + 3 < K && (ldc & 3) == 0 && (((uintptr_t)C) & 15) == 0) {
+        st<f32x4>(c, ld<f32x4>(c) + s);
+    } else {
+#pragma unroll
+        for (int r = 0; r < 4; ++r)
+            if (k + r < K) c[r] += s[r];
     }
 }
 
@@ -1563,7 +1436,11 @@ static int gemm_nt_bf16_impl(const void* A1, int64_t lda1, int K1, const void* A
     p.rowmask = rowmask; p.resid = (const bf16_t*)resid; p.ldr = ldr;
     const int tn = (N + BN - 1) / BN;
     p.probe = flags & (E2K_GEMM_PROBE_NO_LOADS | E2K_GEMM_PROBE_NO_MATH);
-    const int pprobe = flags & (E2K_GEMM_PROBE_NO_STORE | E2K_GEMM_PROBE_STAGGER);        // probes of the persistent kernel only
+    // C tile through LDS in whole-line row segments (nt_epilogue_staged*) when every epilogue operand allows 4-element accesses
+    p.staged = !(flags & E2K_GEMM_NO_STAGE) && (K1 % BK) == 0 && (K2 % BK) == 0 && !(flags & E2K_GEMM_NO_GLDS) &&
+               (N & 3) == 0 && (ldc & 3) == 0 && ((uintptr_t)C & 15) == 0 &&
+               (!bias || ((uintptr_t)bias & 15) == 0) && (!colscale || ((lds & 3) == 0 && ((uintptr_t)colscale & 15) == 0)) &&
+               (!resid || ((ldr & 3) == 0 && ((uintptr_t)resid & 7) == 0));
     const bool glds = !(flags & E2K_GEMM_NO_GLDS) && (K1 % BK) == 0 && (K2 % BK) == 0;
     const int t256 = ((M + QBM - 1) / QBM) * ((N + QBN - 1) / QBN);
     // default: shapes whose 256 x 256 tiles fill >= 7/8 of a round of the 256 workgroup slots (measured on MI355X: +10-22 %
@@ -1589,15 +1466,7 @@ static int gemm_nt_bf16_impl(const void* A1, int64_t lda1, int K1, const void* A
         }
         dim3 grid(p.full + rem * p.split);
         hipStream_t st = (hipStream_t)stream;
-        p.rem = rem;
-        if ((flags & E2K_GEMM_PERSIST) && T >= slots) {
-            p.probe = pprobe;
-            // persistent form: `slots` workgroups, each walks its share of the whole tiles and then at most one remainder
-            // unit (a K-range part when the remainder is split, a whole remainder tile otherwise)
-            if (!rem) { p.full = T - T % slots; p.split = 1; p.rem = T % slots; }
-            if (out_f32) hipLaunchKernelGGL(gemm_nt_256p_kernel<true>, dim3(slots), dim3(QTHREADS), 0, st, p);
-            else hipLaunchKernelGGL(gemm_nt_256p_kernel<false>, dim3(slots), dim3(QTHREADS), 0, st, p);
-        } else if (out_f32) hipLaunchKernelGGL(gemm_nt_256_kernel<true>, grid, dim3(QTHREADS), 0, st, p);
+        if (out_f32) hipLaunchKernelGGL(gemm_nt_256_kernel<true>, grid, dim3(QTHREADS), 0, st, p);
         else hipLaunchKernelGGL(gemm_nt_256_kernel<false>, grid, dim3(QTHREADS), 0, st, p);
         E2K_CHECK_LAUNCH();
         if (rem) {
@@ -1710,6 +1579,17 @@ extern "C" int e2k_query_gemm_tn_splits_mode(int M, int N, int K, int splits, in
     return tn_use_256(M, N, K, use_tr) ? tn_splits_256(M, N, K, splits) : tn_splits(M, N, K, splits);
 }
 
+// floats of workspace e2k_gemm_tn_bf16 needs for (M, N, K, splits, use_tr): splits x whole tiles of the selected kernel
+// (partial tiles are stored in fragment order, padded to whole 128 x 128 / 256 x 256 tiles); 0 when nothing is split
+extern "C" int64_t e2k_query_gemm_tn_ws_floats(int M, int N, int K, int splits, int use_tr) {
+    if (M <= 0 || N <= 0 || K <= 0) return 0;
+    const bool big = tn_use_256(M, N, K, use_tr);
+    const int ns = big ? tn_splits_256(M, N, K, splits) : tn_splits(M, N, K, splits);
+    if (ns <= 1) return 0;
+    const int ts = big ? T2 : 128;
+    return (int64_t)ns * ((N + ts - 1) / ts) * ((K + ts - 1) / ts) * ts * ts;
+}
+
 extern "C" int e2k_colsum_bf16(const void* x, int64_t ldx, float* out, int M, int N, void* stream);
 
 static int gemm_tn_bf16_impl(const void* A, int64_t lda, const void* B, int64_t ldb, float* C, int64_t ldc,
@@ -1746,11 +1626,8 @@ static int gemm_tn_bf16_impl(const void* A, int64_t lda, const void* B, int64_t 
     else hipLaunchKernelGGL(gemm_tn_kernel<false>, grid, block, 0, (hipStream_t)stream, p);
     E2K_CHECK_LAUNCH();
     if (splits > 1) {
-        long total = (long)N * K;
-        long g = (total + 255) / 256;
-        if (g > 2048) g = 2048;
-        hipLaunchKernelGGL(tn_reduce_kernel, dim3((int)g), dim3(256), 0, (hipStream_t)stream, (const float*)ws, C,
-                           (long)ldc, N, K, splits);
+        if (big) hipLaunchKernelGGL(tn_reduce_frag_kernel<true>, dim3(tn * tk, 32), dim3(512), 0, (hipStream_t)stream, (const f32x4*)ws, C, (long)ldc, N, K, splits, tk);
+        else hipLaunchKernelGGL(tn_reduce_frag_kernel<false>, dim3(tn * tk, 16), dim3(256), 0, (hipStream_t)stream, (const f32x4*)ws, C, (long)ldc, N, K, splits, tk);
         E2K_CHECK_LAUNCH();
     }
     return 0;

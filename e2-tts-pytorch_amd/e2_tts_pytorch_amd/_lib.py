@@ -31,14 +31,18 @@ _CTYPES = {
 }
 
 
+_RET = {}          # entry point -> ctypes return type (int status / int or int64_t query result)
+
+
 def parse_header(path: Path | None = None):
     """-> {name: [ctype, ...]} for every `int e2k_*(...)` prototype in the header."""
     text = Path(path or _find_header()).read_text()
     text = re.sub(r'/\*.*?\*/', '', text, flags=re.S)
     text = re.sub(r'//[^\n]*', '', text)
     protos = {}
-    for m in re.finditer(r'\bint\s+(e2k_\w+)\s*\(([^)]*)\)\s*;', text):
-        name, args = m.group(1), m.group(2).strip()
+    for m in re.finditer(r'\b(int|int64_t)\s+(e2k_\w+)\s*\(([^)]*)\)\s*;', text):
+        ret, name, args = m.group(1), m.group(2), m.group(3).strip()
+        _RET[name] = _CTYPES[ret]
         types = []
         if args and args != 'void':
             for a in args.split(','):
@@ -64,7 +68,7 @@ class _Lib:
         for name, types in self.protos.items():
             fn = getattr(self.cdll, name)        # AttributeError here == header/library mismatch: fail loudly
             fn.argtypes = types
-            fn.restype = ctypes.c_int
+            fn.restype = _RET.get(name, ctypes.c_int)
             if name.startswith('e2k_query_') or name == 'e2k_version':
                 setattr(self, name, fn)           # returns a value, not a status
             else:

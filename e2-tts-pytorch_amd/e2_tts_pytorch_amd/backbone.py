@@ -47,6 +47,27 @@ class RMSNorm(_Holder):                       # x_transformers.RMSNorm (e2_tts.p
         self.g = nn.Parameter(torch.ones(dim))
 
 
+def rmsnorm_gain_convention(state_dict, prefix=''):
+    """Which RMSNorm convention wrote this state dict?  x-transformers has shipped both `g` = ones with gain = g (what
+    this package and the oracle use) and `g` = zeros with gain = g + 1 ("unit offset").  Both give keys of
+    the same name and shape, so a checkpoint of the other convention loads strict=True and is silently wrong by +1 in
+    every plain RMSNorm.  Trained gains stay near their initial value (1 resp. 0), so the mean over all `.g` entries tells
+    them apart: returns 'plain' (mean > 0.5), 'unit_offset', or None when the dict holds no RMSNorm gain."""
+    vals = [v.float().mean() for k, v in state_dict.items()
+            if k.startswith(prefix) and k.endswith('.g') and torch.is_tensor(v) and v.dim() == 1]
+    if not vals:
+        return None
+    return 'plain' if float(torch.stack(vals).mean()) > 0.5 else 'unit_offset'
+
+
+def convert_rmsnorm_unit_offset(state_dict, prefix=''):
+    """in place: `g` of the unit-offset convention (gain = g + 1) -> this package's (gain = g)"""
+    for k, v in state_dict.items():
+        if k.startswith(prefix) and k.endswith('.g') and torch.is_tensor(v) and v.dim() == 1:
+            state_dict[k] = v + 1
+    return state_dict
+
+
 class AdaptiveRMSNorm(_Holder):               # x_transformers.AdaptiveRMSNorm (e2_tts.py:615,637,645)
     def __init__(self, dim):
         super().__init__()
@@ -310,6 +331,17 @@ class Transformer(Module):
         self._build_layout()
         self._grad_sync = None          # set by ddp.DataParallel: called with (grad_flat, start, end) per finished slab
         self._reset_runtime()
+        # checkpoints written with x-transformers' other RMSNorm convention (g = zeros, gain = g + 1) are converted on load
+        # (rmsnorm_gain_convention; set `rmsnorm_convert_on_load = False` to load `g` verbatim)
+        self.rmsnorm_convert_on_load = True
+        self._register_load_state_dict_pre_hook(self._rmsnorm_load_hook)
+
+    def _rmsnorm_load_hook(self, state_dict, prefix, *_):
+        if self.rmsnorm_convert_on_load and rmsnorm_gain_convention(state_dict, prefix) == 'unit_offset':
+            import warnings
+            warnings.warn('state dict holds RMSNorm gains of the unit-offset convention (g near 0, gain = g + 1): converted to '
+                          'gain = g on load (Transformer.rmsnorm_convert_on_load = False loads them verbatim)')
+            convert_rmsnorm_unit_offset(state_dict, prefix)
 
     # runtime state (device buffers, caches, recorded plans): never part of the module's identity -- a deep copy (the
     # trainer's EMA, trainer.py:170) starts without it and rebuilds its own on first use

@@ -326,8 +326,8 @@ def gemm_tn(a, b, out, *, splits=0, use_tr=True, colsum=None, colsum_from=0, hol
     assert out.shape == (N, K) and out.stride(1) == 1
     lib = _lib.get()
     mode = tn_mode if use_tr is True else int(use_tr)
-    ns = lib.e2k_query_gemm_tn_splits_mode(M, N, K, int(splits), mode)
-    ws = torch.empty((ns * N * K,), dtype=f32, device=a.device) if ns > 1 else None
+    nws = lib.e2k_query_gemm_tn_ws_floats(M, N, K, int(splits), mode)
+    ws = torch.empty((nws,), dtype=f32, device=a.device) if nws > 0 else None
     if colsum is not None:
         _chk(colsum)
         assert colsum.dtype == f32 and colsum.numel() == N and colsum.is_contiguous()

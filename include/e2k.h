@@ -46,12 +46,10 @@ int e2k_gemm_nt_bf16(const void* A1, int64_t lda1, int K1, const void* A2, int64
 int e2k_query_gemm_nt_ws_bytes(void);
 #define E2K_GEMM_NO_GLDS 1   /* flags: stage operands through VGPRs instead of global_load_lds (A/B benchmarking) */
 #define E2K_GEMM_PROBE_NO_LOADS 4 /* flags: bottleneck probe, K loop without its global loads (WRONG results) */
-#define E2K_GEMM_PROBE_NO_STORE 2 /* flags: bottleneck probe of the persistent kernel, K loops without the C-tile stores (WRONG results) */
-#define E2K_GEMM_PROBE_STAGGER 512 /* flags: bottleneck probe of the persistent kernel, workgroups start up to 3/4 of a tile time apart (results unchanged) */
 #define E2K_GEMM_PROBE_NO_MATH 8  /* flags: bottleneck probe, K loop without its LDS reads + MFMAs (WRONG results) */
 #define E2K_GEMM_T256 128        /* flags: 256 x 256 x 64 tile, 8-wave 8-phase kernel for EVERY shape (default: only shapes whose 256 x 256 tiles fill >= 7/8 of a round of the 256 workgroup slots) */
 #define E2K_GEMM_NO_T256 256     /* flags: never use the 256 x 256 kernel (A/B) */
-#define E2K_GEMM_PERSIST 64      /* flags: persistent form of the 256 x 256 kernel (one workgroup per CU walks several tiles, the K-tile prefetch ring keeps running across tile boundaries) for shapes with at least one whole round of tiles */
+#define E2K_GEMM_NO_STAGE 64     /* flags: 256 x 256 kernel stores its C tile straight from the accumulator registers (16 rows x 32 bytes per wave instruction) instead of through LDS in whole-line row segments (A/B) */
 #define E2K_GEMM_NO_SPLIT 16     /* flags: never split remainder tiles over K (A/B) */
 #define E2K_GEMM_TEST_SLOTS8 32  /* flags: pretend the chip holds 8 workgroups (lets small shapes exercise the remainder split in tests) */
 
@@ -67,12 +65,15 @@ int e2k_gemm_tn_bf16(const void* A, int64_t lda, const void* B, int64_t ldb, flo
                      int M, int N, int K, int splits, int use_tr, float* ws, float* colsum, int cs_from, void* stream);
 /* upper bound on the token-dimension splits the call above uses for (M, N, K, splits), whichever kernel it selects
  * (use_tr = 1 means "the library chooses per shape", not "transposing reads"); when it is > 1 the caller passes
- * ws = scratch of at least that many * N * K floats (partial tiles are stored there and combined afterwards).  The exact
- * count for a given use_tr mode: e2k_query_gemm_tn_splits_mode. */
+ * ws = scratch of e2k_query_gemm_tn_ws_floats(...) floats (partial tiles are stored there and combined afterwards).  The
+ * exact count for a given use_tr mode: e2k_query_gemm_tn_splits_mode. */
 int e2k_query_gemm_tn_splits(int M, int N, int K, int splits);
 /* the same for a given use_tr mode: 1 = the library chooses the kernel per shape, 2 = always the 128 x 128 x 64 kernel,
  * 3 = the 256 x 256 x 64 8-phase kernel wherever it can run (M a multiple of 64) */
 int e2k_query_gemm_tn_splits_mode(int M, int N, int K, int splits, int use_tr);
+/* floats of ws the call needs for (M, N, K, splits, use_tr): the partial tiles of the splits are stored in the MFMA fragment
+ * order of the selected kernel (contiguous 1-KB runs per wave store), padded to whole tiles; 0 = nothing is split */
+int64_t e2k_query_gemm_tn_ws_floats(int M, int N, int K, int splits, int use_tr);
 
 /* ---- hyper-connections (hyper_connections.HyperConnections; reference call sites e2_tts.py:870-882,900-939) ----
  * Streams are stored token-major: X[token][4][D] bf16.  coef: per-token fp32 record (e2k_query_hc_coef_width()

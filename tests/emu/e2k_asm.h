@@ -96,6 +96,4 @@ inline void glds4(const void* gsrc, void* lds_base) {
     }
 }
 
-inline void spin_wall_ticks(long long) {}       // (bottleneck probe: no time on the host model)
-
 }  // namespace e2k

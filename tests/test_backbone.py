@@ -442,3 +442,45 @@ def test_plan_recording_rejects_tensor_library_ops(dev):
         with pytest.raises(RuntimeError, match='inside a recorded launch plan'):
             a + 1
     assert b.shape == (3, 4) and c.numel() == 8
+
+
+def test_rmsnorm_unit_offset_checkpoints_are_converted_on_load():
+    """x-transformers has shipped RMSNorm with `g` = ones / gain = g (this package, the oracle) and with `g` = zeros /
+    gain = g + 1; both write the same keys and shapes, so a checkpoint of the other convention would load strict=True and
+    be silently wrong by +1 in every plain RMSNorm (final_norm, the text stream's norms, every norm of the duration
+    predictor).  The load hook recognises it (gains near 0 instead of near 1) and converts; plain checkpoints and
+    rmsnorm_convert_on_load = False are left alone"""
+    from e2_tts_pytorch_amd import Transformer, E2TTS
+    from e2_tts_pytorch_amd.backbone import rmsnorm_gain_convention
+    random.seed(0)
+    torch.manual_seed(0)
+    src = Transformer(dim=128, depth=2, heads=2, max_seq_len=32)
+    with torch.no_grad():
+        for n, p in src.named_parameters():
+            if n.endswith('.g'):
+                p.add_(torch.randn_like(p) * 0.2)            # "trained" gains around 1
+    sd = src.state_dict()
+    gkeys = [k for k in sd if k.endswith('.g')]
+    assert gkeys and rmsnorm_gain_convention(sd) == 'plain'
+    other = {k: (v - 1 if k in gkeys else v.clone()) for k, v in sd.items()}       # the same model, written with gain = g + 1
+    assert rmsnorm_gain_convention(other) == 'unit_offset'
+    dst = Transformer(dim=128, depth=2, heads=2, max_seq_len=32)
+    with pytest.warns(UserWarning, match='unit-offset'):
+        dst.load_state_dict(other, strict=True)
+    assert all(torch.allclose(dst.state_dict()[k], sd[k], atol=1e-6) for k in sd)
+    assert all(torch.equal(other[k], sd[k] - 1) for k in gkeys)                    # (the caller's dict is untouched)
+    import warnings
+    with warnings.catch_warnings():
+        warnings.simplefilter('error')
+        dst.load_state_dict(sd, strict=True)                                       # plain convention: no conversion, no warning
+        dst.rmsnorm_convert_on_load = False
+        dst.load_state_dict(other, strict=True)                                    # opt-out: verbatim
+    assert all(torch.equal(dst.state_dict()[k], other[k]) for k in gkeys)
+    # through the enclosing model (prefix 'transformer.')
+    m = E2TTS(transformer=dict(dim=128, depth=2, heads=2), use_vocos=False)
+    msd = m.state_dict()
+    mo = {k: (v - 1 if k.endswith('.g') else v) for k, v in msd.items()}
+    m2 = E2TTS(transformer=dict(dim=128, depth=2, heads=2), use_vocos=False)
+    with pytest.warns(UserWarning, match='unit-offset'):
+        m2.load_state_dict(mo, strict=True)
+    assert all(torch.allclose(m2.state_dict()[k], msd[k], atol=1e-6) for k in msd if k.endswith('.g'))

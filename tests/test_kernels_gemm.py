@@ -167,32 +167,56 @@ def test_gemm_nt_256_tile(dev, monkeypatch, M, N, K1, K2, kw, flags, late):
         ops.gemm_flags = old
 
 
-@pytest.mark.parametrize('M,N,K1,K2,kw,extra', [
-    (2048, 256, 64, 0, {}, 0),                                    # 8 tiles on the 8-slot hook: one unit each, ONE K tile per unit
-    (2048, 512, 128, 0, dict(bias=1), 0),                         # 16 tiles: two units per workgroup, two K tiles each
-    (2304, 256, 512, 0, dict(f32=1, bias=1), 0),                  # 9 tiles: one whole + 1 remainder tile x 2 K ranges
-    (2304, 768, 320, 0, dict(rs=1), 0),                           # 27 tiles, 5 K tiles (the LDS buffer parity flips between units), 3 whole remainder tiles
-    (1280, 512, 256, 256, dict(bias=1, cs=1, rm=1, rs=1), 0),     # 10 tiles, dual-K, every epilogue operand, 2 remainder tiles x 2 K ranges
-    (2304, 700, 576, 64, dict(bias=1, rs=1), 0),                  # ragged N, 27 tiles, 10 K tiles dual-K: 3 remainder tiles x 2 K ranges
-    (2300, 520, 192, 0, dict(bias=1), 16),                        # ragged M and N, remainder never split (whole remainder tiles)
-    (4352, 512, 192, 0, dict(rm=1), 0),                           # 34 tiles: four whole + 2 remainder
+@pytest.mark.parametrize('M,N,K1,K2,kw', [
+    (256, 256, 64, 0, {}),                                        # one whole tile, no epilogue operand
+    (300, 300, 128, 0, dict(bias=1)),                             # ragged rows and columns (N = 300: chunks of 4 in or out as a whole)
+    (520, 260, 192, 64, dict(bias=1, cs=1, rm=1, rs=1)),          # every epilogue operand, dual-K
+    (2304, 256, 512, 0, dict(f32=1, bias=1)),                     # fp32 output
+    (700, 520, 320, 0, dict(rs=1)),
+    (256, 258, 64, 0, dict(bias=1)),                              # N not a multiple of 4: the direct epilogue must be chosen
 ])
-@pytest.mark.parametrize('late', [0, 1])
-def test_gemm_nt_256_persistent(dev, monkeypatch, M, N, K1, K2, kw, extra, late):
-    """persistent form of the 256 x 256 kernel (E2K_GEMM_PERSIST: a workgroup walks several tiles, the half-tile ring keeps
-    running across tile boundaries) on the 8-slot test hook: unit bookkeeping (whole tiles per XCD range, remainder parts or
-    whole remainder tiles), the staging cursor crossing into the next unit, buffer parity with odd K-tile counts, the
-    waits around the in-loop epilogue; late = 1: LDS-DMA copies land as late as the counted waits allow"""
+def test_gemm_nt_256_staged_epilogue_matches_direct(dev, M, N, K1, K2, kw):
+    """the 256 x 256 kernel writes its C tile through LDS in whole-line row segments (nt_epilogue_staged, the default
+    where every epilogue operand allows 4-element accesses) -- same arithmetic in the same order as the direct epilogue
+    (E2K_GEMM_NO_STAGE = 64): identical bits, also with accumulate into an fp32 C"""
     from e2_tts_pytorch_amd import ops
-    if dev == 'cuda' and late:
-        pytest.skip('LDS-DMA landing extremes exist on the host model only')
-    monkeypatch.setenv('E2K_EMU_GLDS_LATE', str(late))
+    torch.manual_seed(M + N)
+    d = lambda t: None if t is None else t.to(dev)
+    a = d(torch.randn(M, K1).to(bf16))
+    a2 = d(torch.randn(M, K2).to(bf16)) if K2 else None
+    b = d(torch.randn(N, K1 + K2).to(bf16))
+    bias = d(torch.randn(N)) if kw.get('bias') else None
+    nb = 3
+    rpb = (M + nb - 1) // nb
+    cs = d(torch.rand(nb, N)) if kw.get('cs') else None
+    rm = d(torch.rand(M) > 0.3) if kw.get('rm') else None
+    rs = d(torch.randn(M, N).to(bf16)) if kw.get('rs') else None
+    f32o = bool(kw.get('f32'))
     old = ops.gemm_flags
-    ops.gemm_flags = 128 | 32 | 64 | extra
+    res = {}
     try:
-        test_gemm_nt(dev, M, N, K1, K2, kw)
+        for flags in (128, 128 | 64):
+            ops.gemm_flags = flags
+            out = d(torch.full((M, N), 0.5)) if f32o else None
+            o = ops.gemm_nt(a, b, a2=a2, bias=bias, colscale=cs, rows_per_batch=rpb, rowmask=rm, resid=rs, out=out,
+                            accumulate=f32o, out_dtype=torch.float32 if f32o else bf16)
+            res[flags] = o.cpu()
     finally:
         ops.gemm_flags = old
+    assert torch.equal(res[128], res[128 | 64])
+    A = torch.cat([a.cpu(), a2.cpu()], 1).float() if K2 else a.cpu().float()
+    ref = A @ b.cpu().float().T
+    if bias is not None:
+        ref = ref + bias.cpu()
+    if cs is not None:
+        ref = ref * cs.cpu()[torch.arange(M) // rpb]
+    if rm is not None:
+        ref = ref * rm.cpu()[:, None].float()
+    if rs is not None:
+        ref = ref + rs.cpu().float()
+    if f32o:
+        ref = ref + 0.5
+    assert rel(res[128], ref) < (1e-5 if f32o else 6e-3)
 
 
 @pytest.mark.parametrize('late', [0, 1])

@@ -64,6 +64,78 @@ def test_rotary_is_a_rotation_of_adjacent_pairs():
     assert abs((rot(q, 5) @ rot(k, 3)).item() - (rot(q, 7) @ rot(k, 5)).item()) < 1e-3
 
 
+def test_rotary_against_gptj_rotate_every_two():
+    """the interleaved-pair rotary restated in the oracle (x-transformers RotaryEmbedding + apply_rotary_pos_emb, SURVEY.md
+    A.6) against an independent implementation that is installed here: Hugging Face transformers' GPT-J
+    (`rotate_every_two` / `apply_rotary_pos_emb` / `create_sinusoidal_positions`), same base 10000 and pair layout"""
+    G = pytest.importorskip('transformers.models.gptj.modeling_gptj')
+    torch.manual_seed(0)
+    b, h, n, d = 2, 3, 11, 64
+    t = torch.randn(b, h, n, d)
+    freqs, _ = O.RotaryEmbedding(d).forward_from_seq_len(n)
+    ours = O.apply_rotary_pos_emb(t, freqs)
+    sincos = G.create_sinusoidal_positions(n, d)                   # (n, d): [sin | cos] halves of d / 2 frequencies
+    sin, cos = sincos[:, :d // 2][None], sincos[:, d // 2:][None]
+    theirs = G.apply_rotary_pos_emb(t.transpose(1, 2), sin, cos).transpose(1, 2)     # GPT-J layout (b, n, h, d)
+    assert (ours - theirs).abs().max().item() < 1e-5
+
+
+def test_rmsnorm_against_torch_rms_norm():
+    """x-transformers RMSNorm as restated (F.normalize * sqrt(dim) * g) == torch.nn.functional.rms_norm
+    with weight g (x * rsqrt(mean x^2) * g) away from the 1e-12 norm floor; AdaptiveRMSNorm with a zero-initialised
+    to_gamma is the plain norm with unit gain"""
+    torch.manual_seed(0)
+    x = torch.randn(3, 7, 96) * 3
+    m = O.RMSNorm(96)
+    with torch.no_grad():
+        m.g.copy_(1 + 0.3 * torch.randn(96))
+    ref = F.rms_norm(x, (96,), weight=m.g, eps=0.)
+    assert (m(x) - ref).abs().max().item() < 1e-5
+    a = O.AdaptiveRMSNorm(96)
+    assert (a(x, condition=torch.randn(3, 96)) - F.rms_norm(x, (96,), eps=0.)).abs().max().item() < 1e-5
+
+
+def test_hyper_connections_against_the_papers_equations_fp64():
+    """HyperConnections as restated against the dynamic hyper-connection equations of the paper
+    (Zhu et al. 2024, "Hyper-Connections", eqs. for DHC with tanh), written out stream by stream in fp64 with explicit
+    loops -- no einsum, no shared code with the oracle module:
+        Hn_s   = norm(H_s)                                   (RMS norm with gain gamma + 1)
+        B_s    = s_beta  * tanh(Hn_s . W_beta)      + B_s^static
+        Am_s   = s_alpha * tanh(Hn_s . W_alpha[:,0]) + A^static[s, 0]          (width: weights of the branch input)
+        Ar_s,t = s_alpha * tanh(Hn_s . W_alpha[:,1+t]) + A^static[s, 1+t]      (width: stream mixing)
+        h0     = sum_s Am_s H_s                              (branch input)
+        H'_t   = sum_s Ar_s,t H_s + B_t * y                  (depth: y = branch output)"""
+    torch.manual_seed(0)
+    S, D, b, n = 4, 32, 2, 5
+    hc = O.HyperConnections(S, dim=D).double()
+    with torch.no_grad():
+        hc.dynamic_alpha_fn.copy_(torch.randn(D, S + 1) * 0.3)
+        hc.dynamic_beta_fn.copy_(torch.randn(D) * 0.3)
+        hc.dynamic_alpha_scale.fill_(0.7)
+        hc.dynamic_beta_scale.fill_(0.4)
+        hc.static_alpha.add_(torch.randn(S, S + 1) * 0.2)
+        hc.static_beta.add_(torch.randn(S) * 0.2)
+        hc.norm.gamma.copy_(torch.randn(D) * 0.2)
+    H = torch.randn(b * S, n, D, dtype=torch.float64)            # the reference's layout: streams inner in the batch dim
+    y = torch.randn(b, n, D, dtype=torch.float64)
+    bin_o, add = hc(H)
+    out_o = add(y)
+    Wa, wb = hc.dynamic_alpha_fn.detach(), hc.dynamic_beta_fn.detach()
+    sa, sb = float(hc.dynamic_alpha_scale), float(hc.dynamic_beta_scale)
+    A, B, gam = hc.static_alpha.detach(), hc.static_beta.detach(), hc.norm.gamma.detach()
+    for bi in range(b):
+        for ni in range(n):
+            Hs = [H[bi * S + s, ni] for s in range(S)]
+            Hn = [h / h.norm() * D ** 0.5 * (gam + 1) for h in Hs]
+            beta = [sb * torch.tanh(Hn[s] @ wb) + B[s] for s in range(S)]
+            alpha = [[sa * torch.tanh(Hn[s] @ Wa[:, t]) + A[s, t] for t in range(S + 1)] for s in range(S)]
+            h0 = sum(alpha[s][0] * Hs[s] for s in range(S))
+            assert (bin_o[bi, ni] - h0).abs().max().item() < 1e-12
+            for t in range(S):
+                Ht = sum(alpha[s][1 + t] * Hs[s] for s in range(S)) + beta[t] * y[bi, ni]
+                assert (out_o[bi * S + t, ni] - Ht).abs().max().item() < 1e-12
+
+
 def test_init_invariants():
     """at initialisation the zero-init paths make exact statements possible"""
     random.seed(0)
