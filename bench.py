@@ -161,6 +161,8 @@ def main():
     ap.add_argument('--grad-dtype', default='bf16', choices=['fp32', 'bf16'],
                     help='element type of the gradient slabs on the xGMI links (bf16 halves the bytes: 1.45 instead of 2.9 GB per step)')
     ap.add_argument('--bucket-layers', type=int, default=1, help='layer slabs merged per all-reduce')
+    ap.add_argument('--ddp-bisect', default=None, choices=['init', 'nohook', 'nooutside'],
+                    help='diagnosis of the --force-ddp overhead: init = only init_process_group (no wrapper); nohook = wrapper without the slab hook; nooutside = wrapper without the non-backbone all-reduce')
     ap.add_argument('--ddp-defer', action='store_true', help='one gradient all-reduce after the backward pass instead of per-layer slabs overlapped with it (A/B)')
     ap.add_argument('--dump-ops', default=None, help='write the per-shape launch table of the profiled plan replays (name, flops, count, '
                     'average ms, TFLOP/s) to this JSON file')
@@ -175,13 +177,16 @@ def main():
     assert world == args.gpus, f'--gpus {args.gpus} but WORLD_SIZE={world}'
     torch.cuda.set_device(local_rank)
     dev = torch.device('cuda', local_rank)
-    if world > 1 or args.force_ddp:
+    if world > 1 or args.force_ddp or args.ddp_bisect:
         os.environ.setdefault('MASTER_ADDR', '127.0.0.1')
         os.environ.setdefault('MASTER_PORT', '29533')
         os.environ.setdefault('RANK', '0')
         os.environ.setdefault('WORLD_SIZE', '1')
         os.environ.setdefault('HSA_ENABLE_IPC_MODE_LEGACY', '0')
-        dist.init_process_group('nccl', device_id=dev)
+        if os.environ.get('E2K_BENCH_LAZY_PG') == '1':          # (diagnosis: communicator created at the first collective instead of here)
+            dist.init_process_group('nccl')
+        else:
+            dist.init_process_group('nccl', device_id=dev)
 
     dim, depth, heads, B, T = CONFIGS[args.config]
     B = args.batch or B
@@ -191,7 +196,12 @@ def main():
                   cond_drop_prob=0.).to(dev)
     model.train()
     net = DataParallel(model, grad_dtype=torch.bfloat16 if args.grad_dtype == 'bf16' else torch.float32,
-                       bucket_layers=args.bucket_layers, defer=args.ddp_defer) if (world > 1 or args.force_ddp) else model
+                       bucket_layers=args.bucket_layers, defer=args.ddp_defer) if (world > 1 or args.force_ddp or args.ddp_bisect in ('nohook', 'nooutside')) else model
+    if args.ddp_bisect == 'nohook':
+        for bb in net._backbones:
+            bb._grad_sync = None
+    if args.ddp_bisect == 'nooutside':
+        net._outside = []
     torch.manual_seed(1000 + rank)        # different synthetic data per rank (weak scaling: B per GPU fixed)
     mel = torch.randn(B, T, 100, device=dev)
     text = synthetic_text(B, 1000 + rank)

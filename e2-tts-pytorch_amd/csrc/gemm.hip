@@ -189,46 +189,53 @@ constexpr int QSTAGE_ROW = 256 * 4 + 16, QSTAGE_BYTES = 128 * QSTAGE_ROW;
 constexpr int GSTAGE_ROW = 128 * 4 + 16, GSTAGE_BYTES = 128 * GSTAGE_ROW;       // 128 x 128 kernel: the whole tile at once
 
 // read-back half of the staged epilogue: ROWS x COLS fp32 staged at S (row stride COLS * 4 + 16 bytes), C rows m_base + r,
-// columns n0 + ...; lane (tid & 31) owns columns h * 128 + 4 (tid & 31) .. + 3 of row pass * (THREADS / 32) + (tid >> 5)
+// columns n0 + ...  A lane owns 8 consecutive columns of a row (COLS / 8 lanes per row): bf16 results leave as ONE 16-byte
+// store per lane -- the epilogue is bound by the number of store instructions per CU, not by bytes (8-byte stores in
+// whole-line order measured no faster than the direct epilogue, profiles/r03_gemm_epilogue_ab_8byte_stores.json).  The
+// residual rows of all passes are fetched up front (their latency would otherwise be paid once per pass).
 template <bool OUT_F32, int ROWS, int COLS, int THREADS>
 __device__ __forceinline__ void nt_stage_readback(const NTArgs& p, const unsigned char* S, int m_base, int n0, int tid) {
-    constexpr int HN = COLS / 128, RPP = THREADS / 32, ROWB = COLS * 4 + 16;
-    const int c = tid & 31, rsub = tid >> 5;
-    f32x4 bias4[HN];
-    bool colok[HN];
+    constexpr int LPR = COLS / 8, RPP = THREADS / LPR, NP = ROWS / RPP, ROWB = COLS * 4 + 16;
+    const int c = tid % LPR, rsub = tid / LPR;
+    const int n = n0 + 8 * c;
+    if (n >= p.N) return;                                // (N is a multiple of 8 on this path: a chunk is in or out as a whole)
+    f32x4 b0 = {0.f, 0.f, 0.f, 0.f}, b1 = b0;
+    if (p.bias) { b0 = ld<f32x4>(p.bias + n); b1 = ld<f32x4>(p.bias + n + 4); }
+    u32x4 rs[NP];
+    if (p.resid) {
 #pragma unroll
-    for (int h = 0; h < HN; ++h) {
-        const int n = n0 + h * 128 + 4 * c;
-        colok[h] = n < p.N;                              // (N is a multiple of 4 on this path: a chunk is in or out as a whole)
-        bias4[h] = (p.bias && colok[h]) ? ld<f32x4>(p.bias + n) : f32x4{0.f, 0.f, 0.f, 0.f};
+        for (int pass = 0; pass < NP; ++pass) {
+            const int m = min(m_base + pass * RPP + rsub, p.M - 1);
+            rs[pass] = ld<u32x4>(p.resid + (long)m * p.ldr + n);
+        }
     }
-#pragma unroll 2
-    for (int pass = 0; pass < ROWS / RPP; ++pass) {
+#pragma unroll
+    for (int pass = 0; pass < NP; ++pass) {
         const int r = pass * RPP + rsub, m = m_base + r;
         if (m >= p.M) continue;
         const float rm = p.rowmask ? (p.rowmask[m] ? 1.f : 0.f) : 1.f;
-        const float* cs = p.colscale ? p.colscale + (long)(m / p.rows_per_batch) * p.lds : nullptr;
-#pragma unroll
-        for (int h = 0; h < HN; ++h) {
-            if (!colok[h]) continue;
-            const int n = n0 + h * 128 + 4 * c;
-            f32x4 x = ld<f32x4>(S + r * ROWB + (h * 128 + 4 * c) * 4) + bias4[h];
-            if (cs) x *= ld<f32x4>(cs + n);
-            x *= rm;
-            if (p.resid) {
-                float rs[4];
-                unpack4(ld<u32x2>(p.resid + (long)m * p.ldr + n), rs);
-#pragma unroll
-                for (int q = 0; q < 4; ++q) x[q] += rs[q];
-            }
-            if (OUT_F32) {
-                float* cp = (float*)p.C + (long)m * p.ldc + n;
-                if (p.accumulate) x += ld<f32x4>(cp);
-                st<f32x4>(cp, x);
-            } else {
-                float v[4] = {x[0], x[1], x[2], x[3]};
-                st<u32x2>((bf16_t*)p.C + (long)m * p.ldc + n, pack4(v));
-            }
+        f32x4 x0 = ld<f32x4>(S + r * ROWB + c * 32) + b0, x1 = ld<f32x4>(S + r * ROWB + c * 32 + 16) + b1;
+        if (p.colscale) {
+            const float* cs = p.colscale + (long)(m / p.rows_per_batch) * p.lds + n;
+            x0 *= ld<f32x4>(cs);
+            x1 *= ld<f32x4>(cs + 4);
+        }
+        x0 *= rm;
+        x1 *= rm;
+        if (p.resid) {
+            float f[8];
+            unpack8(rs[pass], f);
+            x0 += f32x4{f[0], f[1], f[2], f[3]};
+            x1 += f32x4{f[4], f[5], f[6], f[7]};
+        }
+        if (OUT_F32) {
+            float* cp = (float*)p.C + (long)m * p.ldc + n;
+            if (p.accumulate) { x0 += ld<f32x4>(cp); x1 += ld<f32x4>(cp + 4); }
+            st<f32x4>(cp, x0);
+            st<f32x4>(cp + 4, x1);
+        } else {
+            float v[8] = {x0[0], x0[1], x0[2], x0[3], x1[0], x1[1], x1[2], x1[3]};
+            st<u32x4>((bf16_t*)p.C + (long)m * p.ldc + n, pack8(v));
         }
     }
 }
@@ -568,6 +575,60 @@ __device__ __forceinline__ void nt_epilogue_glu(const NTArgs& p, f32x4 (&au)[NI]
     }
 }
 
+// Inference form of the GEGLU epilogue (H not stored) through LDS: the products of half a tile (128 rows x 128 activation
+// columns, fp32, row stride 528 B) are staged and leave as one 16-byte store per lane in whole-line row segments, like
+// nt_epilogue_staged (the epilogue is bound by the number of store instructions per CU).  Same values as nt_epilogue_glu.
+template <int UNUSED = 0>
+__device__ __forceinline__ void nt_epilogue_glu_staged(const NTArgs& p, f32x4 (&acc)[2][2][4][2], unsigned char* S, int m0, int n0,
+                                                       int tid, int wr, int wc, int l15, int g) {
+    const int F = p.N >> 1;
+    const unsigned seed = p.seed_dev ? *p.seed_dev : p.seed;
+    const int nb = n0 + wc * 32 + 4 * g;
+    f32x4 bu[2], bg[2];
+#pragma unroll
+    for (int j = 0; j < 2; ++j) {
+        bu[j] = bg[j] = f32x4{0.f, 0.f, 0.f, 0.f};
+        if (p.bias) {
+#pragma unroll
+            for (int r = 0; r < 4; ++r) { bu[j][r] = p.bias[nb + j * 16 + r]; bg[j][r] = p.bias[F + nb + j * 16 + r]; }
+        }
+    }
+    const int c = tid & 15, rsub = tid >> 4;              // read-back: 16 lanes x 8 columns per row, 32 rows per pass
+#pragma unroll
+    for (int a = 0; a < 2; ++a) {
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const int row = wr * 64 + i * 16 + l15, m = m0 + a * 128 + row;
+#pragma unroll
+            for (int j = 0; j < 2; ++j) {
+                const int n = nb + j * 16;
+                const f32x4 xu = acc[a][0][i][j] + bu[j], xg = acc[a][1][i][j] + bg[j];
+                float u[4] = {xu[0], xu[1], xu[2], xu[3]}, gt[4] = {xg[0], xg[1], xg[2], xg[3]};
+                const u32x2 hu = pack4(u), hg = pack4(gt);           // (the product is formed from the bf16-rounded pre-activation)
+                unpack4(hu, u);
+                unpack4(hg, gt);
+                f32x4 o;
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    const float ks = p.thresh ? keep_scale(seed, p.stream_id, m, n + r, p.thresh, p.inv_keep) : 1.f;
+                    o[r] = u[r] * gelu_erf_fast(gt[r]) * ks;
+                }
+                st<f32x4>(S + row * GSTAGE_ROW + (wc * 32 + j * 16 + 4 * g) * 4, o);
+            }
+        }
+        __syncthreads();
+#pragma unroll
+        for (int pass = 0; pass < 4; ++pass) {
+            const int r = pass * 32 + rsub, m = m0 + a * 128 + r;
+            if (m >= p.M) continue;
+            const f32x4 x0 = ld<f32x4>(S + r * GSTAGE_ROW + c * 32), x1 = ld<f32x4>(S + r * GSTAGE_ROW + c * 32 + 16);
+            float v[8] = {x0[0], x0[1], x0[2], x0[3], x1[0], x1[1], x1[2], x1[3]};
+            st<u32x4>(p.glu_out + (long)m * p.ldg + n0 + 8 * c, pack8(v));
+        }
+        if (a == 0) __syncthreads();
+    }
+}
+
 // 256 x 256 x 64 tile, EIGHT waves (512 threads, one workgroup per CU, two waves per SIMD), 128 KB of LDS, 8 phases per
 // pair of K tiles (cdna_hip_programming.md "256^2 8-phase template", rebuilt for this kernel's operand layout and
 // epilogue).  Default for shapes that fill the chip with 256 x 256 tiles; on MI355X 790-1011 TFLOP/s on the cfg3 shapes
@@ -769,6 +830,11 @@ __global__ __launch_bounds__(QTHREADS, 1) void gemm_nt_256_kernel(NTArgs p) {
         return;                                               // (the fix-up kernels finish the tile)
     }
     if (GLU) {
+        if (p.staged) {                      // inference form (H not stored), every row of the tile's 128 activation columns exists
+            __syncthreads();
+            nt_epilogue_glu_staged(p, acc, smem, m0, n0, tid, wr, wc, l15, g);
+            return;
+        }
 #pragma unroll
         for (int a = 0; a < 2; ++a) nt_epilogue_glu<4>(p, acc[a][0], acc[a][1], m0 + a * 128 + wr * 64, n0 + wc * 32, l15, g);
         return;
@@ -1328,37 +1394,64 @@ __global__ __launch_bounds__(T2THREADS, 1) void gemm_tn_256_kernel(TNArgs p) {
 // parked at s_waitcnt / barriers 58 % of the time, but halving the MFMAs per barrier costs more than the deeper
 // prefetch recovers.  Removed; see DESIGN.md.)
 
-// sums the fragment-order partial tiles over the splits and adds the total to C.  One workgroup per (tile, fragment group):
-// the thread <-> (n, k) mapping of a fragment is the GEMM kernel's, so its 16-byte loads are contiguous over the lanes
+// sums the fragment-order partial tiles over the splits and adds the total to C.  One workgroup per 16-ROW SLAB of a tile:
+// the fragments that hold those 16 output rows belong to the GEMM waves of one row group -- 2 waves x 4 fragments for the
+// 128 x 128 kernels, 4 waves x 4 fragments for the 256 x 256 kernel -- and this kernel's threads stand in for exactly those
+// waves (same lane <-> (n, k) mapping, so the 16-byte loads of the partials are contiguous over the lanes).  The slab's
+// totals are transposed through LDS and C is read and written in whole rows.  Two earlier forms, both measured on MI355X:
+// a fragment-shaped read-modify-write of C (16 rows x 64 bytes per wave instruction) lost 10-15 % on large outputs with few
+// splits (FeedForward's second weight, qkv); one workgroup per whole tile left 16-64 workgroups on the chip for the small
+// outputs and ran 2-3x slower (profiles/r03_gemm_epilogue_ab_16byte_stores.json, `tn` rows).
+//   BIG  (256 x 256 tiles): grid (tiles, 16 slabs), 256 threads;   otherwise (128 x 128): grid (tiles, 8 slabs), 128 threads
 template <bool BIG>
-__global__ __launch_bounds__(BIG ? 512 : 256) void tn_reduce_frag_kernel(const f32x4* ws, float* C, long ldc, int N, int K, int splits, int tk) {
-    constexpr int NF = BIG ? 32 : 16, T = BIG ? 512 : 256, TS = BIG ? 256 : 128;
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, q = lane & 15, g = lane >> 4;
-    const int tile = blockIdx.x, tiles = gridDim.x, f = blockIdx.y;
-    const int n0 = (tile / tk) * TS, k0 = (tile % tk) * TS;
-    int n, k;
-    if (BIG) {
-        const int wr = wave >> 2, wc = wave & 3, a = f >> 4, b = (f >> 3) & 1, i = (f >> 1) & 3, j = f & 1;
-        n = n0 + a * 128 + wr * 64 + i * 16 + q;
-        k = k0 + b * 128 + wc * 32 + j * 16 + 4 * g;
-    } else {
-        const int wn = wave >> 1, wk = wave & 1, i = f >> 2, j = f & 3;
-        n = n0 + wn * 64 + j * 16 + q;
-        k = k0 + wk * 64 + i * 16 + 4 * g;
-    }
-    if (n >= N || k >= K) return;
-    f32x4 s = {0.f, 0.f, 0.f, 0.f};
-    const f32x4* w = ws + ((long)tile * NF + f) * T + tid;
+__global__ __launch_bounds__(BIG ? 256 : 128) void tn_reduce_frag_kernel(const f32x4* ws, float* C, long ldc, int N, int K, int splits, int tk) {
+    constexpr int NF = BIG ? 32 : 16, T = BIG ? 512 : 256, TS = BIG ? 256 : 128, ROWB = TS * 4 + 16, RT = BIG ? 256 : 128;
+    __shared__ __attribute__((aligned(16))) unsigned char S[16 * ROWB];
+    const int tid = threadIdx.x, lane = tid & 63, wl = tid >> 6, q = lane & 15, g = lane >> 4;
+    const int tile = blockIdx.x, tiles = gridDim.x, slab = blockIdx.y;
     const long stride = (long)tiles * NF * T;
-#pragma unroll 4
-    for (int sp = 0; sp < splits; ++sp) s += w[sp * stride];
-    float* c = C + (long)n * ldc + k;
-    if (k + 3 < K && (ldc & 3) == 0 && (((uintptr_t)C) & 15) == 0) {
-        st<f32x4>(c, ld<f32x4>(c) + s);
-    } else {
+    int n0 = (tile / tk) * TS;
+    const int k0 = (tile % tk) * TS;
 #pragma unroll
-        for (int r = 0; r < 4; ++r)
-            if (k + r < K) c[r] += s[r];
+    for (int ff = 0; ff < 4; ++ff) {
+        int f, gtid, col;
+        if (BIG) {                          // slab = (a*2 + wr)*4 + i: rows a*128 + wr*64 + i*16 + q; waves (wr, wc = wl), fragments (b, j) = ff
+            const int a = slab >> 3, wr = (slab >> 2) & 1, i = slab & 3, b = ff >> 1, j = ff & 1;
+            f = ((a * 2 + b) * 4 + i) * 2 + j;
+            gtid = (wr * 4 + wl) * 64 + lane;
+            col = b * 128 + wl * 32 + j * 16 + 4 * g;
+        } else {                            // slab = wn*4 + j: rows wn*64 + j*16 + q; waves (wn, wk = wl), fragments i = ff
+            const int wn = slab >> 2, jj = slab & 3;
+            f = ff * 4 + jj;
+            gtid = (wn * 2 + wl) * 64 + lane;
+            col = wl * 64 + ff * 16 + 4 * g;
+        }
+        const f32x4* w = ws + ((long)tile * NF + f) * T + gtid;
+        f32x4 s = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll 4
+        for (int sp = 0; sp < splits; ++sp) s += w[sp * stride];
+        st<f32x4>(S + q * ROWB + col * 4, s);
+    }
+    __syncthreads();
+    n0 += BIG ? ((slab >> 3) * 128 + ((slab >> 2) & 1) * 64 + (slab & 3) * 16) : ((slab >> 2) * 64 + (slab & 3) * 16);
+    constexpr int LPR = TS / 4, RPP = RT / LPR;           // lanes per row, rows per pass
+    const int c = tid % LPR, rsub = tid / LPR;
+    const int k = k0 + 4 * c;
+    if (k >= K) return;
+    const bool vec = k + 3 < K && (ldc & 3) == 0 && (((uintptr_t)C) & 15) == 0;
+#pragma unroll
+    for (int pass = 0; pass < 16 / RPP; ++pass) {
+        const int r = pass * RPP + rsub, n = n0 + r;
+        if (n >= N) continue;
+        const f32x4 s = ld<f32x4>(S + r * ROWB + c * 16);
+        float* cp = C + (long)n * ldc + k;
+        if (vec) {
+            st<f32x4>(cp, ld<f32x4>(cp) + s);
+        } else {
+#pragma unroll
+            for (int e = 0; e < 4; ++e)
+                if (k + e < K) cp[e] += s[e];
+        }
     }
 }
 
@@ -1436,11 +1529,11 @@ static int gemm_nt_bf16_impl(const void* A1, int64_t lda1, int K1, const void* A
     p.rowmask = rowmask; p.resid = (const bf16_t*)resid; p.ldr = ldr;
     const int tn = (N + BN - 1) / BN;
     p.probe = flags & (E2K_GEMM_PROBE_NO_LOADS | E2K_GEMM_PROBE_NO_MATH);
-    // C tile through LDS in whole-line row segments (nt_epilogue_staged*) when every epilogue operand allows 4-element accesses
+    // C tile through LDS in whole-line row segments (nt_epilogue_staged*) when every epilogue operand allows 16-byte accesses
     p.staged = !(flags & E2K_GEMM_NO_STAGE) && (K1 % BK) == 0 && (K2 % BK) == 0 && !(flags & E2K_GEMM_NO_GLDS) &&
-               (N & 3) == 0 && (ldc & 3) == 0 && ((uintptr_t)C & 15) == 0 &&
+               (N & 7) == 0 && (ldc & 7) == 0 && ((uintptr_t)C & 15) == 0 &&
                (!bias || ((uintptr_t)bias & 15) == 0) && (!colscale || ((lds & 3) == 0 && ((uintptr_t)colscale & 15) == 0)) &&
-               (!resid || ((ldr & 3) == 0 && ((uintptr_t)resid & 7) == 0));
+               (!resid || ((ldr & 7) == 0 && ((uintptr_t)resid & 15) == 0));
     const bool glds = !(flags & E2K_GEMM_NO_GLDS) && (K1 % BK) == 0 && (K2 % BK) == 0;
     const int t256 = ((M + QBM - 1) / QBM) * ((N + QBN - 1) / QBN);
     // default: shapes whose 256 x 256 tiles fill >= 7/8 of a round of the 256 workgroup slots (measured on MI355X: +10-22 %
@@ -1551,6 +1644,7 @@ static int gemm_nt_geglu_bf16_impl(const void* A, int64_t lda, int K, const void
         else rem = 0;
     }
     hipStream_t st = (hipStream_t)stream;
+    p.staged = !(flags & E2K_GEMM_NO_STAGE) && H == nullptr && (ldo & 7) == 0 && ((uintptr_t)out & 15) == 0;      // F % 128 == 0 already
     hipLaunchKernelGGL((gemm_nt_256_kernel<false, true>), dim3(p.full + rem * p.split), dim3(QTHREADS), 0, st, p);
     E2K_CHECK_LAUNCH();
     if (rem) {
@@ -1626,8 +1720,8 @@ static int gemm_tn_bf16_impl(const void* A, int64_t lda, const void* B, int64_t 
     else hipLaunchKernelGGL(gemm_tn_kernel<false>, grid, block, 0, (hipStream_t)stream, p);
     E2K_CHECK_LAUNCH();
     if (splits > 1) {
-        if (big) hipLaunchKernelGGL(tn_reduce_frag_kernel<true>, dim3(tn * tk, 32), dim3(512), 0, (hipStream_t)stream, (const f32x4*)ws, C, (long)ldc, N, K, splits, tk);
-        else hipLaunchKernelGGL(tn_reduce_frag_kernel<false>, dim3(tn * tk, 16), dim3(256), 0, (hipStream_t)stream, (const f32x4*)ws, C, (long)ldc, N, K, splits, tk);
+        if (big) hipLaunchKernelGGL(tn_reduce_frag_kernel<true>, dim3(tn * tk, 16), dim3(256), 0, (hipStream_t)stream, (const f32x4*)ws, C, (long)ldc, N, K, splits, tk);
+        else hipLaunchKernelGGL(tn_reduce_frag_kernel<false>, dim3(tn * tk, 8), dim3(128), 0, (hipStream_t)stream, (const f32x4*)ws, C, (long)ldc, N, K, splits, tk);
         E2K_CHECK_LAUNCH();
     }
     return 0;

@@ -25,6 +25,7 @@ struct MelArgs {
     const float* wave; long nw; const float* window; const float* fb; const float* twc; const float* tws;
     float* out; int B, frames, hop, n_mels;
     const int* lens; float pad_value;        // ragged batch: valid samples per row (nullptr = every row has nw), fill of the frames past a row's end
+    const int* bands;                        // optional [n_mels][2]: bins [lo, hi) outside of which column m of fb is zero
 };
 
 __global__ __launch_bounds__(256) void melspec_kernel(MelArgs p) {
@@ -86,6 +87,19 @@ __global__ __launch_bounds__(256) void melspec_kernel(MelArgs p) {
         }
     }
     __syncthreads();
+    if (p.bands) {
+        // the htk triangles overlap only their neighbours: a bin feeds at most two bands, band m reads bins [lo, hi) only
+        // (513 x 100 dense = 51 k multiply-adds per frame, of which 1 k are non-zero).  One (band, frame) pair per thread.
+        for (int idx = tid; idx < p.n_mels * FR; idx += 256) {
+            const int m = idx % p.n_mels, fr = idx / p.n_mels, f = f0 + fr;
+            if (f >= p.frames) continue;
+            const int lo = max(0, p.bands[2 * m]), hi = min(NBIN, p.bands[2 * m + 1]);
+            float acc = 0.f;
+            for (int k = lo; k < hi; ++k) acc = fmaf(re[fr][k], p.fb[(long)k * p.n_mels + m], acc);
+            p.out[((long)b * p.n_mels + m) * p.frames + f] = f < nframes ? logf(fmaxf(acc, 1e-5f)) : p.pad_value;
+        }
+        return;
+    }
     if (tid < p.n_mels) {
         float acc[FR];
 #pragma unroll
@@ -106,11 +120,11 @@ __global__ __launch_bounds__(256) void melspec_kernel(MelArgs p) {
 }  // namespace
 
 static int melspec_impl(const float* wave, int64_t nw, const float* window, const float* fb, const float* twc,
-                           const float* tws, float* out, int B, int n_fft, int hop, int n_mels, void* stream) {
+                           const float* tws, float* out, int B, int n_fft, int hop, int n_mels, const int32_t* bands, void* stream) {
     if (B <= 0 || nw <= 0) return 0;
     if (n_fft != NFFT || n_mels > 256 || n_mels <= 0 || hop <= 0 || nw <= NFFT / 2) return E2K_ERR_SHAPE;
     if (!wave || !window || !fb || !twc || !tws || !out) return E2K_ERR_ARG;
-    MelArgs a{wave, (long)nw, window, fb, twc, tws, out, B, (int)(1 + nw / hop), hop, n_mels, nullptr, 0.f};
+    MelArgs a{wave, (long)nw, window, fb, twc, tws, out, B, (int)(1 + nw / hop), hop, n_mels, nullptr, 0.f, bands};
     hipLaunchKernelGGL(melspec_kernel, dim3((a.frames + FR - 1) / FR, B), dim3(256), 0, (hipStream_t)stream, a);
     E2K_CHECK_LAUNCH();
     return 0;
@@ -118,11 +132,11 @@ static int melspec_impl(const float* wave, int64_t nw, const float* window, cons
 
 static int melspec_ragged_impl(const float* wave, int64_t nw, const int32_t* lens, const float* window, const float* fb,
                                   const float* twc, const float* tws, float* out, float pad_value, int B, int n_fft, int hop,
-                                  int n_mels, void* stream) {
+                                  int n_mels, const int32_t* bands, void* stream) {
     if (B <= 0 || nw <= 0) return 0;
     if (n_fft != NFFT || n_mels > 256 || n_mels <= 0 || hop <= 0 || nw <= NFFT / 2) return E2K_ERR_SHAPE;
     if (!wave || !lens || !window || !fb || !twc || !tws || !out) return E2K_ERR_ARG;
-    MelArgs a{wave, (long)nw, window, fb, twc, tws, out, B, (int)(1 + nw / hop), hop, n_mels, lens, pad_value};
+    MelArgs a{wave, (long)nw, window, fb, twc, tws, out, B, (int)(1 + nw / hop), hop, n_mels, lens, pad_value, bands};
     hipLaunchKernelGGL(melspec_kernel, dim3((a.frames + FR - 1) / FR, B), dim3(256), 0, (hipStream_t)stream, a);
     E2K_CHECK_LAUNCH();
     return 0;
@@ -131,12 +145,12 @@ static int melspec_ragged_impl(const float* wave, int64_t nw, const int32_t* len
 // ---- C ABI: every compute entry point goes through e2k::dispatch (plan.h) so that a launch plan can record it
 
 extern "C" int e2k_melspec(const float* wave, int64_t nw, const float* window, const float* fb, const float* twc,
-                           const float* tws, float* out, int B, int n_fft, int hop, int n_mels, void* stream) {
-    return e2k::dispatch("melspec", melspec_impl, wave, nw, window, fb, twc, tws, out, B, n_fft, hop, n_mels, stream);
+                           const float* tws, float* out, int B, int n_fft, int hop, int n_mels, const int32_t* bands, void* stream) {
+    return e2k::dispatch("melspec", melspec_impl, wave, nw, window, fb, twc, tws, out, B, n_fft, hop, n_mels, bands, stream);
 }
 
 extern "C" int e2k_melspec_ragged(const float* wave, int64_t nw, const int32_t* lens, const float* window, const float* fb,
                                   const float* twc, const float* tws, float* out, float pad_value, int B, int n_fft, int hop,
-                                  int n_mels, void* stream) {
-    return e2k::dispatch("melspec_ragged", melspec_ragged_impl, wave, nw, lens, window, fb, twc, tws, out, pad_value, B, n_fft, hop, n_mels, stream);
+                                  int n_mels, const int32_t* bands, void* stream) {
+    return e2k::dispatch("melspec_ragged", melspec_ragged_impl, wave, nw, lens, window, fb, twc, tws, out, pad_value, B, n_fft, hop, n_mels, bands, stream);
 }

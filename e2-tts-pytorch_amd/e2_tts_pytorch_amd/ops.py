@@ -799,6 +799,7 @@ def transpose_f32(src, C):
 # ------------------------------------------------------------------------------------------------ MelSpec
 
 _twiddles = {}
+_mel_bands = {}
 
 
 def melspec(wave, window, fb, n_fft, hop, lens=None, pad_value=0.):
@@ -814,15 +815,26 @@ def melspec(wave, window, fb, n_fft, hop, lens=None, pad_value=0.):
         _twiddles[key] = (ang.cos().float().to(wave.device), ang.sin().float().to(wave.device))
     twc, tws = _twiddles[key]
     n_mels = fb.shape[1]
+    fb = fb.float().contiguous()
+    bkey = (fb.data_ptr(), fb._version, tuple(fb.shape), str(fb.device))
+    bands = _mel_bands.get(bkey)
+    if bands is None:                        # non-zero bin range of every filterbank column (the htk triangles are narrow)
+        nz = (fb != 0).cpu()
+        ks = torch.arange(fb.shape[0])[:, None]
+        lo = torch.where(nz, ks, fb.shape[0]).amin(0)
+        hi = torch.where(nz, ks + 1, 0).amax(0)
+        if len(_mel_bands) > 8:
+            _mel_bands.clear()
+        bands = _mel_bands[bkey] = torch.stack([lo, hi], 1).to(device=fb.device, dtype=torch.int32).contiguous()
     out = torch.empty((B, n_mels, 1 + nw // hop), dtype=f32, device=wave.device)
     if lens is not None:
         assert lens.shape == (B,)
         lens32 = lens.to(device=wave.device, dtype=torch.int32).contiguous()
-        _lib.get().e2k_melspec_ragged(_p(wave), nw, _p(lens32), _p(window.float().contiguous()), _p(fb.float().contiguous()),
-                                      _p(twc), _p(tws), _p(out), float(pad_value), B, n_fft, hop, n_mels, _stream(wave))
+        _lib.get().e2k_melspec_ragged(_p(wave), nw, _p(lens32), _p(window.float().contiguous()), _p(fb),
+                                      _p(twc), _p(tws), _p(out), float(pad_value), B, n_fft, hop, n_mels, _p(bands), _stream(wave))
         return out
-    _lib.get().e2k_melspec(_p(wave), nw, _p(window.float().contiguous()), _p(fb.float().contiguous()), _p(twc), _p(tws),
-                           _p(out), B, n_fft, hop, n_mels, _stream(wave))
+    _lib.get().e2k_melspec(_p(wave), nw, _p(window.float().contiguous()), _p(fb), _p(twc), _p(tws),
+                           _p(out), B, n_fft, hop, n_mels, _p(bands), _stream(wave))
     return out
 
 

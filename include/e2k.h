@@ -211,9 +211,12 @@ int e2k_attn_bwd(const void* dOg, const void* O, const float* gate, const float*
 
 /* ---- MelSpec (e2_tts.py:248-290 -> torchaudio MelSpectrogram(n_fft=1024, hop, power=1, center, htk, norm=None)) ----
  * wave (B, nw) fp32 -> out (B, n_mels, 1 + nw/hop) fp32 = log(clamp(mel, 1e-5)).  window (n_fft) periodic Hann,
- * fb (n_fft/2+1, n_mels) filterbank, twc/tws (n_fft/2): cos/sin(2*pi*k/n_fft).  n_fft must be 1024. */
+ * fb (n_fft/2+1, n_mels) filterbank, twc/tws (n_fft/2): cos/sin(2*pi*k/n_fft).  n_fft must be 1024.
+ * bands (optional, int32 [n_mels][2]): bins [lo, hi) outside of which column m of fb is zero -- the htk triangles of
+ * torchaudio's melscale_fbanks overlap only their neighbours, so the 513 x 100 contraction has ~1 k non-zero terms of
+ * 51 k; NULL = dense contraction. */
 int e2k_melspec(const float* wave, int64_t nw, const float* window, const float* fb, const float* twc,
-                const float* tws, float* out, int B, int n_fft, int hop, int n_mels, void* stream);
+                const float* tws, float* out, int B, int n_fft, int hop, int n_mels, const int32_t* bands, void* stream);
 
 /* Ragged batch (the dataset side): wave (B, nw) holds clips of different length, zero-padded; lens[b]
  * = valid samples of row b (n_fft/2 < lens[b] <= nw).  Row b is transformed exactly as if it were alone (reflection
@@ -222,7 +225,7 @@ int e2k_melspec(const float* wave, int64_t nw, const float* window, const float*
  * (trainer.py:61-82,101-131), in one launch on the device. */
 int e2k_melspec_ragged(const float* wave, int64_t nw, const int32_t* lens, const float* window, const float* fb,
                        const float* twc, const float* tws, float* out, float pad_value, int B, int n_fft, int hop,
-                       int n_mels, void* stream);
+                       int n_mels, const int32_t* bands, void* stream);
 
 /* ---- optimizer side over flat fp32 buffers (reference trainer.py:272-279) ----
  * out[0] += sum x^2 (fp64 accumulation): the global gradient norm of accelerator.clip_grad_norm_ (trainer.py:272-273). */

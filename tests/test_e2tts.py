@@ -33,6 +33,21 @@ def test_melspec(dev):
     got = MelSpec()(wave.to(dev))
     assert got.shape == ref.shape == (2, 100, 22)
     assert (got.cpu() - ref).abs().max().item() < 2e-3      # log-mel, fp32 FFT vs torch.stft
+    # the banded filterbank contraction (each htk triangle reads only its own bins) against the dense one (bands = NULL):
+    # the skipped terms are exact zeros, so only the summation of zeros differs -- same values to the last place
+    from e2_tts_pytorch_amd import ops
+    m = MelSpec().to(dev)
+    w = wave.to(dev).contiguous()
+    fb = m.mel_stft.mel_scale.fb.float().contiguous()
+    win = m.mel_stft.spectrogram.window.float().contiguous()
+    ops.melspec(w, win, fb, 1024, 256)
+    twc, tws = ops._twiddles[(str(w.device), 1024)]
+    dense = torch.empty_like(got)
+    ops.lib().e2k_melspec(ops._p(w), w.shape[1], ops._p(win), ops._p(fb), ops._p(twc), ops._p(tws), ops._p(dense), 2, 1024, 256, 100,
+                          None, ops._stream(w))
+    assert (dense.cpu() - got.cpu()).abs().max().item() < 1e-5
+    bands = next(iter(ops._mel_bands.values())).cpu()
+    assert int((bands[:, 1] - bands[:, 0]).sum()) < 0.05 * 513 * 100 and int((bands[:, 1] - bands[:, 0]).min()) >= 1
 
 
 @pytest.mark.gpu

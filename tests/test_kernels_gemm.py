@@ -169,11 +169,11 @@ def test_gemm_nt_256_tile(dev, monkeypatch, M, N, K1, K2, kw, flags, late):
 
 @pytest.mark.parametrize('M,N,K1,K2,kw', [
     (256, 256, 64, 0, {}),                                        # one whole tile, no epilogue operand
-    (300, 300, 128, 0, dict(bias=1)),                             # ragged rows and columns (N = 300: chunks of 4 in or out as a whole)
-    (520, 260, 192, 64, dict(bias=1, cs=1, rm=1, rs=1)),          # every epilogue operand, dual-K
+    (300, 296, 128, 0, dict(bias=1)),                             # ragged rows and columns (N = 296: chunks of 8 in or out as a whole)
+    (520, 264, 192, 64, dict(bias=1, cs=1, rm=1, rs=1)),          # every epilogue operand, dual-K
     (2304, 256, 512, 0, dict(f32=1, bias=1)),                     # fp32 output
     (700, 520, 320, 0, dict(rs=1)),
-    (256, 258, 64, 0, dict(bias=1)),                              # N not a multiple of 4: the direct epilogue must be chosen
+    (256, 260, 64, 0, dict(bias=1)),                              # N not a multiple of 8: the direct epilogue must be chosen
 ])
 def test_gemm_nt_256_staged_epilogue_matches_direct(dev, M, N, K1, K2, kw):
     """the 256 x 256 kernel writes its C tile through LDS in whole-line row segments (nt_epilogue_staged, the default

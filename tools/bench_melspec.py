@@ -1,5 +1,5 @@
 """MelSpec kernel throughput at the benchmark shape: B = 8 utterances of 261 888 samples (1024 frames each), against its
-algorithmic bytes 4 * nw + 400 * frames per utterance.  -> gpurun_out/r02_melspec.json"""
+algorithmic bytes 4 * nw + 400 * frames per utterance.  -> gpurun_out/r03_melspec.json"""
 import json, sys
 from pathlib import Path
 ROOT = Path(__file__).resolve().parent.parent
@@ -24,4 +24,4 @@ for B in (8, 64):
     res.append(dict(B=B, samples=nw, frames=frames, ms=ms, algorithmic_MB=nbytes / 1e6, GBps=nbytes / ms / 1e6, frac_of_8TBps=nbytes / ms / 1e6 / 8000,
                     mel_frames_per_s=B * frames / ms * 1e3))
     print(res[-1], flush=True)
-json.dump(res, open(ROOT / 'gpurun_out' / 'r02_melspec.json', 'w'), indent=1)
+json.dump(res, open(ROOT / 'gpurun_out' / 'r03_melspec.json', 'w'), indent=1)
