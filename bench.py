@@ -20,6 +20,13 @@ import sys
 import time
 from pathlib import Path
 
+# The step runs on up to five HIP streams (the caller's, the TEXT and WGRAD launch lanes, the gradient-exchange side stream,
+# RCCL's own).  The HIP runtime maps streams onto GPU_MAX_HW_QUEUES hardware queues (default 4); a fifth stream shares a
+# queue with a lane and serialises against it: measured on MI355X, merely creating an RCCL communicator took the cfg3 step
+# from 93.3 to 104.3 ms, and GPU_MAX_HW_QUEUES=8 brought it back to 93.3 (profiles/r03_hw_queues.jsonl).  Must be set
+# before the HIP runtime initialises, i.e. before the first device call of this process.
+os.environ.setdefault('GPU_MAX_HW_QUEUES', '8')
+
 ROOT = Path(__file__).resolve().parent
 for p in (ROOT / 'e2-tts-pytorch_amd', ROOT):
     if str(p) not in sys.path:

@@ -493,6 +493,7 @@ constexpr int RSTAGE = 16384, RKM = 4096;
 template <bool DROP, bool SHARE, int RING>       // RING stages: tiles are issued RING - 1 ahead
 __global__ __launch_bounds__(256, 2) void attn_fwd_ring_kernel(AttnArgs p) {
     __shared__ __attribute__((aligned(16))) unsigned char smem[RING * RSTAGE + RKM + 4 * 256];
+    lds_declare(smem, sizeof(smem));
     unsigned char* const kms = smem + RING * RSTAGE;                 // key mask of this batch row (Npad bytes)
     unsigned long long* const bal = (unsigned long long*)(smem + RING * RSTAGE + RKM);     // [wave][2][16] ballot words
     const int tid = threadIdx.x, lane = tid & 63, wave = uniform_i(tid >> 6);
@@ -849,6 +850,7 @@ __global__ __launch_bounds__(NW * 64, 2) void attn_bwd_dq_kernel(AttnArgs p) {
 template <bool DROP, bool SHARE>
 __global__ __launch_bounds__(256, 3) void attn_bwd_dq_ring_kernel(AttnArgs p) {
     __shared__ __attribute__((aligned(16))) unsigned char smem[2 * RSTAGE + RKM];
+    lds_declare(smem, sizeof(smem));
     unsigned char* const kms = smem + 2 * RSTAGE;
     const int tid = threadIdx.x, lane = tid & 63, wave = uniform_i(tid >> 6);
     const int l15 = lane & 15, g = lane >> 4;
@@ -1177,6 +1179,7 @@ constexpr int DSTAGE = 2 * 8192 + 512;
 template <bool DROP, bool SHARE>
 __global__ __launch_bounds__(256, 3) void attn_bwd_dkv_ring_kernel(AttnArgs p) {
     __shared__ __attribute__((aligned(16))) unsigned char smem[2 * DSTAGE];
+    lds_declare(smem, sizeof(smem));
     const int tid = threadIdx.x, lane = tid & 63, wave = uniform_i(tid >> 6);
     const int l15 = lane & 15, g = lane >> 4;
     const int k0 = blockIdx.x * 64, h = blockIdx.y, b = blockIdx.z;

@@ -368,6 +368,7 @@ __global__ __launch_bounds__(256, 2) void gemm_nt_glds_kernel(NTArgs p) {
     // two K-tile buffers (64 KB); the staged epilogue needs 66 KB (two workgroups per CU still fit the 160 KB)
     __shared__ __attribute__((aligned(16))) unsigned char smem_raw[GSTAGE_BYTES > 4 * BM * BK * 2 ? GSTAGE_BYTES : 4 * BM * BK * 2];
     unsigned char (*smem)[2][BM * BK * 2] = reinterpret_cast<unsigned char (*)[2][BM * BK * 2]>(smem_raw);
+    lds_declare(smem_raw, sizeof(smem_raw));
     const int tid = threadIdx.x, lane = tid & 63, wave = uniform_i(tid >> 6);
     const int wm = wave >> 1, wn = wave & 1;
     const int l15 = lane & 15, g = lane >> 4;
@@ -664,6 +665,7 @@ constexpr int QBM = 256, QBN = 256, QHALF = 128 * BK * 2, QBUF = 4 * QHALF, QTHR
 template <bool OUT_F32, bool GLU = false>
 __global__ __launch_bounds__(QTHREADS, 1) void gemm_nt_256_kernel(NTArgs p) {
     __shared__ __attribute__((aligned(16))) unsigned char smem[(2 * QBUF > QSTAGE_BYTES) ? 2 * QBUF : QSTAGE_BYTES];
+    lds_declare(smem, sizeof(smem));
     const int tid = threadIdx.x, lane = tid & 63, wave = uniform_i(tid >> 6);
     const int wr = wave >> 2, wc = wave & 3;
     const int l15 = lane & 15, g = lane >> 4;
@@ -910,6 +912,10 @@ struct TNArgs {
     float* ws;                   // [splits][N][K] partial tiles when splits > 1
     int M, N, K, splits, chunk;
     float* colsum; int cs_from;  // optional: colsum[n] += sum_m A[m][n] for n >= cs_from (bias gradient of the same dY)
+    // dual-source operands (256 x 256 kernel only): columns n >= N1 of A come from A2 (M, N - N1), columns k >= K1 of B from
+    // B2 (M, K - K1); N1 / K1 are multiples of 256, so a tile lies in one source.  A2 / B2 == nullptr: single source
+    const bf16_t* A2; long lda2; int N1;
+    const bf16_t* B2; long ldb2; int K1;
 };
 
 template <bool USE_TR>
@@ -1044,6 +1050,7 @@ __global__ __launch_bounds__(256) void gemm_tn_kernel(TNArgs p) {
 template <bool CS>       // CS: also accumulate the column sums of A (bias gradient) in the k-tile-0 workgroups
 __global__ __launch_bounds__(256, 2) void gemm_tn_glds_kernel(TNArgs p) {
     __shared__ __attribute__((aligned(16))) unsigned char smem[2][2][TBM * 256];
+    lds_declare(smem, sizeof(smem));
     const int tid = threadIdx.x, lane = tid & 63, wave = uniform_i(tid >> 6);
     const int wn = wave >> 1, wk = wave & 1;
     const int q = lane & 15, g = lane >> 4;
@@ -1169,6 +1176,7 @@ constexpr int T2 = 256, T2HALF = TBM * 256, T2BUF = 4 * T2HALF, T2THREADS = 512;
 template <bool CS>
 __global__ __launch_bounds__(T2THREADS, 1) void gemm_tn_256_kernel(TNArgs p) {
     __shared__ __attribute__((aligned(16))) unsigned char smem[2 * T2BUF];
+    lds_declare(smem, sizeof(smem));
     const int tid = threadIdx.x, lane = tid & 63, wave = uniform_i(tid >> 6);
     const int wr = wave >> 2, wc = wave & 3;
     const int q = lane & 15, g = lane >> 4;
@@ -1179,6 +1187,13 @@ __global__ __launch_bounds__(T2THREADS, 1) void gemm_tn_256_kernel(TNArgs p) {
     const int mbeg = blockIdx.y * p.chunk;
     const int mend = min(p.M, mbeg + p.chunk);
     const int nt = (mend - mbeg) / TBM;                       // reduction steps of this workgroup
+    // operand sources of this tile (dual-source launches: the tile lies in exactly one column block of A and of B)
+    const bool a2 = p.A2 != nullptr && n0 >= p.N1, b2 = p.B2 != nullptr && k0 >= p.K1;        // wave-uniform
+    const bf16_t* const Asrc = a2 ? p.A2 : p.A;
+    const bf16_t* const Bsrc = b2 ? p.B2 : p.B;
+    const long lda = a2 ? p.lda2 : p.lda, ldb = b2 ? p.ldb2 : p.ldb;
+    const int na0 = a2 ? n0 - p.N1 : n0, kb0 = b2 ? k0 - p.K1 : k0;                           // tile origin inside its source
+    const int Na = p.A2 ? (a2 ? p.N - p.N1 : p.N1) : p.N, Kb = p.B2 ? (b2 ? p.K - p.K1 : p.K1) : p.K;   // columns of that source
 
     // staging: a half tile is 16 wave instructions of 4 rows; wave w issues rows (2w + u) * 4 + (lane >> 4), u = 0, 1
     unsigned va[2][2], vb[2][2];
@@ -1188,9 +1203,9 @@ __global__ __launch_bounds__(T2THREADS, 1) void gemm_tn_256_kernel(TNArgs p) {
         for (int u = 0; u < 2; ++u) {
             const int row = (wave * 2 + u) * 4 + (lane >> 4);
             const int c = (lane & 15) ^ (2 * (row & 7));
-            const int cn = min(n0 + h * 128 + c * 8, ((p.N + 7) & ~7) - 8), ck = min(k0 + h * 128 + c * 8, ((p.K + 7) & ~7) - 8);
-            va[h][u] = (unsigned)((((long)(mbeg + row)) * p.lda + cn) * 2);
-            vb[h][u] = (unsigned)((((long)(mbeg + row)) * p.ldb + ck) * 2);
+            const int cn = min(na0 + h * 128 + c * 8, ((Na + 7) & ~7) - 8), ck = min(kb0 + h * 128 + c * 8, ((Kb + 7) & ~7) - 8);
+            va[h][u] = (unsigned)((((long)(mbeg + row)) * lda + cn) * 2);
+            vb[h][u] = (unsigned)((((long)(mbeg + row)) * ldb + ck) * 2);
         }
     // fragment read offsets inside a half tile: row (4g + q/4) of a 16-row slab, chunk (col/8 ^ 2*(row&7)) + (q&3)/2, byte (q&1)*8
     const int r7 = (4 * g + (q >> 2)) & 7;
@@ -1205,14 +1220,14 @@ __global__ __launch_bounds__(T2THREADS, 1) void gemm_tn_256_kernel(TNArgs p) {
     // half-tile slots of a buffer: 0 = Alo, 1 = Ahi, 2 = Blo, 3 = Bhi; steps past the end are simply not staged
     auto stage_a = [&](int step, int h) __attribute__((always_inline)) {
         if (step >= nt) return;
-        const char* sa = (const char*)p.A + (long)step * TBM * p.lda * 2;
+        const char* sa = (const char*)Asrc + (long)step * TBM * lda * 2;
         unsigned char* dst = S0 + (step & 1) * T2BUF + h * T2HALF + wave * 2048;
 #pragma unroll
         for (int u = 0; u < 2; ++u) glds16(sa + va[h][u], dst + u * 1024);
     };
     auto stage_b = [&](int step, int h) __attribute__((always_inline)) {
         if (step >= nt) return;
-        const char* sb = (const char*)p.B + (long)step * TBM * p.ldb * 2;
+        const char* sb = (const char*)Bsrc + (long)step * TBM * ldb * 2;
         unsigned char* dst = S0 + (step & 1) * T2BUF + (2 + h) * T2HALF + wave * 2048;
 #pragma unroll
         for (int u = 0; u < 2; ++u) glds16(sb + vb[h][u], dst + u * 1024);
@@ -1688,11 +1703,21 @@ extern "C" int e2k_colsum_bf16(const void* x, int64_t ldx, float* out, int M, in
 
 static int gemm_tn_bf16_impl(const void* A, int64_t lda, const void* B, int64_t ldb, float* C, int64_t ldc,
                                 int M, int N, int K, int splits, int use_tr, float* ws, float* colsum, int cs_from,
+                                const void* A2, int64_t lda2, int N1, const void* B2, int64_t ldb2, int K1,
                                 void* stream) {
     if (M <= 0 || N <= 0 || K <= 0) return 0;
-    // 16-B loads may run past N / K up to the next multiple of 8: that must still be inside the row
-    if ((lda & 7) || (ldb & 7) || ((N + 7) & ~7) > lda || ((K + 7) & ~7) > ldb) return E2K_ERR_ALIGN;
-    if (((uintptr_t)A | (uintptr_t)B) & 15) return E2K_ERR_ALIGN;
+    if (A2 || B2) {                  // dual-source: 256 x 256 kernel only, block boundaries on tile boundaries
+        if ((M % TBM) != 0 || colsum) return E2K_ERR_SHAPE;
+        if (A2 && (N1 <= 0 || N1 >= N || (N1 % T2) != 0 || (lda2 & 7) || ((uintptr_t)A2 & 15) || ((N - N1 + 7) & ~7) > lda2)) return E2K_ERR_SHAPE;
+        if (B2 && (K1 <= 0 || K1 >= K || (K1 % T2) != 0 || (ldb2 & 7) || ((uintptr_t)B2 & 15) || ((K - K1 + 7) & ~7) > ldb2)) return E2K_ERR_SHAPE;
+        if ((lda & 7) || (ldb & 7) || (((uintptr_t)A | (uintptr_t)B) & 15)) return E2K_ERR_ALIGN;
+        if (((A2 ? N1 : N) + 7 & ~7) > lda || ((B2 ? K1 : K) + 7 & ~7) > ldb) return E2K_ERR_ALIGN;
+        use_tr = 3;
+    } else
+    {   // 16-B loads may run past N / K up to the next multiple of 8: that must still be inside the row
+        if ((lda & 7) || (ldb & 7) || ((N + 7) & ~7) > lda || ((K + 7) & ~7) > ldb) return E2K_ERR_ALIGN;
+        if (((uintptr_t)A | (uintptr_t)B) & 15) return E2K_ERR_ALIGN;
+    }
     const bool big = tn_use_256(M, N, K, use_tr);
     const int tsz = big ? T2 : 128;
     const int tn = (N + tsz - 1) / tsz, tk = (K + tsz - 1) / tsz;
@@ -1704,6 +1729,7 @@ static int gemm_tn_bf16_impl(const void* A, int64_t lda, const void* B, int64_t 
     p.ws = ws;
     p.A = (const bf16_t*)A; p.lda = lda; p.B = (const bf16_t*)B; p.ldb = ldb;
     p.C = C; p.ldc = ldc; p.M = M; p.N = N; p.K = K; p.splits = splits; p.chunk = chunk;
+    p.A2 = (const bf16_t*)A2; p.lda2 = lda2; p.N1 = N1; p.B2 = (const bf16_t*)B2; p.ldb2 = ldb2; p.K1 = K1;
     const bool fast = use_tr && (M % TBM) == 0 && N >= 8 && K >= 8;
     if (colsum && (cs_from < 0 || cs_from >= N || (cs_from & 1))) return E2K_ERR_ARG;
     p.colsum = fast ? colsum : nullptr; p.cs_from = cs_from;
@@ -1747,5 +1773,14 @@ extern "C" int e2k_gemm_nt_geglu_bf16(const void* A, int64_t lda, int K, const v
 extern "C" int e2k_gemm_tn_bf16(const void* A, int64_t lda, const void* B, int64_t ldb, float* C, int64_t ldc,
                                 int M, int N, int K, int splits, int use_tr, float* ws, float* colsum, int cs_from,
                                 void* stream) {
-    return e2k::dispatch("gemm_tn_bf16", gemm_tn_bf16_impl, A, lda, B, ldb, C, ldc, M, N, K, splits, use_tr, ws, colsum, cs_from, stream);
+    return e2k::dispatch("gemm_tn_bf16", gemm_tn_bf16_impl, A, lda, B, ldb, C, ldc, M, N, K, splits, use_tr, ws, colsum, cs_from,
+                         (const void*)nullptr, (int64_t)0, 0, (const void*)nullptr, (int64_t)0, 0, stream);
+}
+
+extern "C" int e2k_gemm_tn_dual_bf16(const void* A1, int64_t lda1, int N1, const void* A2, int64_t lda2, int N2,
+                                     const void* B1, int64_t ldb1, int K1, const void* B2, int64_t ldb2, int K2,
+                                     float* C, int64_t ldc, int M, int splits, float* ws, void* stream) {
+    if ((A2 == nullptr) != (N2 == 0) || (B2 == nullptr) != (K2 == 0) || N2 < 0 || K2 < 0) return E2K_ERR_ARG;
+    return e2k::dispatch("gemm_tn_dual_bf16", gemm_tn_bf16_impl, A1, lda1, B1, ldb1, C, ldc, M, N1 + N2, K1 + K2, splits, 3, ws,
+                         (float*)nullptr, 0, A2, lda2, N1, B2, ldb2, K1, stream);
 }

@@ -1170,6 +1170,22 @@ class Transformer(Module):
                 ops.gemm_tn(a, b, out, hold=hold[0], splits=_WGRAD_LANE_SPLITS, **kw)
         run.wgrad = wgrad
 
+        def wgrad_dual(a1, a2, b1, b2, out):
+            """out += cat(a1, a2)^T cat(b1, b2) as ONE weight-gradient launch (the cross-condition's four blocks, the skip
+            projection's two); shapes the dual-source kernel cannot take fall back to one GEMM per block"""
+            if not (_WGRAD_DUAL and ops.can_gemm_tn_dual(a1.shape[0], a1.shape[1], b1.shape[1])):
+                n1, k1 = a1.shape[1], b1.shape[1]
+                for a, r0 in ((a1, 0), (a2, n1)):
+                    for b_, c0 in ((b1, 0), (b2, k1)):
+                        if a is not None and b_ is not None:
+                            wgrad(a, b_, out[r0:r0 + a.shape[1], c0:c0 + b_.shape[1]])
+                return
+            if not Ln.has(ops.WGRAD):
+                return ops.gemm_tn_dual(a1, a2, b1, b2, out)
+            Ln.fence(Ln.cur, ops.WGRAD)
+            with Ln.lane(ops.WGRAD):
+                ops.gemm_tn_dual(a1, a2, b1, b2, out, hold=hold[0], splits=_WGRAD_LANE_SPLITS)
+
         def entry(ent):
             kind = ent[0]
             if kind == 'hc':
@@ -1201,11 +1217,9 @@ class Transformer(Module):
                 gx, gt = grads['x'].view(-1, D), grads['t'].view(-1, Dt)
                 WT = self._wT(tr.crossT)                       # (D+Dt, rows)
                 gW = G(tr.cross, tr.cross_rows, D + Dt)
-                wgrad(gx, X, gW[:D, :D])
-                wgrad(gx, Tt, gW[:D, D:])
+                # d[text_to_audio; audio_to_text] = cat(d audio, d text)^T cat(audio, text): one launch for the four blocks
+                wgrad_dual(gx, gt if tr.cross_rows > D else None, X, Tt, gW)
                 if tr.cross_rows > D:
-                    wgrad(gt, X, gW[D:, :D])
-                    wgrad(gt, Tt, gW[D:, D:])
                     ngx = ops.gemm_nt(gx, WT[:D], a2=gt, resid=gx)
                     ngt = ops.gemm_nt(gx, WT[D:], a2=gt, resid=gt)
                 else:
@@ -1216,8 +1230,7 @@ class Transformer(Module):
                 _, sr, X, Sk = ent
                 gx = grads['x'].view(-1, D)
                 gW = G(sr.skip, D, 2 * D)
-                wgrad(gx, X, gW[:, :D])
-                wgrad(gx, Sk, gW[:, D:])
+                wgrad_dual(gx, None, X, Sk, gW)                 # d skip_proj = dX^T cat(x, skip)
                 WT = self._wT(sr.skipT)                        # (2D, D)
                 skip_grads.append((gx, WT[D:]))
                 grads['x'] = ops.gemm_nt(gx, WT[:D]).view(Mtok, 4, D)
@@ -1413,6 +1426,8 @@ class _TimeCondFn(torch.autograd.Function):
 # token-dimension splits of the weight-gradient GEMMs on the WGRAD lane (0 = the library's cost model, which assumes the
 # GEMM has the chip to itself; on the lane it runs next to the main chain)
 _WGRAD_LANE_SPLITS = int(_os.environ.get('E2K_WGRAD_SPLITS', '0'))
+# dual-source weight-gradient launches for the cross-condition / skip projections (E2K_WGRAD_DUAL=0: one GEMM per block, A/B)
+_WGRAD_DUAL = _os.environ.get('E2K_WGRAD_DUAL', '1') != '0'
 
 _VIEW_OPS = {'view', '_unsafe_view', 'as_strided', 'slice', 'select', 'expand', 't', 'transpose', 'permute', 'unsqueeze', 'squeeze',
              'detach', 'alias', '_reshape_alias', 'reshape', 'split', 'split_with_sizes', 'unbind', 'narrow', 'lift_fresh', 'unfold',

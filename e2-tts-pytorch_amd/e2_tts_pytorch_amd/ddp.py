@@ -21,6 +21,12 @@ Two ways in:
 `grad_dtype=torch.bfloat16` halves the bytes on the links (2.9 GB -> 1.45 GB per dim-1024 / depth-24 step): a slab is
 pre-divided by the world size in fp32, rounded to bf16, summed by RCCL in bf16 and added back into the fp32 buffer.
 `bucket_layers=k` merges k consecutive layer slabs into one collective.
+
+Hardware queues: the step runs on the caller's stream, the backbone's two launch lanes, this module's side stream and
+RCCL's own streams.  The HIP runtime maps streams onto GPU_MAX_HW_QUEUES hardware queues (default 4); with a communicator
+alive the fifth stream shares a queue with a launch lane and serialises against it (MI355X, cfg3: 93.3 -> 104.3 ms per
+step from creating the communicator alone; 93.3 again with GPU_MAX_HW_QUEUES=8, profiles/r03_hw_queues.jsonl).  Set
+GPU_MAX_HW_QUEUES=8 in the environment before the process makes its first device call (bench.py does).
 """
 from __future__ import annotations
 
@@ -116,6 +122,14 @@ class _GradSync:
             self._pending = (s, e, k)
 
 
+def _warn_hw_queues():
+    import os
+    import warnings
+    if torch.cuda.is_available() and int(os.environ.get('GPU_MAX_HW_QUEUES', '4')) < 6:
+        warnings.warn('GPU_MAX_HW_QUEUES is below 6: the launch lanes, the gradient-exchange stream and RCCL will share hardware '
+                      'queues and serialise (measured +11 ms per cfg3 step); export GPU_MAX_HW_QUEUES=8 before the first device call')
+
+
 def _flat_params(bb):
     return [p for p, _ in bb._layout.slots]
 
@@ -133,6 +147,7 @@ class DataParallel(nn.Module):
                  grad_dtype: torch.dtype = torch.float32, bucket_layers: int = 1, defer: bool = False):
         super().__init__()
         assert dist.is_initialized(), 'torch.distributed must be initialised (backend "nccl" is RCCL on ROCm)'
+        _warn_hw_queues()
         self.module = module
         self.group = process_group
         self.world = dist.get_world_size(process_group)
@@ -202,6 +217,7 @@ def enable_overlap_under_ddp(module: nn.Module, process_group=None, broadcast_fr
     slab hook instead (overlapped with the backbone's backward on a side stream); the remaining parameters keep going
     through stock DDP's buckets.  Returns the hook object (`.calls`, `.bytes` for inspection)."""
     assert dist.is_initialized()
+    _warn_hw_queues()
     backbones = [(name, m) for name, m in module.named_modules() if isinstance(m, Transformer)]
     sync = _GradSync(process_group, grad_dtype, bucket_layers)
     ignore = list(getattr(module, '_ddp_params_and_buffers_to_ignore', []))

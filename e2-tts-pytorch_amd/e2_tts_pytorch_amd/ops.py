@@ -340,6 +340,34 @@ def gemm_tn(a, b, out, *, splits=0, use_tr=True, colsum=None, colsum_from=0, hol
     return out
 
 
+def can_gemm_tn_dual(M, N1, K1):
+    """shapes e2k_gemm_tn_dual_bf16 takes: block boundaries on 256-column tile boundaries, 64-row reduction steps"""
+    return M % 64 == 0 and N1 % 256 == 0 and K1 % 256 == 0
+
+
+def gemm_tn_dual(a1, a2, b1, b2, out, *, splits=0, hold=None):
+    """out[N1+N2, K1+K2] += cat(a1, a2, 1).T @ cat(b1, b2, 1) in one launch, neither concatenation materialised
+    (a2 / b2 may be None).  fp32 out, bf16 operands."""
+    _chk(a1, a2, b1, b2, out)
+    M, lda1 = _rows(a1)
+    N1, K1 = a1.shape[1], b1.shape[1]
+    _, ldb1 = _rows(b1)
+    N2 = a2.shape[1] if a2 is not None else 0
+    K2 = b2.shape[1] if b2 is not None else 0
+    lda2 = _rows(a2)[1] if a2 is not None else 0
+    ldb2 = _rows(b2)[1] if b2 is not None else 0
+    assert out.dtype == f32 and out.shape == (N1 + N2, K1 + K2) and out.stride(1) == 1
+    lib = _lib.get()
+    nws = lib.e2k_query_gemm_tn_ws_floats(M, N1 + N2, K1 + K2, int(splits), 3)
+    ws = torch.empty((nws,), dtype=f32, device=a1.device) if nws > 0 else None
+    _note(2.0 * M * (N1 + N2) * (K1 + K2))
+    lib.e2k_gemm_tn_dual_bf16(_p(a1), lda1, N1, _p(a2), lda2, N2, _p(b1), ldb1, K1, _p(b2), ldb2, K2, _p(out), out.stride(0),
+                              M, int(splits), _p(ws), _stream(a1))
+    if hold is not None:
+        hold.append((a1, a2, b1, b2, ws))
+    return out
+
+
 # ------------------------------------------------------------------------------------------------ hyper-connections
 
 HC_PARAM_NAMES = ('static_beta', 'static_alpha', 'dynamic_alpha_fn', 'dynamic_alpha_scale', 'dynamic_beta_fn',

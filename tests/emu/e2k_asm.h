@@ -1,5 +1,7 @@
 // TEST INFRASTRUCTURE: host model of csrc/e2k_asm.h (see tests/emu/hip/hip_runtime.h).
 #pragma once
+#include <cstdio>
+#include <cstdlib>
 #include <hip/hip_runtime.h>
 
 namespace e2k {
@@ -69,9 +71,21 @@ inline void wave_sync() { (void)__shfl_xor(0, 1); }       // fibers of a wave ru
 template <int P> inline void set_prio() {}
 inline void sched_fence() {}
 
+// the static LDS array the calling kernel's LDS-DMA copies must land in (set by lds_declare at kernel entry; a block's
+// fibers all run on one host thread, and so do its `static thread_local` __shared__ arrays)
+inline thread_local const char* g_lds_lo = nullptr;
+inline thread_local const char* g_lds_hi = nullptr;
+inline void lds_declare(const void* base, unsigned bytes) { g_lds_lo = (const char*)base; g_lds_hi = g_lds_lo + bytes; }
+inline void lds_check(const void* dst, int n) {
+    if (g_lds_lo == nullptr || (const char*)dst < g_lds_lo || (const char*)dst + n > g_lds_hi) {
+        fprintf(stderr, "emu: global_load_lds destination %p (+%d) outside the kernel's declared LDS array [%p, %p)\n", dst, n, (const void*)g_lds_lo, (const void*)g_lds_hi);
+        abort();
+    }
+}
 // host model of global_load_lds_dwordx4: lane l copies its 16 bytes to (wave-uniform) lds_base + 16*l
 inline void glds16(const void* gsrc, void* lds_base) {
     void* dst = (char*)lds_base + 16 * emu::lane_id();
+    lds_check(dst, 16);
     if (emu::g_glds_late) {
         emu::PendingCopy c;
         memcpy(c.data, gsrc, 16);
@@ -85,6 +99,7 @@ inline void glds16(const void* gsrc, void* lds_base) {
 // global_load_lds_dword: lane l copies 4 bytes to lds_base + 4*l
 inline void glds4(const void* gsrc, void* lds_base) {
     void* dst = (char*)lds_base + 4 * emu::lane_id();
+    lds_check(dst, 4);
     if (emu::g_glds_late) {
         emu::PendingCopy c;
         memcpy(c.data, gsrc, 4);

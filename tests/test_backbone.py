@@ -484,3 +484,41 @@ def test_rmsnorm_unit_offset_checkpoints_are_converted_on_load():
     with pytest.warns(UserWarning, match='unit-offset'):
         m2.load_state_dict(mo, strict=True)
     assert all(torch.allclose(m2.state_dict()[k], msd[k], atol=1e-6) for k in msd if k.endswith('.g'))
+
+
+def test_dual_source_weight_gradients_in_the_backbone(dev):
+    """the cross-condition's (D + Dt, D + Dt) and the skip projection's (D, 2D) weight gradients as ONE dual-source launch
+    each (e2k_gemm_tn_dual_bf16) against one GEMM per block: same gradients (summation order over the token splits
+    differs), and the recorded backward holds the dual calls"""
+    from e2_tts_pytorch_amd import Transformer, backbone as bbm
+    random.seed(0)
+    torch.manual_seed(0)
+    dim, depth, B, T = 256, 2, 2, 16            # (T + 32) * 4 * B = 384 rows of the 4-stream tensors: a multiple of 64
+    mod = Transformer(dim=dim, depth=depth, heads=dim // 64, dropout=0., max_seq_len=T)
+    randomize(mod)
+    mod = mod.to(dev)
+    x0, t0, txt0 = torch.randn(B, T, dim), torch.rand(B), torch.randn(B, T, dim // 2)
+    R = torch.randn(B, T, dim).to(dev)
+
+    def grads():
+        mod.zero_grad(set_to_none=True)
+        mod._drop_plans()
+        for _ in range(3):                      # eager, recording, replay
+            mod.zero_grad(set_to_none=True)
+            out = mod(x0.to(dev), times=t0.to(dev), text_embed=txt0.to(dev))
+            (out * R).sum().backward()
+        st = [v for v in mod._plans.values() if not isinstance(v, str) and v.bwd]
+        return {n: p.grad.detach().cpu().clone() for n, p in mod.named_parameters() if p.grad is not None}, ops_names(st[0].bwd)
+
+    old = bbm._WGRAD_DUAL
+    try:
+        bbm._WGRAD_DUAL = True
+        g1, names1 = grads()
+        bbm._WGRAD_DUAL = False
+        g0, names0 = grads()
+    finally:
+        bbm._WGRAD_DUAL = old
+    assert names1.count('gemm_tn_dual_bf16') == depth + depth // 2 and 'gemm_tn_dual_bf16' not in names0
+    assert names0.count('gemm_tn_bf16') - names1.count('gemm_tn_bf16') == (4 + 2) * 1 + 2 * 1          # layer 0: 4 cross blocks, layer 1: 2 (no audio_to_text) + 2 skip blocks
+    for n in g0:          # (everything else is computed by the same calls; fp32 atomics in some reductions make the order free)
+        assert rel2(g1[n], g0[n]) < 1e-5 or float(g0[n].norm()) < 1e-7, n

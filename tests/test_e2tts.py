@@ -421,7 +421,7 @@ def test_reference_golden_sample_duration(dev):
     model = fill_params(E2TTS(transformer=dict(**c['kw']), use_vocos=False, cond_drop_prob=0.2), c['weight_seed']).to(dev).eval()
     out = model.sample(c['cond'].to(dev), text=c['text'], lens=c['lens'].to(dev), duration=c['duration'].to(dev), steps=c['steps'],
                        cfg_strength=c['cfg_strength'], _y0=c['y0'].to(dev))
-    assert out.shape == c['out'].shape and rel2(out, c['out']) < 2e-2, rel2(out, c['out'])
+    assert out.shape == c['out'].shape and rel2(out, c['out']) < 1e-2, rel2(out, c['out'])      # north-star tolerance (bf16)
     c = gold['duration']
     dp = fill_params(DurationPredictor(transformer=dict(**c['kw'])), c['weight_seed']).to(dev)
     loss = dp(c['mel'].to(dev), text=c['text'], lens=c['lens'].to(dev), _rand_frac_index=c['rand_frac_index'].to(dev))
@@ -460,4 +460,4 @@ def test_reference_golden_sample_front_end(dev):
     y0 = torch.randn(c['out'].shape)
     out = m.sample(c['wave'].to(dev), text=c['text'], lens=c['lens'].to(dev), steps=c['steps'], cfg_strength=c['cfg_strength'],
                    max_duration=c['max_duration'], cfg_null_model=null, _y0=y0.to(dev))
-    assert out.shape == c['out'].shape and rel2(out, c['out']) < 2e-2, rel2(out, c['out'])
+    assert out.shape == c['out'].shape and rel2(out, c['out']) < 1e-2, rel2(out, c['out'])      # north-star tolerance (bf16)

@@ -163,6 +163,36 @@ def test_cfg3_dims_depth24(init, B):
     _check_grads(rec, init, (0.03, 0.15))
 
 
+def test_cfg2_batch8():
+    """cfg2 as BASELINE.json states it: dim 512 / depth 8, B = 8, T = 1024, synthetic mel + random text, one forward +
+    backward against the CPU oracle (reference initialisation)"""
+    import string
+    rng = random.Random(5)
+    text = [''.join(rng.choice(string.ascii_lowercase + ' ') for _ in range(rng.randint(20, 120))) for _ in range(8)]
+    rec = _train_step_parity('cfg2', dict(dim=512, depth=8, dropout=0.), 8, 1024, text, 'reference_init')
+    _check_grads(rec, 'reference_init', (0.02, 0.05))
+
+
+def test_cfg5_sample_at_cfg3_dims():
+    """sample() with the transformer of the headline config (dim 1024, depth 24, 16 heads): B = 2, prompt of 5 frames, 384
+    target frames, 5 midpoint steps (8 function evaluations x (cond + null) = 16 forwards of the depth-24 backbone, no-grad
+    plans, fused GEGLU epilogue) against the CPU oracle; reference initialisation"""
+    torch.set_num_threads(min(32, os.cpu_count() or 1))
+    kw = dict(dim=1024, depth=24, heads=16, dropout=0.)
+    ref, model = _pair(kw, 'reference_init', seed=3)
+    B, Tp, dur, steps = 2, 5, 384, 5
+    cond = torch.randn(B, Tp, 100)
+    y0 = torch.randn(B, dur, 100)
+    text = ['Hi there', 'A somewhat longer line of text to speak']
+    s_r = ref.sample(cond, text=text, duration=dur, steps=steps, cfg_strength=1., _y0=y0)
+    s = model.sample(cond.cuda(), text=text, duration=dur, steps=steps, cfg_strength=1., _y0=y0.cuda())
+    e = rel2(s, s_r)
+    _report('cfg5_sample_cfg3_dims_reference_init', dict(case='sample() at cfg3 dims', kw=kw, B=B, prompt=Tp, duration=dur, steps=steps,
+                                                         sampled_mel_rel_l2=e))
+    print('sampled mel rel-L2 at cfg3 dims', e)
+    assert s.shape == s_r.shape == (B, dur, 100) and e < 1e-2, e
+
+
 @pytest.mark.parametrize('init', ['reference_init', 'randomized'])
 def test_cfg5_shape_sample_32_steps(init):
     torch.set_num_threads(min(32, os.cpu_count() or 1))

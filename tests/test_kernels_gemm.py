@@ -420,3 +420,35 @@ def test_gemm_nt_geglu_edge_shapes(dev, M):
     assert torch.equal(H.cpu(), H2.cpu())
     assert (act.cpu() != act2.cpu()).float().mean().item() < 2e-2 and rel(act, act2) < 8e-3
     assert H.shape == (M, 2 * F) and act.shape == (M, F)
+
+
+@pytest.mark.parametrize('M,N1,N2,K1,K2,splits', [
+    (256, 256, 0, 256, 0, 0),            # single source through the dual entry point
+    (512, 256, 128, 256, 264, 2),        # both operands split; ragged second blocks; two token splits
+    (320, 512, 0, 256, 256, 0),          # the skip projection's form: one dY, cat(x, skip)
+    (640, 256, 256, 512, 0, 3),          # A split only
+])
+def test_gemm_tn_dual_source(dev, M, N1, N2, K1, K2, splits):
+    """C[N1+N2, K1+K2] += cat(A1, A2)^T cat(B1, B2) in one launch of the 256 x 256 weight-gradient kernel
+    (e2k_gemm_tn_dual_bf16: the cross-condition's four gradient blocks / the skip projection's two, neither concatenation
+    materialised) against the block-by-block single-source GEMMs and the fp32 product, accumulated onto a non-zero C"""
+    from e2_tts_pytorch_amd import ops
+    torch.manual_seed(M + N1 + K2)
+    d = lambda t: None if t is None else t.to(dev)
+    a1, b1 = torch.randn(M, N1).to(bf16), torch.randn(M, K1).to(bf16)
+    a2 = torch.randn(M, N2).to(bf16) if N2 else None
+    b2 = torch.randn(M, K2).to(bf16) if K2 else None
+    c0 = torch.randn(N1 + N2, K1 + K2)
+    assert ops.can_gemm_tn_dual(M, N1, K1)
+    out = d(c0.clone())
+    ops.gemm_tn_dual(d(a1), d(a2), d(b1), d(b2), out, splits=splits)
+    A = torch.cat([a1] + ([a2] if N2 else []), 1).float()
+    Bm = torch.cat([b1] + ([b2] if K2 else []), 1).float()
+    ref = c0 + A.T @ Bm
+    assert rel(out, ref) < 2e-3
+    blk = d(c0.clone())
+    for a, r0 in ((a1, 0), (a2, N1)):
+        for b_, k0 in ((b1, 0), (b2, K1)):
+            if a is not None and b_ is not None:
+                ops.gemm_tn(d(a), d(b_), blk[r0:r0 + a.shape[1], k0:k0 + b_.shape[1]], use_tr=3)
+    assert rel(out, blk) < 1e-5

@@ -49,41 +49,23 @@ int e2k_query_gemm_nt_ws_bytes(void);
 #define E2K_GEMM_PROBE_NO_MATH 8  /* flags: bottleneck probe, K loop without its LDS reads + MFMAs (WRONG results) */
 #define E2K_GEMM_T256 128        /* flags: 256 x 256 x 64 tile, 8-wave 8-phase kernel for EVERY shape (default: only shapes whose 256 x 256 tiles fill >= 7/8 of a round of the 256 workgroup slots) */
 #define E2K_GEMM_NO_T256 256     /* flags: never use the 256 x 256 kernel (A/B) */
-#define E2K_GEMM_NO_STAGE 64     /* flags: 256 x 256 kernel stores its C tile straight from the accumulator registers (16 rows x 32 bytes per wave instruction) instead of through LDS in whole-line row segments (A/B) */
 #define E2K_GEMM_NO_SPLIT 16     /* flags: never split remainder tiles over K (A/B) */
 #define E2K_GEMM_TEST_SLOTS8 32  /* flags: pretend the chip holds 8 workgroups (lets small shapes exercise the remainder split in tests) */
 
 /* C[N,K] += A[M,N]^T . B[M,K]  (weight gradients; C fp32, A = dY, B = X, bf16).  The token dimension M is
  * split over `splits` workgroups per tile (0 = choose); partial tiles go to `ws` and are combined by a reduce kernel.
- * use_tr: 0 = the general kernel with plain 16-bit LDS gathers; 1 = the library chooses per shape between the 128 x 128
- * and the 256 x 256 kernel (both read fragments with ds_read_b64_tr_b16); 2 = always 128 x 128; 3 = 256 x 256 wherever
- * it can run (M a multiple of 64).  Same results up to summation order.
+ * use_tr = 1 reads MFMA fragments with ds_read_b64_tr_b16, 0 = plain 16-bit LDS gathers (same results).
  * colsum (optional, fp32 [N]): colsum[n] += sum_m A[m][n] for n >= cs_from (even) -- the bias gradient of the same
  * Linear (e.g. FeedForward proj bias, e2_tts.py:937), computed in the same pass over dY by one extra MFMA per 16
  * columns with an all-ones operand. */
 int e2k_gemm_tn_bf16(const void* A, int64_t lda, const void* B, int64_t ldb, float* C, int64_t ldc,
                      int M, int N, int K, int splits, int use_tr, float* ws, float* colsum, int cs_from, void* stream);
-/* The same weight gradient with column-split operands, in ONE launch of the 256 x 256 kernel:
- *   C[N1+N2, K1+K2] += [A1 | A2]^T . [B1 | B2]        (A2 / B2 may be NULL with N2 / K2 = 0)
- * TextAudioCrossCondition's two Linears both read cat(audio, text) and their gradients come from (d audio, d text): the
- * four blocks of the (D + Dt, D + Dt) weight gradient are one product of the concatenations (e2_tts.py:494-513), and the
- * skip projection's (D, 2D) gradient is dX^T . [x | skip] (e2_tts.py:895-896) -- neither concatenation is materialised.
- * N1 and K1 multiples of 256 (a tile lies in one source), M a multiple of 64; ws = e2k_query_gemm_tn_ws_floats(M, N1+N2,
- * K1+K2, splits, 3) floats. */
-int e2k_gemm_tn_dual_bf16(const void* A1, int64_t lda1, int N1, const void* A2, int64_t lda2, int N2,
-                          const void* B1, int64_t ldb1, int K1, const void* B2, int64_t ldb2, int K2,
-                          float* C, int64_t ldc, int M, int splits, float* ws, void* stream);
-/* upper bound on the token-dimension splits the call above uses for (M, N, K, splits), whichever kernel it selects
- * (use_tr = 1 means "the library chooses per shape", not "transposing reads"); when it is > 1 the caller passes
- * ws = scratch of e2k_query_gemm_tn_ws_floats(...) floats (partial tiles are stored there and combined afterwards).  The
- * exact count for a given use_tr mode: e2k_query_gemm_tn_splits_mode. */
+/* number of token-dimension splits the call above will use for (M, N, K, splits); when it is > 1 the caller passes
+ * ws = scratch of splits*N*K floats (partial tiles are stored there and combined by a second small kernel). */
 int e2k_query_gemm_tn_splits(int M, int N, int K, int splits);
 /* the same for a given use_tr mode: 1 = the library chooses the kernel per shape, 2 = always the 128 x 128 x 64 kernel,
  * 3 = the 256 x 256 x 64 8-phase kernel wherever it can run (M a multiple of 64) */
 int e2k_query_gemm_tn_splits_mode(int M, int N, int K, int splits, int use_tr);
-/* floats of ws the call needs for (M, N, K, splits, use_tr): the partial tiles of the splits are stored in the MFMA fragment
- * order of the selected kernel (contiguous 1-KB runs per wave store), padded to whole tiles; 0 = nothing is split */
-int64_t e2k_query_gemm_tn_ws_floats(int M, int N, int K, int splits, int use_tr);
 
 /* ---- hyper-connections (hyper_connections.HyperConnections; reference call sites e2_tts.py:870-882,900-939) ----
  * Streams are stored token-major: X[token][4][D] bf16.  coef: per-token fp32 record (e2k_query_hc_coef_width()
@@ -136,21 +118,6 @@ int e2k_geglu_fwd(const void* H, int64_t ldh, void* out, int M, int F, float p_d
 int e2k_geglu_bwd(const void* dout, const void* H, int64_t ldh, void* dH, int M, int F, float p_drop,
                   uint32_t seed, const uint32_t* seed_dev, uint32_t stream_id, void* stream);
 
-/* FeedForward's first Linear with the GEGLU (+ Dropout) as the GEMM's epilogue (x_transformers.FeedForward(glu=True),
- * e2_tts.py:646,692):  h = A (M,K) . W1 (2F,K)^T + bias;  out (M,F) = h[:, :F] * gelu(h[:, F:]) * keep.
- * One launch instead of e2k_gemm_nt_bf16 + e2k_geglu_fwd: h is rounded to bf16 before the product, so out is
- * e2k_geglu_fwd of the stored H up to the erf approximation of the epilogue (|error| <= 1.5e-7, below bf16 rounding), and H
- * is bit-identical to e2k_gemm_nt_bf16's wherever both sum K in one pass;
- * h is stored to H (M, 2F; what e2k_geglu_bwd reads) unless H is NULL (inference).  The 256 x 256 kernel stages the
- * value rows and the gate rows of W1 as its two B half tiles, which needs F % 128 == 0 and K % 64 == 0:
- * e2k_query_gemm_nt_geglu returns 1 for shapes it takes, other shapes are refused with E2K_ERR_SHAPE.
- * flags / ws / ws_bytes as e2k_gemm_nt_bf16 (remainder split); dropout arguments as e2k_geglu_fwd. */
-int e2k_gemm_nt_geglu_bf16(const void* A, int64_t lda, int K, const void* W1, int64_t ldb, const float* bias,
-                           void* H, int64_t ldh, void* out, int64_t ldo, int M, int F, float p_drop, uint32_t seed,
-                           const uint32_t* seed_dev, uint32_t stream_id, int flags, float* ws, int64_t ws_bytes,
-                           void* stream);
-int e2k_query_gemm_nt_geglu(int M, int F, int K);
-
 /* out[n] += sum_m x[m][n]   (bias gradients; x bf16 (M,N), out fp32) */
 int e2k_colsum_bf16(const void* x, int64_t ldx, float* out, int M, int N, void* stream);
 
@@ -165,13 +132,9 @@ int e2k_cast_transpose_batch(const float* flat, void* flatT, const int64_t* desc
  *   pre = conv1d(mask * x) + bias ;  y = mask * silu(pre).   ks in {3,7,15,31}, C multiple of 64. */
 int e2k_dwconv_fwd(const void* x, const uint8_t* mask, const float* w, const float* bias, void* pre,
                    void* y, int B, int N, int C, int ks, void* stream);
-/* dx, and dw / dbias ACCUMULATED (fp32).  ws: scratch of e2k_query_dwconv_bwd_ws_floats(B, N, C, ks) floats for the
- * per-workgroup (dw, dbias) partials (NULL: global fp32 atomics instead, ~1.3x slower at the cfg3 shapes).
- * split: bit 0 must be 0 (round 1's two-kernel form is gone); bits 1..: tuning / ablation (2 = no gradient flush,
- * 4 = loads and staging only -- WRONG results; >> 8: workgroups per channel tile and batch) */
-int e2k_query_dwconv_bwd_ws_floats(int B, int N, int C, int ks);
+/* dx, and dw / dbias ACCUMULATED (fp32).  split = 0: one fused kernel; 1: a dx kernel and a (dw, dbias) kernel (A/B) */
 int e2k_dwconv_bwd(const void* dy, const void* pre, const void* x, const uint8_t* mask, const float* w,
-                   void* dx, float* dw, float* dbias, float* ws, int B, int N, int C, int ks, int split, void* stream);
+                   void* dx, float* dw, float* dbias, int B, int N, int C, int ks, int split, void* stream);
 
 /* ---- attention (x_transformers.Attention, call sites e2_tts.py:875,911; dim_head = 64) ----
  * qkvg (B*N, ldq) bf16 = fused projection output, columns [q (H*64) | k | v | head-gate logits (H) | value-residual
@@ -201,17 +164,14 @@ int e2k_attn_fwd(const void* Q, const void* K, const void* VT, const uint8_t* km
 #define E2K_ATTN_PROBE_NO_PV 8       /* no V LDS reads + second MFMAs */
 #define E2K_ATTN_PROBE_NO_LOADS 16   /* no global K / V tile loads after the first */
 #define E2K_ATTN_PROBE_NO_BARRIER 32 /* no workgroup barriers */
-#define E2K_ATTN_NO_RING 128         /* (both calls) the register-staged kernels instead of the LDS-DMA ring kernels (A/B; same results) */
+#define E2K_ATTN_RING3 256           /* (forward) three / four LDS-DMA ring stages instead of two (A/B: lower occupancy, slower) */
+#define E2K_ATTN_RING4 512
+#define E2K_ATTN_NO_RING 128         /* (forward) register-staged K / V tiles instead of the LDS-DMA ring (A/B; same results) */
+#define E2K_ATTN_WG128 64            /* (both calls) 128 query rows / keys per workgroup instead of 64 (A/B; same results, not faster on MI355X) */
 /* dropbits (optional, both calls; NULL = every kernel re-derives the dropout mask from the counter hash): scratch of
  * e2k_query_attn_dropbits_bytes(B, H, N) bytes in which the forward leaves its keep decisions as 64-bit wave ballot words
  * and from which the backward kernels read them back.  Same mask either way (bit-identical results). */
 int e2k_query_attn_dropbits_bytes(int B, int H, int N);
-/* Which transposed copies the backward needs: bit 0 = KT (the register-staged dQ kernel: flag E2K_ATTN_NO_RING, or
- * Npad > 4096), bit 1 = QT and dOT (the register-staged dK,dV kernel: that flag).  The default
- * (LDS-DMA ring) kernels read K^T / Q^T / dO^T out of the row-major tiles with ds_read_b64_tr_b16: e2k_qkv_post_fwd
- * then takes QT = KT = NULL and e2k_attn_bwd dOT = NULL (17 MB less written per transposed copy at the cfg3 shape). */
-int e2k_query_attn_bwd_transposes(int Npad, int flags);
-
 /* backward: dOg (B*N, H*64) -> dQ, dK, dV (B,H,N,64), dgate_pre (B,H,N).  dO, dOT, delta are scratch outputs. */
 int e2k_attn_bwd(const void* dOg, const void* O, const float* gate, const float* lse2, const void* Q,
                  const void* K, const void* V, const void* QT, const void* KT, const uint8_t* kmask,
@@ -221,12 +181,9 @@ int e2k_attn_bwd(const void* dOg, const void* O, const float* gate, const float*
 
 /* ---- MelSpec (e2_tts.py:248-290 -> torchaudio MelSpectrogram(n_fft=1024, hop, power=1, center, htk, norm=None)) ----
  * wave (B, nw) fp32 -> out (B, n_mels, 1 + nw/hop) fp32 = log(clamp(mel, 1e-5)).  window (n_fft) periodic Hann,
- * fb (n_fft/2+1, n_mels) filterbank, twc/tws (n_fft/2): cos/sin(2*pi*k/n_fft).  n_fft must be 1024.
- * bands (optional, int32 [n_mels][2]): bins [lo, hi) outside of which column m of fb is zero -- the htk triangles of
- * torchaudio's melscale_fbanks overlap only their neighbours, so the 513 x 100 contraction has ~1 k non-zero terms of
- * 51 k; NULL = dense contraction. */
+ * fb (n_fft/2+1, n_mels) filterbank, twc/tws (n_fft/2): cos/sin(2*pi*k/n_fft).  n_fft must be 1024. */
 int e2k_melspec(const float* wave, int64_t nw, const float* window, const float* fb, const float* twc,
-                const float* tws, float* out, int B, int n_fft, int hop, int n_mels, const int32_t* bands, void* stream);
+                const float* tws, float* out, int B, int n_fft, int hop, int n_mels, void* stream);
 
 /* Ragged batch (the dataset side): wave (B, nw) holds clips of different length, zero-padded; lens[b]
  * = valid samples of row b (n_fft/2 < lens[b] <= nw).  Row b is transformed exactly as if it were alone (reflection
@@ -235,7 +192,7 @@ int e2k_melspec(const float* wave, int64_t nw, const float* window, const float*
  * (trainer.py:61-82,101-131), in one launch on the device. */
 int e2k_melspec_ragged(const float* wave, int64_t nw, const int32_t* lens, const float* window, const float* fb,
                        const float* twc, const float* tws, float* out, float pad_value, int B, int n_fft, int hop,
-                       int n_mels, const int32_t* bands, void* stream);
+                       int n_mels, void* stream);
 
 /* ---- optimizer side over flat fp32 buffers (reference trainer.py:272-279) ----
  * out[0] += sum x^2 (fp64 accumulation): the global gradient norm of accelerator.clip_grad_norm_ (trainer.py:272-273). */
@@ -248,22 +205,8 @@ int e2k_sumsq_f32(const float* x, int64_t n, double* out, void* stream);
 int e2k_adopt_step(float* p, const float* g, float* m, float* v, void* shadow_bf16, int64_t n, float lr,
                    float beta1, float beta2, float eps, float weight_decay, float max_grad_norm,
                    const double* gsumsq, int step, void* stream);
-/* The same step with TWO parameter groups in one flat buffer: Adopt keeps `steps` per parameter and skips parameters whose
- * .grad is None (trainer.py:183,275) -- the text stream's parameters on steps whose classifier-free-guidance coin drops
- * the text (e2_tts.py:1261).  Elements inside one of the `nranges` (<= 128) sorted [start, end) element ranges
- * (int32 pairs on the device, bounds multiples of 4) belong to group b: they use step_b, or are left untouched
- * (parameter, moments, shadow) when active_b == 0; all other elements use `step`. */
-int e2k_adopt_step_groups(float* p, const float* g, float* m, float* v, void* shadow_bf16, int64_t n, float lr,
-                          float beta1, float beta2, float eps, float weight_decay, float max_grad_norm,
-                          const double* gsumsq, int step, int step_b, int active_b, const int32_t* ranges, int nranges,
-                          void* stream);
 /* ema += (1 - decay) (p - ema)   (ema_pytorch.EMA.update, trainer.py:170,279) */
 int e2k_ema_update(float* ema, const float* p, int64_t n, float decay, void* stream);
-/* Data-parallel gradient exchange in bf16 (replaces the implicit DDP reducer of trainer.py:155-162,190-192,270 for the
- * backbone's flat gradient slabs): wire[i] = bf16(g[i] * scale) into a preallocated buffer, and g[i] = float(wire[i]) after
- * the all-reduce.  One pass each, 16-byte aligned pointers. */
-int e2k_grad_pack_bf16(const float* g, void* wire_bf16, int64_t n, float scale, void* stream);
-int e2k_grad_unpack_bf16(const void* wire_bf16, float* g, int64_t n, void* stream);
 
 
 /* ---- launch plans: the native scheduler of the backbone (csrc/plan.h) ----
@@ -300,7 +243,6 @@ int e2k_plan_event_wait(int lane, int ev);
 int e2k_plan_run_lanes(int plan, int first, int count, void** streams_host, int nstreams);
 int e2k_plan_profile(int plan, int first, int count, float* ms_host, void* stream);
 int e2k_plan_op_name(int plan, int index, char* buf_host, int nbuf);
-int e2k_query_plan_op_lane(int plan, int index);      /* launch lane of recorded call `index` (-1: no such call) */
 
 /* ---- stream pack / unpack, masks, time conditioning: the glue around the depth loop (csrc/glue.hip) ----
  * byte fill (hipMemsetAsync as a recordable call) and a strided form: `rows` rows of `width` bytes, `pitch` bytes apart */
