@@ -301,9 +301,11 @@ def main():
         achieved = gemm_flops / (gemm_ms * 1e-3) / 1e12 if gemm_ms > 0 else 0.0
         # HBM traffic of the dominant kernel per launch: PMC counters cannot be read from inside this process, so the
         # number comes from the committed rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes over the same launch mix
-        # (profiles/r02_nt_traffic.json, produced by tools/nt_shapes.py + tools/nt_traffic_probe.py + tools/nt_traffic_reduce.py); cfg3 only
+        # (profiles/r03_nt_traffic.json, produced by tools/nt_shapes.py + tools/nt_traffic_probe.py + tools/nt_traffic_reduce.py); cfg3 only
         traffic, traffic_note = None, None
-        tf = ROOT / 'profiles' / 'r02_nt_traffic.json'
+        tf = ROOT / 'profiles' / 'r03_nt_traffic.json'
+        if not tf.exists():
+            tf = ROOT / 'profiles' / 'r02_nt_traffic.json'
         if args.config == 'cfg3' and B == CONFIGS['cfg3'][3] and not args.drop_text and tf.exists():
             tj = json.load(open(tf))
             traffic = tj['traffic_bytes_per_launch']
@@ -335,7 +337,7 @@ def main():
                              'note': 'text branches / weight-gradient GEMMs on side streams (ops.Lanes, csrc/plan.h); E2K_LANES=0 for the single-stream schedule'},
             'kernel_groups_ms_per_step': _groups(prof_rows, nprof) if prof_rows else None,
             'roofline': {
-                'bound': 'mfma', 'kernel': 'e2k_gemm_nt_bf16: gemm_nt_256_kernel (256x256x64, 8-phase) / gemm_nt_glds_kernel (128x128x64) + fix-ups (bf16 MFMA 16x16x32; every forward and dgrad GEMM of the step)',
+                'bound': 'mfma', 'kernel': 'e2k_gemm_nt_bf16: gemm_nt_256_kernel (256x256x64, 8-phase) / gemm_nt_glds_kernel (128x128x64), C tiles through LDS in whole-line 16-byte stores, + fix-ups (bf16 MFMA 16x16x32; every forward and dgrad GEMM of the step)',
                 'achieved': achieved, 'peak': PEAK_BF16_TFLOPS, 'unit': 'TFLOP/s', 'frac': achieved / PEAK_BF16_TFLOPS,
                 'launches_per_step': n_launch / nprof,
                 'avg_launch_ms': gemm_ms / max(n_launch, 1),

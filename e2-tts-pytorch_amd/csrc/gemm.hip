@@ -14,6 +14,7 @@
 // of tile t+1 are issued before the MFMAs of tile t and written to the other LDS buffer after them
 // (one barrier per K step).  MFMA operands are swapped (srcA = weight fragment, srcB = activation fragment) so
 // that a lane's 4 accumulator registers are 4 consecutive output columns -> 8-byte bf16 stores.
+#include <type_traits>
 #include "e2k_device.h"
 #include "plan.h"
 #include <e2k_asm.h>
@@ -918,6 +919,38 @@ struct TNArgs {
     const bf16_t* B2; long ldb2; int K1;
 };
 
+// A GROUP of weight-gradient GEMMs with the same token count M in one launch of the 256 x 256 kernel (e2k_gemm_tn_group_bf16):
+// the tiles of all problems form one grid (x = tile over the whole group, y = token split), so that the small outputs of a
+// layer (attention out 1024 x 1024 = 16 tiles, the text stream's 4-32 tiles) fill the chip together instead of one by one.
+constexpr int TN_GROUP_MAX = 8;
+struct TNProb {
+    const bf16_t* A; long lda; const bf16_t* B; long ldb; float* C; long ldc;
+    int N, K, tile0;             // tile0: index of this problem's first tile in the group's tile list
+    float* colsum; int cs_from;
+};
+struct TNGroupArgs {
+    TNProb prob[TN_GROUP_MAX];
+    int n, M, splits, chunk, tiles;
+    float* ws;
+};
+// problem that holds tile t of the group (wave-uniform; n <= 8: a linear scan)
+__device__ __forceinline__ int tn_group_find(const TNGroupArgs& g, int t) {
+    int i = 0;
+#pragma unroll
+    for (int k = 1; k < TN_GROUP_MAX; ++k)
+        if (k < g.n && t >= g.prob[k].tile0) i = k;
+    return i;
+}
+__device__ __forceinline__ TNArgs tn_group_args(const TNGroupArgs& g, int i) {
+    TNArgs p;
+    const TNProb& q = g.prob[i];
+    p.A = q.A; p.lda = q.lda; p.B = q.B; p.ldb = q.ldb; p.C = q.C; p.ldc = q.ldc; p.ws = g.ws;
+    p.M = g.M; p.N = q.N; p.K = q.K; p.splits = g.splits; p.chunk = g.chunk;
+    p.colsum = q.colsum; p.cs_from = q.cs_from;
+    p.A2 = nullptr; p.lda2 = 0; p.N1 = 0; p.B2 = nullptr; p.ldb2 = 0; p.K1 = 0;
+    return p;
+}
+
 template <bool USE_TR>
 __device__ __forceinline__ bf16x8 tn_frag(const unsigned char* T, int kk, int col0, int q, int g) {
     bf16x8 f;
@@ -1173,16 +1206,32 @@ __global__ __launch_bounds__(256, 2) void gemm_tn_glds_kernel(TNArgs p) {
 // Half the LDS-read bytes per flop and a quarter of the partial-tile traffic per flop of the 128 x 128 kernel.
 constexpr int T2 = 256, T2HALF = TBM * 256, T2BUF = 4 * T2HALF, T2THREADS = 512;
 
-template <bool CS>
-__global__ __launch_bounds__(T2THREADS, 1) void gemm_tn_256_kernel(TNArgs p) {
+template <bool CS, class ARGS = TNArgs>
+__global__ __launch_bounds__(T2THREADS, 1) void gemm_tn_256_kernel(ARGS args) {
     __shared__ __attribute__((aligned(16))) unsigned char smem[2 * T2BUF];
     lds_declare(smem, sizeof(smem));
     const int tid = threadIdx.x, lane = tid & 63, wave = uniform_i(tid >> 6);
     const int wr = wave >> 2, wc = wave & 3;
     const int q = lane & 15, g = lane >> 4;
+    // single problem: the tile list is this problem's; group: locate the problem that owns this workgroup's tile
+    constexpr bool GROUP = !std::is_same<ARGS, TNArgs>::value;
+    const int gtile = xcd_remap(blockIdx.x, gridDim.x);          // (contiguous runs of the tile list per XCD)
+    TNArgs p;
+    int ltile, ws_tile0;
+    if constexpr (GROUP) {
+        const int pi = tn_group_find(args, gtile);
+        p = tn_group_args(args, pi);
+        ws_tile0 = args.prob[pi].tile0;
+        ltile = gtile - ws_tile0;
+    } else {
+        p = args;
+        ws_tile0 = 0;
+        ltile = gtile;
+    }
+    const int ws_tiles = gridDim.x;
     const int tn = (p.N + T2 - 1) / T2, tk = (p.K + T2 - 1) / T2;
     int tile_n, tile_k;
-    tile_coords(xcd_remap(blockIdx.x, gridDim.x), tn, tk, tile_n, tile_k);
+    tile_coords(ltile, tn, tk, tile_n, tile_k);
     const int n0 = tile_n * T2, k0 = tile_k * T2;
     const int mbeg = blockIdx.y * p.chunk;
     const int mend = min(p.M, mbeg + p.chunk);
@@ -1252,7 +1301,7 @@ __global__ __launch_bounds__(T2THREADS, 1) void gemm_tn_256_kernel(TNArgs p) {
     s16x4_ ar[2][4][2], blo[2][2][2], bhi[2][2][2];
     // column sums of A (bias gradient of the same dY) ride along in the k-tile-0 workgroups: wave (wr, wc) takes the
     // 16-column group i = wc of its 64 columns, one extra MFMA per A half and 32 rows with an all-ones operand
-    const bool do_cs = CS && tile_k == 0 && n0 + T2 > p.cs_from;          // wave-uniform
+    const bool do_cs = CS && p.colsum != nullptr && tile_k == 0 && n0 + T2 > p.cs_from;          // wave-uniform (a group may mix problems with and without a bias gradient)
     f32x4 cs[2] = {f32x4{0.f, 0.f, 0.f, 0.f}, f32x4{0.f, 0.f, 0.f, 0.f}};
     const short one = 0x3F80;
     const bf16x8 ones = bf16x8{one, one, one, one, one, one, one, one};
@@ -1367,7 +1416,7 @@ __global__ __launch_bounds__(T2THREADS, 1) void gemm_tn_256_kernel(TNArgs p) {
     // splits == 1: C += acc.  splits > 1: the partial tile in fragment order (see tn_store),
     //     ws[((split * tiles + tile) * 32 + ((a*2 + b)*4 + i)*2 + j) * 512 + tid]   (f32x4 units)
     if (p.splits > 1) {
-        f32x4* w = (f32x4*)p.ws + ((long)blockIdx.y * (tn * tk) + tile_n * tk + tile_k) * (32 * T2THREADS) + tid;
+        f32x4* w = (f32x4*)p.ws + ((long)blockIdx.y * ws_tiles + ws_tile0 + tile_n * tk + tile_k) * (32 * T2THREADS) + tid;
 #pragma unroll
         for (int a = 0; a < 2; ++a)
 #pragma unroll
@@ -1418,15 +1467,28 @@ __global__ __launch_bounds__(T2THREADS, 1) void gemm_tn_256_kernel(TNArgs p) {
 // splits (FeedForward's second weight, qkv); one workgroup per whole tile left 16-64 workgroups on the chip for the small
 // outputs and ran 2-3x slower (profiles/r03_gemm_epilogue_ab_16byte_stores.json, `tn` rows).
 //   BIG  (256 x 256 tiles): grid (tiles, 16 slabs), 256 threads;   otherwise (128 x 128): grid (tiles, 8 slabs), 128 threads
-template <bool BIG>
-__global__ __launch_bounds__(BIG ? 256 : 128) void tn_reduce_frag_kernel(const f32x4* ws, float* C, long ldc, int N, int K, int splits, int tk) {
+struct TNReduceGroup { TNProb prob[TN_GROUP_MAX]; int n; };
+
+template <bool BIG, bool GROUP = false>
+__global__ __launch_bounds__(BIG ? 256 : 128) void tn_reduce_frag_kernel(const f32x4* ws, float* C, long ldc, int N, int K, int splits, int tk,
+                                                                         TNReduceGroup grp) {
     constexpr int NF = BIG ? 32 : 16, T = BIG ? 512 : 256, TS = BIG ? 256 : 128, ROWB = TS * 4 + 16, RT = BIG ? 256 : 128;
     __shared__ __attribute__((aligned(16))) unsigned char S[16 * ROWB];
     const int tid = threadIdx.x, lane = tid & 63, wl = tid >> 6, q = lane & 15, g = lane >> 4;
     const int tile = blockIdx.x, tiles = gridDim.x, slab = blockIdx.y;
     const long stride = (long)tiles * NF * T;
-    int n0 = (tile / tk) * TS;
-    const int k0 = (tile % tk) * TS;
+    int ltile = tile;
+    if (GROUP) {                             // the problem that owns this tile of the group: its C, shape and tile grid
+        int pi = 0;
+#pragma unroll
+        for (int k = 1; k < TN_GROUP_MAX; ++k)
+            if (k < grp.n && tile >= grp.prob[k].tile0) pi = k;
+        const TNProb& pr = grp.prob[pi];
+        C = pr.C; ldc = pr.ldc; N = pr.N; K = pr.K; tk = (pr.K + TS - 1) / TS;
+        ltile = tile - pr.tile0;
+    }
+    int n0 = (ltile / tk) * TS;
+    const int k0 = (ltile % tk) * TS;
 #pragma unroll
     for (int ff = 0; ff < 4; ++ff) {
         int f, gtid, col;
@@ -1746,11 +1808,95 @@ static int gemm_tn_bf16_impl(const void* A, int64_t lda, const void* B, int64_t 
     else hipLaunchKernelGGL(gemm_tn_kernel<false>, grid, block, 0, (hipStream_t)stream, p);
     E2K_CHECK_LAUNCH();
     if (splits > 1) {
-        if (big) hipLaunchKernelGGL(tn_reduce_frag_kernel<true>, dim3(tn * tk, 16), dim3(256), 0, (hipStream_t)stream, (const f32x4*)ws, C, (long)ldc, N, K, splits, tk);
-        else hipLaunchKernelGGL(tn_reduce_frag_kernel<false>, dim3(tn * tk, 8), dim3(128), 0, (hipStream_t)stream, (const f32x4*)ws, C, (long)ldc, N, K, splits, tk);
+        if (big) hipLaunchKernelGGL(tn_reduce_frag_kernel<true>, dim3(tn * tk, 16), dim3(256), 0, (hipStream_t)stream, (const f32x4*)ws, C, (long)ldc, N, K, splits, tk, TNReduceGroup{});
+        else hipLaunchKernelGGL(tn_reduce_frag_kernel<false>, dim3(tn * tk, 8), dim3(128), 0, (hipStream_t)stream, (const f32x4*)ws, C, (long)ldc, N, K, splits, tk, TNReduceGroup{});
         E2K_CHECK_LAUNCH();
     }
     return 0;
+}
+
+// token splits of a grouped launch: all problems share M and the split count; pick the count with the fewest rounds x steps
+static int tn_group_splits(int M, int tiles, int splits) {
+    if (splits <= 0) {
+        const int maxs = M / (TBM * 8) < 1 ? 1 : (M / (TBM * 8) > 16 ? 16 : M / (TBM * 8));
+        long best = -1;
+        splits = 1;
+        for (int sp = 1; sp <= maxs; ++sp) {
+            const long rounds = ((long)tiles * sp + 255) / 256;
+            const long steps = ((M + sp - 1) / sp + TBM - 1) / TBM;
+            const long cost = rounds * (steps + 6) + (sp > 1 ? 2 : 0);        // (+6: prologue + partial-tile store of a workgroup, in steps)
+            if (best < 0 || cost < best) { best = cost; splits = sp; }
+        }
+    }
+    int chunk = (M + splits - 1) / splits;
+    chunk = (chunk + TBM - 1) / TBM * TBM;
+    return (M + chunk - 1) / chunk;
+}
+
+struct TNGroupHost { e2k_tn_problem p[TN_GROUP_MAX]; int n; };
+
+static int tn_group_tiles(const TNGroupHost& h) {
+    int t = 0;
+    for (int i = 0; i < h.n; ++i) t += ((h.p[i].N + T2 - 1) / T2) * ((h.p[i].K + T2 - 1) / T2);
+    return t;
+}
+
+static int gemm_tn_group_impl(TNGroupHost h, int M, int splits, float* ws, void* stream) {
+    if (h.n <= 0 || M <= 0) return 0;
+    if (h.n > TN_GROUP_MAX || (M % TBM) != 0) return E2K_ERR_SHAPE;
+    TNGroupArgs g;
+    TNReduceGroup r;
+    bool any_cs = false;
+    int tiles = 0;
+    for (int i = 0; i < h.n; ++i) {
+        const e2k_tn_problem& q = h.p[i];
+        if (q.N < 8 || q.K < 8 || !q.A || !q.B || !q.C) return E2K_ERR_ARG;
+        if ((q.lda & 7) || (q.ldb & 7) || ((q.N + 7) & ~7) > q.lda || ((q.K + 7) & ~7) > q.ldb) return E2K_ERR_ALIGN;
+        if (((uintptr_t)q.A | (uintptr_t)q.B) & 15) return E2K_ERR_ALIGN;
+        if (q.colsum && (q.cs_from < 0 || q.cs_from >= q.N || (q.cs_from & 1))) return E2K_ERR_ARG;
+        TNProb& d = g.prob[i];
+        d.A = (const bf16_t*)q.A; d.lda = q.lda; d.B = (const bf16_t*)q.B; d.ldb = q.ldb; d.C = q.C; d.ldc = q.ldc;
+        d.N = q.N; d.K = q.K; d.tile0 = tiles; d.colsum = q.colsum; d.cs_from = q.cs_from;
+        r.prob[i] = d;
+        any_cs = any_cs || q.colsum != nullptr;
+        tiles += ((q.N + T2 - 1) / T2) * ((q.K + T2 - 1) / T2);
+    }
+    for (int i = h.n; i < TN_GROUP_MAX; ++i) { g.prob[i] = g.prob[0]; g.prob[i].tile0 = 1 << 30; r.prob[i] = g.prob[i]; }
+    splits = tn_group_splits(M, tiles, splits);
+    if (splits > 1 && ws == nullptr) return E2K_ERR_ARG;
+    int chunk = (M + splits - 1) / splits;
+    chunk = (chunk + TBM - 1) / TBM * TBM;
+    g.n = h.n; g.M = M; g.splits = splits; g.chunk = chunk; g.tiles = tiles; g.ws = ws;
+    r.n = h.n;
+    dim3 grid(tiles, splits);
+    if (any_cs) hipLaunchKernelGGL((gemm_tn_256_kernel<true, TNGroupArgs>), grid, dim3(T2THREADS), 0, (hipStream_t)stream, g);
+    else hipLaunchKernelGGL((gemm_tn_256_kernel<false, TNGroupArgs>), grid, dim3(T2THREADS), 0, (hipStream_t)stream, g);
+    E2K_CHECK_LAUNCH();
+    if (splits > 1) {
+        hipLaunchKernelGGL((tn_reduce_frag_kernel<true, true>), dim3(tiles, 16), dim3(256), 0, (hipStream_t)stream, (const f32x4*)ws,
+                           (float*)nullptr, 0l, 0, 0, splits, 1, r);
+        E2K_CHECK_LAUNCH();
+    }
+    return 0;
+}
+
+extern "C" int e2k_gemm_tn_group_bf16(const e2k_tn_problem* problems, int n, int M, int splits, float* ws, void* stream) {
+    if (n < 0 || n > TN_GROUP_MAX || (n > 0 && problems == nullptr)) return E2K_ERR_ARG;
+    TNGroupHost h;
+    h.n = n;
+    for (int i = 0; i < n; ++i) h.p[i] = problems[i];
+    for (int i = n; i < TN_GROUP_MAX; ++i) h.p[i] = e2k_tn_problem{};
+    return e2k::dispatch("gemm_tn_group_bf16", gemm_tn_group_impl, h, M, splits, ws, stream);
+}
+
+extern "C" int64_t e2k_query_gemm_tn_group_ws_floats(const e2k_tn_problem* problems, int n, int M, int splits) {
+    if (n <= 0 || n > TN_GROUP_MAX || problems == nullptr || M <= 0) return 0;
+    TNGroupHost h;
+    h.n = n;
+    for (int i = 0; i < n; ++i) h.p[i] = problems[i];
+    const int tiles = tn_group_tiles(h);
+    const int ns = tn_group_splits(M, tiles, splits);
+    return ns <= 1 ? 0 : (int64_t)ns * tiles * T2 * T2;
 }
 
 // ---- C ABI: every compute entry point goes through e2k::dispatch (plan.h) so that a launch plan can record it

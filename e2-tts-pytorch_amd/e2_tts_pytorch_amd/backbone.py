@@ -1161,13 +1161,47 @@ class Transformer(Module):
         Ln = run.blanes = ops.Lanes(dev, self._lane_streams(dev) if (run.lanes.on and self._lanes_bwd) else [], self._lane_mask)
         hold = [[], []]           # operands of the weight-gradient GEMMs of [this layer, the layer before]
 
-        def wgrad(a, b, out, **kw):
-            """out += a^T b for a parameter gradient: nothing on the chain reads it, so it goes to the WGRAD lane"""
+        pending = []              # (a, b, out, colsum, colsum_from) of the layer being walked, launched as ONE group at its end
+
+        def wgrad(a, b, out, colsum=None, colsum_from=0):
+            """out += a^T b for a parameter gradient: nothing on the chain reads it, so it goes to the WGRAD lane -- and, since
+            nothing needs it before the layer's gradient slab is handed over, it waits for the other weight gradients of its
+            layer and shares ONE grouped launch with them (ops.gemm_tn_group: the small outputs fill the chip together)"""
+            if _WGRAD_GROUP and ops.can_group_tn(a, b) and (not pending or pending[0][0].shape[0] == a.shape[0]):
+                pending.append((a, b, out, colsum, colsum_from))
+                if len(pending) == ops.TN_GROUP_MAX:
+                    flush_wgrads()
+                return
+            wgrad_now(a, b, out, colsum=colsum, colsum_from=colsum_from)
+
+        def wgrad_now(a, b, out, **kw):
             if not Ln.has(ops.WGRAD):
                 return ops.gemm_tn(a, b, out, **kw)
             Ln.fence(Ln.cur, ops.WGRAD)
             with Ln.lane(ops.WGRAD):
                 ops.gemm_tn(a, b, out, hold=hold[0], splits=_WGRAD_LANE_SPLITS, **kw)
+
+        def flush_wgrads():
+            """launch what `pending` holds (end of a layer: before its slab goes to the data-parallel hook)"""
+            if not pending:
+                return
+            probs = list(pending)
+            pending.clear()
+            if len(probs) == 1:
+                a, b, out, cs, cf = probs[0]
+                if not Ln.has(ops.WGRAD):
+                    return ops.gemm_tn(a, b, out, colsum=cs, colsum_from=cf)
+                Ln.fence(ops.MAIN, ops.WGRAD)
+                Ln.fence(ops.TEXT, ops.WGRAD)
+                with Ln.lane(ops.WGRAD):
+                    ops.gemm_tn(a, b, out, hold=hold[0], splits=_WGRAD_LANE_SPLITS, colsum=cs, colsum_from=cf)
+                return
+            if not Ln.has(ops.WGRAD):
+                return ops.gemm_tn_group(probs)
+            Ln.fence(ops.MAIN, ops.WGRAD)             # the operands were produced on MAIN and (text stream) on TEXT
+            Ln.fence(ops.TEXT, ops.WGRAD)
+            with Ln.lane(ops.WGRAD):
+                ops.gemm_tn_group(probs, hold=hold[0], splits=_WGRAD_LANE_SPLITS)
         run.wgrad = wgrad
 
         def wgrad_dual(a1, a2, b1, b2, out):
@@ -1178,7 +1212,7 @@ class Transformer(Module):
                 for a, r0 in ((a1, 0), (a2, n1)):
                     for b_, c0 in ((b1, 0), (b2, k1)):
                         if a is not None and b_ is not None:
-                            wgrad(a, b_, out[r0:r0 + a.shape[1], c0:c0 + b_.shape[1]])
+                            wgrad_now(a, b_, out[r0:r0 + a.shape[1], c0:c0 + b_.shape[1]])
                 return
             if not Ln.has(ops.WGRAD):
                 return ops.gemm_tn_dual(a1, a2, b1, b2, out)
@@ -1251,6 +1285,7 @@ class Transformer(Module):
         for ent in reversed(run.tape):
             kind = ent[0]
             if kind == 'layer':
+                flush_wgrads()
                 if Ln.has(ops.WGRAD):
                     Ln.wait(ops.MAIN, ev_w)
                     hold[1].clear()
@@ -1275,6 +1310,7 @@ class Transformer(Module):
                 ev_main, need_main = Ln.record(ops.MAIN), True
             else:
                 entry(ent)
+        flush_wgrads()
         Ln.join()                 # (the remaining weight gradients included: their operands die with this frame)
         thold.clear()
 
@@ -1428,6 +1464,8 @@ class _TimeCondFn(torch.autograd.Function):
 _WGRAD_LANE_SPLITS = int(_os.environ.get('E2K_WGRAD_SPLITS', '0'))
 # dual-source weight-gradient launches for the cross-condition / skip projections (E2K_WGRAD_DUAL=0: one GEMM per block, A/B)
 _WGRAD_DUAL = _os.environ.get('E2K_WGRAD_DUAL', '1') != '0'
+# one grouped launch for the weight gradients of a layer (E2K_WGRAD_GROUP=0: one GEMM each, as they become ready; A/B)
+_WGRAD_GROUP = _os.environ.get('E2K_WGRAD_GROUP', '1') != '0'
 
 _VIEW_OPS = {'view', '_unsafe_view', 'as_strided', 'slice', 'select', 'expand', 't', 'transpose', 'permute', 'unsqueeze', 'squeeze',
              'detach', 'alias', '_reshape_alias', 'reshape', 'split', 'split_with_sizes', 'unbind', 'narrow', 'lift_fresh', 'unfold',

@@ -6,6 +6,8 @@ from __future__ import annotations
 
 import contextlib
 
+import ctypes
+
 import torch
 
 from . import _lib
@@ -366,6 +368,47 @@ def gemm_tn_dual(a1, a2, b1, b2, out, *, splits=0, hold=None):
     if hold is not None:
         hold.append((a1, a2, b1, b2, ws))
     return out
+
+
+class _TNProblem(ctypes.Structure):
+    """e2k_tn_problem (include/e2k.h)"""
+    _fields_ = [('A', ctypes.c_void_p), ('lda', ctypes.c_int64), ('B', ctypes.c_void_p), ('ldb', ctypes.c_int64),
+                ('C', ctypes.c_void_p), ('ldc', ctypes.c_int64), ('N', ctypes.c_int32), ('K', ctypes.c_int32),
+                ('colsum', ctypes.c_void_p), ('cs_from', ctypes.c_int32), ('reserved', ctypes.c_int32)]
+
+
+TN_GROUP_MAX = 8
+
+
+def can_group_tn(a, b):
+    """operands the grouped weight-gradient launch takes: 64-row reduction steps, at least 8 columns each"""
+    return a.shape[0] % 64 == 0 and a.shape[1] >= 8 and b.shape[1] >= 8
+
+
+def gemm_tn_group(problems, *, splits=0, hold=None):
+    """problems: [(a (M, N_i) bf16, b (M, K_i) bf16, out (N_i, K_i) fp32, colsum or None, colsum_from)], all with the same
+    M: out_i += a_i.T @ b_i (+ colsum_i[n] += sum_m a_i[m][n] for n >= colsum_from) in ONE launch (e2k_gemm_tn_group_bf16)"""
+    assert 1 <= len(problems) <= TN_GROUP_MAX
+    M = problems[0][0].shape[0]
+    arr = (_TNProblem * len(problems))()
+    fl = 0.
+    for i, (a, b, out, cs, cs_from) in enumerate(problems):
+        _chk(a, b, out, cs)
+        assert a.dtype == bf16 and b.dtype == bf16 and out.dtype == f32 and a.shape[0] == M and b.shape[0] == M
+        N, K = a.shape[1], b.shape[1]
+        assert out.shape == (N, K) and out.stride(1) == 1
+        if cs is not None:
+            assert cs.dtype == f32 and cs.numel() == N and cs.is_contiguous()
+        arr[i] = _TNProblem(_p(a), _rows(a)[1], _p(b), _rows(b)[1], _p(out), out.stride(0), N, K, _p(cs), int(cs_from), 0)
+        fl += 2.0 * M * N * K
+    lib = _lib.get()
+    ap = ctypes.cast(arr, ctypes.c_void_p)
+    nws = lib.e2k_query_gemm_tn_group_ws_floats(ap, len(problems), M, int(splits))
+    ws = torch.empty((nws,), dtype=f32, device=problems[0][0].device) if nws > 0 else None
+    _note(fl)
+    lib.e2k_gemm_tn_group_bf16(ap, len(problems), M, int(splits), _p(ws), _stream(problems[0][0]))
+    if hold is not None:
+        hold.append((problems, ws))
 
 
 # ------------------------------------------------------------------------------------------------ hyper-connections

@@ -73,6 +73,19 @@ int e2k_gemm_tn_bf16(const void* A, int64_t lda, const void* B, int64_t ldb, flo
 int e2k_gemm_tn_dual_bf16(const void* A1, int64_t lda1, int N1, const void* A2, int64_t lda2, int N2,
                           const void* B1, int64_t ldb1, int K1, const void* B2, int64_t ldb2, int K2,
                           float* C, int64_t ldc, int M, int splits, float* ws, void* stream);
+/* A GROUP of up to 8 independent weight gradients with the same token count M in one launch of the 256 x 256 kernel:
+ *   C_i[N_i, K_i] += A_i[M, N_i]^T . B_i[M, K_i]     (colsum_i optional: the bias gradient of the same dY_i, as above)
+ * The weight gradients of one layer (attention out / qkv / FeedForward 1 and 2, audio and text stream: 4-128 tiles of
+ * 256 x 256 each) fill the chip together instead of one after the other; nothing on the backward chain reads them before
+ * the optimizer.  M a multiple of 64; ws = e2k_query_gemm_tn_group_ws_floats(...) floats (partial tiles in fragment order
+ * over the group's tile list); splits = 0 lets the library choose one split count for the group. */
+typedef struct {
+    const void* A; int64_t lda; const void* B; int64_t ldb; float* C; int64_t ldc;
+    int32_t N, K;
+    float* colsum; int32_t cs_from; int32_t reserved;
+} e2k_tn_problem;
+int e2k_gemm_tn_group_bf16(const e2k_tn_problem* problems, int n, int M, int splits, float* ws, void* stream);
+int64_t e2k_query_gemm_tn_group_ws_floats(const e2k_tn_problem* problems, int n, int M, int splits);
 /* upper bound on the token-dimension splits the call above uses for (M, N, K, splits), whichever kernel it selects
  * (use_tr = 1 means "the library chooses per shape", not "transposing reads"); when it is > 1 the caller passes
  * ws = scratch of e2k_query_gemm_tn_ws_floats(...) floats (partial tiles are stored there and combined afterwards).  The

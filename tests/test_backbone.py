@@ -486,14 +486,16 @@ def test_rmsnorm_unit_offset_checkpoints_are_converted_on_load():
     assert all(torch.allclose(m2.state_dict()[k], msd[k], atol=1e-6) for k in msd if k.endswith('.g'))
 
 
-def test_dual_source_weight_gradients_in_the_backbone(dev):
-    """the cross-condition's (D + Dt, D + Dt) and the skip projection's (D, 2D) weight gradients as ONE dual-source launch
-    each (e2k_gemm_tn_dual_bf16) against one GEMM per block: same gradients (summation order over the token splits
-    differs), and the recorded backward holds the dual calls"""
+def test_dual_source_and_grouped_weight_gradients_in_the_backbone(dev):
+    """weight-gradient launches of the backward schedule: the cross-condition's (D + Dt, D + Dt) and the skip projection's
+    (D, 2D) gradients as ONE dual-source launch each (e2k_gemm_tn_dual_bf16), and a layer's remaining weight gradients
+    (attention out / qkv / feed-forward 1 and 2 of both streams) as ONE grouped launch at the end of the layer
+    (e2k_gemm_tn_group_bf16) -- against one GEMM per block / per weight: same gradients (the summation order over the token
+    splits differs), and the recorded backward holds the fused calls"""
     from e2_tts_pytorch_amd import Transformer, backbone as bbm
     random.seed(0)
     torch.manual_seed(0)
-    dim, depth, B, T = 256, 2, 2, 16            # (T + 32) * 4 * B = 384 rows of the 4-stream tensors: a multiple of 64
+    dim, depth, B, T = 256, 2, 4, 32            # (T + 32) * B = 256 token rows (x 4 streams = 1024): multiples of 64
     mod = Transformer(dim=dim, depth=depth, heads=dim // 64, dropout=0., max_seq_len=T)
     randomize(mod)
     mod = mod.to(dev)
@@ -510,15 +512,17 @@ def test_dual_source_weight_gradients_in_the_backbone(dev):
         st = [v for v in mod._plans.values() if not isinstance(v, str) and v.bwd]
         return {n: p.grad.detach().cpu().clone() for n, p in mod.named_parameters() if p.grad is not None}, ops_names(st[0].bwd)
 
-    old = bbm._WGRAD_DUAL
+    old = bbm._WGRAD_DUAL, bbm._WGRAD_GROUP
     try:
-        bbm._WGRAD_DUAL = True
+        bbm._WGRAD_DUAL, bbm._WGRAD_GROUP = True, True
         g1, names1 = grads()
-        bbm._WGRAD_DUAL = False
+        bbm._WGRAD_DUAL, bbm._WGRAD_GROUP = False, False
         g0, names0 = grads()
     finally:
-        bbm._WGRAD_DUAL = old
+        bbm._WGRAD_DUAL, bbm._WGRAD_GROUP = old
     assert names1.count('gemm_tn_dual_bf16') == depth + depth // 2 and 'gemm_tn_dual_bf16' not in names0
-    assert names0.count('gemm_tn_bf16') - names1.count('gemm_tn_bf16') == (4 + 2) * 1 + 2 * 1          # layer 0: 4 cross blocks, layer 1: 2 (no audio_to_text) + 2 skip blocks
-    for n in g0:          # (everything else is computed by the same calls; fp32 atomics in some reductions make the order free)
+    assert names1.count('gemm_tn_group_bf16') == depth and 'gemm_tn_group_bf16' not in names0      # 8 weight gradients per layer = one full group
+    # per layer 8 branch gradients (4 audio + 4 text); layer 0: 4 cross blocks; layer 1: 2 cross blocks (no audio_to_text) + 2 skip blocks
+    assert names0.count('gemm_tn_bf16') - names1.count('gemm_tn_bf16') == 8 * depth + 4 + 2 + 2
+    for n in g0:          # (fp32 atomics in some reductions make the summation order free: tolerance, not bits)
         assert rel2(g1[n], g0[n]) < 1e-5 or float(g0[n].norm()) < 1e-7, n

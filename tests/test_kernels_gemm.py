@@ -452,3 +452,32 @@ def test_gemm_tn_dual_source(dev, M, N1, N2, K1, K2, splits):
             if a is not None and b_ is not None:
                 ops.gemm_tn(d(a), d(b_), blk[r0:r0 + a.shape[1], k0:k0 + b_.shape[1]], use_tr=3)
     assert rel(out, blk) < 1e-5
+
+
+def test_gemm_tn_group(dev):
+    """up to 8 weight gradients with the same token count in ONE launch of the 256 x 256 kernel (e2k_gemm_tn_group_bf16: a
+    layer's attention-out / qkv / feed-forward gradients of both streams share the chip) against one GEMM per problem:
+    ragged shapes, bias-gradient column sums on two of them, accumulated onto non-zero C, explicit and library-chosen
+    split counts"""
+    from e2_tts_pytorch_amd import ops
+    torch.manual_seed(3)
+    M = 640
+    shapes = [(256, 512, 1, 0), (264, 136, 0, 0), (1040, 256, 1, 16), (136, 264, 0, 0), (520, 520, 0, 0)]
+    for splits in (0, 1, 3):
+        probs, refs = [], []
+        for (N, K, cs, cs_from) in shapes:
+            a, b = torch.randn(M, N).to(bf16), torch.randn(M, K).to(bf16)
+            c0 = torch.randn(N, K)
+            col0 = torch.full((N,), 0.25) if cs else None
+            probs.append((a.to(dev), b.to(dev), c0.clone().to(dev), None if col0 is None else col0.clone().to(dev), cs_from))
+            want_cs = None
+            if cs:
+                want_cs = col0.clone()
+                want_cs[cs_from:] += a.float().sum(0)[cs_from:]
+            refs.append((c0 + a.float().T @ b.float(), want_cs))
+        assert all(ops.can_group_tn(p[0], p[1]) for p in probs)
+        ops.gemm_tn_group(probs, splits=splits)
+        for (a, b, out, col, _), (want, want_cs) in zip(probs, refs):
+            assert rel(out, want) < 2e-3, splits
+            if want_cs is not None:
+                assert torch.allclose(col.cpu(), want_cs, rtol=1e-4, atol=2e-3), splits
