@@ -1167,7 +1167,8 @@ class Transformer(Module):
             """out += a^T b for a parameter gradient: nothing on the chain reads it, so it goes to the WGRAD lane -- and, since
             nothing needs it before the layer's gradient slab is handed over, it waits for the other weight gradients of its
             layer and shares ONE grouped launch with them (ops.gemm_tn_group: the small outputs fill the chip together)"""
-            if _WGRAD_GROUP and ops.can_group_tn(a, b) and (not pending or pending[0][0].shape[0] == a.shape[0]):
+            if (_WGRAD_GROUP and a.shape[0] >= _WGRAD_MIN_ROWS and ops.can_group_tn(a, b)
+                    and (not pending or pending[0][0].shape[0] == a.shape[0])):
                 pending.append((a, b, out, colsum, colsum_from))
                 if len(pending) == ops.TN_GROUP_MAX:
                     flush_wgrads()
@@ -1207,7 +1208,7 @@ class Transformer(Module):
         def wgrad_dual(a1, a2, b1, b2, out):
             """out += cat(a1, a2)^T cat(b1, b2) as ONE weight-gradient launch (the cross-condition's four blocks, the skip
             projection's two); shapes the dual-source kernel cannot take fall back to one GEMM per block"""
-            if not (_WGRAD_DUAL and ops.can_gemm_tn_dual(a1.shape[0], a1.shape[1], b1.shape[1])):
+            if not (_WGRAD_DUAL and a1.shape[0] >= _WGRAD_MIN_ROWS and ops.can_gemm_tn_dual(a1.shape[0], a1.shape[1], b1.shape[1])):
                 n1, k1 = a1.shape[1], b1.shape[1]
                 for a, r0 in ((a1, 0), (a2, n1)):
                     for b_, c0 in ((b1, 0), (b2, k1)):
@@ -1466,6 +1467,9 @@ _WGRAD_LANE_SPLITS = int(_os.environ.get('E2K_WGRAD_SPLITS', '0'))
 _WGRAD_DUAL = _os.environ.get('E2K_WGRAD_DUAL', '1') != '0'
 # one grouped launch for the weight gradients of a layer (E2K_WGRAD_GROUP=0: one GEMM each, as they become ready; A/B)
 _WGRAD_GROUP = _os.environ.get('E2K_WGRAD_GROUP', '1') != '0'
+# below this many token rows the fused weight-gradient launches are not used: they always run the 256 x 256 kernel, whose fixed
+# cost (a 256-KB partial tile per workgroup + the reduce pass) only pays on real sizes
+_WGRAD_MIN_ROWS = int(_os.environ.get('E2K_WGRAD_MIN_ROWS', '1024'))
 
 _VIEW_OPS = {'view', '_unsafe_view', 'as_strided', 'slice', 'select', 'expand', 't', 'transpose', 'permute', 'unsqueeze', 'squeeze',
              'detach', 'alias', '_reshape_alias', 'reshape', 'split', 'split_with_sizes', 'unbind', 'narrow', 'lift_fresh', 'unfold',

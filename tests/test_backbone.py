@@ -512,14 +512,14 @@ def test_dual_source_and_grouped_weight_gradients_in_the_backbone(dev):
         st = [v for v in mod._plans.values() if not isinstance(v, str) and v.bwd]
         return {n: p.grad.detach().cpu().clone() for n, p in mod.named_parameters() if p.grad is not None}, ops_names(st[0].bwd)
 
-    old = bbm._WGRAD_DUAL, bbm._WGRAD_GROUP
+    old = bbm._WGRAD_DUAL, bbm._WGRAD_GROUP, bbm._WGRAD_MIN_ROWS
     try:
-        bbm._WGRAD_DUAL, bbm._WGRAD_GROUP = True, True
+        bbm._WGRAD_DUAL, bbm._WGRAD_GROUP, bbm._WGRAD_MIN_ROWS = True, True, 0       # (the fused launches are for >= 1024 rows by default)
         g1, names1 = grads()
         bbm._WGRAD_DUAL, bbm._WGRAD_GROUP = False, False
         g0, names0 = grads()
     finally:
-        bbm._WGRAD_DUAL, bbm._WGRAD_GROUP = old
+        bbm._WGRAD_DUAL, bbm._WGRAD_GROUP, bbm._WGRAD_MIN_ROWS = old
     assert names1.count('gemm_tn_dual_bf16') == depth + depth // 2 and 'gemm_tn_dual_bf16' not in names0
     assert names1.count('gemm_tn_group_bf16') == depth and 'gemm_tn_group_bf16' not in names0      # 8 weight gradients per layer = one full group
     # per layer 8 branch gradients (4 audio + 4 text); layer 0: 4 cross blocks; layer 1: 2 cross blocks (no audio_to_text) + 2 skip blocks
