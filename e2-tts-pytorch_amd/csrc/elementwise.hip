@@ -319,6 +319,7 @@ struct ConvArgs {
     float* ws;          // backward: per-workgroup (dw, dbias) partials [b][channel tile][x][64][ks + 1], or NULL (atomics)
     int B, N, C, tiles_per_block;
     int tune;           // backward tuning / ablation bits (e2k_dwconv_bwd `split` argument >> 1): 1 = no gradient flush, 2 = no arithmetic; >> 7: workgroups per (channel tile, batch)
+    int defer_reduce;      // backward: leave the (dw, dbias) partials in ws, e2k_dwconv_bwd_reduce sums them later
 };
 
 template <int KS>
@@ -553,7 +554,7 @@ template <int KS> int launch_conv(ConvArgs a, bool bwd, hipStream_t st) {
         {
             grid.x = (ntiles + a.tiles_per_block - 1) / a.tiles_per_block;
             hipLaunchKernelGGL(dwconv_bwd_kernel<KS>, grid, block, 0, st, a);
-            if (a.ws && !(a.tune & 1))
+            if (a.ws && !(a.tune & 1) && !a.defer_reduce)
                 hipLaunchKernelGGL(conv_reduce_kernel, dim3(a.C / CTC, (CTC * (KS + 1) + 255) / 256), dim3(256), 0, st,
                                    (const float*)a.ws, a.dw, a.dbias, a.B, a.C / CTC, (int)grid.x, KS);
         }
@@ -697,17 +698,33 @@ static int dwconv_bwd_impl(const void* dy, const void* pre, const void* x, const
                               void* dx, float* dw, float* dbias, float* ws, int B, int N, int C, int ks, int split, void* stream) {
     if (B <= 0 || N <= 0) return 0;
     if (C % CTC) return E2K_ERR_SHAPE;
-    if (split & 1) return E2K_ERR_ARG;          // (the two-kernel form of round 1 is gone: it was slower and used LDS float atomics)
+    if ((split & 1) && !ws) return E2K_ERR_ARG;     // bit 0: the caller sums the partials later (e2k_dwconv_bwd_reduce): needs the workspace
     ConvArgs a{};
     a.x = (const bf16_t*)x; a.mask = mask; a.w = w; a.pre = (bf16_t*)pre; a.dy = (const bf16_t*)dy;
-    a.dx = (bf16_t*)dx; a.dw = dw; a.dbias = dbias; a.ws = ws; a.B = B; a.N = N; a.C = C; a.tune = split >> 1;
+    a.dx = (bf16_t*)dx; a.dw = dw; a.dbias = dbias; a.ws = ws; a.B = B; a.N = N; a.C = C; a.tune = split >> 1; a.defer_reduce = split & 1;
     int rc = dispatch_conv(a, ks, true, (hipStream_t)stream);
     if (rc) return rc;
     E2K_CHECK_LAUNCH();
     return 0;
 }
 
+// second half of e2k_dwconv_bwd(split bit 0): sums the per-workgroup (dw, dbias) partials of ws into dw / dbias.  Nothing on
+// the backward chain reads them: the schedule runs it with the weight-gradient GEMMs on the WGRAD lane
+static int dwconv_bwd_reduce_impl(const float* ws, float* dw, float* dbias, int B, int N, int C, int ks, int split, void* stream) {
+    if (B <= 0 || N <= 0) return 0;
+    if (!ws || !dw || !dbias || (C % CTC) || !(ks == 31 || ks == 15 || ks == 7 || ks == 3)) return E2K_ERR_ARG;
+    const int gx = conv_bwd_gx(B, N, C, split >> 1);
+    hipLaunchKernelGGL(conv_reduce_kernel, dim3(C / CTC, (CTC * (ks + 1) + 255) / 256), dim3(256), 0, (hipStream_t)stream,
+                       ws, dw, dbias, B, C / CTC, gx, ks);
+    E2K_CHECK_LAUNCH();
+    return 0;
+}
+
 // ---- C ABI: every compute entry point goes through e2k::dispatch (plan.h) so that a launch plan can record it
+
+extern "C" int e2k_dwconv_bwd_reduce(const float* ws, float* dw, float* dbias, int B, int N, int C, int ks, int split, void* stream) {
+    return e2k::dispatch("dwconv_bwd_reduce", dwconv_bwd_reduce_impl, ws, dw, dbias, B, N, C, ks, split, stream);
+}
 
 extern "C" int e2k_rmsnorm_fwd(const void* x, const float* gamma, int64_t ldg, float gamma_off, int rows_per_batch,
                                void* y, float* rn, int M, int D, void* stream) {

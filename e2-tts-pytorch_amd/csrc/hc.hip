@@ -651,7 +651,7 @@ static int hc_bwd_impl(const void* Xin, const void* yprev, const float* coef_pre
     HC_DISPATCH_BWD(D, launch_bwd, a, has_depth != 0, has_width != 0, grid, (hipStream_t)stream);
     if (rc) return rc;
     E2K_CHECK_LAUNCH();
-    if (has_width) {
+    if (has_width == 1) {            // (has_width == 2: the caller runs e2k_hc_bwd_reduce later, e.g. on another stream)
         HCReduceArgs r;
         r.partial = partial; r.nblocks = grid; r.D = D; r.hp = a.hp;
         r.g_static_beta = g_static_beta; r.g_static_alpha = g_static_alpha; r.g_dyn_alpha_fn = g_dyn_alpha_fn;
@@ -660,6 +660,25 @@ static int hc_bwd_impl(const void* Xin, const void* yprev, const float* coef_pre
         hipLaunchKernelGGL(hc_reduce_kernel, dim3(D / 32 + 1, RSPLIT), dim3(256), 0, (hipStream_t)stream, r);
         E2K_CHECK_LAUNCH();
     }
+    return 0;
+}
+
+// second half of e2k_hc_bwd(has_width = 2): the per-workgroup partials -> parameter gradients.  Nothing on the backward chain
+// reads these gradients, so the schedule runs it with the weight-gradient GEMMs on the WGRAD lane
+static int hc_bwd_reduce_impl(const float* partial, const float* dyn_alpha_fn, const float* dyn_beta_fn, const float* gamma,
+                              float* g_static_beta, float* g_static_alpha, float* g_dyn_alpha_fn, float* g_dyn_alpha_scale,
+                              float* g_dyn_beta_fn, float* g_dyn_beta_scale, float* g_gamma, int Mtok, int D, void* stream) {
+    if (Mtok <= 0) return 0;
+    if (!partial || !gamma || !g_gamma || !dyn_alpha_fn || !dyn_beta_fn) return E2K_ERR_ARG;
+    if (D % 32) return E2K_ERR_SHAPE;
+    HCReduceArgs r;
+    r.partial = partial; r.nblocks = grid_for(Mtok, D, 768, true); r.D = D;
+    r.hp = HCParams{nullptr, nullptr, dyn_alpha_fn, nullptr, dyn_beta_fn, nullptr, gamma};
+    r.g_static_beta = g_static_beta; r.g_static_alpha = g_static_alpha; r.g_dyn_alpha_fn = g_dyn_alpha_fn;
+    r.g_dyn_alpha_scale = g_dyn_alpha_scale; r.g_dyn_beta_fn = g_dyn_beta_fn; r.g_dyn_beta_scale = g_dyn_beta_scale;
+    r.g_gamma = g_gamma;
+    hipLaunchKernelGGL(hc_reduce_kernel, dim3(D / 32 + 1, RSPLIT), dim3(256), 0, (hipStream_t)stream, r);
+    E2K_CHECK_LAUNCH();
     return 0;
 }
 
@@ -681,4 +700,10 @@ extern "C" int e2k_hc_bwd(const void* Xin, const void* yprev, const float* coef_
                           float* g_dyn_alpha_scale, float* g_dyn_beta_fn, float* g_dyn_beta_scale, float* g_gamma,
                           float* partial, int Mtok, int D, int has_depth, int has_width, void* stream) {
     return e2k::dispatch("hc_bwd", hc_bwd_impl, Xin, yprev, coef_prev, G, dbin, ycur, coef, dR, dyprev, static_beta, static_alpha, dyn_alpha_fn, dyn_alpha_scale, dyn_beta_fn, dyn_beta_scale, gamma, g_static_beta, g_static_alpha, g_dyn_alpha_fn, g_dyn_alpha_scale, g_dyn_beta_fn, g_dyn_beta_scale, g_gamma, partial, Mtok, D, has_depth, has_width, stream);
+}
+
+extern "C" int e2k_hc_bwd_reduce(const float* partial, const float* dyn_alpha_fn, const float* dyn_beta_fn, const float* gamma,
+                                 float* g_static_beta, float* g_static_alpha, float* g_dyn_alpha_fn, float* g_dyn_alpha_scale,
+                                 float* g_dyn_beta_fn, float* g_dyn_beta_scale, float* g_gamma, int Mtok, int D, void* stream) {
+    return e2k::dispatch("hc_bwd_reduce", hc_bwd_reduce_impl, partial, dyn_alpha_fn, dyn_beta_fn, gamma, g_static_beta, g_static_alpha, g_dyn_alpha_fn, g_dyn_alpha_scale, g_dyn_beta_fn, g_dyn_beta_scale, g_gamma, Mtok, D, stream);
 }

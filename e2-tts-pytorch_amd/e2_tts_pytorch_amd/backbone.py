@@ -1162,6 +1162,11 @@ class Transformer(Module):
         hold = [[], []]           # operands of the weight-gradient GEMMs of [this layer, the layer before]
 
         pending = []              # (a, b, out, colsum, colsum_from) of the layer being walked, launched as ONE group at its end
+        # parameter-gradient reductions of the hyper-connection and depthwise-conv backward kernels (per-workgroup partials ->
+        # gradients): nothing on the chain reads them, so with the WGRAD lane they leave the chain and run there at the end of
+        # the layer (192 small launches per cfg3 step, each behind a launch gap on MAIN / TEXT otherwise)
+        reduces = []
+        defer_reduces = _DEFER_REDUCES and Ln.has(ops.WGRAD)
 
         def wgrad(a, b, out, colsum=None, colsum_from=0):
             """out += a^T b for a parameter gradient: nothing on the chain reads it, so it goes to the WGRAD lane -- and, since
@@ -1184,6 +1189,14 @@ class Transformer(Module):
 
         def flush_wgrads():
             """launch what `pending` holds (end of a layer: before its slab goes to the data-parallel hook)"""
+            if reduces:
+                Ln.fence(ops.MAIN, ops.WGRAD)
+                Ln.fence(ops.TEXT, ops.WGRAD)
+                with Ln.lane(ops.WGRAD):
+                    for fn in reduces:
+                        fn()
+                hold[0].append(list(reduces))        # (the closures keep the partial buffers alive until the lane has been waited for)
+                reduces.clear()
             if not pending:
                 return
             probs = list(pending)
@@ -1228,7 +1241,7 @@ class Transformer(Module):
                 hg = [G(o, *s) for o, s in zip(rec.hc.offs, rec.hc.shapes)]
                 dR, dyprev = ops.hc_bwd(grads[key], xin=rec.xin, yprev=rec.yprev, coef_prev=rec.coef_prev,
                                         dbin=rec.dbin, ycur=rec.ycur, coef=rec.coef,
-                                        params=self._hc_params(rec.hc), grads=hg)
+                                        params=self._hc_params(rec.hc), grads=hg, deferred=reduces if defer_reduces else None)
                 grads[key] = dR
                 if exists(rec.yprev):
                     rec.prev.dy = dyprev
@@ -1241,7 +1254,7 @@ class Transformer(Module):
                 C, ks = lr.conv.C, lr.conv.ks
                 cw = self._f(lr.conv.w, C * ks).view(C, ks)
                 dbin = ops.dwconv_bwd(rec.dy.view(B, N, C), pre, binp.view(B, N, C), run.mask_n, cw,
-                                      G(lr.conv.w, C, ks), G(lr.conv.b, C))
+                                      G(lr.conv.w, C, ks), G(lr.conv.b, C), deferred=reduces if defer_reduces else None)
                 rec.dbin = dbin.view(Mtok, C)
             elif kind == 'attn':
                 self._attn_bwd(run, ent, G, dvfirst)
@@ -1470,6 +1483,8 @@ _WGRAD_GROUP = _os.environ.get('E2K_WGRAD_GROUP', '1') != '0'
 # below this many token rows the fused weight-gradient launches are not used: they always run the 256 x 256 kernel, whose fixed
 # cost (a 256-KB partial tile per workgroup + the reduce pass) only pays on real sizes
 _WGRAD_MIN_ROWS = int(_os.environ.get('E2K_WGRAD_MIN_ROWS', '1024'))
+# hyper-connection / depthwise-conv parameter-gradient reductions on the WGRAD lane instead of on the chain (E2K_DEFER_REDUCES=0: A/B)
+_DEFER_REDUCES = _os.environ.get('E2K_DEFER_REDUCES', '1') != '0'
 
 _VIEW_OPS = {'view', '_unsafe_view', 'as_strided', 'slice', 'select', 'expand', 't', 'transpose', 'permute', 'unsqueeze', 'squeeze',
              'detach', 'alias', '_reshape_alias', 'reshape', 'split', 'split_with_sizes', 'unbind', 'narrow', 'lift_fresh', 'unfold',

@@ -457,7 +457,57 @@ def _odeint_rk4(fn, y0, t):
     return y
 
 
-_SOLVERS = {'midpoint': _odeint_midpoint, 'euler': _odeint_euler, 'rk4': _odeint_rk4}
+def _odeint_dopri5(fn, y0, t, rtol=1e-5, atol=1e-5):
+    """torchdiffeq.odeint(method='dopri5'), the package's adaptive default (`odeint_kwargs` carries `atol` / `rtol` for it,
+    e2_tts.py:1122-1126,1421): Dormand-Prince 5(4) with first-same-as-last, the mixed error norm
+    rms(err / (atol + rtol max(|y0|, |y1|))), step factors clamped to [0.2, 10] with safety 0.9 and Hairer's starting step.
+    torchdiffeq is not installed here, so this is a restatement of the published method, held to scipy's RK45 and to
+    analytic solutions in tests/test_oracle.py (UNPINNED against the package).  Only the state at t[-1] is needed by
+    sample(): the last step is clamped onto it (torchdiffeq steps past and interpolates; both are within the tolerance)."""
+    c = (1 / 5, 3 / 10, 4 / 5, 8 / 9, 1., 1.)
+    a = ((1 / 5,), (3 / 40, 9 / 40), (44 / 45, -56 / 15, 32 / 9), (19372 / 6561, -25360 / 2187, 64448 / 6561, -212 / 729),
+         (9017 / 3168, -355 / 33, 46732 / 5247, 49 / 176, -5103 / 18656), (35 / 384, 0., 500 / 1113, 125 / 192, -2187 / 6784, 11 / 84))
+    e = (35 / 384 - 5179 / 57600, 0., 500 / 1113 - 7571 / 16695, 125 / 192 - 393 / 640, -2187 / 6784 + 92097 / 339200, 11 / 84 - 187 / 2100, -1 / 40)
+
+    def norm(x):
+        return float(x.double().pow(2).mean().sqrt())
+    t0, t1 = float(t[0]), float(t[-1])
+    tt = lambda v: torch.as_tensor(v, dtype=t.dtype, device=t.device)
+    y, f0 = y0, fn(tt(t0), y0)
+    # starting step (Hairer, Norsett, Wanner I, II.4)
+    sc = atol + rtol * y.abs()
+    d0, d1 = norm(y / sc), norm(f0 / sc)
+    h0 = 1e-6 if d0 < 1e-5 or d1 < 1e-5 else 0.01 * d0 / d1
+    f1 = fn(tt(t0 + h0), y + h0 * f0)
+    d2 = norm((f1 - f0) / sc) / h0
+    h = min(100 * h0, max(1e-6, h0 * 1e-3) if max(d1, d2) <= 1e-15 else (0.01 / max(d1, d2)) ** (1 / 5))
+    tc, k1, nfe = t0, f0, 2
+    while tc < t1 - 1e-12:
+        h = min(h, t1 - tc)
+        ks = [k1]
+        for ci, ai in zip(c, a):
+            yi = y
+            for aij, kj in zip(ai, ks):
+                if aij:
+                    yi = yi + (h * aij) * kj
+            ks.append(fn(tt(tc + ci * h), yi))
+        nfe += 6
+        y_new = yi                                        # (the last stage is the 5th-order solution: first same as last)
+        err = sum((h * ej) * kj for ej, kj in zip(e, ks) if ej)
+        ratio = norm(err / (atol + rtol * torch.maximum(y.abs(), y_new.abs())))
+        if ratio <= 1.:
+            tc, y, k1 = tc + h, y_new, ks[-1]
+        factor = 10. if ratio == 0. else min(10., max(0.2, 0.9 * ratio ** -0.2))
+        h = h * factor
+        assert nfe < 100000, 'dopri5: step size underflow'
+    return y
+
+
+def _adaptive(fn, y0, t, kw):
+    return _odeint_dopri5(fn, y0, t, rtol=kw.get('rtol', 1e-5), atol=kw.get('atol', 1e-5))
+
+
+_SOLVERS = {'midpoint': _odeint_midpoint, 'euler': _odeint_euler, 'rk4': _odeint_rk4, 'dopri5': _odeint_dopri5}
 
 
 class E2TTS(Module):
@@ -487,7 +537,7 @@ class E2TTS(Module):
         if num_freq_tokens != 1:
             raise NotImplementedError('num_freq_tokens > 1 (has_freq_axis) is not built')
         if odeint_kwargs.get('method', 'midpoint') not in _SOLVERS:
-            raise NotImplementedError(f'fixed-grid solvers {sorted(_SOLVERS)} are built (the reference default is midpoint); '
+            raise NotImplementedError(f'solvers {sorted(_SOLVERS)} are built (the reference default is midpoint; dopri5 = torchdiffeq\'s adaptive default); '
                                       'adaptive torchdiffeq methods are not')
         self.num_freq_tokens, self.has_freq_axis = 1, False
         if isinstance(transformer, dict):
@@ -608,7 +658,8 @@ class E2TTS(Module):
 
         y0 = _y0 if exists(_y0) else torch.randn_like(cond)
         t = torch.linspace(0, 1, steps, device=self.device)
-        sampled = _SOLVERS[self.odeint_kwargs.get('method', 'midpoint')](fn, y0, t)
+        method = self.odeint_kwargs.get('method', 'midpoint')
+        sampled = _adaptive(fn, y0, t, self.odeint_kwargs) if method == 'dopri5' else _SOLVERS[method](fn, y0, t)
         out = torch.where(cond_mask, cond, sampled)
         if exists(return_raw_output) and return_raw_output:
             return out

@@ -438,9 +438,11 @@ def hc_fwd(xin, params, *, yprev=None, coef_prev=None, width=True):
     return mout, binp, coef
 
 
-def hc_bwd(G, *, xin=None, yprev=None, coef_prev=None, dbin=None, ycur=None, coef=None, params=None, grads=None):
+def hc_bwd(G, *, xin=None, yprev=None, coef_prev=None, dbin=None, ycur=None, coef=None, params=None, grads=None, deferred=None):
     """Backward of hc_fwd. width iff coef is given; depth iff yprev is given.
-    Returns (dR, dyprev); with width=False dR is G itself."""
+    Returns (dR, dyprev); with width=False dR is G itself.  deferred (a list): the reduction of the per-workgroup partials
+    into the parameter gradients is NOT launched; a zero-argument callable that launches it (on whatever stream is current
+    then) is appended instead"""
     _chk(G, xin, yprev, coef_prev, dbin, ycur, coef)
     Mtok, S, D = G.shape
     width, depth = coef is not None, yprev is not None
@@ -454,8 +456,12 @@ def hc_bwd(G, *, xin=None, yprev=None, coef_prev=None, dbin=None, ycur=None, coe
     ps = [_p(t) for t in params] if width else [None] * 7
     gs = [_p(t) for t in grads] if width else [None] * 7
     lib.e2k_hc_bwd(_p(xin), _p(yprev), _p(coef_prev), _p(G), _p(dbin), _p(ycur), _p(coef),
-                   _p(dR) if width else None, _p(dyprev), *ps, *gs, _p(partial), Mtok, D, int(depth), int(width),
-                   _stream(G))
+                   _p(dR) if width else None, _p(dyprev), *ps, *gs, _p(partial), Mtok, D, int(depth),
+                   (2 if deferred is not None else 1) if width else 0, _stream(G))
+    if width and deferred is not None:
+        def reduce_(partial=partial, params=params, grads=grads, Mtok=Mtok, D=D):
+            lib.e2k_hc_bwd_reduce(_p(partial), _p(params[2]), _p(params[4]), _p(params[6]), *[_p(t) for t in grads], Mtok, D, _stream(partial))
+        deferred.append(reduce_)
     return dR, dyprev
 
 
@@ -590,7 +596,8 @@ def dwconv_fwd(x, mask, w, bias):
 dwconv_bwd_workspace = True
 
 
-def dwconv_bwd(dy, pre, x, mask, w, dw, dbias):
+def dwconv_bwd(dy, pre, x, mask, w, dw, dbias, deferred=None):
+    """deferred (a list): the sum of the (dw, dbias) partials is not launched; a callable that launches it is appended"""
     _chk(dy, pre, x, mask, w, dw, dbias)
     B, N, C = x.shape
     ks = w.shape[-1]
@@ -598,8 +605,13 @@ def dwconv_bwd(dy, pre, x, mask, w, dw, dbias):
     dx = torch.empty_like(x)
     L = _lib.get()
     ws = torch.empty((L.e2k_query_dwconv_bwd_ws_floats(B, N, C, ks),), dtype=f32, device=x.device) if dwconv_bwd_workspace else None
+    defer = deferred is not None and ws is not None
     L.e2k_dwconv_bwd(_p(dy), _p(pre), _p(x), _p(mask), _p(w), _p(dx), _p(dw), _p(dbias), _p(ws), B, N, C, ks,
-                     0, _stream(x))
+                     1 if defer else 0, _stream(x))
+    if defer:
+        def reduce_(ws=ws, dw=dw, dbias=dbias):
+            L.e2k_dwconv_bwd_reduce(_p(ws), _p(dw), _p(dbias), B, N, C, ks, 1, _stream(ws))
+        deferred.append(reduce_)
     return dx
 
 

@@ -123,6 +123,12 @@ int e2k_hc_bwd(const void* Xin, const void* yprev, const float* coef_prev, const
                const float* gamma, float* g_static_beta, float* g_static_alpha, float* g_dyn_alpha_fn,
                float* g_dyn_alpha_scale, float* g_dyn_beta_fn, float* g_dyn_beta_scale, float* g_gamma,
                float* partial, int Mtok, int D, int has_depth, int has_width, void* stream);
+/* has_width = 2 in the call above leaves the per-workgroup partials in `partial` and does NOT launch the reduction into the
+ * parameter gradients; this is that second half (same Mtok, D, partial).  Nothing on the backward chain reads these
+ * gradients, so a schedule can run it off the chain (the WGRAD launch lane). */
+int e2k_hc_bwd_reduce(const float* partial, const float* dyn_alpha_fn, const float* dyn_beta_fn, const float* gamma,
+                      float* g_static_beta, float* g_static_alpha, float* g_dyn_alpha_fn, float* g_dyn_alpha_scale,
+                      float* g_dyn_beta_fn, float* g_dyn_beta_scale, float* g_gamma, int Mtok, int D, void* stream);
 
 /* ---- RMSNorm / AdaptiveRMSNorm (x_transformers; e2_tts.py:615,637,645,688,691,729,908,937) ----
  * y[m] = x[m] / max(|x[m]|, 1e-12) * sqrt(D) * (gamma[m / rows_per_batch] + gamma_off);  rn[m] = 1 / max(|x[m]|, 1e-12)
@@ -180,11 +186,13 @@ int e2k_dwconv_fwd(const void* x, const uint8_t* mask, const float* w, const flo
                    void* y, int B, int N, int C, int ks, void* stream);
 /* dx, and dw / dbias ACCUMULATED (fp32).  ws: scratch of e2k_query_dwconv_bwd_ws_floats(B, N, C, ks) floats for the
  * per-workgroup (dw, dbias) partials (NULL: global fp32 atomics instead, ~1.3x slower at the cfg3 shapes).
- * split: bit 0 must be 0 (round 1's two-kernel form is gone); bits 1..: tuning / ablation (2 = no gradient flush,
+ * split: bit 0 = leave the partials in ws and do not sum them: the caller runs e2k_dwconv_bwd_reduce(ws, ...) with the same
+ * B, N, C, ks, split later (off the backward chain); bits 1..: tuning / ablation (2 = no gradient flush,
  * 4 = loads and staging only -- WRONG results; >> 8: workgroups per channel tile and batch) */
 int e2k_query_dwconv_bwd_ws_floats(int B, int N, int C, int ks);
 int e2k_dwconv_bwd(const void* dy, const void* pre, const void* x, const uint8_t* mask, const float* w,
                    void* dx, float* dw, float* dbias, float* ws, int B, int N, int C, int ks, int split, void* stream);
+int e2k_dwconv_bwd_reduce(const float* ws, float* dw, float* dbias, int B, int N, int C, int ks, int split, void* stream);
 
 /* ---- attention (x_transformers.Attention, call sites e2_tts.py:875,911; dim_head = 64) ----
  * qkvg (B*N, ldq) bf16 = fused projection output, columns [q (H*64) | k | v | head-gate logits (H) | value-residual

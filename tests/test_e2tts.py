@@ -327,6 +327,30 @@ def test_sample_other_fixed_grid_solvers(dev, method):
     assert rel2(s, s_r) < 2e-2, rel2(s, s_r)
 
 
+@pytest.mark.late
+def test_sample_adaptive_dopri5(dev):
+    """odeint_kwargs(method='dopri5', atol, rtol) -- torchdiffeq's adaptive default, which the reference forwards to odeint
+    (e2_tts.py:1122-1126,1421): the adaptive solution agrees with a fine fixed-grid midpoint integration of the SAME model
+    (the HIP path's own vector field), tighter tolerance = closer"""
+    from e2_tts_pytorch_amd import E2TTS
+    kw = dict(dim=256, depth=2, heads=4, dropout=0.)
+    random.seed(5)
+    torch.manual_seed(5)
+    model = E2TTS(transformer=dict(**kw), use_vocos=False, cond_drop_prob=0.)
+    randomize(model)
+    model = model.to(dev).eval()
+    cond = torch.randn(1, 5, 100).to(dev)
+    y0 = torch.randn(1, 12, 100).to(dev)
+    fine = model.sample(cond, text=['solver'], duration=12, steps=17, cfg_strength=0., _y0=y0)
+    errs = []
+    for tol in ((3e-2, 2e-3) if dev == 'cuda' else (2e-3,)):          # (the host model runs ~1 s per function evaluation)
+        model.odeint_kwargs = dict(method='dopri5', atol=tol, rtol=tol)
+        s = model.sample(cond, text=['solver'], duration=12, steps=5, cfg_strength=0., _y0=y0)
+        errs.append(rel2(s, fine))
+    model.odeint_kwargs = dict(method='midpoint')
+    assert errs[-1] < 1e-2 and errs[-1] <= errs[0] + 1e-3, errs
+
+
 def test_duration_predictor(dev):
     from e2_tts_pytorch_amd import DurationPredictor
     random.seed(3)

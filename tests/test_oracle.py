@@ -121,7 +121,7 @@ def test_hyper_connections_against_the_papers_equations_fp64():
     bin_o, add = hc(H)
     out_o = add(y)
     Wa, wb = hc.dynamic_alpha_fn.detach(), hc.dynamic_beta_fn.detach()
-    sa, sb = float(hc.dynamic_alpha_scale), float(hc.dynamic_beta_scale)
+    sa, sb = float(hc.dynamic_alpha_scale.detach()), float(hc.dynamic_beta_scale.detach())
     A, B, gam = hc.static_alpha.detach(), hc.static_beta.detach(), hc.norm.gamma.detach()
     for bi in range(b):
         for ni in range(n):
@@ -339,3 +339,30 @@ def test_reference_golden_sample_and_duration():
     m.eval()
     with torch.no_grad():
         assert _maxrel(m(c['mel'], text=c['text'], lens=c['lens'], return_loss=False), c['pred']) < 1e-5
+
+
+def test_dopri5_against_scipy_and_analytic():
+    """the adaptive solver behind odeint_kwargs(method='dopri5', atol, rtol) -- torchdiffeq's default, restated from the
+    published Dormand-Prince 5(4) scheme because the package is not installed -- against scipy's RK45 (the same tableau,
+    an independent implementation) and analytic solutions: a decaying oscillator system and a stiff-ish scalar problem"""
+    import numpy as np
+    from scipy.integrate import solve_ivp
+    from e2_tts_pytorch_amd.e2_tts import _odeint_dopri5
+    A = torch.tensor([[-0.5, 4.0], [-4.0, -0.5]], dtype=torch.float64)
+    calls = [0]
+
+    def fn(t, y):
+        calls[0] += 1
+        return y @ A.T + torch.sin(3 * t) * torch.tensor([1.0, 0.0], dtype=torch.float64)
+    y0 = torch.tensor([[1.0, 0.0], [0.3, -0.7]], dtype=torch.float64)
+    t = torch.linspace(0, 1, 32, dtype=torch.float64)
+    for tol in (1e-5, 1e-8):
+        calls[0] = 0
+        y = _odeint_dopri5(fn, y0, t, rtol=tol, atol=tol)
+        ref = np.stack([solve_ivp(lambda tt, yy: (A.numpy() @ yy + np.sin(3 * tt) * np.array([1.0, 0.0])), (0., 1.), r.numpy(),
+                                  method='RK45', rtol=1e-12, atol=1e-12).y[:, -1] for r in y0])
+        assert np.abs(y.numpy() - ref).max() < 20 * tol, (tol, np.abs(y.numpy() - ref).max())
+        assert calls[0] < 400                              # (adaptive: tens of steps, not thousands)
+    # scalar decay with a fast rate: exact solution exp(-25 t)
+    y = _odeint_dopri5(lambda t_, y_: -25. * y_, torch.ones(1, dtype=torch.float64), t, rtol=1e-7, atol=1e-9)
+    assert abs(y.item() - math.exp(-25.)) < 1e-8
