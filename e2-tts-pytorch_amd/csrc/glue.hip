@@ -304,6 +304,59 @@ static int cast_pad_bf16_impl(const float* src, int64_t lds_, void* dst, int64_t
     return 0;
 }
 
+// Classifier-free-guidance combine of sample() (e2_tts.py:1303-1330: cfg_transformer_with_pred_head + project):
+//   u = pred - null ;  unit = pred / max(|pred|, 1e-12)  (fp64, per sample over all of its (n, d) elements)
+//   par = (u . unit) unit ;  orth = u - par   (fp64, each rounded to fp32 as `project` returns them)
+//   out = pred + (orth + par * keep_parallel_frac) * cfg_strength          (remove_parallel = 0: out = pred + u * cfg_strength)
+// One workgroup per sample: reduce (fp64), then a second pass over the sample (L2-resident) -- six tensor-library passes and
+// two fp64 copies of the predictions in the reference.
+__global__ __launch_bounds__(256) void cfg_combine_kernel(const float* pred, const float* nul, float* out, long L, float strength,
+                                                          float keep_frac, int remove_parallel) {
+    __shared__ double red[2][4];
+    const long b = blockIdx.x;
+    const float* p = pred + b * L;
+    const float* q = nul + b * L;
+    float* o = out + b * L;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    double coef = 0.0, inv = 0.0;
+    if (remove_parallel) {
+        double up = 0.0, pp = 0.0;
+        for (long i = tid; i < L; i += 256) {
+            const double pv = (double)p[i], uv = (double)(p[i] - q[i]);          // (pred - null is formed in fp32, then widened)
+            up = fma(uv, pv, up);
+            pp = fma(pv, pv, pp);
+        }
+#pragma unroll
+        for (int m = 32; m >= 1; m >>= 1) { up += __shfl_xor(up, m); pp += __shfl_xor(pp, m); }
+        if (lane == 0) { red[0][wave] = up; red[1][wave] = pp; }
+        __syncthreads();
+        up = red[0][0] + red[0][1] + red[0][2] + red[0][3];
+        pp = red[1][0] + red[1][1] + red[1][2] + red[1][3];
+        inv = 1.0 / fmax(sqrt(pp), 1e-12);               // F.normalize(y, dim=-1): y / max(|y|, eps)
+        coef = up * inv;                                   // u . unit
+    }
+    for (long i = tid; i < L; i += 256) {
+        const float pv = p[i], uv = pv - q[i];
+        float upd = uv;
+        if (remove_parallel) {
+            const double par = coef * ((double)pv * inv);
+            const float parf = (float)par, orthf = (float)((double)uv - par);
+            upd = orthf + parf * keep_frac;
+        }
+        o[i] = pv + upd * strength;
+    }
+}
+
+static int cfg_combine_impl(const float* pred, const float* null_pred, float* out, int B, int64_t L, float cfg_strength,
+                            float keep_parallel_frac, int remove_parallel, void* stream) {
+    if (B <= 0 || L <= 0) return 0;
+    if (!pred || !null_pred || !out) return E2K_ERR_ARG;
+    hipLaunchKernelGGL(cfg_combine_kernel, dim3(B), dim3(256), 0, (hipStream_t)stream, pred, null_pred, out, (long)L, cfg_strength,
+                       keep_parallel_frac, remove_parallel);
+    E2K_CHECK_LAUNCH();
+    return 0;
+}
+
 static int masked_mse_fwd_impl(const float* pred, const float* flow, const uint8_t* mask, float* acc, int M, int C, void* stream) {
     if (M <= 0 || C <= 0) return E2K_ERR_SHAPE;
     hipError_t e = hipMemsetAsync(acc, 0, 2 * sizeof(float), (hipStream_t)stream);
@@ -489,4 +542,9 @@ extern "C" int e2k_masked_mse_fwd(const float* pred, const float* flow, const ui
 extern "C" int e2k_masked_mse_bwd(const float* pred, const float* flow, const uint8_t* mask, const float* acc, const float* dloss,
                                   float* dpred, int M, int C, void* stream) {
     return e2k::dispatch("masked_mse_bwd", masked_mse_bwd_impl, pred, flow, mask, acc, dloss, dpred, M, C, stream);
+}
+
+extern "C" int e2k_cfg_combine(const float* pred, const float* null_pred, float* out, int B, int64_t L, float cfg_strength,
+                               float keep_parallel_frac, int remove_parallel, void* stream) {
+    return e2k::dispatch("cfg_combine", cfg_combine_impl, pred, null_pred, out, B, L, cfg_strength, keep_parallel_frac, remove_parallel, stream);
 }

@@ -614,6 +614,9 @@ class E2TTS(Module):
         null_drop_text_cond = not exists(cfg_null_model)
         cfg_null_model = default(cfg_null_model, self)
         null_pred = cfg_null_model.transformer_with_pred_head(*args, drop_text_cond=null_drop_text_cond, **kwargs)
+        if not torch.is_grad_enabled() and pred.dtype == torch.float32 and _on_kernels(pred):
+            # sample(): one kernel for the update, its fp64 projection and the combine
+            return ops.cfg_combine(pred.contiguous(), null_pred.contiguous(), cfg_strength, keep_parallel_frac, remove_parallel_component)
         cfg_update = pred - null_pred
         if remove_parallel_component:
             parallel, orthogonal = project(cfg_update, pred)

@@ -971,3 +971,15 @@ def grad_unpack_bf16(wire, g):
     _chk(g, wire)
     assert g.dtype == f32 and wire.dtype == bf16 and g.is_contiguous() and wire.is_contiguous() and wire.numel() >= g.numel()
     _lib.get().e2k_grad_unpack_bf16(_p(wire), _p(g), g.numel(), _stream(g))
+
+
+def cfg_combine(pred, null_pred, cfg_strength, keep_parallel_frac=0., remove_parallel=True):
+    """pred + cfg_update * cfg_strength with the fp64 parallel-component projection of e2_tts.py:113-124,1303-1330 in one
+    kernel; pred / null_pred (B, ...) fp32 contiguous"""
+    _chk(pred, null_pred)
+    assert pred.dtype == f32 and null_pred.dtype == f32 and pred.is_contiguous() and null_pred.is_contiguous() and pred.shape == null_pred.shape
+    out = torch.empty_like(pred)
+    B = pred.shape[0]
+    _lib.get().e2k_cfg_combine(_p(pred), _p(null_pred), _p(out), B, pred.numel() // B, float(cfg_strength), float(keep_parallel_frac),
+                               int(bool(remove_parallel)), _stream(pred))
+    return out

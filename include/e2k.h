@@ -357,6 +357,12 @@ int e2k_cond_bwd_prep(float* dcond, const float* gates, void* dcb, void* dct, fl
 /* fp32 (R, C), rows lds floats apart -> bf16 (R, ldd) with columns C .. Cpad-1 zeroed: operands of the 100-channel input /
  * output projections (e2_tts.py:1267-1277,1296: proj_in, cond_proj_in, to_pred), whose K is padded to a multiple of 8 */
 int e2k_cast_pad_bf16(const float* src, int64_t lds, void* dst, int64_t ldd, int R, int C, int Cpad, void* stream);
+/* Classifier-free-guidance combine of E2TTS.sample (e2_tts.py:1303-1330 with `project`, :113-124), per sample b over its L
+ * = frames * channels elements, fp32 in / out, the projection in fp64 as the reference does it:
+ *   u = pred - null;  par = (u . unit) unit with unit = pred / max(|pred|, 1e-12);  orth = u - par
+ *   out = pred + (orth + par * keep_parallel_frac) * cfg_strength      (remove_parallel = 0: out = pred + u * cfg_strength) */
+int e2k_cfg_combine(const float* pred, const float* null_pred, float* out, int B, int64_t L, float cfg_strength,
+                    float keep_parallel_frac, int remove_parallel, void* stream);
 /* flow-matching loss (e2_tts.py:1578-1582: F.mse_loss(pred, flow, reduction = 'none')[rand_span_mask].mean()) without the
  * boolean-index gather: acc[0] = sum over masked rows of sum_c (pred - flow)^2, acc[1] = number of masked rows (acc is
  * zeroed by the call); loss = acc[0] / (acc[1] * C).  bwd: dpred = dloss[0] * 2 (pred - flow) mask / (acc[1] * C) */

@@ -485,3 +485,24 @@ def test_reference_golden_sample_front_end(dev):
     out = m.sample(c['wave'].to(dev), text=c['text'], lens=c['lens'].to(dev), steps=c['steps'], cfg_strength=c['cfg_strength'],
                    max_duration=c['max_duration'], cfg_null_model=null, _y0=y0.to(dev))
     assert out.shape == c['out'].shape and rel2(out, c['out']) < 1e-2, rel2(out, c['out'])      # north-star tolerance (bf16)
+
+
+@pytest.mark.parametrize('remove_parallel,keep', [(True, 0.), (True, 0.3), (False, 0.)])
+def test_cfg_combine_kernel(dev, remove_parallel, keep):
+    """One-kernel classifier-free-guidance combine of sample() against the oracle's fp64 `project` + fp32 combine
+    (e2_tts.py:113-124, 1303-1330); tolerance: a few fp32 ulps of the largest term (the kernel forms par / orth in fp64 and
+    rounds each to fp32 like `project` does; only the fp64 summation order differs)."""
+    from e2_tts_pytorch_amd import ops
+    torch.manual_seed(3)
+    pred, nul = torch.randn(3, 37, 100), torch.randn(3, 37, 100)
+    nul[1] = pred[1] * 0.25                                  # a purely parallel update: orthogonal part is rounding noise only
+    upd = pred - nul
+    if remove_parallel:
+        par, orth = O.project(upd, pred)
+        upd = orth + par * keep
+    ref = pred + upd * 2.0
+    got = ops.cfg_combine(pred.to(dev), nul.to(dev), 2.0, keep, remove_parallel).cpu()
+    assert (got - ref).abs().max().item() <= 4e-6 * ref.abs().max().item()
+    # a zero prediction: F.normalize's eps keeps the unit vector finite (0), the update passes through as orthogonal
+    z = ops.cfg_combine(torch.zeros(1, 8, 100, device=dev), nul[:1, :8].contiguous().to(dev), 1.5, keep, remove_parallel).cpu()
+    assert torch.equal(z, -nul[:1, :8] * 1.5)
