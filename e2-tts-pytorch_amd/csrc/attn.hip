@@ -151,6 +151,10 @@ struct PostArgs {
     int B, H, N, Npad;
     // backward
     const bf16_t *dQ, *dK, *dV; const float* dgate_pre; float* dvfirst; bf16_t* dqkvg; int first_layer;
+    // LASER attention (Attention(laser = True), e2_tts.py:543-544,641): the values that enter the attention are
+    // exp(c tanh(v / c)) of the (mixed) values; laser_c = 0 turns it off.  Vorig (first layer only): the values before that
+    // map, which later layers mix in as their value residual
+    float laser_c; bf16_t* Vorig;
 };
 
 __global__ __launch_bounds__(256) void qkv_post_fwd_kernel(PostArgs p) {
@@ -190,6 +194,12 @@ __global__ __launch_bounds__(256) void qkv_post_fwd_kernel(PostArgs p) {
         }
         if (seg == 0) p.gate[bh * p.N + n] = sigmoidf_(bf2f(gp[h]));
         const long o = (bh * p.N + n) * DH + seg * 16;
+        if (p.laser_c > 0.f) {
+            if (p.Vorig) { st<u32x4>(p.Vorig + o, pack8(v)); st<u32x4>(p.Vorig + o + 8, pack8(v + 8)); }
+            const float ic = 1.f / p.laser_c;
+#pragma unroll
+            for (int e = 0; e < 16; ++e) v[e] = __expf(p.laser_c * tanhf_(v[e] * ic));
+        }
         st<u32x4>(p.Q + o, pack8(q)); st<u32x4>(p.Q + o + 8, pack8(q + 8));
         st<u32x4>(p.K + o, pack8(k)); st<u32x4>(p.K + o + 8, pack8(k + 8));
         st<u32x4>(p.V + o, pack8(v)); st<u32x4>(p.V + o + 8, pack8(v + 8));
@@ -237,13 +247,27 @@ __global__ __launch_bounds__(256) void qkv_post_bwd_kernel(PostArgs p) {
         dk[2 * j] = b0 * c + b1 * s;  dk[2 * j + 1] = b1 * c - b0 * s;
     }
     bf16_t* drow = p.dqkvg + ((long)b * p.N + n) * p.ldq;
-    if (p.vfirst) {
-        const float mx = p.mix[bh * p.N + n];
-        float v[16], vf[16];
+    float v[16], vf[16];
+    if (p.vfirst || p.laser_c > 0.f) {
         const bf16_t* vrow = p.qkvg + ((long)b * p.N + n) * p.ldq + 2 * I + h * DH + seg * 16;
         unpack8(ld<u32x4>(vrow), v); unpack8(ld<u32x4>(vrow + 8), v + 8);
+    }
+    if (p.vfirst) {
         const bf16_t* vr = p.vfirst + o;
         unpack8(ld<u32x4>(vr), vf); unpack8(ld<u32x4>(vr + 8), vf + 8);
+    }
+    if (p.laser_c > 0.f) {
+        // d(mixed value) = d(exp(c tanh(vm / c))) = dV' V' (1 - tanh^2), vm recomputed from the projection row (and the mix)
+        const float mxl = p.vfirst ? p.mix[bh * p.N + n] : 1.f, ic = 1.f / p.laser_c;
+#pragma unroll
+        for (int e = 0; e < 16; ++e) {
+            const float vm = p.vfirst ? vf[e] + mxl * (v[e] - vf[e]) : v[e];
+            const float t = tanhf_(vm * ic);
+            dv[e] *= __expf(p.laser_c * t) * (1.f - t * t);
+        }
+    }
+    if (p.vfirst) {
+        const float mx = p.mix[bh * p.N + n];
         float* dvf = p.dvfirst + o;
         float dmix = 0.f;
         f32x4 acc4[4];                  // fp32 accumulator of d(v_first) over the layers: 16-byte read-modify-write
@@ -1367,15 +1391,95 @@ __global__ __launch_bounds__(256, 3) void attn_bwd_dkv_ring_kernel(AttnArgs p) {
     }
 }
 
+// LASER output map (x-transformers Attention(laser = True): `out = log(out)` between the attention and the head gates):
+//   forward   Og = log(max(O, 1e-20)) gate          (0 on masked query rows; O = the attention's un-gated output)
+//   backward  dOin = dOg / O  (0 where O <= 1e-20), which the ordinary attention backward turns into dO = dOin gate;
+//             dgate_pre = sum_d dOg log(max(O, 1e-20)) gate (1 - gate)   (replaces the attention backward's own)
+// 8 lanes per (token, head), 8 channels each.
+struct LaserArgs {
+    const bf16_t* O; const float* gate; const uint8_t* kmask; bf16_t* Og;
+    const bf16_t* dOg; bf16_t* dOin; float* dgate_pre;
+    int B, H, N, Npad;
+};
+
+template <bool BWD>
+__global__ __launch_bounds__(256) void laser_out_kernel(LaserArgs p) {
+    const long t = (long)blockIdx.x * 256 + threadIdx.x;
+    const long total = (long)p.B * p.N * p.H * 8;
+    const bool live = t < total;
+    const long tt = live ? t : total - 1;
+    const int c8 = (int)(tt & 7);
+    const long rh = tt >> 3;
+    const int h = (int)(rh % p.H);
+    const long row = rh / p.H;
+    const int b = (int)(row / p.N), n = (int)(row - (long)b * p.N);
+    const bool keep = p.kmask[(long)b * p.Npad + n] != 0;
+    const float g = p.gate[((long)b * p.H + h) * p.N + n];
+    const long off = row * ((long)p.H * DH) + h * DH + c8 * 8;
+    float o[8], lo[8];
+    unpack8(ld<u32x4>(p.O + off), o);
+#pragma unroll
+    for (int k = 0; k < 8; ++k) lo[k] = __logf(fmaxf(o[k], 1e-20f));
+    if (!BWD) {
+        float y[8];
+#pragma unroll
+        for (int k = 0; k < 8; ++k) y[k] = keep ? lo[k] * g : 0.f;
+        if (live) st<u32x4>(p.Og + off, pack8(y));
+    } else {
+        float dl[8], di[8], s = 0.f;
+        unpack8(ld<u32x4>(p.dOg + off), dl);
+#pragma unroll
+        for (int k = 0; k < 8; ++k) {
+            di[k] = (keep && o[k] > 1e-20f) ? dl[k] / o[k] : 0.f;
+            s = fmaf(dl[k], lo[k], s);
+        }
+        s += __shfl_xor(s, 1);
+        s += __shfl_xor(s, 2);
+        s += __shfl_xor(s, 4);
+        if (live) {
+            st<u32x4>(p.dOin + off, pack8(di));
+            if (c8 == 0) p.dgate_pre[((long)b * p.H + h) * p.N + n] = keep ? s * g * (1.f - g) : 0.f;
+        }
+    }
+}
+
 }  // namespace
+
+static int laser_out_fwd_impl(const void* O, const float* gate, const uint8_t* kmask, void* Og, int B, int H, int N, int Npad, void* stream) {
+    if (B <= 0 || N <= 0 || H <= 0) return 0;
+    if (!O || !gate || !kmask || !Og) return E2K_ERR_ARG;
+    if (Npad < N) return E2K_ERR_SHAPE;
+    LaserArgs a{};
+    a.O = (const bf16_t*)O; a.gate = gate; a.kmask = kmask; a.Og = (bf16_t*)Og; a.B = B; a.H = H; a.N = N; a.Npad = Npad;
+    const long total = (long)B * N * H * 8;
+    hipLaunchKernelGGL(laser_out_kernel<false>, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, (hipStream_t)stream, a);
+    E2K_CHECK_LAUNCH();
+    return 0;
+}
+
+static int laser_out_bwd_impl(const void* dOg, const void* O, const float* gate, const uint8_t* kmask, void* dOin, float* dgate_pre,
+                              int B, int H, int N, int Npad, void* stream) {
+    if (B <= 0 || N <= 0 || H <= 0) return 0;
+    if (!dOg || !O || !gate || !kmask || !dOin || !dgate_pre) return E2K_ERR_ARG;
+    if (Npad < N) return E2K_ERR_SHAPE;
+    LaserArgs a{};
+    a.O = (const bf16_t*)O; a.gate = gate; a.kmask = kmask; a.dOg = (const bf16_t*)dOg; a.dOin = (bf16_t*)dOin; a.dgate_pre = dgate_pre;
+    a.B = B; a.H = H; a.N = N; a.Npad = Npad;
+    const long total = (long)B * N * H * 8;
+    hipLaunchKernelGGL(laser_out_kernel<true>, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, (hipStream_t)stream, a);
+    E2K_CHECK_LAUNCH();
+    return 0;
+}
 
 static int qkv_post_fwd_impl(const void* qkvg, int64_t ldq, const float* cosb, const float* sinb, const void* vfirst,
                                 void* Q, void* K, void* V, void* QT, void* KT, void* VT, float* gate, float* mix,
-                                int B, int H, int N, int Npad, void* stream) {
+                                void* v_orig, float laser_clamp, int B, int H, int N, int Npad, void* stream) {
     if (B <= 0 || N <= 0) return 0;
     if ((ldq & 7) || (Npad & 63) || Npad < N) return E2K_ERR_ALIGN;
     if (!qkvg || !cosb || !sinb || !Q || !K || !V || !VT || !gate || (vfirst && !mix)) return E2K_ERR_ARG;     // (QT, KT: optional)
+    if (laser_clamp < 0.f || (v_orig && !(laser_clamp > 0.f))) return E2K_ERR_ARG;
     PostArgs a{};
+    a.laser_c = laser_clamp; a.Vorig = (bf16_t*)v_orig;
     a.qkvg = (const bf16_t*)qkvg; a.ldq = ldq; a.cosb = cosb; a.sinb = sinb; a.vfirst = (const bf16_t*)vfirst;
     a.Q = (bf16_t*)Q; a.K = (bf16_t*)K; a.V = (bf16_t*)V; a.QT = (bf16_t*)QT; a.KT = (bf16_t*)KT; a.VT = (bf16_t*)VT;
     a.gate = gate; a.mix = mix; a.B = B; a.H = H; a.N = N; a.Npad = Npad;
@@ -1387,11 +1491,13 @@ static int qkv_post_fwd_impl(const void* qkvg, int64_t ldq, const float* cosb, c
 static int qkv_post_bwd_impl(const void* dQ, const void* dK, const void* dV, const float* dgate_pre,
                                 const void* qkvg, int64_t ldq, const float* cosb, const float* sinb,
                                 const void* vfirst, const float* mix, float* dvfirst, int first_layer, void* dqkvg,
-                                int B, int H, int N, void* stream) {
+                                float laser_clamp, int B, int H, int N, void* stream) {
     if (B <= 0 || N <= 0) return 0;
     if (ldq & 7) return E2K_ERR_ALIGN;
     if (!dQ || !dK || !dV || !dgate_pre || !cosb || !sinb || !dqkvg || (vfirst && (!mix || !dvfirst || !qkvg))) return E2K_ERR_ARG;
+    if (laser_clamp < 0.f || (laser_clamp > 0.f && !qkvg)) return E2K_ERR_ARG;
     PostArgs a{};
+    a.laser_c = laser_clamp;
     a.dQ = (const bf16_t*)dQ; a.dK = (const bf16_t*)dK; a.dV = (const bf16_t*)dV; a.dgate_pre = dgate_pre;
     a.qkvg = (const bf16_t*)qkvg; a.ldq = ldq; a.cosb = cosb; a.sinb = sinb; a.vfirst = (const bf16_t*)vfirst;
     a.mix = const_cast<float*>(mix); a.dvfirst = dvfirst; a.first_layer = first_layer; a.dqkvg = (bf16_t*)dqkvg;
@@ -1505,15 +1611,15 @@ static int attn_bwd_impl(const void* dOg, const void* O, const float* gate, cons
 
 extern "C" int e2k_qkv_post_fwd(const void* qkvg, int64_t ldq, const float* cosb, const float* sinb, const void* vfirst,
                                 void* Q, void* K, void* V, void* QT, void* KT, void* VT, float* gate, float* mix,
-                                int B, int H, int N, int Npad, void* stream) {
-    return e2k::dispatch("qkv_post_fwd", qkv_post_fwd_impl, qkvg, ldq, cosb, sinb, vfirst, Q, K, V, QT, KT, VT, gate, mix, B, H, N, Npad, stream);
+                                void* v_orig, float laser_clamp, int B, int H, int N, int Npad, void* stream) {
+    return e2k::dispatch("qkv_post_fwd", qkv_post_fwd_impl, qkvg, ldq, cosb, sinb, vfirst, Q, K, V, QT, KT, VT, gate, mix, v_orig, laser_clamp, B, H, N, Npad, stream);
 }
 
 extern "C" int e2k_qkv_post_bwd(const void* dQ, const void* dK, const void* dV, const float* dgate_pre,
                                 const void* qkvg, int64_t ldq, const float* cosb, const float* sinb,
                                 const void* vfirst, const float* mix, float* dvfirst, int first_layer, void* dqkvg,
-                                int B, int H, int N, void* stream) {
-    return e2k::dispatch("qkv_post_bwd", qkv_post_bwd_impl, dQ, dK, dV, dgate_pre, qkvg, ldq, cosb, sinb, vfirst, mix, dvfirst, first_layer, dqkvg, B, H, N, stream);
+                                float laser_clamp, int B, int H, int N, void* stream) {
+    return e2k::dispatch("qkv_post_bwd", qkv_post_bwd_impl, dQ, dK, dV, dgate_pre, qkvg, ldq, cosb, sinb, vfirst, mix, dvfirst, first_layer, dqkvg, laser_clamp, B, H, N, stream);
 }
 
 extern "C" int e2k_attn_fwd(const void* Q, const void* K, const void* VT, const uint8_t* kmask, const float* gate,
@@ -1528,4 +1634,13 @@ extern "C" int e2k_attn_bwd(const void* dOg, const void* O, const float* gate, c
                             void* dV, int B, int H, int N, int Npad, float p_drop, uint32_t seed, const uint32_t* seed_dev,
                             uint32_t stream_id, int flags, void* stream) {
     return e2k::dispatch("attn_bwd", attn_bwd_impl, dOg, O, gate, lse2, Q, K, V, QT, KT, kmask, dropbits, dO, dOT, delta, dgate_pre, dQ, dK, dV, B, H, N, Npad, p_drop, seed, seed_dev, stream_id, flags, stream);
+}
+
+extern "C" int e2k_laser_out_fwd(const void* O, const float* gate, const uint8_t* kmask, void* Og, int B, int H, int N, int Npad, void* stream) {
+    return e2k::dispatch("laser_out_fwd", laser_out_fwd_impl, O, gate, kmask, Og, B, H, N, Npad, stream);
+}
+
+extern "C" int e2k_laser_out_bwd(const void* dOg, const void* O, const float* gate, const uint8_t* kmask, void* dOin, float* dgate_pre,
+                                 int B, int H, int N, int Npad, void* stream) {
+    return e2k::dispatch("laser_out_bwd", laser_out_bwd_impl, dOg, O, gate, kmask, dOin, dgate_pre, B, H, N, Npad, stream);
 }

@@ -218,6 +218,53 @@ __global__ __launch_bounds__(256) void colsum_kernel(const bf16_t* x, long ldx, 
     if (col + 1 < N) atomicAdd(out + col + 1, a1);
 }
 
+// ------------------------------------------------------------------------------------------------ LinearFourierEmbed
+
+// LinearFourierEmbed's activation (e2_tts.py:368-386, `attn_fourier_embed_input`): h (M, nf + nrest) = linear(x) ->
+// y (M, 2 nf + nrest) = [sin h[:nf] | cos h[:nf] | h[nf:]].  One thread per 8 output columns (nf, nrest multiples of 8).
+__global__ __launch_bounds__(256) void fourier_cat_fwd_kernel(const bf16_t* h, long ldh, bf16_t* y, long ldy, long M, int nf, int nrest) {
+    const int cv = (2 * nf + nrest) / 8;
+    const long total = M * cv;
+    for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < total; i += (long)gridDim.x * 256) {
+        const long m = i / cv;
+        const int c = (int)(i - m * cv) * 8;
+        const int src = c < nf ? c : (c < 2 * nf ? c - nf : c - nf);
+        float f[8];
+        unpack8(ld<u32x4>(h + m * ldh + src), f);
+        if (c < nf) {
+#pragma unroll
+            for (int k = 0; k < 8; ++k) f[k] = sinf(f[k]);
+        } else if (c < 2 * nf) {
+#pragma unroll
+            for (int k = 0; k < 8; ++k) f[k] = cosf(f[k]);
+        }
+        st<u32x4>(y + m * ldy + c, pack8(f));
+    }
+}
+
+// dh[:nf] = dy_sin cos h - dy_cos sin h ;  dh[nf:] = dy[2 nf:]
+__global__ __launch_bounds__(256) void fourier_cat_bwd_kernel(const bf16_t* dy, long ldy, const bf16_t* h, long ldh, bf16_t* dh, long lddh,
+                                                              long M, int nf, int nrest) {
+    const int cv = (nf + nrest) / 8;
+    const long total = M * cv;
+    for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < total; i += (long)gridDim.x * 256) {
+        const long m = i / cv;
+        const int c = (int)(i - m * cv) * 8;
+        float f[8];
+        if (c < nf) {
+            float hv[8], ds[8], dc[8];
+            unpack8(ld<u32x4>(h + m * ldh + c), hv);
+            unpack8(ld<u32x4>(dy + m * ldy + c), ds);
+            unpack8(ld<u32x4>(dy + m * ldy + nf + c), dc);
+#pragma unroll
+            for (int k = 0; k < 8; ++k) f[k] = ds[k] * cosf(hv[k]) - dc[k] * sinf(hv[k]);
+        } else {
+            unpack8(ld<u32x4>(dy + m * ldy + nf + c), f);
+        }
+        st<u32x4>(dh + m * lddh + c, pack8(f));
+    }
+}
+
 // ------------------------------------------------------------------------------------------------ casts
 
 __global__ __launch_bounds__(256) void cast_bf16_kernel(const float* src, bf16_t* dst, long n) {
@@ -655,6 +702,31 @@ static int colsum_bf16_impl(const void* x, int64_t ldx, float* out, int M, int N
     return 0;
 }
 
+static int fourier_cat_fwd_impl(const void* h, int64_t ldh, void* y, int64_t ldy, int64_t M, int nf, int nrest, void* stream) {
+    if (M <= 0) return 0;
+    if (nf < 0 || nrest < 0 || (nf & 7) || (nrest & 7) || nf + nrest == 0 || (ldh & 7) || (ldy & 7)) return E2K_ERR_SHAPE;
+    if (!h || !y) return E2K_ERR_ARG;
+    if (((uintptr_t)h | (uintptr_t)y) & 15) return E2K_ERR_ALIGN;
+    long g = (M * ((2 * nf + nrest) / 8) + 255) / 256; if (g > 8192) g = 8192;
+    hipLaunchKernelGGL(fourier_cat_fwd_kernel, dim3((int)g), dim3(256), 0, (hipStream_t)stream, (const bf16_t*)h, (long)ldh, (bf16_t*)y,
+                       (long)ldy, (long)M, nf, nrest);
+    E2K_CHECK_LAUNCH();
+    return 0;
+}
+
+static int fourier_cat_bwd_impl(const void* dy, int64_t ldy, const void* h, int64_t ldh, void* dh, int64_t lddh, int64_t M, int nf,
+                                int nrest, void* stream) {
+    if (M <= 0) return 0;
+    if (nf < 0 || nrest < 0 || (nf & 7) || (nrest & 7) || nf + nrest == 0 || (ldh & 7) || (ldy & 7) || (lddh & 7)) return E2K_ERR_SHAPE;
+    if (!dy || !h || !dh) return E2K_ERR_ARG;
+    if (((uintptr_t)dy | (uintptr_t)h | (uintptr_t)dh) & 15) return E2K_ERR_ALIGN;
+    long g = (M * ((nf + nrest) / 8) + 255) / 256; if (g > 8192) g = 8192;
+    hipLaunchKernelGGL(fourier_cat_bwd_kernel, dim3((int)g), dim3(256), 0, (hipStream_t)stream, (const bf16_t*)dy, (long)ldy,
+                       (const bf16_t*)h, (long)ldh, (bf16_t*)dh, (long)lddh, (long)M, nf, nrest);
+    E2K_CHECK_LAUNCH();
+    return 0;
+}
+
 static int cast_bf16_impl(const float* src, void* dst, int64_t n, void* stream) {
     if (n <= 0) return 0;
     if (((uintptr_t)src | (uintptr_t)dst) & 15) return E2K_ERR_ALIGN;
@@ -781,4 +853,13 @@ extern "C" int e2k_query_dwconv_bwd_ws_floats(int B, int N, int C, int ks) {
 extern "C" int e2k_dwconv_bwd(const void* dy, const void* pre, const void* x, const uint8_t* mask, const float* w,
                               void* dx, float* dw, float* dbias, float* ws, int B, int N, int C, int ks, int split, void* stream) {
     return e2k::dispatch("dwconv_bwd", dwconv_bwd_impl, dy, pre, x, mask, w, dx, dw, dbias, ws, B, N, C, ks, split, stream);
+}
+
+extern "C" int e2k_fourier_cat_fwd(const void* h, int64_t ldh, void* y, int64_t ldy, int64_t M, int nf, int nrest, void* stream) {
+    return e2k::dispatch("fourier_cat_fwd", fourier_cat_fwd_impl, h, ldh, y, ldy, M, nf, nrest, stream);
+}
+
+extern "C" int e2k_fourier_cat_bwd(const void* dy, int64_t ldy, const void* h, int64_t ldh, void* dh, int64_t lddh, int64_t M, int nf,
+                                   int nrest, void* stream) {
+    return e2k::dispatch("fourier_cat_bwd", fourier_cat_bwd_impl, dy, ldy, h, ldh, dh, lddh, M, nf, nrest, stream);
 }

@@ -87,9 +87,20 @@ class Identity(_Holder):                      # e2_tts.py:107
     pass
 
 
-class Attention(_Holder):                     # x_transformers.Attention (e2_tts.py:641,689)
-    def __init__(self, dim, heads, dim_head, learned_value_residual_mix):
+class LinearFourierEmbed(_Holder):            # e2_tts.py:368-386 (attn_fourier_embed_input)
+    def __init__(self, dim, p=0.5):
         super().__init__()
+        assert p <= 1.
+        dim_fourier = int(p * dim)
+        dim_rest = dim - dim_fourier * 2
+        self.linear = nn.Linear(dim, dim_fourier + dim_rest, bias=False)
+        self.split_dims = (dim_fourier, dim_rest)
+
+
+class Attention(_Holder):                     # x_transformers.Attention (e2_tts.py:641,689)
+    def __init__(self, dim, heads, dim_head, learned_value_residual_mix, laser=False, laser_softclamp_value=15.):
+        super().__init__()
+        self.laser, self.laser_softclamp_value = laser, laser_softclamp_value
         inner = heads * dim_head
         self.to_q = nn.Linear(dim, inner, bias=False)
         self.to_k = nn.Linear(dim, inner, bias=False)
@@ -259,8 +270,13 @@ class Transformer(Module):
         super().__init__()
         assert depth % 2 == 0, 'depth needs to be even'
         # default-off variants of the reference are not on the hot path
-        if has_freq_axis or attn_laser or attn_fourier_embed_input:
-            raise NotImplementedError('has_freq_axis / attn_laser / attn_fourier_embed_input are not built yet')
+        if has_freq_axis:
+            raise NotImplementedError('has_freq_axis is not built yet')
+        laser = dict(laser=attn_laser, laser_softclamp_value=attn_laser_softclamp_value)
+        if attn_fourier_embed_input:
+            nf = int(attn_fourier_embed_input_frac * dim)
+            if nf % 8 or (dim - 2 * nf) % 8 or dim - nf <= 0:
+                raise NotImplementedError('attn_fourier_embed_input: int(frac * dim) and dim - 2 int(frac * dim) must be multiples of 8')
         if num_residual_streams != 4:
             raise NotImplementedError('the hyper-connection kernels are built for 4 residual streams')
         if dict(attn_kwargs) != dict(gate_value_heads=True, softclamp_logits=True) or dict(ff_kwargs):
@@ -303,8 +319,8 @@ class Transformer(Module):
                 nn.Linear(dim * 2, dim, bias=False) if later_half else None,
                 DepthwiseConv(dim, kernel_size=kernel_size),
                 norm_klass(),
-                Attention(dim, heads, dim_head, learned_value_residual_mix=not first),
-                nn.Identity(),
+                Attention(dim, heads, dim_head, learned_value_residual_mix=not first, **laser),
+                LinearFourierEmbed(dim, p=attn_fourier_embed_input_frac) if attn_fourier_embed_input else nn.Identity(),
                 post_klass(),
                 norm_klass(),
                 FeedForward(dim, ff_mult, dropout),
@@ -316,7 +332,7 @@ class Transformer(Module):
                 text_modules = ModuleList([
                     DepthwiseConv(dim_text, kernel_size=kernel_size),
                     RMSNorm(dim_text),
-                    Attention(dim_text, text_heads, text_dim_head, learned_value_residual_mix=not first),
+                    Attention(dim_text, text_heads, text_dim_head, learned_value_residual_mix=not first, **laser),
                     RMSNorm(dim_text),
                     FeedForward(dim_text, text_ff_mult, dropout),
                     TextAudioCrossCondition(dim=dim, dim_text=dim_text, cond_audio_to_text=ind != text_depth - 1)])
@@ -389,7 +405,8 @@ class Transformer(Module):
         cols = 3 * I + H + (H if exists(mixl) else 0)
         # row stride of the fused projection output / its gradient: a multiple of 64 so that the dgrad GEMM (K = ldq,
         # zero padded) takes the global_load_lds path
-        r = NS(H=H, I=I, cols=cols, ldq=(cols + 63) // 64 * 64, has_mix=exists(mixl))
+        r = NS(H=H, I=I, cols=cols, ldq=(cols + 63) // 64 * 64, has_mix=exists(mixl),
+               laser=float(attn.laser_softclamp_value) if attn.laser else 0.)
         r.w = lay.add(attn.to_q.weight)
         for p in (attn.to_k.weight, attn.to_v.weight, attn.to_v_head_gate.weight):
             lay.add(p, chain=True)
@@ -449,6 +466,10 @@ class Transformer(Module):
             s.skip = lay.add(sm[0].weight) if exists(sm[0]) else None
             s.conv = self._conv_rec(lay, sm[1])
             s.attn = self._attn_rec(lay, sm[3], D)
+            s.lfe = None
+            if isinstance(sm[4], LinearFourierEmbed):
+                nf, nrest = sm[4].split_dims
+                s.lfe = NS(w=lay.add(sm[4].linear.weight), nf=nf, nout=nf + nrest)
             s.ff = self._ff_rec(lay, sm[7], D)
             if not self.cond_on_time:
                 s.attn_g, s.ff_g = lay.add(sm[2].g), lay.add(sm[6].g)
@@ -495,6 +516,8 @@ class Transformer(Module):
                 f.w2T = tr(f.w2, d, f.F)                  # (F, d)
             if exists(r.s.skip):
                 r.s.skipT = tr(r.s.skip, D, 2 * D)        # (2D, D)
+            if exists(r.s.lfe):
+                r.s.lfe.wT = tr(r.s.lfe.w, r.s.lfe.nout, D)      # (D, nout)
             if exists(r.t):
                 r.t.crossT = tr(r.t.cross, r.t.cross_rows, D + Dt)     # (D+Dt, rows)
         self._tlist, self._tsize = tl, tn
@@ -1007,18 +1030,24 @@ class Transformer(Module):
             gam, off, rpb = run.condall[:, (ind * 4 + 0) * D:(ind * 4 + 1) * D], 1., N
             gate = run.gates[:, (ind * 4 + 1) * D:(ind * 4 + 2) * D]
         xn, rn = ops.rmsnorm_fwd(binp, gam, off, rpb)
+        lfe = None if text else lr.lfe
+        hf = xa = None
+        if exists(lfe):
+            # attn_input_fourier_embed (e2_tts.py:909): bias-free projection, then [sin | cos | rest] feeds the q / k / v projections
+            hf = ops.gemm_nt(xn, self._w(lfe.w, lfe.nout, D))
+            xa = ops.fourier_cat_fwd(hf, lfe.nf)
         qkvg = torch.empty((Mtok, a.ldq), dtype=bf16, device=run.dev)[:, :a.cols]
-        ops.gemm_nt(xn, self._w(a.w, a.cols, D), bias=self._f(a.bias, a.cols), out=qkvg)
+        ops.gemm_nt(xn if xa is None else xa, self._w(a.w, a.cols, D), bias=self._f(a.bias, a.cols), out=qkvg)
         first = run.vfirst[key] is None
-        ast = ops.qkv_post_fwd(qkvg, B, a.H, N, run.rot[0], run.rot[1], run.vfirst[key])
+        ast = ops.qkv_post_fwd(qkvg, B, a.H, N, run.rot[0], run.rot[1], run.vfirst[key], laser=a.laser)
         if first:
-            run.vfirst[key] = ast.V
+            run.vfirst[key] = ast.Vorig if a.laser > 0 else ast.V      # (LASER: the values before the exp map)
         sid = (ind * 2 + int(text)) * 4
         Og = ops.attn_fwd(ast, run.kmask, run.p_drop, run.seed, sid, run.seed_dev)
         y = ops.gemm_nt(Og, self._w(a.out, D, a.I), colscale=gate, rows_per_batch=N)
         self._hc_depth(S, rec, y)
         if exists(tape):
-            tape.append(('attn', rec, lr, ind, text, binp, xn, rn, qkvg, ast, first, y, key, sid))
+            tape.append(('attn', rec, lr, ind, text, binp, xn, rn, qkvg, ast, first, y, key, sid, hf, xa))
         # ---- feed-forward
         binp, rec = self._hc_width(run, S, lr.hc[2])
         f = lr.ff
@@ -1348,7 +1377,7 @@ class Transformer(Module):
         return dxs, dcond, dtext, gflat
 
     def _attn_bwd(self, run, ent, G, dvfirst):
-        _, rec, lr, ind, text, binp, xn, rn, qkvg, ast, first, y, key, sid = ent
+        _, rec, lr, ind, text, binp, xn, rn, qkvg, ast, first, y, key, sid, hf, xa = ent
         B, N, Mtok = run.B, run.N, run.Mtok
         a = lr.attn
         D = a.dim
@@ -1369,10 +1398,15 @@ class Transformer(Module):
         nb = a.cols - 3 * a.I                                                      # gate (+ mix) bias gradients
         assert nb % 2 == 0, 'odd head counts are not supported'
         # weight gradient; the gate (+ mix) bias gradients = column sums of the same dY ride along in the kernel
-        run.wgrad(dqkvg, xn, G(a.w, a.cols, D), colsum=G(a.bias, a.cols), colsum_from=3 * a.I)
+        run.wgrad(dqkvg, xn if xa is None else xa, G(a.w, a.cols, D), colsum=G(a.bias, a.cols), colsum_from=3 * a.I)
         # dgrad over the padded row (pad columns of dqkvg / rows of W^T are zero)
         dq_full = dqkvg if a.ldq == a.cols else torch.as_strided(dqkvg, (Mtok, a.ldq), (a.ldq, 1))
         dxn = ops.gemm_nt(dq_full, self._wT(a.wT))
+        if xa is not None:
+            lfe = lr.lfe
+            dhf = ops.fourier_cat_bwd(dxn, hf, lfe.nf)
+            run.wgrad(dhf, xn, G(lfe.w, lfe.nout, D))
+            dxn = ops.gemm_nt(dhf, self._wT(lfe.wT))
         rec.dbin = ops.rmsnorm_bwd(dxn, binp, rn, gam, off, rpb, dgam)
 
     def _ff_bwd(self, run, ent, G):

@@ -626,10 +626,12 @@ def rotary_table(n, device, dim_head=64, base=10000.):
 
 class AttnState:
     """buffers produced by qkv_post_fwd / attn_fwd and consumed by the backward"""
-    __slots__ = ('Q', 'K', 'V', 'QT', 'KT', 'VT', 'gate', 'mix', 'O', 'Og', 'lse2', 'B', 'H', 'N', 'Npad', 'dropbits')
+    __slots__ = ('Q', 'K', 'V', 'QT', 'KT', 'VT', 'gate', 'mix', 'O', 'Og', 'lse2', 'B', 'H', 'N', 'Npad', 'dropbits', 'laser', 'Vorig')
 
 
-def qkv_post_fwd(qkvg, B, H, N, cosb, sinb, vfirst=None):
+def qkv_post_fwd(qkvg, B, H, N, cosb, sinb, vfirst=None, laser=0.):
+    """laser > 0: LASER attention's value map exp(c tanh(v / c)) (st.laser); on the first layer st.Vorig keeps the values
+    before it (the value residual of the later layers)"""
     _chk(qkvg, cosb, sinb, vfirst)
     assert qkvg.dtype == bf16 and qkvg.stride(1) == 1 and qkvg.shape[0] == B * N
     dev = qkvg.device
@@ -643,8 +645,11 @@ def qkv_post_fwd(qkvg, B, H, N, cosb, sinb, vfirst=None):
     st.QT = torch.empty((B, H, 64, Npad), dtype=bf16, device=dev) if need & 2 else None
     st.gate = torch.empty((B, H, N), dtype=f32, device=dev)
     st.mix = torch.empty((B, H, N), dtype=f32, device=dev) if vfirst is not None else None
+    st.laser = float(laser)
+    st.Vorig = torch.empty((B, H, N, 64), dtype=bf16, device=dev) if laser > 0 and vfirst is None else None
     _lib.get().e2k_qkv_post_fwd(_p(qkvg), qkvg.stride(0), _p(cosb), _p(sinb), _p(vfirst), _p(st.Q), _p(st.K), _p(st.V),
-                                _p(st.QT), _p(st.KT), _p(st.VT), _p(st.gate), _p(st.mix), B, H, N, Npad, _stream(qkvg))
+                                _p(st.QT), _p(st.KT), _p(st.VT), _p(st.gate), _p(st.mix), _p(st.Vorig), st.laser, B, H, N, Npad,
+                                _stream(qkvg))
     return st
 
 
@@ -673,6 +678,10 @@ def attn_fwd(st, kmask_pad, p_drop=0., seed=0, stream_id=0, seed_dev=None):
     _lib.get().e2k_attn_fwd(_p(st.Q), _p(st.K), _p(st.VT), _p(kmask_pad), _p(st.gate), _p(st.O), _p(st.Og), _p(st.lse2),
                             _p(st.dropbits), B, H, N, Npad, float(p_drop), int(seed), _p(seed_dev), int(stream_id),
                             attn_probe, _stream(st.Q))
+    if st.laser > 0:
+        # LASER: the head gates apply to log(out) (x-transformers Attention.forward); st.O keeps the attention's own output
+        st.Og = torch.empty_like(st.Og)
+        _lib.get().e2k_laser_out_fwd(_p(st.O), _p(st.gate), _p(kmask_pad), _p(st.Og), B, H, N, Npad, _stream(st.Q))
     return st.Og
 
 
@@ -687,12 +696,18 @@ def attn_bwd(st, dOg, kmask_pad, p_drop=0., seed=0, stream_id=0, seed_dev=None):
     delta = torch.empty((B, H, N), dtype=f32, device=dev)
     dgate = torch.empty((B, H, N), dtype=f32, device=dev)
     dQ, dK, dV = (torch.empty((B, H, N, 64), dtype=bf16, device=dev) for _ in range(3))
+    dgate_laser = None
+    if st.laser > 0:
+        dOin, dgate_laser = torch.empty_like(dOg), torch.empty((B, H, N), dtype=f32, device=dev)
+        _lib.get().e2k_laser_out_bwd(_p(dOg), _p(st.O), _p(st.gate), _p(kmask_pad), _p(dOin), _p(dgate_laser), B, H, N, Npad,
+                                     _stream(dOg))
+        dOg = dOin
     _note(10.0 * B * H * N * N * 64)
     _lib.get().e2k_attn_bwd(_p(dOg), _p(st.O), _p(st.gate), _p(st.lse2), _p(st.Q), _p(st.K), _p(st.V), _p(st.QT),
                             _p(st.KT), _p(kmask_pad), _p(st.dropbits), _p(dO), _p(dOT), _p(delta), _p(dgate), _p(dQ), _p(dK),
                             _p(dV), B, H, N, Npad, float(p_drop), int(seed), _p(seed_dev), int(stream_id), attn_probe & 128,
                             _stream(dOg))
-    return dQ, dK, dV, dgate
+    return dQ, dK, dV, dgate if dgate_laser is None else dgate_laser
 
 
 def qkv_post_bwd(st, dQ, dK, dV, dgate_pre, qkvg, cosb, sinb, vfirst=None, dvfirst=None, first_layer=False):
@@ -707,7 +722,8 @@ def qkv_post_bwd(st, dQ, dK, dV, dgate_pre, qkvg, cosb, sinb, vfirst=None, dvfir
         fill_cols_(full, cols)
         dqkvg = full[:, :cols]
     _lib.get().e2k_qkv_post_bwd(_p(dQ), _p(dK), _p(dV), _p(dgate_pre), _p(qkvg), qkvg.stride(0), _p(cosb), _p(sinb),
-                                _p(vfirst), _p(st.mix), _p(dvfirst), int(first_layer), _p(dqkvg), B, H, N, _stream(dQ))
+                                _p(vfirst), _p(st.mix), _p(dvfirst), int(first_layer), _p(dqkvg), st.laser, B, H, N,
+                                _stream(dQ))
     return dqkvg
 
 
@@ -983,3 +999,22 @@ def cfg_combine(pred, null_pred, cfg_strength, keep_parallel_frac=0., remove_par
     _lib.get().e2k_cfg_combine(_p(pred), _p(null_pred), _p(out), B, pred.numel() // B, float(cfg_strength), float(keep_parallel_frac),
                                int(bool(remove_parallel)), _stream(pred))
     return out
+
+
+def fourier_cat_fwd(h, nf):
+    """[sin h[:, :nf] | cos h[:, :nf] | h[:, nf:]]  (LinearFourierEmbed, e2_tts.py:383-386); h (M, nf + nrest) bf16"""
+    _chk(h)
+    M, nh = h.shape
+    assert h.dtype == bf16 and h.stride(1) == 1
+    y = torch.empty((M, nh + nf), dtype=bf16, device=h.device)
+    _lib.get().e2k_fourier_cat_fwd(_p(h), h.stride(0), _p(y), y.stride(0), M, nf, nh - nf, _stream(h))
+    return y
+
+
+def fourier_cat_bwd(dy, h, nf):
+    _chk(dy, h)
+    M, nh = h.shape
+    assert dy.dtype == bf16 and h.dtype == bf16 and dy.shape == (M, nh + nf) and dy.stride(1) == 1 and h.stride(1) == 1
+    dh = torch.empty((M, nh), dtype=bf16, device=h.device)
+    _lib.get().e2k_fourier_cat_bwd(_p(dy), dy.stride(0), _p(h), h.stride(0), _p(dh), dh.stride(0), M, nf, nh - nf, _stream(h))
+    return dh

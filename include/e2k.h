@@ -173,6 +173,13 @@ int e2k_query_gemm_nt_geglu(int M, int F, int K);
 /* out[n] += sum_m x[m][n]   (bias gradients; x bf16 (M,N), out fp32) */
 int e2k_colsum_bf16(const void* x, int64_t ldx, float* out, int M, int N, void* stream);
 
+/* LinearFourierEmbed's activation (e2_tts.py:368-386; Transformer(attn_fourier_embed_input = True), :639,909): the bias-free
+ * projection h (M, nf + nrest) is an e2k_gemm_nt_bf16 call; this is  y (M, 2 nf + nrest) = [sin h[:nf] | cos h[:nf] | h[nf:]]
+ * and its backward  dh[:nf] = dy[:nf] cos h - dy[nf:2nf] sin h,  dh[nf:] = dy[2nf:].  bf16 rows, nf / nrest / strides % 8 == 0. */
+int e2k_fourier_cat_fwd(const void* h, int64_t ldh, void* y, int64_t ldy, int64_t M, int nf, int nrest, void* stream);
+int e2k_fourier_cat_bwd(const void* dy, int64_t ldy, const void* h, int64_t ldh, void* dh, int64_t lddh, int64_t M, int nf,
+                        int nrest, void* stream);
+
 /* fp32 master parameters -> bf16 compute shadows (flat, and (R,C) -> transposed (C,R) with row stride ldd) */
 int e2k_cast_bf16(const float* src, void* dst, int64_t n, void* stream);
 int e2k_cast_transpose_bf16(const float* src, void* dst, int R, int C, int64_t ldd, void* stream);
@@ -199,16 +206,26 @@ int e2k_dwconv_bwd_reduce(const float* ws, float* dw, float* dbias, int B, int N
  * mix logits (H)].  cosb/sinb: rotary table (N, 32) fp32 (theta_j = 10000^(-2j/64), interleaved pairs).
  * vfirst: first layer's un-mixed values (B,H,N,64), NULL on the first layer (then V = v is what later layers use).
  * Outputs head-major Q,K,V (B,H,N,64), transposed QT,KT,VT (B,H,64,Npad; Npad = N rounded up to 64, zero padded),
- * gate = sigmoid(gate logits), mix = sigmoid(mix logits) (B,H,N) fp32. */
+ * gate = sigmoid(gate logits), mix = sigmoid(mix logits) (B,H,N) fp32.
+ * laser_clamp > 0: LASER attention (Transformer(attn_laser = True, attn_laser_softclamp_value = c), e2_tts.py:543-544,641):
+ * V / VT hold exp(c tanh(v / c)) of the (mixed) values and v_orig (first layer; may be NULL) receives the values before
+ * that map, i.e. what later layers take as `vfirst`.  laser_clamp = 0 (then v_orig = NULL): the default attention. */
 int e2k_qkv_post_fwd(const void* qkvg, int64_t ldq, const float* cosb, const float* sinb, const void* vfirst,
                      void* Q, void* K, void* V, void* QT, void* KT, void* VT, float* gate, float* mix,
-                     int B, int H, int N, int Npad, void* stream);
+                     void* v_orig, float laser_clamp, int B, int H, int N, int Npad, void* stream);
 /* dqkvg (B*N, ldq) from dQ,dK,dV (B,H,N,64): inverse rotary, value-residual mix backward (dvfirst (B,H,N,64) fp32
- * is ACCUMULATED on later layers and consumed when first_layer = 1), gate / mix logit gradients. */
+ * is ACCUMULATED on later layers and consumed when first_layer = 1), gate / mix logit gradients; laser_clamp as above
+ * (dV is then the gradient of the mapped values). */
 int e2k_qkv_post_bwd(const void* dQ, const void* dK, const void* dV, const float* dgate_pre,
                      const void* qkvg, int64_t ldq, const float* cosb, const float* sinb,
                      const void* vfirst, const float* mix, float* dvfirst, int first_layer, void* dqkvg,
-                     int B, int H, int N, void* stream);
+                     float laser_clamp, int B, int H, int N, void* stream);
+/* LASER output map between the attention and the head gates (`out = log(out)`, clamped at 1e-20): O = e2k_attn_fwd's
+ * un-gated output (B*N, H*64), Og = log(max(O, 1e-20)) gate, 0 on masked query rows.  Backward: dOin = dOg / O (0 where
+ * O <= 1e-20) is what e2k_attn_bwd takes as its dOg; dgate_pre (B,H,N) REPLACES the one e2k_attn_bwd computes. */
+int e2k_laser_out_fwd(const void* O, const float* gate, const uint8_t* kmask, void* Og, int B, int H, int N, int Npad, void* stream);
+int e2k_laser_out_bwd(const void* dOg, const void* O, const float* gate, const uint8_t* kmask, void* dOin, float* dgate_pre,
+                      int B, int H, int N, int Npad, void* stream);
 /* O = softmax(mask(50*tanh(Q.K^T/8/50))) . V  (dropout on the probabilities if p_drop > 0), per (b,h).
  * kmask (B, Npad) u8: 1 = attend; also used as the query-row mask of the output (reference: where(mask, out, 0)).
  * O / Og: token-major (B*N, H*64) un-gated / gated by `gate`;  lse2 (B,H,N): log2-domain log-sum-exp. */

@@ -240,10 +240,10 @@ Intermediates = namedtuple('Intermediates', ['values'])
 
 class Attention(Module):                     # A.3
     def __init__(self, dim, heads=8, dim_head=64, dropout=0., learned_value_residual_mix=False,
-                 gate_value_heads=True, softclamp_logits=True, logit_softclamp_value=50.,
+                 gate_value_heads=False, softclamp_logits=False, logit_softclamp_value=50.,
                  laser=False, laser_softclamp_value=15.):
         super().__init__()
-        assert not laser, 'laser variant is out of scope (SURVEY section 2 row 8)'
+        self.laser, self.laser_softclamp_value = laser, laser_softclamp_value
         self.heads, self.dim_head, self.scale = heads, dim_head, dim_head ** -0.5
         inner = heads * dim_head
         self.to_q = nn.Linear(dim, inner, bias=False)
@@ -269,12 +269,19 @@ class Attention(Module):                     # A.3
         q, k, v = (t.view(b, n, h, -1).transpose(1, 2) for t in (q, k, v))
         orig_values = v
         if exists(value_residual):
-            mix = self.to_value_residual_mix(x).transpose(1, 2)[..., None]      # b h n 1
+            # learned per-head mix, or the constant 0.5 when `learned_value_residual_mix` is off (the frequency attention of
+            # `has_freq_axis`, e2_tts.py:655,925: x-transformers' `always(0.5)`)
+            mix = self.to_value_residual_mix(x).transpose(1, 2)[..., None] if exists(self.to_value_residual_mix) else 0.5
             v = value_residual.lerp(v, mix)
         if exists(rotary_pos_emb):
             freqs, _ = rotary_pos_emb
             q = apply_rotary_pos_emb(q, freqs)
             k = apply_rotary_pos_emb(k, freqs)
+        if self.laser:
+            # LASER attention (e2_tts.py:543-544,641; x-transformers `laser`): attend over exp(softclamp(v)), take the log of the
+            # result (clamped at 1e-20) before the head gates.  UNPINNED restatement of the third-party module.
+            c = self.laser_softclamp_value
+            v = ((v / c).tanh() * c).exp()
         sim = torch.einsum('bhid,bhjd->bhij', q, k) * self.scale
         if self.softclamp_logits:
             sim = (sim / self.logit_softclamp_value).tanh() * self.logit_softclamp_value
@@ -286,6 +293,8 @@ class Attention(Module):                     # A.3
         elif self.training and self.dropout_p > 0:
             attn = F.dropout(attn, self.dropout_p)
         out = torch.einsum('bhij,bhjd->bhid', attn, v)
+        if self.laser:
+            out = out.clamp(min=1e-20).log()
         if exists(self.to_v_head_gate):
             gate = self.to_v_head_gate(x).sigmoid()                              # b n h
             out = out * gate.transpose(1, 2)[..., None]
@@ -495,6 +504,21 @@ class TextAudioCrossCondition(Module):       # e2_tts.py:486-513
         return audio + text_cond, text + audio_cond
 
 
+class LinearFourierEmbed(Module):
+    """e2_tts.py:368-386 -- bias-free linear whose first int(p dim) outputs pass through sin and cos"""
+    def __init__(self, dim, p=0.5):
+        super().__init__()
+        assert p <= 1.
+        dim_fourier = int(p * dim)
+        dim_rest = dim - dim_fourier * 2
+        self.linear = nn.Linear(dim, dim_fourier + dim_rest, bias=False)
+        self.split_dims = (dim_fourier, dim_rest)
+
+    def forward(self, x):
+        fourier, rest = self.linear(x).split(self.split_dims, dim=-1)
+        return torch.cat((fourier.sin(), fourier.cos(), rest), dim=-1)
+
+
 # ---------------------------------------------------------------- Transformer (e2_tts.py:518-952)
 
 class Transformer(Module):
@@ -507,7 +531,6 @@ class Transformer(Module):
                  attn_kwargs=dict(gate_value_heads=True, softclamp_logits=True), ff_kwargs=dict()):
         super().__init__()
         assert depth % 2 == 0, 'depth needs to be even'
-        assert not has_freq_axis and not attn_laser and not attn_fourier_embed_input, 'default-off variants are out of scope'
         assert num_residual_streams > 1
         self.max_seq_len = max_seq_len
         self.abs_pos_emb = nn.Embedding(max_seq_len, dim) if abs_pos_emb else None
@@ -519,6 +542,8 @@ class Transformer(Module):
         text_ff_mult = default(text_ff_mult, ff_mult)
         text_depth = default(text_depth, depth)
         assert 1 <= text_depth <= depth
+        freq_heads = default(freq_heads, heads)                    # e2_tts.py:577-578
+        freq_dim_head = default(freq_dim_head, dim_head)
         self.has_freq_axis = has_freq_axis
         self.depth = depth
         self.num_registers = num_registers
@@ -528,6 +553,8 @@ class Transformer(Module):
         nn.init.normal_(self.text_registers, std=0.02)
         self.rotary_emb = RotaryEmbedding(dim_head)
         self.text_rotary_emb = RotaryEmbedding(text_dim_head)
+        if has_freq_axis:
+            self.freq_rotary_emb = RotaryEmbedding(freq_dim_head)
         self.num_residual_streams = s = num_residual_streams
         self.cond_on_time = cond_on_time
         norm_klass = (lambda: AdaptiveRMSNorm(dim)) if cond_on_time else (lambda: RMSNorm(dim))
@@ -540,26 +567,33 @@ class Transformer(Module):
             first = ind == 0
             later_half = ind >= depth // 2
             has_text = ind < text_depth
+            laser = dict(laser=attn_laser, laser_softclamp_value=attn_laser_softclamp_value)
+            freq_norm = freq_attn = freq_adaln = None
+            if has_freq_axis:                                      # e2_tts.py:653-656: a default-keyword Attention (no gates, no soft-clamp)
+                freq_norm = norm_klass()
+                freq_attn = Attention(dim=dim, heads=freq_heads, dim_head=freq_dim_head)
+                freq_adaln = post_klass()
             speech_modules = ModuleList([
                 nn.Linear(dim * 2, dim, bias=False) if later_half else None,
                 DepthwiseConv(dim, kernel_size=kernel_size),
                 norm_klass(),
                 Attention(dim=dim, heads=heads, dim_head=dim_head, dropout=dropout,
-                          learned_value_residual_mix=not first, **attn_kwargs),
-                nn.Identity(),
+                          learned_value_residual_mix=not first, **laser, **attn_kwargs),
+                LinearFourierEmbed(dim, p=attn_fourier_embed_input_frac) if attn_fourier_embed_input else nn.Identity(),
                 post_klass(),
                 norm_klass(),
                 FeedForward(dim=dim, glu=True, mult=ff_mult, dropout=dropout, **ff_kwargs),
                 post_klass(),
-                None, None, None])
-            speech_hc = ModuleList([HyperConnections(s, dim=dim) for _ in range(3)] + [None])
+                freq_norm, freq_attn, freq_adaln])
+            speech_hc = ModuleList([HyperConnections(s, dim=dim) for _ in range(3)] +
+                                   [HyperConnections(s, dim=dim) if has_freq_axis else None])
             text_modules = text_hc = None
             if has_text:
                 text_modules = ModuleList([
                     DepthwiseConv(dim_text, kernel_size=kernel_size),
                     RMSNorm(dim_text),
                     Attention(dim=dim_text, heads=text_heads, dim_head=text_dim_head, dropout=dropout,
-                              learned_value_residual_mix=not first, **attn_kwargs),
+                              learned_value_residual_mix=not first, **laser, **attn_kwargs),
                     RMSNorm(dim_text),
                     FeedForward(dim=dim_text, glu=True, mult=text_ff_mult, dropout=dropout, **ff_kwargs),
                     TextAudioCrossCondition(dim=dim, dim_text=dim_text, cond_audio_to_text=ind != text_depth - 1)])
@@ -572,7 +606,15 @@ class Transformer(Module):
 
     def forward(self, x, times=None, mask=None, text_embed=None):
         orig_batch = x.shape[0]
-        assert x.ndim == 3
+        assert (x.ndim == 4) == self.has_freq_axis
+        freq_seq_len = 1
+        if self.has_freq_axis:                                    # e2_tts.py:744-752: frequency tokens ride in the batch
+            freq_seq_len = x.shape[1]
+            x = x.reshape(orig_batch * freq_seq_len, *x.shape[2:])
+            if exists(text_embed):
+                text_embed = text_embed.repeat_interleave(freq_seq_len, dim=0)
+            if exists(mask):
+                mask = mask.repeat_interleave(freq_seq_len, dim=0)
         batch, seq_len, device = x.shape[0], x.shape[1], x.device
         assert not (exists(times) ^ self.cond_on_time)
         s = self.num_residual_streams
@@ -582,26 +624,33 @@ class Transformer(Module):
         x = torch.cat((self.registers[None].expand(batch, -1, -1), x), dim=1)
         if exists(mask):
             mask = F.pad(mask, (self.num_registers, 0), value=True)
-        norm_kwargs = dict()
+        norm_kwargs, freq_norm_kwargs = dict(), dict()
         if exists(times):
             if times.ndim == 0:
                 times = times[None].expand(orig_batch)
             times = self.time_cond_mlp(times)
+            if self.has_freq_axis:                                # e2_tts.py:784-789
+                freq_norm_kwargs.update(condition=times.repeat_interleave(x.shape[-2], dim=0))
+            times = times.repeat_interleave(freq_seq_len, dim=0)
             norm_kwargs.update(condition=times)
         rotary_pos_emb = self.rotary_emb.forward_from_seq_len(x.shape[-2])
+        if self.has_freq_axis:
+            freq_rotary_pos_emb = self.freq_rotary_emb.forward_from_seq_len(freq_seq_len)
         if exists(text_embed):
             text_rotary_pos_emb = self.text_rotary_emb.forward_from_seq_len(x.shape[-2])
             text_embed = torch.cat((self.text_registers[None].expand(batch, -1, -1), text_embed), dim=1)
         skips = []
         text_attn_first_values = None
+        freq_attn_first_values = None
         attn_first_values = None
         x = hc_expand(x, s)
         if exists(text_embed):
             text_embed = hc_expand(text_embed, s)
         for ind, ((speech_modules, text_modules), (speech_hc, text_hc)) in enumerate(zip(self.layers, self.hyper_conns)):
             layer = ind + 1
-            (skip_proj, speech_conv, attn_norm, attn, _fe, attn_adaln, ff_norm, ff, ff_adaln, _, _, _) = speech_modules
-            conv_residual, attn_residual, ff_residual, _ = speech_hc
+            (skip_proj, speech_conv, attn_norm, attn, attn_input_fourier_embed, attn_adaln, ff_norm, ff, ff_adaln,
+             freq_attn_norm, freq_attn, freq_attn_adaln) = speech_modules
+            conv_residual, attn_residual, ff_residual, freq_attn_residual = speech_hc
             if exists(text_embed) and exists(text_modules):
                 text_conv, text_attn_norm, text_attn, text_ff_norm, text_ff, cross_condition = text_modules
                 t_conv_res, t_attn_res, t_ff_res = text_hc
@@ -629,11 +678,22 @@ class Transformer(Module):
             x = add_residual(x)
             x, add_residual = attn_residual(x)
             x = attn_norm(x, **norm_kwargs)
+            x = attn_input_fourier_embed(x)
             attn_out, inter = attn(x, rotary_pos_emb=rotary_pos_emb, mask=mask, return_intermediates=True,
                                    value_residual=attn_first_values)
             attn_out = attn_adaln(attn_out, **norm_kwargs)
             x = add_residual(attn_out)
             attn_first_values = default(attn_first_values, inter.values)
+            if self.has_freq_axis:                                # e2_tts.py:920-932: attention across the frequency tokens of a frame
+                x, add_residual = freq_attn_residual(x)
+                f, n, d = freq_seq_len, x.shape[-2], x.shape[-1]
+                x = x.reshape(orig_batch, f, n, d).transpose(1, 2).reshape(orig_batch * n, f, d)
+                attn_out, inter = freq_attn(freq_attn_norm(x, **freq_norm_kwargs), rotary_pos_emb=freq_rotary_pos_emb,
+                                            return_intermediates=True, value_residual=freq_attn_first_values)
+                attn_out = freq_attn_adaln(attn_out, **freq_norm_kwargs)
+                attn_out = attn_out.reshape(orig_batch, n, f, d).transpose(1, 2).reshape(orig_batch * f, n, d)
+                x = add_residual(attn_out)
+                freq_attn_first_values = default(freq_attn_first_values, inter.values)
             x, add_residual = ff_residual(x)
             ff_out = ff(ff_norm(x, **norm_kwargs))
             ff_out = ff_adaln(ff_out, **norm_kwargs)
@@ -641,6 +701,8 @@ class Transformer(Module):
         assert len(skips) == 0
         x = x[:, self.num_registers:]
         x = hc_reduce(x, s)
+        if self.has_freq_axis:
+            x = x.reshape(orig_batch, freq_seq_len, *x.shape[1:])
         return self.final_norm(x)
 
 

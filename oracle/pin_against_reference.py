@@ -159,8 +159,13 @@ def case_transformer(R, results, golden):
     # head count, 15-tap convolution, 8 registers, no absolute position embedding
     kw1 = dict(dim=256, depth=4, heads=4, dim_head=64, dropout=0., max_seq_len=64, text_depth=2, dim_text=128, text_heads=2,
                kernel_size=15, num_registers=8, abs_pos_emb=False, ff_mult=2, text_ff_mult=4)
+    # the default-off switches of the constructor (e2_tts.py:533-546): LASER attention, LinearFourierEmbed on the attention input,
+    # and the frequency axis (x is (b, f, n, d): an extra attention across the f tokens of every frame in each layer)
+    kw2 = dict(kw0, depth=2, attn_laser=True, attn_fourier_embed_input=True)
+    kw3 = dict(kw0, depth=2, has_freq_axis=True, freq_heads=2)
     for name, cond_on_time, with_text, with_mask, kw in (('full', True, True, True, kw0), ('bare', False, False, False, kw0),
-                                                         ('variant', True, True, True, kw1)):
+                                                         ('variant', True, True, True, kw1), ('laser_fourier', True, True, True, kw2),
+                                                         ('freq_axis', True, True, True, kw3), ('freq_axis_bare', False, False, True, kw3)):
         random.seed(3)
         torch.manual_seed(3)
         ref = R.Transformer(**kw, cond_on_time=cond_on_time)
@@ -173,11 +178,12 @@ def case_transformer(R, results, golden):
         assert all(torch.equal(chk[k], v) for k, v in ref.state_dict().items())   # ... and that the seed alone reproduces the weights
         B, T = 2, 24
         g = torch.Generator().manual_seed(10)
-        x = torch.randn(B, T, 256, generator=g)
+        fshape = (3,) if kw.get('has_freq_axis') else ()
+        x = torch.randn(B, *fshape, T, 256, generator=g)
         times = torch.rand(B, generator=g) if cond_on_time else None
         text = torch.randn(B, T, ref.dim_text, generator=g) if with_text else None
         mask = (torch.arange(T)[None] < torch.tensor([T, T - 7])[:, None]) if with_mask else None
-        Rw = torch.randn(B, T, 256, generator=g)
+        Rw = torch.randn(B, *fshape, T, 256, generator=g)
         outs = []
         for m in (ref, ora):
             xi = x.clone().requires_grad_(True)

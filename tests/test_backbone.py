@@ -43,25 +43,36 @@ def randomize(model, seed=0):
                 p.copy_(1 + torch.randn(p.shape, generator=g) * 0.2)
 
 
-@pytest.mark.parametrize('cond_on_time,with_text,with_mask', [(True, True, True), (False, False, False)])
-def test_backbone(dev, cond_on_time, with_text, with_mask):
+VARIANTS = {                                   # the constructor's default-off switches (e2_tts.py:533-546), depth 2
+    'fourier': dict(depth=2, attn_fourier_embed_input=True),
+    'laser': dict(depth=2, attn_laser=True),
+    'freq_axis': dict(depth=2, has_freq_axis=True, freq_heads=2),
+}
+
+
+@pytest.mark.parametrize('cond_on_time,with_text,with_mask,variant', [
+    (True, True, True, None), (False, False, False, None),
+    (True, True, True, 'fourier'), (True, True, True, 'laser'), (True, True, True, 'freq_axis'), (False, False, True, 'freq_axis')])
+def test_backbone(dev, cond_on_time, with_text, with_mask, variant):
     from e2_tts_pytorch_amd import Transformer
     random.seed(0)
     torch.manual_seed(0)
     kw = dict(dim=256, depth=4, heads=2, dropout=0., max_seq_len=64)
+    kw.update(VARIANTS.get(variant, {}))
+    fshape = (3,) if kw.get('has_freq_axis') else ()
     ref = O.Transformer(**kw, cond_on_time=cond_on_time)
     randomize(ref)
     mod = Transformer(**kw, cond_on_time=cond_on_time)
     missing = mod.load_state_dict(ref.state_dict(), strict=True)
     mod = mod.to(dev)
     B, T = 2, 40
-    x = torch.randn(B, T, 256)
+    x = torch.randn(B, *fshape, T, 256)
     times = torch.rand(B) if cond_on_time else None
     text = torch.randn(B, T, 128) if with_text else None
     mask = None
     if with_mask:
         mask = torch.arange(T)[None] < torch.tensor([T, T - 9])[:, None]
-    R = torch.randn(B, T, 256)
+    R = torch.randn(B, *fshape, T, 256)
 
     xr = x.clone().requires_grad_(True)
     tr = text.clone().requires_grad_(True) if with_text else None

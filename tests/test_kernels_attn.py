@@ -33,7 +33,8 @@ def test_attention(dev, N, has_vres, use_mask, qk_gain):
     torch.manual_seed(0)
     B, H = 2, 4
     D = I = H * 64
-    attn = Attention(dim=D, heads=H, dim_head=64, dropout=0., learned_value_residual_mix=has_vres)
+    attn = Attention(dim=D, heads=H, dim_head=64, dropout=0., learned_value_residual_mix=has_vres, gate_value_heads=True,
+                     softclamp_logits=True)
     with torch.no_grad():
         attn.to_out.weight.copy_(torch.eye(D))
         attn.to_v_head_gate.weight.normal_(0, 0.05)
@@ -108,7 +109,7 @@ def test_attention_dropout(dev):
     torch.manual_seed(1)
     B, H, N, p, seed, sid = 1, 8, 70, 0.25, 12345, 6
     D = I = H * 64
-    attn = Attention(dim=D, heads=H, dim_head=64, dropout=p)
+    attn = Attention(dim=D, heads=H, dim_head=64, dropout=p, gate_value_heads=True, softclamp_logits=True)
     with torch.no_grad():
         attn.to_out.weight.copy_(torch.eye(D))
     x = torch.randn(B, N, D)
