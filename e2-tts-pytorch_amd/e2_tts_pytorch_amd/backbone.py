@@ -98,7 +98,8 @@ class LinearFourierEmbed(_Holder):            # e2_tts.py:368-386 (attn_fourier_
 
 
 class Attention(_Holder):                     # x_transformers.Attention (e2_tts.py:641,689)
-    def __init__(self, dim, heads, dim_head, learned_value_residual_mix, laser=False, laser_softclamp_value=15.):
+    def __init__(self, dim, heads, dim_head, learned_value_residual_mix, laser=False, laser_softclamp_value=15.,
+                 gate_value_heads=True):
         super().__init__()
         self.laser, self.laser_softclamp_value = laser, laser_softclamp_value
         inner = heads * dim_head
@@ -106,9 +107,11 @@ class Attention(_Holder):                     # x_transformers.Attention (e2_tts
         self.to_k = nn.Linear(dim, inner, bias=False)
         self.to_v = nn.Linear(dim, inner, bias=False)
         self.to_out = nn.Linear(inner, dim, bias=False)
-        self.to_v_head_gate = nn.Linear(dim, heads)
-        nn.init.constant_(self.to_v_head_gate.weight, 0)
-        nn.init.constant_(self.to_v_head_gate.bias, 10)
+        self.to_v_head_gate = None           # (the frequency attention of `has_freq_axis` is a default-keyword Attention: no gates)
+        if gate_value_heads:
+            self.to_v_head_gate = nn.Linear(dim, heads)
+            nn.init.constant_(self.to_v_head_gate.weight, 0)
+            nn.init.constant_(self.to_v_head_gate.bias, 10)
         self.to_value_residual_mix = None
         if learned_value_residual_mix:
             self.to_value_residual_mix = nn.Sequential(nn.Linear(dim, heads), nn.Sigmoid())
@@ -270,8 +273,6 @@ class Transformer(Module):
         super().__init__()
         assert depth % 2 == 0, 'depth needs to be even'
         # default-off variants of the reference are not on the hot path
-        if has_freq_axis:
-            raise NotImplementedError('has_freq_axis is not built yet')
         laser = dict(laser=attn_laser, laser_softclamp_value=attn_laser_softclamp_value)
         if attn_fourier_embed_input:
             nf = int(attn_fourier_embed_input_frac * dim)
@@ -287,13 +288,16 @@ class Transformer(Module):
         text_ff_mult = default(text_ff_mult, ff_mult)
         text_depth = default(text_depth, depth)
         assert 1 <= text_depth <= depth, 'must have at least 1 layer of text conditioning, but less than total number of speech layers'
-        if dim_head != 64 or text_dim_head != 64:
+        freq_heads = default(freq_heads, heads)
+        freq_dim_head = default(freq_dim_head, dim_head)
+        if dim_head != 64 or text_dim_head != 64 or (has_freq_axis and freq_dim_head != 64):
             raise NotImplementedError('the attention kernels are built for dim_head = 64')
 
         self.max_seq_len = max_seq_len
         self.abs_pos_emb = nn.Embedding(max_seq_len, dim) if abs_pos_emb else None
         self.dim, self.dim_text = dim, dim_text
-        self.has_freq_axis = False
+        self.has_freq_axis = has_freq_axis
+        self.freq_heads = freq_heads
         self.depth, self.text_depth = depth, text_depth
         self.heads, self.text_heads = heads, text_heads
         self.ff_inner, self.text_ff_inner = int(dim * ff_mult), int(dim_text * text_ff_mult)
@@ -305,6 +309,8 @@ class Transformer(Module):
         nn.init.normal_(self.text_registers, std=0.02)
         self.rotary_emb = RotaryEmbedding(dim_head)
         self.text_rotary_emb = RotaryEmbedding(text_dim_head)
+        if has_freq_axis:
+            self.freq_rotary_emb = RotaryEmbedding(freq_dim_head)
         self.cond_on_time = cond_on_time
         norm_klass = (lambda: AdaptiveRMSNorm(dim)) if cond_on_time else (lambda: RMSNorm(dim))
         post_klass = (lambda: AdaLNZero(dim)) if cond_on_time else Identity
@@ -325,8 +331,10 @@ class Transformer(Module):
                 norm_klass(),
                 FeedForward(dim, ff_mult, dropout),
                 post_klass(),
-                None, None, None])
-            speech_hc = ModuleList([HyperConnections(4, dim=dim) for _ in range(3)] + [None])
+                norm_klass() if has_freq_axis else None,
+                Attention(dim, freq_heads, freq_dim_head, learned_value_residual_mix=False, gate_value_heads=False) if has_freq_axis else None,
+                post_klass() if has_freq_axis else None])
+            speech_hc = ModuleList([HyperConnections(4, dim=dim) for _ in range(3)] + [HyperConnections(4, dim=dim) if has_freq_axis else None])
             text_modules = text_hc = None
             if has_text:
                 text_modules = ModuleList([
@@ -444,11 +452,14 @@ class Transformer(Module):
         g.text_registers = lay.add(self.text_registers)
         g.final_g = lay.add(self.final_norm.g)
         # hoisted time conditioning: rows [layer][attn_norm gamma | attn AdaLN gate | ff_norm gamma | ff AdaLN gate]
+        # (with has_freq_axis two more slots per layer: [freq_attn_norm gamma | freq attn AdaLN gate]; depth is even, so the row
+        #  count stays a multiple of 4 D -- cond_bwd_prep only needs gamma / gate slots to alternate)
+        self._ncs = ncs = 6 if self.has_freq_axis else 4
         if self.cond_on_time:
             lay.align()
             g.wcond = lay.n
             for (sm, _tm) in self.layers:
-                for k, mod in enumerate((sm[2], sm[5], sm[6], sm[8])):
+                for k, mod in enumerate((sm[2], sm[5], sm[6], sm[8]) + ((sm[9], sm[11]) if self.has_freq_axis else ())):
                     lay.add(mod.to_gamma.weight, chain=True)
             g.bcond = lay.hole(0)
             for (sm, _tm) in self.layers:
@@ -456,6 +467,9 @@ class Transformer(Module):
                 lay.add(sm[5].to_gamma.bias, chain=True)
                 lay.hole(D, chain=True)
                 lay.add(sm[8].to_gamma.bias, chain=True)
+                if self.has_freq_axis:
+                    lay.hole(D, chain=True)
+                    lay.add(sm[11].to_gamma.bias, chain=True)
         lay.align()
         g.end = lay.n
         recs = []
@@ -471,9 +485,18 @@ class Transformer(Module):
                 nf, nrest = sm[4].split_dims
                 s.lfe = NS(w=lay.add(sm[4].linear.weight), nf=nf, nout=nf + nrest)
             s.ff = self._ff_rec(lay, sm[7], D)
+            s.fattn = None
+            if self.has_freq_axis:
+                fa = sm[10]
+                s.fattn = NS(w=lay.add(fa.to_q.weight), H=self.freq_heads, I=fa.to_q.out_features)
+                lay.add(fa.to_k.weight, chain=True)
+                lay.add(fa.to_v.weight, chain=True)
+                s.fattn.out = lay.add(fa.to_out.weight)
             if not self.cond_on_time:
                 s.attn_g, s.ff_g = lay.add(sm[2].g), lay.add(sm[6].g)
-            s.hc = [self._hc_rec(lay, h, D) for h in list(shc)[:3]]
+                if self.has_freq_axis:
+                    s.fattn_g = lay.add(sm[9].g)
+            s.hc = [self._hc_rec(lay, h, D) for h in list(shc) if exists(h)]
             r.s = s
             r.t = None
             if exists(tm):
@@ -518,6 +541,9 @@ class Transformer(Module):
                 r.s.skipT = tr(r.s.skip, D, 2 * D)        # (2D, D)
             if exists(r.s.lfe):
                 r.s.lfe.wT = tr(r.s.lfe.w, r.s.lfe.nout, D)      # (D, nout)
+            if exists(r.s.fattn):
+                r.s.fattn.wT = tr(r.s.fattn.w, 3 * r.s.fattn.I, D)      # (D, 3I)
+                r.s.fattn.outT = tr(r.s.fattn.out, D, r.s.fattn.I)      # (I, D)
             if exists(r.t):
                 r.t.crossT = tr(r.t.cross, r.t.cross_rows, D + Dt)     # (D+Dt, rows)
         self._tlist, self._tsize = tl, tn
@@ -631,15 +657,32 @@ class Transformer(Module):
     # ------------------------------------------------------------------ public forward
 
     def forward(self, x, times=None, mask=None, text_embed=None):
-        assert x.ndim == 3, 'has_freq_axis tensors (4 dims) are not supported'
+        assert (x.ndim == 4) == self.has_freq_axis, '`has_freq_axis` must be set if passing in tensor with frequency dimension (4 ndims), and not set if passing in only 3'
         assert not (exists(times) ^ self.cond_on_time), '`times` must be passed in if `cond_on_time` is set to `True` and vice versa'
+        if self.has_freq_axis:
+            # e2_tts.py:744-752: the F frequency tokens ride in the batch ((b f) n d); text and mask are repeated for them.  The
+            # conditioning stays one row per ORIGINAL batch element: the kernels index it by row // (F N)
+            Bo, F = x.shape[:2]
+            if not 1 <= F <= 8:
+                raise NotImplementedError('the frequency attention kernel is built for up to 8 frequency tokens')
+            self._freq_len = F
+            if exists(text_embed):
+                text_embed = text_embed.repeat_interleave(F, dim=0)
+            if exists(mask):
+                mask = mask.repeat_interleave(F, dim=0)
+            self._rot_table(F, x.device)                           # (cached before any recording starts)
+            out = self._forward3(x.reshape(Bo * F, *x.shape[2:]), times, mask, text_embed, Bo)
+            return out.reshape(Bo, F, *out.shape[1:])
+        return self._forward3(x, times, mask, text_embed, x.shape[0])
+
+    def _forward3(self, x, times, mask, text_embed, Bo):
         B, T, _ = x.shape
         if exists(self.abs_pos_emb):
             assert T <= self.max_seq_len, f'{T} exceeds the set `max_seq_len` ({self.max_seq_len}) on Transformer'
         cond = None
         if exists(times):
             if times.ndim == 0:
-                times = times[None].expand(B)
+                times = times[None].expand(Bo)
             cond = self._time_cond(times)                          # (B, D) fp32: RandomFourierEmbed + Linear + SiLU kernel
         need_grad = torch.is_grad_enabled() and (
             x.requires_grad or (exists(cond) and cond.requires_grad) or (exists(text_embed) and text_embed.requires_grad)
@@ -745,7 +788,8 @@ class Transformer(Module):
 
     def _plan_forward(self, x, cond, text_embed, mask, need_grad, rot):
         p_drop = self.dropout if self.training else 0.
-        key = (tuple(x.shape), exists(text_embed), exists(mask), need_grad, p_drop, str(x.device))
+        key = (tuple(x.shape), exists(text_embed), exists(mask), need_grad, p_drop, str(x.device),
+               self._freq_len if self.has_freq_axis else 1)
         st = self._plans.get(key)
         if st is None:                              # first sighting: eager (one-off shapes never pay for a recording)
             if len(self._plans) > 64:
@@ -891,6 +935,11 @@ class Transformer(Module):
         N = T + R
         Mtok = B * N
         run = NS(B=B, T=T, N=N, Mtok=Mtok, tape=[] if want_tape else None, dev=dev)
+        # has_freq_axis: B counts (batch element, frequency token) pairs; one conditioning row serves the F N tokens of a batch element
+        run.F = self._freq_len if self.has_freq_axis else 1
+        run.rpb = run.F * N
+        run.frot = self._rot_table(run.F, dev) if self.has_freq_axis else None
+        ncs = self._ncs
         tape = run.tape
         p_drop = self.dropout if self.training else 0.
         run.p_drop = p_drop
@@ -908,8 +957,8 @@ class Transformer(Module):
         if self.cond_on_time:
             cond = cond if (cond.dtype == f32 and cond.is_contiguous()) else cond.float().contiguous()
             cb = ops.cast_bf16(cond, torch.empty(cond.shape, dtype=bf16, device=dev))
-            wc = self._w(g.wcond, 4 * depth * D, D)
-            condall = ops.gemm_nt(cb, wc, bias=self._f(g.bcond, 4 * depth * D), out_dtype=f32)       # (B, 4LD)
+            wc = self._w(g.wcond, ncs * depth * D, D)
+            condall = ops.gemm_nt(cb, wc, bias=self._f(g.bcond, ncs * depth * D), out_dtype=f32)       # (B, 4LD)
             run.cb, run.condall = cb, condall
             run.gates = ops.sigmoid(condall)
             run.dcond = ops.zeros(condall.shape, f32, dev) if want_tape else None
@@ -924,6 +973,7 @@ class Transformer(Module):
             st = _Stream(ops.stream_pack_fwd(te, None, self._f(g.text_registers, R * Dt).view(R, Dt)), 't')
         run.has_text = exists(st)
         run.vfirst = {'x': None, 't': None}
+        run.fvfirst = None
         run.attn0 = {'x': None, 't': None}
         skips = []
 
@@ -1012,6 +1062,7 @@ class Transformer(Module):
         tape = run.tape
         key = S.key
         L = self.depth
+        ncs, rpbc = self._ncs, run.rpb
         # ---- conv
         binp, rec = self._hc_width(run, S, lr.hc[0])
         cw = self._f(lr.conv.w, D * lr.conv.ks).view(D, lr.conv.ks)
@@ -1027,8 +1078,8 @@ class Transformer(Module):
         if text or not self.cond_on_time:
             gam, off, rpb, gate = self._f(lr.attn_g, D).view(1, D), 0., Mtok, None
         else:
-            gam, off, rpb = run.condall[:, (ind * 4 + 0) * D:(ind * 4 + 1) * D], 1., N
-            gate = run.gates[:, (ind * 4 + 1) * D:(ind * 4 + 2) * D]
+            gam, off, rpb = run.condall[:, (ind * ncs + 0) * D:(ind * ncs + 1) * D], 1., rpbc
+            gate = run.gates[:, (ind * ncs + 1) * D:(ind * ncs + 2) * D]
         xn, rn = ops.rmsnorm_fwd(binp, gam, off, rpb)
         lfe = None if text else lr.lfe
         hf = xa = None
@@ -1044,18 +1095,37 @@ class Transformer(Module):
             run.vfirst[key] = ast.Vorig if a.laser > 0 else ast.V      # (LASER: the values before the exp map)
         sid = (ind * 2 + int(text)) * 4
         Og = ops.attn_fwd(ast, run.kmask, run.p_drop, run.seed, sid, run.seed_dev)
-        y = ops.gemm_nt(Og, self._w(a.out, D, a.I), colscale=gate, rows_per_batch=N)
+        y = ops.gemm_nt(Og, self._w(a.out, D, a.I), colscale=gate, rows_per_batch=rpbc)
         self._hc_depth(S, rec, y)
         if exists(tape):
             tape.append(('attn', rec, lr, ind, text, binp, xn, rn, qkvg, ast, first, y, key, sid, hf, xa))
+        # ---- attention across the frequency tokens of a frame (e2_tts.py:920-932), audio stream only
+        if self.has_freq_axis and not text:
+            binp, rec = self._hc_width(run, S, lr.hc[3])
+            fa = lr.fattn
+            if not self.cond_on_time:
+                gam, off, rpb, gate = self._f(lr.fattn_g, D).view(1, D), 0., Mtok, None
+            else:
+                gam, off, rpb = run.condall[:, (ind * ncs + 4) * D:(ind * ncs + 5) * D], 1., rpbc
+                gate = run.gates[:, (ind * ncs + 5) * D:(ind * ncs + 6) * D]
+            xn, rn = ops.rmsnorm_fwd(binp, gam, off, rpb)
+            qkv = ops.gemm_nt(xn, self._w(fa.w, 3 * fa.I, D))
+            ffirst = run.fvfirst is None
+            fo = ops.freq_attn_fwd(qkv, B // run.F, run.F, N, fa.H, run.frot[0], run.frot[1], None if ffirst else run.fvfirst)
+            if ffirst:
+                run.fvfirst = qkv[:, 2 * fa.I:]              # the first layer's values, as the projection left them
+            y = ops.gemm_nt(fo, self._w(fa.out, D, fa.I), colscale=gate, rows_per_batch=rpbc)
+            self._hc_depth(S, rec, y)
+            if exists(tape):
+                tape.append(('fattn', rec, lr, ind, binp, xn, rn, qkv, fo, ffirst, y, key))
         # ---- feed-forward
         binp, rec = self._hc_width(run, S, lr.hc[2])
         f = lr.ff
         if text or not self.cond_on_time:
             gam, off, rpb, gate = self._f(lr.ff_g, D).view(1, D), 0., Mtok, None
         else:
-            gam, off, rpb = run.condall[:, (ind * 4 + 2) * D:(ind * 4 + 3) * D], 1., N
-            gate = run.gates[:, (ind * 4 + 3) * D:(ind * 4 + 4) * D]
+            gam, off, rpb = run.condall[:, (ind * ncs + 2) * D:(ind * ncs + 3) * D], 1., rpbc
+            gate = run.gates[:, (ind * ncs + 3) * D:(ind * ncs + 4) * D]
         xn, rn = ops.rmsnorm_fwd(binp, gam, off, rpb)
         if ops.fuse_geglu and not exists(tape) and ops.can_fuse_geglu(xn.shape[0], f.F, D):
             # no-grad forward (sample()): GEGLU as the epilogue of the first GEMM, the pre-activation H is never written
@@ -1066,7 +1136,7 @@ class Transformer(Module):
         else:
             Hh = ops.gemm_nt(xn, self._w(f.w1, 2 * f.F, D), bias=self._f(f.b1, 2 * f.F))
             act = ops.geglu_fwd(Hh, run.p_drop, run.seed, sid + 1, run.seed_dev)
-        y = ops.gemm_nt(act, self._w(f.w2, D, f.F), bias=self._f(f.b2, D), colscale=gate, rows_per_batch=N)
+        y = ops.gemm_nt(act, self._w(f.w2, D, f.F), bias=self._f(f.b2, D), colscale=gate, rows_per_batch=rpbc)
         self._hc_depth(S, rec, y)
         if exists(tape):
             tape.append(('ff', rec, lr, ind, text, binp, xn, rn, Hh, act, y, key, sid + 1))
@@ -1182,7 +1252,9 @@ class Transformer(Module):
         if run.has_text:
             grads['t'] = ops.zeros((Mtok, 4, Dt), bf16, dev)
         dvfirst = {'x': ops.zeros((B, self.heads, N, 64), f32, dev),
-                   't': ops.zeros((B, self.text_heads, N, 64), f32, dev) if run.has_text else None}
+                   't': ops.zeros((B, self.text_heads, N, 64), f32, dev) if run.has_text else None,
+                   'f': ops.zeros((Mtok, self.freq_heads * 64), f32, dev) if self.has_freq_axis else None}
+        ncs = self._ncs
         skip_grads = []
 
         # (history: with LDS float atomics in its gradient flush hc_bwd_kernel did not reproduce its own results next to an
@@ -1287,6 +1359,8 @@ class Transformer(Module):
                 rec.dbin = dbin.view(Mtok, C)
             elif kind == 'attn':
                 self._attn_bwd(run, ent, G, dvfirst)
+            elif kind == 'fattn':
+                self._fattn_bwd(run, ent, G, dvfirst)
             elif kind == 'ff':
                 self._ff_bwd(run, ent, G)
             elif kind == 'cross':
@@ -1368,11 +1442,12 @@ class Transformer(Module):
             # gate slots x (1 - gate), bf16 copies (plain and transposed) for the two GEMMs below; only the AdaLN-Zero
             # biases (slots 1, 3 of a layer's row) receive a bias gradient -- slots 0, 2 are layout holes that must
             # keep a zero gradient (AdaptiveRMSNorm.to_gamma has no bias), or the flat optimizer would train them
-            dcb, dct = ops.cond_bwd_prep(run.dcond, run.gates, G(g.bcond, 4 * L * D), B, L, D)
-            ops.gemm_tn(dcb, run.cb, G(g.wcond, 4 * L * D, D))                    # d W_cond
+            Bc = run.dcond.shape[0]                                                # conditioning rows (= B / F with a frequency axis)
+            dcb, dct = ops.cond_bwd_prep(run.dcond, run.gates, G(g.bcond, ncs * L * D), Bc, L * ncs // 4, D)
+            ops.gemm_tn(dcb, run.cb, G(g.wcond, ncs * L * D, D))                  # d W_cond
             dcT = ops.zeros((D, dct.shape[1]), f32, dev)
-            ops.gemm_tn(self._w(g.wcond, 4 * L * D, D), dct, dcT)                 # (D, B) = W_cond^T . dcond^T
-            dcond = ops.transpose_f32(dcT, B)
+            ops.gemm_tn(self._w(g.wcond, ncs * L * D, D), dct, dcT)               # (D, B) = W_cond^T . dcond^T
+            dcond = ops.transpose_f32(dcT, Bc)
         yield 0, g.end
         return dxs, dcond, dtext, gflat
 
@@ -1386,10 +1461,11 @@ class Transformer(Module):
             dgam = G(lr.attn_g, 1, D)
             dao = rec.dy
         else:
-            gam, off, rpb = run.condall[:, (ind * 4 + 0) * D:(ind * 4 + 1) * D], 1., N
-            dgam = run.dcond[:, (ind * 4 + 0) * D:(ind * 4 + 1) * D]
-            gate = run.gates[:, (ind * 4 + 1) * D:(ind * 4 + 2) * D]
-            dao = ops.gate_bwd(rec.dy, y, gate, run.dcond[:, (ind * 4 + 1) * D:(ind * 4 + 2) * D], N)
+            ncs = self._ncs
+            gam, off, rpb = run.condall[:, (ind * ncs + 0) * D:(ind * ncs + 1) * D], 1., run.rpb
+            dgam = run.dcond[:, (ind * ncs + 0) * D:(ind * ncs + 1) * D]
+            gate = run.gates[:, (ind * ncs + 1) * D:(ind * ncs + 2) * D]
+            dao = ops.gate_bwd(rec.dy, y, gate, run.dcond[:, (ind * ncs + 1) * D:(ind * ncs + 2) * D], run.rpb)
         run.wgrad(dao, ast.Og, G(a.out, D, a.I))
         dOg = ops.gemm_nt(dao, self._wT(a.outT))                                   # (Mtok, I)
         dQ, dK, dV, dgate = ops.attn_bwd(ast, dOg, run.kmask, run.p_drop, run.seed, sid, run.seed_dev)
@@ -1409,6 +1485,28 @@ class Transformer(Module):
             dxn = ops.gemm_nt(dhf, self._wT(lfe.wT))
         rec.dbin = ops.rmsnorm_bwd(dxn, binp, rn, gam, off, rpb, dgam)
 
+    def _fattn_bwd(self, run, ent, G, dvfirst):
+        """backward of the attention across the frequency tokens (audio stream, has_freq_axis)"""
+        _, rec, lr, ind, binp, xn, rn, qkv, fo, ffirst, y, key = ent
+        N, Mtok, D = run.N, run.Mtok, self.dim
+        fa, ncs = lr.fattn, self._ncs
+        if not self.cond_on_time:
+            gam, off, rpb = self._f(lr.fattn_g, D).view(1, D), 0., Mtok
+            dgam = G(lr.fattn_g, 1, D)
+            dao = rec.dy
+        else:
+            gam, off, rpb = run.condall[:, (ind * ncs + 4) * D:(ind * ncs + 5) * D], 1., run.rpb
+            dgam = run.dcond[:, (ind * ncs + 4) * D:(ind * ncs + 5) * D]
+            gate = run.gates[:, (ind * ncs + 5) * D:(ind * ncs + 6) * D]
+            dao = ops.gate_bwd(rec.dy, y, gate, run.dcond[:, (ind * ncs + 5) * D:(ind * ncs + 6) * D], run.rpb)
+        run.wgrad(dao, fo, G(fa.out, D, fa.I))
+        dfo = ops.gemm_nt(dao, self._wT(fa.outT))                                  # (Mtok, I)
+        dqkv = ops.freq_attn_bwd(dfo, qkv, run.B // run.F, run.F, N, fa.H, run.frot[0], run.frot[1],
+                                 None if ffirst else run.fvfirst, dvfirst['f'], first_layer=ffirst)
+        run.wgrad(dqkv, xn, G(fa.w, 3 * fa.I, D))
+        dxn = ops.gemm_nt(dqkv, self._wT(fa.wT))
+        rec.dbin = ops.rmsnorm_bwd(dxn, binp, rn, gam, off, rpb, dgam)
+
     def _ff_bwd(self, run, ent, G):
         _, rec, lr, ind, text, binp, xn, rn, Hh, act, y, key, sid = ent
         N, Mtok = run.N, run.Mtok
@@ -1419,10 +1517,11 @@ class Transformer(Module):
             dgam = G(lr.ff_g, 1, D)
             dao = rec.dy
         else:
-            gam, off, rpb = run.condall[:, (ind * 4 + 2) * D:(ind * 4 + 3) * D], 1., N
-            dgam = run.dcond[:, (ind * 4 + 2) * D:(ind * 4 + 3) * D]
-            gate = run.gates[:, (ind * 4 + 3) * D:(ind * 4 + 4) * D]
-            dao = ops.gate_bwd(rec.dy, y, gate, run.dcond[:, (ind * 4 + 3) * D:(ind * 4 + 4) * D], N)
+            ncs = self._ncs
+            gam, off, rpb = run.condall[:, (ind * ncs + 2) * D:(ind * ncs + 3) * D], 1., run.rpb
+            dgam = run.dcond[:, (ind * ncs + 2) * D:(ind * ncs + 3) * D]
+            gate = run.gates[:, (ind * ncs + 3) * D:(ind * ncs + 4) * D]
+            dao = ops.gate_bwd(rec.dy, y, gate, run.dcond[:, (ind * ncs + 3) * D:(ind * ncs + 4) * D], run.rpb)
         run.wgrad(dao, act, G(f.w2, D, f.F), colsum=G(f.b2, D))                  # dW2 and db2 in one pass over dY
         dact = ops.gemm_nt(dao, self._wT(f.w2T))
         dH = ops.geglu_bwd(dact, Hh, run.p_drop, run.seed, sid, run.seed_dev)

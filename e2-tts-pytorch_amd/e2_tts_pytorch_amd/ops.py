@@ -1018,3 +1018,27 @@ def fourier_cat_bwd(dy, h, nf):
     dh = torch.empty((M, nh), dtype=bf16, device=h.device)
     _lib.get().e2k_fourier_cat_bwd(_p(dy), dy.stride(0), _p(h), h.stride(0), _p(dh), dh.stride(0), M, nf, nh - nf, _stream(h))
     return dh
+
+
+def freq_attn_fwd(qkv, B, F, N, H, cosb, sinb, vfirst=None):
+    """attention over the F frequency tokens of every (batch row, frame) (e2_tts.py:920-932); qkv (B*F*N, 3*H*64) bf16 in
+    token order (b f) n; vfirst = the first layer's v columns (a strided view) or None"""
+    _chk(qkv, cosb, sinb, vfirst)
+    I = H * 64
+    assert qkv.dtype == bf16 and qkv.shape == (B * F * N, 3 * I) and qkv.stride(1) == 1
+    assert cosb.shape == (F, 32) and cosb.is_contiguous() and sinb.is_contiguous()
+    out = torch.empty((B * F * N, I), dtype=bf16, device=qkv.device)
+    _lib.get().e2k_freq_attn_fwd(_p(qkv), qkv.stride(0), _p(vfirst), 0 if vfirst is None else vfirst.stride(0), _p(cosb), _p(sinb),
+                                 _p(out), B, F, N, H, _stream(qkv))
+    return out
+
+
+def freq_attn_bwd(dout, qkv, B, F, N, H, cosb, sinb, vfirst=None, dvfirst=None, first_layer=False):
+    _chk(dout, qkv, cosb, sinb, vfirst, dvfirst)
+    I = H * 64
+    assert dout.dtype == bf16 and dout.shape == (B * F * N, I) and dout.is_contiguous()
+    assert dvfirst is None or (dvfirst.dtype == f32 and dvfirst.shape == (B * F * N, I) and dvfirst.is_contiguous())
+    dqkv = torch.empty((B * F * N, 3 * I), dtype=bf16, device=qkv.device)
+    _lib.get().e2k_freq_attn_bwd(_p(dout), _p(qkv), qkv.stride(0), _p(vfirst), 0 if vfirst is None else vfirst.stride(0), _p(cosb),
+                                 _p(sinb), _p(dvfirst), int(first_layer), _p(dqkv), dqkv.stride(0), B, F, N, H, _stream(dout))
+    return dqkv

@@ -257,6 +257,19 @@ int e2k_attn_bwd(const void* dOg, const void* O, const float* gate, const float*
                  int B, int H, int N, int Npad, float p_drop, uint32_t seed, const uint32_t* seed_dev,
                  uint32_t stream_id, int flags, void* stream);
 
+/* ---- attention across the frequency tokens of a frame (Transformer(has_freq_axis = True), e2_tts.py:653-656,920-932) ----
+ * The reference rearranges '(b f) n d -> (b n) f d' and runs a default-keyword x_transformers.Attention (dim_head = 64: no
+ * mask, dropout, soft-clamp or head gates; rotary over the token index; value residual mixed at 0.5) over the F <= 8 tokens.
+ * qkv (B*F*N, ld) bf16 = [q (H*64) | k | v] in the backbone's own token order (row (b F + j) N + n): no rearrangement is
+ * materialised.  vfirst (row stride ldv): the first layer's v columns, NULL on the first layer.  cosb / sinb: rotary table
+ * (F, 32).  out (B*F*N, H*64).  Backward: dqkv (B*F*N, lddq) from dout; dvfirst (B*F*N, H*64) fp32 is ACCUMULATED on the
+ * later layers and consumed when first_layer = 1 (as in e2k_qkv_post_bwd). */
+int e2k_freq_attn_fwd(const void* qkv, int64_t ld, const void* vfirst, int64_t ldv, const float* cosb, const float* sinb,
+                      void* out, int B, int F, int N, int H, void* stream);
+int e2k_freq_attn_bwd(const void* dout, const void* qkv, int64_t ld, const void* vfirst, int64_t ldv, const float* cosb,
+                      const float* sinb, float* dvfirst, int first_layer, void* dqkv, int64_t lddq, int B, int F, int N,
+                      int H, void* stream);
+
 /* ---- MelSpec (e2_tts.py:248-290 -> torchaudio MelSpectrogram(n_fft=1024, hop, power=1, center, htk, norm=None)) ----
  * wave (B, nw) fp32 -> out (B, n_mels, 1 + nw/hop) fp32 = log(clamp(mel, 1e-5)).  window (n_fft) periodic Hann,
  * fb (n_fft/2+1, n_mels) filterbank, twc/tws (n_fft/2): cos/sin(2*pi*k/n_fft).  n_fft must be 1024.

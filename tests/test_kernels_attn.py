@@ -175,3 +175,51 @@ def test_attention_shared_dropout_mask(dev, N):
             ops.attn_share_dropmask = True
     for a, b in zip(*res):
         assert torch.equal(a, b)
+
+
+@pytest.mark.parametrize('F,has_vres', [(3, False), (2, True), (8, True), (1, False)])
+def test_freq_attention(dev, F, has_vres, dma_landing):
+    """attention across the F frequency tokens of a frame (e2_tts.py:920-932) against the oracle's default-keyword Attention
+    core (rotary over the token index, plain softmax, value residual at 0.5), forward and backward, on the backbone's own
+    token order (b f) n -- the reference's '(b f) n d -> (b n) f d' rearrangement is never materialised"""
+    from e2_tts_pytorch_amd import ops
+    from oracle.e2tts_oracle import apply_rotary_pos_emb
+    torch.manual_seed(1)
+    B, N, H = 2, 5, 2
+    I = H * 64
+    qkv = torch.randn(B * F * N, 3 * I).to(bf16)
+    vf = torch.randn(B * F * N, 3 * I).to(bf16) if has_vres else None          # the first layer's projection output
+    dout = torch.randn(B * F * N, I).to(bf16)
+    cosb, sinb = ops.rotary_table(F, dev)
+
+    def ref(qkv_, vf_):
+        # rows (b f) n  ->  (b n), h, f, 64
+        def heads(t):
+            return t.view(B, F, N, H, 64).permute(0, 2, 3, 1, 4).reshape(B * N, H, F, 64)
+        q, k, v = (heads(t) for t in qkv_.float().split(I, dim=-1))
+        if vf_ is not None:
+            v = heads(vf_.float()[:, 2 * I:]).lerp(v, 0.5)
+        freqs, _ = RotaryEmbedding(64).forward_from_seq_len(F)
+        q, k = apply_rotary_pos_emb(q, freqs), apply_rotary_pos_emb(k, freqs)
+        attn = (torch.einsum('bhid,bhjd->bhij', q, k) * 0.125).softmax(dim=-1)
+        out = torch.einsum('bhij,bhjd->bhid', attn, v)                           # (b n) h f d
+        return out.view(B, N, H, F, 64).permute(0, 3, 1, 2, 4).reshape(B * F * N, I)
+
+    qr = qkv.float().requires_grad_(True)
+    vr = vf.float().requires_grad_(True) if has_vres else None
+    out_r = ref(qr, vr)
+    out_r.backward(dout.float())
+
+    qd = qkv.to(dev)
+    vfd = vf.to(dev)[:, 2 * I:] if has_vres else None
+    out = ops.freq_attn_fwd(qd, B, F, N, H, cosb, sinb, vfd)
+    assert rel(out, out_r) < 1e-2, rel(out, out_r)
+    acc0 = torch.randn(B * F * N, I)
+    dvfirst = acc0.clone().to(dev)
+    dqkv = ops.freq_attn_bwd(dout.to(dev), qd, B, F, N, H, cosb, sinb, vfd, dvfirst, first_layer=not has_vres)
+    want = qr.grad.clone()
+    if has_vres:        # later layer: half of dv' goes to the first layer's values through the accumulator
+        assert rel(dvfirst.cpu() - acc0, vr.grad[:, 2 * I:]) < 1e-2
+    else:               # first layer: the accumulated value-residual gradient joins this layer's dv
+        want[:, 2 * I:] += acc0
+    assert rel(dqkv, want) < 1.5e-2, rel(dqkv, want)
