@@ -222,7 +222,8 @@ __global__ __launch_bounds__(256) void colsum_kernel(const bf16_t* x, long ldx, 
 
 // LinearFourierEmbed's activation (e2_tts.py:368-386, `attn_fourier_embed_input`): h (M, nf + nrest) = linear(x) ->
 // y (M, 2 nf + nrest) = [sin h[:nf] | cos h[:nf] | h[nf:]].  One thread per 8 output columns (nf, nrest multiples of 8).
-__global__ __launch_bounds__(256) void fourier_cat_fwd_kernel(const bf16_t* h, long ldh, bf16_t* y, long ldy, long M, int nf, int nrest) {
+// h stays fp32 (the projection GEMM's fp32 output): rounding an angle of a few radians to bf16 moves its sine by percents.
+__global__ __launch_bounds__(256) void fourier_cat_fwd_kernel(const float* h, long ldh, bf16_t* y, long ldy, long M, int nf, int nrest) {
     const int cv = (2 * nf + nrest) / 8;
     const long total = M * cv;
     for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < total; i += (long)gridDim.x * 256) {
@@ -230,7 +231,11 @@ __global__ __launch_bounds__(256) void fourier_cat_fwd_kernel(const bf16_t* h, l
         const int c = (int)(i - m * cv) * 8;
         const int src = c < nf ? c : (c < 2 * nf ? c - nf : c - nf);
         float f[8];
-        unpack8(ld<u32x4>(h + m * ldh + src), f);
+        {
+            const f32x4 a = ld<f32x4>(h + m * ldh + src), b = ld<f32x4>(h + m * ldh + src + 4);
+#pragma unroll
+            for (int k = 0; k < 4; ++k) { f[k] = a[k]; f[4 + k] = b[k]; }
+        }
         if (c < nf) {
 #pragma unroll
             for (int k = 0; k < 8; ++k) f[k] = sinf(f[k]);
@@ -243,7 +248,7 @@ __global__ __launch_bounds__(256) void fourier_cat_fwd_kernel(const bf16_t* h, l
 }
 
 // dh[:nf] = dy_sin cos h - dy_cos sin h ;  dh[nf:] = dy[2 nf:]
-__global__ __launch_bounds__(256) void fourier_cat_bwd_kernel(const bf16_t* dy, long ldy, const bf16_t* h, long ldh, bf16_t* dh, long lddh,
+__global__ __launch_bounds__(256) void fourier_cat_bwd_kernel(const bf16_t* dy, long ldy, const float* h, long ldh, bf16_t* dh, long lddh,
                                                               long M, int nf, int nrest) {
     const int cv = (nf + nrest) / 8;
     const long total = M * cv;
@@ -253,7 +258,11 @@ __global__ __launch_bounds__(256) void fourier_cat_bwd_kernel(const bf16_t* dy, 
         float f[8];
         if (c < nf) {
             float hv[8], ds[8], dc[8];
-            unpack8(ld<u32x4>(h + m * ldh + c), hv);
+            {
+                const f32x4 a = ld<f32x4>(h + m * ldh + c), b = ld<f32x4>(h + m * ldh + c + 4);
+#pragma unroll
+                for (int k = 0; k < 4; ++k) { hv[k] = a[k]; hv[4 + k] = b[k]; }
+            }
             unpack8(ld<u32x4>(dy + m * ldy + c), ds);
             unpack8(ld<u32x4>(dy + m * ldy + nf + c), dc);
 #pragma unroll
@@ -702,27 +711,27 @@ static int colsum_bf16_impl(const void* x, int64_t ldx, float* out, int M, int N
     return 0;
 }
 
-static int fourier_cat_fwd_impl(const void* h, int64_t ldh, void* y, int64_t ldy, int64_t M, int nf, int nrest, void* stream) {
+static int fourier_cat_fwd_impl(const float* h, int64_t ldh, void* y, int64_t ldy, int64_t M, int nf, int nrest, void* stream) {
     if (M <= 0) return 0;
-    if (nf < 0 || nrest < 0 || (nf & 7) || (nrest & 7) || nf + nrest == 0 || (ldh & 7) || (ldy & 7)) return E2K_ERR_SHAPE;
+    if (nf < 0 || nrest < 0 || (nf & 7) || (nrest & 7) || nf + nrest == 0 || (ldh & 3) || (ldy & 7)) return E2K_ERR_SHAPE;
     if (!h || !y) return E2K_ERR_ARG;
     if (((uintptr_t)h | (uintptr_t)y) & 15) return E2K_ERR_ALIGN;
     long g = (M * ((2 * nf + nrest) / 8) + 255) / 256; if (g > 8192) g = 8192;
-    hipLaunchKernelGGL(fourier_cat_fwd_kernel, dim3((int)g), dim3(256), 0, (hipStream_t)stream, (const bf16_t*)h, (long)ldh, (bf16_t*)y,
+    hipLaunchKernelGGL(fourier_cat_fwd_kernel, dim3((int)g), dim3(256), 0, (hipStream_t)stream, (const float*)h, (long)ldh, (bf16_t*)y,
                        (long)ldy, (long)M, nf, nrest);
     E2K_CHECK_LAUNCH();
     return 0;
 }
 
-static int fourier_cat_bwd_impl(const void* dy, int64_t ldy, const void* h, int64_t ldh, void* dh, int64_t lddh, int64_t M, int nf,
+static int fourier_cat_bwd_impl(const void* dy, int64_t ldy, const float* h, int64_t ldh, void* dh, int64_t lddh, int64_t M, int nf,
                                 int nrest, void* stream) {
     if (M <= 0) return 0;
-    if (nf < 0 || nrest < 0 || (nf & 7) || (nrest & 7) || nf + nrest == 0 || (ldh & 7) || (ldy & 7) || (lddh & 7)) return E2K_ERR_SHAPE;
+    if (nf < 0 || nrest < 0 || (nf & 7) || (nrest & 7) || nf + nrest == 0 || (ldh & 3) || (ldy & 7) || (lddh & 7)) return E2K_ERR_SHAPE;
     if (!dy || !h || !dh) return E2K_ERR_ARG;
     if (((uintptr_t)dy | (uintptr_t)h | (uintptr_t)dh) & 15) return E2K_ERR_ALIGN;
     long g = (M * ((nf + nrest) / 8) + 255) / 256; if (g > 8192) g = 8192;
     hipLaunchKernelGGL(fourier_cat_bwd_kernel, dim3((int)g), dim3(256), 0, (hipStream_t)stream, (const bf16_t*)dy, (long)ldy,
-                       (const bf16_t*)h, (long)ldh, (bf16_t*)dh, (long)lddh, (long)M, nf, nrest);
+                       (const float*)h, (long)ldh, (bf16_t*)dh, (long)lddh, (long)M, nf, nrest);
     E2K_CHECK_LAUNCH();
     return 0;
 }
@@ -855,11 +864,11 @@ extern "C" int e2k_dwconv_bwd(const void* dy, const void* pre, const void* x, co
     return e2k::dispatch("dwconv_bwd", dwconv_bwd_impl, dy, pre, x, mask, w, dx, dw, dbias, ws, B, N, C, ks, split, stream);
 }
 
-extern "C" int e2k_fourier_cat_fwd(const void* h, int64_t ldh, void* y, int64_t ldy, int64_t M, int nf, int nrest, void* stream) {
+extern "C" int e2k_fourier_cat_fwd(const float* h, int64_t ldh, void* y, int64_t ldy, int64_t M, int nf, int nrest, void* stream) {
     return e2k::dispatch("fourier_cat_fwd", fourier_cat_fwd_impl, h, ldh, y, ldy, M, nf, nrest, stream);
 }
 
-extern "C" int e2k_fourier_cat_bwd(const void* dy, int64_t ldy, const void* h, int64_t ldh, void* dh, int64_t lddh, int64_t M, int nf,
+extern "C" int e2k_fourier_cat_bwd(const void* dy, int64_t ldy, const float* h, int64_t ldh, void* dh, int64_t lddh, int64_t M, int nf,
                                    int nrest, void* stream) {
     return e2k::dispatch("fourier_cat_bwd", fourier_cat_bwd_impl, dy, ldy, h, ldh, dh, lddh, M, nf, nrest, stream);
 }

@@ -1085,7 +1085,7 @@ class Transformer(Module):
         hf = xa = None
         if exists(lfe):
             # attn_input_fourier_embed (e2_tts.py:909): bias-free projection, then [sin | cos | rest] feeds the q / k / v projections
-            hf = ops.gemm_nt(xn, self._w(lfe.w, lfe.nout, D))
+            hf = ops.gemm_nt(xn, self._w(lfe.w, lfe.nout, D), out_dtype=f32)      # (fp32: these are angles)
             xa = ops.fourier_cat_fwd(hf, lfe.nf)
         qkvg = torch.empty((Mtok, a.ldq), dtype=bf16, device=run.dev)[:, :a.cols]
         ops.gemm_nt(xn if xa is None else xa, self._w(a.w, a.cols, D), bias=self._f(a.bias, a.cols), out=qkvg)

@@ -284,6 +284,16 @@ class MelSpec(Module):
 
 # ------------------------------------------------------------------------------------------------ small modules
 
+class SplitFreq(Module):                                       # Rearrange('b n (f d) -> b f n d') (e2_tts.py:1010,1208)
+    def __init__(self, f):
+        super().__init__()
+        self.f = f
+
+    def forward(self, x):
+        b, n, fd = x.shape
+        return x.reshape(b, n, self.f, fd // self.f).permute(0, 2, 1, 3)
+
+
 class CharacterEmbed(Module):                                  # e2_tts.py:390-412
     def __init__(self, dim, num_embeds=256):
         super().__init__()
@@ -378,19 +388,20 @@ class DurationPredictor(Module):                               # e2_tts.py:956-1
                  tokenizer='char_utf8'):
         super().__init__()
         assert num_freq_tokens > 0
-        if num_freq_tokens != 1:
-            raise NotImplementedError('num_freq_tokens > 1 (has_freq_axis) is not built')
-        self.num_freq_tokens, self.has_freq_axis = 1, False
+        self.num_freq_tokens, self.has_freq_axis = num_freq_tokens, num_freq_tokens > 1
         if isinstance(transformer, dict):
             transformer = dict(transformer)
-            set_if_missing_key(transformer, 'has_freq_axis', False)
+            set_if_missing_key(transformer, 'has_freq_axis', self.has_freq_axis)
             transformer = Transformer(**transformer, cond_on_time=False)
         assert transformer.has_freq_axis == self.has_freq_axis
         self.mel_spec = MelSpec(**mel_spec_kwargs)
         self.num_channels = default(num_channels, self.mel_spec.n_mel_channels)
         self.transformer = transformer
         self.dim = transformer.dim
-        self.proj_in = nn.Linear(self.num_channels, self.dim)
+        if not self.has_freq_axis:                                  # e2_tts.py:1004-1011
+            self.proj_in = nn.Linear(self.num_channels, self.dim)
+        else:
+            self.proj_in = nn.Sequential(nn.Linear(self.num_channels, self.dim * num_freq_tokens), SplitFreq(num_freq_tokens))
         self.tokenizer, text_num_embeds = _resolve_tokenizer(tokenizer, text_num_embeds)
         self.embed_text = CharacterEmbed(transformer.dim_text, num_embeds=text_num_embeds, **char_embed_kwargs)
         self.hl_gauss_layer = HLGaussLayer(self.dim, hl_gauss_loss=hl_gauss_loss, use_regression=use_regression,
@@ -417,6 +428,8 @@ class DurationPredictor(Module):                               # e2_tts.py:956-1
             seq = torch.arange(seq_len, device=device)
             mask = mask & (seq[None, :] < rand_index[:, None])
         embed = self.transformer(x, mask=mask, text_embed=text_embed)
+        if self.has_freq_axis:                                      # e2_tts.py:1030,1098: mean over the frequency tokens
+            embed = embed.mean(dim=1)
         pooled = maybe_masked_mean(embed, mask)
         if not return_loss:
             return self.hl_gauss_layer(pooled)
@@ -534,15 +547,13 @@ class E2TTS(Module):
     ):
         super().__init__()
         assert num_freq_tokens > 0
-        if num_freq_tokens != 1:
-            raise NotImplementedError('num_freq_tokens > 1 (has_freq_axis) is not built')
         if odeint_kwargs.get('method', 'midpoint') not in _SOLVERS:
             raise NotImplementedError(f'solvers {sorted(_SOLVERS)} are built (the reference default is midpoint; dopri5 = torchdiffeq\'s adaptive default); '
                                       'adaptive torchdiffeq methods are not')
-        self.num_freq_tokens, self.has_freq_axis = 1, False
+        self.num_freq_tokens, self.has_freq_axis = num_freq_tokens, num_freq_tokens > 1
         if isinstance(transformer, dict):
             transformer = dict(transformer)
-            set_if_missing_key(transformer, 'has_freq_axis', False)
+            set_if_missing_key(transformer, 'has_freq_axis', self.has_freq_axis)
             transformer = Transformer(**transformer, cond_on_time=True)
         assert transformer.has_freq_axis == self.has_freq_axis
         self.transformer = transformer
@@ -559,10 +570,11 @@ class E2TTS(Module):
         self.sampling_rate = default(sampling_rate, getattr(self.mel_spec, 'sampling_rate', None))
         self.concat_cond = concat_cond                    # e2_tts.py:1196-1204: one projection of cat(cond, x) instead of two summed
         if concat_cond:
-            self.proj_in = nn.Linear(num_channels * 2, dim)
+            self.proj_in = nn.Linear(num_channels * 2, dim * num_freq_tokens)
         else:
-            self.proj_in = nn.Linear(num_channels, dim)
-            self.cond_proj_in = nn.Linear(num_channels, dim)
+            self.proj_in = nn.Linear(num_channels, dim * num_freq_tokens)
+            self.cond_proj_in = nn.Linear(num_channels, dim * num_freq_tokens)
+        self.maybe_split_freq = SplitFreq(num_freq_tokens) if self.has_freq_axis else nn.Identity()      # e2_tts.py:1208-1210
         self.to_pred = nn.Linear(dim, num_channels)
         self.tokenizer, text_num_embeds = _resolve_tokenizer(tokenizer, text_num_embeds)
         self.cond_drop_prob = cond_drop_prob
@@ -600,7 +612,10 @@ class E2TTS(Module):
         text_embed = None
         if exists(text) and not drop_text_cond:
             text_embed = self.embed_text(text, seq_len, mask=mask)
-        embed = self.transformer(x, times=times, mask=mask, text_embed=text_embed)
+        # (the split of the frequency tokens commutes with the sum of the two projections, e2_tts.py:1268-1277)
+        embed = self.transformer(self.maybe_split_freq(x), times=times, mask=mask, text_embed=text_embed)
+        if self.has_freq_axis:                            # e2_tts.py:1210,1296: mean over the frequency tokens
+            embed = embed.mean(dim=1)
         pred = _OutProjFn.apply(embed, self.to_pred.weight, self.to_pred.bias)
         if not return_drop_text_cond:
             return pred

@@ -1002,10 +1002,10 @@ def cfg_combine(pred, null_pred, cfg_strength, keep_parallel_frac=0., remove_par
 
 
 def fourier_cat_fwd(h, nf):
-    """[sin h[:, :nf] | cos h[:, :nf] | h[:, nf:]]  (LinearFourierEmbed, e2_tts.py:383-386); h (M, nf + nrest) bf16"""
+    """[sin h[:, :nf] | cos h[:, :nf] | h[:, nf:]]  (LinearFourierEmbed, e2_tts.py:383-386); h (M, nf + nrest) fp32 -> bf16"""
     _chk(h)
     M, nh = h.shape
-    assert h.dtype == bf16 and h.stride(1) == 1
+    assert h.dtype == f32 and h.stride(1) == 1
     y = torch.empty((M, nh + nf), dtype=bf16, device=h.device)
     _lib.get().e2k_fourier_cat_fwd(_p(h), h.stride(0), _p(y), y.stride(0), M, nf, nh - nf, _stream(h))
     return y
@@ -1014,7 +1014,7 @@ def fourier_cat_fwd(h, nf):
 def fourier_cat_bwd(dy, h, nf):
     _chk(dy, h)
     M, nh = h.shape
-    assert dy.dtype == bf16 and h.dtype == bf16 and dy.shape == (M, nh + nf) and dy.stride(1) == 1 and h.stride(1) == 1
+    assert dy.dtype == bf16 and h.dtype == f32 and dy.shape == (M, nh + nf) and dy.stride(1) == 1 and h.stride(1) == 1
     dh = torch.empty((M, nh), dtype=bf16, device=h.device)
     _lib.get().e2k_fourier_cat_bwd(_p(dy), dy.stride(0), _p(h), h.stride(0), _p(dh), dh.stride(0), M, nf, nh - nf, _stream(h))
     return dh

@@ -175,9 +175,10 @@ int e2k_colsum_bf16(const void* x, int64_t ldx, float* out, int M, int N, void* 
 
 /* LinearFourierEmbed's activation (e2_tts.py:368-386; Transformer(attn_fourier_embed_input = True), :639,909): the bias-free
  * projection h (M, nf + nrest) is an e2k_gemm_nt_bf16 call; this is  y (M, 2 nf + nrest) = [sin h[:nf] | cos h[:nf] | h[nf:]]
- * and its backward  dh[:nf] = dy[:nf] cos h - dy[nf:2nf] sin h,  dh[nf:] = dy[2nf:].  bf16 rows, nf / nrest / strides % 8 == 0. */
-int e2k_fourier_cat_fwd(const void* h, int64_t ldh, void* y, int64_t ldy, int64_t M, int nf, int nrest, void* stream);
-int e2k_fourier_cat_bwd(const void* dy, int64_t ldy, const void* h, int64_t ldh, void* dh, int64_t lddh, int64_t M, int nf,
+ * and its backward  dh[:nf] = dy[:nf] cos h - dy[nf:2nf] sin h,  dh[nf:] = dy[2nf:].  h is the GEMM's FP32 output (an angle
+ * of a few radians rounded to bf16 moves its sine by percents); y, dy, dh bf16; nf / nrest % 8 == 0. */
+int e2k_fourier_cat_fwd(const float* h, int64_t ldh, void* y, int64_t ldy, int64_t M, int nf, int nrest, void* stream);
+int e2k_fourier_cat_bwd(const void* dy, int64_t ldy, const float* h, int64_t ldh, void* dh, int64_t lddh, int64_t M, int nf,
                         int nrest, void* stream);
 
 /* fp32 master parameters -> bf16 compute shadows (flat, and (R,C) -> transposed (C,R) with row stride ldd) */

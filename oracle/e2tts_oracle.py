@@ -722,6 +722,17 @@ class HLGaussLayer(Module):
         return F.mse_loss(pred, target)
 
 
+class SplitFreq(Module):
+    """Rearrange('b n (f d) -> b f n d') (e2_tts.py:1010,1208): the projection's channels hold the frequency tokens f-major"""
+    def __init__(self, f):
+        super().__init__()
+        self.f = f
+
+    def forward(self, x):
+        b, n, fd = x.shape
+        return x.reshape(b, n, self.f, fd // self.f).permute(0, 2, 1, 3)
+
+
 # ---------------------------------------------------------------- DurationPredictor (e2_tts.py:956-1113)
 
 class DurationPredictor(Module):
@@ -729,14 +740,21 @@ class DurationPredictor(Module):
                  text_num_embeds=None, num_freq_tokens=1, hl_gauss_loss=None, use_regression=True,
                  tokenizer='char_utf8'):
         super().__init__()
-        assert num_freq_tokens == 1
+        assert num_freq_tokens > 0
+        self.num_freq_tokens, self.has_freq_axis = num_freq_tokens, num_freq_tokens > 1       # e2_tts.py:977-989
         if isinstance(transformer, dict):
+            transformer = dict(transformer)
+            transformer.setdefault('has_freq_axis', self.has_freq_axis)
             transformer = Transformer(**transformer, cond_on_time=False)
+        assert transformer.has_freq_axis == self.has_freq_axis
         self.mel_spec = MelSpec(**mel_spec_kwargs)
         self.num_channels = default(num_channels, self.mel_spec.n_mel_channels)
         self.transformer = transformer
         self.dim = transformer.dim
-        self.proj_in = nn.Linear(self.num_channels, self.dim)
+        if not self.has_freq_axis:                                  # e2_tts.py:1004-1011
+            self.proj_in = nn.Linear(self.num_channels, self.dim)
+        else:
+            self.proj_in = nn.Sequential(nn.Linear(self.num_channels, self.dim * num_freq_tokens), SplitFreq(num_freq_tokens))
         if callable(tokenizer):
             assert exists(text_num_embeds)
             self.tokenizer = tokenizer
@@ -770,6 +788,8 @@ class DurationPredictor(Module):
             seq = torch.arange(seq_len, device=device)
             mask = mask & (seq[None, :] < rand_index[:, None])
         embed = self.transformer(x, mask=mask, text_embed=text_embed)
+        if self.has_freq_axis:                                      # e2_tts.py:1030,1098: Reduce('b f n d -> b n d', 'mean')
+            embed = embed.mean(dim=1)
         pooled = maybe_masked_mean(embed, mask)
         if not return_loss:
             return self.hl_gauss_layer(pooled)
@@ -822,9 +842,13 @@ class E2TTS(Module):
                  text_num_embeds=None, tokenizer='char_utf8', use_vocos=False, pretrained_vocos_path=None,
                  sampling_rate=None, velocity_consistency_weight=0.):
         super().__init__()
-        assert num_freq_tokens == 1 and not use_vocos
+        assert num_freq_tokens > 0 and not use_vocos
+        self.num_freq_tokens, self.has_freq_axis = num_freq_tokens, num_freq_tokens > 1       # e2_tts.py:1150-1164
         if isinstance(transformer, dict):
+            transformer = dict(transformer)
+            transformer.setdefault('has_freq_axis', self.has_freq_axis)
             transformer = Transformer(**transformer, cond_on_time=True)
+        assert transformer.has_freq_axis == self.has_freq_axis
         self.transformer = transformer
         if isinstance(duration_predictor, dict):
             duration_predictor = DurationPredictor(**duration_predictor)
@@ -839,10 +863,11 @@ class E2TTS(Module):
         self.sampling_rate = default(sampling_rate, getattr(self.mel_spec, 'sampling_rate', None))
         self.concat_cond = concat_cond                    # e2_tts.py:1196-1204
         if concat_cond:
-            self.proj_in = nn.Linear(num_channels * 2, dim)
+            self.proj_in = nn.Linear(num_channels * 2, dim * num_freq_tokens)
         else:
-            self.proj_in = nn.Linear(num_channels, dim)
-            self.cond_proj_in = nn.Linear(num_channels, dim)
+            self.proj_in = nn.Linear(num_channels, dim * num_freq_tokens)
+            self.cond_proj_in = nn.Linear(num_channels, dim * num_freq_tokens)
+        self.maybe_split_freq = SplitFreq(num_freq_tokens) if self.has_freq_axis else nn.Identity()       # e2_tts.py:1208-1210
         self.to_pred = nn.Linear(dim, num_channels)
         if callable(tokenizer):
             assert exists(text_num_embeds)
@@ -867,13 +892,15 @@ class E2TTS(Module):
         seq_len = x.shape[-2]
         drop_text_cond = default(drop_text_cond, self.training and _pyrandom.random() < self.cond_drop_prob)
         if self.concat_cond:                              # e2_tts.py:1263-1276
-            x = self.proj_in(torch.cat((cond, x), dim=-1))
+            x = self.maybe_split_freq(self.proj_in(torch.cat((cond, x), dim=-1)))
         else:
-            x = self.proj_in(x) + self.cond_proj_in(cond)
+            x = self.maybe_split_freq(self.proj_in(x)) + self.maybe_split_freq(self.cond_proj_in(cond))
         text_embed = None
         if exists(text) and not drop_text_cond:
             text_embed = self.embed_text(text, seq_len, mask=mask)
         embed = self.transformer(x, times=times, mask=mask, text_embed=text_embed)
+        if self.has_freq_axis:
+            embed = embed.mean(dim=1)
         pred = self.to_pred(embed)
         if not return_drop_text_cond:
             return pred

@@ -189,7 +189,8 @@ def test_persistent_grads(dev):
 
 
 @pytest.mark.late
-@pytest.mark.parametrize('case', ['transformer_full', 'transformer_bare', 'transformer_variant'])
+@pytest.mark.parametrize('case', ['transformer_full', 'transformer_bare', 'transformer_variant', 'transformer_laser_fourier',
+                                  'transformer_freq_axis', 'transformer_freq_axis_bare'])
 def test_reference_golden_backbone(dev, case):
     """hand-scheduled backbone vs the outputs of the reference's own Transformer (tests/golden/reference_pinned.pt, written
     by oracle/pin_against_reference.py): forward, input gradients and the magnitude of every parameter gradient.
@@ -454,6 +455,43 @@ def test_plan_replay_matches_eager(dev):
     assert twin._plans == {} and twin._flat is None
     with torch.no_grad():
         assert torch.equal(twin(x, times=t, mask=mask, text_embed=txt), eager)
+
+
+def test_plan_replay_with_the_default_off_switches(dev):
+    """has_freq_axis + attn_laser + attn_fourier_embed_input all on: the recorded plan (forward and backward, launch lanes on)
+    reproduces the eager schedule -- the frequency attention, LASER maps and Fourier kernels are ordinary recorded calls and
+    the frequency-token count is part of the plan's signature"""
+    from e2_tts_pytorch_amd import Transformer
+    random.seed(0)
+    torch.manual_seed(0)
+    T = 24
+    mod = Transformer(dim=256, depth=2, heads=2, dropout=0., max_seq_len=64, has_freq_axis=True, freq_heads=2, attn_laser=True,
+                      attn_fourier_embed_input=True)
+    randomize(mod)
+    mod = mod.to(dev)
+    B = 2
+
+    def step(seed, F):
+        mod.zero_grad(set_to_none=True)
+        g = torch.Generator().manual_seed(seed)
+        x = torch.randn(B, F, T, 256, generator=g).to(dev).requires_grad_(True)
+        t = torch.rand(B, generator=g).to(dev)
+        txt = torch.randn(B, T, 128, generator=g).to(dev).requires_grad_(True)
+        mask = (torch.arange(T)[None] < torch.tensor([T, T - 5 - seed])[:, None]).to(dev)
+        R = torch.randn(B, F, T, 256, generator=g).to(dev)
+        out = mod(x, times=t, mask=mask, text_embed=txt)
+        (out * R).sum().backward()
+        return out.detach().clone(), x.grad.clone(), txt.grad.clone(), {n: p.grad.clone() for n, p in mod.named_parameters()}
+
+    mod.enable_plans(False)
+    ref = [step(s, 3) for s in (1, 2, 3)] + [step(4, 2)]
+    mod.enable_plans(True)
+    got = [step(s, 3) for s in (1, 2, 3)] + [step(4, 2)]        # first sighting, recording, replay; then another token count (eager)
+    assert len([v for v in mod._plans.values() if not isinstance(v, str)]) == 1
+    for (o0, dx0, dt0, g0), (o1, dx1, dt1, g1) in zip(ref, got):
+        assert torch.equal(o1, o0) and torch.equal(dx1, dx0) and torch.equal(dt1, dt0)
+        for n in g0:
+            assert rel2(g1[n], g0[n]) < 2e-3 or float(g0[n].norm()) < 1e-6, n
 
 
 def test_plan_recording_rejects_tensor_library_ops(dev):

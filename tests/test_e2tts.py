@@ -407,7 +407,7 @@ def _ref_gold():
 
 
 @pytest.mark.late
-@pytest.mark.parametrize('case', ['e2tts_text_on', 'e2tts_cfg_drop', 'e2tts_concat_cond', 'e2tts_interp_text'])
+@pytest.mark.parametrize('case', ['e2tts_text_on', 'e2tts_cfg_drop', 'e2tts_concat_cond', 'e2tts_interp_text', 'e2tts_freq_tokens'])
 def test_reference_golden_forward(dev, case):
     from e2_tts_pytorch_amd import E2TTS
     from oracle.golden_weights import fill_params
@@ -446,10 +446,11 @@ def test_reference_golden_sample_duration(dev):
     out = model.sample(c['cond'].to(dev), text=c['text'], lens=c['lens'].to(dev), duration=c['duration'].to(dev), steps=c['steps'],
                        cfg_strength=c['cfg_strength'], _y0=c['y0'].to(dev))
     assert out.shape == c['out'].shape and rel2(out, c['out']) < 1e-2, rel2(out, c['out'])      # north-star tolerance (bf16)
-    c = gold['duration']
-    dp = fill_params(DurationPredictor(transformer=dict(**c['kw'])), c['weight_seed']).to(dev)
-    loss = dp(c['mel'].to(dev), text=c['text'], lens=c['lens'].to(dev), _rand_frac_index=c['rand_frac_index'].to(dev))
-    assert abs(loss.item() - c['loss'].item()) / abs(c['loss'].item()) < 2e-2
+    for key in ('duration', 'duration_freq_tokens'):              # (num_freq_tokens = 2: the frequency axis, e2_tts.py:977-1011,1098)
+        c = gold[key]
+        dp = fill_params(DurationPredictor(transformer=dict(**c['kw']), **c.get('extra', {})), c['weight_seed']).to(dev)
+        loss = dp(c['mel'].to(dev), text=c['text'], lens=c['lens'].to(dev), _rand_frac_index=c['rand_frac_index'].to(dev))
+        assert abs(loss.item() - c['loss'].item()) / abs(c['loss'].item()) < 2e-2, key
 
 
 @pytest.mark.late
