@@ -76,7 +76,13 @@ def test_module_contract():
     m2 = copy.deepcopy(m)
     assert sum(p.numel() for p in m2.parameters()) == sum(p.numel() for p in ref.parameters())
     assert m.velocity_consistency_weight == 0.
+    # the constructor's default-off switches are built and give the reference's state_dict keys; what stays refused says so
+    ref_v = O.Transformer(dim=256, depth=2, has_freq_axis=True, attn_laser=True, attn_fourier_embed_input=True)
+    mod_v = pkg.Transformer(dim=256, depth=2, has_freq_axis=True, attn_laser=True, attn_fourier_embed_input=True)
+    assert {k: tuple(v.shape) for k, v in mod_v.state_dict().items()} == {k: tuple(v.shape) for k, v in ref_v.state_dict().items()}
     with pytest.raises(NotImplementedError):
-        pkg.Transformer(dim=256, depth=2, has_freq_axis=True)
+        pkg.Transformer(dim=256, depth=2, dim_head=32)
+    with pytest.raises(NotImplementedError):
+        pkg.Transformer(dim=256, depth=2, num_residual_streams=2)
     with pytest.raises(AssertionError):
         pkg.Transformer(dim=256, depth=3)
