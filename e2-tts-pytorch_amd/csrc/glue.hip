@@ -293,6 +293,90 @@ __global__ __launch_bounds__(256) void masked_mse_bwd_kernel(const float* pred, 
     }
 }
 
+// ---- CharacterEmbed (e2_tts.py:390-412): out[b][n] = W[n < nt ? tok[b][n] + 1 : 0]  (the byte tokens are
+// shifted by one so that the -1 padding and the frames past the text both land on row 0); fp32 rows of D.
+__global__ __launch_bounds__(256) void char_embed_fwd_kernel(const long* tok, const float* W, float* out, int B, int nt, int T, int D, int V) {
+    const long total = (long)B * T * (D / 4);
+    const int dv = D / 4;
+    for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < total; i += (long)gridDim.x * 256) {
+        const long bn = i / dv;
+        const int c = (int)(i - bn * dv) * 4, n = (int)(bn % T), b = (int)(bn / T);
+        long idx = n < nt ? tok[(long)b * nt + n] + 1 : 0;
+        idx = idx < 0 ? 0 : (idx >= V ? V - 1 : idx);               // (nn.Embedding raises on out-of-range ids: the host checks, this only keeps the read in bounds)
+        st<f32x4>(out + bn * D + c, ld<f32x4>(W + idx * D + c));
+    }
+}
+// dW[idx] += dout[b][n]  (fp32 atomics: rows of the 257-entry table collect thousands of tokens each)
+__global__ __launch_bounds__(256) void char_embed_bwd_kernel(const long* tok, const float* dout, float* dW, int B, int nt, int T, int D, int V) {
+    const long total = (long)B * T * D;
+    for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < total; i += (long)gridDim.x * 256) {
+        const long bn = i / D;
+        const int c = (int)(i - bn * D), n = (int)(bn % T), b = (int)(bn / T);
+        long idx = n < nt ? tok[(long)b * nt + n] + 1 : 0;
+        idx = idx < 0 ? 0 : (idx >= V ? V - 1 : idx);
+        atomicAdd(dW + idx * D + c, dout[i]);
+    }
+}
+
+// ---- duration head (e2_tts.py:1098-1111 with maybe_masked_mean :212-224 and HLGaussLayer's regression mode):
+//   pooled[b] = sum_n mask[b][n] embed[b][n] / max(sum_n mask[b][n], 1)      (mask = NULL: plain mean over n)
+//   pred[b]   = softplus(w . pooled[b])                                      (nn.Softplus: x for x > 20)
+// One workgroup per batch row; pooled and the pre-activation z are kept for the backward.
+__global__ __launch_bounds__(256) void duration_head_fwd_kernel(const float* embed, const uint8_t* mask, const float* w, float* pooled,
+                                                                 float* z, float* pred, int T, int D) {
+    __shared__ float red[4];
+    __shared__ float cnt_s;
+    const int b = blockIdx.x, tid = threadIdx.x;
+    const float* e = embed + (long)b * T * D;
+    const uint8_t* m = mask ? mask + (long)b * T : nullptr;
+    if (tid == 0) {
+        float c = 0.f;
+        for (int n = 0; n < T; ++n) c += (!m || m[n]) ? 1.f : 0.f;
+        cnt_s = m ? fmaxf(c, 1.f) : (float)T;
+    }
+    __syncthreads();
+    const float inv = 1.f / cnt_s;
+    float dot = 0.f;
+    for (int d = tid; d < D; d += 256) {
+        float s = 0.f;
+        for (int n = 0; n < T; ++n)
+            if (!m || m[n]) s += e[(long)n * D + d];
+        s *= inv;
+        pooled[(long)b * D + d] = s;
+        dot = fmaf(s, w[d], dot);
+    }
+    dot = wave_sum(dot);
+    if ((tid & 63) == 0) red[tid >> 6] = dot;
+    __syncthreads();
+    if (tid == 0) {
+        const float zz = red[0] + red[1] + red[2] + red[3];
+        z[b] = zz;
+        pred[b] = zz > 20.f ? zz : log1pf(__expf(zz));
+    }
+}
+// dpred (B) -> dembed[b][n] = mask[b][n] / cnt_b * dz_b w ;  dw += sum_b dz_b pooled[b] ;  dz = dpred sigmoid(z)
+__global__ __launch_bounds__(256) void duration_head_bwd_kernel(const float* dpred, const float* z, const float* pooled, const uint8_t* mask,
+                                                                 const float* w, float* dembed, float* dw, int T, int D) {
+    __shared__ float cnt_s;
+    const int b = blockIdx.x, tid = threadIdx.x;
+    const uint8_t* m = mask ? mask + (long)b * T : nullptr;
+    if (tid == 0) {
+        float c = 0.f;
+        for (int n = 0; n < T; ++n) c += (!m || m[n]) ? 1.f : 0.f;
+        cnt_s = m ? fmaxf(c, 1.f) : (float)T;
+    }
+    __syncthreads();
+    const float zz = z[b];
+    const float dz = dpred[b] * (zz > 20.f ? 1.f : sigmoidf_(zz));
+    const float k = dz / cnt_s;
+    float* de = dembed + (long)b * T * D;
+    for (int d = tid; d < D; d += 256) {
+        const float g = k * w[d];
+        for (int n = 0; n < T; ++n) de[(long)n * D + d] = (!m || m[n]) ? g : 0.f;
+        atomicAdd(dw + d, dz * pooled[(long)b * D + d]);
+    }
+}
+
 }  // namespace
 
 static int cast_pad_bf16_impl(const float* src, int64_t lds_, void* dst, int64_t ldd, int R, int C, int Cpad, void* stream) {
@@ -372,6 +456,47 @@ static int masked_mse_bwd_impl(const float* pred, const float* flow, const uint8
     if (M <= 0 || C <= 0) return E2K_ERR_SHAPE;
     hipLaunchKernelGGL(masked_mse_bwd_kernel, dim3(grid_1d((long)M * C)), dim3(256), 0, (hipStream_t)stream, pred, flow, mask, acc,
                        dloss, dpred, M, C);
+    E2K_CHECK_LAUNCH();
+    return 0;
+}
+
+static int char_embed_fwd_impl(const int64_t* tok, const float* W, float* out, int B, int nt, int T, int D, int V, void* stream) {
+    if (B <= 0 || T <= 0) return 0;
+    if (D <= 0 || (D & 3) || V <= 0 || nt < 0) return E2K_ERR_SHAPE;
+    if (!W || !out || (nt > 0 && !tok)) return E2K_ERR_ARG;
+    if (((uintptr_t)W | (uintptr_t)out) & 15) return E2K_ERR_ALIGN;
+    hipLaunchKernelGGL(char_embed_fwd_kernel, dim3(grid_1d((long)B * T * (D / 4))), dim3(256), 0, (hipStream_t)stream, (const long*)tok, W,
+                       out, B, nt, T, D, V);
+    E2K_CHECK_LAUNCH();
+    return 0;
+}
+
+static int char_embed_bwd_impl(const int64_t* tok, const float* dout, float* dW, int B, int nt, int T, int D, int V, void* stream) {
+    if (B <= 0 || T <= 0) return 0;
+    if (D <= 0 || V <= 0 || nt < 0) return E2K_ERR_SHAPE;
+    if (!dout || !dW || (nt > 0 && !tok)) return E2K_ERR_ARG;
+    hipLaunchKernelGGL(char_embed_bwd_kernel, dim3(grid_1d((long)B * T * D)), dim3(256), 0, (hipStream_t)stream, (const long*)tok, dout, dW,
+                       B, nt, T, D, V);
+    E2K_CHECK_LAUNCH();
+    return 0;
+}
+
+static int duration_head_fwd_impl(const float* embed, const uint8_t* mask, const float* w, float* pooled, float* z, float* pred, int B,
+                                  int T, int D, void* stream) {
+    if (B <= 0) return 0;
+    if (T <= 0 || D <= 0) return E2K_ERR_SHAPE;
+    if (!embed || !w || !pooled || !z || !pred) return E2K_ERR_ARG;
+    hipLaunchKernelGGL(duration_head_fwd_kernel, dim3(B), dim3(256), 0, (hipStream_t)stream, embed, mask, w, pooled, z, pred, T, D);
+    E2K_CHECK_LAUNCH();
+    return 0;
+}
+
+static int duration_head_bwd_impl(const float* dpred, const float* z, const float* pooled, const uint8_t* mask, const float* w,
+                                  float* dembed, float* dw, int B, int T, int D, void* stream) {
+    if (B <= 0) return 0;
+    if (T <= 0 || D <= 0) return E2K_ERR_SHAPE;
+    if (!dpred || !z || !pooled || !w || !dembed || !dw) return E2K_ERR_ARG;
+    hipLaunchKernelGGL(duration_head_bwd_kernel, dim3(B), dim3(256), 0, (hipStream_t)stream, dpred, z, pooled, mask, w, dembed, dw, T, D);
     E2K_CHECK_LAUNCH();
     return 0;
 }
@@ -547,4 +672,19 @@ extern "C" int e2k_masked_mse_bwd(const float* pred, const float* flow, const ui
 extern "C" int e2k_cfg_combine(const float* pred, const float* null_pred, float* out, int B, int64_t L, float cfg_strength,
                                float keep_parallel_frac, int remove_parallel, void* stream) {
     return e2k::dispatch("cfg_combine", cfg_combine_impl, pred, null_pred, out, B, L, cfg_strength, keep_parallel_frac, remove_parallel, stream);
+}
+
+extern "C" int e2k_char_embed_fwd(const int64_t* tok, const float* W, float* out, int B, int nt, int T, int D, int V, void* stream) {
+    return e2k::dispatch("char_embed_fwd", char_embed_fwd_impl, tok, W, out, B, nt, T, D, V, stream);
+}
+extern "C" int e2k_char_embed_bwd(const int64_t* tok, const float* dout, float* dW, int B, int nt, int T, int D, int V, void* stream) {
+    return e2k::dispatch("char_embed_bwd", char_embed_bwd_impl, tok, dout, dW, B, nt, T, D, V, stream);
+}
+extern "C" int e2k_duration_head_fwd(const float* embed, const uint8_t* mask, const float* w, float* pooled, float* z, float* pred,
+                                     int B, int T, int D, void* stream) {
+    return e2k::dispatch("duration_head_fwd", duration_head_fwd_impl, embed, mask, w, pooled, z, pred, B, T, D, stream);
+}
+extern "C" int e2k_duration_head_bwd(const float* dpred, const float* z, const float* pooled, const uint8_t* mask, const float* w,
+                                     float* dembed, float* dw, int B, int T, int D, void* stream) {
+    return e2k::dispatch("duration_head_bwd", duration_head_bwd_impl, dpred, z, pooled, mask, w, dembed, dw, B, T, D, stream);
 }

@@ -190,6 +190,43 @@ def _on_kernels(t):
     return t.is_cuda or ops.host_ok()
 
 
+class _CharEmbedFn(torch.autograd.Function):
+    """CharacterEmbed (e2_tts.py:400-412): shift the byte tokens by one, cut / pad to the audio length with the padding row,
+    gather -- one kernel; the backward scatters into the (num_embeds + 1, dim) table with fp32 atomics"""
+
+    @staticmethod
+    def forward(ctx, text, W, max_seq_len):
+        out, tk = ops.char_embed_fwd(text.contiguous(), W.detach().contiguous(), max_seq_len)
+        ctx.save_for_backward(tk)
+        ctx.V = W.shape[0]
+        return out
+
+    @staticmethod
+    def backward(ctx, dout):
+        tk, = ctx.saved_tensors
+        return None, ops.char_embed_bwd(tk, _f32c(dout), ctx.V), None
+
+
+class _DurationHeadFn(torch.autograd.Function):
+    """maybe_masked_mean + HLGaussLayer's regression head with Softplus (e2_tts.py:1098-1111,212-224): pred (B,)"""
+
+    @staticmethod
+    def forward(ctx, embed, mask, w):
+        e = _f32c(embed.detach())
+        m8 = mask.contiguous().view(torch.uint8) if exists(mask) else None
+        wv = w.detach().reshape(-1).contiguous()
+        pred, pooled, z = ops.duration_head_fwd(e, m8, wv)
+        ctx.save_for_backward(pooled, z, wv, *((m8,) if exists(m8) else ()))
+        ctx.T, ctx.wshape = e.shape[1], w.shape
+        return pred
+
+    @staticmethod
+    def backward(ctx, dpred):
+        pooled, z, wv, *rest = ctx.saved_tensors
+        dembed, dw = ops.duration_head_bwd(_f32c(dpred), z, pooled, rest[0] if rest else None, wv, ctx.T)
+        return dembed, None, dw.view(ctx.wshape)
+
+
 # ------------------------------------------------------------------------------------------------ MelSpec
 
 def _melscale_fbanks_htk(n_freqs, f_min, f_max, n_mels, sample_rate):
@@ -301,6 +338,8 @@ class CharacterEmbed(Module):                                  # e2_tts.py:390-4
         self.embed = nn.Embedding(num_embeds + 1, dim)
 
     def forward(self, text, max_seq_len, **kwargs):
+        if _on_kernels(self.embed.weight) and text.dtype == torch.int64 and self.embed.weight.dtype == torch.float32 and self.dim % 4 == 0:
+            return _CharEmbedFn.apply(text, self.embed.weight, max_seq_len)      # one gather kernel
         text = text + 1
         text = text[:, :max_seq_len]
         text = pad_to_length(text, max_seq_len, value=0)
@@ -430,10 +469,15 @@ class DurationPredictor(Module):                               # e2_tts.py:956-1
         embed = self.transformer(x, mask=mask, text_embed=text_embed)
         if self.has_freq_axis:                                      # e2_tts.py:1030,1098: mean over the frequency tokens
             embed = embed.mean(dim=1)
+        hl = self.hl_gauss_layer
+        if _on_kernels(embed) and isinstance(hl.act, nn.Softplus) and hl.act.beta == 1 and hl.act.threshold == 20:
+            # masked mean over the frames, the (dim -> 1) regression head and its Softplus in one kernel
+            pred = _DurationHeadFn.apply(embed, mask, hl.to_pred.weight)
+            return pred if not return_loss else F.mse_loss(pred, lens.float())
         pooled = maybe_masked_mean(embed, mask)
         if not return_loss:
-            return self.hl_gauss_layer(pooled)
-        return self.hl_gauss_layer(pooled, lens.float())
+            return hl(pooled)
+        return hl(pooled, lens.float())
 
 
 # ------------------------------------------------------------------------------------------------ E2TTS

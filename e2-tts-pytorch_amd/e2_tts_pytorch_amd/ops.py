@@ -1042,3 +1042,46 @@ def freq_attn_bwd(dout, qkv, B, F, N, H, cosb, sinb, vfirst=None, dvfirst=None, 
     _lib.get().e2k_freq_attn_bwd(_p(dout), _p(qkv), qkv.stride(0), _p(vfirst), 0 if vfirst is None else vfirst.stride(0), _p(cosb),
                                  _p(sinb), _p(dvfirst), int(first_layer), _p(dqkv), dqkv.stride(0), B, F, N, H, _stream(dout))
     return dqkv
+
+
+def char_embed_fwd(tok, W, T):
+    """CharacterEmbed (e2_tts.py:400-412): tok (B, nt) int64 (-1 = padding) -> (B, T, D) fp32 rows of W (V, D)"""
+    _chk(tok, W)
+    assert tok.dtype == torch.int64 and tok.is_contiguous() and W.dtype == f32 and W.is_contiguous()
+    B, nt = tok.shape
+    nt = min(nt, T)
+    tk = tok if tok.shape[1] == nt else tok[:, :nt].contiguous()
+    V, D = W.shape
+    out = torch.empty((B, T, D), dtype=f32, device=W.device)
+    _lib.get().e2k_char_embed_fwd(_p(tk), _p(W), _p(out), B, nt, T, D, V, _stream(W))
+    return out, tk
+
+
+def char_embed_bwd(tk, dout, V):
+    _chk(tk, dout)
+    assert dout.dtype == f32 and dout.is_contiguous()
+    B, T, D = dout.shape
+    dW = zeros((V, D), f32, dout.device)
+    _lib.get().e2k_char_embed_bwd(_p(tk), _p(dout), _p(dW), B, tk.shape[1], T, D, V, _stream(dout))
+    return dW
+
+
+def duration_head_fwd(embed, mask8, w):
+    """masked mean over frames + softplus(w . pooled) (e2_tts.py:1098-1111); embed (B, T, D) fp32, mask8 (B, T) uint8 or None"""
+    _chk(embed, mask8, w)
+    assert embed.dtype == f32 and embed.is_contiguous() and w.dtype == f32 and w.is_contiguous()
+    B, T, D = embed.shape
+    dev = embed.device
+    pooled, z, pred = torch.empty((B, D), dtype=f32, device=dev), torch.empty(B, dtype=f32, device=dev), torch.empty(B, dtype=f32, device=dev)
+    _lib.get().e2k_duration_head_fwd(_p(embed), _p(mask8), _p(w), _p(pooled), _p(z), _p(pred), B, T, D, _stream(embed))
+    return pred, pooled, z
+
+
+def duration_head_bwd(dpred, z, pooled, mask8, w, T):
+    _chk(dpred, z, pooled, mask8, w)
+    B, D = pooled.shape
+    dev = pooled.device
+    dembed = torch.empty((B, T, D), dtype=f32, device=dev)
+    dw = zeros((D,), f32, dev)
+    _lib.get().e2k_duration_head_bwd(_p(dpred), _p(z), _p(pooled), _p(mask8), _p(w), _p(dembed), _p(dw), B, T, D, _stream(pooled))
+    return dembed, dw

@@ -388,6 +388,17 @@ int e2k_cond_bwd_prep(float* dcond, const float* gates, void* dcb, void* dct, fl
 /* fp32 (R, C), rows lds floats apart -> bf16 (R, ldd) with columns C .. Cpad-1 zeroed: operands of the 100-channel input /
  * output projections (e2_tts.py:1267-1277,1296: proj_in, cond_proj_in, to_pred), whose K is padded to a multiple of 8 */
 int e2k_cast_pad_bf16(const float* src, int64_t lds, void* dst, int64_t ldd, int R, int C, int Cpad, void* stream);
+/* CharacterEmbed (e2_tts.py:390-412): tok (B, nt) int64 byte tokens with -1 padding -> out (B, T, D) fp32 =
+ * W[n < nt ? tok + 1 : 0], W (V, D) = nn.Embedding(num_embeds + 1, dim).weight.  Backward: dW (V, D) += scatter of dout (ACCUMULATES). */
+int e2k_char_embed_fwd(const int64_t* tok, const float* W, float* out, int B, int nt, int T, int D, int V, void* stream);
+int e2k_char_embed_bwd(const int64_t* tok, const float* dout, float* dW, int B, int nt, int T, int D, int V, void* stream);
+/* Duration head (e2_tts.py:1098-1111: maybe_masked_mean :212-224 + HLGaussLayer regression mode with Softplus):
+ * embed (B, T, D) fp32, mask (B, T) u8 or NULL, w (D) = hl_gauss_layer.to_pred.weight -> pooled (B, D), z (B) = w . pooled,
+ * pred (B) = softplus(z).  Backward from dpred (B): dembed (B, T, D) written, dw (D) ACCUMULATED. */
+int e2k_duration_head_fwd(const float* embed, const uint8_t* mask, const float* w, float* pooled, float* z, float* pred,
+                          int B, int T, int D, void* stream);
+int e2k_duration_head_bwd(const float* dpred, const float* z, const float* pooled, const uint8_t* mask, const float* w,
+                          float* dembed, float* dw, int B, int T, int D, void* stream);
 /* Classifier-free-guidance combine of E2TTS.sample (e2_tts.py:1303-1330 with `project`, :113-124), per sample b over its L
  * = frames * channels elements, fp32 in / out, the projection in fp64 as the reference does it:
  *   u = pred - null;  par = (u . unit) unit with unit = pred / max(|pred|, 1e-12);  orth = u - par

@@ -507,3 +507,53 @@ def test_cfg_combine_kernel(dev, remove_parallel, keep):
     # a zero prediction: F.normalize's eps keeps the unit vector finite (0), the update passes through as orthogonal
     z = ops.cfg_combine(torch.zeros(1, 8, 100, device=dev), nul[:1, :8].contiguous().to(dev), 1.5, keep, remove_parallel).cpu()
     assert torch.equal(z, -nul[:1, :8] * 1.5)
+
+
+def test_character_embed_kernel(dev):
+    """CharacterEmbed as one gather kernel against the oracle module: text shorter and longer than the audio
+    length, -1 padding inside the batch, gradient of the table (scatter with fp32 atomics)"""
+    from e2_tts_pytorch_amd.e2_tts import CharacterEmbed
+    torch.manual_seed(5)
+    ref = O.CharacterEmbed(128)
+    mod = CharacterEmbed(128)
+    mod.load_state_dict(ref.state_dict())
+    mod = mod.to(dev)
+    text = O.list_str_to_tensor(['short', 'a much longer line of text than the audio has frames', ''])
+    for T in (12, 70):
+        R = torch.randn(3, T, 128)
+        out_r = ref(text, T)
+        (out_r * R).sum().backward()
+        out = mod(text.to(dev), T)
+        (out * R.to(dev)).sum().backward()
+        assert torch.equal(out.cpu(), out_r)
+        assert rel2(mod.embed.weight.grad, ref.embed.weight.grad) < 1e-6
+        ref.zero_grad(), mod.zero_grad()
+
+
+@pytest.mark.parametrize('with_mask', [True, False])
+def test_duration_head_kernel(dev, with_mask):
+    """masked mean + regression head + Softplus in one kernel against the oracle's maybe_masked_mean + HLGaussLayer:
+    prediction, loss, gradients to the embedding and the head weight; one row fully masked (count clamped at 1), one
+    pre-activation past Softplus' linear threshold"""
+    from e2_tts_pytorch_amd.e2_tts import _DurationHeadFn
+    import torch.nn.functional as F
+    torch.manual_seed(6)
+    B, T, D = 3, 37, 256
+    embed = torch.randn(B, T, D)
+    embed[2] += 3.0
+    w = torch.randn(1, D) * 0.1
+    w[0, :8] += 1.0                                    # row 2: z > 20
+    mask = torch.rand(B, T) > 0.3 if with_mask else None
+    if with_mask:
+        mask[1] = False
+    lens = torch.tensor([30., 12., 37.])
+    er, wr = embed.clone().requires_grad_(True), w.clone().requires_grad_(True)
+    pooled = O.maybe_masked_mean(er, mask)
+    pred_r = F.softplus(pooled @ wr.t()).squeeze(-1)
+    F.mse_loss(pred_r, lens).backward()
+    ek, wk = embed.clone().to(dev).requires_grad_(True), w.clone().to(dev).requires_grad_(True)
+    pred = _DurationHeadFn.apply(ek, None if mask is None else mask.to(dev), wk)
+    F.mse_loss(pred, lens.to(dev)).backward()
+    assert (pred.cpu() - pred_r).abs().max().item() < 1e-4 * pred_r.abs().max().item()
+    assert pred_r[2].item() > 20.
+    assert rel2(ek.grad, er.grad) < 1e-5 and rel2(wk.grad, wr.grad) < 1e-5
