@@ -147,6 +147,41 @@ def cpu_baseline(dim, depth, heads, T, sample_depth=12, threads=None):
                       f'executed (oracle/pin_against_reference.py); /root/reference itself cannot travel to the GPU box'}
 
 
+def optimizer_leg(model, net, mel, text, noise, ms_plain, k=4):
+    """fwd + bwd + global-norm clip + ADOPT over the flat buffers (optim.FusedAdopt: one sumsq + one update launch for the
+    backbone) and, separately, + the EMA update (optim.FusedEMA; the reference trainer runs it every 10th step,
+    ema_pytorch's default).  Same plan, same inputs as the headline loop; lr tiny so that k steps leave the model alone."""
+    from e2_tts_pytorch_amd.optim import FusedAdopt, FusedEMA
+    opt = FusedAdopt(model, lr=1e-7, max_grad_norm=1.0)
+    ema = FusedEMA(model, update_after_step=0, update_every=1)
+
+    def train_step(with_ema):
+        out = net(mel, text=text, _noise=noise)
+        out.loss.backward()
+        opt.step()
+        opt.zero_grad(set_to_none=True)
+        if with_ema:
+            ema.update()
+
+    out = {}
+    for name, with_ema in (('ms_per_step_with_clip_adopt', False), ('ms_per_step_with_clip_adopt_ema', True)):
+        for _ in range(2):
+            train_step(with_ema)
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for _ in range(k):
+            train_step(with_ema)
+        torch.cuda.synchronize()
+        out[name] = (time.perf_counter() - t0) / k * 1e3
+    out['ms_per_step_fwd_bwd'] = ms_plain
+    out['clip_adopt_ms'] = out['ms_per_step_with_clip_adopt'] - ms_plain
+    out['ema_update_ms'] = out['ms_per_step_with_clip_adopt_ema'] - out['ms_per_step_with_clip_adopt']
+    out['steps'] = k
+    out['note'] = ('fused clip + ADOPT (per-parameter steps, text-stream group skipped on text-dropped steps) and EMA over the flat fp32 '
+                   'buffers, trainer.py:270-279; the EMA update runs every 10th step in the reference configuration')
+    return out
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument('--gpus', type=int, default=1)
@@ -171,6 +206,8 @@ def main():
     ap.add_argument('--ddp-bisect', default=None, choices=['init', 'nohook', 'nooutside'],
                     help='diagnosis of the --force-ddp overhead: init = only init_process_group (no wrapper); nohook = wrapper without the slab hook; nooutside = wrapper without the non-backbone all-reduce')
     ap.add_argument('--ddp-defer', action='store_true', help='one gradient all-reduce after the backward pass instead of per-layer slabs overlapped with it (A/B)')
+    ap.add_argument('--no-optimizer-leg', action='store_true', help='skip the extra leg that times the step WITH the fused gradient clip + '
+                    'ADOPT update (+ EMA) after the headline measurement (N = 1 only; it never enters `value`)')
     ap.add_argument('--dump-ops', default=None, help='write the per-shape launch table of the profiled plan replays (name, flops, count, '
                     'average ms, TFLOP/s) to this JSON file')
     args = ap.parse_args()
@@ -345,7 +382,7 @@ def main():
                 'time_share_of_step': (gemm_ms / nprof) / ms,
                 'measured': 'HIP events on the launch stream around every recorded launch (e2k_plan_profile), 2 replays of the '
                             'timed plan right after the timed region, every call ALONE on one stream; the rocprofv3 summary that '
-                            'agrees with avg_launch_ms is the single-stream one (E2K_LANES=0, profiles/r02_bench_cfg3_kernel_stats_e_single_stream.csv): '
+                            'agrees with avg_launch_ms is the single-stream one (E2K_LANES=0, profiles/r03_bench_cfg3_kernel_stats_c_single_stream.csv): '
                             'with the launch lanes the kernels of different lanes overlap and stretch (…_d_lanes.csv)',
                 'traffic': traffic, 'traffic_note': traffic_note,
             },
@@ -355,6 +392,13 @@ def main():
                 res['host_launch_floor'] = host_launch_floor(depth, dev, args.dropout)
             except Exception as e:      # noqa: BLE001
                 res['host_launch_floor'] = {'error': repr(e)}
+        if world == 1 and not args.eager and not args.no_optimizer_leg:
+            # The headline metric is BASELINE.json's fwd + bwd; what the trainer adds per step (trainer.py:270-279: clip_grad_norm_,
+            # Adopt.step, zero_grad, EMA.update) is timed here on the same model, after the timed region, and reported beside it
+            try:
+                res['optimizer_leg'] = optimizer_leg(model, net, mel, text, noise, ms)
+            except Exception as e:      # noqa: BLE001
+                res['optimizer_leg'] = {'error': repr(e)}
         if world == 1 and not args.no_cpu_baseline:
             try:
                 res['cpu_baseline'] = cpu_baseline(dim, depth, heads, T)
