@@ -58,7 +58,7 @@ __global__ __launch_bounds__(256) void adopt_kernel(AdoptArgs a) {
     // clip factor of torch.nn.utils.clip_grad_norm_: min(1, max_norm / (total_norm + 1e-6))
     float cs = 1.f;
     if (a.gsumsq && a.max_norm > 0.f) cs = fminf(1.f, a.max_norm / ((float)sqrt(*a.gsumsq) + 1e-6f));
-    const long n4 = a.n >> 2, stride = (long)gridDim.x * 256;
+    const long n4 = a.n >> 2;
     // the ranges of the second group, staged once per workgroup (at most 128 ranges)
     __shared__ int rng[256];
     const int nr = a.nranges;
@@ -69,10 +69,10 @@ __global__ __launch_bounds__(256) void adopt_kernel(AdoptArgs a) {
         while (lo < hi) { const int mid = (lo + hi) >> 1; if ((long)rng[2 * mid] <= e) lo = mid + 1; else hi = mid; }
         return lo > 0 && e < (long)rng[2 * lo - 1];
     };
-    auto one = [&](long i, f32x4 p, f32x4 g, f32x4 m, f32x4 v) {
+    auto one = [&](long i, bool grp_b, f32x4 p, f32x4 g, f32x4 m, f32x4 v) {
         float pv[4];
         bool first = a.first; float clamp = a.clamp;
-        if (nr && in_b(4 * i)) {
+        if (grp_b) {
             if (!a.active_b) return;                       // no gradient this step: parameter, moments and step count stay
             first = a.first_b; clamp = a.clamp_b;
         }
@@ -83,16 +83,29 @@ __global__ __launch_bounds__(256) void adopt_kernel(AdoptArgs a) {
         st<f32x4>(a.v + 4 * i, v);
         if (a.shadow) st<u32x2>(a.shadow + 4 * i, pack4(pv));
     };
-    long i = (long)blockIdx.x * 256 + threadIdx.x;
-    for (; i + stride < n4; i += 2 * stride) {            // two elements groups (8 x 16-byte loads) per thread in flight
-        const long j = i + stride;
-        const f32x4 p0 = ld<f32x4>(a.p + 4 * i), g0 = ld<f32x4>(a.g + 4 * i), m0 = ld<f32x4>(a.m + 4 * i), v0 = ld<f32x4>(a.v + 4 * i);
-        const f32x4 p1 = ld<f32x4>(a.p + 4 * j), g1 = ld<f32x4>(a.g + 4 * j), m1 = ld<f32x4>(a.m + 4 * j), v1 = ld<f32x4>(a.v + 4 * j);
-        one(i, p0, g0, m0, v0);
-        one(j, p1, g1, m1, v1);
+    // Each workgroup owns ONE contiguous span of 16-byte groups and walks it in blocks of 512 groups (two sweeps of the 256
+    // threads in flight).  Which parameter group a block belongs to is decided once per block from the sorted ranges, with
+    // workgroup-uniform state (`ri` = first range that ends past the block's start): a block is outside every range, inside
+    // one, or -- only at the few range boundaries -- mixed, and only then do its lanes search.  Blocks of a group without a
+    // gradient are skipped before their loads.  (Round 3: the per-lane binary search of every 16-byte group put seven
+    // dependent LDS reads in front of each group's stores; clip + update of the cfg3 model 6.7 ms per step.)
+    const long per = ((n4 + gridDim.x - 1) / gridDim.x + 511) & ~511L;
+    const long b0 = (long)blockIdx.x * per, b1 = min(b0 + per, n4);
+    int ri = 0;
+    for (long base = b0; base < b1; base += 512) {
+        const long e0 = 4 * base, e1 = 4 * min(base + 512, b1);
+        while (ri < nr && (long)rng[2 * ri + 1] <= e0) ++ri;
+        int kind = 0;                                       // 0: outside every range, 1: inside range ri, 2: mixed
+        if (ri < nr && (long)rng[2 * ri] < e1) kind = ((long)rng[2 * ri] <= e0 && (long)rng[2 * ri + 1] >= e1) ? 1 : 2;
+        if (kind == 1 && !a.active_b) continue;
+        const long i = base + threadIdx.x, j = i + 256;
+        const bool hi = i < b1, hj = j < b1;
+        f32x4 p0, g0, m0, v0, p1, g1, m1, v1;
+        if (hi) { p0 = ld<f32x4>(a.p + 4 * i); g0 = ld<f32x4>(a.g + 4 * i); m0 = ld<f32x4>(a.m + 4 * i); v0 = ld<f32x4>(a.v + 4 * i); }
+        if (hj) { p1 = ld<f32x4>(a.p + 4 * j); g1 = ld<f32x4>(a.g + 4 * j); m1 = ld<f32x4>(a.m + 4 * j); v1 = ld<f32x4>(a.v + 4 * j); }
+        if (hi) one(i, kind == 1 || (kind == 2 && in_b(4 * i)), p0, g0, m0, v0);
+        if (hj) one(j, kind == 1 || (kind == 2 && in_b(4 * j)), p1, g1, m1, v1);
     }
-    for (; i < n4; i += stride)
-        one(i, ld<f32x4>(a.p + 4 * i), ld<f32x4>(a.g + 4 * i), ld<f32x4>(a.m + 4 * i), ld<f32x4>(a.v + 4 * i));
     if (blockIdx.x == 0 && threadIdx.x < (a.n & 3)) {
         const long i = 4 * n4 + threadIdx.x;
         float mm = a.m[i], vv = a.v[i];
