@@ -382,7 +382,7 @@ def main():
                 'time_share_of_step': (gemm_ms / nprof) / ms,
                 'measured': 'HIP events on the launch stream around every recorded launch (e2k_plan_profile), 2 replays of the '
                             'timed plan right after the timed region, every call ALONE on one stream; the rocprofv3 summary that '
-                            'agrees with avg_launch_ms is the single-stream one (E2K_LANES=0, profiles/r03_bench_cfg3_kernel_stats_c_single_stream.csv): '
+                            'agrees with avg_launch_ms is the single-stream one (E2K_LANES=0, profiles/r03_bench_cfg3_kernel_stats_d_single_stream.csv): '
                             'with the launch lanes the kernels of different lanes overlap and stretch (…_d_lanes.csv)',
                 'traffic': traffic, 'traffic_note': traffic_note,
             },
