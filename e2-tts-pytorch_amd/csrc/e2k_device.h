@@ -139,9 +139,14 @@ template <int VEC, int NCH> __device__ __forceinline__ void load_row_f32(const f
     switch (D) {                                                  \
         case 128: rc = FN<2, 1>(__VA_ARGS__); break;              \
         case 256: rc = FN<4, 1>(__VA_ARGS__); break;              \
+        case 384: rc = FN<2, 3>(__VA_ARGS__); break;              \
         case 512: rc = FN<8, 1>(__VA_ARGS__); break;              \
+        case 640: rc = FN<2, 5>(__VA_ARGS__); break;              \
         case 768: rc = FN<4, 3>(__VA_ARGS__); break;              \
+        case 896: rc = FN<2, 7>(__VA_ARGS__); break;              \
         case 1024: rc = FN<8, 2>(__VA_ARGS__); break;             \
+        case 1280: rc = FN<4, 5>(__VA_ARGS__); break;             \
+        case 1792: rc = FN<4, 7>(__VA_ARGS__); break;             \
         case 1536: rc = FN<8, 3>(__VA_ARGS__); break;             \
         case 2048: rc = FN<8, 4>(__VA_ARGS__); break;             \
         default: rc = E2K_ERR_SHAPE;                              \

@@ -573,9 +573,14 @@ int launch_bwd(const HCBwdArgs& a, bool depth, bool width, int grid, hipStream_t
     switch (D) {                                                      \
         case 128: rc = FN<2, 1, 1>(__VA_ARGS__); break;               \
         case 256: rc = FN<4, 1, 1>(__VA_ARGS__); break;               \
+        case 384: rc = FN<2, 3, 1>(__VA_ARGS__); break;               \
         case 512: rc = FN<8, 1, 1>(__VA_ARGS__); break;               \
+        case 640: rc = FN<2, 5, 1>(__VA_ARGS__); break;               \
         case 768: rc = FN<4, 3, 1>(__VA_ARGS__); break;               \
+        case 896: rc = FN<2, 7, 1>(__VA_ARGS__); break;               \
         case 1024: rc = FN<8, 1, 2>(__VA_ARGS__); break;              \
+        case 1280: rc = FN<4, 5, 1>(__VA_ARGS__); break;              \
+        case 1792: rc = FN<2, 7, 2>(__VA_ARGS__); break;              \
         case 1536: rc = FN<4, 3, 2>(__VA_ARGS__); break;              \
         case 2048: rc = FN<8, 1, 4>(__VA_ARGS__); break;              \
         default: rc = E2K_ERR_SHAPE;                                  \
@@ -586,9 +591,14 @@ int launch_bwd(const HCBwdArgs& a, bool depth, bool width, int grid, hipStream_t
     switch (D) {                                                      \
         case 128: rc = FN<2, 1, 1>(__VA_ARGS__); break;               \
         case 256: rc = FN<4, 1, 1>(__VA_ARGS__); break;               \
+        case 384: rc = FN<2, 3, 1>(__VA_ARGS__); break;               \
         case 512: rc = FN<4, 1, 2>(__VA_ARGS__); break;               \
+        case 640: rc = FN<2, 5, 1>(__VA_ARGS__); break;               \
         case 768: rc = FN<4, 3, 1>(__VA_ARGS__); break;               \
+        case 896: rc = FN<2, 7, 1>(__VA_ARGS__); break;               \
         case 1024: rc = FN<4, 1, 4>(__VA_ARGS__); break;              \
+        case 1280: rc = FN<2, 5, 2>(__VA_ARGS__); break;              \
+        case 1792: rc = FN<2, 7, 2>(__VA_ARGS__); break;              \
         case 1536: rc = FN<4, 3, 2>(__VA_ARGS__); break;              \
         case 2048: rc = FN<8, 1, 4>(__VA_ARGS__); break;              \
         default: rc = E2K_ERR_SHAPE;                                  \

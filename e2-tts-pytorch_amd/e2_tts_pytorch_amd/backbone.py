@@ -238,6 +238,9 @@ class _Stream:
 
 # ------------------------------------------------------------------------------------------------ the backbone
 
+_ROW_WIDTHS = frozenset((128, 256, 384, 512, 640, 768, 896, 1024, 1280, 1536, 1792, 2048))      # E2K_ROW_DISPATCH / HC_DISPATCH (csrc)
+
+
 class Transformer(Module):
     def __init__(
         self,
@@ -288,6 +291,11 @@ class Transformer(Module):
         text_ff_mult = default(text_ff_mult, ff_mult)
         text_depth = default(text_depth, depth)
         assert 1 <= text_depth <= depth, 'must have at least 1 layer of text conditioning, but less than total number of speech layers'
+        # widths the row kernels (hyper-connections, norms, gates) are instantiated for: 64 lanes x {2, 4, 8} elements x chunks
+        for what, d in (('dim', dim), ('dim_text', dim_text)):
+            if d not in _ROW_WIDTHS:
+                raise NotImplementedError(f'{what} = {d}: the row kernels are built for {sorted(_ROW_WIDTHS)} '
+                                          '(with the default dim_text = dim // 2: dim a multiple of 256 up to 2048)')
         freq_heads = default(freq_heads, heads)
         freq_dim_head = default(freq_dim_head, dim_head)
         if dim_head != 64 or text_dim_head != 64 or (has_freq_axis and freq_dim_head != 64):

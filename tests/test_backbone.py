@@ -589,3 +589,34 @@ def test_dual_source_and_grouped_weight_gradients_in_the_backbone(dev):
     assert names0.count('gemm_tn_bf16') - names1.count('gemm_tn_bf16') == 8 * depth + 4 + 2 + 2
     for n in g0:          # (fp32 atomics in some reductions make the summation order free: tolerance, not bits)
         assert rel2(g1[n], g0[n]) < 1e-5 or float(g0[n].norm()) < 1e-7, n
+
+
+@pytest.mark.parametrize('dim', [768, 1280])
+def test_backbone_other_widths(dev, dim):
+    """model widths besides the benchmark's: the row kernels (hyper-connections, norms, gates) are instantiated for every
+    multiple of 128 the dispatch tables list (csrc/e2k_device.h E2K_ROW_DISPATCH, hc.hip HC_DISPATCH); dim 768 runs its text
+    stream at 384 = 64 lanes x 2 elements x 3 chunks, dim 1280 at 640 = 64 x 2 x 5.  Forward, input and parameter gradients
+    against the oracle; unsupported widths are refused at construction, not at the first kernel call"""
+    from e2_tts_pytorch_amd import Transformer
+    random.seed(0)
+    torch.manual_seed(0)
+    kw = dict(dim=dim, depth=2, heads=2, dropout=0., max_seq_len=64)
+    ref = O.Transformer(**kw)
+    randomize(ref)
+    mod = Transformer(**kw)
+    mod.load_state_dict(ref.state_dict(), strict=True)
+    mod = mod.to(dev)
+    B, T = 2, 12
+    x, t, txt = torch.randn(B, T, dim), torch.rand(B), torch.randn(B, T, dim // 2)
+    xr, xk = x.clone().requires_grad_(True), x.clone().to(dev).requires_grad_(True)
+    out_r = ref(xr, times=t, text_embed=txt)
+    out_r.sum().backward()
+    out_k = mod(xk, times=t.to(dev), text_embed=txt.to(dev))
+    out_k.sum().backward()
+    assert rel2(out_k, out_r) < 2e-2 and rel2(xk.grad, xr.grad) < 5e-2
+    gp = dict(ref.named_parameters())
+    for n, p in mod.named_parameters():
+        if p.numel() > 64 and gp[n].grad is not None and float(gp[n].grad.norm()) > 0:
+            assert rel2(p.grad, gp[n].grad) < 0.2, n
+    with pytest.raises(NotImplementedError):
+        Transformer(dim=320, depth=2, heads=2)
