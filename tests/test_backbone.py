@@ -517,7 +517,7 @@ def test_rmsnorm_unit_offset_checkpoints_are_converted_on_load():
     from e2_tts_pytorch_amd.backbone import rmsnorm_gain_convention
     random.seed(0)
     torch.manual_seed(0)
-    src = Transformer(dim=128, depth=2, heads=2, max_seq_len=32)
+    src = Transformer(dim=256, depth=2, heads=2, max_seq_len=32)
     with torch.no_grad():
         for n, p in src.named_parameters():
             if n.endswith('.g'):
@@ -527,7 +527,7 @@ def test_rmsnorm_unit_offset_checkpoints_are_converted_on_load():
     assert gkeys and rmsnorm_gain_convention(sd) == 'plain'
     other = {k: (v - 1 if k in gkeys else v.clone()) for k, v in sd.items()}       # the same model, written with gain = g + 1
     assert rmsnorm_gain_convention(other) == 'unit_offset'
-    dst = Transformer(dim=128, depth=2, heads=2, max_seq_len=32)
+    dst = Transformer(dim=256, depth=2, heads=2, max_seq_len=32)
     with pytest.warns(UserWarning, match='unit-offset'):
         dst.load_state_dict(other, strict=True)
     assert all(torch.allclose(dst.state_dict()[k], sd[k], atol=1e-6) for k in sd)
@@ -540,10 +540,10 @@ def test_rmsnorm_unit_offset_checkpoints_are_converted_on_load():
         dst.load_state_dict(other, strict=True)                                    # opt-out: verbatim
     assert all(torch.equal(dst.state_dict()[k], other[k]) for k in gkeys)
     # through the enclosing model (prefix 'transformer.')
-    m = E2TTS(transformer=dict(dim=128, depth=2, heads=2), use_vocos=False)
+    m = E2TTS(transformer=dict(dim=256, depth=2, heads=2), use_vocos=False)
     msd = m.state_dict()
     mo = {k: (v - 1 if k.endswith('.g') else v) for k, v in msd.items()}
-    m2 = E2TTS(transformer=dict(dim=128, depth=2, heads=2), use_vocos=False)
+    m2 = E2TTS(transformer=dict(dim=256, depth=2, heads=2), use_vocos=False)
     with pytest.warns(UserWarning, match='unit-offset'):
         m2.load_state_dict(mo, strict=True)
     assert all(torch.allclose(m2.state_dict()[k], msd[k], atol=1e-6) for k in msd if k.endswith('.g'))
