@@ -464,7 +464,7 @@ def test_plan_replay_with_the_default_off_switches(dev):
     from e2_tts_pytorch_amd import Transformer
     random.seed(0)
     torch.manual_seed(0)
-    T = 24
+    T = 24 if dev == 'cuda' else 12
     mod = Transformer(dim=256, depth=2, heads=2, dropout=0., max_seq_len=64, has_freq_axis=True, freq_heads=2, attn_laser=True,
                       attn_fourier_embed_input=True)
     randomize(mod)
@@ -606,7 +606,7 @@ def test_backbone_other_widths(dev, dim):
     mod = Transformer(**kw)
     mod.load_state_dict(ref.state_dict(), strict=True)
     mod = mod.to(dev)
-    B, T = 2, 12
+    B, T = (2, 12) if dev == 'cuda' else (1, 8)
     x, t, txt = torch.randn(B, T, dim), torch.rand(B), torch.randn(B, T, dim // 2)
     xr, xk = x.clone().requires_grad_(True), x.clone().to(dev).requires_grad_(True)
     out_r = ref(xr, times=t, text_embed=txt)

@@ -341,14 +341,15 @@ def test_sample_adaptive_dopri5(dev):
     model = model.to(dev).eval()
     cond = torch.randn(1, 5, 100).to(dev)
     y0 = torch.randn(1, 12, 100).to(dev)
-    fine = model.sample(cond, text=['solver'], duration=12, steps=17, cfg_strength=0., _y0=y0)
+    on_gpu = dev == 'cuda'                                             # (the host model runs ~1 s per function evaluation: coarser there)
+    fine = model.sample(cond, text=['solver'], duration=12, steps=17 if on_gpu else 9, cfg_strength=0., _y0=y0)
     errs = []
-    for tol in ((3e-2, 2e-3) if dev == 'cuda' else (2e-3,)):          # (the host model runs ~1 s per function evaluation)
+    for tol in ((3e-2, 2e-3) if on_gpu else (1e-2,)):
         model.odeint_kwargs = dict(method='dopri5', atol=tol, rtol=tol)
         s = model.sample(cond, text=['solver'], duration=12, steps=5, cfg_strength=0., _y0=y0)
         errs.append(rel2(s, fine))
     model.odeint_kwargs = dict(method='midpoint')
-    assert errs[-1] < 1e-2 and errs[-1] <= errs[0] + 1e-3, errs
+    assert errs[-1] < (1e-2 if on_gpu else 3e-2) and errs[-1] <= errs[0] + 1e-3, errs
 
 
 def test_duration_predictor(dev):
