@@ -210,7 +210,7 @@ _gemm_shapes = None        # tools/nt_shapes.py: dict counting the (M, N, K1, K2
 # E2K_GEMM_* bits passed to every gemm_nt call (A/B benchmarking of kernel variants: 64 = 256 x 128 tile, 128 = 256 x 256
 # 8-phase tile for every shape, 256 = the same where it fills the chip).  E2K_GEMM_FLAGS in the environment presets it.
 # ---- launch lanes (csrc/plan.h) --------------------------------------------------------------------------------------
-MAIN, TEXT, WGRAD = 0, 1, 2
+MAIN, TEXT, WGRAD, RNG = 0, 1, 2, 3
 
 
 class Lanes:
@@ -660,17 +660,23 @@ attn_share_dropmask = True
 attn_probe = int(_os.environ.get('E2K_ATTN_FLAGS', '0'))      # E2K_ATTN_* bits: 128 = the register-staged kernels instead of the LDS-DMA rings (A/B); probes 1..32 give wrong results on purpose
 
 
-def attn_dropbits(B, H, N, p_drop, seed, stream_id, seed_dev, device):
-    """the dropout keep decisions of one attention call, ahead of its forward (e2k_attn_dropbits); None when there is no dropout"""
+def attn_dropbits(B, H, N, p_drop, seed, stream_id, seed_dev, device, bits=None):
+    """the dropout keep decisions of one attention call, ahead of its forward (e2k_attn_dropbits); None when there is no dropout.
+    bits: fill this buffer (from attn_dropbits_alloc: allocate on the consumer's lane, fill on another)"""
     if not p_drop > 0:
         return None
-    nbytes = _lib.get().e2k_query_attn_dropbits_bytes(B, H, N)
-    if nbytes <= 0:
-        return None
-    bits = torch.empty(nbytes // 8, dtype=torch.int64, device=device)
+    if bits is None:
+        bits = attn_dropbits_alloc(B, H, N, device)
+        if bits is None:
+            return None
     Npad = (N + 63) // 64 * 64
     _lib.get().e2k_attn_dropbits(_p(bits), B, H, N, Npad, float(p_drop), int(seed), _p(seed_dev), int(stream_id), _stream(bits))
     return bits
+
+
+def attn_dropbits_alloc(B, H, N, device):
+    nbytes = _lib.get().e2k_query_attn_dropbits_bytes(B, H, N)
+    return torch.empty(nbytes // 8, dtype=torch.int64, device=device) if nbytes > 0 else None
 
 
 def attn_fwd(st, kmask_pad, p_drop=0., seed=0, stream_id=0, seed_dev=None, dropbits=None):
