@@ -498,48 +498,6 @@ __global__ __launch_bounds__(NW * 64, NW == 8 ? 4 : 2) void attn_fwd_kernel(Attn
     }
 }
 
-// Dropout keep decisions of one attention call produced AHEAD of its forward (e2k_attn_dropbits): exactly the ballot words the
-// forward would publish in SHARE mode (same hash, same lane <-> (query, key) layout), written by a kernel that has no LDS
-// tiles, no MFMAs and 40 registers -- it fits next to a GEMM workgroup on the same CU and uses the vector ALU the GEMM leaves
-// idle.  The forward then reads the words like the backward kernels do (scalar loads + v_cndmask) instead of spending 37 % of
-// its vector instructions on the hash, the compares and the publication (profiles/r03_attn_isa_mix.json).
-__global__ __launch_bounds__(256) void attn_dropbits_kernel(AttnArgs p) {
-    __shared__ unsigned long long bal[4 * 32];
-    const int tid = threadIdx.x, lane = tid & 63, wave = uniform_i(tid >> 6);
-    const int l15 = lane & 15, g = lane >> 4;
-    const int q0 = blockIdx.x * 64, h = blockIdx.y, b = blockIdx.z;
-    const long bh = (long)b * p.H + h;
-    const int q = q0 + wave * 16 + l15;
-    const unsigned dstream = attn_stream(p.stream_id, (unsigned)bh);
-    const int ntiles = (p.N + 63) / 64;
-    const unsigned hrow = rand_base(p.seed_dev ? *p.seed_dev : p.seed, dstream) + (unsigned)q * 0x85ebca77u;
-    const unsigned hlane = hrow + (unsigned)(2 * g) * 0xc2b2ae3du;
-    unsigned long long* const wbal = bal + wave * 32;
-    for (int kt = 0; kt < ntiles; ++kt) {
-        const int k0 = kt * 64;
-        unsigned long long mk[16];
-#pragma unroll
-        for (int t = 0; t < 4; ++t) {
-            unsigned w0, w1;
-            drop4(hlane, (unsigned)(k0 >> 2) + 8 * (t >> 1) + (t & 1), w0, w1);
-            mk[4 * t + 0] = wave_ballot((w0 & 0xffffu) >= p.thresh);
-            mk[4 * t + 1] = wave_ballot((w0 >> 16) >= p.thresh);
-            mk[4 * t + 2] = wave_ballot((w1 & 0xffffu) >= p.thresh);
-            mk[4 * t + 3] = wave_ballot((w1 >> 16) >= p.thresh);
-        }
-        unsigned long long* wb = wbal + (kt & 1) * 16;
-        if (lane == 0) {
-#pragma unroll
-            for (int i = 0; i < 16; ++i) wb[i] = mk[i];
-        }
-        wave_sync();
-        if (lane < 16) {
-            unsigned long long* dropw = p.dropbits + ((((long)bh * ntiles + kt) * ntiles + blockIdx.x) * 4 + wave) * 16;
-            dropw[lane] = wb[lane];
-        }
-    }
-}
-
 // ---- forward with an LDS-DMA ring ---------------------------------------------------------------------------------
 // Same arithmetic and the same LDS tile images as attn_fwd_kernel (NW = 4), different data movement.  K / V tiles go
 // HBM -> LDS directly (global_load_lds, no staging VGPRs, no LDS write pass) into a ring of 16-KB stages with a counted
@@ -556,8 +514,8 @@ __global__ __launch_bounds__(256) void attn_dropbits_kernel(AttnArgs p) {
 // (V^T), produced by permuting the per-lane SOURCE address (the LDS destination of an LDS-DMA is lane-linear).
 constexpr int RSTAGE = 16384, RKM = 4096;
 
-template <bool DROP, int SHARE, int RING>       // RING stages: tiles are issued RING - 1 ahead.  SHARE: 0 = keep decisions stay in the kernel
-__global__ __launch_bounds__(256, 2) void attn_fwd_ring_kernel(AttnArgs p) {      // (the backward re-hashes), 1 = published as ballot words, 2 = read from e2k_attn_dropbits' words
+template <bool DROP, bool SHARE, int RING>       // RING stages: tiles are issued RING - 1 ahead
+__global__ __launch_bounds__(256, 2) void attn_fwd_ring_kernel(AttnArgs p) {
     __shared__ __attribute__((aligned(16))) unsigned char smem[RING * RSTAGE + RKM + 4 * 256];
     lds_declare(smem, sizeof(smem));
     unsigned char* const kms = smem + RING * RSTAGE;                 // key mask of this batch row (Npad bytes)
@@ -661,8 +619,6 @@ __global__ __launch_bounds__(256, 2) void attn_fwd_ring_kernel(AttnArgs p) {    
                 }
         }
         unsigned long long mk[16];
-        const unsigned long long* dropin = (DROP && SHARE == 2)
-            ? p.dropbits + ((((long)bh * ntiles + kt) * ntiles + blockIdx.x) * 4 + wave) * 16 : nullptr;
 #pragma unroll
         for (int t = 0; t < 4; ++t) {
             float pr[4];
@@ -670,23 +626,20 @@ __global__ __launch_bounds__(256, 2) void attn_fwd_ring_kernel(AttnArgs p) {    
             for (int r = 0; r < 4; ++r) pr[r] = fast_exp2(s[t][r]);
             lsum2 += f32x2_{pr[0], pr[1]};           // softmax denominators are taken BEFORE dropout
             lsum2 += f32x2_{pr[2], pr[3]};
-            if (DROP && SHARE == 2) {
-#pragma unroll
-                for (int r = 0; r < 4; ++r) pr[r] = wave_inverse_ballot(sload64(dropin + 4 * t + r)) ? pr[r] : 0.f;
-            } else if (DROP) {
+            if (DROP) {
                 unsigned w0, w1;
                 drop4(hlane, (unsigned)(k0 >> 2) + 8 * (t >> 1) + (t & 1), w0, w1);
                 const bool kp[4] = {(w0 & 0xffffu) >= p.thresh, (w0 >> 16) >= p.thresh, (w1 & 0xffffu) >= p.thresh, (w1 >> 16) >= p.thresh};
 #pragma unroll
                 for (int r = 0; r < 4; ++r) {
                     pr[r] = kp[r] ? pr[r] : 0.f;
-                    if (SHARE == 1) mk[4 * t + r] = wave_ballot(kp[r]);
+                    if (SHARE) mk[4 * t + r] = wave_ballot(kp[r]);
                 }
             }
 #pragma unroll
             for (int r = 0; r < 4; ++r) s[t][r] = pr[r];
         }
-        if (DROP && SHARE == 1) {
+        if (DROP && SHARE) {
             // the 16 compare masks of this tile: lane 0 parks them in LDS, lanes 0-15 write them out as one 128-byte store
             unsigned long long* wb = wbal + (kt & 1) * 16;
             if (lane == 0) {
@@ -1577,20 +1530,6 @@ extern "C" int e2k_query_attn_dropbits_bytes(int B, int H, int N) {
     return bytes > 0x7fffffffL ? -1 : (int)bytes;
 }
 
-static int attn_dropbits_impl(void* dropbits, int B, int H, int N, int Npad, float p_drop, uint32_t seed, const uint32_t* seed_dev,
-                              uint32_t stream_id, void* stream) {
-    if (B <= 0 || N <= 0) return 0;
-    if (!dropbits) return E2K_ERR_ARG;
-    AttnArgs a{};
-    int rc = fill_attn(a, B, H, N, Npad, p_drop, seed, seed_dev, stream_id);
-    if (rc) return rc;
-    if (!a.thresh) return 0;
-    a.dropbits = (unsigned long long*)dropbits;
-    hipLaunchKernelGGL(attn_dropbits_kernel, dim3((N + 63) / 64, H, B), dim3(256), 0, (hipStream_t)stream, a);
-    E2K_CHECK_LAUNCH();
-    return 0;
-}
-
 static int attn_fwd_impl(const void* Q, const void* K, const void* VT, const uint8_t* kmask, const float* gate,
                             void* O, void* Og, float* lse2, void* dropbits, int B, int H, int N, int Npad, float p_drop,
                             uint32_t seed, const uint32_t* seed_dev, uint32_t stream_id, int flags, void* stream) {
@@ -1603,7 +1542,6 @@ static int attn_fwd_impl(const void* Q, const void* K, const void* VT, const uin
     a.O = (bf16_t*)O; a.Og = (bf16_t*)Og; a.lse2 = lse2;
     a.dropbits = (unsigned long long*)dropbits;
     a.probe = flags & 63;      // (bits 6.. select kernel variants, see e2k.h)
-    if ((flags & E2K_ATTN_DROPBITS_READY) && a.thresh && (!dropbits || (flags & E2K_ATTN_NO_RING) || Npad > RKM || a.probe)) return E2K_ERR_ARG;
     hipStream_t st = (hipStream_t)stream;
     if (a.probe) {              // bottleneck probes (wrong results on purpose): separate instantiations
         const dim3 grid((N + 63) / 64, H, B), block(256);
@@ -1612,10 +1550,9 @@ static int attn_fwd_impl(const void* Q, const void* K, const void* VT, const uin
         else hipLaunchKernelGGL((attn_fwd_kernel<false, false, 4, true>), grid, block, 0, st, a);
     } else if (!(flags & E2K_ATTN_NO_RING) && Npad <= RKM) {
         const dim3 grid((N + 63) / 64, H, B), block(256);
-        if (a.thresh && dropbits && (flags & E2K_ATTN_DROPBITS_READY)) hipLaunchKernelGGL((attn_fwd_ring_kernel<true, 2, 2>), grid, block, 0, st, a);
-        else if (a.thresh && dropbits) hipLaunchKernelGGL((attn_fwd_ring_kernel<true, 1, 2>), grid, block, 0, st, a);
-        else if (a.thresh) hipLaunchKernelGGL((attn_fwd_ring_kernel<true, 0, 2>), grid, block, 0, st, a);
-        else hipLaunchKernelGGL((attn_fwd_ring_kernel<false, 0, 2>), grid, block, 0, st, a);
+        if (a.thresh && dropbits) hipLaunchKernelGGL((attn_fwd_ring_kernel<true, true, 2>), grid, block, 0, st, a);
+        else if (a.thresh) hipLaunchKernelGGL((attn_fwd_ring_kernel<true, false, 2>), grid, block, 0, st, a);
+        else hipLaunchKernelGGL((attn_fwd_ring_kernel<false, false, 2>), grid, block, 0, st, a);
     } else {
         const dim3 grid((N + 63) / 64, H, B), block(256);
         if (a.thresh && dropbits) hipLaunchKernelGGL((attn_fwd_kernel<true, true, 4>), grid, block, 0, st, a);
@@ -1706,9 +1643,4 @@ extern "C" int e2k_laser_out_fwd(const void* O, const float* gate, const uint8_t
 extern "C" int e2k_laser_out_bwd(const void* dOg, const void* O, const float* gate, const uint8_t* kmask, void* dOin, float* dgate_pre,
                                  int B, int H, int N, int Npad, void* stream) {
     return e2k::dispatch("laser_out_bwd", laser_out_bwd_impl, dOg, O, gate, kmask, dOin, dgate_pre, B, H, N, Npad, stream);
-}
-
-extern "C" int e2k_attn_dropbits(void* dropbits, int B, int H, int N, int Npad, float p_drop, uint32_t seed, const uint32_t* seed_dev,
-                                 uint32_t stream_id, void* stream) {
-    return e2k::dispatch("attn_dropbits", attn_dropbits_impl, dropbits, B, H, N, Npad, p_drop, seed, seed_dev, stream_id, stream);
 }

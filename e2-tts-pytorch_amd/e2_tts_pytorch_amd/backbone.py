@@ -238,12 +238,6 @@ class _Stream:
 
 # ------------------------------------------------------------------------------------------------ the backbone
 
-# E2K_DROPBITS_AHEAD=1: the dropout keep decisions of every attention call of a step are produced at the start of the forward by
-# the register-only generator (e2k_attn_dropbits) on a fourth launch lane, next to whatever the chain is running; the attention
-# forwards then read them instead of hashing (MI355X, cfg3 shape: forward 129 -> 99 us, generator 37.5 us alone and about half
-# hidden next to a GEMM, profiles/r03_dropbits_overlap.json).  Off by default until a step-level A/B says otherwise.
-_DROPBITS_AHEAD = _os.environ.get('E2K_DROPBITS_AHEAD', '0') == '1'
-
 _ROW_WIDTHS = frozenset((128, 256, 384, 512, 640, 768, 896, 1024, 1280, 1536, 1792, 2048))      # E2K_ROW_DISPATCH / HC_DISPATCH (csrc)
 
 
@@ -391,7 +385,7 @@ class Transformer(Module):
         self._rot_cache = {}
         self._plans_on = getattr(self, '_plans_on', True)       # enable_plans(): record-and-replay of the launch schedule
         self._max_plans = getattr(self, '_max_plans', 4)
-        self._lane_mask = (int(_os.environ.get('E2K_LANES', '3')) or 3) | (4 if _DROPBITS_AHEAD else 0)   # bit 0: TEXT lane, bit 1: WGRAD lane, bit 2: RNG lane (A/B, fault isolation)
+        self._lane_mask = int(_os.environ.get('E2K_LANES', '3')) or 3   # bit 0: TEXT lane, bit 1: WGRAD lane (A/B, fault isolation)
         self._lanes_on = getattr(self, '_lanes_on', _os.environ.get('E2K_LANES', '3') != '0')      # enable_lanes(); E2K_LANES=0 turns them off
         self._lanes_bwd = getattr(self, '_lanes_bwd', _os.environ.get('E2K_LANES_BWD', '1') != '0')
         self.__dict__.pop('_lane_ss', None)
@@ -773,12 +767,11 @@ class Transformer(Module):
         if not self._lanes_on:
             return []
         dev = torch.device(dev)
-        nside = 3 if (self._lane_mask & 4) else 2          # (+ the RNG lane of E2K_DROPBITS_AHEAD)
         if dev.type != 'cuda':
-            return [None] * nside
+            return [None, None]
         ss = self.__dict__.get('_lane_ss')
-        if ss is None or ss[0] != dev or len(ss[1]) != nside:
-            ss = self.__dict__['_lane_ss'] = (dev, [torch.cuda.Stream(device=dev) for _ in range(nside)])
+        if ss is None or ss[0] != dev:
+            ss = self.__dict__['_lane_ss'] = (dev, [torch.cuda.Stream(device=dev), torch.cuda.Stream(device=dev)])
         return ss[1]
 
     def _drop_plans(self):
@@ -996,19 +989,6 @@ class Transformer(Module):
         # i - 1 left it, so they run on the TEXT lane next to the audio branches of layer i - 1
         L = run.lanes = ops.Lanes(dev, self._lane_streams(dev) if exists(st) else [], self._lane_mask)
         ev_cross = L.record(ops.MAIN)
-        run.bits = {}
-        if p_drop > 0 and L.has(ops.RNG):
-            # buffers are allocated here (MAIN), filled on the RNG lane; each attention call waits for its own event
-            L.wait(ops.RNG, ev_cross)
-            for r in self._recs:
-                for text in ((True, False) if (exists(st) and exists(r.t)) else (False,)):
-                    a_ = (r.t if text else r.s).attn
-                    bits = ops.attn_dropbits_alloc(B, a_.H, N, dev)
-                    if bits is None:
-                        continue
-                    with L.lane(ops.RNG):
-                        ops.attn_dropbits(B, a_.H, N, p_drop, run.seed, (r.index * 2 + int(text)) * 4, run.seed_dev, dev, bits=bits)
-                    run.bits[(r.index, text)] = (bits, L.record(ops.RNG))
         # what MAIN hands to the TEXT lane (the packed text stream, then each cross projection's output) is allocated on
         # MAIN: it must stay referenced until MAIN has waited for the TEXT lane again, or the next MAIN allocation could
         # land on it while the TEXT lane still reads it
@@ -1122,10 +1102,7 @@ class Transformer(Module):
         if first:
             run.vfirst[key] = ast.Vorig if a.laser > 0 else ast.V      # (LASER: the values before the exp map)
         sid = (ind * 2 + int(text)) * 4
-        ready = run.bits.get((ind, text))
-        if ready is not None:
-            run.lanes.wait(run.lanes.cur, ready[1])
-        Og = ops.attn_fwd(ast, run.kmask, run.p_drop, run.seed, sid, run.seed_dev, dropbits=None if ready is None else ready[0])
+        Og = ops.attn_fwd(ast, run.kmask, run.p_drop, run.seed, sid, run.seed_dev)
         y = ops.gemm_nt(Og, self._w(a.out, D, a.I), colscale=gate, rows_per_batch=rpbc)
         self._hc_depth(S, rec, y)
         if exists(tape):

@@ -210,7 +210,7 @@ _gemm_shapes = None        # tools/nt_shapes.py: dict counting the (M, N, K1, K2
 # E2K_GEMM_* bits passed to every gemm_nt call (A/B benchmarking of kernel variants: 64 = 256 x 128 tile, 128 = 256 x 256
 # 8-phase tile for every shape, 256 = the same where it fills the chip).  E2K_GEMM_FLAGS in the environment presets it.
 # ---- launch lanes (csrc/plan.h) --------------------------------------------------------------------------------------
-MAIN, TEXT, WGRAD, RNG = 0, 1, 2, 3
+MAIN, TEXT, WGRAD = 0, 1, 2
 
 
 class Lanes:
@@ -660,28 +660,8 @@ attn_share_dropmask = True
 attn_probe = int(_os.environ.get('E2K_ATTN_FLAGS', '0'))      # E2K_ATTN_* bits: 128 = the register-staged kernels instead of the LDS-DMA rings (A/B); probes 1..32 give wrong results on purpose
 
 
-def attn_dropbits(B, H, N, p_drop, seed, stream_id, seed_dev, device, bits=None):
-    """the dropout keep decisions of one attention call, ahead of its forward (e2k_attn_dropbits); None when there is no dropout.
-    bits: fill this buffer (from attn_dropbits_alloc: allocate on the consumer's lane, fill on another)"""
-    if not p_drop > 0:
-        return None
-    if bits is None:
-        bits = attn_dropbits_alloc(B, H, N, device)
-        if bits is None:
-            return None
-    Npad = (N + 63) // 64 * 64
-    _lib.get().e2k_attn_dropbits(_p(bits), B, H, N, Npad, float(p_drop), int(seed), _p(seed_dev), int(stream_id), _stream(bits))
-    return bits
-
-
-def attn_dropbits_alloc(B, H, N, device):
-    nbytes = _lib.get().e2k_query_attn_dropbits_bytes(B, H, N)
-    return torch.empty(nbytes // 8, dtype=torch.int64, device=device) if nbytes > 0 else None
-
-
-def attn_fwd(st, kmask_pad, p_drop=0., seed=0, stream_id=0, seed_dev=None, dropbits=None):
-    """kmask_pad (B, Npad) uint8.  Fills st.O / st.Og / st.lse2, returns Og (B*N, H*64).  dropbits: this call's keep decisions
-    from attn_dropbits (the forward then reads them instead of hashing and publishing them)"""
+def attn_fwd(st, kmask_pad, p_drop=0., seed=0, stream_id=0, seed_dev=None):
+    """kmask_pad (B, Npad) uint8.  Fills st.O / st.Og / st.lse2, returns Og (B*N, H*64)."""
     _chk(kmask_pad)
     B, H, N, Npad = st.B, st.H, st.N, st.Npad
     assert kmask_pad.shape == (B, Npad) and kmask_pad.dtype == torch.uint8 and kmask_pad.is_contiguous()
@@ -690,17 +670,14 @@ def attn_fwd(st, kmask_pad, p_drop=0., seed=0, stream_id=0, seed_dev=None, dropb
     st.Og = torch.empty((B * N, H * 64), dtype=bf16, device=dev)
     st.lse2 = torch.empty((B, H, N), dtype=f32, device=dev)
     st.dropbits = None
-    ready = 0
-    if dropbits is not None and p_drop > 0 and not (attn_probe & 191) and Npad <= 4096:
-        st.dropbits, ready = dropbits, 256                # E2K_ATTN_DROPBITS_READY
-    elif attn_share_dropmask and p_drop > 0:
+    if attn_share_dropmask and p_drop > 0:
         nbytes = _lib.get().e2k_query_attn_dropbits_bytes(B, H, N)
         if nbytes > 0:
             st.dropbits = torch.empty(nbytes // 8, dtype=torch.int64, device=dev)
     _note(4.0 * B * H * N * N * 64)
     _lib.get().e2k_attn_fwd(_p(st.Q), _p(st.K), _p(st.VT), _p(kmask_pad), _p(st.gate), _p(st.O), _p(st.Og), _p(st.lse2),
                             _p(st.dropbits), B, H, N, Npad, float(p_drop), int(seed), _p(seed_dev), int(stream_id),
-                            attn_probe | ready, _stream(st.Q))
+                            attn_probe, _stream(st.Q))
     if st.laser > 0:
         # LASER: the head gates apply to log(out) (x-transformers Attention.forward); st.O keeps the attention's own output
         st.Og = torch.empty_like(st.Og)

@@ -241,16 +241,10 @@ int e2k_attn_fwd(const void* Q, const void* K, const void* VT, const uint8_t* km
 #define E2K_ATTN_PROBE_NO_LOADS 16   /* no global K / V tile loads after the first */
 #define E2K_ATTN_PROBE_NO_BARRIER 32 /* no workgroup barriers */
 #define E2K_ATTN_NO_RING 128         /* (both calls) the register-staged kernels instead of the LDS-DMA ring kernels (A/B; same results) */
-#define E2K_ATTN_DROPBITS_READY 256  /* (e2k_attn_fwd) `dropbits` already holds this call's keep decisions (e2k_attn_dropbits ran first): read them instead of hashing */
 /* dropbits (optional, both calls; NULL = every kernel re-derives the dropout mask from the counter hash): scratch of
  * e2k_query_attn_dropbits_bytes(B, H, N) bytes in which the forward leaves its keep decisions as 64-bit wave ballot words
  * and from which the backward kernels read them back.  Same mask either way (bit-identical results). */
 int e2k_query_attn_dropbits_bytes(int B, int H, int N);
-/* The keep decisions of one attention call (same seed / stream_id / p_drop as its e2k_attn_fwd), written into `dropbits` ahead of
- * the forward by a register-only kernel that can share a CU with a GEMM workgroup; e2k_attn_fwd with E2K_ATTN_DROPBITS_READY and
- * e2k_attn_bwd then read them.  Bit-identical to what the forward publishes itself. */
-int e2k_attn_dropbits(void* dropbits, int B, int H, int N, int Npad, float p_drop, uint32_t seed, const uint32_t* seed_dev,
-                      uint32_t stream_id, void* stream);
 /* Which transposed copies the backward needs: bit 0 = KT (the register-staged dQ kernel: flag E2K_ATTN_NO_RING, or
  * Npad > 4096), bit 1 = QT and dOT (the register-staged dK,dV kernel: that flag).  The default
  * (LDS-DMA ring) kernels read K^T / Q^T / dO^T out of the row-major tiles with ds_read_b64_tr_b16: e2k_qkv_post_fwd

@@ -494,42 +494,6 @@ def test_plan_replay_with_the_default_off_switches(dev):
             assert rel2(g1[n], g0[n]) < 2e-3 or float(g0[n].norm()) < 1e-6, n
 
 
-def test_dropout_keep_bits_ahead_of_the_forward(dev, monkeypatch):
-    """E2K_DROPBITS_AHEAD: the keep decisions of every attention call come from the generator kernel on a fourth launch lane
-    at the start of the forward and the attention forwards read them -- same masks, so the training step (dropout 0.1) gives
-    the same outputs and gradients bit for bit as the default schedule, eagerly and through a recorded plan"""
-    from e2_tts_pytorch_amd import Transformer, backbone
-    T, B = (24, 2) if dev == 'cuda' else (12, 1)
-
-    def run(ahead, plans):
-        monkeypatch.setattr(backbone, '_DROPBITS_AHEAD', ahead)
-        random.seed(0)
-        torch.manual_seed(0)
-        mod = Transformer(dim=256, depth=2, heads=2, dropout=0.1, max_seq_len=64)
-        randomize(mod)
-        mod = mod.to(dev).train()
-        assert bool(mod._lane_mask & 4) == ahead
-        mod.enable_plans(plans)
-        mod._plan_py_seed = True
-        outs = []
-        for step in range(3 if plans else 1):
-            random.seed(100 + step)
-            torch.manual_seed(100 + step)
-            g = torch.Generator().manual_seed(step)
-            x = torch.randn(B, T, 256, generator=g).to(dev).requires_grad_(True)
-            txt = torch.randn(B, T, 128, generator=g).to(dev)
-            mod.zero_grad(set_to_none=True)
-            out = mod(x, times=torch.rand(B, generator=g).to(dev), text_embed=txt)
-            out.sum().backward()
-            outs.append((out.detach().clone(), x.grad.clone(), mod.layers[1][0][3].to_q.weight.grad.clone()))
-        return outs
-    for plans in (False, True):
-        a, b = run(False, plans), run(True, plans)
-        for (o0, dx0, g0), (o1, dx1, g1) in zip(a, b):
-            assert torch.equal(o0, o1) and torch.equal(dx0, dx1)
-            assert rel2(g1, g0) < 2e-3
-
-
 def test_plan_recording_rejects_tensor_library_ops(dev):
     """a plan replays e2k calls only: a torch op doing device work inside the recorded region must raise, not vanish"""
     from e2_tts_pytorch_amd import ops

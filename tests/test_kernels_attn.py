@@ -175,18 +175,6 @@ def test_attention_shared_dropout_mask(dev, N):
             ops.attn_share_dropmask = True
     for a, b in zip(*res):
         assert torch.equal(a, b)
-    # third way: the keep decisions produced AHEAD of the forward by the register-only generator (e2k_attn_dropbits), which the
-    # forward then reads instead of hashing: same words as the forward publishes, same outputs and gradients
-    st = ops.qkv_post_fwd(qkvg, B, H, N, cosb, sinb, None)
-    bits = ops.attn_dropbits(B, H, N, 0.25, 1234, 3, None, qkvg.device)
-    Og = ops.attn_fwd(st, kmask.to(dev), 0.25, 1234, 3, dropbits=bits).clone()
-    assert st.dropbits is bits
-    st2 = ops.qkv_post_fwd(qkvg, B, H, N, cosb, sinb, None)
-    ops.attn_fwd(st2, kmask.to(dev), 0.25, 1234, 3)
-    assert torch.equal(bits, st2.dropbits)
-    dQ, dK, dV, dg = ops.attn_bwd(st, dOg, kmask.to(dev), 0.25, 1234, 3)
-    for a, b in zip(res[1], (Og, dQ, dK, dV, dg)):
-        assert torch.equal(a, b)
 
 
 @pytest.mark.parametrize('F,has_vres', [(3, False), (2, True), (8, True), (1, False)])

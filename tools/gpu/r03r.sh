@@ -1,4 +1,6 @@
-# Round 3, GPU call 18: dropout keep bits ahead of the forward (fourth launch lane) -- test on hardware, then A/B of the step
+# Round 3, GPU call 18: dropout keep bits ahead of the forward (fourth launch lane) -- test on hardware, then A/B of the step.
+# (Record of a measurement: the generator kernel, the forward's read-the-bits mode and E2K_DROPBITS_AHEAD were removed after it --
+#  step-neutral, profiles/r03_dropbits_ahead_ab.jsonl; the code is in the history at the commit named in profiles/README.md.)
 tag=${1:-r03r}
 mkdir -p gpurun_out
 export PYTHONUNBUFFERED=1
