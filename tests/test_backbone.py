@@ -143,7 +143,7 @@ def test_persistent_grads(dev):
     from e2_tts_pytorch_amd import Transformer
     random.seed(0)
     torch.manual_seed(0)
-    mod = Transformer(dim=256, depth=2, heads=2, dropout=0., max_seq_len=64)
+    mod = Transformer(dim=256, depth=2, heads=2, dropout=0., max_seq_len=64, num_registers=32 if dev == 'cuda' else 8)      # (host model: fewer register tokens, same schedule)
     randomize(mod)
     mod = mod.to(dev)
     B, T = 2, 24
@@ -254,7 +254,7 @@ def test_launch_lanes_match_single_stream(dev):
     torch.manual_seed(0)
     big = dev == 'cuda'
     dim, depth, B, T = (512, 6, 4, 200) if big else (256, 2, 1, 16)
-    mod = Transformer(dim=dim, depth=depth, heads=dim // 64, dropout=0., max_seq_len=T)
+    mod = Transformer(dim=dim, depth=depth, heads=dim // 64, dropout=0., max_seq_len=T, num_registers=32 if dev == 'cuda' else 8)
     randomize(mod)
     mod = mod.to(dev)
     R = torch.randn(B, T, dim).to(dev)
@@ -321,7 +321,7 @@ def test_geglu_epilogue_in_the_backbone(dev):
     torch.manual_seed(0)
     big = dev == 'cuda'
     dim, depth, B, T = (512, 4, 4, 200) if big else (256, 2, 1, 24)
-    mod = Transformer(dim=dim, depth=depth, heads=dim // 64, dropout=0.1, max_seq_len=T)
+    mod = Transformer(dim=dim, depth=depth, heads=dim // 64, dropout=0.1, max_seq_len=T, num_registers=32 if dev == 'cuda' else 8)
     randomize(mod)
     mod = mod.to(dev)
     mod.train()
@@ -387,7 +387,7 @@ def test_plan_replay_matches_eager(dev):
     random.seed(0)
     torch.manual_seed(0)
     depth, T = (4, 40) if dev == 'cuda' else (2, 24)          # (the host model is ~1000x slower than the GPU: same schedule, fewer layers / frames)
-    mod = Transformer(dim=256, depth=depth, heads=2, dropout=0., max_seq_len=64)
+    mod = Transformer(dim=256, depth=depth, heads=2, dropout=0., max_seq_len=64, num_registers=32 if dev == 'cuda' else 8)
     randomize(mod)
     mod = mod.to(dev)
     B = 2
@@ -466,7 +466,7 @@ def test_plan_replay_with_the_default_off_switches(dev):
     torch.manual_seed(0)
     T = 24 if dev == 'cuda' else 12
     mod = Transformer(dim=256, depth=2, heads=2, dropout=0., max_seq_len=64, has_freq_axis=True, freq_heads=2, attn_laser=True,
-                      attn_fourier_embed_input=True)
+                      attn_fourier_embed_input=True, num_registers=32 if dev == 'cuda' else 8)
     randomize(mod)
     mod = mod.to(dev)
     B = 2

@@ -314,10 +314,24 @@ def test_sample(dev):
 
 
 @pytest.mark.late
+def test_sample_with_frequency_tokens(dev):
+    """E2TTS(num_freq_tokens=2).sample against the oracle: the frequency axis through the classifier-free-guidance pair of
+    forwards (text stream on and dropped) and the ODE steps"""
+    kw = dict(dim=256, depth=2, heads=4, dropout=0., num_registers=32 if dev == 'cuda' else 8)
+    ref, model = _pair(kw, seed=6, num_freq_tokens=2)
+    model = model.to(dev)
+    cond = torch.randn(1, 5, 100)
+    y0 = torch.randn(1, 16, 100)
+    s_r = ref.sample(cond, text=['freq'], duration=16, steps=3, cfg_strength=1., _y0=y0)
+    s = model.sample(cond.to(dev), text=['freq'], duration=16, steps=3, cfg_strength=1., _y0=y0.to(dev))
+    assert s.shape == s_r.shape and rel2(s, s_r) < 2e-2, rel2(s, s_r)
+
+
+@pytest.mark.late
 @pytest.mark.parametrize('method', ['euler', 'rk4'])
 def test_sample_other_fixed_grid_solvers(dev, method):
     """odeint_kwargs method 'euler' / 'rk4' (torchdiffeq's fixed-grid solvers) against the oracle restatement"""
-    kw = dict(dim=256, depth=2, heads=4, dropout=0.)
+    kw = dict(dim=256, depth=2, heads=4, dropout=0., num_registers=32 if dev == 'cuda' else 8)
     ref, model = _pair(kw, seed=4, odeint_kwargs=dict(method=method))
     model = model.to(dev)
     cond = torch.randn(1, 5, 100)
@@ -333,23 +347,24 @@ def test_sample_adaptive_dopri5(dev):
     (e2_tts.py:1122-1126,1421): the adaptive solution agrees with a fine fixed-grid midpoint integration of the SAME model
     (the HIP path's own vector field), tighter tolerance = closer"""
     from e2_tts_pytorch_amd import E2TTS
-    kw = dict(dim=256, depth=2, heads=4, dropout=0.)
+    kw = dict(dim=256, depth=2, heads=4, dropout=0., num_registers=32 if dev == 'cuda' else 8)
     random.seed(5)
     torch.manual_seed(5)
     model = E2TTS(transformer=dict(**kw), use_vocos=False, cond_drop_prob=0.)
     randomize(model)
     model = model.to(dev).eval()
-    cond = torch.randn(1, 5, 100).to(dev)
-    y0 = torch.randn(1, 12, 100).to(dev)
     on_gpu = dev == 'cuda'                                             # (the host model runs ~1 s per function evaluation: coarser there)
-    fine = model.sample(cond, text=['solver'], duration=12, steps=17 if on_gpu else 9, cfg_strength=0., _y0=y0)
+    dur = 12 if on_gpu else 8
+    cond = torch.randn(1, 5, 100).to(dev)
+    y0 = torch.randn(1, dur, 100).to(dev)
+    fine = model.sample(cond, text=['solver'], duration=dur, steps=17 if on_gpu else 7, cfg_strength=0., _y0=y0)
     errs = []
-    for tol in ((3e-2, 2e-3) if on_gpu else (1e-2,)):
+    for tol in ((3e-2, 2e-3) if on_gpu else (2e-2,)):
         model.odeint_kwargs = dict(method='dopri5', atol=tol, rtol=tol)
-        s = model.sample(cond, text=['solver'], duration=12, steps=5, cfg_strength=0., _y0=y0)
+        s = model.sample(cond, text=['solver'], duration=dur, steps=5, cfg_strength=0., _y0=y0)
         errs.append(rel2(s, fine))
     model.odeint_kwargs = dict(method='midpoint')
-    assert errs[-1] < (1e-2 if on_gpu else 3e-2) and errs[-1] <= errs[0] + 1e-3, errs
+    assert errs[-1] < (1e-2 if on_gpu else 5e-2) and errs[-1] <= errs[0] + 1e-3, errs
 
 
 def test_duration_predictor(dev):
