@@ -19,6 +19,7 @@
 #include <cstdlib>
 #include <cstring>
 #include <functional>
+#include <mutex>
 #include <thread>
 #include <vector>
 
@@ -222,6 +223,23 @@ inline void run_block(Block& blk, const std::function<void()>& body) {
     g_blk = nullptr;
 }
 
+// Fiber stacks are pooled for the life of the process: a fresh 256-KB malloc per fiber per launch is an mmap, a page fault or
+// two and a munmap each -- ~16 k system calls per launch with 8 workers x 512 fibers, which was most of the suite's sys time.
+inline std::mutex& stack_mutex() { static std::mutex m; return m; }
+inline std::vector<char*>& stack_pool() { static std::vector<char*> v; return v; }
+inline char* stack_get() {
+    {
+        std::lock_guard<std::mutex> g(stack_mutex());
+        auto& v = stack_pool();
+        if (!v.empty()) { char* s = v.back(); v.pop_back(); return s; }
+    }
+    return (char*)malloc(kStack);
+}
+inline void stack_put(char* s) {
+    std::lock_guard<std::mutex> g(stack_mutex());
+    stack_pool().push_back(s);
+}
+
 inline void launch(dim3 grid, dim3 block, const std::function<void()>& body) {
     long nblocks = (long)grid.x * grid.y * grid.z;
     int nthreads = block.x * block.y * block.z;
@@ -239,14 +257,14 @@ inline void launch(dim3 grid, dim3 block, const std::function<void()>& body) {
         blk.nthreads = nthreads;
         blk.fibers.resize(nthreads);
         blk.waves.resize((nthreads + kWave - 1) / kWave);
-        for (auto& f : blk.fibers) f.stack = (char*)malloc(kStack);
+        for (auto& f : blk.fibers) f.stack = stack_get();
         for (;;) {
             long b = next.fetch_add(1);
             if (b >= nblocks) break;
             blk.bid = dim3(b % grid.x, (b / grid.x) % grid.y, b / ((long)grid.x * grid.y));
             run_block(blk, body);
         }
-        for (auto& f : blk.fibers) free(f.stack);
+        for (auto& f : blk.fibers) stack_put(f.stack);
     };
     if (nworkers == 1) {
         worker();
