@@ -147,38 +147,43 @@ def cpu_baseline(dim, depth, heads, T, sample_depth=12, threads=None):
                       f'executed (oracle/pin_against_reference.py); /root/reference itself cannot travel to the GPU box'}
 
 
-def optimizer_leg(model, net, mel, text, noise, ms_plain, k=4):
+def optimizer_leg(model, net, mel, text, noise, ms_plain, k=6):
     """fwd + bwd + global-norm clip + ADOPT over the flat buffers (optim.FusedAdopt: one sumsq + one update launch for the
     backbone) and, separately, + the EMA update (optim.FusedEMA; the reference trainer runs it every 10th step,
-    ema_pytorch's default).  Same plan, same inputs as the headline loop; lr tiny so that k steps leave the model alone."""
+    ema_pytorch's default).  Same plan, same inputs as the headline loop; lr tiny so that k steps leave the model alone.
+    The three loops (plain, + clip / ADOPT, + EMA) are timed the same way with the same k, so that the start-up of a short
+    timed loop (the host walks E2TTS.forward before the first launch) cancels in the differences."""
     from e2_tts_pytorch_amd.optim import FusedAdopt, FusedEMA
     opt = FusedAdopt(model, lr=1e-7, max_grad_norm=1.0)
     ema = FusedEMA(model, update_after_step=0, update_every=1)
 
-    def train_step(with_ema):
+    def train_step(with_opt, with_ema):
         out = net(mel, text=text, _noise=noise)
         out.loss.backward()
-        opt.step()
+        if with_opt:
+            opt.step()
         opt.zero_grad(set_to_none=True)
         if with_ema:
             ema.update()
 
     out = {}
-    for name, with_ema in (('ms_per_step_with_clip_adopt', False), ('ms_per_step_with_clip_adopt_ema', True)):
+    for name, with_opt, with_ema in (('ms_per_step_fwd_bwd_same_loop', False, False), ('ms_per_step_with_clip_adopt', True, False),
+                                     ('ms_per_step_with_clip_adopt_ema', True, True)):
         for _ in range(2):
-            train_step(with_ema)
+            train_step(with_opt, with_ema)
         torch.cuda.synchronize()
         t0 = time.perf_counter()
         for _ in range(k):
-            train_step(with_ema)
+            train_step(with_opt, with_ema)
         torch.cuda.synchronize()
         out[name] = (time.perf_counter() - t0) / k * 1e3
     out['ms_per_step_fwd_bwd'] = ms_plain
-    out['clip_adopt_ms'] = out['ms_per_step_with_clip_adopt'] - ms_plain
+    out['clip_adopt_ms'] = out['ms_per_step_with_clip_adopt'] - out['ms_per_step_fwd_bwd_same_loop']
     out['ema_update_ms'] = out['ms_per_step_with_clip_adopt_ema'] - out['ms_per_step_with_clip_adopt']
     out['steps'] = k
     out['note'] = ('fused clip + ADOPT (per-parameter steps, text-stream group skipped on text-dropped steps) and EMA over the flat fp32 '
-                   'buffers, trainer.py:270-279; the EMA update runs every 10th step in the reference configuration')
+                   'buffers, trainer.py:270-279; the EMA update runs every 10th step in the reference configuration; differences are '
+                   'taken between loops of the same length (a short timed loop carries the host walk of the first E2TTS.forward)')
     return out
 
 

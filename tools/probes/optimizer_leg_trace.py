@@ -69,7 +69,40 @@ if opt_idx:
     print('timeline around the first optimizer kernels (offset ms, duration us, name):')
     for r in rows[a:b]:
         print(f"  {(r['start_us'] - t_first) / 1e3:9.3f} {r['dur_us']:9.1f}  {r['name']}")
+# the same kernels with and without the optimizer at the end of every step: device time per kernel name over 3 steps each
+def trace_totals(fn, n=3):
+    for _ in range(3):
+        fn()
+    torch.cuda.synchronize()
+    with profile(activities=[ProfilerActivity.CUDA]) as pr:
+        for _ in range(n):
+            fn()
+        torch.cuda.synchronize()
+    tot, seq = {}, []
+    for e in pr.events():
+        if e.device_type == torch.autograd.DeviceType.CUDA:
+            d = e.time_range.end - e.time_range.start
+            tot[e.name[:60]] = tot.get(e.name[:60], 0.0) + d / n
+            seq.append((e.time_range.start, e.name[:60], d))
+    return tot, sorted(seq)
+
+def plain_step():
+    out = model(mel, text=text)
+    out.loss.backward()
+    opt.zero_grad(set_to_none=True)
+
+tp, _ = trace_totals(plain_step)
+tt, _ = trace_totals(train_step)
+names = sorted(set(tp) | set(tt), key=lambda k: -(tt.get(k, 0) - tp.get(k, 0)))
+print(f'device time per step (sum over kernels): plain {sum(tp.values()) / 1e3:.2f} ms, with optimizer {sum(tt.values()) / 1e3:.2f} ms')
+print('largest per-kernel differences (us per step: with optimizer - plain, plain, ratio):')
+diffs = []
+for k in names[:14] + names[-4:]:
+    a, b = tp.get(k, 0.0), tt.get(k, 0.0)
+    print(f'  {b - a:9.1f} {a:10.1f} {b / a if a else float("nan"):6.3f}  {k}')
+    diffs.append(dict(kernel=k, plain_us=a, with_optimizer_us=b))
 (ROOT / 'gpurun_out').mkdir(exist_ok=True)
-json.dump(dict(wall_ms_per_train_step=wall, host_ms_opt_step=sum(host) / len(host), span_ms=span / 1e3, busy_ms=busy / 1e3,
+json.dump(dict(per_kernel=diffs, plain_device_ms=sum(tp.values()) / 1e3, with_optimizer_device_ms=sum(tt.values()) / 1e3,
+               wall_ms_per_train_step=wall, host_ms_opt_step=sum(host) / len(host), span_ms=span / 1e3, busy_ms=busy / 1e3,
                largest_gaps=[dict(us=g, before=n, at_ms=off / 1e3) for g, n, off in gaps[:30]]),
           open(ROOT / 'gpurun_out' / 'optimizer_leg_trace.json', 'w'), indent=1)
