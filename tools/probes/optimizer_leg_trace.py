@@ -91,8 +91,31 @@ def plain_step():
     out.loss.backward()
     opt.zero_grad(set_to_none=True)
 
-tp, _ = trace_totals(plain_step)
-tt, _ = trace_totals(train_step)
+tp, seq_p = trace_totals(plain_step)
+tt, seq_t = trace_totals(train_step)
+
+
+def boundary(seq, label):
+    # union busy time, span per step, and the kernels around the boundary between the first and the second traced step
+    t0, cur, busy = seq[0][0], seq[0][0], 0.0
+    for s_, _, d in seq:
+        e_ = s_ + d
+        if s_ > cur:
+            busy += d
+        else:
+            busy += max(0.0, e_ - cur)
+        cur = max(cur, e_)
+    print(f'{label}: span of 3 steps {(cur - t0) / 1e3:.2f} ms = {(cur - t0) / 3e3:.2f} per step, device busy (union) {busy / 3e3:.2f} ms per step')
+    idx = [i for i, (_, n, _) in enumerate(seq) if 'stream_pack_fwd' in n]
+    if len(idx) >= 4:
+        i0 = idx[2]            # first stream_pack_fwd of the second step (audio; the text one follows)
+        print(f'  kernels around the start of the second step ({label}); offset ms, duration us, name')
+        for s_, n, d in seq[max(0, i0 - 40):i0 + 4]:
+            print(f'    {(s_ - t0) / 1e3:9.3f} {d:8.1f}  {n}')
+
+
+boundary(seq_p, 'plain loop')
+boundary(seq_t, 'with optimizer')
 names = sorted(set(tp) | set(tt), key=lambda k: -(tt.get(k, 0) - tp.get(k, 0)))
 print(f'device time per step (sum over kernels): plain {sum(tp.values()) / 1e3:.2f} ms, with optimizer {sum(tt.values()) / 1e3:.2f} ms')
 print('largest per-kernel differences (us per step: with optimizer - plain, plain, ratio):')
