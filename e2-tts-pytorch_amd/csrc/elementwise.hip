@@ -363,7 +363,8 @@ __global__ __launch_bounds__(256) void cast_transpose_batch_kernel(const float* 
 }
 
 // ------------------------------------------------------------------------------------------------ depthwise conv + SiLU
-// channels-last: x (B, N, C); block = 64 frames x 64 channels of one batch row; thread = 2 channels x 8 frames.
+// channels-last: x (B, N, C); forward block = 128 frames x 64 channels of one batch row, thread = 2 channels x 16 frames;
+// backward block = 64 frames x 64 channels per tile, several tiles per workgroup, thread = 2 channels x 8 frames.
 
 typedef float f32x2_ __attribute__((ext_vector_type(2)));
 constexpr int CTN = 64, CTC = 64;
@@ -378,13 +379,22 @@ struct ConvArgs {
     int defer_reduce;      // backward: leave the (dw, dbias) partials in ws, e2k_dwconv_bwd_reduce sums them later
 };
 
+// Forward: 128 frames x 64 channels per workgroup (the 30-row halo is 23 % of the tile), thread = 2 channels x 16 frames; the
+// 64 x KS weights and the frame mask go through LDS once per workgroup.  (Round 3; the first kernel used 64-frame tiles -- halo
+// 47 % -- and had every thread fetch its 2 x KS weights itself, 62 loads per thread = 5 x the tile's bytes through the L1, and the
+// mask byte of each of its frames from global memory: 31.4 -> 24.4 us at the cfg3 audio shape with a mask, 17.6 -> 15.4 us at the
+// text shape, profiles/r03_dwconv_fwd_ab.jsonl.  Still 2.1 TB/s of its algorithmic bytes: 154 VGPRs -> 3 workgroups per CU, and
+// the load / compute / store phases of a workgroup do not overlap.)
 template <int KS>
 __global__ __launch_bounds__(256) void dwconv_fwd_kernel(ConvArgs p) {
-    constexpr int PAD = KS / 2, ROWS = CTN + KS - 1;
+    constexpr int FR = 128, PAD = KS / 2, ROWS = FR + KS - 1;
     __shared__ __attribute__((aligned(16))) unsigned xt[ROWS][CTC / 2];
+    __shared__ __attribute__((aligned(16))) float wl[KS][CTC];
+    __shared__ float bl[CTC];
+    __shared__ unsigned char mk[FR];
     const int tid = threadIdx.x;
-    const int n0 = blockIdx.x * CTN, c0 = blockIdx.y * CTC, b = blockIdx.z;
-    {   // tile load: 16 bytes (8 channels) per item, all loads of a thread issued before any is consumed
+    const int n0 = blockIdx.x * FR, c0 = blockIdx.y * CTC, b = blockIdx.z;
+    {
         constexpr int ITEMS = ROWS * (CTC / 8), NIT = (ITEMS + 255) / 256;
         u32x4 v[NIT];
 #pragma unroll
@@ -393,9 +403,16 @@ __global__ __launch_bounds__(256) void dwconv_fwd_kernel(ConvArgs p) {
             const int j = i / (CTC / 8), c8 = (i % (CTC / 8)) * 8;
             const int n = n0 - PAD + j;
             const int nc = min(max(n, 0), p.N - 1);
-            const u32x4 raw = ld<u32x4>(p.x + ((long)b * p.N + nc) * p.C + c0 + c8);     // (c8 < CTC for any i)
-            const unsigned char mk = p.mask ? p.mask[(long)b * p.N + nc] : (unsigned char)1;
-            v[it] = (n >= 0 && n < p.N && mk != 0) ? raw : u32x4{0u, 0u, 0u, 0u};
+            const u32x4 raw = ld<u32x4>(p.x + ((long)b * p.N + nc) * p.C + c0 + c8);
+            const unsigned char m = p.mask ? p.mask[(long)b * p.N + nc] : (unsigned char)1;
+            v[it] = (n >= 0 && n < p.N && m != 0 && i < ITEMS) ? raw : u32x4{0u, 0u, 0u, 0u};
+        }
+        // weights of this channel tile: (64, KS) contiguous in global memory -> wl[k][c]
+        for (int i = tid; i < CTC * KS; i += 256) wl[i % KS][i / KS] = p.w[(long)c0 * KS + i];
+        if (tid < CTC) bl[tid] = p.bias[c0 + tid];
+        if (tid < FR) {
+            const int n = n0 + tid;
+            mk[tid] = (n < p.N && (p.mask == nullptr || p.mask[(long)b * p.N + n])) ? 1 : 0;
         }
 #pragma unroll
         for (int it = 0; it < NIT; ++it) {
@@ -403,37 +420,32 @@ __global__ __launch_bounds__(256) void dwconv_fwd_kernel(ConvArgs p) {
             if (i < ITEMS) st<u32x4>(&xt[i / (CTC / 8)][(i % (CTC / 8)) * 4], v[it]);
         }
     }
-    const int cp = tid & 31, fg = tid >> 5;
-    const int ch = c0 + cp * 2;
-    f32x2_ w[KS];          // (channel ch, channel ch + 1) pairs: one v_pk_fma_f32 per tap and frame
-#pragma unroll
-    for (int k = 0; k < KS; ++k) w[k] = f32x2_{p.w[(long)ch * KS + k], p.w[(long)(ch + 1) * KS + k]};
-    const f32x2_ bb = {p.bias[ch], p.bias[ch + 1]};
     __syncthreads();
-    f32x2_ a[8];
+    const int cp = tid & 31, fg = tid >> 5;
+    f32x2_ w[KS];
 #pragma unroll
-    for (int o = 0; o < 8; ++o) a[o] = bb;
+    for (int k = 0; k < KS; ++k) w[k] = *reinterpret_cast<const f32x2_*>(&wl[k][cp * 2]);
+    const f32x2_ bb = *reinterpret_cast<const f32x2_*>(&bl[cp * 2]);
+    f32x2_ a[16];
 #pragma unroll
-    for (int i = 0; i < 8 + KS - 1; ++i) {
-        const unsigned v = xt[fg * 8 + i][cp];
+    for (int o = 0; o < 16; ++o) a[o] = bb;
+#pragma unroll
+    for (int i = 0; i < 16 + KS - 1; ++i) {
+        const unsigned v = xt[fg * 16 + i][cp];
         const f32x2_ xx = {bflo(v), bfhi(v)};
 #pragma unroll
-        for (int o = 0; o < 8; ++o) {
+        for (int o = 0; o < 16; ++o) {
             const int k = i - o;
             if (k >= 0 && k < KS) a[o] = __builtin_elementwise_fma(w[k], xx, a[o]);
         }
     }
-    float a0[8], a1[8];
+    bf16_t* pre = p.pre + ((long)b * p.N + n0 + fg * 16) * p.C + c0 + cp * 2;
+    bf16_t* y = p.y + ((long)b * p.N + n0 + fg * 16) * p.C + c0 + cp * 2;
 #pragma unroll
-    for (int o = 0; o < 8; ++o) { a0[o] = a[o][0]; a1[o] = a[o][1]; }
-#pragma unroll
-    for (int o = 0; o < 8; ++o) {
-        const int n = n0 + fg * 8 + o;
-        if (n < p.N) {
-            const long off = ((long)b * p.N + n) * p.C + ch;
-            st<unsigned>(p.pre + off, pack2bf(a0[o], a1[o]));
-            const bool keep = p.mask == nullptr || p.mask[(long)b * p.N + n];
-            st<unsigned>(p.y + off, keep ? pack2bf(siluf_(a0[o]), siluf_(a1[o])) : 0u);
+    for (int o = 0; o < 16; ++o) {
+        if (n0 + fg * 16 + o < p.N) {
+            st<unsigned>(pre + (long)o * p.C, pack2bf(a[o][0], a[o][1]));
+            st<unsigned>(y + (long)o * p.C, mk[fg * 16 + o] ? pack2bf(siluf_(a[o][0]), siluf_(a[o][1])) : 0u);
         }
     }
 }
@@ -615,6 +627,7 @@ template <int KS> int launch_conv(ConvArgs a, bool bwd, hipStream_t st) {
                                    (const float*)a.ws, a.dw, a.dbias, a.B, a.C / CTC, (int)grid.x, KS);
         }
     } else {
+        grid.x = (a.N + 127) / 128;
         hipLaunchKernelGGL(dwconv_fwd_kernel<KS>, grid, block, 0, st, a);
     }
     return 0;
