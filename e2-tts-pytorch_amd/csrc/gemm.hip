@@ -15,6 +15,7 @@
 // (one barrier per K step).  MFMA operands are swapped (srcA = weight fragment, srcB = activation fragment) so
 // that a lane's 4 accumulator registers are 4 consecutive output columns -> 8-byte bf16 stores.
 #include <type_traits>
+#include <cstdlib>
 #include "e2k_device.h"
 #include "plan.h"
 #include <e2k_asm.h>
@@ -1613,10 +1614,15 @@ static int gemm_nt_bf16_impl(const void* A1, int64_t lda1, int K1, const void* A
                (!resid || ((ldr & 7) == 0 && ((uintptr_t)resid & 15) == 0));
     const bool glds = !(flags & E2K_GEMM_NO_GLDS) && (K1 % BK) == 0 && (K2 % BK) == 0;
     const int t256 = ((M + QBM - 1) / QBM) * ((N + QBN - 1) / QBN);
-    // default: shapes whose 256 x 256 tiles fill >= 7/8 of a round of the 256 workgroup slots (measured on MI355X: +10-22 %
-    // on those, profiles/r02_gemm_t256_first_hw_run.json; -10-15 % on half-filled ones such as 8448 x 1024 x 4096)
+    // default: shapes with at least 64 tiles of 256 x 256.  Timed ALONE the kernel pays only where its tiles fill >= 7/8 of the
+    // 256 workgroup slots (+10-22 % there, -10-15 % on half-filled shapes such as 8448 x 1024 x 4096,
+    // profiles/r02_gemm_t256_first_hw_run.json) and round 2 drew the line at 224 tiles; IN the step the CUs a half-filling launch
+    // leaves free are taken by the other launch lanes' kernels, and the big tile's better K loop wins: cfg3 step 88.9 -> 87.5 ms
+    // on one box, 95.5 -> 92.4 on another, the same for thresholds 132 / 66 / 33 / 1 (profiles/r03_t256_threshold_ab.jsonl).
+    // E2K_GEMM_T256_MIN overrides (A/B).
+    static const int t256_min = getenv("E2K_GEMM_T256_MIN") ? atoi(getenv("E2K_GEMM_T256_MIN")) : 64;
     const bool q256 = glds && !p.probe && !(flags & E2K_GEMM_NO_T256) &&
-                      ((flags & E2K_GEMM_T256) || (t256 >= 224 && (K1 + K2) >= 4 * BK));
+                      ((flags & E2K_GEMM_T256) || (t256 >= t256_min && (K1 + K2) >= 4 * BK));
     if (q256) {
         const int T = t256;
         p.full = T; p.split = 1; p.ws = ws;
