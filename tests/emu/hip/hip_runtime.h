@@ -19,6 +19,7 @@
 #include <cstdlib>
 #include <cstring>
 #include <functional>
+#include <condition_variable>
 #include <mutex>
 #include <thread>
 #include <vector>
@@ -240,6 +241,55 @@ inline void stack_put(char* s) {
     stack_pool().push_back(s);
 }
 
+// Helper threads live for the life of the process (a launch used to create and join up to 8 threads): `run(n, fn)` has n
+// helpers execute fn next to the caller and returns when all are done.  A block's `static thread_local` LDS arrays therefore
+// keep what the previous launch on that thread left in them -- as real LDS does; a kernel must not count on zeroed LDS.
+// (Processes are started with `spawn` in the tests, never forked after the pool exists.)
+struct HelperPool {
+    std::mutex m;
+    std::condition_variable cv_job, cv_done;
+    std::vector<std::thread> threads;
+    const std::function<void()>* fn = nullptr;
+    long epoch = 0;
+    int want = 0, pending = 0;
+    void ensure(int n) {
+        while ((int)threads.size() < n) {
+            const int idx = (int)threads.size();
+            threads.emplace_back([this, idx]() {
+                long seen = 0;
+                for (;;) {
+                    const std::function<void()>* f = nullptr;
+                    {
+                        std::unique_lock<std::mutex> g(m);
+                        cv_job.wait(g, [&] { return epoch != seen; });
+                        seen = epoch;
+                        if (idx < want) f = fn;
+                    }
+                    if (f) {
+                        (*f)();
+                        std::lock_guard<std::mutex> g(m);
+                        if (--pending == 0) cv_done.notify_all();
+                    }
+                }
+            });
+            threads.back().detach();
+        }
+    }
+    void run(int n, const std::function<void()>& f) {
+        {
+            std::unique_lock<std::mutex> g(m);
+            ensure(n);
+            fn = &f; want = n; pending = n; ++epoch;
+        }
+        cv_job.notify_all();
+        f();
+        std::unique_lock<std::mutex> g(m);
+        cv_done.wait(g, [&] { return pending == 0; });
+        want = 0;
+    }
+};
+inline HelperPool& helper_pool() { static HelperPool* p = new HelperPool; return *p; }      // (leaked on purpose: detached threads outlive statics)
+
 inline void launch(dim3 grid, dim3 block, const std::function<void()>& body) {
     long nblocks = (long)grid.x * grid.y * grid.z;
     int nthreads = block.x * block.y * block.z;
@@ -250,7 +300,7 @@ inline void launch(dim3 grid, dim3 block, const std::function<void()>& body) {
     if (hw < 1) hw = 1;
     long nworkers = std::min<long>(hw, nblocks);
     std::atomic<long> next{0};
-    auto worker = [&]() {
+    const std::function<void()> worker = [&]() {
         Block blk;
         blk.bdim = block;
         blk.gdim = grid;
@@ -269,9 +319,7 @@ inline void launch(dim3 grid, dim3 block, const std::function<void()>& body) {
     if (nworkers == 1) {
         worker();
     } else {
-        std::vector<std::thread> ts;
-        for (long i = 0; i < nworkers; ++i) ts.emplace_back(worker);
-        for (auto& t : ts) t.join();
+        helper_pool().run((int)nworkers - 1, worker);      // the calling thread is the first worker
     }
 }
 
