@@ -625,9 +625,13 @@ class Transformer(Module):
             self._recast()
             self._shadow_key = key
 
-    def _recast(self):
+    def _recast(self, transposes=True):
         """fp32 master parameters -> bf16 shadows (+ transposed shadows for the dgrad GEMMs)"""
         ops.cast_bf16(self._flat, self._shadow)
+        if transposes:
+            self._recast_transposes()
+
+    def _recast_transposes(self):
         if self._tdesc is not None:
             ops.cast_transpose_batch(self._flat, self._shadowT, self._tdesc, self._tblocks)
 
@@ -867,9 +871,12 @@ class Transformer(Module):
             ops.begin_recording(st.meta_f)
             try:
                 if st.need_grad:
-                    self._recast()                  # training: the parameters change every step
+                    # training: the parameters change every step.  The transposed shadows are read by the backward only: they
+                    # are refreshed inside the forward on the WGRAD lane, which has nothing else to do there (_run_forward)
+                    self._recast(transposes=not _RECAST_T_ON_LANE)
                 with ops.pinned_stream(dev):
-                    run = self._run_forward(st.x, st.cond, st.text, st.mask, st.need_grad, seed_dev=st.seed, rot=rot)
+                    run = self._run_forward(st.x, st.cond, st.text, st.mask, st.need_grad, seed_dev=st.seed, rot=rot,
+                                            recast_T=st.need_grad and _RECAST_T_ON_LANE)
                 st.fwd = ops.end_recording()
             except BaseException:
                 ops.abort_recording()
@@ -934,7 +941,7 @@ class Transformer(Module):
 
     # ------------------------------------------------------------------ forward schedule
 
-    def _run_forward(self, x_in, cond, text_embed, mask, want_tape, seed_dev=None, rot=None):
+    def _run_forward(self, x_in, cond, text_embed, mask, want_tape, seed_dev=None, rot=None, recast_T=False):
         """the whole forward as a sequence of e2k calls (nothing else touches the device in here: a launch plan replays
         exactly the recorded calls, so a tensor-library op in between would silently be skipped on replay)"""
         dev = x_in.device
@@ -989,6 +996,12 @@ class Transformer(Module):
         # i - 1 left it, so they run on the TEXT lane next to the audio branches of layer i - 1
         L = run.lanes = ops.Lanes(dev, self._lane_streams(dev) if exists(st) else [], self._lane_mask)
         ev_cross = L.record(ops.MAIN)
+        if recast_T:
+            # (the lane starts after everything the caller's stream had queued before this forward -- the optimizer's update of
+            #  the fp32 parameters included; the forward's final join makes MAIN, hence the backward, wait for it)
+            L.wait(ops.WGRAD, ev_cross)
+            with L.lane(ops.WGRAD):
+                self._recast_transposes()
         # what MAIN hands to the TEXT lane (the packed text stream, then each cross projection's output) is allocated on
         # MAIN: it must stay referenced until MAIN has waited for the TEXT lane again, or the next MAIN allocation could
         # land on it while the TEXT lane still reads it
@@ -1025,6 +1038,8 @@ class Transformer(Module):
         y, rn = ops.rmsnorm_fwd(xsum, gfin, 0., B * T)
         run.tail = (xsum, rn)
         run.out = ops.cast_f32(y).view(B, T, D)
+        if recast_T:
+            L.fence(ops.WGRAD, ops.MAIN)        # the backward (MAIN and, through it, every lane) starts after the transposed shadows are written
         return run
 
     # -- stream helpers --------------------------------------------------------
@@ -1626,6 +1641,9 @@ _WGRAD_GROUP = _os.environ.get('E2K_WGRAD_GROUP', '1') != '0'
 _WGRAD_MIN_ROWS = int(_os.environ.get('E2K_WGRAD_MIN_ROWS', '1024'))
 # hyper-connection / depthwise-conv parameter-gradient reductions on the WGRAD lane instead of on the chain (E2K_DEFER_REDUCES=0: A/B)
 _DEFER_REDUCES = _os.environ.get('E2K_DEFER_REDUCES', '1') != '0'
+# recorded training plans refresh the transposed bf16 weight shadows (dgrad operands) on the WGRAD lane during the forward instead
+# of at its start on the chain (E2K_RECAST_T_ON_LANE=0: A/B)
+_RECAST_T_ON_LANE = _os.environ.get('E2K_RECAST_T_ON_LANE', '1') != '0'
 
 _VIEW_OPS = {'view', '_unsafe_view', 'as_strided', 'slice', 'select', 'expand', 't', 'transpose', 'permute', 'unsqueeze', 'squeeze',
              'detach', 'alias', '_reshape_alias', 'reshape', 'split', 'split_with_sizes', 'unbind', 'narrow', 'lift_fresh', 'unfold',
