@@ -779,13 +779,9 @@ class Transformer(Module):
         return ss[1]
 
     def _drop_plans(self):
-        lib = None
         for st in self._plans.values():
             if isinstance(st, NS):
-                lib = lib or ops.lib()
-                for h in (st.fwd, st.bwd):
-                    if h:
-                        lib.e2k_plan_free(h)
+                st.free_handles()
         self._plans = {}
 
     def _pool_ctx(self, dev, st):
@@ -795,8 +791,8 @@ class Transformer(Module):
         if dev.type != 'cuda':
             return contextlib.nullcontext()
         if st.pool is None:
-            st.pool = torch.cuda.MemPool()
-        return torch.cuda.use_mem_pool(st.pool, device=dev)
+            st.pool = _PlanPool()
+        return st.pool.use(dev)
 
     def _plan_forward(self, x, cond, text_embed, mask, need_grad, rot):
         p_drop = self.dropout if self.training else 0.
@@ -815,10 +811,7 @@ class Transformer(Module):
                 old = min(live, key=lambda k: self._plans[k].used)
                 if self._plans[old].outstanding:
                     return None
-                ost = self._plans.pop(old)
-                for h in (ost.fwd, ost.bwd):
-                    if h:
-                        ops.lib().e2k_plan_free(h)
+                self._plans.pop(old).free_handles()
             st = self._plan_new(key, x, cond, text_embed, mask, need_grad, p_drop)
             self._plans[key] = st
         elif st.outstanding or not self._is_packed():
@@ -839,7 +832,7 @@ class Transformer(Module):
 
     def _plan_new(self, key, x, cond, text_embed, mask, need_grad, p_drop):
         dev = x.device
-        st = NS(key=key, need_grad=need_grad, fwd=None, bwd=None, segs=None, outstanding=False, used=0, keep=[], meta_f=[], meta_b=[], pool=None)
+        st = _PlanState(key=key, need_grad=need_grad, fwd=None, bwd=None, segs=None, outstanding=False, used=0, keep=[], meta_f=[], meta_b=[], pool=None)
         with self._pool_ctx(dev, st):
             st.x = torch.empty(x.shape, dtype=f32, device=dev)
             st.cond = torch.empty(cond.shape, dtype=f32, device=dev) if exists(cond) else None
@@ -1558,6 +1551,68 @@ def _numel(shape):
     for s in shape:
         n *= s
     return n
+
+
+class _PlanState(NS):
+    """everything one recorded plan owns: static input / output buffers, the tape of its forward, its private memory pool and
+    the handles of the recorded launch sequences in the C++ registry (csrc/plan.hip), which are released with it"""
+
+    def free_handles(self):
+        for k in ('fwd', 'bwd'):
+            h = self.__dict__.get(k)
+            if h:
+                self.__dict__[k] = None
+                try:
+                    ops.lib().e2k_plan_free(h)
+                except Exception:
+                    pass
+
+    def __del__(self):
+        self.free_handles()
+
+
+class _PlanPool:
+    """The private caching-allocator pool of one recorded plan -- and the rule about when it may die.
+
+    `torch.cuda.MemPool.__del__` empties the pool's cache, and the allocator asserts on the way that no `use_mem_pool` /
+    graph-capture context is active anywhere in the process (`captures_underway.empty()`, c10/hip/HIPCachingAllocator.cpp).
+    The assertion fires inside a C++ destructor, so it does not raise: it ends the process with SIGABRT.  A plan's state
+    (and with it its pool) becomes garbage whenever its module does, and Python's cycle collector runs whenever it likes --
+    also in the middle of ANOTHER plan's recording, which is a `use_mem_pool` context.  That is what killed the round-3 GPU
+    test run (an abort inside a recorded backward pass, on one box in four: whether the collector runs inside that window
+    depends on the allocation count of everything the process did before).  So a plan pool is never destroyed where it
+    dies: its finaliser parks the MemPool in a process-wide list, which is emptied at points where no pool context of this
+    package is active (`reap`, called when a recording context is left and before a new one is entered)."""
+
+    _parked = []            # MemPools whose plan is gone, waiting for a safe point
+    _active = 0             # use_mem_pool contexts of this package that are open right now (any thread)
+
+    def __init__(self):
+        self.pool = torch.cuda.MemPool()
+
+    def __del__(self):
+        try:
+            _PlanPool._parked.append(self.pool)
+        except Exception:       # interpreter shutdown: the process is going away anyway
+            pass
+
+    @contextlib.contextmanager
+    def use(self, dev):
+        _PlanPool.reap()
+        _PlanPool._active += 1
+        try:
+            with torch.cuda.use_mem_pool(self.pool, device=dev):
+                yield
+        finally:
+            _PlanPool._active -= 1
+            _PlanPool.reap()
+
+    @staticmethod
+    def reap():
+        """destroy the parked pools if no pool context is open (their segments go back to the device)"""
+        if _PlanPool._active == 0 and _PlanPool._parked and not torch.cuda.is_current_stream_capturing():
+            dead, _PlanPool._parked = _PlanPool._parked, []
+            del dead
 
 
 class _BackboneFn(torch.autograd.Function):

@@ -10,10 +10,20 @@ def install_lib(path, host_pointers):
     install(path, host_pointers)
 
 
+# the launch lanes + the gradient-exchange stream + RCCL's own streams need more than the default 4 hardware queues (DESIGN.md
+# section 4.1 / 6); bench.py sets the same before its first device call, so tests and bench run one queue mapping
+os.environ.setdefault('GPU_MAX_HW_QUEUES', '8')
+
 ROOT = Path(__file__).resolve().parent.parent
 for p in (ROOT / 'e2-tts-pytorch_amd', ROOT, ROOT / 'tests'):
     if str(p) not in sys.path:
         sys.path.insert(0, str(p))
+
+
+def gpu_shapes(dev):
+    """the shapes a test uses on the MI355X; E2K_EMU_GPU_SHAPES=1 makes the (~1000x slower) host model run them too --
+    used with tests/emu/guardmalloc.c to look for out-of-bounds accesses at exactly the sizes the GPU run sees"""
+    return dev == 'cuda' or os.environ.get('E2K_EMU_GPU_SHAPES') == '1'
 
 
 def pytest_configure(config):

@@ -4,6 +4,8 @@ import random
 import pytest
 import torch
 
+from conftest import gpu_shapes
+
 from oracle import e2tts_oracle as O
 
 bf16 = torch.bfloat16
@@ -143,7 +145,7 @@ def test_persistent_grads(dev):
     from e2_tts_pytorch_amd import Transformer
     random.seed(0)
     torch.manual_seed(0)
-    mod = Transformer(dim=256, depth=2, heads=2, dropout=0., max_seq_len=64, num_registers=32 if dev == 'cuda' else 8)      # (host model: fewer register tokens, same schedule)
+    mod = Transformer(dim=256, depth=2, heads=2, dropout=0., max_seq_len=64, num_registers=32 if gpu_shapes(dev) else 8)      # (host model: fewer register tokens, same schedule)
     randomize(mod)
     mod = mod.to(dev)
     B, T = 2, 24
@@ -252,9 +254,9 @@ def test_launch_lanes_match_single_stream(dev):
     from e2_tts_pytorch_amd import Transformer
     random.seed(0)
     torch.manual_seed(0)
-    big = dev == 'cuda'
+    big = gpu_shapes(dev)
     dim, depth, B, T = (512, 6, 4, 200) if big else (256, 2, 1, 16)
-    mod = Transformer(dim=dim, depth=depth, heads=dim // 64, dropout=0., max_seq_len=T, num_registers=32 if dev == 'cuda' else 8)
+    mod = Transformer(dim=dim, depth=depth, heads=dim // 64, dropout=0., max_seq_len=T, num_registers=32 if gpu_shapes(dev) else 8)
     randomize(mod)
     mod = mod.to(dev)
     R = torch.randn(B, T, dim).to(dev)
@@ -319,9 +321,9 @@ def test_geglu_epilogue_in_the_backbone(dev):
     from e2_tts_pytorch_amd import Transformer, ops
     random.seed(0)
     torch.manual_seed(0)
-    big = dev == 'cuda'
+    big = gpu_shapes(dev)
     dim, depth, B, T = (512, 4, 4, 200) if big else (256, 2, 1, 24)
-    mod = Transformer(dim=dim, depth=depth, heads=dim // 64, dropout=0.1, max_seq_len=T, num_registers=32 if dev == 'cuda' else 8)
+    mod = Transformer(dim=dim, depth=depth, heads=dim // 64, dropout=0.1, max_seq_len=T, num_registers=32 if gpu_shapes(dev) else 8)
     randomize(mod)
     mod = mod.to(dev)
     mod.train()
@@ -386,8 +388,8 @@ def test_plan_replay_matches_eager(dev):
     from e2_tts_pytorch_amd import Transformer
     random.seed(0)
     torch.manual_seed(0)
-    depth, T = (4, 40) if dev == 'cuda' else (2, 24)          # (the host model is ~1000x slower than the GPU: same schedule, fewer layers / frames)
-    mod = Transformer(dim=256, depth=depth, heads=2, dropout=0., max_seq_len=64, num_registers=32 if dev == 'cuda' else 8)
+    depth, T = (4, 40) if gpu_shapes(dev) else (2, 24)          # (the host model is ~1000x slower than the GPU: same schedule, fewer layers / frames)
+    mod = Transformer(dim=256, depth=depth, heads=2, dropout=0., max_seq_len=64, num_registers=32 if gpu_shapes(dev) else 8)
     randomize(mod)
     mod = mod.to(dev)
     B = 2
@@ -464,9 +466,9 @@ def test_plan_replay_with_the_default_off_switches(dev):
     from e2_tts_pytorch_amd import Transformer
     random.seed(0)
     torch.manual_seed(0)
-    T = 24 if dev == 'cuda' else 12
+    T = 24 if gpu_shapes(dev) else 12
     mod = Transformer(dim=256, depth=2, heads=2, dropout=0., max_seq_len=64, has_freq_axis=True, freq_heads=2, attn_laser=True,
-                      attn_fourier_embed_input=True, num_registers=32 if dev == 'cuda' else 8)
+                      attn_fourier_embed_input=True, num_registers=32 if gpu_shapes(dev) else 8)
     randomize(mod)
     mod = mod.to(dev)
     B = 2
@@ -492,6 +494,72 @@ def test_plan_replay_with_the_default_off_switches(dev):
         assert torch.equal(o1, o0) and torch.equal(dx1, dx0) and torch.equal(dt1, dt0)
         for n in g0:
             assert rel2(g1[n], g0[n]) < 2e-3 or float(g0[n].norm()) < 1e-6, n
+
+
+@pytest.mark.gpu
+def test_plan_pools_survive_the_collector_inside_a_recording():
+    """GPUTEST_r03 died here: a dead module's plan is cyclic garbage, its private torch.cuda.MemPool is destroyed whenever the
+    cycle collector runs, and a MemPool destroyed while ANOTHER use_mem_pool context is open (= inside any plan recording)
+    trips `captures_underway.empty()` in the caching allocator's destructor path -> std::terminate -> SIGABRT.  Children of
+    tools/probes/mempool_dtor_abort.py: with the collector FORCED to run inside the next module's recording the package must
+    survive (backbone._PlanPool parks the pool until no pool context is open).  In a child process: a regression would kill it,
+    not the test run."""
+    import importlib.util
+    from pathlib import Path
+    path = Path(__file__).resolve().parent.parent / 'tools' / 'probes' / 'mempool_dtor_abort.py'
+    spec = importlib.util.spec_from_file_location('mempool_dtor_abort', path)
+    probe = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(probe)
+    args = dict(pkg=str(probe.ROOT / 'e2-tts-pytorch_amd'), root=str(probe.ROOT))
+    now = probe.run(probe.PRODUCT % dict(args, old=False))
+    assert now['rc'] == 0 and 'survived' in now['stdout'], now
+
+
+@pytest.mark.gpu
+def test_plan_stress_every_switch_combination():
+    """plan record + 20 replays on a FRESH module for each of the 8 combinations of has_freq_axis / attn_laser /
+    attn_fourier_embed_input, garbage of the previous modules (their plans, pools, side streams) left to the collector:
+    every replay reproduces the eager schedule's output and input gradients bit for bit"""
+    import gc
+    import itertools
+    from e2_tts_pytorch_amd import Transformer
+    dev, T, B = 'cuda', 24, 2
+    for k, (fa, laser, fourier) in enumerate(itertools.product((False, True), repeat=3)):
+        random.seed(k)
+        torch.manual_seed(k)
+        mod = Transformer(dim=256, depth=2, heads=2, dropout=0., max_seq_len=64, has_freq_axis=fa, freq_heads=2, attn_laser=laser,
+                          attn_fourier_embed_input=fourier)
+        randomize(mod, seed=k)
+        mod = mod.to(dev)
+        F = 3 if fa else 1
+
+        def step(seed):
+            mod.zero_grad(set_to_none=True)
+            g = torch.Generator().manual_seed(seed)
+            shape = (B, F, T, 256) if fa else (B, T, 256)
+            x = torch.randn(*shape, generator=g).to(dev).requires_grad_(True)
+            t = torch.rand(B, generator=g).to(dev)
+            txt = torch.randn(B, T, 128, generator=g).to(dev).requires_grad_(True)
+            mask = (torch.arange(T)[None] < torch.tensor([T, T - 5])[:, None]).to(dev)
+            R = torch.randn(*shape, generator=g).to(dev)
+            out = mod(x, times=t, mask=mask, text_embed=txt)
+            (out * R).sum().backward()
+            return out.detach().clone(), x.grad.clone(), txt.grad.clone()
+
+        mod.enable_plans(False)
+        ref = step(3)
+        mod.enable_plans(True)
+        step(1), step(2)                                   # first sighting, recording
+        for it in range(20):
+            got = step(3)
+            assert all(torch.equal(a, b) for a, b in zip(got, ref)), (fa, laser, fourier, it)
+            if it == 10:
+                gc.collect()
+        assert len([v for v in mod._plans.values() if not isinstance(v, str)]) == 1
+        mod.__dict__['_me'] = mod                          # cyclic garbage, like a module held by a trainer object that went away
+        del mod
+    gc.collect()
+    torch.cuda.synchronize()
 
 
 def test_plan_recording_rejects_tensor_library_ops(dev):
@@ -606,7 +674,7 @@ def test_backbone_other_widths(dev, dim):
     mod = Transformer(**kw)
     mod.load_state_dict(ref.state_dict(), strict=True)
     mod = mod.to(dev)
-    B, T = (2, 12) if dev == 'cuda' else (1, 8)
+    B, T = (2, 12) if gpu_shapes(dev) else (1, 8)
     x, t, txt = torch.randn(B, T, dim), torch.rand(B), torch.randn(B, T, dim // 2)
     xr, xk = x.clone().requires_grad_(True), x.clone().to(dev).requires_grad_(True)
     out_r = ref(xr, times=t, text_embed=txt)

@@ -5,6 +5,8 @@ import random
 import pytest
 import torch
 
+from conftest import gpu_shapes
+
 from oracle import e2tts_oracle as O
 
 from test_backbone import randomize
@@ -317,7 +319,7 @@ def test_sample(dev):
 def test_sample_with_frequency_tokens(dev):
     """E2TTS(num_freq_tokens=2).sample against the oracle: the frequency axis through the classifier-free-guidance pair of
     forwards (text stream on and dropped) and the ODE steps"""
-    kw = dict(dim=256, depth=2, heads=4, dropout=0., num_registers=32 if dev == 'cuda' else 8)
+    kw = dict(dim=256, depth=2, heads=4, dropout=0., num_registers=32 if gpu_shapes(dev) else 8)
     ref, model = _pair(kw, seed=6, num_freq_tokens=2)
     model = model.to(dev)
     cond = torch.randn(1, 5, 100)
@@ -331,7 +333,7 @@ def test_sample_with_frequency_tokens(dev):
 @pytest.mark.parametrize('method', ['euler', 'rk4'])
 def test_sample_other_fixed_grid_solvers(dev, method):
     """odeint_kwargs method 'euler' / 'rk4' (torchdiffeq's fixed-grid solvers) against the oracle restatement"""
-    kw = dict(dim=256, depth=2, heads=4, dropout=0., num_registers=32 if dev == 'cuda' else 8)
+    kw = dict(dim=256, depth=2, heads=4, dropout=0., num_registers=32 if gpu_shapes(dev) else 8)
     ref, model = _pair(kw, seed=4, odeint_kwargs=dict(method=method))
     model = model.to(dev)
     cond = torch.randn(1, 5, 100)
@@ -347,7 +349,7 @@ def test_sample_adaptive_dopri5(dev):
     (e2_tts.py:1122-1126,1421): the adaptive solution agrees with a fine fixed-grid midpoint integration of the SAME model
     (the HIP path's own vector field), tighter tolerance = closer"""
     from e2_tts_pytorch_amd import E2TTS
-    kw = dict(dim=256, depth=2, heads=4, dropout=0., num_registers=32 if dev == 'cuda' else 8)
+    kw = dict(dim=256, depth=2, heads=4, dropout=0., num_registers=32 if gpu_shapes(dev) else 8)
     random.seed(5)
     torch.manual_seed(5)
     model = E2TTS(transformer=dict(**kw), use_vocos=False, cond_drop_prob=0.)

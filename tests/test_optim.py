@@ -2,6 +2,8 @@
 import pytest
 import torch
 
+from conftest import gpu_shapes
+
 from oracle import optim_oracle as O
 
 
@@ -60,7 +62,7 @@ def test_fused_adopt_on_model(dev, persist):
     import random
     random.seed(0)
     torch.manual_seed(0)
-    model = E2TTS(transformer=dict(dim=256, depth=2, heads=4, dropout=0., num_registers=32 if dev == 'cuda' else 8), use_vocos=False, cond_drop_prob=0.).to(dev)
+    model = E2TTS(transformer=dict(dim=256, depth=2, heads=4, dropout=0., num_registers=32 if gpu_shapes(dev) else 8), use_vocos=False, cond_drop_prob=0.).to(dev)
     mel = torch.randn(2, 24, 100, device=dev)
     if persist:
         model.transformer.enable_persistent_grads()
@@ -133,7 +135,7 @@ def test_adopt_steps_are_per_parameter_and_text_is_skipped(dev, persist):
     import random
     random.seed(0)
     torch.manual_seed(0)
-    model = E2TTS(transformer=dict(dim=256, depth=2, heads=4, dropout=0., num_registers=32 if dev == 'cuda' else 8), use_vocos=False, cond_drop_prob=0.).to(dev)
+    model = E2TTS(transformer=dict(dim=256, depth=2, heads=4, dropout=0., num_registers=32 if gpu_shapes(dev) else 8), use_vocos=False, cond_drop_prob=0.).to(dev)
     if persist:
         model.transformer.enable_persistent_grads()
     opt = FusedAdopt(model, lr=1e-3, max_grad_norm=1.0)
@@ -182,7 +184,7 @@ def test_layout_holes_stay_zero(dev):
     import random
     random.seed(0)
     torch.manual_seed(0)
-    model = E2TTS(transformer=dict(dim=256, depth=2, heads=4, dropout=0., num_registers=32 if dev == 'cuda' else 8), use_vocos=False, cond_drop_prob=0.).to(dev)
+    model = E2TTS(transformer=dict(dim=256, depth=2, heads=4, dropout=0., num_registers=32 if gpu_shapes(dev) else 8), use_vocos=False, cond_drop_prob=0.).to(dev)
     with torch.no_grad():           # zero-init gates would hide the time-conditioning gradients
         for n, p in model.named_parameters():
             if 'to_gamma' in n:
@@ -211,7 +213,7 @@ def test_training_loop_reduces_loss(dev):
     import random
     random.seed(0)
     torch.manual_seed(0)
-    model = E2TTS(transformer=dict(dim=256, depth=2, heads=4, dropout=0., num_registers=32 if dev == 'cuda' else 8), use_vocos=False, cond_drop_prob=0.).to(dev)
+    model = E2TTS(transformer=dict(dim=256, depth=2, heads=4, dropout=0., num_registers=32 if gpu_shapes(dev) else 8), use_vocos=False, cond_drop_prob=0.).to(dev)
     B, T = 2, 16
     mel = torch.randn(B, T, 100, device=dev)
     noise = dict(x0=torch.randn(B, T, 100, device=dev), times=torch.tensor([0.3, 0.7], device=dev),
@@ -242,7 +244,7 @@ def test_checkpoint_round_trip_and_format(dev, tmp_path):
     def make():
         random.seed(0)
         torch.manual_seed(0)
-        model = E2TTS(transformer=dict(dim=256, depth=2, heads=4, dropout=0., num_registers=32 if dev == 'cuda' else 8), use_vocos=False, cond_drop_prob=0.).to(dev)
+        model = E2TTS(transformer=dict(dim=256, depth=2, heads=4, dropout=0., num_registers=32 if gpu_shapes(dev) else 8), use_vocos=False, cond_drop_prob=0.).to(dev)
         return model, FusedAdopt(model, lr=1e-3, max_grad_norm=1.0), FusedEMA(model, update_after_step=0, update_every=1)
 
     def set_grads(model, seed):                # fixed gradients: the optimizer is then deterministic
