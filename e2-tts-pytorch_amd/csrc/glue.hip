@@ -302,7 +302,7 @@ __global__ __launch_bounds__(256) void char_embed_fwd_kernel(const long* tok, co
         const long bn = i / dv;
         const int c = (int)(i - bn * dv) * 4, n = (int)(bn % T), b = (int)(bn / T);
         long idx = n < nt ? tok[(long)b * nt + n] + 1 : 0;
-        idx = idx < 0 ? 0 : (idx >= V ? V - 1 : idx);               // (nn.Embedding raises on out-of-range ids: the host checks, this only keeps the read in bounds)
+        idx = idx < 0 ? 0 : (idx >= V ? V - 1 : idx);               // (nn.Embedding raises on out-of-range ids: _CharEmbedFn checks host-side token tensors, device ones under E2K_CHECK_TOKEN_IDS=1; this only keeps the read in bounds)
         st<f32x4>(out + bn * D + c, ld<f32x4>(W + idx * D + c));
     }
 }

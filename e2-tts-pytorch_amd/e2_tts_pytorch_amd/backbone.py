@@ -377,7 +377,8 @@ class Transformer(Module):
 
     # runtime state (device buffers, caches, recorded plans): never part of the module's identity -- a deep copy (the
     # trainer's EMA, trainer.py:170) starts without it and rebuilds its own on first use
-    _RUNTIME = ('_flat', '_shadow', '_shadowT', '_shadow_key', '_tdesc', '_vcache', '_rot_cache', '_plans', '_pg', '_no_pgrads', '_lane_ss')
+    _RUNTIME = ('_flat', '_shadow', '_shadowT', '_shadow_key', '_tdesc', '_vcache', '_rot_cache', '_plans', '_pg', '_no_pgrads', '_lane_ss',
+                '_text_ids', '_text_live_handle')
 
     def _reset_runtime(self):
         self._flat = None
@@ -452,6 +453,7 @@ class Transformer(Module):
         return NS(offs=[lay.add(p) for p in hc.param_list()], shapes=[tuple(p.shape) for p in hc.param_list()], dim=dim)
 
     def _build_layout(self):
+        self.__dict__.pop('_text_ids', None)
         lay = _Layout()
         D, Dt, L = self.dim, self.dim_text, self.depth
         g = NS()
@@ -701,6 +703,7 @@ class Transformer(Module):
             or any(p.requires_grad for p, _ in self._layout.slots))
         dev = x.device
         rot = self._rot_table(T + self.num_registers, dev)
+        self._text_live_handle = self._begin_text_live(exists(text_embed), dev) if need_grad else None
         if self._plans_on and (x.is_cuda or ops.host_ok()):
             out = self._plan_forward(x, cond, text_embed, mask, need_grad, rot)
             if exists(out):
@@ -710,6 +713,42 @@ class Transformer(Module):
             return _BackboneFn.apply(self, x, cond, text_embed, mask, rot, *self._params_in_order())
         with ops.pinned_stream(dev):
             return self._run_forward(x, cond, text_embed, mask, False, rot=rot).out
+
+    # -- did this pass's text stream run on ANY data-parallel rank?  (ddp._GradSync.begin_text_live) --------------
+    def _sync_target(self):
+        sync = self._grad_sync
+        return getattr(sync, '__self__', sync) if exists(sync) else None
+
+    def _begin_text_live(self, has_text, dev):
+        tgt = self._sync_target()
+        begin = getattr(tgt, 'begin_text_live', None)
+        return begin(has_text, dev) if begin is not None else bool(has_text)
+
+    def _end_text_live(self, handle, has_text):
+        """-> the text stream's parameters received a gradient in this backward pass (on some rank); also ORed into
+        `_text_grad_live`, which the fused optimizer reads and resets once per step"""
+        live = bool(has_text)
+        if handle is not None and not isinstance(handle, bool):
+            live = self._sync_target().end_text_live(handle)
+        elif isinstance(handle, bool):
+            live = handle
+        self._text_grad_live = bool(getattr(self, '_text_grad_live', None)) or live
+        return live
+
+    def _param_grads(self, gflat, live):
+        """gradient views handed to autograd.  The text stream's parameters get exact ZEROS, not None, on a pass whose text
+        stream ran on no rank: the whole backbone is one autograd node, so a stock DistributedDataParallel that manages these
+        parameters (no `enable_overlap_under_ddp`) waits for a gradient hook of every one of them.  That such a step must not
+        update them -- the reference leaves `p.grad` None and its optimizer skips the parameter, trainer.py:275 -- is carried
+        by `_text_grad_live`, which optim.FusedAdopt honours on every gradient path."""
+        return [gflat[off:off + p.numel()].view(p.shape) if p.requires_grad else None for p, off in self._layout.slots]
+
+    def _text_param_ids(self):
+        ids = self.__dict__.get('_text_ids')
+        if ids is None:
+            rng = self.text_param_ranges()
+            ids = self.__dict__['_text_ids'] = {id(p) for p, off in self._layout.slots if any(a <= off < b for a, b in rng)}
+        return ids
 
     def _time_cond(self, times):
         mlp = self.time_cond_mlp
@@ -881,7 +920,7 @@ class Transformer(Module):
         dev = st.x.device
         lib = ops.lib()
         sync = self._grad_sync
-        self._text_grad_live = getattr(self, '_text_grad_live', False) or st.key[1]      # (key[1]: the signature has a text stream)
+        live = self._end_text_live(st.text_live, st.key[1])      # (key[1]: the signature has a text stream)
         self._sync_lanes(st.lane_ss)
         if exists(st.bwd):
             for first, count, slab in st.segs:
@@ -921,8 +960,7 @@ class Transformer(Module):
         # default: hand the gradients to autograd (AccumulateGrad, DDP hooks, accumulation over several backward passes
         # all behave as usual).  The plan's gradient buffer is rewritten by the next replay, hence the copy (one read +
         # write of the gradients, ~1 ms at dim 1024 / depth 24); enable_persistent_grads() removes it.
-        gflat = st.gflat.clone()
-        return [gflat[off:off + p.numel()].view(p.shape) if p.requires_grad else None for p, off in self._layout.slots]
+        return self._param_grads(st.gflat.clone(), live)
 
     def plan_profile(self):
         """HIP-event time of every recorded launch of the most recently used plan: list of dict(name, ms, flops, phase)"""
@@ -1186,7 +1224,7 @@ class Transformer(Module):
     def _run_backward(self, run, dout):
         """eager backward: drive the schedule, hand finished gradient slabs to the data-parallel hook"""
         gen = self._backward_gen(run, dout, self._persist_grads)
-        self._text_grad_live = getattr(self, '_text_grad_live', False) or run.has_text
+        live = self._end_text_live(run.text_live, run.has_text)
         self._sync_lanes(self._lane_streams(dout.device) if run.lanes.on else [])
         while True:
             try:
@@ -1203,7 +1241,7 @@ class Transformer(Module):
             self._attach_grads()
             pgrads = self._no_pgrads
         else:
-            pgrads = [gflat[off:off + p.numel()].view(p.shape) if p.requires_grad else None for p, off in self._layout.slots]
+            pgrads = self._param_grads(gflat, live)
         return dxs, dcond, dtext, pgrads
 
     # persistent gradients -------------------------------------------------------
@@ -1623,6 +1661,7 @@ class _BackboneFn(torch.autograd.Function):
         with ops.pinned_stream(x_in.device):
             run = module._run_forward(x_in.detach(), cond.detach() if exists(cond) else None,
                                       text_embed.detach() if exists(text_embed) else None, mask, True, rot=rot)
+        run.text_live = module.__dict__.pop('_text_live_handle', None)
         ctx.run, ctx.module = run, module
         ctx.has_cond, ctx.has_text = exists(cond), exists(text_embed)
         ctx.x_dtype = x_in.dtype
@@ -1646,6 +1685,7 @@ class _PlanFn(torch.autograd.Function):
     def forward(ctx, module, st, rot, x_in, cond, text_embed, mask, *params):
         module._plan_inputs(st, x_in, cond, text_embed, mask)
         module._plan_run_forward(st, rot)
+        st.text_live = module.__dict__.pop('_text_live_handle', None)
         st.outstanding = True
         ctx.module, ctx.st = module, st
         ctx.has_cond, ctx.has_text = exists(cond), exists(text_embed)

@@ -93,6 +93,41 @@ class _GradSync:
         else:
             run()
 
+    # Which parameters received a gradient is a GLOBAL fact under data parallelism.  The classifier-free-guidance coin that
+    # drops the text stream (e2_tts.py:1261-1262) is flipped per rank; the reference's DistributedDataParallel
+    # (find_unused_parameters=True, trainer.py:155-162) all-reduces its used-parameter map, so a parameter is updated on
+    # every rank as soon as ANY rank used it and skipped on all of them otherwise.  The slab all-reduce gives every rank the
+    # averaged text-stream gradients whatever its own coin said; the optimizer's skip decision (optim.FusedAdopt, and the
+    # `None` gradients handed to autograd) must follow the same global fact or the replicas drift apart.  One MAX
+    # all-reduce of a single word per forward pass, launched on the exchange stream when the forward starts and read when
+    # the backward starts (long finished by then: no stall beyond the ranks' host skew).
+    def begin_text_live(self, live, device):
+        if self.world == 1:
+            return bool(live)
+        t = torch.tensor([1 if live else 0], dtype=torch.int32, device=device)
+        if not t.is_cuda:
+            dist.all_reduce(t, op=dist.ReduceOp.MAX, group=self.group)
+            return bool(t.item())
+        if self.side is None:
+            self.side = torch.cuda.Stream(device=device)
+        self.side.wait_stream(torch.cuda.current_stream(device))
+        with torch.cuda.stream(self.side):
+            dist.all_reduce(t, op=dist.ReduceOp.MAX, group=self.group)
+            host = torch.empty(1, dtype=torch.int32, pin_memory=True)
+            host.copy_(t, non_blocking=True)
+            ev = torch.cuda.Event()
+            ev.record(self.side)
+        t.record_stream(self.side)
+        return (host, ev)
+
+    @staticmethod
+    def end_text_live(handle):
+        if isinstance(handle, bool):
+            return handle
+        host, ev = handle
+        ev.synchronize()
+        return bool(host.item())
+
     def __call__(self, gflat, start, end):
         if start is None:                                   # flush, then wait for every slab launched so far
             if self._pending is not None:
@@ -171,6 +206,12 @@ class DataParallel(nn.Module):
     @lanes.setter
     def lanes(self, streams):
         self._sync.lanes = list(streams)
+
+    def begin_text_live(self, live, device):
+        return self._sync.begin_text_live(live, device)
+
+    def end_text_live(self, handle):
+        return self._sync.end_text_live(handle)
 
     def _hook(self, gflat, start, end):
         if start is None and self._outside and not self._outside_queued:

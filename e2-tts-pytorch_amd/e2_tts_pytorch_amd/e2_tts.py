@@ -186,6 +186,9 @@ class _MaskedMSEFn(torch.autograd.Function):
         return dpred, (-dpred if ctx.needs_input_grad[1] else None), None          # d/d(flow) = -d/d(pred)
 
 
+_CHECK_TOKEN_IDS = __import__('os').environ.get('E2K_CHECK_TOKEN_IDS', '0') == '1'
+
+
 def _on_kernels(t):
     return t.is_cuda or ops.host_ok()
 
@@ -196,6 +199,13 @@ class _CharEmbedFn(torch.autograd.Function):
 
     @staticmethod
     def forward(ctx, text, W, max_seq_len):
+        # nn.Embedding raises on ids outside the table (a tokenizer that does not match text_num_embeds); the kernel only keeps
+        # its reads in bounds.  Ids are checked where that is free (token tensors that are still on the host) and, for device
+        # tensors, when E2K_CHECK_TOKEN_IDS=1 (one device -> host synchronisation per call)
+        if text.numel() and (not text.is_cuda or _CHECK_TOKEN_IDS):
+            lo, hi = int(text.min()), int(text.max())
+            if lo < -1 or hi + 1 >= W.shape[0]:
+                raise IndexError(f'token ids span [{lo}, {hi}] but the embedding table has {W.shape[0]} rows (ids are shifted by one; -1 = padding)')
         out, tk = ops.char_embed_fwd(text.contiguous(), W.detach().contiguous(), max_seq_len)
         ctx.save_for_backward(tk)
         ctx.V = W.shape[0]
@@ -408,6 +418,16 @@ class HLGaussLayer(Module):                                    # hl_gauss_pytorc
         return F.mse_loss(pred, target)
 
 
+def _check_token_ids(tok, num_embeds):
+    """host-side token tensors straight from a tokenizer: nn.Embedding(num_embeds + 1) would raise on an id it has no row
+    for (e2_tts.py:398,407-410); the gather kernel would only keep its read in bounds.  Free here (no device round trip)"""
+    if tok.numel() and not tok.is_cuda:
+        lo, hi = int(tok.min()), int(tok.max())
+        if lo < -1 or hi >= num_embeds:
+            raise IndexError(f'tokenizer produced ids in [{lo}, {hi}] but text_num_embeds = {num_embeds} (-1 = padding)')
+    return tok
+
+
 def _resolve_tokenizer(tokenizer, text_num_embeds):
     if callable(tokenizer):
         assert exists(text_num_embeds), '`text_num_embeds` must be given if supplying your own tokenizer encode function'
@@ -561,7 +581,14 @@ def _odeint_dopri5(fn, y0, t, rtol=1e-5, atol=1e-5):
 
 
 def _adaptive(fn, y0, t, kw):
-    return _odeint_dopri5(fn, y0, t, rtol=kw.get('rtol', 1e-5), atol=kw.get('atol', 1e-5))
+    # absent keys fall back to torchdiffeq.odeint's own defaults (rtol 1e-7, atol 1e-9), not to the reference constructor's
+    return _odeint_dopri5(fn, y0, t, rtol=kw.get('rtol', 1e-7), atol=kw.get('atol', 1e-9))
+
+
+def _method(kw):
+    """an `odeint_kwargs` without `method` means torchdiffeq's default solver, dopri5 (the reference passes the dict through
+    unchanged, e2_tts.py:1421; its own default dict names 'midpoint')"""
+    return kw.get('method', 'dopri5')
 
 
 _SOLVERS = {'midpoint': _odeint_midpoint, 'euler': _odeint_euler, 'rk4': _odeint_rk4, 'dopri5': _odeint_dopri5}
@@ -591,7 +618,7 @@ class E2TTS(Module):
     ):
         super().__init__()
         assert num_freq_tokens > 0
-        if odeint_kwargs.get('method', 'midpoint') not in _SOLVERS:
+        if _method(odeint_kwargs) not in _SOLVERS:
             raise NotImplementedError(f'solvers {sorted(_SOLVERS)} are built (the reference default is midpoint; dopri5 = torchdiffeq\'s adaptive default); '
                                       'adaptive torchdiffeq methods are not')
         self.num_freq_tokens, self.has_freq_axis = num_freq_tokens, num_freq_tokens > 1
@@ -693,7 +720,7 @@ class E2TTS(Module):
         if not exists(lens):
             lens = torch.full((batch,), cond_seq_len, device=device, dtype=torch.long)
         if isinstance(text, list):
-            text = self.tokenizer(text).to(device)
+            text = _check_token_ids(self.tokenizer(text), self.embed_text.embed.num_embeddings - 1).to(device)
             assert text.shape[0] == batch
         if exists(text):
             text_lens = (text != -1).sum(dim=-1)
@@ -720,7 +747,7 @@ class E2TTS(Module):
 
         y0 = _y0 if exists(_y0) else torch.randn_like(cond)
         t = torch.linspace(0, 1, steps, device=self.device)
-        method = self.odeint_kwargs.get('method', 'midpoint')
+        method = _method(self.odeint_kwargs)
         sampled = _adaptive(fn, y0, t, self.odeint_kwargs) if method == 'dopri5' else _SOLVERS[method](fn, y0, t)
         out = torch.where(cond_mask, cond, sampled)
         if exists(return_raw_output) and return_raw_output:
@@ -745,7 +772,7 @@ class E2TTS(Module):
             assert inp.shape[-1] == self.num_channels
         batch, seq_len, dtype, device = inp.shape[0], inp.shape[1], inp.dtype, self.device
         if isinstance(text, list):
-            text = self.tokenizer(text)
+            text = _check_token_ids(self.tokenizer(text), self.embed_text.embed.num_embeddings - 1)
             # pinned staging + non-blocking copy: a pageable H2D copy is a synchronising HIP call, i.e. the host would
             # wait here for the previous step's kernels before it can enqueue this one
             text = text.pin_memory().to(device, non_blocking=True) if device.type == 'cuda' else text.to(device)

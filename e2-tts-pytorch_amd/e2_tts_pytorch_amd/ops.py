@@ -914,17 +914,27 @@ def melspec(wave, window, fb, n_fft, hop, lens=None, pad_value=0.):
         _twiddles[key] = (ang.cos().float().to(wave.device), ang.sin().float().to(wave.device))
     twc, tws = _twiddles[key]
     n_mels = fb.shape[1]
+    fb_in = fb
     fb = fb.float().contiguous()
-    bkey = (fb.data_ptr(), fb._version, tuple(fb.shape), str(fb.device))
-    bands = _mel_bands.get(bkey)
+    # the band table is cached per CALLER tensor (weak reference + version counter): a key made of the address of a converted
+    # temporary could be met again by another filterbank that the allocator put at the same place
+    ent = _mel_bands.get(id(fb_in))
+    bands = None
+    if ent is not None and ent[0]() is fb_in and ent[1] == fb_in._version and ent[2].device == fb.device:
+        bands = ent[2]
     if bands is None:                        # non-zero bin range of every filterbank column (the htk triangles are narrow)
         nz = (fb != 0).cpu()
         ks = torch.arange(fb.shape[0])[:, None]
         lo = torch.where(nz, ks, fb.shape[0]).amin(0)
         hi = torch.where(nz, ks + 1, 0).amax(0)
+        bands = torch.stack([lo, hi], 1).to(device=fb.device, dtype=torch.int32).contiguous()
         if len(_mel_bands) > 8:
             _mel_bands.clear()
-        bands = _mel_bands[bkey] = torch.stack([lo, hi], 1).to(device=fb.device, dtype=torch.int32).contiguous()
+        try:
+            import weakref
+            _mel_bands[id(fb_in)] = (weakref.ref(fb_in), fb_in._version, bands)
+        except TypeError:
+            pass
     out = torch.empty((B, n_mels, 1 + nw // hop), dtype=f32, device=wave.device)
     if lens is not None:
         assert lens.shape == (B,)

@@ -208,7 +208,7 @@ class FusedAdopt:
                 base = _grad_base(slots, flat.numel())
             if base is not None and all(q.data_ptr() == flat.data_ptr() + off * 4 for q, off in slots):
                 ranges, text_ids = self._text_group(tr, flat.device)
-                live = bool(getattr(tr, '_text_grad_live', True))
+                live = getattr(tr, '_text_grad_live', None) is not False      # (None: no backward pass of ours since the last step -- trust the gradients that are there)
                 main = [self._index[id(q)] for q, _ in slots if id(q) not in text_ids and id(q) in self._index]
                 text = [self._index[id(q)] for q, _ in slots if id(q) in text_ids and id(q) in self._index]
                 # (all parameters of a group have stepped together since construction / load, so one count per group)
@@ -216,8 +216,17 @@ class FusedAdopt:
                                                        step_b=self.steps[text[0]] if text else 0, active_b=live)))
                 stepped += main + (text if live else [])
                 taken.update(id(q) for q, _ in slots)
-                tr._text_grad_live = False
-        rest = [(p, g) for p, g in pairs if id(p) not in taken]
+        # backbones that did not go through the flat path (gradients that are not views of one buffer at the layout offsets:
+        # stock DDP bucket views, a re-packed parameter buffer, ...): on a step whose text stream ran on no rank their
+        # text-stream parameters hold exact zeros, not None (backbone._param_grads says why), and must be skipped like a
+        # parameter without a gradient -- no weight decay, no moment decay, no step count
+        dead = set()
+        for tr in self._backbones:
+            slots = getattr(getattr(tr, '_layout', None), 'slots', None)
+            if slots and id(slots[0][0]) not in taken and getattr(tr, '_text_grad_live', None) is False:
+                dead |= tr._text_param_ids()
+            tr._text_grad_live = None           # consumed: the next backward pass sets it again
+        rest = [(p, g) for p, g in pairs if id(p) not in taken and id(p) not in dead]
         for pf, gf, k in _runs(rest, [self.steps[self._index[id(p)]] for p, _ in rest]):
             runs.append((pf, gf, dict(step=k)))
         stepped += [self._index[id(p)] for p, _ in rest]

@@ -5,8 +5,11 @@
  * point cites the reference call site(s) it replaces (file:line into /root/reference/e2_tts_pytorch).
  *
  * Conventions
- *   - every function returns 0 on success, E2K_ERR_* (or 1000 + hipError_t) otherwise; no exceptions,
- *     no global mutable state, re-entrant, nothing is allocated or freed inside;
+ *   - every function returns 0 on success, E2K_ERR_* (or 1000 + hipError_t) otherwise; no exceptions;
+ *   - the COMPUTE entry points keep no state between calls, are re-entrant and allocate or free no device memory.
+ *     The launch-plan entry points (e2k_plan_*, bottom of this header) are the one exception: a recording in progress is
+ *     per-thread state (every compute call made by that thread is appended to it), and finished plans live in a
+ *     process-wide registry behind a mutex, addressed by the integer handle e2k_query_plan_end returns, until e2k_plan_free;
  *   - the caller owns every buffer; all pointers are device pointers (HBM) unless stated otherwise;
  *   - `stream` is a hipStream_t (NULL = default stream); kernels are only enqueued, never synchronised;
  *   - "bf16" buffers hold raw bfloat16 bits (uint16_t); leading dimensions (ld*) are in ELEMENTS;

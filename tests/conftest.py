@@ -28,15 +28,17 @@ def gpu_shapes(dev):
 
 def pytest_configure(config):
     config.addinivalue_line('markers', 'gpu: needs a real MI355X (run with -m gpu on the GPU box)')
-    config.addinivalue_line('markers', 'late: run after everything else (tests whose [gpu] variant has not been on hardware yet, '
-                                       'so that with -x a surprise there cannot hide the established kernel parity results)')
+    config.addinivalue_line('markers', 'late: run after everything else (the long full-size and 200-trial cases)')
 
 
 def pytest_collection_modifyitems(config, items):
-    late = [it for it in items if it.get_closest_marker('late')]
-    if late:
-        rest = [it for it in items if not it.get_closest_marker('late')]
-        items[:] = rest + late
+    """the comparisons with the REFERENCE'S OWN outputs (tests/golden/reference_pinned.pt) run first -- with -x a surprise
+    anywhere else cannot hide them --, the long cases last"""
+    def rank(it):
+        if it.name.startswith('test_reference_golden'):
+            return 0
+        return 2 if it.get_closest_marker('late') else 1
+    items.sort(key=rank)            # (stable: collection order inside each group)
 
 
 @pytest.fixture(scope='session')

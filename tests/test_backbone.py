@@ -190,7 +190,6 @@ def test_persistent_grads(dev):
     assert mod._pg is None and not mod._persist_grads
 
 
-@pytest.mark.late
 @pytest.mark.parametrize('case', ['transformer_full', 'transformer_bare', 'transformer_variant', 'transformer_laser_fourier',
                                   'transformer_freq_axis', 'transformer_freq_axis_bare'])
 def test_reference_golden_backbone(dev, case):

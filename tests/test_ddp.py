@@ -137,3 +137,91 @@ def test_two_rank_gradient_mean(emu_lib):
     for status, bad, calls in res:
         assert status == 'ok' and not bad, bad[:10]
         assert calls >= 3          # one slab per layer + the global/conditioning slab
+
+
+def _adopt_worker(rank, world, port, emu_lib, q):
+    """the classifier-free-guidance coin is flipped per rank; whether the text stream's parameters are
+    updated must be the same on every rank (the reference's DDP all-reduces its used-parameter map).  Three optimizer steps
+    -- rank 1 drops the text, nobody does, everybody does -- through both gradient paths (persistent flat buffer = one fused
+    launch; views handed to autograd = the per-run path): parameters, moments and step counts must be identical on the two
+    ranks after every step, and on the all-dropped step the text stream must not move at all."""
+    sys.path[:0] = [str(ROOT / 'e2-tts-pytorch_amd'), str(ROOT), str(ROOT / 'tests')]
+    os.environ.update(MASTER_ADDR='127.0.0.1', MASTER_PORT=str(port), E2K_EMU_THREADS='2')
+    torch.set_num_threads(2)
+    dist.init_process_group('gloo', rank=rank, world_size=world)
+    from e2_tts_pytorch_amd import E2TTS
+    from e2_tts_pytorch_amd.ddp import DataParallel
+    from e2_tts_pytorch_amd.optim import FusedAdopt
+    from test_backbone import randomize
+    install_lib(emu_lib, host_pointers=True)
+    bad = []
+    for persistent in (True, False):
+        random.seed(11)
+        torch.manual_seed(11)
+        model = E2TTS(transformer=dict(dim=256, depth=2, heads=4, dropout=0., num_registers=8), use_vocos=False, cond_drop_prob=0.)
+        randomize(model, seed=3)
+        net = DataParallel(model)
+        tr = model.transformer
+        tr.enable_plans(False)
+        tr.enable_persistent_grads(persistent)
+        opt = FusedAdopt(model, lr=1e-2, max_grad_norm=1.0)
+        text_ids = tr._text_param_ids()
+        names = {id(p): n for n, p in model.named_parameters()}
+        torch.manual_seed(200 + rank)
+        B, T = 1, 16
+        for step, drops in enumerate(((False, True), (False, False), (True, True))):
+            mel = torch.randn(B, T, 100)
+            noise = dict(x0=torch.randn(B, T, 100), times=torch.rand(B), frac_lengths=torch.tensor([0.8]),
+                         span_rand=torch.tensor([0.4]), drop_text_cond=drops[rank])
+            before = {id(p): p.detach().clone() for p in model.parameters() if id(p) in text_ids}
+            net(mel, text=['hello'], _noise=noise).loss.backward()
+            opt.step()
+            opt.zero_grad()
+            sd = opt.state_dict()['state']
+            flat = torch.cat([p.detach().reshape(-1) for p in model.parameters()] +
+                             [torch.cat([sd[i]['m'].reshape(-1), sd[i]['v'].reshape(-1)]) for i in sorted(sd)] +
+                             [torch.tensor([float(s) for s in opt.steps])])
+            both = [torch.empty_like(flat) for _ in range(world)]
+            dist.all_gather(both, flat)
+            if not torch.equal(both[0], both[1]):
+                bad.append((persistent, step, 'ranks differ', float((both[0] - both[1]).abs().max())))
+            moved = [names[i] for i, b in before.items() if not torch.equal(b, dict((id(p), p) for p in model.parameters())[i].detach())]
+            if all(drops) and moved:
+                bad.append((persistent, step, 'text stream moved although every rank dropped it', moved[:3]))
+            if not all(drops) and step > 0 and len(moved) < len(before) // 2:          # (ADOPT's first step only initialises v)
+                bad.append((persistent, step, 'text stream did not move although a rank used it', len(moved), len(before)))
+        tcount = {opt.steps[opt._index[i]] for i in text_ids if i in opt._index}
+        ocount = {s for i, s in enumerate(opt.steps) if id(opt.params[i]) not in text_ids and names[id(opt.params[i])].startswith('transformer.')}
+        if tcount != {2} or ocount != {3}:
+            bad.append((persistent, 'step counts', sorted(tcount), sorted(ocount)))
+        tr._grad_sync = None
+    q.put(('ok', bad, 3))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_two_rank_fused_adopt_with_per_rank_text_drop(emu_lib):
+    ctx = mp.get_context('spawn')
+    q = ctx.Queue()
+    port = 31500 + os.getpid() % 2000
+    procs = [ctx.Process(target=_adopt_worker, args=(r, 2, port, str(emu_lib), q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    import queue as _queue
+    res, waited = [], 0
+    while len(res) < len(procs) and waited < 900:
+        try:
+            res.append(q.get(timeout=5))
+        except _queue.Empty:
+            waited += 5
+            dead = [p.exitcode for p in procs if p.exitcode not in (None, 0)]
+            if dead:
+                for p in procs:
+                    p.kill()
+                raise AssertionError(f'a rank exited with {dead} (see its traceback above)')
+    assert len(res) == len(procs), 'timed out'
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    for status, bad, _ in res:
+        assert status == 'ok' and not bad, bad[:10]

@@ -41,7 +41,7 @@ def rel2(a, b):
 def _report(name, rec):
     out = ROOT / 'gpurun_out'
     if out.is_dir():
-        json.dump(rec, open(out / f'r03_parity_{name}.json', 'w'), indent=1)
+        json.dump(rec, open(out / f'r04_parity_{name}.json', 'w'), indent=1)
 
 
 def _pair(kw, init, seed=0):
@@ -212,3 +212,49 @@ def test_cfg5_shape_sample_32_steps(init):
     # 31 midpoint steps x 2 evaluations integrate the per-evaluation error; north star 1e-2 for the reference's own
     # initialisation, 3e-2 for the stress weights (bf16 residual-stream storage, see _train_step_parity)
     assert e < (1e-2 if init == 'reference_init' else 3e-2), e
+
+
+def test_cfg3_batch8_forward_only():
+    """the headline configuration at its FULL batch: dim 1024 / depth 24 / 16 heads, B = 8, T = 1024, text on -- loss and
+    pred_flow of one no-grad forward against the CPU oracle (no saved activations: the fp32 oracle of B = 8 fits host RAM;
+    the forward + backward comparison at these dims is test_cfg3_dims_depth24 at B = 1, 2).  Reference initialisation."""
+    import string
+    torch.set_num_threads(min(32, os.cpu_count() or 1))
+    kw = dict(dim=1024, depth=24, heads=16, dropout=0.)
+    ref, model = _pair(kw, 'reference_init', seed=5)
+    B, T = 8, 1024
+    rng = random.Random(9)
+    text = [''.join(rng.choice(string.ascii_lowercase + ' ') for _ in range(rng.randint(20, 200))) for _ in range(B)]
+    mel = torch.randn(B, T, 100)
+    noise = dict(x0=torch.randn(B, T, 100), times=torch.rand(B), frac_lengths=torch.full((B,), 0.85),
+                 span_rand=torch.rand(B), drop_text_cond=False)
+    with torch.no_grad():
+        out_r = ref(mel, text=text, _noise=noise)
+        dn = {k: (v.cuda() if torch.is_tensor(v) else v) for k, v in noise.items()}
+        out = model(mel.cuda(), text=text, _noise=dn)
+    e_loss = abs(out.loss.item() - out_r.loss.item()) / abs(out_r.loss.item())
+    e_flow = rel2(out.pred_flow, out_r.pred_flow)
+    _report('cfg3_B8_forward_only_reference_init', dict(case='cfg3 at B = 8, forward only', kw=kw, B=B, T=T, loss_rel=e_loss, pred_flow_rel_l2=e_flow))
+    print('cfg3 B=8 forward only: loss rel', e_loss, 'pred_flow rel-L2', e_flow)
+    assert e_loss < 1e-2 and e_flow < 1e-2, (e_loss, e_flow)
+
+
+def test_cfg5_sample_batch8_1024_frames():
+    """sample() at a full batch of full-length targets: B = 8, prompt of 5 frames, 1024 target frames, 8 midpoint steps with
+    classifier-free guidance (14 function evaluations x (cond + null)), the cfg2 transformer (dim 512, depth 8: the CPU oracle
+    of the depth-24 one would hold the GPU box for half an hour; its sample() is test_cfg5_sample_at_cfg3_dims)"""
+    torch.set_num_threads(min(32, os.cpu_count() or 1))
+    kw = dict(dim=512, depth=8, dropout=0.)
+    ref, model = _pair(kw, 'reference_init', seed=4)
+    B, Tp, dur, steps = 8, 5, 1024, 8
+    cond = torch.randn(B, Tp, 100)
+    y0 = torch.randn(B, dur, 100)
+    rng = random.Random(3)
+    text = [''.join(rng.choice('abcdefghijklmnopqrstuvwxyz ,.') for _ in range(rng.randint(10, 90))) for _ in range(B)]
+    s_r = ref.sample(cond, text=text, duration=dur, steps=steps, cfg_strength=1., _y0=y0)
+    s = model.sample(cond.cuda(), text=text, duration=dur, steps=steps, cfg_strength=1., _y0=y0.cuda())
+    e = rel2(s, s_r)
+    _report('cfg5_sample_B8_1024_frames_reference_init', dict(case='sample(), B = 8, 1024 frames, 8 steps', kw=kw, B=B, prompt=Tp, duration=dur,
+                                                              steps=steps, sampled_mel_rel_l2=e))
+    print('sampled mel rel-L2 (B = 8, 1024 frames, 8 steps)', e)
+    assert s.shape == s_r.shape == (B, dur, 100) and e < 1e-2, e
