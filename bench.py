@@ -213,6 +213,8 @@ def main():
     ap.add_argument('--ddp-defer', action='store_true', help='one gradient all-reduce after the backward pass instead of per-layer slabs overlapped with it (A/B)')
     ap.add_argument('--no-optimizer-leg', action='store_true', help='skip the extra leg that times the step WITH the fused gradient clip + '
                     'ADOPT update (+ EMA) after the headline measurement (N = 1 only; it never enters `value`)')
+    ap.add_argument('--main-cus', default=None, help='first:count -- run the step on a HIP stream confined to these CUs '
+                    '(hipExtStreamCreateWithCUMask; A/B of the launch lanes with E2K_LANE_CUS, DESIGN.md section 5.1)')
     ap.add_argument('--dump-ops', default=None, help='write the per-shape launch table of the profiled plan replays (name, flops, count, '
                     'average ms, TFLOP/s) to this JSON file')
     args = ap.parse_args()
@@ -270,6 +272,10 @@ def main():
         for p in params:                  # == optimizer.zero_grad(set_to_none=True) (trainer.py:277) without walking the
             p.grad = None                 #    module tree every step (model.zero_grad costs ~10 ms of host time here)
         return out.loss
+
+    if args.main_cus:
+        a, n = (int(v) for v in args.main_cus.split(':'))
+        torch.cuda.set_stream(ops.cu_masked_stream(dev, a, n))
 
     launch_mode_note = 'eager launches from Python (--eager)' if args.eager else \
         'recorded launch plan re-issued from C++ (e2k_plan_run; eager stream launches, no HIP graph)'
@@ -372,6 +378,7 @@ def main():
             'mfma_roofline_frac_whole_step': sf / (dt / args.steps) / 1e12 / PEAK_BF16_TFLOPS,
             'loss': loss_val,
             'host_enqueue_ms_per_step': t_enqueue / args.steps * 1e3,
+            'cu_masks': {'main': args.main_cus, 'lanes': os.environ.get('E2K_LANE_CUS')},
             'launch_mode': launch_mode_note, 'gemm_flags': ops.gemm_flags, 'fuse_geglu': bool(ops.fuse_geglu),
             'launches_per_step': (len(prof_rows) // nprof) if prof_rows else None,
             'lane_ms_per_step': _lane_ms(prof_rows, nprof),          # work of each lane, every call timed alone: the step cannot be shorter than the longest chain

@@ -297,6 +297,11 @@ __global__ __launch_bounds__(256) void qkv_post_bwd_kernel(PostArgs p) {
         }
     }
     if (!valid) return;
+    if (h == p.H - 1) {
+        // pad columns of a row whose stride is rounded up (they are read as K padding by the dgrad GEMM): zeroed here instead of by
+        // a fill launch per call
+        for (int c = 3 * I + p.H * (p.vfirst ? 2 : 1) + seg; c < (int)p.ldq; c += 4) drow[c] = 0;
+    }
     if (seg == 0) drow[3 * I + h] = f2bf(p.dgate_pre[bh * p.N + n]);
     bf16_t* dst = drow + h * DH + seg * 16;
     st<u32x4>(dst, pack8(dq)); st<u32x4>(dst + 8, pack8(dq + 8));

@@ -53,6 +53,10 @@ struct NTArgs {
     int M, N;
     const float* bias; const float* colscale; long lds; int rows_per_batch;
     const uint8_t* rowmask; const bf16_t* resid; long ldr;
+    // two-output form (e2k_gemm_nt2_bf16): columns [nsplit, N) of the product go to a second matrix.  C2 / resid2 are stored
+    // SHIFTED by -nsplit columns, so that the epilogues index them with the same global column as C / resid; nsplit is a
+    // multiple of 256, i.e. a tile lies in one output and the choice is wave-uniform (nt_bind_output)
+    int nsplit; void* C2; long ldc2; const bf16_t* resid2; long ldr2;
     int probe;          // E2K_GEMM_PROBE_* bits (bottleneck probes: results are wrong on purpose)
     // remainder split: workgroups [0, full) own whole tiles; the last T - full tiles (a partial round of the 512
     // resident workgroups) are cut into `split` K ranges each, fp32 partials go to `ws`, gemm_nt_fixup_kernel finishes
@@ -61,6 +65,13 @@ struct NTArgs {
     // GEGLU epilogue (gemm_nt_256_kernel<false, true> only): N = 2F, C = pre-activation H (may be NULL), glu_out (M, F)
     bf16_t* glu_out; long ldg; unsigned seed, stream_id, thresh; float inv_keep; const unsigned* seed_dev;
 };
+
+// two-output form: rebinds the (by-value) argument block of a workgroup whose tile lies in the second output
+__device__ __forceinline__ void nt_bind_output(NTArgs& p, int n0) {
+    if (p.nsplit > 0 && n0 >= p.nsplit) {
+        p.C = p.C2; p.ldc = p.ldc2; p.resid = p.resid2; p.ldr = p.ldr2;
+    }
+}
 
 // epilogue of an interior tile (all 128 x 128 outputs exist, rows 8-byte aligned): no per-element bounds checks, the
 // optional operands are selected once per tile (wave-uniform), bias kept in registers across the 4 row groups
@@ -284,6 +295,7 @@ __global__ __launch_bounds__(256) void gemm_nt_kernel(NTArgs p) {
     int tile_m, tile_n;
     tile_coords(xcd_remap(blockIdx.x, gridDim.x), tm, tn, tile_m, tile_n);
     const int m0 = tile_m * BM, n0 = tile_n * BN;
+    nt_bind_output(p, n0);
     const int K = p.K1 + p.K2;
     const int nk = (K + BK - 1) / BK;
 
@@ -388,6 +400,7 @@ __global__ __launch_bounds__(256, 2) void gemm_nt_glds_kernel(NTArgs p) {
         ke = (int)((long)nk * (sidx + 1) / p.split);
     }
     const int m0 = tile_m * BM, n0 = tile_n * BN;
+    nt_bind_output(p, n0);
 
     // per-lane 32-bit byte offsets of the 4 (A) + 4 (B) wave instructions of a K step at k = 0; the K advance goes
     // into the scalar base, so a load is `global_load_lds_dwordx4 voff, s[base]` with no per-step vector arithmetic
@@ -502,6 +515,7 @@ __global__ __launch_bounds__(256) void gemm_nt_fixup_kernel(NTArgs p) {
     const int i = blockIdx.y;
     int tile_m, tile_n;
     tile_coords(p.full + blockIdx.x, tm, tn, tile_m, tile_n);
+    nt_bind_output(p, tile_n * BN);
     f32x4 acc[1][4];
 #pragma unroll
     for (int j = 0; j < 4; ++j) acc[0][j] = f32x4{0.f, 0.f, 0.f, 0.f};
@@ -685,6 +699,7 @@ __global__ __launch_bounds__(QTHREADS, 1) void gemm_nt_256_kernel(NTArgs p) {
         ke = (int)((long)nk * (sidx + 1) / p.split);
     }
     const int m0 = tile_m * QBM, n0 = GLU ? tile_n * 128 : tile_n * QBN;
+    if (!GLU) nt_bind_output(p, n0);
     const int nhalf = GLU ? (p.N >> 1) : 128;                // B rows between the "low" and the "high" half tile
     const int nt = ke - kb;                                  // K tiles of this workgroup (>= 1)
 
@@ -864,6 +879,7 @@ __global__ __launch_bounds__(QTHREADS) void gemm_nt_256_fixup_kernel(NTArgs p) {
     const int q = blockIdx.y >> 2, i = blockIdx.y & 3, a = q >> 1, b = q & 1;
     int tile_m, tile_n;
     tile_coords(p.full + blockIdx.x, tm, tn, tile_m, tile_n);
+    nt_bind_output(p, tile_n * QBN);
     f32x4 acc[1][2];
     acc[0][0] = acc[0][1] = f32x4{0.f, 0.f, 0.f, 0.f};
     const float* w = p.ws + (((long)blockIdx.x * p.split * 32 + (q * 4 + i) * 2) * QTHREADS + tid) * 4;
@@ -1590,8 +1606,12 @@ static int gemm_nt_bf16_impl(const void* A1, int64_t lda1, int K1, const void* A
                                 const void* B, int64_t ldb, void* C, int64_t ldc, int out_f32, int accumulate,
                                 int M, int N, const float* bias, const float* colscale, int64_t lds,
                                 int rows_per_batch, const uint8_t* rowmask, const void* resid, int64_t ldr, int flags,
-                                float* ws, int64_t ws_bytes, void* stream) {
+                                float* ws, int64_t ws_bytes, int nsplit, void* C2, int64_t ldc2, const void* resid2, int64_t ldr2,
+                                void* stream) {
     if (M <= 0 || N <= 0) return 0;
+    if (nsplit < 0 || nsplit >= N || (nsplit > 0 && ((nsplit % QBN) || !C2 || (ldc2 & 7) || (ldr2 & 7) || ((uintptr_t)C2 & 15) ||
+                                                    ((uintptr_t)resid2 & 15) || (resid != nullptr) != (resid2 != nullptr))))
+        return E2K_ERR_ARG;
     if (K1 <= 0 || (K1 & 7) || (K2 & 7) || K2 < 0) return E2K_ERR_SHAPE;
     if ((lda1 & 7) || (ldb & 7) || (K2 > 0 && ((lda2 & 7) || A2 == nullptr))) return E2K_ERR_ALIGN;
     if (((uintptr_t)A1 | (uintptr_t)B | (uintptr_t)A2) & 15) return E2K_ERR_ALIGN;
@@ -1605,13 +1625,16 @@ static int gemm_nt_bf16_impl(const void* A1, int64_t lda1, int K1, const void* A
     p.M = M; p.N = N;
     p.bias = bias; p.colscale = colscale; p.lds = lds; p.rows_per_batch = rows_per_batch;
     p.rowmask = rowmask; p.resid = (const bf16_t*)resid; p.ldr = ldr;
+    p.nsplit = nsplit; p.ldc2 = ldc2; p.ldr2 = ldr2;
+    p.C2 = nsplit ? (void*)((char*)C2 - (int64_t)nsplit * (out_f32 ? 4 : 2)) : nullptr;
+    p.resid2 = (nsplit && resid2) ? (const bf16_t*)resid2 - nsplit : nullptr;
     const int tn = (N + BN - 1) / BN;
     p.probe = flags & (E2K_GEMM_PROBE_NO_LOADS | E2K_GEMM_PROBE_NO_MATH);
     // C tile through LDS in whole-line row segments (nt_epilogue_staged*) when every epilogue operand allows 16-byte accesses
     p.staged = !(flags & E2K_GEMM_NO_STAGE) && (K1 % BK) == 0 && (K2 % BK) == 0 && !(flags & E2K_GEMM_NO_GLDS) &&
                (N & 7) == 0 && (ldc & 7) == 0 && ((uintptr_t)C & 15) == 0 &&
                (!bias || ((uintptr_t)bias & 15) == 0) && (!colscale || ((lds & 3) == 0 && ((uintptr_t)colscale & 15) == 0)) &&
-               (!resid || ((ldr & 7) == 0 && ((uintptr_t)resid & 15) == 0));
+               (!resid || ((ldr & 7) == 0 && ((uintptr_t)resid & 15) == 0));      // (the second output's operands were checked above)
     const bool glds = !(flags & E2K_GEMM_NO_GLDS) && (K1 % BK) == 0 && (K2 % BK) == 0;
     const int t256 = ((M + QBM - 1) / QBM) * ((N + QBN - 1) / QBN);
     // default: shapes with at least 64 tiles of 256 x 256.  Timed ALONE the kernel pays only where its tiles fill >= 7/8 of the
@@ -1912,7 +1935,15 @@ extern "C" int e2k_gemm_nt_bf16(const void* A1, int64_t lda1, int K1, const void
                                 int M, int N, const float* bias, const float* colscale, int64_t lds,
                                 int rows_per_batch, const uint8_t* rowmask, const void* resid, int64_t ldr, int flags,
                                 float* ws, int64_t ws_bytes, void* stream) {
-    return e2k::dispatch("gemm_nt_bf16", gemm_nt_bf16_impl, A1, lda1, K1, A2, lda2, K2, B, ldb, C, ldc, out_f32, accumulate, M, N, bias, colscale, lds, rows_per_batch, rowmask, resid, ldr, flags, ws, ws_bytes, stream);
+    return e2k::dispatch("gemm_nt_bf16", gemm_nt_bf16_impl, A1, lda1, K1, A2, lda2, K2, B, ldb, C, ldc, out_f32, accumulate, M, N, bias, colscale, lds, rows_per_batch, rowmask, resid, ldr, flags, ws, ws_bytes, 0, (void*)nullptr, (int64_t)0, (const void*)nullptr, (int64_t)0, stream);
+}
+
+extern "C" int e2k_gemm_nt2_bf16(const void* A1, int64_t lda1, int K1, const void* A2, int64_t lda2, int K2,
+                                 const void* B, int64_t ldb, int M, int N, int nsplit, void* C, int64_t ldc, void* C2, int64_t ldc2,
+                                 const void* resid, int64_t ldr, const void* resid2, int64_t ldr2, int flags,
+                                 float* ws, int64_t ws_bytes, void* stream) {
+    if (nsplit <= 0) return E2K_ERR_ARG;
+    return e2k::dispatch("gemm_nt_bf16", gemm_nt_bf16_impl, A1, lda1, K1, A2, lda2, K2, B, ldb, C, ldc, 0, 0, M, N, (const float*)nullptr, (const float*)nullptr, (int64_t)0, 0, (const uint8_t*)nullptr, resid, ldr, flags, ws, ws_bytes, nsplit, C2, ldc2, resid2, ldr2, stream);
 }
 
 extern "C" int e2k_gemm_nt_geglu_bf16(const void* A, int64_t lda, int K, const void* W1, int64_t ldb, const float* bias,

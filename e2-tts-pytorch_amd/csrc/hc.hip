@@ -492,14 +492,14 @@ struct HCReduceArgs {
 // b = y*8 + part (mod 8*RSPLIT), coalesced over d, LDS tree over the row-groups, then one atomic add per gradient
 // element (RSPLIT adds per address).  x = D/32: the 26 scalar gradients.
 constexpr int RSPLIT = 8;
-__global__ __launch_bounds__(256) void hc_reduce_kernel(HCReduceArgs p) {
+__device__ __forceinline__ void hc_reduce_body(const HCReduceArgs& p, int bx, int by) {
     __shared__ float red[8][NJ][32];
     const int D = p.D, stride = NJ * D + NSC;
     const int tid = threadIdx.x;
-    const int part = tid >> 5, row0 = blockIdx.y * 8 + part;
-    if ((int)blockIdx.x < D / 32) {
+    const int part = tid >> 5, row0 = by * 8 + part;
+    if (bx < D / 32) {
         const int dl = tid & 31;
-        const int d = blockIdx.x * 32 + dl;
+        const int d = bx * 32 + dl;
         float acc[NJ];
 #pragma unroll
         for (int j = 0; j < NJ; ++j) acc[j] = 0.f;
@@ -547,6 +547,18 @@ __global__ __launch_bounds__(256) void hc_reduce_kernel(HCReduceArgs p) {
             else atomicAdd(&p.g_dyn_beta_scale[0], s);
         }
     }
+}
+__global__ __launch_bounds__(256) void hc_reduce_kernel(HCReduceArgs p) { hc_reduce_body(p, blockIdx.x, blockIdx.y); }
+
+// the reductions of up to HC_BATCH_MAX hyper-connections in ONE launch (grid.z = item): a layer's six (audio 3-4, text 3) are
+// launched together at the end of the layer instead of one 264-workgroup launch each (144 launches per cfg3 step, each
+// reading its 19 MB of partials at a quarter of the HBM rate)
+constexpr int HC_BATCH_MAX = 8;
+struct HCReduceBatch { HCReduceArgs it[HC_BATCH_MAX]; int n; };
+__global__ __launch_bounds__(256) void hc_reduce_batch_kernel(HCReduceBatch b) {
+    const HCReduceArgs& p = b.it[blockIdx.z];
+    if ((int)blockIdx.x > p.D / 32) return;          // (the grid is sized for the widest item)
+    hc_reduce_body(p, blockIdx.x, blockIdx.y);
 }
 
 template <int VEC, int NCH, int NW>
@@ -692,7 +704,40 @@ static int hc_bwd_reduce_impl(const float* partial, const float* dyn_alpha_fn, c
     return 0;
 }
 
+struct HCReduceBatchHost { e2k_hc_reduce_item it[HC_BATCH_MAX]; int n; };
+static int hc_bwd_reduce_batch_impl(HCReduceBatchHost h, void* stream) {
+    HCReduceBatch b;
+    b.n = 0;
+    int dmax = 0;
+    for (int i = 0; i < h.n; ++i) {
+        const e2k_hc_reduce_item& q = h.it[i];
+        if (q.Mtok <= 0) continue;
+        if (!q.partial || !q.gamma || !q.g_gamma || !q.dyn_alpha_fn || !q.dyn_beta_fn) return E2K_ERR_ARG;
+        if (q.D % 32) return E2K_ERR_SHAPE;
+        HCReduceArgs& r = b.it[b.n++];
+        r.partial = q.partial; r.nblocks = grid_for(q.Mtok, q.D, 768, true); r.D = q.D;
+        r.hp = HCParams{nullptr, nullptr, q.dyn_alpha_fn, nullptr, q.dyn_beta_fn, nullptr, q.gamma};
+        r.g_static_beta = q.g_static_beta; r.g_static_alpha = q.g_static_alpha; r.g_dyn_alpha_fn = q.g_dyn_alpha_fn;
+        r.g_dyn_alpha_scale = q.g_dyn_alpha_scale; r.g_dyn_beta_fn = q.g_dyn_beta_fn; r.g_dyn_beta_scale = q.g_dyn_beta_scale;
+        r.g_gamma = q.g_gamma;
+        dmax = q.D > dmax ? q.D : dmax;
+    }
+    if (b.n == 0) return 0;
+    hipLaunchKernelGGL(hc_reduce_batch_kernel, dim3(dmax / 32 + 1, RSPLIT, b.n), dim3(256), 0, (hipStream_t)stream, b);
+    E2K_CHECK_LAUNCH();
+    return 0;
+}
+
 // ---- C ABI: every compute entry point goes through e2k::dispatch (plan.h) so that a launch plan can record it
+
+extern "C" int e2k_hc_bwd_reduce_batch(const e2k_hc_reduce_item* items, int n, void* stream) {
+    if (n < 0 || n > HC_BATCH_MAX || (n > 0 && !items)) return E2K_ERR_ARG;
+    HCReduceBatchHost h;
+    h.n = n;
+    for (int i = 0; i < n; ++i) h.it[i] = items[i];
+    for (int i = n; i < HC_BATCH_MAX; ++i) h.it[i] = e2k_hc_reduce_item{};
+    return e2k::dispatch("hc_bwd_reduce_batch", hc_bwd_reduce_batch_impl, h, stream);
+}
 
 extern "C" int e2k_hc_fwd(const void* Xin, const void* yprev, const float* coef_prev, void* Mout, void* bin,
                           float* coef, const float* static_beta, const float* static_alpha,

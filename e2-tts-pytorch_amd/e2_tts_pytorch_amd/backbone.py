@@ -814,7 +814,17 @@ class Transformer(Module):
             return [None, None]
         ss = self.__dict__.get('_lane_ss')
         if ss is None or ss[0] != dev:
-            ss = self.__dict__['_lane_ss'] = (dev, [torch.cuda.Stream(device=dev), torch.cuda.Stream(device=dev)])
+            # E2K_LANE_CUS="first:count,first:count" confines the TEXT / WGRAD lane to a slice of the chip's CUs (A/B instrument,
+            # profiles/r04_cu_mask_ab.jsonl; empty field = the whole chip)
+            spec = (_os.environ.get('E2K_LANE_CUS', '') + ',').split(',')[:2]
+            lanes = []
+            for f in spec:
+                if f.strip():
+                    a, n = (int(v) for v in f.split(':'))
+                    lanes.append(ops.cu_masked_stream(dev, a, n))
+                else:
+                    lanes.append(torch.cuda.Stream(device=dev))
+            ss = self.__dict__['_lane_ss'] = (dev, lanes)
         return ss[1]
 
     def _drop_plans(self):
@@ -897,8 +907,15 @@ class Transformer(Module):
         lib = ops.lib()
         if exists(st.fwd):
             ops.run_plan(st.fwd, 0, -1, dev, st.lane_ss)
+            if st.run.grads_zeroed is not None:         # the recorded forward zero-fills the gradient buffer on its WGRAD lane
+                pg = self._pg
+                pg.token += 1
+                pg.dirty = False
+                st.run.grads_zeroed = pg.token
             return
         # first run of this plan: execute the schedule with the C ABI recording, inside the pool
+        if st.need_grad:
+            self._pg_state(dev)             # (the long-lived gradient buffer: allocated outside the plan's pool and recording)
         with self._pool_ctx(dev, st), _RecordGuard(st.keep if dev.type != 'cuda' else None):
             ops.begin_recording(st.meta_f)
             try:
@@ -908,7 +925,7 @@ class Transformer(Module):
                     self._recast(transposes=not _RECAST_T_ON_LANE)
                 with ops.pinned_stream(dev):
                     run = self._run_forward(st.x, st.cond, st.text, st.mask, st.need_grad, seed_dev=st.seed, rot=rot,
-                                            recast_T=st.need_grad and _RECAST_T_ON_LANE)
+                                            recast_T=st.need_grad and _RECAST_T_ON_LANE, zero_grads=st.need_grad and _ZERO_GRADS_ON_LANE)
                 st.fwd = ops.end_recording()
             except BaseException:
                 ops.abort_recording()
@@ -923,6 +940,9 @@ class Transformer(Module):
         live = self._end_text_live(st.text_live, st.key[1])      # (key[1]: the signature has a text stream)
         self._sync_lanes(st.lane_ss)
         if exists(st.bwd):
+            if not self._grads_prezeroed(st.run, self._pg) and not st.run.bwd_filled:
+                with ops.pinned_stream(dev):
+                    ops.fill_(self._pg.buf)         # (another pass wrote into the buffer since this pass's forward zeroed it)
             for first, count, slab in st.segs:
                 ops.run_plan(st.bwd, first, count, dev, st.lane_ss)
                 if exists(sync) and exists(slab):
@@ -972,7 +992,7 @@ class Transformer(Module):
 
     # ------------------------------------------------------------------ forward schedule
 
-    def _run_forward(self, x_in, cond, text_embed, mask, want_tape, seed_dev=None, rot=None, recast_T=False):
+    def _run_forward(self, x_in, cond, text_embed, mask, want_tape, seed_dev=None, rot=None, recast_T=False, zero_grads=False):
         """the whole forward as a sequence of e2k calls (nothing else touches the device in here: a launch plan replays
         exactly the recorded calls, so a tensor-library op in between would silently be skipped on replay)"""
         dev = x_in.device
@@ -1027,12 +1047,23 @@ class Transformer(Module):
         # i - 1 left it, so they run on the TEXT lane next to the audio branches of layer i - 1
         L = run.lanes = ops.Lanes(dev, self._lane_streams(dev) if exists(st) else [], self._lane_mask)
         ev_cross = L.record(ops.MAIN)
-        if recast_T:
+        run.grads_zeroed = None
+        if recast_T or zero_grads:
             # (the lane starts after everything the caller's stream had queued before this forward -- the optimizer's update of
-            #  the fp32 parameters included; the forward's final join makes MAIN, hence the backward, wait for it)
+            #  the fp32 parameters and its read of the gradients included; the forward's final join makes MAIN, hence the
+            #  backward, wait for it)
             L.wait(ops.WGRAD, ev_cross)
             with L.lane(ops.WGRAD):
-                self._recast_transposes()
+                if recast_T:
+                    self._recast_transposes()
+                if zero_grads:
+                    # the flat gradient buffer of the persistent-gradient mode (2.9 GB at dim 1024 / depth 24) is zero-filled
+                    # here, next to the forward, instead of at the head of the backward chain (0.5 ms there)
+                    pg = self._pg_state(dev)
+                    ops.fill_(pg.buf)
+                    pg.token += 1
+                    pg.dirty = False
+                    run.grads_zeroed = pg.token
         # what MAIN hands to the TEXT lane (the packed text stream, then each cross projection's output) is allocated on
         # MAIN: it must stay referenced until MAIN has waited for the TEXT lane again, or the next MAIN allocation could
         # land on it while the TEXT lane still reads it
@@ -1069,7 +1100,7 @@ class Transformer(Module):
         y, rn = ops.rmsnorm_fwd(xsum, gfin, 0., B * T)
         run.tail = (xsum, rn)
         run.out = ops.cast_f32(y).view(B, T, D)
-        if recast_T:
+        if recast_T or zero_grads:
             L.fence(ops.WGRAD, ops.MAIN)        # the backward (MAIN and, through it, every lane) starts after the transposed shadows are written
         return run
 
@@ -1203,8 +1234,12 @@ class Transformer(Module):
         D, Dt = self.dim, self.dim_text
         X, Tt = sx.X.view(-1, D), st.X.view(-1, Dt)
         W = self._w(tr.cross, tr.cross_rows, D + Dt)
-        Xn = ops.gemm_nt(X, W[:D], a2=Tt, resid=X)
-        Tn = ops.gemm_nt(X, W[D:], a2=Tt, resid=Tt) if tr.cross_rows > D else Tt
+        if tr.cross_rows > D and _CROSS_ONE_LAUNCH and D % 256 == 0:
+            # both projections read the same cat(audio, text): one launch over the stacked weight rows, two outputs
+            Xn, Tn = ops.gemm_nt2(X, W, D, a2=Tt, resid=X, resid2=Tt)
+        else:
+            Xn = ops.gemm_nt(X, W[:D], a2=Tt, resid=X)
+            Tn = ops.gemm_nt(X, W[D:], a2=Tt, resid=Tt) if tr.cross_rows > D else Tt
         if exists(run.tape):
             run.tape.append(('cross', tr, X, Tt))
         sx.X, st.X = Xn.view(-1, 4, D), Tn.view(-1, 4, Dt)
@@ -1256,9 +1291,7 @@ class Transformer(Module):
         no accumulation over several backward passes, `zero_grad()` between steps is unnecessary (and with
         `set_to_none=True` only costs a re-attach), and the module must not appear twice in one autograd graph.  Tensor
         hooks registered on the parameters do not fire (the gradients do not travel through AccumulateGrad)."""
-        self._persist_grads = bool(on)
-        if not on:
-            self._pg = None
+        self._persist_grads = bool(on)          # (the buffer itself stays: recorded plans write into it either way)
         return self
 
     def _pg_state(self, dev):
@@ -1266,9 +1299,18 @@ class Transformer(Module):
         if pg is None or pg.buf.device != dev:
             buf = torch.zeros(self._layout.n, dtype=f32, device=dev)
             views = [buf[off:off + p.numel()].view(p.shape) for p, off in self._layout.slots]
-            pg = self._pg = NS(buf=buf, views=views, gcache={})
+            # token: bumped by every zero fill issued from a forward pass; dirty: a backward pass has written since the last fill
+            pg = self._pg = NS(buf=buf, views=views, gcache={}, token=0, dirty=True)
             self._no_pgrads = [None] * len(views)
         return pg
+
+    @staticmethod
+    def _grads_prezeroed(run, pg):
+        """the forward of this very pass zero-filled the persistent gradient buffer (on the WGRAD lane) and no other backward
+        pass has written into it since; marks the buffer dirty for whoever comes next"""
+        ok = run.__dict__.get('grads_zeroed') is not None and run.grads_zeroed == pg.token and not pg.dirty
+        pg.dirty = True
+        return ok
 
     def _attach_grads(self):
         for (p, _), v in zip(self._layout.slots, self._pg.views):
@@ -1284,7 +1326,10 @@ class Transformer(Module):
         lay, g = self._layout, self._glob
         if persist:
             pg = self._pg_state(dev)
-            gflat, gc, mk = ops.fill_(pg.buf), pg.gcache, self._g
+            run.bwd_filled = not self._grads_prezeroed(run, pg)
+            if run.bwd_filled:
+                ops.fill_(pg.buf)
+            gflat, gc, mk = pg.buf, pg.gcache, self._g
 
             def G(off, *shape):                       # the buffer outlives the step, so do its views
                 v = gc.get((off, shape))
@@ -1348,8 +1393,11 @@ class Transformer(Module):
                 Ln.fence(ops.MAIN, ops.WGRAD)
                 Ln.fence(ops.TEXT, ops.WGRAD)
                 with Ln.lane(ops.WGRAD):
+                    hcs = [fn for fn in reduces if isinstance(fn, ops.HCReduce)] if _BATCH_REDUCES else []
+                    ops.launch_hc_reduces(hcs)          # the layer's hyper-connection reductions: one launch
                     for fn in reduces:
-                        fn()
+                        if not (_BATCH_REDUCES and isinstance(fn, ops.HCReduce)):
+                            fn()
                 hold[0].append(list(reduces))        # (the closures keep the partial buffers alive until the lane has been waited for)
                 reduces.clear()
             if not pending:
@@ -1424,7 +1472,9 @@ class Transformer(Module):
                 gW = G(tr.cross, tr.cross_rows, D + Dt)
                 # d[text_to_audio; audio_to_text] = cat(d audio, d text)^T cat(audio, text): one launch for the four blocks
                 wgrad_dual(gx, gt if tr.cross_rows > D else None, X, Tt, gW)
-                if tr.cross_rows > D:
+                if tr.cross_rows > D and _CROSS_ONE_LAUNCH and D % 256 == 0:
+                    ngx, ngt = ops.gemm_nt2(gx, WT, D, a2=gt, resid=gx, resid2=gt)
+                elif tr.cross_rows > D:
                     ngx = ops.gemm_nt(gx, WT[:D], a2=gt, resid=gx)
                     ngt = ops.gemm_nt(gx, WT[D:], a2=gt, resid=gt)
                 else:
@@ -1660,7 +1710,8 @@ class _BackboneFn(torch.autograd.Function):
     def forward(ctx, module, x_in, cond, text_embed, mask, rot, *params):
         with ops.pinned_stream(x_in.device):
             run = module._run_forward(x_in.detach(), cond.detach() if exists(cond) else None,
-                                      text_embed.detach() if exists(text_embed) else None, mask, True, rot=rot)
+                                      text_embed.detach() if exists(text_embed) else None, mask, True, rot=rot,
+                                      zero_grads=module._persist_grads and _ZERO_GRADS_ON_LANE)
         run.text_live = module.__dict__.pop('_text_live_handle', None)
         ctx.run, ctx.module = run, module
         ctx.has_cond, ctx.has_text = exists(cond), exists(text_embed)
@@ -1739,6 +1790,16 @@ _DEFER_REDUCES = _os.environ.get('E2K_DEFER_REDUCES', '1') != '0'
 # recorded training plans refresh the transposed bf16 weight shadows (dgrad operands) on the WGRAD lane during the forward instead
 # of at its start on the chain (E2K_RECAST_T_ON_LANE=0: A/B)
 _RECAST_T_ON_LANE = _os.environ.get('E2K_RECAST_T_ON_LANE', '1') != '0'
+
+# the persistent flat gradient buffer is zero-filled on the WGRAD lane during the forward instead of at the head of the backward
+# chain (E2K_ZERO_GRADS_ON_LANE=0: A/B)
+_ZERO_GRADS_ON_LANE = _os.environ.get('E2K_ZERO_GRADS_ON_LANE', '1') != '0'
+
+# the hyper-connection parameter-gradient reductions of a layer go out as one launch (E2K_BATCH_REDUCES=0: one each, A/B)
+_BATCH_REDUCES = _os.environ.get('E2K_BATCH_REDUCES', '1') != '0'
+
+# TextAudioCrossCondition's two projections (and the two halves of its dgrad) as ONE two-output GEMM launch (E2K_CROSS_ONE_LAUNCH=0: A/B)
+_CROSS_ONE_LAUNCH = _os.environ.get('E2K_CROSS_ONE_LAUNCH', '1') != '0'
 
 _VIEW_OPS = {'view', '_unsafe_view', 'as_strided', 'slice', 'select', 'expand', 't', 'transpose', 'permute', 'unsqueeze', 'squeeze',
              'detach', 'alias', '_reshape_alias', 'reshape', 'split', 'split_with_sizes', 'unbind', 'narrow', 'lift_fresh', 'unfold',

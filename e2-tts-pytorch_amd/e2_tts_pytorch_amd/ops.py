@@ -191,6 +191,34 @@ def gemm_nt(a, b, *, a2=None, out=None, out_dtype=bf16, accumulate=False, bias=N
     return out
 
 
+def gemm_nt2(a, b, nsplit, *, a2=None, resid=None, resid2=None):
+    """(out1 (M, nsplit), out2 (M, N - nsplit)) = split of [a|a2] @ b.T (+ resid / resid2) over the output columns, one launch
+    (e2k_gemm_nt2_bf16); nsplit a multiple of 256"""
+    _chk(a, b, a2, resid, resid2)
+    assert a.dtype == bf16 and b.dtype == bf16
+    M, lda = _rows(a)
+    N, ldb = _rows(b)
+    K1 = a.shape[1]
+    K2, lda2 = 0, 0
+    if a2 is not None:
+        assert a2.dtype == bf16 and a2.shape[0] == M
+        _, lda2 = _rows(a2)
+        K2 = a2.shape[1]
+    assert b.shape[1] == K1 + K2 and 0 < nsplit < N and nsplit % 256 == 0
+    out1 = torch.empty((M, nsplit), dtype=bf16, device=a.device)
+    out2 = torch.empty((M, N - nsplit), dtype=bf16, device=a.device)
+    assert (resid is None) == (resid2 is None)
+    if resid is not None:
+        assert resid.dtype == bf16 and resid.shape == out1.shape and resid.stride(1) == 1
+        assert resid2.dtype == bf16 and resid2.shape == out2.shape and resid2.stride(1) == 1
+    _note(2.0 * M * N * (K1 + K2))
+    stream = _stream(a)
+    _lib.get().e2k_gemm_nt2_bf16(_p(a), lda, K1, _p(a2), lda2, K2, _p(b), ldb, M, N, int(nsplit), _p(out1), out1.stride(0),
+                                 _p(out2), out2.stride(0), _p(resid), 0 if resid is None else resid.stride(0),
+                                 _p(resid2), 0 if resid2 is None else resid2.stride(0), gemm_flags, *_nt_ws(a.device, stream), stream)
+    return out1, out2
+
+
 _nt_ws_cache = {}
 
 
@@ -284,6 +312,36 @@ class Lanes:
         """MAIN waits for every side lane (end of a pass)"""
         for k in range(1, self.n):
             self.fence(k, MAIN)
+
+
+_hip_rt = None
+
+
+def cu_masked_stream(device, first_cu, n_cus, total=256):
+    """a HIP stream whose kernels may only run on `n_cus` of the chip's CUs, [first_cu, first_cu + n_cus) in the runtime's CU
+    numbering (hipExtStreamCreateWithCUMask; the driver deals consecutive mask bits round-robin over the 8 XCDs, so a run of
+    64 bits is 8 CUs of every XCD), wrapped for torch.  A/B instrument for the launch lanes."""
+    global _hip_rt
+    import re
+    if _hip_rt is None:
+        path = None
+        for line in open('/proc/self/maps'):
+            m = re.search(r'(/\S*libamdhip64\.so\S*)', line)
+            if m:
+                path = m.group(1)
+                break
+        _hip_rt = ctypes.CDLL(path or 'libamdhip64.so')
+    words = (total + 31) // 32
+    mask = (ctypes.c_uint32 * words)()
+    for c in range(first_cu, min(first_cu + n_cus, total)):
+        mask[c // 32] |= 1 << (c % 32)
+    st = ctypes.c_void_p()
+    dev = torch.device(device)
+    with torch.cuda.device(dev):
+        rc = _hip_rt.hipExtStreamCreateWithCUMask(ctypes.byref(st), ctypes.c_uint32(words), mask)
+    if rc != 0:
+        raise E2KError(f'hipExtStreamCreateWithCUMask failed with {rc}')
+    return torch.cuda.ExternalStream(st.value, device=dev)
 
 
 def run_plan(handle, first, count, device, side_streams=()):
@@ -459,10 +517,46 @@ def hc_bwd(G, *, xin=None, yprev=None, coef_prev=None, dbin=None, ycur=None, coe
                    _p(dR) if width else None, _p(dyprev), *ps, *gs, _p(partial), Mtok, D, int(depth),
                    (2 if deferred is not None else 1) if width else 0, _stream(G))
     if width and deferred is not None:
-        def reduce_(partial=partial, params=params, grads=grads, Mtok=Mtok, D=D):
-            lib.e2k_hc_bwd_reduce(_p(partial), _p(params[2]), _p(params[4]), _p(params[6]), *[_p(t) for t in grads], Mtok, D, _stream(partial))
-        deferred.append(reduce_)
+        deferred.append(HCReduce(partial, params, grads, Mtok, D))
     return dR, dyprev
+
+
+class _HCReduceItem(ctypes.Structure):
+    """e2k_hc_reduce_item (include/e2k.h)"""
+    _fields_ = [(n, ctypes.c_void_p) for n in ('partial', 'dyn_alpha_fn', 'dyn_beta_fn', 'gamma', 'g_static_beta', 'g_static_alpha',
+                                               'g_dyn_alpha_fn', 'g_dyn_alpha_scale', 'g_dyn_beta_fn', 'g_dyn_beta_scale', 'g_gamma')] + \
+               [('Mtok', ctypes.c_int32), ('D', ctypes.c_int32)]
+
+
+HC_BATCH_MAX = 8
+
+
+class HCReduce:
+    """the deferred second half of an hc_bwd(width) call: per-workgroup partials -> parameter gradients.  Calling it launches
+    it alone (on whatever stream is current); `launch_hc_reduces` launches up to HC_BATCH_MAX of them as one kernel.  The
+    object keeps the partial buffer alive until it is dropped."""
+
+    def __init__(self, partial, params, grads, Mtok, D):
+        self.partial, self.params, self.grads, self.Mtok, self.D = partial, params, grads, Mtok, D
+
+    def item(self):
+        return _HCReduceItem(_p(self.partial), _p(self.params[2]), _p(self.params[4]), _p(self.params[6]),
+                             *[_p(t) for t in self.grads], self.Mtok, self.D)
+
+    def __call__(self):
+        _lib.get().e2k_hc_bwd_reduce(_p(self.partial), _p(self.params[2]), _p(self.params[4]), _p(self.params[6]),
+                                     *[_p(t) for t in self.grads], self.Mtok, self.D, _stream(self.partial))
+
+
+def launch_hc_reduces(items):
+    """items: [HCReduce]; one launch per HC_BATCH_MAX of them (e2k_hc_bwd_reduce_batch)"""
+    for i in range(0, len(items), HC_BATCH_MAX):
+        chunk = items[i:i + HC_BATCH_MAX]
+        if len(chunk) == 1:
+            chunk[0]()
+            continue
+        arr = (_HCReduceItem * len(chunk))(*[c.item() for c in chunk])
+        _lib.get().e2k_hc_bwd_reduce_batch(ctypes.cast(arr, ctypes.c_void_p), len(chunk), _stream(chunk[0].partial))
 
 
 # ------------------------------------------------------------------------------------------------ norms / gates / GEGLU
@@ -710,17 +804,19 @@ def attn_bwd(st, dOg, kmask_pad, p_drop=0., seed=0, stream_id=0, seed_dev=None):
     return dQ, dK, dV, dgate if dgate_laser is None else dgate_laser
 
 
-def qkv_post_bwd(st, dQ, dK, dV, dgate_pre, qkvg, cosb, sinb, vfirst=None, dvfirst=None, first_layer=False):
-    _chk(dQ, dK, dV, dgate_pre, qkvg, vfirst, dvfirst)
+def qkv_post_bwd(st, dQ, dK, dV, dgate_pre, qkvg, cosb, sinb, vfirst=None, dvfirst=None, first_layer=False, out=None):
+    """out (tests): a preallocated (M, ld) bf16 buffer to write the gradient rows into"""
+    _chk(dQ, dK, dV, dgate_pre, qkvg, vfirst, dvfirst, out)
     B, H, N = st.B, st.H, st.N
     M, cols = qkvg.shape
     ld = qkvg.stride(0)
-    if ld == cols:
+    if out is not None:
+        assert out.shape == (M, ld) and out.dtype == bf16 and out.is_contiguous()
+        dqkvg = out[:, :cols]
+    elif ld == cols:
         dqkvg = torch.empty((M, cols), dtype=bf16, device=qkvg.device)
-    else:                                        # padded row stride: only the pad columns need zeroing (they are read
-        full = torch.empty((M, ld), dtype=bf16, device=qkvg.device)      # as K padding by the dgrad GEMM)
-        fill_cols_(full, cols)
-        dqkvg = full[:, :cols]
+    else:                                        # padded row stride: the kernel zeroes the pad columns (they are read as K
+        dqkvg = torch.empty((M, ld), dtype=bf16, device=qkvg.device)[:, :cols]      # padding by the dgrad GEMM)
     _lib.get().e2k_qkv_post_bwd(_p(dQ), _p(dK), _p(dV), _p(dgate_pre), _p(qkvg), qkvg.stride(0), _p(cosb), _p(sinb),
                                 _p(vfirst), _p(st.mix), _p(dvfirst), int(first_layer), _p(dqkvg), st.laser, B, H, N,
                                 _stream(dQ))

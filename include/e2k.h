@@ -47,6 +47,15 @@ int e2k_gemm_nt_bf16(const void* A1, int64_t lda1, int K1, const void* A2, int64
  * count leaves a partial last round of the 512 resident workgroups, those tiles are split over K into partials in ws
  * and finished by a second small kernel.  One ws per stream: launches on the same stream serialise on it. */
 int e2k_query_gemm_nt_ws_bytes(void);
+/* The same product with TWO outputs: columns [0, nsplit) of [A1|A2] . B^T (+ resid) go to C (M, nsplit), columns
+ * [nsplit, N) (+ resid2) to C2 (M, N - nsplit); bf16 outputs, nsplit a multiple of 256, resid and resid2 both given or both
+ * NULL.  TextAudioCrossCondition (e2_tts.py:503-513) computes text_to_audio(cat(audio, text)) + audio and
+ * audio_to_text(cat(audio, text)) + text from the SAME concatenated operand: one launch over the stacked weight rows
+ * [text_to_audio; audio_to_text] instead of two (the same for the two halves of its dgrad). */
+int e2k_gemm_nt2_bf16(const void* A1, int64_t lda1, int K1, const void* A2, int64_t lda2, int K2,
+                      const void* B, int64_t ldb, int M, int N, int nsplit, void* C, int64_t ldc, void* C2, int64_t ldc2,
+                      const void* resid, int64_t ldr, const void* resid2, int64_t ldr2, int flags,
+                      float* ws, int64_t ws_bytes, void* stream);
 #define E2K_GEMM_NO_GLDS 1   /* flags: stage operands through VGPRs instead of global_load_lds (A/B benchmarking) */
 #define E2K_GEMM_PROBE_NO_LOADS 4 /* flags: bottleneck probe, K loop without its global loads (WRONG results) */
 #define E2K_GEMM_PROBE_NO_MATH 8  /* flags: bottleneck probe, K loop without its LDS reads + MFMAs (WRONG results) */
@@ -132,6 +141,15 @@ int e2k_hc_bwd(const void* Xin, const void* yprev, const float* coef_prev, const
 int e2k_hc_bwd_reduce(const float* partial, const float* dyn_alpha_fn, const float* dyn_beta_fn, const float* gamma,
                       float* g_static_beta, float* g_static_alpha, float* g_dyn_alpha_fn, float* g_dyn_alpha_scale,
                       float* g_dyn_beta_fn, float* g_dyn_beta_scale, float* g_gamma, int Mtok, int D, void* stream);
+/* the same for up to 8 hyper-connections in ONE launch (the six of a layer, e2_tts.py:870-872,908-939: their reductions are
+ * independent and small).  `items` is a HOST array, copied during the call. */
+typedef struct {
+    const float* partial; const float* dyn_alpha_fn; const float* dyn_beta_fn; const float* gamma;
+    float* g_static_beta; float* g_static_alpha; float* g_dyn_alpha_fn; float* g_dyn_alpha_scale;
+    float* g_dyn_beta_fn; float* g_dyn_beta_scale; float* g_gamma;
+    int32_t Mtok, D;
+} e2k_hc_reduce_item;
+int e2k_hc_bwd_reduce_batch(const e2k_hc_reduce_item* items, int n, void* stream);
 
 /* ---- RMSNorm / AdaptiveRMSNorm (x_transformers; e2_tts.py:615,637,645,688,691,729,908,937) ----
  * y[m] = x[m] / max(|x[m]|, 1e-12) * sqrt(D) * (gamma[m / rows_per_batch] + gamma_off);  rn[m] = 1 / max(|x[m]|, 1e-12)
@@ -219,7 +237,8 @@ int e2k_qkv_post_fwd(const void* qkvg, int64_t ldq, const float* cosb, const flo
                      void* v_orig, float laser_clamp, int B, int H, int N, int Npad, void* stream);
 /* dqkvg (B*N, ldq) from dQ,dK,dV (B,H,N,64): inverse rotary, value-residual mix backward (dvfirst (B,H,N,64) fp32
  * is ACCUMULATED on later layers and consumed when first_layer = 1), gate / mix logit gradients; laser_clamp as above
- * (dV is then the gradient of the mapped values). */
+ * (dV is then the gradient of the mapped values).  Columns [3 H 64 + H (+ H with vfirst), ldq) of every dqkvg row -- the
+ * padding of a rounded-up row stride, read as zero K padding by the dgrad GEMM -- are written as zeros. */
 int e2k_qkv_post_bwd(const void* dQ, const void* dK, const void* dV, const float* dgate_pre,
                      const void* qkvg, int64_t ldq, const float* cosb, const float* sinb,
                      const void* vfirst, const float* mix, float* dvfirst, int first_layer, void* dqkvg,

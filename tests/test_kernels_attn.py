@@ -92,7 +92,17 @@ def test_attention(dev, N, has_vres, use_mask, qk_gain):
     dOg = R.reshape(B * N, D).to(bf16).to(dev)
     dQ, dK, dV, dgate = ops.attn_bwd(st, dOg, kmask)
     dvfirst = torch.zeros(B, H, N, 64, device=dev) if has_vres else None
+    # row stride rounded up to 64 columns as the backbone does (the dgrad GEMM reads the pad as K padding): the kernel must
+    # zero it itself -- the buffer starts out as NaN
+    ld64 = (qkvg_c.shape[1] + 63) // 64 * 64
+    q64 = torch.zeros(B * N, ld64, dtype=bf16, device=dev)
+    q64[:, :qkvg_c.shape[1]] = qkvg
+    full = torch.full((B * N, ld64), float('nan'), dtype=bf16, device=dev)
+    dv2 = torch.zeros(B, H, N, 64, device=dev) if has_vres else None
+    d64 = ops.qkv_post_bwd(st, dQ, dK, dV, dgate, q64[:, :qkvg_c.shape[1]], cosb, sinb, vfirst, dv2, out=full)
+    assert not torch.isnan(full.float()).any() and float(full[:, qkvg_c.shape[1]:].float().abs().max()) == 0.
     dqkvg = ops.qkv_post_bwd(st, dQ, dK, dV, dgate, qkvg, cosb, sinb, vfirst, dvfirst)
+    assert torch.equal(d64.float().cpu(), dqkvg.float().cpu())
     ref = cols.grad
     names = ['q', 'k', 'v', 'gate'] + (['mix'] if has_vres else [])
     for name, got, want in zip(names, dqkvg.float().cpu().split([I, I, I, H] + ([H] if has_vres else []), dim=-1),

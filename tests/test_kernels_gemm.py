@@ -481,3 +481,31 @@ def test_gemm_tn_group(dev):
             assert rel(out, want) < 2e-3, splits
             if want_cs is not None:
                 assert torch.allclose(col.cpu(), want_cs, rtol=1e-4, atol=2e-3), splits
+
+
+@pytest.mark.parametrize('M,N1,N2,K1,K2,flags', [(300, 256, 128, 128, 64, 0), (520, 512, 256, 256, 128, 128), (264, 256, 256, 192, 0, 0),
+                                               (700, 512, 256, 512, 256, 128 + 32), (600, 512, 384, 512, 0, 256 + 32)])     # (+ 32: remainder split + fix-up kernels)
+def test_gemm_nt_two_outputs(dev, M, N1, N2, K1, K2, flags):
+    """e2k_gemm_nt2_bf16 (TextAudioCrossCondition's two projections in one launch): bit-identical to two e2k_gemm_nt_bf16
+    launches over the two row blocks of the weight, with and without residuals, on the 128 x 128 and the 256 x 256 kernel"""
+    from e2_tts_pytorch_amd import ops
+    torch.manual_seed(M + N1)
+    a = torch.randn(M, K1).to(bf16).to(dev)
+    a2 = torch.randn(M, K2).to(bf16).to(dev) if K2 else None
+    w = (torch.randn(N1 + N2, K1 + K2) * 0.1).to(bf16).to(dev)
+    r1, r2 = torch.randn(M, N1).to(bf16).to(dev), torch.randn(M, N2).to(bf16).to(dev)
+    old = ops.gemm_flags
+    ops.gemm_flags = flags
+    try:
+        for res in (False, True):
+            o1, o2 = ops.gemm_nt2(a, w, N1, a2=a2, resid=r1 if res else None, resid2=r2 if res else None)
+            e1 = ops.gemm_nt(a, w[:N1], a2=a2, resid=r1 if res else None)
+            e2 = ops.gemm_nt(a, w[N1:], a2=a2, resid=r2 if res else None)
+            if flags & 32:          # a remainder tile is split over K in one form and not in the other: another fp32 summation order
+                assert rel(o1.float().cpu(), e1.float().cpu()) < 1e-2 and rel(o2.float().cpu(), e2.float().cpu()) < 1e-2, res
+            else:
+                assert torch.equal(o1.float().cpu(), e1.float().cpu()) and torch.equal(o2.float().cpu(), e2.float().cpu()), res
+        ref = torch.cat([a.float().cpu(), a2.float().cpu()], 1) @ w.float().cpu().T if K2 else a.float().cpu() @ w.float().cpu().T
+        assert rel(e1.float().cpu(), ref[:, :N1] + r1.float().cpu()) < 2e-2
+    finally:
+        ops.gemm_flags = old
