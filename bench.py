@@ -349,11 +349,11 @@ def main():
         achieved = gemm_flops / (gemm_ms * 1e-3) / 1e12 if gemm_ms > 0 else 0.0
         # HBM traffic of the dominant kernel per launch: PMC counters cannot be read from inside this process, so the
         # number comes from the committed rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes over the same launch mix
-        # (profiles/r03_nt_traffic.json, produced by tools/nt_shapes.py + tools/nt_traffic_probe.py + tools/nt_traffic_reduce.py); cfg3 only
+        # (profiles/r04_nt_traffic.json, produced by tools/nt_shapes.py + tools/nt_traffic_probe.py + tools/nt_traffic_reduce.py); cfg3 only
         traffic, traffic_note = None, None
-        tf = ROOT / 'profiles' / 'r03_nt_traffic.json'
+        tf = ROOT / 'profiles' / 'r04_nt_traffic.json'
         if not tf.exists():
-            tf = ROOT / 'profiles' / 'r02_nt_traffic.json'
+            tf = ROOT / 'profiles' / 'r03_nt_traffic.json'
         if args.config == 'cfg3' and B == CONFIGS['cfg3'][3] and not args.drop_text and tf.exists():
             tj = json.load(open(tf))
             traffic = tj['traffic_bytes_per_launch']
@@ -394,7 +394,7 @@ def main():
                 'time_share_of_step': (gemm_ms / nprof) / ms,
                 'measured': 'HIP events on the launch stream around every recorded launch (e2k_plan_profile), 2 replays of the '
                             'timed plan right after the timed region, every call ALONE on one stream; the rocprofv3 summary that '
-                            'agrees with avg_launch_ms is the single-stream one (E2K_LANES=0, profiles/r03_bench_cfg3_kernel_stats_d_single_stream.csv): '
+                            'agrees with avg_launch_ms is the single-stream one (E2K_LANES=0, profiles/r04_bench_cfg3_kernel_stats_single_stream.csv): '
                             'with the launch lanes the kernels of different lanes overlap and stretch (…_d_lanes.csv).  Since the end of '
                             'round 3 outputs of 64-223 tiles of 256 x 256 (the 8448-token GEMMs with N <= 2048) run the 256 x 256 kernel on '
                             'a part of the CUs: in the step the other launch lanes use the rest (step -1.5 to -3 %, '

@@ -211,6 +211,9 @@ def gemm_nt2(a, b, nsplit, *, a2=None, resid=None, resid2=None):
     if resid is not None:
         assert resid.dtype == bf16 and resid.shape == out1.shape and resid.stride(1) == 1
         assert resid2.dtype == bf16 and resid2.shape == out2.shape and resid2.stride(1) == 1
+    if _gemm_shapes is not None:
+        key = (M, N, K1, K2, 0, int(resid is not None))
+        _gemm_shapes[key] = _gemm_shapes.get(key, 0) + 1
     _note(2.0 * M * N * (K1 + K2))
     stream = _stream(a)
     _lib.get().e2k_gemm_nt2_bf16(_p(a), lda, K1, _p(a2), lda2, K2, _p(b), ldb, M, N, int(nsplit), _p(out1), out1.stride(0),
