@@ -85,13 +85,24 @@ __device__ __forceinline__ bf16x8 pack_frag(const float* lo4, const float* hi4) 
 
 // Dropout keep decisions: four 16-bit uniform samples per hash for the keys 4j .. 4j+3 of query row q
 // (hrow = rand_base(seed, stream) + q * 0x85ebca77 is hoisted by the caller; key j keeps iff its sample >= thresh;
-// oracle/dropout_hash.py restates this bit for bit).  One full avalanche (fmix32) for the first word, a cheap xor-shift-multiply
-// of it for the second: the round-1 generator spent one fmix32 per PAIR of keys, 40 % of the forward's VALU instructions.
+// oracle/dropout_hash.py restates this bit for bit).  Round 4: the two 64-bit words come from three 24 x 24 -> 32-bit
+// multiply-adds (v_mad_u32_u24, a full-rate instruction; the 32-bit v_mul_lo_u32 of the murmur finaliser used before issues at a
+// quarter of that rate and was 13 % of the forward's vector-ALU clocks) with xor-shifts in between; the addend of each multiply
+// carries the bits the 24-bit multiplicand drops.  Avalanche (every input bit flips every output bit with probability 0.5 +-
+// 0.007 over 1e5 inputs) and the grid statistics of the masks (keep rate, sample / decision correlations between neighbouring
+// keys and queries, per-row and per-column drop-count variance against the binomial) equal the finaliser's: tools/probes/drop_hash_stats.py.
+__device__ __forceinline__ unsigned mad24(unsigned x, unsigned y, unsigned z) { return (x & 0xffffffu) * (y & 0xffffffu) + z; }      // (selected as v_mad_u32_u24)
 __device__ __forceinline__ void drop4(unsigned hrow, unsigned key4, unsigned& w0, unsigned& w1) {
-    w0 = fmix32(hrow + key4 * 0xc2b2ae3du);
-    unsigned x = w0 ^ (w0 >> 15);
-    x *= 0x2c1b3c6du;
-    w1 = x ^ (x >> 12);
+    const unsigned h = hrow + key4 * 0xc2b2ae3du;
+    unsigned x = h ^ (h >> 16);
+    x = mad24(x, 0x85ebcbu, h >> 8);
+    x ^= x >> 13;
+    unsigned a = mad24(x, 0xc2b2afu, x >> 11);
+    a ^= a >> 15;
+    unsigned b = mad24(a, 0x9e3779u, x >> 7);
+    b ^= b >> 12;
+    w0 = a;
+    w1 = b;
 }
 __device__ __forceinline__ unsigned drop_sample(unsigned w0, unsigned w1, int j) {      // j = key & 3
     const unsigned w = (j & 2) ? w1 : w0;
@@ -1143,8 +1154,8 @@ __global__ __launch_bounds__(NW * 64, 2) void attn_bwd_dkv_kernel(AttnArgs p) {
                         if (SHARE) {         // bit of (query qi, this lane's key) in the forward's ballot words
                             ks[r] = ((dword[kk2] >> (dbit0 + 4 * tt + r)) & 1ull) ? p.inv_keep : 0.f;
                         } else {
-                            unsigned w0 = fmix32(hkey + (unsigned)(q0 + qi0 + r) * 0x85ebca77u), w1 = 0;
-                            if (key & 2) { unsigned x = w0 ^ (w0 >> 15); x *= 0x2c1b3c6du; w1 = x ^ (x >> 12); }
+                            unsigned w0, w1;          // (hkey already holds base + (key >> 2) * 0xc2b2ae3d)
+                            drop4(hkey + (unsigned)(q0 + qi0 + r) * 0x85ebca77u, 0u, w0, w1);
                             ks[r] = drop_sample(w0, w1, key & 3) >= p.thresh ? p.inv_keep : 0.f;
                         }
                     }
@@ -1342,8 +1353,8 @@ __global__ __launch_bounds__(256, 3) void attn_bwd_dkv_ring_kernel(AttnArgs p) {
                         if (SHARE) {
                             ks[r] = ((dword[kk2] >> (dbit0 + 4 * tt + r)) & 1ull) ? p.inv_keep : 0.f;
                         } else {
-                            unsigned w0 = fmix32(hkey + (unsigned)(q0 + qi0 + r) * 0x85ebca77u), w1 = 0;
-                            if (key & 2) { unsigned x = w0 ^ (w0 >> 15); x *= 0x2c1b3c6du; w1 = x ^ (x >> 12); }
+                            unsigned w0, w1;          // (hkey already holds base + (key >> 2) * 0xc2b2ae3d)
+                            drop4(hkey + (unsigned)(q0 + qi0 + r) * 0x85ebca77u, 0u, w0, w1);
                             ks[r] = drop_sample(w0, w1, key & 3) >= p.thresh ? p.inv_keep : 0.f;
                         }
                     }

@@ -34,8 +34,7 @@ __device__ __forceinline__ int xcd_remap(int orig, int nwg) {
     return (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + (orig >> 3);
 }
 
-__device__ __forceinline__ void tile_coords(int wgid, int tm, int tn, int& tile_m, int& tile_n) {
-    const int group = 8;
+__device__ __forceinline__ void tile_coords(int wgid, int tm, int tn, int& tile_m, int& tile_n, int group = 8) {
     int width = group * tn;
     int gid = wgid / width;
     int first_m = gid * group;
@@ -57,6 +56,8 @@ struct NTArgs {
     // SHIFTED by -nsplit columns, so that the epilogues index them with the same global column as C / resid; nsplit is a
     // multiple of 256, i.e. a tile lies in one output and the choice is wave-uniform (nt_bind_output)
     int nsplit; void* C2; long ldc2; const bf16_t* resid2; long ldr2;
+    int group;          // row tiles per group of the tile order (tile_coords): chosen so that a group is about one XCD's share
+
     int probe;          // E2K_GEMM_PROBE_* bits (bottleneck probes: results are wrong on purpose)
     // remainder split: workgroups [0, full) own whole tiles; the last T - full tiles (a partial round of the 512
     // resident workgroups) are cut into `split` K ranges each, fp32 partials go to `ws`, gemm_nt_fixup_kernel finishes
@@ -293,7 +294,7 @@ __global__ __launch_bounds__(256) void gemm_nt_kernel(NTArgs p) {
     const int l15 = lane & 15, g = lane >> 4;
     const int tm = (p.M + BM - 1) / BM, tn = (p.N + BN - 1) / BN;
     int tile_m, tile_n;
-    tile_coords(xcd_remap(blockIdx.x, gridDim.x), tm, tn, tile_m, tile_n);
+    tile_coords(xcd_remap(blockIdx.x, gridDim.x), tm, tn, tile_m, tile_n, p.group);
     const int m0 = tile_m * BM, n0 = tile_n * BN;
     nt_bind_output(p, n0);
     const int K = p.K1 + p.K2;
@@ -391,11 +392,11 @@ __global__ __launch_bounds__(256, 2) void gemm_nt_glds_kernel(NTArgs p) {
     const int nk1 = p.K1 / BK, nk = (p.K1 + p.K2) / BK;
     int kb = 0, ke = nk, part = -1;          // K-step range of this workgroup; part >= 0: partial result slot in ws
     if ((int)blockIdx.x < p.full) {
-        tile_coords(xcd_remap(blockIdx.x, p.full), tm, tn, tile_m, tile_n);
+        tile_coords(xcd_remap(blockIdx.x, p.full), tm, tn, tile_m, tile_n, p.group);
     } else {
         part = blockIdx.x - p.full;
         const int r = part / p.split, sidx = part - r * p.split;
-        tile_coords(p.full + r, tm, tn, tile_m, tile_n);
+        tile_coords(p.full + r, tm, tn, tile_m, tile_n, p.group);
         kb = (int)((long)nk * sidx / p.split);
         ke = (int)((long)nk * (sidx + 1) / p.split);
     }
@@ -514,7 +515,7 @@ __global__ __launch_bounds__(256) void gemm_nt_fixup_kernel(NTArgs p) {
     const int tm = (p.M + BM - 1) / BM, tn = (p.N + BN - 1) / BN;
     const int i = blockIdx.y;
     int tile_m, tile_n;
-    tile_coords(p.full + blockIdx.x, tm, tn, tile_m, tile_n);
+    tile_coords(p.full + blockIdx.x, tm, tn, tile_m, tile_n, p.group);
     nt_bind_output(p, tile_n * BN);
     f32x4 acc[1][4];
 #pragma unroll
@@ -690,11 +691,11 @@ __global__ __launch_bounds__(QTHREADS, 1) void gemm_nt_256_kernel(NTArgs p) {
     const int nk1 = p.K1 / BK, nk = (p.K1 + p.K2) / BK;
     int kb = 0, ke = nk, part = -1;
     if ((int)blockIdx.x < p.full) {
-        tile_coords(xcd_remap(blockIdx.x, p.full), tm, tn, tile_m, tile_n);
+        tile_coords(xcd_remap(blockIdx.x, p.full), tm, tn, tile_m, tile_n, p.group);
     } else {
         part = blockIdx.x - p.full;
         const int r = part / p.split, sidx = part - r * p.split;
-        tile_coords(p.full + r, tm, tn, tile_m, tile_n);
+        tile_coords(p.full + r, tm, tn, tile_m, tile_n, p.group);
         kb = (int)((long)nk * sidx / p.split);
         ke = (int)((long)nk * (sidx + 1) / p.split);
     }
@@ -878,7 +879,7 @@ __global__ __launch_bounds__(QTHREADS) void gemm_nt_256_fixup_kernel(NTArgs p) {
     const int tm = (p.M + QBM - 1) / QBM, tn = (p.N + QBN - 1) / QBN;
     const int q = blockIdx.y >> 2, i = blockIdx.y & 3, a = q >> 1, b = q & 1;
     int tile_m, tile_n;
-    tile_coords(p.full + blockIdx.x, tm, tn, tile_m, tile_n);
+    tile_coords(p.full + blockIdx.x, tm, tn, tile_m, tile_n, p.group);
     nt_bind_output(p, tile_n * QBN);
     f32x4 acc[1][2];
     acc[0][0] = acc[0][1] = f32x4{0.f, 0.f, 0.f, 0.f};
@@ -898,7 +899,7 @@ __global__ __launch_bounds__(QTHREADS) void gemm_nt_256_fixup_glu_kernel(NTArgs 
     const int tm = (p.M + QBM - 1) / QBM, tn = (p.N + QBN - 1) / QBN;
     const int a = blockIdx.y >> 2, i = blockIdx.y & 3;
     int tile_m, tile_n;
-    tile_coords(p.full + blockIdx.x, tm, tn, tile_m, tile_n);
+    tile_coords(p.full + blockIdx.x, tm, tn, tile_m, tile_n, p.group);
     f32x4 acc[2][1][2];
 #pragma unroll
     for (int b = 0; b < 2; ++b) {
@@ -1629,6 +1630,7 @@ static int gemm_nt_bf16_impl(const void* A1, int64_t lda1, int K1, const void* A
     p.C2 = nsplit ? (void*)((char*)C2 - (int64_t)nsplit * (out_f32 ? 4 : 2)) : nullptr;
     p.resid2 = (nsplit && resid2) ? (const bf16_t*)resid2 - nsplit : nullptr;
     const int tn = (N + BN - 1) / BN;
+    p.group = 8;
     p.probe = flags & (E2K_GEMM_PROBE_NO_LOADS | E2K_GEMM_PROBE_NO_MATH);
     // C tile through LDS in whole-line row segments (nt_epilogue_staged*) when every epilogue operand allows 16-byte accesses
     p.staged = !(flags & E2K_GEMM_NO_STAGE) && (K1 % BK) == 0 && (K2 % BK) == 0 && !(flags & E2K_GEMM_NO_GLDS) &&
@@ -1648,6 +1650,20 @@ static int gemm_nt_bf16_impl(const void* A1, int64_t lda1, int K1, const void* A
                       ((flags & E2K_GEMM_T256) || (t256 >= t256_min && (K1 + K2) >= 4 * BK));
     if (q256) {
         const int T = t256;
+        // tile order: workgroups go round-robin over the 8 XCDs and xcd_remap hands each XCD a contiguous run of T / 8 tiles, taken
+        // from groups of `group` row tiles x all column tiles.  With the fixed 8 rows a group of a narrow output is the share of
+        // TWO or more XCDs (8448 x 1024: 32 tiles against 16.5 per XCD), i.e. every A row panel is fetched by several L2s; the
+        // group is sized to one XCD's share instead (E2K_GEMM_GROUP: fixed value, A/B)
+        {
+            static const int group_env = getenv("E2K_GEMM_GROUP") ? atoi(getenv("E2K_GEMM_GROUP")) : 0;
+            const int tn256 = (N + QBN - 1) / QBN;
+            const float per_xcd = T / 8.f;
+            if (group_env > 0) p.group = group_env;
+            else if (tn256 * 8 > 1.5f * per_xcd) {
+                int g = (int)(per_xcd / tn256 + 0.5f);
+                p.group = g < 1 ? 1 : (g > 8 ? 8 : g);
+            }
+        }
         p.full = T; p.split = 1; p.ws = ws;
         int rem = 0;
         const int slots = (flags & E2K_GEMM_TEST_SLOTS8) ? 8 : 256;
@@ -1735,6 +1751,7 @@ static int gemm_nt_geglu_bf16_impl(const void* A, int64_t lda, int K, const void
     p.glu_out = (bf16_t*)out; p.ldg = ldo;
     p.seed = seed; p.seed_dev = seed_dev; p.stream_id = stream_id;
     p.thresh = (unsigned)(p_drop * 65536.f + 0.5f); p.inv_keep = 1.f / (1.f - p_drop);
+    p.group = 8;
     const int T = ((M + QBM - 1) / QBM) * (F / 128);
     p.full = T; p.split = 1; p.ws = ws;
     int rem = 0;

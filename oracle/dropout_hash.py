@@ -40,19 +40,37 @@ def _keep(seed, stream, rows, cols, p):
     return torch.from_numpy(np.where(r16 >= thresh, np.float32(1.0 / (1.0 - p)), np.float32(0.0)))
 
 
+def _mad24(x, y, z):
+    """v_mad_u32_u24: (x & 0xffffff) * (y & 0xffffff) + z, low 32 bits"""
+    return ((x.astype(np.uint64) & np.uint64(0xffffff)) * np.uint64(y & 0xffffff) + z.astype(np.uint64)).astype(np.uint32)
+
+
+def drop4_words(h):
+    """attn.hip drop4(): the two 32-bit words (four 16-bit samples) of the counter value h"""
+    h = h.astype(np.uint32)
+    x = h ^ (h >> _M(16))
+    x = _mad24(x, 0x85ebcb, h >> _M(8))
+    x = x ^ (x >> _M(13))
+    a = _mad24(x, 0xc2b2af, x >> _M(11))
+    a = a ^ (a >> _M(15))
+    b = _mad24(a, 0x9e3779, x >> _M(7))
+    b = b ^ (b >> _M(12))
+    return a, b
+
+
 def _keep4(seed, stream, rows, cols, p):
     """keep-scale matrix of the attention kernels (attn.hip drop4 / drop_sample): one hash per group of FOUR consecutive
-    keys -- word 0 = fmix32(base + q * 0x85ebca77 + (key >> 2) * 0xc2b2ae3d), word 1 = a xor-shift-multiply of word 0;
-    key & 3 selects (word 0 low, word 0 high, word 1 low, word 1 high) 16 bits; kept iff that sample >= thresh"""
+    keys of the counter h = rand_base(seed, stream) + q * 0x85ebca77 + (key >> 2) * 0xc2b2ae3d -> two 32-bit words; key & 3
+    selects (word 0 low, word 0 high, word 1 low, word 1 high) 16 bits; kept iff that sample >= thresh"""
     thresh = int(p * 65536.0 + 0.5)
     r = np.asarray(rows, dtype=np.uint32)[:, None]
     c = np.asarray(cols, dtype=np.uint32)[None, :]
     shape = (r.shape[0], c.shape[1])
-    w0 = rand_u32(seed, stream, np.broadcast_to(r, shape), np.broadcast_to(c >> _M(2), shape))
     with np.errstate(over='ignore'):
-        x = w0 ^ (w0 >> _M(15))
-        x = (x * _M(0x2c1b3c6d)).astype(np.uint32)
-        w1 = x ^ (x >> _M(12))
+        seed, stream = np.uint32(seed), np.uint32(stream)
+        base = fmix32(np.asarray(seed ^ np.uint32((int(stream) * 0x9e3779b1) & 0xffffffff), dtype=np.uint32))
+        h = (base + np.broadcast_to(r, shape) * _M(0x85ebca77) + np.broadcast_to(c >> _M(2), shape) * _M(0xc2b2ae3d)).astype(np.uint32)
+    w0, w1 = drop4_words(h)
     j = np.broadcast_to(c & _M(3), shape)
     w = np.where((j & _M(2)) != 0, w1, w0)
     r16 = np.where((j & _M(1)) != 0, w >> _M(16), w & _M(0xffff))
