@@ -344,16 +344,18 @@ struct AttnArgs {
 
 // scores of one 64-key tile for this wave's 16 query rows, S^T layout: s[t][r] <-> key perm_row(t, 4g+r), q = l&15
 __device__ __forceinline__ void score_tile(const unsigned char* Kt, const bf16x8 (&qf)[2], int l15, int g, f32x4 (&s)[4]) {
+    // the two MFMAs of a 16-key block accumulate into the same registers: issued back to back the second one waits out the
+    // first one's latency (the compiler pads with s_nop 6-7).  All four blocks' first halves go first, then the second halves:
+    // four MFMAs between a result and its use
+    bf16x8 kf[2][4];
 #pragma unroll
-    for (int t = 0; t < 4; ++t) {
-        s[t] = f32x4{0.f, 0.f, 0.f, 0.f};
-        const int row = 16 * t + l15;            // tile stored with tile_sstore_perm
+    for (int kk = 0; kk < 2; ++kk)
 #pragma unroll
-        for (int kk = 0; kk < 2; ++kk) {
-            bf16x8 kf = tile_frag(Kt, row, kk * 4 + g);
-            s[t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(kf, qf[kk], s[t], 0, 0, 0);
-        }
-    }
+        for (int t = 0; t < 4; ++t) kf[kk][t] = tile_frag(Kt, 16 * t + l15, kk * 4 + g);      // tile stored with tile_sstore_perm
+#pragma unroll
+    for (int t = 0; t < 4; ++t) s[t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(kf[0][t], qf[0], f32x4{0.f, 0.f, 0.f, 0.f}, 0, 0, 0);
+#pragma unroll
+    for (int t = 0; t < 4; ++t) s[t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(kf[1][t], qf[1], s[t], 0, 0, 0);
 }
 
 
@@ -532,10 +534,9 @@ constexpr int RSTAGE = 16384, RKM = 4096;
 
 template <bool DROP, bool SHARE, int RING>       // RING stages: tiles are issued RING - 1 ahead
 __global__ __launch_bounds__(256, 2) void attn_fwd_ring_kernel(AttnArgs p) {
-    __shared__ __attribute__((aligned(16))) unsigned char smem[RING * RSTAGE + RKM + 4 * 256];
+    __shared__ __attribute__((aligned(16))) unsigned char smem[RING * RSTAGE + RKM];
     lds_declare(smem, sizeof(smem));
     unsigned char* const kms = smem + RING * RSTAGE;                 // key mask of this batch row (Npad bytes)
-    unsigned long long* const bal = (unsigned long long*)(smem + RING * RSTAGE + RKM);     // [wave][2][16] ballot words
     const int tid = threadIdx.x, lane = tid & 63, wave = uniform_i(tid >> 6);
     const int l15 = lane & 15, g = lane >> 4;
     const int q0 = blockIdx.x * 64, h = blockIdx.y, b = blockIdx.z;
@@ -545,7 +546,10 @@ __global__ __launch_bounds__(256, 2) void attn_fwd_ring_kernel(AttnArgs p) {
     const unsigned dstream = attn_stream(p.stream_id, (unsigned)bh);
     const int ntiles = (p.N + 63) / 64;
 
-    for (int i = tid * 16; i < p.Npad; i += 256 * 16) st<u32x4>(kms + i, ld<u32x4>(p.kmask + (long)b * p.Npad + i));
+    // one BYTE of mask bits per 8 keys (the 8 mask bytes squeezed once per workgroup; squeezing them per tile and lane cost two
+    // 64-bit multiplies = six quarter-rate v_mul per tile in this loop)
+    for (int j = tid; j < p.Npad / 8; j += 256) kms[j] = (unsigned char)mask_bits(ld<unsigned long long>(p.kmask + (long)b * p.Npad + j * 8));
+    wait_lgkm0();                 // (the first barrier of the tile loop is a raw one: it publishes what has been WRITTEN)
 
     bf16x8 qf[2];
 #pragma unroll
@@ -584,7 +588,6 @@ __global__ __launch_bounds__(256, 2) void attn_fwd_ring_kernel(AttnArgs p) {
     const ClampPoly cp = clamp_poly(kx, cl2);
     const unsigned hrow = rand_base(p.seed_dev ? *p.seed_dev : p.seed, dstream) + (unsigned)q * 0x85ebca77u;
     const unsigned hlane = hrow + (unsigned)(2 * g) * 0xc2b2ae3du;
-    unsigned long long* const wbal = bal + wave * 32;
 
     // every ordinary global load of the prologue must have been waited for BEFORE the first LDS-DMA is issued: the
     // compiler counts vmcnt in order, so a Q fragment first used inside the loop would make it drain the whole prefetch
@@ -607,8 +610,7 @@ __global__ __launch_bounds__(256, 2) void attn_fwd_ring_kernel(AttnArgs p) {
         const unsigned char* Vt = Kt + 8192;
         f32x4 s[4];
         score_tile(Kt, qf, l15, g, s);
-        const unsigned km = mask_bits(ld<unsigned long long>(kms + k0 + g * 8)) |
-                            (mask_bits(ld<unsigned long long>(kms + k0 + 32 + g * 8)) << 8);
+        const unsigned km = (unsigned)kms[(k0 >> 3) + g] | ((unsigned)kms[(k0 >> 3) + 4 + g] << 8);
         const bool allk = wave_all(km == 0xffffu);
         if (wave_all(abs_max16(s) * kx <= TANH_POLY_MAX)) {
 #pragma unroll
@@ -656,16 +658,18 @@ __global__ __launch_bounds__(256, 2) void attn_fwd_ring_kernel(AttnArgs p) {
             for (int r = 0; r < 4; ++r) s[t][r] = pr[r];
         }
         if (DROP && SHARE) {
-            // the 16 compare masks of this tile: lane 0 parks them in LDS, lanes 0-15 write them out as one 128-byte store
-            unsigned long long* wb = wbal + (kt & 1) * 16;
-            if (lane == 0) {
+            // the 16 compare masks of this tile (SGPR pairs): mask i is written into lane i's registers (v_writelane), lanes 0-15
+            // store them as one 128-byte line.  (Round 3 parked them in LDS through lane 0: 33 v_mov + 8 ds_write_b128 under an
+            // exec mask, a wave barrier and a read back per tile.)
+            unsigned blo = 0, bhi = 0;
 #pragma unroll
-                for (int i = 0; i < 16; ++i) wb[i] = mk[i];
+            for (int i = 0; i < 16; ++i) {
+                blo = wave_writelane(blo, (unsigned)mk[i], i);
+                bhi = wave_writelane(bhi, (unsigned)(mk[i] >> 32), i);
             }
-            wave_sync();
             if (lane < 16) {
                 unsigned long long* dropw = p.dropbits + ((((long)bh * ntiles + kt) * ntiles + blockIdx.x) * 4 + wave) * 16;
-                dropw[lane] = wb[lane];
+                dropw[lane] = (unsigned long long)blo | ((unsigned long long)bhi << 32);
             }
         }
 #pragma unroll
@@ -901,7 +905,9 @@ __global__ __launch_bounds__(256, 3) void attn_bwd_dq_ring_kernel(AttnArgs p) {
     const unsigned dstream = attn_stream(p.stream_id, (unsigned)bh);
     const int ntiles = (p.N + 63) / 64;
 
-    for (int i = tid * 16; i < p.Npad; i += 256 * 16) st<u32x4>(kms + i, ld<u32x4>(p.kmask + (long)b * p.Npad + i));
+    // one BYTE of mask bits per 8 keys (the 8 mask bytes squeezed once per workgroup; squeezing them per tile and lane cost two
+    // 64-bit multiplies = six quarter-rate v_mul per tile in this loop)
+    for (int j = tid; j < p.Npad / 8; j += 256) kms[j] = (unsigned char)mask_bits(ld<unsigned long long>(p.kmask + (long)b * p.Npad + j * 8));
 
     bf16x8 qf[2], dof[2];
 #pragma unroll
@@ -962,8 +968,7 @@ __global__ __launch_bounds__(256, 3) void attn_bwd_dq_ring_kernel(AttnArgs p) {
         if (kt + 1 < ntiles) issue(kt + 1, (kt + 1) & 1);
         const unsigned char* Kt = smem + (kt & 1) * RSTAGE;
         const unsigned char* Vr = Kt + 8192;
-        const unsigned km = mask_bits(ld<unsigned long long>(kms + k0 + g * 8)) |
-                            (mask_bits(ld<unsigned long long>(kms + k0 + 32 + g * 8)) << 8);
+        const unsigned km = (unsigned)kms[(k0 >> 3) + g] | ((unsigned)kms[(k0 >> 3) + 4 + g] << 8);
         const bool allk = wave_all(km == 0xffffu);
         const unsigned long long* dropw = (DROP && SHARE)
             ? p.dropbits + ((((long)bh * ntiles + kt) * ntiles + blockIdx.x) * 4 + wave) * 16 : nullptr;
@@ -976,19 +981,34 @@ __global__ __launch_bounds__(256, 3) void attn_bwd_dq_ring_kernel(AttnArgs p) {
                 lds_tr_issue(khi[ct], Kt + trc[ct], kk2 * (32 * 128) + 16 * 128);
             }
             float dsv[2][4];
+            // scores and dP of both 16-key blocks of this half first, the first reduction halves of all four products before the
+            // second ones (an accumulating MFMA issued right behind its predecessor waits out its latency)
+            f32x4 st2[2], dp2[2];
+            {
+                bf16x8 kfr[2][2], vfr[2][2];
+#pragma unroll
+                for (int kk = 0; kk < 2; ++kk)
+#pragma unroll
+                    for (int tt = 0; tt < 2; ++tt) {
+                        kfr[kk][tt] = tile_frag(Kt, 16 * (2 * kk2 + tt) + l15, kk * 4 + g);
+                        vfr[kk][tt] = tile_frag(Vr, 16 * (2 * kk2 + tt) + l15, kk * 4 + g);
+                    }
+#pragma unroll
+                for (int tt = 0; tt < 2; ++tt) {
+                    st2[tt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(kfr[0][tt], qf[0], f32x4{0.f, 0.f, 0.f, 0.f}, 0, 0, 0);
+                    dp2[tt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(vfr[0][tt], dof[0], f32x4{0.f, 0.f, 0.f, 0.f}, 0, 0, 0);      // dP^T = V . dO^T
+                }
+#pragma unroll
+                for (int tt = 0; tt < 2; ++tt) {
+                    st2[tt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(kfr[1][tt], qf[1], st2[tt], 0, 0, 0);
+                    dp2[tt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(vfr[1][tt], dof[1], dp2[tt], 0, 0, 0);
+                }
+            }
 #pragma unroll
             for (int tt = 0; tt < 2; ++tt) {
                 const int t = 2 * kk2 + tt;
                 // s[r] <-> key perm_row(t, 4g+r), q = l&15
-                f32x4 st_ = {0.f, 0.f, 0.f, 0.f}, dpt = {0.f, 0.f, 0.f, 0.f};
-                const int row = 16 * t + l15;
-#pragma unroll
-                for (int kk = 0; kk < 2; ++kk) {
-                    bf16x8 kfr = tile_frag(Kt, row, kk * 4 + g);
-                    bf16x8 vfr = tile_frag(Vr, row, kk * 4 + g);
-                    st_ = __builtin_amdgcn_mfma_f32_16x16x32_bf16(kfr, qf[kk], st_, 0, 0, 0);
-                    dpt = __builtin_amdgcn_mfma_f32_16x16x32_bf16(vfr, dof[kk], dpt, 0, 0, 0);      // dP^T = V . dO^T
-                }
+                const f32x4 st_ = st2[tt], dpt = dp2[tt];
                 const float am = fmaxf(fmaxf(fabsf(st_[0]), fabsf(st_[1])), fmaxf(fabsf(st_[2]), fabsf(st_[3])));
                 const bool small = wave_all(am * kx <= TANH_POLY_MAX);
                 float ks[4] = {1.f, 1.f, 1.f, 1.f};
@@ -1216,6 +1236,8 @@ __global__ __launch_bounds__(NW * 64, 2) void attn_bwd_dkv_kernel(AttnArgs p) {
 // Rows past the end of the sequence are read from row N - 1 and switched off through lse = 1e30 (p = exp2(-1e30) = 0).
 constexpr int DSTAGE = 2 * 8192 + 512;
 
+// (three waves per SIMD: with dropout masks handed over it needs 152 VGPRs.  Compiled for four -- 128 VGPRs, 24 dwords spilled
+//  into the loop -- the backward of a cfg3 attention call took 366 us instead of 282, profiles/r04_attn_micro_ab.txt)
 template <bool DROP, bool SHARE>
 __global__ __launch_bounds__(256, 3) void attn_bwd_dkv_ring_kernel(AttnArgs p) {
     __shared__ __attribute__((aligned(16))) unsigned char smem[2 * DSTAGE];
@@ -1325,18 +1347,32 @@ __global__ __launch_bounds__(256, 3) void attn_bwd_dkv_ring_kernel(AttnArgs p) {
 #pragma unroll
         for (int kk2 = 0; kk2 < 2; ++kk2) {
             float pd[2][4], dsv[2][4];
+            // (all four products' first reduction halves before the second ones: see attn_bwd_dq_ring_kernel)
+            f32x4 st2[2], dp2[2];
+            {
+                bf16x8 qfr[2][2], dofr[2][2];
+#pragma unroll
+                for (int kk = 0; kk < 2; ++kk)
+#pragma unroll
+                    for (int tt = 0; tt < 2; ++tt) {
+                        qfr[kk][tt] = tile_frag(Qt, 16 * (2 * kk2 + tt) + l15, kk * 4 + g);
+                        dofr[kk][tt] = tile_frag(dOt, 16 * (2 * kk2 + tt) + l15, kk * 4 + g);
+                    }
+#pragma unroll
+                for (int tt = 0; tt < 2; ++tt) {
+                    st2[tt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(qfr[0][tt], kf[0], f32x4{0.f, 0.f, 0.f, 0.f}, 0, 0, 0);
+                    dp2[tt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(dofr[0][tt], vf[0], f32x4{0.f, 0.f, 0.f, 0.f}, 0, 0, 0);
+                }
+#pragma unroll
+                for (int tt = 0; tt < 2; ++tt) {
+                    st2[tt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(qfr[1][tt], kf[1], st2[tt], 0, 0, 0);
+                    dp2[tt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(dofr[1][tt], vf[1], dp2[tt], 0, 0, 0);
+                }
+            }
 #pragma unroll
             for (int tt = 0; tt < 2; ++tt) {
                 const int t = 2 * kk2 + tt;
-                f32x4 st_ = {0.f, 0.f, 0.f, 0.f}, dpt = {0.f, 0.f, 0.f, 0.f};
-                const int row = 16 * t + l15;
-#pragma unroll
-                for (int kk = 0; kk < 2; ++kk) {
-                    bf16x8 qfr = tile_frag(Qt, row, kk * 4 + g);
-                    bf16x8 dofr = tile_frag(dOt, row, kk * 4 + g);
-                    st_ = __builtin_amdgcn_mfma_f32_16x16x32_bf16(qfr, kf[kk], st_, 0, 0, 0);
-                    dpt = __builtin_amdgcn_mfma_f32_16x16x32_bf16(dofr, vf[kk], dpt, 0, 0, 0);
-                }
+                const f32x4 st_ = st2[tt], dpt = dp2[tt];
                 const float am = fmaxf(fmaxf(fabsf(st_[0]), fabsf(st_[1])), fmaxf(fabsf(st_[2]), fabsf(st_[3])));
                 const bool small = wave_all(am * kx <= TANH_POLY_MAX);
                 const int qi0 = perm_row(t, 4 * g);

@@ -117,6 +117,14 @@ __device__ __forceinline__ bool wave_all(bool pred) { return __builtin_amdgcn_ba
 // v_cndmask as its select operand (no per-lane unpacking)
 __device__ __forceinline__ unsigned long long wave_ballot(bool pred) { return __builtin_amdgcn_ballot_w64(pred); }
 __device__ __forceinline__ bool wave_inverse_ballot(unsigned long long m) { return __builtin_amdgcn_inverse_ballot_w64(m); }
+// v_writelane_b32: `old` with the register of lane `lane_sel` (a compile-time constant here) replaced by the wave-uniform `val`
+// (inline assembly: clang declares the writelane builtin for the device pass only, and this header is also seen by the host pass.
+//  The data operand is an SGPR a v_cmp may just have written: the ISA lists a wait-state requirement only for an SGPR used as
+//  the LANE SELECT of v_readlane / v_writelane, which is an immediate here)
+__device__ __forceinline__ unsigned wave_writelane(unsigned old, unsigned val, int lane_sel) {
+    asm volatile("v_writelane_b32 %0, %1, %2" : "+v"(old) : "s"(val), "n"(lane_sel));
+    return old;
+}
 // 64-bit load through the constant address space (s_load_dwordx2 when the address is wave-uniform), see sload()
 __device__ __forceinline__ unsigned long long sload64(const unsigned long long* p) {
     typedef const __attribute__((address_space(4))) unsigned long long* cp_t;
@@ -125,6 +133,8 @@ __device__ __forceinline__ unsigned long long sload64(const unsigned long long* 
 
 // counted wait on outstanding vector-memory ops (LDS-DMA included) and a raw workgroup barrier that does NOT drain
 // them: lets global_load_lds prefetches stay in flight across barriers (cdna_hip_programming.md T3+T4)
+// this wave's LDS operations (and scalar loads) have completed: what a raw barrier does NOT wait for
+__device__ __forceinline__ void wait_lgkm0() { asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); }
 template <int N> __device__ __forceinline__ void wait_vmcnt() { asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory"); }
 __device__ __forceinline__ void barrier_keep_vm() {
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");

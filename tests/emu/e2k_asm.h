@@ -60,10 +60,12 @@ inline unsigned long long wave_ballot(bool pred) {
     return v;
 }
 inline bool wave_inverse_ballot(unsigned long long m) { return (m >> emu::lane_id()) & 1ull; }
+inline unsigned wave_writelane(unsigned old, unsigned val, int lane_sel) { return emu::lane_id() == lane_sel ? val : old; }      // (val is wave-uniform)
 inline unsigned long long sload64(const unsigned long long* p) { return *p; }
 inline float fast_exp2(float x) { return exp2f(x); }
 inline float fast_rcp(float x) { return 1.0f / x; }
 
+inline void wait_lgkm0() {}
 template <int N> inline void wait_vmcnt() { emu::land_pending(N); }
 inline void barrier_keep_vm() { emu::block_rendezvous(); }
 inline void barrier_raw() { emu::block_rendezvous(); }
