@@ -1315,14 +1315,14 @@ __global__ __launch_bounds__(256, 3) void attn_bwd_dkv_ring_kernel(AttnArgs p) {
     // (t', g', r') the position of THIS key in the forward's key permutation: one 64-bit word per (t>>1) covers
     // all eight (t&1, r) of it.  The words of tile qt + 1 are fetched while tile qt is computed.
     const int pos = wave * 16 + l15;
-    const int dbit0 = 16 * ((pos >> 3) & 3) + 8 * (g & 1);
-    const unsigned long long* dbase = nullptr;
-    unsigned long long dnext[2] = {0ull, 0ull};
+    const int dbit0 = 16 * ((pos >> 3) & 3) + 8 * (g & 1);        // (a multiple of 8: the eight bits are ONE BYTE of the word)
+    const unsigned char* dbase = nullptr;
+    unsigned dnext[2] = {0u, 0u};
     if (DROP && SHARE) {
         const int tf = 2 * (pos >> 5) + ((pos >> 2) & 1), rf = pos & 3;
-        dbase = p.dropbits + ((((long)bh * ntiles + kt64) * ntiles) * 4 + (g >> 1)) * 16 + 4 * tf + rf;
+        dbase = (const unsigned char*)(p.dropbits + ((((long)bh * ntiles + kt64) * ntiles) * 4 + (g >> 1)) * 16 + 4 * tf + rf) + (dbit0 >> 3);
         dnext[0] = dbase[0];
-        dnext[1] = dbase[2 * 16];
+        dnext[1] = dbase[2 * 16 * 8];
     }
     // every ordinary global load of the prologue is waited for BEFORE the first LDS-DMA (see attn_fwd_ring_kernel)
     asm volatile("" ::"v"(kf[0]), "v"(kf[1]), "v"(vf[0]), "v"(vf[1]), "v"(hkey), "v"(kkeep));
@@ -1331,11 +1331,11 @@ __global__ __launch_bounds__(256, 3) void attn_bwd_dkv_ring_kernel(AttnArgs p) {
         const int q0 = qt * 64;
         wait_vmcnt<0>();                 // tile qt has landed for this wave ...
         barrier_raw();                   // ... and for every wave; everyone has finished tile qt - 1
-        const unsigned long long dword[2] = {dnext[0], dnext[1]};
+        const unsigned dword[2] = {dnext[0], dnext[1]};
         if (qt + 1 < ntiles) {
             if (DROP && SHARE) {
-                dnext[0] = dbase[(long)(qt + 1) * 64];
-                dnext[1] = dbase[(long)(qt + 1) * 64 + 2 * 16];
+                dnext[0] = dbase[(long)(qt + 1) * 64 * 8];
+                dnext[1] = dbase[((long)(qt + 1) * 64 + 2 * 16) * 8];
             }
             issue(qt + 1, (qt + 1) & 1);
         }
@@ -1347,6 +1347,7 @@ __global__ __launch_bounds__(256, 3) void attn_bwd_dkv_ring_kernel(AttnArgs p) {
 #pragma unroll
         for (int kk2 = 0; kk2 < 2; ++kk2) {
             float pd[2][4], dsv[2][4];
+            const unsigned dbits = dword[kk2];       // this lane's eight keep bits of the half tile (one byte of the forward's ballot word)
             // (all four products' first reduction halves before the second ones: see attn_bwd_dq_ring_kernel)
             f32x4 st2[2], dp2[2];
             {
@@ -1387,7 +1388,7 @@ __global__ __launch_bounds__(256, 3) void attn_bwd_dkv_ring_kernel(AttnArgs p) {
 #pragma unroll
                     for (int r = 0; r < 4; ++r) {
                         if (SHARE) {
-                            ks[r] = ((dword[kk2] >> (dbit0 + 4 * tt + r)) & 1ull) ? p.inv_keep : 0.f;
+                            ks[r] = ((dbits >> (4 * tt + r)) & 1u) ? p.inv_keep : 0.f;
                         } else {
                             unsigned w0, w1;          // (hkey already holds base + (key >> 2) * 0xc2b2ae3d)
                             drop4(hkey + (unsigned)(q0 + qi0 + r) * 0x85ebca77u, 0u, w0, w1);
@@ -1417,17 +1418,27 @@ __global__ __launch_bounds__(256, 3) void attn_bwd_dkv_ring_kernel(AttnArgs p) {
             }
             bf16x8 pf = pack_frag(pd[0], pd[1]);
             bf16x8 df = pack_frag(dsv[0], dsv[1]);
-            s16x4_ dlo[4], dhi[4], qlo[4], qhi[4];
-            tr_issue4(dlo, dhi, dOt, kk2);
-            tr_issue4(qlo, qhi, Qt, kk2);
-            lds_tr_wait(dlo[0], dhi[0], dlo[1], dhi[1], dlo[2], dhi[2], dlo[3], dhi[3],
-                        qlo[0], qhi[0], qlo[1], qhi[1], qlo[2], qhi[2], qlo[3], qhi[3]);
+            // dO^T fragments -> dV, then Q^T fragments -> dK: the two groups of transposing reads are not alive together
+            // (16 registers less at the kernel's pressure point)
+            {
+                s16x4_ dlo[4], dhi[4];
+                tr_issue4(dlo, dhi, dOt, kk2);
+                lds_tr_wait(dlo[0], dhi[0], dlo[1], dhi[1], dlo[2], dhi[2], dlo[3], dhi[3]);
 #pragma unroll
-            for (int ct = 0; ct < 4; ++ct) {
-                bf16x8 dotf = __builtin_shufflevector(dlo[ct], dhi[ct], 0, 1, 2, 3, 4, 5, 6, 7);
-                bf16x8 qtf = __builtin_shufflevector(qlo[ct], qhi[ct], 0, 1, 2, 3, 4, 5, 6, 7);
-                dv[ct] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(dotf, pf, dv[ct], 0, 0, 0);
-                dk[ct] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(qtf, df, dk[ct], 0, 0, 0);
+                for (int ct = 0; ct < 4; ++ct) {
+                    bf16x8 dotf = __builtin_shufflevector(dlo[ct], dhi[ct], 0, 1, 2, 3, 4, 5, 6, 7);
+                    dv[ct] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(dotf, pf, dv[ct], 0, 0, 0);
+                }
+            }
+            {
+                s16x4_ qlo[4], qhi[4];
+                tr_issue4(qlo, qhi, Qt, kk2);
+                lds_tr_wait(qlo[0], qhi[0], qlo[1], qhi[1], qlo[2], qhi[2], qlo[3], qhi[3]);
+#pragma unroll
+                for (int ct = 0; ct < 4; ++ct) {
+                    bf16x8 qtf = __builtin_shufflevector(qlo[ct], qhi[ct], 0, 1, 2, 3, 4, 5, 6, 7);
+                    dk[ct] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(qtf, df, dk[ct], 0, 0, 0);
+                }
             }
         }
     }
