@@ -11,7 +11,8 @@ import re
 from pathlib import Path
 
 _PKG = Path(__file__).resolve().parent
-_LIB_PATH = _PKG / 'libe2k.so'
+# E2K_LIB: another build of the SAME ABI (tools/ab/build_variants.py: same-box A/B of kernel versions); never a fallback
+_LIB_PATH = Path(os.environ['E2K_LIB']) if os.environ.get('E2K_LIB') else _PKG / 'libe2k.so'
 
 
 def _find_header() -> Path:
