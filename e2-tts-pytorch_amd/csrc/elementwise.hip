@@ -107,10 +107,10 @@ template <int VEC, int NCH> int launch_norm_fwd(const NormArgs& a, hipStream_t s
 }
 template <int VEC, int NCH> int launch_norm_bwd(const NormArgs& a, hipStream_t st) {
     const int nb = (a.M + a.rows_per_batch - 1) / a.rows_per_batch;
-    // ~512 workgroups in all: every workgroup ends with D atomic adds into d(gamma), and with one gamma row (plain
+    // ~256 workgroups in all: every workgroup ends with D atomic adds into d(gamma), and with one gamma row (plain
     // RMSNorm) all of them hit the same D addresses
     int per = (min(a.rows_per_batch, a.M) + 3) / 4;
-    int cap = (512 + nb - 1) / nb;
+    int cap = (256 + nb - 1) / nb;          // (256 against 512 / 1024 workgroups: 1.64 / 1.78 / 2.63 ms per cfg3 step, profiles/r04_row_grid_ab.txt)
     if (per > cap) per = cap;
     hipLaunchKernelGGL((rmsnorm_bwd_kernel<VEC, NCH>), dim3(per, nb), dim3(256), 0, st, a);
     return 0;
@@ -134,11 +134,22 @@ __global__ __launch_bounds__(256) void gate_bwd_kernel(GateArgs p) {
     load_row_f32<VEC, NCH>(p.g + (long)b * p.ldg, lane, g);
 #pragma unroll
     for (int e = 0; e < EPL; ++e) acc[e] = 0.f;
-    for (int i = blockIdx.x * 4 + wave; i < nrows; i += gridDim.x * 4) {
+    // the next row of this wave is fetched (packed bf16 pairs) while the current one is processed
+    unsigned ry[EPL / 2], rdy[EPL / 2];
+    const int step = gridDim.x * 4;
+    int i = blockIdx.x * 4 + wave;
+    auto prefetch = [&](int ii) {
+        const long row = row0 + min(ii, nrows - 1);
+        load_raw_row<VEC, NCH>(p.y + row * D, lane, ry);
+        load_raw_row<VEC, NCH>(p.dy + row * D, lane, rdy);
+    };
+    if (i < nrows) prefetch(i);
+    for (; i < nrows; i += step) {
         const long row = row0 + i;
         float y[EPL], dy[EPL];
-        load_row<VEC, NCH>(p.y + row * D, lane, y);
-        load_row<VEC, NCH>(p.dy + row * D, lane, dy);
+        unpack_raw_row<EPL>(ry, y);
+        unpack_raw_row<EPL>(rdy, dy);
+        prefetch(i + step);
 #pragma unroll
         for (int e = 0; e < EPL; ++e) { acc[e] = fmaf(dy[e], y[e], acc[e]); dy[e] *= g[e]; }
         store_row<VEC, NCH>(p.dao + row * D, lane, dy);
@@ -154,7 +165,7 @@ __global__ __launch_bounds__(256) void gate_bwd_kernel(GateArgs p) {
 template <int VEC, int NCH> int launch_gate_bwd(const GateArgs& a, hipStream_t st) {
     const int nb = (a.M + a.rows_per_batch - 1) / a.rows_per_batch;
     int per = (min(a.rows_per_batch, a.M) + 3) / 4;
-    int cap = (1024 + nb - 1) / nb;
+    int cap = (512 + nb - 1) / nb;          // (512 workgroups + the row prefetch: 0.72 ms per cfg3 step against 0.97 with 1024 and none)
     if (per > cap) per = cap;
     hipLaunchKernelGGL((gate_bwd_kernel<VEC, NCH>), dim3(per, nb), dim3(256), 0, st, a);
     return 0;
