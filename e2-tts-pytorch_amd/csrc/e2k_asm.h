@@ -159,6 +159,11 @@ __device__ __forceinline__ void barrier_raw() {
 __device__ __forceinline__ void wave_sync() { __builtin_amdgcn_wave_barrier(); }
 template <int P> __device__ __forceinline__ void set_prio() { __builtin_amdgcn_s_setprio(P); }
 __device__ __forceinline__ void sched_fence() { __builtin_amdgcn_sched_barrier(0); }
+// Pins a value into its registers at this point of the program: arithmetic that produced it cannot sink below, arithmetic that uses
+// it cannot rise above (sched_barrier alone orders memory operations only: instruction selection places pure arithmetic where it
+// likes).  With order_memory() a fully unrolled loop keeps the load / compute interleaving it was written with.  No instructions.
+template <class T> __device__ __forceinline__ void pin_vgpr(T& x) { asm volatile("" : "+v"(x)); }
+__device__ __forceinline__ void order_memory() { asm volatile("" ::: "memory"); }
 
 // Names the static LDS array that this kernel's global_load_lds copies land in.  No code on the GPU; the host model of the
 // kernels (tests/emu) records the range and aborts on an LDS-DMA whose destination leaves it (an out-of-range destination

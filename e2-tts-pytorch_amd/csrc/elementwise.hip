@@ -45,10 +45,14 @@ __global__ __launch_bounds__(256) void rmsnorm_fwd_kernel(NormArgs p) {
 }
 
 // grid (blocks_per_batch, nb): every block stays inside one batch row-group so d(gamma) reduces in registers
+// RB_WAVES waves per workgroup, each with one row in flight ahead of the one it works on: the bytes in flight are what bounds these
+// kernels (4 waves x 256 workgroups x 4 KB = 4 MB, about 2 us of latency: 2-3 TB/s), and more workgroups mean more tail atomics
+constexpr int RB_WAVES = 8;
+constexpr int RMS_BWD_WGS = 256;
 template <int VEC, int NCH>
-__global__ __launch_bounds__(256) void rmsnorm_bwd_kernel(NormArgs p) {
+__global__ __launch_bounds__(64 * RB_WAVES) void rmsnorm_bwd_kernel(NormArgs p) {
     constexpr int EPL = VEC * NCH, D = 64 * EPL;
-    __shared__ float red[4][D];
+    __shared__ float red[RB_WAVES][D];
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int b = blockIdx.y;
     const int row0 = b * p.rows_per_batch;
@@ -61,8 +65,8 @@ __global__ __launch_bounds__(256) void rmsnorm_bwd_kernel(NormArgs p) {
     // the next row of this wave is fetched (packed bf16 pairs) while the current one is processed
     unsigned rx[EPL / 2], rdy[EPL / 2];
     float rnn = 0.f;
-    const int step = gridDim.x * 4;
-    int i = blockIdx.x * 4 + wave;
+    const int step = gridDim.x * RB_WAVES;
+    int i = blockIdx.x * RB_WAVES + wave;
     auto prefetch = [&](int ii) {
         const long row = row0 + min(ii, nrows - 1);
         load_raw_row<VEC, NCH>(p.x + row * D, lane, rx);
@@ -96,8 +100,12 @@ __global__ __launch_bounds__(256) void rmsnorm_bwd_kernel(NormArgs p) {
 #pragma unroll
         for (int v = 0; v < VEC; ++v) red[wave][c * 64 * VEC + lane * VEC + v] = dg[c * VEC + v];
     __syncthreads();
-    for (int d = threadIdx.x; d < D; d += 256)
-        atomicAdd(p.dgamma + (long)b * p.ldg + d, red[0][d] + red[1][d] + red[2][d] + red[3][d]);
+    for (int d = threadIdx.x; d < D; d += 64 * RB_WAVES) {
+        float sum = 0.f;
+#pragma unroll
+        for (int w = 0; w < RB_WAVES; ++w) sum += red[w][d];
+        atomicAdd(p.dgamma + (long)b * p.ldg + d, sum);
+    }
 }
 
 template <int VEC, int NCH> int launch_norm_fwd(const NormArgs& a, hipStream_t st) {
@@ -109,10 +117,10 @@ template <int VEC, int NCH> int launch_norm_bwd(const NormArgs& a, hipStream_t s
     const int nb = (a.M + a.rows_per_batch - 1) / a.rows_per_batch;
     // ~256 workgroups in all: every workgroup ends with D atomic adds into d(gamma), and with one gamma row (plain
     // RMSNorm) all of them hit the same D addresses
-    int per = (min(a.rows_per_batch, a.M) + 3) / 4;
-    int cap = (256 + nb - 1) / nb;          // (256 against 512 / 1024 workgroups: 1.64 / 1.78 / 2.63 ms per cfg3 step, profiles/r04_row_grid_ab.txt)
+    int per = (min(a.rows_per_batch, a.M) + RB_WAVES - 1) / RB_WAVES;
+    int cap = (RMS_BWD_WGS + nb - 1) / nb;  // (256 against 512 / 1024 workgroups: 1.64 / 1.78 / 2.63 ms per cfg3 step, profiles/r04_row_grid_ab.txt)
     if (per > cap) per = cap;
-    hipLaunchKernelGGL((rmsnorm_bwd_kernel<VEC, NCH>), dim3(per, nb), dim3(256), 0, st, a);
+    hipLaunchKernelGGL((rmsnorm_bwd_kernel<VEC, NCH>), dim3(per, nb), dim3(64 * RB_WAVES), 0, st, a);
     return 0;
 }
 
@@ -123,9 +131,9 @@ template <int VEC, int NCH> int launch_norm_bwd(const NormArgs& a, hipStream_t s
 struct GateArgs { const bf16_t* dy; const bf16_t* y; const float* g; bf16_t* dao; float* gsum; long ldg; int M, rows_per_batch; };
 
 template <int VEC, int NCH>
-__global__ __launch_bounds__(256) void gate_bwd_kernel(GateArgs p) {
+__global__ __launch_bounds__(64 * RB_WAVES) void gate_bwd_kernel(GateArgs p) {
     constexpr int EPL = VEC * NCH, D = 64 * EPL;
-    __shared__ float red[4][D];
+    __shared__ float red[RB_WAVES][D];
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int b = blockIdx.y;
     const int row0 = b * p.rows_per_batch;
@@ -136,8 +144,8 @@ __global__ __launch_bounds__(256) void gate_bwd_kernel(GateArgs p) {
     for (int e = 0; e < EPL; ++e) acc[e] = 0.f;
     // the next row of this wave is fetched (packed bf16 pairs) while the current one is processed
     unsigned ry[EPL / 2], rdy[EPL / 2];
-    const int step = gridDim.x * 4;
-    int i = blockIdx.x * 4 + wave;
+    const int step = gridDim.x * RB_WAVES;
+    int i = blockIdx.x * RB_WAVES + wave;
     auto prefetch = [&](int ii) {
         const long row = row0 + min(ii, nrows - 1);
         load_raw_row<VEC, NCH>(p.y + row * D, lane, ry);
@@ -159,15 +167,20 @@ __global__ __launch_bounds__(256) void gate_bwd_kernel(GateArgs p) {
 #pragma unroll
         for (int v = 0; v < VEC; ++v) red[wave][c * 64 * VEC + lane * VEC + v] = acc[c * VEC + v];
     __syncthreads();
-    for (int d = threadIdx.x; d < D; d += 256)
-        atomicAdd(p.gsum + (long)b * p.ldg + d, red[0][d] + red[1][d] + red[2][d] + red[3][d]);
+    for (int d = threadIdx.x; d < D; d += 64 * RB_WAVES) {
+        float sum = 0.f;
+#pragma unroll
+        for (int w = 0; w < RB_WAVES; ++w) sum += red[w][d];
+        atomicAdd(p.gsum + (long)b * p.ldg + d, sum);
+    }
 }
+constexpr int GATE_WGS = 2048 / RB_WAVES;
 template <int VEC, int NCH> int launch_gate_bwd(const GateArgs& a, hipStream_t st) {
     const int nb = (a.M + a.rows_per_batch - 1) / a.rows_per_batch;
-    int per = (min(a.rows_per_batch, a.M) + 3) / 4;
-    int cap = (512 + nb - 1) / nb;          // (512 workgroups + the row prefetch: 0.72 ms per cfg3 step against 0.97 with 1024 and none)
+    int per = (min(a.rows_per_batch, a.M) + RB_WAVES - 1) / RB_WAVES;
+    int cap = (GATE_WGS + nb - 1) / nb;     // (512 workgroups of 4 waves + the row prefetch: 0.72 ms per cfg3 step against 0.97 with 1024 and none)
     if (per > cap) per = cap;
-    hipLaunchKernelGGL((gate_bwd_kernel<VEC, NCH>), dim3(per, nb), dim3(256), 0, st, a);
+    hipLaunchKernelGGL((gate_bwd_kernel<VEC, NCH>), dim3(per, nb), dim3(64 * RB_WAVES), 0, st, a);
     return 0;
 }
 
@@ -433,22 +446,37 @@ __global__ __launch_bounds__(256) void dwconv_fwd_kernel(ConvArgs p) {
     }
     __syncthreads();
     const int cp = tid & 31, fg = tid >> 5;
-    f32x2_ w[KS];
-#pragma unroll
-    for (int k = 0; k < KS; ++k) w[k] = *reinterpret_cast<const f32x2_*>(&wl[k][cp * 2]);
+    // input row i meets the taps k = i - o of the 16 outputs: a window of 16 (+ 4) taps, one new tap per row out of LDS (all KS taps in
+    // registers were 62 of this kernel's 154 VGPRs)
+    constexpr int WIN = 16 + 4;         // + the rows of a chunk whose taps are fetched before its first row is used
+    f32x2_ w[WIN];
     const f32x2_ bb = *reinterpret_cast<const f32x2_*>(&bl[cp * 2]);
     f32x2_ a[16];
 #pragma unroll
     for (int o = 0; o < 16; ++o) a[o] = bb;
 #pragma unroll
-    for (int i = 0; i < 16 + KS - 1; ++i) {
-        const unsigned v = xt[fg * 16 + i][cp];
-        const f32x2_ xx = {bflo(v), bfhi(v)};
+    for (int i0 = 0; i0 < 16 + KS - 1; i0 += 4) {       // four rows at a time, pinned: left alone the compiler fetches all taps and rows first and runs one output's chain after the other
+        unsigned v[4];
 #pragma unroll
-        for (int o = 0; o < 16; ++o) {
-            const int k = i - o;
-            if (k >= 0 && k < KS) a[o] = __builtin_elementwise_fma(w[k], xx, a[o]);
+        for (int u = 0; u < 4; ++u) {
+            const int i = i0 + u;
+            if (i < KS) w[i % WIN] = *reinterpret_cast<const f32x2_*>(&wl[i][cp * 2]);
+            if (i < 16 + KS - 1) v[u] = xt[fg * 16 + i][cp];
         }
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            const int i = i0 + u;
+            if (i >= 16 + KS - 1) continue;
+            const f32x2_ xx = {bflo(v[u]), bfhi(v[u])};
+#pragma unroll
+            for (int o = 0; o < 16; ++o) {
+                const int k = i - o;
+                if (k >= 0 && k < KS) a[o] = __builtin_elementwise_fma(w[k % WIN], xx, a[o]);
+            }
+        }
+#pragma unroll
+        for (int o = 0; o < 16; ++o) pin_vgpr(a[o]);
+        order_memory();
     }
     bf16_t* pre = p.pre + ((long)b * p.N + n0 + fg * 16) * p.C + c0 + cp * 2;
     bf16_t* y = p.y + ((long)b * p.N + n0 + fg * 16) * p.C + c0 + cp * 2;
@@ -463,24 +491,27 @@ __global__ __launch_bounds__(256) void dwconv_fwd_kernel(ConvArgs p) {
 
 __device__ __forceinline__ float silu_grad(float x) { float s = sigmoidf_(x); return s * (1.f + x * (1.f - s)); }
 
+// Backward, round 4: d(pre-activation) tile in fp32, the masked input as the bf16 pairs it arrives in (row stride 36 words: the two
+// frame groups of a wave land in different bank halves), the flipped taps in LDS with a window of 8 in registers (as the forward).
+// All KS taps + all KS tap gradients in registers were 226 VGPRs = two workgroups per CU, whose load and arithmetic phases did not
+// overlap (1.0 TB/s of the kernel's bytes); now the tap gradients are the only long-lived registers.
+constexpr int XTS = CTC / 2 + 4;
 template <int KS>
-__global__ __launch_bounds__(256, 2) void dwconv_bwd_kernel(ConvArgs p) {
+__global__ __launch_bounds__(256, 3) void dwconv_bwd_kernel(ConvArgs p) {
     constexpr int PAD = KS / 2, ROWS = CTN + KS - 1;
-    __shared__ __attribute__((aligned(16))) float smem[2][ROWS][CTC];
-    float (*dpt)[CTC] = smem[0];        // d(pre-activation), frame n0 - PAD + j
-    float (*xt)[CTC] = smem[1];         // masked input,      frame n0 - PAD + j
-    static_assert(4 * (KS + 1) * CTC <= 2 * ROWS * CTC, "the gradient staging reuses the tile buffers");
+    __shared__ __attribute__((aligned(16))) float smem[ROWS * CTC + ROWS * XTS];
+    __shared__ __attribute__((aligned(16))) float wl[KS][CTC];      // flipped: wl[k][c] = w[c][KS - 1 - k]
+    float (*dpt)[CTC] = reinterpret_cast<float (*)[CTC]>(smem);                         // d(pre-activation), frame n0 - PAD + j
+    unsigned (*xt)[XTS] = reinterpret_cast<unsigned (*)[XTS]>(smem + ROWS * CTC);      // masked input,      frame n0 - PAD + j
+    static_assert(4 * (KS + 1) * CTC <= ROWS * CTC + ROWS * XTS, "the gradient staging reuses the tile buffers");
     const int tid = threadIdx.x;
     const int c0 = blockIdx.y * CTC, b = blockIdx.z;
     const int cp = tid & 31, fg = tid >> 5;
     const int ch = c0 + cp * 2;
+    for (int i = tid; i < CTC * KS; i += 256) wl[KS - 1 - i % KS][i / KS] = p.w[(long)c0 * KS + i];
     // channel pair (ch, ch+1) lives in the two halves of 64-bit register pairs: every FMA below is one v_pk_fma_f32
-    // whose operands are already adjacent (separate per-channel arrays cost a v_mov per operand to form the pairs)
-    f32x2_ w[KS];     // flipped
-#pragma unroll
-    for (int k = 0; k < KS; ++k) w[k] = f32x2_{p.w[(long)ch * KS + (KS - 1 - k)], p.w[(long)(ch + 1) * KS + (KS - 1 - k)]};
     // weight / bias gradient partials stay in registers over all frame tiles of this workgroup (p.tiles_per_block):
-    // one LDS + global atomic flush per workgroup instead of per tile
+    // one LDS + global flush per workgroup instead of per tile
     f32x2_ gw[KS], sb = {0.f, 0.f};
 #pragma unroll
     for (int k = 0; k < KS; ++k) gw[k] = f32x2_{0.f, 0.f};
@@ -488,9 +519,8 @@ __global__ __launch_bounds__(256, 2) void dwconv_bwd_kernel(ConvArgs p) {
     const int t_beg = blockIdx.x * p.tiles_per_block, t_end = min(ntiles, t_beg + p.tiles_per_block);
     for (int tile = t_beg; tile < t_end; ++tile) {
         const int n0 = tile * CTN;
-        __syncthreads();                  // previous tile fully consumed (also orders the dwl zero-fill)
-        // 8 channels (16 B) per item; the loads of two items (6 x 16 B) are in flight together (the weight / gradient
-        // registers of this kernel leave no room for more)
+        __syncthreads();                  // previous tile fully consumed
+        // 8 channels (16 B) per item; the loads of two items (6 x 16 B) are in flight together
         constexpr int ITEMS = ROWS * (CTC / 8), NIT = (ITEMS + 255) / 256;
 #pragma unroll
         for (int it0 = 0; it0 < NIT; it0 += 2) {
@@ -503,9 +533,8 @@ __global__ __launch_bounds__(256, 2) void dwconv_bwd_kernel(ConvArgs p) {
                 const int n = n0 - PAD + j;
                 // unconditional loads from a clamped row, mask byte fetched alongside (a load that depends on the mask
                 // byte costs a second memory latency per item)
-                const int nc = min(max(n, 0), p.N - 1), jc = min(j, ROWS - 1);
+                const int nc = min(max(n, 0), p.N - 1);
                 const long off = ((long)b * p.N + nc) * p.C + c0 + (i < ITEMS ? c8 : 0);
-                (void)jc;
                 rd[u] = ld<u32x4>(p.dy + off);
                 rp[u] = ld<u32x4>(p.pre + off);
                 rx[u] = ld<u32x4>(p.x + off);
@@ -517,37 +546,50 @@ __global__ __launch_bounds__(256, 2) void dwconv_bwd_kernel(ConvArgs p) {
                 const int i = tid + (it0 + u) * 256;
                 if (it0 + u >= NIT || i >= ITEMS) continue;
                 const int j = i / (CTC / 8), c8 = (i % (CTC / 8)) * 8;
-                float d[8], x[8];
+                float d[8];
 #pragma unroll
-                for (int e = 0; e < 8; ++e) { d[e] = 0.f; x[e] = 0.f; }
+                for (int e = 0; e < 8; ++e) d[e] = 0.f;
                 if (live[u]) {
                     float pr[8];
                     unpack8(rd[u], d);
                     unpack8(rp[u], pr);
-                    unpack8(rx[u], x);
 #pragma unroll
                     for (int e = 0; e < 8; ++e) d[e] *= silu_grad(pr[e]);
                 }
                 st<f32x4>(&dpt[j][c8], f32x4{d[0], d[1], d[2], d[3]});
                 st<f32x4>(&dpt[j][c8 + 4], f32x4{d[4], d[5], d[6], d[7]});
-                st<f32x4>(&xt[j][c8], f32x4{x[0], x[1], x[2], x[3]});
-                st<f32x4>(&xt[j][c8 + 4], f32x4{x[4], x[5], x[6], x[7]});
+                st<u32x4>(&xt[j][c8 / 2], live[u] ? rx[u] : u32x4{0u, 0u, 0u, 0u});
             }
         }
         __syncthreads();
         if (p.tune & 2) continue;
-        // dx[o] = sum_k' wflip[k'] dp_tile[o + k']
-        f32x2_ a[8];
+        // dx[o] = sum_k' wflip[k'] dp_tile[o + k']: row i meets the taps k' = i - o of the 8 outputs
+        constexpr int WIN = 8 + 4;
+        f32x2_ a[8], ww[WIN];
 #pragma unroll
         for (int o = 0; o < 8; ++o) a[o] = f32x2_{0.f, 0.f};
 #pragma unroll
-        for (int i = 0; i < 8 + KS - 1; ++i) {
-            const f32x2_ dd = ld<f32x2_>(&dpt[fg * 8 + i][cp * 2]);
+        for (int i0 = 0; i0 < 8 + KS - 1; i0 += 4) {        // four rows at a time, pinned (as the forward)
+            f32x2_ dd[4];
 #pragma unroll
-            for (int o = 0; o < 8; ++o) {
-                const int k = i - o;
-                if (k >= 0 && k < KS) a[o] = __builtin_elementwise_fma(w[k], dd, a[o]);
+            for (int u = 0; u < 4; ++u) {
+                const int i = i0 + u;
+                if (i < KS) ww[i % WIN] = ld<f32x2_>(&wl[i][cp * 2]);
+                if (i < 8 + KS - 1) dd[u] = ld<f32x2_>(&dpt[fg * 8 + i][cp * 2]);
             }
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+                const int i = i0 + u;
+                if (i >= 8 + KS - 1) continue;
+#pragma unroll
+                for (int o = 0; o < 8; ++o) {
+                    const int k = i - o;
+                    if (k >= 0 && k < KS) a[o] = __builtin_elementwise_fma(ww[k % WIN], dd[u], a[o]);
+                }
+            }
+#pragma unroll
+            for (int o = 0; o < 8; ++o) pin_vgpr(a[o]);
+            order_memory();
         }
 #pragma unroll
         for (int o = 0; o < 8; ++o) {
@@ -566,7 +608,8 @@ __global__ __launch_bounds__(256, 2) void dwconv_bwd_kernel(ConvArgs p) {
         }
 #pragma unroll
         for (int i = 0; i < 8 + KS - 1; ++i) {
-            const f32x2_ xx = ld<f32x2_>(&xt[fg * 8 + i][cp * 2]);
+            const unsigned xv = xt[fg * 8 + i][cp];
+            const f32x2_ xx = {bflo(xv), bfhi(xv)};
 #pragma unroll
             for (int o = 0; o < 8; ++o) {
                 const int k = i - o;
@@ -579,7 +622,7 @@ __global__ __launch_bounds__(256, 2) void dwconv_bwd_kernel(ConvArgs p) {
     // (dw, dbias) of the workgroup: the two frame groups of a wave (lanes l, l + 32: same channel pair) are added with a
     // shuffle, the four waves through plain LDS stores into the (now free) tile buffers.  LDS float atomics here
     // (8 adds per address) cost 42 of the kernel's 84 us at the cfg3 audio shape (tools/probes/conv_ablate.py).
-    float (*stage)[KS + 1][CTC] = reinterpret_cast<float (*)[KS + 1][CTC]>(&smem[0][0][0]);
+    float (*stage)[KS + 1][CTC] = reinterpret_cast<float (*)[KS + 1][CTC]>(smem);
     const int wv = tid >> 6, lane = tid & 63;
 #pragma unroll
     for (int k = 0; k <= KS; ++k) {
@@ -600,23 +643,34 @@ __global__ __launch_bounds__(256, 2) void dwconv_bwd_kernel(ConvArgs p) {
     }
 }
 
-// dw[c][k] += sum over (batch, x) of the workgroup partials; grid (C / 64, ceil(64 (ks + 1) / 256))
-__global__ __launch_bounds__(256) void conv_reduce_kernel(const float* ws, float* dw, float* dbias, int B, int nct, int gx, int KS) {
+// dw[c][k] += sum over (batch, x) of the workgroup partials; grid (C / 64, 64 (ks + 1) / 64) of ONE wave each: 512 single-wave
+// workgroups spread over the chip (128 workgroups of 256 threads with one running sum: 12-17 us for 4-6 MB of partials), four
+// independent sums per thread in a fixed order
+__global__ __launch_bounds__(64) void conv_reduce_kernel(const float* ws, float* dw, float* dbias, int B, int nct, int gx, int KS) {
     const int E = CTC * (KS + 1);
-    const int ct = blockIdx.x, i = blockIdx.y * 256 + threadIdx.x;
+    const int ct = blockIdx.x, i = blockIdx.y * 64 + threadIdx.x;
     if (i >= E) return;
-    float s = 0.f;
-    for (int b = 0; b < B; ++b)
-        for (int x = 0; x < gx; ++x) s += ws[(((long)b * nct + ct) * gx + x) * E + i];
+    float s4[4] = {0.f, 0.f, 0.f, 0.f};
+    for (int b = 0; b < B; ++b) {
+        const float* pb = ws + ((long)b * nct + ct) * gx * E + i;
+        int x = 0;
+        for (; x + 4 <= gx; x += 4) {
+#pragma unroll
+            for (int u = 0; u < 4; ++u) s4[u] += pb[(long)(x + u) * E];
+        }
+        for (; x < gx; ++x) s4[x & 3] += pb[(long)x * E];
+    }
+    const float s = (s4[0] + s4[1]) + (s4[2] + s4[3]);
     const int k = i / CTC, c = i % CTC;
     if (k < KS) dw[(long)(ct * CTC + c) * KS + k] += s;
     else dbias[ct * CTC + c] += s;
 }
 
+constexpr int CONV_BWD_WGS = 768;      // three workgroups per CU
 int conv_bwd_gx(int B, int N, int C, int tune) {
     // about 512 workgroups: fewer, longer workgroups cut the traffic of the (dw, dbias) partials
     const int ntiles = (N + CTN - 1) / CTN, cb = (C / CTC) * B;
-    int gx = (512 + cb - 1) / cb;
+    int gx = (CONV_BWD_WGS + cb - 1) / cb;
     if (tune >> 7) gx = tune >> 7;
     if (gx > ntiles) gx = ntiles;
     if (gx < 1) gx = 1;
@@ -634,7 +688,7 @@ template <int KS> int launch_conv(ConvArgs a, bool bwd, hipStream_t st) {
             grid.x = (ntiles + a.tiles_per_block - 1) / a.tiles_per_block;
             hipLaunchKernelGGL(dwconv_bwd_kernel<KS>, grid, block, 0, st, a);
             if (a.ws && !(a.tune & 1) && !a.defer_reduce)
-                hipLaunchKernelGGL(conv_reduce_kernel, dim3(a.C / CTC, (CTC * (KS + 1) + 255) / 256), dim3(256), 0, st,
+                hipLaunchKernelGGL(conv_reduce_kernel, dim3(a.C / CTC, KS + 1), dim3(64), 0, st,
                                    (const float*)a.ws, a.dw, a.dbias, a.B, a.C / CTC, (int)grid.x, KS);
         }
     } else {
@@ -819,7 +873,7 @@ static int dwconv_bwd_reduce_impl(const float* ws, float* dw, float* dbias, int 
     if (B <= 0 || N <= 0) return 0;
     if (!ws || !dw || !dbias || (C % CTC) || !(ks == 31 || ks == 15 || ks == 7 || ks == 3)) return E2K_ERR_ARG;
     const int gx = conv_bwd_gx(B, N, C, split >> 1);
-    hipLaunchKernelGGL(conv_reduce_kernel, dim3(C / CTC, (CTC * (ks + 1) + 255) / 256), dim3(256), 0, (hipStream_t)stream,
+    hipLaunchKernelGGL(conv_reduce_kernel, dim3(C / CTC, ks + 1), dim3(64), 0, (hipStream_t)stream,
                        ws, dw, dbias, B, C / CTC, gx, ks);
     E2K_CHECK_LAUNCH();
     return 0;

@@ -1671,7 +1671,10 @@ static int gemm_nt_bf16_impl(const void* A1, int64_t lda1, int K1, const void* A
             rem = T % slots;
             const int nk = (K1 + K2) / BK;
             int split = 1;
-            while (split * 2 <= 16 && split * 2 * rem <= slots && split * 2 * 4 <= nk) split *= 2;   // >= 4 K tiles per part
+            // (tuning instruments: E2K_GEMM_SPLIT_CAP bounds the split, E2K_GEMM_SPLIT_MINK the K tiles per part)
+            static const int split_cap = getenv("E2K_GEMM_SPLIT_CAP") ? atoi(getenv("E2K_GEMM_SPLIT_CAP")) : 16;
+            static const int split_mink = getenv("E2K_GEMM_SPLIT_MINK") ? atoi(getenv("E2K_GEMM_SPLIT_MINK")) : 4;
+            while (split * 2 <= split_cap && split * 2 * rem <= slots && split * 2 * split_mink <= nk) split *= 2;   // >= 4 K tiles per part
             // same trade as below: half a round saved (~1 us per K step of a 256 x 256 tile) against 256 KB of fp32
             // partials per part written and re-read, plus the fix-up launch.  UNMEASURED constants (scaled from the 128 x 128 ones)
             if (!(flags & E2K_GEMM_TEST_SLOTS8))

@@ -72,6 +72,8 @@ inline void barrier_raw() { emu::block_rendezvous(); }
 inline void wave_sync() { (void)__shfl_xor(0, 1); }       // fibers of a wave run one after the other: a true rendezvous
 template <int P> inline void set_prio() {}
 inline void sched_fence() {}
+template <class T> inline void pin_vgpr(T&) {}
+inline void order_memory() {}
 
 // the static LDS array the calling kernel's LDS-DMA copies must land in (set by lds_declare at kernel entry; a block's
 // fibers all run on one host thread, and so do its `static thread_local` __shared__ arrays)
