@@ -340,7 +340,28 @@ struct AttnArgs {
     bf16_t* dO; bf16_t* dOT;                   // head-major / transposed
     float* delta; float* dgate_pre;            // (B,h,N)
     bf16_t *dQ, *dK, *dV;                      // (B,h,N,64)
+    int xcd_map;                               // ring kernels: re-number the workgroups so that a (batch, head) row stays on one XCD
 };
+
+// The ring kernels run on a 1-D grid of (64-row tiles) x heads x batch.  Workgroups are handed to the 8 XCDs round-robin in launch
+// order, so with the plain numbering the 17 tiles of a (batch, head) row -- which all stream the SAME K / V (the backward: Q / dO)
+// tiles -- sit on all 8 XCDs and every L2 holds every row in flight (60 rows x 270 KB against 4 MB).  Re-numbered, an XCD gets a
+// contiguous run of rows: 7-8 rows in flight per L2, each tile of K / V fetched once per row instead of once per XCD.
+struct RingWG { int x, h, b; };
+__device__ __forceinline__ RingWG ring_wg(const AttnArgs& p, int nx) {
+    const int nwg = (int)gridDim.x;
+    int lin = (int)blockIdx.x;
+    if (p.xcd_map) {
+        const int xcd = lin & 7, q = nwg >> 3, r = nwg & 7;
+        lin = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + (lin >> 3);
+    }
+    RingWG w;
+    w.x = lin % nx;
+    const int bh = lin / nx;
+    w.h = bh % p.H;
+    w.b = bh / p.H;
+    return w;
+}
 
 // scores of one 64-key tile for this wave's 16 query rows, S^T layout: s[t][r] <-> key perm_row(t, 4g+r), q = l&15
 __device__ __forceinline__ void score_tile(const unsigned char* Kt, const bf16x8 (&qf)[2], int l15, int g, f32x4 (&s)[4]) {
@@ -539,12 +560,13 @@ __global__ __launch_bounds__(256, 2) void attn_fwd_ring_kernel(AttnArgs p) {
     unsigned char* const kms = smem + RING * RSTAGE;                 // key mask of this batch row (Npad bytes)
     const int tid = threadIdx.x, lane = tid & 63, wave = uniform_i(tid >> 6);
     const int l15 = lane & 15, g = lane >> 4;
-    const int q0 = blockIdx.x * 64, h = blockIdx.y, b = blockIdx.z;
+    const int ntiles = (p.N + 63) / 64;
+    const RingWG wg = ring_wg(p, ntiles);
+    const int q0 = wg.x * 64, h = wg.h, b = wg.b;
     const long bh = (long)b * p.H + h;
     const int q = q0 + wave * 16 + l15;
     const bool qin = q < p.N;
     const unsigned dstream = attn_stream(p.stream_id, (unsigned)bh);
-    const int ntiles = (p.N + 63) / 64;
 
     // one BYTE of mask bits per 8 keys (the 8 mask bytes squeezed once per workgroup; squeezing them per tile and lane cost two
     // 64-bit multiplies = six quarter-rate v_mul per tile in this loop)
@@ -668,7 +690,7 @@ __global__ __launch_bounds__(256, 2) void attn_fwd_ring_kernel(AttnArgs p) {
                 bhi = wave_writelane(bhi, (unsigned)(mk[i] >> 32), i);
             }
             if (lane < 16) {
-                unsigned long long* dropw = p.dropbits + ((((long)bh * ntiles + kt) * ntiles + blockIdx.x) * 4 + wave) * 16;
+                unsigned long long* dropw = p.dropbits + ((((long)bh * ntiles + kt) * ntiles + wg.x) * 4 + wave) * 16;
                 dropw[lane] = (unsigned long long)blo | ((unsigned long long)bhi << 32);
             }
         }
@@ -898,12 +920,13 @@ __global__ __launch_bounds__(256, 3) void attn_bwd_dq_ring_kernel(AttnArgs p) {
     unsigned char* const kms = smem + 2 * RSTAGE;
     const int tid = threadIdx.x, lane = tid & 63, wave = uniform_i(tid >> 6);
     const int l15 = lane & 15, g = lane >> 4;
-    const int q0 = blockIdx.x * 64, h = blockIdx.y, b = blockIdx.z;
+    const int ntiles = (p.N + 63) / 64;
+    const RingWG wg = ring_wg(p, ntiles);
+    const int q0 = wg.x * 64, h = wg.h, b = wg.b;
     const long bh = (long)b * p.H + h;
     const int q = q0 + wave * 16 + l15;
     const bool qin = q < p.N;
     const unsigned dstream = attn_stream(p.stream_id, (unsigned)bh);
-    const int ntiles = (p.N + 63) / 64;
 
     // one BYTE of mask bits per 8 keys (the 8 mask bytes squeezed once per workgroup; squeezing them per tile and lane cost two
     // 64-bit multiplies = six quarter-rate v_mul per tile in this loop)
@@ -971,7 +994,7 @@ __global__ __launch_bounds__(256, 3) void attn_bwd_dq_ring_kernel(AttnArgs p) {
         const unsigned km = (unsigned)kms[(k0 >> 3) + g] | ((unsigned)kms[(k0 >> 3) + 4 + g] << 8);
         const bool allk = wave_all(km == 0xffffu);
         const unsigned long long* dropw = (DROP && SHARE)
-            ? p.dropbits + ((((long)bh * ntiles + kt) * ntiles + blockIdx.x) * 4 + wave) * 16 : nullptr;
+            ? p.dropbits + ((((long)bh * ntiles + kt) * ntiles + wg.x) * 4 + wave) * 16 : nullptr;
 #pragma unroll
         for (int kk2 = 0; kk2 < 2; ++kk2) {
             s16x4_ klo[4], khi[4];
@@ -1244,8 +1267,9 @@ __global__ __launch_bounds__(256, 3) void attn_bwd_dkv_ring_kernel(AttnArgs p) {
     lds_declare(smem, sizeof(smem));
     const int tid = threadIdx.x, lane = tid & 63, wave = uniform_i(tid >> 6);
     const int l15 = lane & 15, g = lane >> 4;
-    const int k0 = blockIdx.x * 64, h = blockIdx.y, b = blockIdx.z;
-    const int kt64 = blockIdx.x;
+    const RingWG wg = ring_wg(p, (p.N + 63) / 64);
+    const int k0 = wg.x * 64, h = wg.h, b = wg.b;
+    const int kt64 = wg.x;
     const long bh = (long)b * p.H + h;
     const int key = k0 + wave * 16 + l15;
     const bool kin = key < p.N;
@@ -1579,6 +1603,8 @@ static int fill_attn(AttnArgs& a, int B, int H, int N, int Npad, float p_drop, u
     a.seed = seed; a.seed_dev = seed_dev; a.stream_id = stream_id;
     a.thresh = (unsigned)(p_drop * 65536.f + 0.5f);
     a.inv_keep = 1.f / (1.f - p_drop);
+    static const int xcd_env = getenv("E2K_ATTN_XCD") ? atoi(getenv("E2K_ATTN_XCD")) : 1;      // (0: plain numbering, A/B)
+    a.xcd_map = xcd_env;
     return 0;
 }
 
@@ -1612,7 +1638,7 @@ static int attn_fwd_impl(const void* Q, const void* K, const void* VT, const uin
         else if (a.thresh) hipLaunchKernelGGL((attn_fwd_kernel<true, false, 4, true>), grid, block, 0, st, a);
         else hipLaunchKernelGGL((attn_fwd_kernel<false, false, 4, true>), grid, block, 0, st, a);
     } else if (!(flags & E2K_ATTN_NO_RING) && Npad <= RKM) {
-        const dim3 grid((N + 63) / 64, H, B), block(256);
+        const dim3 grid(((N + 63) / 64) * H * B), block(256);          // 1-D: ring_wg() numbers the workgroups
         if (a.thresh && dropbits) hipLaunchKernelGGL((attn_fwd_ring_kernel<true, true, 2>), grid, block, 0, st, a);
         else if (a.thresh) hipLaunchKernelGGL((attn_fwd_ring_kernel<true, false, 2>), grid, block, 0, st, a);
         else hipLaunchKernelGGL((attn_fwd_ring_kernel<false, false, 2>), grid, block, 0, st, a);
@@ -1650,18 +1676,19 @@ static int attn_bwd_impl(const void* dOg, const void* O, const float* gate, cons
     E2K_CHECK_LAUNCH();
     {
         const dim3 grid((N + 63) / 64, H, B), block(256);
+        const dim3 grid1(((N + 63) / 64) * H * B);                     // ring kernels: 1-D, ring_wg() numbers the workgroups
         if (!(flags & E2K_ATTN_NO_RING) && Npad <= RKM) {
-            if (a.thresh && dropbits) hipLaunchKernelGGL((attn_bwd_dq_ring_kernel<true, true>), grid, block, 0, st, a);
-            else if (a.thresh) hipLaunchKernelGGL((attn_bwd_dq_ring_kernel<true, false>), grid, block, 0, st, a);
-            else hipLaunchKernelGGL((attn_bwd_dq_ring_kernel<false, false>), grid, block, 0, st, a);
+            if (a.thresh && dropbits) hipLaunchKernelGGL((attn_bwd_dq_ring_kernel<true, true>), grid1, block, 0, st, a);
+            else if (a.thresh) hipLaunchKernelGGL((attn_bwd_dq_ring_kernel<true, false>), grid1, block, 0, st, a);
+            else hipLaunchKernelGGL((attn_bwd_dq_ring_kernel<false, false>), grid1, block, 0, st, a);
         } else if (a.thresh && dropbits) hipLaunchKernelGGL((attn_bwd_dq_kernel<true, true, 4>), grid, block, 0, st, a);
         else if (a.thresh) hipLaunchKernelGGL((attn_bwd_dq_kernel<true, false, 4>), grid, block, 0, st, a);
         else hipLaunchKernelGGL((attn_bwd_dq_kernel<false, false, 4>), grid, block, 0, st, a);
         E2K_CHECK_LAUNCH();
         if (!(flags & E2K_ATTN_NO_RING)) {
-            if (a.thresh && dropbits) hipLaunchKernelGGL((attn_bwd_dkv_ring_kernel<true, true>), grid, block, 0, st, a);
-            else if (a.thresh) hipLaunchKernelGGL((attn_bwd_dkv_ring_kernel<true, false>), grid, block, 0, st, a);
-            else hipLaunchKernelGGL((attn_bwd_dkv_ring_kernel<false, false>), grid, block, 0, st, a);
+            if (a.thresh && dropbits) hipLaunchKernelGGL((attn_bwd_dkv_ring_kernel<true, true>), grid1, block, 0, st, a);
+            else if (a.thresh) hipLaunchKernelGGL((attn_bwd_dkv_ring_kernel<true, false>), grid1, block, 0, st, a);
+            else hipLaunchKernelGGL((attn_bwd_dkv_ring_kernel<false, false>), grid1, block, 0, st, a);
         } else if (a.thresh && dropbits) hipLaunchKernelGGL((attn_bwd_dkv_kernel<true, true, 4>), grid, block, 0, st, a);
         else if (a.thresh) hipLaunchKernelGGL((attn_bwd_dkv_kernel<true, false, 4>), grid, block, 0, st, a);
         else hipLaunchKernelGGL((attn_bwd_dkv_kernel<false, false, 4>), grid, block, 0, st, a);
