@@ -28,6 +28,8 @@ for k in ('pmc', 'pmc2', 'pmc3'):
 out = {'note': f'rocprofv3 --pmc passes (tools/gpu/pmc.sh {what}) over tools/gemm_probe.py {what}; averages per launch, whole chip; '
                'SQ_*_CYCLES / SQ_ACTIVE_* / SQ_WAIT_* are in quad-cycles summed over waves', 'kernels': {}}
 for name, cs in sorted(acc.items()):
+    if name.startswith('at::') or 'elementwise_kernel' in name:
+        continue          # torch's own kernels of the probe's set-up
     d = {c: round(sum(v) / len(v)) for c, v in sorted(cs.items())}
     if d.get('SQ_WAVES') and d.get('SQ_INSTS_VALU'):
         d['derived_valu_instr_per_wave'] = round(d['SQ_INSTS_VALU'] / d['SQ_WAVES'])
