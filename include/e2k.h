@@ -13,7 +13,10 @@
  *   - the caller owns every buffer; all pointers are device pointers (HBM) unless stated otherwise;
  *   - `stream` is a hipStream_t (NULL = default stream); kernels are only enqueued, never synchronised;
  *   - "bf16" buffers hold raw bfloat16 bits (uint16_t); leading dimensions (ld*) are in ELEMENTS;
- *   - 16-byte vector access: bf16 base pointers must be 16-B aligned and ld* multiples of 8.
+ *   - 16-byte vector access: bf16 base pointers must be 16-B aligned and ld* multiples of 8;
+ *   - tuning instruments, read from the environment once per process; they choose between launch geometries of the same
+ *     arithmetic: E2K_GEMM_T256_MIN, E2K_GEMM_GROUP, E2K_GEMM_SPLIT_CAP, E2K_GEMM_SPLIT_MINK (NT GEMM: kernel threshold, tile-group
+ *     height, bounds of the remainder split) and E2K_ATTN_XCD (0: plain workgroup numbering of the attention ring kernels).
  */
 #ifndef E2K_H
 #define E2K_H
