@@ -143,7 +143,7 @@ def _adopt_worker(rank, world, port, emu_lib, q):
     """the classifier-free-guidance coin is flipped per rank; whether the text stream's parameters are
     updated must be the same on every rank (the reference's DDP all-reduces its used-parameter map).  Three optimizer steps
     -- rank 1 drops the text, nobody does, everybody does -- through both gradient paths (persistent flat buffer = one fused
-    launch; views handed to autograd = the per-run path): parameters, moments and step counts must be identical on the two
+    launch; views handed to autograd = the per-run path) and under the stock DistributedDataParallel with the overlap shim: parameters, moments and step counts must be identical on the two
     ranks after every step, and on the all-dropped step the text stream must not move at all."""
     sys.path[:0] = [str(ROOT / 'e2-tts-pytorch_amd'), str(ROOT), str(ROOT / 'tests')]
     os.environ.update(MASTER_ADDR='127.0.0.1', MASTER_PORT=str(port), E2K_EMU_THREADS='2')
@@ -155,15 +155,24 @@ def _adopt_worker(rank, world, port, emu_lib, q):
     from test_backbone import randomize
     install_lib(emu_lib, host_pointers=True)
     bad = []
-    for persistent in (True, False):
+    # (wrapper, persistent flat gradient buffer): this package's DataParallel through both gradient paths, and the stock
+    # DistributedDataParallel with the overlap shim (what accelerator.prepare builds around the reference trainer's model)
+    for wrapper, persistent in (('dp', True), ('dp', False), ('stock', False)):
         random.seed(11)
         torch.manual_seed(11)
         model = E2TTS(transformer=dict(dim=256, depth=2, heads=4, dropout=0., num_registers=8), use_vocos=False, cond_drop_prob=0.)
         randomize(model, seed=3)
-        net = DataParallel(model)
+        if wrapper == 'dp':
+            net = DataParallel(model)
+        else:
+            from torch.nn.parallel import DistributedDataParallel as DDP
+            from e2_tts_pytorch_amd.ddp import enable_overlap_under_ddp
+            enable_overlap_under_ddp(model)
+            net = DDP(model, find_unused_parameters=True)
         tr = model.transformer
         tr.enable_plans(False)
         tr.enable_persistent_grads(persistent)
+        persistent = (wrapper, persistent)          # (label of the failure records below)
         opt = FusedAdopt(model, lr=1e-2, max_grad_norm=1.0)
         text_ids = tr._text_param_ids()
         names = {id(p): n for n, p in model.named_parameters()}
