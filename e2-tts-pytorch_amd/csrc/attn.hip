@@ -1595,7 +1595,7 @@ static int qkv_post_bwd_impl(const void* dQ, const void* dK, const void* dV, con
 }
 
 static int fill_attn(AttnArgs& a, int B, int H, int N, int Npad, float p_drop, uint32_t seed, const uint32_t* seed_dev,
-                     uint32_t stream_id) {
+                     uint32_t stream_id, int flags) {
     if ((Npad & 63) || Npad < N) return E2K_ERR_ALIGN;
     if ((long)B * H >= 65536 || stream_id >= 32768u) return E2K_ERR_SHAPE;      // attn_stream() packs (call id, b * H + h)
     a.B = B; a.H = H; a.N = N; a.Npad = Npad;
@@ -1604,7 +1604,7 @@ static int fill_attn(AttnArgs& a, int B, int H, int N, int Npad, float p_drop, u
     a.thresh = (unsigned)(p_drop * 65536.f + 0.5f);
     a.inv_keep = 1.f / (1.f - p_drop);
     static const int xcd_env = getenv("E2K_ATTN_XCD") ? atoi(getenv("E2K_ATTN_XCD")) : 1;      // (0: plain numbering, A/B)
-    a.xcd_map = xcd_env;
+    a.xcd_map = (flags & E2K_ATTN_PLAIN_WG) ? 0 : xcd_env;
     return 0;
 }
 
@@ -1625,7 +1625,7 @@ static int attn_fwd_impl(const void* Q, const void* K, const void* VT, const uin
     if (B <= 0 || N <= 0) return 0;
     if (!Q || !K || !VT || !kmask || !gate || !O || !Og || !lse2) return E2K_ERR_ARG;
     AttnArgs a{};
-    int rc = fill_attn(a, B, H, N, Npad, p_drop, seed, seed_dev, stream_id);
+    int rc = fill_attn(a, B, H, N, Npad, p_drop, seed, seed_dev, stream_id, flags);
     if (rc) return rc;
     a.Q = (const bf16_t*)Q; a.K = (const bf16_t*)K; a.VT = (const bf16_t*)VT; a.kmask = kmask; a.gate = gate;
     a.O = (bf16_t*)O; a.Og = (bf16_t*)Og; a.lse2 = lse2;
@@ -1663,7 +1663,7 @@ static int attn_bwd_impl(const void* dOg, const void* O, const float* gate, cons
     if (((need & 1) && !KT) || ((need & 2) && (!QT || !dOT))) return E2K_ERR_ARG;
     if (!(need & 2)) dOT = nullptr;
     AttnArgs a{};
-    int rc = fill_attn(a, B, H, N, Npad, p_drop, seed, seed_dev, stream_id);
+    int rc = fill_attn(a, B, H, N, Npad, p_drop, seed, seed_dev, stream_id, flags);
     if (rc) return rc;
     a.dOg = (const bf16_t*)dOg; a.O = (bf16_t*)O; a.gate = gate; a.lse2 = const_cast<float*>(lse2);
     a.Q = (const bf16_t*)Q; a.K = (const bf16_t*)K; a.V = (const bf16_t*)V; a.QT = (const bf16_t*)QT;

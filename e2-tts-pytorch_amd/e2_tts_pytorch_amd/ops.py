@@ -754,6 +754,7 @@ def qkv_post_fwd(qkvg, B, H, N, cosb, sinb, vfirst=None, laser=0.):
 # kernels read them back instead of re-hashing: bit-identical results (tools/attn_share_check.py on MI355X), forward
 # 0.132 -> 0.140 ms, backward 0.403 -> 0.358 ms per cfg3 attention.  False = every kernel re-derives the mask.
 attn_share_dropmask = True
+_ATTN_BOTH = 64 | 128 | 256        # flag bits that select kernel variants (forward and backward calls alike)
 attn_probe = int(_os.environ.get('E2K_ATTN_FLAGS', '0'))      # E2K_ATTN_* bits: 128 = the register-staged kernels instead of the LDS-DMA rings (A/B); probes 1..32 give wrong results on purpose
 
 
@@ -802,7 +803,7 @@ def attn_bwd(st, dOg, kmask_pad, p_drop=0., seed=0, stream_id=0, seed_dev=None):
     _note(10.0 * B * H * N * N * 64)
     _lib.get().e2k_attn_bwd(_p(dOg), _p(st.O), _p(st.gate), _p(st.lse2), _p(st.Q), _p(st.K), _p(st.V), _p(st.QT),
                             _p(st.KT), _p(kmask_pad), _p(st.dropbits), _p(dO), _p(dOT), _p(delta), _p(dgate), _p(dQ), _p(dK),
-                            _p(dV), B, H, N, Npad, float(p_drop), int(seed), _p(seed_dev), int(stream_id), attn_probe & 128,
+                            _p(dV), B, H, N, Npad, float(p_drop), int(seed), _p(seed_dev), int(stream_id), attn_probe & _ATTN_BOTH,
                             _stream(dOg))
     return dQ, dK, dV, dgate if dgate_laser is None else dgate_laser
 

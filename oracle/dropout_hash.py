@@ -82,13 +82,35 @@ def attn_stream(stream_id, bh):
     return (0x80000000 | ((int(stream_id) << 16) & 0x7fff0000) | int(bh)) & 0xffffffff
 
 
+def _keep4_square(seed, stream, N, p):
+    """_keep4 for rows = cols = arange(N), hashing each (query, group of four keys) counter ONCE (the general form above
+    hashes it four times): the (N, N) keep-scale matrix, bit-identical to _keep4(seed, stream, arange(N), arange(N), p)"""
+    thresh = int(p * 65536.0 + 0.5)
+    n4 = (N + 3) // 4
+    r = np.arange(N, dtype=np.uint32)[:, None]
+    c4 = np.arange(n4, dtype=np.uint32)[None, :]
+    with np.errstate(over='ignore'):
+        seed, stream = np.uint32(seed), np.uint32(stream)
+        base = fmix32(np.asarray(seed ^ np.uint32((int(stream) * 0x9e3779b1) & 0xffffffff), dtype=np.uint32))
+        h = (base + r * _M(0x85ebca77) + c4 * _M(0xc2b2ae3d)).astype(np.uint32)
+    w0, w1 = drop4_words(h)
+    r16 = np.stack([w0 & _M(0xffff), w0 >> _M(16), w1 & _M(0xffff), w1 >> _M(16)], axis=-1).reshape(N, 4 * n4)[:, :N]
+    return torch.from_numpy(np.where(r16 >= thresh, np.float32(1.0 / (1.0 - p)), np.float32(0.0)))
+
+
 def attn_dropout_mask(seed, stream_id, B, H, N, p):
     """(B, H, N, N) mask of e2k_attn_fwd(p_drop=p, seed, stream_id): element [b,h,q,key]"""
     out = torch.empty(B, H, N, N)
-    idx = np.arange(N)
-    for b in range(B):
-        for h in range(H):
-            out[b, h] = _keep4(seed, attn_stream(stream_id, b * H + h), idx, idx, p)
+
+    def one(bh):
+        out[bh // H, bh % H] = _keep4_square(seed, attn_stream(stream_id, bh), N, p)
+    if B * H * N * N < (1 << 22):
+        for bh in range(B * H):
+            one(bh)
+    else:                               # (numpy releases the GIL inside its loops: full-size masks in a few threads)
+        from concurrent.futures import ThreadPoolExecutor
+        with ThreadPoolExecutor(max_workers=8) as ex:
+            list(ex.map(one, range(B * H)))
     return out
 
 

@@ -171,6 +171,66 @@ def test_e2tts_cfg3_width():
         assert gk is not None and rel2(gk, gr) < 0.15, (name, rel2(gk, gr))
 
 
+def feed_oracle_dropout_masks(ref, seed, B, N, p):
+    """hand the oracle the keep masks the HIP path draws from its counter hash (oracle/dropout_hash.py): attention call of layer
+    `ind`, stream t (0 audio, 1 text) uses stream id (2 ind + t) * 4, the GEGLU dropout of the same block that id + 1
+    (backbone.py `_attn_block` / `_ff_block`); rows of the GEGLU mask are the token rows b * N + n"""
+    from oracle.dropout_hash import attn_dropout_mask, geglu_dropout_mask
+    tr = ref.transformer
+    for ind, (speech, text) in enumerate(tr.layers):
+        for t, (mods, ia, iff) in enumerate(((speech, 3, 7), (text, 2, 4))):
+            if mods is None:
+                continue
+            attn, ff = mods[ia], mods[iff]
+            sid = (ind * 2 + t) * 4
+            attn.dropout_mask = attn_dropout_mask(seed, sid, B, attn.heads, N, p)
+            F_ = ff.ff[2].in_features
+            ff.ff[1].mask = geglu_dropout_mask(seed, sid + 1, B * N, F_, p).view(B, N, F_)
+
+
+def spy_dropout_seed(monkeypatch):
+    """records (seed, stream id) of every ops.attn_fwd call (the seed word is read back from the device in plan mode)"""
+    from e2_tts_pytorch_amd import ops
+    calls, orig = [], ops.attn_fwd
+
+    def spy(st, kmask_pad, p_drop=0., seed=0, stream_id=0, seed_dev=None):
+        calls.append((int(seed) if seed_dev is None else int(seed_dev.item()), int(stream_id)))
+        return orig(st, kmask_pad, p_drop, seed, stream_id, seed_dev)
+    monkeypatch.setattr(ops, 'attn_fwd', spy)
+    return calls
+
+
+def test_training_dropout_against_oracle(dev, monkeypatch):
+    """one training step with dropout 0.1 (attention-probability and GEGLU dropout live in every block of both streams)
+    against the fp32 oracle fed the very masks the kernels drew: loss, pred_flow, gradients"""
+    kw = dict(dim=256, depth=2, heads=4, dropout=0.1)
+    ref, model = _pair(kw)
+    model = model.to(dev).train()
+    ref.train()
+    B, T = 2, 72 if gpu_shapes(dev) else 40
+    N = T + 32
+    mel = torch.randn(B, T, 100)
+    lens = torch.tensor([T, T - 11])
+    noise = dict(x0=torch.randn(B, T, 100), times=torch.rand(B), frac_lengths=torch.tensor([0.75, 0.9]),
+                 span_rand=torch.tensor([0.2, 0.7]), drop_text_cond=False)
+    text = ['Hello', 'Goodbye, world']
+    calls = spy_dropout_seed(monkeypatch)
+    dn = {k: (v.to(dev) if torch.is_tensor(v) else v) for k, v in noise.items()}
+    out = model(mel.to(dev), text=text, lens=lens.to(dev), _noise=dn)
+    out.loss.backward()
+    assert len(calls) == 4 and len({c[0] for c in calls}) == 1 and sorted(c[1] for c in calls) == [0, 4, 8, 12], calls
+    feed_oracle_dropout_masks(ref, calls[0][0], B, N, 0.1)
+    out_r = ref(mel, text=text, lens=lens, _noise=noise)
+    out_r.loss.backward()
+    assert abs(out.loss.item() - out_r.loss.item()) / abs(out_r.loss.item()) < 1e-2, (out.loss.item(), out_r.loss.item())
+    assert rel2(out.pred_flow, out_r.pred_flow) < 1e-2, rel2(out.pred_flow, out_r.pred_flow)
+    refp = dict(ref.named_parameters())
+    for name in ('to_pred.weight', 'proj_in.weight', 'transformer.layers.0.0.3.to_out.weight', 'transformer.layers.1.0.3.to_q.weight',
+                 'transformer.layers.1.0.7.ff.0.proj.weight', 'transformer.layers.1.1.2.to_v.weight', 'transformer.layers.1.1.4.ff.0.proj.weight'):
+        gk, gr = dict(model.named_parameters())[name].grad, refp[name].grad
+        assert gk is not None and rel2(gk, gr) < 0.1, (name, rel2(gk, gr))
+
+
 def test_training_dropout_shared_masks(dev):
     """a training step with dropout 0.1 (attention + GEGLU dropout active): handing the attention keep masks from the
     forward to the backward (the default) gives exactly the loss and gradients of re-hashing them in every kernel"""

@@ -41,7 +41,7 @@ def rel2(a, b):
 def _report(name, rec):
     out = ROOT / 'gpurun_out'
     if out.is_dir():
-        json.dump(rec, open(out / f'r04_parity_{name}.json', 'w'), indent=1)
+        json.dump(rec, open(out / f'r05_parity_{name}.json', 'w'), indent=1)
 
 
 def _pair(kw, init, seed=0):
@@ -152,10 +152,9 @@ def test_cfg1_readme_exact(init):
 @pytest.mark.parametrize('init,B', [('reference_init', 1), ('reference_init', 2), ('half_randomized', 1), ('randomized', 1)])
 def test_cfg3_dims_depth24(init, B):
     text = ['The quick brown fox jumps over the lazy dog.', 'Pack my box with five dozen liquor jugs!'][:B]
-    rec = _train_step_parity('cfg3' if B == 1 else f'cfg3_B{B}', dict(dim=1024, depth=24, heads=16, dropout=0.), B, 1024, text, init,
-                             flow_limit=2e-2 if init == 'half_randomized' else 1e-2)
+    rec = _train_step_parity('cfg3' if B == 1 else f'cfg3_B{B}', dict(dim=1024, depth=24, heads=16, dropout=0.), B, 1024, text, init)
     if init == 'half_randomized':
-        assert rec['pred_flow_rel_l2'] < 2e-2, rec['pred_flow_rel_l2']       # off-init at depth 24, asserted directly
+        assert rec['pred_flow_rel_l2'] < 1e-2, rec['pred_flow_rel_l2']       # off-init at depth 24: the north-star tolerance, asserted directly (measured 0.88 %)
         return
     # measured on MI355X: 0.7-1.3 % per layer; the worst single tensor is the zero-initialised hyper-connection mixing
     # projection of the last layer (12 %: a (D, 5) sum over all tokens of products with a tiny gradient), every weight
@@ -214,31 +213,6 @@ def test_cfg5_shape_sample_32_steps(init):
     assert e < (1e-2 if init == 'reference_init' else 3e-2), e
 
 
-def test_cfg3_batch8_forward_only():
-    """the headline configuration at its FULL batch: dim 1024 / depth 24 / 16 heads, B = 8, T = 1024, text on -- loss and
-    pred_flow of one no-grad forward against the CPU oracle (no saved activations: the fp32 oracle of B = 8 fits host RAM;
-    the forward + backward comparison at these dims is test_cfg3_dims_depth24 at B = 1, 2).  Reference initialisation."""
-    import string
-    torch.set_num_threads(min(32, os.cpu_count() or 1))
-    kw = dict(dim=1024, depth=24, heads=16, dropout=0.)
-    ref, model = _pair(kw, 'reference_init', seed=5)
-    B, T = 8, 1024
-    rng = random.Random(9)
-    text = [''.join(rng.choice(string.ascii_lowercase + ' ') for _ in range(rng.randint(20, 200))) for _ in range(B)]
-    mel = torch.randn(B, T, 100)
-    noise = dict(x0=torch.randn(B, T, 100), times=torch.rand(B), frac_lengths=torch.full((B,), 0.85),
-                 span_rand=torch.rand(B), drop_text_cond=False)
-    with torch.no_grad():
-        out_r = ref(mel, text=text, _noise=noise)
-        dn = {k: (v.cuda() if torch.is_tensor(v) else v) for k, v in noise.items()}
-        out = model(mel.cuda(), text=text, _noise=dn)
-    e_loss = abs(out.loss.item() - out_r.loss.item()) / abs(out_r.loss.item())
-    e_flow = rel2(out.pred_flow, out_r.pred_flow)
-    _report('cfg3_B8_forward_only_reference_init', dict(case='cfg3 at B = 8, forward only', kw=kw, B=B, T=T, loss_rel=e_loss, pred_flow_rel_l2=e_flow))
-    print('cfg3 B=8 forward only: loss rel', e_loss, 'pred_flow rel-L2', e_flow)
-    assert e_loss < 1e-2 and e_flow < 1e-2, (e_loss, e_flow)
-
-
 def test_cfg5_sample_batch8_1024_frames():
     """sample() at a full batch of full-length targets: B = 8, prompt of 5 frames, 1024 target frames, 8 midpoint steps with
     classifier-free guidance (14 function evaluations x (cond + null)), the cfg2 transformer (dim 512, depth 8: the CPU oracle
@@ -258,3 +232,94 @@ def test_cfg5_sample_batch8_1024_frames():
                                                               steps=steps, sampled_mel_rel_l2=e))
     print('sampled mel rel-L2 (B = 8, 1024 frames, 8 steps)', e)
     assert s.shape == s_r.shape == (B, dur, 100) and e < 1e-2, e
+
+
+def _grad_report(model, ref):
+    refp = dict(ref.named_parameters())
+    per_layer, worst = {}, []
+    for n, p in model.named_parameters():
+        gr = refp[n].grad
+        if gr is None or p.grad is None or float(gr.norm()) == 0. or p.numel() < 4096:
+            continue
+        e = rel2(p.grad, gr)
+        key = '.'.join(n.split('.')[:3]) if n.startswith('transformer.layers.') else ('transformer.other' if n.startswith('transformer.') else 'head')
+        per_layer.setdefault(key, []).append(e)
+        worst.append((e, n))
+    worst.sort(reverse=True)
+    rms = lambda v: (sum(x * x for x in v) / len(v)) ** 0.5
+    return {k: rms(v) for k, v in per_layer.items()}, [(round(e, 4), n) for e, n in worst[:10]]
+
+
+def test_cfg3_dims_dropout_against_fed_masks(monkeypatch):
+    """the configuration bench.py TIMES has dropout 0.1: one training step at the headline dims (dim 1024 / depth 24 / 16 heads,
+    T = 1024, B = 1) in train mode against the fp32 oracle fed the attention-probability and GEGLU keep masks the kernels drew
+    (oracle/dropout_hash.py; 48 attention masks of 16 x 1056 x 1056 and 48 GEGLU masks): loss, pred_flow, per-layer weight gradients"""
+    from test_e2tts import feed_oracle_dropout_masks, spy_dropout_seed
+    torch.set_num_threads(min(32, os.cpu_count() or 1))
+    kw = dict(dim=1024, depth=24, heads=16, dropout=0.1)
+    ref, model = _pair(kw, 'reference_init', seed=7)
+    model.train()
+    ref.train()
+    B, T = 1, 1024
+    text = ['The quick brown fox jumps over the lazy dog.']
+    mel = torch.randn(B, T, 100)
+    noise = dict(x0=torch.randn(B, T, 100), times=torch.rand(B), frac_lengths=torch.full((B,), 0.85),
+                 span_rand=torch.rand(B), drop_text_cond=False)
+    calls = spy_dropout_seed(monkeypatch)
+    dn = {k: (v.cuda() if torch.is_tensor(v) else v) for k, v in noise.items()}
+    out = model(mel.cuda(), text=text, _noise=dn)
+    out.loss.backward()
+    torch.cuda.synchronize()
+    assert len(calls) == 48 and len({c[0] for c in calls}) == 1, calls[:4]
+    feed_oracle_dropout_masks(ref, calls[0][0], B, T + 32, 0.1)
+    out_r = ref(mel, text=text, _noise=noise)
+    out_r.loss.backward()
+    e_loss = abs(out.loss.item() - out_r.loss.item()) / abs(out_r.loss.item())
+    e_flow = rel2(out.pred_flow, out_r.pred_flow)
+    by_layer, worst = _grad_report(model, ref)
+    _report('cfg3_dropout_fed_masks', dict(case='cfg3 dims, B = 1, dropout 0.1, oracle fed the kernels\' masks', kw=kw, B=B, T=T, loss_rel=e_loss,
+                                           pred_flow_rel_l2=e_flow, weight_grad_rel_l2_by_layer=by_layer, worst=worst))
+    print('cfg3 dropout 0.1: loss rel', e_loss, 'pred_flow rel-L2', e_flow, 'worst grads', worst[:4])
+    assert e_loss < 1e-2 and e_flow < 1e-2, (e_loss, e_flow)
+    assert max(by_layer.values()) < 0.03 and worst[0][0] < 0.15, (by_layer, worst[:5])
+
+
+def test_cfg3_batch8_forward_backward():
+    """the headline configuration at its FULL batch, forward AND backward: dim 1024 / depth 24 / 16 heads, B = 8, T = 1024, text on.
+    The oracle's loss is a masked sum over samples divided by ONE global count (e2_tts.py:1578-1582), and no operation of the model
+    mixes samples, so the fp32 oracle's gradients are accumulated one sample at a time: sample b alone gives loss_b = S_b / C_b,
+    the batch loss is sum_b (C_b / C) loss_b (host RAM holds one sample's activations at a time).  Reference initialisation."""
+    import string
+    torch.set_num_threads(min(32, os.cpu_count() or 1))
+    kw = dict(dim=1024, depth=24, heads=16, dropout=0.)
+    ref, model = _pair(kw, 'reference_init', seed=5)
+    B, T = 8, 1024
+    rng = random.Random(9)
+    text = [''.join(rng.choice(string.ascii_lowercase + ' ') for _ in range(rng.randint(20, 200))) for _ in range(B)]
+    mel = torch.randn(B, T, 100)
+    noise = dict(x0=torch.randn(B, T, 100), times=torch.rand(B), frac_lengths=0.7 + 0.3 * torch.rand(B),
+                 span_rand=torch.rand(B), drop_text_cond=False)
+    dn = {k: (v.cuda() if torch.is_tensor(v) else v) for k, v in noise.items()}
+    out = model(mel.cuda(), text=text, _noise=dn)
+    out.loss.backward()
+    torch.cuda.synchronize()
+    counts = (out.cond == 0).all(dim=-1).sum(dim=-1).cpu().double()          # masked frames per sample (mel is never exactly 0)
+    assert float(counts.min()) > 0
+    wts = (counts / counts.sum()).tolist()
+    loss_r, flows = 0., []
+    for b in range(B):
+        nb = {k: (v[b:b + 1] if torch.is_tensor(v) else v) for k, v in noise.items()}
+        out_b = ref(mel[b:b + 1], text=[text[b]], _noise=nb)
+        (out_b.loss * wts[b]).backward()                                     # .grad accumulates over the samples
+        loss_r += out_b.loss.item() * wts[b]
+        flows.append(out_b.pred_flow.detach())
+        assert torch.equal(out_b.cond, out.cond[b:b + 1].cpu())
+        del out_b
+    e_loss = abs(out.loss.item() - loss_r) / abs(loss_r)
+    e_flow = rel2(out.pred_flow, torch.cat(flows))
+    by_layer, worst = _grad_report(model, ref)
+    _report('cfg3_B8_forward_backward_reference_init', dict(case='cfg3 at B = 8, forward + backward, oracle accumulated per sample', kw=kw, B=B, T=T,
+                                                            loss_rel=e_loss, pred_flow_rel_l2=e_flow, weight_grad_rel_l2_by_layer=by_layer, worst=worst))
+    print('cfg3 B=8 fwd+bwd: loss rel', e_loss, 'pred_flow rel-L2', e_flow, 'worst grads', worst[:4])
+    assert e_loss < 1e-2 and e_flow < 1e-2, (e_loss, e_flow)
+    assert max(by_layer.values()) < 0.03 and worst[0][0] < 0.15, (by_layer, worst[:5])

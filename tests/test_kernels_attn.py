@@ -112,21 +112,41 @@ def test_attention(dev, N, has_vres, use_mask, qk_gain):
         assert rel(dvfirst, vres.grad) < 4e-2, rel(dvfirst, vres.grad)
 
 
-def test_attention_dropout(dev):
-    """attention-probability dropout: the oracle is fed the very mask the kernel's counter hash generates"""
+@pytest.mark.parametrize('shape', ['two_key_tiles', 'ragged_small',
+                                   pytest.param('bench', marks=pytest.mark.late), pytest.param('bench_plain_numbering', marks=pytest.mark.late)])
+def test_attention_dropout(dev, shape, monkeypatch):
+    """attention-probability dropout: the oracle is fed the very mask the kernel's counter hash generates.
+    `bench*` (GPU only): the shape bench.py times -- 16 heads, N = 1056 (17 key tiles), p = 0.1, a ragged key mask, B = 2 --
+    with the XCD-aware workgroup numbering of the ring kernels on (default) and off: output and all four gradients"""
+    from conftest import gpu_shapes
     from e2_tts_pytorch_amd import ops
     from oracle.dropout_hash import attn_dropout_mask
     torch.manual_seed(1)
-    B, H, N, p, seed, sid = 1, 8, 70, 0.25, 12345, 6
+    if shape.startswith('bench'):
+        if not gpu_shapes(dev):
+            pytest.skip('bench shape: GPU only (the host model would need an hour)')
+        B, H, N, p, seed, sid, lens = 2, 16, 1056, 0.1, 2024, 92, [1056, 1056 - 389]
+        if shape == 'bench_plain_numbering':
+            monkeypatch.setattr(ops, 'attn_probe', ops.attn_probe | 256)          # E2K_ATTN_PLAIN_WG
+    elif shape == 'ragged_small':
+        B, H, N, p, seed, sid, lens = 2, 3, 150, 0.1, 77, 5, [150, 150 - 37]
+    else:
+        B, H, N, p, seed, sid, lens = 1, 8, 70, 0.25, 12345, 6, None
     D = I = H * 64
     attn = Attention(dim=D, heads=H, dim_head=64, dropout=p, gate_value_heads=True, softclamp_logits=True)
     with torch.no_grad():
         attn.to_out.weight.copy_(torch.eye(D))
     x = torch.randn(B, N, D)
+    mask = None
+    if lens is not None:
+        mask = torch.arange(N)[None] < torch.tensor(lens)[:, None]
     rot = RotaryEmbedding(64).forward_from_seq_len(N)
     Ws = [attn.to_q.weight, attn.to_k.weight, attn.to_v.weight, attn.to_v_head_gate.weight]
     bs = [torch.zeros(3 * I), attn.to_v_head_gate.bias]
     qkvg = (x.reshape(B * N, D) @ torch.cat(Ws).T + torch.cat(bs)).detach().to(bf16)
+    if 3 * I + H != (3 * I + H + 7) // 8 * 8:                  # row stride a multiple of 8 elements
+        ld = (3 * I + H + 7) // 8 * 8
+        qkvg = torch.as_strided(torch.cat([qkvg, torch.zeros(B * N, ld - 3 * I - H, dtype=bf16)], 1).contiguous(), (B * N, 3 * I + H), (ld, 1))
     cols = qkvg.float().requires_grad_(True)
     parts = list(cols.split([I, I, I, H], dim=-1))
 
@@ -141,21 +161,35 @@ def test_attention_dropout(dev):
     attn.dropout_mask = attn_dropout_mask(seed, sid, B, H, N, p)
     frac = (attn.dropout_mask == 0).float().mean().item()
     assert abs(frac - p) < 0.02, frac
-    out = attn(x, rotary_pos_emb=rot)
+    out = attn(x, mask=mask, rotary_pos_emb=rot)
     R = torch.randn(B, N, D)
     (out * R).sum().backward()
 
     cosb, sinb = ops.rotary_table(N, dev)
-    st = ops.qkv_post_fwd(qkvg.to(dev), B, H, N, cosb, sinb, None)
+    if qkvg.stride(0) != qkvg.shape[1]:
+        qd = torch.as_strided(torch.zeros(B * N, qkvg.stride(0), dtype=bf16, device=dev), qkvg.shape, qkvg.stride())
+        qd.copy_(qkvg)
+    else:
+        qd = qkvg.to(dev)
+    st = ops.qkv_post_fwd(qd, B, H, N, cosb, sinb, None)
     kmask = torch.zeros(B, st.Npad, dtype=torch.uint8)
-    kmask[:, :N] = 1
+    kmask[:, :N] = 1 if mask is None else mask.to(torch.uint8)
     kmask = kmask.to(dev)
     Og = ops.attn_fwd(st, kmask, p, seed, sid)
     assert rel(Og.view(B, N, D), out) < 2e-2, rel(Og.view(B, N, D), out)
     dQ, dK, dV, dgate = ops.attn_bwd(st, R.reshape(B * N, D).to(bf16).to(dev), kmask, p, seed, sid)
-    dqkvg = ops.qkv_post_bwd(st, dQ, dK, dV, dgate, qkvg.to(dev), cosb, sinb)
+    dqkvg = ops.qkv_post_bwd(st, dQ, dK, dV, dgate, qd, cosb, sinb)
+    errs = {}
     for name, got, want in zip('qkvg', dqkvg.float().cpu().split([I, I, I, H], dim=-1), cols.grad.split([I, I, I, H], dim=-1)):
-        assert rel(got, want) < 4e-2, (name, rel(got, want))
+        errs[name] = rel(got, want)
+        assert errs[name] < 4e-2, (name, errs)
+    if shape.startswith('bench'):
+        import json
+        from pathlib import Path
+        out_dir = Path(__file__).resolve().parent.parent / 'gpurun_out'
+        if out_dir.is_dir():
+            json.dump(dict(case=shape, B=B, H=H, N=N, p=p, lens=lens, out_rel_max=rel(Og.view(B, N, D), out), grad_rel_max=errs),
+                      open(out_dir / f'r05_parity_attn_dropout_{shape}.json', 'w'), indent=1)
 
 
 @pytest.mark.parametrize('N', [70, 150])
