@@ -131,6 +131,42 @@ __device__ __forceinline__ unsigned long long sload64(const unsigned long long* 
     return *(cp_t)(p);
 }
 
+// v_mfma_f32_32x32x16_bf16: A 32x16 (lane l: row l & 31, k-slots 8 (l >> 5) .. + 7), B 16x32 (lane l: column l & 31, the same
+// k-slots), C / D 32x32: lane l holds column l & 31, register r <-> row (r & 3) + 8 (r >> 2) + 4 (l >> 5)
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+typedef short bf16x8_ __attribute__((ext_vector_type(8)));
+__device__ __forceinline__ f32x16 mfma32(bf16x8_ a, bf16x8_ b, f32x16 c) { return __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, b, c, 0, 0, 0); }
+// v_permlane32_swap_b32: lanes 32..63 of `a` trade places with lanes 0..31 of `b` (the other two halves stay)
+__device__ __forceinline__ void lane32_swap(unsigned& a, unsigned& b) {
+    const auto r = __builtin_amdgcn_permlane32_swap(a, b, false, false);
+    a = r[0];
+    b = r[1];
+}
+// value of the same register in lane (l ^ 32)
+__device__ __forceinline__ float lane32_other(float v) {
+    unsigned a = __builtin_bit_cast(unsigned, v), b = a;
+    lane32_swap(a, b);              // lanes 0..31: b = upper half's value; lanes 32..63: a = lower half's value
+    return __builtin_bit_cast(float, (__builtin_amdgcn_mbcnt_hi(~0u, __builtin_amdgcn_mbcnt_lo(~0u, 0u)) < 32u) ? b : a);
+}
+
+// 16 wave masks (SGPR pairs, e.g. fresh from v_cmp) -> 128 consecutive bytes at a wave-uniform address, through the scalar data cache
+// (s_store_dwordx2: no vector instruction, no VGPR).  The statement waits for its own stores (lgkmcnt) before the SGPRs may be reused;
+// the leading s_nop covers a VALU write of an SGPR read by the scalar memory instruction.  The cache is written back by
+// sstore_flush(), which every wave that stored must execute before it ends.
+__device__ __forceinline__ void sstore_masks16(unsigned long long* dst, const unsigned long long (&m)[16]) {
+    typedef __attribute__((address_space(1))) unsigned long long* gp_t;
+    asm volatile(
+        "s_nop 4\n"
+        "s_store_dwordx2 %1, %0, 0x0\n s_store_dwordx2 %2, %0, 0x8\n s_store_dwordx2 %3, %0, 0x10\n s_store_dwordx2 %4, %0, 0x18\n"
+        "s_store_dwordx2 %5, %0, 0x20\n s_store_dwordx2 %6, %0, 0x28\n s_store_dwordx2 %7, %0, 0x30\n s_store_dwordx2 %8, %0, 0x38\n"
+        "s_store_dwordx2 %9, %0, 0x40\n s_store_dwordx2 %10, %0, 0x48\n s_store_dwordx2 %11, %0, 0x50\n s_store_dwordx2 %12, %0, 0x58\n"
+        "s_store_dwordx2 %13, %0, 0x60\n s_store_dwordx2 %14, %0, 0x68\n s_store_dwordx2 %15, %0, 0x70\n s_store_dwordx2 %16, %0, 0x78\n"
+        "s_waitcnt lgkmcnt(0)"
+        :: "s"((gp_t)dst), "s"(m[0]), "s"(m[1]), "s"(m[2]), "s"(m[3]), "s"(m[4]), "s"(m[5]), "s"(m[6]), "s"(m[7]),
+           "s"(m[8]), "s"(m[9]), "s"(m[10]), "s"(m[11]), "s"(m[12]), "s"(m[13]), "s"(m[14]), "s"(m[15]) : "memory");
+}
+__device__ __forceinline__ void sstore_flush() { asm volatile("s_dcache_wb\n s_waitcnt lgkmcnt(0)" ::: "memory"); }
+
 // counted wait on outstanding vector-memory ops (LDS-DMA included) and a raw workgroup barrier that does NOT drain
 // them: lets global_load_lds prefetches stay in flight across barriers (cdna_hip_programming.md T3+T4)
 // this wave's LDS operations (and scalar loads) have completed: what a raw barrier does NOT wait for

@@ -14,7 +14,7 @@ CSRC = ROOT / 'e2-tts-pytorch_amd' / 'csrc'
 OUT = HERE / 'libe2k_emu.so'
 OBJ = HERE / 'build'
 CXX = os.environ.get('EMU_CXX', '/opt/rocm/lib/llvm/bin/clang++')
-FLAGS = ['-O2', '-g0', '-std=c++17', '-fPIC', '-ffp-contract=off', '-Wno-unused-value', '-Wno-unknown-attributes',
+FLAGS = ['-O2', '-g0', '-std=c++17', '-fPIC', '-ffp-contract=off', '-Wno-unused-value', '-Wno-unknown-attributes', '-Wno-psabi',
          '-I', str(HERE), '-I', str(ROOT / 'include'), '-I', str(CSRC), '-x', 'c++']
 
 

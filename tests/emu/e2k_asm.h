@@ -65,6 +65,46 @@ inline unsigned long long sload64(const unsigned long long* p) { return *p; }
 inline float fast_exp2(float x) { return exp2f(x); }
 inline float fast_rcp(float x) { return 1.0f / x; }
 
+// host model of v_mfma_f32_32x32x16_bf16 (fragment layout: csrc/e2k_asm.h)
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+typedef short bf16x8_ __attribute__((ext_vector_type(8)));
+inline f32x16 mfma32(bf16x8_ a, bf16x8_ b, f32x16 c) {
+    struct AB { bf16x8_ a, b; };
+    emu::Wave& w = emu::cur_wave();
+    emu::Fiber& f = emu::cur_fiber();
+    int p = f.par;
+    f.par ^= 1;
+    int lane = emu::lane_id();
+    AB ab{a, b};
+    memcpy(w.slot[p][lane], &ab, sizeof(AB));
+    emu::wave_rendezvous(w);
+    const int j = lane & 31, hi = lane >> 5;
+    f32x16 d = c;
+    for (int r = 0; r < 16; ++r) {
+        const int i = (r & 3) + 8 * (r >> 2) + 4 * hi;
+        float acc = d[r];
+        for (int h = 0; h < 2; ++h) {
+            AB ra, rb;
+            memcpy(&ra, w.slot[p][i + 32 * h], sizeof(AB));
+            memcpy(&rb, w.slot[p][j + 32 * h], sizeof(AB));
+            for (int e = 0; e < 8; ++e) acc = fmaf(emu_bf2f(ra.a[e]), emu_bf2f(rb.b[e]), acc);
+        }
+        d[r] = acc;
+    }
+    return d;
+}
+inline void lane32_swap(unsigned& a, unsigned& b) {
+    struct P { unsigned a, b; };
+    const int lane = emu::lane_id();
+    const P other = emu::wave_exchange(P{a, b}, lane ^ 32);
+    if (lane < 32) b = other.a; else a = other.b;
+}
+inline float lane32_other(float v) { return __shfl_xor(v, 32); }
+
+inline void sstore_masks16(unsigned long long* dst, const unsigned long long (&m)[16]) {      // (every lane writes the same 128 bytes)
+    for (int i = 0; i < 16; ++i) dst[i] = m[i];
+}
+inline void sstore_flush() {}
 inline void wait_lgkm0() {}
 template <int N> inline void wait_vmcnt() { emu::land_pending(N); }
 inline void barrier_keep_vm() { emu::block_rendezvous(); }
