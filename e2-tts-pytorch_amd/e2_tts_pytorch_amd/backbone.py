@@ -673,6 +673,8 @@ class Transformer(Module):
     def forward(self, x, times=None, mask=None, text_embed=None):
         assert (x.ndim == 4) == self.has_freq_axis, '`has_freq_axis` must be set if passing in tensor with frequency dimension (4 ndims), and not set if passing in only 3'
         assert not (exists(times) ^ self.cond_on_time), '`times` must be passed in if `cond_on_time` is set to `True` and vice versa'
+        if _PlanPool._parked:           # pools of dead plans (another model's): returned to the device at this always-reached safe point
+            _PlanPool.reap()
         if self.has_freq_axis:
             # e2_tts.py:744-752: the F frequency tokens ride in the batch ((b f) n d); text and mask are repeated for them.  The
             # conditioning stays one row per ORIGINAL batch element: the kernels index it by row // (F N)
@@ -733,9 +735,13 @@ class Transformer(Module):
         elif isinstance(handle, bool):
             live = handle
         self._text_grad_live = bool(getattr(self, '_text_grad_live', None)) or live
+        # Is that flag a GLOBAL fact?  Only when our own gradient exchange computed it (ddp._GradSync.begin_text_live).  Under a stock
+        # DistributedDataParallel without the shim it is this rank's own coin: optim.FusedAdopt then makes it global itself (one MAX
+        # all-reduce per optimizer step) before it decides to skip the text stream's parameters -- or the replicas drift apart
+        self._text_live_is_global = getattr(self._sync_target(), 'begin_text_live', None) is not None
         return live
 
-    def _param_grads(self, gflat, live):
+    def _param_grads(self, gflat):
         """gradient views handed to autograd.  The text stream's parameters get exact ZEROS, not None, on a pass whose text
         stream ran on no rank: the whole backbone is one autograd node, so a stock DistributedDataParallel that manages these
         parameters (no `enable_overlap_under_ddp`) waits for a gradient hook of every one of them.  That such a step must not
@@ -832,6 +838,7 @@ class Transformer(Module):
             if isinstance(st, NS):
                 st.free_handles()
         self._plans = {}
+        _PlanPool.reap()            # (a safe point that is reached even if no plan is ever recorded or run again)
 
     def _pool_ctx(self, dev, st):
         # one private pool PER PLAN: a block freed while plan A is being recorded may only be handed out again inside plan
@@ -980,7 +987,7 @@ class Transformer(Module):
         # default: hand the gradients to autograd (AccumulateGrad, DDP hooks, accumulation over several backward passes
         # all behave as usual).  The plan's gradient buffer is rewritten by the next replay, hence the copy (one read +
         # write of the gradients, ~1 ms at dim 1024 / depth 24); enable_persistent_grads() removes it.
-        return self._param_grads(st.gflat.clone(), live)
+        return self._param_grads(st.gflat.clone())
 
     def plan_profile(self):
         """HIP-event time of every recorded launch of the most recently used plan: list of dict(name, ms, flops, phase)"""
@@ -1276,7 +1283,7 @@ class Transformer(Module):
             self._attach_grads()
             pgrads = self._no_pgrads
         else:
-            pgrads = self._param_grads(gflat, live)
+            pgrads = self._param_grads(gflat)
         return dxs, dcond, dtext, pgrads
 
     # persistent gradients -------------------------------------------------------

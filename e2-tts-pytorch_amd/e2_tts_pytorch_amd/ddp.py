@@ -104,7 +104,7 @@ class _GradSync:
     def begin_text_live(self, live, device):
         if self.world == 1:
             return bool(live)
-        t = torch.tensor([1 if live else 0], dtype=torch.int32, device=device)
+        t = torch.full((1,), 1 if live else 0, dtype=torch.int32, device=device)     # (a fill kernel: torch.tensor(..., device=cuda) is a pageable host copy, which synchronises the host with the stream)
         if not t.is_cuda:
             dist.all_reduce(t, op=dist.ReduceOp.MAX, group=self.group)
             return bool(t.item())

@@ -668,6 +668,12 @@ class E2TTS(Module):
     def device(self):
         return next(self.parameters()).device
 
+    def _num_text_ids(self):
+        """ids a tokenizer may produce: CharacterEmbed shifts them by one into a table of text_num_embeds + 1 rows (row 0 = padding,
+        e2_tts.py:398,407-410), InterpolatedCharacterEmbed indexes nn.Embedding(text_num_embeds) directly (e2_tts.py:429,468)"""
+        rows = self.embed_text.embed.num_embeddings
+        return rows if isinstance(self.embed_text, InterpolatedCharacterEmbed) else rows - 1
+
     def transformer_with_pred_head(self, x, cond, times, mask=None, text=None, drop_text_cond=None,
                                    return_drop_text_cond=False):
         seq_len = x.shape[-2]
@@ -720,7 +726,7 @@ class E2TTS(Module):
         if not exists(lens):
             lens = torch.full((batch,), cond_seq_len, device=device, dtype=torch.long)
         if isinstance(text, list):
-            text = _check_token_ids(self.tokenizer(text), self.embed_text.embed.num_embeddings - 1).to(device)
+            text = _check_token_ids(self.tokenizer(text), self._num_text_ids()).to(device)
             assert text.shape[0] == batch
         if exists(text):
             text_lens = (text != -1).sum(dim=-1)
@@ -772,7 +778,7 @@ class E2TTS(Module):
             assert inp.shape[-1] == self.num_channels
         batch, seq_len, dtype, device = inp.shape[0], inp.shape[1], inp.dtype, self.device
         if isinstance(text, list):
-            text = _check_token_ids(self.tokenizer(text), self.embed_text.embed.num_embeddings - 1)
+            text = _check_token_ids(self.tokenizer(text), self._num_text_ids())
             # pinned staging + non-blocking copy: a pageable H2D copy is a synchronising HIP call, i.e. the host would
             # wait here for the previous step's kernels before it can enqueue this one
             text = text.pin_memory().to(device, non_blocking=True) if device.type == 'cuda' else text.to(device)

@@ -98,6 +98,30 @@ class FusedAdopt:
         """optimizer steps taken (= the largest per-parameter count)"""
         return max(self.steps) if self.steps else 0
 
+    def _globalise_text_live(self, dev):
+        """`Transformer._text_grad_live` (did the text stream's parameters receive a gradient this step?) decides whether those
+        parameters are skipped, so it must be the same on every data-parallel rank: the classifier-free-guidance coin that drops the
+        text is flipped per rank (e2_tts.py:1261-1262), and the reference's DistributedDataParallel all-reduces its used-parameter map
+        (trainer.py:155-162).  ddp.DataParallel / enable_overlap_under_ddp make the flag global during the pass; under a stock DDP
+        without the shim it is this rank's own, and one MAX all-reduce over the default group per optimizer step -- a point every
+        rank of a data-parallel job reaches equally often -- settles it here."""
+        import torch.distributed as dist
+        if not (dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1):
+            return
+        local = [tr for tr in self._backbones if getattr(tr, '_text_grad_live', None) is not None and not getattr(tr, '_text_live_is_global', False)]
+        # (every rank must take the same decision about calling the collective: which backbones ran a backward pass of ours since the
+        #  last step is the same everywhere in a data-parallel job; the per-rank part is only the VALUE of the flag)
+        if not local:
+            return
+        t = torch.full((len(local),), 0, dtype=torch.int32, device=dev if dist.get_backend() != 'gloo' else 'cpu')
+        for i, tr in enumerate(local):
+            if tr._text_grad_live:
+                t[i] = 1
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        for tr, v in zip(local, t.tolist()):
+            tr._text_grad_live = bool(v)
+            tr._text_live_is_global = True
+
     def _text_group(self, tr, dev):
         ent = self._ranges.get(id(tr))
         if ent is None or ent[0].device != dev:
@@ -196,6 +220,7 @@ class FusedAdopt:
         # whole flat parameter buffer (alignment pads and the zero "holes" of the layout included: nothing writes their
         # gradients, so they stay exactly zero through the update)
         runs, taken, stepped = [], set(), []
+        self._globalise_text_live(dev)
         for tr in self._backbones:
             slots = getattr(getattr(tr, '_layout', None), 'slots', None)
             flat = getattr(tr, '_flat', None)

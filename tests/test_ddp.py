@@ -157,7 +157,8 @@ def _adopt_worker(rank, world, port, emu_lib, q):
     bad = []
     # (wrapper, persistent flat gradient buffer): this package's DataParallel through both gradient paths, and the stock
     # DistributedDataParallel with the overlap shim (what accelerator.prepare builds around the reference trainer's model)
-    for wrapper, persistent in (('dp', True), ('dp', False), ('stock', False)):
+    # ... and the stock DDP WITHOUT the shim: the flag is then this rank's own until FusedAdopt.step makes it global
+    for wrapper, persistent in (('dp', True), ('dp', False), ('stock', False), ('stock_no_shim', False)):
         random.seed(11)
         torch.manual_seed(11)
         model = E2TTS(transformer=dict(dim=256, depth=2, heads=4, dropout=0., num_registers=8), use_vocos=False, cond_drop_prob=0.)
@@ -167,7 +168,8 @@ def _adopt_worker(rank, world, port, emu_lib, q):
         else:
             from torch.nn.parallel import DistributedDataParallel as DDP
             from e2_tts_pytorch_amd.ddp import enable_overlap_under_ddp
-            enable_overlap_under_ddp(model)
+            if wrapper == 'stock':
+                enable_overlap_under_ddp(model)
             net = DDP(model, find_unused_parameters=True)
         tr = model.transformer
         tr.enable_plans(False)
