@@ -119,17 +119,17 @@ def synthetic_text(B, seed):
     return [''.join(rng.choice(alphabet) for _ in range(rng.randint(20, 200))) for _ in range(B)]
 
 
-def cpu_baseline(dim, depth, heads, T, sample_depth=12, threads=None):
-    """oracle (fp32, torch CPU) on a bounded sample of the same workload: same width / heads / sequence length,
-    B = 1 and `sample_depth` of the `depth` layers (every layer costs the same), one fwd+bwd; the rate is scaled to
-    the full depth (x sample_depth / depth) so that it is in the metric's unit.  Thread count capped at 32: torch's
-    eager CPU ops are bandwidth bound and slow down badly when a 256-thread host oversubscribes them."""
+def cpu_baseline(dim, depth, heads, T, sample_depth=None, threads=None):
+    """oracle (fp32, torch CPU) on a bounded sample of the same workload: the FULL model (same width / heads / depth / sequence
+    length) at B = 1, one fwd+bwd (about 26 s on the GPU box's host: no extrapolation over layers; `sample_depth` < depth times
+    fewer layers and scales, for quick runs).  Thread count capped at 32: torch's eager CPU ops are bandwidth bound and slow down
+    badly when a 256-thread host oversubscribes them."""
     from oracle import e2tts_oracle as O
     threads = threads or min(32, os.cpu_count() or 1)
     torch.set_num_threads(threads)
     random.seed(0)
     torch.manual_seed(0)
-    sd = min(sample_depth, depth)
+    sd = min(sample_depth or depth, depth)
     model = O.E2TTS(transformer=dict(dim=dim, depth=sd, heads=heads), cond_drop_prob=0.)
     text = synthetic_text(1, 1)
     warm = model(torch.randn(1, 64, 100), text=text)          # thread pool / allocator warm-up, not timed
@@ -142,8 +142,8 @@ def cpu_baseline(dim, depth, heads, T, sample_depth=12, threads=None):
     dt = time.perf_counter() - t0
     return {'value': T / dt * sd / depth, 'unit': 'mel-frames/s', 'cores': threads, 'kind': 'port',
             'sample': f'CPU oracle (fp32 torch eager, {threads} threads): dim={dim} heads={heads} T={T} B=1, '
-                      f'{sd} of {depth} layers, one fwd+bwd = {dt:.1f} s measured; value = T/dt scaled by {sd}/{depth} '
-                      f'to the full-depth step.  The port reproduces the reference source bit for bit where that can be '
+                      f'{sd} of {depth} layers, one fwd+bwd = {dt:.1f} s measured' + ('' if sd == depth else f'; value = T/dt scaled by {sd}/{depth} to the full-depth step') +
+                      f'.  The port reproduces the reference source bit for bit where that can be '
                       f'executed (oracle/pin_against_reference.py); /root/reference itself cannot travel to the GPU box'}
 
 

@@ -51,19 +51,17 @@ __device__ __forceinline__ Clamp32 clamp32(float kx, float out) {
     c.cl = out;
     return c;
 }
+// two scores per packed-fp32 instruction (v_pk_mul_f32 / v_pk_fma_f32: the vector ALU is 16 lanes wide, a wave64 instruction takes
+// 4 clocks whether it carries one fp32 operation per lane or two)
 template <int TIER>
-__device__ __forceinline__ float clamp_eval(float s, const Clamp32& c) {
+__device__ __forceinline__ f32x2_ clamp_eval2(f32x2_ s, const Clamp32& c) {
     if (TIER == 0) {
-        const float w = s * s;
-        return s * fmaf(w, c.c1, c.c0);
+        const f32x2_ w = s * s;
+        return s * (w * c.c1 + c.c0);
     } else if (TIER == 1) {
-        const float w = s * s;
-        float pl = fmaf(w, c.p7.a3, c.p7.a2);
-        pl = fmaf(pl, w, c.p7.a1);
-        pl = fmaf(pl, w, c.p7.a0);
-        return s * pl;
+        return clamp2(s, c.p7);
     } else {
-        return clamp_tanh_scaled(s, c.k2, c.cl);
+        return f32x2_{clamp_tanh_scaled(s[0], c.k2, c.cl), clamp_tanh_scaled(s[1], c.k2, c.cl)};
     }
 }
 __device__ __forceinline__ float abs_max_16(const f32x16& s, float a) {
@@ -113,25 +111,30 @@ __device__ __forceinline__ void store_rows32(const f32x16 (&acc)[2], int hi, boo
 // The 16 scores of one 32-key block of a lane (s[r]: key 16 (r >> 3) + 8 hi + (r & 7) of the block) -> soft-clamp, exp2, row sums,
 // dropout, the two packed B operands of the second MFMA; mk[r]: the keep decisions of score r as a wave ballot.
 //   hk: counter of the block's first group of four keys for this lane; kmb: key-mask bits, bit 16 s2 + e <-> score 8 s2 + e
-template <int TIER, bool DROP, bool SHARE, bool MASKED>
-__device__ __forceinline__ void fwd_block(const f32x16& s, int kb, const Clamp32& cc, float (&lsum4)[4], unsigned hk, unsigned thresh,
+template <int TIER, bool DROP, bool SHARE, bool MASKED, int PROBE>
+__device__ __forceinline__ void fwd_block(const f32x16& s, int kb, const Clamp32& cc, f32x2_ (&lsum2)[2], unsigned hk, unsigned thresh,
                                           unsigned kmb, bf16x8 (&pf)[2], unsigned long long (&mk)[16]) {
 #pragma unroll
     for (int s2 = 0; s2 < 2; ++s2) {
         float pr[8];
 #pragma unroll
-        for (int e = 0; e < 8; ++e) {
-            float z = clamp_eval<TIER>(s[8 * s2 + e], cc);
-            if (MASKED) z = ((kmb >> (16 * s2 + e)) & 1u) ? z : NEG_MASK;      // masked keys (only the last tile or two): exp2 gives an exact 0
-            pr[e] = fast_exp2(z);
-            lsum4[e & 3] += pr[e];                // softmax denominators are taken BEFORE dropout
+        for (int e = 0; e < 8; e += 2) {
+            f32x2_ z = clamp_eval2<TIER>(f32x2_{s[8 * s2 + e], s[8 * s2 + e + 1]}, cc);
+            if (MASKED) {           // masked keys (only the last tile or two): exp2 gives an exact 0
+                z[0] = ((kmb >> (16 * s2 + e)) & 1u) ? z[0] : NEG_MASK;
+                z[1] = ((kmb >> (16 * s2 + e + 1)) & 1u) ? z[1] : NEG_MASK;
+            }
+            pr[e] = (PROBE & 1) ? z[0] : fast_exp2(z[0]);
+            pr[e + 1] = (PROBE & 1) ? z[1] : fast_exp2(z[1]);
+            lsum2[(e >> 1) & 1] += f32x2_{pr[e], pr[e + 1]};          // softmax denominators are taken BEFORE dropout
         }
         if (DROP) {
             // keys 32 kb + 16 s2 + 8 hi + e of the tile: two groups of four consecutive keys = two counter values
 #pragma unroll
             for (int half = 0; half < 2; ++half) {
                 unsigned w0, w1;
-                drop4(hk, (unsigned)(4 * s2 + half), w0, w1);
+                if (PROBE & 2) { w0 = hk + (unsigned)(4 * s2 + half) * 0x10001u; w1 = hk ^ 0x55aa1234u; }
+                else drop4(hk, (unsigned)(4 * s2 + half), w0, w1);
                 const bool kp[4] = {(w0 & 0xffffu) >= thresh, (w0 >> 16) >= thresh, (w1 & 0xffffu) >= thresh, (w1 >> 16) >= thresh};
 #pragma unroll
                 for (int j = 0; j < 4; ++j) {
@@ -147,7 +150,9 @@ __device__ __forceinline__ void fwd_block(const f32x16& s, int kb, const Clamp32
 
 // One workgroup = 128 query rows of one (batch, head): 4 waves x 32 rows.  K / V^T tiles of 64 keys go HBM -> LDS by global_load_lds
 // into a 2-stage ring (counted wait + ONE raw barrier per tile, the next tile in flight during the computation of this one).
-template <bool DROP, bool SHARE, int PUB>          // PUB (SHARE only): how the compare masks are published, 0 v_writelane + vector store, 1 scalar stores
+// PROBE (E2K_ATTN32_PROBE, bottleneck probes: WRONG RESULTS on purpose): 1 no exp2, 2 no counter hash, 4 no score MFMAs, 8 no LDS fragment reads,
+// 16 no output MFMAs, 32 no LDS-DMA after the first two tiles, 64 no barriers
+template <bool DROP, bool SHARE, int PUB, int PROBE = 0>          // PUB (SHARE only): how the compare masks are published, 0 v_writelane + vector store, 1 scalar stores
 __global__ __launch_bounds__(256, 4) void attn_fwd32_kernel(AttnArgs p) {
     __shared__ __attribute__((aligned(16))) unsigned char smem[2 * FSTAGE + RKM];
     lds_declare(smem, sizeof(smem));
@@ -189,9 +194,11 @@ __global__ __launch_bounds__(256, 4) void attn_fwd32_kernel(AttnArgs p) {
         unsigned char* S = smem + stage * FSTAGE;
 #pragma unroll
         for (int u = 0; u < 2; ++u) {
-            const int row = min(k0 + krow[u], p.N - 1);                     // keys past the end: any valid row (masked below)
-            glds16((const char*)Kbase + (long)row * (DH * 2) + kcol[u], S + (wave * 2 + u) * 1024);
-            glds16((const char*)VTbase + (long)k0 * 2 + voff[u], S + 8192 + (wave * 2 + u) * 1024);
+            // keys past the end: any valid row (masked below).  Wave-uniform bases + 32-bit per-lane offsets (no 64-bit per-lane pointers
+            // kept across the loop)
+            const unsigned koff = (unsigned)min(k0 + krow[u], p.N - 1) * (DH * 2) + kcol[u];
+            glds16((const char*)Kbase + koff, S + (wave * 2 + u) * 1024);
+            glds16((const char*)VTbase + ((unsigned)k0 * 2 + voff[u]), S + 8192 + (wave * 2 + u) * 1024);
         }
     };
     int foff[4];
@@ -202,7 +209,7 @@ __global__ __launch_bounds__(256, 4) void attn_fwd32_kernel(AttnArgs p) {
     for (int db = 0; db < 2; ++db)
 #pragma unroll
         for (int r = 0; r < 16; ++r) o[db][r] = 0.f;
-    float lsum4[4] = {0.f, 0.f, 0.f, 0.f};
+    f32x2_ lsum2[2] = {f32x2_{0.f, 0.f}, f32x2_{0.f, 0.f}};
     const float kx = p.scale / CLAMP;
     const Clamp32 cc = clamp32(kx, CLAMP * LOG2E);
     const unsigned hrow = rand_base(p.seed_dev ? *p.seed_dev : p.seed, dstream) + (unsigned)q * 0x85ebca77u;
@@ -214,8 +221,8 @@ __global__ __launch_bounds__(256, 4) void attn_fwd32_kernel(AttnArgs p) {
     for (int kt = 0; kt < nt; ++kt) {
         const int k0 = kt * 64;
         wait_vmcnt<0>();                  // tile kt has landed for this wave ...
-        barrier_raw();                    // ... and for every wave; everyone has finished tile kt - 1
-        if (kt + 1 < nt) issue(kt + 1, (kt + 1) & 1);
+        if (!(PROBE & 64)) barrier_raw(); // ... and for every wave; everyone has finished tile kt - 1
+        if (kt + 1 < nt && !((PROBE & 32) && kt >= 1)) issue(kt + 1, (kt + 1) & 1);
         if (!live) continue;
         const unsigned char* Kt = smem + (kt & 1) * FSTAGE;
         const unsigned char* Vt = Kt + 8192;
@@ -230,18 +237,22 @@ __global__ __launch_bounds__(256, 4) void attn_fwd32_kernel(AttnArgs p) {
 #pragma unroll
             for (int r = 0; r < 16; ++r) s[r] = 0.f;
 #pragma unroll
-            for (int ks = 0; ks < 4; ++ks) s = mfma32(ld<bf16x8>(Kt + foff[ks] + kb * 4096), qf[ks], s);
+            for (int ks = 0; ks < 4; ++ks) {
+                const bf16x8 kf = (PROBE & 8) ? qf[(ks + 1) & 3] : ld<bf16x8>(Kt + foff[ks] + kb * 4096);
+                if (PROBE & 4) s[ks] += __uint_as_float(__builtin_bit_cast(u32x4, kf)[0] & 0x3fffffffu);
+                else s = mfma32(kf, qf[ks], s);
+            }
             bf16x8 pf[2];
             unsigned long long mk[16];
             const int tier = clamp_tier(abs_max_16(s, 0.f), kx);
             const unsigned kmb = (unsigned)(km8 >> (32 * kb));
             const unsigned hk = hlane + ((unsigned)(k0 >> 2) + 8 * kb) * 0xc2b2ae3du;
             if (allk) {
-                if (tier == 0) fwd_block<0, DROP, SHARE, false>(s, kb, cc, lsum4, hk, p.thresh, kmb, pf, mk);
-                else if (tier == 1) fwd_block<1, DROP, SHARE, false>(s, kb, cc, lsum4, hk, p.thresh, kmb, pf, mk);
-                else fwd_block<2, DROP, SHARE, false>(s, kb, cc, lsum4, hk, p.thresh, kmb, pf, mk);
+                if (tier == 0) fwd_block<0, DROP, SHARE, false, PROBE>(s, kb, cc, lsum2, hk, p.thresh, kmb, pf, mk);
+                else if (tier == 1) fwd_block<1, DROP, SHARE, false, PROBE>(s, kb, cc, lsum2, hk, p.thresh, kmb, pf, mk);
+                else fwd_block<2, DROP, SHARE, false, PROBE>(s, kb, cc, lsum2, hk, p.thresh, kmb, pf, mk);
             } else {                    // tiles with masked keys (the last one or two of a sequence): one generic path
-                fwd_block<2, DROP, SHARE, true>(s, kb, cc, lsum4, hk, p.thresh, kmb, pf, mk);
+                fwd_block<2, DROP, SHARE, true, PROBE>(s, kb, cc, lsum2, hk, p.thresh, kmb, pf, mk);
             }
             if (DROP && SHARE) {
                 if (PUB == 1) {             // the 16 compare masks of the block (SGPR pairs) leave through the scalar data cache: no vector instruction
@@ -257,7 +268,11 @@ __global__ __launch_bounds__(256, 4) void attn_fwd32_kernel(AttnArgs p) {
 #pragma unroll
             for (int s2 = 0; s2 < 2; ++s2)
 #pragma unroll
-                for (int db = 0; db < 2; ++db) o[db] = mfma32(ld<bf16x8>(Vt + foff[2 * kb + s2] + db * 4096), pf[s2], o[db]);
+                for (int db = 0; db < 2; ++db) {
+                    const bf16x8 vf = (PROBE & 8) ? qf[2 * s2 + db] : ld<bf16x8>(Vt + foff[2 * kb + s2] + db * 4096);
+                    if (PROBE & 16) o[db][s2] += __uint_as_float((__builtin_bit_cast(u32x4, vf)[0] ^ __builtin_bit_cast(u32x4, pf[s2])[db]) & 0x3fffffffu);
+                    else o[db] = mfma32(vf, pf[s2], o[db]);
+                }
         }
         if (DROP && SHARE && PUB == 0 && lane < 32) {       // lanes 0-31 store the 32 masks as one 256-byte run
             unsigned long long* dropw = p.dropbits + (((long)bh * nt + kt) * nqb + qb) * 32;
@@ -266,7 +281,7 @@ __global__ __launch_bounds__(256, 4) void attn_fwd32_kernel(AttnArgs p) {
     }
     if (DROP && SHARE && PUB == 1) sstore_flush();     // (every wave: write the scalar data cache back before the kernel ends)
     if (!live) return;
-    float lsum = (lsum4[0] + lsum4[1]) + (lsum4[2] + lsum4[3]);
+    float lsum = (lsum2[0][0] + lsum2[0][1]) + (lsum2[1][0] + lsum2[1][1]);
     lsum += lane32_other(lsum);                 // a row's keys are split over lanes l and l + 32
     const float inv = lsum > 0.f ? (DROP ? p.inv_keep : 1.f) / lsum : 0.f;
     const float gt = qin ? p.gate[bh * p.N + q] : 0.f;
@@ -330,16 +345,16 @@ __device__ __forceinline__ bf16x8 tr_frag(const unsigned char* T, const TrOff& t
 
 // soft-clamp tanh of the 16 scores of a block: three wave-uniform tiers (clamp_tier), out-of-line so that the rest of the block's
 // arithmetic exists once
-__device__ __forceinline__ void clamp_block(const f32x16& s, int tier, const Clamp32& cc, float (&th)[16]) {
+__device__ __forceinline__ void clamp_block(const f32x16& s, int tier, const Clamp32& cc, f32x2_ (&th)[8]) {
     if (tier == 0) {
 #pragma unroll
-        for (int r = 0; r < 16; ++r) th[r] = clamp_eval<0>(s[r], cc);
+        for (int r = 0; r < 8; ++r) th[r] = clamp_eval2<0>(f32x2_{s[2 * r], s[2 * r + 1]}, cc);
     } else if (tier == 1) {
 #pragma unroll
-        for (int r = 0; r < 16; ++r) th[r] = clamp_eval<1>(s[r], cc);
+        for (int r = 0; r < 8; ++r) th[r] = clamp_eval2<1>(f32x2_{s[2 * r], s[2 * r + 1]}, cc);
     } else {
 #pragma unroll
-        for (int r = 0; r < 16; ++r) th[r] = clamp_eval<2>(s[r], cc);
+        for (int r = 0; r < 8; ++r) th[r] = clamp_eval2<2>(f32x2_{s[2 * r], s[2 * r + 1]}, cc);
     }
 }
 // keeps a rarely taken, wave-uniform branch a branch (left alone the compiler turns its selects into unconditional ones on the hot path)
@@ -348,7 +363,7 @@ __device__ __forceinline__ void cold_path() { asm volatile("" ::: "memory"); }
 // 16 scores (th = tanh of them) + 16 dP of one 32-key block of a lane -> dS^T (packed, two slabs of 8 keys) -> dQ^T += K^T dS^T
 //   dw: the forward's 16 compare masks of the block (SHARE); Kb: the block's 32 rows of the K tile image
 template <bool DROP, bool SHARE>
-__device__ __forceinline__ void dq_block(const float (&th)[16], const f32x16& dp, float cl2, float lse, float dl, float inv_keep,
+__device__ __forceinline__ void dq_block(const f32x2_ (&th)[8], const f32x16& dp, float cl2, float lse, float dl, float inv_keep,
                                          unsigned hk, unsigned thresh, const unsigned long long* dw, bool allk, unsigned kmb, const unsigned char* Kb,
                                          const TrOff& tro, f32x16 (&dq)[2]) {
 #pragma unroll
@@ -367,19 +382,25 @@ __device__ __forceinline__ void dq_block(const float (&th)[16], const f32x16& dp
             }
         }
 #pragma unroll
-        for (int e = 0; e < 8; ++e) {
+        for (int e = 0; e < 8; e += 2) {
             const int r = 8 * s2 + e;
-            const float pv = fast_exp2(fmaf(th[r], cl2, -lse));
-            float t1 = dp[r];
+            const f32x2_ t = th[r >> 1];
+            const f32x2_ arg = t * cl2 - lse;
+            const f32x2_ pv = {fast_exp2(arg[0]), fast_exp2(arg[1])};
+            f32x2_ t1 = {dp[r], dp[r + 1]};
             if (DROP) {
-                const bool keep = SHARE ? wave_inverse_ballot(sload64(dw + r)) : kp[e];
-                t1 = keep ? t1 : 0.f;
-                t1 = fmaf(t1, inv_keep, -dl);
+                const bool k0 = SHARE ? wave_inverse_ballot(sload64(dw + r)) : kp[e];
+                const bool k1 = SHARE ? wave_inverse_ballot(sload64(dw + r + 1)) : kp[e + 1];
+                t1[0] = k0 ? t1[0] : 0.f;
+                t1[1] = k1 ? t1[1] : 0.f;
+                t1 = t1 * inv_keep - dl;
             } else {
                 t1 = t1 - dl;
             }
-            const float t2 = fmaf(-th[r], th[r], 1.f);
-            dsv[e] = (pv * t2) * t1;
+            const f32x2_ t2 = 1.f - t * t;
+            const f32x2_ ds = (pv * t2) * t1;
+            dsv[e] = ds[0];
+            dsv[e + 1] = ds[1];
         }
         if (!allk) {            // masked keys contribute nothing (only the last tile or two of a sequence)
             cold_path();
@@ -394,8 +415,8 @@ __device__ __forceinline__ void dq_block(const float (&th)[16], const f32x16& dp
 
 // dQ: same sweep and lane layout as the forward (lane = one query, 16 + 16 keys of each 32-key block); K and V tiles (both as
 // K-type images) in a 2-stage LDS-DMA ring; dS^T feeds dQ^T = K^T dS^T with K^T read out of the row-major K tile by transposing reads.
-template <bool DROP, bool SHARE>
-__global__ __launch_bounds__(256, 3) void attn_dq32_kernel(AttnArgs p) {
+template <bool DROP, bool SHARE, int WPS>          // WPS: waves per SIMD the register budget is compiled for
+__global__ __launch_bounds__(256, WPS) void attn_dq32_kernel(AttnArgs p) {
     __shared__ __attribute__((aligned(16))) unsigned char smem[2 * FSTAGE + RKM];
     lds_declare(smem, sizeof(smem));
     unsigned char* const kms = smem + 2 * FSTAGE;
@@ -431,22 +452,19 @@ __global__ __launch_bounds__(256, 3) void attn_dq32_kernel(AttnArgs p) {
 
     const bf16_t* Kbase = p.K + bh * p.N * DH;
     const bf16_t* Vbase = p.V + bh * p.N * DH;
-    int srow[2];
-    unsigned scol[2];
-#pragma unroll
-    for (int u = 0; u < 2; ++u) {
-        const int r = (wave * 2 + u) * 8 + (lane >> 3);
-        srow[u] = swap23(r);
-        scol[u] = (unsigned)((((lane & 7) ^ swz(r))) * 16);
-    }
+    // (LDS row r + 8 of the second instruction: swap23 adds 4 to the tile row, the chunk swizzle flips bit 2 -- derived, not kept in registers)
+    const int srow0 = swap23(wave * 16 + (lane >> 3));
+    const unsigned scol0 = (unsigned)(((lane & 7) ^ swz(wave * 16 + (lane >> 3))) * 16);
     auto issue = [&](int t, int stage) __attribute__((always_inline)) {
         const int k0 = t * 64;
         unsigned char* S = smem + stage * FSTAGE;
 #pragma unroll
         for (int u = 0; u < 2; ++u) {
-            const long row = min(k0 + srow[u], p.N - 1);
-            glds16((const char*)Kbase + row * (DH * 2) + scol[u], S + (wave * 2 + u) * 1024);
-            glds16((const char*)Vbase + row * (DH * 2) + scol[u], S + 8192 + (wave * 2 + u) * 1024);
+            // (a wave-uniform base + ONE 32-bit per-lane offset for both tensors: four 64-bit per-lane pointers kept across the loop were what
+            //  the 168-register budget spilled)
+            const unsigned off = (unsigned)min(k0 + srow0 + 4 * u, p.N - 1) * (DH * 2) + (scol0 ^ (64u * u));
+            glds16((const char*)Kbase + off, S + (wave * 2 + u) * 1024);
+            glds16((const char*)Vbase + off, S + 8192 + (wave * 2 + u) * 1024);
         }
     };
     int foff[4];
@@ -483,13 +501,14 @@ __global__ __launch_bounds__(256, 3) void attn_dq32_kernel(AttnArgs p) {
                 const bf16x8 vf = ld<bf16x8>(Vr + foff[ks] + kb * 4096);
                 s = mfma32(kf, qf[ks], s);
                 dp = mfma32(vf, dof[ks], dp);             // dP^T = V dO^T
+                if (WPS == 3 && ks == 1) sched_fence();  // (at most four fragments in flight: eight cost 16 registers the 168-register budget does not have)
             }
             const int tier = clamp_tier(abs_max_16(s, 0.f), kx);
             const unsigned kmb = (unsigned)(km8 >> (32 * kb));
             const unsigned hk = hlane + ((unsigned)(k0 >> 2) + 8 * kb) * 0xc2b2ae3du;
             const unsigned long long* dw = (DROP && SHARE) ? dropw + 16 * kb : nullptr;
             const unsigned char* Kb = Kt + kb * 4096;
-            float th[16];
+            f32x2_ th[8];
             clamp_block(s, tier, cc, th);
             dq_block<DROP, SHARE>(th, dp, cl2, lse, dl, p.inv_keep, hk, p.thresh, dw, allk, kmb, Kb, tro, dq);
         }
@@ -510,7 +529,7 @@ __global__ __launch_bounds__(256, 3) void attn_dq32_kernel(AttnArgs p) {
 // lane's first query on; nvalid: queries of this lane (counted from its first one) that lie inside the sequence (tail tile only);
 // hq: dropout counter of (first query, key >> 2); dbits: the forward's keep bits of the block for this key (bit 16 s2 + e)
 template <bool DROP, bool SHARE>
-__device__ __forceinline__ void dkv_block(const float (&th)[16], const f32x16& dp, float cl2, float scale, float inv_keep,
+__device__ __forceinline__ void dkv_block(const f32x2_ (&th)[8], const f32x16& dp, float cl2, float scale, float inv_keep,
                                           const float* lse8, const float* del8, bool tail, int nvalid, unsigned hq, int key3, unsigned thresh,
                                           unsigned dbits, const unsigned char* Qb, const unsigned char* dOb, const TrOff& tro, f32x16 (&dk)[2],
                                           f32x16 (&dv)[2]) {
@@ -527,28 +546,41 @@ __device__ __forceinline__ void dkv_block(const float (&th)[16], const f32x16& d
                 for (int j = 0; j < 4; ++j) ls4[j] = 16 * s2 + 4 * eh + j < nvalid ? ls4[j] : 1e30f;
             }
 #pragma unroll
-            for (int j = 0; j < 4; ++j) {
+            for (int j = 0; j < 4; j += 2) {
                 const int e = 4 * eh + j, r = 8 * s2 + e;
-                const float pr = fast_exp2(fmaf(th[r], cl2, -ls4[j]));
-                float pk = pr, t1 = dp[r];
+                const f32x2_ t = th[r >> 1];
+                const f32x2_ arg = t * cl2 - f32x2_{ls4[j], ls4[j + 1]};
+                const f32x2_ pr = {fast_exp2(arg[0]), fast_exp2(arg[1])};
+                f32x2_ pk = pr, t1 = {dp[r], dp[r + 1]};
+                const f32x2_ dl2 = {dl4[j], dl4[j + 1]};
                 if (DROP) {
-                    bool keep;
-                    if (SHARE) {
-                        keep = (dbits >> (16 * s2 + e)) & 1u;
+                    if (SHARE) {             // the keep bit as an all-ones / all-zeros word (v_bfe_i32), ANDed onto the two values it switches
+                        const unsigned m0 = 0u - ((dbits >> (16 * s2 + e)) & 1u), m1 = 0u - ((dbits >> (16 * s2 + e + 1)) & 1u);
+                        pk[0] = __uint_as_float(__float_as_uint(pr[0]) & m0);
+                        pk[1] = __uint_as_float(__float_as_uint(pr[1]) & m1);
+                        t1[0] = __uint_as_float(__float_as_uint(t1[0]) & m0);
+                        t1[1] = __uint_as_float(__float_as_uint(t1[1]) & m1);
                     } else {
                         unsigned w0, w1;
                         drop4(hq + (unsigned)(16 * s2 + e) * 0x85ebca77u, 0u, w0, w1);
-                        keep = drop_sample(w0, w1, key3) >= thresh;
+                        const bool k0 = drop_sample(w0, w1, key3) >= thresh;
+                        drop4(hq + (unsigned)(16 * s2 + e + 1) * 0x85ebca77u, 0u, w0, w1);
+                        const bool k1 = drop_sample(w0, w1, key3) >= thresh;
+                        pk[0] = k0 ? pr[0] : 0.f;
+                        pk[1] = k1 ? pr[1] : 0.f;
+                        t1[0] = k0 ? t1[0] : 0.f;
+                        t1[1] = k1 ? t1[1] : 0.f;
                     }
-                    pk = keep ? pr : 0.f;             // (1 / (1 - p) is applied to dV once at the end)
-                    t1 = keep ? t1 : 0.f;
-                    t1 = fmaf(t1, inv_keep, -dl4[j]);
+                    t1 = t1 * inv_keep - dl2;         // (1 / (1 - p) is applied to dV once at the end)
                 } else {
-                    t1 = t1 - dl4[j];
+                    t1 = t1 - dl2;
                 }
-                const float t2 = fmaf(th[r] * -scale, th[r], scale);      // (1 - th^2) * scale
-                pd[e] = pk;
-                dsv[e] = (pr * t2) * t1;
+                const f32x2_ t2 = (t * -scale) * t + scale;      // (1 - th^2) * scale
+                const f32x2_ ds = (pr * t2) * t1;
+                pd[e] = pk[0];
+                pd[e + 1] = pk[1];
+                dsv[e] = ds[0];
+                dsv[e + 1] = ds[1];
             }
         }
         // (no key masking here: a lane's scores all belong to ITS key, whose dK / dV row is zeroed at the end)
@@ -603,22 +635,17 @@ __global__ __launch_bounds__(256, 2) void attn_dkv32_kernel(AttnArgs p) {
     const bf16_t* dObase = p.dO + bh * p.N * DH;
     const float* lsebase = p.lse2 + bh * p.N;
     const float* delbase = p.delta + bh * p.N;
-    int srow[2];
-    unsigned scol[2];
-#pragma unroll
-    for (int u = 0; u < 2; ++u) {
-        const int r = (wave * 2 + u) * 8 + (lane >> 3);
-        srow[u] = swap23(r);
-        scol[u] = (unsigned)((((lane & 7) ^ swz(r))) * 16);
-    }
+    // (LDS row r + 8 of the second instruction: swap23 adds 4 to the tile row, the chunk swizzle flips bit 2 -- derived, not kept in registers)
+    const int srow0 = swap23(wave * 16 + (lane >> 3));
+    const unsigned scol0 = (unsigned)(((lane & 7) ^ swz(wave * 16 + (lane >> 3))) * 16);
     auto issue = [&](int t, int stage) __attribute__((always_inline)) {
         const int q0 = t * 64;
         unsigned char* S = smem + stage * DSTAGE32;
 #pragma unroll
         for (int u = 0; u < 2; ++u) {
-            const long row = min(q0 + srow[u], p.N - 1);
-            glds16((const char*)Qbase + row * (DH * 2) + scol[u], S + (wave * 2 + u) * 1024);
-            glds16((const char*)dObase + row * (DH * 2) + scol[u], S + 8192 + (wave * 2 + u) * 1024);
+            const unsigned off = (unsigned)min(q0 + srow0 + 4 * u, p.N - 1) * (DH * 2) + (scol0 ^ (64u * u));
+            glds16((const char*)Qbase + off, S + (wave * 2 + u) * 1024);
+            glds16((const char*)dObase + off, S + 8192 + (wave * 2 + u) * 1024);
         }
         if (wave < 2) glds4((wave == 0 ? lsebase : delbase) + min(q0 + lane, p.N - 1), S + FSTAGE + wave * 256);
     };
@@ -677,7 +704,7 @@ __global__ __launch_bounds__(256, 2) void attn_dkv32_kernel(AttnArgs p) {
             const unsigned char* dOb = dOt + qb2 * 4096;
             const int qrow = q0 + 32 * qb2 + 8 * hi;              // + 16 s2 + e: this lane's queries
             const unsigned hq = hkey + (unsigned)qrow * 0x85ebca77u;
-            float th[16];
+            f32x2_ th[8];
             clamp_block(s, tier, cc, th);
             dkv_block<DROP, SHARE>(th, dp, cl2, p.scale, p.inv_keep, lse_s + 32 * qb2 + 8 * hi, del_s + 32 * qb2 + 8 * hi, tail, p.N - qrow, hq, key & 3,
                                    p.thresh, dword[qb2], Qb, dOb, tro, dk, dv);
@@ -711,8 +738,17 @@ namespace e2k_attn32 {
 void fwd(const void* attn_args, bool drop, bool share, hipStream_t st) {
     const AttnArgs& a = *(const AttnArgs*)attn_args;
     const dim3 grid(((a.N + 127) / 128) * a.H * a.B), block(256);
-    const char* pe = getenv("E2K_ATTN32_PUB");              // (1: scalar stores, see attn_fwd32_kernel; read per call: A/B inside one process)
-    const int pub = pe ? atoi(pe) : 0;
+    const char* pe = getenv("E2K_ATTN32_PUB");              // (default 1: scalar stores, 0: v_writelane, see attn_fwd32_kernel; read per call: A/B inside one process)
+    const int pub = pe ? atoi(pe) : 1;
+    const char* pr = getenv("E2K_ATTN32_PROBE");
+    const int probe = pr ? atoi(pr) : 0;
+    if (probe && drop && share) {
+        switch (probe) {
+#define E2K_P(X) case X: hipLaunchKernelGGL((attn_fwd32_kernel<true, true, 1, X>), grid, block, 0, st, a); return;
+            E2K_P(1) E2K_P(2) E2K_P(3) E2K_P(4) E2K_P(8) E2K_P(12) E2K_P(16) E2K_P(28) E2K_P(32) E2K_P(64) E2K_P(96) E2K_P(31) E2K_P(127)
+#undef E2K_P
+        }
+    }
     if (drop && share && pub == 1) hipLaunchKernelGGL((attn_fwd32_kernel<true, true, 1>), grid, block, 0, st, a);
     else if (drop && share) hipLaunchKernelGGL((attn_fwd32_kernel<true, true, 0>), grid, block, 0, st, a);
     else if (drop) hipLaunchKernelGGL((attn_fwd32_kernel<true, false, 0>), grid, block, 0, st, a);
@@ -722,9 +758,16 @@ void fwd(const void* attn_args, bool drop, bool share, hipStream_t st) {
 void bwd_dq(const void* attn_args, bool drop, bool share, hipStream_t st) {
     const AttnArgs& a = *(const AttnArgs*)attn_args;
     const dim3 grid(((a.N + 127) / 128) * a.H * a.B), block(256);
-    if (drop && share) hipLaunchKernelGGL((attn_dq32_kernel<true, true>), grid, block, 0, st, a);
-    else if (drop) hipLaunchKernelGGL((attn_dq32_kernel<true, false>), grid, block, 0, st, a);
-    else hipLaunchKernelGGL((attn_dq32_kernel<false, false>), grid, block, 0, st, a);
+    const char* we = getenv("E2K_ATTN32_DQ_WPS");           // (A/B: 2 = no register cap)
+    if (we && atoi(we) == 2) {
+        if (drop && share) hipLaunchKernelGGL((attn_dq32_kernel<true, true, 2>), grid, block, 0, st, a);
+        else if (drop) hipLaunchKernelGGL((attn_dq32_kernel<true, false, 2>), grid, block, 0, st, a);
+        else hipLaunchKernelGGL((attn_dq32_kernel<false, false, 2>), grid, block, 0, st, a);
+        return;
+    }
+    if (drop && share) hipLaunchKernelGGL((attn_dq32_kernel<true, true, 3>), grid, block, 0, st, a);
+    else if (drop) hipLaunchKernelGGL((attn_dq32_kernel<true, false, 3>), grid, block, 0, st, a);
+    else hipLaunchKernelGGL((attn_dq32_kernel<false, false, 3>), grid, block, 0, st, a);
 }
 
 void bwd_dkv(const void* attn_args, bool drop, bool share, hipStream_t st) {

@@ -25,13 +25,13 @@ st = ops.qkv_post_fwd(qkvg, B, H, N, cosb, sinb, vfirst)
 kmask = torch.zeros(B, st.Npad, dtype=torch.uint8, device=dev)
 kmask[:, :N] = 1
 dOg = torch.randn(M, I, device=dev).to(bf16)
-VARIANTS = {'ring16': (64, '0'), 'attn32_writelane': (0, '0'), 'attn32_sstore': (0, '1')}
+VARIANTS = {'ring16': (64, '0', '3'), 'attn32_writelane': (0, '0', '3'), 'attn32_sstore': (0, '1', '3'), 'attn32_sstore_dq2': (0, '1', '2')}
 if '--no-sstore' in sys.argv:
     VARIANTS.pop('attn32_sstore')
 
 
 def select(name):
-    ops.attn_probe, os.environ['E2K_ATTN32_PUB'] = VARIANTS[name]
+    ops.attn_probe, os.environ['E2K_ATTN32_PUB'], os.environ['E2K_ATTN32_DQ_WPS'] = VARIANTS[name]
 
 
 def timeit(fn, iters=20):
