@@ -1148,7 +1148,7 @@ constexpr int DSTAGE = 2 * 8192 + 512;
 
 // (three waves per SIMD: with dropout masks handed over it needs 152 VGPRs.  Compiled for four -- 128 VGPRs, 24 dwords spilled
 //  into the loop -- the backward of a cfg3 attention call took 366 us instead of 282, profiles/r04_attn_micro_ab.txt)
-template <bool DROP, bool SHARE>
+template <bool DROP, bool SHARE, bool L32 = false>       // L32: the keep masks come in the layout attn_fwd32_kernel publishes (attn32.hip)
 __global__ __launch_bounds__(256, 3) void attn_bwd_dkv_ring_kernel(AttnArgs p) {
     __shared__ __attribute__((aligned(16))) unsigned char smem[2 * DSTAGE];
     lds_declare(smem, sizeof(smem));
@@ -1229,11 +1229,21 @@ __global__ __launch_bounds__(256, 3) void attn_bwd_dkv_ring_kernel(AttnArgs p) {
     const int dbit0 = 16 * ((pos >> 3) & 3) + 8 * (g & 1);        // (a multiple of 8: the eight bits are ONE BYTE of the word)
     const unsigned char* dbase = nullptr;
     unsigned dnext[2] = {0u, 0u};
+    // L32: the forward keeps (query, key) in ballot word [key tile][32-query block][16 kbf + 8 sf + ef], bit (query & 31) + 32 hif, with
+    // key & 63 = 32 kbf + 16 sf + 8 hif + ef: this lane's eight queries 8 g .. 8 g + 7 of a 32-query block are byte g of the key's half word
+    const int nqb = (p.N + 31) / 32;
+    const long dstep = L32 ? 2L * 32 * 8 : 64L * 8;              // bytes from one 64-query tile to the next
+    const long dhalf = L32 ? 32L * 8 : 2L * 16 * 8;               // ... from its first 32-query half to the second
     if (DROP && SHARE) {
-        const int tf = 2 * (pos >> 5) + ((pos >> 2) & 1), rf = pos & 3;
-        dbase = (const unsigned char*)(p.dropbits + ((((long)bh * ntiles + kt64) * ntiles) * 4 + (g >> 1)) * 16 + 4 * tf + rf) + (dbit0 >> 3);
+        if (L32) {
+            const int wf = 16 * (pos >> 5) + 8 * ((pos >> 4) & 1) + (pos & 7), hif = (pos >> 3) & 1;
+            dbase = (const unsigned char*)(p.dropbits + ((long)bh * ntiles + kt64) * nqb * 32 + wf) + 4 * hif + g;
+        } else {
+            const int tf = 2 * (pos >> 5) + ((pos >> 2) & 1), rf = pos & 3;
+            dbase = (const unsigned char*)(p.dropbits + ((((long)bh * ntiles + kt64) * ntiles) * 4 + (g >> 1)) * 16 + 4 * tf + rf) + (dbit0 >> 3);
+        }
         dnext[0] = dbase[0];
-        dnext[1] = dbase[2 * 16 * 8];
+        dnext[1] = (!L32 || 1 < nqb) ? dbase[dhalf] : 0u;
     }
     // every ordinary global load of the prologue is waited for BEFORE the first LDS-DMA (see attn_fwd_ring_kernel)
     asm volatile("" ::"v"(kf[0]), "v"(kf[1]), "v"(vf[0]), "v"(vf[1]), "v"(hkey), "v"(kkeep));
@@ -1245,8 +1255,8 @@ __global__ __launch_bounds__(256, 3) void attn_bwd_dkv_ring_kernel(AttnArgs p) {
         const unsigned dword[2] = {dnext[0], dnext[1]};
         if (qt + 1 < ntiles) {
             if (DROP && SHARE) {
-                dnext[0] = dbase[(long)(qt + 1) * 64 * 8];
-                dnext[1] = dbase[((long)(qt + 1) * 64 + 2 * 16) * 8];
+                dnext[0] = dbase[(qt + 1) * dstep];
+                dnext[1] = (!L32 || 2 * qt + 3 < nqb) ? dbase[(qt + 1) * dstep + dhalf] : 0u;      // (L32: the last 64-query tile may hold one 32-query block)
             }
             issue(qt + 1, (qt + 1) & 1);
         }
@@ -1567,9 +1577,17 @@ static int attn_bwd_impl(const void* dOg, const void* O, const float* gate, cons
         const dim3 grid((N + 63) / 64, H, B), block(256);
         const dim3 grid1(((N + 63) / 64) * H * B);                     // ring kernels: 1-D, ring_wg() numbers the workgroups
         if (!(flags & (E2K_ATTN_NO_RING | E2K_ATTN_RING16)) && Npad <= RKM) {
+            // second generation (attn32.hip).  E2K_ATTN32_DKV=16: dK / dV by the first-generation kernel (16 keys per wave, three waves per
+            // SIMD) reading the keep masks in the layout of attn_fwd32_kernel -- same-box A/B at the bench shape: backward 264.6 us with the
+            // 32-key kernel, 268.8 with this mix, 264.5 all first generation (profiles/r05g_attn32_ab.json): no difference, the default is
+            // the one generation
             e2k_attn32::bwd_dq(&a, a.thresh != 0, a.thresh && dropbits, st);
             E2K_CHECK_LAUNCH();
-            e2k_attn32::bwd_dkv(&a, a.thresh != 0, a.thresh && dropbits, st);
+            const char* de = getenv("E2K_ATTN32_DKV");
+            if (!(de && atoi(de) == 16)) e2k_attn32::bwd_dkv(&a, a.thresh != 0, a.thresh && dropbits, st);
+            else if (a.thresh && dropbits) hipLaunchKernelGGL((attn_bwd_dkv_ring_kernel<true, true, true>), grid1, block, 0, st, a);
+            else if (a.thresh) hipLaunchKernelGGL((attn_bwd_dkv_ring_kernel<true, false>), grid1, block, 0, st, a);
+            else hipLaunchKernelGGL((attn_bwd_dkv_ring_kernel<false, false>), grid1, block, 0, st, a);
             E2K_CHECK_LAUNCH();
             return 0;
         }

@@ -150,9 +150,9 @@ __device__ __forceinline__ void fwd_block(const f32x16& s, int kb, const Clamp32
 
 // One workgroup = 128 query rows of one (batch, head): 4 waves x 32 rows.  K / V^T tiles of 64 keys go HBM -> LDS by global_load_lds
 // into a 2-stage ring (counted wait + ONE raw barrier per tile, the next tile in flight during the computation of this one).
-// PROBE (E2K_ATTN32_PROBE, bottleneck probes: WRONG RESULTS on purpose): 1 no exp2, 2 no counter hash, 4 no score MFMAs, 8 no LDS fragment reads,
-// 16 no output MFMAs, 32 no LDS-DMA after the first two tiles, 64 no barriers
-template <bool DROP, bool SHARE, int PUB, int PROBE = 0>          // PUB (SHARE only): how the compare masks are published, 0 v_writelane + vector store, 1 scalar stores
+// PROBE (E2K_ATTN32_PROBE, bottleneck probes: WRONG RESULTS on purpose): 1 no exp2, 2 no counter hash, 4 no score MFMAs, 8 no LDS fragment
+// reads, 16 no output MFMAs, 32 no LDS-DMA after the first two tiles, 64 no barriers
+template <bool DROP, bool SHARE, int PROBE = 0>
 __global__ __launch_bounds__(256, 4) void attn_fwd32_kernel(AttnArgs p) {
     __shared__ __attribute__((aligned(16))) unsigned char smem[2 * FSTAGE + RKM];
     lds_declare(smem, sizeof(smem));
@@ -163,6 +163,9 @@ __global__ __launch_bounds__(256, 4) void attn_fwd32_kernel(AttnArgs p) {
     const RingWG wg = ring_wg(p, nq);
     const int h = wg.h, b = wg.b;
     const long bh = (long)b * p.H + h;
+    // (the partly filled last tile of a row -- one live wave of four at N = 1056 -- as a launch of its own whose waves split the keys of the
+    //  live block was measured: 95.9 us against 90 for this single launch, in which those workgroups overlap the end of the others;
+    //  profiles/r05h_attn32_tail_split_ab.json)
     const int qb = wg.x * 4 + wave;                               // 32-row block of this wave
     const int q = qb * 32 + l31;
     const bool qin = q < p.N;
@@ -229,8 +232,7 @@ __global__ __launch_bounds__(256, 4) void attn_fwd32_kernel(AttnArgs p) {
         // key-mask bits of this lane's keys: byte 4 kb + 2 s2 + hi of the tile's eight
         const unsigned long long km8 = ld<unsigned long long>(kms + (k0 >> 3)) >> (8 * hi);
         const bool allk = wave_all((km8 & 0x00ff00ff00ff00ffull) == 0x00ff00ff00ff00ffull);
-        unsigned blo = 0, bhi = 0;               // (SHARE) compare mask i of the tile = lane i's (blo, bhi)
-        // one 32-key block at a time from the score MFMAs to the output MFMAs (WPS = 4: 16 score registers live instead of 32)
+        // one 32-key block at a time from the score MFMAs to the output MFMAs (16 score registers live instead of 32)
 #pragma unroll
         for (int kb = 0; kb < 2; ++kb) {
             f32x16 s;
@@ -255,33 +257,24 @@ __global__ __launch_bounds__(256, 4) void attn_fwd32_kernel(AttnArgs p) {
                 fwd_block<2, DROP, SHARE, true, PROBE>(s, kb, cc, lsum2, hk, p.thresh, kmb, pf, mk);
             }
             if (DROP && SHARE) {
-                if (PUB == 1) {             // the 16 compare masks of the block (SGPR pairs) leave through the scalar data cache: no vector instruction
-                    sstore_masks16(p.dropbits + (((long)bh * nt + kt) * nqb + qb) * 32 + 16 * kb, mk);
-                } else {                    // mask i goes into lane 16 kb + i's registers (v_writelane)
-#pragma unroll
-                    for (int i = 0; i < 16; ++i) {
-                        blo = wave_writelane(blo, (unsigned)mk[i], 16 * kb + i);
-                        bhi = wave_writelane(bhi, (unsigned)(mk[i] >> 32), 16 * kb + i);
-                    }
-                }
+                // the compare masks of the block (SGPR pairs) leave through the scalar data cache: no vector instruction
+                unsigned long long* dw = p.dropbits + (((long)bh * nt + kt) * nqb + qb) * 32 + 16 * kb;
+                sstore_masks16(dw, mk);
             }
 #pragma unroll
-            for (int s2 = 0; s2 < 2; ++s2)
+            for (int s2 = 0; s2 < 2; ++s2) {
 #pragma unroll
                 for (int db = 0; db < 2; ++db) {
                     const bf16x8 vf = (PROBE & 8) ? qf[2 * s2 + db] : ld<bf16x8>(Vt + foff[2 * kb + s2] + db * 4096);
                     if (PROBE & 16) o[db][s2] += __uint_as_float((__builtin_bit_cast(u32x4, vf)[0] ^ __builtin_bit_cast(u32x4, pf[s2])[db]) & 0x3fffffffu);
                     else o[db] = mfma32(vf, pf[s2], o[db]);
                 }
-        }
-        if (DROP && SHARE && PUB == 0 && lane < 32) {       // lanes 0-31 store the 32 masks as one 256-byte run
-            unsigned long long* dropw = p.dropbits + (((long)bh * nt + kt) * nqb + qb) * 32;
-            dropw[lane] = (unsigned long long)blo | ((unsigned long long)bhi << 32);
+            }
         }
     }
-    if (DROP && SHARE && PUB == 1) sstore_flush();     // (every wave: write the scalar data cache back before the kernel ends)
-    if (!live) return;
+    if (DROP && SHARE) sstore_flush();     // (every wave: write the scalar data cache back before the kernel ends)
     float lsum = (lsum2[0][0] + lsum2[0][1]) + (lsum2[1][0] + lsum2[1][1]);
+    if (!live) return;
     lsum += lane32_other(lsum);                 // a row's keys are split over lanes l and l + 32
     const float inv = lsum > 0.f ? (DROP ? p.inv_keep : 1.f) / lsum : 0.f;
     const float gt = qin ? p.gate[bh * p.N + q] : 0.f;
@@ -738,33 +731,23 @@ namespace e2k_attn32 {
 void fwd(const void* attn_args, bool drop, bool share, hipStream_t st) {
     const AttnArgs& a = *(const AttnArgs*)attn_args;
     const dim3 grid(((a.N + 127) / 128) * a.H * a.B), block(256);
-    const char* pe = getenv("E2K_ATTN32_PUB");              // (default 1: scalar stores, 0: v_writelane, see attn_fwd32_kernel; read per call: A/B inside one process)
-    const int pub = pe ? atoi(pe) : 1;
     const char* pr = getenv("E2K_ATTN32_PROBE");
     const int probe = pr ? atoi(pr) : 0;
     if (probe && drop && share) {
         switch (probe) {
-#define E2K_P(X) case X: hipLaunchKernelGGL((attn_fwd32_kernel<true, true, 1, X>), grid, block, 0, st, a); return;
+#define E2K_P(X) case X: hipLaunchKernelGGL((attn_fwd32_kernel<true, true, X>), grid, block, 0, st, a); return;
             E2K_P(1) E2K_P(2) E2K_P(3) E2K_P(4) E2K_P(8) E2K_P(12) E2K_P(16) E2K_P(28) E2K_P(32) E2K_P(64) E2K_P(96) E2K_P(31) E2K_P(127)
 #undef E2K_P
         }
     }
-    if (drop && share && pub == 1) hipLaunchKernelGGL((attn_fwd32_kernel<true, true, 1>), grid, block, 0, st, a);
-    else if (drop && share) hipLaunchKernelGGL((attn_fwd32_kernel<true, true, 0>), grid, block, 0, st, a);
-    else if (drop) hipLaunchKernelGGL((attn_fwd32_kernel<true, false, 0>), grid, block, 0, st, a);
-    else hipLaunchKernelGGL((attn_fwd32_kernel<false, false, 0>), grid, block, 0, st, a);
+    if (drop && share) hipLaunchKernelGGL((attn_fwd32_kernel<true, true>), grid, block, 0, st, a);
+    else if (drop) hipLaunchKernelGGL((attn_fwd32_kernel<true, false>), grid, block, 0, st, a);
+    else hipLaunchKernelGGL((attn_fwd32_kernel<false, false>), grid, block, 0, st, a);
 }
 
 void bwd_dq(const void* attn_args, bool drop, bool share, hipStream_t st) {
     const AttnArgs& a = *(const AttnArgs*)attn_args;
     const dim3 grid(((a.N + 127) / 128) * a.H * a.B), block(256);
-    const char* we = getenv("E2K_ATTN32_DQ_WPS");           // (A/B: 2 = no register cap)
-    if (we && atoi(we) == 2) {
-        if (drop && share) hipLaunchKernelGGL((attn_dq32_kernel<true, true, 2>), grid, block, 0, st, a);
-        else if (drop) hipLaunchKernelGGL((attn_dq32_kernel<true, false, 2>), grid, block, 0, st, a);
-        else hipLaunchKernelGGL((attn_dq32_kernel<false, false, 2>), grid, block, 0, st, a);
-        return;
-    }
     if (drop && share) hipLaunchKernelGGL((attn_dq32_kernel<true, true, 3>), grid, block, 0, st, a);
     else if (drop) hipLaunchKernelGGL((attn_dq32_kernel<true, false, 3>), grid, block, 0, st, a);
     else hipLaunchKernelGGL((attn_dq32_kernel<false, false, 3>), grid, block, 0, st, a);

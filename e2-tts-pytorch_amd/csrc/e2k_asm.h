@@ -153,17 +153,33 @@ __device__ __forceinline__ float lane32_other(float v) {
 // (s_store_dwordx2: no vector instruction, no VGPR).  The statement waits for its own stores (lgkmcnt) before the SGPRs may be reused;
 // the leading s_nop covers a VALU write of an SGPR read by the scalar memory instruction.  The cache is written back by
 // sstore_flush(), which every wave that stored must execute before it ends.
+template <bool WAIT = true>
 __device__ __forceinline__ void sstore_masks16(unsigned long long* dst, const unsigned long long (&m)[16]) {
+    typedef __attribute__((address_space(1))) unsigned long long* gp_t;
+#define E2K_SST16_ \
+        "s_nop 4\n" \
+        "s_store_dwordx2 %1, %0, 0x0\n s_store_dwordx2 %2, %0, 0x8\n s_store_dwordx2 %3, %0, 0x10\n s_store_dwordx2 %4, %0, 0x18\n" \
+        "s_store_dwordx2 %5, %0, 0x20\n s_store_dwordx2 %6, %0, 0x28\n s_store_dwordx2 %7, %0, 0x30\n s_store_dwordx2 %8, %0, 0x38\n" \
+        "s_store_dwordx2 %9, %0, 0x40\n s_store_dwordx2 %10, %0, 0x48\n s_store_dwordx2 %11, %0, 0x50\n s_store_dwordx2 %12, %0, 0x58\n" \
+        "s_store_dwordx2 %13, %0, 0x60\n s_store_dwordx2 %14, %0, 0x68\n s_store_dwordx2 %15, %0, 0x70\n s_store_dwordx2 %16, %0, 0x78\n"
+#define E2K_SST16_OPS_ \
+        :: "s"((gp_t)dst), "s"(m[0]), "s"(m[1]), "s"(m[2]), "s"(m[3]), "s"(m[4]), "s"(m[5]), "s"(m[6]), "s"(m[7]), \
+           "s"(m[8]), "s"(m[9]), "s"(m[10]), "s"(m[11]), "s"(m[12]), "s"(m[13]), "s"(m[14]), "s"(m[15]) : "memory"
+    if (WAIT) asm volatile(E2K_SST16_ "s_waitcnt lgkmcnt(0)" E2K_SST16_OPS_);
+    else asm volatile(E2K_SST16_ "s_nop 0" E2K_SST16_OPS_);          // (probe: are the data SGPRs read at issue?)
+#undef E2K_SST16_
+#undef E2K_SST16_OPS_
+}
+// eight masks (64 bytes)
+__device__ __forceinline__ void sstore_masks8(unsigned long long* dst, unsigned long long m0, unsigned long long m1, unsigned long long m2, unsigned long long m3,
+                                              unsigned long long m4, unsigned long long m5, unsigned long long m6, unsigned long long m7) {
     typedef __attribute__((address_space(1))) unsigned long long* gp_t;
     asm volatile(
         "s_nop 4\n"
         "s_store_dwordx2 %1, %0, 0x0\n s_store_dwordx2 %2, %0, 0x8\n s_store_dwordx2 %3, %0, 0x10\n s_store_dwordx2 %4, %0, 0x18\n"
         "s_store_dwordx2 %5, %0, 0x20\n s_store_dwordx2 %6, %0, 0x28\n s_store_dwordx2 %7, %0, 0x30\n s_store_dwordx2 %8, %0, 0x38\n"
-        "s_store_dwordx2 %9, %0, 0x40\n s_store_dwordx2 %10, %0, 0x48\n s_store_dwordx2 %11, %0, 0x50\n s_store_dwordx2 %12, %0, 0x58\n"
-        "s_store_dwordx2 %13, %0, 0x60\n s_store_dwordx2 %14, %0, 0x68\n s_store_dwordx2 %15, %0, 0x70\n s_store_dwordx2 %16, %0, 0x78\n"
         "s_waitcnt lgkmcnt(0)"
-        :: "s"((gp_t)dst), "s"(m[0]), "s"(m[1]), "s"(m[2]), "s"(m[3]), "s"(m[4]), "s"(m[5]), "s"(m[6]), "s"(m[7]),
-           "s"(m[8]), "s"(m[9]), "s"(m[10]), "s"(m[11]), "s"(m[12]), "s"(m[13]), "s"(m[14]), "s"(m[15]) : "memory");
+        :: "s"((gp_t)dst), "s"(m0), "s"(m1), "s"(m2), "s"(m3), "s"(m4), "s"(m5), "s"(m6), "s"(m7) : "memory");
 }
 __device__ __forceinline__ void sstore_flush() { asm volatile("s_dcache_wb\n s_waitcnt lgkmcnt(0)" ::: "memory"); }
 

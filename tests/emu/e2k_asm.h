@@ -101,8 +101,13 @@ inline void lane32_swap(unsigned& a, unsigned& b) {
 }
 inline float lane32_other(float v) { return __shfl_xor(v, 32); }
 
+template <bool WAIT = true>
 inline void sstore_masks16(unsigned long long* dst, const unsigned long long (&m)[16]) {      // (every lane writes the same 128 bytes)
     for (int i = 0; i < 16; ++i) dst[i] = m[i];
+}
+inline void sstore_masks8(unsigned long long* dst, unsigned long long m0, unsigned long long m1, unsigned long long m2, unsigned long long m3,
+                          unsigned long long m4, unsigned long long m5, unsigned long long m6, unsigned long long m7) {
+    dst[0] = m0; dst[1] = m1; dst[2] = m2; dst[3] = m3; dst[4] = m4; dst[5] = m5; dst[6] = m6; dst[7] = m7;
 }
 inline void sstore_flush() {}
 inline void wait_lgkm0() {}

@@ -1,6 +1,5 @@
 """Same-box A/B of the attention ring kernels at the bench shape (B 8, H 16, N 1056, dropout 0.1, keep masks handed over):
-first generation (E2K_ATTN_RING16: 16 rows per wave) vs second generation (attn32.hip) with the keep masks published by v_writelane
-(E2K_ATTN32_PUB=0) or by scalar stores (=1).  Interleaved rounds in one process; also checks the variants against each other
+first generation (E2K_ATTN_RING16: 16 rows per wave) vs second generation (attn32.hip).  Interleaved rounds in one process; also checks the variants against each other
 (outputs within bf16 rounding; shared masks == re-hashed masks bit for bit).  -> gpurun_out/r05_attn32_ab.json"""
 import json
 import os
@@ -25,13 +24,11 @@ st = ops.qkv_post_fwd(qkvg, B, H, N, cosb, sinb, vfirst)
 kmask = torch.zeros(B, st.Npad, dtype=torch.uint8, device=dev)
 kmask[:, :N] = 1
 dOg = torch.randn(M, I, device=dev).to(bf16)
-VARIANTS = {'ring16': (64, '0', '3'), 'attn32_writelane': (0, '0', '3'), 'attn32_sstore': (0, '1', '3'), 'attn32_sstore_dq2': (0, '1', '2')}
-if '--no-sstore' in sys.argv:
-    VARIANTS.pop('attn32_sstore')
+VARIANTS = {'ring16': (64, '0'), 'attn32': (0, '0')}
 
 
 def select(name):
-    ops.attn_probe, os.environ['E2K_ATTN32_PUB'], os.environ['E2K_ATTN32_DQ_WPS'] = VARIANTS[name]
+    ops.attn_probe, os.environ['E2K_ATTN32_PROBE'] = VARIANTS[name]
 
 
 def timeit(fn, iters=20):
