@@ -65,6 +65,9 @@ struct NTArgs {
     int staged;         // 256 x 256 kernel: C tile written through LDS in whole 512-byte row segments (nt_epilogue_staged)
     // GEGLU epilogue (gemm_nt_256_kernel<false, true> only): N = 2F, C = pre-activation H (may be NULL), glu_out (M, F)
     bf16_t* glu_out; long ldg; unsigned seed, stream_id, thresh; float inv_keep; const unsigned* seed_dev;
+    // GEGLU BACKWARD as the epilogue (e2k_gemm_nt_geglu_bwd_bf16): the product is d(activation) (M, N = F); with the stored
+    // pre-activation gb_H (M, 2F) = [u | g] the epilogue writes gb_dH (M, 2F) = [d keep gelu(g) | d keep u gelu'(g)] and C is not written
+    const bf16_t* gb_H; long gb_ldh; bf16_t* gb_dH; long gb_lddh;
 };
 
 // two-output form: rebinds the (by-value) argument block of a workgroup whose tile lies in the second output
@@ -72,6 +75,45 @@ __device__ __forceinline__ void nt_bind_output(NTArgs& p, int n0) {
     if (p.nsplit > 0 && n0 >= p.nsplit) {
         p.C = p.C2; p.ldc = p.ldc2; p.resid = p.resid2; p.ldr = p.ldr2;
     }
+}
+
+// GEGLU backward on NC consecutive columns n .. n + NC - 1 of row m (x: the product = d(activation), fp32): the arithmetic of
+// geglu_kernel<true> (elementwise.hip; FeedForward, e2_tts.py:646,692) with the A&S erfc of the forward epilogue (gelu_erf_pair below:
+// one v_rcp_f32 + one v_exp_f32 for gelu AND its derivative; |error| <= 1.5e-7), fed the fp32 accumulator instead of a bf16-rounded copy
+__device__ __forceinline__ void gelu_erf_pair(float x, float& gel, float& dgel) {
+    const float ax = fabsf(x);
+    const float t = fast_rcp(fmaf(0.3275911f * 0.70710678118654752f, ax, 1.f));
+    float y = fmaf(t, 0.5f * 1.061405429f, 0.5f * -1.453152027f);
+    y = fmaf(t, y, 0.5f * 1.421413741f);
+    y = fmaf(t, y, 0.5f * -0.284496736f);
+    y = fmaf(t, y, 0.5f * 0.254829592f);
+    const float e = fast_exp2(x * x * (-0.5f * 1.4426950408889634f));         // exp(-x^2 / 2)
+    y = y * t * e;                                                              // erfc(|x| / sqrt 2) / 2
+    const float phi = x < 0.f ? y : 1.f - y;                                    // Phi(x)
+    gel = x * phi;
+    dgel = fmaf(x * e, 0.3989422804014327f, phi);                               // Phi(x) + x phi(x)
+}
+template <int NC>
+__device__ __forceinline__ void nt_store_geglu_bwd(const NTArgs& p, int m, int n, const float* x) {
+    static_assert(NC == 4 || NC == 8, "");
+    const int F = p.N;
+    float u[NC], gt[NC], du[NC], dg[NC];
+    const bf16_t* hrow = p.gb_H + (long)m * p.gb_ldh + n;
+    if (NC == 8) { unpack8(ld<u32x4>(hrow), u); unpack8(ld<u32x4>(hrow + F), gt); }
+    else { unpack4(ld<u32x2>(hrow), u); unpack4(ld<u32x2>(hrow + F), gt); }
+    const unsigned seed = p.seed_dev ? *p.seed_dev : p.seed;
+#pragma unroll
+    for (int e = 0; e < NC; ++e) {
+        const float ks = p.thresh ? keep_scale(seed, p.stream_id, m, n + e, p.thresh, p.inv_keep) : 1.f;
+        float gel, dgel;
+        gelu_erf_pair(gt[e], gel, dgel);
+        const float dd = x[e] * ks;
+        du[e] = dd * gel;
+        dg[e] = dd * u[e] * dgel;
+    }
+    bf16_t* drow = p.gb_dH + (long)m * p.gb_lddh + n;
+    if (NC == 8) { st<u32x4>(drow, pack8(du)); st<u32x4>(drow + F, pack8(dg)); }
+    else { st<u32x2>(drow, pack4(du)); st<u32x2>(drow + F, pack4(dg)); }
 }
 
 // epilogue of an interior tile (all 128 x 128 outputs exist, rows 8-byte aligned): no per-element bounds checks, the
@@ -124,6 +166,19 @@ __device__ __forceinline__ void nt_epilogue_full(const NTArgs& p, f32x4 (&acc)[N
 // C[m][n..n+3], m = mw + i*16 + l15 (i < NI), n = nw + j*16 + 4g (j < NJ)
 template <bool OUT_F32, int NI, int NJ = 4>
 __device__ __forceinline__ void nt_epilogue(const NTArgs& p, f32x4 (&acc)[NI][NJ], int mw, int nw, int l15, int g) {
+    if (!OUT_F32 && p.gb_H) {            // GEGLU backward epilogue (N = F is a multiple of 256: every column of a tile exists)
+#pragma unroll
+        for (int i = 0; i < NI; ++i) {
+            const int m = mw + i * 16 + l15;
+            if (m >= p.M) continue;
+#pragma unroll
+            for (int j = 0; j < NJ; ++j) {
+                const float x[4] = {acc[i][j][0], acc[i][j][1], acc[i][j][2], acc[i][j][3]};
+                nt_store_geglu_bwd<4>(p, m, nw + j * 16 + 4 * g, x);
+            }
+        }
+        return;
+    }
     const bool vec_ok = (p.ldc & 3) == 0 && (p.resid == nullptr || (p.ldr & 3) == 0);
     if (vec_ok && mw + NI * 16 <= p.M && nw + NJ * 16 <= p.N) {       // wave-uniform: the whole sub-tile exists
         if (p.colscale) {
@@ -227,6 +282,12 @@ __device__ __forceinline__ void nt_stage_readback(const NTArgs& p, const unsigne
     for (int pass = 0; pass < NP; ++pass) {
         const int r = pass * RPP + rsub, m = m_base + r;
         if (m >= p.M) continue;
+        if (!OUT_F32 && p.gb_H) {            // GEGLU backward epilogue: 8 columns of d(activation) -> 8 + 8 columns of dH
+            const f32x4 y0 = ld<f32x4>(S + r * ROWB + c * 32), y1 = ld<f32x4>(S + r * ROWB + c * 32 + 16);
+            const float x[8] = {y0[0], y0[1], y0[2], y0[3], y1[0], y1[1], y1[2], y1[3]};
+            nt_store_geglu_bwd<8>(p, m, n, x);
+            continue;
+        }
         const float rm = p.rowmask ? (p.rowmask[m] ? 1.f : 0.f) : 1.f;
         f32x4 x0 = ld<f32x4>(S + r * ROWB + c * 32) + b0, x1 = ld<f32x4>(S + r * ROWB + c * 32 + 16) + b1;
         if (p.colscale) {
@@ -1623,7 +1684,7 @@ static int gemm_nt_bf16_impl(const void* A1, int64_t lda1, int K1, const void* A
     if (((uintptr_t)A1 | (uintptr_t)B | (uintptr_t)A2) & 15) return E2K_ERR_ALIGN;
     if (colscale && rows_per_batch <= 0) return E2K_ERR_SHAPE;
     if (accumulate && !out_f32) return E2K_ERR_SHAPE;
-    NTArgs p;
+    NTArgs p{};
     p.A1 = (const bf16_t*)A1; p.lda1 = lda1; p.K1 = K1;
     p.A2 = (const bf16_t*)A2; p.lda2 = lda2; p.K2 = K2;
     p.B = (const bf16_t*)B; p.ldb = ldb;
@@ -1786,6 +1847,70 @@ static int gemm_nt_geglu_bf16_impl(const void* A, int64_t lda, int K, const void
 }
 
 extern "C" int e2k_query_gemm_nt_geglu(int M, int F, int K) { return nt_geglu_ok(M, F, K) ? 1 : 0; }
+
+// FeedForward's second Linear dgrad with the GEGLU backward as its epilogue: d(act) = dY W2 never goes to memory.  The 256 x 256
+// kernel only (same tile order and remainder split as e2k_gemm_nt_bf16); shapes it cannot take are refused, the caller then runs
+// e2k_gemm_nt_bf16 + e2k_geglu_bwd (e2k_query_gemm_nt_geglu_bwd says which)
+static bool nt_geglu_bwd_ok(int M, int F, int K) { return M > 0 && F >= QBN && (F % QBN) == 0 && K >= 4 * BK && (K % BK) == 0; }
+
+static int gemm_nt_geglu_bwd_bf16_impl(const void* dY, int64_t ldy, int K, const void* W2T, int64_t ldb, const void* H, int64_t ldh,
+                                          void* dH, int64_t lddh, int M, int F, float p_drop, uint32_t seed, const uint32_t* seed_dev,
+                                          uint32_t stream_id, int flags, float* ws, int64_t ws_bytes, void* stream) {
+    if (M <= 0 || F <= 0) return 0;
+    if (!nt_geglu_bwd_ok(M, F, K)) return E2K_ERR_SHAPE;
+    if ((ldy & 7) || (ldb & 7) || (ldh & 7) || (lddh & 7)) return E2K_ERR_ALIGN;
+    if (((uintptr_t)dY | (uintptr_t)W2T | (uintptr_t)H | (uintptr_t)dH) & 15) return E2K_ERR_ALIGN;
+    if (!H || !dH || !(p_drop >= 0.f && p_drop < 1.f)) return E2K_ERR_ARG;
+    NTArgs p{};
+    p.A1 = (const bf16_t*)dY; p.lda1 = ldy; p.K1 = K;
+    p.B = (const bf16_t*)W2T; p.ldb = ldb;
+    p.C = dH; p.ldc = lddh; p.M = M; p.N = F;              // (C is never written in this mode)
+    p.gb_H = (const bf16_t*)H; p.gb_ldh = ldh; p.gb_dH = (bf16_t*)dH; p.gb_lddh = lddh;
+    p.seed = seed; p.seed_dev = seed_dev; p.stream_id = stream_id;
+    p.thresh = (unsigned)(p_drop * 65536.f + 0.5f); p.inv_keep = 1.f / (1.f - p_drop);
+    p.staged = !(flags & E2K_GEMM_NO_STAGE);
+    const int T = ((M + QBM - 1) / QBM) * (F / QBN);
+    {
+        const int tn256 = F / QBN;
+        const float per_xcd = T / 8.f;
+        p.group = 8;
+        if (tn256 * 8 > 1.5f * per_xcd) {
+            int g = (int)(per_xcd / tn256 + 0.5f);
+            p.group = g < 1 ? 1 : (g > 8 ? 8 : g);
+        }
+    }
+    p.full = T; p.split = 1; p.ws = ws;
+    int rem = 0;
+    const int slots = (flags & E2K_GEMM_TEST_SLOTS8) ? 8 : 256;
+    if (ws && !(flags & E2K_GEMM_NO_SPLIT) && T > slots && (T % slots) != 0) {      // same remainder split as the plain kernel
+        rem = T % slots;
+        const int nk = K / BK;
+        int split = 1;
+        while (split * 2 <= 16 && split * 2 * rem <= slots && split * 2 * 4 <= nk) split *= 2;
+        if (!(flags & E2K_GEMM_TEST_SLOTS8))
+            while (split > 1 && 1.0f * nk < 1.2f * (rem * split * 0.104f + 4.f)) split >>= 1;
+        if (split > 1 && (int64_t)rem * split * QBM * QBN * 4 <= ws_bytes) { p.full = T - rem; p.split = split; }
+        else rem = 0;
+    }
+    hipStream_t st = (hipStream_t)stream;
+    hipLaunchKernelGGL(gemm_nt_256_kernel<false>, dim3(p.full + rem * p.split), dim3(QTHREADS), 0, st, p);
+    E2K_CHECK_LAUNCH();
+    if (rem) {
+        hipLaunchKernelGGL(gemm_nt_256_fixup_kernel<false>, dim3(rem, 16), dim3(QTHREADS), 0, st, p);
+        E2K_CHECK_LAUNCH();
+    }
+    return 0;
+}
+
+extern "C" int e2k_query_gemm_nt_geglu_bwd(int M, int F, int K) { return nt_geglu_bwd_ok(M, F, K) ? 1 : 0; }
+
+extern "C" int e2k_gemm_nt_geglu_bwd_bf16(const void* dY, int64_t ldy, int K, const void* W2T, int64_t ldb, const void* H, int64_t ldh,
+                                          void* dH, int64_t lddh, int M, int F, float p_drop, uint32_t seed, const uint32_t* seed_dev,
+                                          uint32_t stream_id, int flags, float* ws, int64_t ws_bytes, void* stream) {
+    return e2k::dispatch("gemm_nt_geglu_bwd_bf16", gemm_nt_geglu_bwd_bf16_impl, dY, ldy, K, W2T, ldb, H, ldh, dH, lddh, M, F, p_drop, seed, seed_dev,
+                         stream_id, flags, ws, ws_bytes, stream);
+}
+
 
 // 512 partial slots of a 128 x 128 tile or 256 of a 256 x 256 tile (every remainder split fits: rem * split <= slots)
 extern "C" int e2k_query_gemm_nt_ws_bytes(void) { return 256 * QBM * QBN * 4; }

@@ -1634,8 +1634,13 @@ class Transformer(Module):
             gate = run.gates[:, (ind * ncs + 3) * D:(ind * ncs + 4) * D]
             dao = ops.gate_bwd(rec.dy, y, gate, run.dcond[:, (ind * ncs + 3) * D:(ind * ncs + 4) * D], run.rpb)
         run.wgrad(dao, act, G(f.w2, D, f.F), colsum=G(f.b2, D))                  # dW2 and db2 in one pass over dY
-        dact = ops.gemm_nt(dao, self._wT(f.w2T))
-        dH = ops.geglu_bwd(dact, Hh, run.p_drop, run.seed, sid, run.seed_dev)
+        w2T = self._wT(f.w2T)
+        if ops.fuse_geglu_bwd and ops.can_fuse_geglu_bwd(Mtok, f.F, D):
+            # d(act) = dY W2 never goes to memory: the GEGLU backward is the dgrad GEMM's epilogue (e2k_gemm_nt_geglu_bwd_bf16)
+            dH = ops.gemm_nt_geglu_bwd(dao, w2T, Hh, run.p_drop, run.seed, sid, run.seed_dev)
+        else:
+            dact = ops.gemm_nt(dao, w2T)
+            dH = ops.geglu_bwd(dact, Hh, run.p_drop, run.seed, sid, run.seed_dev)
         run.wgrad(dH, xn, G(f.w1, 2 * f.F, D), colsum=G(f.b1, 2 * f.F))           # dW1 and db1
         dxn = ops.gemm_nt(dH, self._wT(f.w1T))
         rec.dbin = ops.rmsnorm_bwd(dxn, binp, rn, gam, off, rpb, dgam)

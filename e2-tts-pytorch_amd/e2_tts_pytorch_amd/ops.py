@@ -634,6 +634,31 @@ def gemm_nt_geglu(a, w1, bias=None, p_drop=0., seed=0, stream_id=0, seed_dev=Non
     return H, act
 
 
+# GEGLU backward as the epilogue of FeedForward's second dgrad GEMM (E2K_FUSE_GEGLU_BWD=0: two launches)
+fuse_geglu_bwd = bool(int(_os.environ.get('E2K_FUSE_GEGLU_BWD', '1')))
+
+
+def can_fuse_geglu_bwd(M, F, K):
+    return bool(_lib.get().e2k_query_gemm_nt_geglu_bwd(int(M), int(F), int(K)))
+
+
+def gemm_nt_geglu_bwd(dy, w2T, H, p_drop=0., seed=0, stream_id=0, seed_dev=None):
+    """dH (M, 2F) = geglu_bwd(dy @ w2T.T, H) in one launch (d(act) is never written); dy (M, K), w2T (F, K), H (M, 2F).
+    Shapes: can_fuse_geglu_bwd(M, F, K)."""
+    _chk(dy, w2T, H, seed_dev)
+    assert dy.dtype == bf16 and w2T.dtype == bf16 and H.dtype == bf16
+    M, ldy = _rows(dy)
+    F, ldb = _rows(w2T)
+    K = dy.shape[1]
+    assert w2T.shape[1] == K and H.shape == (M, 2 * F) and H.stride(1) == 1
+    dH = torch.empty((M, 2 * F), dtype=bf16, device=dy.device)
+    _note(2.0 * M * F * K)
+    stream = _stream(dy)
+    _lib.get().e2k_gemm_nt_geglu_bwd_bf16(_p(dy), ldy, K, _p(w2T), ldb, _p(H), H.stride(0), _p(dH), dH.stride(0), M, F, float(p_drop),
+                                          int(seed), _p(seed_dev), int(stream_id), gemm_flags, *_nt_ws(dy.device, stream), stream)
+    return dH
+
+
 def geglu_bwd(dout, H, p_drop=0., seed=0, stream_id=0, seed_dev=None):
     _chk(dout, H)
     M, F2 = H.shape

@@ -372,6 +372,50 @@ def test_gemm_nt_geglu_epilogue(dev, monkeypatch, M, F, K, p, flags, bias, want_
         ops.gemm_nt_geglu(d(a), d(torch.zeros(2 * (F + 8), K).to(bf16)), None)
 
 
+@pytest.mark.parametrize('M,F,K,p,flags', [
+    (256, 256, 256, 0.0, 0),                # one tile
+    (200, 256, 256, 0.25, 0),               # partial row tile, dropout
+    (1280, 512, 256, 0.1, 32),              # 10 tiles on 8 test slots: remainder split + fix-up kernel
+    (512, 256, 320, 0.0, 64),               # direct (un-staged) epilogue
+])
+@pytest.mark.parametrize('late', [0, 1])
+def test_gemm_nt_geglu_bwd_epilogue(dev, monkeypatch, M, F, K, p, flags, late):
+    """FeedForward's second dgrad GEMM with the GEGLU backward (+ dropout) as its epilogue (e2_tts.py:646,692,937) against the two
+    launches it replaces and against the fp32 formula with the oracle's dropout mask.  The epilogue works on the fp32 accumulator
+    where the separate kernel reads d(act) rounded to bf16: agreement to bf16 rounding, not bit for bit."""
+    from e2_tts_pytorch_amd import ops
+    from oracle.dropout_hash import geglu_dropout_mask
+    if dev == 'cuda' and late:
+        pytest.skip('LDS-DMA landing extremes exist on the host model only')
+    monkeypatch.setenv('E2K_EMU_GLDS_LATE', str(late))
+    assert ops.can_fuse_geglu_bwd(M, F, K) and not ops.can_fuse_geglu_bwd(M, F + 128, K) and not ops.can_fuse_geglu_bwd(M, F, 96)
+    torch.manual_seed(M + F + K)
+    dy = (torch.randn(M, K) * 0.5).to(bf16)
+    w2T = (torch.randn(F, K) * 0.1).to(bf16)
+    H = torch.randn(M, 2 * F).to(bf16)
+    seed, sid = 77, 9
+    d = lambda t: t.to(dev)
+    old = ops.gemm_flags
+    ops.gemm_flags = flags
+    try:
+        dH = ops.gemm_nt_geglu_bwd(d(dy), d(w2T), d(H), p, seed, sid)
+        ops.gemm_flags = flags | 128
+        dH2 = ops.geglu_bwd(ops.gemm_nt(d(dy), d(w2T)), d(H), p, seed, sid)
+    finally:
+        ops.gemm_flags = old
+    assert dH.shape == (M, 2 * F) and rel(dH, dH2) < 1.5e-2, rel(dH, dH2)
+    dact = dy.double() @ w2T.double().T
+    u, g = H[:, :F].double(), H[:, F:].double()
+    keep = geglu_dropout_mask(seed, sid, M, F, p).double() if p else 1.
+    Phi = 0.5 * (1 + torch.erf(g / 2 ** 0.5))
+    ref = torch.cat([dact * keep * g * Phi, dact * keep * u * (Phi + g * torch.exp(-g * g / 2) / (2 * torch.pi) ** 0.5)], 1)
+    assert rel(dH, ref.float()) < 1e-2, rel(dH, ref.float())
+    # ... and closer to the fp64 formula than the two-launch pair is (no bf16 rounding of d(act) in between)
+    assert (dH.cpu().float() - ref.float()).norm() <= 1.02 * (dH2.cpu().float() - ref.float()).norm()
+    with pytest.raises(Exception):
+        ops.gemm_nt_geglu_bwd(d(dy), d(torch.zeros(F + 8, K).to(bf16)), d(H))
+
+
 def test_gelu_erf_fast_accuracy(dev):
     """the GEGLU epilogue's x * Phi(x) (Abramowitz & Stegun 7.1.26 with one rcp + one exp2; csrc/gemm.hip) against
     float64 erf over the range of bf16 gates: within one bf16 last place of the exact value from -5 up, and no
