@@ -164,9 +164,9 @@ __device__ __forceinline__ void nt_epilogue_full(const NTArgs& p, f32x4 (&acc)[N
 
 // epilogue shared by the NT kernels.  (mw, nw) = first row / column of this wave's (16 NI) x (16 NJ) sub-tile; lane holds
 // C[m][n..n+3], m = mw + i*16 + l15 (i < NI), n = nw + j*16 + 4g (j < NJ)
-template <bool OUT_F32, int NI, int NJ = 4>
+template <bool OUT_F32, int NI, int NJ = 4, bool GB = false>      // GB: a separate instantiation, so that the plain kernels carry none of it
 __device__ __forceinline__ void nt_epilogue(const NTArgs& p, f32x4 (&acc)[NI][NJ], int mw, int nw, int l15, int g) {
-    if (!OUT_F32 && p.gb_H) {            // GEGLU backward epilogue (N = F is a multiple of 256: every column of a tile exists)
+    if (GB) {            // GEGLU backward epilogue (N = F is a multiple of 256: every column of a tile exists)
 #pragma unroll
         for (int i = 0; i < NI; ++i) {
             const int m = mw + i * 16 + l15;
@@ -262,7 +262,7 @@ constexpr int GSTAGE_ROW = 128 * 4 + 16, GSTAGE_BYTES = 128 * GSTAGE_ROW;       
 // store per lane -- the epilogue is bound by the number of store instructions per CU, not by bytes (8-byte stores in
 // whole-line order measured no faster than the direct epilogue, profiles/r03_gemm_epilogue_ab_8byte_stores.json).  The
 // residual rows of all passes are fetched up front (their latency would otherwise be paid once per pass).
-template <bool OUT_F32, int ROWS, int COLS, int THREADS>
+template <bool OUT_F32, int ROWS, int COLS, int THREADS, bool GB = false>
 __device__ __forceinline__ void nt_stage_readback(const NTArgs& p, const unsigned char* S, int m_base, int n0, int tid) {
     constexpr int LPR = COLS / 8, RPP = THREADS / LPR, NP = ROWS / RPP, ROWB = COLS * 4 + 16;
     const int c = tid % LPR, rsub = tid / LPR;
@@ -282,7 +282,7 @@ __device__ __forceinline__ void nt_stage_readback(const NTArgs& p, const unsigne
     for (int pass = 0; pass < NP; ++pass) {
         const int r = pass * RPP + rsub, m = m_base + r;
         if (m >= p.M) continue;
-        if (!OUT_F32 && p.gb_H) {            // GEGLU backward epilogue: 8 columns of d(activation) -> 8 + 8 columns of dH
+        if (GB) {            // GEGLU backward epilogue: 8 columns of d(activation) -> 8 + 8 columns of dH
             const f32x4 y0 = ld<f32x4>(S + r * ROWB + c * 32), y1 = ld<f32x4>(S + r * ROWB + c * 32 + 16);
             const float x[8] = {y0[0], y0[1], y0[2], y0[3], y1[0], y1[1], y1[2], y1[3]};
             nt_store_geglu_bwd<8>(p, m, n, x);
@@ -315,7 +315,7 @@ __device__ __forceinline__ void nt_stage_readback(const NTArgs& p, const unsigne
     }
 }
 
-template <bool OUT_F32>
+template <bool OUT_F32, bool GB = false>
 __device__ __forceinline__ void nt_epilogue_staged(const NTArgs& p, f32x4 (&acc)[2][2][4][2], unsigned char* S, int m0, int n0,
                                                    int tid, int wr, int wc, int l15, int g) {
 #pragma unroll
@@ -328,7 +328,7 @@ __device__ __forceinline__ void nt_epilogue_staged(const NTArgs& p, f32x4 (&acc)
                 for (int j = 0; j < 2; ++j)
                     st<f32x4>(S + (wr * 64 + i * 16 + l15) * QSTAGE_ROW + (b * 128 + wc * 32 + j * 16 + 4 * g) * 4, acc[a][b][i][j]);
         __syncthreads();
-        nt_stage_readback<OUT_F32, 128, 256, 512>(p, S, m0 + a * 128, n0, tid);
+        nt_stage_readback<OUT_F32, 128, 256, 512, GB>(p, S, m0 + a * 128, n0, tid);
         if (a == 0) __syncthreads();                     // the second half overwrites the staging rows
     }
 }
@@ -740,7 +740,7 @@ __device__ __forceinline__ void nt_epilogue_glu_staged(const NTArgs& p, f32x4 (&
 //   * In the last five phases nothing is left to issue, and the count is lowered step by step (4, 2, 0).
 constexpr int QBM = 256, QBN = 256, QHALF = 128 * BK * 2, QBUF = 4 * QHALF, QTHREADS = 512;
 
-template <bool OUT_F32, bool GLU = false>
+template <bool OUT_F32, bool GLU = false, bool GB = false>       // GB: GEGLU backward epilogue (e2k_gemm_nt_geglu_bwd_bf16)
 __global__ __launch_bounds__(QTHREADS, 1) void gemm_nt_256_kernel(NTArgs p) {
     __shared__ __attribute__((aligned(16))) unsigned char smem[(2 * QBUF > QSTAGE_BYTES) ? 2 * QBUF : QSTAGE_BYTES];
     lds_declare(smem, sizeof(smem));
@@ -927,18 +927,18 @@ __global__ __launch_bounds__(QTHREADS, 1) void gemm_nt_256_kernel(NTArgs p) {
     }
     if (p.staged) {                          // (every DMA has landed and every fragment read has been waited for: the ring is free)
         __syncthreads();
-        nt_epilogue_staged<OUT_F32>(p, acc, smem, m0, n0, tid, wr, wc, l15, g);
+        nt_epilogue_staged<OUT_F32, GB>(p, acc, smem, m0, n0, tid, wr, wc, l15, g);
         return;
     }
 #pragma unroll
     for (int a = 0; a < 2; ++a)
 #pragma unroll
         for (int b = 0; b < 2; ++b)
-            nt_epilogue<OUT_F32, 4, 2>(p, acc[a][b], m0 + a * 128 + wr * 64, n0 + b * 128 + wc * 32, l15, g);
+            nt_epilogue<OUT_F32, 4, 2, GB>(p, acc[a][b], m0 + a * 128 + wr * 64, n0 + b * 128 + wc * 32, l15, g);
 }
 
 // blockIdx.x = remainder tile, blockIdx.y = (A half * 2 + B half) * 4 + m16 group
-template <bool OUT_F32>
+template <bool OUT_F32, bool GB = false>
 __global__ __launch_bounds__(QTHREADS) void gemm_nt_256_fixup_kernel(NTArgs p) {
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int wr = wave >> 2, wc = wave & 3, l15 = lane & 15, g = lane >> 4;
@@ -955,7 +955,7 @@ __global__ __launch_bounds__(QTHREADS) void gemm_nt_256_fixup_kernel(NTArgs p) {
 #pragma unroll
         for (int j = 0; j < 2; ++j) acc[0][j] += ld<f32x4>(w + ((long)sidx * 32 + j) * (QTHREADS * 4));
     }
-    nt_epilogue<OUT_F32, 1, 2>(p, acc, tile_m * QBM + a * 128 + wr * 64 + i * 16, tile_n * QBN + b * 128 + wc * 32, l15, g);
+    nt_epilogue<OUT_F32, 1, 2, GB>(p, acc, tile_m * QBM + a * 128 + wr * 64 + i * 16, tile_n * QBN + b * 128 + wc * 32, l15, g);
 }
 
 // GEGLU fix-up: blockIdx.y = A half * 4 + m16 group; both B halves (value | gate) are summed by the same lane
@@ -1893,10 +1893,10 @@ static int gemm_nt_geglu_bwd_bf16_impl(const void* dY, int64_t ldy, int K, const
         else rem = 0;
     }
     hipStream_t st = (hipStream_t)stream;
-    hipLaunchKernelGGL(gemm_nt_256_kernel<false>, dim3(p.full + rem * p.split), dim3(QTHREADS), 0, st, p);
+    hipLaunchKernelGGL((gemm_nt_256_kernel<false, false, true>), dim3(p.full + rem * p.split), dim3(QTHREADS), 0, st, p);
     E2K_CHECK_LAUNCH();
     if (rem) {
-        hipLaunchKernelGGL(gemm_nt_256_fixup_kernel<false>, dim3(rem, 16), dim3(QTHREADS), 0, st, p);
+        hipLaunchKernelGGL((gemm_nt_256_fixup_kernel<false, true>), dim3(rem, 16), dim3(QTHREADS), 0, st, p);
         E2K_CHECK_LAUNCH();
     }
     return 0;
