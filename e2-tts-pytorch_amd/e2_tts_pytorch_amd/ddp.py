@@ -19,7 +19,9 @@ Two ways in:
     become ready at once when the backbone's single autograd node finishes, i.e. nothing overlaps.
 
 `grad_dtype=torch.bfloat16` halves the bytes on the links (2.9 GB -> 1.45 GB per dim-1024 / depth-24 step): a slab is
-pre-divided by the world size in fp32, rounded to bf16, summed by RCCL in bf16 and added back into the fp32 buffer.
+pre-divided by the world size in fp32, rounded to bf16, summed by RCCL in bf16 and added back into the fp32 buffer;
+`wire_fp32_sum=True` keeps the bf16 wire but sums in fp32 (all-to-all of shards + local fp32 sum + all-gather: the same
+bytes, one rounding instead of world - 1).
 `bucket_layers=k` merges k consecutive layer slabs into one collective.
 
 Hardware queues: the step runs on the caller's stream, the backbone's two launch lanes, this module's side stream and
@@ -38,8 +40,12 @@ from .backbone import Transformer
 
 
 class _GradSync:
-    def __init__(self, group=None, grad_dtype=torch.float32, bucket_layers=1, defer=False):
+    def __init__(self, group=None, grad_dtype=torch.float32, bucket_layers=1, defer=False, wire_fp32_sum=False):
         assert grad_dtype in (torch.float32, torch.bfloat16)
+        # bf16 wire with fp32 accumulation: RCCL's all-reduce sums in the wire dtype, i.e. an 8-rank bf16 sum rounds 7 times.  With
+        # wire_fp32_sum the slab travels as bf16 shards (all-to-all = the reduce-scatter half), every rank sums ITS shard in fp32,
+        # rounds once and the shards are all-gathered: the same bytes on the links as the bf16 all-reduce, one rounding
+        self.wire_fp32_sum = bool(wire_fp32_sum) and grad_dtype == torch.bfloat16
         self.defer = bool(defer)      # one collective over everything when the backward pass has finished (no overlap, no CU sharing)
         self.group = group
         self.world = dist.get_world_size(group)
@@ -69,11 +75,17 @@ class _GradSync:
                         self._wire = torch.empty(slab.numel(), dtype=torch.bfloat16, device=slab.device)
                     buf = self._wire[:slab.numel()]
                     ops.grad_pack_bf16(slab, buf, 1.0 / self.world)
-                    dist.all_reduce(buf, op=dist.ReduceOp.SUM, group=self.group)
+                    if self.wire_fp32_sum and self.world > 1:
+                        buf = self._sum_fp32(buf)
+                    else:
+                        dist.all_reduce(buf, op=dist.ReduceOp.SUM, group=self.group)
                     ops.grad_unpack_bf16(buf, slab)
                 else:
                     buf = (slab * (1.0 / self.world)).to(torch.bfloat16)
-                    dist.all_reduce(buf, op=dist.ReduceOp.SUM, group=self.group)
+                    if self.wire_fp32_sum and self.world > 1:
+                        buf = self._sum_fp32(buf)
+                    else:
+                        dist.all_reduce(buf, op=dist.ReduceOp.SUM, group=self.group)
                     slab.copy_(buf)
             elif self._avg is not None:
                 dist.all_reduce(slab, op=self._avg, group=self.group)          # in place, no scaling pass
@@ -92,6 +104,19 @@ class _GradSync:
             slab.record_stream(self.side)
         else:
             run()
+
+    def _sum_fp32(self, buf):
+        """bf16 wire, fp32 sum: all-to-all of the world's shards, local fp32 sum of this rank's shard, one rounding, all-gather.
+        -> a bf16 tensor of buf's length holding the sum (identical on every rank)"""
+        w, n = self.world, buf.numel()
+        per = (n + w - 1) // w
+        send = buf if per * w == n else torch.cat([buf, buf.new_zeros(per * w - n)])
+        recv = torch.empty_like(send)
+        dist.all_to_all_single(recv, send, group=self.group)          # recv[r * per : (r + 1) * per] = rank r's copy of MY shard
+        mine = recv.view(w, per).float().sum(0).to(torch.bfloat16)
+        out = torch.empty_like(send)
+        dist.all_gather_into_tensor(out, mine, group=self.group)
+        return out[:n]
 
     # Which parameters received a gradient is a GLOBAL fact under data parallelism.  The classifier-free-guidance coin that
     # drops the text stream (e2_tts.py:1261-1262) is flipped per rank; the reference's DistributedDataParallel
@@ -157,6 +182,11 @@ class _GradSync:
             self._pending = (s, e, k)
 
 
+def _null_ctx():
+    import contextlib
+    return contextlib.nullcontext()
+
+
 def _warn_hw_queues():
     import os
     import warnings
@@ -179,7 +209,7 @@ class DataParallel(nn.Module):
     """wraps an E2TTS / DurationPredictor / Transformer; call it like the wrapped module, then loss.backward()."""
 
     def __init__(self, module: nn.Module, process_group=None, broadcast_from: int | None = 0,
-                 grad_dtype: torch.dtype = torch.float32, bucket_layers: int = 1, defer: bool = False):
+                 grad_dtype: torch.dtype = torch.float32, bucket_layers: int = 1, defer: bool = False, wire_fp32_sum: bool = False):
         super().__init__()
         assert dist.is_initialized(), 'torch.distributed must be initialised (backend "nccl" is RCCL on ROCm)'
         _warn_hw_queues()
@@ -189,7 +219,7 @@ class DataParallel(nn.Module):
         self._backbones = [m for m in module.modules() if isinstance(m, Transformer)]
         inside = {id(p) for bb in self._backbones for p in _flat_params(bb)}
         self._outside = [p for p in module.parameters() if id(p) not in inside]
-        self._sync = _GradSync(process_group, grad_dtype, bucket_layers, defer)
+        self._sync = _GradSync(process_group, grad_dtype, bucket_layers, defer, wire_fp32_sum)
         self._outside_queued = False
         for bb in self._backbones:
             bb._grad_sync = self._hook
@@ -228,18 +258,32 @@ class DataParallel(nn.Module):
         ps = [p for p in self._outside if p.requires_grad]
         if not ps:
             return
-        flat = torch.cat([(p.grad if p.grad is not None else torch.zeros_like(p)).reshape(-1).float() for p in ps])
-        flat.mul_(1.0 / self.world)
-        dist.all_reduce(flat, op=dist.ReduceOp.SUM, group=self.group)
-        off = 0
-        for p in ps:
-            n = p.numel()
-            g = flat[off:off + n].view_as(p).to(p.dtype)
-            if p.grad is None:
-                p.grad = g.clone()
-            else:
-                p.grad.copy_(g)
-            off += n
+        dev = ps[0].device
+        side = None
+        if dev.type == 'cuda':
+            # on the exchange stream, like the slabs: the collective queues behind the last slab instead of in front of whatever the
+            # compute stream does next; the compute stream waits for it once, at the end
+            if self._sync.side is None:
+                self._sync.side = torch.cuda.Stream(device=dev)
+            side = self._sync.side
+            side.wait_stream(torch.cuda.current_stream(dev))
+        with (torch.cuda.stream(side) if side is not None else _null_ctx()):
+            flat = torch.cat([(p.grad if p.grad is not None else torch.zeros_like(p)).reshape(-1).float() for p in ps])
+            flat.mul_(1.0 / self.world)
+            dist.all_reduce(flat, op=dist.ReduceOp.SUM, group=self.group)
+            off = 0
+            for p in ps:
+                n = p.numel()
+                g = flat[off:off + n].view_as(p).to(p.dtype)
+                if p.grad is None:
+                    p.grad = g.clone()
+                else:
+                    p.grad.copy_(g)
+                off += n
+        if side is not None:
+            for p in ps:
+                p.grad.record_stream(side)
+            torch.cuda.current_stream(dev).wait_stream(side)
 
     def forward(self, *args, **kwargs):
         return self.module(*args, **kwargs)
@@ -252,7 +296,7 @@ class DataParallel(nn.Module):
 
 
 def enable_overlap_under_ddp(module: nn.Module, process_group=None, broadcast_from: int | None = 0,
-                             grad_dtype: torch.dtype = torch.float32, bucket_layers: int = 1):
+                             grad_dtype: torch.dtype = torch.float32, bucket_layers: int = 1, wire_fp32_sum: bool = False):
     """Call BEFORE wrapping `module` in the stock DistributedDataParallel (`accelerator.prepare(model)` in the reference
     trainer): every backbone's parameters are marked to be ignored by the stock reducer and exchanged by the per-layer
     slab hook instead (overlapped with the backbone's backward on a side stream); the remaining parameters keep going
@@ -260,7 +304,7 @@ def enable_overlap_under_ddp(module: nn.Module, process_group=None, broadcast_fr
     assert dist.is_initialized()
     _warn_hw_queues()
     backbones = [(name, m) for name, m in module.named_modules() if isinstance(m, Transformer)]
-    sync = _GradSync(process_group, grad_dtype, bucket_layers)
+    sync = _GradSync(process_group, grad_dtype, bucket_layers, wire_fp32_sum=wire_fp32_sum)
     ignore = list(getattr(module, '_ddp_params_and_buffers_to_ignore', []))
     names = {id(p): n for n, p in module.named_parameters()}
     for _, bb in backbones:

@@ -75,7 +75,7 @@ def _worker(rank, world, port, emu_lib, q):
     for bb in (tr,):
         bb._grad_sync = None
     model.zero_grad(set_to_none=True)
-    hook = enable_overlap_under_ddp(model, grad_dtype=torch.bfloat16, bucket_layers=2)
+    hook = enable_overlap_under_ddp(model, grad_dtype=torch.bfloat16, bucket_layers=2, wire_fp32_sum=True)      # bf16 wire, fp32 sum (all-to-all + all-gather)
     stock = DDP(model, find_unused_parameters=True)
     stock(mels[rank], text=['hello'], _noise=noises[rank]).loss.backward()
     bad_s = []
