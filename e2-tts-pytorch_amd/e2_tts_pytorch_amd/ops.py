@@ -652,6 +652,9 @@ def gemm_nt_geglu_bwd(dy, w2T, H, p_drop=0., seed=0, stream_id=0, seed_dev=None)
     K = dy.shape[1]
     assert w2T.shape[1] == K and H.shape == (M, 2 * F) and H.stride(1) == 1
     dH = torch.empty((M, 2 * F), dtype=bf16, device=dy.device)
+    if _gemm_shapes is not None:          # (tools/nt_shapes.py: counted as the plain NT GEMM of its shape)
+        key = (M, F, K, 0, 0, 0)
+        _gemm_shapes[key] = _gemm_shapes.get(key, 0) + 1
     _note(2.0 * M * F * K)
     stream = _stream(dy)
     _lib.get().e2k_gemm_nt_geglu_bwd_bf16(_p(dy), ldy, K, _p(w2T), ldb, _p(H), H.stride(0), _p(dH), dH.stride(0), M, F, float(p_drop),

@@ -503,8 +503,10 @@ def test_reference_golden_forward(dev, case):
         got = float(dict(model.named_parameters())[n].grad.double().abs().sum())
         # to_pred sees the backbone's forward only; the input projections hang off the backbone's INPUT gradient, which with
         # the fixture's all-random weights is ill-conditioned in the model itself (rounding weights and input to bf16 alone
-        # moves it by 6 % in the fp32 oracle, tests/test_backbone.py::test_reference_golden_backbone)
-        tol = 5e-2 if n == 'to_pred.weight' else 1e-1
+        # moves it by 6 % in the fp32 oracle, tests/test_backbone.py::test_reference_golden_backbone, whose 0.15 is used here
+        # too: e2tts_cfg_drop sits at 9.9 % with the two-launch GEGLU backward and 10.3 % with the fused one, the other four
+        # cases within 3.5 %; a missing term moves these sums by >= 30 %)
+        tol = 5e-2 if n == 'to_pred.weight' else 1.5e-1
         assert abs(got - c['grad_abs_sums'][n]) < tol * c['grad_abs_sums'][n], (n, got, c['grad_abs_sums'][n])
 
 

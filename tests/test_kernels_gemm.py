@@ -377,6 +377,8 @@ def test_gemm_nt_geglu_epilogue(dev, monkeypatch, M, F, K, p, flags, bias, want_
     (200, 256, 256, 0.25, 0),               # partial row tile, dropout
     (1280, 512, 256, 0.1, 32),              # 10 tiles on 8 test slots: remainder split + fix-up kernel
     (512, 256, 320, 0.0, 64),               # direct (un-staged) epilogue
+    (66, 1024, 256, 0.0, 0),                # a short batch: one partial row tile, four column tiles
+    (130, 512, 256, 0.1, 0),
 ])
 @pytest.mark.parametrize('late', [0, 1])
 def test_gemm_nt_geglu_bwd_epilogue(dev, monkeypatch, M, F, K, p, flags, late):

@@ -36,4 +36,4 @@ res = {'metric': 'sampled mel-frames/sec (E2TTS.sample, 32 midpoint steps, CFG)'
        'launch_plans': '--eager' not in sys.argv, 'model_tflops_per_s': fwd_flops / dt / 1e12, 'shape': list(out.shape)}
 print(json.dumps(res))
 (ROOT / 'gpurun_out').mkdir(exist_ok=True)
-json.dump(res, open(ROOT / 'gpurun_out' / ('r04_sample_cfg5%s.json' % ('_eager' if '--eager' in sys.argv else '')), 'w'), indent=1)
+json.dump(res, open(ROOT / 'gpurun_out' / ('r05_sample_cfg5%s.json' % ('_eager' if '--eager' in sys.argv else '')), 'w'), indent=1)
