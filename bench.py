@@ -148,42 +148,52 @@ def cpu_baseline(dim, depth, heads, T, sample_depth=None, threads=None):
 
 
 def optimizer_leg(model, net, mel, text, noise, ms_plain, k=6):
-    """fwd + bwd + global-norm clip + ADOPT over the flat buffers (optim.FusedAdopt: one sumsq + one update launch for the
-    backbone) and, separately, + the EMA update (optim.FusedEMA; the reference trainer runs it every 10th step,
-    ema_pytorch's default).  Same plan, same inputs as the headline loop; lr tiny so that k steps leave the model alone.
-    The three loops (plain, + clip / ADOPT, + EMA) are timed the same way with the same k, so that the start-up of a short
-    timed loop (the host walks E2TTS.forward before the first launch) cancels in the differences."""
+    """what the trainer adds to a step (trainer.py:270-279): global-norm clip + ADOPT over the flat buffers (optim.FusedAdopt: one sumsq + one
+    update launch for the backbone) and the EMA update (optim.FusedEMA; every 10th step in the reference configuration, ema_pytorch's
+    default), on its own and folded into the ADOPT pass (FusedAdopt.attach_ema).  Same plan, same inputs as the headline loop, lr tiny so
+    that the steps leave the model alone.
+
+    ONE loop whose steps cycle through the four modes, a HIP event at the start of every step: a step's time is its start event to the
+    next one (the host runs ahead, the queue never drains), and each mode's cost is the difference of MEDIANS against the plain steps of
+    the same loop.  (Rounds 1-4 timed three loops one after the other and charged the optimizer with the warming of the chip between
+    them -- a cfg3 step goes from ~84 to ~87 ms over the first ten seconds of load: 6.9 + 2.5 ms reported where the launches themselves
+    took 4.6 + 1.7, profiles/r05l_optimizer_leg_in_context.json.)"""
     from e2_tts_pytorch_amd.optim import FusedAdopt, FusedEMA
     opt = FusedAdopt(model, lr=1e-7, max_grad_norm=1.0)
     ema = FusedEMA(model, update_after_step=0, update_every=1)
-
-    def train_step(with_opt, with_ema):
+    modes = [('fwd_bwd', False, False, False), ('with_clip_adopt', True, False, False), ('with_clip_adopt_ema', True, True, False),
+             ('with_clip_adopt_ema_folded', True, True, True)]
+    ev, tags = [], []
+    for i in range(4 * (k + 1) + 1):
+        name, with_opt, with_ema, fold = modes[i % 4]
+        e = torch.cuda.Event(enable_timing=True)
+        e.record()
+        ev.append(e)
+        tags.append(name)
         out = net(mel, text=text, _noise=noise)
         out.loss.backward()
+        opt.attach_ema(ema if fold else None)
         if with_opt:
             opt.step()
         opt.zero_grad(set_to_none=True)
         if with_ema:
             ema.update()
-
+    torch.cuda.synchronize()
     out = {}
-    for name, with_opt, with_ema in (('ms_per_step_fwd_bwd_same_loop', False, False), ('ms_per_step_with_clip_adopt', True, False),
-                                     ('ms_per_step_with_clip_adopt_ema', True, True)):
-        for _ in range(2):
-            train_step(with_opt, with_ema)
-        torch.cuda.synchronize()
-        t0 = time.perf_counter()
-        for _ in range(k):
-            train_step(with_opt, with_ema)
-        torch.cuda.synchronize()
-        out[name] = (time.perf_counter() - t0) / k * 1e3
-    out['ms_per_step_fwd_bwd'] = ms_plain
-    out['clip_adopt_ms'] = out['ms_per_step_with_clip_adopt'] - out['ms_per_step_fwd_bwd_same_loop']
-    out['ema_update_ms'] = out['ms_per_step_with_clip_adopt_ema'] - out['ms_per_step_with_clip_adopt']
-    out['steps'] = k
+    for name, *_ in modes:
+        d = sorted(ev[i].elapsed_time(ev[i + 1]) for i in range(4, len(ev) - 1) if tags[i] == name)      # (the first cycle is warm-up)
+        out['ms_per_step_' + name] = d[len(d) // 2]
+    out['ms_per_step_fwd_bwd_headline'] = ms_plain
+    out['clip_adopt_ms'] = out['ms_per_step_with_clip_adopt'] - out['ms_per_step_fwd_bwd']
+    out['ema_update_ms'] = out['ms_per_step_with_clip_adopt_ema_folded'] - out['ms_per_step_with_clip_adopt']
+    out['ema_update_separate_launch_ms'] = out['ms_per_step_with_clip_adopt_ema'] - out['ms_per_step_with_clip_adopt']
+    out['steps_per_mode'] = k
     out['note'] = ('fused clip + ADOPT (per-parameter steps, text-stream group skipped on text-dropped steps) and EMA over the flat fp32 '
-                   'buffers, trainer.py:270-279; the EMA update runs every 10th step in the reference configuration; differences are '
-                   'taken between loops of the same length (a short timed loop carries the host walk of the first E2TTS.forward)')
+                   'buffers, trainer.py:270-279; ema_update_ms = the EMA folded into the ADOPT pass (FusedAdopt.attach_ema), '
+                   'ema_update_separate_launch_ms = FusedEMA.update() as a pass of its own; the EMA update runs every 10th step in the '
+                   'reference configuration.  Steps of the four modes are interleaved in one loop and timed by HIP events at the step '
+                   'boundaries; differences of medians against the plain steps of the same loop (ms_per_step_fwd_bwd here is a step of a '
+                   'chip that has been under load for several seconds, the headline ms_per_step the first seconds)')
     return out
 
 

@@ -109,6 +109,7 @@ __device__ __forceinline__ float lane_bcast(float v, int L) {
     return __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, v), L));
 }
 __device__ __forceinline__ float fast_rsq(float x) { return __builtin_amdgcn_rsqf(x); }
+__device__ __forceinline__ float fast_sqrt(float x) { return __builtin_amdgcn_sqrtf(x); }       // v_sqrt_f32, 1 ulp
 
 // wave vote: true when the predicate holds in every lane (all 64 lanes active at the call sites)
 __device__ __forceinline__ bool wave_all(bool pred) { return __builtin_amdgcn_ballot_w64(pred) == ~0ull; }

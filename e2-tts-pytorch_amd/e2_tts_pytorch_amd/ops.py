@@ -1086,13 +1086,14 @@ def sumsq(x, out):
 
 
 def adopt_step(p, g, m, v, step, *, lr, beta1=0.9, beta2=0.99, eps=1e-6, weight_decay=0., max_grad_norm=0., gsumsq=None,
-               shadow=None, ranges=None, step_b=0, active_b=True):
-    """one fused ADOPT step on flat fp32 buffers (see e2k_adopt_step / e2k_adopt_step_groups in include/e2k.h).
+               shadow=None, ranges=None, step_b=0, active_b=True, ema=None, ema_decay=0.):
+    """one fused ADOPT step on flat fp32 buffers (see e2k_adopt_step / e2k_adopt_step_groups / e2k_adopt_step_ema in include/e2k.h).
     ranges: int32 device tensor (nr, 2) of sorted [start, end) element ranges that form a second parameter group with its
-    own step count `step_b`, skipped entirely when not active_b"""
-    _chk(p, g, m, v, gsumsq, shadow, ranges)
+    own step count `step_b`, skipped entirely when not active_b.  ema: fp32 buffer like p that follows the NEW parameters in the
+    same pass, ema += (1 - ema_decay) (p - ema)"""
+    _chk(p, g, m, v, gsumsq, shadow, ranges, ema)
     n = p.numel()
-    for t in (p, g, m, v):
+    for t in (p, g, m, v) + ((ema,) if ema is not None else ()):
         assert t.dtype == f32 and t.is_contiguous() and t.numel() == n
     if shadow is not None:
         assert shadow.dtype == bf16 and shadow.is_contiguous() and shadow.numel() == n
@@ -1100,6 +1101,15 @@ def adopt_step(p, g, m, v, step, *, lr, beta1=0.9, beta2=0.99, eps=1e-6, weight_
         assert gsumsq.dtype == torch.float64 and gsumsq.numel() == 1
     if ranges is not None and ranges.numel():
         assert ranges.dtype == torch.int32 and ranges.is_contiguous() and ranges.dim() == 2 and ranges.shape[1] == 2
+    else:
+        ranges = None
+    if ema is not None:
+        _lib.get().e2k_adopt_step_ema(_p(p), _p(g), _p(m), _p(v), _p(shadow), n, float(lr), float(beta1), float(beta2), float(eps),
+                                      float(weight_decay), float(max_grad_norm), _p(gsumsq), int(step), int(step_b),
+                                      int(bool(active_b)), _p(ranges), ranges.shape[0] if ranges is not None else 0, _p(ema),
+                                      float(ema_decay), _stream(p))
+        return
+    if ranges is not None:
         _lib.get().e2k_adopt_step_groups(_p(p), _p(g), _p(m), _p(v), _p(shadow), n, float(lr), float(beta1), float(beta2), float(eps),
                                          float(weight_decay), float(max_grad_norm), _p(gsumsq), int(step), int(step_b),
                                          int(bool(active_b)), _p(ranges), ranges.shape[0], _stream(p))

@@ -92,6 +92,16 @@ class FusedAdopt:
         self._backbones = [m for m in model.modules() if isinstance(m, Transformer)]
         self._index = {id(p): i for i, p in enumerate(self.params)}
         self._ranges = {}          # id(backbone) -> (device int32 (nr, 2) text ranges, set of text parameter ids)
+        self._ema = None           # a FusedEMA whose backbone averages are moved inside the ADOPT pass (attach_ema)
+
+    def attach_ema(self, ema):
+        """fold `ema.update()` for the backbone into this optimizer's pass (e2k_adopt_step_ema): on the steps on which the coming
+        `ema.update()` moves the average, the ADOPT kernel moves it while the new parameter value is in registers (8 B per element
+        instead of a 12-B pass of its own), and `ema.update()` then only handles the few parameters outside the backbone.  This relies on
+        the trainer's order -- one `ema.update()` after every `step()` (trainer.py:275-279) -- and a second `step()` without it raises."""
+        assert ema is None or ema.online is self.model, 'the EMA must follow the model this optimizer updates'
+        self._ema = ema
+        return self
 
     @property
     def step_count(self):
@@ -221,6 +231,11 @@ class FusedAdopt:
         # gradients, so they stay exactly zero through the update)
         runs, taken, stepped = [], set(), []
         self._globalise_text_live(dev)
+        ema, ema_decay, folded = self._ema, None, set()
+        if ema is not None:
+            if ema._folded is not None:
+                raise RuntimeError('FusedAdopt.step() with an attached EMA: ema.update() has to follow every step() (trainer.py:275-279)')
+            ema_decay = ema.pending_decay()             # None: the coming ema.update() copies or does nothing
         for tr in self._backbones:
             slots = getattr(getattr(tr, '_layout', None), 'slots', None)
             flat = getattr(tr, '_flat', None)
@@ -237,8 +252,12 @@ class FusedAdopt:
                 main = [self._index[id(q)] for q, _ in slots if id(q) not in text_ids and id(q) in self._index]
                 text = [self._index[id(q)] for q, _ in slots if id(q) in text_ids and id(q) in self._index]
                 # (all parameters of a group have stepped together since construction / load, so one count per group)
-                runs.append((flat.view(-1), base, dict(step=self.steps[main[0]] if main else 0, ranges=ranges,
-                                                       step_b=self.steps[text[0]] if text else 0, active_b=live)))
+                kw = dict(step=self.steps[main[0]] if main else 0, ranges=ranges, step_b=self.steps[text[0]] if text else 0, active_b=live)
+                te = ema.twin_of(tr) if ema_decay is not None else None
+                if te is not None:
+                    kw.update(ema=te._flat.view(-1), ema_decay=ema_decay)
+                    folded.add(id(te))
+                runs.append((flat.view(-1), base, kw))
                 stepped += main + (text if live else [])
                 taken.update(id(q) for q, _ in slots)
         # backbones that did not go through the flat path (gradients that are not views of one buffer at the layout offsets:
@@ -266,6 +285,8 @@ class FusedAdopt:
         for (pf, gf, kw), (m, v) in zip(runs, mvs):
             ops.adopt_step(pf, gf, m, v, kw.pop('step'), lr=self.lr, beta1=b1, beta2=b2, eps=self.eps,
                            weight_decay=self.weight_decay, max_grad_norm=self.max_grad_norm, gsumsq=gs, **kw)
+        if folded:
+            ema._folded = (ema.step, ema_decay, folded)
         for p, _ in pairs:                                     # the kernels wrote behind autograd's back
             torch.autograd.graph.increment_version(p)
         for i in stepped:
@@ -282,6 +303,7 @@ class FusedEMA:
         self.beta, self.update_after_step, self.update_every = beta, update_after_step, update_every
         self.inv_gamma, self.power = inv_gamma, power
         self.step, self.initted = 0, False
+        self._folded = None        # (step, decay, {id(backbone of the copy)}): averages FusedAdopt.step() already moved for the coming update()
         for m in self.ema_model.modules():            # deepcopy clones every parameter separately: re-establish the
             if isinstance(m, Transformer):            # flat storage of the copy, so that it is one run like the original
                 m._flat = None
@@ -302,8 +324,32 @@ class FusedEMA:
         self.initted = bool(sd['initted'])
         self.step = int(sd['step'])
 
-    def current_decay(self):
-        epoch = max(self.step - self.update_after_step - 1, 0)
+    def twin_of(self, tr):
+        """the copy's backbone that follows the online backbone `tr`, if both are whole flat buffers of the same layout"""
+        for te, to in zip((m for m in self.ema_model.modules() if isinstance(m, Transformer)),
+                          (m for m in self.online.modules() if isinstance(m, Transformer))):
+            if to is tr:
+                return te if self._flat_pair(te, to) else None
+        return None
+
+    @staticmethod
+    def _flat_pair(te, to):
+        fe, fo = getattr(te, '_flat', None), getattr(to, '_flat', None)
+        se, so = getattr(getattr(te, '_layout', None), 'slots', None), getattr(getattr(to, '_layout', None), 'slots', None)
+        if fe is None or fo is None or not se or not so or fe.numel() != fo.numel():
+            return False
+        return (all(q.data_ptr() == fe.data_ptr() + off * 4 for q, off in se) and
+                all(q.data_ptr() == fo.data_ptr() + off * 4 for q, off in so))
+
+    def pending_decay(self):
+        """the decay the NEXT update() will move the averages with, or None when it will copy or do nothing"""
+        step = self.step
+        if step % self.update_every != 0 or step <= self.update_after_step or not self.initted:
+            return None
+        return self.current_decay(step + 1)
+
+    def current_decay(self, step=None):
+        epoch = max((self.step if step is None else step) - self.update_after_step - 1, 0)
         if epoch <= 0:
             return 0.
         return min(max(1. - (1. + epoch / self.inv_gamma) ** -self.power, 0.), self.beta)
@@ -312,6 +358,8 @@ class FusedEMA:
     def update(self):
         step = self.step
         self.step += 1
+        folded, self._folded = self._folded, None
+        assert folded is None or folded[0] == step, 'the folded EMA update belongs to another step'
         if step % self.update_every != 0:
             return
         if step <= self.update_after_step or not self.initted:
@@ -320,17 +368,15 @@ class FusedEMA:
             self.initted = True
             return
         decay = self.current_decay()
+        assert folded is None or folded[1] == decay
         pairs = [(e, p.detach()) for e, p in zip(self.ema_model.parameters(), self.online.parameters()) if e.numel()]
         runs, taken = [], set()
         for te, to in zip((m for m in self.ema_model.modules() if isinstance(m, Transformer)),
                           (m for m in self.online.modules() if isinstance(m, Transformer))):
-            fe, fo = getattr(te, '_flat', None), getattr(to, '_flat', None)
-            se, so = getattr(getattr(te, '_layout', None), 'slots', None), getattr(getattr(to, '_layout', None), 'slots', None)
-            if fe is None or fo is None or not se or not so or fe.numel() != fo.numel():
-                continue
-            if all(q.data_ptr() == fe.data_ptr() + off * 4 for q, off in se) and all(q.data_ptr() == fo.data_ptr() + off * 4 for q, off in so):
-                runs.append((fe.view(-1), fo.view(-1)))          # whole flat buffers (holes / pads are zero in both)
-                taken.update(id(q) for q, _ in se)
+            if self._flat_pair(te, to):
+                if folded is None or id(te) not in folded[2]:     # (folded: FusedAdopt.step() moved this average in its own pass)
+                    runs.append((te._flat.view(-1), to._flat.view(-1)))          # whole flat buffers (holes / pads are zero in both)
+                taken.update(id(q) for q, _ in te._layout.slots)
         runs += _runs([(e, p) for e, p in pairs if id(e) not in taken])
         for ef, pf in runs:
             ops.ema_update(ef, pf, decay)

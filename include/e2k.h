@@ -345,6 +345,14 @@ int e2k_adopt_step_groups(float* p, const float* g, float* m, float* v, void* sh
                           float beta1, float beta2, float eps, float weight_decay, float max_grad_norm,
                           const double* gsumsq, int step, int step_b, int active_b, const int32_t* ranges, int nranges,
                           void* stream);
+/* e2k_adopt_step_groups followed by e2k_ema_update(ema, p, n, ema_decay) in ONE pass: trainer.py:275 and :279 on the steps on which
+ * ema_pytorch.EMA.update() moves the average (every `update_every`-th step).  The average takes the NEW parameter value while it is
+ * in registers (8 B per element instead of a 12-B pass of its own); elements of a skipped group keep their parameter and still
+ * move their average.  nranges may be 0 (ranges NULL). */
+int e2k_adopt_step_ema(float* p, const float* g, float* m, float* v, void* shadow_bf16, int64_t n, float lr,
+                       float beta1, float beta2, float eps, float weight_decay, float max_grad_norm,
+                       const double* gsumsq, int step, int step_b, int active_b, const int32_t* ranges, int nranges,
+                       float* ema, float ema_decay, void* stream);
 /* ema += (1 - decay) (p - ema)   (ema_pytorch.EMA.update, trainer.py:170,279) */
 int e2k_ema_update(float* ema, const float* p, int64_t n, float decay, void* stream);
 /* Data-parallel gradient exchange in bf16 (replaces the implicit DDP reducer of trainer.py:155-162,190-192,270 for the

@@ -49,6 +49,7 @@ inline float group8_sum(float v) {
 inline float lane_bcast(float v, int L) { return __shfl(v, L); }
 inline float sload(const float* p) { return *p; }
 inline float fast_rsq(float x) { return 1.0f / sqrtf(x); }
+inline float fast_sqrt(float x) { return sqrtf(x); }
 inline bool wave_all(bool pred) {
     int v = pred ? 1 : 0;
     for (int m = 32; m >= 1; m >>= 1) v &= __shfl_xor(v, m);

@@ -51,6 +51,114 @@ def test_ema_kernel(dev):
     assert torch.allclose(ek.cpu(), e.lerp(p, 0.01), rtol=1e-6, atol=1e-7)
 
 
+@pytest.mark.parametrize('n,active_b', [(8 * 1024 + 4, True), (8 * 1024 + 4, False), (3000, True)])
+def test_adopt_kernel_with_folded_ema(dev, n, active_b):
+    """e2k_adopt_step_ema = e2k_adopt_step_groups followed by e2k_ema_update on the new parameters (trainer.py:275,279), in one pass:
+    parameters, moments and shadow bit for bit what the two-launch sequence gives, the average to fp32 rounding; elements of the
+    skipped group (ranges, active_b False) keep parameter and moments while their average still moves.  n covers whole 512-group
+    blocks inside, outside and across the ranges, and a ragged tail."""
+    from e2_tts_pytorch_amd import ops
+    torch.manual_seed(5)
+    ranges = torch.tensor([[512, 2048 + 512], [4096, 4096 + 2048 + 8]], dtype=torch.int32) if n > 4096 else torch.tensor([[8, 1000]], dtype=torch.int32)
+    d = lambda t: t.clone().to(dev)
+    p0, e0 = torch.randn(n), torch.randn(n)
+    m0, v0 = torch.randn(n) * 0.1, torch.rand(n) + 1e-3
+    A = dict(p=d(p0), m=d(m0), v=d(v0), e=d(e0))
+    B = dict(p=d(p0), m=d(m0), v=d(v0), e=d(e0))
+    for step in (1, 2):
+        g = torch.randn(n)
+        gs = torch.zeros(1, dtype=torch.float64, device=dev)
+        ops.sumsq(d(g), gs)
+        kw = dict(lr=1e-2, weight_decay=0.01, max_grad_norm=1.0, gsumsq=gs, ranges=ranges.to(dev), step_b=step - 1, active_b=active_b)
+        ops.adopt_step(A['p'], d(g), A['m'], A['v'], step, ema=A['e'], ema_decay=0.9, **kw)
+        ops.adopt_step(B['p'], d(g), B['m'], B['v'], step, **kw)
+        ops.ema_update(B['e'], B['p'], 0.9)
+        for k in 'pmv':
+            assert torch.equal(A[k].cpu(), B[k].cpu()), (step, k)
+        assert torch.allclose(A['e'].cpu(), B['e'].cpu(), rtol=1e-6, atol=1e-7), step
+    inb = torch.zeros(n, dtype=torch.bool)
+    for a, b in ranges.tolist():
+        inb[a:b] = True
+    if not active_b:
+        assert torch.equal(A['p'].cpu()[inb], p0[inb]) and torch.equal(A['m'].cpu()[inb], m0[inb])
+        assert not torch.equal(A['e'].cpu()[inb], e0[inb])                   # the average followed the (unchanged) parameters
+    assert not torch.equal(A['p'].cpu()[~inb], p0[~inb])
+    with pytest.raises(Exception):
+        ops.adopt_step(A['p'], d(g), A['m'], A['v'], 1, lr=1e-2, ema=A['e'][1:], ema_decay=0.9)
+
+
+@pytest.mark.late
+def test_ema_folded_into_adopt_on_model(dev):
+    """FusedAdopt.attach_ema: the backbone's average is moved inside the ADOPT pass on the steps on which ema.update() moves it; two
+    identical models trained side by side, one folded and one not, must agree in parameters (bit for bit) and averages (fp32
+    rounding) through copy steps, skipped steps (update_every 2), text-dropped steps and moving steps; a second step() without
+    ema.update() raises"""
+    from e2_tts_pytorch_amd import E2TTS, ops
+    from e2_tts_pytorch_amd.optim import FusedAdopt, FusedEMA
+    import random
+    nets = []
+    for fold in (True, False):
+        random.seed(0)
+        torch.manual_seed(0)
+        model = E2TTS(transformer=dict(dim=256, depth=2, heads=4, dropout=0., num_registers=32 if gpu_shapes(dev) else 8), use_vocos=False, cond_drop_prob=0.).to(dev)
+        opt = FusedAdopt(model, lr=1e-3, max_grad_norm=1.0)
+        ema = FusedEMA(model, update_after_step=1, update_every=2)
+        if fold:
+            opt.attach_ema(ema)
+        nets.append((model, opt, ema))
+    calls = []
+    real = ops.ema_update
+    g = torch.Generator().manual_seed(3)
+    B, T = 2, 24
+    try:
+        ops.ema_update = lambda e, p, d: (calls.append(e.numel()), real(e, p, d))[1]
+        for step, drop in enumerate([False, False, True, False, False, True, False]):
+            mel = torch.randn(B, T, 100, generator=g)
+            noise = dict(x0=torch.randn(B, T, 100, generator=g), times=torch.rand(B, generator=g), frac_lengths=torch.tensor([0.8, 0.9]),
+                         span_rand=torch.tensor([0.1, 0.5]), drop_text_cond=drop)
+            nd = {k: (v.to(dev) if torch.is_tensor(v) else v) for k, v in noise.items()}
+            for model, opt, ema in nets:
+                model(mel.to(dev), text=['hello', 'x'], _noise=nd).loss.backward()
+            if dev != 'cpu':
+                # on hardware two backward passes differ by the order of the weight gradients' fp32 atomics, and ADOPT's g / sqrt(v) turns
+                # that into different updates wherever a gradient is rounding noise: the second model takes the first one's gradients
+                for a, b in zip(nets[0][0].parameters(), nets[1][0].parameters()):
+                    assert (a.grad is None) == (b.grad is None)
+                    if a.grad is not None:
+                        b.grad.copy_(a.grad)
+            counts = []
+            for model, opt, ema in nets:
+                calls.clear()
+                opt.step()
+                opt.zero_grad()
+                ema.update()
+                counts.append(sum(calls))
+            (ma, _, ea), (mb, _, eb) = nets
+            for (n, a), b in zip(ma.named_parameters(), mb.parameters()):
+                assert torch.equal(a.detach().cpu(), b.detach().cpu()), (step, n)
+            for (n, a), b in zip(ea.ema_model.named_parameters(), eb.ema_model.parameters()):
+                assert torch.allclose(a.cpu(), b.cpu(), rtol=1e-6, atol=1e-7), (step, n)
+            if step in (2, 4, 6):          # moving steps (even, past update_after_step, initted; step 2 also drops the text): the backbone's launch is gone when folded
+                nflat = nets[0][0].transformer._flat.numel()
+                assert counts[1] - counts[0] == nflat, (step, counts)
+            else:
+                assert counts[0] == counts[1], (step, counts)
+    finally:
+        ops.ema_update = real
+    model, opt, ema = nets[0]
+    assert ema.pending_decay() is None                                    # step 7: odd, nothing pending -> step() twice is fine
+    mel = torch.randn(B, T, 100, generator=g).to(dev)
+    for k in range(2):
+        model(mel, text=['hello', 'x']).loss.backward()
+        opt.step()
+        opt.zero_grad()
+        if k == 0:
+            ema.update()                                                  # -> step 8: a moving step is pending now
+    with pytest.raises(RuntimeError):
+        model(mel, text=['hello', 'x']).loss.backward()
+        opt.step()
+
+
 @pytest.mark.late
 @pytest.mark.parametrize('persist', [False, True])
 def test_fused_adopt_on_model(dev, persist):
