@@ -852,8 +852,10 @@ class Transformer(Module):
 
     def _plan_forward(self, x, cond, text_embed, mask, need_grad, rot):
         p_drop = self.dropout if self.training else 0.
+        # (the stream is part of the signature: a recorded plan carries the pointer of ITS stream's split-K workspace, ops._nt_ws, so a
+        #  plan recorded on one stream must not run next to another one on a second stream -- E2TTS's concurrent CFG passes)
         key = (tuple(x.shape), exists(text_embed), exists(mask), need_grad, p_drop, str(x.device),
-               self._freq_len if self.has_freq_axis else 1)
+               self._freq_len if self.has_freq_axis else 1, ops.raw_stream(x.device) if x.is_cuda else None)
         st = self._plans.get(key)
         if st is None:                              # first sighting: eager (one-off shapes never pay for a recording)
             if len(self._plans) > 64:

@@ -7,6 +7,7 @@ interpolation w = (1 - t) x0 + t x1, tokenisation + embedding gather): a handful
 """
 from __future__ import annotations
 
+import os
 from collections import namedtuple
 from random import random
 
@@ -17,6 +18,10 @@ from torch.nn import Module
 
 from . import ops
 from .backbone import Transformer, default, exists
+
+# sample(): conditional and null pass of a function evaluation on two HIP streams (E2TTS._cfg_passes_concurrent); 0 = one after the other
+_CFG_CONCURRENT = os.environ.get('E2K_CFG_CONCURRENT', '1') != '0'
+_CFG_STREAMS = {}          # device index -> the null pass's stream
 
 LossBreakdown = namedtuple('LossBreakdown', ['flow', 'velocity_consistency'])                       # e2_tts.py:71
 E2TTSReturn = namedtuple('E2TTS', ['loss', 'cond', 'pred_flow', 'pred_data', 'loss_breakdown'])     # e2_tts.py:73
@@ -635,6 +640,7 @@ class E2TTS(Module):
         self.frac_lengths_mask = frac_lengths_mask
         self.duration_predictor = duration_predictor
         self.odeint_kwargs = odeint_kwargs
+        self._cfg_seen = {}        # (runtime state of _cfg_passes_concurrent: evaluations seen per signature)
         self.mel_spec = default(mel_spec_module, MelSpec(**mel_spec_kwargs))
         num_channels = default(num_channels, self.mel_spec.n_mel_channels)
         self.num_channels = num_channels
@@ -698,14 +704,53 @@ class E2TTS(Module):
             return pred
         return pred, drop_text_cond
 
+    def _cfg_passes_concurrent(self, args, kwargs, null_model, null_drop_text_cond):
+        """sample(): the conditional and the null pass of one function evaluation (e2_tts.py:1303-1330) are independent until the CFG
+        combine.  The null pass is issued on a second HIP stream, the conditional one on the caller's: the two passes' kernels share
+        the chip -- the row kernels of one (HBM bound: hyper-connections, qkv_post, norms; 30 % of a pass) run under the GEMMs of the
+        other (matrix bound), and each launch's partial last round of tiles is filled by the other stream.  Same kernels, same order
+        inside each pass: bit-identical to the sequential schedule (tests/test_e2tts.py::test_cfg_passes_concurrent_bit_identical).
+
+        What the passes share is read-only once it exists (bf16 weight shadows, rotary tables); things that are created on first use
+        are created while the passes still run one after the other: the shadows are refreshed here, before the streams part, and the
+        first two evaluations of a signature (eager pass, plan recording) are serialised by an extra join.  Launch plans are keyed by
+        stream (backbone._plan_forward), so the null pass's plan and its split-K workspace belong to the side stream."""
+        x = args[0]
+        dev = x.device
+        main = torch.cuda.current_stream(dev)
+        side = _CFG_STREAMS.get(dev.index)
+        if side is None:
+            side = _CFG_STREAMS[dev.index] = torch.cuda.Stream(dev)
+        for m in (self, null_model) if null_model is not self else (self,):
+            sync = getattr(m.transformer, '_sync', None)
+            if sync is not None:
+                sync(dev)
+        key = (tuple(x.shape), exists(kwargs.get('text')), exists(kwargs.get('mask')), id(null_model), main.cuda_stream)
+        seen = self._cfg_seen.get(key, 0)
+        self._cfg_seen[key] = seen + 1
+        if len(self._cfg_seen) > 256:
+            self._cfg_seen = {key: seen + 1}
+        side.wait_stream(main)
+        with torch.cuda.stream(side):
+            null_pred = null_model.transformer_with_pred_head(*args, drop_text_cond=null_drop_text_cond, **kwargs)
+        if seen < 2:
+            main.wait_stream(side)
+        pred = self.transformer_with_pred_head(*args, drop_text_cond=False, **kwargs)
+        main.wait_stream(side)
+        null_pred.record_stream(main)          # (allocated on the side stream, consumed by the combine on the caller's)
+        return pred, null_pred
+
     def cfg_transformer_with_pred_head(self, *args, cfg_strength: float = 1., cfg_null_model=None,
                                        remove_parallel_component: bool = True, keep_parallel_frac: float = 0., **kwargs):
-        pred = self.transformer_with_pred_head(*args, drop_text_cond=False, **kwargs)
         if cfg_strength < 1e-5:
-            return pred
+            return self.transformer_with_pred_head(*args, drop_text_cond=False, **kwargs)
         null_drop_text_cond = not exists(cfg_null_model)
         cfg_null_model = default(cfg_null_model, self)
-        null_pred = cfg_null_model.transformer_with_pred_head(*args, drop_text_cond=null_drop_text_cond, **kwargs)
+        if _CFG_CONCURRENT and not torch.is_grad_enabled() and args[0].is_cuda:
+            pred, null_pred = self._cfg_passes_concurrent(args, kwargs, cfg_null_model, null_drop_text_cond)
+        else:
+            pred = self.transformer_with_pred_head(*args, drop_text_cond=False, **kwargs)
+            null_pred = cfg_null_model.transformer_with_pred_head(*args, drop_text_cond=null_drop_text_cond, **kwargs)
         if not torch.is_grad_enabled() and pred.dtype == torch.float32 and _on_kernels(pred):
             # sample(): one kernel for the update, its fp64 projection and the combine (SURVEY K17)
             return ops.cfg_combine(pred.contiguous(), null_pred.contiguous(), cfg_strength, keep_parallel_frac, remove_parallel_component)

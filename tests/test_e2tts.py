@@ -374,6 +374,36 @@ def test_sample(dev):
     assert rel2(s, s_r) < 2e-2, rel2(s, s_r)
 
 
+@pytest.mark.gpu
+def test_cfg_passes_concurrent_bit_identical(monkeypatch):
+    """sample() issues the null pass of every function evaluation on a second HIP stream next to the conditional pass
+    (E2TTS._cfg_passes_concurrent; reference e2_tts.py:1303-1330 runs them one after the other).  Same kernels in the same order inside
+    each pass, so the samples must be bit-identical to the sequential schedule -- with eager passes, while the plans are recorded and on
+    their replays (8 steps = 14 evaluations), twice over to give a missing ordering point a chance to show, with a separate null model
+    too.  Sized so that the two passes really overlap on the chip (B 8, 512 wide, 288 frames)."""
+    from e2_tts_pytorch_amd import E2TTS, e2_tts
+    assert torch.cuda.is_available()
+    dev = 'cuda'
+    random.seed(0)
+    torch.manual_seed(0)
+    kw = dict(dim=512, depth=4, heads=8, dropout=0.)
+    model = E2TTS(transformer=dict(**kw), use_vocos=False).to(dev)
+    null_model = E2TTS(transformer=dict(**kw), use_vocos=False).to(dev)
+    B, dur = 8, 288
+    cond = torch.randn(B, 7, 100, device=dev)
+    y0 = torch.randn(B, dur, 100, device=dev)
+    text = ['some text %d' % i * (1 + i % 3) for i in range(B)]
+    outs = {}
+    for name, conc, nm in (('seq', False, None), ('conc', True, None), ('conc2', True, None), ('seq_null', False, null_model), ('conc_null', True, null_model)):
+        monkeypatch.setattr(e2_tts, '_CFG_CONCURRENT', conc)
+        outs[name] = model.sample(cond, text=text, duration=dur, steps=8, cfg_strength=1.5, cfg_null_model=nm, _y0=y0)
+        torch.cuda.synchronize()
+    assert torch.isfinite(outs['seq']).all()
+    assert torch.equal(outs['seq'], outs['conc']) and torch.equal(outs['seq'], outs['conc2'])
+    assert torch.equal(outs['seq_null'], outs['conc_null']) and not torch.equal(outs['seq'], outs['seq_null'])
+    assert e2_tts._CFG_STREAMS, 'the concurrent schedule did not run'
+
+
 def test_sample_with_frequency_tokens(dev):
     """E2TTS(num_freq_tokens=2).sample against the oracle: the frequency axis through the classifier-free-guidance pair of
     forwards (text stream on and dropped) and the ODE steps"""

@@ -1,6 +1,7 @@
 """cfg5: E2TTS.sample() ODE inference (32 midpoint steps = 62 function evaluations x (cond + null) = 124 backbone
 forwards), B=32, prompt 5 frames, duration 1024, cfg_strength 1, on one MI355X.  Reports sampled mel-frames/s."""
 import json
+import os
 import random
 import sys
 import time
@@ -33,7 +34,8 @@ dt = time.perf_counter() - t0
 fwd_flops = 6336e12 * (B / 32) * ((steps - 1) / 31)
 res = {'metric': 'sampled mel-frames/sec (E2TTS.sample, 32 midpoint steps, CFG)', 'value': B * 1024 / dt,
        'unit': 'mel-frames/s', 'seconds': dt, 'B': B, 'steps': steps, 'finite': bool(torch.isfinite(out).all()),
-       'launch_plans': '--eager' not in sys.argv, 'model_tflops_per_s': fwd_flops / dt / 1e12, 'shape': list(out.shape)}
+       'launch_plans': '--eager' not in sys.argv, 'cfg_passes_concurrent': __import__('e2_tts_pytorch_amd.e2_tts', fromlist=['x'])._CFG_CONCURRENT,
+       'model_tflops_per_s': fwd_flops / dt / 1e12, 'shape': list(out.shape)}
 print(json.dumps(res))
 (ROOT / 'gpurun_out').mkdir(exist_ok=True)
-json.dump(res, open(ROOT / 'gpurun_out' / ('r05_sample_cfg5%s.json' % ('_eager' if '--eager' in sys.argv else '')), 'w'), indent=1)
+json.dump(res, open(ROOT / 'gpurun_out' / ('r05_sample_cfg5%s%s.json' % ('_eager' if '--eager' in sys.argv else '', '_sequential' if os.environ.get('E2K_CFG_CONCURRENT') == '0' else '')), 'w'), indent=1)
