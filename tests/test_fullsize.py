@@ -234,6 +234,31 @@ def test_cfg5_sample_batch8_1024_frames():
     assert s.shape == s_r.shape == (B, dur, 100) and e < 1e-2, e
 
 
+def test_cfg5_exact_shape_rows_against_oracle():
+    """cfg5 as BASELINE.json states it -- B = 32, prompt of 5 frames, 1024 target frames, the cfg3 transformer (dim 1024, depth 24, 16
+    heads), classifier-free guidance -- on the HIP path (no-grad launch plans at B = 32, both passes of an evaluation on two streams), one
+    midpoint step (2 function evaluations x (cond + null) = 4 backbone forwards at B = 32; the CPU oracle of all 32 steps would hold the
+    box for hours).  The samples of a batch do not interact (per-sample masks, per-sample CFG projection, e2_tts.py:113-124,1303-1330),
+    so the fp32 oracle runs rows 0, 19 and 31 as a batch of three and each must match its row of the B = 32 result."""
+    torch.set_num_threads(min(32, os.cpu_count() or 1))
+    kw = dict(dim=1024, depth=24, heads=16, dropout=0.)
+    ref, model = _pair(kw, 'reference_init', seed=5)
+    B, Tp, dur, steps, rows = 32, 5, 1024, 2, [0, 19, 31]
+    cond = torch.randn(B, Tp, 100)
+    y0 = torch.randn(B, dur, 100)
+    rng = random.Random(5)
+    text = [''.join(rng.choice('abcdefghijklmnopqrstuvwxyz ,.') for _ in range(rng.randint(10, 90))) for _ in range(B)]
+    s = model.sample(cond.cuda(), text=text, duration=dur, steps=steps, cfg_strength=1., _y0=y0.cuda())
+    s_r = ref.sample(cond[rows], text=[text[r] for r in rows], duration=dur, steps=steps, cfg_strength=1., _y0=y0[rows])
+    errs = [rel2(s[r], s_r[i]) for i, r in enumerate(rows)]
+    _report('cfg5_exact_shape_rows', dict(case='sample() at cfg5 exactly (B 32, 1024 frames, cfg3 dims), one midpoint step, oracle on rows', kw=kw,
+                                          B=B, prompt=Tp, duration=dur, steps=steps, rows=rows, sampled_mel_rel_l2_per_row=errs))
+    print('sampled mel rel-L2 per row at cfg5', errs)
+    assert s.shape == (B, dur, 100) and torch.isfinite(s).all()
+    assert max(errs) < 1e-2, errs
+    assert rel2(s[1], s_r[0]) > 0.1           # (the rows are different samples: the comparison is not vacuous)
+
+
 def _grad_report(model, ref):
     refp = dict(ref.named_parameters())
     per_layer, worst = {}, []
