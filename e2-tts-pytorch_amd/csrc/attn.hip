@@ -141,7 +141,7 @@ __global__ __launch_bounds__(256) void qkv_post_fwd_kernel(PostArgs p) {
         }
         st<u32x4>(p.Q + o, pack8(q)); st<u32x4>(p.Q + o + 8, pack8(q + 8));
         st<u32x4>(p.K + o, pack8(k)); st<u32x4>(p.K + o + 8, pack8(k + 8));
-        st<u32x4>(p.V + o, pack8(v)); st<u32x4>(p.V + o + 8, pack8(v + 8));
+        if (p.V) { st<u32x4>(p.V + o, pack8(v)); st<u32x4>(p.V + o + 8, pack8(v + 8)); }     // (null: a no-grad forward reads only V^T)
     }
 #pragma unroll
     for (int e = 0; e < 16; ++e) {
@@ -1460,7 +1460,7 @@ static int qkv_post_fwd_impl(const void* qkvg, int64_t ldq, const float* cosb, c
                                 void* v_orig, float laser_clamp, int B, int H, int N, int Npad, void* stream) {
     if (B <= 0 || N <= 0) return 0;
     if ((ldq & 7) || (Npad & 63) || Npad < N) return E2K_ERR_ALIGN;
-    if (!qkvg || !cosb || !sinb || !Q || !K || !V || !VT || !gate || (vfirst && !mix)) return E2K_ERR_ARG;     // (QT, KT: optional)
+    if (!qkvg || !cosb || !sinb || !Q || !K || !VT || !gate || (vfirst && !mix)) return E2K_ERR_ARG;     // (QT, KT, V: optional)
     if (laser_clamp < 0.f || (v_orig && !(laser_clamp > 0.f))) return E2K_ERR_ARG;
     PostArgs a{};
     a.laser_c = laser_clamp; a.Vorig = (bf16_t*)v_orig;

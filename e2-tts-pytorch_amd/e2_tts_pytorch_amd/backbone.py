@@ -1184,7 +1184,8 @@ class Transformer(Module):
         qkvg = torch.empty((Mtok, a.ldq), dtype=bf16, device=run.dev)[:, :a.cols]
         ops.gemm_nt(xn if xa is None else xa, self._w(a.w, a.cols, D), bias=self._f(a.bias, a.cols), out=qkvg)
         first = run.vfirst[key] is None
-        ast = ops.qkv_post_fwd(qkvg, B, a.H, N, run.rot[0], run.rot[1], run.vfirst[key], laser=a.laser)
+        ast = ops.qkv_post_fwd(qkvg, B, a.H, N, run.rot[0], run.rot[1], run.vfirst[key], laser=a.laser,
+                               need_v=exists(tape) or (first and not a.laser > 0))     # (no-grad: V only where it is the value residual)
         if first:
             run.vfirst[key] = ast.Vorig if a.laser > 0 else ast.V      # (LASER: the values before the exp map)
         sid = (ind * 2 + int(text)) * 4

@@ -754,16 +754,18 @@ class AttnState:
     __slots__ = ('Q', 'K', 'V', 'QT', 'KT', 'VT', 'gate', 'mix', 'O', 'Og', 'lse2', 'B', 'H', 'N', 'Npad', 'dropbits', 'laser', 'Vorig')
 
 
-def qkv_post_fwd(qkvg, B, H, N, cosb, sinb, vfirst=None, laser=0.):
+def qkv_post_fwd(qkvg, B, H, N, cosb, sinb, vfirst=None, laser=0., need_v=True):
     """laser > 0: LASER attention's value map exp(c tanh(v / c)) (st.laser); on the first layer st.Vorig keeps the values
-    before it (the value residual of the later layers)"""
+    before it (the value residual of the later layers).  need_v False: the row-major values are not written (st.V None) -- the
+    forward kernels read V^T, only the backward pass and the value residual of the later layers read V"""
     _chk(qkvg, cosb, sinb, vfirst)
     assert qkvg.dtype == bf16 and qkvg.stride(1) == 1 and qkvg.shape[0] == B * N
     dev = qkvg.device
     Npad = (N + 63) // 64 * 64
     st = AttnState()
     st.B, st.H, st.N, st.Npad, st.dropbits = B, H, N, Npad, None
-    st.Q, st.K, st.V = (torch.empty((B, H, N, 64), dtype=bf16, device=dev) for _ in range(3))
+    st.Q, st.K = (torch.empty((B, H, N, 64), dtype=bf16, device=dev) for _ in range(2))
+    st.V = torch.empty((B, H, N, 64), dtype=bf16, device=dev) if need_v else None
     need = _lib.get().e2k_query_attn_bwd_transposes(Npad, attn_probe & 128)
     st.VT = torch.empty((B, H, 64, Npad), dtype=bf16, device=dev)
     st.KT = torch.empty((B, H, 64, Npad), dtype=bf16, device=dev) if need & 1 else None

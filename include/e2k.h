@@ -239,7 +239,8 @@ int e2k_dwconv_bwd_reduce(const float* ws, float* dw, float* dbias, int B, int N
  * qkvg (B*N, ldq) bf16 = fused projection output, columns [q (H*64) | k | v | head-gate logits (H) | value-residual
  * mix logits (H)].  cosb/sinb: rotary table (N, 32) fp32 (theta_j = 10000^(-2j/64), interleaved pairs).
  * vfirst: first layer's un-mixed values (B,H,N,64), NULL on the first layer (then V = v is what later layers use).
- * Outputs head-major Q,K,V (B,H,N,64), transposed QT,KT,VT (B,H,64,Npad; Npad = N rounded up to 64, zero padded),
+ * Outputs head-major Q,K,V (B,H,N,64), transposed QT,KT,VT (B,H,64,Npad; Npad = N rounded up to 64, zero padded; QT, KT and V may
+ * be NULL: the forward kernels read V^T, only the backward pass and the later layers' value residual read V),
  * gate = sigmoid(gate logits), mix = sigmoid(mix logits) (B,H,N) fp32.
  * laser_clamp > 0: LASER attention (Transformer(attn_laser = True, attn_laser_softclamp_value = c), e2_tts.py:543-544,641):
  * V / VT hold exp(c tanh(v / c)) of the (mixed) values and v_orig (first layer; may be NULL) receives the values before
