@@ -16,17 +16,11 @@ using namespace e2k;
 namespace {
 
 // streaming accesses: every optimizer buffer is read and written once per step and is far larger than the caches (cfg3: 2.9 GB each), so
-// the loads and stores carry the non-temporal hint (NT; E2K_OPTIM_VARIANT bit 1 turns it off for A/B)
-template <bool NT> __device__ __forceinline__ f32x4 ldv(const float* p) {
-    if constexpr (NT) return __builtin_nontemporal_load(reinterpret_cast<const f32x4*>(p));
-    else return *reinterpret_cast<const f32x4*>(p);
-}
-template <bool NT> __device__ __forceinline__ void stv(float* p, f32x4 v) {
-    if constexpr (NT) __builtin_nontemporal_store(v, reinterpret_cast<f32x4*>(p));
-    else *reinterpret_cast<f32x4*>(p) = v;
-}
+// the loads and stores carry the non-temporal hint (sum of squares 5.1 -> 5.8 TB/s, profiles/r05k_optim_kernels_ab.json)
+__device__ __forceinline__ f32x4 ldv(const float* p) { return __builtin_nontemporal_load(reinterpret_cast<const f32x4*>(p)); }
+__device__ __forceinline__ void stv(float* p, f32x4 v) { __builtin_nontemporal_store(v, reinterpret_cast<f32x4*>(p)); }
 
-template <bool NT> __global__ __launch_bounds__(256) void sumsq_kernel(const float* __restrict__ x, long n, double* out) {
+__global__ __launch_bounds__(256) void sumsq_kernel(const float* __restrict__ x, long n, double* out) {
     __shared__ double red[4];
     double acc[4] = {0.0, 0.0, 0.0, 0.0};
     const long n4 = n >> 2, stride = (long)gridDim.x * 256;
@@ -34,14 +28,14 @@ template <bool NT> __global__ __launch_bounds__(256) void sumsq_kernel(const flo
     for (; i + 3 * stride < n4; i += 4 * stride) {          // four 16-byte loads per thread in flight
         f32x4 v[4];
 #pragma unroll
-        for (int u = 0; u < 4; ++u) v[u] = ldv<NT>(x + 4 * (i + u * stride));
+        for (int u = 0; u < 4; ++u) v[u] = ldv(x + 4 * (i + u * stride));
 #pragma unroll
         for (int u = 0; u < 4; ++u)
 #pragma unroll
             for (int r = 0; r < 4; ++r) acc[r] = fma((double)v[u][r], (double)v[u][r], acc[r]);
     }
     for (; i < n4; i += stride) {
-        const f32x4 v = ldv<NT>(x + 4 * i);
+        const f32x4 v = ldv(x + 4 * i);
 #pragma unroll
         for (int r = 0; r < 4; ++r) acc[r] = fma((double)v[r], (double)v[r], acc[r]);
     }
@@ -71,14 +65,11 @@ struct AdoptArgs {
     float* ema; float ema_omd;
 };
 
-// one element: returns the new parameter value.  FAST: v_sqrt_f32 / v_rcp_f32 (1 ulp each) instead of the correctly rounded sequences
-// (~25 instructions per element): |u| differs by <= 3 ulp before the clamp, far inside the 2e-5 the oracle comparison allows
-template <bool FAST>
+// one element: returns the new parameter value.  v_sqrt_f32 / v_rcp_f32 (1 ulp each) instead of the correctly rounded sequences (~25
+// instructions per element): |u| differs by <= 3 ulp before the clamp, far inside the 2e-5 the oracle comparison allows
 __device__ __forceinline__ float adopt_one(const AdoptArgs& a, bool first, float clamp, float p, float g, float& m, float& v) {
     if (first) { v = g * g; return p; }
-    float q;
-    if constexpr (FAST) q = g * fast_rcp(fmaxf(fast_sqrt(v), a.eps));
-    else q = g / fmaxf(sqrtf(v), a.eps);
+    const float q = g * fast_rcp(fmaxf(fast_sqrt(v), a.eps));
     const float u = fminf(fmaxf(q, -clamp), clamp);
     m = m + (1.f - a.beta1) * (u - m);
     p = p * (1.f - a.lr * a.wd) - a.lr * m;
@@ -86,9 +77,8 @@ __device__ __forceinline__ float adopt_one(const AdoptArgs& a, bool first, float
     return p;
 }
 
-// MAP 0: each workgroup owns ONE contiguous span of 16-byte groups (round 3); MAP 1: blocks of 512 groups are dealt round-robin, so
-// that at any moment the chip reads one compact window of each of the streams (sequential DRAM rows per channel, few live pages)
-template <int MAP, bool NT, bool FAST>
+// Blocks of 512 16-byte groups are dealt round-robin over the grid, so that at any moment the chip reads one compact window of each of
+// the streams (round 3 gave each workgroup one contiguous span)
 __global__ __launch_bounds__(256) void adopt_kernel(AdoptArgs a) {
     // clip factor of torch.nn.utils.clip_grad_norm_: min(1, max_norm / (total_norm + 1e-6))
     float cs = 1.f;
@@ -115,33 +105,26 @@ __global__ __launch_bounds__(256) void adopt_kernel(AdoptArgs a) {
         }
         if (upd) {
 #pragma unroll
-            for (int r = 0; r < 4; ++r) { float mm = m[r], vv = v[r]; pv[r] = adopt_one<FAST>(a, first, clamp, p[r], g[r] * cs, mm, vv); m[r] = mm; v[r] = vv; }
-            stv<NT>(a.p + 4 * i, f32x4{pv[0], pv[1], pv[2], pv[3]});
-            stv<NT>(a.m + 4 * i, m);
-            stv<NT>(a.v + 4 * i, v);
+            for (int r = 0; r < 4; ++r) { float mm = m[r], vv = v[r]; pv[r] = adopt_one(a, first, clamp, p[r], g[r] * cs, mm, vv); m[r] = mm; v[r] = vv; }
+            stv(a.p + 4 * i, f32x4{pv[0], pv[1], pv[2], pv[3]});
+            stv(a.m + 4 * i, m);
+            stv(a.v + 4 * i, v);
             if (a.shadow) st<u32x2>(a.shadow + 4 * i, pack4(pv));
         }
-        if (a.ema) stv<NT>(a.ema + 4 * i, e + (f32x4{pv[0], pv[1], pv[2], pv[3]} - e) * a.ema_omd);
+        if (a.ema) stv(a.ema + 4 * i, e + (f32x4{pv[0], pv[1], pv[2], pv[3]} - e) * a.ema_omd);
     };
     // Blocks of 512 groups (two sweeps of the 256 threads in flight).  Which parameter group a block belongs to is decided once per
     // block from the sorted ranges, with workgroup-uniform state: a block is outside every range, inside one, or -- only at the few
     // range boundaries -- mixed, and only then do its lanes search.  Blocks of a group without a gradient are skipped before their
     // loads (unless the moving average has to follow them).  (Round 3: the per-lane binary search of every 16-byte group put seven
     // dependent LDS reads in front of each group's stores.)
-    long b0, b1, bstep;
-    if (MAP == 0) {
-        const long per = ((n4 + gridDim.x - 1) / gridDim.x + 511) & ~511L;
-        b0 = (long)blockIdx.x * per; b1 = min(b0 + per, n4); bstep = 512;
-    } else {
-        b0 = (long)blockIdx.x * 512; b1 = n4; bstep = (long)gridDim.x * 512;
-    }
-    int ri = 0;
-    for (long base = b0; base < b1; base += bstep) {
+    const long b1 = n4, bstep = (long)gridDim.x * 512;
+    for (long base = (long)blockIdx.x * 512; base < b1; base += bstep) {
         const long e0 = 4 * base, e1 = 4 * min(base + 512, b1);
         int kind = 0;                                       // 0: outside every range, 1: inside range ri, 2: mixed
         if (nr) {
-            if (MAP == 0) { while (ri < nr && (long)rng[2 * ri + 1] <= e0) ++ri; }          // ri = first range that ends past the block's start
-            else { ri = last_start(e0); if (ri > 0 && (long)rng[2 * ri - 1] > e0) --ri; }
+            int ri = last_start(e0);                        // -> the first range that ends past the block's start
+            if (ri > 0 && (long)rng[2 * ri - 1] > e0) --ri;
             if (ri < nr && (long)rng[2 * ri] < e1) kind = ((long)rng[2 * ri] <= e0 && (long)rng[2 * ri + 1] >= e1) ? 1 : 2;
         }
         if (kind == 1 && !a.active_b && !a.ema) continue;
@@ -149,16 +132,16 @@ __global__ __launch_bounds__(256) void adopt_kernel(AdoptArgs a) {
         const bool hi = i < b1, hj = j < b1;
         f32x4 p0, g0, m0, v0, p1, g1, m1, v1, e0v, e1v;
         if (a.ema) {
-            if (hi) e0v = ldv<NT>(a.ema + 4 * i);
-            if (hj) e1v = ldv<NT>(a.ema + 4 * j);
+            if (hi) e0v = ldv(a.ema + 4 * i);
+            if (hj) e1v = ldv(a.ema + 4 * j);
         }
         if (kind == 1 && !a.active_b) {                     // only the average moves
-            if (hi) p0 = ldv<NT>(a.p + 4 * i);
-            if (hj) p1 = ldv<NT>(a.p + 4 * j);
+            if (hi) p0 = ldv(a.p + 4 * i);
+            if (hj) p1 = ldv(a.p + 4 * j);
             g0 = m0 = v0 = g1 = m1 = v1 = f32x4{0.f, 0.f, 0.f, 0.f};
         } else {
-            if (hi) { p0 = ldv<NT>(a.p + 4 * i); g0 = ldv<NT>(a.g + 4 * i); m0 = ldv<NT>(a.m + 4 * i); v0 = ldv<NT>(a.v + 4 * i); }
-            if (hj) { p1 = ldv<NT>(a.p + 4 * j); g1 = ldv<NT>(a.g + 4 * j); m1 = ldv<NT>(a.m + 4 * j); v1 = ldv<NT>(a.v + 4 * j); }
+            if (hi) { p0 = ldv(a.p + 4 * i); g0 = ldv(a.g + 4 * i); m0 = ldv(a.m + 4 * i); v0 = ldv(a.v + 4 * i); }
+            if (hj) { p1 = ldv(a.p + 4 * j); g1 = ldv(a.g + 4 * j); m1 = ldv(a.m + 4 * j); v1 = ldv(a.v + 4 * j); }
         }
         if (hi) one(i, kind == 1 || (kind == 2 && in_b(4 * i)), p0, g0, m0, v0, e0v);
         if (hj) one(j, kind == 1 || (kind == 2 && in_b(4 * j)), p1, g1, m1, v1, e1v);
@@ -166,35 +149,30 @@ __global__ __launch_bounds__(256) void adopt_kernel(AdoptArgs a) {
     if (blockIdx.x == 0 && threadIdx.x < (a.n & 3)) {
         const long i = 4 * n4 + threadIdx.x;
         float mm = a.m[i], vv = a.v[i];
-        const float pn = adopt_one<FAST>(a, a.first, a.clamp, a.p[i], a.g[i] * cs, mm, vv);  // (the tail is never inside a range)
+        const float pn = adopt_one(a, a.first, a.clamp, a.p[i], a.g[i] * cs, mm, vv);  // (the tail is never inside a range)
         a.p[i] = pn; a.m[i] = mm; a.v[i] = vv;
         if (a.shadow) a.shadow[i] = f2bf(pn);
         if (a.ema) a.ema[i] += (pn - a.ema[i]) * a.ema_omd;
     }
 }
 
-template <bool NT>
 __global__ __launch_bounds__(256) void ema_kernel(float* ema, const float* p, long n, float one_minus_decay) {
     const long n4 = n >> 2, stride = (long)gridDim.x * 256;
     long i = (long)blockIdx.x * 256 + threadIdx.x;
     for (; i + 3 * stride < n4; i += 4 * stride) {        // four independent 16-byte streams per thread in flight
         f32x4 e[4], w[4];
 #pragma unroll
-        for (int u = 0; u < 4; ++u) { e[u] = ldv<NT>(ema + 4 * (i + u * stride)); w[u] = ldv<NT>(p + 4 * (i + u * stride)); }
+        for (int u = 0; u < 4; ++u) { e[u] = ldv(ema + 4 * (i + u * stride)); w[u] = ldv(p + 4 * (i + u * stride)); }
 #pragma unroll
-        for (int u = 0; u < 4; ++u) stv<NT>(ema + 4 * (i + u * stride), e[u] + (w[u] - e[u]) * one_minus_decay);
+        for (int u = 0; u < 4; ++u) stv(ema + 4 * (i + u * stride), e[u] + (w[u] - e[u]) * one_minus_decay);
     }
     for (; i < n4; i += stride) {
-        f32x4 e = ldv<NT>(ema + 4 * i);
-        const f32x4 w = ldv<NT>(p + 4 * i);
-        stv<NT>(ema + 4 * i, e + (w - e) * one_minus_decay);
+        f32x4 e = ldv(ema + 4 * i);
+        const f32x4 w = ldv(p + 4 * i);
+        stv(ema + 4 * i, e + (w - e) * one_minus_decay);
     }
     if (blockIdx.x == 0 && threadIdx.x < (n & 3)) { const long j = 4 * n4 + threadIdx.x; ema[j] += (p[j] - ema[j]) * one_minus_decay; }
 }
-
-// A/B switches (tools/probes/optim_ab.py): E2K_OPTIM_VARIANT bits: 1 = contiguous spans (round-3 mapping), 2 = plain (temporal) accesses,
-// 4 = correctly rounded sqrt / divide; E2K_OPTIM_GRID = cap of the update pass's grid
-int optim_variant() { static const int v = getenv("E2K_OPTIM_VARIANT") ? atoi(getenv("E2K_OPTIM_VARIANT")) : 0; return v; }
 
 int grid_for(long n) {
     long g = (n / 4 + 255) / 256;
@@ -202,11 +180,11 @@ int grid_for(long n) {
 }
 // the update pass: one workgroup per 512-group block (57 KB of traffic each; 350 000 workgroups at cfg3).  Many short workgroups dealt by
 // the dispatcher keep the eight XCDs level where 4096 long ones drift apart: 3.15 against 3.38 ms alone, 4.04 against 4.37 ms with the
-// average folded in (6.4 TB/s of the 6.3 a float4 copy reaches; profiles/r05m_optim_kernels_ab.json).  E2K_OPTIM_GRID caps the grid (A/B).
+// average folded in (6.4 TB/s of the 6.3 a float4 copy reaches; profiles/r05m_optim_kernels_ab.json, measured with a grid cap switch
+// that is gone again).
 int adopt_grid_for(long n) {
-    static const long cap = getenv("E2K_OPTIM_GRID") ? atol(getenv("E2K_OPTIM_GRID")) : (1L << 22);
     long g = (n / 4 + 511) / 512;
-    return (int)(g < 1 ? 1 : (g > cap ? cap : g));
+    return (int)(g < 1 ? 1 : (g > (1L << 22) ? (1L << 22) : g));
 }
 
 // ---- gradient slab <-> bf16 wire format of the data-parallel exchange (ddp.py; replaces the implicit DDP reducer of
@@ -241,8 +219,7 @@ static int sumsq_f32_impl(const float* x, int64_t n, double* out, void* stream) 
     if (n <= 0) return 0;
     if (!x || !out) return E2K_ERR_ARG;
     if ((uintptr_t)x & 15) return E2K_ERR_ALIGN;
-    if (optim_variant() & 2) hipLaunchKernelGGL(sumsq_kernel<false>, dim3(grid_for(n)), dim3(256), 0, (hipStream_t)stream, x, (long)n, out);
-    else hipLaunchKernelGGL(sumsq_kernel<true>, dim3(grid_for(n)), dim3(256), 0, (hipStream_t)stream, x, (long)n, out);
+    hipLaunchKernelGGL(sumsq_kernel, dim3(grid_for(n)), dim3(256), 0, (hipStream_t)stream, x, (long)n, out);
     E2K_CHECK_LAUNCH();
     return 0;
 }
@@ -261,13 +238,7 @@ static int adopt_step_impl(float* p, const float* g, float* m, float* v, void* s
     a.gsumsq = gsumsq; a.first = step == 0;
     a.ranges = ranges; a.nranges = nranges; a.first_b = step_b == 0; a.clamp_b = sqrtf(sqrtf((float)step_b)); a.active_b = active_b;
     a.ema = ema; a.ema_omd = 1.f - ema_decay;
-    const dim3 grid(adopt_grid_for(n)), block(256);
-    switch (optim_variant() & 7) {
-#define E2K_ADOPT_CASE(V, MAP, NT, FAST) case V: hipLaunchKernelGGL((adopt_kernel<MAP, NT, FAST>), grid, block, 0, (hipStream_t)stream, a); break;
-        E2K_ADOPT_CASE(0, 1, true, true)   E2K_ADOPT_CASE(1, 0, true, true)   E2K_ADOPT_CASE(2, 1, false, true)  E2K_ADOPT_CASE(3, 0, false, true)
-        E2K_ADOPT_CASE(4, 1, true, false)  E2K_ADOPT_CASE(5, 0, true, false)  E2K_ADOPT_CASE(6, 1, false, false) E2K_ADOPT_CASE(7, 0, false, false)
-#undef E2K_ADOPT_CASE
-    }
+    hipLaunchKernelGGL(adopt_kernel, dim3(adopt_grid_for(n)), dim3(256), 0, (hipStream_t)stream, a);
     E2K_CHECK_LAUNCH();
     return 0;
 }
@@ -276,8 +247,7 @@ static int ema_update_impl(float* ema, const float* p, int64_t n, float decay, v
     if (n <= 0) return 0;
     if (!ema || !p) return E2K_ERR_ARG;
     if (((uintptr_t)ema | (uintptr_t)p) & 15) return E2K_ERR_ALIGN;
-    if (optim_variant() & 2) hipLaunchKernelGGL(ema_kernel<false>, dim3(grid_for(n)), dim3(256), 0, (hipStream_t)stream, ema, p, (long)n, 1.f - decay);
-    else hipLaunchKernelGGL(ema_kernel<true>, dim3(grid_for(n)), dim3(256), 0, (hipStream_t)stream, ema, p, (long)n, 1.f - decay);
+    hipLaunchKernelGGL(ema_kernel, dim3(grid_for(n)), dim3(256), 0, (hipStream_t)stream, ema, p, (long)n, 1.f - decay);
     E2K_CHECK_LAUNCH();
     return 0;
 }

@@ -1,6 +1,4 @@
-"""the optimizer-side kernels alone at cfg3 size (716 M fp32 elements per buffer), HIP events, one process per variant (the switches are
-read once per process): E2K_OPTIM_VARIANT bits 1 = contiguous spans, 2 = temporal accesses, 4 = correctly rounded sqrt / divide;
-E2K_OPTIM_GRID = grid cap.   python tools/probes/optim_ab.py [out.json]"""
+"""the optimizer-side kernels alone at cfg3 size (716 M fp32 elements per buffer), HIP events.   python tools/probes/optim_ab.py [out.json]"""
 import json, os, subprocess, sys
 from pathlib import Path
 ROOT = Path(__file__).resolve().parent.parent.parent
@@ -39,16 +37,10 @@ if len(sys.argv) > 1 and sys.argv[1] == '--child':
     print(json.dumps(out))
     sys.exit(0)
 
-res = {}
-for name, var, grid in [('round-robin, nt, fast math, grid 65536', 0, 65536), ('spans', 1, 65536), ('temporal', 2, 65536), ('exact math', 4, 65536),
-                        ('round 4: spans, temporal, exact, grid 4096', 7, 4096), ('grid 4096', 0, 4096), ('grid 16384', 0, 16384), ('grid 32768', 0, 32768),
-                        ('grid 131072', 0, 131072), ('grid 400000', 0, 400000), ('round-robin, nt, fast math, grid 65536 (again)', 0, 65536)]:
-    env = dict(os.environ, E2K_OPTIM_VARIANT=str(var), E2K_OPTIM_GRID=str(grid))
-    r = subprocess.run([sys.executable, __file__, '--child'], env=env, capture_output=True, text=True, timeout=300)
-    try:
-        res[name] = json.loads(r.stdout.strip().splitlines()[-1])
-    except Exception:       # noqa: BLE001
-        res[name] = dict(error=(r.stderr or r.stdout)[-400:])
-    print(name, json.dumps(res[name]), flush=True)
+# (round 5 ran this once per variant through E2K_OPTIM_VARIANT / E2K_OPTIM_GRID switches -- block mapping, non-temporal accesses, fast
+#  sqrt / rcp, grid cap: profiles/r05k_optim_kernels_ab.json, r05m_optim_kernels_ab.json; the switches were removed with the losers)
+r = subprocess.run([sys.executable, __file__, '--child'], capture_output=True, text=True, timeout=300)
+res = json.loads(r.stdout.strip().splitlines()[-1])
+print(json.dumps(res, indent=1))
 if len(sys.argv) > 1:
-    json.dump(dict(n=N, variants=res), open(sys.argv[1], 'w'), indent=1)
+    json.dump(dict(n=N, kernels=res), open(sys.argv[1], 'w'), indent=1)
