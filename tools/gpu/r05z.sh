@@ -5,7 +5,8 @@ export PYTHONUNBUFFERED=1
 O=$GRAFT_REPO_ROOT/gpurun_out/r05z
 mkdir -p $O
 cd $GRAFT_REPO_ROOT
-(timeout 1500 python3 -m pytest tests/ -x -q -m gpu -p no:cacheprovider) > $O/pytest_gpu.log 2>&1
+(timeout 300 python -c 'import __graft_entry__ as g; g.smoke()') > $O/smoke.log 2>&1; echo "smoke rc=$? $(tail -1 $O/smoke.log | cut -c1-200)"
+(timeout 1800 python3 -m pytest tests/ -x -q -m gpu -p no:cacheprovider) > $O/pytest_gpu.log 2>&1
 echo "pytest rc=$? $(tail -1 $O/pytest_gpu.log)"
 (timeout 600 python bench.py) > $O/bench_default.log 2>&1; echo "bench rc=$? $(grep -o '"ms_per_step": [0-9.]*' $O/bench_default.log | head -1)"
 (timeout 300 python bench.py --steps 10 --warmup 3 --no-cpu-baseline --no-optimizer-leg --no-launch-floor --dump-ops $O/ops_by_shape.json) > $O/bench_ops.log 2>&1
