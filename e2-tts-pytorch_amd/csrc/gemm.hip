@@ -751,15 +751,14 @@ __global__ __launch_bounds__(QTHREADS, 1) void gemm_nt_256_kernel(NTArgs p) {
     int tile_m, tile_n;
     const int nk1 = p.K1 / BK, nk = (p.K1 + p.K2) / BK;
     int kb = 0, ke = nk, part = -1;
-    // The K-split remainder workgroups come FIRST in the grid: they run 1 / split of a K loop and then their fp32 partial epilogue while
-    // the full tiles are still in their K loops, which staggers a quarter of the CUs against the synchronised store burst of the others
-    // (round 4, same-box A/B: NT alone-timed -0.8 %, 3 of 3 pairs, profiles/r04_rem_first_ab.txt).  A full tile's index is
-    // blockIdx.x - nsplitwg: its chunk of the tile list still lands on ONE XCD (the chunks are rotated by nsplitwg % 8 XCDs)
-    const int nsplitwg = (int)gridDim.x - p.full;
-    if ((int)blockIdx.x >= nsplitwg) {
-        tile_coords(xcd_remap((int)blockIdx.x - nsplitwg, p.full), tm, tn, tile_m, tile_n, p.group);
+    // The K-split remainder workgroups come LAST in the grid.  Putting them first (they run 1 / split of a K loop and stagger a quarter of
+    // the CUs against the store burst of the full tiles) was landed early in round 5 on a round-4 measurement of -0.8 % and taken out
+    // again: same box, NT 37.15 / 37.38 ms first against 37.45 / 37.40 last, the step equal, and 12 % MORE HBM fetch (FETCH_SIZE over the
+    // step's launch mix 1.89 against 1.69 G units, twice each; profiles/r05t_rem_first_vs_last_fetch_ab.txt)
+    if ((int)blockIdx.x < p.full) {
+        tile_coords(xcd_remap((int)blockIdx.x, p.full), tm, tn, tile_m, tile_n, p.group);
     } else {
-        part = blockIdx.x;
+        part = blockIdx.x - p.full;
         const int r = part / p.split, sidx = part - r * p.split;
         tile_coords(p.full + r, tm, tn, tile_m, tile_n, p.group);
         kb = (int)((long)nk * sidx / p.split);
