@@ -143,12 +143,59 @@ __device__ __forceinline__ void lane32_swap(unsigned& a, unsigned& b) {
     a = r[0];
     b = r[1];
 }
+// v_permlane16_swap_b32: the odd rows (16 lanes each) of `a` trade places with the even rows of `b`
+__device__ __forceinline__ void lane16_swap(unsigned& a, unsigned& b) {
+    const auto r = __builtin_amdgcn_permlane16_swap(a, b, false, false);
+    a = r[0];
+    b = r[1];
+}
 // value of the same register in lane (l ^ 32)
 __device__ __forceinline__ float lane32_other(float v) {
     unsigned a = __builtin_bit_cast(unsigned, v), b = a;
     lane32_swap(a, b);              // lanes 0..31: b = upper half's value; lanes 32..63: a = lower half's value
     return __builtin_bit_cast(float, (__builtin_amdgcn_mbcnt_hi(~0u, __builtin_amdgcn_mbcnt_lo(~0u, 0u)) < 32u) ? b : a);
 }
+
+// Wave totals of N per-lane values (N a multiple of 4), left TRANSPOSED over the rows of the wave: on return v[i], i < N / 4, holds in
+// every lane of row r (lanes 16 r .. 16 r + 15) the total of value i + (N / 4) (r & 1) + (N / 2) (r >> 1).  The two swap levels halve the
+// number of live partial sums each (one swap + one add per PAIR of values), only the last N / 4 registers go through the four in-row DPP
+// levels: 2.5 N instructions where the plain butterfly (wave_sum_last4) takes 6 N.
+template <int K> __device__ __forceinline__ void row_sum_dpp(float* v) {          // K <= 4 registers: sum over the 16 lanes of each row
+    static_assert(K >= 1 && K <= 4, "");
+#define E2K_DPPR_(ctrl)                                                                     \
+    asm("s_nop 1\n"                                                                         \
+        "v_add_f32_dpp %0, %0, %0 " ctrl "\n"                                               \
+        : "+v"(v[0]));                                                                      \
+    if constexpr (K > 1) asm("v_add_f32_dpp %0, %0, %0 " ctrl "\n" : "+v"(v[1]));           \
+    if constexpr (K > 2) asm("v_add_f32_dpp %0, %0, %0 " ctrl "\n" : "+v"(v[2]));           \
+    if constexpr (K > 3) asm("v_add_f32_dpp %0, %0, %0 " ctrl "\n" : "+v"(v[3]));
+    E2K_DPPR_("quad_perm:[1,0,3,2] row_mask:0xf bank_mask:0xf")
+    E2K_DPPR_("quad_perm:[2,3,0,1] row_mask:0xf bank_mask:0xf")
+    E2K_DPPR_("row_half_mirror row_mask:0xf bank_mask:0xf")
+    E2K_DPPR_("row_mirror row_mask:0xf bank_mask:0xf")
+#undef E2K_DPPR_
+}
+template <int N> __device__ __forceinline__ void wave_sum_rows(float (&v)[N]) {
+    static_assert(N % 4 == 0 && N >= 4, "");
+#pragma unroll
+    for (int i = 0; i < N / 2; ++i) {
+        unsigned a = __builtin_bit_cast(unsigned, v[i]), b = __builtin_bit_cast(unsigned, v[i + N / 2]);
+        lane32_swap(a, b);           // lanes 0..31: (a, b) = value i of lanes l, l + 32; lanes 32..63: value i + N / 2
+        v[i] = __builtin_bit_cast(float, a) + __builtin_bit_cast(float, b);
+    }
+#pragma unroll
+    for (int i = 0; i < N / 4; ++i) {
+        unsigned a = __builtin_bit_cast(unsigned, v[i]), b = __builtin_bit_cast(unsigned, v[i + N / 4]);
+        lane16_swap(a, b);           // even rows: value i (+ N / 2) summed over its row pair; odd rows: value i + N / 4 (+ N / 2)
+        v[i] = __builtin_bit_cast(float, a) + __builtin_bit_cast(float, b);
+    }
+    constexpr int R = N / 4;
+#pragma unroll
+    for (int i = 0; i + 4 <= R; i += 4) row_sum_dpp<4>(v + i);
+    if constexpr (R % 4 != 0) row_sum_dpp<R % 4>(v + (R & ~3));
+}
+// value index held by register i of the lanes of row r after wave_sum_rows<N>
+template <int N> __device__ __forceinline__ constexpr int wave_sum_rows_index(int i, int r) { return i + (N / 4) * (r & 1) + (N / 2) * (r >> 1); }
 
 // 16 wave masks (SGPR pairs, e.g. fresh from v_cmp) -> 128 consecutive bytes at a wave-uniform address, through the scalar data cache
 // (s_store_dwordx2: no vector instruction, no VGPR).  The statement waits for its own stores (lgkmcnt) before the SGPRs may be reused;

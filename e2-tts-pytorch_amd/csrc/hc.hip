@@ -109,22 +109,28 @@ __device__ __forceinline__ float tanh_fast(float x) {
 
 constexpr int NRED = 32;                             // LDS exchange row (28 forward / 24 backward values used)
 
-// Reduce N per-lane partials over the NW waves that share a token, leaving the totals spread over LANES instead of
-// broadcast: DPP sums bring each wave total to lane 63, lane 63 stores the N totals to LDS, and after one barrier
-// lane l (< 32) picks up the total with index `pick` (summed over the NW waves).  The per-token scalar math that
+// Reduce N per-lane partials (N a multiple of 8) over the NW waves that share a token, leaving the totals spread over LANES instead of
+// broadcast: wave_sum_rows leaves the total of value i + (N / 4) (r & 1) + (N / 2) (r >> 1) in register i of row r (two swap levels + four
+// in-row DPP levels on N / 4 registers), the first lane of each row stores its N / 4 totals to LDS at their value indices, and after one
+// barrier (the caller's) lane l (< 32) picks up the total with index `pick` (summed over the NW waves).  The per-token scalar math that
 // follows then runs once per lane-slot instead of N times on wave-uniform values.
+template <int N>
+__device__ __forceinline__ void token_scatter_nosync(float (&v)[N], float (*red)[4][NRED], int parity, int wave, int lane, int base = 0) {
+    static_assert(N % 8 == 0 && N <= NRED, "");
+    wave_sum_rows<N>(v);
+    if ((lane & 15) == 0) {
+        float* dst = &red[parity][wave][base + wave_sum_rows_index<N>(0, lane >> 4)];        // (N / 4 consecutive totals, 8-byte aligned)
+#pragma unroll
+        for (int i = 0; i < N / 4; i += 2) *reinterpret_cast<f32x2_*>(dst + i) = f32x2_{v[i], v[i + 1]};
+    }
+}
 template <int N, int NW>
 __device__ __forceinline__ void token_scatter(float* vals, float (*red)[4][NRED], int parity, int wave, int lane) {
-    static_assert(N % 4 == 0, "");
+    constexpr int NP = (N + 7) & ~7;
+    float v[NP];
 #pragma unroll
-    for (int i = 0; i < N; i += 4) wave_sum_last4(vals[i], vals[i + 1], vals[i + 2], vals[i + 3]);
-    if (lane == 63) {
-#pragma unroll
-        for (int i = 0; i < N; i += 4) {
-            f32x4 v = {vals[i], vals[i + 1], vals[i + 2], vals[i + 3]};
-            *reinterpret_cast<f32x4*>(&red[parity][wave][i]) = v;
-        }
-    }
+    for (int i = 0; i < NP; ++i) v[i] = i < N ? vals[i] : 0.f;
+    token_scatter_nosync<NP>(v, red, parity, wave, lane);
     __syncthreads();
 }
 template <int NW>
@@ -359,21 +365,17 @@ __global__ __launch_bounds__(256, 3) void hc_bwd_kernel(HCBwdArgs p) {
         if (!CHECK) prefetch(it + 1);       // (clamped to the last token past the end)
 
         const float* cf = p.coef + tok * CW;
-        // 24 dots: da[s][t] = dm_t . r_s (index s*6 + t) ; db[s] = G_s . y_cur (index s*6 + 5); reduced and handed
-        // to LDS four at a time so that few of them are live at once
+        // 24 dots: da[s][t] = dm_t . r_s (index s*6 + t) ; db[s] = G_s . y_cur (index s*6 + 5); reduced eight at a time (wave_sum_rows: its
+        // cost is linear in the count, and few of them are live at once) and handed to LDS by the first lane of each row
 #pragma unroll
-        for (int g = 0; g < 6; ++g) {
-            float d4[4];
+        for (int g = 0; g < 3; ++g) {
+            float d8[8];
 #pragma unroll
-            for (int q = 0; q < 4; ++q) {
-                const int idx = g * 4 + q, s = idx / 6, t = idx % 6;
-                d4[q] = t < 5 ? dot_pk<EPL>(dm[t], r[s]) : dot_pk<EPL>(dm[s + 1], yc);
+            for (int q = 0; q < 8; ++q) {
+                const int idx = g * 8 + q, s = idx / 6, t = idx % 6;
+                d8[q] = t < 5 ? dot_pk<EPL>(dm[t], r[s]) : dot_pk<EPL>(dm[s + 1], yc);
             }
-            wave_sum_last4(d4[0], d4[1], d4[2], d4[3]);
-            if (lane == 63) {
-                f32x4 v = {d4[0], d4[1], d4[2], d4[3]};
-                *reinterpret_cast<f32x4*>(&red[it & 1][wave][g * 4]) = v;
-            }
+            token_scatter_nosync<8>(d8, red, it & 1, wave, lane, g * 8);
         }
         // independent of the reduction, done while the other waves arrive: pre[s] = sum_t a[s][t] dm_t
         float a[S][5], rn[S], pre[S][EPL];

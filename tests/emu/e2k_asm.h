@@ -101,6 +101,31 @@ inline void lane32_swap(unsigned& a, unsigned& b) {
     if (lane < 32) b = other.a; else a = other.b;
 }
 inline float lane32_other(float v) { return __shfl_xor(v, 32); }
+inline void lane16_swap(unsigned& a, unsigned& b) {
+    struct P { unsigned a, b; };
+    const int lane = emu::lane_id();
+    const P other = emu::wave_exchange(P{a, b}, lane ^ 16);
+    if ((lane >> 4) & 1) a = other.b; else b = other.a;       // odd rows of a <-> even rows of b
+}
+template <int N> inline void wave_sum_rows(float (&v)[N]) {      // same swap / add order as the device version (fp32 sums in the same order)
+    for (int i = 0; i < N / 2; ++i) {
+        unsigned a = __float_as_uint(v[i]), b = __float_as_uint(v[i + N / 2]);
+        lane32_swap(a, b);
+        v[i] = __uint_as_float(a) + __uint_as_float(b);
+    }
+    for (int i = 0; i < N / 4; ++i) {
+        unsigned a = __float_as_uint(v[i]), b = __float_as_uint(v[i + N / 4]);
+        lane16_swap(a, b);
+        v[i] = __uint_as_float(a) + __uint_as_float(b);
+    }
+    for (int i = 0; i < N / 4; ++i) {
+        v[i] += __shfl_xor(v[i], 1);
+        v[i] += __shfl_xor(v[i], 2);
+        v[i] += __shfl(v[i], (emu::lane_id() & ~7) | (7 - (emu::lane_id() & 7)));       // row_half_mirror
+        v[i] += __shfl(v[i], (emu::lane_id() & ~15) | (15 - (emu::lane_id() & 15)));    // row_mirror
+    }
+}
+template <int N> inline constexpr int wave_sum_rows_index(int i, int r) { return i + (N / 4) * (r & 1) + (N / 2) * (r >> 1); }
 
 template <bool WAIT = true>
 inline void sstore_masks16(unsigned long long* dst, const unsigned long long (&m)[16]) {      // (every lane writes the same 128 bytes)
