@@ -323,6 +323,7 @@ class FusedEMA:
         self.ema_model.load_state_dict(inner, strict=True)
         self.initted = bool(sd['initted'])
         self.step = int(sd['step'])
+        self._folded = None                # (a folded update that was pending belongs to the state that was just replaced)
 
     def twin_of(self, tr):
         """the copy's backbone that follows the online backbone `tr`, if both are whole flat buffers of the same layout"""
