@@ -407,8 +407,10 @@ struct ConvArgs {
 // 64 x KS weights and the frame mask go through LDS once per workgroup.  (Round 3; the first kernel used 64-frame tiles -- halo
 // 47 % -- and had every thread fetch its 2 x KS weights itself, 62 loads per thread = 5 x the tile's bytes through the L1, and the
 // mask byte of each of its frames from global memory: 31.4 -> 24.4 us at the cfg3 audio shape with a mask, 17.6 -> 15.4 us at the
-// text shape, profiles/r03_dwconv_fwd_ab.jsonl.  Still 2.1 TB/s of its algorithmic bytes: 154 VGPRs -> 3 workgroups per CU, and
-// the load / compute / store phases of a workgroup do not overlap.)
+// text shape, profiles/r03_dwconv_fwd_ab.jsonl.  Still 2.1 TB/s of its algorithmic bytes: 82 VGPRs, five workgroups per CU -- which is
+// ALL 4.5 workgroups per CU of a cfg3 call at once, so their load / compute / store phases run in lockstep and do not overlap.  It is not
+// the 4-byte stores: the outputs through LDS in 16-byte pieces, a quarter of the store instructions, measured +3 % here and -1 % in
+// the backward (round 5, profiles/r05w_dwconv_16byte_stores_ab.txt) and were taken out again.)
 template <int KS>
 __global__ __launch_bounds__(256) void dwconv_fwd_kernel(ConvArgs p) {
     constexpr int FR = 128, PAD = KS / 2, ROWS = FR + KS - 1;
@@ -483,7 +485,7 @@ __global__ __launch_bounds__(256) void dwconv_fwd_kernel(ConvArgs p) {
 #pragma unroll
     for (int o = 0; o < 16; ++o) {
         if (n0 + fg * 16 + o < p.N) {
-            st<unsigned>(pre + (long)o * p.C, pack2bf(a[o][0], a[o][1]));
+            if (p.pre) st<unsigned>(pre + (long)o * p.C, pack2bf(a[o][0], a[o][1]));       // (null: a no-grad forward, nothing reads the pre-activation)
             st<unsigned>(y + (long)o * p.C, mk[fg * 16 + o] ? pack2bf(siluf_(a[o][0]), siluf_(a[o][1])) : 0u);
         }
     }

@@ -1161,7 +1161,7 @@ class Transformer(Module):
         binp, rec = self._hc_width(run, S, lr.hc[0])
         cw = self._f(lr.conv.w, D * lr.conv.ks).view(D, lr.conv.ks)
         cb = self._f(lr.conv.b, D)
-        pre, y = ops.dwconv_fwd(binp.view(B, N, D), run.mask_n, cw, cb)
+        pre, y = ops.dwconv_fwd(binp.view(B, N, D), run.mask_n, cw, cb, need_pre=exists(tape))
         y = y.view(Mtok, D)
         self._hc_depth(S, rec, y)
         if exists(tape):

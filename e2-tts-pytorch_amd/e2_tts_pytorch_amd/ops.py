@@ -705,13 +705,14 @@ def cast_transpose_batch(flat, flatT, desc, total_blocks):
 
 # ------------------------------------------------------------------------------------------------ depthwise conv
 
-def dwconv_fwd(x, mask, w, bias):
-    """x (B,N,C) bf16, mask (B,N) bool/u8 or None, w (C,1,ks)/(C,ks) fp32 -> (pre, y)"""
+def dwconv_fwd(x, mask, w, bias, need_pre=True):
+    """x (B,N,C) bf16, mask (B,N) bool/u8 or None, w (C,1,ks)/(C,ks) fp32 -> (pre, y); need_pre False: the pre-activation (read by the
+    backward pass only) is not written and None is returned for it"""
     _chk(x, mask, w, bias)
     B, N, C = x.shape
     ks = w.shape[-1]
     assert x.is_contiguous() and w.is_contiguous() and w.dtype == f32 and bias.dtype == f32
-    pre, y = torch.empty_like(x), torch.empty_like(x)
+    pre, y = (torch.empty_like(x) if need_pre else None), torch.empty_like(x)
     _lib.get().e2k_dwconv_fwd(_p(x), _p(mask), _p(w), _p(bias), _p(pre), _p(y), B, N, C, ks, _stream(x))
     return pre, y
 

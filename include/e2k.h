@@ -222,7 +222,8 @@ int e2k_cast_transpose_bf16(const float* src, void* dst, int R, int C, int64_t l
 int e2k_cast_transpose_batch(const float* flat, void* flatT, const int64_t* desc, int n, int total_blocks, void* stream);
 
 /* DepthwiseConv (e2_tts.py:295-328): channels-last x (B,N,C) bf16, mask (B,N) u8 or NULL, w (C,ks) fp32, bias (C):
- *   pre = conv1d(mask * x) + bias ;  y = mask * silu(pre).   ks in {3,7,15,31}, C multiple of 64. */
+ *   pre = conv1d(mask * x) + bias ;  y = mask * silu(pre).   ks in {3,7,15,31}, C multiple of 64.  pre may be NULL (only the backward
+ * pass reads it). */
 int e2k_dwconv_fwd(const void* x, const uint8_t* mask, const float* w, const float* bias, void* pre,
                    void* y, int B, int N, int C, int ks, void* stream);
 /* dx, and dw / dbias ACCUMULATED (fp32).  ws: scratch of e2k_query_dwconv_bwd_ws_floats(B, N, C, ks) floats for the

@@ -138,7 +138,9 @@ def test_dwconv(dev, N, ks, use_mask, split):
     yr.backward(dy.float())
     xd, wd, bd, md = x.to(dev), w.to(dev), bias.to(dev), (None if mask is None else mask.to(dev))
     pre, y = ops.dwconv_fwd(xd, md, wd, bd)
-    assert rel(y, yr) < 1e-2
+    assert rel(y, yr) < 1e-2 and rel(pre, pre_r.detach() if mask is None else torch.where(mask[..., None], pre_r.detach(), pre.cpu().float())) < 1e-2
+    none, y2 = ops.dwconv_fwd(xd, md, wd, bd, need_pre=False)          # no-grad form: the pre-activation is not written
+    assert none is None and torch.equal(y2.cpu(), y.cpu())
     dw, db = torch.zeros_like(wd), torch.zeros_like(bd)
     ops.dwconv_bwd_workspace = not split          # (True: workspace + reduce pass, the default; False: global atomics)
     try:
