@@ -111,6 +111,46 @@ def _worker(rank, world, port, emu_lib, q):
     dist.destroy_process_group()
 
 
+def _sum_worker(rank, world, port, q):
+    sys.path[:0] = [str(ROOT / 'e2-tts-pytorch_amd'), str(ROOT), str(ROOT / 'tests')]
+    os.environ.update(MASTER_ADDR='127.0.0.1', MASTER_PORT=str(port))
+    torch.set_num_threads(1)
+    dist.init_process_group('gloo', rank=rank, world_size=world)
+    from e2_tts_pytorch_amd.ddp import _GradSync
+    sync = _GradSync(None, torch.bfloat16, 1, wire_fp32_sum=True)
+    bad = []
+    for n in (1001, 3 * 512, 5):                       # a length the world size does not divide, one it does, one shorter than a shard row
+        bufs = [(torch.randn(n, generator=torch.Generator().manual_seed(10 * n + r)) * 3).to(torch.bfloat16) for r in range(world)]
+        got = sync._sum_fp32(bufs[rank].clone())
+        want = sum(b.float() for b in bufs).to(torch.bfloat16)          # ONE rounding of the fp32 sum
+        chain = bufs[0].clone()
+        for b in bufs[1:]:
+            chain = (chain + b)                                         # what a bf16 all-reduce does: a rounding per addition
+        if got.shape != (n,) or not torch.equal(got, want):
+            bad.append((n, 'sum differs from the once-rounded fp32 sum'))
+        if n > 100 and torch.equal(want, chain):
+            bad.append((n, 'test is vacuous: the bf16 chain gives the same bits'))
+    q.put(('ok', bad))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_wire_fp32_sum_rounds_once():
+    """ddp._GradSync._sum_fp32 (wire_fp32_sum=True; replaces the bf16 all-reduce of the gradient slabs, trainer.py:155-162): bf16 on the
+    wire, fp32 accumulation -- the result is bit for bit the fp32 sum of the ranks' bf16 slabs rounded ONCE, on every rank, also when the
+    world size does not divide the slab.  3 ranks, gloo."""
+    ctx = mp.get_context('spawn')
+    q = ctx.Queue()
+    port = 31500 + os.getpid() % 2000
+    procs = [ctx.Process(target=_sum_worker, args=(r, 3, port, q)) for r in range(3)]
+    for p in procs:
+        p.start()
+    res = [q.get(timeout=300) for _ in procs]
+    for p in procs:
+        p.join(timeout=60)
+    assert all(r[0] == 'ok' and not r[1] for r in res), res
+
+
 def test_two_rank_gradient_mean(emu_lib):
     ctx = mp.get_context('spawn')
     q = ctx.Queue()
