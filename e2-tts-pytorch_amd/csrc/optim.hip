@@ -67,12 +67,15 @@ struct AdoptArgs {
 
 // one element: returns the new parameter value.  v_sqrt_f32 / v_rcp_f32 (1 ulp each) instead of the correctly rounded sequences (~25
 // instructions per element): |u| differs by <= 3 ulp before the clamp, far inside the 2e-5 the oracle comparison allows
+// (adam_atan2_pytorch.adopt.Adopt.step: the weight decay `p.mul_(1 - lr * wd)` comes FIRST -- before the state is created, i.e. also on the
+//  step that only sets v = g^2 -- and a.wd is the effective factor: the caller divides weight_decay by the initial lr when decoupled_wd)
 __device__ __forceinline__ float adopt_one(const AdoptArgs& a, bool first, float clamp, float p, float g, float& m, float& v) {
+    p = p * (1.f - a.lr * a.wd);
     if (first) { v = g * g; return p; }
     const float q = g * fast_rcp(fmaxf(fast_sqrt(v), a.eps));
     const float u = fminf(fmaxf(q, -clamp), clamp);
     m = m + (1.f - a.beta1) * (u - m);
-    p = p * (1.f - a.lr * a.wd) - a.lr * m;
+    p = p - a.lr * m;
     v = v + (1.f - a.beta2) * (g * g - v);
     return p;
 }

@@ -82,10 +82,18 @@ class FusedAdopt:
     moments and step count stay as they are.  The backbone remains ONE launch: its text-stream slots are a second
     parameter group inside the flat buffer (e2k_adopt_step_groups)."""
 
-    def __init__(self, model, lr=1e-4, betas=(0.9, 0.99), eps=1e-6, weight_decay=0., max_grad_norm=1.0):
+    def __init__(self, model, lr=1e-4, betas=(0.9, 0.99), eps=1e-6, weight_decay=0., max_grad_norm=1.0, decoupled_wd=True,
+                 process_group=None):
         self.model = model
         self.params = [p for p in model.parameters() if p.requires_grad]
         self.lr, self.betas, self.eps, self.weight_decay, self.max_grad_norm = lr, betas, eps, weight_decay, max_grad_norm
+        # adam_atan2_pytorch.adopt.Adopt: `wd /= init_lr` when decoupled_wd (the default), and the decay `p.mul_(1 - lr * wd)` is applied
+        # before anything else on every step a parameter has a gradient -- the first (v = g^2 only) included
+        self.decoupled_wd, self._init_lr = bool(decoupled_wd), lr
+        # the data-parallel group the text-live flag is made global over under a stock DDP without the shim (None: the default group).
+        # A job whose replicas are a SUBGROUP of the default group (or in which not every rank of the default group runs this optimizer)
+        # must pass its group here: the flag exchange is a collective
+        self.process_group = process_group
         self.steps = [0] * len(self.params)            # per parameter, as Adopt's state['steps']
         self._state = {}           # data_ptr of a parameter STORAGE -> (m, v) flat fp32 buffers mirroring that storage
         self._loaded = {}          # parameter index -> (m, v) from load_state_dict, not yet copied into a run
@@ -100,7 +108,7 @@ class FusedAdopt:
         instead of a 12-B pass of its own), and `ema.update()` then only handles the few parameters outside the backbone.  This relies on
         the trainer's order -- one `ema.update()` after every `step()` (trainer.py:275-279) -- and a second `step()` without it raises."""
         assert ema is None or ema.online is self.model, 'the EMA must follow the model this optimizer updates'
-        self._ema = ema
+        self._ema, self._ema_seen = ema, None
         return self
 
     @property
@@ -123,11 +131,16 @@ class FusedAdopt:
         #  last step is the same everywhere in a data-parallel job; the per-rank part is only the VALUE of the flag)
         if not local:
             return
-        t = torch.full((len(local),), 0, dtype=torch.int32, device=dev if dist.get_backend() != 'gloo' else 'cpu')
+        grp = self.process_group
+        if grp is not None and dist.get_world_size(grp) <= 1:
+            return
+        t = torch.full((len(local),), 0, dtype=torch.int32, device=dev if dist.get_backend(grp) != 'gloo' else 'cpu')
         for i, tr in enumerate(local):
             if tr._text_grad_live:
                 t[i] = 1
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        # (one blocking collective + host read-back per optimizer step, only on this un-shimmed path: ddp.DataParallel and
+        #  enable_overlap_under_ddp settle the flag during the pass through a pinned buffer and never come here)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX, group=grp)
         for tr, v in zip(local, t.tolist()):
             tr._text_grad_live = bool(v)
             tr._text_live_is_global = True
@@ -172,8 +185,8 @@ class FusedAdopt:
         state = {i: dict(steps=self.steps[i], m=m.detach().clone(), v=v.detach().clone()) for i, (m, v) in sorted(self._views().items())}
         for i, (m, v) in self._loaded.items():              # loaded but not yet stepped
             state.setdefault(i, dict(steps=self.steps[i], m=m.clone(), v=v.clone()))
-        group = dict(lr=self.lr, betas=tuple(self.betas), eps=self.eps, weight_decay=self.weight_decay, decoupled_wd=True,
-                     params=list(range(len(self.params))))
+        group = dict(lr=self.lr, betas=tuple(self.betas), eps=self.eps, weight_decay=self.weight_decay, decoupled_wd=self.decoupled_wd,
+                     init_lr=self._init_lr, params=list(range(len(self.params))))
         return dict(state=dict(sorted(state.items())), param_groups=[group])
 
     def load_state_dict(self, sd):
@@ -181,6 +194,8 @@ class FusedAdopt:
         assert len(g['params']) == len(self.params), 'parameter count differs from the checkpoint'
         self.lr, self.betas, self.eps = g['lr'], tuple(g['betas']), g['eps']
         self.weight_decay = g.get('weight_decay', 0.)
+        self.decoupled_wd = bool(g.get('decoupled_wd', True))
+        self._init_lr = g.get('init_lr', self._init_lr)         # (Adopt keeps it on the optimizer object, not in the checkpoint: ours survives a reload)
         self.steps = [0] * len(self.params)
         self._loaded = {}
         for i, st in sd['state'].items():
@@ -233,8 +248,13 @@ class FusedAdopt:
         self._globalise_text_live(dev)
         ema, ema_decay, folded = self._ema, None, set()
         if ema is not None:
-            if ema._folded is not None:
-                raise RuntimeError('FusedAdopt.step() with an attached EMA: ema.update() has to follow every step() (trainer.py:275-279)')
+            # the contract is checked on EVERY step, not only on those whose update is folded: a loop that steps more often
+            # than it updates the average fails on its first iteration, not around step 110 when the first fold comes due
+            seen, self._ema_seen = getattr(self, '_ema_seen', None), ema.step
+            if ema._folded is not None or (seen is not None and ema.step != seen + 1):
+                self._ema_seen = None
+                raise RuntimeError('FusedAdopt.step() with an attached EMA: exactly one ema.update() has to follow every step() '
+                                   '(trainer.py:275-279); loops that update the average less often must detach it: attach_ema(None)')
             ema_decay = ema.pending_decay()             # None: the coming ema.update() copies or does nothing
         for tr in self._backbones:
             slots = getattr(getattr(tr, '_layout', None), 'slots', None)
@@ -282,9 +302,10 @@ class FusedAdopt:
         mvs = [self._mv(pf) for pf, _, _ in runs]
         if len(self._state) != nstate:
             self._install_loaded()
+        wd = self.weight_decay / self._init_lr if self.decoupled_wd else self.weight_decay
         for (pf, gf, kw), (m, v) in zip(runs, mvs):
             ops.adopt_step(pf, gf, m, v, kw.pop('step'), lr=self.lr, beta1=b1, beta2=b2, eps=self.eps,
-                           weight_decay=self.weight_decay, max_grad_norm=self.max_grad_norm, gsumsq=gs, **kw)
+                           weight_decay=wd, max_grad_norm=self.max_grad_norm, gsumsq=gs, **kw)
         if folded:
             ema._folded = (ema.step, ema_decay, folded)
         for p, _ in pairs:                                     # the kernels wrote behind autograd's back

@@ -20,14 +20,16 @@ def clip_grad_norm_(grads, max_norm):
 class Adopt:
     """adam_atan2_pytorch.adopt.Adopt(params, lr, betas=(0.9, 0.99), eps=1e-6, weight_decay=0, decoupled_wd=True)
     (trainer.py:183,275): step 0 only sets v = g^2; afterwards
-    u = clamp(g / max(sqrt(v), eps), +-step^0.25), m.lerp_(u, 1 - beta1), p -= lr * m, v.lerp_(g^2, 1 - beta2).
+    u = clamp(g / max(sqrt(v), eps), +-step^0.25), m.lerp_(u, 1 - beta1), p -= lr * m, v.lerp_(g^2, 1 - beta2); the weight decay
+    p *= 1 - lr * (wd / init_lr if decoupled_wd else wd) is applied before all of that, on every step including the first.
     `steps` is per-parameter state and a parameter whose .grad is None is skipped (its count does not advance), as in
     the torch.optim-style loop of that package -- which matters here: the text stream has no gradient on the 25 % of the
     training steps whose classifier-free-guidance coin drops the text (e2_tts.py:1261-1262)."""
 
-    def __init__(self, params, lr=1e-4, betas=(0.9, 0.99), eps=1e-6, weight_decay=0.):
+    def __init__(self, params, lr=1e-4, betas=(0.9, 0.99), eps=1e-6, weight_decay=0., decoupled_wd=True):
         self.params = list(params)
         self.lr, self.betas, self.eps, self.wd = lr, betas, eps, weight_decay
+        self.init_lr, self.decoupled_wd = lr, decoupled_wd      # (`lr` may be changed by a scheduler; the decoupling divides by the INITIAL one)
         self.steps = [0] * len(self.params)
         self.m = [torch.zeros_like(p) for p in self.params]
         self.v = [torch.zeros_like(p) for p in self.params]
@@ -39,13 +41,16 @@ class Adopt:
             g = p.grad
             if g is None:
                 continue
+            # weight decay first -- before the state exists, i.e. also on the step that only sets v -- and, decoupled, divided by the
+            # initial learning rate (`wd /= init_lr; if wd > 0: p.mul_(1 - lr * wd)` in that package's step())
+            wd = self.wd / self.init_lr if self.decoupled_wd else self.wd
+            if wd > 0:
+                p.mul_(1. - self.lr * wd)
             t = self.steps[i]
             self.steps[i] += 1
             if t == 0:
                 v.copy_(g * g)
                 continue
-            if self.wd > 0:
-                p.mul_(1. - self.lr * self.wd)
             u = (g / torch.clamp(v.sqrt(), min=self.eps)).clamp(-t ** 0.25, t ** 0.25)
             m.lerp_(u, 1. - b1)
             p.add_(m, alpha=-self.lr)

@@ -35,8 +35,12 @@ def test_adopt_kernel_matches_oracle(dev, n, max_norm, wd):
             gs = torch.zeros(1, dtype=torch.float64, device=dev)
             ops.sumsq(gk, gs)
             assert abs(gs.item() - float((g.double() ** 2).sum())) <= 1e-10 * float((g.double() ** 2).sum()) + 1e-12
-        ops.adopt_step(pk, gk, m, v, step, lr=1e-2, weight_decay=wd, max_grad_norm=max_norm, gsumsq=gs, shadow=shadow)
+        # (the C ABI takes the EFFECTIVE decay: Adopt divides weight_decay by the initial lr when decoupled_wd, its default -- FusedAdopt
+        #  does that division; the decay is applied on every step, the first one -- which only sets v -- included)
+        ops.adopt_step(pk, gk, m, v, step, lr=1e-2, weight_decay=wd / 1e-2, max_grad_norm=max_norm, gsumsq=gs, shadow=shadow)
         assert torch.allclose(pk.cpu(), pr.detach(), rtol=2e-5, atol=2e-6), (step, (pk.cpu() - pr.detach()).abs().max())
+        if wd > 0 and step == 0:
+            assert torch.allclose(pk.cpu(), p0 * (1. - wd), rtol=1e-6, atol=1e-7)          # decayed although step 0 moves nothing else
         assert torch.allclose(v.cpu(), opt.v[0], rtol=2e-5, atol=1e-7)
         assert torch.allclose(m.cpu(), opt.m[0], rtol=2e-5, atol=1e-7)
         assert torch.equal(shadow.cpu(), pk.cpu().to(torch.bfloat16)) or step == 0
@@ -160,8 +164,8 @@ def test_ema_folded_into_adopt_on_model(dev):
 
 
 @pytest.mark.late
-@pytest.mark.parametrize('persist', [False, True])
-def test_fused_adopt_on_model(dev, persist):
+@pytest.mark.parametrize('persist,wd', [(False, 0.), (True, 0.), (True, 0.01)])
+def test_fused_adopt_on_model(dev, persist, wd):
     """FusedAdopt / FusedEMA on a small E2TTS: runs of adjacent parameters are merged, results match the oracle optimizer
     fed with the same gradients (the backbone's parameters are views of one flat buffer).  persist: the same with
     Transformer.enable_persistent_grads() -- the gradients stay attached across zero_grad and are overwritten in place"""
@@ -174,11 +178,13 @@ def test_fused_adopt_on_model(dev, persist):
     mel = torch.randn(2, 24, 100, device=dev)
     if persist:
         model.transformer.enable_persistent_grads()
-    opt = FusedAdopt(model, lr=1e-3, max_grad_norm=1.0)
+    opt = FusedAdopt(model, lr=1e-3, max_grad_norm=1.0, weight_decay=wd)
     ema = FusedEMA(model, update_after_step=0, update_every=1)
     ref_params = [p.detach().cpu().clone().requires_grad_(True) for p in opt.params]
-    ref = O.Adopt(ref_params, lr=1e-3)
-    for step in range(2):
+    ref = O.Adopt(ref_params, lr=1e-3, weight_decay=wd)       # (decoupled_wd=True: the decay per step is lr * wd / init_lr = wd, from step 0 on)
+    for step in range(3 if wd else 2):
+        if step == 2:
+            opt.lr = ref.lr = 5e-4         # a scheduler moved the rate: the decoupling still divides by the INITIAL one
         out = model(mel, text=['hello world', 'x'])
         out.loss.backward()
         pairs = [(p, p.grad) for p in opt.params if p.grad is not None]
