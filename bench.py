@@ -13,6 +13,7 @@ on a bounded sample of the same workload, rank 0 at N=1 only.
 from __future__ import annotations
 
 import argparse
+import math
 import json
 import os
 import random
@@ -223,6 +224,8 @@ def main():
     ap.add_argument('--ddp-defer', action='store_true', help='one gradient all-reduce after the backward pass instead of per-layer slabs overlapped with it (A/B)')
     ap.add_argument('--no-optimizer-leg', action='store_true', help='skip the extra leg that times the step WITH the fused gradient clip + '
                     'ADOPT update (+ EMA) after the headline measurement (N = 1 only; it never enters `value`)')
+    ap.add_argument('--no-warm-leg', action='store_true', help='skip ms_per_step_warm (>= --warm-seconds of load, then K event-timed steps)')
+    ap.add_argument('--warm-seconds', type=float, default=10.0)
     ap.add_argument('--main-cus', default=None, help='first:count -- run the step on a HIP stream confined to these CUs '
                     '(hipExtStreamCreateWithCUMask; A/B of the launch lanes with E2K_LANE_CUS, DESIGN.md section 5.1)')
     ap.add_argument('--dump-ops', default=None, help='write the per-shape launch table of the profiled plan replays (name, flops, count, '
@@ -352,6 +355,28 @@ def main():
     if world > 1:
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
     dt = float(t.item())
+
+    # warm leg: the contract's W warm-up steps + K timed steps see a chip in its first seconds of load (83-84 ms at cfg3 in round 5); a
+    # training job lives at the clocks the chip settles to after ~10 s (86-87 ms).  Same plan, same step(): >= 10 s of continuous load,
+    # then K steps timed by HIP events at the step boundaries, median (max over ranks).  Reported beside the headline, never as `value`.
+    ms_warm, warm_load_s = None, None
+    if not args.no_warm_leg:
+        n_load = int(math.ceil(args.warm_seconds / max(dt / args.steps, 1e-4)))           # (dt is the max over ranks: every rank runs the same count)
+        tw = time.perf_counter()
+        for _ in range(n_load):
+            step()
+        evs = [torch.cuda.Event(enable_timing=True) for _ in range(args.steps + 1)]
+        evs[0].record()
+        for i in range(args.steps):
+            step()
+            evs[i + 1].record()
+        torch.cuda.synchronize()
+        warm_load_s = time.perf_counter() - tw
+        d = sorted(evs[i].elapsed_time(evs[i + 1]) for i in range(args.steps))
+        tw_ = torch.tensor([d[len(d) // 2]], dtype=torch.float64, device=dev)
+        if world > 1:
+            dist.all_reduce(tw_, op=dist.ReduceOp.MAX)
+        ms_warm = float(tw_.item())
     if rank == 0:
         ms = dt / args.steps * 1e3
         frames = B * T * world
@@ -375,6 +400,11 @@ def main():
             'value': frames / (dt / args.steps),
             'unit': 'mel-frames/s',
             'n_gpus': world, 'steps': args.steps, 'warmup': args.warmup, 'ms_per_step': ms,
+            'ms_per_step_warm': ms_warm,
+            'warm_note': (f'median of {args.steps} steps (HIP events at the step boundaries, max over ranks) after {warm_load_s:.1f} s of continuous load '
+                          f'of the same replayed plan: the clocks a training job runs at; `value` / ms_per_step are the contract\'s W warm-up + K steps, '
+                          f'i.e. the first seconds of load') if ms_warm is not None else None,
+            'mfma_roofline_frac_whole_step_warm': (sf / (ms_warm * 1e-3) / 1e12 / PEAK_BF16_TFLOPS) if ms_warm else None,
             'higher_is_better': True, 'scaling': 'weak', 'vs_baseline': None, 'dtype': 'bf16', 'data': 'synthetic',
             'config': {
                 'workload': f'{args.config}: E2TTS(dim={dim}, depth={depth}, heads={heads}) fwd+bwd, B={B}/GPU, T={T}, '

@@ -1668,6 +1668,12 @@ bool tn_use_256(int M, int N, int K, int use_tr) {
 
 }  // namespace
 
+// smallest number of 256 x 256 output tiles for which e2k_gemm_nt_bf16 takes the 256 x 256 kernel (E2K_GEMM_T256_MIN overrides, A/B)
+static int nt_t256_min() {
+    static const int v = getenv("E2K_GEMM_T256_MIN") ? atoi(getenv("E2K_GEMM_T256_MIN")) : 64;
+    return v;
+}
+
 static int gemm_nt_bf16_impl(const void* A1, int64_t lda1, int K1, const void* A2, int64_t lda2, int K2,
                                 const void* B, int64_t ldb, void* C, int64_t ldc, int out_f32, int accumulate,
                                 int M, int N, const float* bias, const float* colscale, int64_t lds,
@@ -1710,7 +1716,7 @@ static int gemm_nt_bf16_impl(const void* A1, int64_t lda1, int K1, const void* A
     // leaves free are taken by the other launch lanes' kernels, and the big tile's better K loop wins: cfg3 step 88.9 -> 87.5 ms
     // on one box, 95.5 -> 92.4 on another, the same for thresholds 132 / 66 / 33 / 1 (profiles/r03_t256_threshold_ab.jsonl).
     // E2K_GEMM_T256_MIN overrides (A/B).
-    static const int t256_min = getenv("E2K_GEMM_T256_MIN") ? atoi(getenv("E2K_GEMM_T256_MIN")) : 64;
+    const int t256_min = nt_t256_min();
     const bool q256 = glds && !p.probe && !(flags & E2K_GEMM_NO_T256) &&
                       ((flags & E2K_GEMM_T256) || (t256 >= t256_min && (K1 + K2) >= 4 * BK));
     if (q256) {
@@ -1901,7 +1907,14 @@ static int gemm_nt_geglu_bwd_bf16_impl(const void* dY, int64_t ldy, int K, const
     return 0;
 }
 
-extern "C" int e2k_query_gemm_nt_geglu_bwd(int M, int F, int K) { return nt_geglu_bwd_ok(M, F, K) ? 1 : 0; }
+// 1: the fused launch is what the caller should use; 2: it can run (e2k_gemm_nt_geglu_bwd_bf16 accepts the shape) but the output has
+// fewer 256 x 256 tiles than e2k_gemm_nt_bf16 itself asks for before it takes that kernel -- a 256-row tile of a small M is mostly
+// padding, and the 128 x 128 kernel + e2k_geglu_bwd is the better pair there; 0: refused
+extern "C" int e2k_query_gemm_nt_geglu_bwd(int M, int F, int K) {
+    if (!nt_geglu_bwd_ok(M, F, K)) return 0;
+    const int t256 = ((M + QBM - 1) / QBM) * (F / QBN);
+    return t256 >= nt_t256_min() ? 1 : 2;
+}
 
 extern "C" int e2k_gemm_nt_geglu_bwd_bf16(const void* dY, int64_t ldy, int K, const void* W2T, int64_t ldb, const void* H, int64_t ldh,
                                           void* dH, int64_t lddh, int M, int F, float p_drop, uint32_t seed, const uint32_t* seed_dev,

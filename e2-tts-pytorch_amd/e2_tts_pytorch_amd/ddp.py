@@ -272,18 +272,27 @@ class DataParallel(nn.Module):
             flat.mul_(1.0 / self.world)
             dist.all_reduce(flat, op=dist.ReduceOp.SUM, group=self.group)
             off = 0
+            fresh = []               # gradients ALLOCATED in this block, i.e. by the exchange stream's pool
             for p in ps:
                 n = p.numel()
                 g = flat[off:off + n].view_as(p).to(p.dtype)
                 if p.grad is None:
                     p.grad = g.clone()
+                    fresh.append(p.grad)
                 else:
                     p.grad.copy_(g)
                 off += n
         if side is not None:
+            main = torch.cuda.current_stream(dev)
+            fresh_ids = {id(g) for g in fresh}
             for p in ps:
-                p.grad.record_stream(side)
-            torch.cuda.current_stream(dev).wait_stream(side)
+                if id(p.grad) in fresh_ids:
+                    # born on the exchange stream, read by the optimizer on the compute stream: the CONSUMER is what the allocator has to
+                    # be told about, or zero_grad(set_to_none) hands the block back to the side pool while compute-stream readers are pending
+                    p.grad.record_stream(main)
+                else:
+                    p.grad.record_stream(side)      # born on the compute stream, written here
+            main.wait_stream(side)
 
     def forward(self, *args, **kwargs):
         return self.module(*args, **kwargs)

@@ -725,6 +725,12 @@ class E2TTS(Module):
             sync = getattr(m.transformer, '_sync', None)
             if sync is not None:
                 sync(dev)
+            # the rotary table of this length as well: the backbone's cache is cleared once it holds more than 16 lengths, so a
+            # length whose first two evaluations were serialised long ago may find its table gone -- and the null pass would then create
+            # it on the side stream while the conditional pass reads it from the cache on the caller's, unordered
+            rot = getattr(m.transformer, '_rot_table', None)
+            if rot is not None:
+                rot(x.shape[1] + m.transformer.num_registers, dev)
         key = (tuple(x.shape), exists(kwargs.get('text')), exists(kwargs.get('mask')), id(null_model), main.cuda_stream)
         seen = self._cfg_seen.get(key, 0)
         self._cfg_seen[key] = seen + 1

@@ -639,7 +639,11 @@ fuse_geglu_bwd = bool(int(_os.environ.get('E2K_FUSE_GEGLU_BWD', '1')))
 
 
 def can_fuse_geglu_bwd(M, F, K):
-    return bool(_lib.get().e2k_query_gemm_nt_geglu_bwd(int(M), int(F), int(K)))
+    """should FeedForward's backward take the fused launch?  Not where the library itself would not pick its 256 x 256 kernel for
+    this output (few tiles), nor under the A/B flags that take that kernel or its LDS-DMA staging away (E2K_GEMM_NO_T256 / NO_GLDS)"""
+    if gemm_flags & (1 | 256):
+        return False
+    return _lib.get().e2k_query_gemm_nt_geglu_bwd(int(M), int(F), int(K)) == 1
 
 
 def gemm_nt_geglu_bwd(dy, w2T, H, p_drop=0., seed=0, stream_id=0, seed_dev=None):

@@ -196,8 +196,9 @@ int e2k_query_gemm_nt_geglu(int M, int F, int K);
 /* FeedForward's second Linear in the backward pass with the GEGLU backward as the GEMM's epilogue (e2_tts.py:646,692,937; replaces
  * e2k_gemm_nt_bf16 for d(act) = dY W2 followed by e2k_geglu_bwd): dY (M, K = dim), W2T (F, K) = the transposed weight, H (M, 2F) the
  * stored pre-activation [u | g] -> dH (M, 2F) = [d(act) keep gelu(g) | d(act) keep u gelu'(g)]; d(act) itself is never written.
- * 256 x 256 kernel only: F % 256 == 0, K % 64 == 0, K >= 256 (e2k_query_gemm_nt_geglu_bwd returns 1 for shapes it takes, others are
- * refused with E2K_ERR_SHAPE); flags / ws / ws_bytes as e2k_gemm_nt_bf16, dropout arguments as e2k_geglu_bwd (same keep mask). */
+ * 256 x 256 kernel only: F % 256 == 0, K % 64 == 0, K >= 256 (e2k_query_gemm_nt_geglu_bwd: 1 = taken and recommended, 2 = taken, but the
+ * output has fewer 256 x 256 tiles than e2k_gemm_nt_bf16 asks for before it picks that kernel -- the two-launch pair is the better
+ * choice there --, 0 = refused with E2K_ERR_SHAPE); flags / ws / ws_bytes as e2k_gemm_nt_bf16, dropout arguments as e2k_geglu_bwd (same keep mask). */
 int e2k_gemm_nt_geglu_bwd_bf16(const void* dY, int64_t ldy, int K, const void* W2T, int64_t ldb, const void* H, int64_t ldh,
                                void* dH, int64_t lddh, int M, int F, float p_drop, uint32_t seed, const uint32_t* seed_dev,
                                uint32_t stream_id, int flags, float* ws, int64_t ws_bytes, void* stream);

@@ -41,7 +41,7 @@ def rel2(a, b):
 def _report(name, rec):
     out = ROOT / 'gpurun_out'
     if out.is_dir():
-        json.dump(rec, open(out / f'r05_parity_{name}.json', 'w'), indent=1)
+        json.dump(rec, open(out / f'r06_parity_{name}.json', 'w'), indent=1)
 
 
 def _pair(kw, init, seed=0):
@@ -61,12 +61,32 @@ def _pair(kw, init, seed=0):
         init_sd = {k: v.clone() for k, v in ref.state_dict().items()}
         randomize(ref)
         ref.load_state_dict({k: (init_sd[k] + 0.5 * (v - init_sd[k]) if v.is_floating_point() else v) for k, v in ref.state_dict().items()})
+    elif init == 'trained_like':
+        trained_like(ref)
     model = E2TTS(transformer=dict(**kw), use_vocos=False, cond_drop_prob=0.)
     model.load_state_dict(ref.state_dict(), strict=True)
     return ref, model.cuda()
 
 
-def _train_step_parity(name, kw, B, T, text, init, flow_limit=1e-2):
+def trained_like(model, seed=0):
+    """weight statistics of a checkpoint some way into training rather than of step 0 (round 6): every
+    zero-initialised projection at 0.02 randn -- the AdaLN-Zero gates with their bias moved from -2 to 0, i.e. opened to
+    sigma(0) = 0.5 from 0.12 --, everything that the reference initialises non-zero left as it is.  Milder than `half_randomized`
+    (which drives the residual streams to 9e3), and what the north-star tolerance is asserted on directly."""
+    g = torch.Generator().manual_seed(seed)
+    with torch.no_grad():
+        for name, p in model.named_parameters():
+            if name.endswith('to_gamma.weight') or 'text_to_audio' in name or 'audio_to_text' in name:
+                p.copy_(torch.randn(p.shape, generator=g) * 0.02)
+            elif name.endswith('to_gamma.bias'):
+                p.zero_()
+            elif 'dynamic_alpha_fn' in name or 'dynamic_beta_fn' in name:
+                p.copy_(torch.randn(p.shape, generator=g) * 0.02)
+            elif 'norm.gamma' in name:
+                p.copy_(torch.randn(p.shape, generator=g) * 0.02)
+
+
+def _train_step_parity(name, kw, B, T, text, init, flow_limit=1e-2, emulate=False):
     torch.set_num_threads(min(32, os.cpu_count() or 1))
     ref, model = _pair(kw, init)
     mel = torch.randn(B, T, 100)
@@ -80,7 +100,7 @@ def _train_step_parity(name, kw, B, T, text, init, flow_limit=1e-2):
     # north-star tolerance.  The north-star 1e-2 is asserted for the reference's own initialisation (the configuration
     # BASELINE.json names); the stress case is held to 1.3 x this emulation.
     e_emul, g_emul = None, None
-    if init == 'randomized':
+    if init == 'randomized' or emulate:
         from bf16_emulation import bf16_intermediates
         g_fp32 = {n: p.grad.clone() for n, p in ref.named_parameters() if p.grad is not None}
         ref.zero_grad(set_to_none=True)
@@ -116,11 +136,19 @@ def _train_step_parity(name, kw, B, T, text, init, flow_limit=1e-2):
     layer_rms_emul = {k: rms(v) for k, v in per_layer_emul.items()} if g_emul is not None else None
     rec = dict(case=name, init=init, kw=kw, B=B, T=T, loss=out.loss.item(), loss_ref=out_r.loss.item(), loss_rel=e_loss,
                pred_flow_rel_l2=e_flow, pred_flow_rel_l2_of_bf16_emulated_oracle=e_emul, weight_grad_rel_l2_by_layer=layer_rms,
-               weight_grad_rel_l2_by_layer_of_bf16_emulated_oracle=layer_rms_emul, worst=[(round(e, 4), n) for e, n in worst[:10]])
+               weight_grad_rel_l2_by_layer_of_bf16_emulated_oracle=layer_rms_emul, worst=[(round(e, 4), n) for e, n in worst[:10]],
+               worst_of_bf16_emulated_oracle=([(round(g_emul.get(n, 0.), 4), n) for _, n in worst[:10]] if g_emul is not None else None))
     _report(f'{name}_{init}', rec)
-    print(json.dumps({k: rec[k] for k in ('case', 'init', 'loss_rel', 'pred_flow_rel_l2')}), 'worst grads:', rec['worst'][:4])
+    print(json.dumps({k: rec[k] for k in ('case', 'init', 'loss_rel', 'pred_flow_rel_l2')}), 'worst grads:', rec['worst'][:4],
+          'emulation there:', (rec['worst_of_bf16_emulated_oracle'] or [])[:4])
     assert e_loss < 1e-2, e_loss
-    assert e_flow < (flow_limit if e_emul is None else max(1e-2, 1.3 * e_emul)), (e_flow, e_emul)
+    assert e_flow < (flow_limit if (e_emul is None or init != 'randomized') else max(1e-2, 1.3 * e_emul)), (e_flow, e_emul)
+    if emulate:
+        # every tensor that is more than 3 % off the fp32 oracle must be explained by what bf16 storage does to the ORACLE's own gradient of
+        # that tensor: at most 1.5 x the emulation's distance (+ 1 %).  At the reference's initialisation these are the zero-initialised
+        # (D, 5) hyper-connection projections: sums over all tokens of products with a tiny upstream gradient (9.7-12 % in round 5)
+        bad = [(round(e, 4), round(g_emul.get(n, 0.), 4), n) for e, n in worst if e > 0.03 and e > 1.5 * g_emul.get(n, 0.) + 0.01]
+        assert not bad, bad[:8]
     return rec
 
 
@@ -149,12 +177,19 @@ def test_cfg1_readme_exact(init):
     _check_grads(rec, init, (0.02, 0.05))            # measured on MI355X: 0.9 % per layer, worst matrix 1.2 %
 
 
-@pytest.mark.parametrize('init,B', [('reference_init', 1), ('reference_init', 2), ('half_randomized', 1), ('randomized', 1)])
+@pytest.mark.parametrize('init,B', [('reference_init', 1), ('reference_init', 2), ('half_randomized', 1), ('randomized', 1), ('trained_like', 1)])
 def test_cfg3_dims_depth24(init, B):
     text = ['The quick brown fox jumps over the lazy dog.', 'Pack my box with five dozen liquor jugs!'][:B]
-    rec = _train_step_parity('cfg3' if B == 1 else f'cfg3_B{B}', dict(dim=1024, depth=24, heads=16, dropout=0.), B, 1024, text, init)
+    # (round 6: the bf16-emulated oracle is also run at the reference's initialisation (B = 1) and for the trained-like weights, and the
+    #  worst tensors are held against it -- _train_step_parity)
+    rec = _train_step_parity('cfg3' if B == 1 else f'cfg3_B{B}', dict(dim=1024, depth=24, heads=16, dropout=0.), B, 1024, text, init,
+                             emulate=(B == 1 and init in ('reference_init', 'trained_like')))
     if init == 'half_randomized':
         assert rec['pred_flow_rel_l2'] < 1e-2, rec['pred_flow_rel_l2']       # off-init at depth 24: the north-star tolerance, asserted directly (measured 0.88 %)
+        return
+    if init == 'trained_like':
+        assert rec['pred_flow_rel_l2'] < 1e-2, rec['pred_flow_rel_l2']       # trained-like weight statistics: the north-star tolerance, asserted directly
+        assert max(rec['weight_grad_rel_l2_by_layer'].values()) < 0.03, rec['weight_grad_rel_l2_by_layer']
         return
     # measured on MI355X: 0.7-1.3 % per layer; the worst single tensor is the zero-initialised hyper-connection mixing
     # projection of the last layer (12 %: a (D, 5) sum over all tokens of products with a tiny gradient), every weight

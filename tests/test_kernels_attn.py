@@ -21,6 +21,11 @@ def rel(a, b):
     return ((a.float() - b.float()).abs().max() / b.float().abs().max().clamp_min(1e-20)).item()
 
 
+def rel2(a, b):
+    a, b = a.cpu().float(), b.cpu().float()
+    return ((a - b).norm() / b.norm().clamp_min(1e-20)).item()
+
+
 def hm(t, B, H, N):          # (B*N, H*64) token-major -> (B,H,N,64)
     return t.view(B, N, H, 64).permute(0, 2, 1, 3)
 
@@ -87,6 +92,9 @@ def test_attention(dev, N, has_vres, use_mask, qk_gain):
     kmask[:, :N] = 1 if mask is None else mask.to(torch.uint8)
     kmask = kmask.to(dev)
     Og = ops.attn_fwd(st, kmask)
+    # the north-star 1e-2 in rel-L2 (measured 0.42-0.51 %); largest single deviation against the largest output 2e-2 (0.5-0.8 %, 1.7 % with
+    # the logits far into the clamp)
+    assert rel2(Og.view(B, N, D), out) < 1e-2, rel2(Og.view(B, N, D), out)
     assert rel(Og.view(B, N, D), out) < 2e-2, rel(Og.view(B, N, D), out)
 
     dOg = R.reshape(B * N, D).to(bf16).to(dev)
@@ -107,9 +115,11 @@ def test_attention(dev, N, has_vres, use_mask, qk_gain):
     names = ['q', 'k', 'v', 'gate'] + (['mix'] if has_vres else [])
     for name, got, want in zip(names, dqkvg.float().cpu().split([I, I, I, H] + ([H] if has_vres else []), dim=-1),
                                ref.split([I, I, I, H] + ([H] if has_vres else []), dim=-1)):
-        assert rel(got, want) < 4e-2, (name, rel(got, want))
+        # (round 6: 4e-2 max-rel before.  Measured: rel-L2 0.45-0.88 %, largest single deviation 0.4-1.45 %)
+        assert rel2(got, want) < 1e-2, (name, rel2(got, want))
+        assert rel(got, want) < 2e-2, (name, rel(got, want))
     if has_vres:
-        assert rel(dvfirst, vres.grad) < 4e-2, rel(dvfirst, vres.grad)
+        assert rel2(dvfirst, vres.grad) < 1e-2 and rel(dvfirst, vres.grad) < 2e-2, (rel2(dvfirst, vres.grad), rel(dvfirst, vres.grad))
 
 
 @pytest.mark.parametrize('shape', ['two_key_tiles', 'ragged_small',
@@ -176,20 +186,24 @@ def test_attention_dropout(dev, shape, monkeypatch):
     kmask[:, :N] = 1 if mask is None else mask.to(torch.uint8)
     kmask = kmask.to(dev)
     Og = ops.attn_fwd(st, kmask, p, seed, sid)
+    # the north-star 1e-2 in rel-L2 (measured 0.42-0.51 %); largest single deviation against the largest output 2e-2 (0.5-0.8 %, 1.7 % with
+    # the logits far into the clamp)
+    assert rel2(Og.view(B, N, D), out) < 1e-2, rel2(Og.view(B, N, D), out)
     assert rel(Og.view(B, N, D), out) < 2e-2, rel(Og.view(B, N, D), out)
     dQ, dK, dV, dgate = ops.attn_bwd(st, R.reshape(B * N, D).to(bf16).to(dev), kmask, p, seed, sid)
     dqkvg = ops.qkv_post_bwd(st, dQ, dK, dV, dgate, qd, cosb, sinb)
     errs = {}
     for name, got, want in zip('qkvg', dqkvg.float().cpu().split([I, I, I, H], dim=-1), cols.grad.split([I, I, I, H], dim=-1)):
         errs[name] = rel(got, want)
-        assert errs[name] < 4e-2, (name, errs)
+        assert rel2(got, want) < 1e-2, (name, rel2(got, want))             # (round 6: north-star rel-L2 directly; 4e-2 max-rel before)
+        assert errs[name] < 2e-2, (name, errs)
     if shape.startswith('bench'):
         import json
         from pathlib import Path
         out_dir = Path(__file__).resolve().parent.parent / 'gpurun_out'
         if out_dir.is_dir():
             json.dump(dict(case=shape, B=B, H=H, N=N, p=p, lens=lens, out_rel_max=rel(Og.view(B, N, D), out), grad_rel_max=errs),
-                      open(out_dir / f'r05_parity_attn_dropout_{shape}.json', 'w'), indent=1)
+                      open(out_dir / f'r06_parity_attn_dropout_{shape}.json', 'w'), indent=1)
 
 
 @pytest.mark.parametrize('N', [70, 150])

@@ -40,39 +40,42 @@ def rel(a, b):
     return ((a.float() - b.float()).abs().max() / b.float().abs().max().clamp_min(1e-20)).item()
 
 
-def _ok(got, want, D=1024):
-    if got.numel() == 1:        # heavily cancelling sums of bf16-rounded terms: absolute slack
-        return abs(got.item() - want.item()) <= 0.15 * abs(want.item()) + 1.5
-    if got.numel() <= 32 and D > 1024:      # the 4 / 20 static gradients are sums over D * tokens bf16 products: noise ~ sqrt(D)
-        return rel(got, want) < 5e-2
-    return rel(got, want) < 3e-2
+def _rms(v):
+    return (sum(x * x for x in v) / len(v)) ** 0.5
 
 
-@pytest.mark.parametrize('D', [128, 256, 512, 768, 1024, 1536, 2048])
-def test_hc_chain(dev, D):
+def _chain(dev, D, seed_x, hc1, hc2, Mtok=37):
+    """width1 ; depth1 + width2 ; depth2 on the kernels, the same chain on the fp32 oracle (autograd) and on the oracle with bf16
+    intermediates (tests/bf16_emulation.py: the hyper-connection inputs / outputs and the gradients flowing back through them are
+    rounded to bf16 where a bf16 implementation stores them).  Returns forward outputs and the three sets of gradients."""
     from e2_tts_pytorch_amd import ops
-    Mtok = 37
-    hc1, hc2 = _mk_hc(D, 1), _mk_hc(D, 2)
-    torch.manual_seed(3)
+    from bf16_emulation import RoundBoth, bf16_intermediates
+    torch.manual_seed(seed_x)
     X = torch.randn(Mtok, 4, D).to(bf16)
     to = lambda t: t.to(dev)
     Wl = torch.randn(Mtok, 4, D)
     f1 = lambda t: torch.tanh(t) * 1.5
     f2 = lambda t: torch.sin(t) + 0.1 * t
 
-    # ---- oracle chain (fp32, autograd)
-    Xr = X.float().clone().requires_grad_(True)
-    xr = _to_ref_layout(Xr)
-    b1, add1 = hc1(xr)
-    y1r = f1(b1)
-    x2 = add1(y1r)
-    b2, add2 = hc2(x2)
-    y2r = f2(b2)
-    x3 = add2(y2r)
-    loss = (_from_ref_layout(x3) * Wl).sum()
-    loss.backward()
+    def oracle(rnd):
+        for h in (hc1, hc2):
+            for q in _params(h):
+                q.grad = None
+        Xr = X.float().clone().requires_grad_(True)
+        b1, add1 = hc1(_to_ref_layout(Xr))
+        x2 = add1(rnd(f1(b1)))
+        b2, add2 = hc2(x2)
+        x3 = add2(rnd(f2(b2)))
+        # (the kernels are handed the upstream gradient in bf16: the emulation rounds it too, the fp32 oracle does not)
+        (_from_ref_layout(x3) * (Wl.to(bf16).float() if rnd is not ident else Wl)).sum().backward()
+        return dict(b1=b1[0].detach(), b2=b2[0].detach(), x3=_from_ref_layout(x3).detach(), dX=Xr.grad,
+                    g1=[q.grad.clone() for q in _params(hc1)], g2=[q.grad.clone() for q in _params(hc2)])
 
-    # ---- kernels: width1 ; depth1+width2 ; depth2 (materialise)
+    ident = lambda t: t
+    ref = oracle(ident)
+    with bf16_intermediates():
+        emu = oracle(RoundBoth.apply)
+
     p1 = [to(t.detach()) for t in _params(hc1)]
     p2 = [to(t.detach()) for t in _params(hc2)]
     Xd = to(X)
@@ -81,10 +84,6 @@ def test_hc_chain(dev, D):
     M2, bin2, c2 = ops.hc_fwd(M1, p2, yprev=y1, coef_prev=c1)
     y2 = f2(bin2.float()).to(bf16)
     X3, _, _ = ops.hc_fwd(M2, None, yprev=y2, coef_prev=c2, width=False)
-    assert rel(bin1.cpu(), b1[0]) < 2e-2 and rel(bin2.cpu(), b2[0]) < 2e-2
-    assert rel(X3.cpu(), _from_ref_layout(x3)) < 2e-2
-
-    # ---- backward
     g1 = [torch.zeros_like(t) for t in p1]
     g2 = [torch.zeros_like(t) for t in p2]
     dX3 = to(Wl.to(bf16))
@@ -97,8 +96,45 @@ def test_hc_chain(dev, D):
     f1(b1k).backward(dy1.float())
     dbin1 = b1k.grad.to(bf16)
     dX, _ = ops.hc_bwd(dM1, xin=Xd, dbin=dbin1, ycur=y1, coef=c1, params=p1, grads=g1)
-    assert rel(dX.cpu(), Xr.grad) < 3e-2, rel(dX.cpu(), Xr.grad)
-    for name, gk, pr in zip(ops.HC_PARAM_NAMES, g2, _params(hc2)):
-        assert _ok(gk.cpu(), pr.grad, D), (name, 2, gk, pr.grad)
-    for name, gk, pr in zip(ops.HC_PARAM_NAMES, g1, _params(hc1)):
-        assert _ok(gk.cpu(), pr.grad, D), (name, 1, gk, pr.grad)
+    ker = dict(b1=bin1.cpu().float(), b2=bin2.cpu().float(), x3=X3.cpu().float(), dX=dX.cpu().float(),
+               g1=[g.cpu() for g in g1], g2=[g.cpu() for g in g2])
+    return ref, emu, ker
+
+
+@pytest.mark.parametrize('D', [128, 256, 512, 768, 1024, 1536, 2048])
+def test_hc_chain(dev, D):
+    """Outputs and input gradients against the fp32 oracle at bf16 resolution; PARAMETER gradients -- sums over every token of
+    products of bf16-rounded operands, the scalar ones heavily cancelling -- against what bf16 storage does to the ORACLE ITSELF
+    (round 6, replaces an absolute slack of 0.15 |want| + 1.5 on the scalars): over three input draws and both hyper-connections
+    of the chain, the kernels' distance from the fp32 gradient may be at most 1.5 x the bf16-emulated oracle's distance (root mean
+    square over the six cases; no single case beyond 3.5 x that scale; measured: 0.2-1.1 x, i.e. the kernels are CLOSER to fp32 than the
+    emulation -- they keep the coefficients and the reductions in fp32)."""
+    from e2_tts_pytorch_amd import ops
+    hc1, hc2 = _mk_hc(D, 1), _mk_hc(D, 2)
+    dk = {n: [] for n in ops.HC_PARAM_NAMES}
+    de = {n: [] for n in ops.HC_PARAM_NAMES}
+    mg = {n: [] for n in ops.HC_PARAM_NAMES}
+    for seed_x in (3, 4, 5):
+        ref, emu, ker = _chain(dev, D, seed_x, hc1, hc2)
+        assert rel(ker['b1'], ref['b1']) < 2e-2 and rel(ker['b2'], ref['b2']) < 2e-2
+        assert rel(ker['x3'], ref['x3']) < 2e-2
+        assert rel(ker['dX'], ref['dX']) < 3e-2, rel(ker['dX'], ref['dX'])
+        # the input gradient too is no further from fp32 than bf16 storage puts the oracle (rel-L2, 1.5 x)
+        l2 = lambda a, b: ((a - b).norm() / b.norm()).item()
+        assert l2(ker['dX'], ref['dX']) <= 1.5 * l2(emu['dX'], ref['dX']) + 1e-4, (l2(ker['dX'], ref['dX']), l2(emu['dX'], ref['dX']))
+        for which in ('g1', 'g2'):
+            for name, gk, ge, gr in zip(ops.HC_PARAM_NAMES, ker[which], emu[which], ref[which]):
+                dk[name].append((gk - gr).norm().item())
+                de[name].append((ge - gr).norm().item())
+                mg[name].append(gr.norm().item())
+    # relative distances (norm of the deviation / norm of the fp32 gradient, root mean square over the six cases).  A scalar parameter gives
+    # six one-number samples -- a noisy estimate of its own emulation scale -- so the bound for a parameter is the larger of ITS emulation
+    # distance and the root mean square of the seven parameters' emulation distances
+    rk = {n: _rms(dk[n]) / _rms(mg[n]) for n in ops.HC_PARAM_NAMES}
+    re = {n: _rms(de[n]) / _rms(mg[n]) for n in ops.HC_PARAM_NAMES}
+    pooled = _rms(list(re.values()))
+    for name in ops.HC_PARAM_NAMES:
+        scale = max(re[name], pooled)
+        assert rk[name] <= 1.5 * scale, (name, D, 'rms', rk[name], re[name], pooled)
+        assert max(dk[name]) / _rms(mg[name]) <= 3.5 * scale, (name, D, 'max', dk[name], de[name])
+        assert rk[name] < 3e-2, (name, D, rk[name])          # and in absolute terms: bf16 resolution of a well-scaled sum
