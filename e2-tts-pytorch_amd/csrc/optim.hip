@@ -216,7 +216,33 @@ __global__ __launch_bounds__(256) void grad_unpack_kernel(const bf16_t* __restri
         for (long i = nv * 8 + threadIdx.x; i < n; i += 256) g[i] = bf2f(wire[i]);
 }
 
+// bf16 wire, fp32 sum (ddp._GradSync wire_fp32_sum): after the all-to-all a rank holds `world` copies of ITS shard, one per peer, as rows
+// of (world, per) bf16; out[i] = bf16(sum_r float(recv[r][i])) -- the sum accumulated in fp32 in rank order, ONE rounding
+__global__ __launch_bounds__(256) void shard_sum_kernel(const bf16_t* __restrict__ recv, bf16_t* __restrict__ out, long per, int world) {
+    const long nv = per >> 3, stride = (long)gridDim.x * 256;
+    for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < nv; i += stride) {
+        float acc[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+        for (int r = 0; r < world; ++r) {
+            float f[8];
+            unpack8(ld<u32x4>(recv + (long)r * per + i * 8), f);
+#pragma unroll
+            for (int e = 0; e < 8; ++e) acc[e] += f[e];
+        }
+        st<u32x4>(out + i * 8, pack8(acc));
+    }
+}
+
 }  // namespace
+
+static int shard_sum_impl(const void* recv, void* out, int64_t per, int world, void* stream) {
+    if (per <= 0 || world <= 0) return 0;
+    if (!recv || !out) return E2K_ERR_ARG;
+    if ((per & 7) || (((uintptr_t)recv | (uintptr_t)out) & 15)) return E2K_ERR_ALIGN;
+    long gr = (per / 8 + 255) / 256; if (gr > 512) gr = 512; if (gr < 1) gr = 1;          // (a modest grid, as grad_pack: it runs NEXT to the backward pass)
+    hipLaunchKernelGGL(shard_sum_kernel, dim3((int)gr), dim3(256), 0, (hipStream_t)stream, (const bf16_t*)recv, (bf16_t*)out, (long)per, world);
+    E2K_CHECK_LAUNCH();
+    return 0;
+}
 
 static int sumsq_f32_impl(const float* x, int64_t n, double* out, void* stream) {
     if (n <= 0) return 0;
@@ -312,4 +338,8 @@ extern "C" int e2k_grad_pack_bf16(const float* g, void* wire, int64_t n, float s
 
 extern "C" int e2k_grad_unpack_bf16(const void* wire, float* g, int64_t n, void* stream) {
     return e2k::dispatch("grad_unpack_bf16", grad_unpack_impl, wire, g, n, stream);
+}
+
+extern "C" int e2k_shard_sum_bf16(const void* recv_bf16, void* out_bf16, int64_t per, int world, void* stream) {
+    return e2k::dispatch("shard_sum_bf16", shard_sum_impl, recv_bf16, out_bf16, per, world, stream);
 }

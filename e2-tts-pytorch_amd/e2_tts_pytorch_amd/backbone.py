@@ -378,7 +378,7 @@ class Transformer(Module):
     # runtime state (device buffers, caches, recorded plans): never part of the module's identity -- a deep copy (the
     # trainer's EMA, trainer.py:170) starts without it and rebuilds its own on first use
     _RUNTIME = ('_flat', '_shadow', '_shadowT', '_shadow_key', '_tdesc', '_vcache', '_rot_cache', '_plans', '_pg', '_no_pgrads', '_lane_ss',
-                '_text_ids', '_text_live_handle')
+                '_text_ids', '_text_live_handle', '_text_live_pending', '_text_grad_live_v')
 
     def _reset_runtime(self):
         self._flat = None
@@ -726,15 +726,43 @@ class Transformer(Module):
         begin = getattr(tgt, 'begin_text_live', None)
         return begin(has_text, dev) if begin is not None else bool(has_text)
 
+    # `_text_grad_live` is read where the optimizer decides (optim.FusedAdopt.step), not where the backward pass starts: with more than
+    # one rank the answer is a word an all-reduce left in pinned host memory (ddp._GradSync.begin_text_live), and waiting for it at the
+    # START of the backward pass (rounds 3-5) stopped the host until the device had reached this pass's forward, i.e. it capped the
+    # host's run-ahead at one forward pass per step.  The handles are parked here and resolved on the first READ of the flag.
+    @property
+    def _text_grad_live(self):
+        d = self.__dict__
+        pend = d.get('_text_live_pending')
+        if pend:
+            v = d.get('_text_grad_live_v')
+            for tgt, h in pend:
+                v = bool(tgt.end_text_live(h)) or bool(v)
+            d['_text_grad_live_v'] = v
+            pend.clear()
+        return d.get('_text_grad_live_v')
+
+    @_text_grad_live.setter
+    def _text_grad_live(self, v):
+        self.__dict__['_text_grad_live_v'] = v
+        self.__dict__.pop('_text_live_pending', None)
+
     def _end_text_live(self, handle, has_text):
-        """-> the text stream's parameters received a gradient in this backward pass (on some rank); also ORed into
-        `_text_grad_live`, which the fused optimizer reads and resets once per step"""
+        """the text stream's parameters received a gradient in this backward pass (on some rank): ORed into `_text_grad_live`, which
+        the fused optimizer reads and resets once per step.  -> the flag where it is known without waiting (single rank, host model),
+        None where it is still on its way"""
         live = bool(has_text)
         if handle is not None and not isinstance(handle, bool):
-            live = self._sync_target().end_text_live(handle)
-        elif isinstance(handle, bool):
-            live = handle
-        self._text_grad_live = bool(getattr(self, '_text_grad_live', None)) or live
+            self.__dict__.setdefault('_text_live_pending', []).append((self._sync_target(), handle))
+            live = None
+        else:
+            if isinstance(handle, bool):
+                live = handle
+            d = self.__dict__
+            if d.get('_text_live_pending'):
+                d['_text_live_pending'].append((_KnownLive, live))
+            else:
+                d['_text_grad_live_v'] = bool(d.get('_text_grad_live_v')) or live
         # Is that flag a GLOBAL fact?  Only when our own gradient exchange computed it (ddp._GradSync.begin_text_live).  Under a stock
         # DistributedDataParallel without the shim it is this rank's own coin: optim.FusedAdopt then makes it global itself (one MAX
         # all-reduce per optimizer step) before it decides to skip the text stream's parameters -- or the replicas drift apart
@@ -1654,6 +1682,13 @@ def _numel(shape):
     for s in shape:
         n *= s
     return n
+
+
+class _KnownLive:
+    """a text-live answer that needed no exchange, queued behind pending ones (Transformer._text_grad_live)"""
+    @staticmethod
+    def end_text_live(v):
+        return v
 
 
 class _PlanState(NS):

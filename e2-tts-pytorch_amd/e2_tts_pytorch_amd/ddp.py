@@ -57,6 +57,7 @@ class _GradSync:
         self.bytes = 0
         self._pending = None          # (start, end, layers) of the slabs merged so far
         self._wire = None             # bf16 wire buffer, grown to the largest slab seen (slabs are serialised on the side stream)
+        self._recv = self._mine = None    # wire_fp32_sum: receive buffer (world copies of this rank's shard) and the summed shard
         be = dist.get_backend(group)
         self._avg = dist.ReduceOp.AVG if be == 'nccl' else None      # RCCL averages on the links; gloo (CPU tests) only sums
 
@@ -71,12 +72,16 @@ class _GradSync:
                 if slab.is_cuda or ops.host_ok():
                     # one HIP pass each way through a preallocated wire buffer (no tensor-library temporaries on the side
                     # stream): pre-divided in fp32, rounded to bf16, summed by RCCL in bf16, widened back into the slab
-                    if self._wire is None or self._wire.numel() < slab.numel() or self._wire.device != slab.device:
-                        self._wire = torch.empty(slab.numel(), dtype=torch.bfloat16, device=slab.device)
+                    # (wire_fp32_sum: the buffer is a whole number of 8-element-aligned shards, so that the all-to-all needs no padded copy)
+                    per = self._shard_len(slab.numel())
+                    need = per * self.world if self.wire_fp32_sum else slab.numel()
+                    if self._wire is None or self._wire.numel() < need or self._wire.device != slab.device:
+                        self._wire = torch.empty(need, dtype=torch.bfloat16, device=slab.device)
+                        self._recv = self._mine = None
                     buf = self._wire[:slab.numel()]
                     ops.grad_pack_bf16(slab, buf, 1.0 / self.world)
                     if self.wire_fp32_sum and self.world > 1:
-                        buf = self._sum_fp32(buf)
+                        buf = self._sum_fp32(buf, kernels=True)
                     else:
                         dist.all_reduce(buf, op=dist.ReduceOp.SUM, group=self.group)
                     ops.grad_unpack_bf16(buf, slab)
@@ -105,10 +110,31 @@ class _GradSync:
         else:
             run()
 
-    def _sum_fp32(self, buf):
+    def _shard_len(self, n):
+        """elements per rank of a slab of n elements: rounded up to 8 (the kernels move 16 bytes per lane)"""
+        per = (n + self.world - 1) // self.world
+        return (per + 7) // 8 * 8
+
+    def _sum_fp32(self, buf, kernels=False):
         """bf16 wire, fp32 sum: all-to-all of the world's shards, local fp32 sum of this rank's shard, one rounding, all-gather.
-        -> a bf16 tensor of buf's length holding the sum (identical on every rank)"""
+        -> a bf16 tensor of buf's length holding the sum (identical on every rank).  kernels: `buf` is the head of the preallocated
+        wire buffer (per * world elements): no temporaries -- receive and shard buffers are kept, sized to the largest slab (round 6:
+        five slab-sized allocations per slab on the exchange stream before), and the sum is one e2k_shard_sum_bf16 pass"""
         w, n = self.world, buf.numel()
+        if kernels:
+            from . import ops
+            per = self._shard_len(n)
+            send = self._wire[:per * w]
+            if per * w > n:
+                send[n:].zero_()                   # (the pad of the last shard: a handful of elements)
+            if self._recv is None or self._recv.numel() < per * w:
+                self._recv = torch.empty(self._wire.numel(), dtype=torch.bfloat16, device=buf.device)
+                self._mine = torch.empty((self._wire.numel() // w + 7) // 8 * 8, dtype=torch.bfloat16, device=buf.device)
+            recv, mine = self._recv[:per * w], self._mine[:per]
+            dist.all_to_all_single(recv, send, group=self.group)      # recv[r * per : (r + 1) * per] = rank r's copy of MY shard
+            ops.shard_sum_bf16(recv, mine, w)
+            dist.all_gather_into_tensor(send, mine, group=self.group)  # the wire buffer takes the result: send is consumed by then
+            return send[:n]
         per = (n + w - 1) // w
         send = buf if per * w == n else torch.cat([buf, buf.new_zeros(per * w - n)])
         recv = torch.empty_like(send)

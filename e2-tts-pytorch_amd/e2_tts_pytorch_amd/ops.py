@@ -1144,6 +1144,14 @@ def grad_unpack_bf16(wire, g):
     _lib.get().e2k_grad_unpack_bf16(_p(wire), _p(g), g.numel(), _stream(g))
 
 
+def shard_sum_bf16(recv, out, world):
+    """out[i] = bf16(sum_r float(recv[r * per + i])), per = out.numel(): fp32 sum of the peers' copies of this rank's shard"""
+    _chk(recv, out)
+    per = out.numel()
+    assert recv.dtype == bf16 and out.dtype == bf16 and recv.is_contiguous() and out.is_contiguous() and recv.numel() == per * world and per % 8 == 0
+    _lib.get().e2k_shard_sum_bf16(_p(recv), _p(out), per, int(world), _stream(out))
+
+
 def cfg_combine(pred, null_pred, cfg_strength, keep_parallel_frac=0., remove_parallel=True):
     """pred + cfg_update * cfg_strength with the fp64 parallel-component projection of e2_tts.py:113-124,1303-1330 in one
     kernel; pred / null_pred (B, ...) fp32 contiguous"""

@@ -363,6 +363,10 @@ int e2k_ema_update(float* ema, const float* p, int64_t n, float decay, void* str
  * the all-reduce.  One pass each, 16-byte aligned pointers. */
 int e2k_grad_pack_bf16(const float* g, void* wire_bf16, int64_t n, float scale, void* stream);
 int e2k_grad_unpack_bf16(const void* wire_bf16, float* g, int64_t n, void* stream);
+/* The same exchange with fp32 accumulation (one rounding instead of world - 1; the reference's reducer sums fp32 gradients,
+ * trainer.py:155-162): after an all-to-all of the slab's shards a rank holds (world, per) bf16 = every peer's copy of its shard;
+ * out[i] = bf16(sum over r of float(recv[r][i])), summed in rank order.  per a multiple of 8, 16-byte aligned pointers. */
+int e2k_shard_sum_bf16(const void* recv_bf16, void* out_bf16, int64_t per, int world, void* stream);
 
 
 /* ---- launch plans: the native scheduler of the backbone (csrc/plan.h) ----

@@ -87,6 +87,20 @@ def _worker(rank, world, port, emu_lib, q):
                 bad_s.append((n + ' (stock DDP + shim, bf16 slabs)', err))
     assert hook.calls >= 2 and any(n.startswith('transformer.') for n in model._ddp_params_and_buffers_to_ignore)
     bad_p += bad_s
+    # round 6: the wrapper with bucket_layers = 2 AND defer = True (ONE collective over everything the backward covered, issued at the
+    # flush), bf16 wire: same averaged gradients, exactly one slab collective
+    del stock
+    tr._grad_sync = None
+    model.zero_grad(set_to_none=True)
+    net2 = DataParallel(model, broadcast_from=None, grad_dtype=torch.bfloat16, bucket_layers=2, defer=True)
+    net2(mels[rank], text=['hello'], _noise=noises[rank]).loss.backward()
+    assert net2._sync.calls == 1, net2._sync.calls
+    for n, p in model.named_parameters():
+        if n in grads:
+            g = grads[n]
+            err = ((p.grad - g).norm() / g.norm().clamp_min(1e-12)).item() if float(g.norm()) > 0 else float(p.grad.norm())
+            if err > (1e-2 if p.numel() > 1 else 1e-1):
+                bad_p.append((n + ' (bucket_layers 2 + defer, bf16 slab)', err))
     if rank == 0:
         # single-process reference with the broadcast weights: mean over both "ranks" of the per-sample gradients
         ref = E2TTS(transformer=dict(dim=256, depth=2, heads=4, dropout=0.), use_vocos=False, cond_drop_prob=0.)
@@ -111,14 +125,29 @@ def _worker(rank, world, port, emu_lib, q):
     dist.destroy_process_group()
 
 
-def _sum_worker(rank, world, port, q):
+def _sum_worker(rank, world, port, q, emu_lib=None):
     sys.path[:0] = [str(ROOT / 'e2-tts-pytorch_amd'), str(ROOT), str(ROOT / 'tests')]
-    os.environ.update(MASTER_ADDR='127.0.0.1', MASTER_PORT=str(port))
+    os.environ.update(MASTER_ADDR='127.0.0.1', MASTER_PORT=str(port), E2K_EMU_THREADS='1')
     torch.set_num_threads(1)
     dist.init_process_group('gloo', rank=rank, world_size=world)
     from e2_tts_pytorch_amd.ddp import _GradSync
     sync = _GradSync(None, torch.bfloat16, 1, wire_fp32_sum=True)
     bad = []
+    if emu_lib is not None:
+        # the product path of the same exchange (round 6): pack kernel -> preallocated wire buffer of whole 8-aligned shards -> all-to-all ->
+        # e2k_shard_sum_bf16 -> all-gather into the wire buffer -> unpack kernel; slabs of three lengths through ONE _GradSync (the buffers
+        # are kept and sized to the largest), the largest first and last
+        install_lib(emu_lib, host_pointers=True)
+        for n in (4099, 1001, 24, 4099):
+            gs = [torch.randn(n + 16, generator=torch.Generator().manual_seed(7 * n + r)) * 3 for r in range(world)]
+            g = gs[rank].clone()
+            sync._reduce(g, 8, 8 + n)
+            want = sum((x[8:8 + n] * (1.0 / world)).to(torch.bfloat16).float() for x in gs).to(torch.bfloat16).float()
+            if not torch.equal(g[8:8 + n], want):
+                bad.append((n, 'kernel path: slab differs from the once-rounded fp32 sum of the pre-divided bf16 slabs'))
+            if not (torch.equal(g[:8], gs[rank][:8]) and torch.equal(g[8 + n:], gs[rank][8 + n:])):
+                bad.append((n, 'kernel path: wrote outside the slab'))
+        assert sync._recv is not None and sync._wire.numel() >= 4099
     for n in (1001, 3 * 512, 5):                       # a length the world size does not divide, one it does, one shorter than a shard row
         bufs = [(torch.randn(n, generator=torch.Generator().manual_seed(10 * n + r)) * 3).to(torch.bfloat16) for r in range(world)]
         got = sync._sum_fp32(bufs[rank].clone())
@@ -135,14 +164,14 @@ def _sum_worker(rank, world, port, q):
     dist.destroy_process_group()
 
 
-def test_wire_fp32_sum_rounds_once():
+def test_wire_fp32_sum_rounds_once(emu_lib):
     """ddp._GradSync._sum_fp32 (wire_fp32_sum=True; replaces the bf16 all-reduce of the gradient slabs, trainer.py:155-162): bf16 on the
     wire, fp32 accumulation -- the result is bit for bit the fp32 sum of the ranks' bf16 slabs rounded ONCE, on every rank, also when the
     world size does not divide the slab.  3 ranks, gloo."""
     ctx = mp.get_context('spawn')
     q = ctx.Queue()
     port = 31500 + os.getpid() % 2000
-    procs = [ctx.Process(target=_sum_worker, args=(r, 3, port, q)) for r in range(3)]
+    procs = [ctx.Process(target=_sum_worker, args=(r, 3, port, q, str(emu_lib))) for r in range(3)]
     for p in procs:
         p.start()
     res = [q.get(timeout=300) for _ in procs]
