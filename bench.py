@@ -83,7 +83,7 @@ def _lane_ms(rows, nprof):
         return {'error': repr(e)}
 
 
-def host_launch_floor(depth, dev, dropout):
+def host_launch_floor(depth, dev, dropout, graphs=None):
     """host time per training step when the GPU is NOT the bottleneck: the same depth (= the same number of recorded
     launches per step) at a tiny width / batch / length, so that the kernels are negligible.  `host_enqueue_ms_per_step`
     of the real workload cannot show this: once the HIP queue is full the enqueuing thread blocks until the GPU frees a
@@ -92,6 +92,8 @@ def host_launch_floor(depth, dev, dropout):
     m = E2TTS(transformer=dict(dim=256, depth=depth, heads=4, dropout=dropout), use_vocos=False, cond_drop_prob=0.).to(dev).train()
     tr = m.transformer
     tr.enable_persistent_grads()
+    if graphs is not None:
+        tr.enable_graphs(graphs)
     flat = {id(q) for q, _ in tr._layout.slots}
     rest = [p for p in m.parameters() if id(p) not in flat]
     mel, text = torch.randn(1, 96, 100, device=dev), ['launch floor']
@@ -110,7 +112,7 @@ def host_launch_floor(depth, dev, dropout):
     t_host = time.perf_counter() - t0
     torch.cuda.synchronize()
     t_all = time.perf_counter() - t0
-    return {'host_ms_per_step': t_host / n * 1e3, 'wall_ms_per_step': t_all / n * 1e3,
+    return {'host_ms_per_step': t_host / n * 1e3, 'wall_ms_per_step': t_all / n * 1e3, 'graphs': bool(tr._graphs_on),
             'probe': f'E2TTS(dim=256, depth={depth}, heads=4), B=1, T=96: same launches per step, negligible kernel time'}
 
 
@@ -224,6 +226,8 @@ def main():
     ap.add_argument('--ddp-defer', action='store_true', help='one gradient all-reduce after the backward pass instead of per-layer slabs overlapped with it (A/B)')
     ap.add_argument('--no-optimizer-leg', action='store_true', help='skip the extra leg that times the step WITH the fused gradient clip + '
                     'ADOPT update (+ EMA) after the headline measurement (N = 1 only; it never enters `value`)')
+    ap.add_argument('--graphs', type=int, default=None, choices=[0, 1], help='replay the recorded plans as HIP graphs (Transformer.enable_graphs; '
+                    'default: the package default / E2K_GRAPH)')
     ap.add_argument('--no-warm-leg', action='store_true', help='skip ms_per_step_warm (>= --warm-seconds of load, then K event-timed steps)')
     ap.add_argument('--warm-seconds', type=float, default=10.0)
     ap.add_argument('--main-cus', default=None, help='first:count -- run the step on a HIP stream confined to these CUs '
@@ -273,6 +277,8 @@ def main():
 
     tr = model.transformer
     tr.enable_plans(not args.eager)
+    if args.graphs is not None:
+        tr.enable_graphs(bool(args.graphs))
     params = list(model.parameters())
     if not args.autograd_grads:
         tr.enable_persistent_grads()
@@ -290,8 +296,11 @@ def main():
         a, n = (int(v) for v in args.main_cus.split(':'))
         torch.cuda.set_stream(ops.cu_masked_stream(dev, a, n))
 
-    launch_mode_note = 'eager launches from Python (--eager)' if args.eager else \
-        'recorded launch plan re-issued from C++ (e2k_plan_run; eager stream launches, no HIP graph)'
+    graphs_on = bool(getattr(tr, '_graphs_on', False)) and not args.eager
+    launch_mode_note = 'eager launches from Python (--eager)' if args.eager else (
+        'recorded launch plan replayed as ONE HIP graph per pass (e2k_plan_graph_launch; with a gradient exchange the backward pass stays on '
+        'the segmented eager replay)' if graphs_on else
+        'recorded launch plan re-issued from C++ (e2k_plan_run; eager stream launches, no HIP graph)')
     # a signature is recorded the second time it is seen (forward) and at its first backward; do that outside the W
     # warm-up steps so that even --warmup 0 times replayed steps only
     step()
@@ -444,7 +453,8 @@ def main():
         }
         if world == 1 and not args.eager and not args.no_launch_floor:      # (rank 0 alone would keep the other ranks waiting)
             try:
-                res['host_launch_floor'] = host_launch_floor(depth, dev, args.dropout)
+                res['host_launch_floor'] = host_launch_floor(depth, dev, args.dropout, graphs=graphs_on)
+                res['host_launch_floor_other_mode'] = host_launch_floor(depth, dev, args.dropout, graphs=not graphs_on)
             except Exception as e:      # noqa: BLE001
                 res['host_launch_floor'] = {'error': repr(e)}
         if world == 1 and not args.eager and not args.no_optimizer_leg:

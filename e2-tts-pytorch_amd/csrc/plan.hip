@@ -134,6 +134,93 @@ extern "C" int e2k_plan_run_lanes(int plan, int first, int count, void** streams
     return 0;
 }
 
+// ---- HIP-graph form of a replay (round 6) -------------------------------------------------------------------------------------------
+// e2k_plan_run_lanes issues ~1600 launches + ~1200 event operations per cfg3 step from the host: 34 ms of host time (21 us per recorded
+// launch), which is the step of the dim-512 configuration (cfg2: 11.3 of 14.1 ms) and the floor under every future kernel gain.  A range
+// of a plan that no other stream has to interleave with (a forward; a backward when no gradient exchange is installed) is captured ONCE
+// -- the very same replay loop under hipStreamBeginCapture: lane 0 is the capturing stream, the side lanes are forked from it before the
+// first call and joined back after the last, the recorded ordering points become graph edges -- and re-issued with one hipGraphLaunch.
+// The eager replay stays the path of the backward segments between which the RCCL exchange stream interleaves.
+namespace {
+struct PlanGraph { hipGraph_t graph = nullptr; hipGraphExec_t exec = nullptr; };
+std::vector<std::unique_ptr<PlanGraph>> g_graphs;      // handle = index + 1 (g_mu)
+}  // namespace
+
+extern "C" int e2k_query_plan_graph_capture(int plan, int first, int count, void** streams_host, int nstreams) {
+    Plan* p = lookup(plan);
+    if (!p || !streams_host || nstreams < 1 || nstreams > PLAN_MAX_LANES) return -E2K_ERR_ARG;
+    if (plan_tls().recording) return -E2K_ERR_ARG;
+    // every event the replay loop may create lazily is created BEFORE the capture starts (object creation is not a stream operation)
+    for (void*& ev : p->events)
+        if (!ev) {
+            hipEvent_t e;
+            if (hipEventCreateWithFlags(&e, hipEventDisableTiming) != hipSuccess) return -1000;
+            ev = (void*)e;
+        }
+    hipEvent_t fork = nullptr, join[PLAN_MAX_LANES] = {nullptr, nullptr, nullptr, nullptr};
+    if (hipEventCreateWithFlags(&fork, hipEventDisableTiming) != hipSuccess) return -1000;
+    for (int k = 1; k < nstreams; ++k)
+        if (hipEventCreateWithFlags(&join[k], hipEventDisableTiming) != hipSuccess) return -1000;
+    hipStream_t main = (hipStream_t)streams_host[0];
+    int rc = 0;
+    hipGraph_t graph = nullptr;
+    if (hipStreamBeginCapture(main, hipStreamCaptureModeRelaxed) != hipSuccess) rc = 1001;
+    if (!rc) {
+        // fork: a side lane whose first recorded call has no ordering point in front of it would otherwise run OUTSIDE the capture
+        if (nstreams > 1) {
+            if (hipEventRecord(fork, main) != hipSuccess) rc = 1002;
+            for (int k = 1; k < nstreams && !rc; ++k)
+                if (hipStreamWaitEvent((hipStream_t)streams_host[k], fork, 0) != hipSuccess) rc = 1002;
+        }
+        if (!rc) rc = e2k_plan_run_lanes(plan, first, count, streams_host, nstreams);
+        // join: every lane's tail is an ancestor of the capture's end
+        for (int k = 1; k < nstreams && !rc; ++k) {
+            if (hipEventRecord(join[k], (hipStream_t)streams_host[k]) != hipSuccess) rc = 1003;
+            else if (hipStreamWaitEvent(main, join[k], 0) != hipSuccess) rc = 1003;
+        }
+        if (hipStreamEndCapture(main, &graph) != hipSuccess && !rc) rc = 1004;
+    }
+    (void)hipEventDestroy(fork);
+    for (int k = 1; k < nstreams; ++k) (void)hipEventDestroy(join[k]);
+    if (rc || !graph) {
+        if (graph) (void)hipGraphDestroy(graph);
+        return -(rc ? rc : 1004);
+    }
+    std::unique_ptr<PlanGraph> g(new PlanGraph());
+    g->graph = graph;
+    if (hipGraphInstantiate(&g->exec, graph, nullptr, nullptr, 0) != hipSuccess) {
+        (void)hipGraphDestroy(graph);
+        return -1005;
+    }
+    std::lock_guard<std::mutex> lk(g_mu);
+    for (size_t i = 0; i < g_graphs.size(); ++i)
+        if (!g_graphs[i]) { g_graphs[i] = std::move(g); return (int)i + 1; }
+    g_graphs.push_back(std::move(g));
+    return (int)g_graphs.size();
+}
+
+extern "C" int e2k_plan_graph_launch(int graph, void* stream) {
+    hipGraphExec_t ex = nullptr;
+    {
+        std::lock_guard<std::mutex> lk(g_mu);
+        if (graph <= 0 || graph > (int)g_graphs.size() || !g_graphs[graph - 1]) return E2K_ERR_ARG;
+        ex = g_graphs[graph - 1]->exec;
+    }
+    return hipGraphLaunch(ex, (hipStream_t)stream) == hipSuccess ? 0 : 1006;
+}
+
+extern "C" int e2k_plan_graph_free(int graph) {
+    std::unique_ptr<PlanGraph> g;
+    {
+        std::lock_guard<std::mutex> lk(g_mu);
+        if (graph <= 0 || graph > (int)g_graphs.size() || !g_graphs[graph - 1]) return E2K_ERR_ARG;
+        g = std::move(g_graphs[graph - 1]);
+    }
+    if (g->exec) (void)hipGraphExecDestroy(g->exec);
+    if (g->graph) (void)hipGraphDestroy(g->graph);
+    return 0;
+}
+
 extern "C" int e2k_plan_run(int plan, int first, int count, void* stream) {
     return e2k_plan_run_lanes(plan, first, count, &stream, 1);
 }

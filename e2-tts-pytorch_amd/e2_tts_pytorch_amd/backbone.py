@@ -389,6 +389,7 @@ class Transformer(Module):
         self._lane_mask = int(_os.environ.get('E2K_LANES', '3')) or 3   # bit 0: TEXT lane, bit 1: WGRAD lane (A/B, fault isolation)
         self._lanes_on = getattr(self, '_lanes_on', _os.environ.get('E2K_LANES', '3') != '0')      # enable_lanes(); E2K_LANES=0 turns them off
         self._lanes_bwd = getattr(self, '_lanes_bwd', _os.environ.get('E2K_LANES_BWD', '1') != '0')
+        self._graphs_on = getattr(self, '_graphs_on', _os.environ.get('E2K_GRAPH', '0') != '0')      # enable_graphs(): recorded plans replayed as HIP graphs
         self.__dict__.pop('_lane_ss', None)
         self._plans = {}
         self._plan_tick = 0
@@ -816,6 +817,24 @@ class Transformer(Module):
             self._drop_plans()
         return self
 
+    def enable_graphs(self, on: bool = True):
+        """Replay recorded plans as HIP graphs (E2K_GRAPH=1 / 0 in the environment presets it): a forward pass, and a backward pass
+        when no gradient exchange is installed, become ONE hipGraphLaunch each instead of ~800 launches + ~600 event operations
+        issued from the host (34 ms of host time per cfg3 step, 11.3 of the 14.1 ms of a cfg2 step).  The kernels, their arguments,
+        their order and the lanes' ordering points are those of the eager replay (the graph is captured FROM that replay loop), so
+        the results are bit-identical; with a gradient exchange installed (world > 1) the backward keeps the eager per-layer replay
+        between whose segments the exchange stream interleaves."""
+        if bool(on) != self._graphs_on:
+            for st in self._plans.values():
+                if isinstance(st, NS):
+                    for k in ('gfwd', 'gbwd'):
+                        h = st.__dict__.get(k)
+                        if h:
+                            st.__dict__[k] = None
+                            ops.lib().e2k_plan_graph_free(h)
+        self._graphs_on = bool(on)
+        return self
+
     def enable_lanes(self, on: bool = True, backward: bool | None = None):
         """Launch lanes (default: on; E2K_LANES=0 in the environment turns them off, E2K_LANES_BWD=0 only those of the
         backward pass): the text stream's branches run on a side stream next to the audio stream's chain and the
@@ -918,7 +937,7 @@ class Transformer(Module):
 
     def _plan_new(self, key, x, cond, text_embed, mask, need_grad, p_drop):
         dev = x.device
-        st = _PlanState(key=key, need_grad=need_grad, fwd=None, bwd=None, segs=None, outstanding=False, used=0, keep=[], meta_f=[], meta_b=[], pool=None)
+        st = _PlanState(key=key, need_grad=need_grad, fwd=None, bwd=None, gfwd=None, gbwd=None, segs=None, outstanding=False, used=0, keep=[], meta_f=[], meta_b=[], pool=None)
         with self._pool_ctx(dev, st):
             st.x = torch.empty(x.shape, dtype=f32, device=dev)
             st.cond = torch.empty(cond.shape, dtype=f32, device=dev) if exists(cond) else None
@@ -943,7 +962,13 @@ class Transformer(Module):
         dev = st.x.device
         lib = ops.lib()
         if exists(st.fwd):
-            ops.run_plan(st.fwd, 0, -1, dev, st.lane_ss)
+            if self._graphs_on:
+                # HIP-graph form of the same replay (csrc/plan.hip): captured the first time the recorded plan is replayed, one launch after
+                if not st.__dict__.get('gfwd'):
+                    st.gfwd = ops.capture_graph(st.fwd, 0, -1, dev, st.lane_ss)
+                ops.launch_graph(st.gfwd, dev)
+            else:
+                ops.run_plan(st.fwd, 0, -1, dev, st.lane_ss)
             if st.run.grads_zeroed is not None:         # the recorded forward zero-fills the gradient buffer on its WGRAD lane
                 pg = self._pg
                 pg.token += 1
@@ -980,10 +1005,16 @@ class Transformer(Module):
             if not self._grads_prezeroed(st.run, self._pg) and not st.run.bwd_filled:
                 with ops.pinned_stream(dev):
                     ops.fill_(self._pg.buf)         # (another pass wrote into the buffer since this pass's forward zeroed it)
-            for first, count, slab in st.segs:
-                ops.run_plan(st.bwd, first, count, dev, st.lane_ss)
-                if exists(sync) and exists(slab):
-                    sync(st.gflat, slab[0], slab[1])
+            if self._graphs_on and not exists(sync):
+                # no gradient exchange interleaves between the layer segments: the whole backward pass is one graph
+                if not st.__dict__.get('gbwd'):
+                    st.gbwd = ops.capture_graph(st.bwd, 0, -1, dev, st.lane_ss)
+                ops.launch_graph(st.gbwd, dev)
+            else:
+                for first, count, slab in st.segs:
+                    ops.run_plan(st.bwd, first, count, dev, st.lane_ss)
+                    if exists(sync) and exists(slab):
+                        sync(st.gflat, slab[0], slab[1])
         else:
             self._pg_state(dev)
             ops.begin_recording(st.meta_b)
@@ -1696,6 +1727,14 @@ class _PlanState(NS):
     the handles of the recorded launch sequences in the C++ registry (csrc/plan.hip), which are released with it"""
 
     def free_handles(self):
+        for k in ('gfwd', 'gbwd'):
+            h = self.__dict__.get(k)
+            if h:
+                self.__dict__[k] = None
+                try:
+                    ops.lib().e2k_plan_graph_free(h)
+                except Exception:
+                    pass
         for k in ('fwd', 'bwd'):
             h = self.__dict__.get(k)
             if h:

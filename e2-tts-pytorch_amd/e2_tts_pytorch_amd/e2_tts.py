@@ -408,15 +408,65 @@ class InterpolatedCharacterEmbed(Module):
         return out
 
 
-class HLGaussLayer(Module):                                    # hl_gauss_pytorch.HLGaussLayer, regression mode (A.7)
+class HLGaussLoss(Module):
+    """hl_gauss_pytorch.HLGaussLoss (e2_tts.py:966-967 hands its keyword dict through; SURVEY.md A.7, arXiv 2403.03950): a scalar
+    target as the histogram of a Gaussian over `num_bins` bins of [min_value, max_value] (differences of erf at the bin edges,
+    normalised by the mass inside the range), cross-entropy of the logits against it, prediction = softmax expectation of the bin
+    centres.  (B, num_bins) element-wise work on the device the logits live on; `support` / `centers` are non-persistent buffers as in
+    that package, so state_dicts carry neither."""
+
+    def __init__(self, min_value, max_value, num_bins, sigma=None, sigma_to_bin_ratio=None, eps=1e-10, clamp_to_range=False):
+        super().__init__()
+        assert not (exists(sigma) and exists(sigma_to_bin_ratio))
+        self.eps = eps
+        support = torch.linspace(min_value, max_value, num_bins + 1).float()
+        bin_size = (support[1] - support[0]).item()
+        sigma = default(sigma, default(sigma_to_bin_ratio, 2.) * bin_size)
+        assert sigma > 0.
+        self.sigma, self.num_bins, self.min_value, self.max_value, self.clamp_to_range = sigma, num_bins, min_value, max_value, clamp_to_range
+        self.register_buffer('support', support, persistent=False)
+        self.register_buffer('centers', (support[:-1] + support[1:]) / 2, persistent=False)
+        self.sigma_times_sqrt_two = 2. ** 0.5 * sigma
+
+    def transform_from_logits(self, logits):
+        return (logits.softmax(dim=-1) * self.centers).sum(dim=-1)
+
+    def transform_to_probs(self, target):
+        cdf = torch.special.erf((self.support - target[..., None]) / self.sigma_times_sqrt_two)
+        z = cdf[..., -1:] - cdf[..., :1]
+        return (cdf[..., 1:] - cdf[..., :-1]) / z.clamp(min=self.eps)
+
+    def forward(self, logits, target=None):
+        if not exists(target):
+            return self.transform_from_logits(logits)
+        if self.clamp_to_range:
+            target = target.clamp(min=self.min_value, max=self.max_value)
+        return F.cross_entropy(logits, self.transform_to_probs(target))
+
+
+class HLGaussLayer(Module):                                    # hl_gauss_pytorch.HLGaussLayer as e2_tts.py:1035-1040 builds it (A.7)
+    """regression (the reference's default): Linear(dim, 1, no bias) -> activation -> MSE; classification (`use_regression=False` with
+    `hl_gauss_loss=dict(min_value, max_value, num_bins, ...)`, round 6): Linear(dim, num_bins, no bias) -> HLGaussLoss.  On the device
+    the (B, dim) x (num_bins, dim) projection and its gradients run on the HIP GEMMs (_OutProjFn), like every other Linear of the path."""
+
     def __init__(self, dim, hl_gauss_loss=None, use_regression=True, regress_activation=None):
         super().__init__()
-        if not use_regression or hl_gauss_loss is not None:
-            raise NotImplementedError('only the regression mode of HLGaussLayer is built')
-        self.to_pred = nn.Linear(dim, 1, bias=False)
+        if isinstance(hl_gauss_loss, dict):
+            hl_gauss_loss = HLGaussLoss(**hl_gauss_loss)
+        self.hl_gauss_loss = hl_gauss_loss
+        self.use_classification = not use_regression
+        assert not (self.use_classification and not exists(hl_gauss_loss)), '`hl_gauss_loss` is not defined, only regression is permitted'
+        self.to_pred = nn.Linear(dim, hl_gauss_loss.num_bins if self.use_classification else 1, bias=False)
         self.act = default(regress_activation, nn.Identity())
 
     def forward(self, embed, target=None):
+        if self.use_classification:
+            w = self.to_pred.weight
+            if _on_kernels(embed) and embed.ndim == 2 and w.shape[1] % 8 == 0:
+                logits = _OutProjFn.apply(embed[:, None, :], w, torch.zeros(w.shape[0], dtype=torch.float32, device=w.device))[:, 0]
+            else:
+                logits = self.to_pred(embed)
+            return self.hl_gauss_loss(logits, target)
         pred = self.act(self.to_pred(embed)).squeeze(-1)
         if not exists(target):
             return pred
@@ -495,7 +545,7 @@ class DurationPredictor(Module):                               # e2_tts.py:956-1
         if self.has_freq_axis:                                      # e2_tts.py:1030,1098: mean over the frequency tokens
             embed = embed.mean(dim=1)
         hl = self.hl_gauss_layer
-        if _on_kernels(embed) and isinstance(hl.act, nn.Softplus) and hl.act.beta == 1 and hl.act.threshold == 20:
+        if not hl.use_classification and _on_kernels(embed) and isinstance(hl.act, nn.Softplus) and hl.act.beta == 1 and hl.act.threshold == 20:
             # masked mean over the frames, the (dim -> 1) regression head and its Softplus in one kernel
             pred = _DurationHeadFn.apply(embed, mask, hl.to_pred.weight)
             return pred if not return_loss else F.mse_loss(pred, lens.float())

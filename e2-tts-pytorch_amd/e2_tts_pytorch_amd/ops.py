@@ -362,6 +362,32 @@ def run_plan(handle, first, count, device, side_streams=()):
     return L.e2k_plan_run_lanes(handle, first, count, ctypes.addressof(arr), n)
 
 
+def _stream_array(dev, side_streams):
+    import ctypes
+    n = 1 + len(side_streams)
+    arr = (ctypes.c_void_p * n)()
+    arr[0] = raw_stream(dev)
+    for i, ss in enumerate(side_streams):
+        arr[1 + i] = ss.cuda_stream if dev.type == 'cuda' else None
+    return arr, n
+
+
+def capture_graph(handle, first, count, device, side_streams=()):
+    """calls [first, first + count) of a plan as ONE HIP graph (e2k_query_plan_graph_capture): captured on the current stream with the
+    lanes on `side_streams`; nothing executes.  -> graph handle for launch_graph"""
+    import ctypes
+    dev = torch.device(device)
+    arr, n = _stream_array(dev, side_streams or ())
+    g = _lib.get().e2k_query_plan_graph_capture(handle, first, count, ctypes.addressof(arr), n)
+    if g <= 0:
+        raise _lib.E2KError(f'e2k_query_plan_graph_capture failed with code {g}')
+    return g
+
+
+def launch_graph(graph, device):
+    return _lib.get().e2k_plan_graph_launch(graph, raw_stream(torch.device(device)))
+
+
 import os as _os
 gemm_flags = int(_os.environ.get('E2K_GEMM_FLAGS', '0'))
 

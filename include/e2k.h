@@ -402,6 +402,14 @@ int e2k_plan_event_record(int lane, int ev);
 int e2k_plan_event_wait(int lane, int ev);
 int e2k_plan_run_lanes(int plan, int first, int count, void** streams_host, int nstreams);
 int e2k_plan_profile(int plan, int first, int count, float* ms_host, void* stream);
+/* HIP-graph form of a replay (round 6): e2k_query_plan_graph_capture runs the loop of e2k_plan_run_lanes over calls [first, first + count)
+ * under stream capture -- streams_host[0] captures, the side lanes are forked from it and joined back, the recorded ordering points
+ * become graph edges; NOTHING executes -- and returns a graph handle (> 0) or a negative error; e2k_plan_graph_launch re-issues the whole
+ * range with one hipGraphLaunch on `stream`.  For ranges no other stream interleaves with (a forward pass; a backward pass without a
+ * gradient exchange); buffers, like the plan's, must stay where they were. */
+int e2k_query_plan_graph_capture(int plan, int first, int count, void** streams_host, int nstreams);
+int e2k_plan_graph_launch(int graph, void* stream);
+int e2k_plan_graph_free(int graph);
 int e2k_plan_op_name(int plan, int index, char* buf_host, int nbuf);
 int e2k_query_plan_op_lane(int plan, int index);      /* launch lane of recorded call `index` (-1: no such call) */
 

@@ -49,7 +49,9 @@ typedef int hipError_t;
 #define hipSuccess 0
 static inline hipError_t hipGetLastError() { return 0; }
 static inline const char* hipGetErrorString(hipError_t) { return "emu"; }
-static inline hipError_t hipMemsetAsync(void* p, int v, size_t n, hipStream_t) { memset(p, v, n); return 0; }
+struct emu_graph;
+static inline bool emu_capture_memset(void* p, int v, size_t n);
+static inline hipError_t hipMemsetAsync(void* p, int v, size_t n, hipStream_t) { if (!emu_capture_memset(p, v, n)) memset(p, v, n); return 0; }
 // events: the host model runs every launch synchronously; elapsed times are host wall-clock (plan profiling logic only)
 #include <chrono>
 typedef std::chrono::steady_clock::time_point* hipEvent_t;
@@ -347,8 +349,42 @@ inline T wave_exchange(T v, int src_lane) {
 #define gridDim (emu::g_blk->gdim)
 #define warpSize 64
 
+// stream capture -> graph (csrc/plan.hip, e2k_query_plan_graph_capture): between hipStreamBeginCapture and hipStreamEndCapture NOTHING
+// executes -- kernel launches and memsets are appended to the graph as closures -- and hipGraphLaunch runs them in capture order (the
+// host model has no concurrency between lanes: capture order is a valid topological order of the graph).  One capture per thread.
+struct emu_graph { std::vector<std::function<void()>> nodes; };
+typedef emu_graph* hipGraph_t;
+typedef emu_graph* hipGraphExec_t;
+enum hipStreamCaptureMode { hipStreamCaptureModeGlobal = 0, hipStreamCaptureModeThreadLocal = 1, hipStreamCaptureModeRelaxed = 2 };
+inline thread_local emu_graph* emu_capture = nullptr;
+static inline hipError_t hipStreamBeginCapture(hipStream_t, hipStreamCaptureMode) {
+    if (emu_capture) return 901;
+    emu_capture = new emu_graph();
+    return 0;
+}
+static inline hipError_t hipStreamEndCapture(hipStream_t, hipGraph_t* g) {
+    if (!emu_capture) return 901;
+    *g = emu_capture;
+    emu_capture = nullptr;
+    return 0;
+}
+static inline hipError_t hipGraphInstantiate(hipGraphExec_t* e, hipGraph_t g, void*, void*, size_t) { *e = new emu_graph(*g); return 0; }
+static inline hipError_t hipGraphLaunch(hipGraphExec_t e, hipStream_t) {
+    for (auto& f : e->nodes) f();
+    return 0;
+}
+static inline hipError_t hipGraphExecDestroy(hipGraphExec_t e) { delete e; return 0; }
+static inline hipError_t hipGraphDestroy(hipGraph_t g) { delete g; return 0; }
+
+static inline bool emu_capture_memset(void* p, int v, size_t n) {
+    if (!emu_capture) return false;
+    emu_capture->nodes.push_back([=]() { memset(p, v, n); });
+    return true;
+}
+
 template <class K, class... A>
 inline void hipLaunchKernelGGL(K k, dim3 g, dim3 b, size_t, hipStream_t, A... args) {
+    if (emu_capture) { emu_capture->nodes.push_back([=]() { emu::launch(g, b, [=]() { k(args...); }); }); return; }
     emu::launch(g, b, [=]() { k(args...); });
 }
 

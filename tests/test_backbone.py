@@ -466,6 +466,107 @@ def test_plan_replay_matches_eager(dev):
         assert torch.equal(twin(x, times=t, mask=mask, text_embed=txt), eager)
 
 
+def test_plan_graph_replay_matches_eager_replay(dev):
+    """Transformer.enable_graphs (round 6; csrc/plan.hip e2k_query_plan_graph_capture): a recorded plan replayed as ONE HIP graph per
+    pass -- captured from the eager replay loop, lanes forked from / joined to the capturing stream -- gives what the eager replay
+    gives: outputs and input gradients bit for bit, parameter gradients to the order-of-arrival noise of the fp32 atomics; with dropout
+    the device-side seed word keeps the masks fresh (two graph launches with different seeds differ, the same seed repeats); a
+    forward-only (sampling) plan; and an installed gradient hook keeps the backward on the segmented eager replay."""
+    from e2_tts_pytorch_amd import Transformer
+    random.seed(0)
+    torch.manual_seed(0)
+    depth, T = (4, 40) if gpu_shapes(dev) else (2, 24)
+    mod = Transformer(dim=256, depth=depth, heads=2, dropout=0., max_seq_len=64, num_registers=32 if gpu_shapes(dev) else 8)
+    randomize(mod)
+    mod = mod.to(dev)
+    B = 2
+    R = torch.randn(B, T, 256).to(dev)
+
+    def inputs(seed):
+        g = torch.Generator().manual_seed(seed)
+        x = torch.randn(B, T, 256, generator=g).to(dev).requires_grad_(True)
+        t = torch.rand(B, generator=g).to(dev)
+        txt = torch.randn(B, T, 128, generator=g).to(dev).requires_grad_(True)
+        mask = (torch.arange(T)[None] < torch.tensor([T, T - 5 - seed])[:, None]).to(dev)
+        return x, t, txt, mask
+
+    def step(seed):
+        mod.zero_grad(set_to_none=True)
+        x, t, txt, mask = inputs(seed)
+        out = mod(x, times=t, mask=mask, text_embed=txt)
+        (out * R).sum().backward()
+        return out.detach().clone(), x.grad.clone(), txt.grad.clone(), {n: p.grad.clone() for n, p in mod.named_parameters()}
+
+    mod.enable_graphs(False)
+    ref = [step(s) for s in (1, 2, 3, 4, 5)]        # first sighting, recording, three eager replays
+    st = [v for v in mod._plans.values() if not isinstance(v, str)][0]
+    assert st.bwd and not st.gfwd and not st.gbwd
+    mod.enable_graphs(True)
+    got = [step(s) for s in (3, 4, 5)]              # capture + launch, launch, launch
+    assert st.gfwd and st.gbwd, 'no graph was captured'
+    for (o0, dx0, dt0, g0), (o1, dx1, dt1, g1) in zip(ref[2:], got):
+        assert torch.equal(o1, o0) and torch.equal(dx1, dx0) and torch.equal(dt1, dt0)
+        for n in g0:
+            assert rel2(g1[n], g0[n]) < 2e-3 or float(g0[n].norm()) < 1e-6, n
+    # a gradient hook (the data-parallel exchange) must see every slab between the backward's segments: eager replay there
+    seen = []
+
+    class Hook:
+        lanes = []
+
+        def __call__(self, gflat, a, b):
+            seen.append((a, b))
+    mod._grad_sync = Hook()
+    o, dx, dt, g = step(5)
+    mod._grad_sync = None
+    assert len(seen) >= depth + 1 and seen[-1] == (None, None) and torch.equal(o, ref[4][0]) and torch.equal(dx, ref[4][1])
+    # toggling off frees the graphs and the eager replay is back
+    mod.enable_graphs(False)
+    assert not st.gfwd and not st.gbwd
+    o, dx, dt, g = step(4)
+    assert torch.equal(o, ref[3][0]) and torch.equal(dx, ref[3][1])
+    # forward-only plan (the sampling path) as a graph
+    mod.enable_graphs(True)
+    mod.eval()
+    with torch.no_grad():
+        x, t, txt, mask = inputs(7)
+        outs = [mod(x, times=t, mask=mask, text_embed=txt).clone() for _ in range(4)]
+    assert all(torch.equal(outs[0], o) for o in outs[1:])
+    ng = [v for v in mod._plans.values() if not isinstance(v, str) and not v.need_grad]
+    assert ng and ng[0].gfwd
+
+
+def test_plan_graph_replay_keeps_dropout_fresh(dev):
+    """dropout inside a graph: the keep masks come from a device-side seed word that every replay rewrites BEFORE the launch -- two
+    launches of the same graph draw different masks, and re-seeding python's generator repeats them"""
+    from e2_tts_pytorch_amd import Transformer
+    random.seed(0)
+    torch.manual_seed(0)
+    T = 40 if gpu_shapes(dev) else 24
+    mod = Transformer(dim=256, depth=2, heads=2, dropout=0.2, max_seq_len=64, num_registers=32 if gpu_shapes(dev) else 8)
+    randomize(mod)
+    mod = mod.to(dev).train()
+    mod.enable_graphs(True)
+    g = torch.Generator().manual_seed(1)
+    x = torch.randn(2, T, 256, generator=g).to(dev)
+    t = torch.rand(2, generator=g).to(dev)
+    txt = torch.randn(2, T, 128, generator=g).to(dev)
+
+    def run(seed):
+        random.seed(seed)
+        torch.manual_seed(seed)
+        xx = x.clone().requires_grad_(True)
+        out = mod(xx, times=t, text_embed=txt)
+        out.sum().backward()
+        return out.detach().clone(), xx.grad.clone()
+
+    a = [run(s) for s in (11, 12, 13, 14, 13)]          # eager, recording, capture + launch, launch, launch with a repeated seed
+    st = [v for v in mod._plans.values() if not isinstance(v, str)][0]
+    assert st.gfwd and st.gbwd
+    assert not torch.equal(a[2][0], a[3][0])
+    assert torch.equal(a[2][0], a[4][0]) and torch.equal(a[2][1], a[4][1])
+
+
 def test_plan_replay_with_the_default_off_switches(dev):
     """has_freq_axis + attn_laser + attn_fourier_embed_input all on: the recorded plan (forward and backward, launch lanes on)
     reproduces the eager schedule -- the frequency attention, LASER maps and Fourier kernels are ordinary recorded calls and

@@ -488,6 +488,44 @@ def test_duration_predictor(dev):
     assert rel2(pred, pred_r) < 2e-2
 
 
+def test_duration_predictor_hl_gauss_classification(dev):
+    """DurationPredictor(hl_gauss_loss=dict(...), use_regression=False) (e2_tts.py:966-967,1035-1040; round 6: refused before): the
+    duration as a histogram over bins (arXiv 2403.03950) -- loss, gradient of the classification head and predictions against the
+    oracle's restatement of hl_gauss_pytorch; `support` / `centers` are non-persistent, so the state dict is the regression one with
+    a (num_bins, dim) head; also an independent check of the target histogram: it sums to 1 and, away from the range's ends, its mean is the target"""
+    from e2_tts_pytorch_amd import DurationPredictor
+    random.seed(3)
+    torch.manual_seed(3)
+    kw = dict(dim=256, depth=2, heads=4, dropout=0.)
+    hl = dict(min_value=0., max_value=64., num_bins=24)
+    ref = O.DurationPredictor(transformer=dict(**kw), hl_gauss_loss=dict(hl), use_regression=False)
+    randomize(ref)
+    model = DurationPredictor(transformer=dict(**kw), hl_gauss_loss=dict(hl), use_regression=False)
+    assert set(model.state_dict()) == set(ref.state_dict()) and model.hl_gauss_layer.to_pred.weight.shape == (24, 256)
+    model.load_state_dict(ref.state_dict(), strict=True)
+    model = model.to(dev)
+    B, T = 2, 48
+    mel = torch.randn(B, T, 100)
+    lens = torch.tensor([T, 30])
+    rfi = torch.tensor([0.6, 0.9])
+    loss_r = ref(mel, text=['ab', 'cde'], lens=lens, _rand_frac_index=rfi)
+    loss_r.backward()
+    loss = model(mel.to(dev), text=['ab', 'cde'], lens=lens.to(dev), _rand_frac_index=rfi.to(dev))
+    loss.backward()
+    assert abs(loss.item() - loss_r.item()) / abs(loss_r.item()) < 1e-2, (loss.item(), loss_r.item())
+    assert rel2(model.hl_gauss_layer.to_pred.weight.grad, ref.hl_gauss_layer.to_pred.weight.grad) < 2e-2
+    assert rel2(model.proj_in.weight.grad, ref.proj_in.weight.grad) < 5e-2
+    pred_r = ref(mel, text=['ab', 'cde'], lens=lens, return_loss=False)
+    with torch.no_grad():
+        pred = model(mel.to(dev), text=['ab', 'cde'], lens=lens.to(dev), return_loss=False)
+    assert pred.shape == (B,) and rel2(pred, pred_r) < 1e-2
+    probs = model.hl_gauss_layer.hl_gauss_loss.transform_to_probs(torch.tensor([32., 47.5], device=dev))
+    assert torch.allclose(probs.sum(-1).cpu(), torch.ones(2), atol=1e-5)
+    assert torch.allclose((probs * model.hl_gauss_layer.hl_gauss_loss.centers).sum(-1).cpu(), torch.tensor([32., 47.5]), atol=0.05)    # (targets well inside the range: no truncated tail)
+    with pytest.raises(AssertionError):
+        DurationPredictor(transformer=dict(**kw), use_regression=False)          # classification without a loss definition
+
+
 def test_against_golden_fixture(dev):
     """HIP path vs the committed oracle outputs (tests/golden/oracle_small.pt, made by tests/golden/make_golden.py)"""
     from pathlib import Path
