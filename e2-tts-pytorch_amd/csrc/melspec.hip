@@ -117,7 +117,48 @@ __global__ __launch_bounds__(256) void melspec_kernel(MelArgs p) {
     }
 }
 
+// Polyphase sinc resampler of the dataset path (trainer.py:116-118: torchaudio.transforms.Resample(sample_rate, target_sample_rate) per
+// clip; torchaudio's _apply_sinc_resample_kernel restated): with orig / new the two rates divided by their gcd, output sample
+// j * new + ph of a row is sum_k kernel[ph][k] * xpad[j * orig + k], xpad = the row with `width` zeros in front and zeros behind it
+// (a strided conv1d with `new` output channels).  One lane per output sample; a workgroup's 256 consecutive outputs read a window of
+// ~256 * orig / new + taps input samples, which L2 / L1 serve (HBM-bound: 4 B in + 4 B out per sample, the taps are MACs on cached data).
+// Rows are independent: a zero-padded ragged batch gives each row what it would get alone; outputs past ceil(len * new / orig) are zero.
+struct ResampleArgs {
+    const float* x; long ldx; long n_in; const int* lens; const float* kernel; float* out; long ldo; long n_out;
+    int orig, nw, taps, width;
+};
+
+__global__ __launch_bounds__(256) void resample_kernel(ResampleArgs p) {
+    const int b = blockIdx.y;
+    const long o = (long)blockIdx.x * 256 + threadIdx.x;
+    if (o >= p.n_out) return;
+    const long len = p.lens ? min((long)p.lens[b], p.n_in) : p.n_in;
+    const long valid = (len * p.nw + p.orig - 1) / p.orig;          // ceil(new * length / orig)
+    float acc = 0.f;
+    if (o < valid) {
+        const long j = o / p.nw;
+        const int ph = (int)(o - j * p.nw);
+        const float* kr = p.kernel + (long)ph * p.taps;
+        const float* xr = p.x + (long)b * p.ldx;
+        const long i0 = j * p.orig - p.width;                        // input index of tap 0
+        const int k0 = (int)max(0L, -i0), k1 = (int)min((long)p.taps, len - i0);
+        for (int k = k0; k < k1; ++k) acc = fmaf(kr[k], xr[i0 + k], acc);
+    }
+    p.out[(long)b * p.ldo + o] = acc;
+}
+
 }  // namespace
+
+static int resample_impl(const float* x, int64_t ldx, int64_t n_in, const int32_t* lens, const float* kernel, float* out, int64_t ldo,
+                         int64_t n_out, int B, int orig, int nw, int taps, int width, void* stream) {
+    if (B <= 0 || n_out <= 0) return 0;
+    if (!x || !kernel || !out) return E2K_ERR_ARG;
+    if (orig <= 0 || nw <= 0 || taps <= 0 || width < 0 || n_in <= 0 || ldx < n_in || ldo < n_out) return E2K_ERR_SHAPE;
+    ResampleArgs a{x, (long)ldx, (long)n_in, lens, kernel, out, (long)ldo, (long)n_out, orig, nw, taps, width};
+    hipLaunchKernelGGL(resample_kernel, dim3((unsigned)((n_out + 255) / 256), B), dim3(256), 0, (hipStream_t)stream, a);
+    E2K_CHECK_LAUNCH();
+    return 0;
+}
 
 static int melspec_impl(const float* wave, int64_t nw, const float* window, const float* fb, const float* twc,
                            const float* tws, float* out, int B, int n_fft, int hop, int n_mels, const int32_t* bands, void* stream) {
@@ -153,4 +194,9 @@ extern "C" int e2k_melspec_ragged(const float* wave, int64_t nw, const int32_t* 
                                   const float* twc, const float* tws, float* out, float pad_value, int B, int n_fft, int hop,
                                   int n_mels, const int32_t* bands, void* stream) {
     return e2k::dispatch("melspec_ragged", melspec_ragged_impl, wave, nw, lens, window, fb, twc, tws, out, pad_value, B, n_fft, hop, n_mels, bands, stream);
+}
+
+extern "C" int e2k_resample_sinc(const float* x, int64_t ldx, int64_t n_in, const int32_t* lens, const float* kernel, float* out, int64_t ldo,
+                                 int64_t n_out, int B, int orig, int nw, int taps, int width, void* stream) {
+    return e2k::dispatch("resample_sinc", resample_impl, x, ldx, n_in, lens, kernel, out, ldo, n_out, B, orig, nw, taps, width, stream);
 }

@@ -161,7 +161,14 @@ extern "C" int e2k_query_plan_graph_capture(int plan, int first, int count, void
     if (hipEventCreateWithFlags(&fork, hipEventDisableTiming) != hipSuccess) return -1000;
     for (int k = 1; k < nstreams; ++k)
         if (hipEventCreateWithFlags(&join[k], hipEventDisableTiming) != hipSuccess) return -1000;
-    hipStream_t main = (hipStream_t)streams_host[0];
+    // lane 0 is captured on a stream of the library's own: the caller's stream is usually the legacy default stream, which cannot capture
+    // (hipErrorStreamCaptureUnsupported: the first hardware run of this entry point); the graph is launched on the caller's stream all the same
+    static hipStream_t cap = nullptr;
+    if (!cap && hipStreamCreateWithFlags(&cap, hipStreamNonBlocking) != hipSuccess) return -1000;
+    void* lanes[PLAN_MAX_LANES] = {(void*)cap, nullptr, nullptr, nullptr};
+    for (int k = 1; k < nstreams; ++k) lanes[k] = streams_host[k];
+    streams_host = lanes;
+    hipStream_t main = cap;
     int rc = 0;
     hipGraph_t graph = nullptr;
     if (hipStreamBeginCapture(main, hipStreamCaptureModeRelaxed) != hipSuccess) rc = 1001;

@@ -1170,6 +1170,22 @@ def grad_unpack_bf16(wire, g):
     _lib.get().e2k_grad_unpack_bf16(_p(wire), _p(g), g.numel(), _stream(g))
 
 
+def resample_sinc(x, kernel, orig, new, width, lens=None):
+    """x (B, n) fp32 -> (B, ceil(n new / orig)) fp32: polyphase windowed-sinc rate conversion (e2k_resample_sinc); kernel (new, 2 width +
+    orig) fp32; lens (B,) int32: valid samples per row (outputs past a row's end are zero)"""
+    _chk(x, kernel, lens)
+    assert x.dim() == 2 and x.dtype == f32 and x.stride(1) == 1 and kernel.dtype == f32 and kernel.is_contiguous()
+    assert kernel.shape == (new, 2 * width + orig)
+    B, n = x.shape
+    n_out = (n * new + orig - 1) // orig
+    out = torch.empty((B, n_out), dtype=f32, device=x.device)
+    if lens is not None:
+        assert lens.dtype == torch.int32 and lens.numel() == B and lens.is_contiguous()
+    _lib.get().e2k_resample_sinc(_p(x), x.stride(0), n, _p(lens), _p(kernel), _p(out), out.stride(0), n_out, B, int(orig), int(new),
+                                 kernel.shape[1], int(width), _stream(x))
+    return out
+
+
 def shard_sum_bf16(recv, out, world):
     """out[i] = bf16(sum_r float(recv[r * per + i])), per = out.numel(): fp32 sum of the peers' copies of this rank's shard"""
     _chk(recv, out)

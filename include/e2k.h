@@ -328,6 +328,14 @@ int e2k_melspec_ragged(const float* wave, int64_t nw, const int32_t* lens, const
                        const float* twc, const float* tws, float* out, float pad_value, int B, int n_fft, int hop,
                        int n_mels, const int32_t* bands, void* stream);
 
+/* Sample-rate conversion of the dataset path (trainer.py:116-118: torchaudio.transforms.Resample(sample_rate, target) per clip, here for
+ * the whole ragged batch on the device in front of e2k_melspec_ragged).  orig / nw: source / target rate divided by their gcd; kernel
+ * (nw, taps) fp32, taps = 2 width + orig: the windowed-sinc polyphase filter (built on the host, data.Resample); x (B, ldx) holds n_in
+ * samples per row of which lens[b] are valid (NULL: all); out (B, ldo): out[b][j nw + ph] = sum_k kernel[ph][k] xpad_b[j orig + k] for the
+ * first ceil(lens[b] nw / orig) outputs, zeros up to n_out. */
+int e2k_resample_sinc(const float* x, int64_t ldx, int64_t n_in, const int32_t* lens, const float* kernel, float* out, int64_t ldo,
+                      int64_t n_out, int B, int orig, int nw, int taps, int width, void* stream);
+
 /* ---- optimizer side over flat fp32 buffers (reference trainer.py:272-279) ----
  * out[0] += sum x^2 (fp64 accumulation): the global gradient norm of accelerator.clip_grad_norm_ (trainer.py:272-273). */
 int e2k_sumsq_f32(const float* x, int64_t n, double* out, void* stream);

@@ -183,6 +183,51 @@ class MelSpec(Module):
         return log_clamp(self.mel_stft(inp))
 
 
+# ---------------------------------------------------------------- torchaudio.transforms.Resample (trainer.py:116-118)
+
+class Resample(Module):
+    """torchaudio.transforms.Resample(orig_freq, new_freq) with its defaults (resampling_method='sinc_interp_hann',
+    lowpass_filter_width=6, rolloff=0.99), restated from the published torchaudio.functional._get_sinc_resample_kernel /
+    _apply_sinc_resample_kernel (un-vendored, PARITY UNPINNED; tests/test_oracle.py checks it against an analytic band-limited
+    signal): both rates are divided by their gcd; `new` filters of 2 width + orig taps -- a Hann-windowed sinc at
+    rolloff x min(orig, new), one per output phase, built in fp64 and stored fp32 -- are applied as a conv1d of stride `orig` to
+    the clip padded with `width` zeros in front and width + orig behind; the result is cut to ceil(new * length / orig) samples."""
+
+    def __init__(self, orig_freq=16000, new_freq=16000, lowpass_filter_width=6, rolloff=0.99):
+        super().__init__()
+        self.orig_freq, self.new_freq = int(orig_freq), int(new_freq)
+        self.gcd = math.gcd(self.orig_freq, self.new_freq)
+        self.lowpass_filter_width, self.rolloff = lowpass_filter_width, rolloff
+        if self.orig_freq != self.new_freq:
+            kernel, self.width = self.sinc_kernel(self.orig_freq, self.new_freq, self.gcd, lowpass_filter_width, rolloff)
+            self.register_buffer('kernel', kernel, persistent=False)
+
+    @staticmethod
+    def sinc_kernel(orig_freq, new_freq, gcd, lowpass_filter_width=6, rolloff=0.99):
+        orig, new = orig_freq // gcd, new_freq // gcd
+        base = min(orig, new) * rolloff
+        width = math.ceil(lowpass_filter_width * orig / base)
+        idx = torch.arange(-width, width + orig, dtype=torch.float64)[None, None] / orig
+        t = torch.arange(0, -new, -1, dtype=torch.float64)[:, None, None] / new + idx
+        t = (t * base).clamp_(-lowpass_filter_width, lowpass_filter_width)
+        window = torch.cos(t * math.pi / lowpass_filter_width / 2) ** 2
+        t = t * math.pi
+        kernels = torch.where(t == 0, torch.ones_like(t), t.sin() / t) * window * (base / orig)
+        return kernels.float(), width                       # (new, 1, 2 width + orig)
+
+    def forward(self, waveform):
+        if self.orig_freq == self.new_freq:
+            return waveform
+        orig, new = self.orig_freq // self.gcd, self.new_freq // self.gcd
+        shape = waveform.shape
+        wav = waveform.reshape(-1, shape[-1])
+        n, length = wav.shape
+        wav = F.pad(wav, (self.width, self.width + orig))
+        out = F.conv1d(wav[:, None], self.kernel, stride=orig).transpose(1, 2).reshape(n, -1)
+        target = int(math.ceil(new * length / orig))
+        return out[..., :target].reshape(shape[:-1] + (target,))
+
+
 # ---------------------------------------------------------------- x-transformers pieces (SURVEY A.1-A.6)
 
 class RMSNorm(Module):                       # A.1

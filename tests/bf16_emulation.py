@@ -8,6 +8,7 @@ by a small multiple of what this emulation already deviates by.
 """
 import torch
 import torch.nn as nn
+import torch.nn.functional as F
 
 from oracle import e2tts_oracle as O
 
@@ -20,6 +21,18 @@ class RoundBoth(torch.autograd.Function):
     @staticmethod
     def backward(ctx, g):
         return g.bfloat16().float()
+
+
+class RoundFwd(torch.autograd.Function):
+    """bf16 copy of a parameter as a matrix-unit operand: the forward (and, through autograd, the dgrad) product sees the rounded
+    weight, its gradient stays fp32 -- what a bf16 shadow of an fp32 master weight does"""
+    @staticmethod
+    def forward(ctx, w):
+        return w.bfloat16().float()
+
+    @staticmethod
+    def backward(ctx, g):
+        return g
 
 
 class bf16_intermediates:
@@ -36,7 +49,9 @@ class bf16_intermediates:
             return RoundBoth.apply(b), (lambda y: RoundBoth.apply(add(y)))
 
         O.HyperConnections.forward = hc
-        nn.Linear.forward = lambda self_, x: RoundBoth.apply(lin0(self_, RoundBoth.apply(x)))
+        # (round 6: the Linear's weight as a bf16 operand too -- every GEMM of a bf16 implementation reads a rounded copy of the fp32
+        #  master weight; before, only activations were rounded and the emulation under-stated the noise of the gradients by ~1.7 x)
+        nn.Linear.forward = lambda self_, x: RoundBoth.apply(F.linear(RoundBoth.apply(x), RoundFwd.apply(self_.weight), self_.bias))
         torch.Tensor.softmax = lambda self_, *a, **k: RoundBoth.apply(sm0(self_, *a, **k))
         for m in self.mods:
             m.forward = (lambda f: lambda self_, *a, **k: RoundBoth.apply(f(self_, *a, **k)))(self.saved[m])

@@ -63,6 +63,8 @@ static inline hipError_t hipEventElapsedTime(float* ms, hipEvent_t a, hipEvent_t
     return 0;
 }
 static inline hipError_t hipStreamSynchronize(hipStream_t) { return 0; }
+#define hipStreamNonBlocking 1u
+static inline hipError_t hipStreamCreateWithFlags(hipStream_t* s, unsigned) { static int dummy; *s = (hipStream_t)&dummy; return 0; }
 #define hipEventDisableTiming 2u
 static inline hipError_t hipEventCreateWithFlags(hipEvent_t* e, unsigned) { return hipEventCreate(e); }
 // launch lanes (csrc/plan.h): everything runs synchronously here, so a wait has nothing to wait for -- but waiting for an

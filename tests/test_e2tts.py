@@ -102,6 +102,56 @@ def test_melspec_ragged_batch(dev):
         assert float(batch['mel'][i, :, n:].abs().max()) == 0. if n < want.shape[-1] else True
 
 
+@pytest.mark.parametrize('orig,new', [(22050, 24000), (48000, 24000), (16000, 24000), (44100, 24000), (24000, 24000)])
+def test_resample_kernel(dev, orig, new):
+    """data.Resample (e2k_resample_sinc; round 6: `collate_wave_fn` demanded clips at the target rate before) against the oracle's
+    restatement of torchaudio.transforms.Resample as HFDataset.__getitem__ applies it (trainer.py:116-118): a single clip, a batch, and
+    a zero-padded ragged batch in which every row must come out as if it had been converted alone, with exact zeros after its end"""
+    from e2_tts_pytorch_amd.data import Resample
+    torch.manual_seed(2)
+    rs, ro = Resample(orig, new).to(dev), O.Resample(orig, new)
+    x = torch.randn(3, 2000)
+    want = ro(x)
+    got = rs(x.to(dev))
+    assert got.shape == want.shape and (got.cpu() - want).abs().max().item() < 2e-5, (got.shape, want.shape)
+    one = rs(x[0].to(dev))
+    assert one.shape == want[0].shape and torch.equal(one.cpu(), got[0].cpu())
+    if orig == new:
+        return
+    lens = torch.tensor([2000, 1234, 57])
+    xr = x.clone()
+    for i, n in enumerate(lens.tolist()):
+        xr[i, n:] = 0.
+    got, nl = rs(xr.to(dev), lens=lens.to(dev))
+    for i, n in enumerate(lens.tolist()):
+        w = ro(x[i, :n])
+        assert int(nl[i]) == w.shape[0], (i, int(nl[i]), w.shape)
+        assert (got[i, :w.shape[0]].cpu() - w).abs().max().item() < 2e-5
+        assert float(got[i, w.shape[0]:].abs().max()) == 0. if w.shape[0] < got.shape[1] else True
+
+
+def test_data_path_resamples_foreign_rates(dev):
+    """collate_wave_fn + mel_batch on rows that carry their own 'sampling_rate' (the reference's dataset rows do, trainer.py:107) ==
+    HFDataset.__getitem__ clip by clip: Resample to the model's rate where it differs, MelSpec, then collate_fn's zero padding"""
+    from e2_tts_pytorch_amd import MelSpec
+    from e2_tts_pytorch_amd.data import collate_wave_fn, mel_batch
+    torch.manual_seed(4)
+    spec = [(24000, 9000), (22050, 8000), (16000, 7000), (22050, 3100)]
+    items = [dict(wave=torch.randn(n) * 0.3, text='t' * (i + 1), sampling_rate=r) for i, (r, n) in enumerate(spec)]
+    om = O.MelSpec()
+    specs = []
+    for it in items:
+        w = it['wave'] if it['sampling_rate'] == 24000 else O.Resample(it['sampling_rate'], 24000)(it['wave'])
+        specs.append(om(w[None])[0])
+    ml = torch.tensor([sp.shape[-1] for sp in specs])
+    want = torch.stack([torch.nn.functional.pad(sp, (0, int(ml.max()) - sp.shape[-1])) for sp in specs])
+    batch = mel_batch(collate_wave_fn(items), MelSpec().to(dev), device=dev)
+    assert torch.equal(batch['mel_lengths'].cpu(), ml) and batch['mel'].shape[:2] == want.shape[:2]
+    got = batch['mel'].cpu()[..., :want.shape[-1]]
+    assert (got - want).abs().max().item() < 3e-3
+    assert float(batch['mel'].cpu()[..., want.shape[-1]:].abs().max()) == 0. if batch['mel'].shape[-1] > want.shape[-1] else True
+
+
 def _pair(kw, seed=0, duration_predictor=None, **extra):
     from e2_tts_pytorch_amd import E2TTS
     random.seed(seed)

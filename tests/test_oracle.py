@@ -366,3 +366,28 @@ def test_dopri5_against_scipy_and_analytic():
     # scalar decay with a fast rate: exact solution exp(-25 t)
     y = _odeint_dopri5(lambda t_, y_: -25. * y_, torch.ones(1, dtype=torch.float64), t, rtol=1e-7, atol=1e-9)
     assert abs(y.item() - math.exp(-25.)) < 1e-8
+
+
+@pytest.mark.parametrize('orig,new', [(22050, 24000), (48000, 24000), (16000, 24000)])
+def test_resample_against_an_analytic_band_limited_signal(orig, new):
+    """oracle.Resample (torchaudio.transforms.Resample restated, trainer.py:116-118) is un-pinned -- torchaudio is not installed -- so it is
+    held against what ANY correct resampler must do: a sum of sinusoids far below both Nyquist rates, sampled at `orig`, comes out as
+    the same sinusoids sampled at `new` (away from the clip's zero-padded ends), the length is ceil(n new / orig), and an identity
+    conversion returns its input"""
+    import math
+    n = 6000
+    t0 = torch.arange(n, dtype=torch.float64) / orig
+    f = [220.0, 997.0, 1810.0]
+    sig = lambda t: sum(a * torch.sin(2 * math.pi * fr * t + ph) for a, fr, ph in zip((0.5, 0.3, 0.2), f, (0.1, 1.3, 2.2)))
+    y = O.Resample(orig, new)(sig(t0).float())
+    m = math.ceil(n * new / orig)
+    assert y.shape == (m,)
+    t1 = torch.arange(m, dtype=torch.float64) / new
+    edge = 64
+    err = (y.double() - sig(t1))[edge:-edge].abs().max().item()
+    assert err < 2e-3, err
+    x = torch.randn(100)
+    assert torch.equal(O.Resample(24000, 24000)(x), x)
+    # the filter bank: `new / gcd` phases, each a low-pass of unit DC gain (to the window's ripple)
+    r = O.Resample(orig, new)
+    assert r.kernel.shape[0] == new // math.gcd(orig, new) and (r.kernel.sum(-1) - 1).abs().max().item() < 2e-3
