@@ -257,6 +257,32 @@ __global__ __launch_bounds__(256) void cast_pad_kernel(const float* src, long ld
     }
 }
 
+// The prologue of E2TTS.forward (e2_tts.py:1519-1543) in one pass over the (B T, C) mel frames: w = (1 - t) x0 + t x1 (the point on the
+// probability path), flow = x1 - x0 (the regression target), cond = x1 outside the masked span and 0 inside it -- and the two operands
+// of the input projection GEMM, w and cond as bf16 rows zero-padded to Cpad columns (what e2k_cast_pad_bf16 made of them in two more
+// launches).  The products and the sum of w are rounded one by one (no contraction into an fma): bit for bit the tensor library's
+// (1 - t) * x0 + t * x1.
+__global__ __launch_bounds__(256) void flow_pack_kernel(const float* x0, const float* x1, const float* t, const uint8_t* span, bf16_t* wb, bf16_t* cb,
+                                                        long ldp, float* flow, float* cond, int M, int T, int C, int Cpad) {
+    const long total = (long)M * Cpad;
+    for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < total; i += (long)gridDim.x * 256) {
+        const int r = (int)(i / Cpad), c = (int)(i - (long)r * Cpad);
+        bf16_t wv = 0, cv = 0;
+        if (c < C) {
+            const long j = (long)r * C + c;
+            const float a = x0[j], b = x1[j], tt = t[r / T];
+            const float w = __fadd_rn(__fmul_rn(1.f - tt, a), __fmul_rn(tt, b));
+            const float cd = span[r] ? 0.f : b;
+            flow[j] = b - a;
+            cond[j] = cd;
+            wv = f2bf(w);
+            cv = f2bf(cd);
+        }
+        wb[(long)r * ldp + c] = wv;
+        cb[(long)r * ldp + c] = cv;
+    }
+}
+
 // masked mean squared error over the masked span (e2_tts.py:1580-1582: F.mse_loss(pred, flow)[mask].mean()):
 // acc[0] += sum_m mask[m] * sum_c (pred - flow)^2,  acc[1] += sum_m mask[m]      (fp32 atomics, one per block)
 __global__ __launch_bounds__(256) void masked_mse_fwd_kernel(const float* pred, const float* flow, const uint8_t* mask, float* acc,
@@ -378,6 +404,17 @@ __global__ __launch_bounds__(256) void duration_head_bwd_kernel(const float* dpr
 }
 
 }  // namespace
+
+static int flow_pack_impl(const float* x0, const float* x1, const float* t, const uint8_t* span_mask, void* w_bf16, void* cond_bf16, int64_t ldp,
+                          float* flow, float* cond, int B, int T, int C, int Cpad, void* stream) {
+    if (B <= 0 || T <= 0 || Cpad <= 0) return 0;
+    if (!x0 || !x1 || !t || !span_mask || !w_bf16 || !cond_bf16 || !flow || !cond) return E2K_ERR_ARG;
+    if (C <= 0 || C > Cpad || ldp < Cpad) return E2K_ERR_SHAPE;
+    hipLaunchKernelGGL(flow_pack_kernel, dim3(grid_1d((long)B * T * Cpad)), dim3(256), 0, (hipStream_t)stream, x0, x1, t, span_mask, (bf16_t*)w_bf16,
+                       (bf16_t*)cond_bf16, (long)ldp, flow, cond, B * T, T, C, Cpad);
+    E2K_CHECK_LAUNCH();
+    return 0;
+}
 
 static int cast_pad_bf16_impl(const float* src, int64_t lds_, void* dst, int64_t ldd, int R, int C, int Cpad, void* stream) {
     if (R <= 0 || Cpad <= 0) return 0;
@@ -658,6 +695,11 @@ extern "C" int e2k_cond_bwd_prep(float* dcond, const float* gates, void* dcb, vo
 extern "C" int e2k_transpose_f32(const float* in, int64_t ld, float* out, int R, int C, void* stream) {
     return e2k::dispatch("transpose_f32", transpose_f32_impl, in, ld, out, R, C, stream);
 }
+extern "C" int e2k_flow_pack(const float* x0, const float* x1, const float* t, const uint8_t* span_mask, void* w_bf16, void* cond_bf16, int64_t ldp,
+                             float* flow, float* cond, int B, int T, int C, int Cpad, void* stream) {
+    return e2k::dispatch("flow_pack", flow_pack_impl, x0, x1, t, span_mask, w_bf16, cond_bf16, ldp, flow, cond, B, T, C, Cpad, stream);
+}
+
 extern "C" int e2k_cast_pad_bf16(const float* src, int64_t lds_, void* dst, int64_t ldd, int R, int C, int Cpad, void* stream) {
     return e2k::dispatch("cast_pad_bf16", cast_pad_bf16_impl, src, lds_, dst, ldd, R, C, Cpad, stream);
 }

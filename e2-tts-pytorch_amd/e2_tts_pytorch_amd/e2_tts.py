@@ -142,6 +142,38 @@ class _InProjFn(torch.autograd.Function):
         return das[0], das[1], dw1, dw2, db
 
 
+class _FlowInProjFn(torch.autograd.Function):
+    """E2TTS.forward's prologue + input projection (e2_tts.py:1519-1543,1274-1277; round 6): ONE kernel forms
+    w = (1 - t) x0 + t x1, flow = x1 - x0, cond = where(span, 0, x1) and the bf16 K-padded GEMM operands of w and cond (ten
+    tensor-library launches and two cast kernels before), then the dual-K-panel GEMM of _InProjFn.  -> (h (B, T, D), flow, cond).
+    For inputs that need no gradient (the training step: mel, noise and times are data); anything else takes the unfused path."""
+
+    @staticmethod
+    def forward(ctx, x0, x1, times, span_mask, w1, w2, bias):
+        B, T, C = x1.shape
+        Cp, D, dev = _r8(C), w1.shape[0], x1.device
+        a1b, a2b, flow, cond = ops.flow_pack(_f32c(x0), _f32c(x1), _f32c(times), span_mask.contiguous(), Cp)
+        wb = torch.empty((D, 2 * Cp), dtype=torch.bfloat16, device=dev)
+        ops.cast_pad_bf16(w1.detach(), Cp, out=wb, col0=0)
+        ops.cast_pad_bf16(w2.detach(), Cp, out=wb, col0=Cp)
+        out = ops.gemm_nt(a1b, wb, a2=a2b, bias=_f32c(bias.detach()), out_dtype=torch.float32)
+        ctx.save_for_backward(a1b, a2b)
+        ctx.dims = (B, T, C, D)
+        ctx.mark_non_differentiable(flow, cond)
+        return out.view(B, T, D), flow, cond
+
+    @staticmethod
+    def backward(ctx, dout, _dflow, _dcond):
+        a1b, a2b = ctx.saved_tensors
+        B, T, C, D = ctx.dims
+        M, dev = B * T, dout.device
+        dob = ops.cast_bf16(_f32c(dout).view(-1), torch.empty((M, D), dtype=torch.bfloat16, device=dev))
+        dw1, dw2, db = ops.zeros((D, C), torch.float32, dev), ops.zeros((D, C), torch.float32, dev), ops.zeros((D,), torch.float32, dev)
+        ops.gemm_tn(dob, a1b[:, :C], dw1, colsum=db)
+        ops.gemm_tn(dob, a2b[:, :C], dw2)
+        return None, None, None, None, dw1, dw2, db
+
+
 class _OutProjFn(torch.autograd.Function):
     """to_pred (e2_tts.py:1296): (B, T, D) -> (B, T, C) on the NT GEMM; backward dgrad over the K = 104 padded gradient"""
 
@@ -192,6 +224,7 @@ class _MaskedMSEFn(torch.autograd.Function):
 
 
 _CHECK_TOKEN_IDS = __import__('os').environ.get('E2K_CHECK_TOKEN_IDS', '0') == '1'
+_FUSE_FLOW_PROLOGUE = __import__('os').environ.get('E2K_FUSE_FLOW_PROLOGUE', '1') != '0'
 
 
 def _on_kernels(t):
@@ -378,6 +411,15 @@ class InterpolatedCharacterEmbed(Module):
         self.embed = nn.Embedding(num_embeds, dim)
         self.abs_pos_mlp = nn.Sequential(_AddLastDim(), nn.Linear(1, dim), nn.SiLU(), nn.Linear(dim, dim))
 
+    def _abs_pos(self, pos):
+        """abs_pos_mlp (e2_tts.py:432-437): Linear(1, d) is an outer product (element-wise), the (B T, d) x (d, d) Linear behind the SiLU
+        runs on the HIP GEMMs like every other Linear of the path (round 6: it went to the vendor BLAS through nn.Linear before)"""
+        l1, l2 = self.abs_pos_mlp[1], self.abs_pos_mlp[3]
+        if not (_on_kernels(pos) and self.dim % 8 == 0 and l2.weight.dtype == torch.float32):
+            return self.abs_pos_mlp(pos)
+        h = F.silu(pos[..., None] * l1.weight[:, 0] + l1.bias)
+        return _OutProjFn.apply(h, l2.weight, l2.bias)
+
     def forward(self, text, max_seq_len, mask=None):
         B, dev = text.shape[0], text.device
         valid = text >= 0
@@ -402,7 +444,7 @@ class InterpolatedCharacterEmbed(Module):
         inside = (i < naf) & (ntf > 0)                                                 # positions this sample has audio for
         # torch.linspace(0, nt, n_audio): step nt / (n_audio - 1); zero-padded beyond n_audio
         pos = torch.where(inside, i * (ntf / (naf - 1.).clamp(min=1.)), torch.zeros_like(i))
-        out = torch.where(inside[..., None], out, torch.zeros_like(out)) + self.abs_pos_mlp(pos)
+        out = torch.where(inside[..., None], out, torch.zeros_like(out)) + self._abs_pos(pos)
         if exists(mask):
             out = torch.where(mask[..., None], out, torch.zeros_like(out))
         return out
@@ -731,13 +773,15 @@ class E2TTS(Module):
         return rows if isinstance(self.embed_text, InterpolatedCharacterEmbed) else rows - 1
 
     def transformer_with_pred_head(self, x, cond, times, mask=None, text=None, drop_text_cond=None,
-                                   return_drop_text_cond=False):
+                                   return_drop_text_cond=False, _projected=None):
         seq_len = x.shape[-2]
         drop_text_cond = default(drop_text_cond, self.training and random() < self.cond_drop_prob)
         C = self.num_channels
         if not _on_kernels(x):
             raise ops.E2KError('e2_tts_pytorch_amd kernels need tensors on a HIP device (no CPU path)')
-        if self.concat_cond:                              # e2_tts.py:1263-1276: proj_in(cat(cond, x)), never concatenated
+        if _projected is not None:                        # forward(): proj_in(x) + cond_proj_in(cond) already formed by _FlowInProjFn
+            x = _projected
+        elif self.concat_cond:                            # e2_tts.py:1263-1276: proj_in(cat(cond, x)), never concatenated
             w = self.proj_in.weight
             x = _InProjFn.apply(cond, x, w[:, :C], w[:, C:], self.proj_in.bias)
         else:                                             # e2_tts.py:1274-1277: proj_in(x) + cond_proj_in(cond), one GEMM
@@ -898,12 +942,21 @@ class E2TTS(Module):
         t = times[:, None, None]
         if need_velocity_loss:                      # e2_tts.py:1528-1529: keep t + delta inside [0, 1]
             t = t * (1. - velocity_consistency_delta)
-        w = (1. - t) * x0 + t * x1
-        flow = x1 - x0
-        cond = torch.where(rand_span_mask[..., None], torch.zeros_like(x1), x1)
+        fused = (_FUSE_FLOW_PROLOGUE and not need_velocity_loss and not self.concat_cond and _on_kernels(x1) and x1.dtype == torch.float32
+                 and x0.dtype == torch.float32 and not (torch.is_grad_enabled() and (x1.requires_grad or x0.requires_grad or times.requires_grad)))
+        if fused:
+            # w, flow, cond and the input projection's operands in one kernel, the projection GEMM behind it
+            h, flow, cond = _FlowInProjFn.apply(x0, x1, times, rand_span_mask, self.proj_in.weight, self.cond_proj_in.weight,
+                                                self.proj_in.bias + self.cond_proj_in.bias)
+            w = x1                       # (only its shape is read downstream)
+        else:
+            h = None
+            w = (1. - t) * x0 + t * x1
+            flow = x1 - x0
+            cond = torch.where(rand_span_mask[..., None], torch.zeros_like(x1), x1)
         pred, did_drop = self.transformer_with_pred_head(w, cond, times=times, text=text, mask=mask,
                                                          drop_text_cond=_noise.get('drop_text_cond'),
-                                                         return_drop_text_cond=True)
+                                                         return_drop_text_cond=True, _projected=h)
         m = rand_span_mask[..., None].to(pred.dtype)
         velocity_loss = self.zero
         if need_velocity_loss:

@@ -1015,6 +1015,20 @@ def cond_bwd_prep(dcond, gates, gbias, B, L, D):
     return dcb, dct
 
 
+def flow_pack(x0, x1, t, span_mask, cpad):
+    """E2TTS.forward's prologue in one launch (e2k_flow_pack): -> (w bf16 (M, cpad), cond bf16 (M, cpad), flow fp32 (B, T, C), cond fp32 (B, T, C))"""
+    _chk(x0, x1, t, span_mask)
+    B, T, C = x1.shape
+    assert x0.shape == x1.shape and x0.dtype == f32 and x1.dtype == f32 and x0.is_contiguous() and x1.is_contiguous()
+    assert t.dtype == f32 and t.numel() == B and t.is_contiguous() and span_mask.numel() == B * T and span_mask.is_contiguous()
+    m8 = span_mask.view(torch.uint8) if span_mask.dtype == torch.bool else span_mask
+    wb = torch.empty((B * T, cpad), dtype=bf16, device=x1.device)
+    cb = torch.empty((B * T, cpad), dtype=bf16, device=x1.device)
+    flow, cond = torch.empty_like(x1), torch.empty_like(x1)
+    _lib.get().e2k_flow_pack(_p(x0), _p(x1), _p(t), _p(m8), _p(wb), _p(cb), cpad, _p(flow), _p(cond), B, T, C, cpad, _stream(x1))
+    return wb, cb, flow, cond
+
+
 def cast_pad_bf16(src, cpad, out=None, col0=0):
     """src (R, C) fp32 (rows contiguous) -> bf16 (R, cpad) zero padded; with `out` (R, ld) the result goes to its columns
     col0 .. col0 + cpad"""

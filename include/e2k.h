@@ -452,6 +452,11 @@ int e2k_time_cond_bwd(const float* dout, const float* four, const float* pre, fl
  * padded to KB columns, gbias[l][1|3][:] += sum_b dcond (the AdaLN-Zero biases; slots 0, 2 have no bias) */
 int e2k_cond_bwd_prep(float* dcond, const float* gates, void* dcb, void* dct, float* gbias, int B, int L, int D, int KB,
                       void* stream);
+/* The prologue of E2TTS.forward (e2_tts.py:1519-1543) in one pass: x0 (noise), x1 (mel) (B T, C) fp32 contiguous, t (B) the flow times,
+ * span_mask (B T) bytes = the random span to be infilled -> flow = x1 - x0, cond = span ? 0 : x1 (both (B T, C) fp32, returned to the caller
+ * by the reference), and the input projection's GEMM operands w = (1 - t) x0 + t x1 and cond as bf16 (B T, ldp) zero-padded to Cpad columns. */
+int e2k_flow_pack(const float* x0, const float* x1, const float* t, const uint8_t* span_mask, void* w_bf16, void* cond_bf16, int64_t ldp,
+                  float* flow, float* cond, int B, int T, int C, int Cpad, void* stream);
 /* fp32 (R, C), rows lds floats apart -> bf16 (R, ldd) with columns C .. Cpad-1 zeroed: operands of the 100-channel input /
  * output projections (e2_tts.py:1267-1277,1296: proj_in, cond_proj_in, to_pred), whose K is padded to a multiple of 8 */
 int e2k_cast_pad_bf16(const float* src, int64_t lds, void* dst, int64_t ldd, int R, int C, int Cpad, void* stream);

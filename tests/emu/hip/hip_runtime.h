@@ -409,6 +409,9 @@ static inline float __uint_as_float(unsigned u) { float f; memcpy(&f, &u, 4); re
 #define __logf(x) logf(x)
 static inline float __fdividef(float a, float b) { return a / b; }
 static inline float __frcp_rn(float a) { return 1.0f / a; }
+// separately rounded product / sum (never contracted into an fma)
+static inline float __fmul_rn(float a, float b) { volatile float r = a * b; return r; }
+static inline float __fadd_rn(float a, float b) { volatile float r = a + b; return r; }
 static inline float rsqrtf(float a) { return 1.0f / sqrtf(a); }
 #define __sinf(x) sinf(x)
 #define __cosf(x) cosf(x)

@@ -538,6 +538,40 @@ def test_duration_predictor(dev):
     assert rel2(pred, pred_r) < 2e-2
 
 
+def test_flow_prologue_kernel_matches_the_tensor_library(dev, monkeypatch):
+    """e2k_flow_pack (round 6): w / flow / cond of E2TTS.forward (e2_tts.py:1519-1543) and the projection's bf16 operands from one kernel.
+    flow and cond bit for bit the tensor-library expressions, w's bf16 image that of `(1 - t) * x0 + t * x1`; and a training step with
+    the fused prologue returns the same loss, cond, prediction and input-projection gradients as with E2K_FUSE_FLOW_PROLOGUE=0"""
+    from e2_tts_pytorch_amd import ops
+    import e2_tts_pytorch_amd.e2_tts as E
+    torch.manual_seed(5)
+    B, T, C = 3, 37, 100
+    x0, x1, t = torch.randn(B, T, C), torch.randn(B, T, C), torch.rand(B)
+    span = torch.rand(B, T) > 0.4
+    wb, cb, flow, cond = ops.flow_pack(x0.to(dev), x1.to(dev), t.to(dev), span.to(dev), 104)
+    w = (1. - t[:, None, None]) * x0 + t[:, None, None] * x1
+    c = torch.where(span[..., None], torch.zeros_like(x1), x1)
+    assert torch.equal(flow.cpu(), x1 - x0) and torch.equal(cond.cpu(), c)
+    assert torch.equal(wb.cpu()[:, :C].view(B, T, C), w.to(torch.bfloat16)) and torch.equal(cb.cpu()[:, :C].view(B, T, C), c.to(torch.bfloat16))
+    assert float(wb.cpu()[:, C:].float().abs().max()) == 0. and float(cb.cpu()[:, C:].float().abs().max()) == 0.
+    kw = dict(dim=256, depth=2, heads=4, dropout=0.)
+    ref, model = _pair(kw)
+    model = model.to(dev)
+    mel = torch.randn(2, 40, 100).to(dev)
+    noise = dict(x0=torch.randn(2, 40, 100).to(dev), times=torch.rand(2).to(dev), frac_lengths=torch.tensor([0.75, 0.9]).to(dev),
+                 span_rand=torch.tensor([0.2, 0.7]).to(dev), drop_text_cond=False)
+    outs = []
+    for fuse in (True, False):
+        monkeypatch.setattr(E, '_FUSE_FLOW_PROLOGUE', fuse)
+        model.zero_grad(set_to_none=True)
+        out = model(mel, text=['Hello', 'Goodbye'], _noise=noise)
+        out.loss.backward()
+        outs.append((out.loss.detach().cpu(), out.cond.cpu(), out.pred_flow.detach().cpu(), model.proj_in.weight.grad.cpu().clone(),
+                     model.cond_proj_in.weight.grad.cpu().clone(), model.proj_in.bias.grad.cpu().clone()))
+    for a, b in zip(*outs):
+        assert torch.equal(a, b)
+
+
 def test_duration_predictor_hl_gauss_classification(dev):
     """DurationPredictor(hl_gauss_loss=dict(...), use_regression=False) (e2_tts.py:966-967,1035-1040; round 6: refused before): the
     duration as a histogram over bins (arXiv 2403.03950) -- loss, gradient of the classification head and predictions against the

@@ -192,7 +192,12 @@ def test_cfg3_dims_depth24(init, B):
         return
     if init == 'trained_like':
         assert rec['pred_flow_rel_l2'] < 1e-2, rec['pred_flow_rel_l2']       # trained-like weight statistics: the north-star tolerance, asserted directly
-        assert max(rec['weight_grad_rel_l2_by_layer'].values()) < 0.03, rec['weight_grad_rel_l2_by_layer']
+        # per layer 0.9-1.4 % (bf16-emulated oracle 0.55-1.0 %); `transformer.other` holds the hyper-connection projections whose gradients
+        # bf16 storage alone moves by 30 % in the oracle (12 % here), `head` the 100-channel projections (3.5 % on both sides)
+        em = rec['weight_grad_rel_l2_by_layer_of_bf16_emulated_oracle']
+        bad = {k: (v, em[k]) for k, v in rec['weight_grad_rel_l2_by_layer'].items() if v > max(0.03, 1.5 * em[k] + 0.01)}
+        assert not bad, bad
+        assert max(v for k, v in rec['weight_grad_rel_l2_by_layer'].items() if k.startswith('transformer.layers.')) < 0.03
         return
     # measured on MI355X: 0.7-1.3 % per layer; the worst single tensor is the zero-initialised hyper-connection mixing
     # projection of the last layer (12 %: a (D, 5) sum over all tokens of products with a tiny gradient), every weight
@@ -272,8 +277,11 @@ def test_cfg5_sample_batch8_1024_frames():
     assert s.shape == s_r.shape == (B, dur, 100) and e < 1e-2, e
 
 
-def test_cfg5_exact_shape_rows_against_oracle():
-    """cfg5 as BASELINE.json states it -- B = 32, prompt of 5 frames, 1024 target frames, the cfg3 transformer (dim 1024, depth 24, 16
+@pytest.mark.parametrize('steps,rows', [(2, [0, 19, 31]), (5, [7, 24])])
+def test_cfg5_exact_shape_rows_against_oracle(steps, rows):
+    """(round 6: also FOUR midpoint intervals -- steps = 5: 16 backbone forwards at B = 32, the integration error of the depth-24 stack
+    accumulating over the intervals at the exact cfg5 shape, oracle on two rows.)
+    cfg5 as BASELINE.json states it -- B = 32, prompt of 5 frames, 1024 target frames, the cfg3 transformer (dim 1024, depth 24, 16
     heads), classifier-free guidance -- on the HIP path (no-grad launch plans at B = 32, both passes of an evaluation on two streams), one
     midpoint step (2 function evaluations x (cond + null) = 4 backbone forwards at B = 32; the CPU oracle of all 32 steps would hold the
     box for hours).  The samples of a batch do not interact (per-sample masks, per-sample CFG projection, e2_tts.py:113-124,1303-1330),
@@ -281,7 +289,7 @@ def test_cfg5_exact_shape_rows_against_oracle():
     torch.set_num_threads(min(32, os.cpu_count() or 1))
     kw = dict(dim=1024, depth=24, heads=16, dropout=0.)
     ref, model = _pair(kw, 'reference_init', seed=5)
-    B, Tp, dur, steps, rows = 32, 5, 1024, 2, [0, 19, 31]
+    B, Tp, dur = 32, 5, 1024
     cond = torch.randn(B, Tp, 100)
     y0 = torch.randn(B, dur, 100)
     rng = random.Random(5)
@@ -289,7 +297,7 @@ def test_cfg5_exact_shape_rows_against_oracle():
     s = model.sample(cond.cuda(), text=text, duration=dur, steps=steps, cfg_strength=1., _y0=y0.cuda())
     s_r = ref.sample(cond[rows], text=[text[r] for r in rows], duration=dur, steps=steps, cfg_strength=1., _y0=y0[rows])
     errs = [rel2(s[r], s_r[i]) for i, r in enumerate(rows)]
-    _report('cfg5_exact_shape_rows', dict(case='sample() at cfg5 exactly (B 32, 1024 frames, cfg3 dims), one midpoint step, oracle on rows', kw=kw,
+    _report(f'cfg5_exact_shape_rows_{steps - 1}_intervals', dict(case=f'sample() at cfg5 exactly (B 32, 1024 frames, cfg3 dims), {steps - 1} midpoint interval(s), oracle on rows', kw=kw,
                                           B=B, prompt=Tp, duration=dur, steps=steps, rows=rows, sampled_mel_rel_l2_per_row=errs))
     print('sampled mel rel-L2 per row at cfg5', errs)
     assert s.shape == (B, dur, 100) and torch.isfinite(s).all()
