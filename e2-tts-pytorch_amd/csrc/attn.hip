@@ -270,7 +270,7 @@ __device__ __forceinline__ void score_tile(const unsigned char* Kt, const bf16x8
 // Register-staged forward: the fallback for sequences whose key mask does not fit the ring kernel's LDS (Npad > 4096) and
 // the E2K_ATTN_NO_RING A/B.  NW = waves per workgroup (4 = 64 query rows; a 128-row variant changed nothing on MI355X,
 // profiles/r02_attn_ablate.json, and is not instantiated).  Every workgroup sweeps ALL key / value tiles of its (batch,
-// head).  Its loop holds an ordinary global load (the key mask) behind the next tile's prefetch: see attn_bwd_dq_ring_kernel
+// head).  Its loop holds an ordinary global load (the key mask) behind the next tile's prefetch: see attn_dq32_kernel in attn32.hip
 // for what that costs.
 // PROBE: the bottleneck probes (E2K_ATTN_PROBE_*) are compiled into a separate instantiation: the product kernel carries none of their branches
 template <bool DROP, bool SHARE, int NW, bool PROBE = false>      // SHARE: dropout keep masks are handed from the forward to the backward (p.dropbits)
@@ -401,198 +401,6 @@ __global__ __launch_bounds__(NW * 64, NW == 8 ? 4 : 2) void attn_fwd_kernel(Attn
             }
         }
         if (!(PROBE && (p.probe & E2K_ATTN_PROBE_NO_BARRIER))) __syncthreads();
-    }
-    float lsum = lsum2[0] + lsum2[1];           // a row's keys are spread over the lanes l, l+16, l+32, l+48
-    lsum += __shfl_xor(lsum, 16);
-    lsum += __shfl_xor(lsum, 32);
-    if (!qin) return;
-    const float inv = lsum > 0.f ? (DROP ? p.inv_keep : 1.f) / lsum : 0.f;
-    const float gt = p.gate[bh * p.N + q];
-    const bool qkeep = p.kmask[(long)b * p.Npad + q] != 0;
-    if (g == 0) p.lse2[bh * p.N + q] = log2f(fmaxf(lsum, 1e-37f));
-    const long orow = ((long)b * p.N + q) * ((long)p.H * DH) + h * DH;
-#pragma unroll
-    for (int ct = 0; ct < 4; ++ct) {
-        float v[4], vg[4];
-#pragma unroll
-        for (int r = 0; r < 4; ++r) {
-            v[r] = qkeep ? o[ct][r] * inv : 0.f;
-            vg[r] = v[r] * gt;
-        }
-        st<u32x2>(p.O + orow + ct * 16 + 4 * g, pack4(v));
-        st<u32x2>(p.Og + orow + ct * 16 + 4 * g, pack4(vg));
-    }
-}
-
-// ---- forward with an LDS-DMA ring ---------------------------------------------------------------------------------
-// Same arithmetic and the same LDS tile images as attn_fwd_kernel (NW = 4), different data movement.  K / V tiles go
-// HBM -> LDS directly (global_load_lds, no staging VGPRs, no LDS write pass) into a ring of 16-KB stages with a counted
-// s_waitcnt and ONE raw barrier per tile; the key mask of the whole row sits in LDS (no global load inside the tile loop),
-// and the dropout ballots of a tile leave through LDS as one 128-byte store instead of 16 scalar-lane stores.
-// Measured on MI355X (cfg3 shape, dropout 0.1 with mask publication): register-staged kernel 144.7 us; ring of 3 stages
-// (3 workgroups per CU) 141.9; ring of 4 (2 per CU) 140.9; ring of TWO stages = 112 VGPRs and 37 KB of LDS = FOUR workgroups
-// per CU: 115.4 us (no dropout: 93.1 -> 79.6).  The kernel is bound by dependency stalls (MFMA -> soft-max VALU -> MFMA
-// chains, 16 MFMAs between barriers), so the fourth wave per SIMD is what pays, not the deeper prefetch: RING = 2 is
-// the default.
-//   iteration t:  wait until tile t has landed (tile t+1 may stay in flight) | barrier | issue tile t+2 into the stage
-//                 tile t-1 was read from (every wave has passed the barrier, i.e. finished tile t-1) | compute tile t
-// The LDS images are those of tile_sstore_perm (K: row perm_inv(R), 16-byte slots XOR-swizzled by row & 7) and tile_sstore
-// (V^T), produced by permuting the per-lane SOURCE address (the LDS destination of an LDS-DMA is lane-linear).
-constexpr int RSTAGE = 16384;
-
-template <bool DROP, bool SHARE, int RING>       // RING stages: tiles are issued RING - 1 ahead
-__global__ __launch_bounds__(256, 2) void attn_fwd_ring_kernel(AttnArgs p) {
-    __shared__ __attribute__((aligned(16))) unsigned char smem[RING * RSTAGE + RKM];
-    lds_declare(smem, sizeof(smem));
-    unsigned char* const kms = smem + RING * RSTAGE;                 // key mask of this batch row (Npad bytes)
-    const int tid = threadIdx.x, lane = tid & 63, wave = uniform_i(tid >> 6);
-    const int l15 = lane & 15, g = lane >> 4;
-    const int ntiles = (p.N + 63) / 64;
-    const RingWG wg = ring_wg(p, ntiles);
-    const int q0 = wg.x * 64, h = wg.h, b = wg.b;
-    const long bh = (long)b * p.H + h;
-    const int q = q0 + wave * 16 + l15;
-    const bool qin = q < p.N;
-    const unsigned dstream = attn_stream(p.stream_id, (unsigned)bh);
-
-    // one BYTE of mask bits per 8 keys (the 8 mask bytes squeezed once per workgroup; squeezing them per tile and lane cost two
-    // 64-bit multiplies = six quarter-rate v_mul per tile in this loop)
-    for (int j = tid; j < p.Npad / 8; j += 256) kms[j] = (unsigned char)mask_bits(ld<unsigned long long>(p.kmask + (long)b * p.Npad + j * 8));
-    wait_lgkm0();                 // (the first barrier of the tile loop is a raw one: it publishes what has been WRITTEN)
-
-    bf16x8 qf[2];
-#pragma unroll
-    for (int kk = 0; kk < 2; ++kk)
-        qf[kk] = qin ? ld<bf16x8>(p.Q + (bh * p.N + q) * DH + kk * 32 + g * 8) : bf16x8{0, 0, 0, 0, 0, 0, 0, 0};
-
-    // staging: a [64][64] bf16 tile = 8 wave instructions of 8 LDS rows; wave w issues instructions 2w, 2w + 1 of K and of V^T
-    const bf16_t* Kbase = p.K + bh * p.N * DH;
-    const bf16_t* VTbase = p.VT + bh * DH * p.Npad;
-    int krow[2];                  // source row of K (inside a tile) for this lane's LDS position
-    unsigned kcol[2], voff[2];    // byte offsets: K column chunk; V^T row + column chunk
-#pragma unroll
-    for (int u = 0; u < 2; ++u) {
-        const int r = (wave * 2 + u) * 8 + (lane >> 3), sp = lane & 7;      // LDS row, 16-byte slot position
-        krow[u] = (r & 0x23) | ((r & 0x10) >> 2) | ((r & 0x0c) << 1);       // tile row stored at LDS row r (perm_inv^-1)
-        kcol[u] = (unsigned)((sp ^ (r & 7)) * 16);
-        voff[u] = (unsigned)(((long)r * p.Npad + (sp ^ (r & 7)) * 8) * 2);
-    }
-    auto issue = [&](int t, int stage) __attribute__((always_inline)) {
-        const int k0 = t * 64;
-        unsigned char* S = smem + stage * RSTAGE;
-#pragma unroll
-        for (int u = 0; u < 2; ++u) {
-            const int row = min(k0 + krow[u], p.N - 1);                     // keys past the end: any valid row (masked below)
-            glds16((const char*)Kbase + (long)row * (DH * 2) + kcol[u], S + (wave * 2 + u) * 1024);
-            glds16((const char*)VTbase + (long)k0 * 2 + voff[u], S + 8192 + (wave * 2 + u) * 1024);
-        }
-    };
-
-    f32x4 o[4];
-#pragma unroll
-    for (int ct = 0; ct < 4; ++ct) o[ct] = f32x4{0.f, 0.f, 0.f, 0.f};
-    f32x2_ lsum2 = {0.f, 0.f};
-    const float kx = p.scale / CLAMP;
-    const float k2 = 2.f * LOG2E * kx, cl2 = CLAMP * LOG2E;
-    const ClampPoly cp = clamp_poly(kx, cl2);
-    const unsigned hrow = rand_base(p.seed_dev ? *p.seed_dev : p.seed, dstream) + (unsigned)q * 0x85ebca77u;
-    const unsigned hlane = hrow + (unsigned)(2 * g) * 0xc2b2ae3du;
-
-    // every ordinary global load of the prologue must have been waited for BEFORE the first LDS-DMA is issued: the
-    // compiler counts vmcnt in order, so a Q fragment first used inside the loop would make it drain the whole prefetch
-    // queue there (s_waitcnt vmcnt(0) in every iteration)
-    asm volatile("" ::"v"(qf[0]), "v"(qf[1]), "v"(hrow));
-#pragma unroll
-    for (int d = 0; d < RING - 1; ++d)
-        if (d < ntiles) issue(d, d);
-    int stage = 0;
-    for (int kt = 0; kt < ntiles; ++kt) {
-        const int k0 = kt * 64;
-        // tile kt must have landed for this wave; the younger tiles kt + 1 .. kt + RING - 2 (4 loads each) may stay in flight
-        const int fly = min(RING - 2, ntiles - 1 - kt);
-        if (fly >= 2) wait_vmcnt<8>();
-        else if (fly == 1) wait_vmcnt<4>();
-        else wait_vmcnt<0>();
-        barrier_raw();                                  // ... and for every wave; everyone has finished tile kt - 1
-        if (kt + RING - 1 < ntiles) issue(kt + RING - 1, stage == 0 ? RING - 1 : stage - 1);
-        const unsigned char* Kt = smem + stage * RSTAGE;
-        const unsigned char* Vt = Kt + 8192;
-        f32x4 s[4];
-        score_tile(Kt, qf, l15, g, s);
-        const unsigned km = (unsigned)kms[(k0 >> 3) + g] | ((unsigned)kms[(k0 >> 3) + 4 + g] << 8);
-        const bool allk = wave_all(km == 0xffffu);
-        if (wave_all(abs_max16(s) * kx <= TANH_POLY_MAX)) {
-#pragma unroll
-            for (int t = 0; t < 4; ++t)
-#pragma unroll
-                for (int r = 0; r < 4; r += 2) {
-                    const f32x2_ z = clamp2(f32x2_{s[t][r], s[t][r + 1]}, cp);
-                    s[t][r] = z[0];
-                    s[t][r + 1] = z[1];
-                }
-        } else {
-#pragma unroll
-            for (int t = 0; t < 4; ++t)
-#pragma unroll
-                for (int r = 0; r < 4; ++r) s[t][r] = clamp_tanh_scaled(s[t][r], k2, cl2);
-        }
-        if (!allk) {
-#pragma unroll
-            for (int t = 0; t < 4; ++t)
-#pragma unroll
-                for (int r = 0; r < 4; ++r) {
-                    const bool keep = (km >> (8 * (t >> 1) + 4 * (t & 1) + r)) & 1u;
-                    s[t][r] = keep ? s[t][r] : NEG_MASK;
-                }
-        }
-        unsigned long long mk[16];
-#pragma unroll
-        for (int t = 0; t < 4; ++t) {
-            float pr[4];
-#pragma unroll
-            for (int r = 0; r < 4; ++r) pr[r] = fast_exp2(s[t][r]);
-            lsum2 += f32x2_{pr[0], pr[1]};           // softmax denominators are taken BEFORE dropout
-            lsum2 += f32x2_{pr[2], pr[3]};
-            if (DROP) {
-                unsigned w0, w1;
-                drop4(hlane, (unsigned)(k0 >> 2) + 8 * (t >> 1) + (t & 1), w0, w1);
-                const bool kp[4] = {(w0 & 0xffffu) >= p.thresh, (w0 >> 16) >= p.thresh, (w1 & 0xffffu) >= p.thresh, (w1 >> 16) >= p.thresh};
-#pragma unroll
-                for (int r = 0; r < 4; ++r) {
-                    pr[r] = kp[r] ? pr[r] : 0.f;
-                    if (SHARE) mk[4 * t + r] = wave_ballot(kp[r]);
-                }
-            }
-#pragma unroll
-            for (int r = 0; r < 4; ++r) s[t][r] = pr[r];
-        }
-        if (DROP && SHARE) {
-            // the 16 compare masks of this tile (SGPR pairs): mask i is written into lane i's registers (v_writelane), lanes 0-15
-            // store them as one 128-byte line.  (Round 3 parked them in LDS through lane 0: 33 v_mov + 8 ds_write_b128 under an
-            // exec mask, a wave barrier and a read back per tile.)
-            unsigned blo = 0, bhi = 0;
-#pragma unroll
-            for (int i = 0; i < 16; ++i) {
-                blo = wave_writelane(blo, (unsigned)mk[i], i);
-                bhi = wave_writelane(bhi, (unsigned)(mk[i] >> 32), i);
-            }
-            if (lane < 16) {
-                unsigned long long* dropw = p.dropbits + ((((long)bh * ntiles + kt) * ntiles + wg.x) * 4 + wave) * 16;
-                dropw[lane] = (unsigned long long)blo | ((unsigned long long)bhi << 32);
-            }
-        }
-#pragma unroll
-        for (int kk2 = 0; kk2 < 2; ++kk2) {
-            float lo[4] = {s[2 * kk2][0], s[2 * kk2][1], s[2 * kk2][2], s[2 * kk2][3]};
-            float hi[4] = {s[2 * kk2 + 1][0], s[2 * kk2 + 1][1], s[2 * kk2 + 1][2], s[2 * kk2 + 1][3]};
-            bf16x8 pf = pack_frag(lo, hi);
-#pragma unroll
-            for (int ct = 0; ct < 4; ++ct) {
-                bf16x8 vf = tile_frag(Vt, ct * 16 + l15, kk2 * 4 + g);
-                o[ct] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(vf, pf, o[ct], 0, 0, 0);
-            }
-        }
-        stage = stage == RING - 1 ? 0 : stage + 1;
     }
     float lsum = lsum2[0] + lsum2[1];           // a row's keys are spread over the lanes l, l+16, l+32, l+48
     lsum += __shfl_xor(lsum, 16);
@@ -790,192 +598,6 @@ __global__ __launch_bounds__(NW * 64, 2) void attn_bwd_dq_kernel(AttnArgs p) {
     }
 }
 
-// dQ with LDS-DMA staging and transposing LDS reads (default; the kernel above stays as the E2K_ATTN_NO_RING fallback):
-//   * K and V tiles go global -> LDS by global_load_lds into a 2-stage ring (no staging registers), the key mask of the
-//     batch row sits in LDS: the loop holds NO ordinary global load.  In the kernel above the key-mask load follows the
-//     next tile's prefetch loads in program order, and vmcnt is counted in order: its s_waitcnt vmcnt(1) / vmcnt(0) before
-//     the element-wise phase waits for the WHOLE prefetch, i.e. the HBM / L2 latency of a tile is exposed in every
-//     iteration (that, not the arithmetic, was the "dependency stall" of the round-2 ablation)
-//   * K^T for dQ^T = K^T . dS^T is read from the row-major K tile with ds_read_b64_tr_b16: the transposed copy KT in HBM
-//     is not read
-//   * one half of the key tile (32 keys) at a time from the score MFMAs to the dQ MFMAs
-// Keys past the end of the sequence are read from row N - 1 and masked through the key mask (0 past N).
-template <bool DROP, bool SHARE>
-__global__ __launch_bounds__(256, 3) void attn_bwd_dq_ring_kernel(AttnArgs p) {
-    __shared__ __attribute__((aligned(16))) unsigned char smem[2 * RSTAGE + RKM];
-    lds_declare(smem, sizeof(smem));
-    unsigned char* const kms = smem + 2 * RSTAGE;
-    const int tid = threadIdx.x, lane = tid & 63, wave = uniform_i(tid >> 6);
-    const int l15 = lane & 15, g = lane >> 4;
-    const int ntiles = (p.N + 63) / 64;
-    const RingWG wg = ring_wg(p, ntiles);
-    const int q0 = wg.x * 64, h = wg.h, b = wg.b;
-    const long bh = (long)b * p.H + h;
-    const int q = q0 + wave * 16 + l15;
-    const bool qin = q < p.N;
-    const unsigned dstream = attn_stream(p.stream_id, (unsigned)bh);
-
-    // one BYTE of mask bits per 8 keys (the 8 mask bytes squeezed once per workgroup; squeezing them per tile and lane cost two
-    // 64-bit multiplies = six quarter-rate v_mul per tile in this loop)
-    for (int j = tid; j < p.Npad / 8; j += 256) kms[j] = (unsigned char)mask_bits(ld<unsigned long long>(p.kmask + (long)b * p.Npad + j * 8));
-
-    bf16x8 qf[2], dof[2];
-#pragma unroll
-    for (int kk = 0; kk < 2; ++kk) {
-        qf[kk] = qin ? ld<bf16x8>(p.Q + (bh * p.N + q) * DH + kk * 32 + g * 8) : bf16x8{0, 0, 0, 0, 0, 0, 0, 0};
-        dof[kk] = qin ? ld<bf16x8>(p.dO + (bh * p.N + q) * DH + kk * 32 + g * 8) : bf16x8{0, 0, 0, 0, 0, 0, 0, 0};
-    }
-    const float kx = p.scale / CLAMP;
-    const float k2 = 2.f * LOG2E * kx, cl2 = CLAMP * LOG2E;
-    const ClampPoly cp = clamp_poly(kx, 1.f);
-    // dS = P (dP - delta) (1 - th^2) scale: the trailing `scale` is folded into the exponent of P (lse - log2(scale))
-    const float lse = qin ? p.lse2[bh * p.N + q] - log2f(p.scale) : 1e30f;
-    const float dl = qin ? p.delta[bh * p.N + q] : 0.f;
-    const unsigned hrow = rand_base(p.seed_dev ? *p.seed_dev : p.seed, dstream) + (unsigned)q * 0x85ebca77u;
-    const unsigned hlane = hrow + (unsigned)(2 * g) * 0xc2b2ae3du;
-
-    f32x4 dq[4];
-#pragma unroll
-    for (int ct = 0; ct < 4; ++ct) dq[ct] = f32x4{0.f, 0.f, 0.f, 0.f};
-
-    // staging (as in attn_fwd_ring_kernel): wave w issues the wave instructions 2w, 2w + 1 (8 LDS rows each) of K and of V,
-    // both as tile_sstore_perm images
-    const bf16_t* Kbase = p.K + bh * p.N * DH;
-    const bf16_t* Vbase = p.V + bh * p.N * DH;
-    int srow[2];
-    unsigned scol[2];
-#pragma unroll
-    for (int u = 0; u < 2; ++u) {
-        const int r = (wave * 2 + u) * 8 + (lane >> 3), sp = lane & 7;
-        srow[u] = (r & 0x23) | ((r & 0x10) >> 2) | ((r & 0x0c) << 1);
-        scol[u] = (unsigned)((sp ^ (r & 7)) * 16);
-    }
-    auto issue = [&](int t, int stage) __attribute__((always_inline)) {
-        const int k0 = t * 64;
-        unsigned char* S = smem + stage * RSTAGE;
-#pragma unroll
-        for (int u = 0; u < 2; ++u) {
-            const long row = min(k0 + srow[u], p.N - 1);
-            glds16((const char*)Kbase + row * (DH * 2) + scol[u], S + (wave * 2 + u) * 1024);
-            glds16((const char*)Vbase + row * (DH * 2) + scol[u], S + 8192 + (wave * 2 + u) * 1024);
-        }
-    };
-    // transposing reads of K^T (see attn_bwd_dkv_ring_kernel): lane (i = l15, g) addresses key 8g + (i >> 2) (+ 4, + 32 kk2)
-    const int rho = (l15 >> 2) | ((g & 1) << 2);
-    const int troff = ((l15 >> 2) | (g << 2)) * 128 + (l15 & 1) * 8;
-    const int tslot = ((l15 & 3) >> 1) ^ (rho & 1);
-    int trc[4];
-#pragma unroll
-    for (int ct = 0; ct < 4; ++ct) trc[ct] = troff + ((((2 * ct) ^ (rho & 6)) | tslot) << 4);
-
-    __syncthreads();                 // key mask row is in LDS; every ordinary load above has been waited for
-    asm volatile("" ::"v"(qf[0]), "v"(qf[1]), "v"(dof[0]), "v"(dof[1]), "v"(lse), "v"(dl), "v"(hrow));
-    issue(0, 0);
-    for (int kt = 0; kt < ntiles; ++kt) {
-        const int k0 = kt * 64;
-        wait_vmcnt<0>();
-        barrier_raw();
-        if (kt + 1 < ntiles) issue(kt + 1, (kt + 1) & 1);
-        const unsigned char* Kt = smem + (kt & 1) * RSTAGE;
-        const unsigned char* Vr = Kt + 8192;
-        const unsigned km = (unsigned)kms[(k0 >> 3) + g] | ((unsigned)kms[(k0 >> 3) + 4 + g] << 8);
-        const bool allk = wave_all(km == 0xffffu);
-        const unsigned long long* dropw = (DROP && SHARE)
-            ? p.dropbits + ((((long)bh * ntiles + kt) * ntiles + wg.x) * 4 + wave) * 16 : nullptr;
-#pragma unroll
-        for (int kk2 = 0; kk2 < 2; ++kk2) {
-            s16x4_ klo[4], khi[4];
-#pragma unroll
-            for (int ct = 0; ct < 4; ++ct) {
-                lds_tr_issue(klo[ct], Kt + trc[ct], kk2 * (32 * 128));
-                lds_tr_issue(khi[ct], Kt + trc[ct], kk2 * (32 * 128) + 16 * 128);
-            }
-            float dsv[2][4];
-            // scores and dP of both 16-key blocks of this half first, the first reduction halves of all four products before the
-            // second ones (an accumulating MFMA issued right behind its predecessor waits out its latency)
-            f32x4 st2[2], dp2[2];
-            {
-                bf16x8 kfr[2][2], vfr[2][2];
-#pragma unroll
-                for (int kk = 0; kk < 2; ++kk)
-#pragma unroll
-                    for (int tt = 0; tt < 2; ++tt) {
-                        kfr[kk][tt] = tile_frag(Kt, 16 * (2 * kk2 + tt) + l15, kk * 4 + g);
-                        vfr[kk][tt] = tile_frag(Vr, 16 * (2 * kk2 + tt) + l15, kk * 4 + g);
-                    }
-#pragma unroll
-                for (int tt = 0; tt < 2; ++tt) {
-                    st2[tt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(kfr[0][tt], qf[0], f32x4{0.f, 0.f, 0.f, 0.f}, 0, 0, 0);
-                    dp2[tt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(vfr[0][tt], dof[0], f32x4{0.f, 0.f, 0.f, 0.f}, 0, 0, 0);      // dP^T = V . dO^T
-                }
-#pragma unroll
-                for (int tt = 0; tt < 2; ++tt) {
-                    st2[tt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(kfr[1][tt], qf[1], st2[tt], 0, 0, 0);
-                    dp2[tt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(vfr[1][tt], dof[1], dp2[tt], 0, 0, 0);
-                }
-            }
-#pragma unroll
-            for (int tt = 0; tt < 2; ++tt) {
-                const int t = 2 * kk2 + tt;
-                // s[r] <-> key perm_row(t, 4g+r), q = l&15
-                const f32x4 st_ = st2[tt], dpt = dp2[tt];
-                const float am = fmaxf(fmaxf(fabsf(st_[0]), fabsf(st_[1])), fmaxf(fabsf(st_[2]), fabsf(st_[3])));
-                const bool small = wave_all(am * kx <= TANH_POLY_MAX);
-                float ks[4] = {1.f, 1.f, 1.f, 1.f};
-                if (DROP) {
-                    if (SHARE) {             // the forward's compare masks: same lane <-> (query, key) layout as here
-#pragma unroll
-                        for (int r = 0; r < 4; ++r) ks[r] = wave_inverse_ballot(sload64(dropw + 4 * t + r)) ? p.inv_keep : 0.f;
-                    } else {
-                        unsigned w0, w1;
-                        drop4(hlane, (unsigned)(k0 >> 2) + 8 * (t >> 1) + (t & 1), w0, w1);
-                        ks[0] = (w0 & 0xffffu) >= p.thresh ? p.inv_keep : 0.f;
-                        ks[1] = (w0 >> 16) >= p.thresh ? p.inv_keep : 0.f;
-                        ks[2] = (w1 & 0xffffu) >= p.thresh ? p.inv_keep : 0.f;
-                        ks[3] = (w1 >> 16) >= p.thresh ? p.inv_keep : 0.f;
-                    }
-                }
-#pragma unroll
-                for (int r = 0; r < 4; r += 2) {
-                    f32x2_ th;
-                    if (small) th = clamp2(f32x2_{st_[r], st_[r + 1]}, cp);
-                    else th = f32x2_{clamp_tanh(st_[r], k2), clamp_tanh(st_[r + 1], k2)};
-                    const f32x2_ arg = th * cl2 - lse;
-                    const f32x2_ pv = {fast_exp2(arg[0]), fast_exp2(arg[1])};
-                    f32x2_ t1 = f32x2_{dpt[r], dpt[r + 1]};
-                    if (DROP) t1 = t1 * f32x2_{ks[r], ks[r + 1]};
-                    t1 = t1 - dl;
-                    const f32x2_ t2 = 1.f - th * th;
-                    const f32x2_ ds = (pv * t1) * t2;
-                    dsv[tt][r] = ds[0];
-                    dsv[tt][r + 1] = ds[1];
-                }
-                if (!allk) {        // masked keys contribute nothing (only the last tile or two of a sequence)
-#pragma unroll
-                    for (int r = 0; r < 4; ++r) {
-                        const bool keep = (km >> (8 * kk2 + 4 * tt + r)) & 1u;
-                        dsv[tt][r] = keep ? dsv[tt][r] : 0.f;
-                    }
-                }
-            }
-            bf16x8 pf = pack_frag(dsv[0], dsv[1]);
-            lds_tr_wait(klo[0], khi[0], klo[1], khi[1], klo[2], khi[2], klo[3], khi[3]);
-#pragma unroll
-            for (int ct = 0; ct < 4; ++ct) {
-                bf16x8 ktf = __builtin_shufflevector(klo[ct], khi[ct], 0, 1, 2, 3, 4, 5, 6, 7);
-                dq[ct] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ktf, pf, dq[ct], 0, 0, 0);
-            }
-        }
-    }
-    if (!qin) return;
-    const long orow = (bh * p.N + q) * DH;
-#pragma unroll
-    for (int ct = 0; ct < 4; ++ct) {
-        float v[4] = {dq[ct][0], dq[ct][1], dq[ct][2], dq[ct][3]};
-        st<u32x2>(p.dQ + orow + ct * 16 + 4 * g, pack4(v));
-    }
-}
-
 // dK, dV: one workgroup per 16 NW keys (a wave owns 16), sweep over query tiles.
 //   S = Q.K^T (rows = queries, permuted inside the tile), P^T-like accumulators feed dV^T = dO^T.P and dK^T = Q^T.dS
 template <bool DROP, bool SHARE, int NW>      // SHARE: dropout keep masks are handed from the forward to the backward (p.dropbits)
@@ -1136,245 +758,6 @@ __global__ __launch_bounds__(NW * 64, 2) void attn_bwd_dkv_kernel(AttnArgs p) {
 }
 
 
-// dK, dV with LDS-DMA staging and transposing LDS reads (default): the same arithmetic as attn_bwd_dkv_kernel<.., 4>, but
-//   * the Q and dO tiles (and the 64 lse / delta values that go with them) go global -> LDS by global_load_lds into a
-//     2-stage ring: no staging registers (the register-staged kernel holds four 64x64 tiles = 32 VGPRs across the compute
-//     phase), which is what brings the kernel under 168 VGPRs = three waves per SIMD instead of two
-//   * the A operands of the dV^T = dO^T.P and dK^T = Q^T.dS MFMAs (dO^T, Q^T: dh rows, 8 consecutive queries per lane)
-//     are read from the SAME row-major tiles with ds_read_b64_tr_b16: the transposed copies QT / dOT in HBM are not read
-//     (half the LDS footprint and half the tile traffic)
-// Rows past the end of the sequence are read from row N - 1 and switched off through lse = 1e30 (p = exp2(-1e30) = 0).
-constexpr int DSTAGE = 2 * 8192 + 512;
-
-// (three waves per SIMD: with dropout masks handed over it needs 152 VGPRs.  Compiled for four -- 128 VGPRs, 24 dwords spilled
-//  into the loop -- the backward of a cfg3 attention call took 366 us instead of 282, profiles/r04_attn_micro_ab.txt)
-template <bool DROP, bool SHARE, bool L32 = false>       // L32: the keep masks come in the layout attn_fwd32_kernel publishes (attn32.hip)
-__global__ __launch_bounds__(256, 3) void attn_bwd_dkv_ring_kernel(AttnArgs p) {
-    __shared__ __attribute__((aligned(16))) unsigned char smem[2 * DSTAGE];
-    lds_declare(smem, sizeof(smem));
-    const int tid = threadIdx.x, lane = tid & 63, wave = uniform_i(tid >> 6);
-    const int l15 = lane & 15, g = lane >> 4;
-    const RingWG wg = ring_wg(p, (p.N + 63) / 64);
-    const int k0 = wg.x * 64, h = wg.h, b = wg.b;
-    const int kt64 = wg.x;
-    const long bh = (long)b * p.H + h;
-    const int key = k0 + wave * 16 + l15;
-    const bool kin = key < p.N;
-    const int kkeep = kin && p.kmask[(long)b * p.Npad + key] != 0;
-    const unsigned dstream = attn_stream(p.stream_id, (unsigned)bh);
-
-    bf16x8 kf[2], vf[2];
-#pragma unroll
-    for (int kk = 0; kk < 2; ++kk) {
-        kf[kk] = kin ? ld<bf16x8>(p.K + (bh * p.N + key) * DH + kk * 32 + g * 8) : bf16x8{0, 0, 0, 0, 0, 0, 0, 0};
-        vf[kk] = kin ? ld<bf16x8>(p.V + (bh * p.N + key) * DH + kk * 32 + g * 8) : bf16x8{0, 0, 0, 0, 0, 0, 0, 0};
-    }
-    f32x4 dk[4], dv[4];
-#pragma unroll
-    for (int ct = 0; ct < 4; ++ct) { dk[ct] = f32x4{0.f, 0.f, 0.f, 0.f}; dv[ct] = f32x4{0.f, 0.f, 0.f, 0.f}; }
-    const float kx = p.scale / CLAMP;
-    const float k2 = 2.f * LOG2E * kx, cl2 = CLAMP * LOG2E;
-    const ClampPoly cp = clamp_poly(kx, 1.f);
-    const unsigned hkey = rand_base(p.seed_dev ? *p.seed_dev : p.seed, dstream) + ((unsigned)key >> 2) * 0xc2b2ae3du;
-
-    const int ntiles = (p.N + 63) / 64;
-    const bf16_t* Qbase = p.Q + bh * p.N * DH;
-    const bf16_t* dObase = p.dO + bh * p.N * DH;
-    const float* lsebase = p.lse2 + bh * p.N;
-    const float* delbase = p.delta + bh * p.N;
-
-    // staging: a [64][64] bf16 tile = 8 wave instructions of 8 LDS rows; wave w issues instructions 2w, 2w + 1 of Q and dO
-    // (LDS image of tile_sstore_perm: tile row R at LDS row perm_inv(R), 16-byte slots XOR-swizzled by row & 7), wave 0
-    // the 64 lse values, wave 1 the 64 delta values
-    int srow[2];
-    unsigned scol[2];
-#pragma unroll
-    for (int u = 0; u < 2; ++u) {
-        const int r = (wave * 2 + u) * 8 + (lane >> 3), sp = lane & 7;
-        srow[u] = (r & 0x23) | ((r & 0x10) >> 2) | ((r & 0x0c) << 1);
-        scol[u] = (unsigned)((sp ^ (r & 7)) * 16);
-    }
-    auto issue = [&](int t, int stage) __attribute__((always_inline)) {
-        const int q0 = t * 64;
-        unsigned char* S = smem + stage * DSTAGE;
-#pragma unroll
-        for (int u = 0; u < 2; ++u) {
-            const long row = min(q0 + srow[u], p.N - 1);
-            glds16((const char*)Qbase + row * (DH * 2) + scol[u], S + (wave * 2 + u) * 1024);
-            glds16((const char*)dObase + row * (DH * 2) + scol[u], S + 8192 + (wave * 2 + u) * 1024);
-        }
-        if (wave < 2) glds4((wave == 0 ? lsebase : delbase) + min(q0 + lane, p.N - 1), S + 16384 + wave * 256);
-    };
-    // transposing reads: lane (i = l15, g) addresses query 8g + (i >> 2) (+ 4, + 32 kk2) = LDS row (i >> 2) | g << 2
-    // (| 16, | 32 kk2), columns 16 ct + 4 (i & 3) ..; it receives column 16 ct + i of queries 8g .. 8g + 3 (+ 4)
-    const int rho = (l15 >> 2) | ((g & 1) << 2);                  // LDS row & 7
-    const int troff = ((l15 >> 2) | (g << 2)) * 128 + (l15 & 1) * 8;
-    const int tslot = ((l15 & 3) >> 1) ^ (rho & 1);
-    int trc[4];                   // per 16-column group ct: byte offset of this lane's 8 bytes inside the tile
-#pragma unroll
-    for (int ct = 0; ct < 4; ++ct) trc[ct] = troff + ((((2 * ct) ^ (rho & 6)) | tslot) << 4);
-    // (lds_tr_issue, not the builtin: see e2k_asm.h -- the builtin would drain the LDS-DMA queue in every iteration)
-    auto tr_issue4 = [&](s16x4_ (&lo)[4], s16x4_ (&hi)[4], const unsigned char* T, int kk2) __attribute__((always_inline)) {
-#pragma unroll
-        for (int ct = 0; ct < 4; ++ct) {
-            lds_tr_issue(lo[ct], T + trc[ct], kk2 * (32 * 128));
-            lds_tr_issue(hi[ct], T + trc[ct], kk2 * (32 * 128) + 16 * 128);
-        }
-    };
-    // Shared dropout masks: score (t, r) of this lane is (query qi = 32(t>>1) + 8g + 4(t&1) + r, key pos = 16 wave + l15).
-    // In the forward that pair sat in wave qi >> 4 = 2(t>>1) + (g>>1), lane 16 g' + (qi & 15), slot 4t' + r', with
-    // (t', g', r') the position of THIS key in the forward's key permutation: one 64-bit word per (t>>1) covers
-    // all eight (t&1, r) of it.  The words of tile qt + 1 are fetched while tile qt is computed.
-    const int pos = wave * 16 + l15;
-    const int dbit0 = 16 * ((pos >> 3) & 3) + 8 * (g & 1);        // (a multiple of 8: the eight bits are ONE BYTE of the word)
-    const unsigned char* dbase = nullptr;
-    unsigned dnext[2] = {0u, 0u};
-    // L32: the forward keeps (query, key) in ballot word [key tile][32-query block][16 kbf + 8 sf + ef], bit (query & 31) + 32 hif, with
-    // key & 63 = 32 kbf + 16 sf + 8 hif + ef: this lane's eight queries 8 g .. 8 g + 7 of a 32-query block are byte g of the key's half word
-    const int nqb = (p.N + 31) / 32;
-    const long dstep = L32 ? 2L * 32 * 8 : 64L * 8;              // bytes from one 64-query tile to the next
-    const long dhalf = L32 ? 32L * 8 : 2L * 16 * 8;               // ... from its first 32-query half to the second
-    if (DROP && SHARE) {
-        if (L32) {
-            const int wf = 16 * (pos >> 5) + 8 * ((pos >> 4) & 1) + (pos & 7), hif = (pos >> 3) & 1;
-            dbase = (const unsigned char*)(p.dropbits + ((long)bh * ntiles + kt64) * nqb * 32 + wf) + 4 * hif + g;
-        } else {
-            const int tf = 2 * (pos >> 5) + ((pos >> 2) & 1), rf = pos & 3;
-            dbase = (const unsigned char*)(p.dropbits + ((((long)bh * ntiles + kt64) * ntiles) * 4 + (g >> 1)) * 16 + 4 * tf + rf) + (dbit0 >> 3);
-        }
-        dnext[0] = dbase[0];
-        dnext[1] = (!L32 || 1 < nqb) ? dbase[dhalf] : 0u;
-    }
-    // every ordinary global load of the prologue is waited for BEFORE the first LDS-DMA (see attn_fwd_ring_kernel)
-    asm volatile("" ::"v"(kf[0]), "v"(kf[1]), "v"(vf[0]), "v"(vf[1]), "v"(hkey), "v"(kkeep));
-    issue(0, 0);
-    for (int qt = 0; qt < ntiles; ++qt) {
-        const int q0 = qt * 64;
-        wait_vmcnt<0>();                 // tile qt has landed for this wave ...
-        barrier_raw();                   // ... and for every wave; everyone has finished tile qt - 1
-        const unsigned dword[2] = {dnext[0], dnext[1]};
-        if (qt + 1 < ntiles) {
-            if (DROP && SHARE) {
-                dnext[0] = dbase[(qt + 1) * dstep];
-                dnext[1] = (!L32 || 2 * qt + 3 < nqb) ? dbase[(qt + 1) * dstep + dhalf] : 0u;      // (L32: the last 64-query tile may hold one 32-query block)
-            }
-            issue(qt + 1, (qt + 1) & 1);
-        }
-        const unsigned char* Qt = smem + (qt & 1) * DSTAGE;
-        const unsigned char* dOt = Qt + 8192;
-        const float* lse_s = (const float*)(Qt + 16384);
-        const float* del_s = lse_s + 64;
-        const bool tail = q0 + 64 > p.N;
-#pragma unroll
-        for (int kk2 = 0; kk2 < 2; ++kk2) {
-            float pd[2][4], dsv[2][4];
-            const unsigned dbits = dword[kk2];       // this lane's eight keep bits of the half tile (one byte of the forward's ballot word)
-            // (all four products' first reduction halves before the second ones: see attn_bwd_dq_ring_kernel)
-            f32x4 st2[2], dp2[2];
-            {
-                bf16x8 qfr[2][2], dofr[2][2];
-#pragma unroll
-                for (int kk = 0; kk < 2; ++kk)
-#pragma unroll
-                    for (int tt = 0; tt < 2; ++tt) {
-                        qfr[kk][tt] = tile_frag(Qt, 16 * (2 * kk2 + tt) + l15, kk * 4 + g);
-                        dofr[kk][tt] = tile_frag(dOt, 16 * (2 * kk2 + tt) + l15, kk * 4 + g);
-                    }
-#pragma unroll
-                for (int tt = 0; tt < 2; ++tt) {
-                    st2[tt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(qfr[0][tt], kf[0], f32x4{0.f, 0.f, 0.f, 0.f}, 0, 0, 0);
-                    dp2[tt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(dofr[0][tt], vf[0], f32x4{0.f, 0.f, 0.f, 0.f}, 0, 0, 0);
-                }
-#pragma unroll
-                for (int tt = 0; tt < 2; ++tt) {
-                    st2[tt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(qfr[1][tt], kf[1], st2[tt], 0, 0, 0);
-                    dp2[tt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(dofr[1][tt], vf[1], dp2[tt], 0, 0, 0);
-                }
-            }
-#pragma unroll
-            for (int tt = 0; tt < 2; ++tt) {
-                const int t = 2 * kk2 + tt;
-                const f32x4 st_ = st2[tt], dpt = dp2[tt];
-                const float am = fmaxf(fmaxf(fabsf(st_[0]), fabsf(st_[1])), fmaxf(fabsf(st_[2]), fabsf(st_[3])));
-                const bool small = wave_all(am * kx <= TANH_POLY_MAX);
-                const int qi0 = perm_row(t, 4 * g);
-                f32x4 ls4 = ld<f32x4>(&lse_s[qi0]);
-                const f32x4 dl4 = ld<f32x4>(&del_s[qi0]);
-                if (tail) {
-#pragma unroll
-                    for (int r = 0; r < 4; ++r) ls4[r] = q0 + qi0 + r < p.N ? ls4[r] : 1e30f;
-                }
-                float ks[4] = {1.f, 1.f, 1.f, 1.f};
-                if (DROP) {
-#pragma unroll
-                    for (int r = 0; r < 4; ++r) {
-                        if (SHARE) {
-                            ks[r] = ((dbits >> (4 * tt + r)) & 1u) ? p.inv_keep : 0.f;
-                        } else {
-                            unsigned w0, w1;          // (hkey already holds base + (key >> 2) * 0xc2b2ae3d)
-                            drop4(hkey + (unsigned)(q0 + qi0 + r) * 0x85ebca77u, 0u, w0, w1);
-                            ks[r] = drop_sample(w0, w1, key & 3) >= p.thresh ? p.inv_keep : 0.f;
-                        }
-                    }
-                }
-#pragma unroll
-                for (int r = 0; r < 4; r += 2) {
-                    f32x2_ th;
-                    if (small) th = clamp2(f32x2_{st_[r], st_[r + 1]}, cp);
-                    else th = f32x2_{clamp_tanh(st_[r], k2), clamp_tanh(st_[r + 1], k2)};
-                    const f32x2_ arg = th * cl2 - f32x2_{ls4[r], ls4[r + 1]};
-                    const f32x2_ pr = {fast_exp2(arg[0]), fast_exp2(arg[1])};
-                    const f32x2_ k2s = {ks[r], ks[r + 1]};
-                    const f32x2_ pv = DROP ? pr * k2s : pr;
-                    f32x2_ t1 = f32x2_{dpt[r], dpt[r + 1]};
-                    if (DROP) t1 = t1 * k2s;
-                    t1 = t1 - f32x2_{dl4[r], dl4[r + 1]};
-                    const f32x2_ t2 = (th * -p.scale) * th + p.scale;
-                    const f32x2_ ds = (pr * t1) * t2;
-                    pd[tt][r] = pv[0];
-                    pd[tt][r + 1] = pv[1];
-                    dsv[tt][r] = ds[0];
-                    dsv[tt][r + 1] = ds[1];
-                }
-            }
-            bf16x8 pf = pack_frag(pd[0], pd[1]);
-            bf16x8 df = pack_frag(dsv[0], dsv[1]);
-            // dO^T fragments -> dV, then Q^T fragments -> dK: the two groups of transposing reads are not alive together
-            // (16 registers less at the kernel's pressure point)
-            {
-                s16x4_ dlo[4], dhi[4];
-                tr_issue4(dlo, dhi, dOt, kk2);
-                lds_tr_wait(dlo[0], dhi[0], dlo[1], dhi[1], dlo[2], dhi[2], dlo[3], dhi[3]);
-#pragma unroll
-                for (int ct = 0; ct < 4; ++ct) {
-                    bf16x8 dotf = __builtin_shufflevector(dlo[ct], dhi[ct], 0, 1, 2, 3, 4, 5, 6, 7);
-                    dv[ct] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(dotf, pf, dv[ct], 0, 0, 0);
-                }
-            }
-            {
-                s16x4_ qlo[4], qhi[4];
-                tr_issue4(qlo, qhi, Qt, kk2);
-                lds_tr_wait(qlo[0], qhi[0], qlo[1], qhi[1], qlo[2], qhi[2], qlo[3], qhi[3]);
-#pragma unroll
-                for (int ct = 0; ct < 4; ++ct) {
-                    bf16x8 qtf = __builtin_shufflevector(qlo[ct], qhi[ct], 0, 1, 2, 3, 4, 5, 6, 7);
-                    dk[ct] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(qtf, df, dk[ct], 0, 0, 0);
-                }
-            }
-        }
-    }
-    if (!kin) return;
-    const long orow = (bh * p.N + key) * DH;
-#pragma unroll
-    for (int ct = 0; ct < 4; ++ct) {
-        float a[4], c[4];
-#pragma unroll
-        for (int r = 0; r < 4; ++r) { a[r] = kkeep ? dk[ct][r] : 0.f; c[r] = kkeep ? dv[ct][r] : 0.f; }
-        st<u32x2>(p.dK + orow + ct * 16 + 4 * g, pack4(a));
-        st<u32x2>(p.dV + orow + ct * 16 + 4 * g, pack4(c));
-    }
-}
-
 // LASER output map (x-transformers Attention(laser = True): `out = log(out)` between the attention and the head gates):
 //   forward   Og = log(max(O, 1e-20)) gate          (0 on masked query rows; O = the attention's un-gated output)
 //   backward  dOin = dOg / O  (0 where O <= 1e-20), which the ordinary attention backward turns into dO = dOin gate;
@@ -1534,13 +917,8 @@ static int attn_fwd_impl(const void* Q, const void* K, const void* VT, const uin
         if (a.thresh && dropbits) hipLaunchKernelGGL((attn_fwd_kernel<true, true, 4, true>), grid, block, 0, st, a);
         else if (a.thresh) hipLaunchKernelGGL((attn_fwd_kernel<true, false, 4, true>), grid, block, 0, st, a);
         else hipLaunchKernelGGL((attn_fwd_kernel<false, false, 4, true>), grid, block, 0, st, a);
-    } else if (!(flags & (E2K_ATTN_NO_RING | E2K_ATTN_RING16)) && Npad <= RKM) {
-        e2k_attn32::fwd(&a, a.thresh != 0, a.thresh && dropbits, st);  // 32 rows per wave (attn32.hip)
     } else if (!(flags & E2K_ATTN_NO_RING) && Npad <= RKM) {
-        const dim3 grid(((N + 63) / 64) * H * B), block(256);          // 1-D: ring_wg() numbers the workgroups
-        if (a.thresh && dropbits) hipLaunchKernelGGL((attn_fwd_ring_kernel<true, true, 2>), grid, block, 0, st, a);
-        else if (a.thresh) hipLaunchKernelGGL((attn_fwd_ring_kernel<true, false, 2>), grid, block, 0, st, a);
-        else hipLaunchKernelGGL((attn_fwd_ring_kernel<false, false, 2>), grid, block, 0, st, a);
+        e2k_attn32::fwd(&a, a.thresh != 0, a.thresh && dropbits, st);  // 32 rows per wave, LDS-DMA ring (attn32.hip)
     } else {
         const dim3 grid((N + 63) / 64, H, B), block(256);
         if (a.thresh && dropbits) hipLaunchKernelGGL((attn_fwd_kernel<true, true, 4>), grid, block, 0, st, a);
@@ -1575,34 +953,24 @@ static int attn_bwd_impl(const void* dOg, const void* O, const float* gate, cons
     E2K_CHECK_LAUNCH();
     {
         const dim3 grid((N + 63) / 64, H, B), block(256);
-        const dim3 grid1(((N + 63) / 64) * H * B);                     // ring kernels: 1-D, ring_wg() numbers the workgroups
-        if (!(flags & (E2K_ATTN_NO_RING | E2K_ATTN_RING16)) && Npad <= RKM) {
-            // second generation (attn32.hip).  E2K_ATTN32_DKV=16: dK / dV by the first-generation kernel (16 keys per wave, three waves per
-            // SIMD) reading the keep masks in the layout of attn_fwd32_kernel -- same-box A/B at the bench shape: backward 264.6 us with the
-            // 32-key kernel, 268.8 with this mix, 264.5 all first generation (profiles/r05g_attn32_ab.json): no difference, the default is
-            // the one generation
+        if (!(flags & E2K_ATTN_NO_RING) && Npad <= RKM) {
+            // the LDS-DMA ring kernels (attn32.hip): the default.  (The first generation -- 16 rows per wave, 16x16x32 MFMAs -- measured the
+            // same at the bench shape, profiles/r05g_attn32_ab.json, and was deleted in round 6 together with its E2K_ATTN_RING16 switch.)
             e2k_attn32::bwd_dq(&a, a.thresh != 0, a.thresh && dropbits, st);
             E2K_CHECK_LAUNCH();
-            const char* de = getenv("E2K_ATTN32_DKV");
-            if (!(de && atoi(de) == 16)) e2k_attn32::bwd_dkv(&a, a.thresh != 0, a.thresh && dropbits, st);
-            else if (a.thresh && dropbits) hipLaunchKernelGGL((attn_bwd_dkv_ring_kernel<true, true, true>), grid1, block, 0, st, a);
-            else if (a.thresh) hipLaunchKernelGGL((attn_bwd_dkv_ring_kernel<true, false>), grid1, block, 0, st, a);
-            else hipLaunchKernelGGL((attn_bwd_dkv_ring_kernel<false, false>), grid1, block, 0, st, a);
+            e2k_attn32::bwd_dkv(&a, a.thresh != 0, a.thresh && dropbits, st);
             E2K_CHECK_LAUNCH();
             return 0;
         }
-        if (!(flags & E2K_ATTN_NO_RING) && Npad <= RKM) {
-            if (a.thresh && dropbits) hipLaunchKernelGGL((attn_bwd_dq_ring_kernel<true, true>), grid1, block, 0, st, a);
-            else if (a.thresh) hipLaunchKernelGGL((attn_bwd_dq_ring_kernel<true, false>), grid1, block, 0, st, a);
-            else hipLaunchKernelGGL((attn_bwd_dq_ring_kernel<false, false>), grid1, block, 0, st, a);
-        } else if (a.thresh && dropbits) hipLaunchKernelGGL((attn_bwd_dq_kernel<true, true, 4>), grid, block, 0, st, a);
+        // register-staged dQ (the key mask of a row longer than 4096 does not fit the ring kernel's LDS; also E2K_ATTN_NO_RING)
+        if (a.thresh && dropbits) hipLaunchKernelGGL((attn_bwd_dq_kernel<true, true, 4>), grid, block, 0, st, a);
         else if (a.thresh) hipLaunchKernelGGL((attn_bwd_dq_kernel<true, false, 4>), grid, block, 0, st, a);
         else hipLaunchKernelGGL((attn_bwd_dq_kernel<false, false, 4>), grid, block, 0, st, a);
         E2K_CHECK_LAUNCH();
         if (!(flags & E2K_ATTN_NO_RING)) {
-            if (a.thresh && dropbits) hipLaunchKernelGGL((attn_bwd_dkv_ring_kernel<true, true>), grid1, block, 0, st, a);
-            else if (a.thresh) hipLaunchKernelGGL((attn_bwd_dkv_ring_kernel<true, false>), grid1, block, 0, st, a);
-            else hipLaunchKernelGGL((attn_bwd_dkv_ring_kernel<false, false>), grid1, block, 0, st, a);
+            // long rows: dK, dV by the ring kernel all the same (it keeps no key mask in LDS); the forward of such a row was the register-staged
+            // kernel, whose keep masks lie in another layout, so this one draws them again from the counter hash -- the same decisions
+            e2k_attn32::bwd_dkv(&a, a.thresh != 0, false, st);
         } else if (a.thresh && dropbits) hipLaunchKernelGGL((attn_bwd_dkv_kernel<true, true, 4>), grid, block, 0, st, a);
         else if (a.thresh) hipLaunchKernelGGL((attn_bwd_dkv_kernel<true, false, 4>), grid, block, 0, st, a);
         else hipLaunchKernelGGL((attn_bwd_dkv_kernel<false, false, 4>), grid, block, 0, st, a);

@@ -277,8 +277,7 @@ int e2k_attn_fwd(const void* Q, const void* K, const void* VT, const uint8_t* km
 #define E2K_ATTN_PROBE_NO_PV 8       /* no V LDS reads + second MFMAs */
 #define E2K_ATTN_PROBE_NO_LOADS 16   /* no global K / V tile loads after the first */
 #define E2K_ATTN_PROBE_NO_BARRIER 32 /* no workgroup barriers */
-#define E2K_ATTN_RING16 64           /* (both calls) the first-generation ring kernels (16 rows per wave, 16x16x32 MFMAs) instead of the 32-row ones (A/B; same results up to rounding of the soft-clamp polynomial) */
-#define E2K_ATTN_NO_RING 128         /* (both calls) the register-staged kernels instead of the LDS-DMA ring kernels (A/B; same results) */
+#define E2K_ATTN_NO_RING 128         /* (both calls) the register-staged kernels instead of the LDS-DMA ring kernels (A/B and the path of rows longer than 4096 positions; same results) */
 #define E2K_ATTN_PLAIN_WG 256        /* (both calls) ring kernels: plain workgroup numbering instead of the XCD-aware one (same results) */
 /* dropbits (optional, both calls; NULL = every kernel re-derives the dropout mask from the counter hash): scratch of
  * e2k_query_attn_dropbits_bytes(B, H, N) bytes in which the forward leaves its keep decisions as 64-bit wave ballot words
