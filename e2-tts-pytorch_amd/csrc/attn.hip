@@ -883,8 +883,7 @@ static int fill_attn(AttnArgs& a, int B, int H, int N, int Npad, float p_drop, u
     a.seed = seed; a.seed_dev = seed_dev; a.stream_id = stream_id;
     a.thresh = (unsigned)(p_drop * 65536.f + 0.5f);
     a.inv_keep = 1.f / (1.f - p_drop);
-    static const int xcd_env = getenv("E2K_ATTN_XCD") ? atoi(getenv("E2K_ATTN_XCD")) : 1;      // (0: plain numbering, A/B)
-    a.xcd_map = (flags & E2K_ATTN_PLAIN_WG) ? 0 : xcd_env;
+    a.xcd_map = (flags & E2K_ATTN_PLAIN_WG) ? 0 : 1;
     return 0;
 }
 

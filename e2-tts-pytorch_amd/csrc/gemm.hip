@@ -1668,6 +1668,13 @@ bool tn_use_256(int M, int N, int K, int use_tr) {
 
 }  // namespace
 
+// Remainder split (the last, partial round of tiles cut into K ranges + a fix-up launch): OFF by default since round 6.  Timed alone it
+// gains 2-3 % on the NT launch mix of a cfg3 step (736 against 721 TFLOP/s); IN the step the CUs a partial round leaves idle are taken by
+// the other launch lanes' kernels, and the 157 fix-up launches and their fp32 partial traffic are pure cost: 84.94 / 85.02 ms with the
+// split against 84.56 / 84.41 without, same box, interleaved (profiles/r06f_nt_remainder_split_in_step_ab.txt).  E2K_GEMM_SPLIT turns it
+// on (a caller that runs these GEMMs alone on the chip); the 8-slot test hook implies it.
+static bool nt_split_on(int flags) { return (flags & (E2K_GEMM_SPLIT | E2K_GEMM_TEST_SLOTS8)) && !(flags & E2K_GEMM_NO_SPLIT); }
+
 // smallest number of 256 x 256 output tiles for which e2k_gemm_nt_bf16 takes the 256 x 256 kernel (E2K_GEMM_T256_MIN overrides, A/B)
 static int nt_t256_min() {
     static const int v = getenv("E2K_GEMM_T256_MIN") ? atoi(getenv("E2K_GEMM_T256_MIN")) : 64;
@@ -1724,9 +1731,9 @@ static int gemm_nt_bf16_impl(const void* A1, int64_t lda1, int K1, const void* A
         // tile order: workgroups go round-robin over the 8 XCDs and xcd_remap hands each XCD a contiguous run of T / 8 tiles, taken
         // from groups of `group` row tiles x all column tiles.  With the fixed 8 rows a group of a narrow output is the share of
         // TWO or more XCDs (8448 x 1024: 32 tiles against 16.5 per XCD), i.e. every A row panel is fetched by several L2s; the
-        // group is sized to one XCD's share instead (E2K_GEMM_GROUP: fixed value, A/B)
+        // group is sized to one XCD's share instead 
         {
-            static const int group_env = getenv("E2K_GEMM_GROUP") ? atoi(getenv("E2K_GEMM_GROUP")) : 0;
+            const int group_env = 0;            // (a fixed group height was an A/B switch in round 4: the per-XCD rule below won)
             const int tn256 = (N + QBN - 1) / QBN;
             const float per_xcd = T / 8.f;
             if (group_env > 0) p.group = group_env;
@@ -1738,13 +1745,11 @@ static int gemm_nt_bf16_impl(const void* A1, int64_t lda1, int K1, const void* A
         p.full = T; p.split = 1; p.ws = ws;
         int rem = 0;
         const int slots = (flags & E2K_GEMM_TEST_SLOTS8) ? 8 : 256;
-        if (ws && !(flags & E2K_GEMM_NO_SPLIT) && T > slots && (T % slots) != 0) {
+        if (ws && nt_split_on(flags) && T > slots && (T % slots) != 0) {
             rem = T % slots;
             const int nk = (K1 + K2) / BK;
             int split = 1;
-            // (tuning instruments: E2K_GEMM_SPLIT_CAP bounds the split, E2K_GEMM_SPLIT_MINK the K tiles per part)
-            static const int split_cap = getenv("E2K_GEMM_SPLIT_CAP") ? atoi(getenv("E2K_GEMM_SPLIT_CAP")) : 16;
-            static const int split_mink = getenv("E2K_GEMM_SPLIT_MINK") ? atoi(getenv("E2K_GEMM_SPLIT_MINK")) : 4;
+            constexpr int split_cap = 16, split_mink = 4;
             while (split * 2 <= split_cap && split * 2 * rem <= slots && split * 2 * split_mink <= nk) split *= 2;   // >= 4 K tiles per part
             // same trade as below: half a round saved (~1 us per K step of a 256 x 256 tile) against 256 KB of fp32
             // partials per part written and re-read, plus the fix-up launch.  UNMEASURED constants (scaled from the 128 x 128 ones)
@@ -1773,7 +1778,7 @@ static int gemm_nt_bf16_impl(const void* A1, int64_t lda1, int K1, const void* A
     p.full = T; p.split = 1; p.ws = ws;
     int rem = 0;
     const int slots = (flags & E2K_GEMM_TEST_SLOTS8) ? 8 : NT_SLOTS;
-    if (glds && ws && !(flags & E2K_GEMM_NO_SPLIT) && T > slots && (T % slots) != 0) {
+    if (glds && ws && nt_split_on(flags) && T > slots && (T % slots) != 0) {
         rem = T % slots;
         const int nk = (K1 + K2) / BK;
         int split = 1;
@@ -1830,7 +1835,7 @@ static int gemm_nt_geglu_bf16_impl(const void* A, int64_t lda, int K, const void
     p.full = T; p.split = 1; p.ws = ws;
     int rem = 0;
     const int slots = (flags & E2K_GEMM_TEST_SLOTS8) ? 8 : 256;
-    if (ws && !(flags & E2K_GEMM_NO_SPLIT) && T > slots && (T % slots) != 0) {      // same remainder split as the plain kernel
+    if (ws && nt_split_on(flags) && T > slots && (T % slots) != 0) {      // same remainder split as the plain kernel
         rem = T % slots;
         const int nk = K / BK;
         int split = 1;
@@ -1887,7 +1892,7 @@ static int gemm_nt_geglu_bwd_bf16_impl(const void* dY, int64_t ldy, int K, const
     p.full = T; p.split = 1; p.ws = ws;
     int rem = 0;
     const int slots = (flags & E2K_GEMM_TEST_SLOTS8) ? 8 : 256;
-    if (ws && !(flags & E2K_GEMM_NO_SPLIT) && T > slots && (T % slots) != 0) {      // same remainder split as the plain kernel
+    if (ws && nt_split_on(flags) && T > slots && (T % slots) != 0) {      // same remainder split as the plain kernel
         rem = T % slots;
         const int nk = K / BK;
         int split = 1;

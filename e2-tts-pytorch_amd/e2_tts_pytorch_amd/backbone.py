@@ -1864,31 +1864,18 @@ class _TimeCondFn(torch.autograd.Function):
         return None, None, dW, db
 
 
-# token-dimension splits of the weight-gradient GEMMs on the WGRAD lane (0 = the library's cost model, which assumes the
-# GEMM has the chip to itself; on the lane it runs next to the main chain)
-_WGRAD_LANE_SPLITS = int(_os.environ.get('E2K_WGRAD_SPLITS', '0'))
-# dual-source weight-gradient launches for the cross-condition / skip projections (E2K_WGRAD_DUAL=0: one GEMM per block, A/B)
-_WGRAD_DUAL = _os.environ.get('E2K_WGRAD_DUAL', '1') != '0'
-# one grouped launch for the weight gradients of a layer (E2K_WGRAD_GROUP=0: one GEMM each, as they become ready; A/B)
-_WGRAD_GROUP = _os.environ.get('E2K_WGRAD_GROUP', '1') != '0'
-# below this many token rows the fused weight-gradient launches are not used: they always run the 256 x 256 kernel, whose fixed
-# cost (a 256-KB partial tile per workgroup + the reduce pass) only pays on real sizes
-_WGRAD_MIN_ROWS = int(_os.environ.get('E2K_WGRAD_MIN_ROWS', '1024'))
-# hyper-connection / depthwise-conv parameter-gradient reductions on the WGRAD lane instead of on the chain (E2K_DEFER_REDUCES=0: A/B)
-_DEFER_REDUCES = _os.environ.get('E2K_DEFER_REDUCES', '1') != '0'
-# recorded training plans refresh the transposed bf16 weight shadows (dgrad operands) on the WGRAD lane during the forward instead
-# of at its start on the chain (E2K_RECAST_T_ON_LANE=0: A/B)
-_RECAST_T_ON_LANE = _os.environ.get('E2K_RECAST_T_ON_LANE', '1') != '0'
-
-# the persistent flat gradient buffer is zero-filled on the WGRAD lane during the forward instead of at the head of the backward
-# chain (E2K_ZERO_GRADS_ON_LANE=0: A/B)
-_ZERO_GRADS_ON_LANE = _os.environ.get('E2K_ZERO_GRADS_ON_LANE', '1') != '0'
-
-# the hyper-connection parameter-gradient reductions of a layer go out as one launch (E2K_BATCH_REDUCES=0: one each, A/B)
-_BATCH_REDUCES = _os.environ.get('E2K_BATCH_REDUCES', '1') != '0'
-
-# TextAudioCrossCondition's two projections (and the two halves of its dgrad) as ONE two-output GEMM launch (E2K_CROSS_ONE_LAUNCH=0: A/B)
-_CROSS_ONE_LAUNCH = _os.environ.get('E2K_CROSS_ONE_LAUNCH', '1') != '0'
+# Schedule choices that were environment switches while they were being measured (rounds 3-5; the A/Bs are profiles/r03_grouped_wgrad_ab.jsonl,
+# r03_dual_wgrad_ab.jsonl, r04_* and profiles/HISTORY.md) and are decided: module constants since round 6 (tests flip some of them to cover
+# the paths small shapes take).
+_WGRAD_LANE_SPLITS = 0        # token-dimension splits of the weight-gradient GEMMs on the WGRAD lane: 0 = the library's cost model
+_WGRAD_DUAL = True            # dual-source weight-gradient launches for the cross-condition / skip projections
+_WGRAD_GROUP = True           # one grouped launch for the weight gradients of a layer
+_WGRAD_MIN_ROWS = 1024        # below this many token rows the fused weight-gradient launches are not used (256-KB partial tiles + reduce pass)
+_DEFER_REDUCES = True         # hyper-connection / depthwise-conv parameter-gradient reductions on the WGRAD lane instead of on the chain
+_RECAST_T_ON_LANE = True      # recorded training plans refresh the transposed bf16 weight shadows on the WGRAD lane during the forward
+_ZERO_GRADS_ON_LANE = True    # the persistent flat gradient buffer is zero-filled on the WGRAD lane during the forward
+_BATCH_REDUCES = True         # the hyper-connection parameter-gradient reductions of a layer go out as one launch
+_CROSS_ONE_LAUNCH = True      # TextAudioCrossCondition's two projections (and the two halves of its dgrad) as ONE two-output GEMM launch
 
 _VIEW_OPS = {'view', '_unsafe_view', 'as_strided', 'slice', 'select', 'expand', 't', 'transpose', 'permute', 'unsqueeze', 'squeeze',
              'detach', 'alias', '_reshape_alias', 'reshape', 'split', 'split_with_sizes', 'unbind', 'narrow', 'lift_fresh', 'unfold',

@@ -14,9 +14,8 @@
  *   - `stream` is a hipStream_t (NULL = default stream); kernels are only enqueued, never synchronised;
  *   - "bf16" buffers hold raw bfloat16 bits (uint16_t); leading dimensions (ld*) are in ELEMENTS;
  *   - 16-byte vector access: bf16 base pointers must be 16-B aligned and ld* multiples of 8;
- *   - tuning instruments, read from the environment once per process; they choose between launch geometries of the same
- *     arithmetic: E2K_GEMM_T256_MIN, E2K_GEMM_GROUP, E2K_GEMM_SPLIT_CAP, E2K_GEMM_SPLIT_MINK (NT GEMM: kernel threshold, tile-group
- *     height, bounds of the remainder split) and E2K_ATTN_XCD (0: plain workgroup numbering of the attention ring kernels).
+ *   - one tuning instrument is read from the environment once per process: E2K_GEMM_T256_MIN (smallest number of 256 x 256 output
+ *     tiles for which the NT GEMM takes its 256 x 256 kernel; a choice between launch geometries of the same arithmetic).
  */
 #ifndef E2K_H
 #define E2K_H
@@ -65,7 +64,8 @@ int e2k_gemm_nt2_bf16(const void* A1, int64_t lda1, int K1, const void* A2, int6
 #define E2K_GEMM_T256 128        /* flags: 256 x 256 x 64 tile, 8-wave 8-phase kernel for EVERY shape (default: shapes with >= 64 such tiles; E2K_GEMM_T256_MIN overrides) */
 #define E2K_GEMM_NO_T256 256     /* flags: never use the 256 x 256 kernel (A/B) */
 #define E2K_GEMM_NO_STAGE 64     /* flags: 256 x 256 kernel stores its C tile straight from the accumulator registers (16 rows x 32 bytes per wave instruction) instead of through LDS in whole-line row segments (A/B) */
-#define E2K_GEMM_NO_SPLIT 16     /* flags: never split remainder tiles over K (A/B) */
+#define E2K_GEMM_NO_SPLIT 16     /* flags: never split remainder tiles over K (overrides E2K_GEMM_SPLIT) */
+#define E2K_GEMM_SPLIT 512       /* flags: cut the tiles of the last, partial round into K ranges + a fix-up launch.  Pays when the GEMM has the chip to itself (+2-3 % alone-timed); off by default since round 6: next to the launch lanes it costs the step 0.5 ms */
 #define E2K_GEMM_TEST_SLOTS8 32  /* flags: pretend the chip holds 8 workgroups (lets small shapes exercise the remainder split in tests) */
 
 /* C[N,K] += A[M,N]^T . B[M,K]  (weight gradients; C fp32, A = dY, B = X, bf16).  The token dimension M is

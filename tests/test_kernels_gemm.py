@@ -65,6 +65,24 @@ def test_gemm_nt_remainder_split(dev, M, N, K1, K2, kw):
         ops.gemm_flags = old
 
 
+@pytest.mark.gpu
+@pytest.mark.parametrize('M,N,K1,K2,kw', [(8448, 3104, 1024, 0, dict(bias=1)), (8448, 4096, 512, 0, {}), (33792, 1024, 1024, 512, dict(rs=1))])
+def test_gemm_nt_remainder_split_at_step_shapes(M, N, K1, K2, kw):
+    """E2K_GEMM_SPLIT (512; off by default since round 6) on three shapes of a cfg3 step whose tile count leaves a partial round on the
+    chip's 256 workgroup slots (429, 528 and 528 tiles): the real slot count, the fix-up kernel, the fp32 partials -- against the fp32
+    product, and the default (unsplit) launch of the same shape"""
+    from conftest import install_lib
+    from e2_tts_pytorch_amd import ops
+    install_lib(None, host_pointers=False)
+    old = ops.gemm_flags
+    try:
+        for flags in (512, 0):
+            ops.gemm_flags = flags
+            test_gemm_nt('cuda', M, N, K1, K2, kw)
+    finally:
+        ops.gemm_flags = old
+
+
 @pytest.mark.parametrize('use_tr', [False, True])
 @pytest.mark.parametrize('M,N,K,splits', [(128, 128, 128, 1), (300, 136, 72, 0), (1000, 392, 264, 3), (8, 256, 128, 1),
                                           (256, 136, 72, 0), (1024, 392, 264, 3), (192, 8, 520, 1)])
