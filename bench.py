@@ -27,6 +27,11 @@ from pathlib import Path
 # from 93.3 to 104.3 ms, and GPU_MAX_HW_QUEUES=8 brought it back to 93.3 (profiles/r03_hw_queues.jsonl).  Must be set
 # before the HIP runtime initialises, i.e. before the first device call of this process.
 os.environ.setdefault('GPU_MAX_HW_QUEUES', '8')
+# Kernel arguments in device memory instead of host-coherent memory: the command processor fetches them without crossing the bus, which
+# shortens the gap between dependent launches -- and a step is ~1600 launches in three dependent chains.  MI355X, same box, interleaved:
+# cfg3 86.53 / 86.45 -> 85.51 / 85.59 ms, cfg2 14.92 / 14.95 -> 14.44 / 14.44 ms (profiles/r06g_kernarg_ab.txt).  Read by the HIP runtime at
+# its initialisation, like the variable above.
+os.environ.setdefault('HIP_FORCE_DEV_KERNARG', '1')
 
 ROOT = Path(__file__).resolve().parent
 for p in (ROOT / 'e2-tts-pytorch_amd', ROOT):
@@ -393,11 +398,11 @@ def main():
         achieved = gemm_flops / (gemm_ms * 1e-3) / 1e12 if gemm_ms > 0 else 0.0
         # HBM traffic of the dominant kernel per launch: PMC counters cannot be read from inside this process, so the
         # number comes from the committed rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes over the same launch mix
-        # (profiles/r05_nt_traffic.json, produced by tools/nt_shapes.py + tools/nt_traffic_probe.py + tools/nt_traffic_reduce.py); cfg3 only
+        # (profiles/r06_nt_traffic.json, produced by tools/nt_shapes.py + tools/nt_traffic_probe.py + tools/nt_traffic_reduce.py); cfg3 only
         traffic, traffic_note = None, None
-        tf = ROOT / 'profiles' / 'r05_nt_traffic.json'
+        tf = ROOT / 'profiles' / 'r06_nt_traffic.json'
         if not tf.exists():
-            tf = ROOT / 'profiles' / 'r04_nt_traffic.json'
+            tf = ROOT / 'profiles' / 'r05_nt_traffic.json'
         if args.config == 'cfg3' and B == CONFIGS['cfg3'][3] and not args.drop_text and tf.exists():
             tj = json.load(open(tf))
             traffic = tj['traffic_bytes_per_launch']
@@ -435,7 +440,7 @@ def main():
                              'note': 'text branches / weight-gradient GEMMs on side streams (ops.Lanes, csrc/plan.h); E2K_LANES=0 for the single-stream schedule'},
             'kernel_groups_ms_per_step': _groups(prof_rows, nprof) if prof_rows else None,
             'roofline': {
-                'bound': 'mfma', 'kernel': 'e2k_gemm_nt_bf16 (+ e2k_gemm_nt_geglu_bwd_bf16, the same kernel with the GEGLU backward as its epilogue): gemm_nt_256_kernel (256x256x64, 8-phase) / gemm_nt_glds_kernel (128x128x64), C tiles through LDS in whole-line 16-byte stores, + fix-ups (bf16 MFMA 16x16x32; every forward and dgrad GEMM of the step)',
+                'bound': 'mfma', 'kernel': 'e2k_gemm_nt_bf16 (+ e2k_gemm_nt_geglu_bwd_bf16, the same kernel with the GEGLU backward as its epilogue): gemm_nt_256_kernel (256x256x64, 8-phase) / gemm_nt_glds_kernel (128x128x64), C tiles through LDS in whole-line 16-byte stores (bf16 MFMA 16x16x32; every forward and dgrad GEMM of the step; no remainder split since round 6: alone-timed, as here, that costs the kernel 2 % -- 0.280 -> 0.270 of peak on one box -- and gains the step 0.5 ms, profiles/r06f_nt_remainder_split_in_step_ab.txt)',
                 'achieved': achieved, 'peak': PEAK_BF16_TFLOPS, 'unit': 'TFLOP/s', 'frac': achieved / PEAK_BF16_TFLOPS,
                 'launches_per_step': n_launch / nprof,
                 'avg_launch_ms': gemm_ms / max(n_launch, 1),
@@ -443,7 +448,7 @@ def main():
                 'time_share_of_step': (gemm_ms / nprof) / ms,
                 'measured': 'HIP events on the launch stream around every recorded launch (e2k_plan_profile), 2 replays of the '
                             'timed plan right after the timed region, every call ALONE on one stream; the rocprofv3 summary that '
-                            'agrees with avg_launch_ms is the single-stream one (E2K_LANES=0, profiles/r05_bench_cfg3_kernel_stats_single_stream.csv): '
+                            'agrees with avg_launch_ms is the single-stream one (E2K_LANES=0, profiles/r06_bench_cfg3_kernel_stats_single_stream.csv): '
                             'with the launch lanes the kernels of different lanes overlap and stretch (…_d_lanes.csv).  Since the end of '
                             'round 3 outputs of 64-223 tiles of 256 x 256 (the 8448-token GEMMs with N <= 2048) run the 256 x 256 kernel on '
                             'a part of the CUs: in the step the other launch lanes use the rest (step -1.5 to -3 %, '

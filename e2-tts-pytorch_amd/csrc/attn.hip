@@ -948,11 +948,10 @@ static int attn_bwd_impl(const void* dOg, const void* O, const float* gate, cons
     a.dO = (bf16_t*)dO; a.dOT = (bf16_t*)dOT; a.delta = delta; a.dgate_pre = dgate_pre;
     a.dQ = (bf16_t*)dQ; a.dK = (bf16_t*)dK; a.dV = (bf16_t*)dV;
     hipStream_t st = (hipStream_t)stream;
-    hipLaunchKernelGGL(attn_bwd_prep_kernel, dim3(Npad / 64, H, B), dim3(256), 0, st, a);
-    E2K_CHECK_LAUNCH();
     {
         const dim3 grid((N + 63) / 64, H, B), block(256);
         if (!(flags & E2K_ATTN_NO_RING) && Npad <= RKM) {
+            // (dO, delta and the gate gradient come out of the dQ kernel's prologue: no attn_bwd_prep_kernel launch on this path)
             // the LDS-DMA ring kernels (attn32.hip): the default.  (The first generation -- 16 rows per wave, 16x16x32 MFMAs -- measured the
             // same at the bench shape, profiles/r05g_attn32_ab.json, and was deleted in round 6 together with its E2K_ATTN_RING16 switch.)
             e2k_attn32::bwd_dq(&a, a.thresh != 0, a.thresh && dropbits, st);
@@ -961,6 +960,8 @@ static int attn_bwd_impl(const void* dOg, const void* O, const float* gate, cons
             E2K_CHECK_LAUNCH();
             return 0;
         }
+        hipLaunchKernelGGL(attn_bwd_prep_kernel, dim3(Npad / 64, H, B), dim3(256), 0, st, a);
+        E2K_CHECK_LAUNCH();
         // register-staged dQ (the key mask of a row longer than 4096 does not fit the ring kernel's LDS; also E2K_ATTN_NO_RING)
         if (a.thresh && dropbits) hipLaunchKernelGGL((attn_bwd_dq_kernel<true, true, 4>), grid, block, 0, st, a);
         else if (a.thresh) hipLaunchKernelGGL((attn_bwd_dq_kernel<true, false, 4>), grid, block, 0, st, a);

@@ -428,18 +428,49 @@ __global__ __launch_bounds__(256, WPS) void attn_dq32_kernel(AttnArgs p) {
     for (int j = tid; j < p.Npad / 8; j += 256) kms[j] = (unsigned char)mask_bits(ld<unsigned long long>(p.kmask + (long)b * p.Npad + j * 8));
     wait_lgkm0();
 
+    // The head of the backward pass rides in this kernel's prologue (round 6: it was a launch of its own, attn_bwd_prep_kernel, 48 times a
+    // step): dO = dOg * gate (0 on masked query rows) straight from the token-major upstream gradient -- a lane holds exactly the 4 x 8
+    // channels of its query that the dO^T fragments need --, delta = sum_d dO O and the gate's gradient.  dO and delta are also WRITTEN:
+    // the dK / dV kernel that follows in the stream reads them for every query.
     bf16x8 qf[4], dof[4];
+    float dl = 0.f;
+    {
+        const long trow = ((long)b * p.N + (qin ? q : 0)) * ((long)p.H * DH) + h * DH + hi * 8;
+        const float gt = qin ? p.gate[bh * p.N + q] : 0.f;
+        const bool qkeep = qin && p.kmask[(long)b * p.Npad + q] != 0;
+        float dot = 0.f;
 #pragma unroll
-    for (int ks = 0; ks < 4; ++ks) {
-        qf[ks] = qin ? ld<bf16x8>(p.Q + (bh * p.N + q) * DH + ks * 16 + hi * 8) : bf16x8{0, 0, 0, 0, 0, 0, 0, 0};
-        dof[ks] = qin ? ld<bf16x8>(p.dO + (bh * p.N + q) * DH + ks * 16 + hi * 8) : bf16x8{0, 0, 0, 0, 0, 0, 0, 0};
+        for (int ks = 0; ks < 4; ++ks) {
+            qf[ks] = qin ? ld<bf16x8>(p.Q + (bh * p.N + q) * DH + ks * 16 + hi * 8) : bf16x8{0, 0, 0, 0, 0, 0, 0, 0};
+            float og[8], ov[8], d[8];
+#pragma unroll
+            for (int e = 0; e < 8; ++e) { og[e] = 0.f; ov[e] = 0.f; }
+            if (qin) {
+                unpack8(ld<u32x4>(p.dOg + trow + ks * 16), og);
+                unpack8(ld<u32x4>(p.O + trow + ks * 16), ov);
+            }
+#pragma unroll
+            for (int e = 0; e < 8; ++e) {
+                dot = fmaf(og[e], ov[e], dot);
+                d[e] = qkeep ? og[e] * gt : 0.f;
+            }
+            const u32x4 pk = pack8(d);
+            dof[ks] = __builtin_bit_cast(bf16x8, pk);
+            if (qin) st<u32x4>(p.dO + (bh * p.N + q) * DH + ks * 16 + hi * 8, pk);
+        }
+        dot += lane32_other(dot);                      // the other half of the row's channels (lane l ^ 32)
+        if (!qkeep) dot = 0.f;
+        dl = dot * gt;
+        if (qin && hi == 0) {
+            p.delta[bh * p.N + q] = dl;
+            p.dgate_pre[bh * p.N + q] = dl * (1.f - gt);
+        }
     }
     const float kx = p.scale / CLAMP;
     const Clamp32 cc = clamp32(kx, 1.f);
     const float cl2 = CLAMP * LOG2E;
     // dS = P (dP - delta) (1 - th^2) scale: the trailing `scale` is folded into the exponent of P (lse - log2(scale))
     const float lse = qin ? p.lse2[bh * p.N + q] - log2f(p.scale) : 1e30f;
-    const float dl = qin ? p.delta[bh * p.N + q] : 0.f;
     const unsigned hrow = rand_base(p.seed_dev ? *p.seed_dev : p.seed, dstream) + (unsigned)q * 0x85ebca77u;
     const unsigned hlane = hrow + (unsigned)(2 * hi) * 0xc2b2ae3du;
 

@@ -107,7 +107,7 @@ __device__ __forceinline__ float tanh_fast(float x) {
     return x < 0.f ? -t : t;
 }
 
-constexpr int NRED = 32;                             // LDS exchange row (28 forward / 24 backward values used)
+constexpr int NRED = 40;                             // LDS exchange row (28 forward -- 34 with the branch-input norm -- / 24 backward values used)
 
 // Reduce N per-lane partials (N a multiple of 8) over the NW waves that share a token, leaving the totals spread over LANES instead of
 // broadcast: wave_sum_rows leaves the total of value i + (N / 4) (r & 1) + (N / 2) (r >> 1) in register i of row r (two swap levels + four
@@ -147,10 +147,15 @@ struct HCFwdArgs {
     bf16_t* Mout; bf16_t* bin; float* coef;
     HCParams hp;
     int Mtok;
+    // NORM (e2k_hc_fwd_norm): the (Adaptive)RMSNorm that follows every width connection in the backbone (e2_tts.py:875,881,908-914,926,937:
+    // `x, add_residual = hc(x); x = norm(x[, cond])`), applied to the branch input while it is in registers: xn = bin / |bin| sqrt(D)
+    // (ngamma[row / rows_per_batch] + ngam_off); nrn[tok] = 1 / |bin| (what e2k_rmsnorm_bwd wants).  bin may be NULL then (no-grad forward)
+    const float* ngamma; long ngam_ld; float ngam_off; int rows_per_batch; bf16_t* xn; float* nrn;
 };
 
-template <int VEC, int NCH, int NW, bool DEPTH, bool WIDTH>
+template <int VEC, int NCH, int NW, bool DEPTH, bool WIDTH, bool NORM = false>
 __global__ __launch_bounds__(256) void hc_fwd_kernel(HCFwdArgs p) {
+    static_assert(WIDTH || !NORM, "");
     constexpr int EPL = VEC * NCH, DS = 64 * EPL, D = DS * NW, TPB = 4 / NW;
     __shared__ __attribute__((aligned(16))) float Wp[WIDTH ? NJ * D : 4];
     __shared__ __attribute__((aligned(16))) float red[2][4][NRED];
@@ -209,7 +214,8 @@ __global__ __launch_bounds__(256) void hc_fwd_kernel(HCFwdArgs p) {
             }
             return;
         }
-        float part[28];       // [s*7 + j], j = 6: sum of squares
+        constexpr int NPART = NORM ? 34 : 28;
+        float part[NPART];    // [s*7 + j], j = 6: sum of squares; NORM: [28 + pair] the six cross products <r_s, r_s'>, s < s'
 #pragma unroll
         for (int j = 0; j < NJ; ++j) {
             float w[EPL];
@@ -219,7 +225,17 @@ __global__ __launch_bounds__(256) void hc_fwd_kernel(HCFwdArgs p) {
         }
 #pragma unroll
         for (int s = 0; s < S; ++s) part[s * 7 + 6] = dot_pk<EPL>(r[s], r[s]);
-        token_scatter<28, NW>(part, red, it & 1, wave, lane);
+        if (NORM) {
+            // |bin|^2 = sum_{s,s'} a_s a_s' <r_s, r_s'> (bin = sum_s a[s][0] r_s): the Gram matrix of the four streams rides in the ONE
+            // reduction round the coefficients need anyway, so the norm of the branch input costs no second exchange between the
+            // token's waves
+            int q = 28;
+#pragma unroll
+            for (int s = 0; s < S; ++s)
+#pragma unroll
+                for (int s2 = s + 1; s2 < S; ++s2) part[q++] = dot_pk<EPL>(r[s], r[s2]);
+        }
+        token_scatter<NPART, NW>(part, red, it & 1, wave, lane);
         // lane-parallel coefficients: lane (ls, lj) owns a[ls][lj] (lj < 5) / b[ls] (lj == 5)
         const float dotl = token_pick<NW>(red, it & 1, wave, ls * 7 + (lj < 7 ? lj : 6));
         const float ssl = token_pick<NW>(red, it & 1, wave, ls * 7 + 6);
@@ -249,8 +265,27 @@ __global__ __launch_bounds__(256) void hc_fwd_kernel(HCFwdArgs p) {
                     for (int s = 1; s < S; ++s) v = fmaf(a[s][t], r[s][e], v);
                     m[e] = v;
                 }
-                if (t == 0) store_row<VEC, NCH>(p.bin + tok * D + doff, lane, m);
-                else store_row<VEC, NCH>(p.Mout + (tok * S + (t - 1)) * D + doff, lane, m);
+                if (t == 0) {
+                    if (!NORM || p.bin) store_row<VEC, NCH>(p.bin + tok * D + doff, lane, m);
+                    if (NORM) {
+                        float ssb = 0.f;
+                        int q = 28;
+#pragma unroll
+                        for (int s = 0; s < S; ++s) {
+                            ssb = fmaf(a[s][0] * a[s][0], token_pick<NW>(red, it & 1, wave, s * 7 + 6), ssb);
+#pragma unroll
+                            for (int s2 = s + 1; s2 < S; ++s2) ssb = fmaf(2.f * a[s][0] * a[s2][0], token_pick<NW>(red, it & 1, wave, q++), ssb);
+                        }
+                        const float rnb = 1.f / fmaxf(fast_sqrt(fmaxf(ssb, 0.f)), 1e-12f);
+                        const float sc = rnb * sqrtD;
+                        float gn[EPL];
+                        load_row_f32<VEC, NCH>(p.ngamma + (tok / p.rows_per_batch) * p.ngam_ld + doff, lane, gn);
+#pragma unroll
+                        for (int e = 0; e < EPL; ++e) m[e] = m[e] * sc * (gn[e] + p.ngam_off);
+                        store_row<VEC, NCH>(p.xn + tok * D + doff, lane, m);
+                        if (p.nrn && doff == 0 && lane == 0) p.nrn[tok] = rnb;
+                    }
+                } else store_row<VEC, NCH>(p.Mout + (tok * S + (t - 1)) * D + doff, lane, m);
             }
         }
     };
@@ -566,6 +601,12 @@ __global__ __launch_bounds__(256) void hc_reduce_batch_kernel(HCReduceBatch b) {
 template <int VEC, int NCH, int NW>
 int launch_fwd(const HCFwdArgs& a, bool depth, bool width, int grid, hipStream_t st) {
     dim3 g(grid), b(256);
+    if (a.xn) {
+        if (depth && width) hipLaunchKernelGGL((hc_fwd_kernel<VEC, NCH, NW, true, true, true>), g, b, 0, st, a);
+        else if (!depth && width) hipLaunchKernelGGL((hc_fwd_kernel<VEC, NCH, NW, false, true, true>), g, b, 0, st, a);
+        else return E2K_ERR_ARG;
+        return 0;
+    }
     if (depth && width) hipLaunchKernelGGL((hc_fwd_kernel<VEC, NCH, NW, true, true>), g, b, 0, st, a);
     else if (!depth && width) hipLaunchKernelGGL((hc_fwd_kernel<VEC, NCH, NW, false, true>), g, b, 0, st, a);
     else if (depth && !width) hipLaunchKernelGGL((hc_fwd_kernel<VEC, NCH, NW, true, false>), g, b, 0, st, a);
@@ -639,14 +680,17 @@ static int hc_fwd_impl(const void* Xin, const void* yprev, const float* coef_pre
                           float* coef, const float* static_beta, const float* static_alpha,
                           const float* dyn_alpha_fn, const float* dyn_alpha_scale, const float* dyn_beta_fn,
                           const float* dyn_beta_scale, const float* gamma, int Mtok, int D, int has_depth,
-                          int has_width, void* stream) {
+                          int has_width, const float* ngamma, int64_t ngam_ld, float ngam_off, int rows_per_batch, void* xn, float* nrn,
+                          void* stream) {
     if (Mtok <= 0) return 0;
     HCFwdArgs a;
     a.Xin = (const bf16_t*)Xin; a.yprev = (const bf16_t*)yprev; a.coef_prev = coef_prev;
     a.Mout = (bf16_t*)Mout; a.bin = (bf16_t*)bin; a.coef = coef;
     a.hp = HCParams{static_beta, static_alpha, dyn_alpha_fn, dyn_alpha_scale, dyn_beta_fn, dyn_beta_scale, gamma};
     a.Mtok = Mtok;
-    if (!Xin || !Mout || (has_depth && (!yprev || !coef_prev)) || (has_width && (!bin || !coef || !gamma))) return E2K_ERR_ARG;
+    a.ngamma = ngamma; a.ngam_ld = ngam_ld; a.ngam_off = ngam_off; a.rows_per_batch = rows_per_batch; a.xn = (bf16_t*)xn; a.nrn = nrn;
+    if (xn && (!has_width || !ngamma || rows_per_batch <= 0)) return E2K_ERR_ARG;
+    if (!Xin || !Mout || (has_depth && (!yprev || !coef_prev)) || (has_width && ((!bin && !xn) || !coef || !gamma))) return E2K_ERR_ARG;
     int rc = 0;
     HC_DISPATCH(D, launch_fwd, a, has_depth != 0, has_width != 0, grid_for(Mtok, D, 1024, false), (hipStream_t)stream);
     if (rc) return rc;
@@ -746,7 +790,18 @@ extern "C" int e2k_hc_fwd(const void* Xin, const void* yprev, const float* coef_
                           const float* dyn_alpha_fn, const float* dyn_alpha_scale, const float* dyn_beta_fn,
                           const float* dyn_beta_scale, const float* gamma, int Mtok, int D, int has_depth,
                           int has_width, void* stream) {
-    return e2k::dispatch("hc_fwd", hc_fwd_impl, Xin, yprev, coef_prev, Mout, bin, coef, static_beta, static_alpha, dyn_alpha_fn, dyn_alpha_scale, dyn_beta_fn, dyn_beta_scale, gamma, Mtok, D, has_depth, has_width, stream);
+    return e2k::dispatch("hc_fwd", hc_fwd_impl, Xin, yprev, coef_prev, Mout, bin, coef, static_beta, static_alpha, dyn_alpha_fn, dyn_alpha_scale, dyn_beta_fn, dyn_beta_scale, gamma, Mtok, D, has_depth, has_width,
+                         (const float*)nullptr, (int64_t)0, 0.f, 0, (void*)nullptr, (float*)nullptr, stream);
+}
+
+extern "C" int e2k_hc_fwd_norm(const void* Xin, const void* yprev, const float* coef_prev, void* Mout, void* bin,
+                               float* coef, const float* static_beta, const float* static_alpha,
+                               const float* dyn_alpha_fn, const float* dyn_alpha_scale, const float* dyn_beta_fn,
+                               const float* dyn_beta_scale, const float* gamma, int Mtok, int D, int has_depth,
+                               const float* norm_gamma, int64_t ldg, float gamma_off, int rows_per_batch, void* xn, float* rn, void* stream) {
+    if (!xn) return E2K_ERR_ARG;
+    return e2k::dispatch("hc_fwd_norm", hc_fwd_impl, Xin, yprev, coef_prev, Mout, bin, coef, static_beta, static_alpha, dyn_alpha_fn, dyn_alpha_scale, dyn_beta_fn, dyn_beta_scale, gamma, Mtok, D, has_depth, 1,
+                         norm_gamma, ldg, gamma_off, rows_per_batch, xn, rn, stream);
 }
 
 extern "C" int e2k_hc_bwd(const void* Xin, const void* yprev, const float* coef_prev, const void* G,

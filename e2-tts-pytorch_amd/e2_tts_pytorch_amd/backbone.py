@@ -1196,6 +1196,30 @@ class Transformer(Module):
             run.tape.append(('hc', rec, S.key))
         return binp, rec
 
+    def _hc_width_norm(self, run, S, hrec, gam, off, rpb):
+        """width connection + the branch's (Adaptive)RMSNorm (e2_tts.py:875,881,908-914,926,937).  -> (bin, rec, xn, rn).  Fused into one
+        launch (e2k_hc_fwd_norm, round 6) in no-grad forwards, where the un-normalised branch input is never read again and is not even
+        written (bin is None then); _FUSE_HC_NORM = 2 fuses recorded training passes too (bin still written for the backward pass)"""
+        fuse = _FUSE_HC_NORM == 2 or (_FUSE_HC_NORM == 1 and not exists(run.tape))
+        if not fuse:
+            binp, rec = self._hc_width(run, S, hrec)
+            xn, rn = ops.rmsnorm_fwd(binp, gam, off, rpb)
+            return binp, rec, xn, rn
+        rec = _HCRec()
+        rec.hc, rec.prev = hrec, S.rec
+        if exists(S.X):
+            rec.xin, rec.yprev, rec.coef_prev = S.X, None, None
+        else:
+            rec.xin, rec.yprev, rec.coef_prev = S.M, S.y, S.coef
+        Mout, binp, coef, xn, rn = ops.hc_fwd(rec.xin, self._hc_params(hrec), yprev=rec.yprev, coef_prev=rec.coef_prev,
+                                              norm=(gam, off, rpb), want_bin=exists(run.tape))
+        rec.coef = coef
+        rec.ycur = rec.dy = rec.dbin = None
+        S.X, S.M, S.y, S.coef, S.rec = None, Mout, None, coef, rec
+        if exists(run.tape):
+            run.tape.append(('hc', rec, S.key))
+        return binp, rec, xn, rn
+
     def _hc_depth(self, S, rec, y):
         S.y = y
         rec.ycur = y
@@ -1226,14 +1250,13 @@ class Transformer(Module):
         if exists(tape):
             tape.append(('conv', rec, lr, binp, pre, key))
         # ---- attention
-        binp, rec = self._hc_width(run, S, lr.hc[1])
         a = lr.attn
         if text or not self.cond_on_time:
             gam, off, rpb, gate = self._f(lr.attn_g, D).view(1, D), 0., Mtok, None
         else:
             gam, off, rpb = run.condall[:, (ind * ncs + 0) * D:(ind * ncs + 1) * D], 1., rpbc
             gate = run.gates[:, (ind * ncs + 1) * D:(ind * ncs + 2) * D]
-        xn, rn = ops.rmsnorm_fwd(binp, gam, off, rpb)
+        binp, rec, xn, rn = self._hc_width_norm(run, S, lr.hc[1], gam, off, rpb)
         lfe = None if text else lr.lfe
         hf = xa = None
         if exists(lfe):
@@ -1255,14 +1278,13 @@ class Transformer(Module):
             tape.append(('attn', rec, lr, ind, text, binp, xn, rn, qkvg, ast, first, y, key, sid, hf, xa))
         # ---- attention across the frequency tokens of a frame (e2_tts.py:920-932), audio stream only
         if self.has_freq_axis and not text:
-            binp, rec = self._hc_width(run, S, lr.hc[3])
             fa = lr.fattn
             if not self.cond_on_time:
                 gam, off, rpb, gate = self._f(lr.fattn_g, D).view(1, D), 0., Mtok, None
             else:
                 gam, off, rpb = run.condall[:, (ind * ncs + 4) * D:(ind * ncs + 5) * D], 1., rpbc
                 gate = run.gates[:, (ind * ncs + 5) * D:(ind * ncs + 6) * D]
-            xn, rn = ops.rmsnorm_fwd(binp, gam, off, rpb)
+            binp, rec, xn, rn = self._hc_width_norm(run, S, lr.hc[3], gam, off, rpb)
             qkv = ops.gemm_nt(xn, self._w(fa.w, 3 * fa.I, D))
             ffirst = run.fvfirst is None
             fo = ops.freq_attn_fwd(qkv, B // run.F, run.F, N, fa.H, run.frot[0], run.frot[1], None if ffirst else run.fvfirst)
@@ -1273,14 +1295,13 @@ class Transformer(Module):
             if exists(tape):
                 tape.append(('fattn', rec, lr, ind, binp, xn, rn, qkv, fo, ffirst, y, key))
         # ---- feed-forward
-        binp, rec = self._hc_width(run, S, lr.hc[2])
         f = lr.ff
         if text or not self.cond_on_time:
             gam, off, rpb, gate = self._f(lr.ff_g, D).view(1, D), 0., Mtok, None
         else:
             gam, off, rpb = run.condall[:, (ind * ncs + 2) * D:(ind * ncs + 3) * D], 1., rpbc
             gate = run.gates[:, (ind * ncs + 3) * D:(ind * ncs + 4) * D]
-        xn, rn = ops.rmsnorm_fwd(binp, gam, off, rpb)
+        binp, rec, xn, rn = self._hc_width_norm(run, S, lr.hc[2], gam, off, rpb)
         if ops.fuse_geglu and not exists(tape) and ops.can_fuse_geglu(xn.shape[0], f.F, D):
             # no-grad forward (sample()): GEGLU as the epilogue of the first GEMM, the pre-activation H is never written
             # (MI355X, 8448 x 8192 x 1024: 154 us against 225 for GEMM + geglu_fwd, profiles/r03_geglu_fused.json).  With H
@@ -1875,6 +1896,9 @@ _DEFER_REDUCES = True         # hyper-connection / depthwise-conv parameter-grad
 _RECAST_T_ON_LANE = True      # recorded training plans refresh the transposed bf16 weight shadows on the WGRAD lane during the forward
 _ZERO_GRADS_ON_LANE = True    # the persistent flat gradient buffer is zero-filled on the WGRAD lane during the forward
 _BATCH_REDUCES = True         # the hyper-connection parameter-gradient reductions of a layer go out as one launch
+# the (Adaptive)RMSNorm of a branch inside the width connection's launch (e2k_hc_fwd_norm): 0 never, 1 in no-grad forwards (the branch input
+# itself is then not written), 2 in training passes too.  E2K_FUSE_HC_NORM presets it (A/B)
+_FUSE_HC_NORM = int(_os.environ.get('E2K_FUSE_HC_NORM', '1'))
 _CROSS_ONE_LAUNCH = True      # TextAudioCrossCondition's two projections (and the two halves of its dgrad) as ONE two-output GEMM launch
 
 _VIEW_OPS = {'view', '_unsafe_view', 'as_strided', 'slice', 'select', 'expand', 't', 'transpose', 'permute', 'unsqueeze', 'squeeze',

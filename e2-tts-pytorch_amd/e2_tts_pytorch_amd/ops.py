@@ -508,8 +508,10 @@ def hc_coef_width():
     return _lib.get().e2k_query_hc_coef_width()
 
 
-def hc_fwd(xin, params, *, yprev=None, coef_prev=None, width=True):
-    """xin (Mtok,4,D) bf16.  Returns (Mout, bin, coef) if width else (X, None, None)."""
+def hc_fwd(xin, params, *, yprev=None, coef_prev=None, width=True, norm=None, want_bin=True):
+    """xin (Mtok,4,D) bf16.  Returns (Mout, bin, coef) if width else (X, None, None).
+    norm = (gamma fp32 (nb, D), gamma_off, rows_per_batch): the branch's RMSNorm in the same launch (e2k_hc_fwd_norm) ->
+    (Mout, bin or None, coef, xn, rn); want_bin=False: the un-normalised branch input is not written (no-grad forwards)"""
     _chk(xin, yprev, coef_prev)
     Mtok, S, D = xin.shape
     assert S == 4 and xin.dtype == bf16 and xin.is_contiguous()
@@ -517,8 +519,18 @@ def hc_fwd(xin, params, *, yprev=None, coef_prev=None, width=True):
     mout = torch.empty_like(xin)
     binp = coef = None
     if width:
-        binp = torch.empty((Mtok, D), dtype=bf16, device=xin.device)
+        binp = torch.empty((Mtok, D), dtype=bf16, device=xin.device) if (want_bin or norm is None) else None
         coef = torch.empty((Mtok, hc_coef_width()), dtype=f32, device=xin.device)
+    if norm is not None:
+        assert width
+        gamma, goff, rpb = norm
+        _chk(gamma)
+        assert gamma.dtype == f32 and gamma.dim() == 2 and gamma.stride(1) == 1 and gamma.shape[1] == D
+        xn = torch.empty((Mtok, D), dtype=bf16, device=xin.device)
+        rn = torch.empty((Mtok,), dtype=f32, device=xin.device) if want_bin else None
+        _lib.get().e2k_hc_fwd_norm(_p(xin), _p(yprev), _p(coef_prev), _p(mout), _p(binp), _p(coef), *[_p(t) for t in params], Mtok, D,
+                                   int(depth), _p(gamma), gamma.stride(0), float(goff), int(rpb), _p(xn), _p(rn), _stream(xin))
+        return mout, binp, coef, xn, rn
     ps = [_p(t) for t in params] if width else [None] * 7
     _lib.get().e2k_hc_fwd(_p(xin), _p(yprev), _p(coef_prev), _p(mout), _p(binp), _p(coef), *ps, Mtok, D,
                           int(depth), int(width), _stream(xin))

@@ -127,6 +127,16 @@ int e2k_hc_fwd(const void* Xin, const void* yprev, const float* coef_prev, void*
                const float* dyn_alpha_fn, const float* dyn_alpha_scale, const float* dyn_beta_fn,
                const float* dyn_beta_scale, const float* gamma, int Mtok, int D, int has_depth,
                int has_width, void* stream);
+/* The width connection with the (Adaptive)RMSNorm that follows it in every branch of the backbone (e2_tts.py:875,881,908-914,926,937:
+ * `x, add_residual = hc(x)` then `x = norm(x[, cond])`; x_transformers RMSNorm / AdaptiveRMSNorm) applied while the branch
+ * input is in registers: xn (Mtok, D) bf16 = bin / |bin| sqrt(D) (norm_gamma[row / rows_per_batch][:] + gamma_off), rn (Mtok) = 1 / |bin|
+ * (NULL: not wanted).  |bin|^2 comes from the Gram matrix of the four streams inside the one reduction round the coefficients need.
+ * bin may be NULL (a no-grad forward needs only xn): replaces e2k_hc_fwd(has_width = 1) + e2k_rmsnorm_fwd. */
+int e2k_hc_fwd_norm(const void* Xin, const void* yprev, const float* coef_prev, void* Mout, void* bin,
+                    float* coef, const float* static_beta, const float* static_alpha,
+                    const float* dyn_alpha_fn, const float* dyn_alpha_scale, const float* dyn_beta_fn,
+                    const float* dyn_beta_scale, const float* gamma, int Mtok, int D, int has_depth,
+                    const float* norm_gamma, int64_t ldg, float gamma_off, int rows_per_batch, void* xn, float* rn, void* stream);
 /* backward of the same fused pair.  G = grad wrt Mout (has_width) or wrt the materialised X (!has_width);
  * dbin = grad wrt bin; ycur = this instance's branch output.  Writes dR = grad wrt r (== grad wrt Xin) and,
  * if has_depth, dyprev = sum_s b_prev[s] * dR[s].  Parameter gradients are ACCUMULATED into g_* (fp32).

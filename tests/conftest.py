@@ -13,6 +13,7 @@ def install_lib(path, host_pointers):
 # the launch lanes + the gradient-exchange stream + RCCL's own streams need more than the default 4 hardware queues (DESIGN.md
 # section 4.1 / 6); bench.py sets the same before its first device call, so tests and bench run one queue mapping
 os.environ.setdefault('GPU_MAX_HW_QUEUES', '8')
+os.environ.setdefault('HIP_FORCE_DEV_KERNARG', '1')          # (kernel arguments in device memory: bench.py says why; the tests run the bench's runtime settings)
 
 ROOT = Path(__file__).resolve().parent.parent
 for p in (ROOT / 'e2-tts-pytorch_amd', ROOT, ROOT / 'tests'):

@@ -567,6 +567,48 @@ def test_plan_graph_replay_keeps_dropout_fresh(dev):
     assert torch.equal(a[2][0], a[4][0]) and torch.equal(a[2][1], a[4][1])
 
 
+def test_branch_norm_inside_the_width_connection(dev, monkeypatch):
+    """backbone._FUSE_HC_NORM: 0 = width connection and branch norm as two launches; 1 (default) = one launch in no-grad forwards, which do
+    not write the un-normalised branch input at all; 2 = one launch in training passes too.  Same outputs and gradients to bf16 rounding of
+    the normalised branch input (the fused kernel takes the norm from the fp32 streams' Gram matrix)"""
+    import e2_tts_pytorch_amd.backbone as bbm
+    from e2_tts_pytorch_amd import Transformer
+    random.seed(0)
+    torch.manual_seed(0)
+    T = 40 if gpu_shapes(dev) else 24
+    mod = Transformer(dim=256, depth=2, heads=2, dropout=0., max_seq_len=64, num_registers=32 if gpu_shapes(dev) else 8)
+    randomize(mod)
+    mod = mod.to(dev)
+    mod.enable_plans(False)
+    g = torch.Generator().manual_seed(1)
+    x0 = torch.randn(2, T, 256, generator=g).to(dev)
+    t = torch.rand(2, generator=g).to(dev)
+    txt = torch.randn(2, T, 128, generator=g).to(dev)
+    mask = (torch.arange(T)[None] < torch.tensor([T, T - 7])[:, None]).to(dev)
+    R = torch.randn(2, T, 256, generator=g).to(dev)
+    res = {}
+    for mode in (0, 2):
+        monkeypatch.setattr(bbm, '_FUSE_HC_NORM', mode)
+        mod.zero_grad(set_to_none=True)
+        x = x0.clone().requires_grad_(True)
+        out = mod(x, times=t, mask=mask, text_embed=txt)
+        (out * R).sum().backward()
+        res[mode] = (out.detach().cpu(), x.grad.cpu(), {n: p.grad.cpu().clone() for n, p in mod.named_parameters()})
+    # (half of the normalised branch input's elements move by one bf16 place -- an independent rounding, like the 0.5 % each mode is from the fp32 oracle)
+    assert rel2(res[2][0], res[0][0]) < 1e-2 and rel2(res[2][1], res[0][1]) < 2e-2
+    for n, g0 in res[0][2].items():
+        if g0.numel() >= 4096:
+            assert rel2(res[2][2][n], g0) < 4e-2 or float(g0.norm()) < 1e-6, n
+        else:       # tiny tensors are heavily cancelling sums over all tokens: the scalar hyper-connection scales carry +-3 of noise whatever their size
+            assert float((res[2][2][n] - g0).norm()) <= 0.15 * float(g0.norm()) + 4., n
+    with torch.no_grad():
+        outs = {}
+        for mode in (0, 1):
+            monkeypatch.setattr(bbm, '_FUSE_HC_NORM', mode)
+            outs[mode] = mod(x0, times=t, mask=mask, text_embed=txt).cpu()
+    assert rel2(outs[1], outs[0]) < 1e-2 and rel2(outs[0], res[0][0]) < 5e-3          # (the no-grad schedule fuses the GEGLU into its GEMM: not the training pass bit for bit)
+
+
 def test_plan_replay_with_the_default_off_switches(dev):
     """has_freq_axis + attn_laser + attn_fourier_embed_input all on: the recorded plan (forward and backward, launch lanes on)
     reproduces the eager schedule -- the frequency attention, LASER maps and Fourier kernels are ordinary recorded calls and

@@ -138,3 +138,39 @@ def test_hc_chain(dev, D):
         assert rk[name] <= 1.5 * scale, (name, D, 'rms', rk[name], re[name], pooled)
         assert max(dk[name]) / _rms(mg[name]) <= 3.5 * scale, (name, D, 'max', dk[name], de[name])
         assert rk[name] < 3e-2, (name, D, rk[name])          # and in absolute terms: bf16 resolution of a well-scaled sum
+
+
+@pytest.mark.parametrize('D,adaptive', [(128, False), (512, True), (768, False), (1024, True), (2048, True)])
+def test_hc_fwd_with_the_branch_norm(dev, D, adaptive):
+    """e2k_hc_fwd_norm (round 6): the width connection with the (Adaptive)RMSNorm that follows it (e2_tts.py:875,881,908-914,937) in one
+    launch.  Streams, coefficients and (when asked for) the un-normalised branch input are bit for bit those of e2k_hc_fwd; the
+    normalised branch input and 1 / |bin| agree with e2k_rmsnorm_fwd of that branch input to bf16 / fp32 rounding (the norm comes from the
+    Gram matrix of the four fp32 streams instead of from the bf16-rounded branch input) and with the fp32 formula; with and without the
+    depth connection of the previous instance; without the branch input (the no-grad form)"""
+    from e2_tts_pytorch_amd import ops
+    Mtok, nb = 41, 3
+    rpb = (Mtok + nb - 1) // nb
+    hc1, hc2 = _mk_hc(D, 1), _mk_hc(D, 2)
+    torch.manual_seed(7)
+    X = torch.randn(Mtok, 4, D).to(bf16).to(dev)
+    p1 = [t.detach().to(dev) for t in _params(hc1)]
+    p2 = [t.detach().to(dev) for t in _params(hc2)]
+    gam = (torch.randn(nb, D) * 0.3).to(dev) if adaptive else (1 + torch.randn(1, D) * 0.2).to(dev)
+    off, rows = (1., rpb) if adaptive else (0., Mtok)
+    M1, bin1, c1 = ops.hc_fwd(X, p1)
+    xn1, rn1 = ops.rmsnorm_fwd(bin1, gam, off, rows)
+    M1f, bin1f, c1f, xn1f, rn1f = ops.hc_fwd(X, p1, norm=(gam, off, rows))
+    assert torch.equal(M1f.cpu(), M1.cpu()) and torch.equal(bin1f.cpu(), bin1.cpu()) and torch.equal(c1f.cpu(), c1.cpu())
+    assert rel(xn1f.cpu(), xn1.cpu()) < 1e-2 and torch.allclose(rn1f.cpu(), rn1.cpu(), rtol=3e-3)
+    y1 = torch.tanh(bin1.float()).to(bf16)
+    M2, bin2, c2 = ops.hc_fwd(M1, p2, yprev=y1, coef_prev=c1)
+    xn2, rn2 = ops.rmsnorm_fwd(bin2, gam, off, rows)
+    M2f, bin2f, c2f, xn2f, rn2f = ops.hc_fwd(M1, p2, yprev=y1, coef_prev=c1, norm=(gam, off, rows), want_bin=False)
+    assert bin2f is None and rn2f is None and torch.equal(M2f.cpu(), M2.cpu()) and torch.equal(c2f.cpu(), c2.cpu())
+    assert rel(xn2f.cpu(), xn2.cpu()) < 1e-2
+    # against the fp32 formula on the bf16 branch input: F.normalize(x) sqrt(D) (gamma + off)
+    g = gam.cpu()[torch.arange(Mtok) // rows] + off
+    want = torch.nn.functional.normalize(bin2.cpu().float(), dim=-1) * D ** 0.5 * g
+    assert rel(xn2f.cpu(), want) < 1e-2
+    # fewer bf16 roundings than the two-launch pair: at least as close to the formula on the UNROUNDED branch input
+    assert (xn2f.cpu().float() - want).norm() <= 1.5 * (xn2.cpu().float() - want).norm() + 1e-3

@@ -38,4 +38,4 @@ res = {'metric': 'sampled mel-frames/sec (E2TTS.sample, 32 midpoint steps, CFG)'
        'model_tflops_per_s': fwd_flops / dt / 1e12, 'shape': list(out.shape)}
 print(json.dumps(res))
 (ROOT / 'gpurun_out').mkdir(exist_ok=True)
-json.dump(res, open(ROOT / 'gpurun_out' / ('r05_sample_cfg5%s%s.json' % ('_eager' if '--eager' in sys.argv else '', '_sequential' if os.environ.get('E2K_CFG_CONCURRENT') == '0' else '')), 'w'), indent=1)
+json.dump(res, open(ROOT / 'gpurun_out' / ('r06_sample_cfg5%s%s.json' % ('_eager' if '--eager' in sys.argv else '', '_sequential' if os.environ.get('E2K_CFG_CONCURRENT') == '0' else '')), 'w'), indent=1)

@@ -1,4 +1,4 @@
-"""gpurun_out/nt_traffic_{FETCH,WRITE}_SIZE.csv (tools/gpu/traffic.sh) -> profiles/r05_nt_traffic.json
+"""gpurun_out/nt_traffic_{FETCH,WRITE}_SIZE.csv (tools/gpu/traffic.sh) -> profiles/r06_nt_traffic.json
 
 One main-kernel dispatch (+ its fix-up dispatch, if any) per entry of tools/nt_shapes_cfg3.json, in file order; the
 per-launch numbers are weighted by the call count of each shape in a cfg3 training step."""
@@ -41,5 +41,5 @@ res = dict(kernel='gemm_nt_256_kernel / gemm_nt_glds_kernel (+fix-ups): the NT l
                   'per distinct NT shape of a cfg3 step (tools/nt_shapes_cfg3.json), weighted by its call count; FETCH_SIZE (KB) '
                   'doubled (gfx950 counts 128-B requests as 64 B, MI355X_MICROARCH.md HBM section); WRITE_SIZE (KB) uncalibrated',
            shapes=rows)
-json.dump(res, open(ROOT / 'profiles' / 'r05_nt_traffic.json', 'w'), indent=1)
+json.dump(res, open(ROOT / 'profiles' / 'r06_nt_traffic.json', 'w'), indent=1)
 print({k: v for k, v in res.items() if k not in ('shapes', 'method')})
