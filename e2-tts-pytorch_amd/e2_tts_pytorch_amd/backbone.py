@@ -1197,9 +1197,10 @@ class Transformer(Module):
         return binp, rec
 
     def _hc_width_norm(self, run, S, hrec, gam, off, rpb):
-        """width connection + the branch's (Adaptive)RMSNorm (e2_tts.py:875,881,908-914,926,937).  -> (bin, rec, xn, rn).  Fused into one
-        launch (e2k_hc_fwd_norm, round 6) in no-grad forwards, where the un-normalised branch input is never read again and is not even
-        written (bin is None then); _FUSE_HC_NORM = 2 fuses recorded training passes too (bin still written for the backward pass)"""
+        """width connection + the branch's (Adaptive)RMSNorm (e2_tts.py:875,881,908-914,926,937).  -> (bin, rec, xn, rn).  One launch
+        (e2k_hc_fwd_norm, round 6).  In no-grad forwards the un-normalised branch input is never read again and is not even written (bin is
+        None then); training passes keep it for the backward pass (_FUSE_HC_NORM = 2, the default: 96 launches less per cfg3 step, 84.48 /
+        84.44 -> 84.34 / 84.25 ms; 1 = no-grad forwards only, 0 = two launches; profiles/r06i_hc_norm_fused_ab.txt)"""
         fuse = _FUSE_HC_NORM == 2 or (_FUSE_HC_NORM == 1 and not exists(run.tape))
         if not fuse:
             binp, rec = self._hc_width(run, S, hrec)
@@ -1897,8 +1898,8 @@ _RECAST_T_ON_LANE = True      # recorded training plans refresh the transposed b
 _ZERO_GRADS_ON_LANE = True    # the persistent flat gradient buffer is zero-filled on the WGRAD lane during the forward
 _BATCH_REDUCES = True         # the hyper-connection parameter-gradient reductions of a layer go out as one launch
 # the (Adaptive)RMSNorm of a branch inside the width connection's launch (e2k_hc_fwd_norm): 0 never, 1 in no-grad forwards (the branch input
-# itself is then not written), 2 in training passes too.  E2K_FUSE_HC_NORM presets it (A/B)
-_FUSE_HC_NORM = int(_os.environ.get('E2K_FUSE_HC_NORM', '1'))
+# itself is then not written), 2 (default) in training passes too.  E2K_FUSE_HC_NORM presets it (A/B)
+_FUSE_HC_NORM = int(_os.environ.get('E2K_FUSE_HC_NORM', '2'))
 _CROSS_ONE_LAUNCH = True      # TextAudioCrossCondition's two projections (and the two halves of its dgrad) as ONE two-output GEMM launch
 
 _VIEW_OPS = {'view', '_unsafe_view', 'as_strided', 'slice', 'select', 'expand', 't', 'transpose', 'permute', 'unsqueeze', 'squeeze',

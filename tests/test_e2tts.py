@@ -219,7 +219,7 @@ def test_e2tts_cfg3_width():
                  'transformer.layers.1.1.4.ff.0.proj.weight', 'transformer.layers.1.1.5.text_to_audio.weight',
                  'transformer.layers.1.0.1.dw_conv1d.0.weight'):
         gk, gr = dict(model.named_parameters())[name].grad, refp[name].grad
-        assert gk is not None and rel2(gk, gr) < 0.15, (name, rel2(gk, gr))
+        assert gk is not None and rel2(gk, gr) < 0.03, (name, rel2(gk, gr))          # (round 6: 0.15 before; measured 0.4-1.3 %, profiles/r06_parity_e2tts_cfg3_width.json)
         seen[name] = rel2(gk, gr)
     import json
     from pathlib import Path
