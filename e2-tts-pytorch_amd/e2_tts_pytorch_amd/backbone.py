@@ -754,7 +754,15 @@ class Transformer(Module):
         None where it is still on its way"""
         live = bool(has_text)
         if handle is not None and not isinstance(handle, bool):
-            self.__dict__.setdefault('_text_live_pending', []).append((self._sync_target(), handle))
+            pend = self.__dict__.setdefault('_text_live_pending', [])
+            pend.append((self._sync_target(), handle))
+            if len(pend) > 64:              # nobody reads the flag (a loop without FusedAdopt): fold the oldest answers in -- their exchange
+                d = self.__dict__          # finished dozens of steps ago -- so that the parked handles stay bounded
+                v = d.get('_text_grad_live_v')
+                for tgt, h in pend[:32]:
+                    v = bool(tgt.end_text_live(h)) or bool(v)
+                d['_text_grad_live_v'] = v
+                del pend[:32]
             live = None
         else:
             if isinstance(handle, bool):
@@ -1303,12 +1311,12 @@ class Transformer(Module):
             gam, off, rpb = run.condall[:, (ind * ncs + 2) * D:(ind * ncs + 3) * D], 1., rpbc
             gate = run.gates[:, (ind * ncs + 3) * D:(ind * ncs + 4) * D]
         binp, rec, xn, rn = self._hc_width_norm(run, S, lr.hc[2], gam, off, rpb)
-        if ops.fuse_geglu and not exists(tape) and ops.can_fuse_geglu(xn.shape[0], f.F, D):
+        if ops.fuse_geglu and (not exists(tape) or _FUSE_GEGLU_TRAIN) and ops.can_fuse_geglu(xn.shape[0], f.F, D):
             # no-grad forward (sample()): GEGLU as the epilogue of the first GEMM, the pre-activation H is never written
             # (MI355X, 8448 x 8192 x 1024: 154 us against 225 for GEMM + geglu_fwd, profiles/r03_geglu_fused.json).  With H
             # stored for a backward pass the fusion measured step-neutral (95.4 vs 95.2 ms), so training keeps two launches.
             Hh, act = ops.gemm_nt_geglu(xn, self._w(f.w1, 2 * f.F, D), self._f(f.b1, 2 * f.F), run.p_drop, run.seed, sid + 1,
-                                        run.seed_dev, want_h=False)
+                                        run.seed_dev, want_h=exists(tape))
         else:
             Hh = ops.gemm_nt(xn, self._w(f.w1, 2 * f.F, D), bias=self._f(f.b1, 2 * f.F))
             act = ops.geglu_fwd(Hh, run.p_drop, run.seed, sid + 1, run.seed_dev)
@@ -1509,7 +1517,7 @@ class Transformer(Module):
             Ln.fence(ops.MAIN, ops.WGRAD)             # the operands were produced on MAIN and (text stream) on TEXT
             Ln.fence(ops.TEXT, ops.WGRAD)
             with Ln.lane(ops.WGRAD):
-                ops.gemm_tn_group(probs, hold=hold[0], splits=_WGRAD_LANE_SPLITS)
+                ops.gemm_tn_group(probs, hold=hold[0], splits=_WGRAD_GROUP_SPLITS)
         run.wgrad = wgrad
 
         def wgrad_dual(a1, a2, b1, b2, out):
@@ -1526,7 +1534,7 @@ class Transformer(Module):
                 return ops.gemm_tn_dual(a1, a2, b1, b2, out)
             Ln.fence(Ln.cur, ops.WGRAD)
             with Ln.lane(ops.WGRAD):
-                ops.gemm_tn_dual(a1, a2, b1, b2, out, hold=hold[0], splits=_WGRAD_LANE_SPLITS)
+                ops.gemm_tn_dual(a1, a2, b1, b2, out, hold=hold[0], splits=_WGRAD_DUAL_SPLITS)
 
         def entry(ent):
             kind = ent[0]
@@ -1889,7 +1897,11 @@ class _TimeCondFn(torch.autograd.Function):
 # Schedule choices that were environment switches while they were being measured (rounds 3-5; the A/Bs are profiles/r03_grouped_wgrad_ab.jsonl,
 # r03_dual_wgrad_ab.jsonl, r04_* and profiles/HISTORY.md) and are decided: module constants since round 6 (tests flip some of them to cover
 # the paths small shapes take).
-_WGRAD_LANE_SPLITS = 0        # token-dimension splits of the weight-gradient GEMMs on the WGRAD lane: 0 = the library's cost model
+_WGRAD_LANE_SPLITS = int(_os.environ.get('E2K_WGRAD_SPLITS', '0'))        # token-dimension splits of the weight-gradient GEMMs on the WGRAD lane: 0 = the library's cost model (A/B instrument)
+_WGRAD_DUAL_SPLITS = int(_os.environ.get('E2K_WGRAD_SPLITS_DUAL', '2'))       # dual-source launches (36 tiles, M = 33792): TWO splits = 72 workgroups.  The cost model's 16 fill the chip (5.3 ms per step alone
+# against 13.5) and cost the step 0.45 ms: this launch lives on the WGRAD lane, off the critical chain, and a narrow grid leaves the CUs to the chain (profiles/r06l_wgrad_splits_in_step_ab.txt)      # the same for the dual-source launches (cross-condition / skip blocks)
+_FUSE_GEGLU_TRAIN = _os.environ.get('E2K_FUSE_GEGLU_TRAIN', '0') != '0'      # training passes: GEGLU as the first GEMM's epilogue WITH the pre-activation stored (A/B: neutral in round 3)
+_WGRAD_GROUP_SPLITS = int(_os.environ.get('E2K_WGRAD_SPLITS_GROUP', '0'))
 _WGRAD_DUAL = True            # dual-source weight-gradient launches for the cross-condition / skip projections
 _WGRAD_GROUP = True           # one grouped launch for the weight gradients of a layer
 _WGRAD_MIN_ROWS = 1024        # below this many token rows the fused weight-gradient launches are not used (256-KB partial tiles + reduce pass)

@@ -674,6 +674,9 @@ def gemm_nt_geglu(a, w1, bias=None, p_drop=0., seed=0, stream_id=0, seed_dev=Non
 
 # GEGLU backward as the epilogue of FeedForward's second dgrad GEMM (E2K_FUSE_GEGLU_BWD=0: two launches)
 fuse_geglu_bwd = bool(int(_os.environ.get('E2K_FUSE_GEGLU_BWD', '1')))
+# remainder split (E2K_GEMM_SPLIT) for this launch only: its tiles end in a long element-wise epilogue, so the 16 tiles that 528 leave over 512 slots
+# cost a whole extra round (A/B instrument, round 6)
+geglu_bwd_split = int(_os.environ.get('E2K_GEGLU_BWD_SPLIT', '0'))
 
 
 def can_fuse_geglu_bwd(M, F, K):
@@ -700,7 +703,7 @@ def gemm_nt_geglu_bwd(dy, w2T, H, p_drop=0., seed=0, stream_id=0, seed_dev=None)
     _note(2.0 * M * F * K)
     stream = _stream(dy)
     _lib.get().e2k_gemm_nt_geglu_bwd_bf16(_p(dy), ldy, K, _p(w2T), ldb, _p(H), H.stride(0), _p(dH), dH.stride(0), M, F, float(p_drop),
-                                          int(seed), _p(seed_dev), int(stream_id), gemm_flags, *_nt_ws(dy.device, stream), stream)
+                                          int(seed), _p(seed_dev), int(stream_id), gemm_flags | (512 if geglu_bwd_split else 0), *_nt_ws(dy.device, stream), stream)
     return dH
 
 

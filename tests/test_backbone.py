@@ -635,6 +635,47 @@ def test_branch_norm_inside_the_width_connection(dev, monkeypatch):
     assert rel2(outs[1], outs[0]) < 1e-2 and rel2(outs[0], res[0][0]) < 5e-3          # (the no-grad schedule fuses the GEGLU into its GEMM: not the training pass bit for bit)
 
 
+def test_text_live_flag_is_resolved_where_it_is_read():
+    """Transformer._text_grad_live under a data-parallel exchange whose answer arrives later (ddp._GradSync.begin_text_live on a HIP device
+    returns a handle: pinned word + event): the backward pass only PARKS the handle (round 6: it used to wait for it), the first read of
+    the flag resolves every parked handle and ORs the answers, assignment (the optimizer's `= None`) clears them, answers known at once
+    (single rank) queue behind pending ones, and the parked list stays bounded when nobody ever reads the flag"""
+    from e2_tts_pytorch_amd import Transformer
+    tr = Transformer(dim=256, depth=2, heads=2, max_seq_len=64)
+    waited = []
+
+    class FakeSync:
+        lanes = []
+
+        def begin_text_live(self, live, device):
+            return ('handle', live)
+
+        def end_text_live(self, handle):
+            waited.append(handle)
+            return handle[1]
+
+        def __call__(self, *a):
+            pass
+    tr._grad_sync = FakeSync()
+    assert tr._text_grad_live is None
+    assert tr._end_text_live(tr._begin_text_live(False, 'cpu'), False) is None and not waited          # parked, nobody waited
+    tr._end_text_live(tr._begin_text_live(True, 'cpu'), True)
+    tr._end_text_live(False, False)                                                               # an immediate answer behind pending ones
+    assert not waited and tr._text_live_is_global
+    assert tr._text_grad_live is True and len(waited) == 2                                        # first read: resolved, ORed
+    assert tr._text_grad_live is True and len(waited) == 2                                        # (once)
+    tr._text_grad_live = None                                                                     # the optimizer consumed it
+    tr._end_text_live(tr._begin_text_live(False, 'cpu'), False)
+    assert tr._text_grad_live is False and len(waited) == 3
+    tr._text_grad_live = None
+    for _ in range(200):
+        tr._end_text_live(tr._begin_text_live(False, 'cpu'), False)
+    assert len(tr.__dict__['_text_live_pending']) <= 64 and tr._text_grad_live is False
+    tr._grad_sync = None
+    tr._text_grad_live = None
+    assert tr._end_text_live(True, True) is True and tr._text_grad_live is True                   # single rank: known at once
+
+
 def test_plan_replay_with_the_default_off_switches(dev):
     """has_freq_axis + attn_laser + attn_fourier_embed_input all on: the recorded plan (forward and backward, launch lanes on)
     reproduces the eager schedule -- the frequency attention, LASER maps and Fourier kernels are ordinary recorded calls and
