@@ -992,10 +992,14 @@ class Transformer(Module):
                 if st.need_grad:
                     # training: the parameters change every step.  The transposed shadows are read by the backward only: they
                     # are refreshed inside the forward on the WGRAD lane, which has nothing else to do there (_run_forward)
-                    self._recast(transposes=not _RECAST_T_ON_LANE)
+                    if not _RECAST_W_ON_LANE:
+                        self._recast(transposes=not _RECAST_T_ON_LANE)
+                    elif not _RECAST_T_ON_LANE:
+                        self._recast_transposes()
                 with ops.pinned_stream(dev):
                     run = self._run_forward(st.x, st.cond, st.text, st.mask, st.need_grad, seed_dev=st.seed, rot=rot,
-                                            recast_T=st.need_grad and _RECAST_T_ON_LANE, zero_grads=st.need_grad and _ZERO_GRADS_ON_LANE)
+                                            recast_T=st.need_grad and _RECAST_T_ON_LANE, zero_grads=st.need_grad and _ZERO_GRADS_ON_LANE,
+                                            recast_W=st.need_grad and _RECAST_W_ON_LANE)
                 st.fwd = ops.end_recording()
             except BaseException:
                 ops.abort_recording()
@@ -1068,7 +1072,7 @@ class Transformer(Module):
 
     # ------------------------------------------------------------------ forward schedule
 
-    def _run_forward(self, x_in, cond, text_embed, mask, want_tape, seed_dev=None, rot=None, recast_T=False, zero_grads=False):
+    def _run_forward(self, x_in, cond, text_embed, mask, want_tape, seed_dev=None, rot=None, recast_T=False, zero_grads=False, recast_W=False):
         """the whole forward as a sequence of e2k calls (nothing else touches the device in here: a launch plan replays
         exactly the recorded calls, so a tensor-library op in between would silently be skipped on replay)"""
         dev = x_in.device
@@ -1094,6 +1098,14 @@ class Transformer(Module):
             mask = mask if mask.is_contiguous() else mask.contiguous()
         run.kmask, run.mask_n = ops.build_masks(mask, B, T, R, dev, want_mask_n=exists(mask))
         run.rot = rot if exists(rot) else ops.rotary_table(N, dev)
+
+        # bf16 shadows of the fp32 master weights (recorded training plans, recast_W): the cast of the whole 716 M-element buffer was the first
+        # launch of the step, 0.9 ms in front of everything.  Round 6: only the global slab and the first layer are cast here, on the chain;
+        # the other layers' slabs follow on the WGRAD lane (idle in the forward), two layers per launch, each with an ordering point that
+        # the chain and the TEXT lane wait for in front of the first layer of the chunk -- the casts run a layer or two ahead of their use
+        w_head = self._recs[0].end if recast_W else 0
+        if recast_W:
+            ops.cast_bf16(self._flat[:w_head], self._shadow[:w_head])
 
         # time conditioning, hoisted out of the layer loop: one GEMM for every layer's gamma / gate
         if self.cond_on_time:
@@ -1124,6 +1136,21 @@ class Transformer(Module):
         L = run.lanes = ops.Lanes(dev, self._lane_streams(dev) if exists(st) else [], self._lane_mask)
         ev_cross = L.record(ops.MAIN)
         run.grads_zeroed = None
+        ev_w = {}                      # layer index -> ordering point after which that layer's (and its chunk's) bf16 shadows are written
+        if recast_W and w_head < self._flat.numel():
+            if L.has(ops.WGRAD):
+                L.wait(ops.WGRAD, ev_cross)
+                with L.lane(ops.WGRAD):
+                    for k in range(1, len(self._recs), _RECAST_W_CHUNK):
+                        a = self._recs[k].start
+                        b = self._recs[min(k + _RECAST_W_CHUNK, len(self._recs)) - 1].end
+                        ops.cast_bf16(self._flat[a:b], self._shadow[a:b])
+                        ev_w[k] = L.record(ops.WGRAD)
+                tail = self._recs[-1].end
+            else:
+                tail = w_head
+            if tail < self._flat.numel():                       # (no lane for it, or whatever the layout keeps behind the last layer)
+                ops.cast_bf16(self._flat[tail:], self._shadow[tail:])
         if recast_T or zero_grads:
             # (the lane starts after everything the caller's stream had queued before this forward -- the optimizer's update of
             #  the fp32 parameters and its read of the gradients included; the forward's final join makes MAIN, hence the
@@ -1148,6 +1175,10 @@ class Transformer(Module):
             ind = r.index
             if exists(tape):
                 tape.append(('layer', r))
+            if ind in ev_w:                     # this layer's bf16 weights come from the WGRAD lane: both consumers wait for them
+                L.wait(ops.MAIN, ev_w[ind])
+                if exists(st):
+                    L.wait(ops.TEXT, ev_w[ind])
             if exists(st) and exists(r.t):
                 L.wait(ops.TEXT, ev_cross)
                 with L.lane(ops.TEXT):
@@ -1176,7 +1207,7 @@ class Transformer(Module):
         y, rn = ops.rmsnorm_fwd(xsum, gfin, 0., B * T)
         run.tail = (xsum, rn)
         run.out = ops.cast_f32(y).view(B, T, D)
-        if recast_T or zero_grads:
+        if recast_T or zero_grads or ev_w:
             L.fence(ops.WGRAD, ops.MAIN)        # the backward (MAIN and, through it, every lane) starts after the transposed shadows are written
         return run
 
@@ -1906,6 +1937,8 @@ _WGRAD_DUAL = True            # dual-source weight-gradient launches for the cro
 _WGRAD_GROUP = True           # one grouped launch for the weight gradients of a layer
 _WGRAD_MIN_ROWS = 1024        # below this many token rows the fused weight-gradient launches are not used (256-KB partial tiles + reduce pass)
 _DEFER_REDUCES = True         # hyper-connection / depthwise-conv parameter-gradient reductions on the WGRAD lane instead of on the chain
+_RECAST_W_ON_LANE = _os.environ.get('E2K_RECAST_W_ON_LANE', '1') != '0'      # ... and the bf16 shadows themselves layer by layer ahead of their use (round 6; A/B)
+_RECAST_W_CHUNK = 2             # layers per cast launch on the lane
 _RECAST_T_ON_LANE = True      # recorded training plans refresh the transposed bf16 weight shadows on the WGRAD lane during the forward
 _ZERO_GRADS_ON_LANE = True    # the persistent flat gradient buffer is zero-filled on the WGRAD lane during the forward
 _BATCH_REDUCES = True         # the hyper-connection parameter-gradient reductions of a layer go out as one launch

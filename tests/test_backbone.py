@@ -635,6 +635,56 @@ def test_branch_norm_inside_the_width_connection(dev, monkeypatch):
     assert rel2(outs[1], outs[0]) < 1e-2 and rel2(outs[0], res[0][0]) < 5e-3          # (the no-grad schedule fuses the GEGLU into its GEMM: not the training pass bit for bit)
 
 
+def test_recorded_training_plan_recasts_its_weights_every_replay(dev):
+    """a recorded training plan refreshes the bf16 shadows of the fp32 master weights itself -- since round 6 the global slab and the first
+    layer on the chain and the other layers two at a time on the WGRAD lane, each chunk with an ordering point its consumers wait for
+    (backbone._RECAST_W_ON_LANE).  After the parameters changed (an optimizer step between replays) a replay must compute with the NEW
+    weights in every layer: shadows equal to the rounded masters afterwards, and the output that of a fresh eager pass"""
+    from e2_tts_pytorch_amd import Transformer
+    random.seed(0)
+    torch.manual_seed(0)
+    T = 40 if gpu_shapes(dev) else 24
+    mod = Transformer(dim=256, depth=4, heads=2, dropout=0., max_seq_len=64, num_registers=32 if gpu_shapes(dev) else 8)
+    randomize(mod)
+    mod = mod.to(dev)
+    g = torch.Generator().manual_seed(2)
+    x = torch.randn(2, T, 256, generator=g).to(dev)
+    t = torch.rand(2, generator=g).to(dev)
+    txt = torch.randn(2, T, 128, generator=g).to(dev)
+
+    def step():
+        mod.zero_grad(set_to_none=True)
+        out = mod(x.clone().requires_grad_(True), times=t, text_embed=txt)
+        out.sum().backward()
+        return out.detach().clone()
+
+    import copy
+    twin = copy.deepcopy(mod)                                # the eager schedule on the same weights
+    twin.enable_plans(False)
+
+    def step_twin():
+        twin.zero_grad(set_to_none=True)
+        out = twin(x.clone().requires_grad_(True), times=t, text_embed=txt)
+        out.sum().backward()
+        return out.detach().clone()
+
+    step(); step(); step()                                   # eager, recording, replay
+    st = [v for v in mod._plans.values() if not isinstance(v, str)][0]
+    assert st.fwd and st.bwd
+    for k in range(3):
+        with torch.no_grad():
+            for p, q in zip(mod.parameters(), twin.parameters()):        # an "optimizer step" that moves every layer
+                d = torch.randn(p.shape, generator=g).to(dev) * 0.02 * (p.abs().mean() + 1e-3)
+                p.add_(d)
+                q.add_(d)
+                torch.autograd.graph.increment_version(p)
+                torch.autograd.graph.increment_version(q)
+        got = step()                                         # a replay of the recorded plan
+        assert [v for v in mod._plans.values() if not isinstance(v, str)][0] is st
+        assert torch.equal(mod._shadow.cpu(), mod._flat.to(torch.bfloat16).cpu()), k
+        assert torch.equal(got, step_twin()), k
+
+
 def test_text_live_flag_is_resolved_where_it_is_read():
     """Transformer._text_grad_live under a data-parallel exchange whose answer arrives later (ddp._GradSync.begin_text_live on a HIP device
     returns a handle: pinned word + event): the backward pass only PARKS the handle (round 6: it used to wait for it), the first read of
