@@ -339,7 +339,7 @@ def main():
         # the per-call times are those of each kernel running alone, their sum exceeds the step time when lanes overlap)
         lane_ops = sum(r['name'].startswith('lane_event') for r in prof_rows) // nprof
         prof_rows = [r for r in prof_rows if not r['name'].startswith('lane_event')]
-        gemm = [r for r in prof_rows if r['name'] in ('gemm_nt_bf16', 'gemm_nt_geglu_bf16', 'gemm_nt_geglu_bwd_bf16')]     # (the NT kernel family: plain, + GEGLU forward epilogue (inference), + GEGLU backward epilogue)
+        gemm = [r for r in prof_rows if r['name'] in ('gemm_nt_bf16', 'gemm_nt_geglu_bf16', 'gemm_nt_geglu_bwd_bf16', 'gemm_nt_qkrot_bf16')]     # (the NT kernel family: plain, + GEGLU forward epilogue (inference), + GEGLU backward epilogue, + rotary q / k epilogue)
         gemm_flops, gemm_ms, n_launch = sum(r['flops'] for r in gemm), sum(r['ms'] for r in gemm), len(gemm)
     else:
         prof = []
@@ -440,7 +440,7 @@ def main():
                              'note': 'text branches / weight-gradient GEMMs on side streams (ops.Lanes, csrc/plan.h); E2K_LANES=0 for the single-stream schedule'},
             'kernel_groups_ms_per_step': _groups(prof_rows, nprof) if prof_rows else None,
             'roofline': {
-                'bound': 'mfma', 'kernel': 'e2k_gemm_nt_bf16 (+ e2k_gemm_nt_geglu_bwd_bf16, the same kernel with the GEGLU backward as its epilogue): gemm_nt_256_kernel (256x256x64, 8-phase) / gemm_nt_glds_kernel (128x128x64), C tiles through LDS in whole-line 16-byte stores (bf16 MFMA 16x16x32; every forward and dgrad GEMM of the step; no remainder split since round 6: alone-timed, as here, that costs the kernel 2 % -- 0.280 -> 0.270 of peak on one box -- and gains the step 0.5 ms, profiles/r06f_nt_remainder_split_in_step_ab.txt)',
+                'bound': 'mfma', 'kernel': 'e2k_gemm_nt_bf16 (+ e2k_gemm_nt_geglu_bwd_bf16 / e2k_gemm_nt_qkrot_bf16, the same kernel with the GEGLU backward / the rotary embedding of q and k as its epilogue): gemm_nt_256_kernel (256x256x64, 8-phase) / gemm_nt_glds_kernel (128x128x64), C tiles through LDS in whole-line 16-byte stores (bf16 MFMA 16x16x32; every forward and dgrad GEMM of the step; no remainder split since round 6: alone-timed, as here, that costs the kernel 2 % -- 0.280 -> 0.270 of peak on one box -- and gains the step 0.5 ms, profiles/r06f_nt_remainder_split_in_step_ab.txt)',
                 'achieved': achieved, 'peak': PEAK_BF16_TFLOPS, 'unit': 'TFLOP/s', 'frac': achieved / PEAK_BF16_TFLOPS,
                 'launches_per_step': n_launch / nprof,
                 'avg_launch_ms': gemm_ms / max(n_launch, 1),

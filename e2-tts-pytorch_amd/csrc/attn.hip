@@ -96,8 +96,11 @@ struct PostArgs {
     float laser_c; bf16_t* Vorig;
 };
 
+// QK false: q and k were written (rotated, head-major) by the projection GEMM's epilogue (e2k_gemm_nt_qkrot_bf16); what is left is the
+// value path (value residual, LASER map, V and V^T) and the two gate columns
+template <bool QK>
 __global__ __launch_bounds__(256) void qkv_post_fwd_kernel(PostArgs p) {
-    __shared__ bf16_t tT[3][DH][64 + 8];
+    __shared__ bf16_t tT[QK ? 3 : 1][DH][64 + 8];
     const int tid = threadIdx.x;
     const int n0 = blockIdx.x * 64, h = blockIdx.y, b = blockIdx.z;
     const int tok = tid >> 2, seg = tid & 3;
@@ -109,17 +112,18 @@ __global__ __launch_bounds__(256) void qkv_post_fwd_kernel(PostArgs p) {
     for (int e = 0; e < 16; ++e) { q[e] = 0.f; k[e] = 0.f; v[e] = 0.f; }
     if (n < p.N) {
         const bf16_t* row = p.qkvg + ((long)b * p.N + n) * p.ldq + h * DH + seg * 16;
-        unpack8(ld<u32x4>(row), q);             unpack8(ld<u32x4>(row + 8), q + 8);
-        unpack8(ld<u32x4>(row + I), k);         unpack8(ld<u32x4>(row + I + 8), k + 8);
         unpack8(ld<u32x4>(row + 2 * I), v);     unpack8(ld<u32x4>(row + 2 * I + 8), v + 8);
-        const float* cs = p.cosb + (long)n * 32 + seg * 8;
-        const float* sn = p.sinb + (long)n * 32 + seg * 8;
+        if (QK) {
+            unpack8(ld<u32x4>(row), q);             unpack8(ld<u32x4>(row + 8), q + 8);
+            unpack8(ld<u32x4>(row + I), k);         unpack8(ld<u32x4>(row + I + 8), k + 8);
+            const float* cs = p.cosb + (long)n * 32 + seg * 8;
+            const float* sn = p.sinb + (long)n * 32 + seg * 8;
 #pragma unroll
-        for (int j = 0; j < 8; ++j) {
-            float c = cs[j], s = sn[j];
-            float q0 = q[2 * j], q1 = q[2 * j + 1], k0 = k[2 * j], k1 = k[2 * j + 1];
-            q[2 * j] = q0 * c - q1 * s;  q[2 * j + 1] = q1 * c + q0 * s;
-            k[2 * j] = k0 * c - k1 * s;  k[2 * j + 1] = k1 * c + k0 * s;
+            for (int j = 0; j < 8; ++j) {
+                float c = cs[j], s = sn[j];
+                rot_pair(q[2 * j], q[2 * j + 1], c, s);
+                rot_pair(k[2 * j], k[2 * j + 1], c, s);
+            }
         }
         const bf16_t* gp = p.qkvg + ((long)b * p.N + n) * p.ldq + 3 * I;
         if (p.vfirst) {
@@ -139,15 +143,17 @@ __global__ __launch_bounds__(256) void qkv_post_fwd_kernel(PostArgs p) {
 #pragma unroll
             for (int e = 0; e < 16; ++e) v[e] = __expf(p.laser_c * tanhf_(v[e] * ic));
         }
-        st<u32x4>(p.Q + o, pack8(q)); st<u32x4>(p.Q + o + 8, pack8(q + 8));
-        st<u32x4>(p.K + o, pack8(k)); st<u32x4>(p.K + o + 8, pack8(k + 8));
+        if (QK) {
+            st<u32x4>(p.Q + o, pack8(q)); st<u32x4>(p.Q + o + 8, pack8(q + 8));
+            st<u32x4>(p.K + o, pack8(k)); st<u32x4>(p.K + o + 8, pack8(k + 8));
+        }
         if (p.V) { st<u32x4>(p.V + o, pack8(v)); st<u32x4>(p.V + o + 8, pack8(v + 8)); }     // (null: a no-grad forward reads only V^T)
     }
 #pragma unroll
     for (int e = 0; e < 16; ++e) {
-        if (p.QT) tT[0][seg * 16 + e][tok] = f2bf(q[e]);
-        if (p.KT) tT[1][seg * 16 + e][tok] = f2bf(k[e]);
-        tT[2][seg * 16 + e][tok] = f2bf(v[e]);
+        if (QK && p.QT) tT[0][seg * 16 + e][tok] = f2bf(q[e]);
+        if (QK && p.KT) tT[1][seg * 16 + e][tok] = f2bf(k[e]);
+        tT[QK ? 2 : 0][seg * 16 + e][tok] = f2bf(v[e]);
     }
     __syncthreads();
     // transposed copies: thread writes 16 consecutive tokens of one dh row (Q^T, K^T only for the register-staged backward
@@ -155,11 +161,11 @@ __global__ __launch_bounds__(256) void qkv_post_fwd_kernel(PostArgs p) {
     const int d = tid >> 2, ts = (tid & 3) * 16;
     bf16_t* outs[3] = {p.QT, p.KT, p.VT};
 #pragma unroll
-    for (int w = 0; w < 3; ++w) {
+    for (int w = QK ? 0 : 2; w < 3; ++w) {
         if (!outs[w]) continue;
         bf16_t* dst = outs[w] + (bh * DH + d) * p.Npad + n0 + ts;
-        st<u32x4>(dst, ld<u32x4>(&tT[w][d][ts]));
-        st<u32x4>(dst + 8, ld<u32x4>(&tT[w][d][ts + 8]));
+        st<u32x4>(dst, ld<u32x4>(&tT[QK ? w : 0][d][ts]));
+        st<u32x4>(dst + 8, ld<u32x4>(&tT[QK ? w : 0][d][ts + 8]));
     }
 }
 
@@ -843,14 +849,17 @@ static int qkv_post_fwd_impl(const void* qkvg, int64_t ldq, const float* cosb, c
                                 void* v_orig, float laser_clamp, int B, int H, int N, int Npad, void* stream) {
     if (B <= 0 || N <= 0) return 0;
     if ((ldq & 7) || (Npad & 63) || Npad < N) return E2K_ERR_ALIGN;
-    if (!qkvg || !cosb || !sinb || !Q || !K || !VT || !gate || (vfirst && !mix)) return E2K_ERR_ARG;     // (QT, KT, V: optional)
+    if (!qkvg || !cosb || !sinb || !VT || !gate || (vfirst && !mix)) return E2K_ERR_ARG;     // (QT, KT, V: optional)
+    // Q = K = NULL: both were written by e2k_gemm_nt_qkrot_bf16 (then no transposed copies of them can be asked for either)
+    if ((Q == nullptr) != (K == nullptr) || (!Q && (QT || KT))) return E2K_ERR_ARG;
     if (laser_clamp < 0.f || (v_orig && !(laser_clamp > 0.f))) return E2K_ERR_ARG;
     PostArgs a{};
     a.laser_c = laser_clamp; a.Vorig = (bf16_t*)v_orig;
     a.qkvg = (const bf16_t*)qkvg; a.ldq = ldq; a.cosb = cosb; a.sinb = sinb; a.vfirst = (const bf16_t*)vfirst;
     a.Q = (bf16_t*)Q; a.K = (bf16_t*)K; a.V = (bf16_t*)V; a.QT = (bf16_t*)QT; a.KT = (bf16_t*)KT; a.VT = (bf16_t*)VT;
     a.gate = gate; a.mix = mix; a.B = B; a.H = H; a.N = N; a.Npad = Npad;
-    hipLaunchKernelGGL(qkv_post_fwd_kernel, dim3(Npad / 64, H, B), dim3(256), 0, (hipStream_t)stream, a);
+    if (Q) hipLaunchKernelGGL(qkv_post_fwd_kernel<true>, dim3(Npad / 64, H, B), dim3(256), 0, (hipStream_t)stream, a);
+    else hipLaunchKernelGGL(qkv_post_fwd_kernel<false>, dim3(Npad / 64, H, B), dim3(256), 0, (hipStream_t)stream, a);
     E2K_CHECK_LAUNCH();
     return 0;
 }

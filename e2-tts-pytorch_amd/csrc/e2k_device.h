@@ -48,6 +48,14 @@ __device__ __forceinline__ u32x2 pack4(const float* f) {
     u32x2 v; v[0] = pack2bf(f[0], f[1]); v[1] = pack2bf(f[2], f[3]); return v;
 }
 
+// rotary position embedding on one interleaved pair (x-transformers rotate_half on (d/2, 2) pairs; e2_tts.py:875,911): ONE definition
+// with explicit fused multiply-adds, shared by qkv_post_fwd_kernel and the QKV GEMM's rotating epilogue (gemm.hip, nt_stage_readback
+// EPI 2) so that the two produce the same bits
+__device__ __forceinline__ void rot_pair(float& x0, float& x1, float c, float s) {
+    const float a = fmaf(x0, c, -(x1 * s)), b = fmaf(x1, c, x0 * s);
+    x0 = a; x1 = b;
+}
+
 __device__ __forceinline__ float wave_sum(float v) {
 #pragma unroll
     for (int m = 32; m >= 1; m >>= 1) v += __shfl_xor(v, m);

@@ -26,6 +26,7 @@ using namespace e2k;
 namespace {
 
 constexpr int BM = 128, BN = 128, BK = 64;
+constexpr int DH_ROT = 64;       // dim_head of the rotary epilogue (the attention kernels' 64)
 constexpr int NT_SLOTS = 512;        // resident NT workgroups on the chip: 256 CUs x 2 (64 KB LDS each)
 
 __device__ __forceinline__ int xcd_remap(int orig, int nwg) {
@@ -68,6 +69,10 @@ struct NTArgs {
     // GEGLU BACKWARD as the epilogue (e2k_gemm_nt_geglu_bwd_bf16): the product is d(activation) (M, N = F); with the stored
     // pre-activation gb_H (M, 2F) = [u | g] the epilogue writes gb_dH (M, 2F) = [d keep gelu(g) | d keep u gelu'(g)] and C is not written
     const bf16_t* gb_H; long gb_ldh; bf16_t* gb_dH; long gb_lddh;
+    // rotary q / k as the epilogue of the attention's input projection (e2k_gemm_nt_qkrot_bf16, gemm_nt_256_kernel<false, false, 2>):
+    // tiles left of column rot_2I = 2 H 64 hold q | k; their values leave rotated and HEAD-MAJOR, (B, H, rot_N, 64) at rot_Q / rot_K
+    // (what qkv_post_fwd_kernel would have made of them), the other tiles (v, head gates, value-residual mix) go to C as always
+    bf16_t *rot_Q, *rot_K; const float *rot_cos, *rot_sin; int rot_I, rot_2I, rot_N, rot_H;
 };
 
 // two-output form: rebinds the (by-value) argument block of a workgroup whose tile lies in the second output
@@ -262,7 +267,8 @@ constexpr int GSTAGE_ROW = 128 * 4 + 16, GSTAGE_BYTES = 128 * GSTAGE_ROW;       
 // store per lane -- the epilogue is bound by the number of store instructions per CU, not by bytes (8-byte stores in
 // whole-line order measured no faster than the direct epilogue, profiles/r03_gemm_epilogue_ab_8byte_stores.json).  The
 // residual rows of all passes are fetched up front (their latency would otherwise be paid once per pass).
-template <bool OUT_F32, int ROWS, int COLS, int THREADS, bool GB = false>
+// EPI: 0 plain, 1 GEGLU backward, 2 rotary q / k (each its own instantiation: the plain kernels carry none of it)
+template <bool OUT_F32, int ROWS, int COLS, int THREADS, int EPI = 0>
 __device__ __forceinline__ void nt_stage_readback(const NTArgs& p, const unsigned char* S, int m_base, int n0, int tid) {
     constexpr int LPR = COLS / 8, RPP = THREADS / LPR, NP = ROWS / RPP, ROWB = COLS * 4 + 16;
     const int c = tid % LPR, rsub = tid / LPR;
@@ -270,6 +276,30 @@ __device__ __forceinline__ void nt_stage_readback(const NTArgs& p, const unsigne
     if (n >= p.N) return;                                // (N is a multiple of 8 on this path: a chunk is in or out as a whole)
     f32x4 b0 = {0.f, 0.f, 0.f, 0.f}, b1 = b0;
     if (p.bias) { b0 = ld<f32x4>(p.bias + n); b1 = ld<f32x4>(p.bias + n + 4); }
+    if (EPI == 2 && n0 < p.rot_2I) {       // (tile-uniform: rot_2I is a multiple of the tile width)
+        // a lane's 8 columns are 4 rotation pairs of one head: column n = which * I + h * 64 + d0.  The product is rounded to bf16
+        // first, as if it had gone through C: bit-identical to e2k_gemm_nt_bf16 + the q / k half of e2k_qkv_post_fwd
+        const int which = n >= p.rot_I ? 1 : 0, nn = n - which * p.rot_I, h = nn >> 6, d0 = nn & 63;
+        bf16_t* const base = (which ? p.rot_K : p.rot_Q) + (long)h * p.rot_N * DH_ROT + d0;
+        const int mf = m_base + rsub;
+        int b = mf / p.rot_N, tok = mf - b * p.rot_N;
+#pragma unroll
+        for (int pass = 0; pass < NP; ++pass) {
+            const int r = pass * RPP + rsub;
+            if (m_base + r < p.M) {
+                const f32x4 x0 = ld<f32x4>(S + r * ROWB + c * 32) + b0, x1 = ld<f32x4>(S + r * ROWB + c * 32 + 16) + b1;
+                const f32x4 cs = ld<f32x4>(p.rot_cos + (long)tok * 32 + (d0 >> 1)), sn = ld<f32x4>(p.rot_sin + (long)tok * 32 + (d0 >> 1));
+                float v[8] = {x0[0], x0[1], x0[2], x0[3], x1[0], x1[1], x1[2], x1[3]};
+                unpack8(pack8(v), v);
+#pragma unroll
+                for (int j = 0; j < 4; ++j) rot_pair(v[2 * j], v[2 * j + 1], cs[j], sn[j]);
+                st<u32x4>(base + ((long)b * p.rot_H * p.rot_N + tok) * DH_ROT, pack8(v));
+            }
+            tok += RPP;
+            while (tok >= p.rot_N) { tok -= p.rot_N; ++b; }
+        }
+        return;
+    }
     u32x4 rs[NP];
     if (p.resid) {
 #pragma unroll
@@ -282,7 +312,7 @@ __device__ __forceinline__ void nt_stage_readback(const NTArgs& p, const unsigne
     for (int pass = 0; pass < NP; ++pass) {
         const int r = pass * RPP + rsub, m = m_base + r;
         if (m >= p.M) continue;
-        if (GB) {            // GEGLU backward epilogue: 8 columns of d(activation) -> 8 + 8 columns of dH
+        if (EPI == 1) {      // GEGLU backward epilogue: 8 columns of d(activation) -> 8 + 8 columns of dH
             const f32x4 y0 = ld<f32x4>(S + r * ROWB + c * 32), y1 = ld<f32x4>(S + r * ROWB + c * 32 + 16);
             const float x[8] = {y0[0], y0[1], y0[2], y0[3], y1[0], y1[1], y1[2], y1[3]};
             nt_store_geglu_bwd<8>(p, m, n, x);
@@ -315,7 +345,7 @@ __device__ __forceinline__ void nt_stage_readback(const NTArgs& p, const unsigne
     }
 }
 
-template <bool OUT_F32, bool GB = false>
+template <bool OUT_F32, int EPI = 0>
 __device__ __forceinline__ void nt_epilogue_staged(const NTArgs& p, f32x4 (&acc)[2][2][4][2], unsigned char* S, int m0, int n0,
                                                    int tid, int wr, int wc, int l15, int g) {
 #pragma unroll
@@ -328,7 +358,7 @@ __device__ __forceinline__ void nt_epilogue_staged(const NTArgs& p, f32x4 (&acc)
                 for (int j = 0; j < 2; ++j)
                     st<f32x4>(S + (wr * 64 + i * 16 + l15) * QSTAGE_ROW + (b * 128 + wc * 32 + j * 16 + 4 * g) * 4, acc[a][b][i][j]);
         __syncthreads();
-        nt_stage_readback<OUT_F32, 128, 256, 512, GB>(p, S, m0 + a * 128, n0, tid);
+        nt_stage_readback<OUT_F32, 128, 256, 512, EPI>(p, S, m0 + a * 128, n0, tid);
         if (a == 0) __syncthreads();                     // the second half overwrites the staging rows
     }
 }
@@ -740,7 +770,8 @@ __device__ __forceinline__ void nt_epilogue_glu_staged(const NTArgs& p, f32x4 (&
 //   * In the last five phases nothing is left to issue, and the count is lowered step by step (4, 2, 0).
 constexpr int QBM = 256, QBN = 256, QHALF = 128 * BK * 2, QBUF = 4 * QHALF, QTHREADS = 512;
 
-template <bool OUT_F32, bool GLU = false, bool GB = false>       // GB: GEGLU backward epilogue (e2k_gemm_nt_geglu_bwd_bf16)
+// EPI 1: GEGLU backward epilogue (e2k_gemm_nt_geglu_bwd_bf16); EPI 2: rotary q / k epilogue (e2k_gemm_nt_qkrot_bf16, staged only)
+template <bool OUT_F32, bool GLU = false, int EPI = 0>
 __global__ __launch_bounds__(QTHREADS, 1) void gemm_nt_256_kernel(NTArgs p) {
     __shared__ __attribute__((aligned(16))) unsigned char smem[(2 * QBUF > QSTAGE_BYTES) ? 2 * QBUF : QSTAGE_BYTES];
     lds_declare(smem, sizeof(smem));
@@ -926,14 +957,14 @@ __global__ __launch_bounds__(QTHREADS, 1) void gemm_nt_256_kernel(NTArgs p) {
     }
     if (p.staged) {                          // (every DMA has landed and every fragment read has been waited for: the ring is free)
         __syncthreads();
-        nt_epilogue_staged<OUT_F32, GB>(p, acc, smem, m0, n0, tid, wr, wc, l15, g);
+        nt_epilogue_staged<OUT_F32, EPI>(p, acc, smem, m0, n0, tid, wr, wc, l15, g);
         return;
     }
 #pragma unroll
     for (int a = 0; a < 2; ++a)
 #pragma unroll
         for (int b = 0; b < 2; ++b)
-            nt_epilogue<OUT_F32, 4, 2, GB>(p, acc[a][b], m0 + a * 128 + wr * 64, n0 + b * 128 + wc * 32, l15, g);
+            nt_epilogue<OUT_F32, 4, 2, EPI == 1>(p, acc[a][b], m0 + a * 128 + wr * 64, n0 + b * 128 + wc * 32, l15, g);
 }
 
 // blockIdx.x = remainder tile, blockIdx.y = (A half * 2 + B half) * 4 + m16 group
@@ -1903,7 +1934,7 @@ static int gemm_nt_geglu_bwd_bf16_impl(const void* dY, int64_t ldy, int K, const
         else rem = 0;
     }
     hipStream_t st = (hipStream_t)stream;
-    hipLaunchKernelGGL((gemm_nt_256_kernel<false, false, true>), dim3(p.full + rem * p.split), dim3(QTHREADS), 0, st, p);
+    hipLaunchKernelGGL((gemm_nt_256_kernel<false, false, 1>), dim3(p.full + rem * p.split), dim3(QTHREADS), 0, st, p);
     E2K_CHECK_LAUNCH();
     if (rem) {
         hipLaunchKernelGGL((gemm_nt_256_fixup_kernel<false, true>), dim3(rem, 16), dim3(QTHREADS), 0, st, p);
@@ -1928,6 +1959,59 @@ extern "C" int e2k_gemm_nt_geglu_bwd_bf16(const void* dY, int64_t ldy, int K, co
                          stream_id, flags, ws, ws_bytes, stream);
 }
 
+
+// Attention's input projection with the rotary embedding of q and k as its epilogue: columns [0, 2 H 64) of
+// x W^T leave the kernel rotated and head-major, (B, H, Ntok, 64) at Q / Kh -- the q / k half of e2k_qkv_post_fwd, which then runs with
+// Q = K = NULL and reads only the value columns and the gate columns of C.  The 256 x 256 kernel with the staged epilogue only; shapes
+// the kernel cannot take are refused (e2k_query_gemm_nt_qkrot says which, and which it can take but should not), the caller then runs the
+// two-launch form.  Bit-identical to it: the product is rounded to bf16 before the rotation, as if it had been stored.  Never splits a remainder.
+static bool nt_qkrot_ok(int M, int N, int K, int H) {
+    return M > 0 && H > 0 && !(H & 1) && N >= 3 * H * DH_ROT && !(N & 7) && K >= 4 * BK && (K % BK) == 0;
+}
+
+static int gemm_nt_qkrot_bf16_impl(const void* A, int64_t lda, int K, const void* W, int64_t ldb, const float* bias, void* C, int64_t ldc,
+                                   void* Q, void* Kh, const float* cosb, const float* sinb, int B, int H, int Ntok, int N, void* stream) {
+    if (B <= 0 || Ntok <= 0 || N <= 0) return 0;
+    const int M = B * Ntok;
+    if (!nt_qkrot_ok(M, N, K, H)) return E2K_ERR_SHAPE;
+    if (!A || !W || !C || !Q || !Kh || !cosb || !sinb) return E2K_ERR_ARG;
+    if ((lda & 7) || (ldb & 7) || (ldc & 7)) return E2K_ERR_ALIGN;
+    if (((uintptr_t)A | (uintptr_t)W | (uintptr_t)C | (uintptr_t)Q | (uintptr_t)Kh | (uintptr_t)cosb | (uintptr_t)sinb | (uintptr_t)bias) & 15)
+        return E2K_ERR_ALIGN;
+    NTArgs p{};
+    p.A1 = (const bf16_t*)A; p.lda1 = lda; p.K1 = K;
+    p.B = (const bf16_t*)W; p.ldb = ldb;
+    p.C = C; p.ldc = ldc; p.M = M; p.N = N; p.bias = bias;
+    p.rot_Q = (bf16_t*)Q; p.rot_K = (bf16_t*)Kh; p.rot_cos = cosb; p.rot_sin = sinb;
+    p.rot_I = H * DH_ROT; p.rot_2I = 2 * H * DH_ROT; p.rot_N = Ntok; p.rot_H = H;
+    p.staged = 1;
+    const int tn256 = (N + QBN - 1) / QBN, T = ((M + QBM - 1) / QBM) * tn256;
+    {
+        const float per_xcd = T / 8.f;          // (tile order: the rule of e2k_gemm_nt_bf16)
+        p.group = 8;
+        if (tn256 * 8 > 1.5f * per_xcd) {
+            int g = (int)(per_xcd / tn256 + 0.5f);
+            p.group = g < 1 ? 1 : (g > 8 ? 8 : g);
+        }
+    }
+    p.full = T; p.split = 1;
+    hipLaunchKernelGGL((gemm_nt_256_kernel<false, false, 2>), dim3(T), dim3(QTHREADS), 0, (hipStream_t)stream, p);
+    E2K_CHECK_LAUNCH();
+    return 0;
+}
+
+// 1: the fused launch is what the caller should use; 2: it can run, but the output has fewer 256 x 256 tiles than e2k_gemm_nt_bf16 asks
+// for before it takes that kernel (the 128 x 128 kernel + the full e2k_qkv_post_fwd is the better pair there); 0: refused
+extern "C" int e2k_query_gemm_nt_qkrot(int M, int N, int K, int H) {
+    if (!nt_qkrot_ok(M, N, K, H)) return 0;
+    const int t256 = ((M + QBM - 1) / QBM) * ((N + QBN - 1) / QBN);
+    return t256 >= nt_t256_min() ? 1 : 2;
+}
+
+extern "C" int e2k_gemm_nt_qkrot_bf16(const void* A, int64_t lda, int K, const void* W, int64_t ldb, const float* bias, void* C, int64_t ldc,
+                                      void* Q, void* Kh, const float* cosb, const float* sinb, int B, int H, int Ntok, int N, void* stream) {
+    return e2k::dispatch("gemm_nt_qkrot_bf16", gemm_nt_qkrot_bf16_impl, A, lda, K, W, ldb, bias, C, ldc, Q, Kh, cosb, sinb, B, H, Ntok, N, stream);
+}
 
 // 512 partial slots of a 128 x 128 tile or 256 of a 256 x 256 tile (every remainder split fits: rem * split <= slots)
 extern "C" int e2k_query_gemm_nt_ws_bytes(void) { return 256 * QBM * QBN * 4; }

@@ -1304,9 +1304,17 @@ class Transformer(Module):
             hf = ops.gemm_nt(xn, self._w(lfe.w, lfe.nout, D), out_dtype=f32)      # (fp32: these are angles)
             xa = ops.fourier_cat_fwd(hf, lfe.nf)
         qkvg = torch.empty((Mtok, a.ldq), dtype=bf16, device=run.dev)[:, :a.cols]
-        ops.gemm_nt(xn if xa is None else xa, self._w(a.w, a.cols, D), bias=self._f(a.bias, a.cols), out=qkvg)
+        ain = xn if xa is None else xa
+        qk = None
+        if _FUSE_QK_ROT and ops.can_fuse_qk_rot(Mtok, a.cols, D, a.H, (N + 63) // 64 * 64):
+            # rotary of q / k as the projection's epilogue: the q | k columns of qkvg are never written (nor read: the backward pass
+            # takes v and the gate logits from it), the post kernel runs the value path only
+            qk = ops.gemm_nt_qkrot(ain, self._w(a.w, a.cols, D), qkvg, B, a.H, N, run.rot[0], run.rot[1],
+                                   bias=self._f(a.bias, a.cols))
+        else:
+            ops.gemm_nt(ain, self._w(a.w, a.cols, D), bias=self._f(a.bias, a.cols), out=qkvg)
         first = run.vfirst[key] is None
-        ast = ops.qkv_post_fwd(qkvg, B, a.H, N, run.rot[0], run.rot[1], run.vfirst[key], laser=a.laser,
+        ast = ops.qkv_post_fwd(qkvg, B, a.H, N, run.rot[0], run.rot[1], run.vfirst[key], laser=a.laser, qk=qk,
                                need_v=exists(tape) or (first and not a.laser > 0))     # (no-grad: V only where it is the value residual)
         if first:
             run.vfirst[key] = ast.Vorig if a.laser > 0 else ast.V      # (LASER: the values before the exp map)
@@ -1945,6 +1953,9 @@ _BATCH_REDUCES = True         # the hyper-connection parameter-gradient reductio
 # the (Adaptive)RMSNorm of a branch inside the width connection's launch (e2k_hc_fwd_norm): 0 never, 1 in no-grad forwards (the branch input
 # itself is then not written), 2 (default) in training passes too.  E2K_FUSE_HC_NORM presets it (A/B)
 _FUSE_HC_NORM = int(_os.environ.get('E2K_FUSE_HC_NORM', '2'))
+# rotary q / k written head-major by the attention projection's own epilogue (e2k_gemm_nt_qkrot_bf16; bit-identical to the two-launch form).
+# E2K_FUSE_QK_ROT presets it (A/B)
+_FUSE_QK_ROT = _os.environ.get('E2K_FUSE_QK_ROT', '1') == '1'
 _CROSS_ONE_LAUNCH = True      # TextAudioCrossCondition's two projections (and the two halves of its dgrad) as ONE two-output GEMM launch
 
 _VIEW_OPS = {'view', '_unsafe_view', 'as_strided', 'slice', 'select', 'expand', 't', 'transpose', 'permute', 'unsqueeze', 'squeeze',

@@ -707,6 +707,40 @@ def gemm_nt_geglu_bwd(dy, w2T, H, p_drop=0., seed=0, stream_id=0, seed_dev=None)
     return dH
 
 
+qk_rot_any_size = False      # tests: take the fused projection wherever the kernel can run, not only where the library recommends it
+
+
+def can_fuse_qk_rot(M, N, K, H, Npad):
+    """can the attention's input projection write q and k rotated and head-major itself (gemm_nt_qkrot)?  Not under the A/B flags that
+    take the 256 x 256 kernel, its LDS-DMA staging or its staged epilogue away, nor where the backward kernels ask for transposed
+    copies of q / k (rows beyond 4096 or the register-staged family, E2K_ATTN_FLAGS 128: those come out of qkv_post_fwd)"""
+    if gemm_flags & (1 | 4 | 8 | 64 | 256) or _lib.get().e2k_query_attn_bwd_transposes(int(Npad), attn_probe & 128):
+        return False
+    q = _lib.get().e2k_query_gemm_nt_qkrot(int(M), int(N), int(K), int(H))
+    return q == 1 or (q == 2 and qk_rot_any_size)
+
+
+def gemm_nt_qkrot(a, w, out, B, H, N, cosb, sinb, bias=None):
+    """out[:, 2 H 64:] = (a @ w.T + bias)[:, 2 H 64:]; the q and k columns leave the launch rotated and head-major -> (Q, K), each
+    (B, H, N, 64) bf16 (e2k_gemm_nt_qkrot_bf16; qkv_post_fwd(..., qk=(Q, K)) does the rest).  Shapes: can_fuse_qk_rot."""
+    _chk(a, w, out, cosb, sinb, bias)
+    assert a.dtype == bf16 and w.dtype == bf16 and out.dtype == bf16 and out.stride(1) == 1
+    M, lda = _rows(a)
+    cols, ldb = _rows(w)
+    Kd = a.shape[1]
+    assert M == B * N and w.shape[1] == Kd and out.shape == (M, cols)
+    if bias is not None:
+        assert bias.dtype == f32 and bias.numel() == cols and bias.is_contiguous()
+    Q, K = (torch.empty((B, H, N, 64), dtype=bf16, device=a.device) for _ in range(2))
+    if _gemm_shapes is not None:          # (tools/nt_shapes.py: counted as the plain NT GEMM of its shape)
+        key = (M, cols, Kd, 0, 0, 0)
+        _gemm_shapes[key] = _gemm_shapes.get(key, 0) + 1
+    _note(2.0 * M * cols * Kd)
+    _lib.get().e2k_gemm_nt_qkrot_bf16(_p(a), lda, Kd, _p(w), ldb, _p(bias), _p(out), out.stride(0), _p(Q), _p(K), _p(cosb), _p(sinb),
+                                      B, H, N, cols, _stream(a))
+    return Q, K
+
+
 def geglu_bwd(dout, H, p_drop=0., seed=0, stream_id=0, seed_dev=None):
     _chk(dout, H)
     M, F2 = H.shape
@@ -800,8 +834,9 @@ class AttnState:
     __slots__ = ('Q', 'K', 'V', 'QT', 'KT', 'VT', 'gate', 'mix', 'O', 'Og', 'lse2', 'B', 'H', 'N', 'Npad', 'dropbits', 'laser', 'Vorig')
 
 
-def qkv_post_fwd(qkvg, B, H, N, cosb, sinb, vfirst=None, laser=0., need_v=True):
-    """laser > 0: LASER attention's value map exp(c tanh(v / c)) (st.laser); on the first layer st.Vorig keeps the values
+def qkv_post_fwd(qkvg, B, H, N, cosb, sinb, vfirst=None, laser=0., need_v=True, qk=None):
+    """qk = (Q, K): both were written by gemm_nt_qkrot already (the kernel then runs the value path and the gates only).
+    laser > 0: LASER attention's value map exp(c tanh(v / c)) (st.laser); on the first layer st.Vorig keeps the values
     before it (the value residual of the later layers).  need_v False: the row-major values are not written (st.V None) -- the
     forward kernels read V^T, only the backward pass and the value residual of the later layers read V"""
     _chk(qkvg, cosb, sinb, vfirst)
@@ -810,9 +845,13 @@ def qkv_post_fwd(qkvg, B, H, N, cosb, sinb, vfirst=None, laser=0., need_v=True):
     Npad = (N + 63) // 64 * 64
     st = AttnState()
     st.B, st.H, st.N, st.Npad, st.dropbits = B, H, N, Npad, None
-    st.Q, st.K = (torch.empty((B, H, N, 64), dtype=bf16, device=dev) for _ in range(2))
-    st.V = torch.empty((B, H, N, 64), dtype=bf16, device=dev) if need_v else None
     need = _lib.get().e2k_query_attn_bwd_transposes(Npad, attn_probe & 128)
+    if qk is None:
+        st.Q, st.K = (torch.empty((B, H, N, 64), dtype=bf16, device=dev) for _ in range(2))
+    else:
+        st.Q, st.K = qk
+        assert not need and st.Q.shape == (B, H, N, 64) and st.K.shape == (B, H, N, 64)
+    st.V = torch.empty((B, H, N, 64), dtype=bf16, device=dev) if need_v else None
     st.VT = torch.empty((B, H, 64, Npad), dtype=bf16, device=dev)
     st.KT = torch.empty((B, H, 64, Npad), dtype=bf16, device=dev) if need & 1 else None
     st.QT = torch.empty((B, H, 64, Npad), dtype=bf16, device=dev) if need & 2 else None
@@ -820,7 +859,8 @@ def qkv_post_fwd(qkvg, B, H, N, cosb, sinb, vfirst=None, laser=0., need_v=True):
     st.mix = torch.empty((B, H, N), dtype=f32, device=dev) if vfirst is not None else None
     st.laser = float(laser)
     st.Vorig = torch.empty((B, H, N, 64), dtype=bf16, device=dev) if laser > 0 and vfirst is None else None
-    _lib.get().e2k_qkv_post_fwd(_p(qkvg), qkvg.stride(0), _p(cosb), _p(sinb), _p(vfirst), _p(st.Q), _p(st.K), _p(st.V),
+    _lib.get().e2k_qkv_post_fwd(_p(qkvg), qkvg.stride(0), _p(cosb), _p(sinb), _p(vfirst), _p(st.Q if qk is None else None),
+                                _p(st.K if qk is None else None), _p(st.V),
                                 _p(st.QT), _p(st.KT), _p(st.VT), _p(st.gate), _p(st.mix), _p(st.Vorig), st.laser, B, H, N, Npad,
                                 _stream(qkvg))
     return st

@@ -213,6 +213,17 @@ int e2k_gemm_nt_geglu_bwd_bf16(const void* dY, int64_t ldy, int K, const void* W
                                void* dH, int64_t lddh, int M, int F, float p_drop, uint32_t seed, const uint32_t* seed_dev,
                                uint32_t stream_id, int flags, float* ws, int64_t ws_bytes, void* stream);
 int e2k_query_gemm_nt_geglu_bwd(int M, int F, int K);
+/* x_transformers.Attention's fused input projection with the rotary embedding of q and k as the GEMM's epilogue (call sites
+ * e2_tts.py:875,911; replaces e2k_gemm_nt_bf16 followed by the q / k half of e2k_qkv_post_fwd): A (B*Ntok, K) bf16, W (N, K) with
+ * N >= 3 H 64 columns ordered as e2k_qkv_post_fwd's qkvg.  Columns [0, 2 H 64) of A W^T (+ bias) leave the kernel rounded to bf16, rotated
+ * by the table cosb / sinb (Ntok, 32) and HEAD-MAJOR at Q / Kh (B, H, Ntok, 64); the other columns (v, gate logits, mix logits) go to
+ * C (B*Ntok, ldc) and columns [0, 2 H 64) of C are NOT written.  e2k_qkv_post_fwd is then called with Q = K = NULL.  Bit-identical to
+ * the two-launch form.  256 x 256 kernel only: H even, N % 8 == 0, K % 64 == 0, K >= 256 (e2k_query_gemm_nt_qkrot: 1 = taken and
+ * recommended, 2 = taken, but the output has fewer 256 x 256 tiles than e2k_gemm_nt_bf16 asks for before it picks that kernel -- the
+ * two-launch pair is the better choice there --, 0 = refused with E2K_ERR_SHAPE); never splits a remainder. */
+int e2k_gemm_nt_qkrot_bf16(const void* A, int64_t lda, int K, const void* W, int64_t ldb, const float* bias, void* C, int64_t ldc,
+                           void* Q, void* Kh, const float* cosb, const float* sinb, int B, int H, int Ntok, int N, void* stream);
+int e2k_query_gemm_nt_qkrot(int M, int N, int K, int H);
 
 /* out[n] += sum_m x[m][n]   (bias gradients; x bf16 (M,N), out fp32) */
 int e2k_colsum_bf16(const void* x, int64_t ldx, float* out, int M, int N, void* stream);
@@ -254,6 +265,8 @@ int e2k_dwconv_bwd_reduce(const float* ws, float* dw, float* dbias, int B, int N
  * Outputs head-major Q,K,V (B,H,N,64), transposed QT,KT,VT (B,H,64,Npad; Npad = N rounded up to 64, zero padded; QT, KT and V may
  * be NULL: the forward kernels read V^T, only the backward pass and the later layers' value residual read V),
  * gate = sigmoid(gate logits), mix = sigmoid(mix logits) (B,H,N) fp32.
+ * Q = K = NULL (both, and then QT = KT = NULL): q and k were already written by e2k_gemm_nt_qkrot_bf16; only the value path and the
+ * gates run.
  * laser_clamp > 0: LASER attention (Transformer(attn_laser = True, attn_laser_softclamp_value = c), e2_tts.py:543-544,641):
  * V / VT hold exp(c tanh(v / c)) of the (mixed) values and v_orig (first layer; may be NULL) receives the values before
  * that map, i.e. what later layers take as `vfirst`.  laser_clamp = 0 (then v_orig = NULL): the default attention. */

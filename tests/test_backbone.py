@@ -635,6 +635,67 @@ def test_branch_norm_inside_the_width_connection(dev, monkeypatch):
     assert rel2(outs[1], outs[0]) < 1e-2 and rel2(outs[0], res[0][0]) < 5e-3          # (the no-grad schedule fuses the GEGLU into its GEMM: not the training pass bit for bit)
 
 
+def test_rotary_inside_the_attention_projection(dev, monkeypatch):
+    """backbone._FUSE_QK_ROT: the attention's input projection writes q and k rotated and head-major from its own epilogue
+    (e2k_gemm_nt_qkrot_bf16) and the post kernel runs the value path only.  Bit-identical to the two-launch form in the output and in
+    every gradient, eagerly and as a recorded plan; the text branch of this model (K = 128) and its first layer (772 columns) are shapes the
+    fused launch refuses: they stay on the two-launch form in the same pass"""
+    import e2_tts_pytorch_amd.backbone as bbm
+    from e2_tts_pytorch_amd import Transformer, ops
+    random.seed(0)
+    torch.manual_seed(0)
+    T = 40 if gpu_shapes(dev) else 24
+    mod = Transformer(dim=256, depth=4, heads=4, dropout=0., max_seq_len=64, num_registers=32 if gpu_shapes(dev) else 8)
+    randomize(mod)
+    mod = mod.to(dev)
+    g = torch.Generator().manual_seed(1)
+    x0 = torch.randn(2, T, 256, generator=g).to(dev)
+    t = torch.rand(2, generator=g).to(dev)
+    txt = torch.randn(2, T, 128, generator=g).to(dev)
+    mask = (torch.arange(T)[None] < torch.tensor([T, T - 7])[:, None]).to(dev)
+    R = torch.randn(2, T, 256, generator=g).to(dev)
+    monkeypatch.setattr(ops, 'qk_rot_any_size', True)      # (a model this small has fewer tiles than the library recommends the launch for)
+    calls = []
+    inner = ops.gemm_nt_qkrot
+    monkeypatch.setattr(ops, 'gemm_nt_qkrot', lambda *a, **k: (calls.append(a[0].shape), inner(*a, **k))[1])
+
+    def run():
+        mod.zero_grad(set_to_none=True)
+        x = x0.clone().requires_grad_(True)
+        out = mod(x, times=t, mask=mask, text_embed=txt)
+        (out * R).sum().backward()
+        return [out.detach().cpu(), x.grad.cpu()] + [p.grad.cpu().clone() for p in mod.parameters()]
+
+    res = {}
+    for fused in (False, True):
+        monkeypatch.setattr(bbm, '_FUSE_QK_ROT', fused)
+        mod.enable_plans(False)
+        res[fused] = run()
+        # the speech branch of layers 2 to 4; the first layer's projection (no value-residual mix: 3 x 256 + 4 columns, not a multiple
+        # of 8) and the text branch are refused
+        assert len(calls) == (3 if fused else 0)
+    names = ['out', 'dx'] + [n for n, _ in mod.named_parameters()]
+
+    def same(got, want):
+        # out and d(x) bit for bit; parameter gradients to the order of their fp32 atomic sums -- 1e-7 of the tensor's largest entry where
+        # the sum is the gradient, up to 1e-5 (measured on MI355X: to_gamma.weight) where the summed quantity is rounded to a bf16 GEMM
+        # operand afterwards and a different arrival order flips a rounding
+        for i, (n, a, b) in enumerate(zip(names, got, want)):
+            assert torch.equal(a, b) if i < 2 else float((a - b).abs().max()) <= 1e-4 * float(b.abs().max()), (n, float((a - b).abs().max()), float(b.abs().max()))
+
+    same(res[True], res[False])
+    mod.enable_plans(True)
+    for _ in range(3):                                      # eager, recording, replay
+        same(run(), res[False])
+    with torch.no_grad():
+        outs = {}
+        for fused in (False, True):
+            monkeypatch.setattr(bbm, '_FUSE_QK_ROT', fused)
+            mod.enable_plans(False)
+            outs[fused] = mod(x0, times=t, mask=mask, text_embed=txt).cpu()
+    assert torch.equal(outs[True], outs[False])
+
+
 def test_recorded_training_plan_recasts_its_weights_every_replay(dev):
     """a recorded training plan refreshes the bf16 shadows of the fp32 master weights itself -- since round 6 the global slab and the first
     layer on the chain and the other layers two at a time on the WGRAD lane, each chunk with an ordering point its consumers wait for

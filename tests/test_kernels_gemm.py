@@ -575,3 +575,62 @@ def test_gemm_nt_two_outputs(dev, M, N1, N2, K1, K2, flags):
         assert rel(e1.float().cpu(), ref[:, :N1] + r1.float().cpu()) < 2e-2
     finally:
         ops.gemm_flags = old
+
+
+@pytest.mark.parametrize('B,N,H,K,vres,bias,need_v', [(2, 150, 4, 256, True, False, True), (1, 300, 4, 320, False, True, True),
+                                                      (30, 10, 4, 256, True, True, False), (2, 257, 8, 256, False, False, True)])
+@pytest.mark.parametrize('late', [0, 1])
+def test_qkv_projection_with_the_rotary_epilogue(dev, monkeypatch, B, N, H, K, vres, bias, need_v, late):
+    """e2k_gemm_nt_qkrot_bf16 + the value-only e2k_qkv_post_fwd against e2k_gemm_nt_bf16 + the full e2k_qkv_post_fwd: the same bits in
+    everything the attention kernels and the backward pass read (x_transformers.Attention's projection + rotary, e2_tts.py:875,911).
+    Rows of several batch elements inside one 16-row pass of the epilogue (N = 10), a ragged last row tile, an odd q | k boundary inside a
+    tile are all in the shapes; against the fp32 rotation of the bf16-rounded projection as well"""
+    if dev == 'cuda' and late:
+        pytest.skip('LDS-DMA landing extremes exist on the host model only')
+    monkeypatch.setenv('E2K_EMU_GLDS_LATE', str(late))
+    from e2_tts_pytorch_amd import ops
+    torch.manual_seed(0)
+    I = H * 64
+    cols = 3 * I + 2 * H
+    M = B * N
+    x = torch.randn(M, K).to(bf16).to(dev)
+    w = (torch.randn(cols, K) / K ** 0.5).to(bf16).to(dev)
+    bs = torch.randn(cols).to(dev) if bias else None
+    cosb, sinb = ops.rotary_table(N, dev)
+    vfirst = torch.randn(B, H, N, 64).to(bf16).to(dev) if vres else None
+    assert ops._lib.get().e2k_query_gemm_nt_qkrot(M, cols, K, H) in (1, 2)
+    ldq = (cols + 7) // 8 * 8 + 8
+    # two launches
+    qa = torch.zeros(M, ldq, dtype=bf16, device=dev)[:, :cols]
+    ops.gemm_nt(x, w, bias=bs, out=qa)
+    sa = ops.qkv_post_fwd(qa, B, H, N, cosb, sinb, vfirst, need_v=need_v)
+    # fused
+    qb = torch.full((M, ldq), 7., dtype=bf16, device=dev)[:, :cols]
+    Q, Kh = ops.gemm_nt_qkrot(x, w, qb, B, H, N, cosb, sinb, bias=bs)
+    sb = ops.qkv_post_fwd(qb, B, H, N, cosb, sinb, vfirst, need_v=need_v, qk=(Q, Kh))
+    assert torch.equal(qb[:, 2 * I:], qa[:, 2 * I:])
+    assert (qb[:, :2 * I] == 7).all()                    # the q | k columns of the row-major output are not written
+    for name in ('Q', 'K', 'V', 'VT', 'gate', 'mix'):
+        ta, tb = getattr(sa, name), getattr(sb, name)
+        assert (ta is None) == (tb is None), name
+        if ta is not None:
+            assert torch.equal(ta, tb), name
+    # and against the definition: rotation of interleaved pairs by the table, on the bf16-rounded projection
+    ref = qa[:, :2 * I].float().cpu().view(B, N, 2, H, 32, 2)
+    c, s = cosb.cpu().view(1, N, 1, 1, 32), sinb.cpu().view(1, N, 1, 1, 32)
+    rot = torch.stack((ref[..., 0] * c - ref[..., 1] * s, ref[..., 1] * c + ref[..., 0] * s), -1).reshape(B, N, 2, H, 64)
+    assert rel(Q, rot[:, :, 0].permute(0, 2, 1, 3)) < 8e-3 and rel(Kh, rot[:, :, 1].permute(0, 2, 1, 3)) < 8e-3
+
+
+def test_qkv_projection_with_the_rotary_epilogue_refusals(dev):
+    from e2_tts_pytorch_amd import ops
+    q = ops._lib.get().e2k_query_gemm_nt_qkrot
+    assert q(8448, 3104, 1024, 16) == 1 and q(8448, 1552, 512, 8) == 1       # cfg3: speech and text branches
+    assert q(300, 776, 256, 4) == 2                                           # can run, not recommended (few tiles)
+    assert q(8448, 3104, 1024, 15) == 0 and q(8448, 3104, 192, 16) == 0 and q(8448, 3104, 1000, 16) == 0 and q(8448, 3000, 1024, 16) == 0
+    assert not ops.can_fuse_qk_rot(300, 776, 256, 4, 320) and ops.can_fuse_qk_rot(8448, 3104, 1024, 16, 1088)
+    assert not ops.can_fuse_qk_rot(8 * 4160, 3104, 1024, 16, 4160)            # rows beyond 4096: the backward wants Q^T / K^T
+    x = torch.zeros(300, 256, dtype=bf16, device=dev)
+    w = torch.zeros(776, 192, dtype=bf16, device=dev)
+    with pytest.raises(Exception):
+        ops.gemm_nt_qkrot(x[:, :192], w, torch.zeros(300, 776, dtype=bf16, device=dev), 2, 4, 150, *ops.rotary_table(150, dev))
