@@ -50,9 +50,13 @@ __device__ __forceinline__ u32x2 pack4(const float* f) {
 
 // rotary position embedding on one interleaved pair (x-transformers rotate_half on (d/2, 2) pairs; e2_tts.py:875,911): ONE definition
 // with explicit fused multiply-adds, shared by qkv_post_fwd_kernel and the QKV GEMM's rotating epilogue (gemm.hip, nt_stage_readback
-// EPI 2) so that the two produce the same bits
+// EPI 2) so that the two produce the same bits.
+// The second component is  fma(x0, s, x1 c)  and NOT  fma(x1, c, x0 s): the latter compiles (hipcc 7.2, -O3) to
+// `v_pk_mul_f32 .. op_sel_hi:[0,1] neg_hi:[1,0]` -- a source broadcast from its low register, negated in the high lane only -- and the
+// kernel with that form did not reproduce its own results next to kernels of another launch lane on MI355X (round 6: four models, every
+// run; profiles/r06t_rotary_form_vs_lanes.txt).  tests/test_abi.py refuses the form anywhere in the library's device code.
 __device__ __forceinline__ void rot_pair(float& x0, float& x1, float c, float s) {
-    const float a = fmaf(x0, c, -(x1 * s)), b = fmaf(x1, c, x0 * s);
+    const float a = fmaf(x0, c, -(x1 * s)), b = fmaf(x0, s, x1 * c);
     x0 = a; x1 = b;
 }
 

@@ -31,6 +31,54 @@ def test_header_parses_and_library_exports_everything():
     assert lib.e2k_version() >= 1
 
 
+def _asymmetric_negation_of_a_broadcast(line):
+    """a packed-fp32 instruction (v_pk_mul / fma / add_f32) with a source whose two lanes read the SAME register half (op_sel == op_sel_hi at
+    that position) but negated in only one of them"""
+    import re
+    m = re.search(r'v_pk_(mul|fma|add)_f32', line)
+    if not m:
+        return False
+    n = 3 if m.group(1) == 'fma' else 2
+
+    def mod(name, default):
+        mm = re.search(name + r':\[([0-9,]+)\]', line)
+        v = [int(x) for x in mm.group(1).split(',')] if mm else []
+        return v + [default] * (n - len(v))
+    osl, osh, nl, nh = mod('op_sel', 0), mod('op_sel_hi', 1), mod('neg_lo', 0), mod('neg_hi', 0)
+    return any(osl[i] == osh[i] and nl[i] != nh[i] for i in range(n))
+
+
+def test_device_code_has_no_one_lane_negation_of_a_broadcast_packed_fp32_source(tmp_path):
+    """Round 6 finding (profiles/r06t_*): the rotary pair written as  b = fma(x1, c, x0 s)  compiled to
+    `v_pk_mul_f32 v[a:b], v[s:s+1], v[x0:x1] op_sel_hi:[0,1] neg_hi:[1,0]` -- src0 broadcast from its low register and negated in the high
+    lane only -- and the kernel that contained it (16 such instructions; none in the other 70 000 packed instructions of the library) did not
+    reproduce its own results next to kernels of another launch lane on MI355X (test_launch_lanes_match_single_stream failed one run in
+    three; four models, every run).  The same arithmetic as  b = fma(x0, s, x1 c)  compiles without the form and is clean.  This guard
+    disassembles the gfx950 code objects of the built library and refuses the form wherever it appears."""
+    import shutil
+    import subprocess
+    objdump = Path('/opt/rocm/lib/llvm/bin/llvm-objdump')
+    so = ROOT / 'e2-tts-pytorch_amd' / 'e2_tts_pytorch_amd' / 'libe2k.so'
+    if not objdump.exists() or not so.exists():
+        pytest.skip('needs the ROCm llvm-objdump and the built library')
+    assert _asymmetric_negation_of_a_broadcast('v_pk_mul_f32 v[54:55], v[28:29], v[52:53] op_sel_hi:[0,1] neg_hi:[1,0]')
+    assert not _asymmetric_negation_of_a_broadcast('v_pk_fma_f32 v[84:85], v[24:25], v[52:53], v[54:55] op_sel:[0,0,1] op_sel_hi:[0,1,0] neg_lo:[0,0,1] neg_hi:[0,0,1]')
+    assert not _asymmetric_negation_of_a_broadcast('v_pk_fma_f32 v[2:3], s[4:5], v[6:7], v[8:9] op_sel_hi:[0,1,1] neg_lo:[1,0,0] neg_hi:[1,0,0]')
+    shutil.copy(so, tmp_path / 'libe2k.so')
+    subprocess.run([str(objdump), '--offloading', 'libe2k.so'], cwd=tmp_path, check=True, capture_output=True)
+    objs = sorted(tmp_path.glob('libe2k.so.*gfx950'))
+    assert objs, 'no gfx950 code object in the library'
+    packed, bad = 0, []
+    for o in objs:
+        text = subprocess.run([str(objdump), '-d', str(o)], check=True, capture_output=True, text=True).stdout
+        for line in text.splitlines():
+            if 'v_pk_' in line and '_f32' in line:
+                packed += 1
+                if _asymmetric_negation_of_a_broadcast(line):
+                    bad.append(line.strip())
+    assert packed > 1000 and not bad, (len(bad), bad[:4])
+
+
 def test_no_cpu_fallback():
     """product ops refuse CPU tensors (the host logic-checker is only reachable through the test fixtures)"""
     import torch

@@ -16,17 +16,18 @@ from e2_tts_pytorch_amd import Transformer                     # noqa: E402
 from test_backbone import randomize                            # noqa: E402
 
 dev = 'cuda'
-random.seed(0)
-torch.manual_seed(0)
+SEED = int(os.environ.get('SEED', '0'))      # (another model and other inputs: is the mismatch a property of particular values?)
+random.seed(SEED)
+torch.manual_seed(SEED)
 dim, depth, B, T = 512, 6, 4, 200
 mod = Transformer(dim=dim, depth=depth, heads=dim // 64, dropout=0., max_seq_len=T, num_registers=32)
-randomize(mod)
+randomize(mod, seed=SEED)
 mod = mod.to(dev)
 R = torch.randn(B, T, dim).to(dev)
 
 
 def inputs(seed):
-    g = torch.Generator().manual_seed(seed)
+    g = torch.Generator().manual_seed(seed + 100 * SEED)
     x = torch.randn(B, T, dim, generator=g).to(dev).requires_grad_(True)
     t = torch.rand(B, generator=g).to(dev)
     txt = torch.randn(B, T, dim // 2, generator=g).to(dev).requires_grad_(True)
