@@ -53,7 +53,8 @@ def test_device_code_has_no_one_lane_negation_of_a_broadcast_packed_fp32_source(
     `v_pk_mul_f32 v[a:b], v[s:s+1], v[x0:x1] op_sel_hi:[0,1] neg_hi:[1,0]` -- src0 broadcast from its low register and negated in the high
     lane only -- and the kernel that contained it (16 such instructions; none in the other 70 000 packed instructions of the library) did not
     reproduce its own results next to kernels of another launch lane on MI355X (test_launch_lanes_match_single_stream failed one run in
-    three; four models, every run).  The same arithmetic as  b = fma(x0, s, x1 c)  compiles without the form and is clean.  This guard
+    three; four models, every run; as a two-kernel reproducer: wrong values in 4-225 of 4800 back-to-back calls next to LDS-DMA GEMMs, none
+    alone -- tests/test_concurrency.py holds that loop).  The same arithmetic as  b = fma(x0, s, x1 c)  compiles without the form and is clean.  This guard
     disassembles the gfx950 code objects of the built library and refuses the form wherever it appears."""
     import shutil
     import subprocess

@@ -65,6 +65,8 @@ def _victims_and_corunners(dev):
     ta, tb = torch.randn(1024, 264, device=dev).to(bf16), torch.randn(1024, 200, device=dev).to(bf16)
     gsum = torch.zeros(2, D, device=dev)
     gates = torch.rand(2, D, device=dev)
+    qx, qw = torch.randn(B * N, 256, device=dev).to(bf16), (torch.randn(cols, 256, device=dev) / 16).to(bf16)
+    qo = torch.empty(B * N, ld, device=dev, dtype=bf16)[:, :cols]
 
     def tn_victim():
         o = torch.zeros(264, 200, device=dev)
@@ -85,6 +87,7 @@ def _victims_and_corunners(dev):
         'attn_fwd': lambda: (ops.attn_fwd(st, kmask, 0.1, 7, 3),),
         'attn_bwd': lambda: ops.attn_bwd(st, dOg, kmask, 0.1, 7, 3),
         'gemm_nt (staged epilogue)': lambda: (ops.gemm_nt(va, vb, out=vo),),
+        'gemm_nt_qkrot (rotary epilogue)': lambda: ops.gemm_nt_qkrot(qx, qw, qo, B, H, N, cosb, sinb),
         'gemm_tn (fragment partials + reduce)': tn_victim,
     }
     corunners = {
@@ -118,6 +121,65 @@ def _count_differing(victims, corunners, trials, dev):
             if n:
                 bad[vn, cn] = n
     return bad
+
+
+def _count_differing_tight(victims, inner, iters, dev):
+    """the same question asked the way round 6's failure needed it asked: the victim `inner` times back to back on one stream while another
+    stream runs nothing but 128 x 128 LDS-DMA GEMMs of the shapes a small model's text branch launches -- no host synchronisation inside an
+    iteration.  (The 200-trial screen above synchronises around every victim call: it passed with the build that failed under the launch lanes;
+    this loop finds 4-225 wrong calls of 4800 for it, by box -- profiles/r06t_rotary_form_vs_lanes.txt, tools/probes/pk_neg_broadcast2.py.)"""
+    from e2_tts_pytorch_amd import ops
+    side = torch.cuda.Stream()
+    gem = [(torch.randn(m, k, device=dev).to(bf16), torch.randn(n, k, device=dev).to(bf16))
+           for m, n, k in ((928, 1552, 512), (928, 512, 512), (928, 776, 256), (928, 2048, 256), (8448, 1024, 1024))]
+    bad = {}
+    for vn, fn in victims.items():
+        keep = lambda out: [t for t in out if torch.is_tensor(t)]
+        ref = [t.clone() for t in keep(fn())]
+        if any(not torch.equal(a, b) for a, b in zip(keep(fn()), ref)):
+            continue                      # (fp32 atomics in its reduction: not reproducible even alone)
+        n = 0
+        for _ in range(iters):
+            side.wait_stream(torch.cuda.current_stream())
+            flags = ops.gemm_flags
+            with torch.cuda.stream(side):
+                ops.gemm_flags = flags | 256          # E2K_GEMM_NO_T256: the 128 x 128 kernel for every shape
+                try:
+                    for _ in range(4):
+                        for a, w in gem:
+                            ops.gemm_nt(a, w)
+                finally:
+                    ops.gemm_flags = flags
+            outs = [keep(fn()) for _ in range(inner)]
+            n += sum(any(not torch.equal(g, r) for g, r in zip(got, ref)) for got in outs)
+            torch.cuda.current_stream().wait_stream(side)
+        torch.cuda.synchronize()
+        if n:
+            bad[vn] = n
+    return bad
+
+
+@pytest.mark.gpu
+def test_kernels_with_the_rotary_helper_back_to_back_next_to_lds_dma_gemms():
+    """e2k_qkv_post_fwd and the rotating GEMM epilogue, 2400 calls each in tight loops next to LDS-DMA GEMMs on another stream: the first
+    version of their shared rotary helper compiled to a packed-fp32 operand form whose results were wrong in a few calls per thousand under
+    exactly this load and never alone (round 6)"""
+    from e2_tts_pytorch_amd import _lib
+    install_lib(None, host_pointers=False)
+    victims, _ = _victims_and_corunners('cuda')
+    bad = _count_differing_tight({k: v for k, v in victims.items() if k.startswith(('qkv_post_fwd', 'gemm_nt_qkrot'))}, 24, 100, 'cuda')
+    assert not bad, bad
+
+
+@pytest.mark.gpu
+@pytest.mark.late
+def test_every_kernel_back_to_back_next_to_lds_dma_gemms():
+    """the tight-loop screen over every kernel family of the step (768 calls each)"""
+    from e2_tts_pytorch_amd import _lib
+    install_lib(None, host_pointers=False)
+    victims, _ = _victims_and_corunners('cuda')
+    bad = _count_differing_tight(victims, 16, 48, 'cuda')
+    assert not bad, bad
 
 
 @pytest.mark.gpu
