@@ -66,6 +66,8 @@ def _victims_and_corunners(dev):
     gsum = torch.zeros(2, D, device=dev)
     gates = torch.rand(2, D, device=dev)
     qx, qw = torch.randn(B * N, 256, device=dev).to(bf16), (torch.randn(cols, 256, device=dev) / 16).to(bf16)
+    fx, fw1, fb1 = torch.randn(M, 256, device=dev).to(bf16), (torch.randn(2 * D, 256, device=dev) / 16).to(bf16), torch.randn(2 * D, device=dev)
+    fw2T = (torch.randn(D, D, device=dev) / 22).to(bf16)          # (F = D = 512 columns of d(act), K = D)
     qo = torch.empty(B * N, ld, device=dev, dtype=bf16)[:, :cols]
 
     def tn_victim():
@@ -88,6 +90,13 @@ def _victims_and_corunners(dev):
         'attn_bwd': lambda: ops.attn_bwd(st, dOg, kmask, 0.1, 7, 3),
         'gemm_nt (staged epilogue)': lambda: (ops.gemm_nt(va, vb, out=vo),),
         'gemm_nt_qkrot (rotary epilogue)': lambda: ops.gemm_nt_qkrot(qx, qw, qo, B, H, N, cosb, sinb),
+        # (round 6) the forms the no-grad passes of sample() run next to the other guidance pass's GEMMs
+        'hc_fwd_norm (no-grad form)': lambda: ops.hc_fwd(M1, params, yprev=y1, coef_prev=c1, norm=(gam, 1., M), want_bin=False),
+        'hc_fwd_norm (training form)': lambda: ops.hc_fwd(M1, params, yprev=y1, coef_prev=c1, norm=(gam, 1., M)),
+        'qkv_post_fwd (value path only)': lambda: (lambda s_: (s_.V, s_.VT, s_.gate, s_.mix))(
+            ops.qkv_post_fwd(qkvg, B, H, N, cosb, sinb, vfirst, qk=(st.Q, st.K))),
+        'gemm_nt_geglu (GEGLU epilogue, inference form)': lambda: ops.gemm_nt_geglu(fx, fw1, bias=fb1, want_h=False),
+        'gemm_nt_geglu_bwd (GEGLU backward epilogue)': lambda: (ops.gemm_nt_geglu_bwd(dact, fw2T, Hh, 0.1, 5, 2),),
         'gemm_tn (fragment partials + reduce)': tn_victim,
     }
     corunners = {
