@@ -449,7 +449,7 @@ def main():
                 'measured': 'HIP events on the launch stream around every recorded launch (e2k_plan_profile), 2 replays of the '
                             'timed plan right after the timed region, every call ALONE on one stream; the rocprofv3 summary that '
                             'agrees with avg_launch_ms is the single-stream one (E2K_LANES=0, profiles/r06_bench_cfg3_kernel_stats_single_stream.csv): '
-                            'with the launch lanes the kernels of different lanes overlap and stretch (…_d_lanes.csv).  Since the end of '
+                            'with the launch lanes the kernels of different lanes overlap and stretch (profiles/r06_bench_cfg3_kernel_stats_lanes.csv).  Since the end of '
                             'round 3 outputs of 64-223 tiles of 256 x 256 (the 8448-token GEMMs with N <= 2048) run the 256 x 256 kernel on '
                             'a part of the CUs: in the step the other launch lanes use the rest (step -1.5 to -3 %, '
                             'profiles/r03_t256_threshold_ab.jsonl); timed ALONE, as here, the same choice costs 4 % (751 -> 724 TFLOP/s)',
