@@ -132,7 +132,7 @@ def _count_differing(victims, corunners, trials, dev):
     return bad
 
 
-def _count_differing_tight(victims, inner, iters, dev):
+def _count_differing_tight(victims, inner, iters, dev, mix='128 x 128 NT GEMMs'):
     """the same question asked the way round 6's failure needed it asked: the victim `inner` times back to back on one stream while another
     stream runs nothing but 128 x 128 LDS-DMA GEMMs of the shapes a small model's text branch launches -- no host synchronisation inside an
     iteration.  (The 200-trial screen above synchronises around every victim call: it passed with the build that failed under the launch lanes;
@@ -141,6 +141,14 @@ def _count_differing_tight(victims, inner, iters, dev):
     side = torch.cuda.Stream()
     gem = [(torch.randn(m, k, device=dev).to(bf16), torch.randn(n, k, device=dev).to(bf16))
            for m, n, k in ((928, 1552, 512), (928, 512, 512), (928, 776, 256), (928, 2048, 256), (8448, 1024, 1024))]
+    if mix == 'every LDS-DMA family':       # + the 256 x 256 NT kernel, the weight-gradient kernel and the attention ring kernels
+        big = (torch.randn(8448, 1024, device=dev).to(bf16), torch.randn(3072, 1024, device=dev).to(bf16))
+        ta, tb, to = torch.randn(4096, 1024, device=dev).to(bf16), torch.randn(4096, 1024, device=dev).to(bf16), torch.zeros(1024, 1024, device=dev)
+        B2, H2, N2 = 2, 8, 520
+        cs2, sn2 = ops.rotary_table(N2, dev)
+        st2 = ops.qkv_post_fwd((torch.randn(B2 * N2, 3 * H2 * 64 + 2 * H2, device=dev) * 0.5).to(bf16), B2, H2, N2, cs2, sn2, None)
+        km2 = torch.ones(B2, st2.Npad, dtype=torch.uint8, device=dev)
+        km2[:, N2:] = 0
     bad = {}
     for vn, fn in victims.items():
         keep = lambda out: [t for t in out if torch.is_tensor(t)]
@@ -159,6 +167,11 @@ def _count_differing_tight(victims, inner, iters, dev):
                             ops.gemm_nt(a, w)
                 finally:
                     ops.gemm_flags = flags
+                if mix == 'every LDS-DMA family':
+                    for _ in range(2):
+                        ops.gemm_nt(*big)
+                        ops.gemm_tn(ta, tb, to)
+                        ops.attn_fwd(st2, km2)
             outs = [keep(fn()) for _ in range(inner)]
             n += sum(any(not torch.equal(g, r) for g, r in zip(got, ref)) for got in outs)
             torch.cuda.current_stream().wait_stream(side)
@@ -188,6 +201,8 @@ def test_every_kernel_back_to_back_next_to_lds_dma_gemms():
     install_lib(None, host_pointers=False)
     victims, _ = _victims_and_corunners('cuda')
     bad = _count_differing_tight(victims, 16, 48, 'cuda')
+    assert not bad, bad
+    bad = _count_differing_tight(victims, 16, 32, 'cuda', mix='every LDS-DMA family')
     assert not bad, bad
 
 
